@@ -1,0 +1,219 @@
+/*
+ * lamehip_types.h -- plain-old-data layouts shared by the host C layer, the HIP
+ * kernels, the CPU oracle (oracle/) and the reference harness (oracle/_ref).
+ *
+ * Every struct here is a flat, pointer-free image so that it can be uploaded to
+ * HBM with one memcpy.  The reference keeps the same information scattered over
+ * SessionConfig_t / PsyConst_t / ATH_t / QntStateVar_t / EncStateVar_t
+ * (reference libmp3lame/util.h:166-459) and gr_info / III_side_info_t
+ * (reference libmp3lame/l3side.h:47-93).
+ */
+#ifndef LAMEHIP_TYPES_H
+#define LAMEHIP_TYPES_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* dimensions, reference libmp3lame/encoder.h:93-114 */
+#define LH_SBMAX_L     22
+#define LH_SBMAX_S     13
+#define LH_SBPSY_L     21
+#define LH_SBPSY_S     12
+#define LH_PSFB21      6
+#define LH_PSFB12      6
+#define LH_SFBMAX      39
+#define LH_CBANDS      64
+#define LH_BLKSIZE     1024
+#define LH_HBLKSIZE    513
+#define LH_BLKSIZE_S   256
+#define LH_HBLKSIZE_S  129
+#define LH_PRECALC     8208      /* IXMAX_VAL+2, reference quantize_pvt.h:24-29 */
+#define LH_IXMAX       8206
+#define LH_QMAX        257
+#define LH_QMAX2       116
+#define LH_LARGE_BITS  100000
+#define LH_MAX_BITS_PER_CHANNEL 4095
+#define LH_MAX_BITS_PER_GRANULE 7680
+#define LH_S3_MAX      1280      /* upper bound for the packed spreading matrix */
+
+#define LH_NORM_TYPE   0
+#define LH_START_TYPE  1
+#define LH_SHORT_TYPE  2
+#define LH_STOP_TYPE   3
+
+#define LH_MPG_MD_LR_LR 0
+#define LH_MPG_MD_MS_LR 2
+
+/* MPEG modes, reference include/lame.h MPEG_mode */
+#define LH_MODE_STEREO       0
+#define LH_MODE_JOINT_STEREO 1
+#define LH_MODE_DUAL         2
+#define LH_MODE_MONO         3
+
+/* polyphase / framing delays, reference libmp3lame/encoder.h:57-83 */
+#define LH_ENCDELAY    576
+#define LH_POSTDELAY   1152
+#define LH_MDCTDELAY   48
+#define LH_FFTOFFSET   (224 + LH_MDCTDELAY)
+#define LH_MF_START    (LH_ENCDELAY - LH_MDCTDELAY)   /* 528, reference lame.c:2302 */
+#define LH_MF_NEEDED   1904                          /* reference lame.c:1627-1648, MPEG-1 */
+
+/* ------------------------------------------------------------------ */
+/* resolved per-stream constants (subset of SessionConfig_t)           */
+typedef struct LhConfig {
+    int     version;              /* 1 = MPEG-1 */
+    int     samplerate;           /* in == out, no resampling on this path */
+    int     samplerate_index;
+    int     bitrate_index;
+    int     avg_bitrate;          /* kbps */
+    int     mode;                 /* LH_MODE_* */
+    int     mode_gr;              /* 2 */
+    int     channels;             /* 2 */
+    int     vbr;                  /* 0 = vbr_off (CBR) */
+    int     quality;
+    int     noise_shaping;
+    int     noise_shaping_amp;
+    int     noise_shaping_stop;
+    int     subblock_gain;
+    int     use_best_huffman;
+    int     full_outer_loop;
+    int     substep_shaping;
+    int     quant_comp;
+    int     quant_comp_short;
+    int     sfb21_extra;
+    int     short_blocks;         /* 1 = coupled, 0 = allowed, 2 dispensed, 3 forced (reference lame.h short_block_t) */
+    int     use_safe_joint_stereo;
+    int     use_temporal_masking;
+    int     force_ms;
+    int     sideinfo_len;
+    int     buffer_constraint;
+    int     frac_SpF;
+    int     disable_reservoir;
+    int     error_protection;
+    int     copyright, original, extension, emphasis;
+    int     lowpassfreq;
+    float   msfix;
+    float   ATHfixpoint;
+    float   ATH_offset_db;
+    float   ATH_offset_factor;
+    float   ATHcurve;
+    int     ATHtype;
+    float   minval;
+    float   mask_adjust;
+    float   mask_adjust_short;
+    float   masking_lower_long;   /* pow(10, mask_adjust*0.1), reference quantize.c:2029 */
+    float   masking_lower_short;
+    float   pcm_scale;            /* pcm_transform diagonal, reference lame.c:1209-1234 */
+    float   interChRatio;
+} LhConfig;
+
+/* partition -> scalefactor-band mapping, PsyConst_CB2SB_t (reference util.h:188-203) */
+typedef struct LhPsyBand {
+    float   masking_lower[LH_CBANDS];
+    float   minval[LH_CBANDS];
+    float   rnumlines[LH_CBANDS];
+    float   mld_cb[LH_CBANDS];
+    float   mld[LH_SBMAX_L];
+    float   bo_weight[LH_SBMAX_L];
+    int     s3ind[LH_CBANDS][2];
+    int     numlines[LH_CBANDS];
+    int     bm[LH_SBMAX_L];
+    int     bo[LH_SBMAX_L];
+    int     npart;
+    int     n_sb;
+    int     s3_count;
+    int     s3_row[LH_CBANDS];    /* offset of row b in s3[] (derived; not in the reference) */
+    float   s3[LH_S3_MAX];
+} LhPsyBand;
+
+typedef struct LhTables {
+    /* scalefactor band boundaries, reference quantize_pvt.c:100-167, lame.c:927-946 */
+    int     sfb_l[LH_SBMAX_L + 1];
+    int     sfb_s[LH_SBMAX_S + 1];
+    int     psfb21[LH_PSFB21 + 1];
+    int     psfb12[LH_PSFB12 + 1];
+    /* quantiser power tables, reference quantize_pvt.c:171-179, 350-366 */
+    float   pow43[LH_PRECALC];
+    float   adj43asm[LH_PRECALC];
+    float   ipow20[LH_QMAX];
+    float   pow20[LH_QMAX + LH_QMAX2 + 1];
+    int     bv_scf[576];          /* reference takehiro.c:1334-1375 */
+    /* ATH, reference util.h:166-182 */
+    float   ath_l[LH_SBMAX_L];
+    float   ath_s[LH_SBMAX_S];
+    float   ath_psfb21[LH_PSFB21];
+    float   ath_psfb12[LH_PSFB12];
+    float   ath_cb_l[LH_CBANDS];
+    float   ath_cb_s[LH_CBANDS];
+    float   ath_eql_w[LH_BLKSIZE / 2];
+    float   ath_floor;
+    float   ath_decay;
+    float   aa_sensitivity_p;
+    int     ath_use_adjust;
+    float   longfact[LH_SBMAX_L];
+    float   shortfact[LH_SBMAX_S];
+    /* psycho-acoustic constants, reference psymodel.c:1867-2157 */
+    LhPsyBand psy_l;
+    LhPsyBand psy_s;
+    LhPsyBand psy_l_to_s;
+    float   attack_threshold[4];
+    float   decay;
+    float   ma_max_i1, ma_max_i2;
+    /* FFT windows and the twiddle recurrence unrolled (reference fft.c:56-148, 296-310) */
+    float   fft_window[LH_BLKSIZE];
+    float   fft_window_s[LH_BLKSIZE_S / 2];
+    float   fht_tw[4][128][4];    /* [stage][i] -> c1,s1,c2,s2 as produced by the recurrence fft.c:103-144 */
+    float   amp_filter[32];       /* reference lame.c:103-190 */
+    float   log_table[513];       /* reference util.c:954-972 */
+} LhTables;
+
+/* ------------------------------------------------------------------ */
+/* one granule of one channel as consumed by the bit packer            */
+typedef struct LhGranule {
+    int16_t l3_enc[576];          /* quantised magnitudes, sign bit carries (xr < 0) */
+    int8_t  scalefac[LH_SFBMAX];  /* -1 = shared through scfsi */
+    int8_t  pad0;
+    int16_t part2_3_length;
+    int16_t part2_length;
+    int16_t big_values;
+    int16_t count1;
+    int16_t global_gain;
+    int16_t scalefac_compress;
+    int8_t  block_type;
+    int8_t  mixed_block_flag;
+    int8_t  table_select[3];
+    int8_t  subblock_gain[3];
+    int8_t  region0_count;
+    int8_t  region1_count;
+    int8_t  preflag;
+    int8_t  scalefac_scale;
+    int8_t  count1table_select;
+    int8_t  sfbmax;
+    int8_t  sfbdivide;
+    int8_t  pad1;
+    int16_t count1bits;
+    int16_t pad2;
+} LhGranule;
+
+/* device -> host payload for one frame (what format_bitstream reads, reference bitstream.c:917-985) */
+typedef struct LhFrameOut {
+    LhGranule gr[2][2];
+    int8_t  scfsi[2][4];
+    int16_t main_data_begin;
+    int16_t resvDrain_pre;
+    int16_t resvDrain_post;
+    int8_t  bitrate_index;
+    int8_t  padding;
+    int8_t  mode_ext;
+    int8_t  pad[5];
+    int32_t resv_size;            /* ResvSize after ResvFrameEnd: cross-check for the packer */
+    int32_t frame_bits;
+} LhFrameOut;
+
+#ifdef __cplusplus
+}
+#endif
+#endif
