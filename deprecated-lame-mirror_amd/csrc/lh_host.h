@@ -1,0 +1,72 @@
+/*
+ * lh_host.h -- internal host-side interfaces of liblamehip (plain C).
+ */
+#ifndef LH_HOST_H
+#define LH_HOST_H
+
+#include "lamehip_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* what the lame_set_* calls of the public API collect before lame_init_params */
+typedef struct LhUserParams {
+    int     samplerate;
+    int     channels;
+    int     brate;               /* kbps */
+    int     mode;                /* -1 = not set (joint stereo), else LH_MODE_* */
+    int     quality;             /* -1 = default (3) */
+    int     vbr;                 /* 0 = CBR */
+} LhUserParams;
+
+/* values that only feed table generation */
+typedef struct LhInitAux {
+    float   lowpass1, lowpass2;
+    float   attackthre, attackthre_s;
+} LhInitAux;
+
+void    lh_params_default(LhUserParams * p);
+int     lh_config_resolve(const LhUserParams * p, LhConfig * c, LhInitAux * aux);
+int     lh_tables_build(LhConfig * c, const LhInitAux * aux, LhTables * t);
+
+/* number of MP3 frames the reference produces for n input samples per channel
+ * when followed by lame_encode_flush (reference lame.c:1671-1775, 2041-2120) */
+int     lh_total_frames(long nsamples);
+
+/* ------------------------------------------------------------------ */
+/* serial bit packer (reference bitstream.c), host only                */
+#define LH_MAX_HEADER_BUF 256
+#define LH_MAX_HEADER_LEN 40
+#define LH_BS_BUFSIZE (16384 + 147456)   /* LAME_MAXMP3BUFFER, reference lame.h */
+
+typedef struct LhBitstream {
+    unsigned char *buf;
+    int     buf_size;
+    int     totbit;
+    int     buf_byte_idx;
+    int     buf_bit_idx;
+    struct {
+        int     write_timing;
+        int     ptr;
+        char    buf[LH_MAX_HEADER_LEN];
+    } header[LH_MAX_HEADER_BUF];
+    int     h_ptr, w_ptr;
+    int     ancillary_flag;
+    int     main_data_begin;     /* packer's own running value, cross-checked with the device's */
+    int     error;
+} LhBitstream;
+
+int     lh_bs_init(LhBitstream * bs);
+void    lh_bs_free(LhBitstream * bs);
+/* appends one frame; returns 0, or <0 when the device payload is inconsistent */
+int     lh_bs_format_frame(LhBitstream * bs, const LhConfig * c, const LhTables * t,
+                           const LhFrameOut * fo);
+void    lh_bs_flush(LhBitstream * bs, const LhConfig * c, const LhFrameOut * last);
+/* moves the finished bytes out (reference copy_buffer); -1 if size!=0 and too small */
+int     lh_bs_copy(LhBitstream * bs, unsigned char *out, int size);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
