@@ -1,0 +1,155 @@
+/*
+ * lh_dev_common.h -- shared definitions of the HIP kernels: the LDS image of a
+ * workgroup (one stream, two waves = two channels) and the launch context.
+ *
+ * LDS budget (must stay <= 40 KB so that four workgroups share a CU's 160 KB and
+ * a batch of 1024 streams is fully resident on 256 CUs): see LhLds below.
+ */
+#ifndef LH_DEV_COMMON_H
+#define LH_DEV_COMMON_H
+
+#include <stdint.h>
+#include "lamehip_types.h"
+#include "lh_device.h"
+#include "lh_wave.h"
+#include "lh_dev_math.h"
+
+#define LH_NT 128               /* threads per workgroup: wave 0 = left/mid, wave 1 = right/side */
+#define LH_SQRT2 1.41421356237309504880
+
+#ifdef LH_EMU
+#define LH_SYNC_WG() __syncthreads()
+#else
+#define LH_SYNC_WG() __syncthreads()
+#endif
+
+LH_DEVFN float
+lh_fabsf(float x)
+{
+    return lh_u32_as_f32(lh_f32_as_u32(x) & 0x7fffffffu);
+}
+
+/* ---- LDS layout ---------------------------------------------------- */
+struct LhPsyLds {
+    float   wsamp[2][LH_BLKSIZE];       /* FHT work buffers of L and R (3x256 for short blocks) */
+    union {
+        struct {
+            float   hpf[2][576];        /* high-passed samples for attack detection */
+        } a;
+        struct {
+            float   energy[4][LH_HBLKSIZE + 3];   /* power spectra of L,R,M,S */
+        } b;
+    };
+    float   eb[4 * 64];
+    float   thr[4 * 64];
+    float   smax[2][64];
+    float   savg[2][64];
+    int     sidx[2][64];
+};
+
+struct LhMdctLds {
+    float   sb[2][3][576];      /* [ch][0 = previous granule, 1 = gr0, 2 = gr1][slot*32 + band] */
+};
+
+/* wave-uniform scalar image of gr_info (reference l3side.h:47-84): every lane holds
+ * its own identical copy in registers, so updates need no cross-lane ordering */
+struct LhGrR {
+    int     part2_3_length, big_values, count1, global_gain, scalefac_compress;
+    int     table_select[3], subblock_gain[4];
+    int     region0_count, region1_count, preflag, scalefac_scale, count1table_select;
+    int     part2_length, count1bits;
+    float   xrpow_max;
+};
+
+/* wave-uniform per-granule geometry + the scalar part of calc_noise_data */
+struct LhQR {
+    int     block_type, sfb_lmax, sfb_smin, psy_lmax, sfbmax, psymax, sfbdivide, mnc;
+    int     pn_global_gain, pn_sfb_count1;
+    int     substep_shaping;
+};
+
+struct LhNoiseRes {             /* calc_noise_result */
+    int     over_count, over_SSD, bits;
+    float   over_noise, tot_noise, max_noise;
+};
+
+/* LDS image of one channel's quantiser working set.  Arrays indexed by band are
+ * written by lane == band only (then LH_WAVE_SYNC); line arrays by the lane
+ * owning the line. */
+struct LhChanLds {
+    float   xrpow[576];
+    float   save_xrpow[576];
+    int16_t ix[2][576];         /* [0] = best so far (cod_info), [1] = working copy (cod_info_w) */
+    int     sf[2][LH_SFBMAX + 1];       /* scalefactors of the two images */
+    int     width[LH_SFBMAX + 1], window[LH_SFBMAX + 1], start[LH_SFBMAX + 1];
+    uint8_t sfb_of_line[576];
+    float   l3_xmin[LH_SFBMAX + 1];
+    float   distort[LH_SFBMAX + 1];
+    /* calc_noise_data (reference quantize_pvt.h:75-82), per band */
+    int     pn_step[LH_SFBMAX + 1];
+    float   pn_noise[LH_SFBMAX + 1], pn_noise_log[LH_SFBMAX + 1];
+    int     pseudohalf[LH_SFBMAX + 1];
+    /* scratch */
+    int     sfb_mode[LH_SFBMAX + 1];
+    float   sfb_f[LH_SFBMAX + 1];
+    int     scr[4][64];
+};
+
+struct LhQuantLds {
+    LhChanLds ch[2];
+};
+
+struct LhLds {
+    float   ratio_en[2][4][LH_XMIN_N];  /* [gr][L,R,M,S]: the delayed psy output of each granule */
+    float   ratio_thm[2][4][LH_XMIN_N];
+    float   pe[2][4];
+    float   tot_ener[2][4];
+    float   loudness_sq[2][2];
+    float   sub_short_factor[4][3];
+    int     ns_attacks[4][4];
+    int     ns_uselong[4];
+    int     uselongblock[2];
+    int     next_blocktype[2];
+    int     block_type[2][2];   /* [gr][ch] */
+    int     pstart_l[64], pstart_s[64];
+    /* frame scalars */
+    int     mode_ext, padding, mean_bits, max_bits, frame_bits;
+    int     targ_bits[2];
+    int     bits_used[2];
+    float   pe_use[2][2];
+    float   ms_ener_ratio[2];
+    int     scfsi[2][4];
+    float   xr[2][2][576];      /* [ch][gr] MDCT spectra */
+    union {
+        LhPsyLds psy;
+        LhMdctLds mdct;
+        LhQuantLds quant;
+    } u;
+};
+
+/* ---- launch context -------------------------------------------------- */
+struct LhCtx {
+    const LhConfig *cfg;
+    const LhTables *T;
+    LhStreamState *st;
+    const int16_t *pcm;
+    LhStreamDesc d;
+    long long frame_base;       /* stream sample index of mfbuf[0] for the current frame: 1152 f - 528 */
+    int     lane, wave, tid;
+};
+
+/* sample i of the reference's mfbuf window of the current frame: scaled PCM,
+ * zero outside the stream (reference lame.c:1802-1834 scaling; :1671-1775 framing) */
+LH_DEVFN float
+lh_smp(const LhCtx & c, int ch, int i)
+{
+    long long p = c.frame_base + i;
+    if (p < 0 || p >= c.d.nsamples)
+        return 0.0f;
+    {
+        long long off = (ch == 0 ? c.d.pcm_l : c.d.pcm_r) + (p - c.d.pcm_base);
+        return (float) c.pcm[off] * c.cfg->pcm_scale;
+    }
+}
+
+#endif

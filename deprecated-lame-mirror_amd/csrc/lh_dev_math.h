@@ -1,0 +1,201 @@
+/*
+ * lh_dev_math.h -- device math leaves whose bits must equal the host libm of
+ * the reference build.
+ *
+ * lh_powf(): the reference calls powf() inside the per-frame path
+ * (athAdjust, reference quantize_pvt.c:554-573; NS_INTERP, psymodel.c:443-454).
+ * On the x86-64 hosts this project targets, glibc 2.35 resolves powf to its
+ * FMA variant of the "optimized routines" algorithm (log2 via a 16-entry table
+ * + degree-5 polynomial, exp2 via a 32-entry table + cubic, all in double,
+ * fused multiply-adds where the source has a*b+c).  That algorithm is restated
+ * here with the same tables and the same fused operations so the device result
+ * is bit-identical; tests/test_powf.py sweeps it against the host powf.
+ * Domain: x >= 0 (both call sites guarantee it).
+ *
+ * lh_fast_log2(): table-driven log2 of the reference (util.c:976-1001); the
+ * 513-entry table is built on the host (LhTables.log_table).
+ */
+#ifndef LH_DEV_MATH_H
+#define LH_DEV_MATH_H
+
+#include <stdint.h>
+#include "lh_wave.h"
+
+#ifndef LH_DEVFN
+#ifdef LH_EMU
+#define LH_DEVFN static inline
+#define LH_DEVCONST static const
+#else
+#define LH_DEVFN __device__ __forceinline__
+#define LH_DEVCONST __device__ static const
+#endif
+#endif
+
+LH_DEVCONST uint64_t lh_powf_log2_tab[32] = {
+    0x3ff661ec79f8f3beull, 0xbfdefec65b963019ull, 0x3ff571ed4aaf883dull, 0xbfdb0b6832d4fca4ull,
+    0x3ff49539f0f010b0ull, 0xbfd7418b0a1fb77bull, 0x3ff3c995b0b80385ull, 0xbfd39de91a6dcf7bull,
+    0x3ff30d190c8864a5ull, 0xbfd01d9bf3f2b631ull, 0x3ff25e227b0b8ea0ull, 0xbfc97c1d1b3b7af0ull,
+    0x3ff1bb4a4a1a343full, 0xbfc2f9e393af3c9full, 0x3ff12358f08ae5baull, 0xbfb960cbbf788d5cull,
+    0x3ff0953f419900a7ull, 0xbfaa6f9db6475fceull, 0x3ff0000000000000ull, 0x0000000000000000ull,
+    0x3fee608cfd9a47acull, 0x3fb338ca9f24f53dull, 0x3feca4b31f026aa0ull, 0x3fc476a9543891baull,
+    0x3feb2036576afce6ull, 0x3fce840b4ac4e4d2ull, 0x3fe9c2d163a1aa2dull, 0x3fd40645f0c6651cull,
+    0x3fe886e6037841edull, 0x3fd88e9c2c1b9ff8ull, 0x3fe767dcf5534862ull, 0x3fdce0a44eb17bccull
+};
+
+LH_DEVCONST uint64_t lh_exp2f_tab[32] = {
+    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull,
+    0x3fef72b83c7d517bull, 0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull,
+    0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
+    0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull,
+    0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull,
+    0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
+    0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull,
+    0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull
+};
+
+LH_DEVFN double
+lh_u64_as_f64(uint64_t u)
+{
+    union {
+        uint64_t u;
+        double  d;
+    } c;
+    c.u = u;
+    return c.d;
+}
+
+LH_DEVFN uint64_t
+lh_f64_as_u64(double d)
+{
+    union {
+        uint64_t u;
+        double  d;
+    } c;
+    c.d = d;
+    return c.u;
+}
+
+LH_DEVFN uint32_t
+lh_f32_as_u32(float f)
+{
+    union {
+        uint32_t u;
+        float   f;
+    } c;
+    c.f = f;
+    return c.u;
+}
+
+LH_DEVFN float
+lh_u32_as_f32(uint32_t u)
+{
+    union {
+        uint32_t u;
+        float   f;
+    } c;
+    c.u = u;
+    return c.f;
+}
+
+/* powf for x >= 0, finite or +inf, y finite */
+LH_DEVFN float
+lh_powf(float x, float y)
+{
+    uint32_t ix = lh_f32_as_u32(x);
+    uint32_t iy = lh_f32_as_u32(y);
+    /* special cases that the main path cannot take */
+    if ((iy << 1) == 0)
+        return 1.0f;            /* x^0 */
+    if (ix == 0x3f800000u)
+        return 1.0f;            /* 1^y */
+    if (ix == 0) {
+        /* +0 ^ y */
+        return (iy >> 31) ? lh_u32_as_f32(0x7f800000u) : 0.0f;
+    }
+    if (ix == 0x7f800000u)
+        return (iy >> 31) ? 0.0f : lh_u32_as_f32(0x7f800000u);
+    if (ix < 0x00800000u) {
+        /* subnormal x: normalise */
+        ix = lh_f32_as_u32(x * 8388608.0f);
+        ix &= 0x7fffffffu;
+        ix -= 23u << 23;
+    }
+    {
+        /* log2(x) in double */
+        uint32_t tmp = ix - 0x3f330000u;
+        int     i = (int) ((tmp >> 19) & 15u);
+        uint32_t top = tmp & 0xff800000u;
+        uint32_t iz = ix - top;
+        int     k = ((int32_t) top) >> 23;
+        double  invc = lh_u64_as_f64(lh_powf_log2_tab[2 * i]);
+        double  logc = lh_u64_as_f64(lh_powf_log2_tab[2 * i + 1]);
+        double  z = (double) lh_u32_as_f32(iz);
+        double  r, y0, r2, yy, p, r4, q, logx, ylogx;
+        double const A0 = lh_u64_as_f64(0x3fd27616c9496e0bull);   /*  0x1.27616c9496e0bp-2 */
+        double const A1 = lh_u64_as_f64(0xbfd71969a075c67aull);   /* -0x1.71969a075c67ap-2 */
+        double const A2 = lh_u64_as_f64(0x3fdec70a6ca7baddull);   /*  0x1.ec70a6ca7baddp-2 */
+        double const A3 = lh_u64_as_f64(0xbfe7154748bef6c8ull);   /* -0x1.7154748bef6c8p-1 */
+        double const A4 = lh_u64_as_f64(0x3ff71547652ab82bull);   /*  0x1.71547652ab82bp+0 */
+        r = lh_fma(z, invc, -1.0);
+        y0 = logc + (double) k;
+        r2 = r * r;
+        yy = lh_fma(A0, r, A1);
+        p = lh_fma(A2, r, A3);
+        r4 = r2 * r2;
+        q = lh_fma(A4, r, y0);
+        q = lh_fma(p, r2, q);
+        yy = lh_fma(yy, r4, q);
+        logx = yy;
+        ylogx = (double) y *logx;
+        if (((lh_f64_as_u64(ylogx) >> 47) & 0xffff) >= 0x80bf) {
+            /* |y*log2(x)| >= 126 */
+            if (ylogx > 127.99999995700433)
+                return lh_u32_as_f32(0x7f800000u);      /* overflow */
+            if (ylogx <= -150.0)
+                return 0.0f;    /* underflow */
+            if (ylogx < -149.0)
+                return lh_u32_as_f32(0x00000001u);      /* may-underflow: 0x1.4p-75f squared, rounded */
+        }
+        {
+            /* exp2 in double */
+            double const SHIFT = lh_u64_as_f64(0x42e8000000000000ull);    /* 0x1.8p47 */
+            double const C0 = lh_u64_as_f64(0x3fac6af84b912394ull);       /* 0x1.c6af84b912394p-5 */
+            double const C1 = lh_u64_as_f64(0x3fcebfce50fac4f3ull);       /* 0x1.ebfce50fac4f3p-3 */
+            double const C2 = lh_u64_as_f64(0x3fe62e42ff0c52d6ull);       /* 0x1.62e42ff0c52d6p-1 */
+            double  kd = ylogx + SHIFT;
+            uint64_t ki = lh_f64_as_u64(kd);
+            double  rr, s, zz, rr2, e;
+            uint64_t t;
+            kd -= SHIFT;
+            rr = ylogx - kd;
+            t = lh_exp2f_tab[ki & 31u];
+            t += ki << (52 - 5);
+            s = lh_u64_as_f64(t);
+            zz = lh_fma(C0, rr, C1);
+            rr2 = rr * rr;
+            e = lh_fma(C2, rr, 1.0);
+            e = lh_fma(zz, rr2, e);
+            e = e * s;
+            return (float) e;
+        }
+    }
+}
+
+/* reference util.c:976-1001 */
+LH_DEVFN float
+lh_fast_log2(const float *log_table, float x)
+{
+    float   log2val, partial;
+    uint32_t const bits = lh_f32_as_u32(x);
+    int     mantisse = (int) (bits & 0x7fffffu);
+    log2val = (float) ((int) ((bits >> 23) & 0xFFu) - 0x7f);
+    partial = (float) (mantisse & ((1 << 14) - 1));
+    partial *= 1.0f / ((1 << 14));
+    mantisse >>= 14;
+    log2val += log_table[mantisse] * (1.0f - partial) + log_table[mantisse + 1] * partial;
+    return log2val;
+}
+
+#define LH_LOG2_OVER_LOG10 (0.69314718055994530942 / 2.30258509299404568402)
+
+#endif

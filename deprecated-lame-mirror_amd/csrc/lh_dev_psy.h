@@ -1,0 +1,942 @@
+/*
+ * lh_dev_psy.h -- psycho-acoustic model, wave-parallel (one workgroup = one
+ * stream, wave w = channel w; the mid/side pseudo-channels 2/3 are handled by
+ * wave 0/1 after their own channel).
+ *
+ * What the reference computes with serial loops per granule
+ * (psymodel.c:655-1597, fft.c:63-289) is mapped as follows:
+ *   - high-pass FIR + sub-block peaks: lanes over the 576 samples, peaks by
+ *     wave max-reduction (exact: max is order independent)
+ *   - windowed FHT: the 128 (long) / 96 (3 short) independent butterfly units of
+ *     every radix-4 pass spread over the lanes, spectra in LDS
+ *   - partition energies, tonality index, spreading convolution, thresholds:
+ *     one lane per partition band (<= 64), inner sums stay serial in the
+ *     reference's order because float addition is not associative
+ *   - partition -> scalefactor-band conversion, PE: one lane per independent
+ *     serial chain
+ * All float expressions keep the reference's evaluation order and types; this
+ * translation unit is compiled with -ffp-contract=off.
+ */
+#ifndef LH_DEV_PSY_H
+#define LH_DEV_PSY_H
+
+#include "lh_dev_common.h"
+
+#define LH_NSFIRLEN 21
+#define LH_RPELEV  2
+#define LH_RPELEV2 16
+#define LH_PREECHO_ATT0 0.8
+#define LH_PREECHO_ATT1 0.6
+#define LH_PREECHO_ATT2 0.3
+#define LH_VO_SCALE (1./( 14752*14752 )/(LH_BLKSIZE/2))
+
+LH_DEVCONST float lh_psy_tab[9] = {
+    1.0f, 0.79433f, 0.63096f, 0.63096f, 0.63096f, 0.63096f, 0.63096f, 0.25119f, 0.11749f
+};
+LH_DEVCONST int lh_mask_add_delta[9] = { 2, 2, 2, 1, 1, 1, 0, 0, -1 };
+LH_DEVCONST float lh_mask_table2[10] = {
+    (float) (1.33352 * 1.33352), (float) (1.35879 * 1.35879), (float) (1.38454 * 1.38454),
+    (float) (1.39497 * 1.39497), (float) (1.40548 * 1.40548), (float) (1.3537 * 1.3537),
+    (float) (1.30382 * 1.30382), (float) (1.22321 * 1.22321), (float) (1.14758 * 1.14758), 1.0f
+};
+LH_DEVCONST float lh_hp_fir[10] = {
+    (float) (-8.65163e-18 * 2), (float) (-0.00851586 * 2), (float) (-6.74764e-18 * 2),
+    (float) (0.0209036 * 2), (float) (-3.36639e-17 * 2), (float) (-0.0438162 * 2),
+    (float) (-1.54175e-17 * 2), (float) (0.0931738 * 2), (float) (-5.52212e-17 * 2),
+    (float) (-0.313819 * 2)
+};
+LH_DEVCONST float lh_regcoef_s[12] = {
+    11.8f, 13.6f, 17.2f, 32.f, 46.5f, 51.3f, 57.5f, 67.1f, 71.5f, 84.6f, 97.6f, 130.f
+};
+LH_DEVCONST float lh_regcoef_l[21] = {
+    6.8f, 5.8f, 5.8f, 6.4f, 6.5f, 9.9f, 12.1f, 14.4f, 15.f, 18.9f, 21.6f, 26.9f, 34.2f, 40.2f,
+    46.8f, 56.5f, 60.7f, 73.9f, 85.7f, 93.4f, 126.1f
+};
+
+/* reference psymodel.c:294-341 */
+LH_DEVFN float
+lh_mask_add(const LhTables * T, float m1, float m2, int b, int delta)
+{
+    float   ratio;
+    if (m1 < 0)
+        m1 = 0;
+    if (m2 < 0)
+        m2 = 0;
+    if (m1 <= 0)
+        return m2;
+    if (m2 <= 0)
+        return m1;
+    if (m2 > m1)
+        ratio = m2 / m1;
+    else
+        ratio = m1 / m2;
+    if (b < 0)
+        b = -b;
+    if (b <= delta) {
+        if (ratio >= T->ma_max_i1)
+            return m1 + m2;
+        else {
+            int     i = (int) (lh_fast_log2(T->log_table, ratio) * (LH_LOG2_OVER_LOG10 * (16.0f)));
+            return (m1 + m2) * lh_mask_table2[i];
+        }
+    }
+    if (ratio < T->ma_max_i2)
+        return m1 + m2;
+    if (m1 < m2)
+        m1 = m2;
+    return m1;
+}
+
+/* reference psymodel.c:443-454 */
+LH_DEVFN float
+lh_ns_interp(float x, float y, float r)
+{
+    if (r >= 1.0f)
+        return x;
+    if (r <= 0.0f)
+        return y;
+    if (y > 0.0f)
+        return lh_powf(x / y, r) * y;
+    return 0.0f;
+}
+
+/* one radix-4 FHT pass over `n' points in LDS: the n/8 butterfly units of the
+ * pass (reference fft.c:70-146, one unit = one trip of an inner do-while) are
+ * dealt to the lanes.  `unit0'/`nunits' let the three short transforms share
+ * one call. */
+LH_DEVFN void
+lh_fht_unit(const LhTables * T, float *fz, int stage, int k1, int u)
+{
+    int const kx = k1 >> 1;
+    int const k2 = k1 << 1, k3 = k2 + k1, k4 = k2 << 1;
+    int const blk = u / kx, i = u - blk * kx;
+    if (i == 0) {
+        float  *fi = fz + blk * k4;
+        float  *gi = fi + kx;
+        float   f0, f1, f2, f3;
+        f1 = fi[0] - fi[k1];
+        f0 = fi[0] + fi[k1];
+        f3 = fi[k2] - fi[k3];
+        f2 = fi[k2] + fi[k3];
+        fi[k2] = f0 - f2;
+        fi[0] = f0 + f2;
+        fi[k3] = f1 - f3;
+        fi[k1] = f1 + f3;
+        f1 = gi[0] - gi[k1];
+        f0 = gi[0] + gi[k1];
+        f3 = (float) (LH_SQRT2 * gi[k3]);
+        f2 = (float) (LH_SQRT2 * gi[k2]);
+        gi[k2] = f0 - f2;
+        gi[0] = f0 + f2;
+        gi[k3] = f1 - f3;
+        gi[k1] = f1 + f3;
+    }
+    else {
+        float const c1 = T->fht_tw[stage][i][0], s1 = T->fht_tw[stage][i][1];
+        float const c2 = T->fht_tw[stage][i][2], s2 = T->fht_tw[stage][i][3];
+        float  *fi = fz + blk * k4 + i;
+        float  *gi = fz + blk * k4 + k1 - i;
+        float   a, b, g0, f0, f1, g1, f2, g2, f3, g3;
+        b = s2 * fi[k1] - c2 * gi[k1];
+        a = c2 * fi[k1] + s2 * gi[k1];
+        f1 = fi[0] - a;
+        f0 = fi[0] + a;
+        g1 = gi[0] - b;
+        g0 = gi[0] + b;
+        b = s2 * fi[k3] - c2 * gi[k3];
+        a = c2 * fi[k3] + s2 * gi[k3];
+        f3 = fi[k2] - a;
+        f2 = fi[k2] + a;
+        g3 = gi[k2] - b;
+        g2 = gi[k2] + b;
+        b = s1 * f2 - c1 * g3;
+        a = c1 * f2 + s1 * g3;
+        fi[k2] = f0 - a;
+        fi[0] = f0 + a;
+        gi[k3] = g1 - b;
+        gi[k1] = g1 + b;
+        b = c1 * g2 - s1 * f3;
+        a = s1 * g2 + c1 * f3;
+        gi[k2] = g0 - a;
+        gi[0] = g0 + a;
+        fi[k3] = f1 - b;
+        fi[k1] = f1 + b;
+    }
+}
+
+LH_DEVFN unsigned
+lh_rev8(unsigned v)
+{
+    v = ((v & 0xf0u) >> 4) | ((v & 0x0fu) << 4);
+    v = ((v & 0xccu) >> 2) | ((v & 0x33u) << 2);
+    v = ((v & 0xaau) >> 1) | ((v & 0x55u) << 1);
+    return v;
+}
+
+/* windowed 1024-point FHT of channel ch starting at frame-buffer index `base'
+ * (reference fft.c:245-289); result in x[1024] (LDS), one wave */
+LH_DEVFN void
+lh_fft_long(const LhCtx & c, int ch, int base, float *x)
+{
+    const float *w = c.T->fft_window;
+    int     lane = c.lane;
+    for (int jj = lane; jj < LH_BLKSIZE / 8; jj += 64) {
+        float   f0, f1, f2, f3, ww;
+        float  *o = x + 4 * jj;
+        int     i = (int) lh_rev8((unsigned) jj);
+        f0 = w[i] * lh_smp(c, ch, base + i);
+        ww = w[i + 0x200] * lh_smp(c, ch, base + i + 0x200);
+        f1 = f0 - ww;
+        f0 = f0 + ww;
+        f2 = w[i + 0x100] * lh_smp(c, ch, base + i + 0x100);
+        ww = w[i + 0x300] * lh_smp(c, ch, base + i + 0x300);
+        f3 = f2 - ww;
+        f2 = f2 + ww;
+        o[0] = f0 + f2;
+        o[2] = f0 - f2;
+        o[1] = f1 + f3;
+        o[3] = f1 - f3;
+        f0 = w[i + 0x001] * lh_smp(c, ch, base + i + 0x001);
+        ww = w[i + 0x201] * lh_smp(c, ch, base + i + 0x201);
+        f1 = f0 - ww;
+        f0 = f0 + ww;
+        f2 = w[i + 0x101] * lh_smp(c, ch, base + i + 0x101);
+        ww = w[i + 0x301] * lh_smp(c, ch, base + i + 0x301);
+        f3 = f2 - ww;
+        f2 = f2 + ww;
+        o[LH_BLKSIZE / 2 + 0] = f0 + f2;
+        o[LH_BLKSIZE / 2 + 2] = f0 - f2;
+        o[LH_BLKSIZE / 2 + 1] = f1 + f3;
+        o[LH_BLKSIZE / 2 + 3] = f1 - f3;
+    }
+    LH_WAVE_SYNC();
+    for (int stage = 0, k1 = 4; stage < 4; stage++, k1 <<= 2) {
+        for (int u = lane; u < LH_BLKSIZE / 8; u += 64)
+            lh_fht_unit(c.T, x, stage, k1, u);
+        LH_WAVE_SYNC();
+    }
+}
+
+/* three windowed 256-point FHTs (reference fft.c:193-243); x[3][256] in LDS, one wave */
+LH_DEVFN void
+lh_fft_short(const LhCtx & c, int ch, int base, float *x)
+{
+    const float *ws = c.T->fft_window_s;
+    int     lane = c.lane;
+    for (int t = lane; t < 3 * (LH_BLKSIZE_S / 8); t += 64) {
+        int const b = t >> 5, j = t & 31;
+        int const k = (576 / 3) * (b + 1) + base;
+        float   f0, f1, f2, f3, w;
+        float  *o = x + b * LH_BLKSIZE_S + 4 * j;
+        int     i = (int) lh_rev8((unsigned) (j << 2));
+        f0 = ws[i] * lh_smp(c, ch, i + k);
+        w = ws[0x7f - i] * lh_smp(c, ch, i + k + 0x80);
+        f1 = f0 - w;
+        f0 = f0 + w;
+        f2 = ws[i + 0x40] * lh_smp(c, ch, i + k + 0x40);
+        w = ws[0x3f - i] * lh_smp(c, ch, i + k + 0xc0);
+        f3 = f2 - w;
+        f2 = f2 + w;
+        o[0] = f0 + f2;
+        o[2] = f0 - f2;
+        o[1] = f1 + f3;
+        o[3] = f1 - f3;
+        f0 = ws[i + 0x01] * lh_smp(c, ch, i + k + 0x01);
+        w = ws[0x7e - i] * lh_smp(c, ch, i + k + 0x81);
+        f1 = f0 - w;
+        f0 = f0 + w;
+        f2 = ws[i + 0x41] * lh_smp(c, ch, i + k + 0x41);
+        w = ws[0x3e - i] * lh_smp(c, ch, i + k + 0xc1);
+        f3 = f2 - w;
+        f2 = f2 + w;
+        o[LH_BLKSIZE_S / 2 + 0] = f0 + f2;
+        o[LH_BLKSIZE_S / 2 + 2] = f0 - f2;
+        o[LH_BLKSIZE_S / 2 + 1] = f1 + f3;
+        o[LH_BLKSIZE_S / 2 + 3] = f1 - f3;
+    }
+    LH_WAVE_SYNC();
+    for (int stage = 0, k1 = 4; stage < 3; stage++, k1 <<= 2) {
+        for (int t = lane; t < 3 * (LH_BLKSIZE_S / 8); t += 64) {
+            int const b = t >> 5, u = t & 31;
+            lh_fht_unit(c.T, x + b * LH_BLKSIZE_S, stage, k1, u);
+        }
+        LH_WAVE_SYNC();
+    }
+}
+
+/* power spectrum of chn from the two channel spectra (reference psymodel.c:664-688,
+ * 713-736); n = transform length, out has n/2+1 entries; one wave */
+LH_DEVFN void
+lh_fft_energy(const LhCtx & c, int chn, const float *wl, const float *wr, int n, float *out)
+{
+    float const sqrt2_half = (float) (LH_SQRT2 * 0.5f);
+    int const h = n >> 1;
+    for (int m = c.lane; m <= h; m += 64) {
+        int const ire = m, iim = (m == 0) ? 0 : (n - m);
+        float   re, im;
+        if (chn == 0) {
+            re = wl[ire];
+            im = wl[iim];
+        }
+        else if (chn == 1) {
+            re = wr[ire];
+            im = wr[iim];
+        }
+        else if (chn == 2) {
+            re = (wl[ire] + wr[ire]) * sqrt2_half;
+            im = (wl[iim] + wr[iim]) * sqrt2_half;
+        }
+        else {
+            re = (wl[ire] - wr[ire]) * sqrt2_half;
+            im = (wl[iim] - wr[iim]) * sqrt2_half;
+        }
+        if (m == 0)
+            out[0] = re * re;
+        else
+            out[m] = (re * re + im * im) * 0.5f;
+    }
+}
+
+/* serial partition -> scalefactor band accumulation (reference psymodel.c:350-393);
+ * executed by ONE lane per (channel, table) chain */
+LH_DEVFN void
+lh_partition2sfb(LhPsyBand const *gd, float const *eb, float const *thr, float *enn_out,
+                 float *thm_out, int out_stride, float thm_scale, int replicate3)
+{
+    float   enn = 0.0f, thmm = 0.0f;
+    int     sb, b, n = gd->n_sb;
+    for (sb = b = 0; sb < n; ++b, ++sb) {
+        int const bo_sb = gd->bo[sb];
+        int const npart = gd->npart;
+        int const b_lim = bo_sb < npart ? bo_sb : npart;
+        while (b < b_lim) {
+            enn += eb[b];
+            thmm += thr[b];
+            b++;
+        }
+        if (b >= npart) {
+            float   tv = thm_scale < 0 ? thmm : thmm * thm_scale;
+            enn_out[sb * out_stride] = enn;
+            thm_out[sb * out_stride] = tv;
+            if (replicate3) {
+                enn_out[sb * out_stride + 1] = enn_out[sb * out_stride + 2] = enn;
+                thm_out[sb * out_stride + 1] = thm_out[sb * out_stride + 2] = tv;
+            }
+            ++sb;
+            break;
+        }
+        {
+            float const w_curr = gd->bo_weight[sb];
+            float const w_next = 1.0f - w_curr;
+            float   tv;
+            enn += w_curr * eb[b];
+            thmm += w_curr * thr[b];
+            tv = thm_scale < 0 ? thmm : thmm * thm_scale;
+            enn_out[sb * out_stride] = enn;
+            thm_out[sb * out_stride] = tv;
+            if (replicate3) {
+                enn_out[sb * out_stride + 1] = enn_out[sb * out_stride + 2] = enn;
+                thm_out[sb * out_stride + 1] = thm_out[sb * out_stride + 2] = tv;
+            }
+            enn = w_next * eb[b];
+            thmm = w_next * thr[b];
+        }
+    }
+    for (; sb < n; ++sb) {
+        float   tv = thm_scale < 0 ? 0.0f : 0.0f * thm_scale;
+        enn_out[sb * out_stride] = 0;
+        thm_out[sb * out_stride] = tv;
+        if (replicate3) {
+            enn_out[sb * out_stride + 1] = enn_out[sb * out_stride + 2] = 0;
+            thm_out[sb * out_stride + 1] = thm_out[sb * out_stride + 2] = tv;
+        }
+    }
+}
+
+/* tonality index of partition b (reference psymodel.c:583-652 / 958-1028) */
+LH_DEVFN int
+lh_mask_index(LhPsyBand const *gd, float const *mx, float const *avg, int b)
+{
+    float   m, a;
+    int     k, nl;
+    int const np = gd->npart;
+    if (b == 0) {
+        a = avg[0] + avg[1];
+        m = mx[0];
+        if (m < mx[1])
+            m = mx[1];
+        nl = gd->numlines[0] + gd->numlines[1] - 1;
+        if (!(a > 0.0f))
+            return 0;
+        a = 20.0f * (m * 2.0f - a) / (a * nl);
+    }
+    else if (b == np - 1) {
+        a = avg[b - 1] + avg[b];
+        m = mx[b - 1];
+        if (m < mx[b])
+            m = mx[b];
+        nl = gd->numlines[b - 1] + gd->numlines[b] - 1;
+        if (!(a > 0.0f))
+            return 0;
+        a = 20.0f * (m * 2.0f - a) / (a * nl);
+    }
+    else {
+        a = avg[b - 1] + avg[b] + avg[b + 1];
+        m = mx[b - 1];
+        if (m < mx[b])
+            m = mx[b];
+        if (m < mx[b + 1])
+            m = mx[b + 1];
+        nl = gd->numlines[b - 1] + gd->numlines[b] + gd->numlines[b + 1] - 1;
+        if (!(a > 0.0f))
+            return 0;
+        a = 20.0f * (m * 3.0f - a) / (a * nl);
+    }
+    k = (int) a;
+    if (k > 8)
+        k = 8;
+    return k;
+}
+
+/* Partition energies + tonality + spreading for one pseudo-channel, one lane per
+ * partition.  is_long selects the long-block variant with the pre-echo clamp
+ * against the two previous granules (reference psymodel.c:1134-1262) or the
+ * short-block variant (:1031-1131).  energy = power spectrum in LDS. */
+LH_DEVFN void
+lh_compute_masking(const LhCtx & c, int chn, int is_long, const float *energy, float *eb,
+                   float *thr, float *smax, float *savg, int *sidx, const int *pstart)
+{
+    LhPsyBand const *gd = is_long ? &c.T->psy_l : &c.T->psy_s;
+    int const b = c.lane;
+    int const np = gd->npart;
+    float   ebb = 0, m = 0;
+    if (b < np) {
+        int const n = gd->numlines[b];
+        int     j = pstart[b];
+        for (int i = 0; i < n; ++i, ++j) {
+            float const el = energy[j];
+            ebb += el;
+            if (m < el)
+                m = el;
+        }
+        eb[b] = ebb;
+        smax[b] = m;
+        savg[b] = ebb * gd->rnumlines[b];
+    }
+    LH_WAVE_SYNC();
+    if (b < np)
+        sidx[b] = lh_mask_index(gd, smax, savg, b);
+    LH_WAVE_SYNC();
+    if (b < np) {
+        float   x, ecb, avg_mask, t;
+        float const masking_lower = gd->masking_lower[b] * c.st->masking_lower;
+        int     k = gd->s3_row[b];
+        int     kk = gd->s3ind[b][0];
+        int const last = gd->s3ind[b][1];
+        int const delta = lh_mask_add_delta[sidx[b]];
+        int     dd, dd_n = 1;
+        float   th;
+        dd = sidx[kk];
+        ecb = gd->s3[k] * eb[kk] * lh_psy_tab[sidx[kk]];
+        ++k, ++kk;
+        while (kk <= last) {
+            dd += sidx[kk];
+            dd_n += 1;
+            x = gd->s3[k] * eb[kk] * lh_psy_tab[sidx[kk]];
+            t = lh_mask_add(c.T, ecb, x, kk - b, delta);
+            ecb = t;
+            ++k, ++kk;
+        }
+        dd = (1 + 2 * dd) / (2 * dd_n);
+        avg_mask = lh_psy_tab[dd] * 0.5f;
+        ecb *= avg_mask;
+        if (is_long) {
+            int const bt_old = c.st->blocktype_old[chn & 1];
+            float const n1 = c.st->nb_l1[chn][b], n2 = c.st->nb_l2[chn][b];
+            if (bt_old == LH_SHORT_TYPE) {
+                float const ecb_limit = LH_RPELEV * n1;
+                if (ecb_limit > 0)
+                    th = (ecb < ecb_limit) ? ecb : ecb_limit;
+                else {
+                    float const alt = (float) (ebb * LH_PREECHO_ATT2);
+                    th = (ecb < alt) ? ecb : alt;
+                }
+            }
+            else {
+                float   ecb_limit_2 = LH_RPELEV2 * n2;
+                float   ecb_limit_1 = LH_RPELEV * n1;
+                float   ecb_limit;
+                if (ecb_limit_2 <= 0)
+                    ecb_limit_2 = ecb;
+                if (ecb_limit_1 <= 0)
+                    ecb_limit_1 = ecb;
+                if (bt_old == LH_NORM_TYPE)
+                    ecb_limit = (ecb_limit_1 < ecb_limit_2) ? ecb_limit_1 : ecb_limit_2;
+                else
+                    ecb_limit = ecb_limit_1;
+                th = (ecb < ecb_limit) ? ecb : ecb_limit;
+            }
+            c.st->nb_l2[chn][b] = n1;
+            c.st->nb_l1[chn][b] = ecb;
+        }
+        else
+            th = ecb;
+        x = m;
+        x *= gd->minval[b];
+        x *= avg_mask;
+        if (th > x)
+            th = x;
+        if (masking_lower > 1)
+            th *= masking_lower;
+        if (th > ebb)
+            th = ebb;
+        if (masking_lower < 1)
+            th *= masking_lower;
+        thr[b] = th;
+    }
+    else {
+        eb[b] = 0;
+        thr[b] = 0;
+    }
+    LH_WAVE_SYNC();
+}
+
+/* reference psymodel.c:1326-1388; one lane per partition, eb/thr are [4][64] in LDS */
+LH_DEVFN void
+lh_ms_thresholds(const LhCtx & c, const float *eb, float *thr, const float *cb_mld,
+                 const float *ath_cb, float athlower, float msfix, int n)
+{
+    int const b = c.lane;
+    if (b < n) {
+        float const msfix2 = msfix * 2.f;
+        float   rside, rmid;
+        float const ebM = eb[2 * 64 + b];
+        float const ebS = eb[3 * 64 + b];
+        float const thmL = thr[0 * 64 + b];
+        float const thmR = thr[1 * 64 + b];
+        float   thmM = thr[2 * 64 + b];
+        float   thmS = thr[3 * 64 + b];
+        if (thmL <= 1.58f * thmR && thmR <= 1.58f * thmL) {
+            float const mld_m = cb_mld[b] * ebS;
+            float const mld_s = cb_mld[b] * ebM;
+            float const tmp_m = (thmS < mld_m) ? thmS : mld_m;
+            float const tmp_s = (thmM < mld_s) ? thmM : mld_s;
+            rmid = (thmM > tmp_m) ? thmM : tmp_m;
+            rside = (thmS > tmp_s) ? thmS : tmp_s;
+        }
+        else {
+            rmid = thmM;
+            rside = thmS;
+        }
+        if (msfix > 0.f) {
+            float   thmLR, thmMS;
+            float const ath = ath_cb[b] * athlower;
+            float const tmp_l = (thmL > ath) ? thmL : ath;
+            float const tmp_r = (thmR > ath) ? thmR : ath;
+            thmLR = (tmp_l < tmp_r) ? tmp_l : tmp_r;
+            thmM = (rmid > ath) ? rmid : ath;
+            thmS = (rside > ath) ? rside : ath;
+            thmMS = thmM + thmS;
+            if (thmMS > 0.f && (thmLR * msfix2) < thmMS) {
+                float const f = thmLR * msfix2 / thmMS;
+                thmM *= f;
+                thmS *= f;
+            }
+            rmid = (thmM < rmid) ? thmM : rmid;
+            rside = (thmS < rside) ? thmS : rside;
+        }
+        if (rmid > ebM)
+            rmid = ebM;
+        if (rside > ebS)
+            rside = ebS;
+        thr[2 * 64 + b] = rmid;
+        thr[3 * 64 + b] = rside;
+    }
+}
+
+/* perceptual entropy of one pseudo-channel (reference psymodel.c:458-553); serial, one lane.
+ * en/thm point at a 61-entry III_psy_xmin image (l[22], s[13][3]) */
+LH_DEVFN float
+lh_pecalc(const LhTables * T, const float *en, const float *thm, float masking_lower, int is_short)
+{
+    float   pe;
+    if (is_short) {
+        pe = 1236.28f / 4;
+        for (int sb = 0; sb < LH_SBMAX_S - 1; sb++) {
+            for (int sblock = 0; sblock < 3; sblock++) {
+                float const t = thm[22 + sb * 3 + sblock];
+                if (t > 0.0f) {
+                    float const x = t * masking_lower;
+                    float const e = en[22 + sb * 3 + sblock];
+                    if (e > x) {
+                        if (e > x * 1e10f)
+                            pe = (float) (pe + lh_regcoef_s[sb] * (10.0f * 2.30258509299404568402));
+                        else
+                            pe = (float) (pe + lh_regcoef_s[sb] *
+                                          (lh_fast_log2(T->log_table, e / x) * LH_LOG2_OVER_LOG10));
+                    }
+                }
+            }
+        }
+    }
+    else {
+        pe = 1124.23f / 4;
+        for (int sb = 0; sb < LH_SBMAX_L - 1; sb++) {
+            float const t = thm[sb];
+            if (t > 0.0f) {
+                float const x = t * masking_lower;
+                float const e = en[sb];
+                if (e > x) {
+                    if (e > x * 1e10f)
+                        pe = (float) (pe + lh_regcoef_l[sb] * (10.0f * 2.30258509299404568402));
+                    else
+                        pe = (float) (pe + lh_regcoef_l[sb] *
+                                      (lh_fast_log2(T->log_table, e / x) * LH_LOG2_OVER_LOG10));
+                }
+            }
+        }
+    }
+    return pe;
+}
+
+/* ------------------------------------------------------------------ */
+/* One granule of the psycho-acoustic model for the whole workgroup     */
+/* (reference L3psycho_anal_vbr, psymodel.c:1397-1597).                 */
+LH_DEVFN void
+lh_psy_granule(const LhCtx & c, LhLds & L, int gr)
+{
+    const LhConfig *cfg = c.cfg;
+    const LhTables *T = c.T;
+    LhStreamState *st = c.st;
+    LhPsyLds & P = L.u.psy;
+    int const lane = c.lane, w = c.wave;
+    int const n_chn_psy = (cfg->mode == LH_MODE_JOINT_STEREO) ? 4 : 2;
+    int const bufbase = 576 + gr * 576 - LH_FFTOFFSET;      /* bufp[ch] = &inbuf[ch][bufbase] */
+
+    /* (1) one-granule delay: hand last call's en/thm to the caller and keep them as last_thm */
+    for (int t = c.tid; t < 4 * LH_XMIN_N; t += LH_NT) {
+        int const chn = t / LH_XMIN_N, i = t - chn * LH_XMIN_N;
+        L.ratio_en[gr][chn][i] = st->en[chn][i];
+        L.ratio_thm[gr][chn][i] = st->thm[chn][i];
+    }
+    if (c.tid < 4)
+        L.tot_ener[gr][c.tid] = st->tot_ener[c.tid];
+
+    /* (2) attack detection (reference psymodel.c:759-940) */
+    {
+        int const firbase = bufbase + 576 - 350 - LH_NSFIRLEN + 192;
+        for (int i = lane; i < 576; i += 64) {
+            float   sum1, sum2;
+            sum1 = lh_smp(c, w, firbase + i + 10);
+            sum2 = 0.0;
+            for (int j = 0; j < ((LH_NSFIRLEN - 1) / 2) - 1; j += 2) {
+                sum1 += lh_hp_fir[j] * (lh_smp(c, w, firbase + i + j) +
+                                        lh_smp(c, w, firbase + i + LH_NSFIRLEN - j));
+                sum2 += lh_hp_fir[j + 1] * (lh_smp(c, w, firbase + i + j + 1) +
+                                            lh_smp(c, w, firbase + i + LH_NSFIRLEN - j - 1));
+            }
+            P.a.hpf[w][i] = sum1 + sum2;
+        }
+    }
+    LH_SYNC_WG();
+    for (int pass = 0; pass < 2; pass++) {
+        int const chn = w + 2 * pass;
+        if (chn < n_chn_psy) {
+            float   peak[9];
+            for (int k = 0; k < 9; k++) {
+                int const i = lane + 64 * k;
+                float   v;
+                if (pass == 0)
+                    v = P.a.hpf[w][i];
+                else if (w == 0)
+                    v = P.a.hpf[0][i] + P.a.hpf[1][i];
+                else
+                    v = P.a.hpf[0][i] - P.a.hpf[1][i];
+                v = lh_fabsf(v);
+                /* p = max(1, max |x|): exact under any evaluation order */
+                peak[k] = lh_u32_as_f32(lh_wave_max_u32(lh_f32_as_u32(v)));
+                if (peak[k] < 1.0f)
+                    peak[k] = 1.0f;
+            }
+            {
+                /* wave-uniform scalar part */
+                float   attack_intensity[12];
+                float   en_subshort[12];
+                float   en_short[4] = { 0, 0, 0, 0 };
+                int     nsa[4] = { 0, 0, 0, 0 };
+                int     ns_uselongblock = 1;
+                int const last_att = st->last_attacks[chn];
+                for (int i = 0; i < 3; i++) {
+                    en_subshort[i] = st->last_en_subshort[chn][i + 6];
+                    attack_intensity[i] = en_subshort[i] / st->last_en_subshort[chn][i + 4];
+                    en_short[0] += en_subshort[i];
+                }
+                LH_WAVE_SYNC();
+                for (int i = 0; i < 9; i++) {
+                    float   p = peak[i];
+                    if (lane == 0)
+                        st->last_en_subshort[chn][i] = p;
+                    en_subshort[i + 3] = p;
+                    en_short[1 + i / 3] += p;
+                    if (p > en_subshort[i + 3 - 2])
+                        p = p / en_subshort[i + 3 - 2];
+                    else if (en_subshort[i + 3 - 2] > p * 10.0f)
+                        p = en_subshort[i + 3 - 2] / (p * 10.0f);
+                    else
+                        p = 0.0;
+                    attack_intensity[i + 3] = p;
+                }
+                for (int i = 0; i < 3; ++i) {
+                    float const enn =
+                        en_subshort[i * 3 + 3] + en_subshort[i * 3 + 4] + en_subshort[i * 3 + 5];
+                    float   factor = 1.f;
+                    if (en_subshort[i * 3 + 5] * 6 < enn) {
+                        factor *= 0.5f;
+                        if (en_subshort[i * 3 + 4] * 6 < enn)
+                            factor *= 0.5f;
+                    }
+                    L.sub_short_factor[chn][i] = factor;
+                }
+                {
+                    float const x = T->attack_threshold[chn];
+                    for (int i = 0; i < 12; i++)
+                        if (nsa[i / 3] == 0)
+                            if (attack_intensity[i] > x)
+                                nsa[i / 3] = (i % 3) + 1;
+                }
+                for (int i = 1; i < 4; i++) {
+                    float const u = en_short[i - 1];
+                    float const v = en_short[i];
+                    float const m = (u > v) ? u : v;
+                    if (m < 40000) {
+                        if (u < 1.7f * v && v < 1.7f * u) {
+                            if (i == 1 && nsa[0] <= nsa[i])
+                                nsa[0] = 0;
+                            nsa[i] = 0;
+                        }
+                    }
+                }
+                if (nsa[0] <= last_att)
+                    nsa[0] = 0;
+                if (last_att == 3 || nsa[0] + nsa[1] + nsa[2] + nsa[3]) {
+                    ns_uselongblock = 0;
+                    if (nsa[1] && nsa[0])
+                        nsa[1] = 0;
+                    if (nsa[2] && nsa[1])
+                        nsa[2] = 0;
+                    if (nsa[3] && nsa[2])
+                        nsa[3] = 0;
+                }
+                for (int i = 0; i < 4; i++)
+                    L.ns_attacks[chn][i] = nsa[i];
+                L.ns_uselong[chn] = ns_uselongblock;
+            }
+        }
+        LH_WAVE_SYNC();
+    }
+    LH_SYNC_WG();
+    {
+        /* uselongblock[] resolution (reference psymodel.c:926-933, 1265-1286) */
+        int     ul0 = L.ns_uselong[0], ul1 = L.ns_uselong[1];
+        for (int chn = 2; chn < n_chn_psy; chn++)
+            if (L.ns_uselong[chn] == 0)
+                ul0 = ul1 = 0;
+        if (cfg->short_blocks == 1 && !(ul0 && ul1))
+            ul0 = ul1 = 0;
+        if (cfg->short_blocks == 2)
+            ul0 = ul1 = 1;
+        if (cfg->short_blocks == 3)
+            ul0 = ul1 = 0;
+        LH_SYNC_WG();
+        if (c.tid == 0) {
+            L.uselongblock[0] = ul0;
+            L.uselongblock[1] = ul1;
+        }
+    }
+    LH_SYNC_WG();
+
+    /* (3) long FFTs of L (wave 0) and R (wave 1) */
+    lh_fft_long(c, w, bufbase, P.wsamp[w]);
+    LH_SYNC_WG();
+    /* (4) power spectra of this wave's two pseudo-channels */
+    for (int pass = 0; pass < 2; pass++) {
+        int const chn = w + 2 * pass;
+        if (chn < n_chn_psy)
+            lh_fft_energy(c, chn, P.wsamp[0], P.wsamp[1], LH_BLKSIZE, P.b.energy[chn]);
+    }
+    LH_WAVE_SYNC();
+    /* (5) serial sums: total energy (bins 11..512) and loudness (reference psymodel.c:213-226,
+     * 690-696): lane 0/1 = tot_ener of chn w / w+2, lane 2 = loudness of channel w */
+    if (lane < 3) {
+        int const chn = (lane == 1) ? w + 2 : w;
+        if (chn < n_chn_psy) {
+            const float *e = P.b.energy[chn];
+            float   acc = 0.0f;
+            if (lane < 2) {
+                for (int j = 11; j < LH_HBLKSIZE; j++)
+                    acc += e[j];
+                st->tot_ener[chn] = acc;
+            }
+            else {
+                const float *ew = T->ath_eql_w;
+                for (int i = 0; i < LH_BLKSIZE / 2; ++i)
+                    acc += e[i] * ew[i];
+                acc = (float) (acc * LH_VO_SCALE);
+                L.loudness_sq[gr][w] = st->loudness_sq_save[w];
+                st->loudness_sq_save[w] = acc;
+            }
+        }
+    }
+    /* (6) masking thresholds, long blocks */
+    for (int pass = 0; pass < 2; pass++) {
+        int const chn = w + 2 * pass;
+        if (chn < n_chn_psy)
+            lh_compute_masking(c, chn, 1, P.b.energy[chn], &P.eb[chn * 64], &P.thr[chn * 64],
+                               P.smax[w], P.savg[w], P.sidx[w], L.pstart_l);
+    }
+    LH_SYNC_WG();
+    if (cfg->mode == LH_MODE_JOINT_STEREO && (L.uselongblock[0] + L.uselongblock[1]) == 2) {
+        float const ath_factor =
+            (cfg->msfix > 0.f) ? (cfg->ATH_offset_factor * st->ath_adjust_factor) : 1.f;
+        if (w == 0)
+            lh_ms_thresholds(c, P.eb, P.thr, T->psy_l.mld_cb, T->ath_cb_l, ath_factor, cfg->msfix,
+                             T->psy_l.npart);
+    }
+    LH_SYNC_WG();
+    /* (7) partitions -> scalefactor bands, long and long->short estimates
+     * (reference psymodel.c:411-439); 4 serial chains per wave */
+    if (lane < 4) {
+        int const chn = w + 2 * (lane >> 1);
+        if (chn < n_chn_psy) {
+            if ((lane & 1) == 0)
+                lh_partition2sfb(&T->psy_l, &P.eb[chn * 64], &P.thr[chn * 64], &st->en[chn][0],
+                                 &st->thm[chn][0], 1, -1.0f, 0);
+            else
+                lh_partition2sfb(&T->psy_l_to_s, &P.eb[chn * 64], &P.thr[chn * 64],
+                                 &st->en[chn][22], &st->thm[chn][22], 3, (float) (1. / 64.f), 1);
+        }
+    }
+    LH_SYNC_WG();
+    /* (8) short blocks (reference psymodel.c:1470-1500) */
+    if (!L.uselongblock[w])
+        lh_fft_short(c, w, bufbase, &P.wsamp[w][0]);
+    LH_SYNC_WG();
+    for (int sblock = 0; sblock < 3; sblock++) {
+        for (int pass = 0; pass < 2; pass++) {
+            int const chn = w + 2 * pass;
+            if (chn < n_chn_psy && !L.uselongblock[chn & 1]) {
+                lh_fft_energy(c, chn, &P.wsamp[0][sblock * LH_BLKSIZE_S],
+                              &P.wsamp[1][sblock * LH_BLKSIZE_S], LH_BLKSIZE_S, P.b.energy[chn]);
+                LH_WAVE_SYNC();
+                lh_compute_masking(c, chn, 0, P.b.energy[chn], &P.eb[chn * 64], &P.thr[chn * 64],
+                                   P.smax[w], P.savg[w], P.sidx[w], L.pstart_s);
+            }
+        }
+        LH_SYNC_WG();
+        if (cfg->mode == LH_MODE_JOINT_STEREO && (L.uselongblock[0] + L.uselongblock[1]) == 0) {
+            float const ath_factor =
+                (cfg->msfix > 0.f) ? (cfg->ATH_offset_factor * st->ath_adjust_factor) : 1.f;
+            if (w == 0)
+                lh_ms_thresholds(c, P.eb, P.thr, T->psy_s.mld_cb, T->ath_cb_s, ath_factor,
+                                 cfg->msfix, T->psy_s.npart);
+        }
+        LH_SYNC_WG();
+        if (lane < 2) {
+            int const chn = w + 2 * lane;
+            if (chn < n_chn_psy && !L.uselongblock[chn & 1])
+                lh_partition2sfb(&T->psy_s, &P.eb[chn * 64], &P.thr[chn * 64],
+                                 &st->en[chn][22 + sblock], &st->thm[chn][22 + sblock], 3, -1.0f, 0);
+        }
+        LH_SYNC_WG();
+    }
+    /* (9) short block pre-echo control (reference psymodel.c:1502-1553): one lane per (chn, sb) */
+    {
+        float const pcfact = 0.6f;
+        for (int t = c.tid; t < n_chn_psy * LH_SBMAX_S; t += LH_NT) {
+            int const chn = t / LH_SBMAX_S, sb = t - chn * LH_SBMAX_S;
+            const float *last_thm = &L.ratio_thm[gr][chn][22 + sb * 3];
+            float   new_thmm[3], prev_thm, t1, t2, thmm;
+            int const last_att = st->last_attacks[chn];
+            for (int sblock = 0; sblock < 3; sblock++) {
+                int const a0 = L.ns_attacks[chn][sblock], a1 = L.ns_attacks[chn][sblock + 1];
+                thmm = st->thm[chn][22 + sb * 3 + sblock];
+                thmm = (float) (thmm * LH_PREECHO_ATT0);
+                t1 = t2 = thmm;
+                if (sblock > 0)
+                    prev_thm = new_thmm[sblock - 1];
+                else
+                    prev_thm = last_thm[2];
+                if (a0 >= 2 || a1 == 1)
+                    t1 = lh_ns_interp(prev_thm, thmm, (float) (LH_PREECHO_ATT1 * pcfact));
+                thmm = (t1 < thmm) ? t1 : thmm;
+                if (a0 == 1)
+                    t2 = lh_ns_interp(prev_thm, thmm, (float) (LH_PREECHO_ATT2 * pcfact));
+                else if ((sblock == 0 && last_att == 3)
+                         || (sblock > 0 && L.ns_attacks[chn][sblock - 1] == 3)) {
+                    switch (sblock) {
+                    case 0:
+                        prev_thm = last_thm[1];
+                        break;
+                    case 1:
+                        prev_thm = last_thm[2];
+                        break;
+                    default:
+                        prev_thm = new_thmm[0];
+                        break;
+                    }
+                    t2 = lh_ns_interp(prev_thm, thmm, (float) (LH_PREECHO_ATT2 * pcfact));
+                }
+                thmm = (t1 < thmm) ? t1 : thmm;
+                thmm = (t2 < thmm) ? t2 : thmm;
+                thmm *= L.sub_short_factor[chn][sblock];
+                new_thmm[sblock] = thmm;
+            }
+            for (int sblock = 0; sblock < 3; sblock++)
+                st->thm[chn][22 + sb * 3 + sblock] = new_thmm[sblock];
+        }
+    }
+    LH_SYNC_WG();
+    /* (10) block type state machine (reference psymodel.c:1289-1319) + PE (:1568-1595) */
+    {
+        int     btd[2];
+        for (int chn = 0; chn < 2; chn++) {
+            int     blocktype = LH_NORM_TYPE;
+            int     old = st->blocktype_old[chn];
+            if (L.uselongblock[chn]) {
+                if (old == LH_SHORT_TYPE)
+                    blocktype = LH_STOP_TYPE;
+            }
+            else {
+                blocktype = LH_SHORT_TYPE;
+                if (old == LH_NORM_TYPE)
+                    old = LH_START_TYPE;
+                if (old == LH_STOP_TYPE)
+                    old = LH_SHORT_TYPE;
+            }
+            btd[chn] = old;
+            L.next_blocktype[chn] = blocktype;
+        }
+        LH_SYNC_WG();
+        if (c.tid < 2) {
+            st->blocktype_old[c.tid] = L.next_blocktype[c.tid];
+            L.block_type[gr][c.tid] = btd[c.tid];
+        }
+        if (c.tid < n_chn_psy) {
+            int const chn = c.tid;
+            int     type;
+            if (chn > 1) {
+                type = LH_NORM_TYPE;
+                if (btd[0] == LH_SHORT_TYPE || btd[1] == LH_SHORT_TYPE)
+                    type = LH_SHORT_TYPE;
+            }
+            else
+                type = btd[chn];
+            L.pe[gr][chn] = lh_pecalc(T, L.ratio_en[gr][chn], L.ratio_thm[gr][chn], st->masking_lower,
+                                      type == LH_SHORT_TYPE);
+            st->last_attacks[chn] = L.ns_attacks[chn][2];
+        }
+    }
+    LH_SYNC_WG();
+}
+
+#endif

@@ -1,0 +1,1723 @@
+/*
+ * lh_dev_quant.h -- CBR quantisation / noise-shaping / Huffman-selection loop
+ * on one wavefront per stream-channel
+ * (reference quantize.c:48-1232,1988-2050, quantize_pvt.c:428-913,
+ * takehiro.c:113-1327, reservoir.c:82-293).
+ *
+ * Data layout: the 576 spectral lines of the granule live in LDS (xr, xrpow,
+ * two int16 quantised images: best-so-far and working).  Lane l owns the line
+ * pairs l, l+64, ... (288 pairs), so a pair never straddles lanes and LDS
+ * accesses are stride-1.  The noise-shaping search is a chain of wave-uniform
+ * decisions; inside each step
+ *   - quantisation is per line (lanes over pairs),
+ *   - ix_max / Huffman bit sums / "last non-zero pair" are wave reductions,
+ *   - per-scalefactor-band sums (xmin, noise) keep the reference's serial
+ *     order inside the band and run one band per lane.
+ * Wave-uniform scalars of gr_info live in registers (LhGrR / LhQR: every lane
+ * carries an identical copy), per-band arrays in LDS are written by lane == band
+ * only, per-line arrays by the lane owning the line; LH_WAVE_SYNC() separates a
+ * write phase from the reads of other lanes.  The code is therefore correct for
+ * any interleaving of the lanes between two syncs (the CPU fiber emulator of
+ * tests/hipemu relies on that), not just for lockstep execution.
+ */
+#ifndef LH_DEV_QUANT_H
+#define LH_DEV_QUANT_H
+
+#include "lh_dev_common.h"
+
+#define LH_MAGIC_FLOAT (65536*(128))
+#define LH_MAGIC_INT 0x4b000000
+
+LH_DEVCONST int lh_slen1_n[16] = { 1, 1, 1, 1, 8, 2, 2, 2, 4, 4, 4, 8, 8, 8, 16, 16 };
+LH_DEVCONST int lh_slen2_n[16] = { 1, 2, 4, 8, 1, 2, 4, 8, 2, 4, 8, 2, 4, 8, 4, 8 };
+LH_DEVCONST int lh_slen1_tab[16] = { 0, 0, 0, 0, 3, 1, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4 };
+LH_DEVCONST int lh_slen2_tab[16] = { 0, 1, 2, 3, 0, 1, 2, 3, 1, 2, 3, 1, 2, 3, 2, 3 };
+LH_DEVCONST int lh_scfsi_band[5] = { 0, 6, 11, 16, 21 };
+LH_DEVCONST int lh_scale_short[16] = { 0, 18, 36, 54, 54, 36, 54, 72, 54, 72, 90, 72, 90, 108, 108, 126 };
+LH_DEVCONST int lh_scale_long[16] = { 0, 10, 20, 30, 33, 21, 31, 41, 32, 42, 52, 43, 53, 63, 64, 74 };
+LH_DEVCONST int lh_huf_tbl_noESC[15] = { 1, 2, 5, 7, 7, 10, 10, 13, 13, 13, 13, 13, 13, 13, 13 };
+
+#define LH_HLEN(t)  (lh_ht_len + lh_ht_offset[t])
+
+/* ---------------------------------------------------------------------- */
+/* one line through the x^(3/4) quantiser (reference takehiro.c:144-200)     */
+LH_DEVFN int
+lh_quant_line(const LhTables * T, float istep, float xp)
+{
+    double  x0 = (double) (istep * xp);
+    float   f;
+    int     k;
+    x0 += LH_MAGIC_FLOAT;
+    f = (float) x0;
+    k = (int) lh_f32_as_u32(f) - LH_MAGIC_INT;
+    f = (float) (x0 + T->adj43asm[k]);
+    return (int) lh_f32_as_u32(f) - LH_MAGIC_INT;
+}
+
+/* Huffman cost of the pairs [lo,hi) of ix with the best table; all lanes take
+ * part (reference choose_table_nonMMX, takehiro.c:423-647).  v[][] are this
+ * lane's 5 pairs, pair index p = lane + 64 k. */
+LH_DEVFN int
+lh_choose_table_wave(const LhCtx & c, const int v[5][2], int lo, int hi, int *bits)
+{
+    unsigned mx = 0;
+    int const plo = lo >> 1, phi = hi >> 1;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        int const p = c.lane + 64 * k;
+        if (p >= plo && p < phi) {
+            unsigned const m = (unsigned) (v[k][0] > v[k][1] ? v[k][0] : v[k][1]);
+            mx = m > mx ? m : mx;
+        }
+    }
+    mx = lh_wave_max_u32(mx);
+    if (mx == 0)
+        return 0;
+    if (mx <= 15) {
+        if (mx == 1) {
+            unsigned s = 0;
+            const uint8_t *h1 = LH_HLEN(1);
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                int const p = c.lane + 64 * k;
+                if (p >= plo && p < phi)
+                    s += h1[v[k][0] + v[k][0] + v[k][1]];
+            }
+            s = lh_wave_sum_u32(s);
+            *bits += (int) s;
+            return 1;
+        }
+        if (mx <= 3) {
+            int     t1 = lh_huf_tbl_noESC[mx - 1];
+            unsigned const xlen = lh_ht_xlen[t1];
+            const uint32_t *table = (t1 == 2) ? lh_table23 : lh_table56;
+            unsigned s = 0, s2;
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                int const p = c.lane + 64 * k;
+                if (p >= plo && p < phi)
+                    s += table[(unsigned) v[k][0] * xlen + (unsigned) v[k][1]];
+            }
+            s = lh_wave_sum_u32(s);
+            s2 = s & 0xffffu;
+            s >>= 16u;
+            if (s > s2) {
+                s = s2;
+                t1++;
+            }
+            *bits += (int) s;
+            return t1;
+        }
+        {
+            int const t1 = lh_huf_tbl_noESC[mx - 1];
+            unsigned const xlen = lh_ht_xlen[t1];
+            const uint8_t *h1 = LH_HLEN(t1), *h2 = LH_HLEN(t1 + 1), *h3 = LH_HLEN(t1 + 2);
+            uint64_t s = 0;
+            unsigned s1, s2, s3;
+            int     t;
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                int const p = c.lane + 64 * k;
+                if (p >= plo && p < phi) {
+                    unsigned const x = (unsigned) v[k][0] * xlen + (unsigned) v[k][1];
+                    s += (uint64_t) h1[x] | ((uint64_t) h2[x] << 20) | ((uint64_t) h3[x] << 40);
+                }
+            }
+            s = lh_wave_sum_u64(s);
+            s1 = (unsigned) (s & 0xfffffu);
+            s2 = (unsigned) ((s >> 20) & 0xfffffu);
+            s3 = (unsigned) ((s >> 40) & 0xfffffu);
+            t = t1;
+            if (s1 > s2) {
+                s1 = s2;
+                t++;
+            }
+            if (s1 > s3) {
+                s1 = s3;
+                t = t1 + 2;
+            }
+            *bits += (int) s1;
+            return t;
+        }
+    }
+    if (mx > LH_IXMAX) {
+        *bits = LH_LARGE_BITS;
+        return -1;
+    }
+    {
+        int     choice, choice2;
+        unsigned const m15 = mx - 15u;
+        uint64_t s = 0;
+        unsigned sa, sb, n15;
+        for (choice2 = 24; choice2 < 32; choice2++)
+            if (lh_ht_linmax[choice2] >= m15)
+                break;
+        for (choice = choice2 - 8; choice < 24; choice++)
+            if (lh_ht_linmax[choice] >= m15)
+                break;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            int const p = c.lane + 64 * k;
+            if (p >= plo && p < phi) {
+                unsigned x = (unsigned) v[k][0], y = (unsigned) v[k][1];
+                unsigned cnt = 0, e;
+                if (x >= 15u) {
+                    x = 15u;
+                    cnt++;
+                }
+                if (y >= 15u) {
+                    y = 15u;
+                    cnt++;
+                }
+                e = lh_largetbl[(x << 4) + y];
+                s += (uint64_t) (e >> 16) | ((uint64_t) (e & 0xffffu) << 20) | ((uint64_t) cnt << 40);
+            }
+        }
+        s = lh_wave_sum_u64(s);
+        n15 = (unsigned) (s >> 40);
+        sa = (unsigned) (s & 0xfffffu) + n15 * lh_ht_xlen[choice];
+        sb = (unsigned) ((s >> 20) & 0xfffffu) + n15 * lh_ht_xlen[choice2];
+        if (sa > sb) {
+            sa = sb;
+            choice = choice2;
+        }
+        *bits += (int) sa;
+        return choice;
+    }
+}
+
+/* the same selection done serially by ONE lane over ix[lo,hi) in LDS; used where
+ * many independent regions are evaluated at once, one per lane (best_huffman_divide) */
+LH_DEVFN int
+lh_choose_table_lane(const int16_t * ix, int lo, int hi, int *bits)
+{
+    unsigned mx = 0;
+    for (int i = lo; i < hi; i++) {
+        unsigned const x = (unsigned) ix[i];
+        mx = x > mx ? x : mx;
+    }
+    if (mx == 0)
+        return 0;
+    if (mx <= 15) {
+        if (mx == 1) {
+            unsigned s = 0;
+            const uint8_t *h1 = LH_HLEN(1);
+            for (int i = lo; i < hi; i += 2)
+                s += h1[ix[i] + ix[i] + ix[i + 1]];
+            *bits += (int) s;
+            return 1;
+        }
+        if (mx <= 3) {
+            int     t1 = lh_huf_tbl_noESC[mx - 1];
+            unsigned const xlen = lh_ht_xlen[t1];
+            const uint32_t *table = (t1 == 2) ? lh_table23 : lh_table56;
+            unsigned s = 0, s2;
+            for (int i = lo; i < hi; i += 2)
+                s += table[(unsigned) ix[i] * xlen + (unsigned) ix[i + 1]];
+            s2 = s & 0xffffu;
+            s >>= 16u;
+            if (s > s2) {
+                s = s2;
+                t1++;
+            }
+            *bits += (int) s;
+            return t1;
+        }
+        {
+            int const t1 = lh_huf_tbl_noESC[mx - 1];
+            unsigned const xlen = lh_ht_xlen[t1];
+            const uint8_t *h1 = LH_HLEN(t1), *h2 = LH_HLEN(t1 + 1), *h3 = LH_HLEN(t1 + 2);
+            unsigned s1 = 0, s2 = 0, s3 = 0;
+            int     t;
+            for (int i = lo; i < hi; i += 2) {
+                unsigned const x = (unsigned) ix[i] * xlen + (unsigned) ix[i + 1];
+                s1 += h1[x];
+                s2 += h2[x];
+                s3 += h3[x];
+            }
+            t = t1;
+            if (s1 > s2) {
+                s1 = s2;
+                t++;
+            }
+            if (s1 > s3) {
+                s1 = s3;
+                t = t1 + 2;
+            }
+            *bits += (int) s1;
+            return t;
+        }
+    }
+    if (mx > LH_IXMAX) {
+        *bits = LH_LARGE_BITS;
+        return -1;
+    }
+    {
+        int     choice, choice2;
+        unsigned const m15 = mx - 15u;
+        unsigned sa = 0, sb = 0, n15 = 0;
+        for (choice2 = 24; choice2 < 32; choice2++)
+            if (lh_ht_linmax[choice2] >= m15)
+                break;
+        for (choice = choice2 - 8; choice < 24; choice++)
+            if (lh_ht_linmax[choice] >= m15)
+                break;
+        for (int i = lo; i < hi; i += 2) {
+            unsigned x = (unsigned) ix[i], y = (unsigned) ix[i + 1], e;
+            if (x >= 15u) {
+                x = 15u;
+                n15++;
+            }
+            if (y >= 15u) {
+                y = 15u;
+                n15++;
+            }
+            e = lh_largetbl[(x << 4) + y];
+            sa += e >> 16;
+            sb += e & 0xffffu;
+        }
+        sa += n15 * lh_ht_xlen[choice];
+        sb += n15 * lh_ht_xlen[choice2];
+        if (sa > sb) {
+            sa = sb;
+            choice = choice2;
+        }
+        *bits += (int) sa;
+        return choice;
+    }
+}
+
+/* reference takehiro.c:654-765; quantised image `which' must be complete and synced */
+LH_DEVFN int
+lh_noquant_count_bits(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, int which, int use_prev)
+{
+    const LhTables *T = c.T;
+    const int16_t *ix = Q.ix[which];
+    int     v[5][2];
+    int     bits, i, a1, a2;
+    unsigned top_nz = 0, top_big = 0;
+    int const i0 = (((R.mnc + 2) >> 1) << 1) > 576 ? 576 : (((R.mnc + 2) >> 1) << 1);
+
+    if (use_prev)
+        R.pn_sfb_count1 = 0;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        int const p = c.lane + 64 * k;
+        if (p < 288) {
+            v[k][0] = ix[2 * p];
+            v[k][1] = ix[2 * p + 1];
+            if (2 * p < i0 && (v[k][0] | v[k][1]))
+                top_nz = (unsigned) (p + 1);
+        }
+        else {
+            v[k][0] = v[k][1] = 0;
+        }
+    }
+    top_nz = lh_wave_max_u32(top_nz);
+    i = 2 * (int) top_nz;
+    g.count1 = i;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        int const p = c.lane + 64 * k;
+        if (p < (int) top_nz && (unsigned) (v[k][0] | v[k][1]) > 1)
+            top_big = (unsigned) (p + 1);
+    }
+    top_big = lh_wave_max_u32(top_big);
+    {
+        /* trailing quadruples whose values are all <= 1 */
+        int const q = 2 * (int) top_big;
+        int const nquad = (i - q) / 4;
+        unsigned s = 0;
+        int const bv = i - 4 * nquad;
+        for (int qd = c.lane; qd < nquad; qd += 64) {
+            int const b = bv + 4 * qd;
+            int const p = ((ix[b] * 2 + ix[b + 1]) * 2 + ix[b + 2]) * 2 + ix[b + 3];
+            s += ((unsigned) lh_t32l[p] << 16) + (unsigned) lh_t33l[p];
+        }
+        s = lh_wave_sum_u32(s);
+        a1 = (int) (s >> 16);
+        a2 = (int) (s & 0xffffu);
+        i = bv;
+    }
+    bits = a1;
+    g.count1table_select = 0;
+    if (a1 > a2) {
+        bits = a2;
+        g.count1table_select = 1;
+    }
+    g.count1bits = bits;
+    g.big_values = i;
+    if (i == 0)
+        return bits;
+
+    if (R.block_type == LH_SHORT_TYPE) {
+        a1 = 3 * T->sfb_s[3];
+        if (a1 > g.big_values)
+            a1 = g.big_values;
+        a2 = g.big_values;
+    }
+    else if (R.block_type == LH_NORM_TYPE) {
+        a1 = g.region0_count = T->bv_scf[i - 2];
+        a2 = g.region1_count = T->bv_scf[i - 1];
+        a2 = T->sfb_l[a1 + a2 + 2];
+        a1 = T->sfb_l[a1 + 1];
+        if (a2 < i)
+            g.table_select[2] = lh_choose_table_wave(c, v, a2, i, &bits);
+    }
+    else {
+        g.region0_count = 7;
+        g.region1_count = LH_SBMAX_L - 1 - 7 - 1;
+        a1 = T->sfb_l[7 + 1];
+        a2 = i;
+        if (a1 > a2)
+            a1 = a2;
+    }
+    a1 = (a1 < i) ? a1 : i;
+    a2 = (a2 < i) ? a2 : i;
+    if (0 < a1)
+        g.table_select[0] = lh_choose_table_wave(c, v, 0, a1, &bits);
+    if (a1 < a2)
+        g.table_select[1] = lh_choose_table_wave(c, v, a1, a2, &bits);
+    /* use_best_huffman == 2 (best_huffman_divide inside the loop) is not selected by any quality level */
+    if (use_prev) {
+        if (R.block_type == LH_NORM_TYPE) {
+            int     sfb = 0;
+            while (T->sfb_l[sfb] < g.big_values)
+                sfb++;
+            R.pn_sfb_count1 = sfb;
+        }
+    }
+    return bits;
+}
+
+/* reference takehiro.c:767-801 + quantize_xrpow :281-414 */
+LH_DEVFN int
+lh_count_bits(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, int which, int use_prev)
+{
+    const LhTables *T = c.T;
+    int16_t *ix = Q.ix[which];
+    const int *sf = Q.sf[which];
+    const float *xrpow = Q.xrpow;
+    float const istep = T->ipow20[g.global_gain];
+    float const w = (LH_IXMAX) / istep;
+    int const mnc = R.mnc;
+    int const sfbmax = (R.block_type == LH_SHORT_TYPE) ? 38 : 21;
+    int     s_trunc, l_trunc = 0, j_trunc = 0;
+
+    if (g.xrpow_max > w)
+        return LH_LARGE_BITS;
+    {
+        int const prev_data_use = (use_prev && (g.global_gain == R.pn_global_gain));
+        int const s = c.lane;
+        int     cand = 0;
+        if (s <= sfbmax) {
+            int     step = -1, cached, m01, mode;
+            if (prev_data_use || R.block_type == LH_NORM_TYPE) {
+                int const pre = (g.preflag && s < LH_SBMAX_L) ? lh_pretab[s] : 0;
+                step = g.global_gain - ((sf[s] + pre) << (g.scalefac_scale + 1))
+                    - g.subblock_gain[Q.window[s]] * 8;
+            }
+            cached = prev_data_use && (Q.pn_step[s] == step);
+            m01 = use_prev && R.pn_sfb_count1 > 0 && s >= R.pn_sfb_count1 && Q.pn_step[s] > 0
+                && step >= Q.pn_step[s];
+            mode = cached ? 0 : (m01 ? 2 : 1);
+            Q.sfb_mode[s] = mode;
+            cand = !cached && (Q.start[s] + Q.width[s] > mnc);
+        }
+        {
+            uint64_t const m = lh_ballot(cand);
+            s_trunc = lh_ffs64(m);
+        }
+        if (s_trunc >= 0) {
+            j_trunc = Q.start[s_trunc];
+            l_trunc = mnc - j_trunc + 1;
+            if (l_trunc < 0)
+                l_trunc = 0;
+        }
+    }
+    LH_WAVE_SYNC();
+    {
+        float const compareval0 = (1.0f - 0.4054f) / istep;
+        for (int p = c.lane; p < 288; p += 64) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                int const i = 2 * p + h;
+                int const s = Q.sfb_of_line[i];
+                int     mode;
+                if (s > sfbmax)
+                    mode = 0;   /* lines above the last coded band are never touched by the loop */
+                else
+                    mode = Q.sfb_mode[s];
+                if (s_trunc >= 0) {
+                    if (s > s_trunc)
+                        mode = 0;
+                    if (s == s_trunc && !(i < j_trunc + l_trunc))
+                        mode = 0;
+                    if (i >= mnc && !(s == s_trunc && i < j_trunc + l_trunc))
+                        mode = 3;       /* zeroed by the reference's memset */
+                }
+                if (mode == 1)
+                    ix[i] = (int16_t) lh_quant_line(T, istep, xrpow[i]);
+                else if (mode == 2)
+                    ix[i] = (compareval0 > xrpow[i]) ? 0 : 1;
+                else if (mode == 3)
+                    ix[i] = 0;
+            }
+        }
+    }
+    LH_WAVE_SYNC();
+    if (R.substep_shaping & 2) {
+        int const gain = g.global_gain + g.scalefac_scale;
+        float const roundfac = (float) (0.634521682242439 / T->ipow20[gain]);
+        for (int i = c.lane; i < 576; i += 64) {
+            int const s = Q.sfb_of_line[i];
+            if (s < R.sfbmax && Q.pseudohalf[s])
+                ix[i] = (xrpow[i] >= roundfac) ? ix[i] : (int16_t) 0;
+        }
+        LH_WAVE_SYNC();
+    }
+    return lh_noquant_count_bits(c, Q, R, g, which, use_prev);
+}
+
+/* ---------------------------------------------------------------------- */
+/* reference takehiro.c:1135-1188 (MPEG-1) */
+LH_DEVFN int
+lh_scale_bitcount(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g, int which)
+{
+    int    *sf = Q.sf[which];
+    int     k, sfb, max_slen1 = 0, max_slen2 = 0;
+    const int *tabp;
+    LH_WAVE_SYNC();
+    if (R.block_type == LH_SHORT_TYPE)
+        tabp = lh_scale_short;
+    else {
+        tabp = lh_scale_long;
+        if (!g.preflag) {
+            for (sfb = 11; sfb < LH_SBPSY_L; sfb++)
+                if (sf[sfb] < lh_pretab[sfb])
+                    break;
+            if (sfb == LH_SBPSY_L) {
+                g.preflag = 1;
+                LH_WAVE_SYNC();
+                if (c.lane >= 11 && c.lane < LH_SBPSY_L)
+                    sf[c.lane] -= lh_pretab[c.lane];
+                LH_WAVE_SYNC();
+            }
+        }
+    }
+    for (sfb = 0; sfb < R.sfbdivide; sfb++)
+        if (max_slen1 < sf[sfb])
+            max_slen1 = sf[sfb];
+    for (; sfb < R.sfbmax; sfb++)
+        if (max_slen2 < sf[sfb])
+            max_slen2 = sf[sfb];
+    g.part2_length = LH_LARGE_BITS;
+    for (k = 0; k < 16; k++) {
+        if (max_slen1 < lh_slen1_n[k] && max_slen2 < lh_slen2_n[k] && g.part2_length > tabp[k]) {
+            g.part2_length = tabp[k];
+            g.scalefac_compress = k;
+        }
+    }
+    return g.part2_length == LH_LARGE_BITS;
+}
+
+/* reference quantize_pvt.c:554-573 */
+LH_DEVFN float
+lh_ath_adjust(const LhTables * T, float a, float x, float athFloor, float ATHfixpoint)
+{
+    float const o = 90.30873362f;
+    float const p = (ATHfixpoint < 1.f) ? 94.82444863f : ATHfixpoint;
+    float   u = (float) (lh_fast_log2(T->log_table, x) * (LH_LOG2_OVER_LOG10 * (10.0f)));
+    float const v = a * a;
+    float   w = 0.0f;
+    u -= athFloor;
+    if (v > 1E-20f)
+        w = (float) (1.f + lh_fast_log2(T->log_table, v) * (LH_LOG2_OVER_LOG10 * (10.0f / o)));
+    if (w < 0)
+        w = 0.f;
+    u *= w;
+    u += athFloor + o - p;
+    return lh_powf(10.f, 0.1f * u);
+}
+
+/* reference quantize_pvt.c:589-747: one lane per scalefactor band (window) */
+LH_DEVFN void
+lh_calc_xmin(const LhCtx & c, LhChanLds & Q, LhQR & R, const float *xr, const float *ren,
+             const float *rthm)
+{
+    const LhConfig *cfg = c.cfg;
+    const LhTables *T = c.T;
+    int const s = c.lane;
+    float const adj = c.st->ath_adjust_factor;
+    if (s < R.psymax) {
+        int const is_long = (s < R.psy_lmax);
+        int const sfb = is_long ? s : (R.sfb_smin + (s - R.psy_lmax) / 3);
+        int const b = is_long ? 0 : (s - R.psy_lmax) % 3;
+        float   en0 = 0.0f, xmin, ath, rh1, rh2, rh3, fact, e, t;
+        int const width = Q.width[s];
+        int     j = Q.start[s];
+        if (is_long) {
+            ath = lh_ath_adjust(T, adj, T->ath_l[sfb], T->ath_floor, cfg->ATHfixpoint);
+            fact = T->longfact[sfb];
+            e = ren[sfb];
+            t = rthm[sfb];
+        }
+        else {
+            ath = lh_ath_adjust(T, adj, T->ath_s[sfb], T->ath_floor, cfg->ATHfixpoint);
+            fact = T->shortfact[sfb];
+            e = ren[22 + sfb * 3 + b];
+            t = rthm[22 + sfb * 3 + b];
+        }
+        ath *= fact;
+        rh1 = ath / width;
+        rh2 = (float) 2.2204460492503131e-16;
+        for (int l = 0; l < width; ++l) {
+            float const xa = xr[j++];
+            float const x2 = xa * xa;
+            en0 += x2;
+            rh2 += (x2 < rh1) ? x2 : rh1;
+        }
+        if (en0 < ath)
+            rh3 = en0;
+        else if (rh2 < ath)
+            rh3 = ath;
+        else
+            rh3 = rh2;
+        xmin = rh3;
+        if (e > 1e-12f) {
+            float   x = en0 * t / e;
+            x *= fact;
+            if (xmin < x)
+                xmin = x;
+        }
+        xmin = (float) ((xmin > 2.2204460492503131e-16) ? xmin : 2.2204460492503131e-16);
+        Q.l3_xmin[s] = xmin;
+    }
+    {
+        /* highest non-zero coefficient */
+        unsigned top = 0;
+        int     max_nonzero;
+        for (int k = c.lane; k < 576; k += 64)
+            if (k > 0 && lh_fabsf(xr[k]) > 1e-12f)
+                top = (unsigned) k;
+        top = lh_wave_max_u32(top);
+        max_nonzero = (int) top;
+        if (R.block_type != LH_SHORT_TYPE)
+            max_nonzero |= 1;
+        else {
+            max_nonzero /= 6;
+            max_nonzero *= 6;
+            max_nonzero += 5;
+        }
+        if (cfg->sfb21_extra == 0 && cfg->samplerate < 44000) {
+            int     limit;
+            if (R.block_type != LH_SHORT_TYPE)
+                limit = T->sfb_l[21] - 1;
+            else
+                limit = 3 * T->sfb_s[12] - 1;
+            if (max_nonzero > limit)
+                max_nonzero = limit;
+        }
+        R.mnc = max_nonzero;
+    }
+    LH_WAVE_SYNC();
+    if (cfg->use_temporal_masking && s < R.psymax && s >= R.psy_lmax && ((s - R.psy_lmax) % 3) == 0) {
+        float   x0 = Q.l3_xmin[s], x1 = Q.l3_xmin[s + 1], x2 = Q.l3_xmin[s + 2];
+        if (x0 > x1)
+            x1 += (x0 - x1) * T->decay;
+        if (x1 > x2)
+            x2 += (x1 - x2) * T->decay;
+        Q.l3_xmin[s + 1] = x1;
+        Q.l3_xmin[s + 2] = x2;
+    }
+    LH_WAVE_SYNC();
+}
+
+/* reference quantize_pvt.c:750-913: one lane per band, wave-uniform aggregation */
+LH_DEVFN void
+lh_calc_noise(const LhCtx & c, LhChanLds & Q, LhQR & R, const LhGrR & g, int which,
+              const float *xr, LhNoiseRes & res, int use_prev)
+{
+    const LhTables *T = c.T;
+    const int16_t *ix = Q.ix[which];
+    const int *sf = Q.sf[which];
+    int const s = c.lane;
+    LH_WAVE_SYNC();
+    if (s < R.psymax) {
+        int const pre = (g.preflag && s < LH_SBMAX_L) ? lh_pretab[s] : 0;
+        int const st = g.global_gain - ((sf[s] + pre) << (g.scalefac_scale + 1))
+            - g.subblock_gain[Q.window[s]] * 8;
+        float const r_l3_xmin = 1.f / Q.l3_xmin[s];
+        float   distort_, noise;
+        if (use_prev && (Q.pn_step[s] == st)) {
+            distort_ = r_l3_xmin * Q.pn_noise[s];
+            noise = Q.pn_noise_log[s];
+        }
+        else {
+            float const step = T->pow20[st + LH_QMAX2];
+            int     l = Q.width[s] >> 1;
+            int     j = Q.start[s];
+            /* the reference's running line index lags behind the band start only after a
+             * band cut at max_nonzero_coeff, where the remaining length is 0 either way */
+            if ((j + Q.width[s]) > R.mnc) {
+                int const usefullsize = R.mnc - j + 1;
+                l = (usefullsize > 0) ? (usefullsize >> 1) : 0;
+            }
+            noise = 0;
+            if (j > g.count1) {
+                while (l--) {
+                    float   temp;
+                    temp = xr[j];
+                    j++;
+                    noise += temp * temp;
+                    temp = xr[j];
+                    j++;
+                    noise += temp * temp;
+                }
+            }
+            else if (j > g.big_values) {
+                while (l--) {
+                    float   temp;
+                    temp = lh_fabsf(xr[j]) - (ix[j] ? step : 0.0f);
+                    j++;
+                    noise += temp * temp;
+                    temp = lh_fabsf(xr[j]) - (ix[j] ? step : 0.0f);
+                    j++;
+                    noise += temp * temp;
+                }
+            }
+            else {
+                while (l--) {
+                    float   temp;
+                    temp = lh_fabsf(xr[j]) - T->pow43[ix[j]] * step;
+                    j++;
+                    noise += temp * temp;
+                    temp = lh_fabsf(xr[j]) - T->pow43[ix[j]] * step;
+                    j++;
+                    noise += temp * temp;
+                }
+            }
+            if (use_prev) {
+                Q.pn_step[s] = st;
+                Q.pn_noise[s] = noise;
+            }
+            distort_ = r_l3_xmin * noise;
+            noise = (float) (lh_fast_log2(T->log_table, (distort_ > 1E-20f) ? distort_ : 1E-20f)
+                             * LH_LOG2_OVER_LOG10);
+            if (use_prev)
+                Q.pn_noise_log[s] = noise;
+        }
+        Q.distort[s] = distort_;
+        Q.sfb_f[s] = noise;
+    }
+    if (use_prev)
+        R.pn_global_gain = g.global_gain;
+    LH_WAVE_SYNC();
+    {
+        int     over = 0, ssd = 0;
+        float   over_noise_db = 0, tot_noise_db = 0, max_noise = -20.0f;
+        for (int sfb = 0; sfb < R.psymax; sfb++) {
+            float const noise = Q.sfb_f[sfb];
+            tot_noise_db += noise;
+            if (noise > 0.0) {
+                int     tmp = (int) (noise * 10 + .5);
+                if (tmp < 1)
+                    tmp = 1;
+                ssd += tmp * tmp;
+                over++;
+                over_noise_db += noise;
+            }
+            max_noise = (max_noise > noise) ? max_noise : noise;
+        }
+        res.over_count = over;
+        res.tot_noise = tot_noise_db;
+        res.over_noise = over_noise_db;
+        res.max_noise = max_noise;
+        res.over_SSD = ssd;
+    }
+    LH_WAVE_SYNC();
+}
+
+/* ---------------------------------------------------------------------- */
+/* geometry of the granule + spectrum re-ordering for short blocks
+ * (reference quantize.c:226-346) */
+LH_DEVFN void
+lh_init_outer_loop(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, float *xr, int block_type,
+                   int substep)
+{
+    const LhTables *T = c.T;
+    int const sfb21 = c.cfg->sfb21_extra;
+    g.part2_3_length = 0;
+    g.big_values = 0;
+    g.count1 = 0;
+    g.global_gain = 210;
+    g.scalefac_compress = 0;
+    g.table_select[0] = g.table_select[1] = g.table_select[2] = 0;
+    g.subblock_gain[0] = g.subblock_gain[1] = g.subblock_gain[2] = g.subblock_gain[3] = 0;
+    g.region0_count = g.region1_count = 0;
+    g.preflag = 0;
+    g.scalefac_scale = 0;
+    g.count1table_select = 0;
+    g.part2_length = 0;
+    g.count1bits = 0;
+    g.xrpow_max = 0;
+    R.block_type = block_type;
+    R.sfb_lmax = LH_SBPSY_L;
+    R.sfb_smin = LH_SBPSY_S;
+    R.psy_lmax = sfb21 ? LH_SBMAX_L : LH_SBPSY_L;
+    R.psymax = R.psy_lmax;
+    R.sfbmax = R.sfb_lmax;
+    R.sfbdivide = 11;
+    if (block_type == LH_SHORT_TYPE) {
+        R.sfb_smin = 0;
+        R.sfb_lmax = 0;
+        R.psymax = 3 * ((sfb21 ? LH_SBMAX_S : LH_SBPSY_S));
+        R.sfbmax = 3 * LH_SBPSY_S;
+        R.sfbdivide = R.sfbmax - 18;
+        R.psy_lmax = 0;
+    }
+    R.mnc = 575;
+    R.pn_global_gain = 0;
+    R.pn_sfb_count1 = 0;
+    R.substep_shaping = substep;
+    LH_WAVE_SYNC();
+    if (c.lane <= LH_SFBMAX) {
+        int const s = c.lane;
+        Q.sf[0][s] = 0;
+        Q.sf[1][s] = 0;
+        if (s == LH_SFBMAX) {
+            Q.width[s] = 0;
+            Q.window[s] = 3;
+            Q.start[s] = 576;
+        }
+        else if (block_type == LH_SHORT_TYPE) {
+            int const sfb = s / 3, win = s - 3 * sfb;
+            int const wd = T->sfb_s[sfb + 1] - T->sfb_s[sfb];
+            Q.width[s] = wd;
+            Q.window[s] = win;
+            Q.start[s] = 3 * T->sfb_s[sfb] + win * wd;
+        }
+        else if (s < LH_SBMAX_L) {
+            Q.width[s] = T->sfb_l[s + 1] - T->sfb_l[s];
+            Q.window[s] = 3;
+            Q.start[s] = T->sfb_l[s];
+        }
+        else {
+            Q.width[s] = 0;
+            Q.window[s] = 3;
+            Q.start[s] = 576;
+        }
+    }
+    LH_WAVE_SYNC();
+    {
+        int const nb = (block_type == LH_SHORT_TYPE) ? 39 : 22;
+        for (int i = c.lane; i < 576; i += 64) {
+            int     s = 0;
+            for (int k = 1; k < nb; k++)
+                if (Q.start[k] <= i)
+                    s = k;
+            Q.sfb_of_line[i] = (uint8_t) s;
+        }
+    }
+    if (block_type == LH_SHORT_TYPE) {
+        /* window-major re-ordering inside each short band */
+        float  *tmp = Q.save_xrpow;
+        for (int i = c.lane; i < 576; i += 64)
+            tmp[i] = xr[i];
+        LH_WAVE_SYNC();
+        for (int d = c.lane; d < 576; d += 64) {
+            int     sfb = 0;
+            for (int k = 1; k < LH_SBMAX_S; k++)
+                if (3 * T->sfb_s[k] <= d)
+                    sfb = k;
+            {
+                int const wd = T->sfb_s[sfb + 1] - T->sfb_s[sfb];
+                int const r = d - 3 * T->sfb_s[sfb];
+                int const win = r / wd, l = T->sfb_s[sfb] + (r - win * wd);
+                xr[d] = tmp[3 * l + win];
+            }
+        }
+    }
+    LH_WAVE_SYNC();
+}
+
+/* reference quantize.c:72-144; returns 1 when there is energy to quantise */
+LH_DEVFN int
+lh_init_xrpow(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g, const float *xr)
+{
+    unsigned mxabs = 0, mxpow = 0;
+    int     nonzero;
+    for (int i = c.lane; i < 576; i += 64) {
+        float const tmp = lh_fabsf(xr[i]);
+        float const xp = (float) sqrt((double) tmp * sqrt((double) tmp));
+        unsigned const ub = lh_f32_as_u32(tmp), up = lh_f32_as_u32(xp);
+        Q.xrpow[i] = xp;
+        mxabs = ub > mxabs ? ub : mxabs;
+        mxpow = up > mxpow ? up : mxpow;
+    }
+    mxabs = lh_wave_max_u32(mxabs);
+    mxpow = lh_wave_max_u32(mxpow);
+    g.xrpow_max = lh_u32_as_f32(mxpow);
+    {
+        /* the reference sums |xr| serially and tests sum > 1e-20.  All terms are
+         * non-negative, so max <= sum <= 576*max*(1+2^-23)^576: only inside that
+         * band does the serial order matter, and there it is evaluated serially. */
+        float const mx = lh_u32_as_f32(mxabs);
+        if (mx > 1E-20f)
+            nonzero = 1;
+        else if (mx * 577.0f <= 1E-20f)
+            nonzero = 0;
+        else {
+            float   sum = 0;
+            LH_WAVE_SYNC();
+            for (int i = 0; i < 576; i++)
+                sum += lh_fabsf(xr[i]);
+            nonzero = sum > (float) 1E-20;
+        }
+    }
+    LH_WAVE_SYNC();
+    if (nonzero) {
+        int const j = (R.substep_shaping & 2) ? 1 : 0;
+        if (c.lane < R.psymax)
+            Q.pseudohalf[c.lane] = j;
+        LH_WAVE_SYNC();
+        return 1;
+    }
+    for (int i = c.lane; i < 576; i += 64)
+        Q.ix[0][i] = 0;
+    LH_WAVE_SYNC();
+    return 0;
+}
+
+/* reference quantize.c:367-429 */
+LH_DEVFN int
+lh_bin_search_StepSize(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, int desired_rate, int ch)
+{
+    int     nBits;
+    int     CurrentStep = c.st->CurrentStep[ch];
+    int     flag_GoneOver = 0;
+    int const start = c.st->OldValue[ch];
+    int     Direction = 0;
+    g.global_gain = start;
+    desired_rate -= g.part2_length;
+    for (;;) {
+        int     step;
+        nBits = lh_count_bits(c, Q, R, g, 0, 0);
+        if (CurrentStep == 1 || nBits == desired_rate)
+            break;
+        if (nBits > desired_rate) {
+            if (Direction == 2)
+                flag_GoneOver = 1;
+            if (flag_GoneOver)
+                CurrentStep /= 2;
+            Direction = 1;
+            step = CurrentStep;
+        }
+        else {
+            if (Direction == 1)
+                flag_GoneOver = 1;
+            if (flag_GoneOver)
+                CurrentStep /= 2;
+            Direction = 2;
+            step = -CurrentStep;
+        }
+        g.global_gain += step;
+        if (g.global_gain < 0) {
+            g.global_gain = 0;
+            flag_GoneOver = 1;
+        }
+        if (g.global_gain > 255) {
+            g.global_gain = 255;
+            flag_GoneOver = 1;
+        }
+    }
+    while (nBits > desired_rate && g.global_gain < 255) {
+        g.global_gain++;
+        nBits = lh_count_bits(c, Q, R, g, 0, 0);
+    }
+    LH_WAVE_SYNC();
+    if (c.lane == 0) {
+        c.st->CurrentStep[ch] = (start - g.global_gain >= 4) ? 4 : 2;
+        c.st->OldValue[ch] = g.global_gain;
+    }
+    LH_WAVE_SYNC();
+    g.part2_3_length = nBits;
+    return nBits;
+}
+
+/* reference quantize.c:540-551 */
+LH_DEVFN int
+lh_loop_break(const LhChanLds & Q, const LhQR & R, const LhGrR & g, int which)
+{
+    for (int sfb = 0; sfb < R.sfbmax; sfb++)
+        if (Q.sf[which][sfb] + g.subblock_gain[Q.window[sfb]] == 0)
+            return 0;
+    return 1;
+}
+
+/* reference quantize.c:585-686 (comparator 9, the only one the presets of this path select) */
+LH_DEVFN int
+lh_quant_compare(const LhNoiseRes & best, const LhNoiseRes & calc)
+{
+    int     better;
+    if (best.over_count > 0) {
+        better = calc.over_SSD <= best.over_SSD;
+        if (calc.over_SSD == best.over_SSD)
+            better = calc.bits < best.bits;
+    }
+    else {
+        better = ((calc.max_noise < 0) &&
+                  ((calc.max_noise * 10 + calc.bits) <= (best.max_noise * 10 + best.bits)));
+    }
+    if (best.over_count == 0)
+        better = better && calc.bits < best.bits;
+    return better;
+}
+
+/* multiply the xrpow lines of the flagged bands (Q.sfb_mode[s] != 0, set by lane s)
+ * by their factor Q.sfb_f[s] and refresh xrpow_max; lanes over lines */
+LH_DEVFN void
+lh_scale_bands(const LhCtx & c, LhChanLds & Q, LhGrR & g)
+{
+    unsigned mx = lh_f32_as_u32(g.xrpow_max);
+    LH_WAVE_SYNC();
+    for (int i = c.lane; i < 576; i += 64) {
+        int const s = Q.sfb_of_line[i];
+        if (Q.sfb_mode[s]) {
+            float const v = Q.xrpow[i] * Q.sfb_f[s];
+            unsigned const u = lh_f32_as_u32(v);
+            Q.xrpow[i] = v;
+            mx = u > mx ? u : mx;
+        }
+    }
+    mx = lh_wave_max_u32(mx);
+    g.xrpow_max = lh_u32_as_f32(mx);
+    LH_WAVE_SYNC();
+}
+
+/* reference quantize.c:720-796 */
+LH_DEVFN void
+lh_amp_scalefac_bands(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g, int which,
+                      int bRefine)
+{
+    const LhConfig *cfg = c.cfg;
+    float   ifqstep34, trigger;
+    int     noise_shaping_amp;
+    int     last_visited, ret_before = 0;
+    LH_WAVE_SYNC();
+    if (g.scalefac_scale == 0)
+        ifqstep34 = (float) 1.29683955465100964055;
+    else
+        ifqstep34 = (float) 1.68179283050742922612;
+    trigger = 0;
+    for (int sfb = 0; sfb < R.sfbmax; sfb++)
+        if (trigger < Q.distort[sfb])
+            trigger = Q.distort[sfb];
+    noise_shaping_amp = cfg->noise_shaping_amp;
+    if (noise_shaping_amp == 3)
+        noise_shaping_amp = (bRefine == 1) ? 2 : 1;
+    switch (noise_shaping_amp) {
+    case 2:
+        break;
+    case 1:
+        if (trigger > 1.0)
+            trigger = (float) sqrt((double) trigger);   /* == (float) pow(trigger, .5), see DESIGN.md */
+        else
+            trigger = (float) (trigger * .95);
+        break;
+    case 0:
+    default:
+        if (trigger > 1.0)
+            trigger = 1.0;
+        else
+            trigger = (float) (trigger * .95);
+        break;
+    }
+    /* replay the reference's serial walk (with its early returns) on read-only data */
+    last_visited = R.sfbmax - 1;
+    for (int sfb = 0; sfb < R.sfbmax; sfb++) {
+        if (Q.distort[sfb] < trigger)
+            continue;
+        if (R.substep_shaping & 2) {
+            int const ph = !Q.pseudohalf[sfb];
+            if (!ph && cfg->noise_shaping_amp == 2) {
+                last_visited = sfb;
+                ret_before = 1;
+                break;
+            }
+        }
+        if (cfg->noise_shaping_amp == 2) {
+            last_visited = sfb;
+            break;
+        }
+    }
+    LH_WAVE_SYNC();
+    if (c.lane <= LH_SFBMAX) {
+        int const s = c.lane;
+        int     amplify = 0;
+        if (s < R.sfbmax && s <= last_visited && !(Q.distort[s] < trigger)) {
+            amplify = 1;
+            if (R.substep_shaping & 2)
+                Q.pseudohalf[s] = !Q.pseudohalf[s];
+            if (ret_before && s == last_visited)
+                amplify = 0;
+            if (amplify)
+                Q.sf[which][s]++;
+        }
+        Q.sfb_mode[s] = amplify;
+        Q.sfb_f[s] = ifqstep34;
+    }
+    lh_scale_bands(c, Q, g);
+}
+
+/* reference quantize.c:808-833 */
+LH_DEVFN void
+lh_inc_scalefac_scale(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g, int which)
+{
+    float const ifqstep34 = (float) 1.29683955465100964055;
+    LH_WAVE_SYNC();
+    if (c.lane <= LH_SFBMAX) {
+        int const sfb = c.lane;
+        int     amp = 0;
+        if (sfb < R.sfbmax) {
+            int     s = Q.sf[which][sfb];
+            if (g.preflag)
+                s += lh_pretab[sfb];
+            if (s & 1) {
+                s++;
+                amp = 1;
+            }
+            Q.sf[which][sfb] = s >> 1;
+        }
+        Q.sfb_mode[sfb] = amp;
+        Q.sfb_f[sfb] = ifqstep34;
+    }
+    g.preflag = 0;
+    g.scalefac_scale = 1;
+    lh_scale_bands(c, Q, g);
+}
+
+/* reference quantize.c:847-921 */
+LH_DEVFN int
+lh_inc_subblock_gain(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g, int which)
+{
+    const LhTables *T = c.T;
+    int    *sf = Q.sf[which];
+    int     sfb, window;
+    LH_WAVE_SYNC();
+    for (sfb = 0; sfb < R.sfb_lmax; sfb++)
+        if (sf[sfb] >= 16)
+            return 1;
+    for (window = 0; window < 3; window++) {
+        int     s1 = 0, s2 = 0, top;
+        for (sfb = R.sfb_lmax + window; sfb < R.sfbdivide; sfb += 3)
+            if (s1 < sf[sfb])
+                s1 = sf[sfb];
+        for (; sfb < R.sfbmax; sfb += 3)
+            if (s2 < sf[sfb])
+                s2 = sf[sfb];
+        top = sfb;              /* the band above the last scalefactor band, for this window */
+        if (s1 < 16 && s2 < 8)
+            continue;
+        if (g.subblock_gain[window] >= 7)
+            return 1;
+        g.subblock_gain[window]++;
+        LH_WAVE_SYNC();
+        if (c.lane <= LH_SFBMAX) {
+            int const k = c.lane;
+            int     mode = 0;
+            float   f = 1.0f;
+            if (k >= R.sfb_lmax + window && k < R.sfbmax && ((k - R.sfb_lmax - window) % 3) == 0) {
+                int     s = sf[k];
+                s = s - (4 >> g.scalefac_scale);
+                if (s >= 0)
+                    sf[k] = s;
+                else {
+                    int const gain = 210 + (s << (g.scalefac_scale + 1));
+                    sf[k] = 0;
+                    mode = 1;
+                    f = T->ipow20[gain];
+                }
+            }
+            else if (k == top) {
+                mode = 1;
+                f = T->ipow20[202];
+            }
+            Q.sfb_mode[k] = mode;
+            Q.sfb_f[k] = f;
+        }
+        lh_scale_bands(c, Q, g);
+    }
+    return 0;
+}
+
+/* reference quantize.c:940-988 */
+LH_DEVFN int
+lh_balance_noise(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g, int which, int bRefine)
+{
+    const LhConfig *cfg = c.cfg;
+    int     status;
+    lh_amp_scalefac_bands(c, Q, R, g, which, bRefine);
+    status = lh_loop_break(Q, R, g, which);
+    if (status)
+        return 0;
+    status = lh_scale_bitcount(c, Q, R, g, which);
+    if (!status)
+        return 1;
+    if (cfg->noise_shaping > 1) {
+        LH_WAVE_SYNC();
+        if (c.lane <= LH_SFBMAX)
+            Q.pseudohalf[c.lane] = 0;
+        LH_WAVE_SYNC();
+        if (!g.scalefac_scale) {
+            lh_inc_scalefac_scale(c, Q, R, g, which);
+            status = 0;
+        }
+        else {
+            if (R.block_type == LH_SHORT_TYPE && cfg->subblock_gain > 0)
+                status = lh_inc_subblock_gain(c, Q, R, g, which) || lh_loop_break(Q, R, g, which);
+        }
+    }
+    if (!status)
+        status = lh_scale_bitcount(c, Q, R, g, which);
+    return !status;
+}
+
+/* copy quantised image + scalefactors between the best (0) and working (1) slots;
+ * the register part is copied by the caller */
+LH_DEVFN void
+lh_copy_gr(const LhCtx & c, LhChanLds & Q, int dst, int src)
+{
+    LH_WAVE_SYNC();
+    for (int i = c.lane; i < 288; i += 64)
+        ((uint32_t *) Q.ix[dst])[i] = ((const uint32_t *) Q.ix[src])[i];
+    if (c.lane <= LH_SFBMAX)
+        Q.sf[dst][c.lane] = Q.sf[src][c.lane];
+    LH_WAVE_SYNC();
+}
+
+/* reference quantize.c:1010-1197; gb = cod_info (image 0), returns over_count */
+LH_DEVFN int
+lh_outer_loop(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & gb, const float *xr, int ch,
+              int targ_bits)
+{
+    const LhConfig *cfg = c.cfg;
+    LhGrR   gw;
+    LhNoiseRes best_noise_info;
+    int     huff_bits, better, age;
+    int     best_part2_3_length = 9999999;
+    int     bEndOfSearch = 0, bRefine = 0, best_ggain_pass1 = 0;
+
+    (void) lh_bin_search_StepSize(c, Q, R, gb, targ_bits, ch);
+    if (!cfg->noise_shaping)
+        return 100;
+    LH_WAVE_SYNC();
+    if (c.lane <= LH_SFBMAX) {
+        Q.pn_step[c.lane] = 0;
+        Q.pn_noise[c.lane] = 0;
+        Q.pn_noise_log[c.lane] = 0;
+    }
+    R.pn_global_gain = 0;
+    R.pn_sfb_count1 = 0;
+    LH_WAVE_SYNC();
+    lh_calc_noise(c, Q, R, gb, 0, xr, best_noise_info, 1);
+    best_noise_info.bits = gb.part2_3_length;
+    lh_copy_gr(c, Q, 1, 0);
+    gw = gb;
+    age = 0;
+    for (int i = c.lane; i < 576; i += 64)
+        Q.save_xrpow[i] = Q.xrpow[i];
+    LH_WAVE_SYNC();
+
+    while (!bEndOfSearch) {
+        do {
+            LhNoiseRes noise_info;
+            int     search_limit;
+            int     maxggain = 255;
+            if (R.substep_shaping & 2)
+                search_limit = 20;
+            else
+                search_limit = 3;
+            if (cfg->sfb21_extra) {
+                if (Q.distort[R.sfbmax] > 1.0)
+                    break;
+                if (R.block_type == LH_SHORT_TYPE
+                    && (Q.distort[R.sfbmax + 1] > 1.0 || Q.distort[R.sfbmax + 2] > 1.0))
+                    break;
+            }
+            if (lh_balance_noise(c, Q, R, gw, 1, bRefine) == 0)
+                break;
+            if (gw.scalefac_scale)
+                maxggain = 254;
+            huff_bits = targ_bits - gw.part2_length;
+            if (huff_bits <= 0)
+                break;
+            while ((gw.part2_3_length = lh_count_bits(c, Q, R, gw, 1, 1)) > huff_bits
+                   && gw.global_gain <= maxggain)
+                gw.global_gain++;
+            if (gw.global_gain > maxggain)
+                break;
+            if (best_noise_info.over_count == 0) {
+                while ((gw.part2_3_length = lh_count_bits(c, Q, R, gw, 1, 1)) > best_part2_3_length
+                       && gw.global_gain <= maxggain)
+                    gw.global_gain++;
+                if (gw.global_gain > maxggain)
+                    break;
+            }
+            lh_calc_noise(c, Q, R, gw, 1, xr, noise_info, 1);
+            noise_info.bits = gw.part2_3_length;
+            better = lh_quant_compare(best_noise_info, noise_info);
+            if (better) {
+                best_part2_3_length = gb.part2_3_length;
+                best_noise_info = noise_info;
+                lh_copy_gr(c, Q, 0, 1);
+                gb = gw;
+                age = 0;
+                for (int i = c.lane; i < 576; i += 64)
+                    Q.save_xrpow[i] = Q.xrpow[i];
+                LH_WAVE_SYNC();
+            }
+            else {
+                if (cfg->full_outer_loop == 0) {
+                    if (++age > search_limit && best_noise_info.over_count == 0)
+                        break;
+                    if ((cfg->noise_shaping_amp == 3) && bRefine && age > 30)
+                        break;
+                    if ((cfg->noise_shaping_amp == 3) && bRefine &&
+                        (gw.global_gain - best_ggain_pass1) > 15)
+                        break;
+                }
+            }
+        }
+        while ((gw.global_gain + gw.scalefac_scale) < 255);
+
+        if (cfg->noise_shaping_amp == 3) {
+            if (!bRefine) {
+                lh_copy_gr(c, Q, 1, 0);
+                gw = gb;
+                for (int i = c.lane; i < 576; i += 64)
+                    Q.xrpow[i] = Q.save_xrpow[i];
+                LH_WAVE_SYNC();
+                age = 0;
+                best_ggain_pass1 = gw.global_gain;
+                bRefine = 1;
+            }
+            else
+                bEndOfSearch = 1;
+        }
+        else
+            bEndOfSearch = 1;
+    }
+    return best_noise_info.over_count;
+}
+
+/* ---------------------------------------------------------------------- */
+/* reference takehiro.c:964-1094; gr0's final scalefactors come from the output slot
+ * g0sf (int8, -1 = shared).  scfsi_out[4] is written by lane 0. */
+LH_DEVFN void
+lh_best_scalefac_store(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g, int gr,
+                       const int8_t * g0sf, int g0_block_type, int *scfsi_out)
+{
+    int    *sf = Q.sf[0];
+    const int16_t *ix = Q.ix[0];
+    int     sfb, i;
+    int     recalc = 0;
+    int     scfsi[4] = { 0, 0, 0, 0 };
+    /* bands whose lines are all zero get the wildcard -2 */
+    LH_WAVE_SYNC();
+    if (c.lane < R.sfbmax) {
+        int     any = 0;
+        int const j0 = Q.start[c.lane], j1 = j0 + Q.width[c.lane];
+        for (int l = j0; l < j1; ++l)
+            if (ix[l] != 0) {
+                any = 1;
+                break;
+            }
+        if (!any)
+            sf[c.lane] = -2;
+    }
+    LH_WAVE_SYNC();
+    for (sfb = 0; sfb < R.sfbmax; sfb++)
+        if (sf[sfb] == -2)
+            recalc = -2;
+    if (!g.scalefac_scale && !g.preflag) {
+        int     s = 0;
+        for (sfb = 0; sfb < R.sfbmax; sfb++)
+            if (sf[sfb] > 0)
+                s |= sf[sfb];
+        if (!(s & 1) && s != 0) {
+            LH_WAVE_SYNC();
+            if (c.lane < R.sfbmax && sf[c.lane] > 0)
+                sf[c.lane] >>= 1;
+            LH_WAVE_SYNC();
+            g.scalefac_scale = recalc = 1;
+        }
+    }
+    if (!g.preflag && R.block_type != LH_SHORT_TYPE) {
+        for (sfb = 11; sfb < LH_SBPSY_L; sfb++)
+            if (sf[sfb] < lh_pretab[sfb] && sf[sfb] != -2)
+                break;
+        if (sfb == LH_SBPSY_L) {
+            LH_WAVE_SYNC();
+            if (c.lane >= 11 && c.lane < LH_SBPSY_L && sf[c.lane] > 0)
+                sf[c.lane] -= lh_pretab[c.lane];
+            LH_WAVE_SYNC();
+            g.preflag = recalc = 1;
+        }
+    }
+    if (gr == 1 && g0_block_type != LH_SHORT_TYPE && R.block_type != LH_SHORT_TYPE) {
+        /* scfsi_calc */
+        int     s1, s2, c1, c2;
+        for (i = 0; i < 4; i++) {
+            for (sfb = lh_scfsi_band[i]; sfb < lh_scfsi_band[i + 1]; sfb++)
+                if (g0sf[sfb] != sf[sfb] && sf[sfb] >= 0)
+                    break;
+            if (sfb == lh_scfsi_band[i + 1])
+                scfsi[i] = 1;
+        }
+        LH_WAVE_SYNC();
+        if (c.lane < LH_SBPSY_L) {
+            int     grp = 0;
+            for (i = 1; i < 4; i++)
+                if (c.lane >= lh_scfsi_band[i])
+                    grp = i;
+            if (scfsi[grp])
+                sf[c.lane] = -1;
+        }
+        LH_WAVE_SYNC();
+        s1 = c1 = 0;
+        for (sfb = 0; sfb < 11; sfb++) {
+            if (sf[sfb] == -1)
+                continue;
+            c1++;
+            if (s1 < sf[sfb])
+                s1 = sf[sfb];
+        }
+        s2 = c2 = 0;
+        for (; sfb < LH_SBPSY_L; sfb++) {
+            if (sf[sfb] == -1)
+                continue;
+            c2++;
+            if (s2 < sf[sfb])
+                s2 = sf[sfb];
+        }
+        for (i = 0; i < 16; i++) {
+            if (s1 < lh_slen1_n[i] && s2 < lh_slen2_n[i]) {
+                int const cc = lh_slen1_tab[i] * c1 + lh_slen2_tab[i] * c2;
+                if (g.part2_length > cc) {
+                    g.part2_length = cc;
+                    g.scalefac_compress = i;
+                }
+            }
+        }
+        recalc = 0;
+    }
+    LH_WAVE_SYNC();
+    if (c.lane < R.sfbmax && sf[c.lane] == -2)
+        sf[c.lane] = 0;
+    LH_WAVE_SYNC();
+    if (recalc)
+        (void) lh_scale_bitcount(c, Q, R, g, 0);
+    if (c.lane == 0)
+        for (i = 0; i < 4; i++)
+            scfsi_out[i] = scfsi[i];
+}
+
+/* reference takehiro.c:809-957.  The reference evaluates up to 16 + 128 region
+ * splits with serial choose_table calls; here every candidate split is costed
+ * by its own lane (serial scan of its region in LDS), then the reference's
+ * first-minimum selection is replayed wave-uniformly. */
+LH_DEVFN void
+lh_best_huffman_divide(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g)
+{
+    const LhTables *T = c.T;
+    const int16_t *ix = Q.ix[0];
+    int    *r01_bits = Q.scr[0];        /* [23] */
+    int    *r01_div = Q.scr[1];         /* [23] */
+    int    *r0_tbl = Q.scr[2];          /* [23] */
+    int    *r1_tbl = Q.scr[3];          /* [23] */
+    int const bigv0 = g.big_values;
+    int const count1bits0 = g.count1bits;
+    int     i, a1, a2;
+
+    LH_WAVE_SYNC();
+    if (R.block_type == LH_NORM_TYPE) {
+        /* recalc_divide_init: lanes 0..15 cost region 0 for r0 = lane; then each of the
+         * 128 (r0, r1) pairs costs region 1; results go through LDS (save_xrpow is dead) */
+        int    *r0bits_a = (int *) Q.save_xrpow;      /* [16] */
+        int    *r0t_a = r0bits_a + 16;                /* [16] */
+        int    *comb_bits = r0bits_a + 32;            /* [128] */
+        int    *comb_tbl = comb_bits + 128;           /* [128] */
+        if (c.lane < 16) {
+            int const r0 = c.lane;
+            int const e1 = T->sfb_l[r0 + 1];
+            int     b = 0, t = 0;
+            if (e1 < bigv0)
+                t = lh_choose_table_lane(ix, 0, e1, &b);
+            r0bits_a[r0] = b;
+            r0t_a[r0] = t;
+        }
+        LH_WAVE_SYNC();
+        for (int cmb = c.lane; cmb < 128; cmb += 64) {
+            int const r0 = cmb >> 3, r1 = cmb & 7;
+            int const e1 = T->sfb_l[r0 + 1];
+            int const e2 = T->sfb_l[r0 + r1 + 2];
+            int     b = LH_LARGE_BITS, t = 0;
+            if (e1 < bigv0 && e2 < bigv0) {
+                b = r0bits_a[r0];
+                t = lh_choose_table_lane(ix, e1, e2, &b);
+            }
+            comb_bits[cmb] = b;
+            comb_tbl[cmb] = t;
+        }
+        LH_WAVE_SYNC();
+        if (c.lane < 23) {
+            /* first minimum in (r0 ascending, r1 ascending) order for r0 + r1 = lane */
+            int const sidx = c.lane;
+            int     bestb = LH_LARGE_BITS, bd = 0, bt0 = 0, bt1 = 0;
+            for (int r0 = 0; r0 < 16; r0++) {
+                int const r1 = sidx - r0;
+                /* the reference's loops stop at the first boundary >= bigv */
+                if (T->sfb_l[r0 + 1] >= bigv0)
+                    break;
+                if (r1 < 0 || r1 > 7)
+                    continue;
+                if (T->sfb_l[r0 + r1 + 2] >= bigv0)
+                    continue;
+                if (bestb > comb_bits[r0 * 8 + r1]) {
+                    bestb = comb_bits[r0 * 8 + r1];
+                    bd = r0;
+                    bt0 = r0t_a[r0];
+                    bt1 = comb_tbl[r0 * 8 + r1];
+                }
+            }
+            r01_bits[sidx] = bestb;
+            r01_div[sidx] = bd;
+            r0_tbl[sidx] = bt0;
+            r1_tbl[sidx] = bt1;
+        }
+        LH_WAVE_SYNC();
+    }
+    /* recalc_divide_sub against (bigv, count1bits): first with the original counts,
+     * then (maybe) with one more quadruple moved into the count1 region */
+    for (int pass = 0; pass < 2; pass++) {
+        int     bigv, c1bits, c1, c1sel;
+        if (pass == 0) {
+            if (R.block_type != LH_NORM_TYPE)
+                continue;
+            bigv = bigv0;
+            c1bits = count1bits0;
+            c1 = g.count1;
+            c1sel = g.count1table_select;
+        }
+        else {
+            i = bigv0;
+            if (i == 0 || (unsigned) (ix[i - 2] | ix[i - 1]) > 1)
+                return;
+            i = g.count1 + 2;
+            if (i > 576)
+                return;
+            c1 = i;
+            a1 = a2 = 0;
+            for (; i > g.big_values; i -= 4) {
+                int const p = ((ix[i - 4] * 2 + ix[i - 3]) * 2 + ix[i - 2]) * 2 + ix[i - 1];
+                a1 += lh_t32l[p];
+                a2 += lh_t33l[p];
+            }
+            bigv = i;
+            c1sel = 0;
+            if (a1 > a2) {
+                a1 = a2;
+                c1sel = 1;
+            }
+            c1bits = a1;
+            if (R.block_type != LH_NORM_TYPE) {
+                /* start / stop / short blocks: two fixed regions */
+                int     v[5][2];
+                int     p23 = a1, t0 = g.table_select[0], t1 = g.table_select[1];
+#pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    int const p = c.lane + 64 * k;
+                    v[k][0] = (p < 288) ? ix[2 * p] : 0;
+                    v[k][1] = (p < 288) ? ix[2 * p + 1] : 0;
+                }
+                a1 = T->sfb_l[7 + 1];
+                if (a1 > i)
+                    a1 = i;
+                if (a1 > 0)
+                    t0 = lh_choose_table_wave(c, v, 0, a1, &p23);
+                if (i > a1)
+                    t1 = lh_choose_table_wave(c, v, a1, i, &p23);
+                if (g.part2_3_length > p23) {
+                    g.part2_3_length = p23;
+                    g.count1 = c1;
+                    g.big_values = bigv;
+                    g.count1table_select = c1sel;
+                    g.count1bits = c1bits;
+                    g.table_select[0] = t0;
+                    g.table_select[1] = t1;
+                }
+                return;
+            }
+        }
+        {
+            /* lane r2 costs region 2 = [sfb_l[r2], bigv) */
+            int    *r2bits = (int *) Q.save_xrpow + 320;      /* [23] */
+            int    *r2tbl = r2bits + 32;                      /* [23] */
+            LH_WAVE_SYNC();
+            if (c.lane >= 2 && c.lane < LH_SBMAX_L + 1) {
+                int const r2 = c.lane;
+                int const e2 = T->sfb_l[r2];
+                int     b = 0, t = 0;
+                if (e2 < bigv) {
+                    b = r01_bits[r2 - 2] + c1bits;
+                    if (r01_bits[r2 - 2] < LH_LARGE_BITS)
+                        t = lh_choose_table_lane(ix, e2, bigv, &b);
+                }
+                r2bits[r2] = b;
+                r2tbl[r2] = t;
+            }
+            LH_WAVE_SYNC();
+            for (int r2 = 2; r2 < LH_SBMAX_L + 1; r2++) {
+                int const e2 = T->sfb_l[r2];
+                int     bits;
+                if (e2 >= bigv)
+                    break;
+                bits = r01_bits[r2 - 2] + c1bits;
+                if (g.part2_3_length <= bits)
+                    break;
+                bits = r2bits[r2];
+                if (g.part2_3_length <= bits)
+                    continue;
+                g.part2_3_length = bits;
+                g.big_values = bigv;
+                g.count1 = c1;
+                g.count1bits = c1bits;
+                g.count1table_select = c1sel;
+                g.region0_count = r01_div[r2 - 2];
+                g.region1_count = r2 - 2 - r01_div[r2 - 2];
+                g.table_select[0] = r0_tbl[r2 - 2];
+                g.table_select[1] = r1_tbl[r2 - 2];
+                g.table_select[2] = r2tbl[r2];
+            }
+            LH_WAVE_SYNC();
+        }
+    }
+}
+
+/* ---------------------------------------------------------------------- */
+/* reservoir + bit allocation, wave-uniform integer arithmetic               */
+/* (reference reservoir.c:82-293, quantize_pvt.c:428-545, bitstream.c:60-88) */
+LH_DEVFN int
+lh_frame_bits(const LhConfig * cfg, int bitrate_index, int padding)
+{
+    int const bit_rate = lh_bitrate_mpeg1[bitrate_index];
+    return 8 * ((cfg->version + 1) * 72000 * bit_rate / cfg->samplerate + padding);
+}
+
+LH_DEVFN void
+lh_resv_max_bits(const LhConfig * cfg, int ResvSize, int ResvMax0, int *substep, int mean_bits,
+                 int *targ_bits, int *extra_bits, int cbr)
+{
+    int     add_bits, targBits, extraBits;
+    int     ResvMax = ResvMax0;
+    if (cbr)
+        ResvSize += mean_bits;
+    if (*substep & 1)
+        ResvMax = (int) (ResvMax * 0.9);
+    targBits = mean_bits;
+    if (ResvSize * 10 > ResvMax * 9) {
+        add_bits = ResvSize - (ResvMax * 9) / 10;
+        targBits += add_bits;
+        *substep |= 0x80;
+    }
+    else {
+        add_bits = 0;
+        *substep &= 0x7f;
+        if (!cfg->disable_reservoir && !(*substep & 1))
+            targBits = (int) (targBits - .1 * mean_bits);
+    }
+    extraBits = (ResvSize < (ResvMax0 * 6) / 10 ? ResvSize : (ResvMax0 * 6) / 10);
+    extraBits -= add_bits;
+    if (extraBits < 0)
+        extraBits = 0;
+    *targ_bits = targBits;
+    *extra_bits = extraBits;
+}
+
+LH_DEVFN int
+lh_on_pe(const LhConfig * cfg, int ResvSize, int ResvMax, int *substep, const float pe[2],
+         int targ_bits[2], int mean_bits, int cbr)
+{
+    int     extra_bits = 0, tbits, bits;
+    int     add_bits[2] = { 0, 0 };
+    int     max_bits, ch;
+    lh_resv_max_bits(cfg, ResvSize, ResvMax, substep, mean_bits, &tbits, &extra_bits, cbr);
+    max_bits = tbits + extra_bits;
+    if (max_bits > LH_MAX_BITS_PER_GRANULE)
+        max_bits = LH_MAX_BITS_PER_GRANULE;
+    for (bits = 0, ch = 0; ch < 2; ++ch) {
+        targ_bits[ch] = (LH_MAX_BITS_PER_CHANNEL < tbits / 2) ? LH_MAX_BITS_PER_CHANNEL : tbits / 2;
+        add_bits[ch] = (int) (targ_bits[ch] * pe[ch] / 700.0 - targ_bits[ch]);
+        if (add_bits[ch] > mean_bits * 3 / 4)
+            add_bits[ch] = mean_bits * 3 / 4;
+        if (add_bits[ch] < 0)
+            add_bits[ch] = 0;
+        if (add_bits[ch] + targ_bits[ch] > LH_MAX_BITS_PER_CHANNEL) {
+            int const v = LH_MAX_BITS_PER_CHANNEL - targ_bits[ch];
+            add_bits[ch] = (0 > v) ? 0 : v;
+        }
+        bits += add_bits[ch];
+    }
+    if (bits > extra_bits && bits > 0)
+        for (ch = 0; ch < 2; ++ch)
+            add_bits[ch] = extra_bits * add_bits[ch] / bits;
+    for (ch = 0; ch < 2; ++ch) {
+        targ_bits[ch] += add_bits[ch];
+        extra_bits -= add_bits[ch];
+    }
+    for (bits = 0, ch = 0; ch < 2; ++ch)
+        bits += targ_bits[ch];
+    if (bits > LH_MAX_BITS_PER_GRANULE) {
+        for (ch = 0; ch < 2; ++ch) {
+            targ_bits[ch] *= LH_MAX_BITS_PER_GRANULE;
+            targ_bits[ch] /= bits;
+        }
+    }
+    return max_bits;
+}
+
+LH_DEVFN void
+lh_reduce_side(int targ_bits[2], float ms_ener_ratio, int mean_bits, int max_bits)
+{
+    int     move_bits;
+    float   fac;
+    fac = (float) (.33 * (.5 - ms_ener_ratio) / .5);
+    if (fac < 0)
+        fac = 0;
+    if (fac > .5)
+        fac = .5;
+    move_bits = (int) (fac * .5 * (targ_bits[0] + targ_bits[1]));
+    if (move_bits > LH_MAX_BITS_PER_CHANNEL - targ_bits[0])
+        move_bits = LH_MAX_BITS_PER_CHANNEL - targ_bits[0];
+    if (move_bits < 0)
+        move_bits = 0;
+    if (targ_bits[1] >= 125) {
+        if (targ_bits[1] - move_bits > 125) {
+            if (targ_bits[0] < mean_bits)
+                targ_bits[0] += move_bits;
+            targ_bits[1] -= move_bits;
+        }
+        else {
+            targ_bits[0] += targ_bits[1] - 125;
+            targ_bits[1] = 125;
+        }
+    }
+    move_bits = targ_bits[0] + targ_bits[1];
+    if (move_bits > max_bits) {
+        targ_bits[0] = (max_bits * targ_bits[0]) / move_bits;
+        targ_bits[1] = (max_bits * targ_bits[1]) / move_bits;
+    }
+}
+
+#endif

@@ -1,0 +1,66 @@
+/*
+ * lh_device.h -- layouts shared between the host C++ layer and the HIP kernels:
+ * the per-stream carried state that lives in HBM between launches
+ * (SURVEY.md 8(a) "carried state"; reference util.h:219-338) and the launch
+ * descriptors.
+ */
+#ifndef LH_DEVICE_H
+#define LH_DEVICE_H
+
+#include "lamehip_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LH_XMIN_N 61            /* 22 long + 13*3 short values of III_psy_xmin */
+
+typedef struct LhStreamState {
+    /* psycho-acoustic model (PsyStateVar_t) */
+    float   nb_l1[4][LH_CBANDS];
+    float   nb_l2[4][LH_CBANDS];
+    float   en[4][LH_XMIN_N + 3];       /* l[22] then s[13][3]; padded to 64 */
+    float   thm[4][LH_XMIN_N + 3];
+    float   loudness_sq_save[2];
+    float   tot_ener[4];
+    float   last_en_subshort[4][9];
+    int     last_attacks[4];
+    int     blocktype_old[2];
+    /* ATH auto adjustment */
+    float   ath_adjust_factor;
+    float   ath_adjust_limit;
+    /* polyphase overlap: sub-band samples of the granule preceding the next frame */
+    float   sb_prev[2][18 * 32];
+    /* frame driver / reservoir / quantiser (EncStateVar_t, QntStateVar_t) */
+    float   pefirbuf[19];
+    int     slot_lag;
+    int     ResvSize;
+    int     ResvMax;
+    int     main_data_begin;
+    int     OldValue[2];
+    int     CurrentStep[2];
+    float   masking_lower;
+    int     substep_shaping;
+    int     frame_number;
+    int     primed;
+    int     status;                     /* 0 ok; device-detected inconsistencies are reported here */
+    int     pad[3];
+} LhStreamState;
+
+/* one stream's work for one launch */
+typedef struct LhStreamDesc {
+    long long pcm_l;            /* element offset of this stream's left/right planes in the PCM pool */
+    long long pcm_r;
+    long long pcm_base;         /* stream sample index held at pool offset 0 */
+    long long nsamples;         /* samples of the stream that exist; beyond that the input is zero */
+    long long out_index;        /* first LhFrameOut slot of this launch */
+    int     frame_begin;        /* frames [frame_begin, frame_end) are encoded */
+    int     frame_end;
+} LhStreamDesc;
+
+void    lh_state_init(LhStreamState * s, const LhConfig * cfg);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1004,3 +1004,36 @@ lh_tables_build(LhConfig * c, const LhInitAux * aux, LhTables * t)
         t->log_table[i] = log(1.0f + i / (float) 512) / log(2.0f);
     return 0;
 }
+
+/* initial per-stream carried state (reference psymodel.c:1897-1922, 2075-2076;
+ * lame.c:962-963, 2285-2302) */
+#include "lh_device.h"
+void
+lh_state_init(LhStreamState * s, const LhConfig * cfg)
+{
+    int     i, j;
+    memset(s, 0, sizeof(*s));
+    for (i = 0; i < 4; ++i) {
+        for (j = 0; j < LH_CBANDS; ++j) {
+            s->nb_l1[i][j] = 1e20;
+            s->nb_l2[i][j] = 1e20;
+        }
+        for (j = 0; j < LH_XMIN_N; j++) {
+            s->en[i][j] = 1e20;
+            s->thm[i][j] = 1e20;
+        }
+        s->last_attacks[i] = 0;
+        for (j = 0; j < 9; j++)
+            s->last_en_subshort[i][j] = 10.;
+    }
+    s->blocktype_old[0] = s->blocktype_old[1] = LH_NORM_TYPE;
+    s->ath_adjust_factor = 0.01;
+    s->ath_adjust_limit = 1.0;
+    for (i = 0; i < 19; i++)
+        s->pefirbuf[i] = 700 * cfg->mode_gr * cfg->channels;
+    s->slot_lag = cfg->frac_SpF;
+    s->OldValue[0] = s->OldValue[1] = 180;
+    s->CurrentStep[0] = s->CurrentStep[1] = 4;
+    s->masking_lower = 1;
+    s->substep_shaping = cfg->substep_shaping;
+}
