@@ -1,0 +1,731 @@
+/*
+ * lh_api.cpp -- C-ABI layer of liblamehip (declared in include/lamehip.h).
+ *
+ * Host side only: parameter collection (the lame_set_* subset of the reference,
+ * set_get.c), lame_init_params -> constants + tables -> HBM, PCM staging, kernel
+ * launches (lh_kernels.hip), D2H of the side-info payload and the serial bit
+ * packer (lh_bitstream.c).  The per-frame arithmetic of the hot path runs only
+ * in the HIP kernels; there is no CPU implementation of it in this library.
+ */
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#include "lamehip.h"
+#include "lamehip_types.h"
+#include "lh_host.h"
+#include "lh_device.h"
+
+extern "C" int lh_launch_encode(const LhConfig * cfg, const LhTables * T, const int16_t * pcm,
+                                const LhStreamDesc * descs, LhStreamState * states,
+                                LhFrameOut * out, int nstreams, void *stream);
+
+#define LAME_ID 0xFFF88E3Bu     /* reference util.h:482 */
+
+static thread_local char g_err[512] = "";
+
+static int
+set_err(const char *what, hipError_t e)
+{
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return LAMEHIP_ERR_DEVICE;
+}
+
+#define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return set_err(#call, e_); } while (0)
+
+extern "C" const char *
+lamehip_last_error(void)
+{
+    return g_err;
+}
+
+extern "C" int
+lamehip_device_count(void)
+{
+    int     n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        return 0;
+    return n;
+}
+
+/* device-resident constants shared by a handle or a batch */
+struct LhDeviceConst {
+    LhConfig *d_cfg = nullptr;
+    LhTables *d_tab = nullptr;
+    int upload(const LhConfig & cfg, const LhTables & tab) {
+        HIPCHK(hipMalloc((void **) &d_cfg, sizeof(LhConfig)));
+        HIPCHK(hipMalloc((void **) &d_tab, sizeof(LhTables)));
+        HIPCHK(hipMemcpy(d_cfg, &cfg, sizeof(LhConfig), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d_tab, &tab, sizeof(LhTables), hipMemcpyHostToDevice));
+        return 0;
+    }
+    void release() {
+        if (d_cfg)
+            (void) hipFree(d_cfg);
+        if (d_tab)
+            (void) hipFree(d_tab);
+        d_cfg = nullptr;
+        d_tab = nullptr;
+    }
+};
+
+struct lame_global_struct {
+    unsigned class_id;
+    LhUserParams p;
+    int     out_samplerate;
+    int     write_vbr_tag;
+    int     inited;
+    int     have_device;
+    LhConfig cfg;
+    LhTables *tab;              /* host copy */
+    LhDeviceConst dc;
+    /* streaming state of the single-handle path */
+    std::vector < short >hl, hr; /* samples [hist_base, fed) kept on the host */
+    long long hist_base;
+    long long fed;
+    int     frames_done;
+    int     flushed;
+    LhStreamState *d_state;
+    int16_t *d_pcm;
+    long long d_pcm_cap;
+    LhStreamDesc *d_desc;
+    LhFrameOut *d_out;
+    int     d_out_cap;
+    std::vector < LhFrameOut > h_out;
+    LhFrameOut last_frame;
+    int     have_last;
+    LhBitstream bs;
+    hipStream_t stream;
+};
+
+static int
+valid(const lame_t g)
+{
+    return g && g->class_id == LAME_ID;
+}
+
+extern "C" lame_t
+lame_init(void)
+{
+    lame_t  g = new(std::nothrow) lame_global_struct();
+    if (!g)
+        return nullptr;
+    g->class_id = LAME_ID;
+    lh_params_default(&g->p);
+    g->out_samplerate = 0;
+    g->write_vbr_tag = 1;       /* reference default (lame.c:2340); must be cleared, see lame_init_params */
+    g->inited = 0;
+    g->have_device = 0;
+    g->tab = nullptr;
+    g->hist_base = 0;
+    g->fed = 0;
+    g->frames_done = 0;
+    g->flushed = 0;
+    g->d_state = nullptr;
+    g->d_pcm = nullptr;
+    g->d_pcm_cap = 0;
+    g->d_desc = nullptr;
+    g->d_out = nullptr;
+    g->d_out_cap = 0;
+    g->have_last = 0;
+    g->stream = nullptr;
+    memset(&g->bs, 0, sizeof(g->bs));
+    return g;
+}
+
+#define SETTER(name, field, type) \
+    extern "C" int name(lame_t g, type v) { if (!valid(g)) return -1; g->field = (int) v; return 0; }
+#define GETTER(name, expr, type) \
+    extern "C" type name(const lame_t g) { if (!valid(g)) return (type) 0; return (type) (expr); }
+
+SETTER(lame_set_in_samplerate, p.samplerate, int)
+GETTER(lame_get_in_samplerate, g->p.samplerate, int)
+SETTER(lame_set_num_channels, p.channels, int)
+GETTER(lame_get_num_channels, g->p.channels, int)
+SETTER(lame_set_out_samplerate, out_samplerate, int)
+GETTER(lame_get_out_samplerate, g->inited ? g->cfg.samplerate : g->out_samplerate, int)
+SETTER(lame_set_brate, p.brate, int)
+GETTER(lame_get_brate, g->inited ? g->cfg.avg_bitrate : g->p.brate, int)
+SETTER(lame_set_quality, p.quality, int)
+GETTER(lame_get_quality, g->inited ? g->cfg.quality : g->p.quality, int)
+SETTER(lame_set_bWriteVbrTag, write_vbr_tag, int)
+GETTER(lame_get_bWriteVbrTag, g->write_vbr_tag, int)
+
+extern "C" int
+lame_set_mode(lame_t g, MPEG_mode m)
+{
+    if (!valid(g))
+        return -1;
+    if ((int) m < 0 || m >= MAX_INDICATOR)
+        return -1;
+    g->p.mode = (m == NOT_SET) ? -1 : (int) m;
+    return 0;
+}
+
+extern "C" MPEG_mode
+lame_get_mode(const lame_t g)
+{
+    if (!valid(g))
+        return NOT_SET;
+    if (g->inited)
+        return (MPEG_mode) g->cfg.mode;
+    return g->p.mode < 0 ? NOT_SET : (MPEG_mode) g->p.mode;
+}
+
+extern "C" int
+lame_set_VBR(lame_t g, vbr_mode v)
+{
+    if (!valid(g))
+        return -1;
+    g->p.vbr = (int) v;
+    return 0;
+}
+
+extern "C" vbr_mode
+lame_get_VBR(const lame_t g)
+{
+    return valid(g) ? (vbr_mode) g->p.vbr : vbr_off;
+}
+
+extern "C" int
+lame_set_findReplayGain(lame_t g, int v)
+{
+    (void) v;
+    return valid(g) ? 0 : -1;   /* ReplayGain analysis is outside the hot path */
+}
+
+GETTER(lame_get_framesize, 576 * 2, int)
+GETTER(lame_get_frameNum, g->frames_done, int)
+GETTER(lame_get_encoder_delay, LH_ENCDELAY, int)
+GETTER(lame_get_version, g->inited ? g->cfg.version : 1, int)
+
+extern "C" int
+lame_init_params(lame_t g)
+{
+    LhInitAux aux;
+    if (!valid(g))
+        return -1;
+    if (g->inited)
+        return 0;
+    if (g->out_samplerate != 0 && g->out_samplerate != g->p.samplerate) {
+        snprintf(g_err, sizeof(g_err), "resampling is outside the accelerated path");
+        return -1;
+    }
+    if (g->write_vbr_tag) {
+        snprintf(g_err, sizeof(g_err),
+                 "Xing/LAME tag frame is not produced by this library: call lame_set_bWriteVbrTag(gfp, 0)");
+        return -1;
+    }
+    if (lh_config_resolve(&g->p, &g->cfg, &aux) != 0) {
+        snprintf(g_err, sizeof(g_err), "unsupported settings for the MI355X path (need MPEG-1, 2 channels, CBR)");
+        return -1;
+    }
+    g->tab = (LhTables *) malloc(sizeof(LhTables));
+    if (!g->tab)
+        return -2;
+    if (lh_tables_build(&g->cfg, &aux, g->tab) != 0) {
+        snprintf(g_err, sizeof(g_err), "table generation failed");
+        return -1;
+    }
+    if (lh_bs_init(&g->bs) != 0)
+        return -2;
+    g->inited = 1;              /* host constants are valid from here on (lamehip_get_*) */
+    if (lamehip_device_count() <= 0) {
+        snprintf(g_err, sizeof(g_err), "no HIP device: liblamehip has no CPU encode path");
+        g->have_device = 0;
+        return LAMEHIP_ERR_NODEVICE;
+    }
+    {
+        int     rc = g->dc.upload(g->cfg, *g->tab);
+        LhStreamState s0;
+        if (rc)
+            return rc;
+        HIPCHK(hipStreamCreate(&g->stream));
+        HIPCHK(hipMalloc((void **) &g->d_state, sizeof(LhStreamState)));
+        HIPCHK(hipMalloc((void **) &g->d_desc, sizeof(LhStreamDesc)));
+        lh_state_init(&s0, &g->cfg);
+        HIPCHK(hipMemcpy(g->d_state, &s0, sizeof(s0), hipMemcpyHostToDevice));
+    }
+    g->have_device = 1;
+    return 0;
+}
+
+/* encode frames [frames_done, upto) of the single-handle stream and append the packed bytes */
+static int
+handle_encode_frames(lame_t g, int upto, unsigned char *mp3buf, int mp3buf_size, int *written)
+{
+    int const f0 = g->frames_done, nf = upto - f0;
+    long long p0, p1, n;
+    LhStreamDesc d;
+    if (nf <= 0)
+        return 0;
+    /* samples touched: priming of frame 0 reaches 1152 further back (all zero there) */
+    p0 = 1152LL * f0 - LH_MF_START - 1152;
+    if (p0 < g->hist_base)
+        p0 = g->hist_base;
+    p1 = 1152LL * (upto - 1) - LH_MF_START + LH_MF_NEEDED;
+    if (p1 > g->fed)
+        p1 = g->fed;
+    n = p1 > p0 ? p1 - p0 : 0;
+    if (n > g->d_pcm_cap) {
+        if (g->d_pcm)
+            (void) hipFree(g->d_pcm);
+        g->d_pcm_cap = n + 4096;
+        HIPCHK(hipMalloc((void **) &g->d_pcm, (size_t) g->d_pcm_cap * 2 * sizeof(int16_t)));
+    }
+    if (n > 0) {
+        HIPCHK(hipMemcpyAsync(g->d_pcm, &g->hl[(size_t) (p0 - g->hist_base)], (size_t) n * 2,
+                              hipMemcpyHostToDevice, g->stream));
+        HIPCHK(hipMemcpyAsync(g->d_pcm + g->d_pcm_cap, &g->hr[(size_t) (p0 - g->hist_base)],
+                              (size_t) n * 2, hipMemcpyHostToDevice, g->stream));
+    }
+    if (nf > g->d_out_cap) {
+        if (g->d_out)
+            (void) hipFree(g->d_out);
+        g->d_out_cap = nf + 8;
+        HIPCHK(hipMalloc((void **) &g->d_out, (size_t) g->d_out_cap * sizeof(LhFrameOut)));
+    }
+    d.pcm_l = 0;
+    d.pcm_r = g->d_pcm_cap;
+    d.pcm_base = p0;
+    d.nsamples = g->fed;
+    d.out_index = 0;
+    d.frame_begin = f0;
+    d.frame_end = upto;
+    HIPCHK(hipMemcpyAsync(g->d_desc, &d, sizeof(d), hipMemcpyHostToDevice, g->stream));
+    {
+        int     rc = lh_launch_encode(g->dc.d_cfg, g->dc.d_tab, g->d_pcm, g->d_desc, g->d_state,
+                                      g->d_out, 1, (void *) g->stream);
+        if (rc)
+            return set_err("kernel launch", (hipError_t) rc);
+    }
+    g->h_out.resize((size_t) nf);
+    HIPCHK(hipMemcpyAsync(g->h_out.data(), g->d_out, (size_t) nf * sizeof(LhFrameOut),
+                          hipMemcpyDeviceToHost, g->stream));
+    HIPCHK(hipStreamSynchronize(g->stream));
+    for (int i = 0; i < nf; i++) {
+        int     k;
+        if (lh_bs_format_frame(&g->bs, &g->cfg, g->tab, &g->h_out[(size_t) i]) != 0) {
+            snprintf(g_err, sizeof(g_err), "inconsistent device payload (packer check %d) at frame %d",
+                     g->bs.error, f0 + i);
+            return LAMEHIP_ERR_PAYLOAD;
+        }
+        k = lh_bs_copy(&g->bs, mp3buf + *written, mp3buf_size ? mp3buf_size - *written : 0);
+        if (k < 0)
+            return -1;
+        *written += k;
+    }
+    g->last_frame = g->h_out[(size_t) nf - 1];
+    g->have_last = 1;
+    g->frames_done = upto;
+    /* drop history that no later frame (nor its priming) can touch */
+    {
+        long long keep = 1152LL * g->frames_done - LH_MF_START - 64;
+        if (keep > g->hist_base) {
+            size_t  drop = (size_t) (keep - g->hist_base);
+            if (drop > g->hl.size())
+                drop = g->hl.size();
+            g->hl.erase(g->hl.begin(), g->hl.begin() + (long) drop);
+            g->hr.erase(g->hr.begin(), g->hr.begin() + (long) drop);
+            g->hist_base += (long long) drop;
+        }
+    }
+    return 0;
+}
+
+extern "C" int
+lame_encode_buffer(lame_t g, const short int l[], const short int r[], const int nsamples,
+                   unsigned char *mp3buf, const int mp3buf_size)
+{
+    int     written = 0, rc, avail;
+    if (!valid(g) || !g->inited)
+        return -3;
+    if (!g->have_device)
+        return LAMEHIP_ERR_NODEVICE;
+    if (nsamples == 0)
+        return 0;
+    if (nsamples < 0)
+        return -1;
+    g->hl.insert(g->hl.end(), l, l + nsamples);
+    g->hr.insert(g->hr.end(), r, r + nsamples);
+    g->fed += nsamples;
+    g->flushed = 0;
+    /* a frame is encoded whenever 1904 samples are buffered behind the 528-sample
+     * lead-in (reference lame.c:1737-1769) */
+    avail = (LH_MF_START + g->fed >= LH_MF_NEEDED)
+        ? (int) ((LH_MF_START + g->fed - LH_MF_NEEDED) / 1152 + 1) : 0;
+    rc = handle_encode_frames(g, avail, mp3buf, mp3buf_size, &written);
+    if (rc)
+        return rc;
+    return written;
+}
+
+extern "C" int
+lame_encode_buffer_interleaved(lame_t g, short int pcm[], int num_samples, unsigned char *mp3buf,
+                               int mp3buf_size)
+{
+    std::vector < short >l((size_t) (num_samples > 0 ? num_samples : 0)), r(l.size());
+    for (int i = 0; i < num_samples; i++) {
+        l[(size_t) i] = pcm[2 * i];
+        r[(size_t) i] = pcm[2 * i + 1];
+    }
+    return lame_encode_buffer(g, l.data(), r.data(), num_samples, mp3buf, mp3buf_size);
+}
+
+extern "C" int
+lame_encode_flush(lame_t g, unsigned char *mp3buf, int size)
+{
+    int     written = 0, rc, total, k;
+    if (!valid(g) || !g->inited)
+        return -3;
+    if (!g->have_device)
+        return LAMEHIP_ERR_NODEVICE;
+    if (g->flushed)
+        return 0;               /* reference lame.c:2076-2079 */
+    total = lh_total_frames((long) g->fed);
+    rc = handle_encode_frames(g, total, mp3buf, size, &written);
+    if (rc)
+        return rc;
+    lh_bs_flush(&g->bs, &g->cfg, g->have_last ? &g->last_frame : nullptr);
+    k = lh_bs_copy(&g->bs, mp3buf + written, size ? size - written : 0);
+    if (k < 0)
+        return -1;
+    written += k;
+    g->flushed = 1;
+    /* the reference zeroes the reservoir after padding out the last frame (bitstream.c:886-888) */
+    {
+        LhStreamState s;
+        if (hipMemcpy(&s, g->d_state, sizeof(s), hipMemcpyDeviceToHost) == hipSuccess) {
+            s.ResvSize = 0;
+            s.main_data_begin = 0;
+            (void) hipMemcpy(g->d_state, &s, sizeof(s), hipMemcpyHostToDevice);
+        }
+    }
+    return written;
+}
+
+extern "C" int
+lame_close(lame_t g)
+{
+    if (!valid(g))
+        return -3;
+    g->class_id = 0;
+    if (g->d_state)
+        (void) hipFree(g->d_state);
+    if (g->d_pcm)
+        (void) hipFree(g->d_pcm);
+    if (g->d_desc)
+        (void) hipFree(g->d_desc);
+    if (g->d_out)
+        (void) hipFree(g->d_out);
+    if (g->stream)
+        (void) hipStreamDestroy(g->stream);
+    g->dc.release();
+    if (g->bs.buf)
+        lh_bs_free(&g->bs);
+    free(g->tab);
+    delete  g;
+    return 0;
+}
+
+/* sizes of the POD layouts this build was compiled with (ABI check for bindings) */
+extern "C" int
+lamehip_abi_sizeof(int which)
+{
+    switch (which) {
+    case 0:
+        return (int) sizeof(LhConfig);
+    case 1:
+        return (int) sizeof(LhTables);
+    case 2:
+        return (int) sizeof(LhFrameOut);
+    case 3:
+        return (int) sizeof(LhGranule);
+    case 4:
+        return (int) sizeof(LhStreamState);
+    case 5:
+        return (int) sizeof(LhStreamDesc);
+    }
+    return -1;
+}
+
+extern "C" int
+lamehip_get_config(const lame_t g, void *out, int size)
+{
+    if (!valid(g) || !g->inited || size < (int) sizeof(LhConfig))
+        return -1;
+    memcpy(out, &g->cfg, sizeof(LhConfig));
+    return (int) sizeof(LhConfig);
+}
+
+extern "C" int
+lamehip_get_tables(const lame_t g, void *out, int size)
+{
+    if (!valid(g) || !g->inited || !g->tab || size < (int) sizeof(LhTables))
+        return -1;
+    memcpy(out, g->tab, sizeof(LhTables));
+    return (int) sizeof(LhTables);
+}
+
+/* ====================================================================== */
+/* batch extension                                                          */
+
+struct lamehip_batch {
+    LhConfig cfg;
+    LhTables *tab;
+    LhDeviceConst dc;
+    int     B;
+    long    cap;
+    int16_t *d_pcm;             /* [B][2][cap] */
+    LhStreamState *d_state;
+    LhStreamDesc *d_desc;
+    LhFrameOut *d_out;
+    long long out_cap;
+    std::vector < long >len;
+    std::vector < int >nframes;
+    std::vector < long long >out_off;
+    std::vector < LhStreamDesc > h_desc;
+    hipStream_t stream;
+    hipEvent_t ev0, ev1;
+    float   last_ms;
+    int     encoded;
+};
+
+static int
+batch_reset_states(lamehip_batch * b)
+{
+    std::vector < LhStreamState > s((size_t) b->B);
+    for (int i = 0; i < b->B; i++)
+        lh_state_init(&s[(size_t) i], &b->cfg);
+    HIPCHK(hipMemcpy(b->d_state, s.data(), s.size() * sizeof(LhStreamState), hipMemcpyHostToDevice));
+    b->encoded = 0;
+    return 0;
+}
+
+extern "C" lamehip_batch *
+lamehip_batch_create(const lame_t proto, int nstreams, long capacity_samples)
+{
+    lamehip_batch *b;
+    if (!valid(proto) || !proto->inited || !proto->have_device || nstreams <= 0
+        || capacity_samples <= 0) {
+        snprintf(g_err, sizeof(g_err), "lamehip_batch_create: need an initialised handle on a HIP device");
+        return nullptr;
+    }
+    b = new(std::nothrow) lamehip_batch();
+    if (!b)
+        return nullptr;
+    b->cfg = proto->cfg;
+    b->tab = (LhTables *) malloc(sizeof(LhTables));
+    memcpy(b->tab, proto->tab, sizeof(LhTables));
+    b->B = nstreams;
+    b->cap = capacity_samples;
+    b->d_pcm = nullptr;
+    b->d_state = nullptr;
+    b->d_desc = nullptr;
+    b->d_out = nullptr;
+    b->out_cap = 0;
+    b->len.assign((size_t) nstreams, 0);
+    b->nframes.assign((size_t) nstreams, 0);
+    b->out_off.assign((size_t) nstreams, 0);
+    b->h_desc.resize((size_t) nstreams);
+    b->last_ms = 0;
+    b->encoded = 0;
+    if (b->dc.upload(b->cfg, *b->tab) != 0
+        || hipMalloc((void **) &b->d_pcm, (size_t) nstreams * 2 * (size_t) capacity_samples * 2) != hipSuccess
+        || hipMalloc((void **) &b->d_state, (size_t) nstreams * sizeof(LhStreamState)) != hipSuccess
+        || hipMalloc((void **) &b->d_desc, (size_t) nstreams * sizeof(LhStreamDesc)) != hipSuccess
+        || hipStreamCreate(&b->stream) != hipSuccess
+        || hipEventCreate(&b->ev0) != hipSuccess || hipEventCreate(&b->ev1) != hipSuccess
+        || hipMemset(b->d_pcm, 0, (size_t) nstreams * 2 * (size_t) capacity_samples * 2) != hipSuccess
+        || batch_reset_states(b) != 0) {
+        snprintf(g_err, sizeof(g_err), "lamehip_batch_create: device allocation failed");
+        lamehip_batch_destroy(b);
+        return nullptr;
+    }
+    return b;
+}
+
+extern "C" void
+lamehip_batch_destroy(lamehip_batch * b)
+{
+    if (!b)
+        return;
+    if (b->d_pcm)
+        (void) hipFree(b->d_pcm);
+    if (b->d_state)
+        (void) hipFree(b->d_state);
+    if (b->d_desc)
+        (void) hipFree(b->d_desc);
+    if (b->d_out)
+        (void) hipFree(b->d_out);
+    if (b->stream)
+        (void) hipStreamDestroy(b->stream);
+    if (b->ev0)
+        (void) hipEventDestroy(b->ev0);
+    if (b->ev1)
+        (void) hipEventDestroy(b->ev1);
+    b->dc.release();
+    free(b->tab);
+    delete  b;
+}
+
+extern "C" int
+lamehip_batch_set_length(lamehip_batch * b, int s, long n)
+{
+    if (!b || s < 0 || s >= b->B || n < 0 || n > b->cap)
+        return -1;
+    b->len[(size_t) s] = n;
+    b->nframes[(size_t) s] = lh_total_frames(n);
+    return 0;
+}
+
+extern "C" int
+lamehip_batch_set_pcm(lamehip_batch * b, int s, const short *l, const short *r, long n)
+{
+    if (lamehip_batch_set_length(b, s, n) != 0)
+        return -1;
+    HIPCHK(hipMemcpy(b->d_pcm + ((size_t) s * 2) * (size_t) b->cap, l, (size_t) n * 2, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(b->d_pcm + ((size_t) s * 2 + 1) * (size_t) b->cap, r, (size_t) n * 2, hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" void *
+lamehip_batch_pcm_device_ptr(lamehip_batch * b)
+{
+    return b ? (void *) b->d_pcm : nullptr;
+}
+
+extern "C" int
+lamehip_batch_frames(lamehip_batch * b, int s)
+{
+    if (!b || s < 0 || s >= b->B)
+        return -1;
+    return b->nframes[(size_t) s];
+}
+
+extern "C" int
+lamehip_batch_reset(lamehip_batch * b)
+{
+    if (!b)
+        return -1;
+    return batch_reset_states(b);
+}
+
+extern "C" int
+lamehip_batch_encode(lamehip_batch * b)
+{
+    long long total = 0;
+    if (!b)
+        return -1;
+    for (int s = 0; s < b->B; s++) {
+        LhStreamDesc & d = b->h_desc[(size_t) s];
+        b->out_off[(size_t) s] = total;
+        d.pcm_l = ((long long) s * 2) * b->cap;
+        d.pcm_r = ((long long) s * 2 + 1) * b->cap;
+        d.pcm_base = 0;
+        d.nsamples = b->len[(size_t) s];
+        d.out_index = total;
+        d.frame_begin = 0;
+        d.frame_end = b->nframes[(size_t) s];
+        total += b->nframes[(size_t) s];
+    }
+    if (total > b->out_cap) {
+        if (b->d_out)
+            (void) hipFree(b->d_out);
+        b->out_cap = total;
+        HIPCHK(hipMalloc((void **) &b->d_out, (size_t) total * sizeof(LhFrameOut)));
+    }
+    HIPCHK(hipMemcpyAsync(b->d_desc, b->h_desc.data(), (size_t) b->B * sizeof(LhStreamDesc),
+                          hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipEventRecord(b->ev0, b->stream));
+    {
+        int     rc = lh_launch_encode(b->dc.d_cfg, b->dc.d_tab, b->d_pcm, b->d_desc, b->d_state,
+                                      b->d_out, b->B, (void *) b->stream);
+        if (rc)
+            return set_err("kernel launch", (hipError_t) rc);
+    }
+    HIPCHK(hipEventRecord(b->ev1, b->stream));
+    b->encoded = 1;
+    return 0;
+}
+
+extern "C" int
+lamehip_batch_sync(lamehip_batch * b)
+{
+    if (!b)
+        return -1;
+    HIPCHK(hipStreamSynchronize(b->stream));
+    if (b->encoded) {
+        float   ms = 0;
+        if (hipEventElapsedTime(&ms, b->ev0, b->ev1) == hipSuccess)
+            b->last_ms = ms;
+    }
+    return 0;
+}
+
+extern "C" float
+lamehip_batch_last_kernel_ms(lamehip_batch * b)
+{
+    return b ? b->last_ms : 0.0f;
+}
+
+extern "C" int
+lamehip_batch_get_frames(lamehip_batch * b, int s, void *frames_out, int max_frames)
+{
+    int     n;
+    if (!b || s < 0 || s >= b->B || !b->encoded)
+        return -1;
+    n = b->nframes[(size_t) s];
+    if (n > max_frames)
+        n = max_frames;
+    HIPCHK(hipStreamSynchronize(b->stream));
+    HIPCHK(hipMemcpy(frames_out, b->d_out + b->out_off[(size_t) s], (size_t) n * sizeof(LhFrameOut),
+                     hipMemcpyDeviceToHost));
+    return n;
+}
+
+extern "C" long
+lamehip_batch_pack(lamehip_batch * b, int s, unsigned char *out, long out_size)
+{
+    LhBitstream bs;
+    std::vector < LhFrameOut > fr;
+    long    pos = 0;
+    int     n;
+    if (!b || s < 0 || s >= b->B || !b->encoded)
+        return -1;
+    n = b->nframes[(size_t) s];
+    fr.resize((size_t) n);
+    if (lamehip_batch_get_frames(b, s, fr.data(), n) != n)
+        return LAMEHIP_ERR_DEVICE;
+    if (lh_bs_init(&bs) != 0)
+        return -2;
+    for (int i = 0; i < n; i++) {
+        int     k;
+        if (lh_bs_format_frame(&bs, &b->cfg, b->tab, &fr[(size_t) i]) != 0) {
+            snprintf(g_err, sizeof(g_err), "inconsistent device payload (packer check %d) stream %d frame %d",
+                     bs.error, s, i);
+            lh_bs_free(&bs);
+            return LAMEHIP_ERR_PAYLOAD;
+        }
+        if (bs.buf_byte_idx + 1 > out_size - pos) {
+            lh_bs_free(&bs);
+            return -1;
+        }
+        k = lh_bs_copy(&bs, out + pos, 0);
+        pos += k;
+    }
+    lh_bs_flush(&bs, &b->cfg, n > 0 ? &fr[(size_t) n - 1] : nullptr);
+    {
+        int     k;
+        if (bs.buf_byte_idx + 1 > out_size - pos) {
+            lh_bs_free(&bs);
+            return -1;
+        }
+        k = lh_bs_copy(&bs, out + pos, 0);
+        pos += k;
+    }
+    lh_bs_free(&bs);
+    return pos;
+}

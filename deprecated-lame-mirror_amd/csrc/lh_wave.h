@@ -107,7 +107,7 @@ __device__ __forceinline__ int lh_wave_id(void) { return (int) (threadIdx.x >> 6
 /* LDS traffic of one wave is executed in order; this only stops the compiler
  * from moving LDS accesses across the point where lanes exchange data through
  * LDS, and waits for outstanding LDS operations. */
-#define LH_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); \
+#define LH_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); \
                             __builtin_amdgcn_wave_barrier(); } while (0)
 
 __device__ __forceinline__ uint32_t

@@ -1,0 +1,202 @@
+"""lamehip -- thin ctypes host binding over liblamehip.so (the C ABI in
+include/lamehip.h).  It mirrors the reference's lame.h call sequence
+(lame_init -> lame_set_* -> lame_init_params -> lame_encode_buffer ->
+lame_encode_flush -> lame_close) and adds the batch entry points.  There is no
+Python or CPU implementation of the encode path here: if the HIP library is
+missing, importing the binding's loader fails loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .types import LhConfig, LhFrameOut, LhTables  # noqa: F401
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblamehip.so")
+
+ERR_NODEVICE = -10
+STEREO, JOINT_STEREO = 0, 1
+
+_lib = None
+
+
+def load_library():
+    """Load liblamehip.so (built in-tree by __graft_entry__.build()); raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "liblamehip.so not found at %s: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(the encode path has no CPU fallback)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    lib.lame_init.restype = C.c_void_p
+    for name in ("lame_set_in_samplerate", "lame_set_num_channels", "lame_set_brate", "lame_set_mode",
+                 "lame_set_quality", "lame_set_VBR", "lame_set_bWriteVbrTag", "lame_set_out_samplerate"):
+        getattr(lib, name).argtypes = [C.c_void_p, C.c_int]
+    lib.lame_init_params.argtypes = [C.c_void_p]
+    lib.lame_encode_buffer.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    lib.lame_encode_flush.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    lib.lame_close.argtypes = [C.c_void_p]
+    lib.lame_get_frameNum.argtypes = [C.c_void_p]
+    lib.lamehip_last_error.restype = C.c_char_p
+    lib.lamehip_get_config.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    lib.lamehip_get_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    lib.lamehip_batch_create.restype = C.c_void_p
+    lib.lamehip_batch_create.argtypes = [C.c_void_p, C.c_int, C.c_long]
+    lib.lamehip_batch_destroy.argtypes = [C.c_void_p]
+    lib.lamehip_batch_set_pcm.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_long]
+    lib.lamehip_batch_set_length.argtypes = [C.c_void_p, C.c_int, C.c_long]
+    lib.lamehip_batch_pcm_device_ptr.restype = C.c_void_p
+    lib.lamehip_batch_pcm_device_ptr.argtypes = [C.c_void_p]
+    lib.lamehip_batch_encode.argtypes = [C.c_void_p]
+    lib.lamehip_batch_sync.argtypes = [C.c_void_p]
+    lib.lamehip_batch_reset.argtypes = [C.c_void_p]
+    lib.lamehip_batch_frames.argtypes = [C.c_void_p, C.c_int]
+    lib.lamehip_batch_pack.restype = C.c_long
+    lib.lamehip_batch_pack.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_long]
+    lib.lamehip_batch_get_frames.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    lib.lamehip_batch_last_kernel_ms.restype = C.c_float
+    lib.lamehip_batch_last_kernel_ms.argtypes = [C.c_void_p]
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load_library().lamehip_last_error().decode()
+
+
+class Encoder:
+    """One stream behind the lame.h call sequence."""
+
+    def __init__(self, samplerate=44100, brate=128, mode=None, quality=None, require_device=True):
+        self.lib = load_library()
+        self.h = C.c_void_p(self.lib.lame_init())
+        self.lib.lame_set_in_samplerate(self.h, samplerate)
+        self.lib.lame_set_num_channels(self.h, 2)
+        self.lib.lame_set_brate(self.h, brate)
+        self.lib.lame_set_bWriteVbrTag(self.h, 0)
+        if mode is not None:
+            self.lib.lame_set_mode(self.h, mode)
+        if quality is not None:
+            self.lib.lame_set_quality(self.h, quality)
+        self.rc = self.lib.lame_init_params(self.h)
+        if self.rc == ERR_NODEVICE and not require_device:
+            return
+        if self.rc != 0:
+            msg = last_error()
+            self.close()
+            raise RuntimeError("lame_init_params failed (%d): %s" % (self.rc, msg))
+
+    def config(self):
+        c = LhConfig()
+        assert self.lib.lamehip_get_config(self.h, C.byref(c), C.sizeof(c)) == C.sizeof(c)
+        return c
+
+    def tables(self):
+        t = LhTables()
+        assert self.lib.lamehip_get_tables(self.h, C.byref(t), C.sizeof(t)) == C.sizeof(t)
+        return t
+
+    def encode(self, left, right):
+        left = np.ascontiguousarray(left, dtype=np.int16)
+        right = np.ascontiguousarray(right, dtype=np.int16)
+        n = len(left)
+        buf = C.create_string_buffer(int(1.25 * n) + 7200)
+        k = self.lib.lame_encode_buffer(self.h, left.ctypes.data, right.ctypes.data, n, buf, len(buf))
+        if k < 0:
+            raise RuntimeError("lame_encode_buffer failed (%d): %s" % (k, last_error()))
+        return buf.raw[:k]
+
+    def flush(self):
+        buf = C.create_string_buffer(4 * 7200)
+        k = self.lib.lame_encode_flush(self.h, buf, len(buf))
+        if k < 0:
+            raise RuntimeError("lame_encode_flush failed (%d): %s" % (k, last_error()))
+        return buf.raw[:k]
+
+    def close(self):
+        if self.h:
+            self.lib.lame_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Batch:
+    """B independent streams with common settings, encoded by one kernel launch."""
+
+    def __init__(self, enc, nstreams, capacity):
+        self.lib = enc.lib
+        self.enc = enc
+        self.n = nstreams
+        self.capacity = capacity
+        self.b = C.c_void_p(self.lib.lamehip_batch_create(enc.h, nstreams, capacity))
+        if not self.b:
+            raise RuntimeError("lamehip_batch_create failed: %s" % last_error())
+
+    def set_pcm(self, s, left, right):
+        left = np.ascontiguousarray(left, dtype=np.int16)
+        right = np.ascontiguousarray(right, dtype=np.int16)
+        rc = self.lib.lamehip_batch_set_pcm(self.b, s, left.ctypes.data, right.ctypes.data, len(left))
+        if rc:
+            raise RuntimeError("lamehip_batch_set_pcm failed (%d): %s" % (rc, last_error()))
+
+    def set_length(self, s, n):
+        assert self.lib.lamehip_batch_set_length(self.b, s, n) == 0
+
+    def pcm_device_ptr(self):
+        return self.lib.lamehip_batch_pcm_device_ptr(self.b)
+
+    def encode(self, sync=True):
+        rc = self.lib.lamehip_batch_encode(self.b)
+        if rc:
+            raise RuntimeError("lamehip_batch_encode failed (%d): %s" % (rc, last_error()))
+        if sync:
+            self.sync()
+
+    def sync(self):
+        rc = self.lib.lamehip_batch_sync(self.b)
+        if rc:
+            raise RuntimeError("lamehip_batch_sync failed (%d): %s" % (rc, last_error()))
+
+    def reset(self):
+        assert self.lib.lamehip_batch_reset(self.b) == 0
+
+    def kernel_ms(self):
+        return float(self.lib.lamehip_batch_last_kernel_ms(self.b))
+
+    def frames(self, s):
+        return self.lib.lamehip_batch_frames(self.b, s)
+
+    def get_frames(self, s):
+        n = self.frames(s)
+        arr = (LhFrameOut * n)()
+        got = self.lib.lamehip_batch_get_frames(self.b, s, arr, n)
+        if got != n:
+            raise RuntimeError("lamehip_batch_get_frames failed (%d): %s" % (got, last_error()))
+        return arr
+
+    def pack(self, s):
+        n = self.frames(s)
+        buf = C.create_string_buffer(n * 1500 + 8192)
+        k = self.lib.lamehip_batch_pack(self.b, s, buf, len(buf))
+        if k < 0:
+            raise RuntimeError("lamehip_batch_pack failed (%d): %s" % (k, last_error()))
+        return buf.raw[:k]
+
+    def close(self):
+        if self.b:
+            self.lib.lamehip_batch_destroy(self.b)
+            self.b = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,120 @@
+/*
+ * lamehip.h -- C ABI of liblamehip: the MI355X-native MP3 encode inner loop
+ * behind the reference's public API.
+ *
+ * Part 1 mirrors the subset of the reference's include/lame.h that its frontend
+ * uses for CBR encoding; each entry point cites the reference declaration it
+ * replaces (file:line under /root/reference).  Names, argument meaning, return
+ * codes and the output lag (first call returns 0 bytes) are the reference's.
+ * Part 2 is the batch extension the GPU needs: a single lame_encode_buffer call
+ * carries 26 ms of one stream, a batch call carries whole streams for thousands
+ * of handles.
+ *
+ * Everything here is plain C: pointers and sizes only, no torch / HIP types.
+ * Unsupported settings (mono, VBR/ABR, MPEG-2 rates, resampling) make
+ * lame_init_params() return -1 instead of silently taking another path, and
+ * every call fails with LAMEHIP_ERR_NODEVICE when no HIP device is present --
+ * there is no CPU fallback inside this library.
+ */
+#ifndef LAMEHIP_H
+#define LAMEHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LAMEHIP_ERR_NODEVICE (-10)
+#define LAMEHIP_ERR_DEVICE   (-11)     /* a HIP call failed; see lamehip_last_error() */
+#define LAMEHIP_ERR_PAYLOAD  (-12)     /* device payload failed the packer's consistency checks */
+
+/* ------------------------------------------------------------------ */
+/* Part 1: lame.h-shaped handle API                                    */
+
+struct lame_global_struct;
+typedef struct lame_global_struct lame_global_flags;
+typedef lame_global_flags *lame_t;
+
+/* MPEG_mode, reference include/lame.h:61-69 */
+typedef enum MPEG_mode_e { STEREO = 0, JOINT_STEREO, DUAL_CHANNEL, MONO, NOT_SET, MAX_INDICATOR } MPEG_mode;
+/* vbr_mode, reference include/lame.h:49-58 */
+typedef enum vbr_mode_e { vbr_off = 0, vbr_mt, vbr_rh, vbr_abr, vbr_mtrh, vbr_max_indicator,
+    vbr_default = vbr_mtrh } vbr_mode;
+
+lame_t  lame_init(void);                                            /* lame.h:168 */
+int     lame_set_in_samplerate(lame_t, int);                         /* lame.h:188 */
+int     lame_get_in_samplerate(const lame_t);                        /* lame.h:189 */
+int     lame_set_num_channels(lame_t, int);                          /* lame.h:192 */
+int     lame_get_num_channels(const lame_t);                         /* lame.h:193 */
+int     lame_set_out_samplerate(lame_t, int);                        /* lame.h:224 (must equal the input rate) */
+int     lame_get_out_samplerate(const lame_t);                       /* lame.h:225 */
+int     lame_set_brate(lame_t, int);                                 /* lame.h:353 */
+int     lame_get_brate(const lame_t);                                /* lame.h:354 */
+int     lame_set_mode(lame_t, MPEG_mode);                            /* lame.h:270 */
+MPEG_mode lame_get_mode(const lame_t);                               /* lame.h:271 */
+int     lame_set_quality(lame_t, int);                               /* lame.h:263 */
+int     lame_get_quality(const lame_t);                              /* lame.h:264 */
+int     lame_set_VBR(lame_t, vbr_mode);                              /* lame.h:432 (only vbr_off is built) */
+vbr_mode lame_get_VBR(const lame_t);                                 /* lame.h:433 */
+int     lame_set_bWriteVbrTag(lame_t, int);                          /* lame.h:240 (tag frame is a host-side "next" item; must be 0) */
+int     lame_get_bWriteVbrTag(const lame_t);                         /* lame.h:241 */
+int     lame_set_findReplayGain(lame_t, int);                        /* lame.h:296 (accepted, ignored) */
+int     lame_init_params(lame_t);                                    /* lame.h:636 */
+int     lame_get_framesize(const lame_t);                            /* lame.h:582 */
+int     lame_get_frameNum(const lame_t);                             /* lame.h:597 */
+int     lame_get_encoder_delay(const lame_t);                        /* lame.h:571 */
+int     lame_get_version(const lame_t);                              /* lame.h:568 */
+
+/* return: bytes written to mp3buf (may be 0); -1 mp3buf too small; -2 alloc;
+ * -3 lame_init_params not called; mp3buf_size == 0 disables the size check
+ * (reference lame.h:687-722) */
+int     lame_encode_buffer(lame_t, const short int buffer_l[], const short int buffer_r[],
+                           const int nsamples, unsigned char *mp3buf, const int mp3buf_size);   /* lame.h:715 */
+int     lame_encode_buffer_interleaved(lame_t, short int pcm[], int num_samples,
+                                       unsigned char *mp3buf, int mp3buf_size);                  /* lame.h:730 */
+int     lame_encode_flush(lame_t, unsigned char *mp3buf, int size);                              /* lame.h:856 */
+int     lame_close(lame_t);                                                                      /* lame.h:977 */
+
+/* ------------------------------------------------------------------ */
+/* Part 2: batch extension (not in lame.h)                             */
+
+typedef struct lamehip_batch lamehip_batch;
+
+/* B independent streams that share the settings of `proto' (which must have
+ * passed lame_init_params); capacity = samples per channel per stream. */
+lamehip_batch *lamehip_batch_create(const lame_t proto, int nstreams, long capacity_samples);
+void    lamehip_batch_destroy(lamehip_batch *);
+/* copy one stream's planar s16 PCM host -> HBM (H2D, synchronous) */
+int     lamehip_batch_set_pcm(lamehip_batch *, int stream, const short *l, const short *r, long nsamples);
+/* device pointer of the PCM pool: int16 [stream][2][capacity]; lets a producer
+ * that already lives on the GPU fill it in place (then declare lengths) */
+void   *lamehip_batch_pcm_device_ptr(lamehip_batch *);
+int     lamehip_batch_set_length(lamehip_batch *, int stream, long nsamples);
+/* encode every stream completely (all frames incl. the flush frames), payload
+ * stays in HBM; asynchronous on the batch's HIP stream */
+int     lamehip_batch_encode(lamehip_batch *);
+int     lamehip_batch_sync(lamehip_batch *);
+/* total frames of a stream (known after set_pcm / set_length) */
+int     lamehip_batch_frames(lamehip_batch *, int stream);
+/* D2H of one stream's payload + host bit packing; returns bytes or <0 */
+long    lamehip_batch_pack(lamehip_batch *, int stream, unsigned char *out, long out_size);
+/* raw payload access for tests: copies frames [0, n) of a stream (LhFrameOut[]) */
+int     lamehip_batch_get_frames(lamehip_batch *, int stream, void *frames_out, int max_frames);
+/* elapsed GPU time of the last lamehip_batch_encode in ms (HIP events on the batch stream) */
+float   lamehip_batch_last_kernel_ms(lamehip_batch *);
+int     lamehip_batch_reset(lamehip_batch *);   /* re-initialise all stream states for another run */
+
+const char *lamehip_last_error(void);
+/* sizeof() of the POD layouts (0 LhConfig, 1 LhTables, 2 LhFrameOut, 3 LhGranule,
+ * 4 LhStreamState, 5 LhStreamDesc) this library was built with */
+int     lamehip_abi_sizeof(int which);
+int     lamehip_device_count(void);
+/* table / config access for tests (fills LhConfig / LhTables images) */
+int     lamehip_get_config(const lame_t, void *cfg_out, int size);
+int     lamehip_get_tables(const lame_t, void *tab_out, int size);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,123 @@
+"""Shared test helpers: seeded synthetic PCM (SURVEY.md 8(d) recipe), loaders for
+the CPU oracle and -- when it was built in this tree -- the compiled reference."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "deprecated-lame-mirror_amd")
+if PKG not in sys.path:
+    sys.path.insert(0, PKG)
+
+from lamehip.types import (LhConfig, LhFrameOut, LhInitAux, LhTables, LhUserParams)  # noqa: E402
+
+ORACLE_SO = os.path.join(ROOT, "oracle", "liboracle.so")
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "libref_harness.so")
+
+
+def synth_stream(seed, n, sr=44100, burst_interval=None, white=False):
+    """Music-like seeded stereo s16: 8 partials with independent channel phases,
+    low-level brown noise, decaying white-noise bursts (castanet-like -> short
+    blocks).  burst_interval in seconds (default 1/3)."""
+    rng = np.random.Generator(np.random.PCG64(0x4C414D45 + seed))
+    if white:
+        return (rng.standard_normal((2, n)) * 8000).clip(-32768, 32767).astype(np.int16)
+    t = np.arange(n) / sr
+    x = np.zeros((2, n))
+    for k in range(8):
+        f = 220.0 * 2 ** (k / 2.0)
+        vib = 1.0 + 0.001 * np.sin(2 * np.pi * 5 * t)
+        for c in range(2):
+            x[c] += 0.5 / (k + 1) * np.sin(2 * np.pi * f * t * vib + rng.uniform(0, 2 * np.pi))
+    brown = np.cumsum(rng.standard_normal((2, n)), axis=1)
+    k = 200
+    cs = np.cumsum(np.pad(brown, ((0, 0), (k, 0)), mode="edge"), axis=1)
+    brown = brown - (cs[:, k:] - cs[:, :-k]) / k
+    x += 0.02 * brown / (np.abs(brown).max() + 1e-9)
+    step = int(sr * (burst_interval if burst_interval else 1.0 / 3))
+    for s in range(step // 2, n, max(step, 1)):
+        m = min(2000, n - s)
+        env = np.exp(-np.arange(m) / 300.0)
+        x[:, s:s + m] += 0.6 * env * rng.standard_normal((2, m))
+    x = x / np.abs(x).max() * 0.8 * 32767
+    return x.astype(np.int16)
+
+
+def build_oracle():
+    if not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < max(
+            os.path.getmtime(os.path.join(ROOT, "oracle", f)) for f in os.listdir(os.path.join(ROOT, "oracle"))
+            if f.endswith((".c", ".h"))):
+        subprocess.check_call(["make", "oracle"], cwd=os.path.join(ROOT, "oracle"),
+                              stdout=subprocess.DEVNULL)
+    return ORACLE_SO
+
+
+class Oracle:
+    """CPU restatement (oracle/lame_oracle.c) -- the checker, never the product."""
+
+    def __init__(self):
+        self.lib = C.CDLL(build_oracle())
+
+    def encode_frames(self, cfg, tab, pcm, max_frames=None):
+        left = np.ascontiguousarray(pcm[0], dtype=np.int16)
+        right = np.ascontiguousarray(pcm[1], dtype=np.int16)
+        n = len(left)
+        nf = self.lib.orc_total_frames(C.c_long(n))
+        if max_frames is not None:
+            nf = min(nf, max_frames)
+        out = (LhFrameOut * nf)()
+        self.lib.orc_encode_stream(C.byref(cfg), C.byref(tab), left.ctypes.data_as(C.c_void_p),
+                                   right.ctypes.data_as(C.c_void_p), C.c_long(n), out, nf, None)
+        return out
+
+
+class Reference:
+    """The real reference encoder built by oracle/Makefile (only in trees where
+    /root/reference existed at build time)."""
+
+    def __init__(self):
+        if not os.path.exists(REF_SO):
+            raise FileNotFoundError(REF_SO)
+        self.lib = C.CDLL(REF_SO)
+        self.lib.refh_open.restype = C.c_void_p
+        self.lib.refh_encode_stream.restype = C.c_long
+
+    def encode(self, pcm, sr, brate, mode=-1, quality=-1, max_frames=0):
+        left = np.ascontiguousarray(pcm[0], dtype=np.int16)
+        right = np.ascontiguousarray(pcm[1], dtype=np.int16)
+        n = len(left)
+        h = self.lib.refh_open(sr, brate, mode, quality)
+        assert h, "reference refused the settings"
+        h = C.c_void_p(h)
+        buf = C.create_string_buffer(2 * n + 100000)
+        nf = C.c_int(0)
+        frames = (LhFrameOut * max(max_frames, 1))()
+        k = self.lib.refh_encode_stream(h, left.ctypes.data_as(C.c_void_p), right.ctypes.data_as(C.c_void_p),
+                                        C.c_long(n), buf, C.c_long(len(buf)), frames if max_frames else None,
+                                        None, max_frames, C.byref(nf))
+        cfg, tab = LhConfig(), LhTables()
+        self.lib.refh_get_config(h, C.byref(cfg))
+        self.lib.refh_get_tables(h, C.byref(tab))
+        self.lib.refh_close(h)
+        assert k >= 0
+        return buf.raw[:k], nf.value, frames, cfg, tab
+
+
+def have_reference():
+    return os.path.exists(REF_SO)
+
+
+def normalize_tables(frames):
+    """Table 14 is an estimate-only code book; the packer (like the reference's
+    encodeSideInfo2) writes 16 in its place.  Frames captured from the reference
+    after format_bitstream already carry 16."""
+    for fr in frames:
+        for g in fr.gr:
+            for gg in g:
+                for k in range(3):
+                    if gg.table_select[k] == 14:
+                        gg.table_select[k] = 16
+    return frames
