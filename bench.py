@@ -1,0 +1,181 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the MI355X-native MP3 encode inner loop.
+
+Metric (BASELINE.json): encoded audio seconds per wall-clock second (x real-time)
+at 44.1 kHz stereo CBR 128 kb/s.  A "step" is one pass of the hot path (psycho-
+acoustics + polyphase/MDCT + quantisation loop -> side-info payload in HBM) over
+one batch of synthetic streams whose PCM is already resident in HBM
+(BASELINE config[1]: batch = 1024 streams x 60 s per GPU).  With --gpus N each
+rank encodes its own 1024 streams (static sharding, no collective in the data
+path; weak scaling); rank 0 prints ONE JSON line with the whole-job aggregate.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "deprecated-lame-mirror_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+ALG_BYTES_PER_FRAME = 9792          # 4608 B PCM in + 5184 B side info out
+HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+
+
+def synth_on_device(torch, batch, n, sr, seed0, device, chunk=32):
+    """Seeded music-like stereo s16 PCM generated on the GPU (no dataset access):
+    8 partials with independent phases per channel + low-level noise + decaying
+    noise bursts every 1/3 s.  Returns an int16 tensor [batch, 2, n] on device."""
+    out = torch.empty((batch, 2, n), dtype=torch.int16, device=device)
+    t = torch.arange(n, device=device, dtype=torch.float32) / sr
+    step = sr // 3
+    env = torch.exp(-torch.arange(2000, device=device, dtype=torch.float32) / 300.0)
+    for b0 in range(0, batch, chunk):
+        b1 = min(batch, b0 + chunk)
+        g = torch.Generator(device=device)
+        g.manual_seed(0x4C414D45 + seed0 + b0)
+        x = torch.zeros((b1 - b0, 2, n), device=device)
+        for k in range(8):
+            f = 220.0 * 2 ** (k / 2.0)
+            ph = torch.rand((b1 - b0, 2, 1), generator=g, device=device) * 6.2831853
+            x += (0.5 / (k + 1)) * torch.sin(6.2831853 * f * t + ph)
+        x += 0.01 * torch.randn((b1 - b0, 2, n), generator=g, device=device)
+        for s in range(step // 2, n - 2000, step):
+            x[:, :, s:s + 2000] += 0.6 * env * torch.randn((b1 - b0, 2, 2000), generator=g, device=device)
+        x = x / x.abs().amax(dim=(1, 2), keepdim=True) * (0.8 * 32767)
+        out[b0:b1] = x.to(torch.int16)
+    return out
+
+
+def cpu_baseline(sr, brate, seconds_budget=12.0):
+    """Time the compiled reference (oracle/_ref, kind 'reference') -- or the CPU
+    restatement (kind 'port') when the reference build is absent -- on ONE host
+    core over a bounded sample of the same workload."""
+    import helpers
+    import numpy as np
+    n = sr * 20
+    pcm = helpers.synth_stream(12345, n, sr)
+    if helpers.have_reference():
+        ref = helpers.Reference()
+        kind = "reference"
+
+        def run():
+            ref.encode(pcm, sr, brate)
+    else:
+        import lamehip
+        orc = helpers.Oracle()
+        enc = lamehip.Encoder(sr, brate, require_device=False)
+        cfg, tab = enc.config(), enc.tables()
+        kind = "port"
+
+        def run():
+            orc.encode_frames(cfg, tab, pcm)
+    t0 = time.time()
+    reps = 0
+    while True:
+        run()
+        reps += 1
+        if time.time() - t0 > seconds_budget or reps >= 8:
+            break
+    dt = time.time() - t0
+    return {"value": round(reps * 20.0 / dt, 2), "unit": "x real-time", "cores": 1, "kind": kind,
+            "sample": "%d x 20 s seeded synthetic 44.1 kHz stereo, CBR %d, one host core" % (reps, brate)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--streams", type=int, default=1024, help="streams per GPU")
+    ap.add_argument("--seconds", type=float, default=60.0, help="audio seconds per stream")
+    ap.add_argument("--samplerate", type=int, default=44100)
+    ap.add_argument("--brate", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import lamehip
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback in the product path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    sr, B = args.samplerate, args.streams
+    n = int(args.seconds * sr)
+    enc = lamehip.Encoder(sr, args.brate)
+    batch = lamehip.Batch(enc, B, n)
+    # static sharding: rank r owns global streams [r*B, (r+1)*B); seeds follow the global index
+    pcm = synth_on_device(torch, B, n, sr, rank * B, dev)
+    torch.cuda.synchronize()
+    for s in range(B):
+        batch.set_pcm_device(s, pcm[s, 0].data_ptr(), pcm[s, 1].data_ptr(), n)
+    del pcm
+    torch.cuda.synchronize()
+    frames = sum(batch.frames(s) for s in range(B))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        batch.reset()
+        batch.encode()
+    kernel_ms = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        batch.reset()
+        batch.encode(sync=True)
+        kernel_ms.append(batch.kernel_ms())
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # sanity outside the timed region: the payload must survive the host packer's checks
+    nbytes = len(batch.pack(0))
+    assert nbytes > 0
+
+    if rank == 0:
+        audio_s = world * B * args.seconds * args.steps
+        value = audio_s / dt
+        kavg = sum(kernel_ms) / len(kernel_ms) / 1e3
+        achieved = frames * ALG_BYTES_PER_FRAME / kavg / 1e9
+        res = {
+            "metric": "encoded audio seconds/sec (x real-time) at 44.1kHz stereo CBR128",
+            "value": round(value, 1), "unit": "x real-time", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "batch=%d synthetic %.1f kHz stereo streams x %.0f s, CBR %d kb/s, "
+                                   "per GPU (BASELINE config[1])" % (B, sr / 1000.0, args.seconds, args.brate),
+                       "streams_per_gpu": B, "seconds_per_stream": args.seconds,
+                       "per_stream_x_realtime": round(value / (world * B), 2),
+                       "parallelism": "static stream sharding, no collective"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "kernel": "lh_encode_kernel", "kernel_ms_avg": round(kavg * 1e3, 3),
+                         "alg_bytes_per_frame": ALG_BYTES_PER_FRAME, "frames_per_launch": frames},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline(sr, args.brate)
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -591,6 +591,16 @@ lamehip_batch_set_pcm(lamehip_batch * b, int s, const short *l, const short *r, 
     return 0;
 }
 
+extern "C" int
+lamehip_batch_set_pcm_device(lamehip_batch * b, int s, const void *dl, const void *dr, long n)
+{
+    if (lamehip_batch_set_length(b, s, n) != 0)
+        return -1;
+    HIPCHK(hipMemcpy(b->d_pcm + ((size_t) s * 2) * (size_t) b->cap, dl, (size_t) n * 2, hipMemcpyDeviceToDevice));
+    HIPCHK(hipMemcpy(b->d_pcm + ((size_t) s * 2 + 1) * (size_t) b->cap, dr, (size_t) n * 2, hipMemcpyDeviceToDevice));
+    return 0;
+}
+
 extern "C" void *
 lamehip_batch_pcm_device_ptr(lamehip_batch * b)
 {

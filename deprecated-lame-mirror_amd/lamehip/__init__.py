@@ -47,6 +47,7 @@ def load_library():
     lib.lamehip_batch_create.argtypes = [C.c_void_p, C.c_int, C.c_long]
     lib.lamehip_batch_destroy.argtypes = [C.c_void_p]
     lib.lamehip_batch_set_pcm.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_long]
+    lib.lamehip_batch_set_pcm_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_long]
     lib.lamehip_batch_set_length.argtypes = [C.c_void_p, C.c_int, C.c_long]
     lib.lamehip_batch_pcm_device_ptr.restype = C.c_void_p
     lib.lamehip_batch_pcm_device_ptr.argtypes = [C.c_void_p]
@@ -146,6 +147,11 @@ class Batch:
         rc = self.lib.lamehip_batch_set_pcm(self.b, s, left.ctypes.data, right.ctypes.data, len(left))
         if rc:
             raise RuntimeError("lamehip_batch_set_pcm failed (%d): %s" % (rc, last_error()))
+
+    def set_pcm_device(self, s, dev_left_ptr, dev_right_ptr, n):
+        rc = self.lib.lamehip_batch_set_pcm_device(self.b, s, dev_left_ptr, dev_right_ptr, n)
+        if rc:
+            raise RuntimeError("lamehip_batch_set_pcm_device failed (%d): %s" % (rc, last_error()))
 
     def set_length(self, s, n):
         assert self.lib.lamehip_batch_set_length(self.b, s, n) == 0

@@ -87,6 +87,8 @@ lamehip_batch *lamehip_batch_create(const lame_t proto, int nstreams, long capac
 void    lamehip_batch_destroy(lamehip_batch *);
 /* copy one stream's planar s16 PCM host -> HBM (H2D, synchronous) */
 int     lamehip_batch_set_pcm(lamehip_batch *, int stream, const short *l, const short *r, long nsamples);
+/* same, from planar s16 buffers that already live in HBM (D2D) */
+int     lamehip_batch_set_pcm_device(lamehip_batch *, int stream, const void *dev_l, const void *dev_r, long nsamples);
 /* device pointer of the PCM pool: int16 [stream][2][capacity]; lets a producer
  * that already lives on the GPU fill it in place (then declare lengths) */
 void   *lamehip_batch_pcm_device_ptr(lamehip_batch *);

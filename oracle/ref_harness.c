@@ -324,7 +324,7 @@ refh_get_config(void *hh, LhConfig * c)
     c->subblock_gain = cfg->subblock_gain;
     c->use_best_huffman = cfg->use_best_huffman;
     c->full_outer_loop = cfg->full_outer_loop;
-    c->substep_shaping = gfc->sv_qnt.substep_shaping;
+    c->substep_shaping = gfc->sv_qnt.substep_shaping & 0x7f; /* 0x80 is run-time reservoir state */
     c->quant_comp = cfg->quant_comp;
     c->quant_comp_short = cfg->quant_comp_short;
     c->sfb21_extra = gfc->sv_qnt.sfb21_extra;

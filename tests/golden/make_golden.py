@@ -1,0 +1,85 @@
+#!/usr/bin/env python
+"""Generates the committed golden vectors from the REAL reference (oracle/_ref,
+built from /root/reference by oracle/Makefile).  Runs only in the build
+container.  Each fixture holds the recipe of its input, the reference's MP3 bytes
+and a SHA-256 per frame of the reference's side-info payload (LhFrameOut image
+captured after each lame_encode_buffer call).
+
+    python tests/golden/make_golden.py
+"""
+import hashlib
+import os
+import shutil
+import sys
+import wave
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import helpers  # noqa: E402
+
+CASES = [
+    # name, samplerate, brate, mode, quality, seed, seconds, burst_interval, white
+    ("cbr128_js_44k", 44100, 128, -1, -1, 101, 1.5, None, False),
+    ("cbr128_js_44k_white", 44100, 128, -1, -1, 102, 1.0, None, True),
+    ("cbr320_js_48k_bursts", 48000, 320, 1, -1, 103, 1.0, 1.0 / 40, False),
+    ("cbr192_st_44k", 44100, 192, 0, -1, 104, 1.0, None, False),
+    ("cbr96_js_32k", 32000, 96, -1, -1, 105, 1.0, None, False),
+    ("cbr128_js_44k_q0", 44100, 128, -1, 0, 106, 0.8, None, False),
+    ("cbr256_js_44k_q2", 44100, 256, -1, 2, 107, 0.8, None, False),
+    ("cbr160_js_44k_q5", 44100, 160, -1, 5, 108, 0.8, None, False),
+    ("cbr128_js_44k_silence", 44100, 128, -1, -1, -1, 0.5, None, False),
+]
+
+
+def frame_hash(fr):
+    return hashlib.sha256(bytes(fr)).hexdigest()
+
+
+def table_hashes(tab):
+    out = {}
+    for name, _ in tab._fields_:
+        if name in ("fft_window", "fft_window_s", "fht_tw", "ma_max_i1", "ma_max_i2", "psy_l_to_s"):
+            continue            # file-local in the reference: not visible through the harness
+        v = getattr(tab, name)
+        out[name] = hashlib.sha256(bytes(v) if not isinstance(v, (int, float)) else repr(v).encode()).hexdigest()
+    return out
+
+
+def main():
+    ref = helpers.Reference()
+    # the reference's own test input (data file of its `make test`)
+    src = "/root/reference/testcase.wav"
+    shutil.copyfile(src, os.path.join(HERE, "testcase.wav"))
+    w = wave.open(src)
+    n = w.getnframes()
+    pcm = np.frombuffer(w.readframes(n), dtype=np.int16).reshape(-1, 2).T
+    cases = [("testcase_wav_cbr128", 44100, 128, -1, -1, None, pcm)]
+    for name, sr, br, mode, q, seed, secs, burst, white in CASES:
+        nn = int(sr * secs)
+        x = np.zeros((2, nn), np.int16) if seed < 0 else helpers.synth_stream(seed, nn, sr, burst, white)
+        cases.append((name, sr, br, mode, q, (seed, secs, burst, white), x))
+    for name, sr, br, mode, q, recipe, x in cases:
+        mp3, nf, frames, cfg, tab = ref.encode(x, sr, br, mode, q, max_frames=4096)
+        hashes = [frame_hash(frames[f]) for f in range(nf)]
+        th = table_hashes(tab)
+        np.savez_compressed(
+            os.path.join(HERE, name + ".npz"),
+            samplerate=sr, brate=br, mode=mode, quality=q,
+            recipe=np.array([-2 if recipe is None else recipe[0],
+                             0 if recipe is None else recipe[1],
+                             0 if (recipe is None or recipe[2] is None) else recipe[2],
+                             0 if recipe is None else int(recipe[3])], dtype=np.float64),
+            nsamples=x.shape[1], nframes=nf,
+            mp3=np.frombuffer(mp3, dtype=np.uint8),
+            mp3_sha256=hashlib.sha256(mp3).hexdigest(),
+            frame_sha256=np.array(hashes),
+            config=np.frombuffer(bytes(cfg), dtype=np.uint8),
+            table_names=np.array(list(th.keys())), table_sha256=np.array(list(th.values())),
+            first_frames=np.frombuffer(b"".join(bytes(frames[f]) for f in range(min(nf, 3))), dtype=np.uint8))
+        print(name, "frames", nf, "bytes", len(mp3))
+
+
+if __name__ == "__main__":
+    main()

@@ -121,3 +121,58 @@ def normalize_tables(frames):
                     if gg.table_select[k] == 14:
                         gg.table_select[k] = 16
     return frames
+
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def golden_names():
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz"))
+
+
+def load_golden(name):
+    """Returns (dict of fixture fields, pcm int16 [2, n]) -- the input is rebuilt
+    from its committed recipe (or read from the reference's own testcase.wav)."""
+    import wave
+    g = dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False))
+    seed, secs, burst, white = g["recipe"]
+    sr = int(g["samplerate"])
+    if seed == -2:
+        w = wave.open(os.path.join(GOLDEN_DIR, "testcase.wav"))
+        pcm = np.frombuffer(w.readframes(w.getnframes()), dtype=np.int16).reshape(-1, 2).T
+    elif seed < 0:
+        pcm = np.zeros((2, int(g["nsamples"])), np.int16)
+    else:
+        pcm = synth_stream(int(seed), int(sr * secs), sr, burst if burst > 0 else None, bool(white))
+    assert pcm.shape[1] == int(g["nsamples"])
+    return g, np.ascontiguousarray(pcm)
+
+
+def golden_settings(g):
+    mode = int(g["mode"])
+    q = int(g["quality"])
+    return int(g["samplerate"]), int(g["brate"]), (None if mode < 0 else mode), (None if q < 0 else q)
+
+
+def frame_sha(fr):
+    import hashlib
+    return hashlib.sha256(bytes(fr)).hexdigest()
+
+
+def pack_frames(lib, cfg, tab, frames):
+    """Run the PRODUCT's host bit packer (lh_bitstream.c inside liblamehip.so) over a
+    list of LhFrameOut; returns the byte stream."""
+    bs = C.create_string_buffer(64 * 1024)
+    assert lib.lh_bs_init(bs) == 0
+    out = b""
+    tmp = C.create_string_buffer(32768)
+    for fr in frames:
+        rc = lib.lh_bs_format_frame(bs, C.byref(cfg), C.byref(tab), C.byref(fr))
+        assert rc == 0, "packer consistency check %d" % rc
+        k = lib.lh_bs_copy(bs, tmp, len(tmp))
+        out += tmp.raw[:k]
+    lib.lh_bs_flush(bs, C.byref(cfg), C.byref(frames[len(frames) - 1]) if len(frames) else None)
+    k = lib.lh_bs_copy(bs, tmp, len(tmp))
+    out += tmp.raw[:k]
+    lib.lh_bs_free(bs)
+    return out

@@ -1,0 +1,55 @@
+"""The C-ABI shared library loads on a machine without a GPU and exports every
+symbol include/lamehip.h declares; the POD layouts agree with the bindings."""
+import ctypes as C
+import os
+import re
+
+import helpers
+import lamehip
+from lamehip import types as T
+
+
+def declared_symbols():
+    txt = open(os.path.join(helpers.ROOT, "include", "lamehip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(lame_[a-zA-Z_0-9]+|lamehip_[a-zA-Z_0-9]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = lamehip.load_library()
+    syms = declared_symbols()
+    assert len(syms) > 40
+    missing = [s for s in syms if not hasattr(lib, s)]
+    assert not missing, missing
+
+
+def test_pod_sizes_match_bindings():
+    lib = lamehip.load_library()
+    assert lib.lamehip_abi_sizeof(0) == C.sizeof(T.LhConfig)
+    assert lib.lamehip_abi_sizeof(1) == C.sizeof(T.LhTables)
+    assert lib.lamehip_abi_sizeof(2) == C.sizeof(T.LhFrameOut)
+    assert lib.lamehip_abi_sizeof(3) == C.sizeof(T.LhGranule)
+
+
+def test_unsupported_settings_are_refused_loudly():
+    lib = lamehip.load_library()
+    for setup in (lambda h: lib.lame_set_num_channels(h, 1),          # mono
+                  lambda h: lib.lame_set_VBR(h, 4),                   # vbr_mtrh
+                  lambda h: lib.lame_set_in_samplerate(h, 22050),     # MPEG-2
+                  lambda h: lib.lame_set_brate(h, 64),                # reference would resample to 24 kHz
+                  lambda h: lib.lame_set_bWriteVbrTag(h, 1)):         # tag frame not produced here
+        h = C.c_void_p(lib.lame_init())
+        lib.lame_set_bWriteVbrTag(h, 0)
+        setup(h)
+        assert lib.lame_init_params(h) == -1
+        assert len(lamehip.last_error()) > 0
+        lib.lame_close(h)
+
+
+def test_encode_before_init_params_is_minus_3():
+    lib = lamehip.load_library()
+    h = C.c_void_p(lib.lame_init())
+    buf = C.create_string_buffer(8192)
+    z = (C.c_short * 1152)()
+    assert lib.lame_encode_buffer(h, z, z, 1152, buf, 8192) == -3   # reference lame.h:687-692
+    lib.lame_close(h)

