@@ -339,7 +339,7 @@ lh_encode_frame(LhCtx & c, LhLds & L, LhFrameOut * fo)
         fo->bitrate_index = (int8_t) cfg->bitrate_index;
         fo->padding = (int8_t) padding;
         fo->mode_ext = (int8_t) mode_ext;
-        for (int i = 0; i < 5; i++)
+        for (int i = 0; i < 7; i++)
             fo->pad[i] = 0;
         fo->resv_size = ResvSize;
         fo->frame_bits = frame_bits;

@@ -72,7 +72,7 @@ class LhFrameOut(C.Structure):
         ("gr", (LhGranule * 2) * 2), ("scfsi", (C.c_int8 * 4) * 2),
         ("main_data_begin", C.c_int16), ("resvDrain_pre", C.c_int16),
         ("resvDrain_post", C.c_int16), ("bitrate_index", C.c_int8), ("padding", C.c_int8),
-        ("mode_ext", C.c_int8), ("pad", C.c_int8 * 5), ("resv_size", C.c_int32),
+        ("mode_ext", C.c_int8), ("pad", C.c_int8 * 7), ("resv_size", C.c_int32),
         ("frame_bits", C.c_int32)]
 
 

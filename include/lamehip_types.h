@@ -208,7 +208,7 @@ typedef struct LhFrameOut {
     int8_t  bitrate_index;
     int8_t  padding;
     int8_t  mode_ext;
-    int8_t  pad[5];
+    int8_t  pad[7];              /* explicit: keeps resv_size 4-aligned with no hidden padding */
     int32_t resv_size;            /* ResvSize after ResvFrameEnd: cross-check for the packer */
     int32_t frame_bits;
 } LhFrameOut;
