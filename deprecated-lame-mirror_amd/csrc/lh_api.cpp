@@ -22,6 +22,9 @@ extern "C" int lh_launch_encode(const LhConfig * cfg, const LhTables * T, const 
                                 const LhStreamDesc * descs, LhStreamState * states,
                                 LhFrameOut * out, int nstreams, void *stream);
 
+extern "C" int lh_launch_selftest(unsigned *d_out, unsigned seed, void *stream);
+extern "C" int lh_launch_poison(unsigned pattern, void *stream);
+
 #define LAME_ID 0xFFF88E3Bu     /* reference util.h:482 */
 
 static thread_local char g_err[512] = "";
@@ -308,8 +311,14 @@ handle_encode_frames(lame_t g, int upto, unsigned char *mp3buf, int mp3buf_size,
     for (int i = 0; i < nf; i++) {
         int     k;
         if (lh_bs_format_frame(&g->bs, &g->cfg, g->tab, &g->h_out[(size_t) i]) != 0) {
-            snprintf(g_err, sizeof(g_err), "inconsistent device payload (packer check %d) at frame %d",
-                     g->bs.error, f0 + i);
+            int     n = snprintf(g_err, sizeof(g_err), "inconsistent device payload (packer check %d) at frame %d",
+                                 g->bs.error, f0 + i);
+            for (int q = 0; q < 4 && n > 0 && n < (int) sizeof(g_err); q++) {
+                const LhGranule *gi = &g->h_out[(size_t) i].gr[q >> 1][q & 1];
+                n += snprintf(g_err + n, sizeof(g_err) - (size_t) n, " [bv %d c1 %d gg %d bt %d ts %d/%d/%d r %d/%d]",
+                              gi->big_values, gi->count1, gi->global_gain, gi->block_type, gi->table_select[0],
+                              gi->table_select[1], gi->table_select[2], gi->region0_count, gi->region1_count);
+            }
             return LAMEHIP_ERR_PAYLOAD;
         }
         k = lh_bs_copy(&g->bs, mp3buf + *written, mp3buf_size ? mp3buf_size - *written : 0);
@@ -428,6 +437,27 @@ lame_close(lame_t g)
     free(g->tab);
     delete  g;
     return 0;
+}
+
+/* runs the device self-test of the wave primitives; returns the number of
+ * mismatches (0 = pass) or a negative error */
+extern "C" int
+lamehip_selftest(void)
+{
+    unsigned *d = nullptr, h = 0xffffffffu;
+    if (lamehip_device_count() <= 0)
+        return LAMEHIP_ERR_NODEVICE;
+    HIPCHK(hipMalloc((void **) &d, sizeof(unsigned)));
+    for (unsigned seed = 1; seed <= 4; seed++) {
+        int     rc = lh_launch_selftest(d, seed * 7919u, nullptr);
+        if (rc)
+            return set_err("selftest launch", (hipError_t) rc);
+        HIPCHK(hipMemcpy(&h, d, sizeof(h), hipMemcpyDeviceToHost));
+        if (h != 0)
+            break;
+    }
+    (void) hipFree(d);
+    return (int) h;
 }
 
 /* sizes of the POD layouts this build was compiled with (ABI check for bindings) */
@@ -694,6 +724,39 @@ lamehip_batch_get_frames(lamehip_batch * b, int s, void *frames_out, int max_fra
     HIPCHK(hipMemcpy(frames_out, b->d_out + b->out_off[(size_t) s], (size_t) n * sizeof(LhFrameOut),
                      hipMemcpyDeviceToHost));
     return n;
+}
+
+/* test aid: fill registers, LDS and scratch of the whole device with a garbage pattern */
+extern "C" int
+lamehip_debug_poison(unsigned pattern)
+{
+    int     rc = lh_launch_poison(pattern, nullptr);
+    if (rc)
+        return set_err("poison launch", (hipError_t) rc);
+    HIPCHK(hipDeviceSynchronize());
+    return 0;
+}
+
+/* debug aid: raw LhStreamState carried by a single-stream handle between launches */
+extern "C" int
+lamehip_get_state(const lame_t g, void *out, int size)
+{
+    if (!g || !g->have_device || size < (int) sizeof(LhStreamState))
+        return -1;
+    HIPCHK(hipStreamSynchronize(g->stream));
+    HIPCHK(hipMemcpy(out, g->d_state, sizeof(LhStreamState), hipMemcpyDeviceToHost));
+    return (int) sizeof(LhStreamState);
+}
+
+/* debug / profiling aid: raw LhStreamState of one stream */
+extern "C" int
+lamehip_batch_get_state(lamehip_batch * b, int s, void *out, int size)
+{
+    if (!b || s < 0 || s >= b->B || size < (int) sizeof(LhStreamState))
+        return -1;
+    HIPCHK(hipStreamSynchronize(b->stream));
+    HIPCHK(hipMemcpy(out, b->d_state + s, sizeof(LhStreamState), hipMemcpyDeviceToHost));
+    return (int) sizeof(LhStreamState);
 }
 
 extern "C" long

@@ -379,6 +379,29 @@ lh_bs_format_frame(LhBitstream * bs, const LhConfig * c, const LhTables * t, con
     int     bits, mdb;
     int const bitsPerFrame = fo->frame_bits;
 
+    /* refuse a payload whose fields would index outside the Huffman tables */
+    {
+        int     gr, ch, k;
+        for (gr = 0; gr < 2; gr++)
+            for (ch = 0; ch < 2; ch++) {
+                const LhGranule *gi = &fo->gr[gr][ch];
+                int     bad = gi->big_values < 0 || gi->big_values > 576 || gi->count1 < gi->big_values
+                    || gi->count1 > 576 || (gi->big_values & 1) || ((gi->count1 - gi->big_values) & 3)
+                    || gi->region0_count < 0 || gi->region0_count > 15 || gi->region1_count < 0
+                    || gi->region1_count > 15 || (unsigned) gi->count1table_select > 1u
+                    || (unsigned) gi->block_type > 3u || (unsigned) gi->global_gain > 255u;
+                for (k = 0; k < 3; k++)
+                    bad |= (unsigned) gi->table_select[k] > 31u || gi->table_select[k] == 4;
+                if (bad) {
+                    bs->error = 6;
+                    return -1;
+                }
+            }
+        if (bitsPerFrame <= 0 || bitsPerFrame > 8 * 2880 || fo->resvDrain_pre < 0 || fo->resvDrain_post < 0) {
+            bs->error = 6;
+            return -1;
+        }
+    }
     drain_into_ancillary(bs, c, fo->resvDrain_pre);
     /* ResvFrameEnd moved resvDrain_pre/8 bytes out of the reservoir before the
      * header was built (reference reservoir.c:279-289) */

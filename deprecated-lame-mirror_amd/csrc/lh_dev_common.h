@@ -23,6 +23,16 @@
 #define LH_SYNC_WG() __syncthreads()
 #endif
 
+#if defined(LH_PROF) && !defined(LH_EMU)
+#define LH_PT(var) unsigned long long var = clock64()
+#define LH_PA(idx, var) do { if (c.lane == 0) c.prof[idx] += clock64() - var; } while (0)
+#define LH_PC(idx) do { if (c.lane == 0) c.prof[idx] += 1; } while (0)
+#else
+#define LH_PT(var) do { } while (0)
+#define LH_PA(idx, var) do { } while (0)
+#define LH_PC(idx) do { } while (0)
+#endif
+
 LH_DEVFN float
 lh_fabsf(float x)
 {
@@ -53,6 +63,10 @@ struct LhMdctLds {
 
 /* wave-uniform scalar image of gr_info (reference l3side.h:47-84): every lane holds
  * its own identical copy in registers, so updates need no cross-lane ordering */
+/* out-of-line stages get their own copy of the context, so that the kernel's copy never has
+ * its address taken and stays in registers */
+#define LH_CTXARG const LhCtx
+
 struct LhGrR {
     int     part2_3_length, big_values, count1, global_gain, scalefac_compress;
     int     table_select[3], subblock_gain[4];
@@ -61,12 +75,66 @@ struct LhGrR {
     float   xrpow_max;
 };
 
+/* subblock_gain[w] without a dynamically indexed register array (which would force the
+ * whole struct into scratch memory) */
+LH_DEVFN int
+lh_sbg(const LhGrR & g, int w)
+{
+    return w == 0 ? g.subblock_gain[0] : w == 1 ? g.subblock_gain[1] : w == 2 ? g.subblock_gain[2] : g.subblock_gain[3];
+}
+
 /* wave-uniform per-granule geometry + the scalar part of calc_noise_data */
 struct LhQR {
     int     block_type, sfb_lmax, sfb_smin, psy_lmax, sfbmax, psymax, sfbdivide, mnc;
     int     pn_global_gain, pn_sfb_count1;
     int     substep_shaping;
 };
+
+/* copies of R / g that came back from an out-of-line stage through per-lane memory */
+LH_DEVFN LhQR
+lh_uniform(const LhQR & r)
+{
+    LhQR    o;
+    o.block_type = lh_uni_i(r.block_type);
+    o.sfb_lmax = lh_uni_i(r.sfb_lmax);
+    o.sfb_smin = lh_uni_i(r.sfb_smin);
+    o.psy_lmax = lh_uni_i(r.psy_lmax);
+    o.sfbmax = lh_uni_i(r.sfbmax);
+    o.psymax = lh_uni_i(r.psymax);
+    o.sfbdivide = lh_uni_i(r.sfbdivide);
+    o.mnc = lh_uni_i(r.mnc);
+    o.pn_global_gain = lh_uni_i(r.pn_global_gain);
+    o.pn_sfb_count1 = lh_uni_i(r.pn_sfb_count1);
+    o.substep_shaping = lh_uni_i(r.substep_shaping);
+    return o;
+}
+
+LH_DEVFN LhGrR
+lh_uniform(const LhGrR & a)
+{
+    LhGrR   o;
+    o.part2_3_length = lh_uni_i(a.part2_3_length);
+    o.big_values = lh_uni_i(a.big_values);
+    o.count1 = lh_uni_i(a.count1);
+    o.global_gain = lh_uni_i(a.global_gain);
+    o.scalefac_compress = lh_uni_i(a.scalefac_compress);
+    o.table_select[0] = lh_uni_i(a.table_select[0]);
+    o.table_select[1] = lh_uni_i(a.table_select[1]);
+    o.table_select[2] = lh_uni_i(a.table_select[2]);
+    o.subblock_gain[0] = lh_uni_i(a.subblock_gain[0]);
+    o.subblock_gain[1] = lh_uni_i(a.subblock_gain[1]);
+    o.subblock_gain[2] = lh_uni_i(a.subblock_gain[2]);
+    o.subblock_gain[3] = lh_uni_i(a.subblock_gain[3]);
+    o.region0_count = lh_uni_i(a.region0_count);
+    o.region1_count = lh_uni_i(a.region1_count);
+    o.preflag = lh_uni_i(a.preflag);
+    o.scalefac_scale = lh_uni_i(a.scalefac_scale);
+    o.count1table_select = lh_uni_i(a.count1table_select);
+    o.part2_length = lh_uni_i(a.part2_length);
+    o.count1bits = lh_uni_i(a.count1bits);
+    o.xrpow_max = lh_uni_f(a.xrpow_max);
+    return o;
+}
 
 struct LhNoiseRes {             /* calc_noise_result */
     int     over_count, over_SSD, bits;
@@ -92,7 +160,21 @@ struct LhChanLds {
     /* scratch */
     int     sfb_mode[LH_SFBMAX + 1];
     float   sfb_f[LH_SFBMAX + 1];
-    int     scr[4][64];
+    int     scr[4][24];
+};
+
+/* hot lookup tables of the quantiser, staged into LDS for the iteration-loop phase
+ * (they live behind xr in the region the PCM window occupied earlier in the frame) */
+struct LhQTabs {
+    uint32_t largetbl[256];     /* packed lengths of the two ESC code books */
+    uint32_t table23[9], table56[16];
+    uint16_t sfb_l[24];
+    uint8_t ht_len[1672];       /* code lengths, all tables back to back (lh_ht_off()) */
+    uint8_t bv_scf[576];
+    uint8_t t32l[16], t33l[16];
+    uint8_t pretab[24];
+    float   pow43h[256];        /* heads of pow43 / adj43asm: nearly all quantised values are < 256 */
+    float   adj43h[256];
 };
 
 struct LhQuantLds {
@@ -119,7 +201,14 @@ struct LhLds {
     float   pe_use[2][2];
     float   ms_ener_ratio[2];
     int     scfsi[2][4];
-    float   xr[2][2][576];      /* [ch][gr] MDCT spectra */
+    unsigned long long prof[2][12];
+    union {
+        float   mf[2][LH_MF_NEEDED];    /* scaled float PCM window of the frame (psy, polyphase) */
+        struct {
+            float   xr[2][2][576];      /* [ch][gr] MDCT spectra; written after the last read of mf */
+            LhQTabs qt;                 /* loaded after the MDCT, used by the iteration loop */
+        };
+    };
     union {
         LhPsyLds psy;
         LhMdctLds mdct;
@@ -135,21 +224,40 @@ struct LhCtx {
     const int16_t *pcm;
     LhStreamDesc d;
     long long frame_base;       /* stream sample index of mfbuf[0] for the current frame: 1152 f - 528 */
+    const float *mf;            /* LDS: mf[ch * LH_MF_NEEDED + i] = sample i of the frame window */
+    unsigned long long *prof;   /* LDS: this wave's cycle accumulators (LH_PROF builds) */
+    const LhQTabs *qt;          /* LDS: quantiser lookup tables */
     int     lane, wave, tid;
 };
 
-/* sample i of the reference's mfbuf window of the current frame: scaled PCM,
- * zero outside the stream (reference lame.c:1802-1834 scaling; :1671-1775 framing) */
+/* sample p of the stream as the reference's mfbuf holds it: scaled PCM, zero outside
+ * the stream (reference lame.c:1802-1834 scaling; :1671-1775 framing) */
 LH_DEVFN float
-lh_smp(const LhCtx & c, int ch, int i)
+lh_pcm_sample(const LhCtx & c, int ch, long long p)
 {
-    long long p = c.frame_base + i;
     if (p < 0 || p >= c.d.nsamples)
         return 0.0f;
     {
         long long off = (ch == 0 ? c.d.pcm_l : c.d.pcm_r) + (p - c.d.pcm_base);
         return (float) c.pcm[off] * c.cfg->pcm_scale;
     }
+}
+
+/* stage the 1904-sample window starting at stream sample `base' into LDS (whole workgroup) */
+LH_DEVFN void
+lh_stage_window(const LhCtx & c, float (*mf)[LH_MF_NEEDED], long long base)
+{
+    for (int t = c.tid; t < 2 * LH_MF_NEEDED; t += LH_NT) {
+        int const ch = t >= LH_MF_NEEDED, i = t - ch * LH_MF_NEEDED;
+        mf[ch][i] = lh_pcm_sample(c, ch, base + i);
+    }
+}
+
+/* sample i of the current frame window */
+LH_DEVFN float
+lh_smp(const LhCtx & c, int ch, int i)
+{
+    return c.mf[ch * LH_MF_NEEDED + i];
 }
 
 #endif

@@ -24,9 +24,14 @@
 #ifndef LH_DEVFN
 #ifdef LH_EMU
 #define LH_DEVFN static inline
+#define LH_STAGEFN static
 #define LH_DEVCONST static const
 #else
 #define LH_DEVFN __device__ __forceinline__
+/* stage-level functions are NOT inlined: one giant kernel body made the register
+ * allocator spill thousands of dwords; per-stage allocation keeps the kernel at
+ * two waves per SIMD */
+#define LH_STAGEFN __device__ __attribute__((noinline))
 #define LH_DEVCONST __device__ static const
 #endif
 #endif

@@ -31,14 +31,14 @@
 #define LH_CH0(p,q)   do { xr = a[p] - a[q]; a[p] = xr; } while (0)
 #define LH_CH(p)      do { xr = a[p] - xr; a[p] = xr; } while (0)
 
-/* one polyphase time slot (reference newmdct.c:430-814); x = frame-buffer index of wk */
+/* Polyphase time slot, split in two for the GPU (reference newmdct.c:430-814):
+ * stage 1 -- the 16 independent tap sums of a slot (15 folded window rows + the
+ * centre row), one (slot, row) unit per lane-iteration, written to pre[32];
+ * stage 2 -- the fixed 32-point butterfly network, one slot per lane, in place. */
 LH_DEVFN void
-lh_window_subband(const LhCtx & c, int ch, int x, float *out)
+lh_subband_taps(const LhCtx & c, int ch, int x, int n, float *pre)
 {
-    float   a[32];
-    float   xr;
-#pragma unroll
-    for (int n = 0; n < 15; n++) {
+    if (n < 15) {
         int const x1 = x - n;
         int const x2 = x - 62 + n;
         const float *wp = LH_ENW + 10 + 18 * n;
@@ -60,13 +60,13 @@ lh_window_subband(const LhCtx & c, int ch, int x, float *out)
         }
         s *= wp[6];
         w = t - s;
-        a[2 * n] = t + s;
-        a[2 * n + 1] = wp[7] * w;
+        pre[2 * n] = t + s;
+        pre[2 * n + 1] = wp[7] * w;
     }
-    {
+    else {
         int const x1 = x - 15;
         const float *wp = LH_ENW + 280;
-        float   s, t, u, v;
+        float   s, t;
         t = lh_smp(c, ch, x1 - 16) * wp[-10];
         s = lh_smp(c, ch, x1 - 32) * wp[-2];
         t += (lh_smp(c, ch, x1 - 48) - lh_smp(c, ch, x1 + 16)) * wp[-9];
@@ -83,10 +83,24 @@ lh_window_subband(const LhCtx & c, int ch, int x, float *out)
         s -= lh_smp(c, ch, x1 + 160) * wp[4];
         t += (lh_smp(c, ch, x1 - 240) - lh_smp(c, ch, x1 + 208)) * wp[-3];
         s -= lh_smp(c, ch, x1 + 224);
-        u = s - t;
-        v = s + t;
-        t = a[14];
-        s = a[15] - t;
+        /* u = s - t and v = s + t, combined with rows 14/15 at the start of stage 2 */
+        pre[30] = s - t;
+        pre[31] = s + t;
+    }
+}
+
+LH_STAGEFN void
+lh_subband_network(float *io)
+{
+    float   a[32];
+    float   xr;
+#pragma unroll
+    for (int i = 0; i < 32; i++)
+        a[i] = io[i];
+    {
+        float const u = a[30], v = a[31];
+        float const t = a[14];
+        float const s = a[15] - t;
         a[31] = v + t;
         a[30] = u + s;
         a[15] = u - s;
@@ -233,7 +247,7 @@ lh_window_subband(const LhCtx & c, int ch, int x, float *out)
     LH_FS(29, 2);
 #pragma unroll
     for (int i = 0; i < 32; i++)
-        out[i] = a[i];
+        io[i] = a[i];
 }
 
 /* reference newmdct.c:832-867, in place on 18 values */
@@ -333,15 +347,23 @@ lh_mdct_long(float *out, float const *in)
 
 /* polyphase filtering of the 36 slots of the current frame window of channel
  * `ch' into sb[1..2]; one wave (reference newmdct.c:958-973, 984-991) */
-LH_DEVFN void
-lh_polyphase(const LhCtx & c, int ch, float (*sb)[576])
+LH_STAGEFN void
+lh_polyphase(LH_CTXARG c, int ch, float (*sb)[576])
 {
     const float *amp = c.T->amp_filter;
+    /* stage 1: 36 slots x 16 tap rows */
+    for (int u = c.lane; u < 36 * 16; u += 64) {
+        int const s = u >> 4, n = u & 15;
+        int const gr = s / 18, slot = s - gr * 18;
+        lh_subband_taps(c, ch, 286 + 32 * s, n, &sb[1 + gr][slot * 32]);
+    }
+    LH_WAVE_SYNC();
+    /* stage 2: butterfly network per slot */
     if (c.lane < 36) {
         int const s = c.lane;
         int const gr = s / 18, slot = s - gr * 18;
         float  *out = &sb[1 + gr][slot * 32];
-        lh_window_subband(c, ch, 286 + 32 * s, out);
+        lh_subband_network(out);
         if (slot & 1) {
             /* compensate for the inversion in the analysis filter */
             for (int band = 1; band < 32; band += 2)
@@ -366,8 +388,8 @@ lh_polyphase(const LhCtx & c, int ch, float (*sb)[576])
 
 /* MDCT + alias reduction for both granules of channel ch; one wave
  * (reference newmdct.c:978-1033) */
-LH_DEVFN void
-lh_mdct_granules(const LhCtx & c, LhLds & L, int ch, float (*sb)[576])
+LH_STAGEFN void
+lh_mdct_granules(LH_CTXARG c, LhLds & L, int ch, float (*sb)[576])
 {
     const float *amp = c.T->amp_filter;
     int const gr = c.lane >> 5, band = c.lane & 31;

@@ -209,11 +209,11 @@ lh_fft_long(const LhCtx & c, int ch, int base, float *x)
         o[LH_BLKSIZE / 2 + 1] = f1 + f3;
         o[LH_BLKSIZE / 2 + 3] = f1 - f3;
     }
-    LH_WAVE_SYNC();
+    LH_WAVE_SYNC_MEM();
     for (int stage = 0, k1 = 4; stage < 4; stage++, k1 <<= 2) {
         for (int u = lane; u < LH_BLKSIZE / 8; u += 64)
             lh_fht_unit(c.T, x, stage, k1, u);
-        LH_WAVE_SYNC();
+        LH_WAVE_SYNC_MEM();
     }
 }
 
@@ -254,13 +254,13 @@ lh_fft_short(const LhCtx & c, int ch, int base, float *x)
         o[LH_BLKSIZE_S / 2 + 1] = f1 + f3;
         o[LH_BLKSIZE_S / 2 + 3] = f1 - f3;
     }
-    LH_WAVE_SYNC();
+    LH_WAVE_SYNC_MEM();
     for (int stage = 0, k1 = 4; stage < 3; stage++, k1 <<= 2) {
         for (int t = lane; t < 3 * (LH_BLKSIZE_S / 8); t += 64) {
             int const b = t >> 5, u = t & 31;
             lh_fht_unit(c.T, x + b * LH_BLKSIZE_S, stage, k1, u);
         }
-        LH_WAVE_SYNC();
+        LH_WAVE_SYNC_MEM();
     }
 }
 
@@ -423,10 +423,10 @@ lh_compute_masking(const LhCtx & c, int chn, int is_long, const float *energy, f
         smax[b] = m;
         savg[b] = ebb * gd->rnumlines[b];
     }
-    LH_WAVE_SYNC();
+    LH_WAVE_SYNC_MEM();
     if (b < np)
         sidx[b] = lh_mask_index(gd, smax, savg, b);
-    LH_WAVE_SYNC();
+    LH_WAVE_SYNC_MEM();
     if (b < np) {
         float   x, ecb, avg_mask, t;
         float const masking_lower = gd->masking_lower[b] * c.st->masking_lower;
@@ -498,7 +498,7 @@ lh_compute_masking(const LhCtx & c, int chn, int is_long, const float *energy, f
         eb[b] = 0;
         thr[b] = 0;
     }
-    LH_WAVE_SYNC();
+    LH_WAVE_SYNC_MEM();
 }
 
 /* reference psymodel.c:1326-1388; one lane per partition, eb/thr are [4][64] in LDS */
@@ -602,8 +602,8 @@ lh_pecalc(const LhTables * T, const float *en, const float *thm, float masking_l
 /* ------------------------------------------------------------------ */
 /* One granule of the psycho-acoustic model for the whole workgroup     */
 /* (reference L3psycho_anal_vbr, psymodel.c:1397-1597).                 */
-LH_DEVFN void
-lh_psy_granule(const LhCtx & c, LhLds & L, int gr)
+LH_STAGEFN void
+lh_psy_granule(LH_CTXARG c, LhLds & L, int gr)
 {
     const LhConfig *cfg = c.cfg;
     const LhTables *T = c.T;
@@ -671,7 +671,7 @@ lh_psy_granule(const LhCtx & c, LhLds & L, int gr)
                     attack_intensity[i] = en_subshort[i] / st->last_en_subshort[chn][i + 4];
                     en_short[0] += en_subshort[i];
                 }
-                LH_WAVE_SYNC();
+                LH_WAVE_SYNC_MEM();
                 for (int i = 0; i < 9; i++) {
                     float   p = peak[i];
                     if (lane == 0)
@@ -732,7 +732,7 @@ lh_psy_granule(const LhCtx & c, LhLds & L, int gr)
                 L.ns_uselong[chn] = ns_uselongblock;
             }
         }
-        LH_WAVE_SYNC();
+        LH_WAVE_SYNC_MEM();
     }
     LH_SYNC_WG();
     {
@@ -764,7 +764,7 @@ lh_psy_granule(const LhCtx & c, LhLds & L, int gr)
         if (chn < n_chn_psy)
             lh_fft_energy(c, chn, P.wsamp[0], P.wsamp[1], LH_BLKSIZE, P.b.energy[chn]);
     }
-    LH_WAVE_SYNC();
+    LH_WAVE_SYNC_MEM();
     /* (5) serial sums: total energy (bins 11..512) and loudness (reference psymodel.c:213-226,
      * 690-696): lane 0/1 = tot_ener of chn w / w+2, lane 2 = loudness of channel w */
     if (lane < 3) {
@@ -827,7 +827,7 @@ lh_psy_granule(const LhCtx & c, LhLds & L, int gr)
             if (chn < n_chn_psy && !L.uselongblock[chn & 1]) {
                 lh_fft_energy(c, chn, &P.wsamp[0][sblock * LH_BLKSIZE_S],
                               &P.wsamp[1][sblock * LH_BLKSIZE_S], LH_BLKSIZE_S, P.b.energy[chn]);
-                LH_WAVE_SYNC();
+                LH_WAVE_SYNC_MEM();
                 lh_compute_masking(c, chn, 0, P.b.energy[chn], &P.eb[chn * 64], &P.thr[chn * 64],
                                    P.smax[w], P.savg[w], P.sidx[w], L.pstart_s);
             }

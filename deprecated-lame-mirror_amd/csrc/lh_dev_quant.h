@@ -37,12 +37,58 @@ LH_DEVCONST int lh_scale_short[16] = { 0, 18, 36, 54, 54, 36, 54, 72, 54, 72, 90
 LH_DEVCONST int lh_scale_long[16] = { 0, 10, 20, 30, 33, 21, 31, 41, 32, 42, 52, 43, 53, 63, 64, 74 };
 LH_DEVCONST int lh_huf_tbl_noESC[15] = { 1, 2, 5, 7, 7, 10, 10, 13, 13, 13, 13, 13, 13, 13, 13 };
 
-#define LH_HLEN(t)  (lh_ht_len + lh_ht_offset[t])
+/* Huffman table metadata as immediates (ISO 11172-3 table B.7; equality with the
+ * generated lh_ht_xlen / lh_ht_linmax / lh_ht_offset arrays is asserted by
+ * tests/test_abi.py::test_huffman_immediates).  Avoids chains of dependent loads. */
+LH_DEVFN int
+lh_ht_off(int t)
+{
+    switch (t) {
+    case 1: return 0;
+    case 2: return 4;
+    case 3: return 13;
+    case 5: return 22;
+    case 6: return 38;
+    case 7: return 54;
+    case 8: return 90;
+    case 9: return 126;
+    case 10: return 162;
+    case 11: return 226;
+    case 12: return 290;
+    case 13: return 354;
+    case 14: return 610;
+    case 15: return 866;
+    default: return (t >= 32) ? (t == 32 ? 1634 : 1650) : (t >= 24 ? 1378 : 1122);
+    }
+}
+
+LH_DEVFN unsigned
+lh_ht_xlen_c(int t)
+{
+    /* tables 0..15: alphabet size per dimension; 16..31: linbits; one byte per table */
+    unsigned long long const k = (t < 8) ? 0x0604040003030200ull
+        : (t < 16) ? 0x1000100808080606ull : (t < 24) ? 0x0D0A080604030201ull : 0x0D0B090807060504ull;
+    return (unsigned) ((k >> (8 * (t & 7))) & 0xffu);
+}
+
+LH_DEVFN unsigned
+lh_ht_linmax_c(int t)
+{
+    return (1u << lh_ht_xlen_c(t)) - 1u;        /* tables 16..31 */
+}
+
+LH_DEVFN int
+lh_huf_noESC(unsigned mx)       /* first candidate table for a region maximum 1..15 */
+{
+    return mx == 1 ? 1 : mx == 2 ? 2 : mx == 3 ? 5 : mx <= 5 ? 7 : mx <= 7 ? 10 : 13;
+}
+
+#define LH_HLEN(t)  (qt->ht_len + lh_ht_off(t))
 
 /* ---------------------------------------------------------------------- */
 /* one line through the x^(3/4) quantiser (reference takehiro.c:144-200)     */
 LH_DEVFN int
-lh_quant_line(const LhTables * T, float istep, float xp)
+lh_quant_line(const LhTables * T, const LhQTabs * qt, float istep, float xp)
 {
     double  x0 = (double) (istep * xp);
     float   f;
@@ -50,7 +96,7 @@ lh_quant_line(const LhTables * T, float istep, float xp)
     x0 += LH_MAGIC_FLOAT;
     f = (float) x0;
     k = (int) lh_f32_as_u32(f) - LH_MAGIC_INT;
-    f = (float) (x0 + T->adj43asm[k]);
+    f = (float) (x0 + ((k < 256) ? qt->adj43h[k] : T->adj43asm[k]));
     return (int) lh_f32_as_u32(f) - LH_MAGIC_INT;
 }
 
@@ -60,6 +106,7 @@ lh_quant_line(const LhTables * T, float istep, float xp)
 LH_DEVFN int
 lh_choose_table_wave(const LhCtx & c, const int v[5][2], int lo, int hi, int *bits)
 {
+    const LhQTabs *qt = c.qt;
     unsigned mx = 0;
     int const plo = lo >> 1, phi = hi >> 1;
 #pragma unroll
@@ -88,9 +135,9 @@ lh_choose_table_wave(const LhCtx & c, const int v[5][2], int lo, int hi, int *bi
             return 1;
         }
         if (mx <= 3) {
-            int     t1 = lh_huf_tbl_noESC[mx - 1];
-            unsigned const xlen = lh_ht_xlen[t1];
-            const uint32_t *table = (t1 == 2) ? lh_table23 : lh_table56;
+            int     t1 = lh_huf_noESC(mx);
+            unsigned const xlen = lh_ht_xlen_c(t1);
+            const uint32_t *table = (t1 == 2) ? qt->table23 : qt->table56;
             unsigned s = 0, s2;
 #pragma unroll
             for (int k = 0; k < 5; k++) {
@@ -109,10 +156,10 @@ lh_choose_table_wave(const LhCtx & c, const int v[5][2], int lo, int hi, int *bi
             return t1;
         }
         {
-            int const t1 = lh_huf_tbl_noESC[mx - 1];
-            unsigned const xlen = lh_ht_xlen[t1];
+            int const t1 = lh_huf_noESC(mx);
+            unsigned const xlen = lh_ht_xlen_c(t1);
             const uint8_t *h1 = LH_HLEN(t1), *h2 = LH_HLEN(t1 + 1), *h3 = LH_HLEN(t1 + 2);
-            uint64_t s = 0;
+            unsigned w0 = 0, w1 = 0;
             unsigned s1, s2, s3;
             int     t;
 #pragma unroll
@@ -120,13 +167,15 @@ lh_choose_table_wave(const LhCtx & c, const int v[5][2], int lo, int hi, int *bi
                 int const p = c.lane + 64 * k;
                 if (p >= plo && p < phi) {
                     unsigned const x = (unsigned) v[k][0] * xlen + (unsigned) v[k][1];
-                    s += (uint64_t) h1[x] | ((uint64_t) h2[x] << 20) | ((uint64_t) h3[x] << 40);
+                    w0 += (unsigned) h1[x] | ((unsigned) h2[x] << 16);
+                    w1 += (unsigned) h3[x];
                 }
             }
-            s = lh_wave_sum_u64(s);
-            s1 = (unsigned) (s & 0xfffffu);
-            s2 = (unsigned) ((s >> 20) & 0xfffffu);
-            s3 = (unsigned) ((s >> 40) & 0xfffffu);
+            w0 = lh_wave_sum_u32(w0);
+            w1 = lh_wave_sum_u32(w1);
+            s1 = w0 & 0xffffu;
+            s2 = w0 >> 16;
+            s3 = w1;
             t = t1;
             if (s1 > s2) {
                 s1 = s2;
@@ -147,36 +196,36 @@ lh_choose_table_wave(const LhCtx & c, const int v[5][2], int lo, int hi, int *bi
     {
         int     choice, choice2;
         unsigned const m15 = mx - 15u;
-        uint64_t s = 0;
+        unsigned w0 = 0, w1 = 0;
         unsigned sa, sb, n15;
         for (choice2 = 24; choice2 < 32; choice2++)
-            if (lh_ht_linmax[choice2] >= m15)
+            if (lh_ht_linmax_c(choice2) >= m15)
                 break;
         for (choice = choice2 - 8; choice < 24; choice++)
-            if (lh_ht_linmax[choice] >= m15)
+            if (lh_ht_linmax_c(choice) >= m15)
                 break;
 #pragma unroll
         for (int k = 0; k < 5; k++) {
             int const p = c.lane + 64 * k;
             if (p >= plo && p < phi) {
                 unsigned x = (unsigned) v[k][0], y = (unsigned) v[k][1];
-                unsigned cnt = 0, e;
+                unsigned e;
                 if (x >= 15u) {
                     x = 15u;
-                    cnt++;
+                    w1++;
                 }
                 if (y >= 15u) {
                     y = 15u;
-                    cnt++;
+                    w1++;
                 }
-                e = lh_largetbl[(x << 4) + y];
-                s += (uint64_t) (e >> 16) | ((uint64_t) (e & 0xffffu) << 20) | ((uint64_t) cnt << 40);
+                e = qt->largetbl[(x << 4) + y];
+                w0 += e;        /* high half: table 16.. lengths, low half: table 24.. lengths */
             }
         }
-        s = lh_wave_sum_u64(s);
-        n15 = (unsigned) (s >> 40);
-        sa = (unsigned) (s & 0xfffffu) + n15 * lh_ht_xlen[choice];
-        sb = (unsigned) ((s >> 20) & 0xfffffu) + n15 * lh_ht_xlen[choice2];
+        w0 = lh_wave_sum_u32(w0);
+        n15 = lh_wave_sum_u32(w1);
+        sa = (w0 >> 16) + n15 * lh_ht_xlen_c(choice);
+        sb = (w0 & 0xffffu) + n15 * lh_ht_xlen_c(choice2);
         if (sa > sb) {
             sa = sb;
             choice = choice2;
@@ -189,7 +238,7 @@ lh_choose_table_wave(const LhCtx & c, const int v[5][2], int lo, int hi, int *bi
 /* the same selection done serially by ONE lane over ix[lo,hi) in LDS; used where
  * many independent regions are evaluated at once, one per lane (best_huffman_divide) */
 LH_DEVFN int
-lh_choose_table_lane(const int16_t * ix, int lo, int hi, int *bits)
+lh_choose_table_lane(const LhQTabs * qt, const int16_t * ix, int lo, int hi, int *bits)
 {
     unsigned mx = 0;
     for (int i = lo; i < hi; i++) {
@@ -208,9 +257,9 @@ lh_choose_table_lane(const int16_t * ix, int lo, int hi, int *bits)
             return 1;
         }
         if (mx <= 3) {
-            int     t1 = lh_huf_tbl_noESC[mx - 1];
-            unsigned const xlen = lh_ht_xlen[t1];
-            const uint32_t *table = (t1 == 2) ? lh_table23 : lh_table56;
+            int     t1 = lh_huf_noESC(mx);
+            unsigned const xlen = lh_ht_xlen_c(t1);
+            const uint32_t *table = (t1 == 2) ? qt->table23 : qt->table56;
             unsigned s = 0, s2;
             for (int i = lo; i < hi; i += 2)
                 s += table[(unsigned) ix[i] * xlen + (unsigned) ix[i + 1]];
@@ -224,8 +273,8 @@ lh_choose_table_lane(const int16_t * ix, int lo, int hi, int *bits)
             return t1;
         }
         {
-            int const t1 = lh_huf_tbl_noESC[mx - 1];
-            unsigned const xlen = lh_ht_xlen[t1];
+            int const t1 = lh_huf_noESC(mx);
+            unsigned const xlen = lh_ht_xlen_c(t1);
             const uint8_t *h1 = LH_HLEN(t1), *h2 = LH_HLEN(t1 + 1), *h3 = LH_HLEN(t1 + 2);
             unsigned s1 = 0, s2 = 0, s3 = 0;
             int     t;
@@ -257,10 +306,10 @@ lh_choose_table_lane(const int16_t * ix, int lo, int hi, int *bits)
         unsigned const m15 = mx - 15u;
         unsigned sa = 0, sb = 0, n15 = 0;
         for (choice2 = 24; choice2 < 32; choice2++)
-            if (lh_ht_linmax[choice2] >= m15)
+            if (lh_ht_linmax_c(choice2) >= m15)
                 break;
         for (choice = choice2 - 8; choice < 24; choice++)
-            if (lh_ht_linmax[choice] >= m15)
+            if (lh_ht_linmax_c(choice) >= m15)
                 break;
         for (int i = lo; i < hi; i += 2) {
             unsigned x = (unsigned) ix[i], y = (unsigned) ix[i + 1], e;
@@ -272,12 +321,12 @@ lh_choose_table_lane(const int16_t * ix, int lo, int hi, int *bits)
                 y = 15u;
                 n15++;
             }
-            e = lh_largetbl[(x << 4) + y];
+            e = qt->largetbl[(x << 4) + y];
             sa += e >> 16;
             sb += e & 0xffffu;
         }
-        sa += n15 * lh_ht_xlen[choice];
-        sb += n15 * lh_ht_xlen[choice2];
+        sa += n15 * lh_ht_xlen_c(choice);
+        sb += n15 * lh_ht_xlen_c(choice2);
         if (sa > sb) {
             sa = sb;
             choice = choice2;
@@ -292,6 +341,7 @@ LH_DEVFN int
 lh_noquant_count_bits(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, int which, int use_prev)
 {
     const LhTables *T = c.T;
+    const LhQTabs *qt = c.qt;
     const int16_t *ix = Q.ix[which];
     int     v[5][2];
     int     bits, i, a1, a2;
@@ -332,7 +382,7 @@ lh_noquant_count_bits(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, int w
         for (int qd = c.lane; qd < nquad; qd += 64) {
             int const b = bv + 4 * qd;
             int const p = ((ix[b] * 2 + ix[b + 1]) * 2 + ix[b + 2]) * 2 + ix[b + 3];
-            s += ((unsigned) lh_t32l[p] << 16) + (unsigned) lh_t33l[p];
+            s += ((unsigned) qt->t32l[p] << 16) + (unsigned) qt->t33l[p];
         }
         s = lh_wave_sum_u32(s);
         a1 = (int) (s >> 16);
@@ -357,17 +407,17 @@ lh_noquant_count_bits(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, int w
         a2 = g.big_values;
     }
     else if (R.block_type == LH_NORM_TYPE) {
-        a1 = g.region0_count = T->bv_scf[i - 2];
-        a2 = g.region1_count = T->bv_scf[i - 1];
-        a2 = T->sfb_l[a1 + a2 + 2];
-        a1 = T->sfb_l[a1 + 1];
+        a1 = g.region0_count = qt->bv_scf[i - 2];
+        a2 = g.region1_count = qt->bv_scf[i - 1];
+        a2 = qt->sfb_l[a1 + a2 + 2];
+        a1 = qt->sfb_l[a1 + 1];
         if (a2 < i)
             g.table_select[2] = lh_choose_table_wave(c, v, a2, i, &bits);
     }
     else {
         g.region0_count = 7;
         g.region1_count = LH_SBMAX_L - 1 - 7 - 1;
-        a1 = T->sfb_l[7 + 1];
+        a1 = qt->sfb_l[7 + 1];
         a2 = i;
         if (a1 > a2)
             a1 = a2;
@@ -381,10 +431,9 @@ lh_noquant_count_bits(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, int w
     /* use_best_huffman == 2 (best_huffman_divide inside the loop) is not selected by any quality level */
     if (use_prev) {
         if (R.block_type == LH_NORM_TYPE) {
-            int     sfb = 0;
-            while (T->sfb_l[sfb] < g.big_values)
-                sfb++;
-            R.pn_sfb_count1 = sfb;
+            /* first band whose start is >= big_values (band starts ascend) */
+            uint64_t const below = lh_ballot(c.lane < LH_SBMAX_L + 1 && (int) qt->sfb_l[c.lane < 23 ? c.lane : 22] < g.big_values);
+            R.pn_sfb_count1 = lh_popc64(below);
         }
     }
     return bits;
@@ -394,7 +443,9 @@ lh_noquant_count_bits(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, int w
 LH_DEVFN int
 lh_count_bits(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, int which, int use_prev)
 {
+    LH_PC(10);
     const LhTables *T = c.T;
+    const LhQTabs *qt = c.qt;
     int16_t *ix = Q.ix[which];
     const int *sf = Q.sf[which];
     const float *xrpow = Q.xrpow;
@@ -402,67 +453,78 @@ lh_count_bits(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, int which, in
     float const w = (LH_IXMAX) / istep;
     int const mnc = R.mnc;
     int const sfbmax = (R.block_type == LH_SHORT_TYPE) ? 38 : 21;
-    int     s_trunc, l_trunc = 0, j_trunc = 0;
+    int     zero_mnc;
 
     if (g.xrpow_max > w)
         return LH_LARGE_BITS;
+    /* Per band (lane = band): unchanged step -> keep the old values; count1 region with a
+     * coarser step -> 0/1 comparator; else the full quantiser (reference
+     * quantize_xrpow, takehiro.c:281-414).
+     * Invariant kept by this file: lines above max_nonzero_coeff (mnc) are zero in both
+     * quantised images from lh_zero_tail() on, which is what the reference's memset
+     * re-establishes on every call; so only lines <= mnc are visited.  One quirk of the
+     * reference survives: when the band that holds line mnc is kept but a later band is
+     * not, its memset clears line mnc itself. */
     {
         int const prev_data_use = (use_prev && (g.global_gain == R.pn_global_gain));
         int const s = c.lane;
-        int     cand = 0;
+        int     noncached = 0;
+        int const s_m = Q.sfb_of_line[mnc];
         if (s <= sfbmax) {
-            int     step = -1, cached, m01, mode;
+            int     step = -1, cached, m01;
             if (prev_data_use || R.block_type == LH_NORM_TYPE) {
-                int const pre = (g.preflag && s < LH_SBMAX_L) ? lh_pretab[s] : 0;
+                int const pre = (g.preflag && s < LH_SBMAX_L) ? qt->pretab[s] : 0;
                 step = g.global_gain - ((sf[s] + pre) << (g.scalefac_scale + 1))
-                    - g.subblock_gain[Q.window[s]] * 8;
+                    - lh_sbg(g, Q.window[s]) * 8;
             }
             cached = prev_data_use && (Q.pn_step[s] == step);
             m01 = use_prev && R.pn_sfb_count1 > 0 && s >= R.pn_sfb_count1 && Q.pn_step[s] > 0
                 && step >= Q.pn_step[s];
-            mode = cached ? 0 : (m01 ? 2 : 1);
-            Q.sfb_mode[s] = mode;
-            cand = !cached && (Q.start[s] + Q.width[s] > mnc);
+            Q.sfb_mode[s] = cached ? 0 : (m01 ? 2 : 1);
+            noncached = !cached;
         }
         {
-            uint64_t const m = lh_ballot(cand);
-            s_trunc = lh_ffs64(m);
-        }
-        if (s_trunc >= 0) {
-            j_trunc = Q.start[s_trunc];
-            l_trunc = mnc - j_trunc + 1;
-            if (l_trunc < 0)
-                l_trunc = 0;
+            uint64_t const nc = lh_ballot(noncached);
+            int const cached_m = !((nc >> s_m) & 1);
+            int const later = (s_m < 63) ? ((nc >> (s_m + 1)) != 0) : 0;
+            zero_mnc = cached_m && later;
         }
     }
     LH_WAVE_SYNC();
     {
+        /* batched load levels (band id, band mode, xrpow) instead of a dependent chain per line */
         float const compareval0 = (1.0f - 0.4054f) / istep;
-        for (int p = c.lane; p < 288; p += 64) {
+        int const pm = mnc >> 1;        /* last pair that holds a line <= mnc (mnc is odd) */
+        int     md[5];
+        float   xp[10];
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                int const i = 2 * p + h;
-                int const s = Q.sfb_of_line[i];
-                int     mode;
-                if (s > sfbmax)
-                    mode = 0;   /* lines above the last coded band are never touched by the loop */
-                else
-                    mode = Q.sfb_mode[s];
-                if (s_trunc >= 0) {
-                    if (s > s_trunc)
-                        mode = 0;
-                    if (s == s_trunc && !(i < j_trunc + l_trunc))
-                        mode = 0;
-                    if (i >= mnc && !(s == s_trunc && i < j_trunc + l_trunc))
-                        mode = 3;       /* zeroed by the reference's memset */
-                }
-                if (mode == 1)
-                    ix[i] = (int16_t) lh_quant_line(T, istep, xrpow[i]);
-                else if (mode == 2)
-                    ix[i] = (compareval0 > xrpow[i]) ? 0 : 1;
-                else if (mode == 3)
-                    ix[i] = 0;
+        for (int k = 0; k < 5; k++) {
+            int const p = c.lane + 64 * k;
+            md[k] = (p <= pm) ? Q.sfb_of_line[2 * p] : -1;
+        }
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            int const p = c.lane + 64 * k;
+            md[k] = (md[k] >= 0) ? Q.sfb_mode[md[k]] : 0;
+            xp[2 * k] = (p <= pm) ? xrpow[2 * p] : 0.0f;
+            xp[2 * k + 1] = (p <= pm) ? xrpow[2 * p + 1] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            int const p = c.lane + 64 * k;
+            if (md[k] == 1) {
+                int const q0 = lh_quant_line(T, qt, istep, xp[2 * k]);
+                int const q1 = lh_quant_line(T, qt, istep, xp[2 * k + 1]);
+                ((uint32_t *) ix)[p] = (uint32_t) (q0 & 0xffff) | ((uint32_t) q1 << 16);
             }
+            else if (md[k] == 2) {
+                uint32_t const q0 = (compareval0 > xp[2 * k]) ? 0u : 1u;
+                uint32_t const q1 = (compareval0 > xp[2 * k + 1]) ? 0u : 1u;
+                ((uint32_t *) ix)[p] = q0 | (q1 << 16);
+            }
+        }
+        if (zero_mnc && c.lane == (pm & 63)) {
+            ix[mnc] = 0;
         }
     }
     LH_WAVE_SYNC();
@@ -480,37 +542,36 @@ lh_count_bits(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, int which, in
 }
 
 /* ---------------------------------------------------------------------- */
-/* reference takehiro.c:1135-1188 (MPEG-1) */
+/* reference takehiro.c:1135-1188 (MPEG-1); band s on lane s, maxima by wave reduction */
 LH_DEVFN int
 lh_scale_bitcount(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g, int which)
 {
+    const LhQTabs *qt = c.qt;
     int    *sf = Q.sf[which];
-    int     k, sfb, max_slen1 = 0, max_slen2 = 0;
+    int     k, max_slen1, max_slen2;
     const int *tabp;
+    int     v;
     LH_WAVE_SYNC();
+    v = (c.lane < R.sfbmax) ? sf[c.lane] : 0;
     if (R.block_type == LH_SHORT_TYPE)
         tabp = lh_scale_short;
     else {
         tabp = lh_scale_long;
         if (!g.preflag) {
-            for (sfb = 11; sfb < LH_SBPSY_L; sfb++)
-                if (sf[sfb] < lh_pretab[sfb])
-                    break;
-            if (sfb == LH_SBPSY_L) {
+            int const inr = (c.lane >= 11 && c.lane < LH_SBPSY_L);
+            uint64_t const below = lh_ballot(inr && v < (int) qt->pretab[inr ? c.lane : 0]);
+            if (below == 0) {
                 g.preflag = 1;
-                LH_WAVE_SYNC();
-                if (c.lane >= 11 && c.lane < LH_SBPSY_L)
-                    sf[c.lane] -= lh_pretab[c.lane];
+                if (inr) {
+                    v -= qt->pretab[c.lane];
+                    sf[c.lane] = v;
+                }
                 LH_WAVE_SYNC();
             }
         }
     }
-    for (sfb = 0; sfb < R.sfbdivide; sfb++)
-        if (max_slen1 < sf[sfb])
-            max_slen1 = sf[sfb];
-    for (; sfb < R.sfbmax; sfb++)
-        if (max_slen2 < sf[sfb])
-            max_slen2 = sf[sfb];
+    max_slen1 = (int) lh_wave_max_u32((c.lane < R.sfbdivide && v > 0) ? (unsigned) v : 0u);
+    max_slen2 = (int) lh_wave_max_u32((c.lane >= R.sfbdivide && c.lane < R.sfbmax && v > 0) ? (unsigned) v : 0u);
     g.part2_length = LH_LARGE_BITS;
     for (k = 0; k < 16; k++) {
         if (max_slen1 < lh_slen1_n[k] && max_slen2 < lh_slen2_n[k] && g.part2_length > tabp[k]) {
@@ -541,12 +602,13 @@ lh_ath_adjust(const LhTables * T, float a, float x, float athFloor, float ATHfix
 }
 
 /* reference quantize_pvt.c:589-747: one lane per scalefactor band (window) */
-LH_DEVFN void
-lh_calc_xmin(const LhCtx & c, LhChanLds & Q, LhQR & R, const float *xr, const float *ren,
+LH_STAGEFN void
+lh_calc_xmin(LH_CTXARG c, LhChanLds & Q, LhQR & R, const float *xr, const float *ren,
              const float *rthm)
 {
     const LhConfig *cfg = c.cfg;
     const LhTables *T = c.T;
+    const LhQTabs *qt = c.qt;
     int const s = c.lane;
     float const adj = c.st->ath_adjust_factor;
     if (s < R.psymax) {
@@ -612,7 +674,7 @@ lh_calc_xmin(const LhCtx & c, LhChanLds & Q, LhQR & R, const float *xr, const fl
         if (cfg->sfb21_extra == 0 && cfg->samplerate < 44000) {
             int     limit;
             if (R.block_type != LH_SHORT_TYPE)
-                limit = T->sfb_l[21] - 1;
+                limit = qt->sfb_l[21] - 1;
             else
                 limit = 3 * T->sfb_s[12] - 1;
             if (max_nonzero > limit)
@@ -639,14 +701,16 @@ lh_calc_noise(const LhCtx & c, LhChanLds & Q, LhQR & R, const LhGrR & g, int whi
               const float *xr, LhNoiseRes & res, int use_prev)
 {
     const LhTables *T = c.T;
+    const LhQTabs *qt = c.qt;
     const int16_t *ix = Q.ix[which];
     const int *sf = Q.sf[which];
     int const s = c.lane;
+    float   noise_s = 0.0f;
     LH_WAVE_SYNC();
     if (s < R.psymax) {
-        int const pre = (g.preflag && s < LH_SBMAX_L) ? lh_pretab[s] : 0;
+        int const pre = (g.preflag && s < LH_SBMAX_L) ? qt->pretab[s] : 0;
         int const st = g.global_gain - ((sf[s] + pre) << (g.scalefac_scale + 1))
-            - g.subblock_gain[Q.window[s]] * 8;
+            - lh_sbg(g, Q.window[s]) * 8;
         float const r_l3_xmin = 1.f / Q.l3_xmin[s];
         float   distort_, noise;
         if (use_prev && (Q.pn_step[s] == st)) {
@@ -664,38 +728,17 @@ lh_calc_noise(const LhCtx & c, LhChanLds & Q, LhQR & R, const LhGrR & g, int whi
                 l = (usefullsize > 0) ? (usefullsize >> 1) : 0;
             }
             noise = 0;
-            if (j > g.count1) {
-                while (l--) {
-                    float   temp;
-                    temp = xr[j];
-                    j++;
-                    noise += temp * temp;
-                    temp = xr[j];
-                    j++;
-                    noise += temp * temp;
-                }
-            }
-            else if (j > g.big_values) {
-                while (l--) {
-                    float   temp;
-                    temp = lh_fabsf(xr[j]) - (ix[j] ? step : 0.0f);
-                    j++;
-                    noise += temp * temp;
-                    temp = lh_fabsf(xr[j]) - (ix[j] ? step : 0.0f);
-                    j++;
-                    noise += temp * temp;
-                }
-            }
-            else {
-                while (l--) {
-                    float   temp;
-                    temp = lh_fabsf(xr[j]) - T->pow43[ix[j]] * step;
-                    j++;
-                    noise += temp * temp;
-                    temp = lh_fabsf(xr[j]) - T->pow43[ix[j]] * step;
-                    j++;
-                    noise += temp * temp;
-                }
+            /* One loop for the reference's three cases (calc_noise_core_c,
+             * quantize_pvt.c:750-796): above count1 every ix is 0 and pow43[0]*step = 0,
+             * so |xr| - 0 squares to xr*xr; in the count1 region ix is 0/1 and
+             * pow43[1] = 1.0f makes pow43[ix]*step equal to {0, step} exactly.  The adds
+             * form one serial chain per band (float order matters); the loads do not
+             * depend on it, so the loop is unrolled to keep them in flight. */
+#pragma unroll 8
+            for (int k = 0; k < 2 * l; k++) {
+                int const q = ix[j + k];
+                float const temp = lh_fabsf(xr[j + k]) - ((q < 256) ? qt->pow43h[q] : T->pow43[q]) * step;
+                noise += temp * temp;
             }
             if (use_prev) {
                 Q.pn_step[s] = st;
@@ -708,16 +751,17 @@ lh_calc_noise(const LhCtx & c, LhChanLds & Q, LhQR & R, const LhGrR & g, int whi
                 Q.pn_noise_log[s] = noise;
         }
         Q.distort[s] = distort_;
-        Q.sfb_f[s] = noise;
+        noise_s = noise;
     }
     if (use_prev)
         R.pn_global_gain = g.global_gain;
-    LH_WAVE_SYNC();
     {
+        /* serial (order-preserving) accumulation over the bands, values fetched from
+         * the owning lane's register */
         int     over = 0, ssd = 0;
         float   over_noise_db = 0, tot_noise_db = 0, max_noise = -20.0f;
         for (int sfb = 0; sfb < R.psymax; sfb++) {
-            float const noise = Q.sfb_f[sfb];
+            float const noise = lh_u32_as_f32(lh_bcast_u32(lh_f32_as_u32(noise_s), sfb));
             tot_noise_db += noise;
             if (noise > 0.0) {
                 int     tmp = (int) (noise * 10 + .5);
@@ -741,11 +785,12 @@ lh_calc_noise(const LhCtx & c, LhChanLds & Q, LhQR & R, const LhGrR & g, int whi
 /* ---------------------------------------------------------------------- */
 /* geometry of the granule + spectrum re-ordering for short blocks
  * (reference quantize.c:226-346) */
-LH_DEVFN void
-lh_init_outer_loop(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, float *xr, int block_type,
+LH_STAGEFN void
+lh_init_outer_loop(LH_CTXARG c, LhChanLds & Q, LhQR & R, LhGrR & g, float *xr, int block_type,
                    int substep)
 {
     const LhTables *T = c.T;
+    const LhQTabs *qt = c.qt;
     int const sfb21 = c.cfg->sfb21_extra;
     g.part2_3_length = 0;
     g.big_values = 0;
@@ -798,9 +843,9 @@ lh_init_outer_loop(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, float *x
             Q.start[s] = 3 * T->sfb_s[sfb] + win * wd;
         }
         else if (s < LH_SBMAX_L) {
-            Q.width[s] = T->sfb_l[s + 1] - T->sfb_l[s];
+            Q.width[s] = qt->sfb_l[s + 1] - qt->sfb_l[s];
             Q.window[s] = 3;
-            Q.start[s] = T->sfb_l[s];
+            Q.start[s] = qt->sfb_l[s];
         }
         else {
             Q.width[s] = 0;
@@ -838,6 +883,18 @@ lh_init_outer_loop(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, float *x
             }
         }
     }
+    LH_WAVE_SYNC();
+}
+
+/* Lines above max_nonzero_coeff are zero in every quantised image (the reference clears
+ * them inside each quantize_xrpow call, takehiro.c:296-301, 386-391); here they are
+ * cleared once per granule, after lh_calc_xmin fixed R.mnc, and never written again. */
+LH_DEVFN void
+lh_zero_tail(const LhCtx & c, LhChanLds & Q, const LhQR & R)
+{
+    for (int i = c.lane; i < 576; i += 64)
+        if (i > R.mnc)
+            Q.ix[0][i] = 0;
     LH_WAVE_SYNC();
 }
 
@@ -945,14 +1002,13 @@ lh_bin_search_StepSize(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, int 
     return nBits;
 }
 
-/* reference quantize.c:540-551 */
+/* reference quantize.c:540-551; caller guarantees sf[] is synced */
 LH_DEVFN int
-lh_loop_break(const LhChanLds & Q, const LhQR & R, const LhGrR & g, int which)
+lh_loop_break(const LhCtx & c, const LhChanLds & Q, const LhQR & R, const LhGrR & g, int which)
 {
-    for (int sfb = 0; sfb < R.sfbmax; sfb++)
-        if (Q.sf[which][sfb] + g.subblock_gain[Q.window[sfb]] == 0)
-            return 0;
-    return 1;
+    int const s = c.lane;
+    int const z = (s < R.sfbmax) && (Q.sf[which][s] + lh_sbg(g, Q.window[s]) == 0);
+    return lh_ballot(z) == 0;
 }
 
 /* reference quantize.c:585-686 (comparator 9, the only one the presets of this path select) */
@@ -980,13 +1036,24 @@ LH_DEVFN void
 lh_scale_bands(const LhCtx & c, LhChanLds & Q, LhGrR & g)
 {
     unsigned mx = lh_f32_as_u32(g.xrpow_max);
+    int     sb[9], md[9];
+    float   fac[9], xv[9];
     LH_WAVE_SYNC();
-    for (int i = c.lane; i < 576; i += 64) {
-        int const s = Q.sfb_of_line[i];
-        if (Q.sfb_mode[s]) {
-            float const v = Q.xrpow[i] * Q.sfb_f[s];
+#pragma unroll
+    for (int k = 0; k < 9; k++)
+        sb[k] = Q.sfb_of_line[c.lane + 64 * k];
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        md[k] = Q.sfb_mode[sb[k]];
+        fac[k] = Q.sfb_f[sb[k]];
+        xv[k] = Q.xrpow[c.lane + 64 * k];
+    }
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        if (md[k]) {
+            float const v = xv[k] * fac[k];
             unsigned const u = lh_f32_as_u32(v);
-            Q.xrpow[i] = v;
+            Q.xrpow[c.lane + 64 * k] = v;
             mx = u > mx ? u : mx;
         }
     }
@@ -995,7 +1062,8 @@ lh_scale_bands(const LhCtx & c, LhChanLds & Q, LhGrR & g)
     LH_WAVE_SYNC();
 }
 
-/* reference quantize.c:720-796 */
+/* reference quantize.c:720-796; band s on lane s, the serial walk with its early
+ * returns is replayed on ballot masks */
 LH_DEVFN void
 lh_amp_scalefac_bands(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g, int which,
                       int bRefine)
@@ -1004,15 +1072,17 @@ lh_amp_scalefac_bands(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g,
     float   ifqstep34, trigger;
     int     noise_shaping_amp;
     int     last_visited, ret_before = 0;
+    int const s = c.lane;
+    float   dist;
+    uint64_t cand;
     LH_WAVE_SYNC();
+    dist = (s < R.sfbmax) ? Q.distort[s] : 0.0f;
     if (g.scalefac_scale == 0)
         ifqstep34 = (float) 1.29683955465100964055;
     else
         ifqstep34 = (float) 1.68179283050742922612;
-    trigger = 0;
-    for (int sfb = 0; sfb < R.sfbmax; sfb++)
-        if (trigger < Q.distort[sfb])
-            trigger = Q.distort[sfb];
+    /* distort >= 0, so the float maximum is the maximum of the bit patterns */
+    trigger = lh_u32_as_f32(lh_wave_max_u32(lh_f32_as_u32(dist > 0.0f ? dist : 0.0f)));
     noise_shaping_amp = cfg->noise_shaping_amp;
     if (noise_shaping_amp == 3)
         noise_shaping_amp = (bRefine == 1) ? 2 : 1;
@@ -1033,29 +1103,30 @@ lh_amp_scalefac_bands(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g,
             trigger = (float) (trigger * .95);
         break;
     }
-    /* replay the reference's serial walk (with its early returns) on read-only data */
+    cand = lh_ballot(s < R.sfbmax && !(dist < trigger));
     last_visited = R.sfbmax - 1;
-    for (int sfb = 0; sfb < R.sfbmax; sfb++) {
-        if (Q.distort[sfb] < trigger)
-            continue;
-        if (R.substep_shaping & 2) {
-            int const ph = !Q.pseudohalf[sfb];
-            if (!ph && cfg->noise_shaping_amp == 2) {
-                last_visited = sfb;
-                ret_before = 1;
-                break;
+    if (cfg->noise_shaping_amp == 2) {
+        uint64_t const ph = (R.substep_shaping & 2) ? lh_ballot(s < R.sfbmax && Q.pseudohalf[s]) : 0;
+        uint64_t m = cand;
+        while (m) {
+            int const sfb = lh_ffs64(m);
+            m &= m - 1;
+            if (R.substep_shaping & 2) {
+                int const ph_new = !((ph >> sfb) & 1);
+                if (!ph_new) {
+                    last_visited = sfb;
+                    ret_before = 1;
+                    break;
+                }
             }
-        }
-        if (cfg->noise_shaping_amp == 2) {
             last_visited = sfb;
             break;
         }
     }
     LH_WAVE_SYNC();
-    if (c.lane <= LH_SFBMAX) {
-        int const s = c.lane;
+    if (s <= LH_SFBMAX) {
         int     amplify = 0;
-        if (s < R.sfbmax && s <= last_visited && !(Q.distort[s] < trigger)) {
+        if (s < R.sfbmax && s <= last_visited && ((cand >> s) & 1)) {
             amplify = 1;
             if (R.substep_shaping & 2)
                 Q.pseudohalf[s] = !Q.pseudohalf[s];
@@ -1074,6 +1145,7 @@ lh_amp_scalefac_bands(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g,
 LH_DEVFN void
 lh_inc_scalefac_scale(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g, int which)
 {
+    const LhQTabs *qt = c.qt;
     float const ifqstep34 = (float) 1.29683955465100964055;
     LH_WAVE_SYNC();
     if (c.lane <= LH_SFBMAX) {
@@ -1082,7 +1154,7 @@ lh_inc_scalefac_scale(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g,
         if (sfb < R.sfbmax) {
             int     s = Q.sf[which][sfb];
             if (g.preflag)
-                s += lh_pretab[sfb];
+                s += qt->pretab[sfb];
             if (s & 1) {
                 s++;
                 amp = 1;
@@ -1102,6 +1174,7 @@ LH_DEVFN int
 lh_inc_subblock_gain(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g, int which)
 {
     const LhTables *T = c.T;
+    const LhQTabs *qt = c.qt;
     int    *sf = Q.sf[which];
     int     sfb, window;
     LH_WAVE_SYNC();
@@ -1119,9 +1192,11 @@ lh_inc_subblock_gain(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g, 
         top = sfb;              /* the band above the last scalefactor band, for this window */
         if (s1 < 16 && s2 < 8)
             continue;
-        if (g.subblock_gain[window] >= 7)
+        if (lh_sbg(g, window) >= 7)
             return 1;
-        g.subblock_gain[window]++;
+        g.subblock_gain[0] += (window == 0);
+        g.subblock_gain[1] += (window == 1);
+        g.subblock_gain[2] += (window == 2);
         LH_WAVE_SYNC();
         if (c.lane <= LH_SFBMAX) {
             int const k = c.lane;
@@ -1158,7 +1233,7 @@ lh_balance_noise(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g, int 
     const LhConfig *cfg = c.cfg;
     int     status;
     lh_amp_scalefac_bands(c, Q, R, g, which, bRefine);
-    status = lh_loop_break(Q, R, g, which);
+    status = lh_loop_break(c, Q, R, g, which);
     if (status)
         return 0;
     status = lh_scale_bitcount(c, Q, R, g, which);
@@ -1175,7 +1250,7 @@ lh_balance_noise(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g, int 
         }
         else {
             if (R.block_type == LH_SHORT_TYPE && cfg->subblock_gain > 0)
-                status = lh_inc_subblock_gain(c, Q, R, g, which) || lh_loop_break(Q, R, g, which);
+                status = lh_inc_subblock_gain(c, Q, R, g, which) || lh_loop_break(c, Q, R, g, which);
         }
     }
     if (!status)
@@ -1208,7 +1283,11 @@ lh_outer_loop(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & gb, const float 
     int     best_part2_3_length = 9999999;
     int     bEndOfSearch = 0, bRefine = 0, best_ggain_pass1 = 0;
 
-    (void) lh_bin_search_StepSize(c, Q, R, gb, targ_bits, ch);
+    {
+        LH_PT(t_bs);
+        (void) lh_bin_search_StepSize(c, Q, R, gb, targ_bits, ch);
+        LH_PA(7, t_bs);
+    }
     if (!cfg->noise_shaping)
         return 100;
     LH_WAVE_SYNC();
@@ -1245,8 +1324,13 @@ lh_outer_loop(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & gb, const float 
                     && (Q.distort[R.sfbmax + 1] > 1.0 || Q.distort[R.sfbmax + 2] > 1.0))
                     break;
             }
-            if (lh_balance_noise(c, Q, R, gw, 1, bRefine) == 0)
-                break;
+            {
+                LH_PT(t_bn);
+                int const bn = lh_balance_noise(c, Q, R, gw, 1, bRefine);
+                LH_PA(8, t_bn);
+                if (bn == 0)
+                    break;
+            }
             if (gw.scalefac_scale)
                 maxggain = 254;
             huff_bits = targ_bits - gw.part2_length;
@@ -1264,7 +1348,11 @@ lh_outer_loop(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & gb, const float 
                 if (gw.global_gain > maxggain)
                     break;
             }
-            lh_calc_noise(c, Q, R, gw, 1, xr, noise_info, 1);
+            {
+                LH_PT(t_cn);
+                lh_calc_noise(c, Q, R, gw, 1, xr, noise_info, 1);
+                LH_PA(9, t_cn);
+            }
             noise_info.bits = gw.part2_3_length;
             better = lh_quant_compare(best_noise_info, noise_info);
             if (better) {
@@ -1314,10 +1402,11 @@ lh_outer_loop(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & gb, const float 
 /* ---------------------------------------------------------------------- */
 /* reference takehiro.c:964-1094; gr0's final scalefactors come from the output slot
  * g0sf (int8, -1 = shared).  scfsi_out[4] is written by lane 0. */
-LH_DEVFN void
-lh_best_scalefac_store(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g, int gr,
+LH_STAGEFN void
+lh_best_scalefac_store(LH_CTXARG c, LhChanLds & Q, const LhQR & R, LhGrR & g, int gr,
                        const int8_t * g0sf, int g0_block_type, int *scfsi_out)
 {
+    const LhQTabs *qt = c.qt;
     int    *sf = Q.sf[0];
     const int16_t *ix = Q.ix[0];
     int     sfb, i;
@@ -1355,12 +1444,12 @@ lh_best_scalefac_store(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g
     }
     if (!g.preflag && R.block_type != LH_SHORT_TYPE) {
         for (sfb = 11; sfb < LH_SBPSY_L; sfb++)
-            if (sf[sfb] < lh_pretab[sfb] && sf[sfb] != -2)
+            if (sf[sfb] < qt->pretab[sfb] && sf[sfb] != -2)
                 break;
         if (sfb == LH_SBPSY_L) {
             LH_WAVE_SYNC();
             if (c.lane >= 11 && c.lane < LH_SBPSY_L && sf[c.lane] > 0)
-                sf[c.lane] -= lh_pretab[c.lane];
+                sf[c.lane] -= qt->pretab[c.lane];
             LH_WAVE_SYNC();
             g.preflag = recalc = 1;
         }
@@ -1427,10 +1516,11 @@ lh_best_scalefac_store(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g
  * splits with serial choose_table calls; here every candidate split is costed
  * by its own lane (serial scan of its region in LDS), then the reference's
  * first-minimum selection is replayed wave-uniformly. */
-LH_DEVFN void
-lh_best_huffman_divide(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g)
+LH_STAGEFN void
+lh_best_huffman_divide(LH_CTXARG c, LhChanLds & Q, const LhQR & R, LhGrR & g)
 {
     const LhTables *T = c.T;
+    const LhQTabs *qt = c.qt;
     const int16_t *ix = Q.ix[0];
     int    *r01_bits = Q.scr[0];        /* [23] */
     int    *r01_div = Q.scr[1];         /* [23] */
@@ -1450,22 +1540,22 @@ lh_best_huffman_divide(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g
         int    *comb_tbl = comb_bits + 128;           /* [128] */
         if (c.lane < 16) {
             int const r0 = c.lane;
-            int const e1 = T->sfb_l[r0 + 1];
+            int const e1 = qt->sfb_l[r0 + 1];
             int     b = 0, t = 0;
             if (e1 < bigv0)
-                t = lh_choose_table_lane(ix, 0, e1, &b);
+                t = lh_choose_table_lane(c.qt, ix, 0, e1, &b);
             r0bits_a[r0] = b;
             r0t_a[r0] = t;
         }
         LH_WAVE_SYNC();
         for (int cmb = c.lane; cmb < 128; cmb += 64) {
             int const r0 = cmb >> 3, r1 = cmb & 7;
-            int const e1 = T->sfb_l[r0 + 1];
-            int const e2 = T->sfb_l[r0 + r1 + 2];
+            int const e1 = qt->sfb_l[r0 + 1];
+            int const e2 = qt->sfb_l[r0 + r1 + 2];
             int     b = LH_LARGE_BITS, t = 0;
             if (e1 < bigv0 && e2 < bigv0) {
                 b = r0bits_a[r0];
-                t = lh_choose_table_lane(ix, e1, e2, &b);
+                t = lh_choose_table_lane(c.qt, ix, e1, e2, &b);
             }
             comb_bits[cmb] = b;
             comb_tbl[cmb] = t;
@@ -1478,11 +1568,11 @@ lh_best_huffman_divide(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g
             for (int r0 = 0; r0 < 16; r0++) {
                 int const r1 = sidx - r0;
                 /* the reference's loops stop at the first boundary >= bigv */
-                if (T->sfb_l[r0 + 1] >= bigv0)
+                if (qt->sfb_l[r0 + 1] >= bigv0)
                     break;
                 if (r1 < 0 || r1 > 7)
                     continue;
-                if (T->sfb_l[r0 + r1 + 2] >= bigv0)
+                if (qt->sfb_l[r0 + r1 + 2] >= bigv0)
                     continue;
                 if (bestb > comb_bits[r0 * 8 + r1]) {
                     bestb = comb_bits[r0 * 8 + r1];
@@ -1521,8 +1611,8 @@ lh_best_huffman_divide(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g
             a1 = a2 = 0;
             for (; i > g.big_values; i -= 4) {
                 int const p = ((ix[i - 4] * 2 + ix[i - 3]) * 2 + ix[i - 2]) * 2 + ix[i - 1];
-                a1 += lh_t32l[p];
-                a2 += lh_t33l[p];
+                a1 += qt->t32l[p];
+                a2 += qt->t33l[p];
             }
             bigv = i;
             c1sel = 0;
@@ -1541,7 +1631,7 @@ lh_best_huffman_divide(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g
                     v[k][0] = (p < 288) ? ix[2 * p] : 0;
                     v[k][1] = (p < 288) ? ix[2 * p + 1] : 0;
                 }
-                a1 = T->sfb_l[7 + 1];
+                a1 = qt->sfb_l[7 + 1];
                 if (a1 > i)
                     a1 = i;
                 if (a1 > 0)
@@ -1567,19 +1657,19 @@ lh_best_huffman_divide(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g
             LH_WAVE_SYNC();
             if (c.lane >= 2 && c.lane < LH_SBMAX_L + 1) {
                 int const r2 = c.lane;
-                int const e2 = T->sfb_l[r2];
+                int const e2 = qt->sfb_l[r2];
                 int     b = 0, t = 0;
                 if (e2 < bigv) {
                     b = r01_bits[r2 - 2] + c1bits;
                     if (r01_bits[r2 - 2] < LH_LARGE_BITS)
-                        t = lh_choose_table_lane(ix, e2, bigv, &b);
+                        t = lh_choose_table_lane(c.qt, ix, e2, bigv, &b);
                 }
                 r2bits[r2] = b;
                 r2tbl[r2] = t;
             }
             LH_WAVE_SYNC();
             for (int r2 = 2; r2 < LH_SBMAX_L + 1; r2++) {
-                int const e2 = T->sfb_l[r2];
+                int const e2 = qt->sfb_l[r2];
                 int     bits;
                 if (e2 >= bigv)
                     break;

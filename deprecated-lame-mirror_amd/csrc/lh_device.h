@@ -45,6 +45,8 @@ typedef struct LhStreamState {
     int     primed;
     int     status;                     /* 0 ok; device-detected inconsistencies are reported here */
     int     pad[3];
+    /* per-wave cycle accumulators, only filled by builds with -DLH_PROF (profiling aid) */
+    unsigned long long prof[2][12];
 } LhStreamState;
 
 /* one stream's work for one launch */

@@ -22,6 +22,7 @@
 static inline int lh_lane(void) { return hipemu_lane(); }
 static inline int lh_wave_id(void) { return hipemu_wave(); }
 #define LH_WAVE_SYNC() hipemu_wave_sync()
+#define LH_WAVE_SYNC_MEM() hipemu_wave_sync()
 
 static inline uint32_t
 lh_wave_sum_u32(uint32_t v)
@@ -65,6 +66,16 @@ lh_wave_min_u32(uint32_t v)
     return s;
 }
 
+static inline uint32_t
+lh_wave_or_u32(uint32_t v)
+{
+    const uint64_t *x = hipemu_wave_exchange(v);
+    uint32_t s = 0;
+    for (int i = 0; i < 64; i++)
+        s |= (uint32_t) x[i];
+    return s;
+}
+
 static inline uint64_t
 lh_wave_or_u64(uint64_t v)
 {
@@ -93,6 +104,8 @@ lh_bcast_u32(uint32_t v, int src)
     return (uint32_t) x[src];
 }
 
+static inline int lh_uni_i(int v) { return v; }
+static inline float lh_uni_f(float v) { return v; }
 static inline int lh_ffs64(uint64_t m) { return m ? __builtin_ctzll(m) : -1; }
 static inline int lh_popc64(uint64_t m) { return __builtin_popcountll(m); }
 static inline double lh_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
@@ -106,67 +119,74 @@ __device__ __forceinline__ int lh_wave_id(void) { return (int) (threadIdx.x >> 6
 
 /* LDS traffic of one wave is executed in order; this only stops the compiler
  * from moving LDS accesses across the point where lanes exchange data through
- * LDS, and waits for outstanding LDS operations. */
+ * LDS, and waits for outstanding LDS operations.  The fence names the LDS address space
+ * only: HBM loads in flight (table look-ups) are not drained by it. */
+#ifdef LH_FULL_FENCE
 #define LH_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); \
                             __builtin_amdgcn_wave_barrier(); } while (0)
+#else
+#define LH_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local"); \
+                            __builtin_amdgcn_wave_barrier(); } while (0)
+#endif
+/* same, for phases whose lanes also exchange data through the stream state in HBM (the
+ * psycho-acoustic model): orders and drains global accesses as well */
+#define LH_WAVE_SYNC_MEM() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); \
+                                __builtin_amdgcn_wave_barrier(); } while (0)
 
-__device__ __forceinline__ uint32_t
-lh_wave_sum_u32(uint32_t v)
+/* Wave reductions on the DPP cross-lane network (no LDS round trips): four
+ * full-permutation steps (quad_perm [1,0,3,2], quad_perm [2,3,0,1],
+ * row_half_mirror, row_mirror) leave every lane of a 16-lane row with the row
+ * total; the four row totals are then read with v_readlane and combined on the
+ * scalar unit.  ~12 instructions instead of six ds_bpermute round trips.
+ * lamehip_selftest() checks these against a serial LDS evaluation on the device. */
+template < int CTRL > __device__ __forceinline__ uint32_t
+lh_dpp(uint32_t v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-        v += (uint32_t) __shfl_xor((int) v, o, 64);
-    return v;
+    return (uint32_t) __builtin_amdgcn_update_dpp((int) v, (int) v, CTRL, 0xf, 0xf, false);
 }
 
-__device__ __forceinline__ uint64_t
-lh_wave_sum_u64(uint64_t v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-        v += (uint64_t) __shfl_xor((long long) v, o, 64);
-    return v;
-}
+#define LH_DPP_REDUCE(OP) \
+    { uint32_t t_; \
+      t_ = lh_dpp < 0xB1 > (v); v = OP(v, t_); \
+      t_ = lh_dpp < 0x4E > (v); v = OP(v, t_); \
+      t_ = lh_dpp < 0x141 > (v); v = OP(v, t_); \
+      t_ = lh_dpp < 0x140 > (v); v = OP(v, t_); \
+      { uint32_t const r0_ = (uint32_t) __builtin_amdgcn_readlane((int) v, 0), \
+                       r1_ = (uint32_t) __builtin_amdgcn_readlane((int) v, 16), \
+                       r2_ = (uint32_t) __builtin_amdgcn_readlane((int) v, 32), \
+                       r3_ = (uint32_t) __builtin_amdgcn_readlane((int) v, 48); \
+        return OP(OP(r0_, r1_), OP(r2_, r3_)); } }
 
-__device__ __forceinline__ uint32_t
-lh_wave_max_u32(uint32_t v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        uint32_t w = (uint32_t) __shfl_xor((int) v, o, 64);
-        v = (w > v) ? w : v;
-    }
-    return v;
-}
+#define LH_OP_ADD(a, b) ((a) + (b))
+#define LH_OP_MAX(a, b) ((a) > (b) ? (a) : (b))
+#define LH_OP_MIN(a, b) ((a) < (b) ? (a) : (b))
+#define LH_OP_OR(a, b)  ((a) | (b))
 
-__device__ __forceinline__ uint32_t
-lh_wave_min_u32(uint32_t v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        uint32_t w = (uint32_t) __shfl_xor((int) v, o, 64);
-        v = (w < v) ? w : v;
-    }
-    return v;
-}
+__device__ __forceinline__ uint32_t lh_wave_sum_u32(uint32_t v) LH_DPP_REDUCE(LH_OP_ADD)
+__device__ __forceinline__ uint32_t lh_wave_max_u32(uint32_t v) LH_DPP_REDUCE(LH_OP_MAX)
+__device__ __forceinline__ uint32_t lh_wave_min_u32(uint32_t v) LH_DPP_REDUCE(LH_OP_MIN)
+__device__ __forceinline__ uint32_t lh_wave_or_u32(uint32_t v) LH_DPP_REDUCE(LH_OP_OR)
 
 __device__ __forceinline__ uint64_t
 lh_wave_or_u64(uint64_t v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-        v |= (uint64_t) __shfl_xor((long long) v, o, 64);
-    return v;
+    return (uint64_t) lh_wave_or_u32((uint32_t) v) | ((uint64_t) lh_wave_or_u32((uint32_t) (v >> 32)) << 32);
 }
 
 __device__ __forceinline__ uint64_t lh_ballot(int pred) { return __ballot(pred); }
 
+/* value of lane `src' (src must be wave-uniform) */
 __device__ __forceinline__ uint32_t
 lh_bcast_u32(uint32_t v, int src)
 {
-    return (uint32_t) __shfl((int) v, src, 64);
+    return (uint32_t) __builtin_amdgcn_readlane((int) v, src);
 }
 
+/* Tell the compiler that a value is wave-uniform (it is by construction, but came through
+ * per-lane memory, which the compiler must treat as divergent): the value moves to a scalar
+ * register and everything derived from it -- branches, address arithmetic -- is scalar. */
+__device__ __forceinline__ int lh_uni_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float lh_uni_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 __device__ __forceinline__ int lh_ffs64(uint64_t m) { return m ? (__ffsll((long long) m) - 1) : -1; }
 __device__ __forceinline__ int lh_popc64(uint64_t m) { return __popcll(m); }
 __device__ __forceinline__ double lh_fma(double a, double b, double c) { return __fma_rn(a, b, c); }

@@ -13,7 +13,7 @@ import numpy as np
 from .types import LhConfig, LhFrameOut, LhTables  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblamehip.so")
+LIB_PATH = os.environ.get("LAMEHIP_LIB", os.path.join(_HERE, "liblamehip.so"))   # LAMEHIP_LIB: profiling build
 
 ERR_NODEVICE = -10
 STEREO, JOINT_STEREO = 0, 1
@@ -58,6 +58,7 @@ def load_library():
     lib.lamehip_batch_pack.restype = C.c_long
     lib.lamehip_batch_pack.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_long]
     lib.lamehip_batch_get_frames.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    lib.lamehip_batch_get_state.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
     lib.lamehip_batch_last_kernel_ms.restype = C.c_float
     lib.lamehip_batch_last_kernel_ms.argtypes = [C.c_void_p]
     _lib = lib

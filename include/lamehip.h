@@ -103,10 +103,16 @@ int     lamehip_batch_frames(lamehip_batch *, int stream);
 long    lamehip_batch_pack(lamehip_batch *, int stream, unsigned char *out, long out_size);
 /* raw payload access for tests: copies frames [0, n) of a stream (LhFrameOut[]) */
 int     lamehip_batch_get_frames(lamehip_batch *, int stream, void *frames_out, int max_frames);
+/* debug aid: raw per-stream carried state (LhStreamState, csrc/lh_device.h) */
+int     lamehip_batch_get_state(lamehip_batch *, int stream, void *out, int size);
+int     lamehip_debug_poison(unsigned pattern);   /* test aid: garbage in all VGPRs/LDS/scratch of the device */
+int     lamehip_get_state(const lame_t, void *out, int size);   /* same for a single-stream handle */
 /* elapsed GPU time of the last lamehip_batch_encode in ms (HIP events on the batch stream) */
 float   lamehip_batch_last_kernel_ms(lamehip_batch *);
 int     lamehip_batch_reset(lamehip_batch *);   /* re-initialise all stream states for another run */
 
+/* device self-test of the wave-level primitives the kernels rely on: 0 = pass */
+int     lamehip_selftest(void);
 const char *lamehip_last_error(void);
 /* sizeof() of the POD layouts (0 LhConfig, 1 LhTables, 2 LhFrameOut, 3 LhGranule,
  * 4 LhStreamState, 5 LhStreamDesc) this library was built with */

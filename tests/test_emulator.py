@@ -47,3 +47,32 @@ def test_kernel_source_matches_oracle(name, nframes, emu, oracle):
         d = struct_diff(want[f], got[f])
         assert not d, (f, d[:4])
     enc.close()
+
+
+@pytest.mark.parametrize("name,nframes", [("testcase_wav_cbr128", 6), ("cbr320_js_48k_bursts", 6)])
+def test_kernel_source_frame_per_launch_with_poisoned_lds(name, nframes, emu, oracle):
+    """One launch per frame, as lame_encode_buffer drives the device, with the LDS image
+    overwritten before every launch: nothing may be carried from launch to launch except
+    LhStreamState."""
+    g, pcm = helpers.load_golden(name)
+    sr, br, mode, q = helpers.golden_settings(g)
+    enc = lamehip.Encoder(sr, br, mode, q, require_device=False)
+    cfg, tab = enc.config(), enc.tables()
+    want = oracle.encode_frames(cfg, tab, pcm, max_frames=nframes)
+    n = pcm.shape[1]
+    pool = np.concatenate([pcm[0], pcm[1]]).astype(np.int16)
+    state = C.create_string_buffer(enc.lib.lamehip_abi_sizeof(4))
+    enc.lib.lh_state_init(state, C.byref(cfg))
+    got = (LhFrameOut * nframes)()
+    C.c_int.in_dll(emu, "lh_emu_poison_lds").value = 1
+    try:
+        for f in range(nframes):
+            desc = LhStreamDesc(0, n, 0, n, f, f, f + 1)
+            emu.lh_emu_encode(C.byref(cfg), C.byref(tab), pool.ctypes.data_as(C.c_void_p), C.byref(desc), state,
+                              got, 1)
+    finally:
+        C.c_int.in_dll(emu, "lh_emu_poison_lds").value = 0
+    for f in range(nframes):
+        d = struct_diff(want[f], got[f])
+        assert not d, (f, d[:4])
+    enc.close()

@@ -14,6 +14,11 @@ from lamehip.types import struct_diff
 pytestmark = pytest.mark.gpu
 
 
+def test_wave_primitives_selftest():
+    """DPP reductions / ballot / readlane of csrc/lh_wave.h against a serial LDS evaluation."""
+    assert lamehip.load_library().lamehip_selftest() == 0
+
+
 def _encoder(g):
     sr, br, mode, q = helpers.golden_settings(g)
     return lamehip.Encoder(sr, br, mode, q)
@@ -140,4 +145,35 @@ def test_full_batch_size_properties():
     assert solo.pack(0) == packed[1]
     solo.close()
     b.close()
+    enc.close()
+
+
+@pytest.mark.parametrize("name", ["testcase_wav_cbr128", "cbr320_js_48k_bursts", "cbr128_js_44k_q0"])
+def test_no_dependence_on_uninitialised_device_state(name):
+    """Registers, LDS and scratch memory are not cleared between kernels.  Fill all of them
+    with garbage (lamehip_debug_poison) before every launch: the payload must still be the
+    reference's, frame by frame, on the batch path and on the one-launch-per-call path."""
+    g, pcm = helpers.load_golden(name)
+    enc = _encoder(g)
+    lib = enc.lib
+    want = [str(x) for x in g["frame_sha256"]]
+    for pattern in (0xA5A5A580, 0xFFFFFFFF):
+        b = lamehip.Batch(enc, 1, pcm.shape[1] + 16)
+        b.set_pcm(0, pcm[0], pcm[1])
+        assert lib.lamehip_debug_poison(C.c_uint(pattern)) == 0
+        b.encode()
+        frames = b.get_frames(0)
+        helpers.normalize_tables(frames)
+        bad = [i for i, fr in enumerate(frames) if helpers.frame_sha(fr) != want[i]]
+        assert not bad, "pattern %#x: frames %s differ from the reference" % (pattern, bad[:8])
+        b.close()
+    enc.close()
+    enc = _encoder(g)
+    out = b""
+    n = min(pcm.shape[1], 1152 * 40)
+    for i in range(0, n, 1152):
+        assert lib.lamehip_debug_poison(C.c_uint(0xA5A5A580 + i)) == 0
+        out += enc.encode(pcm[0][i:min(n, i + 1152)], pcm[1][i:min(n, i + 1152)])
+    ref = g["mp3"].tobytes()
+    assert len(out) > 0 and out == ref[:len(out)]
     enc.close()

@@ -1,0 +1,50 @@
+#!/usr/bin/env python
+"""Per-stage cycle breakdown of lh_encode_kernel from the LH_PROF build
+(make -C deprecated-lame-mirror_amd/csrc prof).  Usage on the GPU box:
+    LAMEHIP_LIB=deprecated-lame-mirror_amd/lamehip/liblamehip_prof.so python tools/stage_profile.py [streams] [seconds]
+"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "deprecated-lame-mirror_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+import helpers  # noqa: E402
+import lamehip  # noqa: E402
+
+NAMES = ["frame total", "psy (2 granules)", "polyphase+mdct", "quant total (2 gr)", "init+xrpow+xmin",
+         "outer_loop", "scalefac_store+huffman_divide", "  bin_search", "  balance_noise", "  calc_noise",
+         "count_bits calls", "-"]
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+    secs = float(sys.argv[2]) if len(sys.argv) > 2 else 2.0
+    n = int(44100 * secs)
+    enc = lamehip.Encoder(44100, 128)
+    b = lamehip.Batch(enc, B, n)
+    base = [helpers.synth_stream(900 + i, n) for i in range(8)]
+    for s in range(B):
+        b.set_pcm(s, base[s % 8][0], base[s % 8][1])
+    b.encode()
+    ms = b.kernel_ms()
+    ssz = enc.lib.lamehip_abi_sizeof(4)
+    tot = np.zeros((2, 12))
+    for s in range(0, B, max(1, B // 64)):
+        buf = C.create_string_buffer(ssz)
+        assert enc.lib.lamehip_batch_get_state(b.b, s, buf, ssz) == ssz
+        prof = np.frombuffer(buf.raw[-2 * 12 * 8:], dtype=np.uint64).reshape(2, 12)
+        tot += prof
+    frames = b.frames(0)
+    print("batch %d x %.1f s: kernel %.2f ms, %d frames/stream" % (B, secs, ms, frames))
+    for w in range(2):
+        print("wave %d (cycles per frame, share of frame):" % w)
+        for i, nm in enumerate(NAMES[:11]):
+            v = tot[w][i] / (frames * len(range(0, B, max(1, B // 64))))
+            print("   %-34s %12.0f  %5.1f%%" % (nm, v, 100.0 * tot[w][i] / max(tot[w][0], 1)))
+
+
+if __name__ == "__main__":
+    main()
