@@ -170,7 +170,9 @@ struct LhQTabs {
     uint32_t table23[9], table56[16];
     uint16_t sfb_l[24];
     uint8_t ht_len[1672];       /* code lengths, all tables back to back (lh_ht_off()) */
-    uint8_t bv_scf[576];
+    uint32_t bvpack[288];       /* big_values/2 - 1 -> region0_count | region1_count << 4 | end of region 0 << 8
+                                 * | end of region 1 << 18 (reference takehiro.c:1334-1375 folded with sfb_l) */
+    uint16_t sfb_s3, pad;       /* sfb_s[3] */
     uint8_t t32l[16], t33l[16];
     uint8_t pretab[24];
     float   pow43h[256];        /* heads of pow43 / adj43asm: nearly all quantised values are < 256 */
@@ -201,7 +203,7 @@ struct LhLds {
     float   pe_use[2][2];
     float   ms_ener_ratio[2];
     int     scfsi[2][4];
-    unsigned long long prof[2][12];
+    unsigned long long prof[2][LH_NPROF];
     union {
         float   mf[2][LH_MF_NEEDED];    /* scaled float PCM window of the frame (psy, polyphase) */
         struct {

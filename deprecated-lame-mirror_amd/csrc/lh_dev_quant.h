@@ -96,7 +96,31 @@ lh_quant_line(const LhTables * T, const LhQTabs * qt, float istep, float xp)
     x0 += LH_MAGIC_FLOAT;
     f = (float) x0;
     k = (int) lh_f32_as_u32(f) - LH_MAGIC_INT;
-    f = (float) (x0 + ((k < 256) ? qt->adj43h[k] : T->adj43asm[k]));
+    {
+        /* LDS holds the first 256 entries; the rest (rare: large quantised values) comes from
+         * HBM.  Two separate loads: a select between an LDS and a global pointer would turn
+         * every access into a FLAT load. */
+        float   adj = qt->adj43h[k & 255];
+        if (k >= 256)
+            adj = T->adj43asm[k];
+        f = (float) (x0 + adj);
+    }
+    return (int) lh_f32_as_u32(f) - LH_MAGIC_INT;
+}
+
+/* the same with the rounding table's LDS head only; big = 1 when the first rounding landed
+ * beyond the head (the result is then not valid and the caller redoes the line) */
+LH_DEVFN int
+lh_quant_line_head(const LhQTabs * qt, float istep, float xp, int &big)
+{
+    double  x0 = (double) (istep * xp);
+    float   f;
+    int     k;
+    x0 += LH_MAGIC_FLOAT;
+    f = (float) x0;
+    k = (int) lh_f32_as_u32(f) - LH_MAGIC_INT;
+    big = (k >= 256);
+    f = (float) (x0 + qt->adj43h[k & 255]);
     return (int) lh_f32_as_u32(f) - LH_MAGIC_INT;
 }
 
@@ -336,130 +360,327 @@ lh_choose_table_lane(const LhQTabs * qt, const int16_t * ix, int lo, int hi, int
     }
 }
 
-/* reference takehiro.c:654-765; quantised image `which' must be complete and synced */
-LH_DEVFN int
-lh_noquant_count_bits(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, int which, int use_prev)
+/* Per-lane contribution of the pairs [plo, phi) to the bit counts of the candidate Huffman
+ * tables for a region whose largest value is mx (wave-uniform); mirrors the table selection
+ * of the reference's choose_table_nonMMX (takehiro.c:546-650).  No cross-lane work here:
+ * the caller reduces w0 / w1 of all regions together. */
+LH_DEVFN void
+lh_region_partials(const LhQTabs * qt, const uint32_t pk[5], int lane, int plo, int phi, unsigned mx,
+                   unsigned &w0, unsigned &w1)
 {
-    const LhTables *T = c.T;
+    w0 = 0;
+    w1 = 0;
+    if (mx == 0 || mx > LH_IXMAX)
+        return;
+    if (mx == 1) {
+        const uint8_t *h1 = LH_HLEN(1);
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            int const p = lane + 64 * k;
+            if (64 * k < phi && 64 * k + 63 >= plo && p >= plo && p < phi)
+                w0 += h1[2 * (pk[k] & 0xffffu) + (pk[k] >> 16)];
+        }
+    }
+    else if (mx <= 3) {
+        unsigned const xlen = (mx == 2) ? 3u : 4u;
+        const uint32_t *table = (mx == 2) ? qt->table23 : qt->table56;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            int const p = lane + 64 * k;
+            if (64 * k < phi && 64 * k + 63 >= plo && p >= plo && p < phi)
+                w0 += table[(pk[k] & 0xffffu) * xlen + (pk[k] >> 16)];
+        }
+    }
+    else if (mx <= 15) {
+        int const t1 = lh_huf_noESC(mx);
+        unsigned const xlen = lh_ht_xlen_c(t1);
+        const uint8_t *h1 = LH_HLEN(t1), *h2 = LH_HLEN(t1 + 1), *h3 = LH_HLEN(t1 + 2);
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            int const p = lane + 64 * k;
+            if (64 * k < phi && 64 * k + 63 >= plo && p >= plo && p < phi) {
+                unsigned const x = (pk[k] & 0xffffu) * xlen + (pk[k] >> 16);
+                w0 += (unsigned) h1[x] | ((unsigned) h2[x] << 16);
+                w1 += (unsigned) h3[x];
+            }
+        }
+    }
+    else {
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            int const p = lane + 64 * k;
+            if (64 * k < phi && 64 * k + 63 >= plo && p >= plo && p < phi) {
+                unsigned x = pk[k] & 0xffffu, y = pk[k] >> 16;
+                if (x >= 15u) {
+                    x = 15u;
+                    w1++;
+                }
+                if (y >= 15u) {
+                    y = 15u;
+                    w1++;
+                }
+                w0 += qt->largetbl[(x << 4) + y];       /* high half: tables 16.., low half: tables 24.. */
+            }
+        }
+    }
+}
+
+/* the scalar half of choose_table: table index and bits from the wave totals */
+LH_DEVFN int
+lh_region_decide(unsigned mx, unsigned w0, unsigned w1, int *bits)
+{
+    if (mx == 0)
+        return 0;
+    if (mx > LH_IXMAX) {
+        *bits = LH_LARGE_BITS;
+        return -1;
+    }
+    if (mx == 1) {
+        *bits += (int) w0;
+        return 1;
+    }
+    if (mx <= 3) {
+        int     t1 = lh_huf_noESC(mx);
+        unsigned s = w0 >> 16, s2 = w0 & 0xffffu;
+        if (s > s2) {
+            s = s2;
+            t1++;
+        }
+        *bits += (int) s;
+        return t1;
+    }
+    if (mx <= 15) {
+        int const t1 = lh_huf_noESC(mx);
+        unsigned s1 = w0 & 0xffffu, s2 = w0 >> 16, s3 = w1;
+        int     t = t1;
+        if (s1 > s2) {
+            s1 = s2;
+            t++;
+        }
+        if (s1 > s3) {
+            s1 = s3;
+            t = t1 + 2;
+        }
+        *bits += (int) s1;
+        return t;
+    }
+    {
+        int     choice, choice2;
+        unsigned const m15 = mx - 15u;
+        unsigned sa, sb;
+        for (choice2 = 24; choice2 < 32; choice2++)
+            if (lh_ht_linmax_c(choice2) >= m15)
+                break;
+        for (choice = choice2 - 8; choice < 24; choice++)
+            if (lh_ht_linmax_c(choice) >= m15)
+                break;
+        sa = (w0 >> 16) + w1 * lh_ht_xlen_c(choice);
+        sb = (w0 & 0xffffu) + w1 * lh_ht_xlen_c(choice2);
+        if (sa > sb) {
+            sa = sb;
+            choice = choice2;
+        }
+        *bits += (int) sa;
+        return choice;
+    }
+}
+
+/* index of the highest set bit + 1 over five 64-bit ballot words (word k covers pairs 64k..) */
+LH_DEVFN int
+lh_top_of_masks(const uint64_t m[5])
+{
+    int     top = 0;
+#pragma unroll
+    for (int k = 0; k < 5; k++)
+        if (m[k])
+            top = 64 * k + 64 - lh_clz64(m[k]);
+    return top;
+}
+
+/* Huffman bit count of a quantised image held as packed pairs in registers (pk[k] = pair
+ * lane + 64 k: low half = even line); the image is also in LDS (Q.ix[which]) and the LDS
+ * copy is what the count1 quadruples are read from.  Reference takehiro.c:654-765.
+ * The cross-lane work is arranged in few dependent steps: ballots find count1 / big_values,
+ * the three region maxima are reduced together, and so are all table sums. */
+LH_DEVFN int
+lh_noquant_count_bits(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, int which, int use_prev,
+                      const uint32_t pk[5])
+{
     const LhQTabs *qt = c.qt;
-    const int16_t *ix = Q.ix[which];
-    int     v[5][2];
-    int     bits, i, a1, a2;
-    unsigned top_nz = 0, top_big = 0;
-    int const i0 = (((R.mnc + 2) >> 1) << 1) > 576 ? 576 : (((R.mnc + 2) >> 1) << 1);
+    const uint32_t *ix2 = (const uint32_t *) Q.ix[which];
+    int const lane = c.lane;
+    int const i0p = (((R.mnc + 2) >> 1) > 288) ? 288 : ((R.mnc + 2) >> 1);
+    uint64_t mk[5];
+    int     top_nz, top_big, i, bv, nquad, bits;
+    int     e0, e1, e2;             /* pair index where regions 0, 1, 2 end */
+    int     a1, a2;
+    unsigned quads = 0, sfbcnt_in = 0;
 
     if (use_prev)
         R.pn_sfb_count1 = 0;
 #pragma unroll
-    for (int k = 0; k < 5; k++) {
-        int const p = c.lane + 64 * k;
-        if (p < 288) {
-            v[k][0] = ix[2 * p];
-            v[k][1] = ix[2 * p + 1];
-            if (2 * p < i0 && (v[k][0] | v[k][1]))
-                top_nz = (unsigned) (p + 1);
-        }
-        else {
-            v[k][0] = v[k][1] = 0;
-        }
-    }
-    top_nz = lh_wave_max_u32(top_nz);
-    i = 2 * (int) top_nz;
+    for (int k = 0; k < 5; k++)
+        mk[k] = lh_ballot((lane + 64 * k) < i0p && pk[k] != 0);
+    top_nz = lh_top_of_masks(mk);
+    i = 2 * top_nz;
     g.count1 = i;
 #pragma unroll
-    for (int k = 0; k < 5; k++) {
-        int const p = c.lane + 64 * k;
-        if (p < (int) top_nz && (unsigned) (v[k][0] | v[k][1]) > 1)
-            top_big = (unsigned) (p + 1);
-    }
-    top_big = lh_wave_max_u32(top_big);
-    {
-        /* trailing quadruples whose values are all <= 1 */
-        int const q = 2 * (int) top_big;
-        int const nquad = (i - q) / 4;
-        unsigned s = 0;
-        int const bv = i - 4 * nquad;
-        for (int qd = c.lane; qd < nquad; qd += 64) {
-            int const b = bv + 4 * qd;
-            int const p = ((ix[b] * 2 + ix[b + 1]) * 2 + ix[b + 2]) * 2 + ix[b + 3];
-            s += ((unsigned) qt->t32l[p] << 16) + (unsigned) qt->t33l[p];
-        }
-        s = lh_wave_sum_u32(s);
-        a1 = (int) (s >> 16);
-        a2 = (int) (s & 0xffffu);
-        i = bv;
-    }
-    bits = a1;
-    g.count1table_select = 0;
-    if (a1 > a2) {
-        bits = a2;
-        g.count1table_select = 1;
-    }
-    g.count1bits = bits;
-    g.big_values = i;
-    if (i == 0)
-        return bits;
-
+    for (int k = 0; k < 5; k++)
+        mk[k] = lh_ballot((lane + 64 * k) < top_nz && (pk[k] & 0xfffefffeu) != 0);
+    top_big = lh_top_of_masks(mk);
+    nquad = (i - 2 * top_big) / 4;
+    bv = i - 4 * nquad;
+    g.big_values = bv;
+    /* region layout (scalar) */
     if (R.block_type == LH_SHORT_TYPE) {
-        a1 = 3 * T->sfb_s[3];
-        if (a1 > g.big_values)
-            a1 = g.big_values;
-        a2 = g.big_values;
+        a1 = 3 * (int) qt->sfb_s3;
+        a2 = bv;
     }
     else if (R.block_type == LH_NORM_TYPE) {
-        a1 = g.region0_count = qt->bv_scf[i - 2];
-        a2 = g.region1_count = qt->bv_scf[i - 1];
-        a2 = qt->sfb_l[a1 + a2 + 2];
-        a1 = qt->sfb_l[a1 + 1];
-        if (a2 < i)
-            g.table_select[2] = lh_choose_table_wave(c, v, a2, i, &bits);
+        if (bv > 0) {
+            uint32_t const pack = qt->bvpack[(bv >> 1) - 1];
+            g.region0_count = (int) (pack & 15u);
+            g.region1_count = (int) ((pack >> 4) & 15u);
+            a1 = (int) ((pack >> 8) & 1023u);
+            a2 = (int) ((pack >> 18) & 1023u);
+        }
+        else
+            a1 = a2 = 0;
     }
     else {
-        g.region0_count = 7;
-        g.region1_count = LH_SBMAX_L - 1 - 7 - 1;
-        a1 = qt->sfb_l[7 + 1];
-        a2 = i;
-        if (a1 > a2)
-            a1 = a2;
-    }
-    a1 = (a1 < i) ? a1 : i;
-    a2 = (a2 < i) ? a2 : i;
-    if (0 < a1)
-        g.table_select[0] = lh_choose_table_wave(c, v, 0, a1, &bits);
-    if (a1 < a2)
-        g.table_select[1] = lh_choose_table_wave(c, v, a1, a2, &bits);
-    /* use_best_huffman == 2 (best_huffman_divide inside the loop) is not selected by any quality level */
-    if (use_prev) {
-        if (R.block_type == LH_NORM_TYPE) {
-            /* first band whose start is >= big_values (band starts ascend) */
-            uint64_t const below = lh_ballot(c.lane < LH_SBMAX_L + 1 && (int) qt->sfb_l[c.lane < 23 ? c.lane : 22] < g.big_values);
-            R.pn_sfb_count1 = lh_popc64(below);
+        if (bv > 0) {
+            g.region0_count = 7;
+            g.region1_count = LH_SBMAX_L - 1 - 7 - 1;
         }
+        a1 = qt->sfb_l[7 + 1];
+        a2 = bv;
+    }
+    a1 = (a1 < bv) ? a1 : bv;
+    a2 = (a2 < bv) ? a2 : bv;
+    e0 = a1 >> 1;
+    e1 = a2 >> 1;
+    e2 = (R.block_type == LH_NORM_TYPE) ? (bv >> 1) : e1;
+    if (use_prev && R.block_type == LH_NORM_TYPE)
+        sfbcnt_in = (lane < LH_SBMAX_L + 1) ? qt->sfb_l[lane] : 576u;
+    /* count1 region: quadruples of 0/1 values, from the LDS image */
+    if (nquad > 0) {
+        LH_WAVE_SYNC();
+        for (int qd = lane; qd < nquad; qd += 64) {
+            int const b2 = (bv >> 1) + 2 * qd;
+            uint32_t const u0 = ix2[b2], u1 = ix2[b2 + 1];
+            unsigned const p = (((u0 & 1u) * 2 + (u0 >> 16)) * 2 + (u1 & 1u)) * 2 + (u1 >> 16);
+            quads += ((unsigned) qt->t32l[p] << 16) + (unsigned) qt->t33l[p];
+        }
+    }
+    {
+        /* region maxima: three independent reductions the scheduler can interleave */
+        unsigned m0 = 0, m1 = 0, m2 = 0;
+        unsigned w00, w01, w10, w11, w20, w21;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            int const p = lane + 64 * k;
+            unsigned const lo = pk[k] & 0xffffu, hi = pk[k] >> 16;
+            unsigned const m = lo > hi ? lo : hi;
+            if (p < e0)
+                m0 = m > m0 ? m : m0;
+            else if (p < e1)
+                m1 = m > m1 ? m : m1;
+            else if (p < e2)
+                m2 = m > m2 ? m : m2;
+        }
+        m0 = lh_wave_max_u32(m0);
+        m1 = lh_wave_max_u32(m1);
+        m2 = lh_wave_max_u32(m2);
+        lh_region_partials(qt, pk, lane, 0, e0, m0, w00, w01);
+        lh_region_partials(qt, pk, lane, e0, e1, m1, w10, w11);
+        lh_region_partials(qt, pk, lane, e1, e2, m2, w20, w21);
+        /* the kernel is issue-bound: reductions nobody reads are skipped (wave-uniform tests) */
+        if (nquad > 0)
+            quads = lh_wave_sum_u32(quads);
+        if (m0 > 0)
+            w00 = lh_wave_sum_u32(w00);
+        if (m0 > 3)
+            w01 = lh_wave_sum_u32(w01);
+        if (m1 > 0)
+            w10 = lh_wave_sum_u32(w10);
+        if (m1 > 3)
+            w11 = lh_wave_sum_u32(w11);
+        if (m2 > 0)
+            w20 = lh_wave_sum_u32(w20);
+        if (m2 > 3)
+            w21 = lh_wave_sum_u32(w21);
+        {
+            int const c1a = (int) (quads >> 16), c1b = (int) (quads & 0xffffu);
+            bits = c1a;
+            g.count1table_select = 0;
+            if (c1a > c1b) {
+                bits = c1b;
+                g.count1table_select = 1;
+            }
+            g.count1bits = bits;
+        }
+        if (bv == 0)
+            return bits;
+        /* same order as the reference: region 2 (long blocks), then 0, then 1 */
+        if (e1 < e2)
+            g.table_select[2] = lh_region_decide(m2, w20, w21, &bits);
+        if (0 < e0)
+            g.table_select[0] = lh_region_decide(m0, w00, w01, &bits);
+        if (e0 < e1)
+            g.table_select[1] = lh_region_decide(m1, w10, w11, &bits);
+    }
+    /* use_best_huffman == 2 (best_huffman_divide inside the loop) is not selected by any quality level */
+    if (use_prev && R.block_type == LH_NORM_TYPE) {
+        /* first band whose start is >= big_values (band starts ascend) */
+        R.pn_sfb_count1 = lh_popc64(lh_ballot(lane < LH_SBMAX_L + 1 && (int) sfbcnt_in < bv));
     }
     return bits;
 }
 
-/* reference takehiro.c:767-801 + quantize_xrpow :281-414 */
+/* reference takehiro.c:281-414 (quantize_xrpow) + 768-798 (count_bits) */
 LH_DEVFN int
 lh_count_bits(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, int which, int use_prev)
 {
     LH_PC(10);
+    LH_PT(t_cb);
     const LhTables *T = c.T;
     const LhQTabs *qt = c.qt;
     int16_t *ix = Q.ix[which];
+    uint32_t *ix2 = (uint32_t *) Q.ix[which];
     const int *sf = Q.sf[which];
     const float *xrpow = Q.xrpow;
     float const istep = T->ipow20[g.global_gain];
     float const w = (LH_IXMAX) / istep;
     int const mnc = R.mnc;
+    int const pm = mnc >> 1;            /* last pair that holds a line <= mnc (mnc is odd) */
     int const sfbmax = (R.block_type == LH_SHORT_TYPE) ? 38 : 21;
+    int const lane = c.lane;
+    uint32_t pk[5];
+    int     sb[5];
+    float   xp[10];
+    uint64_t ncmask, m01mask;
     int     zero_mnc;
 
     if (g.xrpow_max > w)
         return LH_LARGE_BITS;
+    /* everything a lane needs that does not depend on the band decisions is loaded first */
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        int const p = lane + 64 * k;
+        sb[k] = 63;
+        pk[k] = 0u;             /* lines above mnc are zero (lh_zero_tail) */
+        xp[2 * k] = xp[2 * k + 1] = 0.0f;
+        if (64 * k <= pm) {     /* wave-uniform: whole iterations above mnc cost nothing */
+            sb[k] = (p <= pm) ? Q.sfb_of_line[2 * p] : 63;
+            pk[k] = (p <= pm) ? ix2[p] : 0u;
+            xp[2 * k] = (p <= pm) ? xrpow[2 * p] : 0.0f;
+            xp[2 * k + 1] = (p <= pm) ? xrpow[2 * p + 1] : 0.0f;
+        }
+    }
     /* Per band (lane = band): unchanged step -> keep the old values; count1 region with a
      * coarser step -> 0/1 comparator; else the full quantiser (reference
-     * quantize_xrpow, takehiro.c:281-414).
+     * quantize_xrpow, takehiro.c:281-414).  The per-band decisions travel as two ballot
+     * masks (scalar registers), not through LDS.
      * Invariant kept by this file: lines above max_nonzero_coeff (mnc) are zero in both
      * quantised images from lh_zero_tail() on, which is what the reference's memset
      * re-establishes on every call; so only lines <= mnc are visited.  One quirk of the
@@ -467,78 +688,104 @@ lh_count_bits(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, int which, in
      * not, its memset clears line mnc itself. */
     {
         int const prev_data_use = (use_prev && (g.global_gain == R.pn_global_gain));
-        int const s = c.lane;
-        int     noncached = 0;
+        int const s = lane;
+        int     noncached = 0, m01 = 0;
         int const s_m = Q.sfb_of_line[mnc];
         if (s <= sfbmax) {
-            int     step = -1, cached, m01;
+            int     step = -1, cached;
+            int const pn_step = Q.pn_step[s];
             if (prev_data_use || R.block_type == LH_NORM_TYPE) {
                 int const pre = (g.preflag && s < LH_SBMAX_L) ? qt->pretab[s] : 0;
                 step = g.global_gain - ((sf[s] + pre) << (g.scalefac_scale + 1))
                     - lh_sbg(g, Q.window[s]) * 8;
             }
-            cached = prev_data_use && (Q.pn_step[s] == step);
-            m01 = use_prev && R.pn_sfb_count1 > 0 && s >= R.pn_sfb_count1 && Q.pn_step[s] > 0
-                && step >= Q.pn_step[s];
-            Q.sfb_mode[s] = cached ? 0 : (m01 ? 2 : 1);
+            cached = prev_data_use && (pn_step == step);
+            m01 = use_prev && R.pn_sfb_count1 > 0 && s >= R.pn_sfb_count1 && pn_step > 0 && step >= pn_step;
             noncached = !cached;
         }
+        ncmask = lh_ballot(noncached);
+        m01mask = lh_ballot(m01);
         {
-            uint64_t const nc = lh_ballot(noncached);
-            int const cached_m = !((nc >> s_m) & 1);
-            int const later = (s_m < 63) ? ((nc >> (s_m + 1)) != 0) : 0;
+            int const cached_m = !((ncmask >> s_m) & 1);
+            int const later = (s_m < 63) ? ((ncmask >> (s_m + 1)) != 0) : 0;
             zero_mnc = cached_m && later;
         }
     }
-    LH_WAVE_SYNC();
     {
-        /* batched load levels (band id, band mode, xrpow) instead of a dependent chain per line */
         float const compareval0 = (1.0f - 0.4054f) / istep;
-        int const pm = mnc >> 1;        /* last pair that holds a line <= mnc (mnc is odd) */
-        int     md[5];
-        float   xp[10];
+        uint32_t newpk[5] = { 0u, 0u, 0u, 0u, 0u };
+        int     anybig = 0;
 #pragma unroll
         for (int k = 0; k < 5; k++) {
-            int const p = c.lane + 64 * k;
-            md[k] = (p <= pm) ? Q.sfb_of_line[2 * p] : -1;
-        }
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-            int const p = c.lane + 64 * k;
-            md[k] = (md[k] >= 0) ? Q.sfb_mode[md[k]] : 0;
-            xp[2 * k] = (p <= pm) ? xrpow[2 * p] : 0.0f;
-            xp[2 * k + 1] = (p <= pm) ? xrpow[2 * p + 1] : 0.0f;
-        }
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-            int const p = c.lane + 64 * k;
-            if (md[k] == 1) {
-                int const q0 = lh_quant_line(T, qt, istep, xp[2 * k]);
-                int const q1 = lh_quant_line(T, qt, istep, xp[2 * k + 1]);
-                ((uint32_t *) ix)[p] = (uint32_t) (q0 & 0xffff) | ((uint32_t) q1 << 16);
+            int const p = lane + 64 * k;
+            int const nc = (int) ((ncmask >> sb[k]) & 1), z1 = (int) ((m01mask >> sb[k]) & 1);
+            uint32_t v = pk[k];
+            if (64 * k > pm)
+                continue;
+            {
+                /* straight-line code for all three cases (no branch per pair, so the table
+                 * look-ups of all pairs are in flight together); the rounding table comes
+                 * from its LDS head, values beyond it are redone below */
+                int     big0, big1;
+                int const q0 = lh_quant_line_head(qt, istep, xp[2 * k], big0);
+                int const q1 = lh_quant_line_head(qt, istep, xp[2 * k + 1], big1);
+                uint32_t const vq = (uint32_t) (q0 & 0xffff) | ((uint32_t) q1 << 16);
+                uint32_t const v01 = ((compareval0 > xp[2 * k]) ? 0u : 1u)
+                    | (((compareval0 > xp[2 * k + 1]) ? 0u : 1u) << 16);
+                anybig |= (nc && !z1) ? (big0 | big1) : 0;
+                v = nc ? (z1 ? v01 : vq) : v;
             }
-            else if (md[k] == 2) {
-                uint32_t const q0 = (compareval0 > xp[2 * k]) ? 0u : 1u;
-                uint32_t const q1 = (compareval0 > xp[2 * k + 1]) ? 0u : 1u;
-                ((uint32_t *) ix)[p] = q0 | (q1 << 16);
+            if (zero_mnc && p == pm)
+                v &= 0xffffu;
+            newpk[k] = v;
+        }
+        if (lh_ballot(anybig)) {
+            /* rare: some quantised value is >= 256, its rounding offset lives in HBM */
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                int const p = lane + 64 * k;
+                int const nc = (int) ((ncmask >> sb[k]) & 1), z1 = (int) ((m01mask >> sb[k]) & 1);
+                if (64 * k <= pm && nc && !z1) {
+                    int const q0 = lh_quant_line(T, qt, istep, xp[2 * k]);
+                    int const q1 = lh_quant_line(T, qt, istep, xp[2 * k + 1]);
+                    uint32_t v = (uint32_t) (q0 & 0xffff) | ((uint32_t) q1 << 16);
+                    if (zero_mnc && p == pm)
+                        v &= 0xffffu;
+                    newpk[k] = v;
+                }
             }
         }
-        if (zero_mnc && c.lane == (pm & 63)) {
-            ix[mnc] = 0;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            int const p = lane + 64 * k;
+            if (64 * k <= pm && newpk[k] != pk[k])
+                ix2[p] = newpk[k];
+            if (64 * k <= pm)
+                pk[k] = newpk[k];
         }
     }
-    LH_WAVE_SYNC();
     if (R.substep_shaping & 2) {
         int const gain = g.global_gain + g.scalefac_scale;
         float const roundfac = (float) (0.634521682242439 / T->ipow20[gain]);
-        for (int i = c.lane; i < 576; i += 64) {
+        LH_WAVE_SYNC();
+        for (int i = lane; i < 576; i += 64) {
             int const s = Q.sfb_of_line[i];
             if (s < R.sfbmax && Q.pseudohalf[s])
                 ix[i] = (xrpow[i] >= roundfac) ? ix[i] : (int16_t) 0;
         }
         LH_WAVE_SYNC();
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            int const p = lane + 64 * k;
+            pk[k] = (p < 288) ? ix2[p] : 0u;
+        }
     }
-    return lh_noquant_count_bits(c, Q, R, g, which, use_prev);
+    LH_PA(12, t_cb);
+    {
+        int const nb = lh_noquant_count_bits(c, Q, R, g, which, use_prev, pk);
+        LH_PA(11, t_cb);
+        return nb;
+    }
 }
 
 /* ---------------------------------------------------------------------- */
@@ -706,40 +953,58 @@ lh_calc_noise(const LhCtx & c, LhChanLds & Q, LhQR & R, const LhGrR & g, int whi
     const int *sf = Q.sf[which];
     int const s = c.lane;
     float   noise_s = 0.0f;
+    float   noise = 0, step = 0, r_l3_xmin = 0;
+    int     st = 0, l = 0, j = 0, fresh = 0, big = 0;
     LH_WAVE_SYNC();
     if (s < R.psymax) {
         int const pre = (g.preflag && s < LH_SBMAX_L) ? qt->pretab[s] : 0;
-        int const st = g.global_gain - ((sf[s] + pre) << (g.scalefac_scale + 1))
-            - lh_sbg(g, Q.window[s]) * 8;
-        float const r_l3_xmin = 1.f / Q.l3_xmin[s];
-        float   distort_, noise;
-        if (use_prev && (Q.pn_step[s] == st)) {
+        st = g.global_gain - ((sf[s] + pre) << (g.scalefac_scale + 1)) - lh_sbg(g, Q.window[s]) * 8;
+        r_l3_xmin = 1.f / Q.l3_xmin[s];
+        fresh = !(use_prev && (Q.pn_step[s] == st));
+    }
+    if (fresh) {
+        step = T->pow20[st + LH_QMAX2];
+        l = Q.width[s] >> 1;
+        j = Q.start[s];
+        /* the reference's running line index lags behind the band start only after a
+         * band cut at max_nonzero_coeff, where the remaining length is 0 either way */
+        if ((j + Q.width[s]) > R.mnc) {
+            int const usefullsize = R.mnc - j + 1;
+            l = (usefullsize > 0) ? (usefullsize >> 1) : 0;
+        }
+        /* One loop for the reference's three cases (calc_noise_core_c,
+         * quantize_pvt.c:750-796): above count1 every ix is 0 and pow43[0]*step = 0,
+         * so |xr| - 0 squares to xr*xr; in the count1 region ix is 0/1 and
+         * pow43[1] = 1.0f makes pow43[ix]*step equal to {0, step} exactly.  The adds
+         * form one serial chain per band (float order matters); the loads do not
+         * depend on it and the body has no branch, so the unrolled loop keeps them in
+         * flight.  pow43 comes from its LDS head; a band with a value beyond it is
+         * redone below. */
+#pragma unroll 8
+        for (int k = 0; k < 2 * l; k++) {
+            int const q = ix[j + k];
+            float const temp = lh_fabsf(xr[j + k]) - qt->pow43h[q & 255] * step;
+            big |= q >> 8;
+            noise += temp * temp;
+        }
+    }
+    if (lh_ballot(big != 0)) {
+        if (big) {
+            noise = 0;
+            for (int k = 0; k < 2 * l; k++) {
+                int const q = ix[j + k];
+                float const temp = lh_fabsf(xr[j + k]) - T->pow43[q] * step;
+                noise += temp * temp;
+            }
+        }
+    }
+    if (s < R.psymax) {
+        float   distort_;
+        if (!fresh) {
             distort_ = r_l3_xmin * Q.pn_noise[s];
             noise = Q.pn_noise_log[s];
         }
         else {
-            float const step = T->pow20[st + LH_QMAX2];
-            int     l = Q.width[s] >> 1;
-            int     j = Q.start[s];
-            /* the reference's running line index lags behind the band start only after a
-             * band cut at max_nonzero_coeff, where the remaining length is 0 either way */
-            if ((j + Q.width[s]) > R.mnc) {
-                int const usefullsize = R.mnc - j + 1;
-                l = (usefullsize > 0) ? (usefullsize >> 1) : 0;
-            }
-            noise = 0;
-            /* One loop for the reference's three cases (calc_noise_core_c,
-             * quantize_pvt.c:750-796): above count1 every ix is 0 and pow43[0]*step = 0,
-             * so |xr| - 0 squares to xr*xr; in the count1 region ix is 0/1 and
-             * pow43[1] = 1.0f makes pow43[ix]*step equal to {0, step} exactly.  The adds
-             * form one serial chain per band (float order matters); the loads do not
-             * depend on it, so the loop is unrolled to keep them in flight. */
-#pragma unroll 8
-            for (int k = 0; k < 2 * l; k++) {
-                int const q = ix[j + k];
-                float const temp = lh_fabsf(xr[j + k]) - ((q < 256) ? qt->pow43h[q] : T->pow43[q]) * step;
-                noise += temp * temp;
-            }
             if (use_prev) {
                 Q.pn_step[s] = st;
                 Q.pn_noise[s] = noise;

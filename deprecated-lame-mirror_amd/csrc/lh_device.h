@@ -13,6 +13,7 @@
 extern "C" {
 #endif
 
+#define LH_NPROF 20             /* cycle accumulators per wave (profiling builds) */
 #define LH_XMIN_N 61            /* 22 long + 13*3 short values of III_psy_xmin */
 
 typedef struct LhStreamState {
@@ -46,7 +47,7 @@ typedef struct LhStreamState {
     int     status;                     /* 0 ok; device-detected inconsistencies are reported here */
     int     pad[3];
     /* per-wave cycle accumulators, only filled by builds with -DLH_PROF (profiling aid) */
-    unsigned long long prof[2][12];
+    unsigned long long prof[2][LH_NPROF];
 } LhStreamState;
 
 /* one stream's work for one launch */

@@ -97,8 +97,17 @@ lh_load_qtabs(const LhCtx & c, LhQTabs & q)
     }
     for (int i = c.tid; i < LH_HT_POOL; i += LH_NT)
         q.ht_len[i] = lh_ht_len[i];
-    for (int i = c.tid; i < 576; i += LH_NT)
-        q.bv_scf[i] = (uint8_t) c.T->bv_scf[i];
+    for (int i = c.tid; i < 288; i += LH_NT) {
+        /* big_values = 2 i + 2: the region split the reference looks up with bv_scf[bv - 2], [bv - 1] */
+        int const bv = 2 * i + 2;
+        int const r0 = c.T->bv_scf[bv - 2], r1 = c.T->bv_scf[bv - 1];
+        int const a1 = c.T->sfb_l[r0 + 1], a2 = c.T->sfb_l[(r0 + r1 + 2 < LH_SBMAX_L) ? r0 + r1 + 2 : LH_SBMAX_L];
+        q.bvpack[i] = (uint32_t) r0 | ((uint32_t) r1 << 4) | ((uint32_t) a1 << 8) | ((uint32_t) a2 << 18);
+    }
+    if (c.tid == 0) {
+        q.sfb_s3 = (uint16_t) c.T->sfb_s[3];
+        q.pad = 0;
+    }
     if (c.tid < 9)
         q.table23[c.tid] = lh_table23[c.tid];
     if (c.tid < 16) {
@@ -166,7 +175,7 @@ lh_encode_frame(LhCtx & c, LhLds & L, LhFrameOut * fo)
     /* ---- polyphase priming on the first frame (reference encoder.c:189-236) ---- */
     c.mf = &L.mf[0][0];
     c.prof = &L.prof[w][0];
-    if (lane < 12)
+    if (lane < LH_NPROF)
         L.prof[w][lane] = 0;
     LH_PT(t_frame);
     if (!st->primed) {
@@ -429,7 +438,7 @@ lh_encode_frame(LhCtx & c, LhLds & L, LhFrameOut * fo)
     LH_PA(0, t_frame);
     LH_SYNC_WG();
 #if defined(LH_PROF) && !defined(LH_EMU)
-    if (lane < 12)
+    if (lane < LH_NPROF)
         st->prof[w][lane] += L.prof[w][lane];
     LH_SYNC_WG();
 #endif

@@ -108,6 +108,7 @@ static inline int lh_uni_i(int v) { return v; }
 static inline float lh_uni_f(float v) { return v; }
 static inline int lh_ffs64(uint64_t m) { return m ? __builtin_ctzll(m) : -1; }
 static inline int lh_popc64(uint64_t m) { return __builtin_popcountll(m); }
+static inline int lh_clz64(uint64_t m) { return m ? __builtin_clzll(m) : 64; }
 static inline double lh_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
 #else
@@ -139,18 +140,20 @@ __device__ __forceinline__ int lh_wave_id(void) { return (int) (threadIdx.x >> 6
  * total; the four row totals are then read with v_readlane and combined on the
  * scalar unit.  ~12 instructions instead of six ds_bpermute round trips.
  * lamehip_selftest() checks these against a serial LDS evaluation on the device. */
-template < int CTRL > __device__ __forceinline__ uint32_t
+/* `old' = the operation's identity with bound_ctrl lets the compiler fold the lane permute into
+ * the arithmetic instruction (v_add_u32_dpp ...): 4 VALU per reduction step chain instead of 8 */
+template < int CTRL, uint32_t IDENT > __device__ __forceinline__ uint32_t
 lh_dpp(uint32_t v)
 {
-    return (uint32_t) __builtin_amdgcn_update_dpp((int) v, (int) v, CTRL, 0xf, 0xf, false);
+    return (uint32_t) __builtin_amdgcn_update_dpp((int) IDENT, (int) v, CTRL, 0xf, 0xf, IDENT == 0u);
 }
 
-#define LH_DPP_REDUCE(OP) \
+#define LH_DPP_REDUCE(OP, IDENT) \
     { uint32_t t_; \
-      t_ = lh_dpp < 0xB1 > (v); v = OP(v, t_); \
-      t_ = lh_dpp < 0x4E > (v); v = OP(v, t_); \
-      t_ = lh_dpp < 0x141 > (v); v = OP(v, t_); \
-      t_ = lh_dpp < 0x140 > (v); v = OP(v, t_); \
+      t_ = lh_dpp < 0xB1, IDENT > (v); v = OP(v, t_); \
+      t_ = lh_dpp < 0x4E, IDENT > (v); v = OP(v, t_); \
+      t_ = lh_dpp < 0x141, IDENT > (v); v = OP(v, t_); \
+      t_ = lh_dpp < 0x140, IDENT > (v); v = OP(v, t_); \
       { uint32_t const r0_ = (uint32_t) __builtin_amdgcn_readlane((int) v, 0), \
                        r1_ = (uint32_t) __builtin_amdgcn_readlane((int) v, 16), \
                        r2_ = (uint32_t) __builtin_amdgcn_readlane((int) v, 32), \
@@ -162,10 +165,10 @@ lh_dpp(uint32_t v)
 #define LH_OP_MIN(a, b) ((a) < (b) ? (a) : (b))
 #define LH_OP_OR(a, b)  ((a) | (b))
 
-__device__ __forceinline__ uint32_t lh_wave_sum_u32(uint32_t v) LH_DPP_REDUCE(LH_OP_ADD)
-__device__ __forceinline__ uint32_t lh_wave_max_u32(uint32_t v) LH_DPP_REDUCE(LH_OP_MAX)
-__device__ __forceinline__ uint32_t lh_wave_min_u32(uint32_t v) LH_DPP_REDUCE(LH_OP_MIN)
-__device__ __forceinline__ uint32_t lh_wave_or_u32(uint32_t v) LH_DPP_REDUCE(LH_OP_OR)
+__device__ __forceinline__ uint32_t lh_wave_sum_u32(uint32_t v) LH_DPP_REDUCE(LH_OP_ADD, 0u)
+__device__ __forceinline__ uint32_t lh_wave_max_u32(uint32_t v) LH_DPP_REDUCE(LH_OP_MAX, 0u)
+__device__ __forceinline__ uint32_t lh_wave_min_u32(uint32_t v) LH_DPP_REDUCE(LH_OP_MIN, 0xffffffffu)
+__device__ __forceinline__ uint32_t lh_wave_or_u32(uint32_t v) LH_DPP_REDUCE(LH_OP_OR, 0u)
 
 __device__ __forceinline__ uint64_t
 lh_wave_or_u64(uint64_t v)
@@ -189,6 +192,7 @@ __device__ __forceinline__ int lh_uni_i(int v) { return __builtin_amdgcn_readfir
 __device__ __forceinline__ float lh_uni_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 __device__ __forceinline__ int lh_ffs64(uint64_t m) { return m ? (__ffsll((long long) m) - 1) : -1; }
 __device__ __forceinline__ int lh_popc64(uint64_t m) { return __popcll(m); }
+__device__ __forceinline__ int lh_clz64(uint64_t m) { return __clzll((long long) m); }
 __device__ __forceinline__ double lh_fma(double a, double b, double c) { return __fma_rn(a, b, c); }
 
 #endif

@@ -1,0 +1,27 @@
+#!/bin/bash
+# Run on the GPU box (through gpurun): kernel-trace statistics and PMC passes of the
+# bench command; raw output under gpurun_out/, text summaries under gpurun_out/summ_*.txt
+# (copy the ones to keep into profiles/).
+# usage: tools/gpu_profile.sh <tag> [bench args...]
+set -u
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+TAG=$1; shift
+ARGS=${*:---streams 1024 --seconds 5 --steps 2 --warmup 1 --no-cpu-baseline}
+OUT=$ROOT/gpurun_out
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$TAG -- python $ROOT/bench.py $ARGS > $OUT/kt_$TAG.log 2>&1
+f=$(find $OUT/kt_$TAG -name '*kernel_stats.csv' | head -1)
+{ echo "# rocprofv3 --kernel-trace --stats -- python bench.py $ARGS"; [ -n "$f" ] && cat "$f"; tail -1 $OUT/kt_$TAG.log; } > $OUT/summ_${TAG}_kernel_stats.txt
+i=0
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
+           "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_BRANCH" \
+           "SQ_INSTS_SMEM SQ_INSTS_FLAT SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_FLAT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_CVT" \
+           "FETCH_SIZE" "WRITE_SIZE"; do
+  i=$((i+1))
+  timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/pmc_${TAG}_$i -- python $ROOT/bench.py $ARGS > $OUT/pmc_${TAG}_$i.log 2>&1
+done
+{ echo "# rocprofv3 --pmc <set> --kernel-trace -- python bench.py $ARGS   (one pass per set; sums over the launches of the run)";
+  for j in 1 2 3 4 5; do python $ROOT/tools/pmc_summary.py $OUT/pmc_${TAG}_$j lh_encode; done; } > $OUT/summ_${TAG}_pmc.txt
+cat $OUT/summ_${TAG}_kernel_stats.txt | cut -c1-250 | head -12
+cat $OUT/summ_${TAG}_pmc.txt

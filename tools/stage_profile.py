@@ -16,7 +16,7 @@ import lamehip  # noqa: E402
 
 NAMES = ["frame total", "psy (2 granules)", "polyphase+mdct", "quant total (2 gr)", "init+xrpow+xmin",
          "outer_loop", "scalefac_store+huffman_divide", "  bin_search", "  balance_noise", "  calc_noise",
-         "count_bits calls", "-"]
+         "count_bits calls", "count_bits total", "  quantise part", "-", "-", "-", "-", "-", "-", "-"]
 
 
 def main():
@@ -31,17 +31,18 @@ def main():
     b.encode()
     ms = b.kernel_ms()
     ssz = enc.lib.lamehip_abi_sizeof(4)
-    tot = np.zeros((2, 12))
+    NP = 20
+    tot = np.zeros((2, NP))
     for s in range(0, B, max(1, B // 64)):
         buf = C.create_string_buffer(ssz)
         assert enc.lib.lamehip_batch_get_state(b.b, s, buf, ssz) == ssz
-        prof = np.frombuffer(buf.raw[-2 * 12 * 8:], dtype=np.uint64).reshape(2, 12)
+        prof = np.frombuffer(buf.raw[-2 * NP * 8:], dtype=np.uint64).reshape(2, NP)
         tot += prof
     frames = b.frames(0)
     print("batch %d x %.1f s: kernel %.2f ms, %d frames/stream" % (B, secs, ms, frames))
     for w in range(2):
         print("wave %d (cycles per frame, share of frame):" % w)
-        for i, nm in enumerate(NAMES[:11]):
+        for i, nm in enumerate(NAMES[:13]):
             v = tot[w][i] / (frames * len(range(0, B, max(1, B // 64))))
             print("   %-34s %12.0f  %5.1f%%" % (nm, v, 100.0 * tot[w][i] / max(tot[w][0], 1)))
 
