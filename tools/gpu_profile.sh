@@ -23,5 +23,6 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_L
 done
 { echo "# rocprofv3 --pmc <set> --kernel-trace -- python bench.py $ARGS   (one pass per set; sums over the launches of the run)";
   for j in 1 2 3 4 5; do python $ROOT/tools/pmc_summary.py $OUT/pmc_${TAG}_$j lh_encode; done; } > $OUT/summ_${TAG}_pmc.txt
+rm -rf $OUT/kt_$TAG $OUT/pmc_${TAG}_[0-9]   # raw traces are large; the summaries are what is kept
 cat $OUT/summ_${TAG}_kernel_stats.txt | cut -c1-250 | head -12
 cat $OUT/summ_${TAG}_pmc.txt
