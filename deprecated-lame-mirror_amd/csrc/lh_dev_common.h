@@ -173,6 +173,7 @@ struct LhQTabs {
     uint32_t bvpack[288];       /* big_values/2 - 1 -> region0_count | region1_count << 4 | end of region 0 << 8
                                  * | end of region 1 << 18 (reference takehiro.c:1334-1375 folded with sfb_l) */
     uint16_t sfb_s3, pad;       /* sfb_s[3] */
+    uint32_t lut_pa[17], lut_pb[17];    /* lh_region_lut() of a region maximum 0..15, 16 = ESC classes */
     uint8_t t32l[16], t33l[16];
     uint8_t pretab[24];
     float   pow43h[256];        /* heads of pow43 / adj43asm: nearly all quantised values are < 256 */

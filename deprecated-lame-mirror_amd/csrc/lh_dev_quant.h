@@ -360,69 +360,36 @@ lh_choose_table_lane(const LhQTabs * qt, const int16_t * ix, int lo, int hi, int
     }
 }
 
-/* Per-lane contribution of the pairs [plo, phi) to the bit counts of the candidate Huffman
- * tables for a region whose largest value is mx (wave-uniform); mirrors the table selection
- * of the reference's choose_table_nonMMX (takehiro.c:546-650).  No cross-lane work here:
- * the caller reduces w0 / w1 of all regions together. */
-LH_DEVFN void
-lh_region_partials(const LhQTabs * qt, const uint32_t pk[5], int lane, int plo, int phi, unsigned mx,
-                   unsigned &w0, unsigned &w1)
+/* Look-up parameters of one region, packed for a per-lane select: the candidate tables are
+ * read from the byte pool ht_len at o1/o2/o3 + x * xlen + y, or (ESC classes) from largetbl at
+ * x * 16 + y; unused candidates alias the first one (their sums are not read). */
+struct LhRegionLut {
+    uint32_t pa;                /* xlen | esc << 8 | o1 << 16 */
+    uint32_t pb;                /* o2 | o3 << 16 */
+};
+
+LH_DEVFN LhRegionLut
+lh_region_lut(unsigned mx)
 {
-    w0 = 0;
-    w1 = 0;
-    if (mx == 0 || mx > LH_IXMAX)
-        return;
-    if (mx == 1) {
-        const uint8_t *h1 = LH_HLEN(1);
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-            int const p = lane + 64 * k;
-            if (64 * k < phi && 64 * k + 63 >= plo && p >= plo && p < phi)
-                w0 += h1[2 * (pk[k] & 0xffffu) + (pk[k] >> 16)];
-        }
+    LhRegionLut r;
+    if (mx == 0 || mx > LH_IXMAX) {
+        r.pa = 2u;              /* nothing is read from the sums; keep the indices in bounds */
+        r.pb = 0u;
     }
-    else if (mx <= 3) {
-        unsigned const xlen = (mx == 2) ? 3u : 4u;
-        const uint32_t *table = (mx == 2) ? qt->table23 : qt->table56;
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-            int const p = lane + 64 * k;
-            if (64 * k < phi && 64 * k + 63 >= plo && p >= plo && p < phi)
-                w0 += table[(pk[k] & 0xffffu) * xlen + (pk[k] >> 16)];
-        }
-    }
-    else if (mx <= 15) {
-        int const t1 = lh_huf_noESC(mx);
-        unsigned const xlen = lh_ht_xlen_c(t1);
-        const uint8_t *h1 = LH_HLEN(t1), *h2 = LH_HLEN(t1 + 1), *h3 = LH_HLEN(t1 + 2);
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-            int const p = lane + 64 * k;
-            if (64 * k < phi && 64 * k + 63 >= plo && p >= plo && p < phi) {
-                unsigned const x = (pk[k] & 0xffffu) * xlen + (pk[k] >> 16);
-                w0 += (unsigned) h1[x] | ((unsigned) h2[x] << 16);
-                w1 += (unsigned) h3[x];
-            }
-        }
+    else if (mx > 15) {
+        unsigned const o = (unsigned) lh_ht_off(13);    /* any 16 x 16 table keeps the byte reads in bounds */
+        r.pa = 16u | (1u << 8) | (o << 16);
+        r.pb = o | (o << 16);
     }
     else {
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-            int const p = lane + 64 * k;
-            if (64 * k < phi && 64 * k + 63 >= plo && p >= plo && p < phi) {
-                unsigned x = pk[k] & 0xffffu, y = pk[k] >> 16;
-                if (x >= 15u) {
-                    x = 15u;
-                    w1++;
-                }
-                if (y >= 15u) {
-                    y = 15u;
-                    w1++;
-                }
-                w0 += qt->largetbl[(x << 4) + y];       /* high half: tables 16.., low half: tables 24.. */
-            }
-        }
+        int const t1 = lh_huf_noESC(mx);
+        unsigned const o1 = (unsigned) lh_ht_off(t1);
+        unsigned const o2 = (t1 >= 2) ? (unsigned) lh_ht_off(t1 + 1) : o1;
+        unsigned const o3 = (t1 >= 7) ? (unsigned) lh_ht_off(t1 + 2) : o1;
+        r.pa = lh_ht_xlen_c(t1) | (o1 << 16);
+        r.pb = o2 | (o3 << 16);
     }
+    return r;
 }
 
 /* the scalar half of choose_table: table index and bits from the wave totals */
@@ -436,12 +403,12 @@ lh_region_decide(unsigned mx, unsigned w0, unsigned w1, int *bits)
         return -1;
     }
     if (mx == 1) {
-        *bits += (int) w0;
+        *bits += (int) (w0 & 0xffffu);
         return 1;
     }
     if (mx <= 3) {
         int     t1 = lh_huf_noESC(mx);
-        unsigned s = w0 >> 16, s2 = w0 & 0xffffu;
+        unsigned s = w0 & 0xffffu, s2 = w0 >> 16;
         if (s > s2) {
             s = s2;
             t1++;
@@ -468,12 +435,16 @@ lh_region_decide(unsigned mx, unsigned w0, unsigned w1, int *bits)
         int     choice, choice2;
         unsigned const m15 = mx - 15u;
         unsigned sa, sb;
-        for (choice2 = 24; choice2 < 32; choice2++)
-            if (lh_ht_linmax_c(choice2) >= m15)
-                break;
-        for (choice = choice2 - 8; choice < 24; choice++)
-            if (lh_ht_linmax_c(choice) >= m15)
-                break;
+        /* smallest table of 24..31, and of choice2-8..23, whose linbits hold mx - 15: the
+         * reference's two linear searches (takehiro.c:631-640) as a function of the bit
+         * length of mx - 15 (linbits 16..23: 1,2,3,4,6,8,10,13; 24..31: 4..9,11,13) */
+        {
+            int const blen = 32 - lh_clz32(m15);                /* 1..13 */
+            int const t24 = (int) ((0x7777665432100000ull >> (4 * blen)) & 15u);
+            int const t16 = (int) ((0x7777766554432100ull >> (4 * blen)) & 15u);
+            choice2 = 24 + t24;
+            choice = 16 + (t16 > t24 ? t16 : t24);
+        }
         sa = (w0 >> 16) + w1 * lh_ht_xlen_c(choice);
         sb = (w0 & 0xffffu) + w1 * lh_ht_xlen_c(choice2);
         if (sa > sb) {
@@ -515,6 +486,7 @@ lh_noquant_count_bits(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, int w
     int     e0, e1, e2;             /* pair index where regions 0, 1, 2 end */
     int     a1, a2;
     unsigned quads = 0, sfbcnt_in = 0;
+    LH_PT(t_nq);
 
     if (use_prev)
         R.pn_sfb_count1 = 0;
@@ -562,6 +534,7 @@ lh_noquant_count_bits(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, int w
     e2 = (R.block_type == LH_NORM_TYPE) ? (bv >> 1) : e1;
     if (use_prev && R.block_type == LH_NORM_TYPE)
         sfbcnt_in = (lane < LH_SBMAX_L + 1) ? qt->sfb_l[lane] : 576u;
+    LH_PA(19, t_nq);
     /* count1 region: quadruples of 0/1 values, from the LDS image */
     if (nquad > 0) {
         LH_WAVE_SYNC();
@@ -572,6 +545,7 @@ lh_noquant_count_bits(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, int w
             quads += ((unsigned) qt->t32l[p] << 16) + (unsigned) qt->t33l[p];
         }
     }
+    LH_PA(20, t_nq);
     {
         /* region maxima: three independent reductions the scheduler can interleave */
         unsigned m0 = 0, m1 = 0, m2 = 0;
@@ -591,24 +565,72 @@ lh_noquant_count_bits(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, int w
         m0 = lh_wave_max_u32(m0);
         m1 = lh_wave_max_u32(m1);
         m2 = lh_wave_max_u32(m2);
-        lh_region_partials(qt, pk, lane, 0, e0, m0, w00, w01);
-        lh_region_partials(qt, pk, lane, e0, e1, m1, w10, w11);
-        lh_region_partials(qt, pk, lane, e1, e2, m2, w20, w21);
-        /* the kernel is issue-bound: reductions nobody reads are skipped (wave-uniform tests) */
-        if (nquad > 0)
-            quads = lh_wave_sum_u32(quads);
-        if (m0 > 0)
-            w00 = lh_wave_sum_u32(w00);
-        if (m0 > 3)
-            w01 = lh_wave_sum_u32(w01);
-        if (m1 > 0)
-            w10 = lh_wave_sum_u32(w10);
-        if (m1 > 3)
-            w11 = lh_wave_sum_u32(w11);
-        if (m2 > 0)
-            w20 = lh_wave_sum_u32(w20);
-        if (m2 > 3)
+        LH_PA(21, t_nq);
+        {
+            /* One look-up sequence per pair, not per (region, pair): each lane selects its
+             * region's parameters, all loads of the (up to) five pairs are in flight together
+             * and the results are added to the accumulators of the pair's region.  Blocks of
+             * 64 pairs above big_values are skipped (wave-uniform). */
+            LhRegionLut l0, l1, l2;     /* = lh_region_lut(m), tabulated in LDS */
+            l0.pa = qt->lut_pa[m0 < 16u ? m0 : 16u];
+            l0.pb = qt->lut_pb[m0 < 16u ? m0 : 16u];
+            l1.pa = qt->lut_pa[m1 < 16u ? m1 : 16u];
+            l1.pb = qt->lut_pb[m1 < 16u ? m1 : 16u];
+            l2.pa = qt->lut_pa[m2 < 16u ? m2 : 16u];
+            l2.pb = qt->lut_pb[m2 < 16u ? m2 : 16u];
+            unsigned v0[5], v1[5];
+            w00 = w01 = w10 = w11 = w20 = w21 = 0;
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                v0[k] = v1[k] = 0;
+                if (64 * k < e2) {
+                    int const p = lane + 64 * k;
+                    uint32_t const pa = (p < e0) ? l0.pa : (p < e1) ? l1.pa : (p < e2) ? l2.pa : 2u;
+                    uint32_t const pb = (p < e0) ? l0.pb : (p < e1) ? l1.pb : (p < e2) ? l2.pb : 0u;
+                    unsigned const x = pk[k] & 0xffffu, y = pk[k] >> 16;
+                    unsigned const xc = x < 15u ? x : 15u, yc = y < 15u ? y : 15u;
+                    unsigned const idx = xc * (pa & 0xffu) + yc;
+                    unsigned const b1 = qt->ht_len[(pa >> 16) + idx];
+                    unsigned const b2 = qt->ht_len[(pb & 0xffffu) + idx];
+                    unsigned const b3 = qt->ht_len[(pb >> 16) + idx];
+                    unsigned const e = qt->largetbl[idx & 255u];
+                    int const esc = (pa >> 8) & 1u;
+                    v0[k] = esc ? e : (b1 | (b2 << 16));
+                    v1[k] = esc ? (unsigned) (x >= 15u) + (unsigned) (y >= 15u) : b3;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                if (64 * k < e2) {
+                    int const p = lane + 64 * k;
+                    if (p < e0) {
+                        w00 += v0[k];
+                        w01 += v1[k];
+                    }
+                    else if (p < e1) {
+                        w10 += v0[k];
+                        w11 += v1[k];
+                    }
+                    else if (p < e2) {
+                        w20 += v0[k];
+                        w21 += v1[k];
+                    }
+                }
+            }
+        }
+        LH_PA(22, t_nq);
+        /* independent reductions, back to back so that their steps interleave */
+        quads = lh_wave_sum_u32(quads);
+        w00 = lh_wave_sum_u32(w00);
+        w10 = lh_wave_sum_u32(w10);
+        w20 = lh_wave_sum_u32(w20);
+        {
+            unsigned const wa = lh_wave_sum_u32(w01 | (w11 << 16));
             w21 = lh_wave_sum_u32(w21);
+            w01 = wa & 0xffffu;
+            w11 = wa >> 16;
+        }
+        LH_PA(23, t_nq);
         {
             int const c1a = (int) (quads >> 16), c1b = (int) (quads & 0xffffu);
             bits = c1a;
@@ -711,6 +733,7 @@ lh_count_bits(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, int which, in
             zero_mnc = cached_m && later;
         }
     }
+    LH_PA(18, t_cb);
     {
         float const compareval0 = (1.0f - 0.4054f) / istep;
         uint32_t newpk[5] = { 0u, 0u, 0u, 0u, 0u };
@@ -954,6 +977,8 @@ lh_calc_noise(const LhCtx & c, LhChanLds & Q, LhQR & R, const LhGrR & g, int whi
     int const s = c.lane;
     float   noise_s = 0.0f;
     float   noise = 0, step = 0, r_l3_xmin = 0;
+    LH_PC(13);
+    LH_PT(t_cn0);
     int     st = 0, l = 0, j = 0, fresh = 0, big = 0;
     LH_WAVE_SYNC();
     if (s < R.psymax) {
@@ -972,32 +997,98 @@ lh_calc_noise(const LhCtx & c, LhChanLds & Q, LhQR & R, const LhGrR & g, int whi
             int const usefullsize = R.mnc - j + 1;
             l = (usefullsize > 0) ? (usefullsize >> 1) : 0;
         }
-        /* One loop for the reference's three cases (calc_noise_core_c,
-         * quantize_pvt.c:750-796): above count1 every ix is 0 and pow43[0]*step = 0,
-         * so |xr| - 0 squares to xr*xr; in the count1 region ix is 0/1 and
-         * pow43[1] = 1.0f makes pow43[ix]*step equal to {0, step} exactly.  The adds
-         * form one serial chain per band (float order matters); the loads do not
-         * depend on it and the body has no branch, so the unrolled loop keeps them in
-         * flight.  pow43 comes from its LDS head; a band with a value beyond it is
-         * redone below. */
-#pragma unroll 8
-        for (int k = 0; k < 2 * l; k++) {
-            int const q = ix[j + k];
-            float const temp = lh_fabsf(xr[j + k]) - qt->pow43h[q & 255] * step;
-            big |= q >> 8;
-            noise += temp * temp;
-        }
     }
-    if (lh_ballot(big != 0)) {
-        if (big) {
-            noise = 0;
-            for (int k = 0; k < 2 * l; k++) {
-                int const q = ix[j + k];
-                float const temp = lh_fabsf(xr[j + k]) - T->pow43[q] * step;
-                noise += temp * temp;
+    /* One formula for the reference's three cases (calc_noise_core_c,
+     * quantize_pvt.c:750-796): above count1 every ix is 0 and pow43[0]*step = 0, so
+     * |xr| - 0 squares to xr*xr; in the count1 region ix is 0/1 and pow43[1] = 1.0f makes
+     * pow43[ix]*step equal to {0, step} exactly. */
+    if (c.cfg->noise_shaping_amp != 3) {
+        /* Phase A, all lanes: the squared error of every line, (|xr| - pow43[ix] step)^2,
+         * nine lines per lane, no branches; the band's step travels through LDS.
+         * Phase B, lane = band: the reference's serial sum over the band's lines (the order
+         * of the float additions is kept), reading the terms back; the loop bound is the
+         * longest fresh band (wave-uniform) and shorter bands add +0.0f, which leaves a
+         * non-negative sum unchanged. */
+        float  *sq = Q.save_xrpow;
+        int     maxw;
+        if (s <= LH_SFBMAX)
+            Q.sfb_f[s] = fresh ? step : 0.0f;
+        maxw = (int) lh_wave_max_u32(fresh ? (unsigned) (2 * l) : 0u);
+        LH_WAVE_SYNC();
+        {
+            int     q[9], sbv[9];
+            float   xv[9], stp[9], p43[9];
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+                int const i = c.lane + 64 * k;
+                q[k] = ix[i];
+                xv[k] = xr[i];
+                sbv[k] = Q.sfb_of_line[i];
+            }
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+                stp[k] = Q.sfb_f[sbv[k]];
+                p43[k] = qt->pow43h[q[k] & 255];
+                big |= q[k] >> 8;
+            }
+            if (lh_ballot(big != 0)) {
+                /* rare: a quantised value beyond the LDS head of pow43 */
+#pragma unroll
+                for (int k = 0; k < 9; k++)
+                    if (q[k] >= 256)
+                        p43[k] = T->pow43[q[k]];
+            }
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+                float const temp = lh_fabsf(xv[k]) - p43[k] * stp[k];
+                sq[c.lane + 64 * k] = temp * temp;
+            }
+        }
+        LH_WAVE_SYNC();
+        LH_PA(14, t_cn0);
+        {
+            /* eight terms are fetched (as four aligned pairs: band starts are even) before
+             * the eight dependent additions, so one LDS round trip is paid per eight lines */
+            int const n = 2 * l;
+            int const jj = (j < 576) ? j : 0;
+            const lh_f32x2 *sq2 = (const lh_f32x2 *) sq;
+            for (int k0 = 0; k0 < maxw; k0 += 8) {
+                lh_f32x2 t[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    int const idx = (jj + k0) / 2 + u;
+                    t[u] = sq2[idx < 288 ? idx : 287];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    noise += (k0 + 2 * u < n) ? t[u].x : 0.0f;
+                    noise += (k0 + 2 * u + 1 < n) ? t[u].y : 0.0f;
+                }
             }
         }
     }
+    else {
+        if (fresh) {
+#pragma unroll 8
+            for (int k = 0; k < 2 * l; k++) {
+                int const q = ix[j + k];
+                float const temp = lh_fabsf(xr[j + k]) - qt->pow43h[q & 255] * step;
+                big |= q >> 8;
+                noise += temp * temp;
+            }
+        }
+        if (lh_ballot(big != 0)) {
+            if (big) {
+                noise = 0;
+                for (int k = 0; k < 2 * l; k++) {
+                    int const q = ix[j + k];
+                    float const temp = lh_fabsf(xr[j + k]) - T->pow43[q] * step;
+                    noise += temp * temp;
+                }
+            }
+        }
+    }
+    LH_PA(15, t_cn0);
     if (s < R.psymax) {
         float   distort_;
         if (!fresh) {
@@ -1020,31 +1111,45 @@ lh_calc_noise(const LhCtx & c, LhChanLds & Q, LhQR & R, const LhGrR & g, int whi
     }
     if (use_prev)
         R.pn_global_gain = g.global_gain;
+    LH_PA(16, t_cn0);
     {
-        /* serial (order-preserving) accumulation over the bands, values fetched from
-         * the owning lane's register */
-        int     over = 0, ssd = 0;
-        float   over_noise_db = 0, tot_noise_db = 0, max_noise = -20.0f;
-        for (int sfb = 0; sfb < R.psymax; sfb++) {
-            float const noise = lh_u32_as_f32(lh_bcast_u32(lh_f32_as_u32(noise_s), sfb));
-            tot_noise_db += noise;
-            if (noise > 0.0) {
-                int     tmp = (int) (noise * 10 + .5);
-                if (tmp < 1)
-                    tmp = 1;
-                ssd += tmp * tmp;
-                over++;
-                over_noise_db += noise;
-            }
-            max_noise = (max_noise > noise) ? max_noise : noise;
+        /* Aggregation over the bands (reference quantize_pvt.c:884-911).  Only the two float
+         * sums depend on the band order: every lane forms them itself from the per-band
+         * values in LDS (uniform addresses, loads in flight together; skipped bands add +0.0f
+         * to a non-negative sum).  Count, integer sum and maximum do not depend on the order
+         * and are taken across the lanes. */
+        float   over_noise_db = 0, tot_noise_db = 0;
+        int const mine = (s < R.psymax);
+        int     tmp = 0;
+        if (s <= LH_SFBMAX)
+            Q.sfb_f[s] = noise_s;
+        if (mine && noise_s > 0.0f) {
+            tmp = (int) (noise_s * 10 + .5);
+            if (tmp < 1)
+                tmp = 1;
         }
-        res.over_count = over;
+        res.over_count = lh_popc64(lh_ballot(mine && noise_s > 0.0f));
+        res.over_SSD = (int) lh_wave_sum_u32((unsigned) (tmp * tmp));
+        res.max_noise = lh_wave_max_f32(mine ? noise_s : -20.0f);
+        LH_WAVE_SYNC();
+        for (int k0 = 0; k0 < R.psymax; k0 += 8) {
+            float   t[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                t[u] = Q.sfb_f[(k0 + u < LH_SFBMAX) ? k0 + u : LH_SFBMAX];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                if (k0 + u < R.psymax) {        /* wave-uniform */
+                    tot_noise_db += t[u];
+                    over_noise_db += (t[u] > 0.0f) ? t[u] : 0.0f;
+                }
+            }
+        }
         res.tot_noise = tot_noise_db;
         res.over_noise = over_noise_db;
-        res.max_noise = max_noise;
-        res.over_SSD = ssd;
     }
     LH_WAVE_SYNC();
+    LH_PA(17, t_cn0);
 }
 
 /* ---------------------------------------------------------------------- */
@@ -1569,8 +1674,12 @@ lh_outer_loop(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & gb, const float 
     lh_copy_gr(c, Q, 1, 0);
     gw = gb;
     age = 0;
-    for (int i = c.lane; i < 576; i += 64)
-        Q.save_xrpow[i] = Q.xrpow[i];
+    /* save_xrpow is only ever read back by the refinement pass of noise_shaping_amp 3
+     * (reference quantize.c:1170-1183); otherwise the buffer is calc_noise's scratch */
+    if (cfg->noise_shaping_amp == 3) {
+        for (int i = c.lane; i < 576; i += 64)
+            Q.save_xrpow[i] = Q.xrpow[i];
+    }
     LH_WAVE_SYNC();
 
     while (!bEndOfSearch) {
@@ -1626,8 +1735,10 @@ lh_outer_loop(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & gb, const float 
                 lh_copy_gr(c, Q, 0, 1);
                 gb = gw;
                 age = 0;
-                for (int i = c.lane; i < 576; i += 64)
-                    Q.save_xrpow[i] = Q.xrpow[i];
+                if (cfg->noise_shaping_amp == 3) {
+                    for (int i = c.lane; i < 576; i += 64)
+                        Q.save_xrpow[i] = Q.xrpow[i];
+                }
                 LH_WAVE_SYNC();
             }
             else {

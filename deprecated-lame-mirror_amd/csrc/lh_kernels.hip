@@ -108,6 +108,11 @@ lh_load_qtabs(const LhCtx & c, LhQTabs & q)
         q.sfb_s3 = (uint16_t) c.T->sfb_s[3];
         q.pad = 0;
     }
+    if (c.tid < 17) {
+        LhRegionLut const r = lh_region_lut((unsigned) c.tid);
+        q.lut_pa[c.tid] = r.pa;
+        q.lut_pb[c.tid] = r.pb;
+    }
     if (c.tid < 9)
         q.table23[c.tid] = lh_table23[c.tid];
     if (c.tid < 16) {
@@ -516,6 +521,17 @@ lh_selftest_kernel(unsigned *out, unsigned seed)
         bad += (lh_ballot((x & 4u) != 0) != rbal);
         bad += (lh_bcast_u32(x, (int) (round & 63)) != vals[round & 63]);
         bad += (lh_ffs64(rbal) != (rbal ? __builtin_ctzll(rbal) : -1));
+        bad += (lh_clz64(rbal | 1ull) != __builtin_clzll(rbal | 1ull));
+        {
+            /* float maximum over values of both signs */
+            float const f = (float) (int) (x & 0xffffu) - 32768.0f;
+            float   rf = -1e30f;
+            for (int i = 0; i < 64; i++) {
+                float const fi = (float) (int) (vals[i] & 0xffffu) - 32768.0f;
+                rf = fi > rf ? fi : rf;
+            }
+            bad += (lh_wave_max_f32(f) != rf);
+        }
         __syncthreads();
     }
     bad = lh_wave_sum_u32(bad);

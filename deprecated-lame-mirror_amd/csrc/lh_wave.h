@@ -104,11 +104,32 @@ lh_bcast_u32(uint32_t v, int src)
     return (uint32_t) x[src];
 }
 
+typedef struct { float x, y; } lh_f32x2;
+
+static inline float
+lh_wave_max_f32(float v)
+{
+    union { float f; uint32_t u; } c;
+    const uint64_t *x;
+    float   m;
+    c.f = v;
+    x = hipemu_wave_exchange(c.u);
+    c.u = (uint32_t) x[0];
+    m = c.f;
+    for (int i = 1; i < 64; i++) {
+        c.u = (uint32_t) x[i];
+        if (c.f > m)
+            m = c.f;
+    }
+    return m;
+}
+
 static inline int lh_uni_i(int v) { return v; }
 static inline float lh_uni_f(float v) { return v; }
 static inline int lh_ffs64(uint64_t m) { return m ? __builtin_ctzll(m) : -1; }
 static inline int lh_popc64(uint64_t m) { return __builtin_popcountll(m); }
 static inline int lh_clz64(uint64_t m) { return m ? __builtin_clzll(m) : 64; }
+static inline int lh_clz32(uint32_t m) { return m ? __builtin_clz(m) : 32; }
 static inline double lh_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
 #else
@@ -170,6 +191,25 @@ __device__ __forceinline__ uint32_t lh_wave_max_u32(uint32_t v) LH_DPP_REDUCE(LH
 __device__ __forceinline__ uint32_t lh_wave_min_u32(uint32_t v) LH_DPP_REDUCE(LH_OP_MIN, 0xffffffffu)
 __device__ __forceinline__ uint32_t lh_wave_or_u32(uint32_t v) LH_DPP_REDUCE(LH_OP_OR, 0u)
 
+typedef float2 lh_f32x2;
+
+/* maximum of 64 floats (no NaNs among them) */
+__device__ __forceinline__ float
+lh_wave_max_f32(float v)
+{
+#define LH_FMAX_STEP(CTRL) { float const t_ = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xf, 0xf, false)); v = (t_ > v) ? t_ : v; }
+    LH_FMAX_STEP(0xB1) LH_FMAX_STEP(0x4E) LH_FMAX_STEP(0x141) LH_FMAX_STEP(0x140)
+#undef LH_FMAX_STEP
+    {
+        float const r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)),
+            r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16)),
+            r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)),
+            r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+        float const a = r0 > r1 ? r0 : r1, b = r2 > r3 ? r2 : r3;
+        return a > b ? a : b;
+    }
+}
+
 __device__ __forceinline__ uint64_t
 lh_wave_or_u64(uint64_t v)
 {
@@ -193,6 +233,7 @@ __device__ __forceinline__ float lh_uni_f(float v) { return __int_as_float(__bui
 __device__ __forceinline__ int lh_ffs64(uint64_t m) { return m ? (__ffsll((long long) m) - 1) : -1; }
 __device__ __forceinline__ int lh_popc64(uint64_t m) { return __popcll(m); }
 __device__ __forceinline__ int lh_clz64(uint64_t m) { return __clzll((long long) m); }
+__device__ __forceinline__ int lh_clz32(uint32_t m) { return __clz((int) m); }
 __device__ __forceinline__ double lh_fma(double a, double b, double c) { return __fma_rn(a, b, c); }
 
 #endif

@@ -16,7 +16,9 @@ import lamehip  # noqa: E402
 
 NAMES = ["frame total", "psy (2 granules)", "polyphase+mdct", "quant total (2 gr)", "init+xrpow+xmin",
          "outer_loop", "scalefac_store+huffman_divide", "  bin_search", "  balance_noise", "  calc_noise",
-         "count_bits calls", "count_bits total", "  quantise part", "-", "-", "-", "-", "-", "-", "-"]
+         "count_bits calls", "count_bits total", "  quantise part", "calc_noise calls", "  cn: after phase A", "  cn: after phase B", "  cn: after per-band log",
+         "  cn: total", "  cb: loads+band decisions", "  nq: count1/big_values/regions", "  nq: + quads", "  nq: + region maxima",
+         "  nq: + table look-ups", "  nq: + sums", "-", "-", "-", "-"]
 
 
 def main():
@@ -31,7 +33,7 @@ def main():
     b.encode()
     ms = b.kernel_ms()
     ssz = enc.lib.lamehip_abi_sizeof(4)
-    NP = 20
+    NP = 28
     tot = np.zeros((2, NP))
     for s in range(0, B, max(1, B // 64)):
         buf = C.create_string_buffer(ssz)
@@ -42,7 +44,7 @@ def main():
     print("batch %d x %.1f s: kernel %.2f ms, %d frames/stream" % (B, secs, ms, frames))
     for w in range(2):
         print("wave %d (cycles per frame, share of frame):" % w)
-        for i, nm in enumerate(NAMES[:13]):
+        for i, nm in enumerate(NAMES[:24]):
             v = tot[w][i] / (frames * len(range(0, B, max(1, B // 64))))
             print("   %-34s %12.0f  %5.1f%%" % (nm, v, 100.0 * tot[w][i] / max(tot[w][0], 1)))
 
