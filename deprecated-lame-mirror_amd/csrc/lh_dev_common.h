@@ -25,8 +25,8 @@
 
 #if defined(LH_PROF) && !defined(LH_EMU)
 #define LH_PT(var) unsigned long long var = clock64()
-#define LH_PA(idx, var) do { if (c.lane == 0) c.prof[idx] += clock64() - var; } while (0)
-#define LH_PC(idx) do { if (c.lane == 0) c.prof[idx] += 1; } while (0)
+#define LH_PA(idx, var) do { if (c.lane == 0) lh_lds.prof[c.wave][idx] += clock64() - var; } while (0)
+#define LH_PC(idx) do { if (c.lane == 0) lh_lds.prof[c.wave][idx] += 1; } while (0)
 #else
 #define LH_PT(var) do { } while (0)
 #define LH_PA(idx, var) do { } while (0)
@@ -219,6 +219,12 @@ struct LhLds {
     } u;
 };
 
+/* The workgroup's LDS image (one stream), at file scope: every device function, in line or
+ * not, addresses it as LDS with constant offsets (ds_* instructions).  Handing it to the
+ * out-of-line stages by reference made all their accesses generic FLAT loads. */
+__shared__ LhLds lh_lds;
+#define LH_QT (&lh_lds.qt)
+
 /* ---- launch context -------------------------------------------------- */
 struct LhCtx {
     const LhConfig *cfg;
@@ -227,11 +233,42 @@ struct LhCtx {
     const int16_t *pcm;
     LhStreamDesc d;
     long long frame_base;       /* stream sample index of mfbuf[0] for the current frame: 1152 f - 528 */
-    const float *mf;            /* LDS: mf[ch * LH_MF_NEEDED + i] = sample i of the frame window */
-    unsigned long long *prof;   /* LDS: this wave's cycle accumulators (LH_PROF builds) */
-    const LhQTabs *qt;          /* LDS: quantiser lookup tables */
     int     lane, wave, tid;
 };
+
+/* The context reaches an out-of-line stage through per-lane memory, which hides from the
+ * compiler that its pointers address HBM; routing them through the global address space once
+ * lets it use global_/s_load instead of FLAT accesses for everything derived from them. */
+#ifdef LH_EMU
+#define LH_AS_GLOBAL(type, p) (p)
+#else
+/* p is wave-uniform and addresses HBM.  The value is rebuilt from two scalar registers behind an
+ * empty asm statement, so that the optimiser cannot fold the address-space casts away; what
+ * comes out is "a global pointer, cast to generic", which address-space inference then
+ * propagates to every access made through it. */
+template < typename X > __device__ __forceinline__ X *
+lh_as_global(X * p)
+{
+    typedef __attribute__((address_space(1))) X GX;
+    unsigned long long const u = (unsigned long long) p;
+    unsigned lo = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) u);
+    unsigned hi = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) (u >> 32));
+    asm volatile("" : "+s"(lo), "+s"(hi));
+    return (X *) (GX *) (((unsigned long long) hi << 32) | lo);
+}
+#define LH_AS_GLOBAL(type, p) lh_as_global < type > (p)
+#endif
+LH_DEVFN LhCtx
+lh_ctx_global(const LhCtx & i)
+{
+    LhCtx   o = i;
+    o.cfg = LH_AS_GLOBAL(const LhConfig, i.cfg);
+    o.T = LH_AS_GLOBAL(const LhTables, i.T);
+    o.st = LH_AS_GLOBAL(LhStreamState, i.st);
+    o.pcm = LH_AS_GLOBAL(const int16_t, i.pcm);
+    o.wave = lh_uni_i(i.wave);
+    return o;
+}
 
 /* sample p of the stream as the reference's mfbuf holds it: scaled PCM, zero outside
  * the stream (reference lame.c:1802-1834 scaling; :1671-1775 framing) */
@@ -260,7 +297,7 @@ lh_stage_window(const LhCtx & c, float (*mf)[LH_MF_NEEDED], long long base)
 LH_DEVFN float
 lh_smp(const LhCtx & c, int ch, int i)
 {
-    return c.mf[ch * LH_MF_NEEDED + i];
+    return lh_lds.mf[ch][i];
 }
 
 #endif

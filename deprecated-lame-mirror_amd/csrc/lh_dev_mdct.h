@@ -90,8 +90,9 @@ lh_subband_taps(const LhCtx & c, int ch, int x, int n, float *pre)
 }
 
 LH_STAGEFN void
-lh_subband_network(float *io)
+lh_subband_network(int ch, int g, int slot)
 {
+    float  *io = &lh_lds.u.mdct.sb[ch][g][slot * 32];
     float   a[32];
     float   xr;
 #pragma unroll
@@ -348,8 +349,10 @@ lh_mdct_long(float *out, float const *in)
 /* polyphase filtering of the 36 slots of the current frame window of channel
  * `ch' into sb[1..2]; one wave (reference newmdct.c:958-973, 984-991) */
 LH_STAGEFN void
-lh_polyphase(LH_CTXARG c, int ch, float (*sb)[576])
+lh_polyphase(LH_CTXARG cin, int ch)
 {
+    LhCtx const c = lh_ctx_global(cin);
+    float   (*sb)[576] = lh_lds.u.mdct.sb[ch];
     const float *amp = c.T->amp_filter;
     /* stage 1: 36 slots x 16 tap rows */
     for (int u = c.lane; u < 36 * 16; u += 64) {
@@ -363,7 +366,7 @@ lh_polyphase(LH_CTXARG c, int ch, float (*sb)[576])
         int const s = c.lane;
         int const gr = s / 18, slot = s - gr * 18;
         float  *out = &sb[1 + gr][slot * 32];
-        lh_subband_network(out);
+        lh_subband_network(ch, 1 + gr, slot);
         if (slot & 1) {
             /* compensate for the inversion in the analysis filter */
             for (int band = 1; band < 32; band += 2)
@@ -389,8 +392,11 @@ lh_polyphase(LH_CTXARG c, int ch, float (*sb)[576])
 /* MDCT + alias reduction for both granules of channel ch; one wave
  * (reference newmdct.c:978-1033) */
 LH_STAGEFN void
-lh_mdct_granules(LH_CTXARG c, LhLds & L, int ch, float (*sb)[576])
+lh_mdct_granules(LH_CTXARG cin, int ch)
 {
+    LhCtx const c = lh_ctx_global(cin);
+    LhLds & L = lh_lds;
+    float   (*sb)[576] = lh_lds.u.mdct.sb[ch];
     const float *amp = c.T->amp_filter;
     int const gr = c.lane >> 5, band = c.lane & 31;
     int const type = L.block_type[gr][ch];

@@ -130,7 +130,7 @@ lh_quant_line_head(const LhQTabs * qt, float istep, float xp, int &big)
 LH_DEVFN int
 lh_choose_table_wave(const LhCtx & c, const int v[5][2], int lo, int hi, int *bits)
 {
-    const LhQTabs *qt = c.qt;
+    const LhQTabs *qt = LH_QT;
     unsigned mx = 0;
     int const plo = lo >> 1, phi = hi >> 1;
 #pragma unroll
@@ -477,7 +477,7 @@ LH_DEVFN int
 lh_noquant_count_bits(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, int which, int use_prev,
                       const uint32_t pk[5])
 {
-    const LhQTabs *qt = c.qt;
+    const LhQTabs *qt = LH_QT;
     const uint32_t *ix2 = (const uint32_t *) Q.ix[which];
     int const lane = c.lane;
     int const i0p = (((R.mnc + 2) >> 1) > 288) ? 288 : ((R.mnc + 2) >> 1);
@@ -666,7 +666,7 @@ lh_count_bits(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, int which, in
     LH_PC(10);
     LH_PT(t_cb);
     const LhTables *T = c.T;
-    const LhQTabs *qt = c.qt;
+    const LhQTabs *qt = LH_QT;
     int16_t *ix = Q.ix[which];
     uint32_t *ix2 = (uint32_t *) Q.ix[which];
     const int *sf = Q.sf[which];
@@ -816,7 +816,7 @@ lh_count_bits(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, int which, in
 LH_DEVFN int
 lh_scale_bitcount(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g, int which)
 {
-    const LhQTabs *qt = c.qt;
+    const LhQTabs *qt = LH_QT;
     int    *sf = Q.sf[which];
     int     k, max_slen1, max_slen2;
     const int *tabp;
@@ -872,13 +872,12 @@ lh_ath_adjust(const LhTables * T, float a, float x, float athFloor, float ATHfix
 }
 
 /* reference quantize_pvt.c:589-747: one lane per scalefactor band (window) */
-LH_STAGEFN void
-lh_calc_xmin(LH_CTXARG c, LhChanLds & Q, LhQR & R, const float *xr, const float *ren,
-             const float *rthm)
+LH_DEVFN void
+lh_calc_xmin_body(const LhCtx & c, LhChanLds & Q, LhQR & R, const float *xr, const float *ren, const float *rthm)
 {
     const LhConfig *cfg = c.cfg;
     const LhTables *T = c.T;
-    const LhQTabs *qt = c.qt;
+    const LhQTabs *qt = LH_QT;
     int const s = c.lane;
     float const adj = c.st->ath_adjust_factor;
     if (s < R.psymax) {
@@ -965,13 +964,24 @@ lh_calc_xmin(LH_CTXARG c, LhChanLds & Q, LhQR & R, const float *xr, const float 
     LH_WAVE_SYNC();
 }
 
+/* out-of-line entry: R travels through per-lane memory, the body works on scalar copies */
+LH_STAGEFN void
+lh_calc_xmin(LH_CTXARG cin, int qch, LhQR & Rio, int gr, int rch)
+{
+    LhCtx const c = lh_ctx_global(cin);
+    LhQR    R = lh_uniform(Rio);
+    lh_calc_xmin_body(c, lh_lds.u.quant.ch[qch], R, lh_lds.xr[qch][gr], lh_lds.ratio_en[gr][rch],
+                      lh_lds.ratio_thm[gr][rch]);
+    Rio = R;
+}
+
 /* reference quantize_pvt.c:750-913: one lane per band, wave-uniform aggregation */
 LH_DEVFN void
 lh_calc_noise(const LhCtx & c, LhChanLds & Q, LhQR & R, const LhGrR & g, int which,
               const float *xr, LhNoiseRes & res, int use_prev)
 {
     const LhTables *T = c.T;
-    const LhQTabs *qt = c.qt;
+    const LhQTabs *qt = LH_QT;
     const int16_t *ix = Q.ix[which];
     const int *sf = Q.sf[which];
     int const s = c.lane;
@@ -1155,12 +1165,11 @@ lh_calc_noise(const LhCtx & c, LhChanLds & Q, LhQR & R, const LhGrR & g, int whi
 /* ---------------------------------------------------------------------- */
 /* geometry of the granule + spectrum re-ordering for short blocks
  * (reference quantize.c:226-346) */
-LH_STAGEFN void
-lh_init_outer_loop(LH_CTXARG c, LhChanLds & Q, LhQR & R, LhGrR & g, float *xr, int block_type,
-                   int substep)
+LH_DEVFN void
+lh_init_outer_loop_body(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, float *xr, int block_type, int substep)
 {
     const LhTables *T = c.T;
-    const LhQTabs *qt = c.qt;
+    const LhQTabs *qt = LH_QT;
     int const sfb21 = c.cfg->sfb21_extra;
     g.part2_3_length = 0;
     g.big_values = 0;
@@ -1254,6 +1263,18 @@ lh_init_outer_loop(LH_CTXARG c, LhChanLds & Q, LhQR & R, LhGrR & g, float *xr, i
         }
     }
     LH_WAVE_SYNC();
+}
+
+LH_STAGEFN void
+lh_init_outer_loop(LH_CTXARG cin, int qch, LhQR & Rio, LhGrR & gio, int gr, int block_type, int substep)
+{
+    LhCtx const c = lh_ctx_global(cin);
+    LhQR    R;
+    LhGrR   g;
+    lh_init_outer_loop_body(c, lh_lds.u.quant.ch[qch], R, g, lh_lds.xr[qch][gr], lh_uni_i(block_type),
+                            lh_uni_i(substep));
+    Rio = R;
+    gio = g;
 }
 
 /* Lines above max_nonzero_coeff are zero in every quantised image (the reference clears
@@ -1515,7 +1536,7 @@ lh_amp_scalefac_bands(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g,
 LH_DEVFN void
 lh_inc_scalefac_scale(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g, int which)
 {
-    const LhQTabs *qt = c.qt;
+    const LhQTabs *qt = LH_QT;
     float const ifqstep34 = (float) 1.29683955465100964055;
     LH_WAVE_SYNC();
     if (c.lane <= LH_SFBMAX) {
@@ -1544,7 +1565,7 @@ LH_DEVFN int
 lh_inc_subblock_gain(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g, int which)
 {
     const LhTables *T = c.T;
-    const LhQTabs *qt = c.qt;
+    const LhQTabs *qt = LH_QT;
     int    *sf = Q.sf[which];
     int     sfb, window;
     LH_WAVE_SYNC();
@@ -1778,11 +1799,11 @@ lh_outer_loop(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & gb, const float 
 /* ---------------------------------------------------------------------- */
 /* reference takehiro.c:964-1094; gr0's final scalefactors come from the output slot
  * g0sf (int8, -1 = shared).  scfsi_out[4] is written by lane 0. */
-LH_STAGEFN void
-lh_best_scalefac_store(LH_CTXARG c, LhChanLds & Q, const LhQR & R, LhGrR & g, int gr,
-                       const int8_t * g0sf, int g0_block_type, int *scfsi_out)
+LH_DEVFN void
+lh_best_scalefac_store_body(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g, int gr,
+                            const int8_t * g0sf, int g0_block_type, int *scfsi_out)
 {
-    const LhQTabs *qt = c.qt;
+    const LhQTabs *qt = LH_QT;
     int    *sf = Q.sf[0];
     const int16_t *ix = Q.ix[0];
     int     sfb, i;
@@ -1888,15 +1909,27 @@ lh_best_scalefac_store(LH_CTXARG c, LhChanLds & Q, const LhQR & R, LhGrR & g, in
             scfsi_out[i] = scfsi[i];
 }
 
+LH_STAGEFN void
+lh_best_scalefac_store(LH_CTXARG cin, int qch, const LhQR & Rio, LhGrR & gio, int gr,
+                       const int8_t * g0sf, int g0_block_type)
+{
+    LhCtx const c = lh_ctx_global(cin);
+    LhQR const R = lh_uniform(Rio);
+    LhGrR   g = lh_uniform(gio);
+    lh_best_scalefac_store_body(c, lh_lds.u.quant.ch[qch], R, g, lh_uni_i(gr), LH_AS_GLOBAL(const int8_t, g0sf),
+                                lh_uni_i(g0_block_type), lh_lds.scfsi[qch]);
+    gio = g;
+}
+
 /* reference takehiro.c:809-957.  The reference evaluates up to 16 + 128 region
  * splits with serial choose_table calls; here every candidate split is costed
  * by its own lane (serial scan of its region in LDS), then the reference's
  * first-minimum selection is replayed wave-uniformly. */
-LH_STAGEFN void
-lh_best_huffman_divide(LH_CTXARG c, LhChanLds & Q, const LhQR & R, LhGrR & g)
+LH_DEVFN void
+lh_best_huffman_divide_body(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g)
 {
     const LhTables *T = c.T;
-    const LhQTabs *qt = c.qt;
+    const LhQTabs *qt = LH_QT;
     const int16_t *ix = Q.ix[0];
     int    *r01_bits = Q.scr[0];        /* [23] */
     int    *r01_div = Q.scr[1];         /* [23] */
@@ -1919,7 +1952,7 @@ lh_best_huffman_divide(LH_CTXARG c, LhChanLds & Q, const LhQR & R, LhGrR & g)
             int const e1 = qt->sfb_l[r0 + 1];
             int     b = 0, t = 0;
             if (e1 < bigv0)
-                t = lh_choose_table_lane(c.qt, ix, 0, e1, &b);
+                t = lh_choose_table_lane(LH_QT, ix, 0, e1, &b);
             r0bits_a[r0] = b;
             r0t_a[r0] = t;
         }
@@ -1931,7 +1964,7 @@ lh_best_huffman_divide(LH_CTXARG c, LhChanLds & Q, const LhQR & R, LhGrR & g)
             int     b = LH_LARGE_BITS, t = 0;
             if (e1 < bigv0 && e2 < bigv0) {
                 b = r0bits_a[r0];
-                t = lh_choose_table_lane(c.qt, ix, e1, e2, &b);
+                t = lh_choose_table_lane(LH_QT, ix, e1, e2, &b);
             }
             comb_bits[cmb] = b;
             comb_tbl[cmb] = t;
@@ -2038,7 +2071,7 @@ lh_best_huffman_divide(LH_CTXARG c, LhChanLds & Q, const LhQR & R, LhGrR & g)
                 if (e2 < bigv) {
                     b = r01_bits[r2 - 2] + c1bits;
                     if (r01_bits[r2 - 2] < LH_LARGE_BITS)
-                        t = lh_choose_table_lane(c.qt, ix, e2, bigv, &b);
+                        t = lh_choose_table_lane(LH_QT, ix, e2, bigv, &b);
                 }
                 r2bits[r2] = b;
                 r2tbl[r2] = t;
@@ -2069,6 +2102,16 @@ lh_best_huffman_divide(LH_CTXARG c, LhChanLds & Q, const LhQR & R, LhGrR & g)
             LH_WAVE_SYNC();
         }
     }
+}
+
+LH_STAGEFN void
+lh_best_huffman_divide(LH_CTXARG cin, int qch, const LhQR & Rio, LhGrR & gio)
+{
+    LhCtx const c = lh_ctx_global(cin);
+    LhQR const R = lh_uniform(Rio);
+    LhGrR   g = lh_uniform(gio);
+    lh_best_huffman_divide_body(c, lh_lds.u.quant.ch[qch], R, g);
+    gio = g;
 }
 
 /* ---------------------------------------------------------------------- */

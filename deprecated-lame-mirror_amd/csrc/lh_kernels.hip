@@ -170,23 +170,22 @@ lh_store_granule(const LhCtx & c, const LhChanLds & Q, const LhQR & R, const LhG
 
 /* one frame of one stream; executed by the whole workgroup */
 LH_DEVFN void
-lh_encode_frame(LhCtx & c, LhLds & L, LhFrameOut * fo)
+lh_encode_frame(LhCtx & c, LhFrameOut * fo)
 {
+    LhLds & L = lh_lds;
     const LhConfig *cfg = c.cfg;
     const LhTables *T = c.T;
     LhStreamState *st = c.st;
     int const w = c.wave, lane = c.lane, tid = c.tid;
 
     /* ---- polyphase priming on the first frame (reference encoder.c:189-236) ---- */
-    c.mf = &L.mf[0][0];
-    c.prof = &L.prof[w][0];
     if (lane < LH_NPROF)
         L.prof[w][lane] = 0;
     LH_PT(t_frame);
     if (!st->primed) {
         lh_stage_window(c, L.mf, c.frame_base - 1152);
         LH_SYNC_WG();
-        lh_polyphase(c, w, L.u.mdct.sb[w]);
+        lh_polyphase(c, w);
         for (int i = lane; i < 576; i += 64)
             st->sb_prev[w][i] = L.u.mdct.sb[w][2][i];
         LH_SYNC_WG();
@@ -221,7 +220,7 @@ lh_encode_frame(LhCtx & c, LhLds & L, LhFrameOut * fo)
     /* ---- stage 1: psycho-acoustic model, two granules ---- */
     LH_PT(t_psy);
     for (int gr = 0; gr < 2; gr++)
-        lh_psy_granule(c, L, gr);
+        lh_psy_granule(c, gr);
     LH_PA(1, t_psy);
 
     float   ms_ener_ratio[2] = { .5f, .5f };
@@ -255,15 +254,14 @@ lh_encode_frame(LhCtx & c, LhLds & L, LhFrameOut * fo)
     LH_PT(t_mdct);
     for (int i = lane; i < 576; i += 64)
         L.u.mdct.sb[w][0][i] = st->sb_prev[w][i];
-    lh_polyphase(c, w, L.u.mdct.sb[w]);
+    lh_polyphase(c, w);
     LH_SYNC_WG();               /* last read of mf (both channels) before xr overwrites it */
-    lh_mdct_granules(c, L, w, L.u.mdct.sb[w]);
+    lh_mdct_granules(c, w);
     for (int i = lane; i < 576; i += 64)
         st->sb_prev[w][i] = L.u.mdct.sb[w][2][i];
     LH_SYNC_WG();
     LH_PA(2, t_mdct);
     lh_load_qtabs(c, L.qt);     /* mf is dead; xr stays */
-    c.qt = &L.qt;
     LH_SYNC_WG();
 
     /* ---- stage 3: M/S decision (reference encoder.c:413-461) ---- */
@@ -352,14 +350,14 @@ lh_encode_frame(LhCtx & c, LhLds & L, LhFrameOut * fo)
             {
                 LhQR    Rt;
                 LhGrR   gt;
-                lh_init_outer_loop(c, Q, Rt, gt, xr, L.block_type[gr][ch], substep);
+                lh_init_outer_loop(c, ch, Rt, gt, gr, L.block_type[gr][ch], substep);
                 R = lh_uniform(Rt);
                 g = lh_uniform(gt);
             }
             if (lh_init_xrpow(c, Q, R, g, xr)) {
                 {
                     LhQR    Rt = R;
-                    lh_calc_xmin(c, Q, Rt, xr, L.ratio_en[gr][msoff + ch], L.ratio_thm[gr][msoff + ch]);
+                    lh_calc_xmin(c, ch, Rt, gr, msoff + ch);
                     R = lh_uniform(Rt);
                 }
                 lh_zero_tail(c, Q, R);
@@ -372,10 +370,9 @@ lh_encode_frame(LhCtx & c, LhLds & L, LhFrameOut * fo)
             {
                 LhQR const Rt = R;
                 LhGrR   gt = g;
-                lh_best_scalefac_store(c, Q, Rt, gt, gr, fo->gr[0][ch].scalefac, L.block_type[0][ch],
-                                       L.scfsi[ch]);
+                lh_best_scalefac_store(c, ch, Rt, gt, gr, fo->gr[0][ch].scalefac, L.block_type[0][ch]);
                 if (cfg->use_best_huffman == 1)
-                    lh_best_huffman_divide(c, Q, Rt, gt);
+                    lh_best_huffman_divide(c, ch, Rt, gt);
                 g = lh_uniform(gt);
             }
             LH_PA(6, t_fin);
@@ -458,7 +455,7 @@ lh_encode_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm,
                  const LhStreamDesc * descs, LhStreamState * states, LhFrameOut * out,
                  int nstreams)
 {
-    __shared__ LhLds L;
+    LhLds & L = lh_lds;
     int const sidx = (int) blockIdx.x;
     if (sidx >= nstreams)
         return;
@@ -482,7 +479,7 @@ lh_encode_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm,
     c.wave = lh_uni_i(c.tid >> 6);      /* scalar: everything indexed by the wave id gets scalar addressing */
     for (int f = c.d.frame_begin; f < c.d.frame_end; f++) {
         c.frame_base = 1152LL * f - LH_MF_START;
-        lh_encode_frame(c, L, &out[c.d.out_index + (f - c.d.frame_begin)]);
+        lh_encode_frame(c, &out[c.d.out_index + (f - c.d.frame_begin)]);
     }
 }
 
