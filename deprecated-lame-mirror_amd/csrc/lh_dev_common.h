@@ -25,7 +25,7 @@
 
 #if defined(LH_PROF) && !defined(LH_EMU)
 #define LH_PT(var) unsigned long long var = clock64()
-#define LH_PA(idx, var) do { if (c.lane == 0) lh_lds.prof[c.wave][idx] += clock64() - var; } while (0)
+#define LH_PA(idx, var) do { if (c.lane == 0) lh_lds.prof[c.wave][idx] += (unsigned) (clock64() - var); } while (0)
 #define LH_PC(idx) do { if (c.lane == 0) lh_lds.prof[c.wave][idx] += 1; } while (0)
 #else
 #define LH_PT(var) do { } while (0)
@@ -63,9 +63,6 @@ struct LhMdctLds {
 
 /* wave-uniform scalar image of gr_info (reference l3side.h:47-84): every lane holds
  * its own identical copy in registers, so updates need no cross-lane ordering */
-/* out-of-line stages get their own copy of the context, so that the kernel's copy never has
- * its address taken and stays in registers */
-#define LH_CTXARG const LhCtx
 
 struct LhGrR {
     int     part2_3_length, big_values, count1, global_gain, scalefac_compress;
@@ -160,7 +157,6 @@ struct LhChanLds {
     /* scratch */
     int     sfb_mode[LH_SFBMAX + 1];
     float   sfb_f[LH_SFBMAX + 1];
-    int     scr[4][24];
 };
 
 /* hot lookup tables of the quantiser, staged into LDS for the iteration-loop phase
@@ -184,6 +180,23 @@ struct LhQuantLds {
     LhChanLds ch[2];
 };
 
+/* launch context of the workgroup, written once per launch (frame_base per frame) by thread 0;
+ * out-of-line stages read it from here instead of receiving a per-lane copy */
+struct LhCtxShared {
+    const LhConfig *cfg;
+    const LhTables *T;
+    LhStreamState *st;
+    const int16_t *pcm;
+    LhStreamDesc d;
+    long long frame_base;       /* stream sample index of mfbuf[0] for the current frame: 1152 f - 528 */
+};
+
+/* per-granule scalars on their way into / out of an out-of-line stage (one slot per wave) */
+struct LhRgSlot {
+    LhQR    R;
+    LhGrR   g;
+};
+
 struct LhLds {
     float   ratio_en[2][4][LH_XMIN_N];  /* [gr][L,R,M,S]: the delayed psy output of each granule */
     float   ratio_thm[2][4][LH_XMIN_N];
@@ -204,7 +217,11 @@ struct LhLds {
     float   pe_use[2][2];
     float   ms_ener_ratio[2];
     int     scfsi[2][4];
-    unsigned long long prof[2][LH_NPROF];
+#if defined(LH_PROF) && !defined(LH_EMU)
+    unsigned prof[2][LH_NPROF];         /* profiling builds only; cycles of one frame fit 32 bits */
+#endif
+    LhCtxShared ctx;
+    LhRgSlot rg[2];
     union {
         float   mf[2][LH_MF_NEEDED];    /* scaled float PCM window of the frame (psy, polyphase) */
         struct {
@@ -258,16 +275,31 @@ lh_as_global(X * p)
 }
 #define LH_AS_GLOBAL(type, p) lh_as_global < type > (p)
 #endif
+/* the context of an out-of-line stage: shared part from LDS, pointers re-typed global */
 LH_DEVFN LhCtx
-lh_ctx_global(const LhCtx & i)
+lh_ctx_load(void)
 {
-    LhCtx   o = i;
-    o.cfg = LH_AS_GLOBAL(const LhConfig, i.cfg);
-    o.T = LH_AS_GLOBAL(const LhTables, i.T);
-    o.st = LH_AS_GLOBAL(LhStreamState, i.st);
-    o.pcm = LH_AS_GLOBAL(const int16_t, i.pcm);
-    o.wave = lh_uni_i(i.wave);
+    LhCtx   o;
+    o.cfg = LH_AS_GLOBAL(const LhConfig, lh_lds.ctx.cfg);
+    o.T = LH_AS_GLOBAL(const LhTables, lh_lds.ctx.T);
+    o.st = LH_AS_GLOBAL(LhStreamState, lh_lds.ctx.st);
+    o.pcm = LH_AS_GLOBAL(const int16_t, lh_lds.ctx.pcm);
+    o.d = lh_lds.ctx.d;
+    o.frame_base = lh_lds.ctx.frame_base;
+    o.tid = (int) threadIdx.x;
+    o.lane = o.tid & 63;
+    o.wave = lh_uni_i(o.tid >> 6);
     return o;
+}
+
+LH_DEVFN void
+lh_rg_put(const LhCtx & c, const LhQR & R, const LhGrR & g)
+{
+    if (c.lane == 0) {
+        lh_lds.rg[c.wave].R = R;
+        lh_lds.rg[c.wave].g = g;
+    }
+    LH_WAVE_SYNC();
 }
 
 /* sample p of the stream as the reference's mfbuf holds it: scaled PCM, zero outside

@@ -349,9 +349,9 @@ lh_mdct_long(float *out, float const *in)
 /* polyphase filtering of the 36 slots of the current frame window of channel
  * `ch' into sb[1..2]; one wave (reference newmdct.c:958-973, 984-991) */
 LH_STAGEFN void
-lh_polyphase(LH_CTXARG cin, int ch)
+lh_polyphase(int ch)
 {
-    LhCtx const c = lh_ctx_global(cin);
+    LhCtx const c = lh_ctx_load();
     float   (*sb)[576] = lh_lds.u.mdct.sb[ch];
     const float *amp = c.T->amp_filter;
     /* stage 1: 36 slots x 16 tap rows */
@@ -392,9 +392,9 @@ lh_polyphase(LH_CTXARG cin, int ch)
 /* MDCT + alias reduction for both granules of channel ch; one wave
  * (reference newmdct.c:978-1033) */
 LH_STAGEFN void
-lh_mdct_granules(LH_CTXARG cin, int ch)
+lh_mdct_granules(int ch)
 {
-    LhCtx const c = lh_ctx_global(cin);
+    LhCtx const c = lh_ctx_load();
     LhLds & L = lh_lds;
     float   (*sb)[576] = lh_lds.u.mdct.sb[ch];
     const float *amp = c.T->amp_filter;

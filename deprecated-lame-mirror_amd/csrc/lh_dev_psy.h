@@ -603,9 +603,9 @@ lh_pecalc(const LhTables * T, const float *en, const float *thm, float masking_l
 /* One granule of the psycho-acoustic model for the whole workgroup     */
 /* (reference L3psycho_anal_vbr, psymodel.c:1397-1597).                 */
 LH_STAGEFN void
-lh_psy_granule(LH_CTXARG cin, int gr)
+lh_psy_granule(int gr)
 {
-    LhCtx const c = lh_ctx_global(cin);
+    LhCtx const c = lh_ctx_load();
     LhLds & L = lh_lds;
     const LhConfig *cfg = c.cfg;
     const LhTables *T = c.T;

@@ -964,15 +964,18 @@ lh_calc_xmin_body(const LhCtx & c, LhChanLds & Q, LhQR & R, const float *xr, con
     LH_WAVE_SYNC();
 }
 
-/* out-of-line entry: R travels through per-lane memory, the body works on scalar copies */
+/* out-of-line entry: R / g travel through the wave's LDS slot (lh_rg_put), the body works on
+ * scalar copies */
 LH_STAGEFN void
-lh_calc_xmin(LH_CTXARG cin, int qch, LhQR & Rio, int gr, int rch)
+lh_calc_xmin(int qch, int gr, int rch)
 {
-    LhCtx const c = lh_ctx_global(cin);
-    LhQR    R = lh_uniform(Rio);
+    LhCtx const c = lh_ctx_load();
+    LhQR    R = lh_uniform(lh_lds.rg[qch].R);
     lh_calc_xmin_body(c, lh_lds.u.quant.ch[qch], R, lh_lds.xr[qch][gr], lh_lds.ratio_en[gr][rch],
                       lh_lds.ratio_thm[gr][rch]);
-    Rio = R;
+    if (c.lane == 0)
+        lh_lds.rg[qch].R = R;
+    LH_WAVE_SYNC();
 }
 
 /* reference quantize_pvt.c:750-913: one lane per band, wave-uniform aggregation */
@@ -1266,15 +1269,14 @@ lh_init_outer_loop_body(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, flo
 }
 
 LH_STAGEFN void
-lh_init_outer_loop(LH_CTXARG cin, int qch, LhQR & Rio, LhGrR & gio, int gr, int block_type, int substep)
+lh_init_outer_loop(int qch, int gr, int block_type, int substep)
 {
-    LhCtx const c = lh_ctx_global(cin);
+    LhCtx const c = lh_ctx_load();
     LhQR    R;
     LhGrR   g;
     lh_init_outer_loop_body(c, lh_lds.u.quant.ch[qch], R, g, lh_lds.xr[qch][gr], lh_uni_i(block_type),
                             lh_uni_i(substep));
-    Rio = R;
-    gio = g;
+    lh_rg_put(c, R, g);
 }
 
 /* Lines above max_nonzero_coeff are zero in every quantised image (the reference clears
@@ -1910,15 +1912,14 @@ lh_best_scalefac_store_body(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGr
 }
 
 LH_STAGEFN void
-lh_best_scalefac_store(LH_CTXARG cin, int qch, const LhQR & Rio, LhGrR & gio, int gr,
-                       const int8_t * g0sf, int g0_block_type)
+lh_best_scalefac_store(int qch, int gr, const int8_t * g0sf, int g0_block_type)
 {
-    LhCtx const c = lh_ctx_global(cin);
-    LhQR const R = lh_uniform(Rio);
-    LhGrR   g = lh_uniform(gio);
+    LhCtx const c = lh_ctx_load();
+    LhQR const R = lh_uniform(lh_lds.rg[qch].R);
+    LhGrR   g = lh_uniform(lh_lds.rg[qch].g);
     lh_best_scalefac_store_body(c, lh_lds.u.quant.ch[qch], R, g, lh_uni_i(gr), LH_AS_GLOBAL(const int8_t, g0sf),
                                 lh_uni_i(g0_block_type), lh_lds.scfsi[qch]);
-    gio = g;
+    lh_rg_put(c, R, g);
 }
 
 /* reference takehiro.c:809-957.  The reference evaluates up to 16 + 128 region
@@ -1931,10 +1932,10 @@ lh_best_huffman_divide_body(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGr
     const LhTables *T = c.T;
     const LhQTabs *qt = LH_QT;
     const int16_t *ix = Q.ix[0];
-    int    *r01_bits = Q.scr[0];        /* [23] */
-    int    *r01_div = Q.scr[1];         /* [23] */
-    int    *r0_tbl = Q.scr[2];          /* [23] */
-    int    *r1_tbl = Q.scr[3];          /* [23] */
+    int    *r01_bits = (int *) Q.save_xrpow + 400;      /* [23]; save_xrpow is dead here: scratch */
+    int    *r01_div = r01_bits + 24;    /* [23] */
+    int    *r0_tbl = r01_bits + 48;     /* [23] */
+    int    *r1_tbl = r01_bits + 72;     /* [23] */
     int const bigv0 = g.big_values;
     int const count1bits0 = g.count1bits;
     int     i, a1, a2;
@@ -2105,13 +2106,13 @@ lh_best_huffman_divide_body(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGr
 }
 
 LH_STAGEFN void
-lh_best_huffman_divide(LH_CTXARG cin, int qch, const LhQR & Rio, LhGrR & gio)
+lh_best_huffman_divide(int qch)
 {
-    LhCtx const c = lh_ctx_global(cin);
-    LhQR const R = lh_uniform(Rio);
-    LhGrR   g = lh_uniform(gio);
+    LhCtx const c = lh_ctx_load();
+    LhQR const R = lh_uniform(lh_lds.rg[qch].R);
+    LhGrR   g = lh_uniform(lh_lds.rg[qch].g);
     lh_best_huffman_divide_body(c, lh_lds.u.quant.ch[qch], R, g);
-    gio = g;
+    lh_rg_put(c, R, g);
 }
 
 /* ---------------------------------------------------------------------- */

@@ -179,13 +179,15 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo)
     int const w = c.wave, lane = c.lane, tid = c.tid;
 
     /* ---- polyphase priming on the first frame (reference encoder.c:189-236) ---- */
+#if defined(LH_PROF) && !defined(LH_EMU)
     if (lane < LH_NPROF)
         L.prof[w][lane] = 0;
+#endif
     LH_PT(t_frame);
     if (!st->primed) {
         lh_stage_window(c, L.mf, c.frame_base - 1152);
         LH_SYNC_WG();
-        lh_polyphase(c, w);
+        lh_polyphase(w);
         for (int i = lane; i < 576; i += 64)
             st->sb_prev[w][i] = L.u.mdct.sb[w][2][i];
         LH_SYNC_WG();
@@ -220,7 +222,7 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo)
     /* ---- stage 1: psycho-acoustic model, two granules ---- */
     LH_PT(t_psy);
     for (int gr = 0; gr < 2; gr++)
-        lh_psy_granule(c, gr);
+        lh_psy_granule(gr);
     LH_PA(1, t_psy);
 
     float   ms_ener_ratio[2] = { .5f, .5f };
@@ -254,9 +256,9 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo)
     LH_PT(t_mdct);
     for (int i = lane; i < 576; i += 64)
         L.u.mdct.sb[w][0][i] = st->sb_prev[w][i];
-    lh_polyphase(c, w);
+    lh_polyphase(w);
     LH_SYNC_WG();               /* last read of mf (both channels) before xr overwrites it */
-    lh_mdct_granules(c, w);
+    lh_mdct_granules(w);
     for (int i = lane; i < 576; i += 64)
         st->sb_prev[w][i] = L.u.mdct.sb[w][2][i];
     LH_SYNC_WG();
@@ -345,21 +347,16 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo)
             float  *xr = L.xr[ch][gr];
             LhGranule *o = &fo->gr[gr][ch];
             LH_PT(t_q);
-            /* the out-of-line stages work on copies: R and g themselves never have their
-             * address taken, so they stay in registers through the inlined outer loop */
-            {
-                LhQR    Rt;
-                LhGrR   gt;
-                lh_init_outer_loop(c, ch, Rt, gt, gr, L.block_type[gr][ch], substep);
-                R = lh_uniform(Rt);
-                g = lh_uniform(gt);
-            }
+            /* R and g never have their address taken (they stay in scalar registers through
+             * the inlined outer loop); the out-of-line stages exchange them through the wave's
+             * LDS slot */
+            lh_init_outer_loop(ch, gr, L.block_type[gr][ch], substep);
+            R = lh_uniform(L.rg[ch].R);
+            g = lh_uniform(L.rg[ch].g);
             if (lh_init_xrpow(c, Q, R, g, xr)) {
-                {
-                    LhQR    Rt = R;
-                    lh_calc_xmin(c, ch, Rt, gr, msoff + ch);
-                    R = lh_uniform(Rt);
-                }
+                lh_rg_put(c, R, g);
+                lh_calc_xmin(ch, gr, msoff + ch);
+                R = lh_uniform(L.rg[ch].R);
                 lh_zero_tail(c, Q, R);
                 LH_PA(4, t_q);
                 LH_PT(t_ol);
@@ -367,14 +364,11 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo)
                 LH_PA(5, t_ol);
             }
             LH_PT(t_fin);
-            {
-                LhQR const Rt = R;
-                LhGrR   gt = g;
-                lh_best_scalefac_store(c, ch, Rt, gt, gr, fo->gr[0][ch].scalefac, L.block_type[0][ch]);
-                if (cfg->use_best_huffman == 1)
-                    lh_best_huffman_divide(c, ch, Rt, gt);
-                g = lh_uniform(gt);
-            }
+            lh_rg_put(c, R, g);
+            lh_best_scalefac_store(ch, gr, fo->gr[0][ch].scalefac, L.block_type[0][ch]);
+            if (cfg->use_best_huffman == 1)
+                lh_best_huffman_divide(ch);
+            g = lh_uniform(L.rg[ch].g);
             LH_PA(6, t_fin);
             lh_store_granule(c, Q, R, g, xr, o);
             LH_PA(3, t_q);
@@ -477,8 +471,17 @@ lh_encode_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm,
     c.tid = (int) threadIdx.x;
     c.lane = c.tid & 63;
     c.wave = lh_uni_i(c.tid >> 6);      /* scalar: everything indexed by the wave id gets scalar addressing */
+    if (c.tid == 0) {
+        L.ctx.cfg = c.cfg;
+        L.ctx.T = c.T;
+        L.ctx.st = c.st;
+        L.ctx.pcm = c.pcm;
+        L.ctx.d = c.d;
+    }
     for (int f = c.d.frame_begin; f < c.d.frame_end; f++) {
         c.frame_base = 1152LL * f - LH_MF_START;
+        if (c.tid == 0)
+            L.ctx.frame_base = c.frame_base;    /* read by the stages after the next workgroup barrier */
         lh_encode_frame(c, &out[c.d.out_index + (f - c.d.frame_begin)]);
     }
 }
