@@ -171,6 +171,7 @@ struct LhQTabs {
     uint16_t sfb_s3, pad;       /* sfb_s[3] */
     uint32_t lut_pa[17], lut_pb[17];    /* lh_region_lut() of a region maximum 0..15, 16 = ESC classes */
     uint8_t t32l[16], t33l[16];
+    uint32_t t3233[16];         /* t32l << 16 | t33l */
     uint8_t pretab[24];
     float   pow43h[256];        /* heads of pow43 / adj43asm: nearly all quantised values are < 256 */
     float   adj43h[256];

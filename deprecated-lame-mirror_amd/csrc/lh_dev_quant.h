@@ -535,15 +535,22 @@ lh_noquant_count_bits(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, int w
     if (use_prev && R.block_type == LH_NORM_TYPE)
         sfbcnt_in = (lane < LH_SBMAX_L + 1) ? qt->sfb_l[lane] : 576u;
     LH_PA(19, t_nq);
-    /* count1 region: quadruples of 0/1 values, from the LDS image */
-    if (nquad > 0) {
-        LH_WAVE_SYNC();
-        for (int qd = lane; qd < nquad; qd += 64) {
+    /* count1 region: quadruples of 0/1 values, from the LDS image (at most 144 of them: three
+     * per lane, loaded unconditionally at clamped positions) */
+    LH_WAVE_SYNC();
+    {
+        unsigned idx[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            int const qd = lane + 64 * k;
             int const b2 = (bv >> 1) + 2 * qd;
-            uint32_t const u0 = ix2[b2], u1 = ix2[b2 + 1];
-            unsigned const p = (((u0 & 1u) * 2 + (u0 >> 16)) * 2 + (u1 & 1u)) * 2 + (u1 >> 16);
-            quads += ((unsigned) qt->t32l[p] << 16) + (unsigned) qt->t33l[p];
+            int const b2c = b2 < 286 ? b2 : 286;
+            uint32_t const u0 = ix2[b2c], u1 = ix2[b2c + 1];
+            idx[k] = ((((u0 & 1u) * 2 + ((u0 >> 16) & 1u)) * 2 + (u1 & 1u)) * 2 + ((u1 >> 16) & 1u));
         }
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+            quads += ((lane + 64 * k) < nquad) ? qt->t3233[idx[k]] : 0u;
     }
     LH_PA(20, t_nq);
     {
@@ -582,8 +589,7 @@ lh_noquant_count_bits(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, int w
             w00 = w01 = w10 = w11 = w20 = w21 = 0;
 #pragma unroll
             for (int k = 0; k < 5; k++) {
-                v0[k] = v1[k] = 0;
-                if (64 * k < e2) {
+                {
                     int const p = lane + 64 * k;
                     uint32_t const pa = (p < e0) ? l0.pa : (p < e1) ? l1.pa : (p < e2) ? l2.pa : 2u;
                     uint32_t const pb = (p < e0) ? l0.pb : (p < e1) ? l1.pb : (p < e2) ? l2.pb : 0u;
@@ -601,21 +607,14 @@ lh_noquant_count_bits(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, int w
             }
 #pragma unroll
             for (int k = 0; k < 5; k++) {
-                if (64 * k < e2) {
-                    int const p = lane + 64 * k;
-                    if (p < e0) {
-                        w00 += v0[k];
-                        w01 += v1[k];
-                    }
-                    else if (p < e1) {
-                        w10 += v0[k];
-                        w11 += v1[k];
-                    }
-                    else if (p < e2) {
-                        w20 += v0[k];
-                        w21 += v1[k];
-                    }
-                }
+                int const p = lane + 64 * k;
+                int const r0 = (p < e0), r1 = (p >= e0 && p < e1), r2 = (p >= e1 && p < e2);
+                w00 += r0 ? v0[k] : 0u;
+                w01 += r0 ? v1[k] : 0u;
+                w10 += r1 ? v0[k] : 0u;
+                w11 += r1 ? v1[k] : 0u;
+                w20 += r2 ? v0[k] : 0u;
+                w21 += r2 ? v1[k] : 0u;
             }
         }
         LH_PA(22, t_nq);
@@ -685,19 +684,20 @@ lh_count_bits(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, int which, in
 
     if (g.xrpow_max > w)
         return LH_LARGE_BITS;
-    /* everything a lane needs that does not depend on the band decisions is loaded first */
+    /* Everything a lane needs that does not depend on the band decisions is loaded first.
+     * The loads are unconditional with clamped indices and the results are selected afterwards:
+     * a load under a condition becomes a branch with its own wait, and nothing overlaps. */
 #pragma unroll
     for (int k = 0; k < 5; k++) {
         int const p = lane + 64 * k;
-        sb[k] = 63;
-        pk[k] = 0u;             /* lines above mnc are zero (lh_zero_tail) */
-        xp[2 * k] = xp[2 * k + 1] = 0.0f;
-        if (64 * k <= pm) {     /* wave-uniform: whole iterations above mnc cost nothing */
-            sb[k] = (p <= pm) ? Q.sfb_of_line[2 * p] : 63;
-            pk[k] = (p <= pm) ? ix2[p] : 0u;
-            xp[2 * k] = (p <= pm) ? xrpow[2 * p] : 0.0f;
-            xp[2 * k + 1] = (p <= pm) ? xrpow[2 * p + 1] : 0.0f;
-        }
+        int const pc = (k < 4 || p < 288) ? p : 287;
+        int const sbv = Q.sfb_of_line[2 * pc];
+        uint32_t const old = ix2[pc];
+        lh_f32x2 const x2 = ((const lh_f32x2 *) xrpow)[pc];
+        sb[k] = (p <= pm) ? sbv : 63;           /* 63: no band; its bit in the masks below is 0 */
+        pk[k] = (k < 4 || p < 288) ? old : 0u;  /* lines above mnc are zero already (lh_zero_tail) */
+        xp[2 * k] = x2.x;
+        xp[2 * k + 1] = x2.y;
     }
     /* Per band (lane = band): unchanged step -> keep the old values; count1 region with a
      * coarser step -> 0/1 comparator; else the full quantiser (reference
@@ -743,8 +743,6 @@ lh_count_bits(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, int which, in
             int const p = lane + 64 * k;
             int const nc = (int) ((ncmask >> sb[k]) & 1), z1 = (int) ((m01mask >> sb[k]) & 1);
             uint32_t v = pk[k];
-            if (64 * k > pm)
-                continue;
             {
                 /* straight-line code for all three cases (no branch per pair, so the table
                  * look-ups of all pairs are in flight together); the rounding table comes
@@ -768,7 +766,7 @@ lh_count_bits(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, int which, in
             for (int k = 0; k < 5; k++) {
                 int const p = lane + 64 * k;
                 int const nc = (int) ((ncmask >> sb[k]) & 1), z1 = (int) ((m01mask >> sb[k]) & 1);
-                if (64 * k <= pm && nc && !z1) {
+                if (nc && !z1) {
                     int const q0 = lh_quant_line(T, qt, istep, xp[2 * k]);
                     int const q1 = lh_quant_line(T, qt, istep, xp[2 * k + 1]);
                     uint32_t v = (uint32_t) (q0 & 0xffff) | ((uint32_t) q1 << 16);
@@ -781,10 +779,9 @@ lh_count_bits(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, int which, in
 #pragma unroll
         for (int k = 0; k < 5; k++) {
             int const p = lane + 64 * k;
-            if (64 * k <= pm && newpk[k] != pk[k])
+            if (k < 4 || p < 288)
                 ix2[p] = newpk[k];
-            if (64 * k <= pm)
-                pk[k] = newpk[k];
+            pk[k] = newpk[k];
         }
     }
     if (R.substep_shaping & 2) {

@@ -119,6 +119,7 @@ lh_load_qtabs(const LhCtx & c, LhQTabs & q)
         q.table56[c.tid] = lh_table56[c.tid];
         q.t32l[c.tid] = lh_t32l[c.tid];
         q.t33l[c.tid] = lh_t33l[c.tid];
+        q.t3233[c.tid] = ((uint32_t) lh_t32l[c.tid] << 16) | lh_t33l[c.tid];
     }
     if (c.tid < 24) {
         q.sfb_l[c.tid] = (uint16_t) ((c.tid < 23) ? c.T->sfb_l[c.tid] : 576);

@@ -169,17 +169,23 @@ lh_dpp(uint32_t v)
     return (uint32_t) __builtin_amdgcn_update_dpp((int) IDENT, (int) v, CTRL, 0xf, 0xf, IDENT == 0u);
 }
 
+/* ... then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3 leave the wave total
+ * in lane 63: seven instructions per reduction */
+template < int CTRL, int ROWMASK, uint32_t IDENT > __device__ __forceinline__ uint32_t
+lh_dpp_rows(uint32_t v)
+{
+    return (uint32_t) __builtin_amdgcn_update_dpp((int) IDENT, (int) v, CTRL, ROWMASK, 0xf, false);
+}
+
 #define LH_DPP_REDUCE(OP, IDENT) \
     { uint32_t t_; \
       t_ = lh_dpp < 0xB1, IDENT > (v); v = OP(v, t_); \
       t_ = lh_dpp < 0x4E, IDENT > (v); v = OP(v, t_); \
       t_ = lh_dpp < 0x141, IDENT > (v); v = OP(v, t_); \
       t_ = lh_dpp < 0x140, IDENT > (v); v = OP(v, t_); \
-      { uint32_t const r0_ = (uint32_t) __builtin_amdgcn_readlane((int) v, 0), \
-                       r1_ = (uint32_t) __builtin_amdgcn_readlane((int) v, 16), \
-                       r2_ = (uint32_t) __builtin_amdgcn_readlane((int) v, 32), \
-                       r3_ = (uint32_t) __builtin_amdgcn_readlane((int) v, 48); \
-        return OP(OP(r0_, r1_), OP(r2_, r3_)); } }
+      t_ = lh_dpp_rows < 0x142, 0xa, IDENT > (v); v = OP(v, t_); \
+      t_ = lh_dpp_rows < 0x143, 0xc, IDENT > (v); v = OP(v, t_); \
+      return (uint32_t) __builtin_amdgcn_readlane((int) v, 63); }
 
 #define LH_OP_ADD(a, b) ((a) + (b))
 #define LH_OP_MAX(a, b) ((a) > (b) ? (a) : (b))
