@@ -167,6 +167,8 @@ def main():
                        "parallelism": "static stream sharding, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "traffic_note": "not collected here (needs rocprofv3 --pmc passes); offline measurement on the "
+                                         "1024 x 5 s workload: profiles/r01_traffic.json, DESIGN.md section 4",
                          "kernel": "lh_encode_kernel", "kernel_ms_avg": round(kavg * 1e3, 3),
                          "alg_bytes_per_frame": ALG_BYTES_PER_FRAME, "frames_per_launch": frames},
         }
