@@ -240,7 +240,7 @@ struct LhLds {
 /* The workgroup's LDS image (one stream), at file scope: every device function, in line or
  * not, addresses it as LDS with constant offsets (ds_* instructions).  Handing it to the
  * out-of-line stages by reference made all their accesses generic FLAT loads. */
-__shared__ LhLds lh_lds;
+__shared__ LhLds lh_lds __attribute__((aligned(16)));
 #define LH_QT (&lh_lds.qt)
 
 /* ---- launch context -------------------------------------------------- */

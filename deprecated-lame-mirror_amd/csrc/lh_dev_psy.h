@@ -299,57 +299,68 @@ lh_fft_energy(const LhCtx & c, int chn, const float *wl, const float *wr, int n,
 
 /* serial partition -> scalefactor band accumulation (reference psymodel.c:350-393);
  * executed by ONE lane per (channel, table) chain */
+/* partitions -> scalefactor bands (reference psymodel.c:350-409), one lane per band.
+ * The reference walks the bands in order and carries (b, enn, thmm) from band to band.  Where
+ * the walk stands when it reaches band sb depends on the tables only: with
+ * bl_k = min(bo[k], npart) the recurrence b_{k+1} = max(b_k, bl_k) + 1, b_0 = 0 has the closed
+ * form b_sb = sb + max(0, max_{k<sb}(bl_k - k)); the band is zero-filled when an earlier band
+ * already ran into npart (b_sb - 1 >= npart), and otherwise its sums start from the
+ * w_next-weighted value of partition b_sb - 1.  The float additions inside the band keep the
+ * reference's order.  `walk' is per-wave LDS scratch of at least n_sb ints; all lanes of the
+ * wave must call. */
 LH_DEVFN void
-lh_partition2sfb(LhPsyBand const *gd, float const *eb, float const *thr, float *enn_out,
-                 float *thm_out, int out_stride, float thm_scale, int replicate3)
+lh_partition2sfb_wave(LhPsyBand const *gd, float const *eb, float const *thr, float *enn_out,
+                      float *thm_out, int out_stride, float thm_scale, int replicate3, int lane,
+                      int active, int *walk)
 {
-    float   enn = 0.0f, thmm = 0.0f;
-    int     sb, b, n = gd->n_sb;
-    for (sb = b = 0; sb < n; ++b, ++sb) {
+    int const npart = gd->npart;
+    int const n_sb = gd->n_sb;
+    int const sb = lane;
+    float   enn = 0.0f, thmm = 0.0f, tv;
+    int     b, live, m = 0;
+    LH_WAVE_SYNC_MEM();
+    if (lane < n_sb) {
+        int const bo_k = gd->bo[lane];
+        walk[lane] = (bo_k < npart ? bo_k : npart) - lane;
+    }
+    LH_WAVE_SYNC_MEM();
+    for (int k = 0; k < LH_SBMAX_L; k++) {
+        int const d = walk[k];
+        m = (k < sb && k < n_sb && d > m) ? d : m;
+    }
+    b = sb + m;
+    live = (sb == 0) || (b - 1 < npart);
+    if (!active || sb >= n_sb)
+        return;
+    if (live) {
         int const bo_sb = gd->bo[sb];
-        int const npart = gd->npart;
         int const b_lim = bo_sb < npart ? bo_sb : npart;
+        if (sb > 0) {
+            float const carry_w = 1.0f - gd->bo_weight[sb - 1];
+            enn = carry_w * eb[b - 1];
+            thmm = carry_w * thr[b - 1];
+        }
         while (b < b_lim) {
             enn += eb[b];
             thmm += thr[b];
             b++;
         }
-        if (b >= npart) {
-            float   tv = thm_scale < 0 ? thmm : thmm * thm_scale;
-            enn_out[sb * out_stride] = enn;
-            thm_out[sb * out_stride] = tv;
-            if (replicate3) {
-                enn_out[sb * out_stride + 1] = enn_out[sb * out_stride + 2] = enn;
-                thm_out[sb * out_stride + 1] = thm_out[sb * out_stride + 2] = tv;
-            }
-            ++sb;
-            break;
-        }
-        {
+        if (b < npart) {
             float const w_curr = gd->bo_weight[sb];
-            float const w_next = 1.0f - w_curr;
-            float   tv;
             enn += w_curr * eb[b];
             thmm += w_curr * thr[b];
-            tv = thm_scale < 0 ? thmm : thmm * thm_scale;
-            enn_out[sb * out_stride] = enn;
-            thm_out[sb * out_stride] = tv;
-            if (replicate3) {
-                enn_out[sb * out_stride + 1] = enn_out[sb * out_stride + 2] = enn;
-                thm_out[sb * out_stride + 1] = thm_out[sb * out_stride + 2] = tv;
-            }
-            enn = w_next * eb[b];
-            thmm = w_next * thr[b];
         }
+        tv = thm_scale < 0 ? thmm : thmm * thm_scale;
     }
-    for (; sb < n; ++sb) {
-        float   tv = thm_scale < 0 ? 0.0f : 0.0f * thm_scale;
-        enn_out[sb * out_stride] = 0;
-        thm_out[sb * out_stride] = tv;
-        if (replicate3) {
-            enn_out[sb * out_stride + 1] = enn_out[sb * out_stride + 2] = 0;
-            thm_out[sb * out_stride + 1] = thm_out[sb * out_stride + 2] = tv;
-        }
+    else {
+        enn = 0;
+        tv = thm_scale < 0 ? 0.0f : 0.0f * thm_scale;
+    }
+    enn_out[sb * out_stride] = enn;
+    thm_out[sb * out_stride] = tv;
+    if (replicate3) {
+        enn_out[sb * out_stride + 1] = enn_out[sb * out_stride + 2] = enn;
+        thm_out[sb * out_stride + 1] = thm_out[sb * out_stride + 2] = tv;
     }
 }
 
@@ -624,6 +635,7 @@ lh_psy_granule(int gr)
     if (c.tid < 4)
         L.tot_ener[gr][c.tid] = st->tot_ener[c.tid];
 
+    LH_PT(t_psy0);
     /* (2) attack detection (reference psymodel.c:759-940) */
     {
         int const firbase = bufbase + 576 - 350 - LH_NSFIRLEN + 192;
@@ -757,9 +769,11 @@ lh_psy_granule(int gr)
     }
     LH_SYNC_WG();
 
+    LH_PA(29, t_psy0);
     /* (3) long FFTs of L (wave 0) and R (wave 1) */
     lh_fft_long(c, w, bufbase, P.wsamp[w]);
     LH_SYNC_WG();
+    LH_PA(30, t_psy0);
     /* (4) power spectra of this wave's two pseudo-channels */
     for (int pass = 0; pass < 2; pass++) {
         int const chn = w + 2 * pass;
@@ -767,28 +781,49 @@ lh_psy_granule(int gr)
             lh_fft_energy(c, chn, P.wsamp[0], P.wsamp[1], LH_BLKSIZE, P.b.energy[chn]);
     }
     LH_WAVE_SYNC_MEM();
+    LH_PA(31, t_psy0);
     /* (5) serial sums: total energy (bins 11..512) and loudness (reference psymodel.c:213-226,
      * 690-696): lane 0/1 = tot_ener of chn w / w+2, lane 2 = loudness of channel w */
     if (lane < 3) {
         int const chn = (lane == 1) ? w + 2 : w;
         if (chn < n_chn_psy) {
+            /* One instruction stream for the three sums: acc += e[j] * m[j], with m = 1.0f for
+             * the energy sums (x * 1.0f is x) and m = eql_w for the loudness; terms outside a
+             * sum's range are replaced by +0.0f, which leaves a non-negative sum unchanged.
+             * Four terms per load keep the dependent additions, not the loads, on the
+             * critical path. */
             const float *e = P.b.energy[chn];
+            const float *ew = T->ath_eql_w;
+            int const loud = (lane == 2);
+            int const lo = loud ? 0 : 11;
             float   acc = 0.0f;
-            if (lane < 2) {
-                for (int j = 11; j < LH_HBLKSIZE; j++)
-                    acc += e[j];
+            for (int j = 0; j < 12; j++) {
+                float const m = loud ? ew[j] : 1.0f;
+                float const t = e[j] * m;
+                acc += (j >= lo) ? t : 0.0f;
+            }
+            for (int j = 12; j < LH_BLKSIZE / 2; j += 4) {
+                lh_f32x4 const v = *(const lh_f32x4 *) &e[j];
+                lh_f32x4 m = *(const lh_f32x4 *) &ew[j];
+                if (!loud)
+                    m.x = m.y = m.z = m.w = 1.0f;
+                acc += v.x * m.x;
+                acc += v.y * m.y;
+                acc += v.z * m.z;
+                acc += v.w * m.w;
+            }
+            if (!loud) {
+                acc += e[LH_BLKSIZE / 2];
                 st->tot_ener[chn] = acc;
             }
             else {
-                const float *ew = T->ath_eql_w;
-                for (int i = 0; i < LH_BLKSIZE / 2; ++i)
-                    acc += e[i] * ew[i];
                 acc = (float) (acc * LH_VO_SCALE);
                 L.loudness_sq[gr][w] = st->loudness_sq_save[w];
                 st->loudness_sq_save[w] = acc;
             }
         }
     }
+    LH_PA(32, t_psy0);
     /* (6) masking thresholds, long blocks */
     for (int pass = 0; pass < 2; pass++) {
         int const chn = w + 2 * pass;
@@ -805,20 +840,22 @@ lh_psy_granule(int gr)
                              T->psy_l.npart);
     }
     LH_SYNC_WG();
+    LH_PA(33, t_psy0);
     /* (7) partitions -> scalefactor bands, long and long->short estimates
      * (reference psymodel.c:411-439); 4 serial chains per wave */
-    if (lane < 4) {
-        int const chn = w + 2 * (lane >> 1);
-        if (chn < n_chn_psy) {
-            if ((lane & 1) == 0)
-                lh_partition2sfb(&T->psy_l, &P.eb[chn * 64], &P.thr[chn * 64], &st->en[chn][0],
-                                 &st->thm[chn][0], 1, -1.0f, 0);
-            else
-                lh_partition2sfb(&T->psy_l_to_s, &P.eb[chn * 64], &P.thr[chn * 64],
-                                 &st->en[chn][22], &st->thm[chn][22], 3, (float) (1. / 64.f), 1);
-        }
+    for (int t = 0; t < 4; t++) {       /* (channel, long | long->short) x lane = band */
+        int const chn = w + 2 * (t >> 1);
+        int const act = chn < n_chn_psy;
+        int const cc = act ? chn : w;
+        if ((t & 1) == 0)
+            lh_partition2sfb_wave(&T->psy_l, &P.eb[cc * 64], &P.thr[cc * 64], &st->en[cc][0],
+                                  &st->thm[cc][0], 1, -1.0f, 0, lane, act, P.sidx[w]);
+        else
+            lh_partition2sfb_wave(&T->psy_l_to_s, &P.eb[cc * 64], &P.thr[cc * 64], &st->en[cc][22],
+                                  &st->thm[cc][22], 3, (float) (1. / 64.f), 1, lane, act, P.sidx[w]);
     }
     LH_SYNC_WG();
+    LH_PA(34, t_psy0);
     /* (8) short blocks (reference psymodel.c:1470-1500) */
     if (!L.uselongblock[w])
         lh_fft_short(c, w, bufbase, &P.wsamp[w][0]);
@@ -843,14 +880,16 @@ lh_psy_granule(int gr)
                                  cfg->msfix, T->psy_s.npart);
         }
         LH_SYNC_WG();
-        if (lane < 2) {
-            int const chn = w + 2 * lane;
-            if (chn < n_chn_psy && !L.uselongblock[chn & 1])
-                lh_partition2sfb(&T->psy_s, &P.eb[chn * 64], &P.thr[chn * 64],
-                                 &st->en[chn][22 + sblock], &st->thm[chn][22 + sblock], 3, -1.0f, 0);
+        for (int t = 0; t < 2; t++) {
+            int const chn = w + 2 * t;
+            int const act = chn < n_chn_psy && !L.uselongblock[chn & 1];
+            int const cc = (chn < n_chn_psy) ? chn : w;
+            lh_partition2sfb_wave(&T->psy_s, &P.eb[cc * 64], &P.thr[cc * 64], &st->en[cc][22 + sblock],
+                                  &st->thm[cc][22 + sblock], 3, -1.0f, 0, lane, act, P.sidx[w]);
         }
         LH_SYNC_WG();
     }
+    LH_PA(35, t_psy0);
     /* (9) short block pre-echo control (reference psymodel.c:1502-1553): one lane per (chn, sb) */
     {
         float const pcfact = 0.6f;
@@ -898,6 +937,7 @@ lh_psy_granule(int gr)
         }
     }
     LH_SYNC_WG();
+    LH_PA(36, t_psy0);
     /* (10) block type state machine (reference psymodel.c:1289-1319) + PE (:1568-1595) */
     {
         int     btd[2];

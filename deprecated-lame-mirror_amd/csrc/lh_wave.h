@@ -105,6 +105,7 @@ lh_bcast_u32(uint32_t v, int src)
 }
 
 typedef struct { float x, y; } lh_f32x2;
+typedef struct { float x, y, z, w; } lh_f32x4;
 
 static inline float
 lh_wave_max_f32(float v)
@@ -198,6 +199,7 @@ __device__ __forceinline__ uint32_t lh_wave_min_u32(uint32_t v) LH_DPP_REDUCE(LH
 __device__ __forceinline__ uint32_t lh_wave_or_u32(uint32_t v) LH_DPP_REDUCE(LH_OP_OR, 0u)
 
 typedef float2 lh_f32x2;
+typedef float4 lh_f32x4;
 
 /* maximum of 64 floats (no NaNs among them) */
 __device__ __forceinline__ float

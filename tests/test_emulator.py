@@ -29,7 +29,7 @@ def emu():
 
 
 @pytest.mark.parametrize("name,nframes", [("cbr128_js_44k", 8), ("cbr320_js_48k_bursts", 8),
-                                          ("cbr256_js_44k_q2", 5)])
+                                          ("cbr256_js_44k_q2", 5), ("cbr96_js_32k", 6)])
 def test_kernel_source_matches_oracle(name, nframes, emu, oracle):
     g, pcm = helpers.load_golden(name)
     sr, br, mode, q = helpers.golden_settings(g)

@@ -18,7 +18,9 @@ NAMES = ["frame total", "psy (2 granules)", "polyphase+mdct", "quant total (2 gr
          "outer_loop", "scalefac_store+huffman_divide", "  bin_search", "  balance_noise", "  calc_noise",
          "count_bits calls", "count_bits total", "  quantise part", "calc_noise calls", "  cn: after phase A", "  cn: after phase B", "  cn: after per-band log",
          "  cn: total", "  cb: loads+band decisions", "  nq: count1/big_values/regions", "  nq: + quads", "  nq: + region maxima",
-         "  nq: + table look-ups", "  nq: + sums", "-", "-", "-", "-"]
+         "  nq: + table look-ups", "  nq: + sums", "-", "-", "-", "-", "-",
+         "  psy: + attack detection", "  psy: + long FFT", "  psy: + power spectra", "  psy: + energy/loudness sums",
+         "  psy: + long masking (+MS)", "  psy: + partition->sfb", "  psy: + short blocks", "  psy: + pre-echo", "-", "-", "-"]
 
 
 def main():
@@ -33,7 +35,7 @@ def main():
     b.encode()
     ms = b.kernel_ms()
     ssz = enc.lib.lamehip_abi_sizeof(4)
-    NP = 28
+    NP = 40
     tot = np.zeros((2, NP))
     for s in range(0, B, max(1, B // 64)):
         buf = C.create_string_buffer(ssz)
@@ -44,7 +46,7 @@ def main():
     print("batch %d x %.1f s: kernel %.2f ms, %d frames/stream" % (B, secs, ms, frames))
     for w in range(2):
         print("wave %d (cycles per frame, share of frame):" % w)
-        for i, nm in enumerate(NAMES[:24]):
+        for i, nm in enumerate(NAMES[:37]):
             v = tot[w][i] / (frames * len(range(0, B, max(1, B // 64))))
             print("   %-34s %12.0f  %5.1f%%" % (nm, v, 100.0 * tot[w][i] / max(tot[w][0], 1)))
 
