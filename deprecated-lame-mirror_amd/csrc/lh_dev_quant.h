@@ -1622,11 +1622,15 @@ lh_balance_noise(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g, int 
 {
     const LhConfig *cfg = c.cfg;
     int     status;
+    LH_PT(t_bal);
     lh_amp_scalefac_bands(c, Q, R, g, which, bRefine);
+    LH_PA(37, t_bal);
     status = lh_loop_break(c, Q, R, g, which);
+    LH_PA(38, t_bal);
     if (status)
         return 0;
     status = lh_scale_bitcount(c, Q, R, g, which);
+    LH_PA(39, t_bal);
     if (!status)
         return 1;
     if (cfg->noise_shaping > 1) {

@@ -20,7 +20,8 @@ NAMES = ["frame total", "psy (2 granules)", "polyphase+mdct", "quant total (2 gr
          "  cn: total", "  cb: loads+band decisions", "  nq: count1/big_values/regions", "  nq: + quads", "  nq: + region maxima",
          "  nq: + table look-ups", "  nq: + sums", "-", "-", "-", "-", "-",
          "  psy: + attack detection", "  psy: + long FFT", "  psy: + power spectra", "  psy: + energy/loudness sums",
-         "  psy: + long masking (+MS)", "  psy: + partition->sfb", "  psy: + short blocks", "  psy: + pre-echo", "-", "-", "-"]
+         "  psy: + long masking (+MS)", "  psy: + partition->sfb", "  psy: + short blocks", "  psy: + pre-echo", "-", "  bal: amp_scalefac_bands", "  bal: + loop_break",
+         "  bal: + scale_bitcount"]
 
 
 def main():
@@ -46,7 +47,7 @@ def main():
     print("batch %d x %.1f s: kernel %.2f ms, %d frames/stream" % (B, secs, ms, frames))
     for w in range(2):
         print("wave %d (cycles per frame, share of frame):" % w)
-        for i, nm in enumerate(NAMES[:37]):
+        for i, nm in enumerate(NAMES[:40]):
             v = tot[w][i] / (frames * len(range(0, B, max(1, B // 64))))
             print("   %-34s %12.0f  %5.1f%%" % (nm, v, 100.0 * tot[w][i] / max(tot[w][0], 1)))
 
