@@ -559,15 +559,17 @@ lh_noquant_count_bits(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, int w
         unsigned w00, w01, w10, w11, w20, w21;
 #pragma unroll
         for (int k = 0; k < 5; k++) {
-            int const p = lane + 64 * k;
-            unsigned const lo = pk[k] & 0xffffu, hi = pk[k] >> 16;
-            unsigned const m = lo > hi ? lo : hi;
-            if (p < e0)
-                m0 = m > m0 ? m : m0;
-            else if (p < e1)
-                m1 = m > m1 ? m : m1;
-            else if (p < e2)
-                m2 = m > m2 ? m : m2;
+            if (k < 2 || 64 * k < e2) {         /* wave-uniform: blocks above big_values hold nothing */
+                int const p = lane + 64 * k;
+                unsigned const lo = pk[k] & 0xffffu, hi = pk[k] >> 16;
+                unsigned const m = lo > hi ? lo : hi;
+                if (p < e0)
+                    m0 = m > m0 ? m : m0;
+                else if (p < e1)
+                    m1 = m > m1 ? m : m1;
+                else if (p < e2)
+                    m2 = m > m2 ? m : m2;
+            }
         }
         m0 = lh_wave_max_u32(m0);
         m1 = lh_wave_max_u32(m1);
@@ -589,7 +591,8 @@ lh_noquant_count_bits(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, int w
             w00 = w01 = w10 = w11 = w20 = w21 = 0;
 #pragma unroll
             for (int k = 0; k < 5; k++) {
-                {
+                v0[k] = v1[k] = 0;
+                if (k < 2 || 64 * k < e2) {
                     int const p = lane + 64 * k;
                     uint32_t const pa = (p < e0) ? l0.pa : (p < e1) ? l1.pa : (p < e2) ? l2.pa : 2u;
                     uint32_t const pb = (p < e0) ? l0.pb : (p < e1) ? l1.pb : (p < e2) ? l2.pb : 0u;
@@ -609,6 +612,8 @@ lh_noquant_count_bits(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, int w
             for (int k = 0; k < 5; k++) {
                 int const p = lane + 64 * k;
                 int const r0 = (p < e0), r1 = (p >= e0 && p < e1), r2 = (p >= e1 && p < e2);
+                if (!(k < 2 || 64 * k < e2))
+                    continue;
                 w00 += r0 ? v0[k] : 0u;
                 w01 += r0 ? v1[k] : 0u;
                 w10 += r1 ? v0[k] : 0u;
@@ -743,7 +748,7 @@ lh_count_bits(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, int which, in
             int const p = lane + 64 * k;
             int const nc = (int) ((ncmask >> sb[k]) & 1), z1 = (int) ((m01mask >> sb[k]) & 1);
             uint32_t v = pk[k];
-            {
+            if (k < 3 || 64 * k <= pm) {        /* wave-uniform: upper blocks above mnc cost one branch */
                 /* straight-line code for all three cases (no branch per pair, so the table
                  * look-ups of all pairs are in flight together); the rounding table comes
                  * from its LDS head, values beyond it are redone below */

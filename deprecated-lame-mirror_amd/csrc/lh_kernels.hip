@@ -208,18 +208,8 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo)
         padding = 1;
     }
 
-    /* ---- partition start tables (prefix sums of numlines) ---- */
-    if (tid < 64) {
-        int     a = 0, b = 0;
-        for (int k = 0; k < tid; k++) {
-            a += T->psy_l.numlines[k];
-            b += T->psy_s.numlines[k];
-        }
-        L.pstart_l[tid] = a;
-        L.pstart_s[tid] = b;
-    }
-    LH_SYNC_WG();
 
+    LH_PA(24, t_frame);
     /* ---- stage 1: psycho-acoustic model, two granules ---- */
     LH_PT(t_psy);
     for (int gr = 0; gr < 2; gr++)
@@ -253,6 +243,7 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo)
     }
     LH_SYNC_WG();
 
+    LH_PA(25, t_frame);
     /* ---- stage 2: polyphase + MDCT (reference encoder.c:405) ---- */
     LH_PT(t_mdct);
     for (int i = lane; i < 576; i += 64)
@@ -310,6 +301,7 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo)
             st->pefirbuf[tid] = buf[tid];
     }
 
+    LH_PA(26, t_frame);
     /* ---- stage 4: CBR iteration loop (reference quantize.c:1988-2050) ---- */
     int     ResvSize = st->ResvSize, ResvMax, mdb = st->main_data_begin;
     int     substep = st->substep_shaping;
@@ -381,6 +373,7 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo)
         total_bits += L.bits_used[0] + L.bits_used[1];
         LH_SYNC_WG();
     }
+    LH_PA(27, t_frame);
     /* ---- ResvFrameEnd (reference reservoir.c:238-293) ---- */
     int     drain_pre = 0, drain_post = 0;
     {
@@ -478,6 +471,16 @@ lh_encode_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm,
         L.ctx.st = c.st;
         L.ctx.pcm = c.pcm;
         L.ctx.d = c.d;
+    }
+    /* partition start tables (prefix sums of numlines): constant for the launch, kept in LDS */
+    if (c.tid < 64) {
+        int     a = 0, b = 0;
+        for (int k = 0; k < c.tid; k++) {
+            a += T->psy_l.numlines[k];
+            b += T->psy_s.numlines[k];
+        }
+        L.pstart_l[c.tid] = a;
+        L.pstart_s[c.tid] = b;
     }
     for (int f = c.d.frame_begin; f < c.d.frame_end; f++) {
         c.frame_base = 1152LL * f - LH_MF_START;

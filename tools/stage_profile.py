@@ -18,7 +18,8 @@ NAMES = ["frame total", "psy (2 granules)", "polyphase+mdct", "quant total (2 gr
          "outer_loop", "scalefac_store+huffman_divide", "  bin_search", "  balance_noise", "  calc_noise",
          "count_bits calls", "count_bits total", "  quantise part", "calc_noise calls", "  cn: after phase A", "  cn: after phase B", "  cn: after per-band log",
          "  cn: total", "  cb: loads+band decisions", "  nq: count1/big_values/regions", "  nq: + quads", "  nq: + region maxima",
-         "  nq: + table look-ups", "  nq: + sums", "-", "-", "-", "-", "-",
+         "  nq: + table look-ups", "  nq: + sums", "t: window staged, pstart", "t: psy + ATH adjust done", "t: mdct, qtabs, M/S, PE FIR done",
+         "t: granule loop done", "-",
          "  psy: + attack detection", "  psy: + long FFT", "  psy: + power spectra", "  psy: + energy/loudness sums",
          "  psy: + long masking (+MS)", "  psy: + partition->sfb", "  psy: + short blocks", "  psy: + pre-echo", "-", "  bal: amp_scalefac_bands", "  bal: + loop_break",
          "  bal: + scale_bitcount"]
