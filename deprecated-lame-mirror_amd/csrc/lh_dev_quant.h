@@ -1044,8 +1044,10 @@ lh_calc_noise(const LhCtx & c, LhChanLds & Q, LhQR & R, const LhGrR & g, int whi
             for (int k = 0; k < 9; k++) {
                 stp[k] = Q.sfb_f[sbv[k]];
                 p43[k] = qt->pow43h[q[k] & 255];
-                big |= q[k] >> 8;
             }
+#pragma unroll
+            for (int k = 0; k < 9; k++)
+                big |= q[k] >> 8;
             if (lh_ballot(big != 0)) {
                 /* rare: a quantised value beyond the LDS head of pow43 */
 #pragma unroll
@@ -1055,8 +1057,11 @@ lh_calc_noise(const LhCtx & c, LhChanLds & Q, LhQR & R, const LhGrR & g, int whi
             }
 #pragma unroll
             for (int k = 0; k < 9; k++) {
-                float const temp = lh_fabsf(xv[k]) - p43[k] * stp[k];
-                sq[c.lane + 64 * k] = temp * temp;
+                /* lines above mnc are never summed (wave-uniform skip of whole blocks) */
+                if (k < 5 || 64 * k <= R.mnc) {
+                    float const temp = lh_fabsf(xv[k]) - p43[k] * stp[k];
+                    sq[c.lane + 64 * k] = temp * temp;
+                }
             }
         }
         LH_WAVE_SYNC();
@@ -1811,109 +1816,102 @@ LH_DEVFN void
 lh_best_scalefac_store_body(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g, int gr,
                             const int8_t * g0sf, int g0_block_type, int *scfsi_out)
 {
+    /* reference takehiro.c:1021-1094 (+ scfsi_calc :964-1019).  Lane = scalefactor band; every
+     * "for all bands" test of the reference is a ballot, its maxima / minima are wave
+     * reductions; the band's scalefactor lives in a register (sfv) until the end. */
     const LhQTabs *qt = LH_QT;
     int    *sf = Q.sf[0];
-    const int16_t *ix = Q.ix[0];
-    int     sfb, i;
+    const uint32_t *ix2 = (const uint32_t *) Q.ix[0];
+    int const s = c.lane;
+    int const inband = (s < R.sfbmax);
+    int     sfv;
     int     recalc = 0;
     int     scfsi[4] = { 0, 0, 0, 0 };
-    /* bands whose lines are all zero get the wildcard -2 */
+    LH_PT(t_bs0);
     LH_WAVE_SYNC();
-    if (c.lane < R.sfbmax) {
-        int     any = 0;
-        int const j0 = Q.start[c.lane], j1 = j0 + Q.width[c.lane];
-        for (int l = j0; l < j1; ++l)
-            if (ix[l] != 0) {
-                any = 1;
-                break;
-            }
-        if (!any)
-            sf[c.lane] = -2;
+    sfv = inband ? sf[s] : 0;
+    /* bands whose lines are all zero get the wildcard -2: every non-zero pair flags its band */
+    if (s <= LH_SFBMAX)
+        Q.sfb_mode[s] = 0;
+    LH_WAVE_SYNC();
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        int const p = s + 64 * k;
+        int const pc = (k < 4 || p < 288) ? p : 287;
+        uint32_t const v = ix2[pc];
+        int const band = Q.sfb_of_line[2 * pc];
+        if ((k < 4 || p < 288) && v != 0u)
+            Q.sfb_mode[band] = 1;
     }
     LH_WAVE_SYNC();
-    for (sfb = 0; sfb < R.sfbmax; sfb++)
-        if (sf[sfb] == -2)
-            recalc = -2;
+    LH_PA(40, t_bs0);
+    if (inband && !Q.sfb_mode[s])
+        sfv = -2;
+    if (lh_ballot(inband && sfv == -2))
+        recalc = -2;
     if (!g.scalefac_scale && !g.preflag) {
-        int     s = 0;
-        for (sfb = 0; sfb < R.sfbmax; sfb++)
-            if (sf[sfb] > 0)
-                s |= sf[sfb];
-        if (!(s & 1) && s != 0) {
-            LH_WAVE_SYNC();
-            if (c.lane < R.sfbmax && sf[c.lane] > 0)
-                sf[c.lane] >>= 1;
-            LH_WAVE_SYNC();
+        uint64_t const pos = lh_ballot(inband && sfv > 0);
+        uint64_t const odd = lh_ballot(inband && sfv > 0 && (sfv & 1));
+        if (pos && !odd) {
+            if (inband && sfv > 0)
+                sfv >>= 1;
             g.scalefac_scale = recalc = 1;
         }
     }
     if (!g.preflag && R.block_type != LH_SHORT_TYPE) {
-        for (sfb = 11; sfb < LH_SBPSY_L; sfb++)
-            if (sf[sfb] < qt->pretab[sfb] && sf[sfb] != -2)
-                break;
-        if (sfb == LH_SBPSY_L) {
-            LH_WAVE_SYNC();
-            if (c.lane >= 11 && c.lane < LH_SBPSY_L && sf[c.lane] > 0)
-                sf[c.lane] -= qt->pretab[c.lane];
-            LH_WAVE_SYNC();
+        int const hi = (s >= 11 && s < LH_SBPSY_L);
+        int const pre = qt->pretab[s < 22 ? s : 0];
+        if (!lh_ballot(hi && sfv < pre && sfv != -2)) {
+            if (hi && sfv > 0)
+                sfv -= pre;
             g.preflag = recalc = 1;
         }
     }
+    LH_PA(41, t_bs0);
     if (gr == 1 && g0_block_type != LH_SHORT_TYPE && R.block_type != LH_SHORT_TYPE) {
-        /* scfsi_calc */
-        int     s1, s2, c1, c2;
-        for (i = 0; i < 4; i++) {
-            for (sfb = lh_scfsi_band[i]; sfb < lh_scfsi_band[i + 1]; sfb++)
-                if (g0sf[sfb] != sf[sfb] && sf[sfb] >= 0)
-                    break;
-            if (sfb == lh_scfsi_band[i + 1])
-                scfsi[i] = 1;
+        /* scfsi_calc: share a group of scalefactors with granule 0 when all of them agree */
+        int const in21 = (s < LH_SBPSY_L);
+        int const g0 = in21 ? (int) g0sf[s] : 0;
+        uint64_t const mism = lh_ballot(in21 && g0 != sfv && sfv >= 0);
+        int     grp = 0, c1, c2;
+        unsigned s1, s2, key, best;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            uint64_t const gm = ((1ull << lh_scfsi_band[i + 1]) - 1ull) & ~((1ull << lh_scfsi_band[i]) - 1ull);
+            scfsi[i] = !(mism & gm);
+            if (i > 0 && s >= lh_scfsi_band[i])
+                grp = i;
         }
-        LH_WAVE_SYNC();
-        if (c.lane < LH_SBPSY_L) {
-            int     grp = 0;
-            for (i = 1; i < 4; i++)
-                if (c.lane >= lh_scfsi_band[i])
-                    grp = i;
-            if (scfsi[grp])
-                sf[c.lane] = -1;
-        }
-        LH_WAVE_SYNC();
-        s1 = c1 = 0;
-        for (sfb = 0; sfb < 11; sfb++) {
-            if (sf[sfb] == -1)
-                continue;
-            c1++;
-            if (s1 < sf[sfb])
-                s1 = sf[sfb];
-        }
-        s2 = c2 = 0;
-        for (; sfb < LH_SBPSY_L; sfb++) {
-            if (sf[sfb] == -1)
-                continue;
-            c2++;
-            if (s2 < sf[sfb])
-                s2 = sf[sfb];
-        }
-        for (i = 0; i < 16; i++) {
-            if (s1 < lh_slen1_n[i] && s2 < lh_slen2_n[i]) {
-                int const cc = lh_slen1_tab[i] * c1 + lh_slen2_tab[i] * c2;
-                if (g.part2_length > cc) {
-                    g.part2_length = cc;
-                    g.scalefac_compress = i;
-                }
-            }
+        if (in21 && (grp == 0 ? scfsi[0] : grp == 1 ? scfsi[1] : grp == 2 ? scfsi[2] : scfsi[3]))
+            sfv = -1;
+        c1 = lh_popc64(lh_ballot(s < 11 && sfv != -1));
+        c2 = lh_popc64(lh_ballot(s >= 11 && in21 && sfv != -1));
+        s1 = lh_wave_max_u32((s < 11 && sfv > 0) ? (unsigned) sfv : 0u);
+        s2 = lh_wave_max_u32((s >= 11 && in21 && sfv > 0) ? (unsigned) sfv : 0u);
+        /* the reference takes the first strictly smaller candidate in ascending order: the
+         * minimum of (bits, index) */
+        key = 0xffffffffu;
+        if (s < 16 && (int) s1 < lh_slen1_n[s] && (int) s2 < lh_slen2_n[s])
+            key = ((unsigned) (lh_slen1_tab[s] * c1 + lh_slen2_tab[s] * c2) << 8) | (unsigned) s;
+        best = lh_wave_min_u32(key);
+        if (best != 0xffffffffu && g.part2_length > (int) (best >> 8)) {
+            g.part2_length = (int) (best >> 8);
+            g.scalefac_compress = (int) (best & 255u);
         }
         recalc = 0;
     }
+    if (inband) {
+        if (sfv == -2)
+            sfv = 0;
+        sf[s] = sfv;
+    }
     LH_WAVE_SYNC();
-    if (c.lane < R.sfbmax && sf[c.lane] == -2)
-        sf[c.lane] = 0;
-    LH_WAVE_SYNC();
+    LH_PA(42, t_bs0);
     if (recalc)
         (void) lh_scale_bitcount(c, Q, R, g, 0);
+    LH_PA(43, t_bs0);
     if (c.lane == 0)
-        for (i = 0; i < 4; i++)
+        for (int i = 0; i < 4; i++)
             scfsi_out[i] = scfsi[i];
 }
 
@@ -1932,6 +1930,131 @@ lh_best_scalefac_store(int qch, int gr, const int8_t * g0sf, int g0_block_type)
  * splits with serial choose_table calls; here every candidate split is costed
  * by its own lane (serial scan of its region in LDS), then the reference's
  * first-minimum selection is replayed wave-uniformly. */
+/* ---- per-band Huffman length sums for best_huffman_divide -------------------------------
+ * Every region the search looks at is a run of whole scalefactor bands (the last one cut at
+ * big_values), and a region's bit count for a table is an integer sum over its pairs.  So the
+ * pairs are visited once: each adds its code length for every table that can hold it to the
+ * accumulator of its band (LDS atomics), a prefix sum over the bands follows, and any region's
+ * choose_table (takehiro.c:546-650) becomes a difference of prefix sums per candidate table.
+ * Ten words per band: seven hold two tables each (16 bits per half: a band has < 2^16 bits),
+ * then the ESC pair (largetbl layout), the count of values >= 15 and the count of non-zero pairs. */
+#define LH_BHD_NW 10
+#define LH_BHD_STRIDE 24
+
+LH_DEVFN void
+lh_bhd_pair_words(const LhQTabs * qt, unsigned x, unsigned y, unsigned w[LH_BHD_NW])
+{
+    unsigned const m = x > y ? x : y;
+    unsigned const xc = x < 15u ? x : 15u, yc = y < 15u ? y : 15u;
+    unsigned const i2 = xc * 2u + yc, i3 = xc * 3u + yc, i4 = xc * 4u + yc, i6 = xc * 6u + yc, i8 = xc * 8u + yc,
+        i16 = xc * 16u + yc;
+    const uint8_t *h = qt->ht_len;
+    unsigned const t1 = h[lh_ht_off(1) + i2], t2 = h[lh_ht_off(2) + i3], t3 = h[lh_ht_off(3) + i3];
+    unsigned const t5 = h[lh_ht_off(5) + i4], t6 = h[lh_ht_off(6) + i4];
+    unsigned const t7 = h[lh_ht_off(7) + i6], t8 = h[lh_ht_off(8) + i6], t9 = h[lh_ht_off(9) + i6];
+    unsigned const t10 = h[lh_ht_off(10) + i8], t11 = h[lh_ht_off(11) + i8], t12 = h[lh_ht_off(12) + i8];
+    unsigned const t13 = h[lh_ht_off(13) + i16], t14 = h[lh_ht_off(14) + i16], t15 = h[lh_ht_off(15) + i16];
+    unsigned const v2 = m < 2u, v3 = m < 3u, v4 = m < 4u, v6 = m < 6u, v8 = m < 8u, v16 = m < 16u;
+    w[0] = (v2 ? t1 : 0u) | ((v3 ? t2 : 0u) << 16);
+    w[1] = (v3 ? t3 : 0u) | ((v4 ? t5 : 0u) << 16);
+    w[2] = (v4 ? t6 : 0u) | ((v6 ? t7 : 0u) << 16);
+    w[3] = (v6 ? t8 : 0u) | ((v6 ? t9 : 0u) << 16);
+    w[4] = (v8 ? t10 : 0u) | ((v8 ? t11 : 0u) << 16);
+    w[5] = (v8 ? t12 : 0u) | ((v16 ? t13 : 0u) << 16);
+    w[6] = (v16 ? t14 : 0u) | ((v16 ? t15 : 0u) << 16);
+    w[7] = qt->largetbl[i16];
+    w[8] = (unsigned) (x >= 15u) + (unsigned) (y >= 15u);
+    w[9] = (m != 0u);
+}
+
+/* build the tables for the image Q.ix[0], pairs below bigv; tab = [LH_BHD_NW][STRIDE] exclusive
+ * prefix sums over the bands (entry 22 = total), bmx[22] = band maxima; whole wave */
+LH_DEVFN void
+lh_bhd_build(const LhCtx & c, LhChanLds & Q, int bigv, int *tab, int *bmx)
+{
+    const LhQTabs *qt = LH_QT;
+    const uint32_t *ix2 = (const uint32_t *) Q.ix[0];
+    int const npair = bigv >> 1;
+    for (int i = c.lane; i < (LH_BHD_NW + 1) * LH_BHD_STRIDE; i += 64)
+        tab[i] = 0;             /* bmx follows tab */
+    LH_WAVE_SYNC();
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        int const p = c.lane + 64 * k;
+        int const pc = (k < 4 || p < 288) ? p : 287;
+        uint32_t const v = ix2[pc];
+        int const band = Q.sfb_of_line[2 * pc];
+        unsigned w[LH_BHD_NW];
+        lh_bhd_pair_words(qt, v & 0xffffu, v >> 16, w);
+        if (p < npair) {
+            unsigned const m = (v & 0xffffu) > (v >> 16) ? (v & 0xffffu) : (v >> 16);
+#pragma unroll
+            for (int j = 0; j < LH_BHD_NW; j++)
+                lh_lds_add(&tab[j * LH_BHD_STRIDE + band], (int) w[j]);
+            lh_lds_max(&bmx[band], (int) m);
+        }
+    }
+    LH_WAVE_SYNC();
+    if (c.lane < LH_BHD_NW) {
+        int    *row = &tab[c.lane * LH_BHD_STRIDE];
+        int     acc = 0;
+        for (int b = 0; b < LH_SBMAX_L; b++) {
+            int const v = row[b];
+            row[b] = acc;
+            acc += v;
+        }
+        row[LH_SBMAX_L] = acc;
+    }
+    LH_WAVE_SYNC();
+}
+
+/* choose_table for the bands [blo, bhi) from the prefix tables; qw != 0: the pair whose words are
+ * qw (it lies in band bq) is taken out again and band bq's maximum is mq */
+LH_DEVFN int
+lh_bhd_region(const int *tab, const int *bmx, int blo, int bhi, const unsigned *qw, int bq, int mq, int *bits)
+{
+    unsigned mx = 0, w0, w1, d[LH_BHD_NW];
+    for (int b = 0; b < LH_SBMAX_L; b++) {
+        unsigned const m = (unsigned) ((qw && b == bq) ? mq : bmx[b]);
+        if (b >= blo && b < bhi && m > mx)
+            mx = m;
+    }
+    if (mx == 0)
+        return 0;
+#pragma unroll
+    for (int j = 0; j < LH_BHD_NW - 1; j++)
+        d[j] = (unsigned) (tab[j * LH_BHD_STRIDE + bhi] - tab[j * LH_BHD_STRIDE + blo]) - (qw ? qw[j] : 0u);
+    if (mx > 15u) {
+        w0 = d[7];
+        w1 = d[8];
+    }
+    else if (mx == 1u) {
+        w0 = d[0] & 0xffffu;
+        w1 = 0;
+    }
+    else if (mx == 2u) {
+        w0 = (d[0] >> 16) | ((d[1] & 0xffffu) << 16);
+        w1 = 0;
+    }
+    else if (mx == 3u) {
+        w0 = (d[1] >> 16) | ((d[2] & 0xffffu) << 16);
+        w1 = 0;
+    }
+    else if (mx <= 5u) {
+        w0 = (d[2] >> 16) | ((d[3] & 0xffffu) << 16);
+        w1 = d[3] >> 16;
+    }
+    else if (mx <= 7u) {
+        w0 = d[4];
+        w1 = d[5] & 0xffffu;
+    }
+    else {
+        w0 = (d[5] >> 16) | ((d[6] & 0xffffu) << 16);
+        w1 = d[6] >> 16;
+    }
+    return lh_region_decide(mx, w0, w1, bits);
+}
+
 LH_DEVFN void
 lh_best_huffman_divide_body(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g)
 {
@@ -1945,6 +2068,8 @@ lh_best_huffman_divide_body(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGr
     int const bigv0 = g.big_values;
     int const count1bits0 = g.count1bits;
     int     i, a1, a2;
+    int    *tab = (int *) Q.xrpow;      /* xrpow is dead after the outer loop: per-band length sums */
+    int    *bmx = tab + LH_BHD_NW * LH_BHD_STRIDE;
 
     LH_WAVE_SYNC();
     if (R.block_type == LH_NORM_TYPE) {
@@ -1954,12 +2079,13 @@ lh_best_huffman_divide_body(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGr
         int    *r0t_a = r0bits_a + 16;                /* [16] */
         int    *comb_bits = r0bits_a + 32;            /* [128] */
         int    *comb_tbl = comb_bits + 128;           /* [128] */
+        lh_bhd_build(c, Q, bigv0, tab, bmx);
         if (c.lane < 16) {
             int const r0 = c.lane;
             int const e1 = qt->sfb_l[r0 + 1];
             int     b = 0, t = 0;
             if (e1 < bigv0)
-                t = lh_choose_table_lane(LH_QT, ix, 0, e1, &b);
+                t = lh_bhd_region(tab, bmx, 0, r0 + 1, 0, 0, 0, &b);
             r0bits_a[r0] = b;
             r0t_a[r0] = t;
         }
@@ -1971,7 +2097,7 @@ lh_best_huffman_divide_body(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGr
             int     b = LH_LARGE_BITS, t = 0;
             if (e1 < bigv0 && e2 < bigv0) {
                 b = r0bits_a[r0];
-                t = lh_choose_table_lane(LH_QT, ix, e1, e2, &b);
+                t = lh_bhd_region(tab, bmx, r0 + 1, r0 + r1 + 2, 0, 0, 0, &b);
             }
             comb_bits[cmb] = b;
             comb_tbl[cmb] = t;
@@ -2070,6 +2196,21 @@ lh_best_huffman_divide_body(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGr
             /* lane r2 costs region 2 = [sfb_l[r2], bigv) */
             int    *r2bits = (int *) Q.save_xrpow + 320;      /* [23] */
             int    *r2tbl = r2bits + 32;                      /* [23] */
+            /* second pass: the pair [bigv, bigv0) has moved to the count1 region; it is taken
+             * out of the band sums (its values are 0/1, so its band's maximum can only drop
+             * from 1 to 0, and only when it was the band's last non-zero pair) */
+            unsigned qw[LH_BHD_NW];
+            int const minus_q = (pass == 1 && bigv == bigv0 - 2);
+            int     bq = 0, mq = 0;
+            if (minus_q) {
+                uint32_t const v = ((const uint32_t *) ix)[(bigv0 >> 1) - 1];
+                bq = Q.sfb_of_line[bigv0 - 2];
+                lh_bhd_pair_words(qt, v & 0xffffu, v >> 16, qw);
+                mq = bmx[bq];
+                if (mq == 1 && v != 0u
+                    && tab[9 * LH_BHD_STRIDE + bq + 1] - tab[9 * LH_BHD_STRIDE + bq] == 1)
+                    mq = 0;
+            }
             LH_WAVE_SYNC();
             if (c.lane >= 2 && c.lane < LH_SBMAX_L + 1) {
                 int const r2 = c.lane;
@@ -2077,8 +2218,12 @@ lh_best_huffman_divide_body(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGr
                 int     b = 0, t = 0;
                 if (e2 < bigv) {
                     b = r01_bits[r2 - 2] + c1bits;
-                    if (r01_bits[r2 - 2] < LH_LARGE_BITS)
-                        t = lh_choose_table_lane(LH_QT, ix, e2, bigv, &b);
+                    if (r01_bits[r2 - 2] < LH_LARGE_BITS) {
+                        if (pass == 0 || minus_q)
+                            t = lh_bhd_region(tab, bmx, r2, LH_SBMAX_L, minus_q ? qw : 0, bq, mq, &b);
+                        else
+                            t = lh_choose_table_lane(LH_QT, ix, e2, bigv, &b);
+                    }
                 }
                 r2bits[r2] = b;
                 r2tbl[r2] = t;

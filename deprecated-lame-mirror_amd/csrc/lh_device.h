@@ -13,7 +13,7 @@
 extern "C" {
 #endif
 
-#define LH_NPROF 40             /* cycle accumulators per wave (profiling builds) */
+#define LH_NPROF 44             /* cycle accumulators per wave (profiling builds) */
 #define LH_XMIN_N 61            /* 22 long + 13*3 short values of III_psy_xmin */
 
 typedef struct LhStreamState {

@@ -21,8 +21,8 @@ NAMES = ["frame total", "psy (2 granules)", "polyphase+mdct", "quant total (2 gr
          "  nq: + table look-ups", "  nq: + sums", "t: window staged, pstart", "t: psy + ATH adjust done", "t: mdct, qtabs, M/S, PE FIR done",
          "t: granule loop done", "-",
          "  psy: + attack detection", "  psy: + long FFT", "  psy: + power spectra", "  psy: + energy/loudness sums",
-         "  psy: + long masking (+MS)", "  psy: + partition->sfb", "  psy: + short blocks", "  psy: + pre-echo", "-", "  bal: amp_scalefac_bands", "  bal: + loop_break",
-         "  bal: + scale_bitcount"]
+         "  psy: + long masking (+MS)", "  psy: + partition->sfb", "  psy: + short blocks", "  psy: + pre-echo", "  fin: best_scalefac_store", "  bal: amp_scalefac_bands", "  bal: + loop_break",
+         "  bal: + scale_bitcount", "  bss: zero bands", "  bss: + scale/preflag", "  bss: + scfsi", "  bss: + scale_bitcount"]
 
 
 def main():
@@ -37,7 +37,7 @@ def main():
     b.encode()
     ms = b.kernel_ms()
     ssz = enc.lib.lamehip_abi_sizeof(4)
-    NP = 40
+    NP = 44
     tot = np.zeros((2, NP))
     for s in range(0, B, max(1, B // 64)):
         buf = C.create_string_buffer(ssz)
@@ -48,7 +48,7 @@ def main():
     print("batch %d x %.1f s: kernel %.2f ms, %d frames/stream" % (B, secs, ms, frames))
     for w in range(2):
         print("wave %d (cycles per frame, share of frame):" % w)
-        for i, nm in enumerate(NAMES[:40]):
+        for i, nm in enumerate(NAMES[:44]):
             v = tot[w][i] / (frames * len(range(0, B, max(1, B // 64))))
             print("   %-34s %12.0f  %5.1f%%" % (nm, v, 100.0 * tot[w][i] / max(tot[w][0], 1)))
 
