@@ -727,7 +727,12 @@ lh_count_bits(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, int which, in
                     - lh_sbg(g, Q.window[s]) * 8;
             }
             cached = prev_data_use && (pn_step == step);
-            m01 = use_prev && R.pn_sfb_count1 > 0 && s >= R.pn_sfb_count1 && pn_step > 0 && step >= pn_step;
+            /* The band that holds line mnc never takes the 0/1 comparator: the reference has
+             * already set sfb = sfbmax + 1 when it tests prev_noise->step[sfb] there
+             * (takehiro.c:366-372), an entry calc_noise never writes (0 for long blocks; for
+             * short blocks the int view of a float noise value, far above any step). */
+            m01 = use_prev && R.pn_sfb_count1 > 0 && s >= R.pn_sfb_count1 && pn_step > 0 && step >= pn_step
+                && s != s_m;
             noncached = !cached;
         }
         ncmask = lh_ballot(noncached);

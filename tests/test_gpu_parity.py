@@ -177,3 +177,55 @@ def test_no_dependence_on_uninitialised_device_state(name):
     ref = g["mp3"].tobytes()
     assert len(out) > 0 and out == ref[:len(out)]
     enc.close()
+
+
+def _stress_signal(seed, n, sr):
+    """Signals picked to reach rarely taken paths: level steps, clipping, DC, silence gaps,
+    impulses, one silent channel, anti-phase channels, near-silence."""
+    rng = np.random.Generator(np.random.PCG64(7000 + seed))
+    kind = seed % 8
+    x = helpers.synth_stream(500 + seed, n, sr, 1.0 / (3 + seed % 13)).astype(np.float64)
+    if kind == 0:
+        x *= np.where((np.arange(n) // (sr // 7)) % 2 == 0, 1.0, 0.01)      # level steps
+    elif kind == 1:
+        x = np.clip(x * 3.0, -32768, 32767)                                 # hard clipping
+    elif kind == 2:
+        x = x * 0.3 + 9000.0                                                # DC offset
+    elif kind == 3:
+        x[:, n // 3: n // 3 + sr // 5] = 0                                  # digital silence gap
+        x[:, :: sr // 9] = 32767                                            # impulses
+    elif kind == 4:
+        x[1] = 0                                                            # one silent channel
+    elif kind == 5:
+        x[1] = -x[0]                                                        # anti-phase (pure side)
+    elif kind == 6:
+        x = rng.integers(-3, 4, size=(2, n)).astype(np.float64)             # near silence
+    else:
+        x = rng.standard_normal((2, n)) * (rng.uniform(50, 12000))          # noise at a random level
+    return np.clip(np.round(x), -32768, 32767).astype(np.int16)
+
+
+@pytest.mark.parametrize("sr,br,mode,q", [(44100, 128, None, None), (44100, 128, None, 0), (48000, 320, 1, None),
+                                          (32000, 96, None, None), (44100, 192, 0, None), (44100, 256, None, 2),
+                                          (48000, 128, None, 7), (32000, 320, 0, 5), (44100, 112, None, 5), (32000, 128, 0, 9),
+                                          (44100, 224, 1, 4)])
+def test_stress_signals_match_oracle(oracle, sr, br, mode, q):
+    """Bit-exact payload against the oracle over signals that exercise the corners of the
+    quantisation loop, for several rates / bit rates / stereo modes / quality levels."""
+    enc = lamehip.Encoder(sr, br, mode, q)
+    cfg, tab = enc.config(), enc.tables()
+    n = int(sr * 1.5)
+    pcms = [_stress_signal(s * 8 + k, n - 37 * k, sr) for s in range(2) for k in range(8)]
+    b = lamehip.Batch(enc, len(pcms), n)
+    for s, x in enumerate(pcms):
+        b.set_pcm(s, x[0], x[1])
+    b.encode()
+    for s, x in enumerate(pcms):
+        got = b.get_frames(s)
+        want = oracle.encode_frames(cfg, tab, x)
+        assert len(got) == len(want)
+        for f in range(len(got)):
+            d = struct_diff(want[f], got[f])
+            assert not d, (s, f, d[:4])
+    b.close()
+    enc.close()
