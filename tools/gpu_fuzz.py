@@ -1,0 +1,61 @@
+#!/usr/bin/env python
+"""Randomised parity hunt on the GPU box: many short streams of awkward signals per setting,
+HIP payload against the CPU oracle, frame by frame.  Usage: gpu_fuzz.py [streams] [seconds] [seed0]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "deprecated-lame-mirror_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+import helpers  # noqa: E402
+import lamehip  # noqa: E402
+from lamehip.types import struct_diff  # noqa: E402
+import test_gpu_parity as tg  # noqa: E402
+
+SETTINGS = [(44100, 128, None, None), (44100, 128, None, 0), (48000, 320, 1, None), (32000, 96, None, None),
+            (44100, 192, 0, None), (44100, 256, None, 2), (48000, 128, None, 7), (32000, 320, 0, 5),
+            (44100, 112, None, 5), (32000, 128, 0, 9), (44100, 224, 1, 4), (44100, 160, None, 3),
+            (48000, 192, None, 1), (44100, 320, None, 6), (32000, 160, 1, 8)]
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    secs = float(sys.argv[2]) if len(sys.argv) > 2 else 2.0
+    seed0 = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
+    orc = helpers.Oracle()
+    bad = tot = 0
+    t0 = time.time()
+    for sr, br, mode, q in SETTINGS:
+        enc = lamehip.Encoder(sr, br, mode, q)
+        cfg, tab = enc.config(), enc.tables()
+        n = int(sr * secs)
+        pcms = [tg._stress_signal(seed0 + i, n - 13 * (i % 31), sr) for i in range(B)]
+        b = lamehip.Batch(enc, B, n)
+        for s, x in enumerate(pcms):
+            b.set_pcm(s, x[0], x[1])
+        b.encode()
+        for s, x in enumerate(pcms):
+            got = b.get_frames(s)
+            want = orc.encode_frames(cfg, tab, x)
+            tot += 1
+            if len(got) != len(want):
+                bad += 1
+                print("LEN MISMATCH", (sr, br, mode, q), "seed", seed0 + s)
+                continue
+            for f in range(len(got)):
+                d = struct_diff(want[f], got[f])
+                if d:
+                    bad += 1
+                    print("MISMATCH", (sr, br, mode, q), "seed", seed0 + s, "frame", f, d[:3], flush=True)
+                    break
+        b.close()
+        enc.close()
+        print("setting", (sr, br, mode, q), "streams", tot, "bad", bad, "%.0fs" % (time.time() - t0), flush=True)
+    print("TOTAL streams", tot, "BAD", bad)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
