@@ -396,40 +396,22 @@ lh_region_lut(unsigned mx)
 LH_DEVFN int
 lh_region_decide(unsigned mx, unsigned w0, unsigned w1, int *bits)
 {
-    if (mx == 0)
-        return 0;
+    if (mx <= 15u) {
+        /* straight-line selects (scalar unit): first candidate table and the number of
+         * candidates as nibble / 2-bit tables indexed by the region maximum */
+        int const t1 = (int) ((0xDDDDDDDDAA775210ull >> (4u * mx)) & 15u);
+        int const nc = (int) ((0xFFFFFFA4u >> (2u * mx)) & 3u);
+        unsigned const s1 = w0 & 0xffffu, s2 = w0 >> 16, s3 = w1;
+        int const take2 = (nc >= 2) && (s1 > s2);
+        unsigned const sa = take2 ? s2 : s1;
+        int const take3 = (nc >= 3) && (sa > s3);
+        unsigned const sb = take3 ? s3 : sa;
+        *bits += (nc > 0) ? (int) sb : 0;
+        return take3 ? t1 + 2 : (take2 ? t1 + 1 : t1);
+    }
     if (mx > LH_IXMAX) {
         *bits = LH_LARGE_BITS;
         return -1;
-    }
-    if (mx == 1) {
-        *bits += (int) (w0 & 0xffffu);
-        return 1;
-    }
-    if (mx <= 3) {
-        int     t1 = lh_huf_noESC(mx);
-        unsigned s = w0 & 0xffffu, s2 = w0 >> 16;
-        if (s > s2) {
-            s = s2;
-            t1++;
-        }
-        *bits += (int) s;
-        return t1;
-    }
-    if (mx <= 15) {
-        int const t1 = lh_huf_noESC(mx);
-        unsigned s1 = w0 & 0xffffu, s2 = w0 >> 16, s3 = w1;
-        int     t = t1;
-        if (s1 > s2) {
-            s1 = s2;
-            t++;
-        }
-        if (s1 > s3) {
-            s1 = s3;
-            t = t1 + 2;
-        }
-        *bits += (int) s1;
-        return t;
     }
     {
         int     choice, choice2;
