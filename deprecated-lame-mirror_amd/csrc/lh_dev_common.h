@@ -165,7 +165,8 @@ struct LhQTabs {
     uint32_t largetbl[256];     /* packed lengths of the two ESC code books */
     uint32_t table23[9], table56[16];
     uint16_t sfb_l[24];
-    uint8_t ht_len[1672];       /* code lengths, all tables back to back (lh_ht_off()) */
+    uint8_t ht_len[1124];       /* code lengths of tables 1..15 back to back (lh_ht_off()); the ESC
+                                 * tables are read through largetbl */
     uint32_t bvpack[288];       /* big_values/2 - 1 -> region0_count | region1_count << 4 | end of region 0 << 8
                                  * | end of region 1 << 18 (reference takehiro.c:1334-1375 folded with sfb_l) */
     uint16_t sfb_s3, pad;       /* sfb_s[3] */
@@ -176,6 +177,7 @@ struct LhQTabs {
     float   pow43h[256];        /* heads of pow43 / adj43asm: nearly all quantised values are < 256 */
     float   adj43h[256];
 };
+
 
 struct LhQuantLds {
     LhChanLds ch[2];
@@ -210,7 +212,7 @@ struct LhLds {
     int     uselongblock[2];
     int     next_blocktype[2];
     int     block_type[2][2];   /* [gr][ch] */
-    int     pstart_l[64], pstart_s[64];
+    uint16_t pstart_l[64], pstart_s[64];
     /* frame scalars */
     int     mode_ext, padding, mean_bits, max_bits, frame_bits;
     int     targ_bits[2];

@@ -415,7 +415,7 @@ lh_mask_index(LhPsyBand const *gd, float const *mx, float const *avg, int b)
  * short-block variant (:1031-1131).  energy = power spectrum in LDS. */
 LH_DEVFN void
 lh_compute_masking(const LhCtx & c, int chn, int is_long, const float *energy, float *eb,
-                   float *thr, float *smax, float *savg, int *sidx, const int *pstart)
+                   float *thr, float *smax, float *savg, int *sidx, const uint16_t *pstart)
 {
     LhPsyBand const *gd = is_long ? &c.T->psy_l : &c.T->psy_s;
     int const b = c.lane;

@@ -95,7 +95,7 @@ lh_load_qtabs(const LhCtx & c, LhQTabs & q)
         q.pow43h[i] = c.T->pow43[i];
         q.adj43h[i] = c.T->adj43asm[i];
     }
-    for (int i = c.tid; i < LH_HT_POOL; i += LH_NT)
+    for (int i = c.tid; i < (int) sizeof(q.ht_len); i += LH_NT)
         q.ht_len[i] = lh_ht_len[i];
     for (int i = c.tid; i < 288; i += LH_NT) {
         /* big_values = 2 i + 2: the region split the reference looks up with bv_scf[bv - 2], [bv - 1] */
@@ -480,8 +480,8 @@ lh_encode_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm,
             a += T->psy_l.numlines[k];
             b += T->psy_s.numlines[k];
         }
-        L.pstart_l[c.tid] = a;
-        L.pstart_s[c.tid] = b;
+        L.pstart_l[c.tid] = (uint16_t) a;
+        L.pstart_s[c.tid] = (uint16_t) b;
     }
     for (int f = c.d.frame_begin; f < c.d.frame_end; f++) {
         c.frame_base = 1152LL * f - LH_MF_START;
