@@ -322,9 +322,32 @@ lh_pcm_sample(const LhCtx & c, int ch, long long p)
 LH_DEVFN void
 lh_stage_window(const LhCtx & c, float (*mf)[LH_MF_NEEDED], long long base)
 {
-    for (int t = c.tid; t < 2 * LH_MF_NEEDED; t += LH_NT) {
-        int const ch = t >= LH_MF_NEEDED, i = t - ch * LH_MF_NEEDED;
-        mf[ch][i] = lh_pcm_sample(c, ch, base + i);
+    /* Loads are issued unconditionally at clamped positions and the out-of-stream samples
+     * are zeroed afterwards, in batches: a load under a condition is a branch with its own
+     * wait, and a frame's window would cost thirty serial HBM round trips per thread. */
+    float const scale = c.cfg->pcm_scale;
+    long long const last = c.d.nsamples - 1;
+    for (int t0 = c.tid; t0 < 2 * LH_MF_NEEDED; t0 += 6 * LH_NT) {
+        int16_t v[6];
+#pragma unroll
+        for (int u = 0; u < 6; u++) {
+            int const t = t0 + u * LH_NT;
+            int const tt = t < 2 * LH_MF_NEEDED ? t : 2 * LH_MF_NEEDED - 1;
+            int const ch = tt >= LH_MF_NEEDED, i = tt - ch * LH_MF_NEEDED;
+            long long p = base + i;
+            p = p < 0 ? 0 : (p > last ? last : p);
+            p = p < c.d.pcm_base ? c.d.pcm_base : p;    /* never before the pool (also nsamples == 0) */
+            v[u] = (c.d.nsamples > 0) ? c.pcm[(ch == 0 ? c.d.pcm_l : c.d.pcm_r) + (p - c.d.pcm_base)] : (int16_t) 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 6; u++) {
+            int const t = t0 + u * LH_NT;
+            if (t < 2 * LH_MF_NEEDED) {
+                int const ch = t >= LH_MF_NEEDED, i = t - ch * LH_MF_NEEDED;
+                long long const p = base + i;
+                mf[ch][i] = (p < 0 || p > last) ? 0.0f : (float) v[u] * scale;
+            }
+        }
     }
 }
 
