@@ -359,7 +359,6 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo)
             LH_PT(t_fin);
             lh_rg_put(c, R, g);
             lh_best_scalefac_store(ch, gr, fo->gr[0][ch].scalefac, L.block_type[0][ch]);
-            LH_PA(36, t_fin);
             if (cfg->use_best_huffman == 1)
                 lh_best_huffman_divide(ch);
             g = lh_uniform(L.rg[ch].g);

@@ -16,13 +16,15 @@ import lamehip  # noqa: E402
 
 NAMES = ["frame total", "psy (2 granules)", "polyphase+mdct", "quant total (2 gr)", "init+xrpow+xmin",
          "outer_loop", "scalefac_store+huffman_divide", "  bin_search", "  balance_noise", "  calc_noise",
-         "count_bits calls", "count_bits total", "  quantise part", "calc_noise calls", "  cn: after phase A", "  cn: after phase B", "  cn: after per-band log",
-         "  cn: total", "  cb: loads+band decisions", "  nq: count1/big_values/regions", "  nq: + quads", "  nq: + region maxima",
-         "  nq: + table look-ups", "  nq: + sums", "t: window staged, pstart", "t: psy + ATH adjust done", "t: mdct, qtabs, M/S, PE FIR done",
-         "t: granule loop done", "-",
-         "  psy: + attack detection", "  psy: + long FFT", "  psy: + power spectra", "  psy: + energy/loudness sums",
-         "  psy: + long masking (+MS)", "  psy: + partition->sfb", "  psy: + short blocks", "  psy: + pre-echo", "  fin: best_scalefac_store", "  bal: amp_scalefac_bands", "  bal: + loop_break",
-         "  bal: + scale_bitcount", "  bss: zero bands", "  bss: + scale/preflag", "  bss: + scfsi", "  bss: + scale_bitcount"]
+         "count_bits calls", "count_bits total", "  quantise part", "calc_noise calls", "  cn: after phase A",
+         "  cn: after phase B", "  cn: after per-band log", "  cn: total", "  cb: loads+band decisions",
+         "  nq: count1/big_values/regions", "  nq: + quads", "  nq: + region maxima", "  nq: + table look-ups",
+         "  nq: + sums", "t: window staged (+ barrier skew)", "t: psy + ATH adjust done",
+         "t: mdct, qtabs, M/S, PE FIR done", "t: granule loop done", "  psy: attack detection", "  psy: + long FFT",
+         "  psy: + power spectra", "  psy: + energy/loudness sums", "  psy: + long masking (+MS)",
+         "  psy: + partition->sfb", "  psy: + short blocks", "  psy: + pre-echo", "  psy: + block type, PE",
+         "  bal: amp_scalefac_bands", "  bal: + loop_break", "  bal: + scale_bitcount", "  bss: zero bands",
+         "  bss: + scale/preflag", "  bss: + scfsi", "  bss: + scale_bitcount"]
 
 
 def main():
@@ -48,7 +50,7 @@ def main():
     print("batch %d x %.1f s: kernel %.2f ms, %d frames/stream" % (B, secs, ms, frames))
     for w in range(2):
         print("wave %d (cycles per frame, share of frame):" % w)
-        for i, nm in enumerate(NAMES[:44]):
+        for i, nm in enumerate(NAMES[:NP]):
             v = tot[w][i] / (frames * len(range(0, B, max(1, B // 64))))
             print("   %-34s %12.0f  %5.1f%%" % (nm, v, 100.0 * tot[w][i] / max(tot[w][0], 1)))
 
