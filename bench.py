@@ -83,6 +83,32 @@ def cpu_baseline(sr, brate, seconds_budget=12.0):
             "sample": "%d x 20 s seeded synthetic 44.1 kHz stereo, CBR %d, one host core" % (reps, brate)}
 
 
+def end_to_end(torch, lamehip, enc, B, sr, dev, seconds=5.0):
+    """SURVEY.md 8(d) region R2: s16 PCM in host memory -> H2D -> kernel -> D2H -> host bit packing
+    to mp3 bytes in memory, all host cores packing.  A separate, smaller sample (B x 5 s)."""
+    n = int(seconds * sr)
+    host = synth_on_device(torch, B, n, sr, 777, dev).cpu().numpy()
+    threads = min(32, os.cpu_count() or 1)      # measured best on the 256-thread host: 32
+    b = lamehip.Batch(enc, B, n)
+    best = None
+    for _ in range(2):
+        b.reset()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for s in range(B):
+            b.set_pcm(s, host[s, 0], host[s, 1])
+        b.encode(sync=True)
+        t1 = time.perf_counter()
+        _, _, sizes = b.pack_all(threads, as_bytes=False)
+        t2 = time.perf_counter()
+        if best is None or t2 - t0 < best[0]:
+            best = (t2 - t0, t1 - t0, t2 - t1, int(sizes.sum()))
+    b.close()
+    return {"value": round(B * seconds / best[0], 1), "unit": "x real-time", "host_threads": threads,
+            "h2d_plus_kernel_s": round(best[1], 3), "d2h_plus_pack_s": round(best[2], 3), "mp3_bytes": best[3],
+            "sample": "%d streams x %.0f s, host s16 in -> mp3 bytes out" % (B, seconds)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -93,6 +119,9 @@ def main():
     ap.add_argument("--samplerate", type=int, default=44100)
     ap.add_argument("--brate", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--end-to-end", action="store_true",
+                    help="also time host PCM -> H2D -> kernel -> D2H -> host bit packing (threads) on a "
+                         "5 s sample; reported as an extra object, never as `value`")
     args = ap.parse_args()
 
     import torch
@@ -174,6 +203,8 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(sr, args.brate)
+        if args.end_to_end and world == 1:
+            res["end_to_end"] = end_to_end(torch, lamehip, enc, B, sr, dev)
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

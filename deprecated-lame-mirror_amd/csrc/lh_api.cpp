@@ -12,6 +12,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+#include <thread>
+#include <atomic>
 
 #include "lamehip.h"
 #include "lamehip_types.h"
@@ -759,24 +761,17 @@ lamehip_batch_get_state(lamehip_batch * b, int s, void *out, int size)
     return (int) sizeof(LhStreamState);
 }
 
-extern "C" long
-lamehip_batch_pack(lamehip_batch * b, int s, unsigned char *out, long out_size)
+/* host bit packing of one stream from its frames (already on the host) */
+static long
+pack_stream(const lamehip_batch * b, int s, const LhFrameOut * fr, int n, unsigned char *out, long out_size)
 {
     LhBitstream bs;
-    std::vector < LhFrameOut > fr;
     long    pos = 0;
-    int     n;
-    if (!b || s < 0 || s >= b->B || !b->encoded)
-        return -1;
-    n = b->nframes[(size_t) s];
-    fr.resize((size_t) n);
-    if (lamehip_batch_get_frames(b, s, fr.data(), n) != n)
-        return LAMEHIP_ERR_DEVICE;
     if (lh_bs_init(&bs) != 0)
         return -2;
     for (int i = 0; i < n; i++) {
         int     k;
-        if (lh_bs_format_frame(&bs, &b->cfg, b->tab, &fr[(size_t) i]) != 0) {
+        if (lh_bs_format_frame(&bs, &b->cfg, b->tab, &fr[i]) != 0) {
             snprintf(g_err, sizeof(g_err), "inconsistent device payload (packer check %d) stream %d frame %d",
                      bs.error, s, i);
             lh_bs_free(&bs);
@@ -789,7 +784,7 @@ lamehip_batch_pack(lamehip_batch * b, int s, unsigned char *out, long out_size)
         k = lh_bs_copy(&bs, out + pos, 0);
         pos += k;
     }
-    lh_bs_flush(&bs, &b->cfg, n > 0 ? &fr[(size_t) n - 1] : nullptr);
+    lh_bs_flush(&bs, &b->cfg, n > 0 ? &fr[n - 1] : nullptr);
     {
         int     k;
         if (bs.buf_byte_idx + 1 > out_size - pos) {
@@ -801,4 +796,75 @@ lamehip_batch_pack(lamehip_batch * b, int s, unsigned char *out, long out_size)
     }
     lh_bs_free(&bs);
     return pos;
+}
+
+extern "C" long
+lamehip_batch_pack(lamehip_batch * b, int s, unsigned char *out, long out_size)
+{
+    std::vector < LhFrameOut > fr;
+    int     n;
+    if (!b || s < 0 || s >= b->B || !b->encoded)
+        return -1;
+    n = b->nframes[(size_t) s];
+    fr.resize((size_t) n);
+    if (lamehip_batch_get_frames(b, s, fr.data(), n) != n)
+        return LAMEHIP_ERR_DEVICE;
+    return pack_stream(b, s, fr.data(), n, out, out_size);
+}
+
+/* All streams, `nthreads' host threads: thread t takes streams t, t + nthreads, ...; each copies
+ * a stream's payload D2H into its own pinned buffer and packs it (the packer is serial per
+ * stream -- reference bitstream.c -- but streams are independent).  Stream s is written at
+ * out + s * out_stride; sizes[s] = bytes, or a negative error code. */
+extern "C" int
+lamehip_batch_pack_all(lamehip_batch * b, int nthreads, unsigned char *out, long out_stride, long *sizes)
+{
+    int     dev = 0, maxf = 0;
+    std::atomic < int >failed(0);
+    if (!b || !b->encoded || !out || !sizes || out_stride <= 0)
+        return -1;
+    if (nthreads < 1)
+        nthreads = 1;
+    if (nthreads > b->B)
+        nthreads = b->B;
+    HIPCHK(hipStreamSynchronize(b->stream));
+    HIPCHK(hipGetDevice(&dev));
+    for (int s = 0; s < b->B; s++)
+        maxf = b->nframes[(size_t) s] > maxf ? b->nframes[(size_t) s] : maxf;
+    {
+        std::vector < std::thread > pool;
+        for (int t = 0; t < nthreads; t++)
+            pool.emplace_back([=, &failed] () {
+                LhFrameOut *h = nullptr;
+                hipStream_t st = nullptr;
+                if (hipSetDevice(dev) != hipSuccess
+                    || hipHostMalloc((void **) &h, (size_t) (maxf > 0 ? maxf : 1) * sizeof(LhFrameOut), 0) != hipSuccess
+                    || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
+                    failed = 1;
+                    for (int s = t; s < b->B; s += nthreads)
+                        sizes[s] = LAMEHIP_ERR_DEVICE;
+                    if (h)
+                        (void) hipHostFree(h);
+                    return;
+                }
+                for (int s = t; s < b->B; s += nthreads) {
+                    int const n = b->nframes[(size_t) s];
+                    long    r;
+                    if (n > 0 && (hipMemcpyAsync(h, b->d_out + b->out_off[(size_t) s], (size_t) n * sizeof(LhFrameOut),
+                                                 hipMemcpyDeviceToHost, st) != hipSuccess
+                                  || hipStreamSynchronize(st) != hipSuccess))
+                        r = LAMEHIP_ERR_DEVICE;
+                    else
+                        r = pack_stream(b, s, h, n, out + (size_t) s * (size_t) out_stride, out_stride);
+                    sizes[s] = r;
+                    if (r < 0)
+                        failed = 1;
+                }
+                (void) hipStreamDestroy(st);
+                (void) hipHostFree(h);
+            });
+        for (auto & th:pool)
+            th.join();
+    }
+    return failed ? LAMEHIP_ERR_PAYLOAD : 0;
 }

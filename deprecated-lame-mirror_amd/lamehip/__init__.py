@@ -52,6 +52,7 @@ def load_library():
     lib.lamehip_batch_pcm_device_ptr.restype = C.c_void_p
     lib.lamehip_batch_pcm_device_ptr.argtypes = [C.c_void_p]
     lib.lamehip_batch_encode.argtypes = [C.c_void_p]
+    lib.lamehip_batch_pack_all.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_long, C.c_void_p]
     lib.lamehip_batch_sync.argtypes = [C.c_void_p]
     lib.lamehip_batch_reset.argtypes = [C.c_void_p]
     lib.lamehip_batch_frames.argtypes = [C.c_void_p, C.c_int]
@@ -196,6 +197,21 @@ class Batch:
         if k < 0:
             raise RuntimeError("lamehip_batch_pack failed (%d): %s" % (k, last_error()))
         return buf.raw[:k]
+
+    def pack_all(self, nthreads=0, as_bytes=True):
+        """Pack every stream with `nthreads' host threads (0 = min(32, cores)).  Returns the list of
+        mp3 byte strings, or (buffer, stride, sizes) when as_bytes is False."""
+        import os
+        nthreads = nthreads or min(32, os.cpu_count() or 1)
+        stride = max(self.frames(s) for s in range(self.n)) * 1500 + 8192
+        buf = np.empty(self.n * stride, dtype=np.uint8)
+        sizes = np.zeros(self.n, dtype=np.int64)
+        rc = self.lib.lamehip_batch_pack_all(self.b, nthreads, buf.ctypes.data, stride, sizes.ctypes.data)
+        if rc != 0 or (sizes < 0).any():
+            raise RuntimeError("lamehip_batch_pack_all failed (%d): %s" % (rc, last_error()))
+        if not as_bytes:
+            return buf, stride, sizes
+        return [buf[s * stride: s * stride + int(sizes[s])].tobytes() for s in range(self.n)]
 
     def close(self):
         if self.b:

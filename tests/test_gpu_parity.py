@@ -229,3 +229,20 @@ def test_stress_signals_match_oracle(oracle, sr, br, mode, q):
             assert not d, (s, f, d[:4])
     b.close()
     enc.close()
+
+
+def test_pack_all_threads_equals_per_stream_pack():
+    """lamehip_batch_pack_all (host threads, one pinned staging buffer each) gives the bytes of
+    the per-stream call."""
+    enc = lamehip.Encoder(44100, 128)
+    lengths = [44100 + 977 * i for i in range(24)] + [1, 1152, 0]
+    pcms = [helpers.synth_stream(900 + i, max(n, 1), 44100, 1.0 / 7)[:, :n] for i, n in enumerate(lengths)]
+    b = lamehip.Batch(enc, len(pcms), max(lengths))
+    for s, x in enumerate(pcms):
+        b.set_pcm(s, x[0], x[1])
+    b.encode()
+    single = [b.pack(s) for s in range(len(pcms))]
+    for nt in (1, 5, 64):
+        assert b.pack_all(nt) == single
+    b.close()
+    enc.close()
