@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""Randomised parity hunt on the GPU box: many short streams of awkward signals per setting,
-HIP payload against the CPU oracle, frame by frame.  Usage: gpu_fuzz.py [streams] [seconds] [seed0]"""
+"""Randomised parity hunt on the GPU box (test tool, not collected by pytest): many short streams
+of awkward signals per setting, HIP payload against the CPU oracle, frame by frame.
+Usage: python tests/fuzz_gpu.py [streams] [seconds] [seed0]"""
 import os
 import sys
 import time
@@ -8,6 +9,7 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "deprecated-lame-mirror_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np  # noqa: E402
 import helpers  # noqa: E402
 import lamehip  # noqa: E402

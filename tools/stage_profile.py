@@ -9,9 +9,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "deprecated-lame-mirror_amd"))
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
-import helpers  # noqa: E402
 import lamehip  # noqa: E402
 
 NAMES = ["frame total", "psy (2 granules)", "polyphase+mdct", "quant total (2 gr)", "init+xrpow+xmin",
@@ -33,7 +31,16 @@ def main():
     n = int(44100 * secs)
     enc = lamehip.Encoder(44100, 128)
     b = lamehip.Batch(enc, B, n)
-    base = [helpers.synth_stream(900 + i, n) for i in range(8)]
+    rng = np.random.Generator(np.random.PCG64(900))
+    t = np.arange(n) / 44100.0
+    base = []
+    for i in range(8):          # music-like: partials + noise bursts (same flavour as the tests' signal)
+        x = sum(0.5 / (k + 1) * np.sin(2 * np.pi * 220.0 * 2 ** (k / 2.0) * t + rng.uniform(0, 6.28, (2, 1)))
+                for k in range(8))
+        x = x + 0.01 * rng.standard_normal((2, n))
+        for s0 in range(7000, n - 2000, 14700):
+            x[:, s0:s0 + 2000] += 0.6 * np.exp(-np.arange(2000) / 300.0) * rng.standard_normal((2, 2000))
+        base.append((x / np.abs(x).max() * 0.8 * 32767).astype(np.int16))
     for s in range(B):
         b.set_pcm(s, base[s % 8][0], base[s % 8][1])
     b.encode()
