@@ -1,0 +1,62 @@
+#!/usr/bin/env python
+"""Settings sweep on the GPU box (test tool, not collected by pytest): every MPEG-1 bit rate x
+sample rate x stereo mode x a set of quality levels that lame_init_params accepts, a few
+awkward signals each, HIP payload against the CPU oracle frame by frame.
+Usage: python tests/sweep_gpu.py [streams_per_setting] [seconds]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "deprecated-lame-mirror_amd"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import helpers  # noqa: E402
+import lamehip  # noqa: E402
+from lamehip.types import struct_diff  # noqa: E402
+import test_gpu_parity as tg  # noqa: E402
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+    secs = float(sys.argv[2]) if len(sys.argv) > 2 else 1.2
+    orc = helpers.Oracle()
+    bad = tot = nset = unsup = 0
+    t0 = time.time()
+    for sr in (32000, 44100, 48000):
+        for br in (32, 40, 48, 56, 64, 80, 96, 112, 128, 160, 192, 224, 256, 320):
+            for mode in (0, 1):
+                for q in (0, 2, 3, 5, 7, 9):
+                    try:
+                        enc = lamehip.Encoder(sr, br, mode, q)
+                    except RuntimeError:
+                        unsup += 1
+                        continue
+                    nset += 1
+                    cfg, tab = enc.config(), enc.tables()
+                    n = int(sr * secs)
+                    pcms = [tg._stress_signal(br + q + 8 * i + i, n - 29 * i, sr) for i in range(B)]
+                    b = lamehip.Batch(enc, B, n)
+                    for s, x in enumerate(pcms):
+                        b.set_pcm(s, x[0], x[1])
+                    b.encode()
+                    for s, x in enumerate(pcms):
+                        got = b.get_frames(s)
+                        want = orc.encode_frames(cfg, tab, x)
+                        tot += 1
+                        ok = len(got) == len(want)
+                        for f in range(len(got) if ok else 0):
+                            d = struct_diff(want[f], got[f])
+                            if d:
+                                ok = False
+                                print("MISMATCH", (sr, br, mode, q), "stream", s, "frame", f, d[:3], flush=True)
+                                break
+                        bad += (not ok)
+                    b.close()
+                    enc.close()
+        print("rate", sr, "settings", nset, "streams", tot, "bad", bad, "%.0fs" % (time.time() - t0), flush=True)
+    print("TOTAL settings", nset, "unsupported", unsup, "streams", tot, "BAD", bad)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
