@@ -103,6 +103,10 @@ struct lame_global_struct {
     int     have_last;
     LhBitstream bs;
     hipStream_t stream;
+    /* Xing/Info + LAME tag (host bookkeeping, lh_vbrtag.c) */
+    LhVbrTag tag;
+    int     tag_placeholder_pending;
+    int     enc_padding;
 };
 
 static int
@@ -120,7 +124,7 @@ lame_init(void)
     g->class_id = LAME_ID;
     lh_params_default(&g->p);
     g->out_samplerate = 0;
-    g->write_vbr_tag = 1;       /* reference default (lame.c:2340); must be cleared, see lame_init_params */
+    g->write_vbr_tag = 1;       /* reference default (lame.c:2340) */
     g->inited = 0;
     g->have_device = 0;
     g->tab = nullptr;
@@ -137,6 +141,9 @@ lame_init(void)
     g->have_last = 0;
     g->stream = nullptr;
     memset(&g->bs, 0, sizeof(g->bs));
+    memset(&g->tag, 0, sizeof(g->tag));
+    g->tag_placeholder_pending = 0;
+    g->enc_padding = 0;
     return g;
 }
 
@@ -218,11 +225,6 @@ lame_init_params(lame_t g)
         snprintf(g_err, sizeof(g_err), "resampling is outside the accelerated path");
         return -1;
     }
-    if (g->write_vbr_tag) {
-        snprintf(g_err, sizeof(g_err),
-                 "Xing/LAME tag frame is not produced by this library: call lame_set_bWriteVbrTag(gfp, 0)");
-        return -1;
-    }
     if (lh_config_resolve(&g->p, &g->cfg, &aux) != 0) {
         snprintf(g_err, sizeof(g_err), "unsupported settings for the MI355X path (need MPEG-1, 2 channels, CBR)");
         return -1;
@@ -237,6 +239,12 @@ lame_init_params(lame_t g)
     if (lh_bs_init(&g->bs) != 0)
         return -2;
     g->inited = 1;              /* host constants are valid from here on (lamehip_get_*) */
+    /* the tag frame is reserved at the head of the stream (reference InitVbrTag); when it does
+     * not fit the reference silently switches it off */
+    if (g->write_vbr_tag && lh_tag_init(&g->tag, &g->cfg) > 0)
+        g->tag_placeholder_pending = 1;
+    else
+        g->write_vbr_tag = 0;
     if (lamehip_device_count() <= 0) {
         snprintf(g_err, sizeof(g_err), "no HIP device: liblamehip has no CPU encode path");
         g->have_device = 0;
@@ -254,6 +262,20 @@ lame_init_params(lame_t g)
         HIPCHK(hipMemcpy(g->d_state, &s0, sizeof(s0), hipMemcpyHostToDevice));
     }
     g->have_device = 1;
+    return 0;
+}
+
+/* the reserved tag frame leaves with the first bytes the caller gets (reference lame.c:1744-1748:
+ * copy_buffer(.., 0) at the start of every lame_encode_buffer call) */
+static int
+emit_tag_placeholder(lame_t g, unsigned char *mp3buf, int mp3buf_size, int *written)
+{
+    if (!g->tag_placeholder_pending)
+        return 0;
+    if (mp3buf_size != 0 && mp3buf_size - *written < g->tag.total_frame_size)
+        return -1;
+    *written += lh_tag_placeholder(&g->tag, &g->cfg, mp3buf + *written);
+    g->tag_placeholder_pending = 0;
     return 0;
 }
 
@@ -326,6 +348,10 @@ handle_encode_frames(lame_t g, int upto, unsigned char *mp3buf, int mp3buf_size,
         k = lh_bs_copy(&g->bs, mp3buf + *written, mp3buf_size ? mp3buf_size - *written : 0);
         if (k < 0)
             return -1;
+        if (g->write_vbr_tag) {
+            lh_tag_add_frame(&g->tag, g->cfg.avg_bitrate);      /* reference encoder.c:550-551 */
+            lh_tag_crc(&g->tag, mp3buf + *written, k);          /* reference bitstream.c:1082-1088 */
+        }
         *written += k;
     }
     g->last_frame = g->h_out[(size_t) nf - 1];
@@ -367,6 +393,8 @@ lame_encode_buffer(lame_t g, const short int l[], const short int r[], const int
      * lead-in (reference lame.c:1737-1769) */
     avail = (LH_MF_START + g->fed >= LH_MF_NEEDED)
         ? (int) ((LH_MF_START + g->fed - LH_MF_NEEDED) / 1152 + 1) : 0;
+    if (emit_tag_placeholder(g, mp3buf, mp3buf_size, &written))
+        return -1;
     rc = handle_encode_frames(g, avail, mp3buf, mp3buf_size, &written);
     if (rc)
         return rc;
@@ -396,6 +424,9 @@ lame_encode_flush(lame_t g, unsigned char *mp3buf, int size)
     if (g->flushed)
         return 0;               /* reference lame.c:2076-2079 */
     total = lh_total_frames((long) g->fed);
+    g->enc_padding = lh_end_padding((long) g->fed);     /* reference lame.c:2088-2091 */
+    if (emit_tag_placeholder(g, mp3buf, size, &written))
+        return -1;
     rc = handle_encode_frames(g, total, mp3buf, size, &written);
     if (rc)
         return rc;
@@ -403,6 +434,8 @@ lame_encode_flush(lame_t g, unsigned char *mp3buf, int size)
     k = lh_bs_copy(&g->bs, mp3buf + written, size ? size - written : 0);
     if (k < 0)
         return -1;
+    if (g->write_vbr_tag)
+        lh_tag_crc(&g->tag, mp3buf + written, k);
     written += k;
     g->flushed = 1;
     /* the reference zeroes the reservoir after padding out the last frame (bitstream.c:886-888) */
@@ -415,6 +448,18 @@ lame_encode_flush(lame_t g, unsigned char *mp3buf, int size)
         }
     }
     return written;
+}
+
+/* reference lame.h:970, VbrTag.c:900: the final tag frame that replaces the placeholder at the
+ * head of the stream; 0 when the tag is off or nothing was encoded; the needed size when `size'
+ * is too small */
+extern "C" size_t
+lame_get_lametag_frame(const lame_t g, unsigned char *buffer, size_t size)
+{
+    if (!valid(g) || !g->inited || !g->write_vbr_tag)
+        return 0;
+    return (size_t) lh_tag_frame(&g->tag, &g->cfg, 4 /* VBR_q default, lame.c:2349 */ , g->enc_padding,
+                                 g->have_last ? g->last_frame.mode_ext : 0, buffer, (long) size);
 }
 
 extern "C" int

@@ -480,3 +480,22 @@ lh_total_frames(long n)
     frames_left = (int) ((to_encode + end_padding) / 1152);
     return (int) (frames + frames_left);
 }
+
+/* end padding that lame_encode_flush adds after n input samples (reference lame.c:2077-2091);
+ * the same arithmetic as in lh_total_frames */
+int
+lh_end_padding(long n)
+{
+    long    to_encode = LH_ENCDELAY + LH_POSTDELAY + n;
+    int     end_padding;
+    if (n > 0) {
+        long const total = LH_MF_START + n;
+        if (total >= LH_MF_NEEDED)
+            to_encode -= 1152 * ((total - LH_MF_NEEDED) / 1152 + 1);
+    }
+    to_encode -= LH_POSTDELAY;
+    end_padding = 1152 - (int) (to_encode % 1152);
+    if (end_padding < 576)
+        end_padding += 1152;
+    return end_padding;
+}

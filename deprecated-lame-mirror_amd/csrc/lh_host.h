@@ -66,6 +66,28 @@ void    lh_bs_flush(LhBitstream * bs, const LhConfig * c, const LhFrameOut * las
 /* moves the finished bytes out (reference copy_buffer); -1 if size!=0 and too small */
 int     lh_bs_copy(LhBitstream * bs, unsigned char *out, int size);
 
+
+/* ---- Xing/Info + LAME tag bookkeeping (lh_vbrtag.c; reference VbrTag.c) ---- */
+#define LH_LAMEHEADERSIZE (4 + 4 + 4 + 4 + 100 + 4 + 9 + 1 + 1 + 8 + 1 + 1 + 3 + 1 + 1 + 2 + 4 + 2 + 2)
+#define LH_TAG_BAG 400
+typedef struct LhVbrTag {
+    int     enabled;
+    int     total_frame_size;
+    int     sum, seen, want, pos, size;
+    int     bag[LH_TAG_BAG];
+    unsigned num_frames;
+    unsigned long bytes_written;
+    uint16_t music_crc;
+} LhVbrTag;
+
+int     lh_tag_init(LhVbrTag * v, const LhConfig * c);
+void    lh_tag_add_frame(LhVbrTag * v, int kbps);
+void    lh_tag_crc(LhVbrTag * v, const unsigned char *buf, long n);
+int     lh_tag_placeholder(const LhVbrTag * v, const LhConfig * c, unsigned char *buf);
+int     lh_tag_frame(const LhVbrTag * v, const LhConfig * c, int vbr_q, int enc_padding, int last_mode_ext,
+                     unsigned char *buf, long size);
+int     lh_end_padding(long nsamples);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,254 @@
+/*
+ * lh_vbrtag.c -- host side: the Xing/"Info" + LAME tag frame of a CBR stream
+ * (SURVEY.md 8(f) row 3).  Behaviour of the reference's libmp3lame/VbrTag.c:
+ *   - lame_init_params reserves a frame-sized placeholder at the start of the stream
+ *     (InitVbrTag :492-581; all zero after the 4 header bytes),
+ *   - every encoded frame adds its bit rate to a bounded seek-point bag (AddVbrFrame :196,
+ *     addVbr :124-148),
+ *   - the audio bytes handed to the caller feed a CRC-16 and a byte count
+ *     (bitstream.c:1078-1090),
+ *   - lame_get_lametag_frame (:900-1018) builds the final frame: "Info", frame and byte
+ *     counts, a 100-entry seek table (Xing_seek_table :151-172) and the LAME extension
+ *     (PutLameVBR :615-861) with two CRCs.
+ * Everything here is byte bookkeeping on the host; nothing touches the GPU.
+ */
+#include <math.h>
+#include <string.h>
+#include "lh_host.h"
+
+static uint16_t lh_crc16_tab[256];
+static int lh_crc16_ready = 0;
+
+static void
+crc16_init(void)
+{
+    /* CRC-16 with the reflected polynomial 0xA001, the table the reference spells out
+     * (VbrTag.c:73-106) */
+    int     i, k;
+    for (i = 0; i < 256; i++) {
+        uint16_t c = (uint16_t) i;
+        for (k = 0; k < 8; k++)
+            c = (uint16_t) ((c & 1) ? (c >> 1) ^ 0xA001 : (c >> 1));
+        lh_crc16_tab[i] = c;
+    }
+    lh_crc16_ready = 1;
+}
+
+static uint16_t
+crc16_update(uint16_t value, uint16_t crc)
+{
+    uint16_t const tmp = (uint16_t) (crc ^ value);
+    return (uint16_t) ((crc >> 8) ^ lh_crc16_tab[tmp & 0xff]);
+}
+
+void
+lh_tag_crc(LhVbrTag * v, const unsigned char *buf, long n)
+{
+    long    i;
+    if (!lh_crc16_ready)
+        crc16_init();
+    for (i = 0; i < n; i++)
+        v->music_crc = crc16_update(buf[i], v->music_crc);
+    v->bytes_written += (unsigned long) n;
+}
+
+/* reference VbrTag.c:492-559: 0 = the tag does not fit, stays off */
+int
+lh_tag_init(LhVbrTag * v, const LhConfig * c)
+{
+    int const total = ((c->version + 1) * 72000 * c->avg_bitrate) / c->samplerate;
+    int const header_size = c->sideinfo_len + LH_LAMEHEADERSIZE;
+    memset(v, 0, sizeof(*v));
+    if (!lh_crc16_ready)
+        crc16_init();
+    if (total < header_size || total > 2880)
+        return 0;
+    v->total_frame_size = total;
+    v->want = 1;
+    v->size = LH_TAG_BAG;
+    v->enabled = 1;
+    return total;
+}
+
+/* reference VbrTag.c:124-148 */
+void
+lh_tag_add_frame(LhVbrTag * v, int kbps)
+{
+    int     i;
+    v->num_frames++;
+    v->sum += kbps;
+    v->seen++;
+    if (v->seen < v->want)
+        return;
+    if (v->pos < v->size) {
+        v->bag[v->pos] = v->sum;
+        v->pos++;
+        v->seen = 0;
+    }
+    if (v->pos == v->size) {
+        for (i = 1; i < v->size; i += 2)
+            v->bag[i / 2] = v->bag[i];
+        v->want *= 2;
+        v->pos /= 2;
+    }
+}
+
+/* the 4 header bytes, reference VbrTag.c:257-323 (MPEG-1, CBR: the stream's own bit rate) */
+static void
+tag_frame_header(const LhConfig * c, int mode_ext, unsigned char *b)
+{
+    b[0] = 0xff;
+    b[1] = (unsigned char) (0xe0 | (1 << 4) | (c->version << 3) | (1 << 1) | (c->error_protection ? 0 : 1));
+    b[1] = (unsigned char) ((b[1] & 0xf1) | 0x0a);
+    b[2] = (unsigned char) (((c->samplerate_index << 2) | (c->extension & 1)) & 0x0d);
+    b[2] = (unsigned char) (b[2] | (16 * c->bitrate_index));
+    b[3] = (unsigned char) ((c->mode << 6) | ((mode_ext & 3) << 4) | ((c->copyright & 1) << 3)
+                            | ((c->original & 1) << 2) | (c->emphasis & 3));
+}
+
+/* the placeholder that opens the stream; returns its size */
+int
+lh_tag_placeholder(const LhVbrTag * v, const LhConfig * c, unsigned char *buf)
+{
+    memset(buf, 0, (size_t) v->total_frame_size);
+    tag_frame_header(c, 0, buf);
+    return v->total_frame_size;
+}
+
+static void
+put_i4(unsigned char *b, uint32_t x)
+{
+    b[0] = (unsigned char) (x >> 24);
+    b[1] = (unsigned char) (x >> 16);
+    b[2] = (unsigned char) (x >> 8);
+    b[3] = (unsigned char) x;
+}
+
+static void
+put_i2(unsigned char *b, int x)
+{
+    b[0] = (unsigned char) ((x >> 8) & 0xff);
+    b[1] = (unsigned char) (x & 0xff);
+}
+
+/* final tag frame; returns the frame size, 0 when there is no tag (reference VbrTag.c:900-1018).
+ * user_quality / vbr_q are the caller-level settings the "quality" byte is made of. */
+int
+lh_tag_frame(const LhVbrTag * v, const LhConfig * c, int vbr_q, int enc_padding, int last_mode_ext,
+             unsigned char *buf, long size)
+{
+    unsigned char toc[100];
+    int     i, n;
+    uint16_t crc = 0;
+    if (!v->enabled || v->pos <= 0)
+        return 0;
+    if (size < v->total_frame_size)
+        return v->total_frame_size;
+    if (!buf)
+        return 0;
+    memset(buf, 0, (size_t) v->total_frame_size);
+    tag_frame_header(c, last_mode_ext, buf);
+    memset(toc, 0, sizeof(toc));
+    for (i = 1; i < 100; ++i) {
+        /* reference Xing_seek_table: float index, float bag / sum, double scaling */
+        float const j = i / (float) 100;
+        float   act, sum;
+        int     indx = (int) (floor(j * v->pos));
+        int     seek_point;
+        if (indx > v->pos - 1)
+            indx = v->pos - 1;
+        act = (float) v->bag[indx];
+        sum = (float) v->sum;
+        seek_point = (int) (256. * act / sum);
+        if (seek_point > 255)
+            seek_point = 255;
+        toc[i] = (unsigned char) seek_point;
+    }
+    n = c->sideinfo_len;
+    if (c->error_protection)
+        n -= 2;
+    memcpy(buf + n, "Info", 4);         /* CBR: "Info", VBR would be "Xing" */
+    n += 4;
+    put_i4(buf + n, 0x0001 | 0x0002 | 0x0004 | 0x0008);    /* frames, bytes, TOC, quality */
+    n += 4;
+    put_i4(buf + n, (uint32_t) v->num_frames);
+    n += 4;
+    put_i4(buf + n, (uint32_t) (v->bytes_written + (unsigned long) v->total_frame_size));
+    n += 4;
+    memcpy(buf + n, toc, sizeof(toc));
+    n += (int) sizeof(toc);
+    for (i = 0; i < n; i++)
+        crc = crc16_update(buf[i], crc);
+    {
+        /* LAME extension, reference PutLameVBR */
+        unsigned char *p = buf + n;
+        int     k = 0;
+        int     quality = 100 - 10 * vbr_q - c->quality;
+        double const lp = (c->lowpassfreq / 100.0) + .5;
+        unsigned char const lowpass = (unsigned char) (lp > 255 ? 255 : lp);
+        int const ath_type = c->ATHtype;
+        int const safe_joint = (c->use_safe_joint_stereo != 0);
+        int     stereo_mode, source_freq, non_optimal = 0;
+        unsigned long const music_length = v->bytes_written + (unsigned long) v->total_frame_size;
+        if (quality < 0)
+            quality = 0;
+        switch (c->mode) {
+        case LH_MODE_MONO:
+            stereo_mode = 0;
+            break;
+        case LH_MODE_STEREO:
+            stereo_mode = 1;
+            break;
+        case LH_MODE_DUAL:
+            stereo_mode = 2;
+            break;
+        case LH_MODE_JOINT_STEREO:
+            stereo_mode = c->force_ms ? 4 : 3;
+            break;
+        default:
+            stereo_mode = 7;
+        }
+        if (c->samplerate <= 32000)
+            source_freq = 0;
+        else if (c->samplerate == 48000)
+            source_freq = 2;
+        else if (c->samplerate > 48000)
+            source_freq = 3;
+        else
+            source_freq = 1;
+        /* short_blocks: 2 = dispensed, 3 = forced (lame.h short_block_t) */
+        if (c->short_blocks == 3 || c->short_blocks == 2 || c->lowpassfreq == -1
+            || (c->disable_reservoir && c->avg_bitrate < 320) || ath_type == 0 || c->samplerate <= 32000)
+            non_optimal = 1;
+        put_i4(p + k, (uint32_t) quality);
+        k += 4;
+        memcpy(p + k, "LAME3.99r", 9);  /* get_lame_tag_encoder_short_version() of 3.99.5 */
+        k += 9;
+        p[k++] = 0x01;                  /* tag revision 0, method 1 = CBR */
+        p[k++] = lowpass;
+        put_i4(p + k, 0);               /* peak signal amplitude: not measured */
+        k += 4;
+        put_i2(p + k, 0);               /* radio ReplayGain: not measured */
+        k += 2;
+        put_i2(p + k, 0);               /* audiophile ReplayGain */
+        k += 2;
+        p[k++] = (unsigned char) (ath_type + (1 << 4) + (safe_joint << 5));
+        p[k++] = (unsigned char) (c->avg_bitrate >= 255 ? 0xFF : c->avg_bitrate);
+        p[k] = (unsigned char) (LH_ENCDELAY >> 4);
+        p[k + 1] = (unsigned char) ((LH_ENCDELAY << 4) + (enc_padding >> 8));
+        p[k + 2] = (unsigned char) enc_padding;
+        k += 3;
+        p[k++] = (unsigned char) (c->noise_shaping + (stereo_mode << 2) + (non_optimal << 5) + (source_freq << 6));
+        p[k++] = 0;                     /* MP3 gain */
+        put_i2(p + k, c->avg_bitrate);  /* preset: apply_preset(brate) leaves the bit rate here (presets.c:361, lame.c:1045) */
+        k += 2;
+        put_i4(p + k, (uint32_t) music_length);
+        k += 4;
+        put_i2(p + k, v->music_crc);
+        k += 2;
+        for (i = 0; i < k; i++)
+            crc = crc16_update(p[i], crc);
+        put_i2(p + k, crc);
+    }
+    return v->total_frame_size;
+}

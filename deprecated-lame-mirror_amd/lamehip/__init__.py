@@ -39,6 +39,8 @@ def load_library():
     lib.lame_encode_buffer.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
     lib.lame_encode_flush.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     lib.lame_close.argtypes = [C.c_void_p]
+    lib.lame_get_lametag_frame.restype = C.c_size_t
+    lib.lame_get_lametag_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     lib.lame_get_frameNum.argtypes = [C.c_void_p]
     lib.lamehip_last_error.restype = C.c_char_p
     lib.lamehip_get_config.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
@@ -73,13 +75,13 @@ def last_error():
 class Encoder:
     """One stream behind the lame.h call sequence."""
 
-    def __init__(self, samplerate=44100, brate=128, mode=None, quality=None, require_device=True):
+    def __init__(self, samplerate=44100, brate=128, mode=None, quality=None, require_device=True, write_tag=False):
         self.lib = load_library()
         self.h = C.c_void_p(self.lib.lame_init())
         self.lib.lame_set_in_samplerate(self.h, samplerate)
         self.lib.lame_set_num_channels(self.h, 2)
         self.lib.lame_set_brate(self.h, brate)
-        self.lib.lame_set_bWriteVbrTag(self.h, 0)
+        self.lib.lame_set_bWriteVbrTag(self.h, 1 if write_tag else 0)
         if mode is not None:
             self.lib.lame_set_mode(self.h, mode)
         if quality is not None:
@@ -117,6 +119,12 @@ class Encoder:
         k = self.lib.lame_encode_flush(self.h, buf, len(buf))
         if k < 0:
             raise RuntimeError("lame_encode_flush failed (%d): %s" % (k, last_error()))
+        return buf.raw[:k]
+
+    def lametag_frame(self):
+        """Final Xing/Info + LAME tag frame (b"" when the tag is off)."""
+        buf = C.create_string_buffer(2880)
+        k = self.lib.lame_get_lametag_frame(self.h, buf, len(buf))
         return buf.raw[:k]
 
     def close(self):

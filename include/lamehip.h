@@ -20,6 +20,7 @@
 #define LAMEHIP_H
 
 #include <stdint.h>
+#include <stddef.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -57,7 +58,7 @@ int     lame_set_quality(lame_t, int);                               /* lame.h:2
 int     lame_get_quality(const lame_t);                              /* lame.h:264 */
 int     lame_set_VBR(lame_t, vbr_mode);                              /* lame.h:432 (only vbr_off is built) */
 vbr_mode lame_get_VBR(const lame_t);                                 /* lame.h:433 */
-int     lame_set_bWriteVbrTag(lame_t, int);                          /* lame.h:240 (tag frame is a host-side "next" item; must be 0) */
+int     lame_set_bWriteVbrTag(lame_t, int);                          /* lame.h:240 (default 1, as in the reference) */
 int     lame_get_bWriteVbrTag(const lame_t);                         /* lame.h:241 */
 int     lame_set_findReplayGain(lame_t, int);                        /* lame.h:296 (accepted, ignored) */
 int     lame_init_params(lame_t);                                    /* lame.h:636 */
@@ -74,6 +75,8 @@ int     lame_encode_buffer(lame_t, const short int buffer_l[], const short int b
 int     lame_encode_buffer_interleaved(lame_t, short int pcm[], int num_samples,
                                        unsigned char *mp3buf, int mp3buf_size);                  /* lame.h:730 */
 int     lame_encode_flush(lame_t, unsigned char *mp3buf, int size);                              /* lame.h:856 */
+/* final Xing/Info + LAME tag frame that replaces the placeholder at the head of the stream */
+size_t  lame_get_lametag_frame(const lame_t, unsigned char *buffer, size_t size);                /* lame.h:970 */
 int     lame_close(lame_t);                                                                      /* lame.h:977 */
 
 /* ------------------------------------------------------------------ */

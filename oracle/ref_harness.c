@@ -65,6 +65,39 @@ refh_open(int samplerate, int brate, int mode, int quality)
     return h;
 }
 
+/* the same with the Xing/LAME tag enabled (reference default): the stream then starts with the
+ * placeholder frame and refh_lametag() returns the final tag frame after the flush */
+void   *
+refh_open_tag(int samplerate, int brate, int mode, int quality)
+{
+    RefH   *h = (RefH *) calloc(1, sizeof(RefH));
+    h->gfp = lame_init();
+    lame_set_errorf(h->gfp, quiet);
+    lame_set_debugf(h->gfp, quiet);
+    lame_set_msgf(h->gfp, quiet);
+    lame_set_in_samplerate(h->gfp, samplerate);
+    lame_set_num_channels(h->gfp, 2);
+    lame_set_brate(h->gfp, brate);
+    lame_set_bWriteVbrTag(h->gfp, 1);
+    if (mode >= 0)
+        lame_set_mode(h->gfp, (MPEG_mode) mode);
+    if (quality >= 0)
+        lame_set_quality(h->gfp, quality);
+    if (lame_init_params(h->gfp) < 0) {
+        lame_close(h->gfp);
+        free(h);
+        return 0;
+    }
+    return h;
+}
+
+int
+refh_lametag(void *hh, unsigned char *out, int outsize)
+{
+    RefH   *h = (RefH *) hh;
+    return (int) lame_get_lametag_frame(h->gfp, out, (size_t) outsize);
+}
+
 void
 refh_close(void *hh)
 {

@@ -106,6 +106,36 @@ class Reference:
         return buf.raw[:k], nf.value, frames, cfg, tab
 
 
+def reference_tagged(pcm, sr, brate, mode=-1, quality=-1, chunk=1152):
+    """The compiled reference with its default tag handling (bWriteVbrTag = 1): returns
+    (stream bytes incl. the placeholder frame, final tag frame)."""
+    ref = Reference()
+    lib = ref.lib
+    lib.refh_open_tag.restype = C.c_void_p
+    h = lib.refh_open_tag(sr, brate, mode, quality)
+    assert h, "reference refused the settings"
+    h = C.c_void_p(h)
+    left = np.ascontiguousarray(pcm[0], dtype=np.int16)
+    right = np.ascontiguousarray(pcm[1], dtype=np.int16)
+    n = len(left)
+    buf = C.create_string_buffer(int(1.25 * chunk) + 7200 + 3000)
+    out = b""
+    for i in range(0, n, chunk):
+        m = min(chunk, n - i)
+        k = lib.refh_encode(h, left[i:].ctypes.data_as(C.c_void_p), right[i:].ctypes.data_as(C.c_void_p), m,
+                            buf, len(buf))
+        assert k >= 0
+        out += buf.raw[:k]
+    k = lib.refh_flush(h, buf, len(buf))
+    assert k >= 0
+    out += buf.raw[:k]
+    t = C.create_string_buffer(2880)
+    k = lib.refh_lametag(h, t, len(t))
+    tag = t.raw[:k]
+    lib.refh_close(h)
+    return out, tag
+
+
 def have_reference():
     return os.path.exists(REF_SO)
 
