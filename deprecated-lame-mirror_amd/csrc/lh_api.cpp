@@ -857,6 +857,37 @@ lamehip_batch_pack(lamehip_batch * b, int s, unsigned char *out, long out_size)
     return pack_stream(b, s, fr.data(), n, out, out_size);
 }
 
+/* One stream as a complete file image: the final Xing/Info + LAME tag frame followed by the audio
+ * frames (what the reference's frontend leaves on disk after lame_mp3_tags_fid).  When the tag
+ * does not fit the frame size the audio alone is returned, as the reference would. */
+extern "C" long
+lamehip_batch_pack_tagged(lamehip_batch * b, int s, unsigned char *out, long out_size)
+{
+    LhVbrTag v;
+    std::vector < LhFrameOut > fr;
+    int     n, total;
+    long    k;
+    if (!b || s < 0 || s >= b->B || !b->encoded)
+        return -1;
+    total = lh_tag_init(&v, &b->cfg);
+    if (out_size < total)
+        return -1;
+    n = b->nframes[(size_t) s];
+    fr.resize((size_t) n);
+    if (lamehip_batch_get_frames(b, s, fr.data(), n) != n)
+        return LAMEHIP_ERR_DEVICE;
+    k = pack_stream(b, s, fr.data(), n, out + total, out_size - total);
+    if (k < 0 || total == 0)
+        return k;
+    for (int i = 0; i < n; i++)
+        lh_tag_add_frame(&v, b->cfg.avg_bitrate);
+    lh_tag_crc(&v, out + total, k);
+    if (lh_tag_frame(&v, &b->cfg, 4, lh_end_padding(b->len[(size_t) s]), n > 0 ? fr[(size_t) n - 1].mode_ext : 0,
+                     out, total) != total)
+        memset(out, 0, (size_t) total);         /* no frames: the reference leaves the placeholder */
+    return k + total;
+}
+
 /* All streams, `nthreads' host threads: thread t takes streams t, t + nthreads, ...; each copies
  * a stream's payload D2H into its own pinned buffer and packs it (the packer is serial per
  * stream -- reference bitstream.c -- but streams are independent).  Stream s is written at

@@ -206,6 +206,17 @@ class Batch:
             raise RuntimeError("lamehip_batch_pack failed (%d): %s" % (k, last_error()))
         return buf.raw[:k]
 
+    def pack_tagged(self, s):
+        """Complete file image of stream s: final tag frame + audio frames."""
+        n = self.frames(s)
+        buf = C.create_string_buffer(n * 1500 + 8192 + 2880)
+        self.lib.lamehip_batch_pack_tagged.restype = C.c_long
+        self.lib.lamehip_batch_pack_tagged.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_long]
+        k = self.lib.lamehip_batch_pack_tagged(self.b, s, buf, len(buf))
+        if k < 0:
+            raise RuntimeError("lamehip_batch_pack_tagged failed (%d): %s" % (k, last_error()))
+        return buf.raw[:k]
+
     def pack_all(self, nthreads=0, as_bytes=True):
         """Pack every stream with `nthreads' host threads (0 = min(32, cores)).  Returns the list of
         mp3 byte strings, or (buffer, stride, sizes) when as_bytes is False."""

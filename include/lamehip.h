@@ -104,6 +104,8 @@ int     lamehip_batch_sync(lamehip_batch *);
 int     lamehip_batch_frames(lamehip_batch *, int stream);
 /* D2H of one stream's payload + host bit packing; returns bytes or <0 */
 long    lamehip_batch_pack(lamehip_batch *, int stream, unsigned char *out, long out_size);
+/* one stream as a complete file image: final Xing/Info + LAME tag frame, then the audio frames */
+long    lamehip_batch_pack_tagged(lamehip_batch *, int stream, unsigned char *out, long out_size);
 /* the same for all streams with `nthreads' host threads (streams are independent; the packer is
  * serial per stream): stream s at out + s * out_stride, sizes[s] = bytes or a negative code */
 int     lamehip_batch_pack_all(lamehip_batch *, int nthreads, unsigned char *out, long out_stride, long *sizes);

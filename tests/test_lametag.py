@@ -76,3 +76,21 @@ def test_api_default_tag_handling_matches_reference(sr, br, mode, chunk):
     assert out == stream
     assert enc.lametag_frame() == tag
     enc.close()
+
+
+@pytest.mark.gpu
+def test_batch_pack_tagged_is_the_reference_file_image():
+    """Batch path: tag frame + audio == the reference's stream with its placeholder replaced by
+    its final tag frame (what the frontend leaves on disk)."""
+    sr, br = 44100, 128
+    pcms = [helpers.synth_stream(777 + i, int(sr * (0.8 + 0.37 * i)), sr, 1.0 / 4) for i in range(4)]
+    enc = lamehip.Encoder(sr, br)
+    b = lamehip.Batch(enc, len(pcms), max(x.shape[1] for x in pcms))
+    for s, x in enumerate(pcms):
+        b.set_pcm(s, x[0], x[1])
+    b.encode()
+    for s, x in enumerate(pcms):
+        stream, tag = helpers.reference_tagged(x, sr, br)
+        assert b.pack_tagged(s) == tag + stream[len(tag):]
+    b.close()
+    enc.close()
