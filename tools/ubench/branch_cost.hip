@@ -88,6 +88,31 @@ __global__ void __launch_bounds__(128) k_dpp_reduce(unsigned long long *out, int
     if (acc == 12345u) out[0] = v;
 }
 
+
+__global__ void __launch_bounds__(128) k_f64_add(unsigned long long *out, int n, int one)
+{
+    double v = threadIdx.x;
+    unsigned long long t0 = clock64();
+    for (int i = 0; i < n; i++) {
+        REP64(asm volatile("v_add_f64 %0, %0, %1\n v_add_f64 %0, %0, %1\n v_add_f64 %0, %0, %1\n v_add_f64 %0, %0, %1\n" : "+v"(v) : "v"(1.5));)
+    }
+    unsigned long long t1 = clock64();
+    if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
+    if (v == 12345.0) out[0] = 1;
+}
+__global__ void __launch_bounds__(128) k_cvt(unsigned long long *out, int n, int one)
+{
+    float f = threadIdx.x;
+    double d;
+    unsigned long long t0 = clock64();
+    for (int i = 0; i < n; i++) {
+        REP64(asm volatile("v_cvt_f64_f32 %1, %0\n v_cvt_f32_f64 %0, %1\n v_cvt_f64_f32 %1, %0\n v_cvt_f32_f64 %0, %1\n" : "+v"(f), "=v"(d));)
+    }
+    unsigned long long t1 = clock64();
+    if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
+    if (f == 12345.0f) out[0] = 1;
+}
+
 template <typename K> static void run(const char *name, K kern, int per_iter, int blocks_per_cu)
 {
     int n = 200;
@@ -114,6 +139,8 @@ int main()
         run("salu-dep x4", k_salu, 64, b);
         run("lds-dep", k_lds_dep, 64, b);
         run("dpp-reduce", k_dpp_reduce, 16, b);
+        run("add_f64 x4", k_f64_add, 64, b);
+        run("cvt x4", k_cvt, 64, b);
     }
     return 0;
 }
