@@ -808,14 +808,10 @@ lh_scale_bitcount(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g, int
     const LhQTabs *qt = LH_QT;
     int    *sf = Q.sf[which];
     int     k, max_slen1, max_slen2;
-    const int *tabp;
     int     v;
     LH_WAVE_SYNC();
     v = (c.lane < R.sfbmax) ? sf[c.lane] : 0;
-    if (R.block_type == LH_SHORT_TYPE)
-        tabp = lh_scale_short;
-    else {
-        tabp = lh_scale_long;
+    if (R.block_type != LH_SHORT_TYPE) {
         if (!g.preflag) {
             int const inr = (c.lane >= 11 && c.lane < LH_SBPSY_L);
             uint64_t const below = lh_ballot(inr && v < (int) qt->pretab[inr ? c.lane : 0]);
@@ -831,11 +827,23 @@ lh_scale_bitcount(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g, int
     }
     max_slen1 = (int) lh_wave_max_u32((c.lane < R.sfbdivide && v > 0) ? (unsigned) v : 0u);
     max_slen2 = (int) lh_wave_max_u32((c.lane >= R.sfbdivide && c.lane < R.sfbmax && v > 0) ? (unsigned) v : 0u);
+    /* the reference scans the 16 (slen1, slen2) pairs in order and keeps the first strictly
+     * smaller size (takehiro.c:1184-1196): the minimum of (size, index), one lane per pair */
     g.part2_length = LH_LARGE_BITS;
-    for (k = 0; k < 16; k++) {
-        if (max_slen1 < lh_slen1_n[k] && max_slen2 < lh_slen2_n[k] && g.part2_length > tabp[k]) {
-            g.part2_length = tabp[k];
-            g.scalefac_compress = k;
+    k = c.lane & 15;
+    {
+        unsigned key = 0xffffffffu, best;
+        /* slen1 / slen2 of pair k as nibble tables (reference takehiro.c:1102-1126); the
+         * table sizes are 11 slen1 + 10 slen2 (long) and 18 (slen1 + slen2) (short) */
+        int const s1 = (int) ((0x4433322211130000ull >> (4 * k)) & 15u);
+        int const s2 = (int) ((0x3232132132103210ull >> (4 * k)) & 15u);
+        int const sz = (R.block_type == LH_SHORT_TYPE) ? 18 * (s1 + s2) : 11 * s1 + 10 * s2;
+        if (c.lane < 16 && max_slen1 < (1 << s1) && max_slen2 < (1 << s2))
+            key = ((unsigned) sz << 8) | (unsigned) k;
+        best = lh_wave_min_u32(key);
+        if (best != 0xffffffffu) {
+            g.part2_length = (int) (best >> 8);
+            g.scalefac_compress = (int) (best & 255u);
         }
     }
     return g.part2_length == LH_LARGE_BITS;
@@ -1878,8 +1886,13 @@ lh_best_scalefac_store_body(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGr
         /* the reference takes the first strictly smaller candidate in ascending order: the
          * minimum of (bits, index) */
         key = 0xffffffffu;
-        if (s < 16 && (int) s1 < lh_slen1_n[s] && (int) s2 < lh_slen2_n[s])
-            key = ((unsigned) (lh_slen1_tab[s] * c1 + lh_slen2_tab[s] * c2) << 8) | (unsigned) s;
+        {
+            int const k16 = s & 15;
+            int const l1 = (int) ((0x4433322211130000ull >> (4 * k16)) & 15u);
+            int const l2 = (int) ((0x3232132132103210ull >> (4 * k16)) & 15u);
+            if (s < 16 && (int) s1 < (1 << l1) && (int) s2 < (1 << l2))
+                key = ((unsigned) (l1 * c1 + l2 * c2) << 8) | (unsigned) s;
+        }
         best = lh_wave_min_u32(key);
         if (best != 0xffffffffu && g.part2_length > (int) (best >> 8)) {
             g.part2_length = (int) (best >> 8);
