@@ -254,7 +254,20 @@ struct LhCtx {
     LhStreamDesc d;
     long long frame_base;       /* stream sample index of mfbuf[0] for the current frame: 1152 f - 528 */
     int     lane, wave, tid;
+    /* the settings the iteration loop tests again and again, read from HBM once (scalar
+     * registers) instead of once per use */
+    int     ns, ns_amp, sfb21_extra, full_outer_loop, subblock_gain;
 };
+
+LH_DEVFN void
+lh_ctx_hot(LhCtx & c)
+{
+    c.ns = lh_uni_i(c.cfg->noise_shaping);
+    c.ns_amp = lh_uni_i(c.cfg->noise_shaping_amp);
+    c.sfb21_extra = lh_uni_i(c.cfg->sfb21_extra);
+    c.full_outer_loop = lh_uni_i(c.cfg->full_outer_loop);
+    c.subblock_gain = lh_uni_i(c.cfg->subblock_gain);
+}
 
 /* The context reaches an out-of-line stage through per-lane memory, which hides from the
  * compiler that its pointers address HBM; routing them through the global address space once
@@ -292,6 +305,7 @@ lh_ctx_load(void)
     o.tid = (int) threadIdx.x;
     o.lane = o.tid & 63;
     o.wave = lh_uni_i(o.tid >> 6);
+    lh_ctx_hot(o);
     return o;
 }
 

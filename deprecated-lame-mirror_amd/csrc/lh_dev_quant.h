@@ -937,7 +937,7 @@ lh_calc_xmin_body(const LhCtx & c, LhChanLds & Q, LhQR & R, const float *xr, con
             max_nonzero *= 6;
             max_nonzero += 5;
         }
-        if (cfg->sfb21_extra == 0 && cfg->samplerate < 44000) {
+        if (c.sfb21_extra == 0 && cfg->samplerate < 44000) {
             int     limit;
             if (R.block_type != LH_SHORT_TYPE)
                 limit = qt->sfb_l[21] - 1;
@@ -1012,7 +1012,7 @@ lh_calc_noise(const LhCtx & c, LhChanLds & Q, LhQR & R, const LhGrR & g, int whi
      * quantize_pvt.c:750-796): above count1 every ix is 0 and pow43[0]*step = 0, so
      * |xr| - 0 squares to xr*xr; in the count1 region ix is 0/1 and pow43[1] = 1.0f makes
      * pow43[ix]*step equal to {0, step} exactly. */
-    if (c.cfg->noise_shaping_amp != 3) {
+    if (c.ns_amp != 3) {
         /* Phase A, all lanes: the squared error of every line, (|xr| - pow43[ix] step)^2,
          * nine lines per lane, no branches; the band's step travels through LDS.
          * Phase B, lane = band: the reference's serial sum over the band's lines (the order
@@ -1175,7 +1175,7 @@ lh_init_outer_loop_body(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, flo
 {
     const LhTables *T = c.T;
     const LhQTabs *qt = LH_QT;
-    int const sfb21 = c.cfg->sfb21_extra;
+    int const sfb21 = c.sfb21_extra;
     g.part2_3_length = 0;
     g.big_values = 0;
     g.count1 = 0;
@@ -1478,7 +1478,7 @@ lh_amp_scalefac_bands(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g,
         ifqstep34 = (float) 1.68179283050742922612;
     /* distort >= 0, so the float maximum is the maximum of the bit patterns */
     trigger = lh_u32_as_f32(lh_wave_max_u32(lh_f32_as_u32(dist > 0.0f ? dist : 0.0f)));
-    noise_shaping_amp = cfg->noise_shaping_amp;
+    noise_shaping_amp = c.ns_amp;
     if (noise_shaping_amp == 3)
         noise_shaping_amp = (bRefine == 1) ? 2 : 1;
     switch (noise_shaping_amp) {
@@ -1500,7 +1500,7 @@ lh_amp_scalefac_bands(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g,
     }
     cand = lh_ballot(s < R.sfbmax && !(dist < trigger));
     last_visited = R.sfbmax - 1;
-    if (cfg->noise_shaping_amp == 2) {
+    if (c.ns_amp == 2) {
         uint64_t const ph = (R.substep_shaping & 2) ? lh_ballot(s < R.sfbmax && Q.pseudohalf[s]) : 0;
         uint64_t m = cand;
         while (m) {
@@ -1638,7 +1638,7 @@ lh_balance_noise(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g, int 
     LH_PA(39, t_bal);
     if (!status)
         return 1;
-    if (cfg->noise_shaping > 1) {
+    if (c.ns > 1) {
         LH_WAVE_SYNC();
         if (c.lane <= LH_SFBMAX)
             Q.pseudohalf[c.lane] = 0;
@@ -1648,7 +1648,7 @@ lh_balance_noise(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g, int 
             status = 0;
         }
         else {
-            if (R.block_type == LH_SHORT_TYPE && cfg->subblock_gain > 0)
+            if (R.block_type == LH_SHORT_TYPE && c.subblock_gain > 0)
                 status = lh_inc_subblock_gain(c, Q, R, g, which) || lh_loop_break(c, Q, R, g, which);
         }
     }
@@ -1687,7 +1687,7 @@ lh_outer_loop(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & gb, const float 
         (void) lh_bin_search_StepSize(c, Q, R, gb, targ_bits, ch);
         LH_PA(7, t_bs);
     }
-    if (!cfg->noise_shaping)
+    if (!c.ns)
         return 100;
     LH_WAVE_SYNC();
     if (c.lane <= LH_SFBMAX) {
@@ -1705,7 +1705,7 @@ lh_outer_loop(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & gb, const float 
     age = 0;
     /* save_xrpow is only ever read back by the refinement pass of noise_shaping_amp 3
      * (reference quantize.c:1170-1183); otherwise the buffer is calc_noise's scratch */
-    if (cfg->noise_shaping_amp == 3) {
+    if (c.ns_amp == 3) {
         for (int i = c.lane; i < 576; i += 64)
             Q.save_xrpow[i] = Q.xrpow[i];
     }
@@ -1720,7 +1720,7 @@ lh_outer_loop(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & gb, const float 
                 search_limit = 20;
             else
                 search_limit = 3;
-            if (cfg->sfb21_extra) {
+            if (c.sfb21_extra) {
                 if (Q.distort[R.sfbmax] > 1.0)
                     break;
                 if (R.block_type == LH_SHORT_TYPE
@@ -1764,19 +1764,19 @@ lh_outer_loop(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & gb, const float 
                 lh_copy_gr(c, Q, 0, 1);
                 gb = gw;
                 age = 0;
-                if (cfg->noise_shaping_amp == 3) {
+                if (c.ns_amp == 3) {
                     for (int i = c.lane; i < 576; i += 64)
                         Q.save_xrpow[i] = Q.xrpow[i];
                 }
                 LH_WAVE_SYNC();
             }
             else {
-                if (cfg->full_outer_loop == 0) {
+                if (c.full_outer_loop == 0) {
                     if (++age > search_limit && best_noise_info.over_count == 0)
                         break;
-                    if ((cfg->noise_shaping_amp == 3) && bRefine && age > 30)
+                    if ((c.ns_amp == 3) && bRefine && age > 30)
                         break;
-                    if ((cfg->noise_shaping_amp == 3) && bRefine &&
+                    if ((c.ns_amp == 3) && bRefine &&
                         (gw.global_gain - best_ggain_pass1) > 15)
                         break;
                 }
@@ -1784,7 +1784,7 @@ lh_outer_loop(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & gb, const float 
         }
         while ((gw.global_gain + gw.scalefac_scale) < 255);
 
-        if (cfg->noise_shaping_amp == 3) {
+        if (c.ns_amp == 3) {
             if (!bRefine) {
                 lh_copy_gr(c, Q, 1, 0);
                 gw = gb;

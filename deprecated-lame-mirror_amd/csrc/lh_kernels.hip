@@ -465,6 +465,7 @@ lh_encode_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm,
     c.tid = (int) threadIdx.x;
     c.lane = c.tid & 63;
     c.wave = lh_uni_i(c.tid >> 6);      /* scalar: everything indexed by the wave id gets scalar addressing */
+    lh_ctx_hot(c);
     if (c.tid == 0) {
         L.ctx.cfg = c.cfg;
         L.ctx.T = c.T;
