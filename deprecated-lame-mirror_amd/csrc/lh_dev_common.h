@@ -174,6 +174,7 @@ struct LhQTabs {
     uint8_t t32l[16], t33l[16];
     uint32_t t3233[16];         /* t32l << 16 | t33l */
     uint8_t pretab[24];
+    float   ipow20w[128];       /* ipow20[128..255]: the step sizes count_bits asks for almost always */
     float   pow43h[256];        /* heads of pow43 / adj43asm: nearly all quantised values are < 256 */
     float   adj43h[256];
 };
@@ -225,19 +226,25 @@ struct LhLds {
 #endif
     LhCtxShared ctx;
     LhRgSlot rg[2];
-    union {
+    /* both unions start on 16-byte boundaries: the kernels read float2 / float4 from the arrays
+     * inside (ds_read_b64 / b128), and a misaligned wide LDS access is split by the hardware --
+     * a layout change that shifted them by 4 bytes once cost 13 % of the whole kernel */
+    union __attribute__((aligned(16))) {
         float   mf[2][LH_MF_NEEDED];    /* scaled float PCM window of the frame (psy, polyphase) */
         struct {
             float   xr[2][2][576];      /* [ch][gr] MDCT spectra; written after the last read of mf */
             LhQTabs qt;                 /* loaded after the MDCT, used by the iteration loop */
         };
     };
-    union {
+    union __attribute__((aligned(16))) {
         LhPsyLds psy;
         LhMdctLds mdct;
         LhQuantLds quant;
     } u;
 };
+
+static_assert(sizeof(LhChanLds) % 16 == 0, "both channels' float2/float4 accesses need 16-byte alignment");
+static_assert(sizeof(LhLds) <= 40960, "four workgroups per CU need <= 40 KiB of the 160 KiB LDS each");
 
 /* The workgroup's LDS image (one stream), at file scope: every device function, in line or
  * not, addresses it as LDS with constant offsets (ds_* instructions).  Handing it to the

@@ -657,8 +657,12 @@ lh_count_bits(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, int which, in
     uint32_t *ix2 = (uint32_t *) Q.ix[which];
     const int *sf = Q.sf[which];
     const float *xrpow = Q.xrpow;
-    float const istep = T->ipow20[g.global_gain];
-    float const w = (LH_IXMAX) / istep;
+    /* global_gain is wave-uniform: one LDS word for the usual range, HBM below it */
+    float   istep;
+    if (g.global_gain >= 128)
+        istep = qt->ipow20w[g.global_gain - 128];
+    else
+        istep = T->ipow20[g.global_gain];
     int const mnc = R.mnc;
     int const pm = mnc >> 1;            /* last pair that holds a line <= mnc (mnc is odd) */
     int const sfbmax = (R.block_type == LH_SHORT_TYPE) ? 38 : 21;
@@ -669,7 +673,7 @@ lh_count_bits(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, int which, in
     uint64_t ncmask, m01mask;
     int     zero_mnc;
 
-    if (g.xrpow_max > w)
+    if (g.xrpow_max > (LH_IXMAX) / istep)
         return LH_LARGE_BITS;
     /* Everything a lane needs that does not depend on the band decisions is loaded first.
      * The loads are unconditional with clamped indices and the results are selected afterwards:

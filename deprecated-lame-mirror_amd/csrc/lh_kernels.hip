@@ -90,6 +90,8 @@ LH_DEVCONST float lh_pe_fir[9] = {
 LH_DEVFN void
 lh_load_qtabs(const LhCtx & c, LhQTabs & q)
 {
+    if (c.tid < 128)
+        q.ipow20w[c.tid] = c.T->ipow20[128 + c.tid];
     for (int i = c.tid; i < 256; i += LH_NT) {
         q.largetbl[i] = lh_largetbl[i];
         q.pow43h[i] = c.T->pow43[i];
