@@ -157,6 +157,8 @@ struct LhChanLds {
     /* scratch */
     int     sfb_mode[LH_SFBMAX + 1];
     float   sfb_f[LH_SFBMAX + 1];
+    float   zero2[2];           /* two zeros on an 8-byte boundary: where masked-out term loads are redirected */
+    float   pad2[2];            /* keeps sizeof a multiple of 16 */
 };
 
 /* hot lookup tables of the quantiser, staged into LDS for the iteration-loop phase

@@ -1066,22 +1066,25 @@ lh_calc_noise(const LhCtx & c, LhChanLds & Q, LhQR & R, const LhGrR & g, int whi
         LH_WAVE_SYNC();
         LH_PA(14, t_cn0);
         {
-            /* eight terms are fetched (as four aligned pairs: band starts are even) before
-             * the eight dependent additions, so one LDS round trip is paid per eight lines */
+            /* Eight terms are fetched (as four aligned pairs: band starts are even) before the
+             * eight dependent additions, so one LDS round trip is paid per eight lines.  A pair
+             * beyond the band's length is fetched from a pair of zeros instead (one select on
+             * the address), and adding +0.0f leaves the non-negative sum unchanged. */
             int const n = 2 * l;
             int const jj = (j < 576) ? j : 0;
             const lh_f32x2 *sq2 = (const lh_f32x2 *) sq;
+            const lh_f32x2 *zero = (const lh_f32x2 *) Q.zero2;
             for (int k0 = 0; k0 < maxw; k0 += 8) {
                 lh_f32x2 t[4];
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
-                    int const idx = (jj + k0) / 2 + u;
-                    t[u] = sq2[idx < 288 ? idx : 287];
+                    const lh_f32x2 *src = (k0 + 2 * u < n) ? &sq2[(jj + k0) / 2 + u] : zero;
+                    t[u] = *src;
                 }
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
-                    noise += (k0 + 2 * u < n) ? t[u].x : 0.0f;
-                    noise += (k0 + 2 * u + 1 < n) ? t[u].y : 0.0f;
+                    noise += t[u].x;
+                    noise += t[u].y;
                 }
             }
         }
@@ -1218,6 +1221,8 @@ lh_init_outer_loop_body(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, flo
         int const s = c.lane;
         Q.sf[0][s] = 0;
         Q.sf[1][s] = 0;
+        if (s < 2)
+            Q.zero2[s] = 0.0f;
         if (s == LH_SFBMAX) {
             Q.width[s] = 0;
             Q.window[s] = 3;
