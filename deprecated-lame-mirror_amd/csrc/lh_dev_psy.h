@@ -963,9 +963,16 @@ lh_psy_granule(int gr)
             st->blocktype_old[c.tid] = L.next_blocktype[c.tid];
             L.block_type[gr][c.tid] = btd[c.tid];
         }
-        if (c.tid < n_chn_psy) {
-            int const chn = c.tid;
-            int     type;
+        /* Perceptual entropy (reference psymodel.c:458-553): the terms coef * log10(en / thr)
+         * are independent of each other -- one lane per term, in double as the reference forms
+         * them -- and only the accumulation pe = (float) (pe + term) runs in band order (a band
+         * that contributes nothing adds 0.0, which leaves pe unchanged).  Wave w: channels w, w+2. */
+        for (int pass = 0; pass < 2; pass++) {
+            int const chn = w + 2 * pass;
+            double *tmp = (double *) P.eb + 40 * chn;       /* eb / thr are dead by now: 4 x 40 doubles */
+            int     type, is_short, nterms;
+            if (chn >= n_chn_psy)
+                continue;
             if (chn > 1) {
                 type = LH_NORM_TYPE;
                 if (btd[0] == LH_SHORT_TYPE || btd[1] == LH_SHORT_TYPE)
@@ -973,9 +980,34 @@ lh_psy_granule(int gr)
             }
             else
                 type = btd[chn];
-            L.pe[gr][chn] = lh_pecalc(T, L.ratio_en[gr][chn], L.ratio_thm[gr][chn], st->masking_lower,
-                                      type == LH_SHORT_TYPE);
-            st->last_attacks[chn] = L.ns_attacks[chn][2];
+            is_short = (type == LH_SHORT_TYPE);
+            nterms = is_short ? 3 * (LH_SBMAX_S - 1) : LH_SBMAX_L - 1;
+            LH_WAVE_SYNC_MEM();
+            if (lane < nterms) {
+                int const idx = is_short ? 22 + lane : lane;
+                float const coef = is_short ? lh_regcoef_s[lane / 3] : lh_regcoef_l[lane];
+                float const t = L.ratio_thm[gr][chn][idx];
+                double  term = 0.0;
+                if (t > 0.0f) {
+                    float const x = t * st->masking_lower;
+                    float const e = L.ratio_en[gr][chn][idx];
+                    if (e > x) {
+                        if (e > x * 1e10f)
+                            term = coef * (10.0f * 2.30258509299404568402);
+                        else
+                            term = coef * (lh_fast_log2(T->log_table, e / x) * LH_LOG2_OVER_LOG10);
+                    }
+                }
+                tmp[lane] = term;
+            }
+            LH_WAVE_SYNC_MEM();
+            if (lane == 0) {
+                float   pe = is_short ? 1236.28f / 4 : 1124.23f / 4;
+                for (int i = 0; i < nterms; i++)
+                    pe = (float) (pe + tmp[i]);
+                L.pe[gr][chn] = pe;
+                st->last_attacks[chn] = L.ns_attacks[chn][2];
+            }
         }
     }
     LH_SYNC_WG();
