@@ -55,7 +55,8 @@ LH_DEVCONST float lh_regcoef_l[21] = {
 
 /* reference psymodel.c:294-341 */
 LH_DEVFN float
-lh_mask_add(const LhTables * T, float m1, float m2, int b, int delta)
+lh_mask_add(const float *log_table, const float *table2, float ma_max_i1, float ma_max_i2, float m1, float m2,
+            int b, int delta)
 {
     float   ratio;
     if (m1 < 0)
@@ -73,14 +74,14 @@ lh_mask_add(const LhTables * T, float m1, float m2, int b, int delta)
     if (b < 0)
         b = -b;
     if (b <= delta) {
-        if (ratio >= T->ma_max_i1)
+        if (ratio >= ma_max_i1)
             return m1 + m2;
         else {
-            int     i = (int) (lh_fast_log2(T->log_table, ratio) * (LH_LOG2_OVER_LOG10 * (16.0f)));
-            return (m1 + m2) * lh_mask_table2[i];
+            int     i = (int) (lh_fast_log2(log_table, ratio) * (LH_LOG2_OVER_LOG10 * (16.0f)));
+            return (m1 + m2) * table2[i];
         }
     }
-    if (ratio < T->ma_max_i2)
+    if (ratio < ma_max_i2)
         return m1 + m2;
     if (m1 < m2)
         m1 = m2;
@@ -415,8 +416,13 @@ lh_mask_index(LhPsyBand const *gd, float const *mx, float const *avg, int b)
  * short-block variant (:1031-1131).  energy = power spectrum in LDS. */
 LH_DEVFN void
 lh_compute_masking(const LhCtx & c, int chn, int is_long, const float *energy, float *eb,
-                   float *thr, float *smax, float *savg, int *sidx, const uint16_t *pstart)
+                   float *thr, float *smax, float *savg, int *sidx, const uint16_t *pstart,
+                   const float *s3, const float *log_table, const float *psy_tab, const float *table2)
 {
+    /* s3 / log_table / psy_tab / table2: the spreading matrix and the small tables of the
+     * masking addition, either in HBM (LhTables, constants) or staged in LDS by the caller: the
+     * spreading loop makes three to four dependent look-ups in them per step */
+    float const ma_max_i1 = c.T->ma_max_i1, ma_max_i2 = c.T->ma_max_i2;
     LhPsyBand const *gd = is_long ? &c.T->psy_l : &c.T->psy_s;
     int const b = c.lane;
     int const np = gd->npart;
@@ -448,18 +454,18 @@ lh_compute_masking(const LhCtx & c, int chn, int is_long, const float *energy, f
         int     dd, dd_n = 1;
         float   th;
         dd = sidx[kk];
-        ecb = gd->s3[k] * eb[kk] * lh_psy_tab[sidx[kk]];
+        ecb = s3[k] * eb[kk] * psy_tab[sidx[kk]];
         ++k, ++kk;
         while (kk <= last) {
             dd += sidx[kk];
             dd_n += 1;
-            x = gd->s3[k] * eb[kk] * lh_psy_tab[sidx[kk]];
-            t = lh_mask_add(c.T, ecb, x, kk - b, delta);
+            x = s3[k] * eb[kk] * psy_tab[sidx[kk]];
+            t = lh_mask_add(log_table, table2, ma_max_i1, ma_max_i2, ecb, x, kk - b, delta);
             ecb = t;
             ++k, ++kk;
         }
         dd = (1 + 2 * dd) / (2 * dd_n);
-        avg_mask = lh_psy_tab[dd] * 0.5f;
+        avg_mask = psy_tab[dd] * 0.5f;
         ecb *= avg_mask;
         if (is_long) {
             int const bt_old = c.st->blocktype_old[chn & 1];
@@ -780,7 +786,23 @@ lh_psy_granule(int gr)
         if (chn < n_chn_psy)
             lh_fft_energy(c, chn, P.wsamp[0], P.wsamp[1], LH_BLKSIZE, P.b.energy[chn]);
     }
-    LH_WAVE_SYNC_MEM();
+    /* The FHT buffers are free until the short FFTs: stage the long-block spreading matrix and
+     * the tables of the masking addition there (the spreading loop of stage 6 makes three to
+     * four dependent look-ups per step; from HBM each costs a few hundred cycles). */
+    float  *stg_s3 = &P.wsamp[0][0];                    /* [LH_S3_MAX] */
+    float  *stg_log = stg_s3 + LH_S3_MAX;               /* [513] */
+    float  *stg_psy = stg_log + 516;                    /* [9] */
+    float  *stg_t2 = stg_psy + 12;                      /* [10] */
+    LH_SYNC_WG();
+    for (int i = c.tid; i < T->psy_l.s3_count; i += LH_NT)
+        stg_s3[i] = T->psy_l.s3[i];
+    for (int i = c.tid; i < 513; i += LH_NT)
+        stg_log[i] = T->log_table[i];
+    if (c.tid < 9)
+        stg_psy[c.tid] = lh_psy_tab[c.tid];
+    if (c.tid < 10)
+        stg_t2[c.tid] = lh_mask_table2[c.tid];
+    LH_SYNC_WG();
     LH_PA(31, t_psy0);
     /* (5) serial sums: total energy (bins 11..512) and loudness (reference psymodel.c:213-226,
      * 690-696): lane 0/1 = tot_ener of chn w / w+2, lane 2 = loudness of channel w */
@@ -829,7 +851,7 @@ lh_psy_granule(int gr)
         int const chn = w + 2 * pass;
         if (chn < n_chn_psy)
             lh_compute_masking(c, chn, 1, P.b.energy[chn], &P.eb[chn * 64], &P.thr[chn * 64],
-                               P.smax[w], P.savg[w], P.sidx[w], L.pstart_l);
+                               P.smax[w], P.savg[w], P.sidx[w], L.pstart_l, stg_s3, stg_log, stg_psy, stg_t2);
     }
     LH_SYNC_WG();
     if (cfg->mode == LH_MODE_JOINT_STEREO && (L.uselongblock[0] + L.uselongblock[1]) == 2) {
@@ -868,7 +890,8 @@ lh_psy_granule(int gr)
                               &P.wsamp[1][sblock * LH_BLKSIZE_S], LH_BLKSIZE_S, P.b.energy[chn]);
                 LH_WAVE_SYNC_MEM();
                 lh_compute_masking(c, chn, 0, P.b.energy[chn], &P.eb[chn * 64], &P.thr[chn * 64],
-                                   P.smax[w], P.savg[w], P.sidx[w], L.pstart_s);
+                                   P.smax[w], P.savg[w], P.sidx[w], L.pstart_s, T->psy_s.s3, T->log_table, lh_psy_tab,
+                                   lh_mask_table2);
             }
         }
         LH_SYNC_WG();

@@ -18,9 +18,9 @@ NAMES = ["frame total", "psy (2 granules)", "polyphase+mdct", "quant total (2 gr
          "  cn: after phase B", "  cn: after per-band log", "  cn: total", "  cb: loads+band decisions",
          "  nq: count1/big_values/regions", "  nq: + quads", "  nq: + region maxima", "  nq: + table look-ups",
          "  nq: + sums", "t: window staged (+ barrier skew)", "t: psy + ATH adjust done",
-         "t: mdct, qtabs, M/S, PE FIR done", "t: granule loop done", "  psy: attack detection", "  psy: + long FFT",
-         "  psy: + power spectra", "  psy: + energy/loudness sums", "  psy: + long masking (+MS)",
-         "  psy: + partition->sfb", "  psy: + short blocks", "  psy: + pre-echo", "  psy: + block type, PE",
+         "t: mdct, qtabs, M/S, PE FIR done", "t: granule loop done", "-", "  psy: attack detection", "  psy: + long FFT",
+         "  psy: + power spectra, table staging", "  psy: + energy/loudness sums", "  psy: + long masking (+MS)",
+         "  psy: + partition->sfb", "  psy: + short blocks", "  psy: + pre-echo",
          "  bal: amp_scalefac_bands", "  bal: + loop_break", "  bal: + scale_bitcount", "  bss: zero bands",
          "  bss: + scale/preflag", "  bss: + scfsi", "  bss: + scale_bitcount"]
 
