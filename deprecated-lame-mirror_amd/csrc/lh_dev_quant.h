@@ -1466,6 +1466,32 @@ lh_scale_bands(const LhCtx & c, LhChanLds & Q, LhGrR & g)
     LH_WAVE_SYNC();
 }
 
+/* the same when every amplified band gets the same factor: the set of bands travels as a
+ * ballot mask in scalar registers instead of per-band LDS arrays (amp_scalefac_bands) */
+LH_DEVFN void
+lh_scale_bands_mask(const LhCtx & c, LhChanLds & Q, LhGrR & g, uint64_t bands, float factor)
+{
+    unsigned mx = lh_f32_as_u32(g.xrpow_max);
+    int     sb[9];
+    float   xv[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        sb[k] = Q.sfb_of_line[c.lane + 64 * k];
+        xv[k] = Q.xrpow[c.lane + 64 * k];
+    }
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        int const on = (int) ((bands >> sb[k]) & 1);
+        float const v = on ? xv[k] * factor : xv[k];
+        unsigned const u = lh_f32_as_u32(v);
+        Q.xrpow[c.lane + 64 * k] = v;
+        mx = (on && u > mx) ? u : mx;
+    }
+    mx = lh_wave_max_u32(mx);
+    g.xrpow_max = lh_u32_as_f32(mx);
+    LH_WAVE_SYNC();
+}
+
 /* reference quantize.c:720-796; band s on lane s, the serial walk with its early
  * returns is replayed on ballot masks */
 LH_DEVFN void
@@ -1528,7 +1554,7 @@ lh_amp_scalefac_bands(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g,
         }
     }
     LH_WAVE_SYNC();
-    if (s <= LH_SFBMAX) {
+    {
         int     amplify = 0;
         if (s < R.sfbmax && s <= last_visited && ((cand >> s) & 1)) {
             amplify = 1;
@@ -1539,10 +1565,8 @@ lh_amp_scalefac_bands(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g,
             if (amplify)
                 Q.sf[which][s]++;
         }
-        Q.sfb_mode[s] = amplify;
-        Q.sfb_f[s] = ifqstep34;
+        lh_scale_bands_mask(c, Q, g, lh_ballot(amplify), ifqstep34);
     }
-    lh_scale_bands(c, Q, g);
 }
 
 /* reference quantize.c:808-833 */
