@@ -246,3 +246,33 @@ def test_pack_all_threads_equals_per_stream_pack():
         assert b.pack_all(nt) == single
     b.close()
     enc.close()
+
+
+@pytest.mark.parametrize("pattern", [[50000, 1, 1151, 7, 30000], [0, 3, 0, 20000], [1152] * 3 + [9999]])
+def test_odd_call_patterns_match_reference_call_by_call(reference, pattern):
+    """Chunk sizes a frontend would not use (one huge call, zero-length calls, single samples),
+    then flush twice: every call must return the reference's bytes for the same call."""
+    sr, br = 44100, 128
+    total = sum(pattern)
+    pcm = helpers.synth_stream(4711 + total, max(total, 1), sr, 1.0 / 8)
+    lib = reference.lib
+    lib.refh_open.restype = C.c_void_p
+    h = C.c_void_p(lib.refh_open(sr, br, -1, -1))
+    enc = lamehip.Encoder(sr, br)
+    buf = C.create_string_buffer(200000)
+    pos = 0
+    for n in pattern:
+        l = np.ascontiguousarray(pcm[0][pos:pos + n])
+        r = np.ascontiguousarray(pcm[1][pos:pos + n])
+        k = lib.refh_encode(h, l.ctypes.data_as(C.c_void_p), r.ctypes.data_as(C.c_void_p), n, buf, len(buf))
+        assert k >= 0
+        want = buf.raw[:k]
+        got = enc.encode(l, r) if n > 0 else b""
+        assert got == want, ("call with %d samples at %d" % (n, pos))
+        pos += n
+    k = lib.refh_flush(h, buf, len(buf))
+    assert enc.flush() == buf.raw[:k]
+    k = lib.refh_flush(h, buf, len(buf))
+    assert k == 0 and enc.flush() == b""          # a second flush has nothing left (reference lame.c:2071)
+    lib.refh_close(h)
+    enc.close()
