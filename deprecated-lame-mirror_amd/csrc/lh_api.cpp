@@ -202,6 +202,26 @@ lame_get_VBR(const lame_t g)
 }
 
 extern "C" int
+lame_set_VBR_q(lame_t g, int q)
+{
+    int     ret = 0;
+    if (!valid(g))
+        return -1;
+    if (q < 0) {                /* reference set_get.c:1127-1141: clamps and reports -1 */
+        ret = -1;
+        q = 0;
+    }
+    if (q > 9) {
+        ret = -1;
+        q = 9;
+    }
+    g->p.vbr_q = q;
+    return ret;
+}
+
+GETTER(lame_get_VBR_q, g->inited ? g->cfg.vbr_q : g->p.vbr_q, int)
+
+extern "C" int
 lame_set_findReplayGain(lame_t g, int v)
 {
     (void) v;
@@ -225,8 +245,10 @@ lame_init_params(lame_t g)
         snprintf(g_err, sizeof(g_err), "resampling is outside the accelerated path");
         return -1;
     }
+    g->p.samplerate_out = g->out_samplerate;
     if (lh_config_resolve(&g->p, &g->cfg, &aux) != 0) {
-        snprintf(g_err, sizeof(g_err), "unsupported settings for the MI355X path (need MPEG-1, 2 channels, CBR)");
+        snprintf(g_err, sizeof(g_err),
+                 "unsupported settings for the MI355X path (need MPEG-1 rates, 2 channels, CBR or vbr_mtrh, no resampling)");
         return -1;
     }
     g->tab = (LhTables *) malloc(sizeof(LhTables));
@@ -249,6 +271,13 @@ lame_init_params(lame_t g)
         snprintf(g_err, sizeof(g_err), "no HIP device: liblamehip has no CPU encode path");
         g->have_device = 0;
         return LAMEHIP_ERR_NODEVICE;
+    }
+    if (g->cfg.vbr != 0) {
+        /* constants and tables are resolved (lamehip_get_config / _tables work), but the VBR
+         * iteration loop has no device kernels yet: refuse rather than run the CBR loop */
+        snprintf(g_err, sizeof(g_err), "vbr_mtrh: the device iteration loop is not built yet");
+        g->have_device = 0;
+        return -1;
     }
     {
         int     rc = g->dc.upload(g->cfg, *g->tab);

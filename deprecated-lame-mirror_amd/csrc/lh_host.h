@@ -17,13 +17,19 @@ typedef struct LhUserParams {
     int     brate;               /* kbps */
     int     mode;                /* -1 = not set (joint stereo), else LH_MODE_* */
     int     quality;             /* -1 = default (3) */
-    int     vbr;                 /* 0 = CBR */
+    int     vbr;                 /* 0 = CBR, 1 / 4 = vbr_mt / vbr_mtrh (the same loop in the reference) */
+    int     vbr_q;               /* VBR quality 0..9 (lame_set_VBR_q), default 4 */
+    int     samplerate_out;      /* 0 = let the encoder choose (must come out equal to samplerate) */
 } LhUserParams;
 
 /* values that only feed table generation */
 typedef struct LhInitAux {
     float   lowpass1, lowpass2;
     float   attackthre, attackthre_s;
+    int     vbr_q;               /* VBR_q / VBR_q_frac as psymodel_init sees them (4 / 0 for CBR) */
+    float   vbr_q_frac;
+    float   athaa_sensitivity;
+    float   adjust_sfb21_db;     /* exp_nspsytune bits 20..25, reference lame.c:1196-1203 */
 } LhInitAux;
 
 void    lh_params_default(LhUserParams * p);

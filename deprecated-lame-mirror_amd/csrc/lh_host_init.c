@@ -114,6 +114,8 @@ lh_params_default(LhUserParams * p)
     p->mode = -1;
     p->quality = -1;
     p->vbr = 0;
+    p->vbr_q = 4;               /* reference lame.c:2360 */
+    p->samplerate_out = 0;
 }
 
 /* quality -> algorithm switches (reference lame.c:362-477) */
@@ -142,6 +144,8 @@ apply_quality(LhConfig * c, int noise_shaping_in, int *attack_unused)
         c->noise_shaping_stop = 0;
         c->use_best_huffman = 0;
         c->full_outer_loop = 0;
+        if (c->vbr == 1 || c->vbr == 4)
+            c->full_outer_loop = -1;    /* selects the guessed scalefactor search, reference lame.c:387 */
         break;
     case 6:
     case 5:
@@ -214,6 +218,208 @@ apply_quality(LhConfig * c, int noise_shaping_in, int *attack_unused)
     return 0;
 }
 
+
+/* VBR (vbr_mt / vbr_mtrh) preset rows, reference presets.c:106-126 (vbr_mt_psy_switch_map) */
+typedef struct {
+    int     expY;
+    float   st_lrm, st_s, masking_adj, masking_adj_short, ath_lower, ath_curve, ath_sensitivity, interch;
+    int     safejoint, sfb21mod;
+    float   msfix, minval, ath_fixpoint;
+} LhVbrPreset;
+
+static const LhVbrPreset vbr_mt_map[11] = {
+    {0, 4.20, 25.0, -6.8, -6.8, 7.1, 1, 0, 0, 2, 31, 1.000, 5, 100},
+    {0, 4.20, 25.0, -4.8, -4.8, 5.4, 1.4, -1, 0, 2, 27, 1.122, 5, 98},
+    {0, 4.20, 25.0, -2.6, -2.6, 3.7, 2.0, -3, 0, 2, 23, 1.288, 5, 97},
+    {1, 4.20, 25.0, -1.6, -1.6, 2.0, 2.0, -5, 0, 2, 18, 1.479, 5, 96},
+    {1, 4.20, 25.0, -0.0, -0.0, 0.0, 2.0, -8, 0, 2, 12, 1.698, 5, 95},
+    {1, 4.20, 25.0, 1.3, 1.3, -6, 3.5, -11, 0, 2, 8, 1.950, 5, 94.2},
+    {1, 4.50, 100.0, 2.2, 2.3, -12.0, 6.0, -14, 0, 2, 4, 2.239, 3, 93.9},
+    {1, 4.80, 200.0, 2.7, 2.7, -18.0, 9.0, -17, 0, 2, 0, 2.570, 1, 93.6},
+    {1, 5.30, 300.0, 2.8, 2.8, -21.0, 10.0, -23, 0.0002, 0, 0, 2.951, 0, 93.3},
+    {1, 6.60, 300.0, 2.8, 2.8, -23.0, 11.0, -25, 0.0006, 0, 0, 3.388, 0, 93.3},
+    {1, 25.00, 300.0, 2.8, 2.8, -25.0, 12.0, -27, 0.0025, 0, 0, 3.500, 0, 93.3}
+};
+
+/* output rate the reference would pick for this lowpass (reference lame.c:273-345);
+ * MPEG-1 rates only: anything else means "resample", which this path refuses */
+static int
+suggested_samplerate(int lp, int samplerate_in)
+{
+    int     suggested = (samplerate_in >= 48000) ? 48000 : (samplerate_in >= 44100) ? 44100 : 32000;
+    if (lp == -1)
+        return suggested;
+    if (lp <= 15960)
+        suggested = 44100;
+    if (lp <= 15250)
+        suggested = 32000;
+    if (lp <= 11220)
+        suggested = 24000;
+    if (samplerate_in < suggested)
+        suggested = samplerate_in;      /* reference keeps a valid rate >= input */
+    return suggested;
+}
+
+static void
+lowpass_edges(LhConfig * c, LhInitAux * aux)
+{
+    int const lp = c->lowpassfreq;
+    aux->lowpass1 = 0;
+    aux->lowpass2 = 0;
+    if (lp > 0 && lp < c->samplerate / 2) {
+        aux->lowpass2 = 2. * lp;
+        aux->lowpass1 = (1 - 0.00) * 2. * lp;
+        aux->lowpass1 /= c->samplerate;
+        aux->lowpass2 /= c->samplerate;
+    }
+}
+
+/* vbr_mt / vbr_mtrh settings (reference lame.c:661-692, 730-744, 770-776, 972-1004, 1064-1094;
+ * presets.c:146-213 apply_vbr_preset with every option still at its default) */
+static int
+config_resolve_vbr(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
+{
+    static const int lp_by_q[11] = { 24000, 19500, 18500, 18000, 17500, 17000, 16500, 15600, 15200, 7230, 3950 };
+    int     vbr_q = p->vbr_q, samplerate_out = p->samplerate_out, lowpassfreq = 0, i;
+    float   vbr_q_frac = 0;
+    LhVbrPreset P, Q;
+    float   x;
+    int     nspsytune = 1;
+
+    if (vbr_q < 0)
+        vbr_q = 0;
+    if (vbr_q > 9)
+        vbr_q = 9;
+    if (samplerate_out == 0) {
+        /* VBR scale -> internal quality + output rate (reference lame.c:661-692); rows 2.. of its table */
+        static const struct { int sr_a; float qa, qb, ta, tb; } m[7] = {
+            {32000, 6.5, 8.0, 5.2, 6.5}, {24000, 8.0, 8.5, 5.2, 6.0}, {22050, 8.5, 9.01, 5.2, 6.5},
+            {16000, 9.01, 9.4, 4.9, 6.5}, {12000, 9.4, 9.6, 4.5, 6.0}, {11025, 9.6, 9.9, 5.1, 6.5},
+            {8000, 9.9, 10., 4.9, 6.5}
+        };
+        float const qval = vbr_q + vbr_q_frac;
+        for (i = 0; i < 7; ++i) {
+            if (p->samplerate == m[i].sr_a) {
+                if (qval < m[i].qa) {
+                    double  d = qval / m[i].qa;
+                    d = d * m[i].ta;
+                    vbr_q = (int) d;
+                    vbr_q_frac = d - vbr_q;
+                }
+            }
+            if (p->samplerate >= m[i].sr_a) {
+                if (m[i].qa <= qval && qval < m[i].qb) {
+                    float const q_ = m[i].qb - m[i].qa;
+                    float const t_ = m[i].tb - m[i].ta;
+                    double  d = m[i].ta + t_ * (qval - m[i].qa) / q_;
+                    vbr_q = (int) d;
+                    vbr_q_frac = d - vbr_q;
+                    samplerate_out = m[i].sr_a;
+                    if (lowpassfreq == 0)
+                        lowpassfreq = -1;
+                    break;
+                }
+            }
+        }
+    }
+    if (lowpassfreq == 0) {
+        double  a = lp_by_q[vbr_q], b = lp_by_q[vbr_q + 1], mm = vbr_q_frac;
+        double  lowpass = a + mm * (b - a);
+        lowpassfreq = lowpass;
+    }
+    if (samplerate_out == 0) {
+        if (2 * lowpassfreq > p->samplerate)
+            lowpassfreq = p->samplerate / 2;
+        samplerate_out = suggested_samplerate(lowpassfreq, p->samplerate);
+    }
+    if (samplerate_out != p->samplerate)
+        return -1;              /* the reference would resample: outside this path */
+    lowpassfreq = (24000 < lowpassfreq) ? 24000 : lowpassfreq;
+    lowpassfreq = (samplerate_out / 2 < lowpassfreq) ? samplerate_out / 2 : lowpassfreq;
+    c->lowpassfreq = lowpassfreq;
+    lowpass_edges(c, aux);
+
+    c->bitrate_index = 1;
+    c->avg_bitrate = 0;         /* gfp->brate stays 0 in VBR mode */
+    c->sideinfo_len = 4 + 32;
+    c->buffer_constraint = 7680 * (c->version + 1);     /* strict_ISO = MDB_MAXIMUM */
+    c->use_temporal_masking = 0;
+
+    /* preset row, interpolated by the fractional quality (reference presets.c:146-171) */
+    P = vbr_mt_map[vbr_q];
+    Q = vbr_mt_map[vbr_q + 1];
+    x = vbr_q_frac;
+#define LERP(f) (P.f = P.f + x * (Q.f - P.f))
+    LERP(st_lrm);
+    LERP(st_s);
+    LERP(masking_adj);
+    LERP(masking_adj_short);
+    LERP(ath_lower);
+    LERP(ath_curve);
+    LERP(ath_sensitivity);
+    LERP(interch);
+    LERP(sfb21mod);
+    LERP(msfix);
+    LERP(minval);
+    LERP(ath_fixpoint);
+#undef LERP
+    c->quant_comp = 9;
+    c->quant_comp_short = 9;
+    aux->attackthre = P.st_lrm;
+    aux->attackthre_s = P.st_s;
+    c->mask_adjust = P.masking_adj;
+    c->mask_adjust_short = P.masking_adj_short;
+    c->ATHtype = 5;
+    c->ATH_offset_db = 0 - P.ath_lower;
+    c->ATH_offset_factor = powf(10.f, c->ATH_offset_db * 0.1f);
+    c->ATHcurve = P.ath_curve;
+    aux->athaa_sensitivity = P.ath_sensitivity;
+    c->interChRatio = (P.interch > 0) ? P.interch : 0;
+    if (P.safejoint > 0)
+        nspsytune |= 2;
+    if (P.sfb21mod > 0)
+        nspsytune |= P.sfb21mod << 20;
+    c->msfix = P.msfix;
+    c->minval = P.minval;
+    {
+        double const y = 10.f * log10(1.0);     /* scale is 1 */
+        c->ATHfixpoint = P.ath_fixpoint - y;
+    }
+    c->use_safe_joint_stereo = nspsytune & 2;
+    {
+        float   db = (nspsytune >> 20) & 63;
+        if (db >= 32.f)
+            db -= 64.f;
+        db *= 0.25f;
+        aux->adjust_sfb21_db = db + 0.f;        /* + adjust_treble_db */
+    }
+    {
+        float   db = c->mask_adjust - 0;
+        c->masking_lower_long = pow(10.0, db * 0.1);
+        db = c->mask_adjust_short - 0;
+        c->masking_lower_short = pow(10.0, db * 0.1);
+    }
+    /* quality levels of the new VBR code (reference lame.c:985-992) */
+    c->quality = (p->quality < 0) ? 3 : p->quality;
+    if (c->quality < 5)
+        c->quality = 0;
+    if (c->quality > 7)
+        c->quality = 7;
+    apply_quality(c, 0, 0);
+    c->sfb21_extra = P.expY ? 0 : (samplerate_out > 44000);
+    c->short_blocks = 1;
+    c->pcm_scale = 1.0f;
+    c->disable_reservoir = 0;
+    c->frac_SpF = 0;
+    c->vbr_q = vbr_q;
+    aux->vbr_q = vbr_q;
+    aux->vbr_q_frac = vbr_q_frac;
+    c->vbr_min_bitrate_index = 1;
+    c->vbr_max_bitrate_index = 14;
+    c->enforce_min_bitrate = 0;
+    return 0;
+}
+
 int
 lh_config_resolve(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
 {
@@ -225,8 +431,10 @@ lh_config_resolve(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
     memset(aux, 0, sizeof(*aux));
     if (p->channels != 2)
         return -1;              /* mono framing is outside this path */
-    if (p->vbr != 0)
-        return -1;              /* VBR iteration loops: not built yet */
+    if (p->vbr != 0 && p->vbr != 1 && p->vbr != 4)
+        return -1;              /* vbr_rh / ABR loops are outside this path */
+    if (p->samplerate_out != 0 && p->samplerate_out != p->samplerate)
+        return -1;              /* resampling is outside this path */
     switch (p->samplerate) {
     case 44100:
         c->samplerate_index = 0;
@@ -244,12 +452,19 @@ lh_config_resolve(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
     c->samplerate = p->samplerate;
     c->mode_gr = 2;
     c->channels = 2;
-    c->vbr = 0;
+    c->vbr = p->vbr;
     c->mode = (p->mode < 0) ? LH_MODE_JOINT_STEREO : p->mode;
     if (c->mode != LH_MODE_JOINT_STEREO && c->mode != LH_MODE_STEREO)
         return -1;
     c->force_ms = 0;
     c->original = 1;
+    aux->vbr_q = 4;
+    aux->vbr_q_frac = 0;
+    aux->athaa_sensitivity = 0;
+    aux->adjust_sfb21_db = 0;
+    c->vbr_q = 4;
+    if (c->vbr != 0)
+        return config_resolve_vbr(p, c, aux);
 
     /* bitrate (reference lame.c:904-915) */
     c->avg_bitrate = find_nearest_bitrate_mpeg1(p->brate > 0 ? p->brate : 128);
@@ -494,12 +709,13 @@ build_bv_scf(LhTables * t)
 
 /* reference quantize_pvt.c:336-417 */
 static void
-iteration_tables(const LhConfig * c, LhTables * t)
+iteration_tables(const LhConfig * c, const LhInitAux * aux, LhTables * t)
 {
     static float const payload_long[4] = { -0.500f, -0.250f, -0.025f, +0.500f };
     static float const payload_short[4] = { -2.000f, -1.000f, -0.050f, +0.500f };
-    /* adjust_{bass,alto,treble,sfb21}_db are all 0 on this path (exp_nspsytune bits 2.. are clear) */
-    float const adj_bass = 0.f, adj_alto = 0.f, adj_treble = 0.f, adj_sfb21 = 0.f + adj_treble;
+    /* adjust_{bass,alto,treble}_db are 0 on this path (exp_nspsytune bits 2..19 are clear); the VBR
+     * presets set the sfb21 bits */
+    float const adj_bass = 0.f, adj_alto = 0.f, adj_treble = 0.f, adj_sfb21 = aux->adjust_sfb21_db;
     float   adjust, db;
     int     i;
 
@@ -820,7 +1036,7 @@ psymodel_tables(LhConfig * c, const LhInitAux * aux, LhTables * t)
     }
     t->ath_decay = pow(10., -12. / 10. * (576. * c->mode_gr / sfreq));
     t->ath_use_adjust = 3;
-    t->aa_sensitivity_p = pow(10.0, 0.0 / -10.0);
+    t->aa_sensitivity_p = pow(10.0, aux->athaa_sensitivity / -10.0);
     {
         float   freq;
         float const freq_inc = (float) c->samplerate / (float) (LH_BLKSIZE);
@@ -846,11 +1062,14 @@ psymodel_tables(LhConfig * c, const LhInitAux * aux, LhTables * t)
         t->attack_threshold[3] = y;
     }
     {
-        /* VBR_q stays at its default 4 on the CBR path: sk[4] + 0 * (sk[4] - sk[5]) */
+        /* VBR_q stays at its default 4 on the CBR path */
         float   sk_s, sk_l;
         static float const sk[] =
             { -7.4, -7.4, -7.4, -9.5, -7.4, -6.1, -5.5, -4.7, -4.7, -4.7, -4.7 };
-        sk_l = sk_s = sk[4] + 0.f * (sk[4] - sk[4 + 1]);
+        if (aux->vbr_q < 4)
+            sk_l = sk_s = sk[0];
+        else
+            sk_l = sk_s = sk[aux->vbr_q] + aux->vbr_q_frac * (sk[aux->vbr_q] - sk[aux->vbr_q + 1]);
         b = 0;
         for (; b < gs->npart; b++) {
             float   m = (float) (gs->npart - b) / gs->npart;
@@ -995,7 +1214,7 @@ lh_tables_build(LhConfig * c, const LhInitAux * aux, LhTables * t)
     t->psfb12[LH_PSFB12] = 192;
 
     ppflt_tables(aux, t);
-    iteration_tables(c, t);
+    iteration_tables(c, aux, t);
     if (psymodel_tables(c, aux, t))
         return -1;
     fft_tables(t);

@@ -75,12 +75,19 @@ def last_error():
 class Encoder:
     """One stream behind the lame.h call sequence."""
 
-    def __init__(self, samplerate=44100, brate=128, mode=None, quality=None, require_device=True, write_tag=False):
+    def __init__(self, samplerate=44100, brate=128, mode=None, quality=None, require_device=True, write_tag=False,
+                 vbr_q=None, out_samplerate=0):
         self.lib = load_library()
         self.h = C.c_void_p(self.lib.lame_init())
         self.lib.lame_set_in_samplerate(self.h, samplerate)
+        if out_samplerate:
+            self.lib.lame_set_out_samplerate(self.h, out_samplerate)
         self.lib.lame_set_num_channels(self.h, 2)
-        self.lib.lame_set_brate(self.h, brate)
+        if vbr_q is None:
+            self.lib.lame_set_brate(self.h, brate)
+        else:                       # vbr_mtrh at quality vbr_q (the reference's -V n)
+            self.lib.lame_set_VBR(self.h, 4)
+            self.lib.lame_set_VBR_q(self.h, vbr_q)
         self.lib.lame_set_bWriteVbrTag(self.h, 1 if write_tag else 0)
         if mode is not None:
             self.lib.lame_set_mode(self.h, mode)

@@ -18,7 +18,9 @@ class LhConfig(C.Structure):
         ("ATH_offset_factor", C.c_float), ("ATHcurve", C.c_float), ("ATHtype", C.c_int),
         ("minval", C.c_float), ("mask_adjust", C.c_float), ("mask_adjust_short", C.c_float),
         ("masking_lower_long", C.c_float), ("masking_lower_short", C.c_float),
-        ("pcm_scale", C.c_float), ("interChRatio", C.c_float)]
+        ("pcm_scale", C.c_float), ("interChRatio", C.c_float),
+        ("vbr_q", C.c_int), ("vbr_min_bitrate_index", C.c_int), ("vbr_max_bitrate_index", C.c_int),
+        ("enforce_min_bitrate", C.c_int)]
 
 
 class LhPsyBand(C.Structure):
@@ -77,11 +79,13 @@ class LhFrameOut(C.Structure):
 
 
 class LhUserParams(C.Structure):
-    _fields_ = [(n, C.c_int) for n in "samplerate channels brate mode quality vbr".split()]
+    _fields_ = [(n, C.c_int) for n in "samplerate channels brate mode quality vbr vbr_q samplerate_out".split()]
 
 
 class LhInitAux(C.Structure):
-    _fields_ = [(n, C.c_float) for n in "lowpass1 lowpass2 attackthre attackthre_s".split()]
+    _fields_ = [(n, C.c_float) for n in "lowpass1 lowpass2 attackthre attackthre_s".split()] + [
+        ("vbr_q", C.c_int), ("vbr_q_frac", C.c_float), ("athaa_sensitivity", C.c_float),
+        ("adjust_sfb21_db", C.c_float)]
 
 
 def struct_diff(a, b, prefix="", skip=()):

@@ -58,6 +58,8 @@ int     lame_set_quality(lame_t, int);                               /* lame.h:2
 int     lame_get_quality(const lame_t);                              /* lame.h:264 */
 int     lame_set_VBR(lame_t, vbr_mode);                              /* lame.h:432 (only vbr_off is built) */
 vbr_mode lame_get_VBR(const lame_t);                                 /* lame.h:433 */
+int     lame_set_VBR_q(lame_t, int);                                 /* lame.h:436 (0 best .. 9; default 4) */
+int     lame_get_VBR_q(const lame_t);                                /* lame.h:437 */
 int     lame_set_bWriteVbrTag(lame_t, int);                          /* lame.h:240 (default 1, as in the reference) */
 int     lame_get_bWriteVbrTag(const lame_t);                         /* lame.h:241 */
 int     lame_set_findReplayGain(lame_t, int);                        /* lame.h:296 (accepted, ignored) */

@@ -72,7 +72,7 @@ typedef struct LhConfig {
     int     mode;                 /* LH_MODE_* */
     int     mode_gr;              /* 2 */
     int     channels;             /* 2 */
-    int     vbr;                  /* 0 = vbr_off (CBR) */
+    int     vbr;                  /* 0 = vbr_off (CBR), 1 / 4 = vbr_mt / vbr_mtrh */
     int     quality;
     int     noise_shaping;
     int     noise_shaping_amp;
@@ -108,6 +108,11 @@ typedef struct LhConfig {
     float   masking_lower_short;
     float   pcm_scale;            /* pcm_transform diagonal, reference lame.c:1209-1234 */
     float   interChRatio;
+    /* VBR (vbr_mt / vbr_mtrh), reference util.h SessionConfig_t */
+    int     vbr_q;
+    int     vbr_min_bitrate_index;
+    int     vbr_max_bitrate_index;
+    int     enforce_min_bitrate;
 } LhConfig;
 
 /* partition -> scalefactor-band mapping, PsyConst_CB2SB_t (reference util.h:188-203) */

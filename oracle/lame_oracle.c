@@ -5,4 +5,5 @@
 #include "orc_psy.c"
 #include "orc_mdct.c"
 #include "orc_quant.c"
+#include "orc_vbr.c"
 #include "orc_frame.c"

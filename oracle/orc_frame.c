@@ -257,12 +257,15 @@ orc_encode_frame(OrcStream * S, const float *inbuf_l, const float *inbuf_r, LhFr
                 pe_use[gr][ch] *= f;
     }
     mdb_header = S->main_data_begin;
-    orc_cbr_iteration_loop(S, pe_use, ms_ener_ratio, masking);
+    if (cfg->vbr)
+        orc_vbr_new_iteration_loop(S, pe_use, masking);
+    else
+        orc_cbr_iteration_loop(S, pe_use, ms_ener_ratio, masking);
     mdb_header = S->main_data_begin;    /* after ResvFrameEnd: the value the header carries */
     {
         /* main_data_begin bookkeeping of format_bitstream, reference bitstream.c:917-935 */
         int     bits = 8 * cfg->sideinfo_len, frame_bits;
-        int     bit_rate = cfg->avg_bitrate;
+        int     bit_rate = lh_bitrate_mpeg1[S->bitrate_index];
         for (gr = 0; gr < 2; gr++)
             for (ch = 0; ch < 2; ch++)
                 bits += S->tt[gr][ch].part2_3_length + S->tt[gr][ch].part2_length;

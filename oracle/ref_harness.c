@@ -91,6 +91,34 @@ refh_open_tag(int samplerate, int brate, int mode, int quality)
     return h;
 }
 
+/* vbr_mtrh at quality vbr_q (0..9); out_samplerate 0 lets the reference choose; tag as above */
+void   *
+refh_open_vbr(int samplerate, int vbr_q, int mode, int quality, int out_samplerate, int tag)
+{
+    RefH   *h = (RefH *) calloc(1, sizeof(RefH));
+    h->gfp = lame_init();
+    lame_set_errorf(h->gfp, quiet);
+    lame_set_debugf(h->gfp, quiet);
+    lame_set_msgf(h->gfp, quiet);
+    lame_set_in_samplerate(h->gfp, samplerate);
+    if (out_samplerate > 0)
+        lame_set_out_samplerate(h->gfp, out_samplerate);
+    lame_set_num_channels(h->gfp, 2);
+    lame_set_VBR(h->gfp, vbr_mtrh);
+    lame_set_VBR_q(h->gfp, vbr_q);
+    lame_set_bWriteVbrTag(h->gfp, tag);
+    if (mode >= 0)
+        lame_set_mode(h->gfp, (MPEG_mode) mode);
+    if (quality >= 0)
+        lame_set_quality(h->gfp, quality);
+    if (lame_init_params(h->gfp) < 0) {
+        lame_close(h->gfp);
+        free(h);
+        return 0;
+    }
+    return h;
+}
+
 int
 refh_lametag(void *hh, unsigned char *out, int outsize)
 {
@@ -388,6 +416,12 @@ refh_get_config(void *hh, LhConfig * c)
     c->masking_lower_short = pow(10.0, gfc->sv_qnt.mask_adjust_short * 0.1);
     c->pcm_scale = cfg->pcm_transform[0][0];
     c->interChRatio = cfg->interChRatio;
+    c->vbr_q = h->gfp->VBR_q;
+    if (cfg->vbr != vbr_off) {
+        c->vbr_min_bitrate_index = cfg->vbr_min_bitrate_index;
+        c->vbr_max_bitrate_index = cfg->vbr_max_bitrate_index;
+        c->enforce_min_bitrate = cfg->enforce_min_bitrate;
+    }
 }
 
 static void

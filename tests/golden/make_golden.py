@@ -32,6 +32,17 @@ CASES = [
     ("cbr128_js_44k_silence", 44100, 128, -1, -1, -1, 0.5, None, False),
 ]
 
+VBR_CASES = [
+    # name, samplerate, vbr_q (vbr_mtrh -V n), mode, quality, seed, seconds, burst_interval, white
+    ("vbr2_js_44k", 44100, 2, -1, -1, 201, 1.5, None, False),          # BASELINE.json config 3
+    ("vbr4_js_44k_white", 44100, 4, -1, -1, 202, 1.0, None, True),     # out-of-bits strategies
+    ("vbr0_js_48k_bursts", 48000, 0, -1, -1, 203, 1.0, 1.0 / 40, False),   # sfb21 bands, short blocks
+    ("vbr5_st_32k", 32000, 5, 0, -1, 204, 1.0, None, False),           # rescaled fractional quality
+    ("vbr6_js_44k_q7", 44100, 6, -1, 7, 205, 0.8, None, False),        # guessed scalefactors
+    ("vbr3_js_44k_q5", 44100, 3, -1, 5, 206, 0.8, None, False),        # no best-huffman pass
+    ("vbr2_js_44k_silence", 44100, 2, -1, -1, -1, 0.5, None, False),
+]
+
 
 def frame_hash(fr):
     return hashlib.sha256(bytes(fr)).hexdigest()
@@ -55,18 +66,22 @@ def main():
     w = wave.open(src)
     n = w.getnframes()
     pcm = np.frombuffer(w.readframes(n), dtype=np.int16).reshape(-1, 2).T
-    cases = [("testcase_wav_cbr128", 44100, 128, -1, -1, None, pcm)]
+    cases = [("testcase_wav_cbr128", 44100, 128, -1, -1, None, pcm, -1), ("testcase_wav_vbr2", 44100, 0, -1, -1, None, pcm, 2)]
     for name, sr, br, mode, q, seed, secs, burst, white in CASES:
         nn = int(sr * secs)
         x = np.zeros((2, nn), np.int16) if seed < 0 else helpers.synth_stream(seed, nn, sr, burst, white)
-        cases.append((name, sr, br, mode, q, (seed, secs, burst, white), x))
-    for name, sr, br, mode, q, recipe, x in cases:
-        mp3, nf, frames, cfg, tab = ref.encode(x, sr, br, mode, q, max_frames=4096)
+        cases.append((name, sr, br, mode, q, (seed, secs, burst, white), x, -1))
+    for name, sr, vq, mode, q, seed, secs, burst, white in VBR_CASES:
+        nn = int(sr * secs)
+        x = np.zeros((2, nn), np.int16) if seed < 0 else helpers.synth_stream(seed, nn, sr, burst, white)
+        cases.append((name, sr, 0, mode, q, (seed, secs, burst, white), x, vq))
+    for name, sr, br, mode, q, recipe, x, vq in cases:
+        mp3, nf, frames, cfg, tab = ref.encode(x, sr, br, mode, q, max_frames=4096, vbr_q=None if vq < 0 else vq)
         hashes = [frame_hash(frames[f]) for f in range(nf)]
         th = table_hashes(tab)
         np.savez_compressed(
             os.path.join(HERE, name + ".npz"),
-            samplerate=sr, brate=br, mode=mode, quality=q,
+            samplerate=sr, brate=br, mode=mode, quality=q, vbr_q=vq,
             recipe=np.array([-2 if recipe is None else recipe[0],
                              0 if recipe is None else recipe[1],
                              0 if (recipe is None or recipe[2] is None) else recipe[2],

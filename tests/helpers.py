@@ -83,13 +83,18 @@ class Reference:
             raise FileNotFoundError(REF_SO)
         self.lib = C.CDLL(REF_SO)
         self.lib.refh_open.restype = C.c_void_p
+        self.lib.refh_open_vbr.restype = C.c_void_p
         self.lib.refh_encode_stream.restype = C.c_long
 
-    def encode(self, pcm, sr, brate, mode=-1, quality=-1, max_frames=0):
+    def encode(self, pcm, sr, brate, mode=-1, quality=-1, max_frames=0, vbr_q=None, out_samplerate=0):
+        """CBR at `brate', or vbr_mtrh at quality vbr_q when that is given."""
         left = np.ascontiguousarray(pcm[0], dtype=np.int16)
         right = np.ascontiguousarray(pcm[1], dtype=np.int16)
         n = len(left)
-        h = self.lib.refh_open(sr, brate, mode, quality)
+        if vbr_q is None:
+            h = self.lib.refh_open(sr, brate, mode, quality)
+        else:
+            h = self.lib.refh_open_vbr(sr, vbr_q, mode, quality, out_samplerate, 0)
         assert h, "reference refused the settings"
         h = C.c_void_p(h)
         buf = C.create_string_buffer(2 * n + 100000)
@@ -156,8 +161,9 @@ def normalize_tables(frames):
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
 
-def golden_names():
-    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz"))
+def golden_names(vbr=False):
+    """CBR fixtures by default; vbr=True lists the vbr_mtrh ones ("vbr" in the name)."""
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and (("vbr" in f) == bool(vbr)))
 
 
 def load_golden(name):
@@ -182,6 +188,12 @@ def golden_settings(g):
     mode = int(g["mode"])
     q = int(g["quality"])
     return int(g["samplerate"]), int(g["brate"]), (None if mode < 0 else mode), (None if q < 0 else q)
+
+
+def golden_vbr_q(g):
+    """None for a CBR fixture, else the vbr_mtrh quality (-V n) it was made with."""
+    v = int(g["vbr_q"]) if "vbr_q" in g else -1
+    return None if v < 0 else v
 
 
 def frame_sha(fr):

@@ -33,6 +33,36 @@ def test_oracle_matches_reference(sr, br, mode, q, seed, secs, oracle, reference
     enc.close()
 
 
+VBR_CASES = [(44100, 2, None, None, 21, 2.0, False), (44100, 4, None, None, 22, 1.5, True),
+             (48000, 0, None, None, 23, 1.5, False), (32000, 6, 0, None, 24, 1.5, False),
+             (44100, 5, None, 7, 25, 1.5, False), (44100, 9, None, 5, 26, 1.5, False), (48000, 8, None, None, 27, 1.0, True)]
+
+
+@pytest.mark.parametrize("sr,vq,mode,q,seed,secs,white", VBR_CASES)
+def test_vbr_oracle_matches_reference(sr, vq, mode, q, seed, secs, white, oracle, reference):
+    """vbr_mtrh (-V n): config, tables, every frame's payload incl. the chosen bitrate, final bytes."""
+    pcm = helpers.synth_stream(seed, int(sr * secs), sr, 1.0 / 7, white)
+    out = sr if vq >= 7 else 0          # -V7.. would resample unless the output rate is pinned
+    mp3, nf, rframes, rcfg, rtab = reference.encode(pcm, sr, 0, -1 if mode is None else mode,
+                                                    -1 if q is None else q, max_frames=2048, vbr_q=vq,
+                                                    out_samplerate=out)
+    enc = lamehip.Encoder(sr, mode=mode, quality=q, require_device=False, vbr_q=vq, out_samplerate=out)
+    cfg, tab = enc.config(), enc.tables()
+    assert not struct_diff(rcfg, cfg, skip=("bitrate_index",))      # run-time state in VBR mode
+    assert not struct_diff(rtab, tab, skip=("fft_window", "fft_window_s", "fht_tw", "ma_max_i1", "ma_max_i2",
+                                            "psy_l_to_s"))
+    frames = oracle.encode_frames(cfg, tab, pcm)
+    assert len(frames) == nf
+    mine = helpers.pack_frames(enc.lib, cfg, tab, frames)
+    helpers.normalize_tables(frames)
+    for f in range(nf):
+        d = struct_diff(rframes[f], frames[f], skip=("frame_bits",))
+        assert not d, (f, d[:4])
+    assert mine == mp3
+    assert len({fr.bitrate_index for fr in frames}) > 1 or white
+    enc.close()
+
+
 def test_odd_lengths_and_flush_framing(oracle, reference):
     for n in (1, 500, 1151, 1152, 1153, 1152 * 3, 1152 * 3 + 17, 5000):
         pcm = helpers.synth_stream(n, n)
