@@ -272,10 +272,10 @@ lame_init_params(lame_t g)
         g->have_device = 0;
         return LAMEHIP_ERR_NODEVICE;
     }
-    if (g->cfg.vbr != 0) {
-        /* constants and tables are resolved (lamehip_get_config / _tables work), but the VBR
-         * iteration loop has no device kernels yet: refuse rather than run the CBR loop */
-        snprintf(g_err, sizeof(g_err), "vbr_mtrh: the device iteration loop is not built yet");
+    if (g->cfg.vbr != 0 && g->cfg.full_outer_loop < 0) {
+        /* -q 7..9 in VBR mode replaces the scalefactor search by a closed form around log10f;
+         * that variant has no device kernel (constants and tables are resolved all the same) */
+        snprintf(g_err, sizeof(g_err), "vbr_mtrh with quality >= 7 is outside the accelerated path");
         g->have_device = 0;
         return -1;
     }
@@ -378,7 +378,7 @@ handle_encode_frames(lame_t g, int upto, unsigned char *mp3buf, int mp3buf_size,
         if (k < 0)
             return -1;
         if (g->write_vbr_tag) {
-            lh_tag_add_frame(&g->tag, g->cfg.avg_bitrate);      /* reference encoder.c:550-551 */
+            lh_tag_add_frame(&g->tag, lh_tag_kbps(g->h_out[(size_t) i].bitrate_index));  /* reference encoder.c:550-551 */
             lh_tag_crc(&g->tag, mp3buf + *written, k);          /* reference bitstream.c:1082-1088 */
         }
         *written += k;
@@ -487,7 +487,7 @@ lame_get_lametag_frame(const lame_t g, unsigned char *buffer, size_t size)
 {
     if (!valid(g) || !g->inited || !g->write_vbr_tag)
         return 0;
-    return (size_t) lh_tag_frame(&g->tag, &g->cfg, 4 /* VBR_q default, lame.c:2349 */ , g->enc_padding,
+    return (size_t) lh_tag_frame(&g->tag, &g->cfg, g->cfg.vbr_q, g->enc_padding,
                                  g->have_last ? g->last_frame.mode_ext : 0, buffer, (long) size);
 }
 
@@ -909,9 +909,9 @@ lamehip_batch_pack_tagged(lamehip_batch * b, int s, unsigned char *out, long out
     if (k < 0 || total == 0)
         return k;
     for (int i = 0; i < n; i++)
-        lh_tag_add_frame(&v, b->cfg.avg_bitrate);
+        lh_tag_add_frame(&v, lh_tag_kbps(fr[(size_t) i].bitrate_index));
     lh_tag_crc(&v, out + total, k);
-    if (lh_tag_frame(&v, &b->cfg, 4, lh_end_padding(b->len[(size_t) s]), n > 0 ? fr[(size_t) n - 1].mode_ext : 0,
+    if (lh_tag_frame(&v, &b->cfg, b->cfg.vbr_q, lh_end_padding(b->len[(size_t) s]), n > 0 ? fr[(size_t) n - 1].mode_ext : 0,
                      out, total) != total)
         memset(out, 0, (size_t) total);         /* no frames: the reference leaves the placeholder */
     return k + total;

@@ -85,6 +85,7 @@ struct LhQR {
     int     block_type, sfb_lmax, sfb_smin, psy_lmax, sfbmax, psymax, sfbdivide, mnc;
     int     pn_global_gain, pn_sfb_count1;
     int     substep_shaping;
+    int     ath_over;           /* calc_xmin's return value != 0 (only the VBR loop asks: analog silence) */
 };
 
 /* copies of R / g that came back from an out-of-line stage through per-lane memory */
@@ -103,6 +104,7 @@ lh_uniform(const LhQR & r)
     o.pn_global_gain = lh_uni_i(r.pn_global_gain);
     o.pn_sfb_count1 = lh_uni_i(r.pn_sfb_count1);
     o.substep_shaping = lh_uni_i(r.substep_shaping);
+    o.ath_over = lh_uni_i(r.ath_over);
     return o;
 }
 
@@ -182,9 +184,26 @@ struct LhQTabs {
 };
 
 
+/* what the VBR loop keeps of a granule between its first pass and the (rare) second pass that
+ * squeezes the frame into its bit budget (algo_t + sfwork / vbrsfmin, reference vbrquantize.c:47-55,
+ * 1254-1256) */
+struct LhVbrSave {
+    uint8_t sfwork[LH_SFBMAX + 1];
+    uint8_t sfmin[LH_SFBMAX + 1];
+    int     mingain_l, mingain_s[3];
+    int     global_gain, mnc, max_bits, use_bits;
+    int     ath_over, nonzero, pad[2];
+};
+
 struct LhQuantLds {
     LhChanLds ch[2];
+    LhVbrSave vbr[2][2];        /* [gr][ch]; fits in the tail the larger psy image leaves free */
 };
+
+/* VBR only: the step tables of the scalefactor search, ipow20[0..255] and pow20[116..371]
+ * (= pow20[sf + Q_MAX2]), staged over the second quantised image, which that loop never uses */
+#define LH_VBR_IPOW20 ((float *) lh_lds.u.quant.ch[0].ix[1])
+#define LH_VBR_POW20  ((float *) lh_lds.u.quant.ch[1].ix[1])
 
 /* launch context of the workgroup, written once per launch (frame_base per frame) by thread 0;
  * out-of-line stages read it from here instead of receiving a per-lane copy */

@@ -881,6 +881,7 @@ lh_calc_xmin_body(const LhCtx & c, LhChanLds & Q, LhQR & R, const float *xr, con
     const LhQTabs *qt = LH_QT;
     int const s = c.lane;
     float const adj = c.st->ath_adjust_factor;
+    int     over = 0;
     if (s < R.psymax) {
         int const is_long = (s < R.psy_lmax);
         int const sfb = is_long ? s : (R.sfb_smin + (s - R.psy_lmax) / 3);
@@ -924,7 +925,10 @@ lh_calc_xmin_body(const LhCtx & c, LhChanLds & Q, LhQR & R, const float *xr, con
         }
         xmin = (float) ((xmin > 2.2204460492503131e-16) ? xmin : 2.2204460492503131e-16);
         Q.l3_xmin[s] = xmin;
+        Q.sfb_mode[s] = (en0 > xmin + 1e-14f) ? 1 : 0;  /* energy_above_cutoff (read by the VBR loop only) */
+        over = (en0 > ath);
     }
+    R.ath_over = (lh_ballot(over) != 0);
     {
         /* highest non-zero coefficient */
         unsigned top = 0;
@@ -1178,7 +1182,8 @@ lh_calc_noise(const LhCtx & c, LhChanLds & Q, LhQR & R, const LhGrR & g, int whi
 /* geometry of the granule + spectrum re-ordering for short blocks
  * (reference quantize.c:226-346) */
 LH_DEVFN void
-lh_init_outer_loop_body(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, float *xr, int block_type, int substep)
+lh_init_outer_loop_body(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, float *xr, int block_type, int substep,
+                        int reorder = 1)
 {
     const LhTables *T = c.T;
     const LhQTabs *qt = LH_QT;
@@ -1216,6 +1221,7 @@ lh_init_outer_loop_body(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, flo
     R.pn_global_gain = 0;
     R.pn_sfb_count1 = 0;
     R.substep_shaping = substep;
+    R.ath_over = 0;
     LH_WAVE_SYNC();
     if (c.lane <= LH_SFBMAX) {
         int const s = c.lane;
@@ -1257,7 +1263,7 @@ lh_init_outer_loop_body(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, flo
             Q.sfb_of_line[i] = (uint8_t) s;
         }
     }
-    if (block_type == LH_SHORT_TYPE) {
+    if (block_type == LH_SHORT_TYPE && reorder) {
         /* window-major re-ordering inside each short band */
         float  *tmp = Q.save_xrpow;
         for (int i = c.lane; i < 576; i += 64)
@@ -1308,8 +1314,10 @@ lh_init_xrpow(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g, const f
 {
     unsigned mxabs = 0, mxpow = 0;
     int     nonzero;
+    /* lines above max_nonzero_coeff count as zero (reference quantize.c:78-83: upper); the CBR
+     * loop calls this before calc_xmin, with mnc still 575 */
     for (int i = c.lane; i < 576; i += 64) {
-        float const tmp = lh_fabsf(xr[i]);
+        float const tmp = (i <= R.mnc) ? lh_fabsf(xr[i]) : 0.0f;
         float const xp = (float) sqrt((double) tmp * sqrt((double) tmp));
         unsigned const ub = lh_f32_as_u32(tmp), up = lh_f32_as_u32(xp);
         Q.xrpow[i] = xp;
@@ -1331,7 +1339,7 @@ lh_init_xrpow(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g, const f
         else {
             float   sum = 0;
             LH_WAVE_SYNC();
-            for (int i = 0; i < 576; i++)
+            for (int i = 0; i <= R.mnc; i++)
                 sum += lh_fabsf(xr[i]);
             nonzero = sum > (float) 1E-20;
         }

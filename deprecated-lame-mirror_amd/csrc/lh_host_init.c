@@ -458,11 +458,12 @@ lh_config_resolve(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
         return -1;
     c->force_ms = 0;
     c->original = 1;
-    aux->vbr_q = 4;
+    /* VBR_q also reaches the CBR path (psymodel_init's masking_lower slope, the tag's quality byte) */
+    aux->vbr_q = (p->vbr_q < 0) ? 0 : (p->vbr_q > 9 ? 9 : p->vbr_q);
     aux->vbr_q_frac = 0;
     aux->athaa_sensitivity = 0;
     aux->adjust_sfb21_db = 0;
-    c->vbr_q = 4;
+    c->vbr_q = aux->vbr_q;
     if (c->vbr != 0)
         return config_resolve_vbr(p, c, aux);
 

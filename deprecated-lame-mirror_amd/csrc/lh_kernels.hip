@@ -171,6 +171,8 @@ lh_store_granule(const LhCtx & c, const LhChanLds & Q, const LhQR & R, const LhG
     }
 }
 
+#include "lh_dev_vbr.h"
+
 /* one frame of one stream; executed by the whole workgroup */
 LH_DEVFN void
 lh_encode_frame(LhCtx & c, LhFrameOut * fo)
@@ -258,6 +260,13 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo)
     LH_SYNC_WG();
     LH_PA(2, t_mdct);
     lh_load_qtabs(c, L.qt);     /* mf is dead; xr stays */
+    if (cfg->vbr) {
+        /* step tables of the VBR scalefactor search (over the unused second quantised image) */
+        for (int i = tid; i < 256; i += LH_NT) {
+            LH_VBR_IPOW20[i] = T->ipow20[i];
+            LH_VBR_POW20[i] = T->pow20[i + LH_QMAX2];
+        }
+    }
     LH_SYNC_WG();
 
     /* ---- stage 3: M/S decision (reference encoder.c:413-461) ---- */
@@ -307,8 +316,15 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo)
     /* ---- stage 4: CBR iteration loop (reference quantize.c:1988-2050) ---- */
     int     ResvSize = st->ResvSize, ResvMax, mdb = st->main_data_begin;
     int     substep = st->substep_shaping;
-    int const frame_bits = lh_frame_bits(cfg, cfg->bitrate_index, padding);
-    int const mean_bits = (frame_bits - cfg->sideinfo_len * 8) / cfg->mode_gr;
+    int     bitrate_index = cfg->bitrate_index;
+    int     frame_bits = lh_frame_bits(cfg, bitrate_index, padding);
+    int     mean_bits = (frame_bits - cfg->sideinfo_len * 8) / cfg->mode_gr;
+    int     total_bits = 0;
+    if (cfg->vbr) {
+        lh_vbr_frame(c, fo, pe_use, mode_ext, msoff, ResvSize, substep, bitrate_index, total_bits);
+        frame_bits = lh_frame_bits(cfg, bitrate_index, 0);
+        mean_bits = (frame_bits - cfg->sideinfo_len * 8) / cfg->mode_gr;
+    }
     {
         /* ResvFrameBegin */
         int const resvLimit = (8 * 256) * cfg->mode_gr - 8;
@@ -318,8 +334,7 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo)
         if (ResvMax < 0 || cfg->disable_reservoir)
             ResvMax = 0;
     }
-    int     total_bits = 0;
-    for (int gr = 0; gr < 2; gr++) {
+    for (int gr = 0; gr < 2 && !cfg->vbr; gr++) {
         int     targ_bits[2];
         int     max_bits = lh_on_pe(cfg, ResvSize, ResvMax, &substep, pe_use[gr], targ_bits, mean_bits, gr);
         LH_SYNC_WG();
@@ -409,7 +424,7 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo)
         fo->main_data_begin = (int16_t) mdb;
         fo->resvDrain_pre = (int16_t) drain_pre;
         fo->resvDrain_post = (int16_t) drain_post;
-        fo->bitrate_index = (int8_t) cfg->bitrate_index;
+        fo->bitrate_index = (int8_t) bitrate_index;
         fo->padding = (int8_t) padding;
         fo->mode_ext = (int8_t) mode_ext;
         for (int i = 0; i < 7; i++)

@@ -52,11 +52,22 @@ lh_tag_crc(LhVbrTag * v, const unsigned char *buf, long n)
     v->bytes_written += (unsigned long) n;
 }
 
+static const int lh_tag_bitrate_mpeg1[16] = { 0, 32, 40, 48, 56, 64, 80, 96, 112, 128, 160, 192, 224, 256, 320, -1 };
+
+/* kbps of an MPEG-1 bitrate index (what AddVbrFrame accumulates, reference VbrTag.c:150-158) */
+int
+lh_tag_kbps(int bitrate_index)
+{
+    return lh_tag_bitrate_mpeg1[bitrate_index & 15];
+}
+
 /* reference VbrTag.c:492-559: 0 = the tag does not fit, stays off */
 int
 lh_tag_init(LhVbrTag * v, const LhConfig * c)
 {
-    int const total = ((c->version + 1) * 72000 * c->avg_bitrate) / c->samplerate;
+    /* CBR: the stream's own frame size; VBR: a 128 kbps frame (XING_BITRATE1, reference VbrTag.c:515-529) */
+    int const kbps_header = (c->vbr == 0) ? c->avg_bitrate : 128;
+    int const total = ((c->version + 1) * 72000 * kbps_header) / c->samplerate;
     int const header_size = c->sideinfo_len + LH_LAMEHEADERSIZE;
     memset(v, 0, sizeof(*v));
     if (!lh_crc16_ready)
@@ -101,7 +112,8 @@ tag_frame_header(const LhConfig * c, int mode_ext, unsigned char *b)
     b[1] = (unsigned char) (0xe0 | (1 << 4) | (c->version << 3) | (1 << 1) | (c->error_protection ? 0 : 1));
     b[1] = (unsigned char) ((b[1] & 0xf1) | 0x0a);
     b[2] = (unsigned char) (((c->samplerate_index << 2) | (c->extension & 1)) & 0x0d);
-    b[2] = (unsigned char) (b[2] | (16 * c->bitrate_index));
+    /* bitrate field: the CBR rate, or 128 kbps (index 9) for VBR streams (reference VbrTag.c:286-303) */
+    b[2] = (unsigned char) (b[2] | (16 * (c->vbr == 0 ? c->bitrate_index : 9)));
     b[3] = (unsigned char) ((c->mode << 6) | ((mode_ext & 3) << 4) | ((c->copyright & 1) << 3)
                             | ((c->original & 1) << 2) | (c->emphasis & 3));
 }
@@ -167,7 +179,7 @@ lh_tag_frame(const LhVbrTag * v, const LhConfig * c, int vbr_q, int enc_padding,
     n = c->sideinfo_len;
     if (c->error_protection)
         n -= 2;
-    memcpy(buf + n, "Info", 4);         /* CBR: "Info", VBR would be "Xing" */
+    memcpy(buf + n, c->vbr == 0 ? "Info" : "Xing", 4);   /* reference VbrTag.c:964-977 */
     n += 4;
     put_i4(buf + n, 0x0001 | 0x0002 | 0x0004 | 0x0008);    /* frames, bytes, TOC, quality */
     n += 4;
@@ -217,14 +229,16 @@ lh_tag_frame(const LhVbrTag * v, const LhConfig * c, int vbr_q, int enc_padding,
         else
             source_freq = 1;
         /* short_blocks: 2 = dispensed, 3 = forced (lame.h short_block_t) */
-        if (c->short_blocks == 3 || c->short_blocks == 2 || c->lowpassfreq == -1
+        /* (the reference's "-k" test needs lowpass and highpass both at -1; the highpass never is) */
+        if (c->short_blocks == 3 || c->short_blocks == 2
             || (c->disable_reservoir && c->avg_bitrate < 320) || ath_type == 0 || c->samplerate <= 32000)
             non_optimal = 1;
         put_i4(p + k, (uint32_t) quality);
         k += 4;
         memcpy(p + k, "LAME3.99r", 9);  /* get_lame_tag_encoder_short_version() of 3.99.5 */
         k += 9;
-        p[k++] = 0x01;                  /* tag revision 0, method 1 = CBR */
+        /* tag revision 0 + method (vbr_type_translator, reference VbrTag.c:646): 1 CBR, 5 vbr_mt, 4 vbr_mtrh */
+        p[k++] = (unsigned char) (c->vbr == 0 ? 1 : (c->vbr == 1 ? 5 : 4));
         p[k++] = lowpass;
         put_i4(p + k, 0);               /* peak signal amplitude: not measured */
         k += 4;
@@ -233,14 +247,20 @@ lh_tag_frame(const LhVbrTag * v, const LhConfig * c, int vbr_q, int enc_padding,
         put_i2(p + k, 0);               /* audiophile ReplayGain */
         k += 2;
         p[k++] = (unsigned char) (ath_type + (1 << 4) + (safe_joint << 5));
-        p[k++] = (unsigned char) (c->avg_bitrate >= 255 ? 0xFF : c->avg_bitrate);
+        {
+            /* CBR: the bit rate; VBR: the lowest allowed one (reference VbrTag.c:679-693) */
+            int const abr = (c->vbr == 0) ? c->avg_bitrate : lh_tag_bitrate_mpeg1[c->vbr_min_bitrate_index];
+            p[k++] = (unsigned char) (abr >= 255 ? 0xFF : abr);
+        }
         p[k] = (unsigned char) (LH_ENCDELAY >> 4);
         p[k + 1] = (unsigned char) ((LH_ENCDELAY << 4) + (enc_padding >> 8));
         p[k + 2] = (unsigned char) enc_padding;
         k += 3;
         p[k++] = (unsigned char) (c->noise_shaping + (stereo_mode << 2) + (non_optimal << 5) + (source_freq << 6));
         p[k++] = 0;                     /* MP3 gain */
-        put_i2(p + k, c->avg_bitrate);  /* preset: apply_preset(brate) leaves the bit rate here (presets.c:361, lame.c:1045) */
+        /* preset: apply_preset(brate) leaves the bit rate here (presets.c:361, lame.c:1045);
+         * the VBR path applies V0..V9 = 500 - 10 q (lame.c:983) */
+        put_i2(p + k, c->vbr == 0 ? c->avg_bitrate : 500 - 10 * c->vbr_q);
         k += 2;
         put_i4(p + k, (uint32_t) music_length);
         k += 4;

@@ -111,13 +111,16 @@ class Reference:
         return buf.raw[:k], nf.value, frames, cfg, tab
 
 
-def reference_tagged(pcm, sr, brate, mode=-1, quality=-1, chunk=1152):
+def reference_tagged(pcm, sr, brate, mode=-1, quality=-1, chunk=1152, vbr_q=None):
     """The compiled reference with its default tag handling (bWriteVbrTag = 1): returns
-    (stream bytes incl. the placeholder frame, final tag frame)."""
+    (stream bytes incl. the placeholder frame, final tag frame).  vbr_q selects vbr_mtrh."""
     ref = Reference()
     lib = ref.lib
     lib.refh_open_tag.restype = C.c_void_p
-    h = lib.refh_open_tag(sr, brate, mode, quality)
+    if vbr_q is None:
+        h = lib.refh_open_tag(sr, brate, mode, quality)
+    else:
+        h = lib.refh_open_vbr(sr, vbr_q, mode, quality, sr if vbr_q >= 7 else 0, 1)
     assert h, "reference refused the settings"
     h = C.c_void_p(h)
     left = np.ascontiguousarray(pcm[0], dtype=np.int16)

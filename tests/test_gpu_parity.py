@@ -19,12 +19,16 @@ def test_wave_primitives_selftest():
     assert lamehip.load_library().lamehip_selftest() == 0
 
 
-def _encoder(g):
+def _encoder(g, **kw):
     sr, br, mode, q = helpers.golden_settings(g)
-    return lamehip.Encoder(sr, br, mode, q)
+    return lamehip.Encoder(sr, br, mode, q, vbr_q=helpers.golden_vbr_q(g), **kw)
 
 
-@pytest.mark.parametrize("name", helpers.golden_names())
+# the closed-form scalefactor guess of VBR at -q 7 has no device kernel (lame_init_params refuses it)
+VBR_GOLDEN = [n for n in helpers.golden_names(vbr=True) if not n.endswith("_q7")]
+
+
+@pytest.mark.parametrize("name", helpers.golden_names() + VBR_GOLDEN)
 def test_batch_payload_and_bytes_match_golden(name):
     g, pcm = helpers.load_golden(name)
     enc = _encoder(g)
@@ -46,7 +50,9 @@ def test_batch_payload_and_bytes_match_golden(name):
 
 
 @pytest.mark.parametrize("name,chunk", [("testcase_wav_cbr128", 1152), ("cbr128_js_44k", 777),
-                                        ("cbr320_js_48k_bursts", 4000), ("cbr128_js_44k_silence", 1)])
+                                        ("cbr320_js_48k_bursts", 4000), ("cbr128_js_44k_silence", 1),
+                                        ("testcase_wav_vbr2", 1152), ("vbr4_js_44k_white", 2500),
+                                        ("vbr0_js_48k_bursts", 600)])
 def test_lame_encode_buffer_call_sequence(name, chunk):
     """lame_init -> set -> init_params -> N x lame_encode_buffer -> flush, as the
     reference frontend drives it (frontend/lame_main.c:381-470)."""
@@ -67,7 +73,7 @@ def test_lame_encode_buffer_call_sequence(name, chunk):
     if n == pcm.shape[1]:
         assert out == g["mp3"].tobytes()
     else:
-        ref_like = lamehip.Encoder(*helpers.golden_settings(g))
+        ref_like = _encoder(g)
         b = lamehip.Batch(ref_like, 1, n)
         b.set_pcm(0, pcm[0][:n], pcm[1][:n])
         b.encode()
@@ -275,4 +281,36 @@ def test_odd_call_patterns_match_reference_call_by_call(reference, pattern):
     k = lib.refh_flush(h, buf, len(buf))
     assert k == 0 and enc.flush() == b""          # a second flush has nothing left (reference lame.c:2071)
     lib.refh_close(h)
+    enc.close()
+
+
+def test_vbr_q7_is_refused_loudly():
+    with pytest.raises(RuntimeError):
+        lamehip.Encoder(44100, quality=7, vbr_q=4)
+
+
+@pytest.mark.parametrize("sr,vq,mode,seed,white", [(44100, 2, None, 31, False), (44100, 0, 0, 32, False),
+                                                   (48000, 5, None, 33, True), (32000, 3, None, 34, False),
+                                                   (44100, 9, None, 35, False), (48000, 1, None, 36, True)])
+def test_vbr_batch_matches_oracle(sr, vq, mode, seed, white, oracle):
+    """vbr_mtrh streams of different lengths in one launch against the CPU oracle (every frame's
+    payload incl. its bitrate index, and the packed bytes)."""
+    lens = [int(sr * 1.3), int(sr * 0.4) + 17, 1, int(sr * 0.9)]
+    out = sr if vq >= 7 else 0
+    enc = lamehip.Encoder(sr, mode=mode, vbr_q=vq, out_samplerate=out)
+    cfg, tab = enc.config(), enc.tables()
+    b = lamehip.Batch(enc, len(lens), max(lens))
+    pcms = [helpers.synth_stream(seed * 10 + i, n, sr, 1.0 / 9, white and i == 0) for i, n in enumerate(lens)]
+    for i, x in enumerate(pcms):
+        b.set_pcm(i, x[0], x[1])
+    b.encode()
+    for i, x in enumerate(pcms):
+        want = oracle.encode_frames(cfg, tab, x)
+        got = b.get_frames(i)
+        assert len(got) == len(want)
+        for f in range(len(want)):
+            d = struct_diff(want[f], got[f])
+            assert not d, (i, f, d[:4])
+        assert b.pack(i) == helpers.pack_frames(enc.lib, cfg, tab, want)
+    b.close()
     enc.close()

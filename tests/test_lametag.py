@@ -17,17 +17,20 @@ class LhVbrTag(C.Structure):
                 ("num_frames", C.c_uint), ("bytes_written", C.c_ulong), ("music_crc", C.c_uint16)]
 
 
-@pytest.mark.parametrize("sr,br,mode,q,secs", [(44100, 128, -1, -1, 0.567), (48000, 320, 1, -1, 1.3),
-                                                (32000, 96, -1, -1, 2.0), (44100, 192, 0, 2, 0.9),
-                                                (44100, 128, -1, 7, 13.0)])
-def test_tag_module_matches_reference(sr, br, mode, q, secs):
+@pytest.mark.parametrize("sr,br,mode,q,secs,vq", [(44100, 128, -1, -1, 0.567, None), (48000, 320, 1, -1, 1.3, None),
+                                                   (32000, 96, -1, -1, 2.0, None), (44100, 192, 0, 2, 0.9, None),
+                                                   (44100, 128, -1, 7, 13.0, None), (44100, 0, -1, -1, 1.1, 2),
+                                                   (48000, 0, 0, 5, 0.8, 0), (32000, 0, -1, -1, 0.9, 6),
+                                                   (44100, 0, -1, -1, 12.0, 8)])
+def test_tag_module_matches_reference(sr, br, mode, q, secs, vq):
     """Feed the reference's own audio bytes and frame count through the tag bookkeeping: the
     placeholder and the final tag frame must be the reference's, byte for byte.  (13 s = 498
     frames also exercises the halving of the 400-entry seek-point bag.)"""
     n = int(sr * secs)
     pcm = helpers.synth_stream(4242 + br, n, sr, 1.0 / 5)
-    stream, tag = helpers.reference_tagged(pcm, sr, br, mode, q)
-    enc = lamehip.Encoder(sr, br, None if mode < 0 else mode, None if q < 0 else q, require_device=False)
+    stream, tag = helpers.reference_tagged(pcm, sr, br, mode, q, vbr_q=vq)
+    enc = lamehip.Encoder(sr, br, None if mode < 0 else mode, None if q < 0 else q, require_device=False, vbr_q=vq,
+                          out_samplerate=sr if (vq or 0) >= 7 else 0)
     cfg = enc.config()
     lib = enc.lib
     v = LhVbrTag()
@@ -38,19 +41,19 @@ def test_tag_module_matches_reference(sr, br, mode, q, secs):
     assert ph.raw == stream[:total]
     audio = stream[total:]
     nframes = lib.lh_total_frames(C.c_long(n))
-    for _ in range(nframes):
-        lib.lh_tag_add_frame(C.byref(v), cfg.avg_bitrate)
+    # bitrate index and mode_ext of the frames come from the payload: take them from the oracle
+    fr = helpers.Oracle().encode_frames(cfg, enc.tables(), pcm)
+    assert len(fr) == nframes
+    for f in range(nframes):
+        lib.lh_tag_add_frame(C.byref(v), lib.lh_tag_kbps(int(fr[f].bitrate_index)))
     lib.lh_tag_crc.argtypes = [C.c_void_p, C.c_char_p, C.c_long]
     half = len(audio) // 3
     lib.lh_tag_crc(C.byref(v), audio[:half], half)          # the CRC does not depend on the chunking
     lib.lh_tag_crc(C.byref(v), audio[half:], len(audio) - half)
-    # mode_ext of the last frame comes from the payload: take it from the oracle
-    fr = helpers.Oracle().encode_frames(cfg, enc.tables(), pcm)
-    assert len(fr) == nframes
     out = C.create_string_buffer(2880)
     lib.lh_tag_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_long]
-    k = lib.lh_tag_frame(C.byref(v), C.byref(cfg), 4, lib.lh_end_padding(C.c_long(n)), fr[nframes - 1].mode_ext, out,
-                         len(out))
+    k = lib.lh_tag_frame(C.byref(v), C.byref(cfg), cfg.vbr_q, lib.lh_end_padding(C.c_long(n)),
+                         fr[nframes - 1].mode_ext, out, len(out))
     assert k == total
     assert out.raw[:k] == tag
     # too small a buffer reports the size needed; no frames -> no tag
@@ -59,14 +62,16 @@ def test_tag_module_matches_reference(sr, br, mode, q, secs):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sr,br,mode,chunk", [(44100, 128, None, 1152), (48000, 320, 1, 4000), (44100, 160, 0, 700)])
-def test_api_default_tag_handling_matches_reference(sr, br, mode, chunk):
+@pytest.mark.parametrize("sr,br,mode,chunk,vq", [(44100, 128, None, 1152, None), (48000, 320, 1, 4000, None),
+                                                 (44100, 160, 0, 700, None), (44100, 0, None, 1152, 2),
+                                                 (48000, 0, None, 3000, 5)])
+def test_api_default_tag_handling_matches_reference(sr, br, mode, chunk, vq):
     """lame_init with its defaults (bWriteVbrTag = 1): the first call delivers the placeholder
     frame, the stream and lame_get_lametag_frame equal the reference's."""
     n = int(sr * 1.7)
     pcm = helpers.synth_stream(31337 + br, n, sr, 1.0 / 6)
-    stream, tag = helpers.reference_tagged(pcm, sr, br, -1 if mode is None else mode, -1, chunk)
-    enc = lamehip.Encoder(sr, br, mode, write_tag=True)
+    stream, tag = helpers.reference_tagged(pcm, sr, br, -1 if mode is None else mode, -1, chunk, vbr_q=vq)
+    enc = lamehip.Encoder(sr, br, mode, write_tag=True, vbr_q=vq)
     out = b""
     for i in range(0, n, chunk):
         out += enc.encode(pcm[0][i:i + chunk], pcm[1][i:i + chunk])
@@ -79,18 +84,19 @@ def test_api_default_tag_handling_matches_reference(sr, br, mode, chunk):
 
 
 @pytest.mark.gpu
-def test_batch_pack_tagged_is_the_reference_file_image():
+@pytest.mark.parametrize("vq", [None, 2])
+def test_batch_pack_tagged_is_the_reference_file_image(vq):
     """Batch path: tag frame + audio == the reference's stream with its placeholder replaced by
     its final tag frame (what the frontend leaves on disk)."""
     sr, br = 44100, 128
     pcms = [helpers.synth_stream(777 + i, int(sr * (0.8 + 0.37 * i)), sr, 1.0 / 4) for i in range(4)]
-    enc = lamehip.Encoder(sr, br)
+    enc = lamehip.Encoder(sr, br, vbr_q=vq)
     b = lamehip.Batch(enc, len(pcms), max(x.shape[1] for x in pcms))
     for s, x in enumerate(pcms):
         b.set_pcm(s, x[0], x[1])
     b.encode()
     for s, x in enumerate(pcms):
-        stream, tag = helpers.reference_tagged(x, sr, br)
+        stream, tag = helpers.reference_tagged(x, sr, br, vbr_q=vq)
         assert b.pack_tagged(s) == tag + stream[len(tag):]
     b.close()
     enc.close()
