@@ -600,6 +600,8 @@ lh_vbr_granule(int qch, int gr, int rch, int pass, int gate, int target, int sub
     gate = lh_uni_i(gate);
     target = lh_uni_i(target);
 
+    LH_PT(t_q);
+    LH_PT(t_a);
     lh_init_outer_loop_body(c, Q, R, g, xr, lh_uni_i(L.block_type[gr][qch]), lh_uni_i(substep), pass == 0);
     if (pass == 0) {
         lh_calc_xmin_body(c, Q, R, xr, L.ratio_en[gr][rch], L.ratio_thm[gr][rch]);
@@ -613,13 +615,19 @@ lh_vbr_granule(int qch, int gr, int rch, int pass, int gate, int target, int sub
         sv.nonzero = nonzero;
     }
     live = nonzero && gate > 0;
+    LH_PA(4, t_a);
     if (live) {
         LhVbrGeo G;
         if (pass == 0) {
             int     vbrmax;
+            LH_PT(t_s);
             G = lh_vbr_geometry(c, Q, R);
+            LH_PA(7, t_s);
             vbrmax = lh_vbr_band_steps(c, Q, R, G, xr, sfw, sfm, mingain_l, mingain_s);
+            LH_PA(5, t_s);
+            LH_PT(t_c);
             lh_vbr_constrain(c, Q, R, g, sfw, sfm, vbrmax, mingain_l, mingain_s);
+            LH_PA(8, t_c);
             if (s <= LH_SFBMAX) {
                 sv.sfwork[s] = (uint8_t) sfw;
                 sv.sfmin[s] = (uint8_t) sfm;
@@ -631,10 +639,15 @@ lh_vbr_granule(int qch, int gr, int rch, int pass, int gate, int target, int sub
                 sv.mingain_s[2] = mingain_s[2];
                 sv.global_gain = g.global_gain;
             }
-            (void) lh_vbr_quantize_count(c, Q, R, g);
+            {
+                LH_PT(t_qc);
+                (void) lh_vbr_quantize_count(c, Q, R, g);
+                LH_PA(9, t_qc);
+            }
         }
         else {
             int     cut;
+            LH_PC(10);
             LH_WAVE_SYNC();
             sfw = sv.sfwork[sc];
             sfm = sv.sfmin[sc];
@@ -655,11 +668,14 @@ lh_vbr_granule(int qch, int gr, int rch, int pass, int gate, int target, int sub
         LH_WAVE_SYNC();
     }
     /* reduce_bit_usage (reference vbrquantize.c:1231-1247) */
+    LH_PT(t_f);
     lh_best_scalefac_store_body(c, Q, R, g, gr, LH_AS_GLOBAL(const int8_t, g0sf), lh_uni_i(L.block_type[0][qch]),
                                 L.scfsi[qch]);
     if (c.cfg->use_best_huffman == 1)
         lh_best_huffman_divide_body(c, Q, R, g);
+    LH_PA(6, t_f);
     lh_store_granule(c, Q, R, g, xr, LH_AS_GLOBAL(LhGranule, o));
+    LH_PA(3, t_q);
     if (s == 0)
         sv.use_bits = g.part2_3_length + g.part2_length;
     LH_WAVE_SYNC();

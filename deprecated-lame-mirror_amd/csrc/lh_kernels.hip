@@ -436,7 +436,9 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo)
         st->ResvMax = ResvMax;
         st->main_data_begin = mdb;
         st->substep_shaping = substep;
-        st->masking_lower = (L.block_type[1][1] != LH_SHORT_TYPE) ? cfg->masking_lower_long
+        /* what the next frame's psy model finds in sv_qnt.masking_lower: the CBR loop leaves the value
+         * of its last granule/channel, the VBR loop always the long-block one (reference quantize.c:1622) */
+        st->masking_lower = (cfg->vbr || L.block_type[1][1] != LH_SHORT_TYPE) ? cfg->masking_lower_long
             : cfg->masking_lower_short;
         st->frame_number = st->frame_number + 1;
         if (mdb * 8 != ResvSize)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Randomised parity hunt on the GPU box (test tool, not collected by pytest): many short streams
 of awkward signals per setting, HIP payload against the CPU oracle, frame by frame.
-Usage: python tests/fuzz_gpu.py [streams] [seconds] [seed0]"""
+Usage: python tests/fuzz_gpu.py [streams] [seconds] [seed0] [cbr|vbr]"""
 import os
 import sys
 import time
@@ -22,6 +22,12 @@ SETTINGS = [(44100, 128, None, None), (44100, 128, None, 0), (48000, 320, 1, Non
             (48000, 192, None, 1), (44100, 320, None, 6), (32000, 160, 1, 8)]
 
 
+# bit rate <= 0: vbr_mtrh at quality -rate
+VBR_SETTINGS = [(44100, -2, None, None), (44100, 0, None, None), (48000, -4, 1, None), (32000, -5, None, None),
+                (44100, -6, 0, None), (44100, -1, None, 5), (48000, -3, None, 5), (32000, -2, 0, None),
+                (44100, -9, None, None), (48000, -7, None, None), (44100, -8, 0, 5), (48000, 0, 0, None)]
+
+
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     secs = float(sys.argv[2]) if len(sys.argv) > 2 else 2.0
@@ -29,8 +35,11 @@ def main():
     orc = helpers.Oracle()
     bad = tot = 0
     t0 = time.time()
-    for sr, br, mode, q in SETTINGS:
-        enc = lamehip.Encoder(sr, br, mode, q)
+    for sr, br, mode, q in (VBR_SETTINGS if (len(sys.argv) > 4 and sys.argv[4] == "vbr") else SETTINGS):
+        if br > 0:
+            enc = lamehip.Encoder(sr, br, mode, q)
+        else:
+            enc = lamehip.Encoder(sr, mode=mode, quality=q, vbr_q=-br, out_samplerate=sr if -br >= 7 else 0)
         cfg, tab = enc.config(), enc.tables()
         n = int(sr * secs)
         pcms = [tg._stress_signal(seed0 + i, n - 13 * (i % 31), sr) for i in range(B)]

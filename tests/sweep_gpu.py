@@ -2,7 +2,8 @@
 """Settings sweep on the GPU box (test tool, not collected by pytest): every MPEG-1 bit rate x
 sample rate x stereo mode x a set of quality levels that lame_init_params accepts, a few
 awkward signals each, HIP payload against the CPU oracle frame by frame.
-Usage: python tests/sweep_gpu.py [streams_per_setting] [seconds]"""
+Usage: python tests/sweep_gpu.py [streams_per_setting] [seconds] [cbr|vbr|all]
+"vbr": vbr_mtrh -V0..-V9 x sample rate x stereo mode x quality 0 / 5 instead of the CBR grid."""
 import os
 import sys
 import time
@@ -19,22 +20,30 @@ import test_gpu_parity as tg  # noqa: E402
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 6
     secs = float(sys.argv[2]) if len(sys.argv) > 2 else 1.2
+    what = sys.argv[3] if len(sys.argv) > 3 else "cbr"
     orc = helpers.Oracle()
     bad = tot = nset = unsup = 0
     t0 = time.time()
+    cbr_grid = [(br, q) for br in (32, 40, 48, 56, 64, 80, 96, 112, 128, 160, 192, 224, 256, 320)
+                for q in (0, 2, 3, 5, 7, 9)] if what in ("cbr", "all") else []
+    vbr_grid = [(-vq, q) for vq in range(10) for q in (0, 5)] if what in ("vbr", "all") else []
     for sr in (32000, 44100, 48000):
-        for br in (32, 40, 48, 56, 64, 80, 96, 112, 128, 160, 192, 224, 256, 320):
+        for br, q in cbr_grid + vbr_grid:       # br <= 0: vbr_mtrh at quality -br
             for mode in (0, 1):
-                for q in (0, 2, 3, 5, 7, 9):
+                for _once in (0,):
                     try:
-                        enc = lamehip.Encoder(sr, br, mode, q)
+                        if br > 0:
+                            enc = lamehip.Encoder(sr, br, mode, q)
+                        else:
+                            enc = lamehip.Encoder(sr, mode=mode, quality=q, vbr_q=-br,
+                                                  out_samplerate=sr if -br >= 7 else 0)
                     except RuntimeError:
                         unsup += 1
                         continue
                     nset += 1
                     cfg, tab = enc.config(), enc.tables()
                     n = int(sr * secs)
-                    pcms = [tg._stress_signal(br + q + 8 * i + i, n - 29 * i, sr) for i in range(B)]
+                    pcms = [tg._stress_signal(abs(br) + q + 8 * i + i, n - 29 * i, sr) for i in range(B)]
                     b = lamehip.Batch(enc, B, n)
                     for s, x in enumerate(pcms):
                         b.set_pcm(s, x[0], x[1])

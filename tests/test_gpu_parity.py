@@ -291,10 +291,12 @@ def test_vbr_q7_is_refused_loudly():
 
 @pytest.mark.parametrize("sr,vq,mode,seed,white", [(44100, 2, None, 31, False), (44100, 0, 0, 32, False),
                                                    (48000, 5, None, 33, True), (32000, 3, None, 34, False),
-                                                   (44100, 9, None, 35, False), (48000, 1, None, 36, True)])
+                                                   (44100, 9, None, 35, False), (48000, 1, None, 36, True),
+                                                   (44100, 6, 0, 37, False)])
 def test_vbr_batch_matches_oracle(sr, vq, mode, seed, white, oracle):
     """vbr_mtrh streams of different lengths in one launch against the CPU oracle (every frame's
-    payload incl. its bitrate index, and the packed bytes)."""
+    payload incl. its bitrate index, and the packed bytes).  -V6 is the one preset whose long and
+    short masking adjustments differ (the value the loop leaves for the next frame's psy model)."""
     lens = [int(sr * 1.3), int(sr * 0.4) + 17, 1, int(sr * 0.9)]
     out = sr if vq >= 7 else 0
     enc = lamehip.Encoder(sr, mode=mode, vbr_q=vq, out_samplerate=out)

@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """Per-stage cycle breakdown of lh_encode_kernel from the LH_PROF build
 (make -C deprecated-lame-mirror_amd/csrc prof).  Usage on the GPU box:
-    LAMEHIP_LIB=deprecated-lame-mirror_amd/lamehip/liblamehip_prof.so python tools/stage_profile.py [streams] [seconds]
+    LAMEHIP_LIB=deprecated-lame-mirror_amd/lamehip/liblamehip_prof.so python tools/stage_profile.py [streams] [seconds] [vbr_q]
+With vbr_q (vbr_mtrh) slots 3..10 mean: quant total, init+xmin+xrpow, geometry+scalefactor search,
+scalefac_store+huffman_divide, geometry, constrain+bitcount, quantise+count, second-pass granules.
 """
 import ctypes as C
 import os
@@ -29,7 +31,8 @@ def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
     secs = float(sys.argv[2]) if len(sys.argv) > 2 else 2.0
     n = int(44100 * secs)
-    enc = lamehip.Encoder(44100, 128)
+    vq = int(sys.argv[3]) if len(sys.argv) > 3 else None
+    enc = lamehip.Encoder(44100, 128, vbr_q=vq)
     b = lamehip.Batch(enc, B, n)
     rng = np.random.Generator(np.random.PCG64(900))
     t = np.arange(n) / 44100.0
