@@ -84,6 +84,7 @@ struct LhVbrGeo {
     int     ngroups;            /* groups of four lines over all visited bands */
     int     ng, gstart;         /* this band's groups */
     int     maxng;              /* longest band in groups (wave-uniform) */
+    int     nfused;             /* trial steps whose group sums fit side by side (432 doubles of scratch) */
 };
 
 LH_DEVFN LhVbrGeo
@@ -106,6 +107,7 @@ lh_vbr_geometry(const LhCtx & c, LhChanLds & Q, const LhQR & R)
     }
     G.ngroups = (int) lh_wave_sum_u32((unsigned) G.ng);
     G.maxng = (int) lh_wave_max_u32((unsigned) G.ng);
+    G.nfused = (3 * G.ngroups <= 432) ? 3 : 2;
     LH_WAVE_SYNC();
     if (s <= LH_SFBMAX) {
         Q.pn_step[s] = G.n;
@@ -117,60 +119,151 @@ lh_vbr_geometry(const LhCtx & c, LhChanLds & Q, const LhQR & R)
     return G;
 }
 
-/* noise of every band at its own trial step `sf' (calc_sfb_noise_x34, reference
- * vbrquantize.c:210-262), for the bands with want != 0; other lanes get 0 */
-LH_DEVFN float
-lh_vbr_noise(const LhCtx & c, LhChanLds & Q, const LhVbrGeo & G, const float *xr, int sf, int want)
+/* "Too noisy?" for every band at up to three trial steps at once: bad[v] = xmin < noise(sf[v])
+ * for the lanes (bands) with want[v] != 0, where noise is calc_sfb_noise_x34 (reference
+ * vbrquantize.c:210-262).  NV = how many variants run side by side (G.nfused).
+ *
+ * The reference's noise is a float accumulator that takes one double group sum after the other;
+ * that serial chain (<= 48 links per band) is only walked when it can matter: all terms are
+ * non-negative, so the chain's result lies within n * 2^-24 (relative) of the true sum, and the
+ * groups also add their sums to a per-band float with LDS atomics (any order, same bound).  When
+ * xmin is farther than 6e-5 (relative) from that approximate sum -- almost always -- the comparison
+ * is decided; otherwise the exact chain runs. */
+template < int NV > LH_DEVFN void
+lh_vbr_noisy_n(const LhCtx & c, LhChanLds & Q, const LhVbrGeo & G, const float *xr, float xmin, const int sf[3],
+               const int want[3], int bad[3])
 {
     const LhTables *T = c.T;
-    const LhQTabs *qt = LH_QT;
     const uint8_t *gband = (const uint8_t *) Q.pn_noise;
-    double *gsum = (double *) Q.save_xrpow;
+    double *gsum = (double *) Q.save_xrpow;     /* NV x G.ngroups doubles: save_xrpow and ix[0] behind it */
+    int    *step = (int *) Q.sfb_f;             /* the band's trial steps, 9 bits each (511 = none) */
+    float  *approx[3] = { Q.distort, Q.l3_xmin, (float *) Q.sf[1] };
     int const s = c.lane;
-    int const sfc = sf < 0 ? 0 : (sf > 255 ? 255 : sf);
+    int     on[3], maxng = 0, ambiguous = 0;
+    LH_PT(t_n);
+    LH_PC(13);
     LH_WAVE_SYNC();
-    if (s <= LH_SFBMAX) {
-        /* bands that are not asked for quantise with step 0: their trial step may lie below the
-         * band's floor, where the quantiser's rounding trick no longer yields a table index */
-        Q.sfb_f[s] = (want && G.visited) ? LH_VBR_IPOW20[sfc] : 0.0f;
-        Q.distort[s] = LH_VBR_POW20[sfc];
+    {
+        unsigned pack = 0;
+#pragma unroll
+        for (int v = 0; v < 3; v++) {
+            int const sfc = sf[v < NV ? v : 0] < 0 ? 0 : (sf[v < NV ? v : 0] > 255 ? 255 : sf[v < NV ? v : 0]);
+            on[v] = (v < NV) && want[v] && G.visited;
+            /* bands that are not asked for quantise with step 0: their trial step may lie below the
+             * band's floor, where the quantiser's rounding trick no longer yields a table index */
+            pack |= (unsigned) (on[v] ? sfc : 511) << (9 * v);
+            if (s <= LH_SFBMAX)
+                approx[v][s] = 0.0f;
+        }
+        if (s <= LH_SFBMAX)
+            step[s] = (int) pack;
     }
     LH_WAVE_SYNC();
     /* phase A: lane = group of four lines of one band */
 #pragma unroll
     for (int r = 0; r < 3; r++) {
-        int const gi = s + 64 * r;
-        int const gic = gi < G.ngroups ? gi : 0;
-        int const b = gband[gic];
-        int const k0 = 4 * (gic - Q.pseudohalf[b]);
-        int const line = Q.start[b] + k0;
-        int const cnt = Q.pn_step[b] - k0;      /* >= 1 */
-        float const sfpow34 = Q.sfb_f[b], sfpow = Q.distort[b];
-        double  e[4];
+        if (64 * r < G.ngroups) {
+            int const gi = s + 64 * r;
+            int const gic = gi < G.ngroups ? gi : 0;
+            int const b = gband[gic];
+            int const k0 = 4 * (gic - Q.pseudohalf[b]);
+            int const line = Q.start[b] + k0;
+            int const cnt = Q.pn_step[b] - k0;  /* >= 1 */
+            unsigned const pack = (unsigned) step[b];
+            float   x34[4], ax[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            int const lc = (k < cnt) ? line + k : line;
-            int const l3 = lh_quant_line(T, qt, sfpow34, Q.xrpow[lc]);
-            int const l3c = l3 < 0 ? 0 : (l3 > LH_IXMAX + 1 ? LH_IXMAX + 1 : l3);   /* unwanted bands may overflow */
-            float const d = lh_fabsf(xr[lc]) - sfpow * lh_pow43(T, qt, l3c);
-            e[k] = (k < cnt) ? (double) d : 0.0;
+            for (int k = 0; k < 4; k++) {
+                int const lc = (k < cnt) ? line + k : line;
+                x34[k] = Q.xrpow[lc];
+                ax[k] = lh_fabsf(xr[lc]);
+            }
+            /* straight-line code: both table look-ups of all lines and variants go to HBM (L1/L2
+             * resident, 64 KiB) unconditionally, so that they are in flight together; trial steps
+             * below the final one quantise to large values, which the LDS heads do not cover */
+            {
+                float   sfpow[NV];
+                double  x0[NV][4];
+                int     k1[NV][4];
+                float   adj[NV][4], p43[NV][4];
+#pragma unroll
+                for (int v = 0; v < NV; v++) {
+                    int const sv = (int) ((pack >> (9 * v)) & 511u);
+                    int const svc = sv > 255 ? 0 : sv;
+                    float const sfpow34 = sv > 255 ? 0.0f : LH_VBR_IPOW20[svc];
+                    sfpow[v] = LH_VBR_POW20[svc];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        x0[v][k] = (double) (sfpow34 * x34[k]) + LH_MAGIC_FLOAT;
+                        k1[v][k] = (int) lh_f32_as_u32((float) x0[v][k]) - LH_MAGIC_INT;
+                    }
+                }
+#pragma unroll
+                for (int v = 0; v < NV; v++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        adj[v][k] = T->adj43asm[k1[v][k]];
+#pragma unroll
+                for (int v = 0; v < NV; v++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        k1[v][k] = (int) lh_f32_as_u32((float) (x0[v][k] + adj[v][k])) - LH_MAGIC_INT;
+#pragma unroll
+                for (int v = 0; v < NV; v++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        p43[v][k] = T->pow43[k1[v][k]];
+#pragma unroll
+                for (int v = 0; v < NV; v++) {
+                    double  e[4], gs;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        float const d = ax[k] - sfpow[v] * p43[v][k];
+                        e[k] = (k < cnt) ? (double) d : 0.0;
+                    }
+                    gs = (e[0] * e[0] + e[1] * e[1]) + (e[2] * e[2] + e[3] * e[3]);
+                    if (gi < G.ngroups) {
+                        gsum[v * G.ngroups + gi] = gs;
+                        lh_lds_addf(&approx[v][b], (float) gs);
+                    }
+                }
+            }
         }
-        if (gi < G.ngroups)
-            gsum[gi] = (e[0] * e[0] + e[1] * e[1]) + (e[2] * e[2] + e[3] * e[3]);
     }
     LH_WAVE_SYNC();
-    /* phase B: lane = band, float accumulator += double group sum, in order */
-    {
-        float   acc = 0.0f;
-        int const on = want && G.visited;
-        for (int i = 0; i < G.maxng; i++) {
-            int const idx = (on && i < G.ng) ? G.gstart + i : 0;
-            double const v = gsum[idx];
-            float const nx = (float) ((double) acc + v);
-            acc = (on && i < G.ng) ? nx : acc;
+    LH_PA(12, t_n);
+#pragma unroll
+    for (int v = 0; v < 3; v++) {
+        /* |chain - sum| <= n 2^-24 sum, |approx - sum| <= (n + 1) 2^-24 sum, n <= 48 */
+        double const a = (double) approx[v][s <= LH_SFBMAX ? s : LH_SFBMAX];
+        double const x = (double) xmin;
+        bad[v] = on[v] && (x < a * (1.0 - 6e-5));
+        if (on[v] && !bad[v] && !(x > a * (1.0 + 6e-5))) {
+            ambiguous = 1;
+            maxng = G.ng > maxng ? G.ng : maxng;
         }
-        return on ? acc : 0.0f;
     }
+    if (lh_ballot(ambiguous)) {
+        /* exact: lane = band, float accumulator += double group sum, in order */
+        float   acc[3] = { 0.0f, 0.0f, 0.0f };
+        LH_PC(14);
+        maxng = (int) lh_wave_max_u32((unsigned) maxng);
+        for (int i = 0; i < maxng; i++) {
+            int const in = i < G.ng;
+#pragma unroll
+            for (int v = 0; v < NV; v++) {
+                int const idx = (on[v] && in) ? v * G.ngroups + G.gstart + i : 0;
+                double const gv = gsum[idx];
+                float const nx = (float) ((double) acc[v] + gv);
+                acc[v] = (on[v] && in) ? nx : acc[v];
+            }
+        }
+        if (ambiguous) {
+#pragma unroll
+            for (int v = 0; v < NV; v++)
+                bad[v] = on[v] && (xmin < acc[v]);
+        }
+    }
+    LH_PA(11, t_n);
 }
 
 /* block_sf (reference vbrquantize.c:397-489): per-band step indices sfw (lane = band) and the
@@ -223,11 +316,28 @@ lh_vbr_band_steps(const LhCtx & c, LhChanLds & Q, const LhQR & R, const LhVbrGeo
             int const need = active && !skip;
             int     bad;
             del >>= 1;
-            bad = xmin < lh_vbr_noise(c, Q, G, xr, sf, need);
-            if (lh_ballot(need && !bad && sf < 255))
-                bad |= xmin < lh_vbr_noise(c, Q, G, xr, sf + 1, need && !bad && sf < 255);
-            if (lh_ballot(need && !bad && sf > 0))
-                bad |= xmin < lh_vbr_noise(c, Q, G, xr, sf - 1, need && !bad && sf > 0);
+            {
+                /* tri_calc_sfb_noise_x34 (reference vbrquantize.c:275-308): too noisy at sf, sf + 1
+                 * or sf - 1.  The three are evaluated side by side when the scratch holds them. */
+                int const sfv[3] = { sf, sf + 1, sf - 1 };
+                int     wv[3] = { need, need && sf < 255, need && sf > 0 };
+                int     bv[3];
+                if (G.nfused >= 3)
+                    lh_vbr_noisy_n < 3 > (c, Q, G, xr, xmin, sfv, wv, bv);
+                else {
+                    lh_vbr_noisy_n < 2 > (c, Q, G, xr, xmin, sfv, wv, bv);
+                    wv[0] = wv[2] && !bv[0] && !bv[1];
+                    bv[2] = 0;
+                    if (lh_ballot(wv[0])) {
+                        int const sf1[3] = { sf - 1, 0, 0 };
+                        int     b1[3];
+                        wv[1] = wv[2] = 0;
+                        lh_vbr_noisy_n < 1 > (c, Q, G, xr, xmin, sf1, wv, b1);
+                        bv[2] = b1[0];
+                    }
+                }
+                bad = bv[0] || bv[1] || bv[2];
+            }
             if (skip)
                 sf += del;
             else if (bad)

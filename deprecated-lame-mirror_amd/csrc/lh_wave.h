@@ -127,6 +127,7 @@ lh_wave_max_f32(float v)
 
 static inline void lh_lds_add(int *p, int v) { *p += v; }      /* fibers interleave only at sync points */
 static inline void lh_lds_max(int *p, int v) { if (v > *p) *p = v; }
+static inline void lh_lds_addf(float *p, float v) { *p += v; }
 static inline int lh_uni_i(int v) { return v; }
 static inline float lh_uni_f(float v) { return v; }
 static inline int lh_ffs64(uint64_t m) { return m ? __builtin_ctzll(m) : -1; }
@@ -238,6 +239,8 @@ lh_bcast_u32(uint32_t v, int src)
 /* LDS atomics without a return value (ds_add_u32 / ds_max_i32) */
 __device__ __forceinline__ void lh_lds_add(int *p, int v) { (void) __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void lh_lds_max(int *p, int v) { (void) __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+/* ds_add_f32: order of the additions is not defined -- only for sums whose use tolerates that */
+__device__ __forceinline__ void lh_lds_addf(float *p, float v) { (void) __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 /* Tell the compiler that a value is wave-uniform (it is by construction, but came through
  * per-lane memory, which the compiler must treat as divergent): the value moves to a scalar
