@@ -81,7 +81,7 @@ struct LhVbrGeo {
     int     visited;            /* this lane's band starts at or below max_nonzero_coeff */
     int     n;                  /* its lines that take part: min(width, room) */
     int     start;
-    int     ngroups;            /* groups of four lines over all visited bands */
+    int     ngroups;            /* groups of four lines over all searched bands */
     int     ng, gstart;         /* this band's groups */
     int     maxng;              /* longest band in groups (wave-uniform) */
     int     nfused;             /* trial steps whose group sums fit side by side (432 doubles of scratch) */
@@ -99,7 +99,9 @@ lh_vbr_geometry(const LhCtx & c, LhChanLds & Q, const LhQR & R)
     G.start = Q.start[sc];
     G.visited = (s < G.nb) && (G.start <= R.mnc);
     G.n = G.visited ? lh_imin(width, R.mnc - G.start + 1) : 0;
-    G.ng = (G.n + 3) >> 2;
+    /* only bands whose step is searched get groups: below psymax and with energy above the
+     * masking threshold (block_sf, reference vbrquantize.c:437-438) */
+    G.ng = (G.visited && s < R.psymax && Q.sfb_mode[sc]) ? (G.n + 3) >> 2 : 0;
     G.gstart = 0;
     for (int u = 0; u < 39; u++) {
         int const t = (int) lh_bcast_u32((unsigned) G.ng, u);
@@ -129,6 +131,9 @@ lh_vbr_geometry(const LhCtx & c, LhChanLds & Q, const LhQR & R)
  * groups also add their sums to a per-band float with LDS atomics (any order, same bound).  When
  * xmin is farther than 6e-5 (relative) from that approximate sum -- almost always -- the comparison
  * is decided; otherwise the exact chain runs. */
+#ifndef LH_VBR_MARGIN
+#define LH_VBR_MARGIN 6e-5      /* tests widen it to drive every comparison through the exact chain */
+#endif
 template < int NV > LH_DEVFN void
 lh_vbr_noisy_n(const LhCtx & c, LhChanLds & Q, const LhVbrGeo & G, const float *xr, float xmin, const int sf[3],
                const int want[3], int bad[3])
@@ -236,8 +241,8 @@ lh_vbr_noisy_n(const LhCtx & c, LhChanLds & Q, const LhVbrGeo & G, const float *
         /* |chain - sum| <= n 2^-24 sum, |approx - sum| <= (n + 1) 2^-24 sum, n <= 48 */
         double const a = (double) approx[v][s <= LH_SFBMAX ? s : LH_SFBMAX];
         double const x = (double) xmin;
-        bad[v] = on[v] && (x < a * (1.0 - 6e-5));
-        if (on[v] && !bad[v] && !(x > a * (1.0 + 6e-5))) {
+        bad[v] = on[v] && (x < a * (1.0 - LH_VBR_MARGIN));
+        if (on[v] && !bad[v] && !(x > a * (1.0 + LH_VBR_MARGIN))) {
             ambiguous = 1;
             maxng = G.ng > maxng ? G.ng : maxng;
         }
