@@ -904,11 +904,32 @@ lh_calc_xmin_body(const LhCtx & c, LhChanLds & Q, LhQR & R, const float *xr, con
         ath *= fact;
         rh1 = ath / width;
         rh2 = (float) 2.2204460492503131e-16;
-        for (int l = 0; l < width; ++l) {
-            float const xa = xr[j++];
-            float const x2 = xa * xa;
-            en0 += x2;
-            rh2 += (x2 < rh1) ? x2 : rh1;
+        {
+            /* the two sums are serial (the reference's order); band starts and widths are even in
+             * every MPEG-1 table, so lines come in aligned pairs, four pairs per trip with their
+             * loads issued ahead of the dependent adds, nothing conditional on the add chains */
+            const lh_f32x2 *xp = (const lh_f32x2 *) (xr + j);
+            int const np = width >> 1;
+            int     p = 0;
+            for (; p + 4 <= np; p += 4) {
+                lh_f32x2 const a0 = xp[p], a1 = xp[p + 1], a2 = xp[p + 2], a3 = xp[p + 3];
+                float const v[8] = { a0.x, a0.y, a1.x, a1.y, a2.x, a2.y, a3.x, a3.y };
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    float const x2 = v[u] * v[u];
+                    en0 += x2;
+                    rh2 += (x2 < rh1) ? x2 : rh1;
+                }
+            }
+            for (; p < np; p++) {
+                lh_f32x2 const a0 = xp[p];
+                float   x2 = a0.x * a0.x;
+                en0 += x2;
+                rh2 += (x2 < rh1) ? x2 : rh1;
+                x2 = a0.y * a0.y;
+                en0 += x2;
+                rh2 += (x2 < rh1) ? x2 : rh1;
+            }
         }
         if (en0 < ath)
             rh3 = en0;
@@ -1254,14 +1275,14 @@ lh_init_outer_loop_body(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, flo
     }
     LH_WAVE_SYNC();
     {
-        int const nb = (block_type == LH_SHORT_TYPE) ? 39 : 22;
-        for (int i = c.lane; i < 576; i += 64) {
-            int     s = 0;
-            for (int k = 1; k < nb; k++)
-                if (Q.start[k] <= i)
-                    s = k;
-            Q.sfb_of_line[i] = (uint8_t) s;
-        }
+        /* band of every line: constant per block type, built by the host (LhTables.sfb_line_*) */
+        const uint32_t *src = (const uint32_t *) ((block_type == LH_SHORT_TYPE) ? T->sfb_line_s : T->sfb_line_l);
+        uint32_t *dst = (uint32_t *) Q.sfb_of_line;
+        uint32_t const a = src[c.lane], b = src[c.lane + 64], d = src[(c.lane < 16) ? c.lane + 128 : 0];
+        dst[c.lane] = a;
+        dst[c.lane + 64] = b;
+        if (c.lane < 16)
+            dst[c.lane + 128] = d;
     }
     if (block_type == LH_SHORT_TYPE && reorder) {
         /* window-major re-ordering inside each short band */

@@ -718,11 +718,13 @@ lh_vbr_granule(int qch, int gr, int rch, int pass, int gate, int target, int sub
     LH_PT(t_q);
     LH_PT(t_a);
     lh_init_outer_loop_body(c, Q, R, g, xr, lh_uni_i(L.block_type[gr][qch]), lh_uni_i(substep), pass == 0);
+    LH_PA(15, t_a);
     if (pass == 0) {
         lh_calc_xmin_body(c, Q, R, xr, L.ratio_en[gr][rch], L.ratio_thm[gr][rch]);
     }
     else
         R.mnc = lh_uni_i(sv.mnc);
+    LH_PA(16, t_a);
     nonzero = lh_init_xrpow(c, Q, R, g, xr);    /* silent granules: all of ix[0] cleared */
     if (pass == 0 && s == 0) {
         sv.mnc = R.mnc;
@@ -786,6 +788,7 @@ lh_vbr_granule(int qch, int gr, int rch, int pass, int gate, int target, int sub
     LH_PT(t_f);
     lh_best_scalefac_store_body(c, Q, R, g, gr, LH_AS_GLOBAL(const int8_t, g0sf), lh_uni_i(L.block_type[0][qch]),
                                 L.scfsi[qch]);
+    LH_PA(17, t_f);
     if (c.cfg->use_best_huffman == 1)
         lh_best_huffman_divide_body(c, Q, R, g);
     LH_PA(6, t_f);

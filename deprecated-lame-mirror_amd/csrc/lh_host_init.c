@@ -1222,6 +1222,24 @@ lh_tables_build(LhConfig * c, const LhInitAux * aux, LhTables * t)
     /* reference util.c:960-972 */
     for (i = 0; i < 513; i++)
         t->log_table[i] = log(1.0f + i / (float) 512) / log(2.0f);
+    {
+        /* band of every line (derived; long: largest sfb with sfb_l[sfb] <= i, short: window-major) */
+        int     i, k;
+        for (i = 0; i < 576; i++) {
+            int     bl = 0, bs = 0;
+            for (k = 1; k < LH_SBMAX_L; k++)
+                if (t->sfb_l[k] <= i)
+                    bl = k;
+            for (k = 1; k < 3 * LH_SBMAX_S; k++) {
+                int const sfb = k / 3, win = k - 3 * sfb;
+                int const wd = t->sfb_s[sfb + 1] - t->sfb_s[sfb];
+                if (3 * t->sfb_s[sfb] + win * wd <= i)
+                    bs = k;
+            }
+            t->sfb_line_l[i] = (uint8_t) bl;
+            t->sfb_line_s[i] = (uint8_t) bs;
+        }
+    }
     return 0;
 }
 

@@ -173,6 +173,10 @@ typedef struct LhTables {
     float   fht_tw[4][128][4];    /* [stage][i] -> c1,s1,c2,s2 as produced by the recurrence fft.c:103-144 */
     float   amp_filter[32];       /* reference lame.c:103-190 */
     float   log_table[513];       /* reference util.c:954-972 */
+    /* scalefactor band of each of the 576 lines as gr_info.width[] lays them out (derived from
+     * sfb_l / sfb_s; long blocks: 22 bands, short blocks: 39 = 13 x 3 windows, window-major) */
+    uint8_t sfb_line_l[576];
+    uint8_t sfb_line_s[576];
 } LhTables;
 
 /* ------------------------------------------------------------------ */

@@ -496,6 +496,24 @@ refh_get_tables(void *hh, LhTables * t)
     for (i = 0; i < 512; i++)
         t->log_table[i] = fast_log2(1.0f + i / 512.0f);
     t->log_table[512] = 1.0f;
+    {
+        /* band of every line (derived, not in the reference; long: largest sfb with sfb_l[sfb] <= i, short: window-major) */
+        int     i, k;
+        for (i = 0; i < 576; i++) {
+            int     bl = 0, bs = 0;
+            for (k = 1; k < LH_SBMAX_L; k++)
+                if (t->sfb_l[k] <= i)
+                    bl = k;
+            for (k = 1; k < 3 * LH_SBMAX_S; k++) {
+                int const sfb = k / 3, win = k - 3 * sfb;
+                int const wd = t->sfb_s[sfb + 1] - t->sfb_s[sfb];
+                if (3 * t->sfb_s[sfb] + win * wd <= i)
+                    bs = k;
+            }
+            t->sfb_line_l[i] = (uint8_t) bl;
+            t->sfb_line_s[i] = (uint8_t) bs;
+        }
+    }
     /* fft_window / fht_tw / ma_max_* are file-local in the reference: left zero
      * here, pinned indirectly through refh_fft_long / whole-frame parity */
 }
