@@ -48,7 +48,7 @@ def synth_on_device(torch, batch, n, sr, seed0, device, chunk=32):
     return out
 
 
-def cpu_baseline(sr, brate, seconds_budget=12.0, vbr_q=None):
+def cpu_baseline(sr, brate, seconds_budget=12.0, vbr_q=None, abr=None):
     """Time the compiled reference (oracle/_ref, kind 'reference') -- or the CPU
     restatement (kind 'port') when the reference build is absent -- on ONE host
     core over a bounded sample of the same workload."""
@@ -61,11 +61,11 @@ def cpu_baseline(sr, brate, seconds_budget=12.0, vbr_q=None):
         kind = "reference"
 
         def run():
-            ref.encode(pcm, sr, brate, vbr_q=vbr_q)
+            ref.encode(pcm, sr, brate, vbr_q=vbr_q, abr=abr)
     else:
         import lamehip
         orc = helpers.Oracle()
-        enc = lamehip.Encoder(sr, brate, require_device=False, vbr_q=vbr_q)
+        enc = lamehip.Encoder(sr, brate, require_device=False, vbr_q=vbr_q, abr=abr)
         cfg, tab = enc.config(), enc.tables()
         kind = "port"
 
@@ -81,7 +81,8 @@ def cpu_baseline(sr, brate, seconds_budget=12.0, vbr_q=None):
     dt = time.time() - t0
     return {"value": round(reps * 20.0 / dt, 2), "unit": "x real-time", "cores": 1, "kind": kind,
             "sample": "%d x 20 s seeded synthetic 44.1 kHz stereo, %s, one host core"
-                      % (reps, ("CBR %d" % brate) if vbr_q is None else ("VBR -V%d" % vbr_q))}
+                      % (reps, ("ABR %d" % abr) if abr is not None else ("CBR %d" % brate) if vbr_q is None
+                         else ("VBR -V%d" % vbr_q))}
 
 
 def end_to_end(torch, lamehip, enc, B, sr, dev, seconds=5.0):
@@ -121,6 +122,7 @@ def main():
     ap.add_argument("--brate", type=int, default=128)
     ap.add_argument("--vbr", type=int, default=None, metavar="Q",
                     help="vbr_mtrh at quality Q (BASELINE config[2] is -V2) instead of CBR; not the default line")
+    ap.add_argument("--abr", type=int, default=None, metavar="KBPS", help="ABR at a mean of KBPS instead of CBR")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--end-to-end", action="store_true",
                     help="also time host PCM -> H2D -> kernel -> D2H -> host bit packing (threads) on a "
@@ -143,7 +145,7 @@ def main():
 
     sr, B = args.samplerate, args.streams
     n = int(args.seconds * sr)
-    enc = lamehip.Encoder(sr, args.brate, vbr_q=args.vbr)
+    enc = lamehip.Encoder(sr, args.brate, vbr_q=args.vbr, abr=args.abr)
     batch = lamehip.Batch(enc, B, n)
     # static sharding: rank r owns global streams [r*B, (r+1)*B); seeds follow the global index
     pcm = synth_on_device(torch, B, n, sr, rank * B, dev)
@@ -188,14 +190,17 @@ def main():
         achieved = frames * ALG_BYTES_PER_FRAME / kavg / 1e9
         res = {
             "metric": "encoded audio seconds/sec (x real-time) at 44.1kHz stereo "
-                      + ("CBR128" if args.vbr is None else "VBR -V%d" % args.vbr),
+                      + ("ABR%d" % args.abr if args.abr is not None else "CBR128" if args.vbr is None
+                         else "VBR -V%d" % args.vbr),
             "value": round(value, 1), "unit": "x real-time", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": ("batch=%d synthetic %.1f kHz stereo streams x %.0f s, CBR %d kb/s, "
                                     "per GPU (BASELINE config[1])" % (B, sr / 1000.0, args.seconds, args.brate))
-                       if args.vbr is None else
+                       if args.vbr is None and args.abr is None else
+                       ("batch=%d synthetic %.1f kHz stereo streams x %.0f s, ABR %d kb/s, per GPU"
+                        % (B, sr / 1000.0, args.seconds, args.abr)) if args.abr is not None else
                        ("batch=%d synthetic %.1f kHz stereo streams x %.0f s, VBR -V%d (vbrquantize.c path), "
                         "per GPU (BASELINE config[2])" % (B, sr / 1000.0, args.seconds, args.vbr)),
                        "streams_per_gpu": B, "seconds_per_stream": args.seconds,
@@ -209,7 +214,7 @@ def main():
                          "alg_bytes_per_frame": ALG_BYTES_PER_FRAME, "frames_per_launch": frames},
         }
         if not args.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline(sr, args.brate, vbr_q=args.vbr)
+            res["cpu_baseline"] = cpu_baseline(sr, args.brate, vbr_q=args.vbr, abr=args.abr)
         if args.end_to_end and world == 1:
             res["end_to_end"] = end_to_end(torch, lamehip, enc, B, sr, dev)
         print(json.dumps(res))

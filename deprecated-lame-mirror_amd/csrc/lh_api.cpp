@@ -220,6 +220,8 @@ lame_set_VBR_q(lame_t g, int q)
 }
 
 GETTER(lame_get_VBR_q, g->inited ? g->cfg.vbr_q : g->p.vbr_q, int)
+SETTER(lame_set_VBR_mean_bitrate_kbps, p.abr_kbps, int)
+GETTER(lame_get_VBR_mean_bitrate_kbps, g->inited ? g->cfg.vbr_avg_bitrate_kbps : g->p.abr_kbps, int)
 
 extern "C" int
 lame_set_findReplayGain(lame_t g, int v)

@@ -1020,4 +1020,75 @@ lh_vbr_frame(const LhCtx & c, LhFrameOut * fo, float pe_use[2][2], int mode_ext,
     total_bits = used;
 }
 
+/* ---- ABR (reference quantize.c:1768-1884, calc_target_bits): the bit budget of every
+ * granule/channel from the mean bitrate and the perceptual entropy; wave-uniform scalar code.
+ * The granule work itself is the CBR loop's (lh_encode_frame). */
+LH_DEVFN void
+lh_abr_target_bits(const LhConfig * cfg, int ResvSize, int substep, float pe[2][2], const float ms_ener_ratio[2],
+                   const int block_type[2][2], int mode_ext, int targ_bits[2][2], int *analog_silence_bits)
+{
+    float   res_factor;
+    int     totbits, mean_bits, dummy, max_frame_bits;
+    int const framesize = 576 * cfg->mode_gr;
+
+    max_frame_bits = lh_vbr_full_bits(cfg, cfg->vbr_max_bitrate_index, ResvSize, &mean_bits, &dummy);
+    mean_bits = lh_frame_bits(cfg, 1, 0) - cfg->sideinfo_len * 8;
+    *analog_silence_bits = mean_bits / (cfg->mode_gr * cfg->channels);
+
+    mean_bits = cfg->vbr_avg_bitrate_kbps * framesize * 1000;
+    if (substep & 1)
+        mean_bits *= 1.09;
+    mean_bits /= cfg->samplerate;
+    mean_bits -= cfg->sideinfo_len * 8;
+    mean_bits /= (cfg->mode_gr * cfg->channels);
+
+    res_factor = .93 + .07 * (11.0 - cfg->compression_ratio) / (11.0 - 5.5);
+    if (res_factor < .90)
+        res_factor = .90;
+    if (res_factor > 1.00)
+        res_factor = 1.00;
+    for (int gr = 0; gr < 2; gr++) {
+        int     sum = 0;
+        for (int ch = 0; ch < 2; ch++) {
+            targ_bits[gr][ch] = res_factor * mean_bits;
+            if (pe[gr][ch] > 700) {
+                int     add_bits = (pe[gr][ch] - 700) / 1.4;
+                if (block_type[gr][ch] == LH_SHORT_TYPE) {
+                    if (add_bits < mean_bits / 2)
+                        add_bits = mean_bits / 2;
+                }
+                if (add_bits > mean_bits * 3 / 2)
+                    add_bits = mean_bits * 3 / 2;
+                else if (add_bits < 0)
+                    add_bits = 0;
+                targ_bits[gr][ch] += add_bits;
+            }
+            if (targ_bits[gr][ch] > LH_MAX_BITS_PER_CHANNEL)
+                targ_bits[gr][ch] = LH_MAX_BITS_PER_CHANNEL;
+            sum += targ_bits[gr][ch];
+        }
+        if (sum > LH_MAX_BITS_PER_GRANULE)
+            for (int ch = 0; ch < 2; ++ch) {
+                targ_bits[gr][ch] *= LH_MAX_BITS_PER_GRANULE;
+                targ_bits[gr][ch] /= sum;
+            }
+    }
+    if (mode_ext == LH_MPG_MD_MS_LR)
+        for (int gr = 0; gr < 2; gr++)
+            lh_reduce_side(targ_bits[gr], ms_ener_ratio[gr], mean_bits * cfg->channels, LH_MAX_BITS_PER_GRANULE);
+    totbits = 0;
+    for (int gr = 0; gr < 2; gr++)
+        for (int ch = 0; ch < 2; ch++) {
+            if (targ_bits[gr][ch] > LH_MAX_BITS_PER_CHANNEL)
+                targ_bits[gr][ch] = LH_MAX_BITS_PER_CHANNEL;
+            totbits += targ_bits[gr][ch];
+        }
+    if (totbits > max_frame_bits && totbits > 0)
+        for (int gr = 0; gr < 2; gr++)
+            for (int ch = 0; ch < 2; ch++) {
+                targ_bits[gr][ch] *= max_frame_bits;
+                targ_bits[gr][ch] /= totbits;
+            }
+}
+
 #endif

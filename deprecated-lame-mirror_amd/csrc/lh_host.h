@@ -17,9 +17,10 @@ typedef struct LhUserParams {
     int     brate;               /* kbps */
     int     mode;                /* -1 = not set (joint stereo), else LH_MODE_* */
     int     quality;             /* -1 = default (3) */
-    int     vbr;                 /* 0 = CBR, 1 / 4 = vbr_mt / vbr_mtrh (the same loop in the reference) */
+    int     vbr;                 /* 0 = CBR, 1 / 4 = vbr_mt / vbr_mtrh (the same loop in the reference), 3 = ABR */
     int     vbr_q;               /* VBR quality 0..9 (lame_set_VBR_q), default 4 */
     int     samplerate_out;      /* 0 = let the encoder choose (must come out equal to samplerate) */
+    int     abr_kbps;            /* ABR mean bitrate (lame_set_VBR_mean_bitrate_kbps), default 128 */
 } LhUserParams;
 
 /* values that only feed table generation */

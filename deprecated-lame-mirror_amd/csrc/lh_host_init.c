@@ -115,6 +115,7 @@ lh_params_default(LhUserParams * p)
     p->quality = -1;
     p->vbr = 0;
     p->vbr_q = 4;               /* reference lame.c:2360 */
+    p->abr_kbps = 128;          /* reference lame.c:2361 */
     p->samplerate_out = 0;
 }
 
@@ -417,6 +418,12 @@ config_resolve_vbr(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
     c->vbr_min_bitrate_index = 1;
     c->vbr_max_bitrate_index = 14;
     c->enforce_min_bitrate = 0;
+    {
+        /* reference lame.c:828-836 */
+        static const float cmp[10] = { 5.7, 6.5, 7.3, 8.2, 10, 11.9, 13, 14, 15, 16.5 };
+        c->compression_ratio = cmp[vbr_q];
+    }
+    c->vbr_avg_bitrate_kbps = 128;      /* VBR_mean_bitrate_kbps default, inside the MPEG-1 range */
     return 0;
 }
 
@@ -431,8 +438,8 @@ lh_config_resolve(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
     memset(aux, 0, sizeof(*aux));
     if (p->channels != 2)
         return -1;              /* mono framing is outside this path */
-    if (p->vbr != 0 && p->vbr != 1 && p->vbr != 4)
-        return -1;              /* vbr_rh / ABR loops are outside this path */
+    if (p->vbr != 0 && p->vbr != 1 && p->vbr != 3 && p->vbr != 4)
+        return -1;              /* the old VBR loop (vbr_rh) is outside this path */
     if (p->samplerate_out != 0 && p->samplerate_out != p->samplerate)
         return -1;              /* resampling is outside this path */
     switch (p->samplerate) {
@@ -464,14 +471,35 @@ lh_config_resolve(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
     aux->athaa_sensitivity = 0;
     aux->adjust_sfb21_db = 0;
     c->vbr_q = aux->vbr_q;
-    if (c->vbr != 0)
+    if (c->vbr == 1 || c->vbr == 4)
         return config_resolve_vbr(p, c, aux);
 
-    /* bitrate (reference lame.c:904-915) */
-    c->avg_bitrate = find_nearest_bitrate_mpeg1(p->brate > 0 ? p->brate : 128);
-    for (r = 1; r <= 14; r++)
-        if (lh_bitrate_mpeg1[r] == c->avg_bitrate)
-            c->bitrate_index = r;
+    if (c->vbr == 3) {
+        /* ABR: any mean bitrate; apply_abr_preset clamps it to 8..320 and leaves it in brate
+         * (reference presets.c:268-272), lame_init_params to the MPEG-1 table range (lame.c:1088-1093) */
+        int     mean = p->abr_kbps;
+        if (p->samplerate_out == 0 && (mean < 8 || mean > 320))
+            return -1;          /* the reference applies no preset at all there (presets.c:411-416) */
+        if (p->samplerate_out)
+            mean = mean < 32 ? 32 : (mean > 320 ? 320 : mean);  /* reference lame.c:654-657 */
+        mean = mean > 320 ? 320 : mean;
+        mean = mean < 8 ? 8 : mean;
+        c->avg_bitrate = mean;
+        c->bitrate_index = 1;
+        c->vbr_avg_bitrate_kbps = mean < 32 ? 32 : mean;
+        c->vbr_min_bitrate_index = 1;
+        c->vbr_max_bitrate_index = 14;
+        c->compression_ratio = c->samplerate * 16 * c->channels / (1.e3 * c->vbr_avg_bitrate_kbps);
+    }
+    else {
+        /* bitrate (reference lame.c:904-915) */
+        c->avg_bitrate = find_nearest_bitrate_mpeg1(p->brate > 0 ? p->brate : 128);
+        for (r = 1; r <= 14; r++)
+            if (lh_bitrate_mpeg1[r] == c->avg_bitrate)
+                c->bitrate_index = r;
+        c->vbr_avg_bitrate_kbps = c->avg_bitrate;       /* lame_set_VBR_mean_bitrate_kbps(brate), lame.c:1043 */
+        c->compression_ratio = c->samplerate * 16 * c->channels / (1.e3 * c->avg_bitrate);
+    }
     if (c->bitrate_index <= 0)
         return -1;
 
@@ -480,22 +508,18 @@ lh_config_resolve(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
         double  lowpass = lowpass_map[nearest_full_index(c->avg_bitrate)];
         int     lp = (int) lowpass;
         int     suggested;
+        (void) suggested;
         /* the reference would pick a lower output rate and resample for this
          * lowpass (optimum_samplefreq, reference lame.c:273-345); resampling is
          * outside this path, so such settings are refused */
-        if (2 * lp > c->samplerate)
-            lp = c->samplerate / 2;
-        suggested = (c->samplerate >= 48000) ? 48000 : (c->samplerate >= 44100) ? 44100 : 32000;
-        if (lp <= 15960)
-            suggested = 44100;
-        if (lp <= 15250)
-            suggested = 32000;
-        if (lp <= 11220)
-            suggested = 24000;
-        if (c->samplerate < suggested)
-            suggested = c->samplerate;  /* reference keeps a valid rate >= input */
-        if (suggested != c->samplerate)
-            return -1;
+        if (p->samplerate_out == 0) {
+            /* only consulted when the caller left the output rate open (reference lame.c:762-767) */
+            if (2 * lp > c->samplerate)
+                lp = c->samplerate / 2;
+            suggested = suggested_samplerate(lp, c->samplerate);
+            if (suggested != c->samplerate)
+                return -1;
+        }
         if (lp > 20500)
             lp = 20500;
         if (lp > c->samplerate / 2)
@@ -559,7 +583,7 @@ lh_config_resolve(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
     c->ATHfixpoint = 0;
     c->pcm_scale = scale;
     c->disable_reservoir = 0;
-    c->frac_SpF = (int) (((c->version + 1) * 72000L * c->avg_bitrate) % c->samplerate);
+    c->frac_SpF = (c->vbr == 0) ? (int) (((c->version + 1) * 72000L * c->avg_bitrate) % c->samplerate) : 0;
     return 0;
 }
 

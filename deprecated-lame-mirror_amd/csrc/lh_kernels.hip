@@ -260,7 +260,7 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo)
     LH_SYNC_WG();
     LH_PA(2, t_mdct);
     lh_load_qtabs(c, L.qt);     /* mf is dead; xr stays */
-    if (cfg->vbr) {
+    if (cfg->vbr == 1 || cfg->vbr == 4) {
         /* step tables of the VBR scalefactor search (over the unused second quantised image) */
         for (int i = tid; i < 256; i += LH_NT) {
             LH_VBR_IPOW20[i] = T->ipow20[i];
@@ -320,10 +320,16 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo)
     int     frame_bits = lh_frame_bits(cfg, bitrate_index, padding);
     int     mean_bits = (frame_bits - cfg->sideinfo_len * 8) / cfg->mode_gr;
     int     total_bits = 0;
-    if (cfg->vbr) {
+    int const vbr_new = (cfg->vbr == 1 || cfg->vbr == 4), abr = (cfg->vbr == 3);
+    int     abr_targ[2][2] = { {0, 0}, {0, 0} }, analog_silence_bits = 0;
+    if (vbr_new) {
         lh_vbr_frame(c, fo, pe_use, mode_ext, msoff, ResvSize, substep, bitrate_index, total_bits);
         frame_bits = lh_frame_bits(cfg, bitrate_index, 0);
         mean_bits = (frame_bits - cfg->sideinfo_len * 8) / cfg->mode_gr;
+    }
+    if (abr) {
+        int const bt[2][2] = { {L.block_type[0][0], L.block_type[0][1]}, {L.block_type[1][0], L.block_type[1][1]} };
+        lh_abr_target_bits(cfg, ResvSize, substep, pe_use, ms_ener_ratio, bt, mode_ext, abr_targ, &analog_silence_bits);
     }
     {
         /* ResvFrameBegin */
@@ -334,9 +340,11 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo)
         if (ResvMax < 0 || cfg->disable_reservoir)
             ResvMax = 0;
     }
-    for (int gr = 0; gr < 2 && !cfg->vbr; gr++) {
-        int     targ_bits[2];
-        int     max_bits = lh_on_pe(cfg, ResvSize, ResvMax, &substep, pe_use[gr], targ_bits, mean_bits, gr);
+    for (int gr = 0; gr < 2 && !vbr_new; gr++) {
+        int     targ_bits[2] = { abr_targ[gr][0], abr_targ[gr][1] };
+        int     max_bits = 0;
+        if (!abr)
+            max_bits = lh_on_pe(cfg, ResvSize, ResvMax, &substep, pe_use[gr], targ_bits, mean_bits, gr);
         LH_SYNC_WG();
         if (mode_ext == LH_MPG_MD_MS_LR) {
             float const k = (float) (LH_SQRT2 * 0.5);
@@ -346,7 +354,8 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo)
                 L.xr[0][gr][i] = (l + r) * k;
                 L.xr[1][gr][i] = (l - r) * k;
             }
-            lh_reduce_side(targ_bits, ms_ener_ratio[gr], mean_bits, max_bits);
+            if (!abr)
+                lh_reduce_side(targ_bits, ms_ener_ratio[gr], mean_bits, max_bits);
         }
         LH_SYNC_WG();
         {
@@ -370,6 +379,8 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo)
                 lh_zero_tail(c, Q, R);
                 LH_PA(4, t_q);
                 LH_PT(t_ol);
+                if (abr && !R.ath_over)
+                    targ_bits[ch] = analog_silence_bits;    /* reference quantize.c:1953-1954 */
                 (void) lh_outer_loop(c, Q, R, g, xr, ch, targ_bits[ch]);
                 LH_PA(5, t_ol);
             }
@@ -389,6 +400,19 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo)
         ResvSize -= L.bits_used[0] + L.bits_used[1];
         total_bits += L.bits_used[0] + L.bits_used[1];
         LH_SYNC_WG();
+    }
+    if (abr) {
+        /* the smallest frame that brings the reservoir back to a non-negative size
+         * (reference quantize.c:1964-1969) */
+        int     i, mb, rm;
+        for (i = cfg->vbr_min_bitrate_index; i < cfg->vbr_max_bitrate_index; i++)
+            if (lh_vbr_full_bits(cfg, i, ResvSize, &mb, &rm) >= 0)
+                break;
+        (void) lh_vbr_full_bits(cfg, i, ResvSize, &mb, &rm);
+        bitrate_index = i;
+        frame_bits = lh_frame_bits(cfg, bitrate_index, 0);
+        mean_bits = mb;
+        ResvMax = rm;
     }
     LH_PA(27, t_frame);
     /* ---- ResvFrameEnd (reference reservoir.c:238-293) ---- */
@@ -438,7 +462,7 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo)
         st->substep_shaping = substep;
         /* what the next frame's psy model finds in sv_qnt.masking_lower: the CBR loop leaves the value
          * of its last granule/channel, the VBR loop always the long-block one (reference quantize.c:1622) */
-        st->masking_lower = (cfg->vbr || L.block_type[1][1] != LH_SHORT_TYPE) ? cfg->masking_lower_long
+        st->masking_lower = (vbr_new || L.block_type[1][1] != LH_SHORT_TYPE) ? cfg->masking_lower_long
             : cfg->masking_lower_short;
         st->frame_number = st->frame_number + 1;
         if (mdb * 8 != ResvSize)

@@ -237,8 +237,8 @@ lh_tag_frame(const LhVbrTag * v, const LhConfig * c, int vbr_q, int enc_padding,
         k += 4;
         memcpy(p + k, "LAME3.99r", 9);  /* get_lame_tag_encoder_short_version() of 3.99.5 */
         k += 9;
-        /* tag revision 0 + method (vbr_type_translator, reference VbrTag.c:646): 1 CBR, 5 vbr_mt, 4 vbr_mtrh */
-        p[k++] = (unsigned char) (c->vbr == 0 ? 1 : (c->vbr == 1 ? 5 : 4));
+        /* tag revision 0 + method (vbr_type_translator, reference VbrTag.c:646): 1 CBR, 5 vbr_mt, 2 ABR, 4 vbr_mtrh */
+        p[k++] = (unsigned char) (c->vbr == 0 ? 1 : (c->vbr == 1 ? 5 : (c->vbr == 3 ? 2 : 4)));
         p[k++] = lowpass;
         put_i4(p + k, 0);               /* peak signal amplitude: not measured */
         k += 4;
@@ -248,8 +248,9 @@ lh_tag_frame(const LhVbrTag * v, const LhConfig * c, int vbr_q, int enc_padding,
         k += 2;
         p[k++] = (unsigned char) (ath_type + (1 << 4) + (safe_joint << 5));
         {
-            /* CBR: the bit rate; VBR: the lowest allowed one (reference VbrTag.c:679-693) */
-            int const abr = (c->vbr == 0) ? c->avg_bitrate : lh_tag_bitrate_mpeg1[c->vbr_min_bitrate_index];
+            /* CBR: the bit rate; ABR: the mean; VBR: the lowest allowed one (reference VbrTag.c:679-693) */
+            int const abr = (c->vbr == 0) ? c->avg_bitrate : (c->vbr == 3) ? c->vbr_avg_bitrate_kbps
+                : lh_tag_bitrate_mpeg1[c->vbr_min_bitrate_index];
             p[k++] = (unsigned char) (abr >= 255 ? 0xFF : abr);
         }
         p[k] = (unsigned char) (LH_ENCDELAY >> 4);
@@ -260,7 +261,7 @@ lh_tag_frame(const LhVbrTag * v, const LhConfig * c, int vbr_q, int enc_padding,
         p[k++] = 0;                     /* MP3 gain */
         /* preset: apply_preset(brate) leaves the bit rate here (presets.c:361, lame.c:1045);
          * the VBR path applies V0..V9 = 500 - 10 q (lame.c:983) */
-        put_i2(p + k, c->vbr == 0 ? c->avg_bitrate : 500 - 10 * c->vbr_q);
+        put_i2(p + k, (c->vbr == 0 || c->vbr == 3) ? c->avg_bitrate : 500 - 10 * c->vbr_q);
         k += 2;
         put_i4(p + k, (uint32_t) music_length);
         k += 4;

@@ -76,14 +76,17 @@ class Encoder:
     """One stream behind the lame.h call sequence."""
 
     def __init__(self, samplerate=44100, brate=128, mode=None, quality=None, require_device=True, write_tag=False,
-                 vbr_q=None, out_samplerate=0):
+                 vbr_q=None, out_samplerate=0, abr=None):
         self.lib = load_library()
         self.h = C.c_void_p(self.lib.lame_init())
         self.lib.lame_set_in_samplerate(self.h, samplerate)
         if out_samplerate:
             self.lib.lame_set_out_samplerate(self.h, out_samplerate)
         self.lib.lame_set_num_channels(self.h, 2)
-        if vbr_q is None:
+        if abr is not None:         # ABR at a mean bitrate of `abr' kb/s (the reference's --abr n)
+            self.lib.lame_set_VBR(self.h, 3)
+            self.lib.lame_set_VBR_mean_bitrate_kbps(self.h, abr)
+        elif vbr_q is None:
             self.lib.lame_set_brate(self.h, brate)
         else:                       # vbr_mtrh at quality vbr_q (the reference's -V n)
             self.lib.lame_set_VBR(self.h, 4)

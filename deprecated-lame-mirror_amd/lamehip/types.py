@@ -20,7 +20,7 @@ class LhConfig(C.Structure):
         ("masking_lower_long", C.c_float), ("masking_lower_short", C.c_float),
         ("pcm_scale", C.c_float), ("interChRatio", C.c_float),
         ("vbr_q", C.c_int), ("vbr_min_bitrate_index", C.c_int), ("vbr_max_bitrate_index", C.c_int),
-        ("enforce_min_bitrate", C.c_int)]
+        ("enforce_min_bitrate", C.c_int), ("vbr_avg_bitrate_kbps", C.c_int), ("compression_ratio", C.c_float)]
 
 
 class LhPsyBand(C.Structure):
@@ -80,7 +80,7 @@ class LhFrameOut(C.Structure):
 
 
 class LhUserParams(C.Structure):
-    _fields_ = [(n, C.c_int) for n in "samplerate channels brate mode quality vbr vbr_q samplerate_out".split()]
+    _fields_ = [(n, C.c_int) for n in "samplerate channels brate mode quality vbr vbr_q samplerate_out abr_kbps".split()]
 
 
 class LhInitAux(C.Structure):

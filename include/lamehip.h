@@ -11,7 +11,7 @@
  * of handles.
  *
  * Everything here is plain C: pointers and sizes only, no torch / HIP types.
- * Unsupported settings (mono, ABR / old VBR, MPEG-2 rates, resampling) make
+ * Unsupported settings (mono, the old VBR loop, MPEG-2 rates, resampling) make
  * lame_init_params() return -1 instead of silently taking another path, and
  * every call fails with LAMEHIP_ERR_NODEVICE when no HIP device is present --
  * there is no CPU fallback inside this library.
@@ -56,10 +56,12 @@ int     lame_set_mode(lame_t, MPEG_mode);                            /* lame.h:2
 MPEG_mode lame_get_mode(const lame_t);                               /* lame.h:271 */
 int     lame_set_quality(lame_t, int);                               /* lame.h:263 */
 int     lame_get_quality(const lame_t);                              /* lame.h:264 */
-int     lame_set_VBR(lame_t, vbr_mode);                              /* lame.h:432 (vbr_off, vbr_mt / vbr_mtrh) */
+int     lame_set_VBR(lame_t, vbr_mode);                              /* lame.h:432 (vbr_off, vbr_abr, vbr_mt / vbr_mtrh) */
 vbr_mode lame_get_VBR(const lame_t);                                 /* lame.h:433 */
 int     lame_set_VBR_q(lame_t, int);                                 /* lame.h:436 (0 best .. 9; default 4) */
 int     lame_get_VBR_q(const lame_t);                                /* lame.h:437 */
+int     lame_set_VBR_mean_bitrate_kbps(lame_t, int);                 /* lame.h:444 (ABR mean, with lame_set_VBR(vbr_abr)) */
+int     lame_get_VBR_mean_bitrate_kbps(const lame_t);                /* lame.h:445 */
 int     lame_set_bWriteVbrTag(lame_t, int);                          /* lame.h:240 (default 1, as in the reference) */
 int     lame_get_bWriteVbrTag(const lame_t);                         /* lame.h:241 */
 int     lame_set_findReplayGain(lame_t, int);                        /* lame.h:296 (accepted, ignored) */

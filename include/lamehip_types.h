@@ -72,7 +72,7 @@ typedef struct LhConfig {
     int     mode;                 /* LH_MODE_* */
     int     mode_gr;              /* 2 */
     int     channels;             /* 2 */
-    int     vbr;                  /* 0 = vbr_off (CBR), 1 / 4 = vbr_mt / vbr_mtrh */
+    int     vbr;                  /* 0 = vbr_off (CBR), 1 / 4 = vbr_mt / vbr_mtrh, 3 = vbr_abr */
     int     quality;
     int     noise_shaping;
     int     noise_shaping_amp;
@@ -113,6 +113,9 @@ typedef struct LhConfig {
     int     vbr_min_bitrate_index;
     int     vbr_max_bitrate_index;
     int     enforce_min_bitrate;
+    /* ABR */
+    int     vbr_avg_bitrate_kbps;
+    float   compression_ratio;
 } LhConfig;
 
 /* partition -> scalefactor-band mapping, PsyConst_CB2SB_t (reference util.h:188-203) */

@@ -6,4 +6,5 @@
 #include "orc_mdct.c"
 #include "orc_quant.c"
 #include "orc_vbr.c"
+#include "orc_abr.c"
 #include "orc_frame.c"

@@ -139,6 +139,7 @@ void    orc_mdct_sub48(OrcStream * S, const float *w0, const float *w1);
 /* orc_quant.c */
 void    orc_cbr_iteration_loop(OrcStream * S, float pe[2][2], const float ms_ener_ratio[2],
                                const OrcRatio ratio[2][2]);
+void    orc_abr_iteration_loop(OrcStream * S, float pe[2][2], const float ms_ener_ratio[2], const OrcRatio ratio[2][2]);
 void    orc_vbr_new_iteration_loop(OrcStream * S, float pe[2][2], const OrcRatio ratio[2][2]);
 float   orc_ath_adjust(const LhTables * t, float a, float x, float athFloor, float ATHfixpoint);
 

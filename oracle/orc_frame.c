@@ -257,7 +257,9 @@ orc_encode_frame(OrcStream * S, const float *inbuf_l, const float *inbuf_r, LhFr
                 pe_use[gr][ch] *= f;
     }
     mdb_header = S->main_data_begin;
-    if (cfg->vbr)
+    if (cfg->vbr == 3)
+        orc_abr_iteration_loop(S, pe_use, ms_ener_ratio, masking);
+    else if (cfg->vbr)
         orc_vbr_new_iteration_loop(S, pe_use, masking);
     else
         orc_cbr_iteration_loop(S, pe_use, ms_ener_ratio, masking);

@@ -119,6 +119,34 @@ refh_open_vbr(int samplerate, int vbr_q, int mode, int quality, int out_samplera
     return h;
 }
 
+/* ABR at `mean_kbps' (vbr_abr) */
+void   *
+refh_open_abr(int samplerate, int mean_kbps, int mode, int quality, int out_samplerate, int tag)
+{
+    RefH   *h = (RefH *) calloc(1, sizeof(RefH));
+    h->gfp = lame_init();
+    lame_set_errorf(h->gfp, quiet);
+    lame_set_debugf(h->gfp, quiet);
+    lame_set_msgf(h->gfp, quiet);
+    lame_set_in_samplerate(h->gfp, samplerate);
+    if (out_samplerate > 0)
+        lame_set_out_samplerate(h->gfp, out_samplerate);
+    lame_set_num_channels(h->gfp, 2);
+    lame_set_VBR(h->gfp, vbr_abr);
+    lame_set_VBR_mean_bitrate_kbps(h->gfp, mean_kbps);
+    lame_set_bWriteVbrTag(h->gfp, tag);
+    if (mode >= 0)
+        lame_set_mode(h->gfp, (MPEG_mode) mode);
+    if (quality >= 0)
+        lame_set_quality(h->gfp, quality);
+    if (lame_init_params(h->gfp) < 0) {
+        lame_close(h->gfp);
+        free(h);
+        return 0;
+    }
+    return h;
+}
+
 int
 refh_lametag(void *hh, unsigned char *out, int outsize)
 {
@@ -422,6 +450,8 @@ refh_get_config(void *hh, LhConfig * c)
         c->vbr_max_bitrate_index = cfg->vbr_max_bitrate_index;
         c->enforce_min_bitrate = cfg->enforce_min_bitrate;
     }
+    c->vbr_avg_bitrate_kbps = cfg->vbr_avg_bitrate_kbps;
+    c->compression_ratio = cfg->compression_ratio;
 }
 
 static void

@@ -44,6 +44,16 @@ VBR_CASES = [
 ]
 
 
+ABR_CASES = [
+    # name, samplerate, mean kb/s (--abr n), mode, quality, seed, seconds, burst_interval, white
+    ("abr128_js_44k", 44100, 128, -1, -1, 301, 1.2, None, False),
+    ("abr200_st_48k_bursts", 48000, 200, 0, -1, 302, 1.0, 1.0 / 40, False),
+    ("abr150_js_32k_white_q5", 32000, 150, -1, 5, 303, 0.8, None, True),
+    ("abr320_js_44k_q0", 44100, 320, -1, 0, 304, 0.8, None, False),
+    ("abr112_js_44k_silence", 44100, 112, -1, -1, -1, 0.5, None, False),
+]
+
+
 def frame_hash(fr):
     return hashlib.sha256(bytes(fr)).hexdigest()
 
@@ -75,13 +85,19 @@ def main():
         nn = int(sr * secs)
         x = np.zeros((2, nn), np.int16) if seed < 0 else helpers.synth_stream(seed, nn, sr, burst, white)
         cases.append((name, sr, 0, mode, q, (seed, secs, burst, white), x, vq))
-    for name, sr, br, mode, q, recipe, x, vq in cases:
-        mp3, nf, frames, cfg, tab = ref.encode(x, sr, br, mode, q, max_frames=4096, vbr_q=None if vq < 0 else vq)
+    cases = [c + (-1,) for c in cases]
+    for name, sr, kb, mode, q, seed, secs, burst, white in ABR_CASES:
+        nn = int(sr * secs)
+        x = np.zeros((2, nn), np.int16) if seed < 0 else helpers.synth_stream(seed, nn, sr, burst, white)
+        cases.append((name, sr, 0, mode, q, (seed, secs, burst, white), x, -1, kb))
+    for name, sr, br, mode, q, recipe, x, vq, abr in cases:
+        mp3, nf, frames, cfg, tab = ref.encode(x, sr, br, mode, q, max_frames=4096, vbr_q=None if vq < 0 else vq,
+                                               abr=None if abr < 0 else abr)
         hashes = [frame_hash(frames[f]) for f in range(nf)]
         th = table_hashes(tab)
         np.savez_compressed(
             os.path.join(HERE, name + ".npz"),
-            samplerate=sr, brate=br, mode=mode, quality=q, vbr_q=vq,
+            samplerate=sr, brate=br, mode=mode, quality=q, vbr_q=vq, abr=abr,
             recipe=np.array([-2 if recipe is None else recipe[0],
                              0 if recipe is None else recipe[1],
                              0 if (recipe is None or recipe[2] is None) else recipe[2],

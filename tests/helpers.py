@@ -84,14 +84,17 @@ class Reference:
         self.lib = C.CDLL(REF_SO)
         self.lib.refh_open.restype = C.c_void_p
         self.lib.refh_open_vbr.restype = C.c_void_p
+        self.lib.refh_open_abr.restype = C.c_void_p
         self.lib.refh_encode_stream.restype = C.c_long
 
-    def encode(self, pcm, sr, brate, mode=-1, quality=-1, max_frames=0, vbr_q=None, out_samplerate=0):
-        """CBR at `brate', or vbr_mtrh at quality vbr_q when that is given."""
+    def encode(self, pcm, sr, brate, mode=-1, quality=-1, max_frames=0, vbr_q=None, out_samplerate=0, abr=None):
+        """CBR at `brate', vbr_mtrh at quality vbr_q, or ABR at a mean of `abr' kb/s."""
         left = np.ascontiguousarray(pcm[0], dtype=np.int16)
         right = np.ascontiguousarray(pcm[1], dtype=np.int16)
         n = len(left)
-        if vbr_q is None:
+        if abr is not None:
+            h = self.lib.refh_open_abr(sr, abr, mode, quality, out_samplerate, 0)
+        elif vbr_q is None:
             h = self.lib.refh_open(sr, brate, mode, quality)
         else:
             h = self.lib.refh_open_vbr(sr, vbr_q, mode, quality, out_samplerate, 0)
@@ -111,13 +114,15 @@ class Reference:
         return buf.raw[:k], nf.value, frames, cfg, tab
 
 
-def reference_tagged(pcm, sr, brate, mode=-1, quality=-1, chunk=1152, vbr_q=None):
+def reference_tagged(pcm, sr, brate, mode=-1, quality=-1, chunk=1152, vbr_q=None, abr=None):
     """The compiled reference with its default tag handling (bWriteVbrTag = 1): returns
     (stream bytes incl. the placeholder frame, final tag frame).  vbr_q selects vbr_mtrh."""
     ref = Reference()
     lib = ref.lib
     lib.refh_open_tag.restype = C.c_void_p
-    if vbr_q is None:
+    if abr is not None:
+        h = lib.refh_open_abr(sr, abr, mode, quality, 0, 1)
+    elif vbr_q is None:
         h = lib.refh_open_tag(sr, brate, mode, quality)
     else:
         h = lib.refh_open_vbr(sr, vbr_q, mode, quality, sr if vbr_q >= 7 else 0, 1)
@@ -164,9 +169,14 @@ def normalize_tables(frames):
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
 
-def golden_names(vbr=False):
-    """CBR fixtures by default; vbr=True lists the vbr_mtrh ones ("vbr" in the name)."""
-    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and (("vbr" in f) == bool(vbr)))
+def golden_names(vbr=False, kind=None):
+    """Fixtures by rate control: CBR by default, vbr=True / kind="vbr" the vbr_mtrh ones, kind="abr"
+    the ABR ones (the kind is in the file name)."""
+    kind = kind or ("vbr" if vbr else "cbr")
+
+    def k(f):
+        return "vbr" if "vbr" in f else ("abr" if "abr" in f else "cbr")
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and k(f) == kind)
 
 
 def load_golden(name):
@@ -196,6 +206,12 @@ def golden_settings(g):
 def golden_vbr_q(g):
     """None for a CBR fixture, else the vbr_mtrh quality (-V n) it was made with."""
     v = int(g["vbr_q"]) if "vbr_q" in g else -1
+    return None if v < 0 else v
+
+
+def golden_abr(g):
+    """None, or the mean bitrate of an ABR fixture."""
+    v = int(g["abr"]) if "abr" in g else -1
     return None if v < 0 else v
 
 

@@ -2,8 +2,9 @@
 """Settings sweep on the GPU box (test tool, not collected by pytest): every MPEG-1 bit rate x
 sample rate x stereo mode x a set of quality levels that lame_init_params accepts, a few
 awkward signals each, HIP payload against the CPU oracle frame by frame.
-Usage: python tests/sweep_gpu.py [streams_per_setting] [seconds] [cbr|vbr|all]
-"vbr": vbr_mtrh -V0..-V9 x sample rate x stereo mode x quality 0 / 5 instead of the CBR grid."""
+Usage: python tests/sweep_gpu.py [streams_per_setting] [seconds] [cbr|vbr|abr|all]
+"vbr": vbr_mtrh -V0..-V9 x sample rate x stereo mode x quality 0 / 5 instead of the CBR grid;
+"abr": ABR means (incl. values between the table rates) x sample rate x mode x quality 0 / 3 / 5 / 7."""
 import os
 import sys
 import time
@@ -27,12 +28,16 @@ def main():
     cbr_grid = [(br, q) for br in (32, 40, 48, 56, 64, 80, 96, 112, 128, 160, 192, 224, 256, 320)
                 for q in (0, 2, 3, 5, 7, 9)] if what in ("cbr", "all") else []
     vbr_grid = [(-vq, q) for vq in range(10) for q in (0, 5)] if what in ("vbr", "all") else []
+    abr_grid = [(1000 + kb, q) for kb in (96, 100, 112, 128, 150, 160, 192, 215, 256, 320)
+                for q in (0, 3, 5, 7)] if what in ("abr", "all") else []
     for sr in (32000, 44100, 48000):
-        for br, q in cbr_grid + vbr_grid:       # br <= 0: vbr_mtrh at quality -br
+        for br, q in cbr_grid + vbr_grid + abr_grid:    # br <= 0: vbr_mtrh at quality -br; >= 1000: ABR
             for mode in (0, 1):
                 for _once in (0,):
                     try:
-                        if br > 0:
+                        if br >= 1000:
+                            enc = lamehip.Encoder(sr, mode=mode, quality=q, abr=br - 1000)
+                        elif br > 0:
                             enc = lamehip.Encoder(sr, br, mode, q)
                         else:
                             enc = lamehip.Encoder(sr, mode=mode, quality=q, vbr_q=-br,

@@ -35,7 +35,6 @@ def test_unsupported_settings_are_refused_loudly():
     lib = lamehip.load_library()
     for setup in (lambda h: lib.lame_set_num_channels(h, 1),          # mono
                   lambda h: lib.lame_set_VBR(h, 2),                   # vbr_rh (old VBR loop)
-                  lambda h: lib.lame_set_VBR(h, 3),                   # ABR
                   lambda h: lib.lame_set_in_samplerate(h, 22050),     # MPEG-2
                   lambda h: lib.lame_set_brate(h, 64)):               # reference would resample to 24 kHz
         h = C.c_void_p(lib.lame_init())

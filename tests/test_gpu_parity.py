@@ -21,14 +21,14 @@ def test_wave_primitives_selftest():
 
 def _encoder(g, **kw):
     sr, br, mode, q = helpers.golden_settings(g)
-    return lamehip.Encoder(sr, br, mode, q, vbr_q=helpers.golden_vbr_q(g), **kw)
+    return lamehip.Encoder(sr, br, mode, q, vbr_q=helpers.golden_vbr_q(g), abr=helpers.golden_abr(g), **kw)
 
 
 # the closed-form scalefactor guess of VBR at -q 7 has no device kernel (lame_init_params refuses it)
 VBR_GOLDEN = [n for n in helpers.golden_names(vbr=True) if not n.endswith("_q7")]
 
 
-@pytest.mark.parametrize("name", helpers.golden_names() + VBR_GOLDEN)
+@pytest.mark.parametrize("name", helpers.golden_names() + VBR_GOLDEN + helpers.golden_names(kind="abr"))
 def test_batch_payload_and_bytes_match_golden(name):
     g, pcm = helpers.load_golden(name)
     enc = _encoder(g)
@@ -52,7 +52,8 @@ def test_batch_payload_and_bytes_match_golden(name):
 @pytest.mark.parametrize("name,chunk", [("testcase_wav_cbr128", 1152), ("cbr128_js_44k", 777),
                                         ("cbr320_js_48k_bursts", 4000), ("cbr128_js_44k_silence", 1),
                                         ("testcase_wav_vbr2", 1152), ("vbr4_js_44k_white", 2500),
-                                        ("vbr0_js_48k_bursts", 600)])
+                                        ("vbr0_js_48k_bursts", 600), ("abr128_js_44k", 1152),
+                                        ("abr200_st_48k_bursts", 3000)])
 def test_lame_encode_buffer_call_sequence(name, chunk):
     """lame_init -> set -> init_params -> N x lame_encode_buffer -> flush, as the
     reference frontend drives it (frontend/lame_main.c:381-470)."""
@@ -300,6 +301,31 @@ def test_vbr_batch_matches_oracle(sr, vq, mode, seed, white, oracle):
     lens = [int(sr * 1.3), int(sr * 0.4) + 17, 1, int(sr * 0.9)]
     out = sr if vq >= 7 else 0
     enc = lamehip.Encoder(sr, mode=mode, vbr_q=vq, out_samplerate=out)
+    cfg, tab = enc.config(), enc.tables()
+    b = lamehip.Batch(enc, len(lens), max(lens))
+    pcms = [helpers.synth_stream(seed * 10 + i, n, sr, 1.0 / 9, white and i == 0) for i, n in enumerate(lens)]
+    for i, x in enumerate(pcms):
+        b.set_pcm(i, x[0], x[1])
+    b.encode()
+    for i, x in enumerate(pcms):
+        want = oracle.encode_frames(cfg, tab, x)
+        got = b.get_frames(i)
+        assert len(got) == len(want)
+        for f in range(len(want)):
+            d = struct_diff(want[f], got[f])
+            assert not d, (i, f, d[:4])
+        assert b.pack(i) == helpers.pack_frames(enc.lib, cfg, tab, want)
+    b.close()
+    enc.close()
+
+
+@pytest.mark.parametrize("sr,kb,mode,q,seed,white", [(44100, 128, None, None, 41, False), (48000, 245, 0, None, 42, False),
+                                                     (32000, 100, None, 5, 43, True), (44100, 320, None, 0, 44, False),
+                                                     (44100, 160, None, 7, 45, False)])
+def test_abr_batch_matches_oracle(sr, kb, mode, q, seed, white, oracle):
+    """ABR (--abr n) streams of different lengths in one launch against the CPU oracle."""
+    lens = [int(sr * 1.1), int(sr * 0.35) + 5, 1, int(sr * 0.8)]
+    enc = lamehip.Encoder(sr, mode=mode, quality=q, abr=kb)
     cfg, tab = enc.config(), enc.tables()
     b = lamehip.Batch(enc, len(lens), max(lens))
     pcms = [helpers.synth_stream(seed * 10 + i, n, sr, 1.0 / 9, white and i == 0) for i, n in enumerate(lens)]

@@ -17,20 +17,21 @@ class LhVbrTag(C.Structure):
                 ("num_frames", C.c_uint), ("bytes_written", C.c_ulong), ("music_crc", C.c_uint16)]
 
 
-@pytest.mark.parametrize("sr,br,mode,q,secs,vq", [(44100, 128, -1, -1, 0.567, None), (48000, 320, 1, -1, 1.3, None),
-                                                   (32000, 96, -1, -1, 2.0, None), (44100, 192, 0, 2, 0.9, None),
-                                                   (44100, 128, -1, 7, 13.0, None), (44100, 0, -1, -1, 1.1, 2),
-                                                   (48000, 0, 0, 5, 0.8, 0), (32000, 0, -1, -1, 0.9, 6),
-                                                   (44100, 0, -1, -1, 12.0, 8)])
-def test_tag_module_matches_reference(sr, br, mode, q, secs, vq):
+@pytest.mark.parametrize("sr,br,mode,q,secs,vq,abr", [(44100, 128, -1, -1, 0.567, None, None), (48000, 320, 1, -1, 1.3, None, None),
+                                                       (32000, 96, -1, -1, 2.0, None, None), (44100, 192, 0, 2, 0.9, None, None),
+                                                       (44100, 128, -1, 7, 13.0, None, None), (44100, 0, -1, -1, 1.1, 2, None),
+                                                       (48000, 0, 0, 5, 0.8, 0, None), (32000, 0, -1, -1, 0.9, 6, None),
+                                                       (44100, 0, -1, -1, 12.0, 8, None), (44100, 0, -1, -1, 1.0, None, 150),
+                                                       (48000, 0, 0, 5, 0.8, None, 313)])
+def test_tag_module_matches_reference(sr, br, mode, q, secs, vq, abr):
     """Feed the reference's own audio bytes and frame count through the tag bookkeeping: the
     placeholder and the final tag frame must be the reference's, byte for byte.  (13 s = 498
     frames also exercises the halving of the 400-entry seek-point bag.)"""
     n = int(sr * secs)
     pcm = helpers.synth_stream(4242 + br, n, sr, 1.0 / 5)
-    stream, tag = helpers.reference_tagged(pcm, sr, br, mode, q, vbr_q=vq)
+    stream, tag = helpers.reference_tagged(pcm, sr, br, mode, q, vbr_q=vq, abr=abr)
     enc = lamehip.Encoder(sr, br, None if mode < 0 else mode, None if q < 0 else q, require_device=False, vbr_q=vq,
-                          out_samplerate=sr if (vq or 0) >= 7 else 0)
+                          out_samplerate=sr if (vq or 0) >= 7 else 0, abr=abr)
     cfg = enc.config()
     lib = enc.lib
     v = LhVbrTag()
@@ -84,19 +85,19 @@ def test_api_default_tag_handling_matches_reference(sr, br, mode, chunk, vq):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("vq", [None, 2])
-def test_batch_pack_tagged_is_the_reference_file_image(vq):
+@pytest.mark.parametrize("vq,abr", [(None, None), (2, None), (None, 180)])
+def test_batch_pack_tagged_is_the_reference_file_image(vq, abr):
     """Batch path: tag frame + audio == the reference's stream with its placeholder replaced by
     its final tag frame (what the frontend leaves on disk)."""
     sr, br = 44100, 128
     pcms = [helpers.synth_stream(777 + i, int(sr * (0.8 + 0.37 * i)), sr, 1.0 / 4) for i in range(4)]
-    enc = lamehip.Encoder(sr, br, vbr_q=vq)
+    enc = lamehip.Encoder(sr, br, vbr_q=vq, abr=abr)
     b = lamehip.Batch(enc, len(pcms), max(x.shape[1] for x in pcms))
     for s, x in enumerate(pcms):
         b.set_pcm(s, x[0], x[1])
     b.encode()
     for s, x in enumerate(pcms):
-        stream, tag = helpers.reference_tagged(x, sr, br, vbr_q=vq)
+        stream, tag = helpers.reference_tagged(x, sr, br, vbr_q=vq, abr=abr)
         assert b.pack_tagged(s) == tag + stream[len(tag):]
     b.close()
     enc.close()

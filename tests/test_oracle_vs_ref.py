@@ -63,6 +63,32 @@ def test_vbr_oracle_matches_reference(sr, vq, mode, q, seed, secs, white, oracle
     enc.close()
 
 
+ABR_CASES = [(44100, 128, None, None, 51, 1.5, False), (48000, 200, 0, None, 52, 1.2, False),
+             (32000, 96, None, 5, 53, 1.2, True), (44100, 313, None, 0, 54, 1.0, False), (44100, 150, 1, 7, 55, 1.2, False)]
+
+
+@pytest.mark.parametrize("sr,kb,mode,q,seed,secs,white", ABR_CASES)
+def test_abr_oracle_matches_reference(sr, kb, mode, q, seed, secs, white, oracle, reference):
+    """ABR (--abr n): config, tables, every frame's payload incl. the chosen bitrate, final bytes."""
+    pcm = helpers.synth_stream(seed, int(sr * secs), sr, 1.0 / 7, white)
+    mp3, nf, rframes, rcfg, rtab = reference.encode(pcm, sr, 0, -1 if mode is None else mode,
+                                                    -1 if q is None else q, max_frames=2048, abr=kb)
+    enc = lamehip.Encoder(sr, mode=mode, quality=q, require_device=False, abr=kb)
+    cfg, tab = enc.config(), enc.tables()
+    assert not struct_diff(rcfg, cfg, skip=("bitrate_index",))      # run-time state outside CBR
+    assert not struct_diff(rtab, tab, skip=("fft_window", "fft_window_s", "fht_tw", "ma_max_i1", "ma_max_i2",
+                                            "psy_l_to_s"))
+    frames = oracle.encode_frames(cfg, tab, pcm)
+    assert len(frames) == nf
+    mine = helpers.pack_frames(enc.lib, cfg, tab, frames)
+    helpers.normalize_tables(frames)
+    for f in range(nf):
+        d = struct_diff(rframes[f], frames[f], skip=("frame_bits",))
+        assert not d, (f, d[:4])
+    assert mine == mp3
+    enc.close()
+
+
 def test_odd_lengths_and_flush_framing(oracle, reference):
     for n in (1, 500, 1151, 1152, 1153, 1152 * 3, 1152 * 3 + 17, 5000):
         pcm = helpers.synth_stream(n, n)
