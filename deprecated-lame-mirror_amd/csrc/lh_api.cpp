@@ -274,13 +274,6 @@ lame_init_params(lame_t g)
         g->have_device = 0;
         return LAMEHIP_ERR_NODEVICE;
     }
-    if (g->cfg.vbr != 0 && g->cfg.full_outer_loop < 0) {
-        /* -q 7..9 in VBR mode replaces the scalefactor search by a closed form around log10f;
-         * that variant has no device kernel (constants and tables are resolved all the same) */
-        snprintf(g_err, sizeof(g_err), "vbr_mtrh with quality >= 7 is outside the accelerated path");
-        g->have_device = 0;
-        return -1;
-    }
     {
         int     rc = g->dc.upload(g->cfg, *g->tab);
         LhStreamState s0;

@@ -203,4 +203,90 @@ lh_fast_log2(const float *log_table, float x)
 
 #define LH_LOG2_OVER_LOG10 (0.69314718055994530942 / 2.30258509299404568402)
 
+/* ---- logf / log10f as the host libm computes them (glibc 2.35: logf = the table-driven double
+ * evaluation of sysdeps/ieee754/flt-32/e_logf.c, FMA variant; log10f = the fdlibm formula
+ * around it, e_log10f.c).  The VBR loop's quality-7 scalefactor guess truncates
+ * c * log10f(xmin / bw) to an integer, so the last bit matters (reference vbrquantize.c:315-333).
+ * tests/test_powf.py sweeps both against the host. */
+LH_DEVCONST uint64_t lh_logf_tab[32] = {
+    0x3ff661ec79f8f3beull, 0xbfd57bf7808caadeull,
+    0x3ff571ed4aaf883dull, 0xbfd2bef0a7c06ddbull,
+    0x3ff49539f0f010b0ull, 0xbfd01eae7f513a67ull,
+    0x3ff3c995b0b80385ull, 0xbfcb31d8a68224e9ull,
+    0x3ff30d190c8864a5ull, 0xbfc6574f0ac07758ull,
+    0x3ff25e227b0b8ea0ull, 0xbfc1aa2bc79c8100ull,
+    0x3ff1bb4a4a1a343full, 0xbfba4e76ce8c0e5eull,
+    0x3ff12358f08ae5baull, 0xbfb1973c5a611cccull,
+    0x3ff0953f419900a7ull, 0xbfa252f438e10c1eull,
+    0x3ff0000000000000ull, 0x0000000000000000ull,
+    0x3fee608cfd9a47acull, 0x3faaa5aa5df25984ull,
+    0x3feca4b31f026aa0ull, 0x3fbc5e53aa362eb4ull,
+    0x3feb2036576afce6ull, 0x3fc526e57720db08ull,
+    0x3fe9c2d163a1aa2dull, 0x3fcbc2860d224770ull,
+    0x3fe886e6037841edull, 0x3fd1058bc8a07ee1ull,
+    0x3fe767dcf5534862ull, 0x3fd4043057b6ee09ull
+};
+
+LH_DEVFN float
+lh_logf(float x)
+{
+    uint32_t ix = lh_f32_as_u32(x);
+    if (ix == 0x3f800000u)
+        return 0.0f;
+    if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) {
+        if (ix * 2u == 0u)
+            return -__builtin_inff();
+        if (ix == 0x7f800000u)
+            return x;
+        if ((ix & 0x80000000u) || ix * 2u >= 0xff000000u)
+            return __builtin_nanf("");
+        ix = lh_f32_as_u32(x * 0x1p23f);        /* subnormal: normalise */
+        ix -= 23u << 23;
+    }
+    {
+        uint32_t const tmp = ix - 0x3f330000u;
+        int const i = (int) ((tmp >> 19) % 16u);
+        int const k = (int32_t) tmp >> 23;
+        uint32_t const iz = ix - (tmp & (0x1ffu << 23));
+        double const z = (double) lh_u32_as_f32(iz);
+        double const invc = lh_u64_as_f64(lh_logf_tab[2 * i]), logc = lh_u64_as_f64(lh_logf_tab[2 * i + 1]);
+        double const A0 = lh_u64_as_f64(0xbfd00ea348b88334ull), A1 = lh_u64_as_f64(0x3fd5575b0be00b6aull), A2 = lh_u64_as_f64(0xbfdffffef20a4123ull);
+        double const Ln2 = lh_u64_as_f64(0x3fe62e42fefa39efull);
+        double const r = lh_fma(z, invc, -1.0);
+        double const y0 = lh_fma((double) k, Ln2, logc);
+        double const r2 = r * r;
+        double  y = lh_fma(A1, r, A2);
+        y = lh_fma(A0, r2, y);
+        y = lh_fma(y, r2, y0 + r);
+        return (float) y;
+    }
+}
+
+LH_DEVFN float
+lh_log10f(float x)
+{
+    float const two25 = 3.3554432000e+07f, ivln10 = 4.3429449201e-01f, log10_2hi = 3.0102920532e-01f,
+        log10_2lo = 7.9034151668e-07f;
+    int32_t hx = (int32_t) lh_f32_as_u32(x), k = 0, i;
+    float   y, z;
+    if (hx < 0x00800000) {
+        if ((hx & 0x7fffffff) == 0)
+            return -__builtin_inff();
+        if (hx < 0)
+            return __builtin_nanf("");
+        k -= 25;
+        x *= two25;
+        hx = (int32_t) lh_f32_as_u32(x);
+    }
+    if (hx >= 0x7f800000)
+        return x + x;
+    k += (hx >> 23) - 127;
+    i = (int32_t) (((uint32_t) k & 0x80000000u) >> 31);
+    hx = (hx & 0x007fffff) | ((0x7f - i) << 23);
+    y = (float) (k + i);
+    x = lh_u32_as_f32((uint32_t) hx);
+    z = y * log10_2lo + ivln10 * lh_logf(x);
+    return z + y * log10_2hi;
+}
+
 #endif

@@ -316,6 +316,14 @@ lh_vbr_band_steps(const LhCtx & c, LhChanLds & Q, const LhQR & R, const LhVbrGeo
         /* find_scalefac_x34 (reference vbrquantize.c:347-382), all bands at once; the memo of the
          * reference only saves work, the noise of a step is a pure function */
         int     sf = 128, ok = 255, del = 128, seen = 0;
+        if (c.full_outer_loop < 0) {
+            /* quality 7..9: closed-form estimate instead of the search (calc_scalefac +
+             * guess_scalefac_x34, reference vbrquantize.c:315-333) */
+            float const cc = 5.799142446f;
+            int const gs = 210 + (int) (cc * lh_log10f(xmin / (float) (G.n > 0 ? G.n : 1)) - .5f);
+            sf = gs < m1 ? m1 : (gs >= 255 ? 255 : gs);
+        }
+        else
         for (int k = 0; k < 8; k++) {
             int const skip = (sf <= m1);
             int const need = active && !skip;
@@ -353,10 +361,12 @@ lh_vbr_band_steps(const LhCtx & c, LhChanLds & Q, const LhQR & R, const LhVbrGeo
                 seen = 1;
             }
         }
-        if (seen)
-            sf = ok;
-        if (sf <= m1)
-            sf = m1;
+        if (c.full_outer_loop >= 0) {
+            if (seen)
+                sf = ok;
+            if (sf <= m1)
+                sf = m1;
+        }
         m2 = sf;
         {
             int     maxsf = lh_wave_max0(regular ? (active ? m2 : 255) : 0);

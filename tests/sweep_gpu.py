@@ -3,7 +3,7 @@
 sample rate x stereo mode x a set of quality levels that lame_init_params accepts, a few
 awkward signals each, HIP payload against the CPU oracle frame by frame.
 Usage: python tests/sweep_gpu.py [streams_per_setting] [seconds] [cbr|vbr|abr|all]
-"vbr": vbr_mtrh -V0..-V9 x sample rate x stereo mode x quality 0 / 5 instead of the CBR grid;
+"vbr": vbr_mtrh -V0..-V9 x sample rate x stereo mode x quality 0 / 5 / 7 instead of the CBR grid;
 "abr": ABR means (incl. values between the table rates) x sample rate x mode x quality 0 / 3 / 5 / 7."""
 import os
 import sys
@@ -27,7 +27,7 @@ def main():
     t0 = time.time()
     cbr_grid = [(br, q) for br in (32, 40, 48, 56, 64, 80, 96, 112, 128, 160, 192, 224, 256, 320)
                 for q in (0, 2, 3, 5, 7, 9)] if what in ("cbr", "all") else []
-    vbr_grid = [(-vq, q) for vq in range(10) for q in (0, 5)] if what in ("vbr", "all") else []
+    vbr_grid = [(-vq, q) for vq in range(10) for q in (0, 5, 7)] if what in ("vbr", "all") else []
     abr_grid = [(1000 + kb, q) for kb in (96, 100, 112, 128, 150, 160, 192, 215, 256, 320)
                 for q in (0, 3, 5, 7)] if what in ("abr", "all") else []
     for sr in (32000, 44100, 48000):

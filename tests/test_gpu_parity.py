@@ -24,8 +24,7 @@ def _encoder(g, **kw):
     return lamehip.Encoder(sr, br, mode, q, vbr_q=helpers.golden_vbr_q(g), abr=helpers.golden_abr(g), **kw)
 
 
-# the closed-form scalefactor guess of VBR at -q 7 has no device kernel (lame_init_params refuses it)
-VBR_GOLDEN = [n for n in helpers.golden_names(vbr=True) if not n.endswith("_q7")]
+VBR_GOLDEN = helpers.golden_names(vbr=True)
 
 
 @pytest.mark.parametrize("name", helpers.golden_names() + VBR_GOLDEN + helpers.golden_names(kind="abr"))
@@ -285,22 +284,18 @@ def test_odd_call_patterns_match_reference_call_by_call(reference, pattern):
     enc.close()
 
 
-def test_vbr_q7_is_refused_loudly():
-    with pytest.raises(RuntimeError):
-        lamehip.Encoder(44100, quality=7, vbr_q=4)
-
-
 @pytest.mark.parametrize("sr,vq,mode,seed,white", [(44100, 2, None, 31, False), (44100, 0, 0, 32, False),
                                                    (48000, 5, None, 33, True), (32000, 3, None, 34, False),
                                                    (44100, 9, None, 35, False), (48000, 1, None, 36, True),
                                                    (44100, 6, 0, 37, False)])
-def test_vbr_batch_matches_oracle(sr, vq, mode, seed, white, oracle):
+@pytest.mark.parametrize("q", [None, 7])
+def test_vbr_batch_matches_oracle(sr, vq, mode, seed, white, q, oracle):
     """vbr_mtrh streams of different lengths in one launch against the CPU oracle (every frame's
     payload incl. its bitrate index, and the packed bytes).  -V6 is the one preset whose long and
     short masking adjustments differ (the value the loop leaves for the next frame's psy model)."""
     lens = [int(sr * 1.3), int(sr * 0.4) + 17, 1, int(sr * 0.9)]
     out = sr if vq >= 7 else 0
-    enc = lamehip.Encoder(sr, mode=mode, vbr_q=vq, out_samplerate=out)
+    enc = lamehip.Encoder(sr, mode=mode, quality=q, vbr_q=vq, out_samplerate=out)   # q 7: guessed scalefactors
     cfg, tab = enc.config(), enc.tables()
     b = lamehip.Batch(enc, len(lens), max(lens))
     pcms = [helpers.synth_stream(seed * 10 + i, n, sr, 1.0 / 9, white and i == 0) for i, n in enumerate(lens)]

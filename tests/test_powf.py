@@ -26,6 +26,12 @@ int main(){
   }
   float sp[] = {0.0f, INFINITY, 1.0f, 1e-45f, 3e38f};
   for (float x: sp) for (float y: {0.36f, 0.18f, -0.5f, 0.0f, 100.0f, -100.0f}) { float a=powf(x,y), c=lh_powf(x,y); n++; if (memcmp(&a,&c,4)) bad++; }
+  /* log10f / logf of the VBR quality-7 scalefactor guess */
+  for (uint32_t b=1; b<0x7f800000u; b+=211) {
+    float x = lh_u32_as_f32(b), a = log10f(x), c = lh_log10f(x), e = logf(x), f = lh_logf(x); n += 2;
+    if (memcmp(&a,&c,4)) bad++;
+    if (memcmp(&e,&f,4)) bad++;
+  }
   printf("%llu %llu\n", n, bad);
   return bad != 0;
 }
