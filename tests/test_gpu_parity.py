@@ -337,3 +337,28 @@ def test_abr_batch_matches_oracle(sr, kb, mode, q, seed, white, oracle):
         assert b.pack(i) == helpers.pack_frames(enc.lib, cfg, tab, want)
     b.close()
     enc.close()
+
+
+@pytest.mark.parametrize("kw", [dict(brate=128), dict(brate=320, samplerate=48000), dict(vbr_q=2), dict(vbr_q=5, quality=5),
+                                dict(abr=160), dict(vbr_q=0, samplerate=48000)])
+def test_long_streams_match_oracle(kw, oracle):
+    """20 s per stream (765+ frames): reservoir, bitrate switching and the psy history over a length
+    that the short fixtures do not reach; bytes and every frame's payload against the CPU oracle."""
+    sr = kw.get("samplerate", 44100)
+    enc = lamehip.Encoder(**kw)
+    cfg, tab = enc.config(), enc.tables()
+    n = sr * 20
+    pcms = [helpers.synth_stream(900 + i, n - 1000 * i, sr, 1.0 / (3 + 4 * i), white=(i == 2)) for i in range(3)]
+    b = lamehip.Batch(enc, len(pcms), n)
+    for i, x in enumerate(pcms):
+        b.set_pcm(i, x[0], x[1])
+    b.encode()
+    for i, x in enumerate(pcms):
+        want = oracle.encode_frames(cfg, tab, x)
+        got = b.get_frames(i)
+        assert len(got) == len(want)
+        bad = [f for f in range(len(want)) if struct_diff(want[f], got[f])]
+        assert not bad, (i, bad[:5])
+        assert b.pack(i) == helpers.pack_frames(enc.lib, cfg, tab, want)
+    b.close()
+    enc.close()
