@@ -250,7 +250,7 @@ lame_init_params(lame_t g)
     g->p.samplerate_out = g->out_samplerate;
     if (lh_config_resolve(&g->p, &g->cfg, &aux) != 0) {
         snprintf(g_err, sizeof(g_err),
-                 "unsupported settings for the MI355X path (need MPEG-1 rates, 2 channels, CBR or vbr_mtrh, no resampling)");
+                 "unsupported settings for the MI355X path (need MPEG-1 rates, 1 or 2 input channels, CBR / ABR / vbr_mtrh, no resampling)");
         return -1;
     }
     g->tab = (LhTables *) malloc(sizeof(LhTables));
@@ -409,6 +409,8 @@ lame_encode_buffer(lame_t g, const short int l[], const short int r[], const int
         return 0;
     if (nsamples < 0)
         return -1;
+    if (g->cfg.channels == 1)
+        r = l;                  /* one input channel: buffer_r is not read (reference lame.c:1855-1866) */
     g->hl.insert(g->hl.end(), l, l + nsamples);
     g->hr.insert(g->hr.end(), r, r + nsamples);
     g->fed += nsamples;
@@ -687,6 +689,8 @@ lamehip_batch_set_pcm(lamehip_batch * b, int s, const short *l, const short *r, 
 {
     if (lamehip_batch_set_length(b, s, n) != 0)
         return -1;
+    if (b->cfg.channels == 1)
+        r = l;                  /* mono: the second plane mirrors the first, the kernel never uses it */
     HIPCHK(hipMemcpy(b->d_pcm + ((size_t) s * 2) * (size_t) b->cap, l, (size_t) n * 2, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(b->d_pcm + ((size_t) s * 2 + 1) * (size_t) b->cap, r, (size_t) n * 2, hipMemcpyHostToDevice));
     return 0;
@@ -697,6 +701,8 @@ lamehip_batch_set_pcm_device(lamehip_batch * b, int s, const void *dl, const voi
 {
     if (lamehip_batch_set_length(b, s, n) != 0)
         return -1;
+    if (b->cfg.channels == 1)
+        dr = dl;
     HIPCHK(hipMemcpy(b->d_pcm + ((size_t) s * 2) * (size_t) b->cap, dl, (size_t) n * 2, hipMemcpyDeviceToDevice));
     HIPCHK(hipMemcpy(b->d_pcm + ((size_t) s * 2 + 1) * (size_t) b->cap, dr, (size_t) n * 2, hipMemcpyDeviceToDevice));
     return 0;

@@ -154,12 +154,12 @@ encode_side_info(LhBitstream * bs, const LhConfig * c, const LhFrameOut * fo, in
     hdr_bits(bs, c->original, 1);
     hdr_bits(bs, c->emphasis, 2);
     hdr_bits(bs, mdb, 9);
-    hdr_bits(bs, 0, 3);         /* private bits */
-    for (ch = 0; ch < 2; ch++)
+    hdr_bits(bs, 0, c->channels == 2 ? 3 : 5);  /* private bits (reference bitstream.c:357-360) */
+    for (ch = 0; ch < c->channels; ch++)
         for (band = 0; band < 4; band++)
             hdr_bits(bs, fo->scfsi[ch][band], 1);
     for (gr = 0; gr < 2; gr++) {
-        for (ch = 0; ch < 2; ch++) {
+        for (ch = 0; ch < c->channels; ch++) {
             const LhGranule *gi = &fo->gr[gr][ch];
             hdr_bits(bs, gi->part2_3_length + gi->part2_length, 12);
             hdr_bits(bs, gi->big_values / 2, 9);
@@ -304,7 +304,7 @@ write_main_data(LhBitstream * bs, const LhConfig * c, const LhTables * t, const 
     int     gr, ch, sfb, data_bits, tot_bits = 0;
     int const sl = c->sideinfo_len;
     for (gr = 0; gr < 2; gr++) {
-        for (ch = 0; ch < 2; ch++) {
+        for (ch = 0; ch < c->channels; ch++) {
             const LhGranule *gi = &fo->gr[gr][ch];
             int const slen1 = slen1_tab[gi->scalefac_compress];
             int const slen2 = slen2_tab[gi->scalefac_compress];
@@ -383,7 +383,7 @@ lh_bs_format_frame(LhBitstream * bs, const LhConfig * c, const LhTables * t, con
     {
         int     gr, ch, k;
         for (gr = 0; gr < 2; gr++)
-            for (ch = 0; ch < 2; ch++) {
+            for (ch = 0; ch < c->channels; ch++) {
                 const LhGranule *gi = &fo->gr[gr][ch];
                 int     bad = gi->big_values < 0 || gi->big_values > 576 || gi->count1 < gi->big_values
                     || gi->count1 > 576 || (gi->big_values & 1) || ((gi->count1 - gi->big_values) & 3)

@@ -629,7 +629,9 @@ lh_psy_granule(int gr)
     LhStreamState *st = c.st;
     LhPsyLds & P = L.u.psy;
     int const lane = c.lane, w = c.wave;
-    int const n_chn_psy = (cfg->mode == LH_MODE_JOINT_STEREO) ? 4 : 2;
+    /* mono: one channel, wave 1 only keeps pace through the workgroup barriers (its per-wave work on
+     * the duplicated PCM is never read) */
+    int const n_chn_psy = (cfg->mode == LH_MODE_JOINT_STEREO) ? 4 : cfg->channels;
     int const bufbase = 576 + gr * 576 - LH_FFTOFFSET;      /* bufp[ch] = &inbuf[ch][bufbase] */
 
     /* (1) one-granule delay: hand last call's en/thm to the caller and keep them as last_thm */
@@ -757,7 +759,7 @@ lh_psy_granule(int gr)
     LH_SYNC_WG();
     {
         /* uselongblock[] resolution (reference psymodel.c:926-933, 1265-1286) */
-        int     ul0 = L.ns_uselong[0], ul1 = L.ns_uselong[1];
+        int     ul0 = L.ns_uselong[0], ul1 = (cfg->channels == 2) ? L.ns_uselong[1] : 1;
         for (int chn = 2; chn < n_chn_psy; chn++)
             if (L.ns_uselong[chn] == 0)
                 ul0 = ul1 = 0;

@@ -2375,12 +2375,14 @@ lh_on_pe(const LhConfig * cfg, int ResvSize, int ResvMax, int *substep, const fl
     int     extra_bits = 0, tbits, bits;
     int     add_bits[2] = { 0, 0 };
     int     max_bits, ch;
+    int const nch = cfg->channels;
     lh_resv_max_bits(cfg, ResvSize, ResvMax, substep, mean_bits, &tbits, &extra_bits, cbr);
     max_bits = tbits + extra_bits;
     if (max_bits > LH_MAX_BITS_PER_GRANULE)
         max_bits = LH_MAX_BITS_PER_GRANULE;
-    for (bits = 0, ch = 0; ch < 2; ++ch) {
-        targ_bits[ch] = (LH_MAX_BITS_PER_CHANNEL < tbits / 2) ? LH_MAX_BITS_PER_CHANNEL : tbits / 2;
+    targ_bits[1] = 0;           /* mono: the second channel has no budget */
+    for (bits = 0, ch = 0; ch < nch; ++ch) {
+        targ_bits[ch] = (LH_MAX_BITS_PER_CHANNEL < tbits / nch) ? LH_MAX_BITS_PER_CHANNEL : tbits / nch;
         add_bits[ch] = (int) (targ_bits[ch] * pe[ch] / 700.0 - targ_bits[ch]);
         if (add_bits[ch] > mean_bits * 3 / 4)
             add_bits[ch] = mean_bits * 3 / 4;
@@ -2393,16 +2395,16 @@ lh_on_pe(const LhConfig * cfg, int ResvSize, int ResvMax, int *substep, const fl
         bits += add_bits[ch];
     }
     if (bits > extra_bits && bits > 0)
-        for (ch = 0; ch < 2; ++ch)
+        for (ch = 0; ch < nch; ++ch)
             add_bits[ch] = extra_bits * add_bits[ch] / bits;
-    for (ch = 0; ch < 2; ++ch) {
+    for (ch = 0; ch < nch; ++ch) {
         targ_bits[ch] += add_bits[ch];
         extra_bits -= add_bits[ch];
     }
-    for (bits = 0, ch = 0; ch < 2; ++ch)
+    for (bits = 0, ch = 0; ch < nch; ++ch)
         bits += targ_bits[ch];
     if (bits > LH_MAX_BITS_PER_GRANULE) {
-        for (ch = 0; ch < 2; ++ch) {
+        for (ch = 0; ch < nch; ++ch) {
             targ_bits[ch] *= LH_MAX_BITS_PER_GRANULE;
             targ_bits[ch] /= bits;
         }

@@ -848,30 +848,36 @@ lh_vbr_share(int share[2], const int use[2], int slack)
 }
 
 LH_DEVFN void
-lh_vbr_budgets(const int max_bits[2][2], const int use_ch[2][2], const int use_gr[2], int max_fr, int max_ch[2][2])
+lh_vbr_budgets(int nch, const int max_bits[2][2], const int use_ch[2][2], const int use_gr[2], int max_fr,
+               int max_ch[2][2])
 {
     int     max_gr[2], ok = 1, sum_fr = 0;
+    max_ch[0][1] = max_ch[1][1] = 0;
     for (int gr = 0; gr < 2; ++gr) {
         max_gr[gr] = 0;
-        for (int ch = 0; ch < 2; ++ch) {
+        for (int ch = 0; ch < nch; ++ch) {
             max_ch[gr][ch] = (use_ch[gr][ch] > LH_MAX_BITS_PER_CHANNEL) ? LH_MAX_BITS_PER_CHANNEL : use_ch[gr][ch];
             max_gr[gr] += max_ch[gr][ch];
         }
         if (max_gr[gr] > LH_MAX_BITS_PER_GRANULE) {
             float   f[2] = { 0.0f, 0.0f }, sm = 0.0f;
-            for (int ch = 0; ch < 2; ++ch) {
+            for (int ch = 0; ch < nch; ++ch) {
                 if (max_ch[gr][ch] > 0) {
                     f[ch] = (float) sqrt(sqrt((double) max_ch[gr][ch]));
                     sm += f[ch];
                 }
             }
-            for (int ch = 0; ch < 2; ++ch)
+            for (int ch = 0; ch < nch; ++ch)
                 max_ch[gr][ch] = (sm > 0) ? (int) (LH_MAX_BITS_PER_GRANULE * f[ch] / sm) : 0;
-            lh_vbr_share(max_ch[gr], use_ch[gr], 32);
-            for (int ch = 0; ch < 2; ++ch)
-                if (max_ch[gr][ch] > LH_MAX_BITS_PER_CHANNEL)
-                    max_ch[gr][ch] = LH_MAX_BITS_PER_CHANNEL;
-            max_gr[gr] = max_ch[gr][0] + max_ch[gr][1];
+            if (nch > 1) {
+                lh_vbr_share(max_ch[gr], use_ch[gr], 32);
+                for (int ch = 0; ch < nch; ++ch)
+                    if (max_ch[gr][ch] > LH_MAX_BITS_PER_CHANNEL)
+                        max_ch[gr][ch] = LH_MAX_BITS_PER_CHANNEL;
+            }
+            max_gr[gr] = 0;
+            for (int ch = 0; ch < nch; ++ch)
+                max_gr[gr] += max_ch[gr][ch];
         }
         sum_fr += max_gr[gr];
     }
@@ -893,24 +899,26 @@ lh_vbr_budgets(const int max_bits[2][2], const int use_ch[2][2], const int use_g
                 max_gr[gr] = LH_MAX_BITS_PER_GRANULE;
         for (int gr = 0; gr < 2; ++gr) {
             float   f[2] = { 0.0f, 0.0f }, sm = 0.0f;
-            for (int ch = 0; ch < 2; ++ch) {
+            for (int ch = 0; ch < nch; ++ch) {
                 if (max_ch[gr][ch] > 0) {
                     f[ch] = (float) sqrt((double) max_ch[gr][ch]);
                     sm += f[ch];
                 }
             }
-            for (int ch = 0; ch < 2; ++ch)
+            for (int ch = 0; ch < nch; ++ch)
                 max_ch[gr][ch] = (sm > 0) ? (int) (max_gr[gr] * f[ch] / sm) : 0;
-            lh_vbr_share(max_ch[gr], use_ch[gr], 32);
-            for (int ch = 0; ch < 2; ++ch)
-                if (max_ch[gr][ch] > LH_MAX_BITS_PER_CHANNEL)
-                    max_ch[gr][ch] = LH_MAX_BITS_PER_CHANNEL;
+            if (nch > 1) {
+                lh_vbr_share(max_ch[gr], use_ch[gr], 32);
+                for (int ch = 0; ch < nch; ++ch)
+                    if (max_ch[gr][ch] > LH_MAX_BITS_PER_CHANNEL)
+                        max_ch[gr][ch] = LH_MAX_BITS_PER_CHANNEL;
+            }
         }
     }
     sum_fr = 0;
     for (int gr = 0; gr < 2; ++gr) {
         int     sum_gr = 0;
-        for (int ch = 0; ch < 2; ++ch) {
+        for (int ch = 0; ch < nch; ++ch) {
             sum_gr += max_ch[gr][ch];
             if (max_ch[gr][ch] > LH_MAX_BITS_PER_CHANNEL)
                 ok = 0;
@@ -923,7 +931,7 @@ lh_vbr_budgets(const int max_bits[2][2], const int use_ch[2][2], const int use_g
         ok = 0;
     if (!ok)
         for (int gr = 0; gr < 2; ++gr)
-            for (int ch = 0; ch < 2; ++ch)
+            for (int ch = 0; ch < nch; ++ch)
                 max_ch[gr][ch] = max_bits[gr][ch];
 }
 
@@ -939,6 +947,7 @@ lh_vbr_frame(const LhCtx & c, LhFrameOut * fo, float pe_use[2][2], int mode_ext,
     const LhConfig *cfg = c.cfg;
     int const w = c.wave, tid = c.tid;
     int const maxi = cfg->vbr_max_bitrate_index;
+    int const nch = cfg->channels;
     int     avg, resv_top, top_bits, dummy;
     int     max_bits[2][2], use_ch[2][2], use_gr[2], use_fr, max_fr = 0, bits = 0;
     int     analog_silence, pad, used, ok;
@@ -967,14 +976,23 @@ lh_vbr_frame(const LhCtx & c, LhFrameOut * fo, float pe_use[2][2], int mode_ext,
         }
     }
     LH_SYNC_WG();
-    for (int gr = 0; gr < 2; gr++)
-        lh_vbr_granule(w, gr, msoff + w, 0, max_bits[gr][w], 0, substep, &fo->gr[gr][w], fo->gr[0][w].scalefac);
+    for (int gr = 0; gr < 2; gr++) {
+        if (w < nch)
+            lh_vbr_granule(w, gr, msoff + w, 0, max_bits[gr][w], 0, substep, &fo->gr[gr][w], fo->gr[0][w].scalefac);
+        else {
+            /* mono: no second channel, its payload slot is all zero */
+            uint32_t *z = (uint32_t *) &fo->gr[gr][w];
+            for (int i = c.lane; i < (int) (sizeof(LhGranule) / 4); i += 64)
+                z[i] = 0u;
+        }
+    }
     LH_SYNC_WG();
     analog_silence = 1;
     use_fr = 0;
     for (int gr = 0; gr < 2; gr++) {
         use_gr[gr] = 0;
-        for (int ch = 0; ch < 2; ch++) {
+        use_ch[gr][1] = 0;
+        for (int ch = 0; ch < nch; ch++) {
             LhVbrSave const &sv = L.u.quant.vbr[gr][ch];
             if (lh_uni_i(sv.ath_over))
                 analog_silence = 0;
@@ -992,22 +1010,23 @@ lh_vbr_frame(const LhCtx & c, LhFrameOut * fo, float pe_use[2][2], int mode_ext,
     for (int gr = 0; gr < 2; gr++) {
         if (use_gr[gr] > LH_MAX_BITS_PER_GRANULE)
             ok = 0;
-        for (int ch = 0; ch < 2; ch++)
+        for (int ch = 0; ch < nch; ch++)
             if (use_ch[gr][ch] > LH_MAX_BITS_PER_CHANNEL)
                 ok = 0;
     }
     used = use_fr;
     if (!ok) {
         int     max_ch[2][2];
-        lh_vbr_budgets(max_bits, use_ch, use_gr, max_fr, max_ch);
+        lh_vbr_budgets(nch, max_bits, use_ch, use_gr, max_fr, max_ch);
         LH_SYNC_WG();
         for (int gr = 0; gr < 2; gr++)
-            lh_vbr_granule(w, gr, msoff + w, 1, max_bits[gr][w], max_ch[gr][w], substep, &fo->gr[gr][w],
-                           fo->gr[0][w].scalefac);
+            if (w < nch)
+                lh_vbr_granule(w, gr, msoff + w, 1, max_bits[gr][w], max_ch[gr][w], substep, &fo->gr[gr][w],
+                               fo->gr[0][w].scalefac);
         LH_SYNC_WG();
         used = 0;
         for (int gr = 0; gr < 2; gr++)
-            for (int ch = 0; ch < 2; ch++)
+            for (int ch = 0; ch < nch; ch++)
                 used += lh_uni_i(L.u.quant.vbr[gr][ch].use_bits);
     }
     /* smallest frame that holds the bits; a larger one while the reservoir could not take the rest */
@@ -1040,6 +1059,8 @@ lh_abr_target_bits(const LhConfig * cfg, int ResvSize, int substep, float pe[2][
     float   res_factor;
     int     totbits, mean_bits, dummy, max_frame_bits;
     int const framesize = 576 * cfg->mode_gr;
+    int const nch = cfg->channels;
+    targ_bits[0][1] = targ_bits[1][1] = 0;
 
     max_frame_bits = lh_vbr_full_bits(cfg, cfg->vbr_max_bitrate_index, ResvSize, &mean_bits, &dummy);
     mean_bits = lh_frame_bits(cfg, 1, 0) - cfg->sideinfo_len * 8;
@@ -1059,7 +1080,7 @@ lh_abr_target_bits(const LhConfig * cfg, int ResvSize, int substep, float pe[2][
         res_factor = 1.00;
     for (int gr = 0; gr < 2; gr++) {
         int     sum = 0;
-        for (int ch = 0; ch < 2; ch++) {
+        for (int ch = 0; ch < nch; ch++) {
             targ_bits[gr][ch] = res_factor * mean_bits;
             if (pe[gr][ch] > 700) {
                 int     add_bits = (pe[gr][ch] - 700) / 1.4;
@@ -1078,7 +1099,7 @@ lh_abr_target_bits(const LhConfig * cfg, int ResvSize, int substep, float pe[2][
             sum += targ_bits[gr][ch];
         }
         if (sum > LH_MAX_BITS_PER_GRANULE)
-            for (int ch = 0; ch < 2; ++ch) {
+            for (int ch = 0; ch < nch; ++ch) {
                 targ_bits[gr][ch] *= LH_MAX_BITS_PER_GRANULE;
                 targ_bits[gr][ch] /= sum;
             }
@@ -1088,14 +1109,14 @@ lh_abr_target_bits(const LhConfig * cfg, int ResvSize, int substep, float pe[2][
             lh_reduce_side(targ_bits[gr], ms_ener_ratio[gr], mean_bits * cfg->channels, LH_MAX_BITS_PER_GRANULE);
     totbits = 0;
     for (int gr = 0; gr < 2; gr++)
-        for (int ch = 0; ch < 2; ch++) {
+        for (int ch = 0; ch < nch; ch++) {
             if (targ_bits[gr][ch] > LH_MAX_BITS_PER_CHANNEL)
                 targ_bits[gr][ch] = LH_MAX_BITS_PER_CHANNEL;
             totbits += targ_bits[gr][ch];
         }
     if (totbits > max_frame_bits && totbits > 0)
         for (int gr = 0; gr < 2; gr++)
-            for (int ch = 0; ch < 2; ch++) {
+            for (int ch = 0; ch < nch; ch++) {
                 targ_bits[gr][ch] *= max_frame_bits;
                 targ_bits[gr][ch] /= totbits;
             }

@@ -342,7 +342,7 @@ config_resolve_vbr(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
 
     c->bitrate_index = 1;
     c->avg_bitrate = 0;         /* gfp->brate stays 0 in VBR mode */
-    c->sideinfo_len = 4 + 32;
+    c->sideinfo_len = (c->channels == 1) ? 4 + 17 : 4 + 32;
     c->buffer_constraint = 7680 * (c->version + 1);     /* strict_ISO = MDB_MAXIMUM */
     c->use_temporal_masking = 0;
 
@@ -408,7 +408,7 @@ config_resolve_vbr(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
         c->quality = 7;
     apply_quality(c, 0, 0);
     c->sfb21_extra = P.expY ? 0 : (samplerate_out > 44000);
-    c->short_blocks = 1;
+    c->short_blocks = (c->mode == LH_MODE_MONO) ? 0 : 1;
     c->pcm_scale = 1.0f;
     c->disable_reservoir = 0;
     c->frac_SpF = 0;
@@ -436,8 +436,8 @@ lh_config_resolve(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
 
     memset(c, 0, sizeof(*c));
     memset(aux, 0, sizeof(*aux));
-    if (p->channels != 2)
-        return -1;              /* mono framing is outside this path */
+    if (p->channels != 1 && p->channels != 2)
+        return -1;
     if (p->vbr != 0 && p->vbr != 1 && p->vbr != 3 && p->vbr != 4)
         return -1;              /* the old VBR loop (vbr_rh) is outside this path */
     if (p->samplerate_out != 0 && p->samplerate_out != p->samplerate)
@@ -458,11 +458,15 @@ lh_config_resolve(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
     c->version = 1;
     c->samplerate = p->samplerate;
     c->mode_gr = 2;
-    c->channels = 2;
     c->vbr = p->vbr;
     c->mode = (p->mode < 0) ? LH_MODE_JOINT_STEREO : p->mode;
-    if (c->mode != LH_MODE_JOINT_STEREO && c->mode != LH_MODE_STEREO)
+    if (p->channels == 1)
+        c->mode = LH_MODE_MONO; /* one input channel: reference lame.c:598-601 */
+    if (c->mode == LH_MODE_MONO && p->channels == 2)
+        return -1;              /* two channels mixed down to mono: not on this path */
+    if (c->mode != LH_MODE_JOINT_STEREO && c->mode != LH_MODE_STEREO && c->mode != LH_MODE_MONO)
         return -1;
+    c->channels = (c->mode == LH_MODE_MONO) ? 1 : 2;
     c->force_ms = 0;
     c->original = 1;
     /* VBR_q also reaches the CBR path (psymodel_init's masking_lower slope, the tag's quality byte) */
@@ -506,7 +510,10 @@ lh_config_resolve(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
     /* lowpass (reference lame.c:194-260, 700-760, 846-862) */
     {
         double  lowpass = lowpass_map[nearest_full_index(c->avg_bitrate)];
-        int     lp = (int) lowpass;
+        int     lp;
+        if (c->mode == LH_MODE_MONO)
+            lowpass *= 1.5;     /* reference lame.c:758-759 */
+        lp = (int) lowpass;
         int     suggested;
         (void) suggested;
         /* the reference would pick a lower output rate and resample for this
@@ -535,7 +542,7 @@ lh_config_resolve(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
         }
     }
 
-    c->sideinfo_len = 4 + 32;
+    c->sideinfo_len = (c->channels == 1) ? 4 + 17 : 4 + 32;
     c->buffer_constraint = 7680 * (c->version + 1);     /* MDB_MAXIMUM, reference bitstream.c:91-131 */
 
     /* preset for the bitrate (reference presets.c:215-317) */
@@ -575,7 +582,7 @@ lh_config_resolve(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
         c->quality = 9;
     apply_quality(c, noise_shaping, 0);
     c->sfb21_extra = 0;
-    c->short_blocks = 1;        /* coupled: stereo / joint stereo default, reference lame.c:1134-1137 */
+    c->short_blocks = (c->mode == LH_MODE_MONO) ? 0 : 1;        /* coupled for stereo / joint stereo, reference lame.c:1134-1137 */
     c->use_temporal_masking = 1;
     c->ATHtype = 4;
     c->ATH_offset_db = 0 - ath_lower_db;

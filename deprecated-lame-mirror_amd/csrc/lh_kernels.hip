@@ -182,6 +182,9 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo)
     const LhTables *T = c.T;
     LhStreamState *st = c.st;
     int const w = c.wave, lane = c.lane, tid = c.tid;
+    /* mono: wave 1 has no channel; it runs the transforms on the duplicated PCM (never read) and
+     * only keeps pace through the barriers of the quantisation stage */
+    int const nch = cfg->channels;
 
     /* ---- polyphase priming on the first frame (reference encoder.c:189-236) ---- */
 #if defined(LH_PROF) && !defined(LH_EMU)
@@ -235,9 +238,10 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo)
         float   factor = st->ath_adjust_factor, limit = st->ath_adjust_limit;
         float   loud[2][2];
         loud[0][0] = L.loudness_sq[0][0];
-        loud[0][1] = L.loudness_sq[0][1];
         loud[1][0] = L.loudness_sq[1][0];
-        loud[1][1] = L.loudness_sq[1][1];
+        /* one channel counts twice (reference encoder.c:72-79) */
+        loud[0][1] = (cfg->channels == 2) ? L.loudness_sq[0][1] : loud[0][0];
+        loud[1][1] = (cfg->channels == 2) ? L.loudness_sq[1][1] : loud[1][0];
         lh_adjust_ATH(T, loud, &factor, &limit);
         LH_SYNC_WG();
         if (tid == 0) {
@@ -294,18 +298,20 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo)
         for (int i = 0; i < 18; i++)
             buf[i] = st->pefirbuf[i + 1];
         f = 0.0;
-        for (int gr = 0; gr < 2; gr++)
-            for (int ch = 0; ch < 2; ch++) {
+        for (int gr = 0; gr < 2; gr++) {
+            pe_use[gr][1] = 0.0f;
+            for (int ch = 0; ch < nch; ch++) {
                 pe_use[gr][ch] = L.pe[gr][msoff + ch];
                 f += pe_use[gr][ch];
             }
+        }
         buf[18] = f;
         f = buf[9];
         for (int i = 0; i < 9; i++)
             f += (buf[i] + buf[18 - i]) * lh_pe_fir[i];
-        f = (670 * 5 * 2 * 2) / f;
+        f = (670 * 5 * 2 * nch) / f;
         for (int gr = 0; gr < 2; gr++)
-            for (int ch = 0; ch < 2; ch++)
+            for (int ch = 0; ch < nch; ch++)
                 pe_use[gr][ch] *= f;
         LH_SYNC_WG();
         if (tid < 19)
@@ -358,7 +364,15 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo)
                 lh_reduce_side(targ_bits, ms_ener_ratio[gr], mean_bits, max_bits);
         }
         LH_SYNC_WG();
-        {
+        if (w >= nch) {
+            /* no second channel: its payload slot is all zero */
+            uint32_t *z = (uint32_t *) &fo->gr[gr][w];
+            for (int i = lane; i < (int) (sizeof(LhGranule) / 4); i += 64)
+                z[i] = 0u;
+            if (lane == 0)
+                L.bits_used[w] = 0;
+        }
+        else {
             int const ch = w;
             LhChanLds & Q = L.u.quant.ch[ch];
             LhQR    R;
@@ -444,7 +458,7 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo)
     if (tid == 0) {
         for (int ch = 0; ch < 2; ch++)
             for (int i = 0; i < 4; i++)
-                fo->scfsi[ch][i] = (int8_t) L.scfsi[ch][i];
+                fo->scfsi[ch][i] = (ch < nch) ? (int8_t) L.scfsi[ch][i] : (int8_t) 0;
         fo->main_data_begin = (int16_t) mdb;
         fo->resvDrain_pre = (int16_t) drain_pre;
         fo->resvDrain_post = (int16_t) drain_post;
@@ -461,8 +475,8 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo)
         st->main_data_begin = mdb;
         st->substep_shaping = substep;
         /* what the next frame's psy model finds in sv_qnt.masking_lower: the CBR loop leaves the value
-         * of its last granule/channel, the VBR loop always the long-block one (reference quantize.c:1622) */
-        st->masking_lower = (vbr_new || L.block_type[1][1] != LH_SHORT_TYPE) ? cfg->masking_lower_long
+         * of its last granule/channel (channel 0 for mono), the VBR loop always the long-block one (reference quantize.c:1622) */
+        st->masking_lower = (vbr_new || L.block_type[1][nch - 1] != LH_SHORT_TYPE) ? cfg->masking_lower_long
             : cfg->masking_lower_short;
         st->frame_number = st->frame_number + 1;
         if (mdb * 8 != ResvSize)

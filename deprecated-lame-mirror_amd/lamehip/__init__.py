@@ -76,13 +76,14 @@ class Encoder:
     """One stream behind the lame.h call sequence."""
 
     def __init__(self, samplerate=44100, brate=128, mode=None, quality=None, require_device=True, write_tag=False,
-                 vbr_q=None, out_samplerate=0, abr=None):
+                 vbr_q=None, out_samplerate=0, abr=None, channels=2):
         self.lib = load_library()
         self.h = C.c_void_p(self.lib.lame_init())
         self.lib.lame_set_in_samplerate(self.h, samplerate)
         if out_samplerate:
             self.lib.lame_set_out_samplerate(self.h, out_samplerate)
-        self.lib.lame_set_num_channels(self.h, 2)
+        self.lib.lame_set_num_channels(self.h, channels)  # 1: mono (only the left buffer is read)
+        self.channels = channels
         if abr is not None:         # ABR at a mean bitrate of `abr' kb/s (the reference's --abr n)
             self.lib.lame_set_VBR(self.h, 3)
             self.lib.lame_set_VBR_mean_bitrate_kbps(self.h, abr)
@@ -114,9 +115,9 @@ class Encoder:
         assert self.lib.lamehip_get_tables(self.h, C.byref(t), C.sizeof(t)) == C.sizeof(t)
         return t
 
-    def encode(self, left, right):
+    def encode(self, left, right=None):
         left = np.ascontiguousarray(left, dtype=np.int16)
-        right = np.ascontiguousarray(right, dtype=np.int16)
+        right = left if right is None else np.ascontiguousarray(right, dtype=np.int16)   # mono: not read
         n = len(left)
         buf = C.create_string_buffer(int(1.25 * n) + 7200)
         k = self.lib.lame_encode_buffer(self.h, left.ctypes.data, right.ctypes.data, n, buf, len(buf))
@@ -161,9 +162,9 @@ class Batch:
         if not self.b:
             raise RuntimeError("lamehip_batch_create failed: %s" % last_error())
 
-    def set_pcm(self, s, left, right):
+    def set_pcm(self, s, left, right=None):
         left = np.ascontiguousarray(left, dtype=np.int16)
-        right = np.ascontiguousarray(right, dtype=np.int16)
+        right = left if right is None else np.ascontiguousarray(right, dtype=np.int16)   # mono: not read
         rc = self.lib.lamehip_batch_set_pcm(self.b, s, left.ctypes.data, right.ctypes.data, len(left))
         if rc:
             raise RuntimeError("lamehip_batch_set_pcm failed (%d): %s" % (rc, last_error()))

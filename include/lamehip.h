@@ -11,7 +11,7 @@
  * of handles.
  *
  * Everything here is plain C: pointers and sizes only, no torch / HIP types.
- * Unsupported settings (mono, the old VBR loop, MPEG-2 rates, resampling) make
+ * Unsupported settings (the old VBR loop, MPEG-2 rates, resampling, stereo mixed down to mono) make
  * lame_init_params() return -1 instead of silently taking another path, and
  * every call fails with LAMEHIP_ERR_NODEVICE when no HIP device is present --
  * there is no CPU fallback inside this library.
@@ -46,7 +46,7 @@ typedef enum vbr_mode_e { vbr_off = 0, vbr_mt, vbr_rh, vbr_abr, vbr_mtrh, vbr_ma
 lame_t  lame_init(void);                                            /* lame.h:168 */
 int     lame_set_in_samplerate(lame_t, int);                         /* lame.h:188 */
 int     lame_get_in_samplerate(const lame_t);                        /* lame.h:189 */
-int     lame_set_num_channels(lame_t, int);                          /* lame.h:192 */
+int     lame_set_num_channels(lame_t, int);                          /* lame.h:192 (2, or 1 = mono: only buffer_l is read) */
 int     lame_get_num_channels(const lame_t);                         /* lame.h:193 */
 int     lame_set_out_samplerate(lame_t, int);                        /* lame.h:224 (must equal the input rate) */
 int     lame_get_out_samplerate(const lame_t);                       /* lame.h:225 */

@@ -35,7 +35,7 @@ abr_target_bits(OrcStream * S, float pe[2][2], const float ms_ener_ratio[2], int
         res_factor = 1.00;
     for (gr = 0; gr < 2; gr++) {
         int     sum = 0;
-        for (ch = 0; ch < 2; ch++) {
+        for (ch = 0; ch < cfg->channels; ch++) {
             targ_bits[gr][ch] = res_factor * mean_bits;
             if (pe[gr][ch] > 700) {
                 int     add_bits = (pe[gr][ch] - 700) / 1.4;
@@ -55,7 +55,7 @@ abr_target_bits(OrcStream * S, float pe[2][2], const float ms_ener_ratio[2], int
             sum += targ_bits[gr][ch];
         }
         if (sum > LH_MAX_BITS_PER_GRANULE)
-            for (ch = 0; ch < 2; ++ch) {
+            for (ch = 0; ch < cfg->channels; ++ch) {
                 targ_bits[gr][ch] *= LH_MAX_BITS_PER_GRANULE;
                 targ_bits[gr][ch] /= sum;
             }
@@ -65,14 +65,14 @@ abr_target_bits(OrcStream * S, float pe[2][2], const float ms_ener_ratio[2], int
             reduce_side(targ_bits[gr], ms_ener_ratio[gr], mean_bits * cfg->channels, LH_MAX_BITS_PER_GRANULE);
     totbits = 0;
     for (gr = 0; gr < 2; gr++)
-        for (ch = 0; ch < 2; ch++) {
+        for (ch = 0; ch < cfg->channels; ch++) {
             if (targ_bits[gr][ch] > LH_MAX_BITS_PER_CHANNEL)
                 targ_bits[gr][ch] = LH_MAX_BITS_PER_CHANNEL;
             totbits += targ_bits[gr][ch];
         }
     if (totbits > *max_frame_bits && totbits > 0)
         for (gr = 0; gr < 2; gr++)
-            for (ch = 0; ch < 2; ch++) {
+            for (ch = 0; ch < cfg->channels; ch++) {
                 targ_bits[gr][ch] *= *max_frame_bits;
                 targ_bits[gr][ch] /= totbits;
             }
@@ -96,7 +96,7 @@ orc_abr_iteration_loop(OrcStream * S, float pe[2][2], const float ms_ener_ratio[
                 S->tt[gr][0].xr[i] = (l + r) * (float) (ORC_SQRT2 * 0.5);
                 S->tt[gr][1].xr[i] = (l - r) * (float) (ORC_SQRT2 * 0.5);
             }
-        for (ch = 0; ch < 2; ch++) {
+        for (ch = 0; ch < cfg->channels; ch++) {
             OrcGr  *cod_info = &S->tt[gr][ch];
             S->masking_lower = (cod_info->block_type != LH_SHORT_TYPE) ? cfg->masking_lower_long
                 : cfg->masking_lower_short;

@@ -60,8 +60,14 @@ adjust_ATH(OrcStream * S)
     }
     max_pow = S->loudness_sq[0][0];
     gr2_max = S->loudness_sq[1][0];
-    max_pow += S->loudness_sq[0][1];
-    gr2_max += S->loudness_sq[1][1];
+    if (S->cfg->channels == 2) {
+        max_pow += S->loudness_sq[0][1];
+        gr2_max += S->loudness_sq[1][1];
+    }
+    else {
+        max_pow += max_pow;
+        gr2_max += gr2_max;
+    }
     max_pow = (max_pow > gr2_max) ? max_pow : gr2_max;
     max_pow *= 0.5;
     max_pow *= T->aa_sensitivity_p;
@@ -93,9 +99,10 @@ static void
 pack_frame(OrcStream * S, LhFrameOut * fo, int mdb_for_header)
 {
     int     gr, ch, i;
+    int const nch = S->cfg->channels;
     memset(fo, 0, sizeof(*fo));
     for (gr = 0; gr < 2; gr++) {
-        for (ch = 0; ch < 2; ch++) {
+        for (ch = 0; ch < nch; ch++) {
             OrcGr const *gi = &S->tt[gr][ch];
             LhGranule *g = &fo->gr[gr][ch];
             for (i = 0; i < 576; i++) {
@@ -128,7 +135,7 @@ pack_frame(OrcStream * S, LhFrameOut * fo, int mdb_for_header)
             g->count1bits = (int16_t) gi->count1bits;
         }
     }
-    for (ch = 0; ch < 2; ch++)
+    for (ch = 0; ch < nch; ch++)
         for (i = 0; i < 4; i++)
             fo->scfsi[ch][i] = (int8_t) S->scfsi[ch][i];
     (void) mdb_for_header;
@@ -155,6 +162,7 @@ orc_encode_frame(OrcStream * S, const float *inbuf_l, const float *inbuf_r, LhFr
     float   pe[2][2] = { {0., 0.}, {0., 0.} }, pe_MS[2][2] = { {0., 0.}, {0., 0.} };
     float   (*pe_use)[2];
     int     ch, gr, mdb_header;
+    int const nch = cfg->channels;
 
     inbuf[0] = inbuf_l;
     inbuf[1] = inbuf_r;
@@ -170,12 +178,13 @@ orc_encode_frame(OrcStream * S, const float *inbuf_l, const float *inbuf_r, LhFr
         for (i = 0, j = 0; i < 286 + 576 * (1 + 2); ++i) {
             if (i >= 1152) {
                 primebuff0[i] = inbuf[0][j];
-                primebuff1[i] = inbuf[1][j];
+                if (nch == 2)
+                    primebuff1[i] = inbuf[1][j];
                 ++j;
             }
         }
         for (gr = 0; gr < 2; gr++)
-            for (ch = 0; ch < 2; ch++)
+            for (ch = 0; ch < nch; ch++)
                 S->tt[gr][ch].block_type = LH_SHORT_TYPE;
         orc_mdct_sub48(S, primebuff0, primebuff1);
     }
@@ -188,7 +197,7 @@ orc_encode_frame(OrcStream * S, const float *inbuf_l, const float *inbuf_r, LhFr
         const float *bufp[2] = { 0, 0 };
         int     blocktype[2];
         for (gr = 0; gr < 2; gr++) {
-            for (ch = 0; ch < 2; ch++)
+            for (ch = 0; ch < nch; ch++)
                 bufp[ch] = &inbuf[ch][576 + gr * 576 - LH_FFTOFFSET];
             orc_psycho_anal(S, bufp, gr, masking_LR, masking_MS, pe[gr], pe_MS[gr], tot_ener[gr],
                             blocktype);
@@ -197,7 +206,7 @@ orc_encode_frame(OrcStream * S, const float *inbuf_l, const float *inbuf_r, LhFr
                 if (ms_ener_ratio[gr] > 0)
                     ms_ener_ratio[gr] = tot_ener[gr][3] / ms_ener_ratio[gr];
             }
-            for (ch = 0; ch < 2; ch++) {
+            for (ch = 0; ch < nch; ch++) {
                 S->tt[gr][ch].block_type = blocktype[ch];
                 S->tt[gr][ch].mixed_block_flag = 0;
             }
@@ -213,7 +222,7 @@ orc_encode_frame(OrcStream * S, const float *inbuf_l, const float *inbuf_r, LhFr
         float   sum_pe_MS = 0;
         float   sum_pe_LR = 0;
         for (gr = 0; gr < 2; gr++) {
-            for (ch = 0; ch < 2; ch++) {
+            for (ch = 0; ch < nch; ch++) {
                 sum_pe_MS += pe_MS[gr][ch];
                 sum_pe_LR += pe[gr][ch];
             }
@@ -245,15 +254,15 @@ orc_encode_frame(OrcStream * S, const float *inbuf_l, const float *inbuf_r, LhFr
             S->pefirbuf[i] = S->pefirbuf[i + 1];
         f = 0.0;
         for (gr = 0; gr < 2; gr++)
-            for (ch = 0; ch < 2; ch++)
+            for (ch = 0; ch < nch; ch++)
                 f += pe_use[gr][ch];
         S->pefirbuf[18] = f;
         f = S->pefirbuf[9];
         for (i = 0; i < 9; i++)
             f += (S->pefirbuf[i] + S->pefirbuf[18 - i]) * fircoef[i];
-        f = (670 * 5 * 2 * 2) / f;
+        f = (670 * 5 * 2 * nch) / f;
         for (gr = 0; gr < 2; gr++)
-            for (ch = 0; ch < 2; ch++)
+            for (ch = 0; ch < nch; ch++)
                 pe_use[gr][ch] *= f;
     }
     mdb_header = S->main_data_begin;
@@ -269,7 +278,7 @@ orc_encode_frame(OrcStream * S, const float *inbuf_l, const float *inbuf_r, LhFr
         int     bits = 8 * cfg->sideinfo_len, frame_bits;
         int     bit_rate = lh_bitrate_mpeg1[S->bitrate_index];
         for (gr = 0; gr < 2; gr++)
-            for (ch = 0; ch < 2; ch++)
+            for (ch = 0; ch < nch; ch++)
                 bits += S->tt[gr][ch].part2_3_length + S->tt[gr][ch].part2_length;
         bits += S->resvDrain_post;
         frame_bits = 8 * ((cfg->version + 1) * 72000 * bit_rate / cfg->samplerate + S->padding);

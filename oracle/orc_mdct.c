@@ -333,7 +333,7 @@ orc_mdct_sub48(OrcStream * S, const float *w0, const float *w1)
     const float *wk = w0 + 286;
     const float *amp = S->tab->amp_filter;
 
-    for (ch = 0; ch < 2; ch++) {
+    for (ch = 0; ch < S->cfg->channels; ch++) {
         for (gr = 0; gr < 2; gr++) {
             int     band;
             OrcGr  *const gi = &S->tt[gr][ch];

@@ -482,7 +482,7 @@ attack_detection(OrcStream * S, const float *const buffer[2], int gr_out,
                  float sub_short_factor[4][3], int ns_attacks[4][4], int uselongblock[2])
 {
     float   ns_hpfsmpl[2][576];
-    int const n_chn_out = 2;
+    int const n_chn_out = S->cfg->channels;
     int const n_chn_psy = (S->cfg->mode == LH_MODE_JOINT_STEREO) ? 4 : n_chn_out;
     int     chn, i, j;
 
@@ -839,7 +839,8 @@ orc_psycho_anal(OrcStream * S, const float *const buffer[2], int gr_out,
     int     ns_attacks[4][4] = { {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0} };
     int     uselongblock[2];
     int     chn, sb, sblock;
-    int const n_chn_psy = (cfg->mode == LH_MODE_JOINT_STEREO) ? 4 : 2;
+    int const n_chn_out = cfg->channels;
+    int const n_chn_psy = (cfg->mode == LH_MODE_JOINT_STEREO) ? 4 : n_chn_out;
 
     memcpy(&last_thm[0], &S->thm[0], sizeof(last_thm));
     attack_detection(S, buffer, gr_out, masking_ratio, masking_MS_ratio, energy, sub_short_factor,
@@ -847,7 +848,7 @@ orc_psycho_anal(OrcStream * S, const float *const buffer[2], int gr_out,
     /* vbrpsy_compute_block_type, reference psymodel.c:1265-1286 */
     if (cfg->short_blocks == 1 && !(uselongblock[0] && uselongblock[1]))
         uselongblock[0] = uselongblock[1] = 0;
-    for (chn = 0; chn < 2; chn++) {
+    for (chn = 0; chn < n_chn_out; chn++) {
         if (cfg->short_blocks == 2)
             uselongblock[chn] = 1;
         if (cfg->short_blocks == 3)
@@ -970,7 +971,7 @@ orc_psycho_anal(OrcStream * S, const float *const buffer[2], int gr_out,
         S->last_attacks[chn] = ns_attacks[chn][2];
 
     /* vbrpsy_apply_block_type, reference psymodel.c:1289-1319 */
-    for (chn = 0; chn < 2; chn++) {
+    for (chn = 0; chn < n_chn_out; chn++) {
         int     blocktype = LH_NORM_TYPE;
         if (uselongblock[chn]) {
             if (S->blocktype_old[chn] == LH_SHORT_TYPE)

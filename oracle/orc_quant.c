@@ -1023,13 +1023,14 @@ on_pe(OrcStream * S, float pe[][2], int targ_bits[2], int mean_bits, int gr, int
     int     extra_bits = 0, tbits, bits;
     int     add_bits[2] = { 0, 0 };
     int     max_bits, ch;
+    int const nch = S->cfg->channels;
 
     ResvMaxBits(S, mean_bits, &tbits, &extra_bits, cbr);
     max_bits = tbits + extra_bits;
     if (max_bits > LH_MAX_BITS_PER_GRANULE)
         max_bits = LH_MAX_BITS_PER_GRANULE;
-    for (bits = 0, ch = 0; ch < 2; ++ch) {
-        targ_bits[ch] = (LH_MAX_BITS_PER_CHANNEL < tbits / 2) ? LH_MAX_BITS_PER_CHANNEL : tbits / 2;
+    for (bits = 0, ch = 0; ch < nch; ++ch) {
+        targ_bits[ch] = (LH_MAX_BITS_PER_CHANNEL < tbits / nch) ? LH_MAX_BITS_PER_CHANNEL : tbits / nch;
         add_bits[ch] = targ_bits[ch] * pe[gr][ch] / 700.0 - targ_bits[ch];
         if (add_bits[ch] > mean_bits * 3 / 4)
             add_bits[ch] = mean_bits * 3 / 4;
@@ -1042,17 +1043,17 @@ on_pe(OrcStream * S, float pe[][2], int targ_bits[2], int mean_bits, int gr, int
         bits += add_bits[ch];
     }
     if (bits > extra_bits && bits > 0) {
-        for (ch = 0; ch < 2; ++ch)
+        for (ch = 0; ch < nch; ++ch)
             add_bits[ch] = extra_bits * add_bits[ch] / bits;
     }
-    for (ch = 0; ch < 2; ++ch) {
+    for (ch = 0; ch < nch; ++ch) {
         targ_bits[ch] += add_bits[ch];
         extra_bits -= add_bits[ch];
     }
-    for (bits = 0, ch = 0; ch < 2; ++ch)
+    for (bits = 0, ch = 0; ch < nch; ++ch)
         bits += targ_bits[ch];
     if (bits > LH_MAX_BITS_PER_GRANULE) {
-        for (ch = 0; ch < 2; ++ch) {
+        for (ch = 0; ch < nch; ++ch) {
             targ_bits[ch] *= LH_MAX_BITS_PER_GRANULE;
             targ_bits[ch] /= bits;
         }
@@ -1608,7 +1609,7 @@ orc_cbr_iteration_loop(OrcStream * S, float pe[2][2], const float ms_ener_ratio[
             }
             reduce_side(targ_bits, ms_ener_ratio[gr], mean_bits, max_bits);
         }
-        for (ch = 0; ch < 2; ch++) {
+        for (ch = 0; ch < cfg->channels; ch++) {
             OrcGr  *cod_info = &S->tt[gr][ch];
             if (cod_info->block_type != LH_SHORT_TYPE)
                 S->masking_lower = cfg->masking_lower_long;

@@ -661,9 +661,10 @@ vbr_encode_frame(OrcStream * S, float xr34[2][2][576], float xmin[2][2][LH_SFBMA
     int     max_ch[2][2], max_gr[2] = { 0, 0 }, max_fr = 0;
     int     use_ch[2][2], use_gr[2], use_fr;
     int     gr, ch, ok, sum_fr;
+    int const nch = S->cfg->channels;
 
     for (gr = 0; gr < 2; ++gr)
-        for (ch = 0; ch < 2; ++ch) {
+        for (ch = 0; ch < nch; ++ch) {
             OrcVbrGr *v = &V[gr][ch];
             max_ch[gr][ch] = max_bits[gr][ch];
             max_gr[gr] += max_bits[gr][ch];
@@ -676,7 +677,7 @@ vbr_encode_frame(OrcStream * S, float xr34[2][2][576], float xmin[2][2][LH_SFBMA
         }
     /* scalefactor search */
     for (gr = 0; gr < 2; ++gr)
-        for (ch = 0; ch < 2; ++ch)
+        for (ch = 0; ch < nch; ++ch)
             if (max_bits[gr][ch] > 0) {
                 OrcVbrGr *v = &V[gr][ch];
                 int const vbrmax = vbr_band_steps(v, xmin[gr][ch]);
@@ -686,7 +687,7 @@ vbr_encode_frame(OrcStream * S, float xr34[2][2][576], float xmin[2][2][LH_SFBMA
     use_fr = 0;
     for (gr = 0; gr < 2; ++gr) {
         use_gr[gr] = 0;
-        for (ch = 0; ch < 2; ++ch) {
+        for (ch = 0; ch < nch; ++ch) {
             if (max_bits[gr][ch] > 0) {
                 memset(S->tt[gr][ch].l3_enc, 0, sizeof(S->tt[gr][ch].l3_enc));
                 (void) vbr_quantize_count(&V[gr][ch]);
@@ -701,7 +702,7 @@ vbr_encode_frame(OrcStream * S, float xr34[2][2][576], float xmin[2][2][LH_SFBMA
         for (gr = 0; gr < 2; ++gr) {
             if (use_gr[gr] > LH_MAX_BITS_PER_GRANULE)
                 ok = 0;
-            for (ch = 0; ch < 2; ++ch)
+            for (ch = 0; ch < nch; ++ch)
                 if (use_ch[gr][ch] > LH_MAX_BITS_PER_CHANNEL)
                     ok = 0;
         }
@@ -713,13 +714,13 @@ vbr_encode_frame(OrcStream * S, float xr34[2][2][576], float xmin[2][2][LH_SFBMA
     sum_fr = 0;
     for (gr = 0; gr < 2; ++gr) {
         max_gr[gr] = 0;
-        for (ch = 0; ch < 2; ++ch) {
+        for (ch = 0; ch < nch; ++ch) {
             max_ch[gr][ch] = (use_ch[gr][ch] > LH_MAX_BITS_PER_CHANNEL) ? LH_MAX_BITS_PER_CHANNEL : use_ch[gr][ch];
             max_gr[gr] += max_ch[gr][ch];
         }
         if (max_gr[gr] > LH_MAX_BITS_PER_GRANULE) {
             float   f[2] = { 0.0f, 0.0f }, s = 0.0f;
-            for (ch = 0; ch < 2; ++ch) {
+            for (ch = 0; ch < nch; ++ch) {
                 if (max_ch[gr][ch] > 0) {
                     f[ch] = sqrt(sqrt(max_ch[gr][ch]));
                     s += f[ch];
@@ -727,13 +728,17 @@ vbr_encode_frame(OrcStream * S, float xr34[2][2][576], float xmin[2][2][LH_SFBMA
                 else
                     f[ch] = 0;
             }
-            for (ch = 0; ch < 2; ++ch)
+            for (ch = 0; ch < nch; ++ch)
                 max_ch[gr][ch] = (s > 0) ? (int) (LH_MAX_BITS_PER_GRANULE * f[ch] / s) : 0;
-            vbr_share(max_ch[gr], use_ch[gr], 32);
-            for (ch = 0; ch < 2; ++ch)
-                if (max_ch[gr][ch] > LH_MAX_BITS_PER_CHANNEL)
-                    max_ch[gr][ch] = LH_MAX_BITS_PER_CHANNEL;
-            max_gr[gr] = max_ch[gr][0] + max_ch[gr][1];
+            if (nch > 1) {
+                vbr_share(max_ch[gr], use_ch[gr], 32);
+                for (ch = 0; ch < nch; ++ch)
+                    if (max_ch[gr][ch] > LH_MAX_BITS_PER_CHANNEL)
+                        max_ch[gr][ch] = LH_MAX_BITS_PER_CHANNEL;
+            }
+            max_gr[gr] = 0;
+            for (ch = 0; ch < nch; ++ch)
+                max_gr[gr] += max_ch[gr][ch];
         }
         sum_fr += max_gr[gr];
     }
@@ -757,7 +762,7 @@ vbr_encode_frame(OrcStream * S, float xr34[2][2][576], float xmin[2][2][LH_SFBMA
                 max_gr[gr] = LH_MAX_BITS_PER_GRANULE;
         for (gr = 0; gr < 2; ++gr) {
             float   f[2] = { 0.0f, 0.0f }, s = 0.0f;
-            for (ch = 0; ch < 2; ++ch) {
+            for (ch = 0; ch < nch; ++ch) {
                 if (max_ch[gr][ch] > 0) {
                     f[ch] = sqrt(max_ch[gr][ch]);
                     s += f[ch];
@@ -765,18 +770,20 @@ vbr_encode_frame(OrcStream * S, float xr34[2][2][576], float xmin[2][2][LH_SFBMA
                 else
                     f[ch] = 0;
             }
-            for (ch = 0; ch < 2; ++ch)
+            for (ch = 0; ch < nch; ++ch)
                 max_ch[gr][ch] = (s > 0) ? (int) (max_gr[gr] * f[ch] / s) : 0;
-            vbr_share(max_ch[gr], use_ch[gr], 32);
-            for (ch = 0; ch < 2; ++ch)
-                if (max_ch[gr][ch] > LH_MAX_BITS_PER_CHANNEL)
-                    max_ch[gr][ch] = LH_MAX_BITS_PER_CHANNEL;
+            if (nch > 1) {
+                vbr_share(max_ch[gr], use_ch[gr], 32);
+                for (ch = 0; ch < nch; ++ch)
+                    if (max_ch[gr][ch] > LH_MAX_BITS_PER_CHANNEL)
+                        max_ch[gr][ch] = LH_MAX_BITS_PER_CHANNEL;
+            }
         }
     }
     sum_fr = 0;
     for (gr = 0; gr < 2; ++gr) {
         int     sum_gr = 0;
-        for (ch = 0; ch < 2; ++ch) {
+        for (ch = 0; ch < nch; ++ch) {
             sum_gr += max_ch[gr][ch];
             if (max_ch[gr][ch] > LH_MAX_BITS_PER_CHANNEL)
                 ok = 0;
@@ -789,18 +796,18 @@ vbr_encode_frame(OrcStream * S, float xr34[2][2][576], float xmin[2][2][LH_SFBMA
         ok = 0;
     if (!ok)                    /* fall back to the on_pe split */
         for (gr = 0; gr < 2; ++gr)
-            for (ch = 0; ch < 2; ++ch)
+            for (ch = 0; ch < nch; ++ch)
                 max_ch[gr][ch] = max_bits[gr][ch];
     /* best_scalefac_store ran already: undo its bookkeeping before the second pass */
-    for (ch = 0; ch < 2; ++ch)
+    for (ch = 0; ch < nch; ++ch)
         S->scfsi[ch][0] = S->scfsi[ch][1] = S->scfsi[ch][2] = S->scfsi[ch][3] = 0;
     for (gr = 0; gr < 2; ++gr)
-        for (ch = 0; ch < 2; ++ch)
+        for (ch = 0; ch < nch; ++ch)
             S->tt[gr][ch].scalefac_compress = 0;
     use_fr = 0;
     for (gr = 0; gr < 2; ++gr) {
         use_gr[gr] = 0;
-        for (ch = 0; ch < 2; ++ch) {
+        for (ch = 0; ch < nch; ++ch) {
             OrcVbrGr *v = &V[gr][ch];
             if (max_bits[gr][ch] > 0) {
                 int     i;
@@ -849,7 +856,7 @@ orc_vbr_new_iteration_loop(OrcStream * S, float pe[2][2], const OrcRatio ratio[2
                 S->tt[gr][1].xr[i] = (l - r) * (float) (ORC_SQRT2 * 0.5);
             }
         }
-        for (ch = 0; ch < 2; ++ch) {
+        for (ch = 0; ch < cfg->channels; ++ch) {
             OrcGr  *gi = &S->tt[gr][ch];
             S->masking_lower = cfg->masking_lower_long; /* pow(10, mask_adjust * 0.1) for every block type */
             init_outer_loop(S, gi);
@@ -859,7 +866,7 @@ orc_vbr_new_iteration_loop(OrcStream * S, float pe[2][2], const OrcRatio ratio[2
         }
     }
     for (gr = 0; gr < 2; gr++)
-        for (ch = 0; ch < 2; ch++)
+        for (ch = 0; ch < cfg->channels; ch++)
             if (bits > top_bits && bits > 0) {
                 max_bits[gr][ch] *= top_bits;
                 max_bits[gr][ch] /= bits;
@@ -868,7 +875,7 @@ orc_vbr_new_iteration_loop(OrcStream * S, float pe[2][2], const OrcRatio ratio[2
         pad = 0;
 
     for (gr = 0; gr < 2; gr++)
-        for (ch = 0; ch < 2; ch++)
+        for (ch = 0; ch < cfg->channels; ch++)
             if (0 == init_xrpow(S, &S->tt[gr][ch], xr34[gr][ch]))
                 max_bits[gr][ch] = 0;   /* silent granule needs no bits */
 
@@ -891,7 +898,7 @@ orc_vbr_new_iteration_loop(OrcStream * S, float pe[2][2], const OrcRatio ratio[2
         S->bitrate_index = i;
     (void) ResvFrameBegin(S, &mean_bits);
     for (gr = 0; gr < 2; gr++)
-        for (ch = 0; ch < 2; ch++)
+        for (ch = 0; ch < cfg->channels; ch++)
             S->ResvSize -= S->tt[gr][ch].part2_3_length + S->tt[gr][ch].part2_length;  /* ResvAdjust */
     ResvFrameEnd(S, mean_bits);
 }

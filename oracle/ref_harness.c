@@ -33,6 +33,16 @@ typedef struct RefH {
     lame_global_flags *gfp;
 } RefH;
 
+/* number of input channels of the handles opened next (1 = mono: the reference then encodes MONO
+ * and reads only the left buffer) */
+static int refh_channels = 2;
+
+void
+refh_set_channels(int n)
+{
+    refh_channels = (n == 1) ? 1 : 2;
+}
+
 static void
 quiet(const char *fmt, va_list ap)
 {
@@ -50,7 +60,7 @@ refh_open(int samplerate, int brate, int mode, int quality)
     lame_set_debugf(h->gfp, quiet);
     lame_set_msgf(h->gfp, quiet);
     lame_set_in_samplerate(h->gfp, samplerate);
-    lame_set_num_channels(h->gfp, 2);
+    lame_set_num_channels(h->gfp, refh_channels);
     lame_set_brate(h->gfp, brate);
     lame_set_bWriteVbrTag(h->gfp, 0);
     if (mode >= 0)
@@ -76,7 +86,7 @@ refh_open_tag(int samplerate, int brate, int mode, int quality)
     lame_set_debugf(h->gfp, quiet);
     lame_set_msgf(h->gfp, quiet);
     lame_set_in_samplerate(h->gfp, samplerate);
-    lame_set_num_channels(h->gfp, 2);
+    lame_set_num_channels(h->gfp, refh_channels);
     lame_set_brate(h->gfp, brate);
     lame_set_bWriteVbrTag(h->gfp, 1);
     if (mode >= 0)
@@ -103,7 +113,7 @@ refh_open_vbr(int samplerate, int vbr_q, int mode, int quality, int out_samplera
     lame_set_in_samplerate(h->gfp, samplerate);
     if (out_samplerate > 0)
         lame_set_out_samplerate(h->gfp, out_samplerate);
-    lame_set_num_channels(h->gfp, 2);
+    lame_set_num_channels(h->gfp, refh_channels);
     lame_set_VBR(h->gfp, vbr_mtrh);
     lame_set_VBR_q(h->gfp, vbr_q);
     lame_set_bWriteVbrTag(h->gfp, tag);
@@ -131,7 +141,7 @@ refh_open_abr(int samplerate, int mean_kbps, int mode, int quality, int out_samp
     lame_set_in_samplerate(h->gfp, samplerate);
     if (out_samplerate > 0)
         lame_set_out_samplerate(h->gfp, out_samplerate);
-    lame_set_num_channels(h->gfp, 2);
+    lame_set_num_channels(h->gfp, refh_channels);
     lame_set_VBR(h->gfp, vbr_abr);
     lame_set_VBR_mean_bitrate_kbps(h->gfp, mean_kbps);
     lame_set_bWriteVbrTag(h->gfp, tag);

@@ -54,6 +54,16 @@ ABR_CASES = [
 ]
 
 
+MONO_CASES = [
+    # name, samplerate, kwargs of Reference.encode (brate / vbr_q / abr), quality, seed, seconds, burst, white
+    ("mono_cbr96_44k", 44100, dict(brate=96), -1, 401, 1.0, None, False),
+    ("mono_cbr160_48k_bursts_q5", 48000, dict(brate=160), 5, 402, 1.0, 1.0 / 30, False),
+    ("mono_vbr2_44k", 44100, dict(vbr_q=2), -1, 403, 1.0, None, False),
+    ("mono_vbr5_32k_white", 32000, dict(vbr_q=5), -1, 404, 0.8, None, True),
+    ("mono_abr100_44k", 44100, dict(abr=100), -1, 405, 1.0, None, False),
+]
+
+
 def frame_hash(fr):
     return hashlib.sha256(bytes(fr)).hexdigest()
 
@@ -90,14 +100,20 @@ def main():
         nn = int(sr * secs)
         x = np.zeros((2, nn), np.int16) if seed < 0 else helpers.synth_stream(seed, nn, sr, burst, white)
         cases.append((name, sr, 0, mode, q, (seed, secs, burst, white), x, -1, kb))
-    for name, sr, br, mode, q, recipe, x, vq, abr in cases:
+    cases = [c + (2,) for c in cases]
+    for name, sr, kw, q, seed, secs, burst, white in MONO_CASES:
+        x = helpers.synth_stream(seed, int(sr * secs), sr, burst, white)
+        x = np.stack([x[0], x[0]])      # mono: the one channel the encoder reads
+        cases.append((name, sr, kw.get("brate", 0), -1, q, (seed, secs, burst, white), x, kw.get("vbr_q", -1),
+                      kw.get("abr", -1), 1))
+    for name, sr, br, mode, q, recipe, x, vq, abr, nch in cases:
         mp3, nf, frames, cfg, tab = ref.encode(x, sr, br, mode, q, max_frames=4096, vbr_q=None if vq < 0 else vq,
-                                               abr=None if abr < 0 else abr)
+                                               abr=None if abr < 0 else abr, channels=nch)
         hashes = [frame_hash(frames[f]) for f in range(nf)]
         th = table_hashes(tab)
         np.savez_compressed(
             os.path.join(HERE, name + ".npz"),
-            samplerate=sr, brate=br, mode=mode, quality=q, vbr_q=vq, abr=abr,
+            samplerate=sr, brate=br, mode=mode, quality=q, vbr_q=vq, abr=abr, channels=nch,
             recipe=np.array([-2 if recipe is None else recipe[0],
                              0 if recipe is None else recipe[1],
                              0 if (recipe is None or recipe[2] is None) else recipe[2],

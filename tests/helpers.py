@@ -87,8 +87,11 @@ class Reference:
         self.lib.refh_open_abr.restype = C.c_void_p
         self.lib.refh_encode_stream.restype = C.c_long
 
-    def encode(self, pcm, sr, brate, mode=-1, quality=-1, max_frames=0, vbr_q=None, out_samplerate=0, abr=None):
-        """CBR at `brate', vbr_mtrh at quality vbr_q, or ABR at a mean of `abr' kb/s."""
+    def encode(self, pcm, sr, brate, mode=-1, quality=-1, max_frames=0, vbr_q=None, out_samplerate=0, abr=None,
+               channels=2):
+        """CBR at `brate', vbr_mtrh at quality vbr_q, or ABR at a mean of `abr' kb/s; channels=1: mono
+        (only pcm[0] is read)."""
+        self.lib.refh_set_channels(channels)
         left = np.ascontiguousarray(pcm[0], dtype=np.int16)
         right = np.ascontiguousarray(pcm[1], dtype=np.int16)
         n = len(left)
@@ -114,12 +117,13 @@ class Reference:
         return buf.raw[:k], nf.value, frames, cfg, tab
 
 
-def reference_tagged(pcm, sr, brate, mode=-1, quality=-1, chunk=1152, vbr_q=None, abr=None):
+def reference_tagged(pcm, sr, brate, mode=-1, quality=-1, chunk=1152, vbr_q=None, abr=None, channels=2):
     """The compiled reference with its default tag handling (bWriteVbrTag = 1): returns
     (stream bytes incl. the placeholder frame, final tag frame).  vbr_q selects vbr_mtrh."""
     ref = Reference()
     lib = ref.lib
     lib.refh_open_tag.restype = C.c_void_p
+    lib.refh_set_channels(channels)
     if abr is not None:
         h = lib.refh_open_abr(sr, abr, mode, quality, 0, 1)
     elif vbr_q is None:
@@ -170,12 +174,12 @@ GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
 
 def golden_names(vbr=False, kind=None):
-    """Fixtures by rate control: CBR by default, vbr=True / kind="vbr" the vbr_mtrh ones, kind="abr"
-    the ABR ones (the kind is in the file name)."""
+    """Fixtures by kind: stereo CBR by default, vbr=True / kind="vbr" the vbr_mtrh ones, kind="abr"
+    the ABR ones, kind="mono" the one-channel ones of any rate control (the kind is in the file name)."""
     kind = kind or ("vbr" if vbr else "cbr")
 
     def k(f):
-        return "vbr" if "vbr" in f else ("abr" if "abr" in f else "cbr")
+        return "mono" if f.startswith("mono_") else "vbr" if "vbr" in f else ("abr" if "abr" in f else "cbr")
     return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and k(f) == kind)
 
 
@@ -193,6 +197,8 @@ def load_golden(name):
         pcm = np.zeros((2, int(g["nsamples"])), np.int16)
     else:
         pcm = synth_stream(int(seed), int(sr * secs), sr, burst if burst > 0 else None, bool(white))
+    if "channels" in g and int(g["channels"]) == 1:
+        pcm = np.stack([pcm[0], pcm[0]])
     assert pcm.shape[1] == int(g["nsamples"])
     return g, np.ascontiguousarray(pcm)
 
@@ -207,6 +213,13 @@ def golden_vbr_q(g):
     """None for a CBR fixture, else the vbr_mtrh quality (-V n) it was made with."""
     v = int(g["vbr_q"]) if "vbr_q" in g else -1
     return None if v < 0 else v
+
+
+def golden_encoder_kwargs(g):
+    """Keyword arguments of lamehip.Encoder for a fixture of any kind."""
+    sr, br, mode, q = golden_settings(g)
+    return dict(samplerate=sr, brate=br, mode=mode, quality=q, vbr_q=golden_vbr_q(g), abr=golden_abr(g),
+                channels=int(g["channels"]) if "channels" in g else 2)
 
 
 def golden_abr(g):

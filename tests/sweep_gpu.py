@@ -2,7 +2,7 @@
 """Settings sweep on the GPU box (test tool, not collected by pytest): every MPEG-1 bit rate x
 sample rate x stereo mode x a set of quality levels that lame_init_params accepts, a few
 awkward signals each, HIP payload against the CPU oracle frame by frame.
-Usage: python tests/sweep_gpu.py [streams_per_setting] [seconds] [cbr|vbr|abr|all]
+Usage: python tests/sweep_gpu.py [streams_per_setting] [seconds] [cbr|vbr|abr|all] [channels]
 "vbr": vbr_mtrh -V0..-V9 x sample rate x stereo mode x quality 0 / 5 / 7 instead of the CBR grid;
 "abr": ABR means (incl. values between the table rates) x sample rate x mode x quality 0 / 3 / 5 / 7."""
 import os
@@ -12,6 +12,7 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "deprecated-lame-mirror_amd"))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import numpy as np  # noqa: E402
 import helpers  # noqa: E402
 import lamehip  # noqa: E402
 from lamehip.types import struct_diff  # noqa: E402
@@ -22,6 +23,7 @@ def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 6
     secs = float(sys.argv[2]) if len(sys.argv) > 2 else 1.2
     what = sys.argv[3] if len(sys.argv) > 3 else "cbr"
+    nch = int(sys.argv[4]) if len(sys.argv) > 4 else 2      # 1: mono input (the mode axis is skipped)
     orc = helpers.Oracle()
     bad = tot = nset = unsup = 0
     t0 = time.time()
@@ -32,16 +34,16 @@ def main():
                 for q in (0, 3, 5, 7)] if what in ("abr", "all") else []
     for sr in (32000, 44100, 48000):
         for br, q in cbr_grid + vbr_grid + abr_grid:    # br <= 0: vbr_mtrh at quality -br; >= 1000: ABR
-            for mode in (0, 1):
+            for mode in ((0, 1) if nch == 2 else (None,)):
                 for _once in (0,):
                     try:
                         if br >= 1000:
-                            enc = lamehip.Encoder(sr, mode=mode, quality=q, abr=br - 1000)
+                            enc = lamehip.Encoder(sr, mode=mode, quality=q, abr=br - 1000, channels=nch)
                         elif br > 0:
-                            enc = lamehip.Encoder(sr, br, mode, q)
+                            enc = lamehip.Encoder(sr, br, mode, q, channels=nch)
                         else:
                             enc = lamehip.Encoder(sr, mode=mode, quality=q, vbr_q=-br,
-                                                  out_samplerate=sr if -br >= 7 else 0)
+                                                  out_samplerate=sr if -br >= 7 else 0, channels=nch)
                     except RuntimeError:
                         unsup += 1
                         continue
@@ -50,6 +52,8 @@ def main():
                     n = int(sr * secs)
                     pcms = [tg._stress_signal(abs(br) + q + 8 * i + i, n - 29 * i, sr) for i in range(B)]
                     b = lamehip.Batch(enc, B, n)
+                    if nch == 1:
+                        pcms = [np.stack([x[0], x[0]]) for x in pcms]
                     for s, x in enumerate(pcms):
                         b.set_pcm(s, x[0], x[1])
                     b.encode()

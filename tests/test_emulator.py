@@ -31,12 +31,12 @@ def emu():
 @pytest.mark.parametrize("name,nframes", [("cbr128_js_44k", 8), ("cbr320_js_48k_bursts", 8),
                                           ("cbr256_js_44k_q2", 5), ("cbr96_js_32k", 6),
                                           ("vbr2_js_44k", 8), ("vbr4_js_44k_white", 8), ("vbr0_js_48k_bursts", 8),
-                                          ("vbr5_st_32k", 6), ("abr128_js_44k", 6), ("abr150_js_32k_white_q5", 6)])
+                                          ("vbr5_st_32k", 6), ("abr128_js_44k", 6), ("abr150_js_32k_white_q5", 6),
+                                          ("mono_cbr160_48k_bursts_q5", 6), ("mono_vbr2_44k", 6), ("mono_abr100_44k", 5)])
 def test_kernel_source_matches_oracle(name, nframes, emu, oracle):
     g, pcm = helpers.load_golden(name)
     sr, br, mode, q = helpers.golden_settings(g)
-    enc = lamehip.Encoder(sr, br, mode, q, require_device=False, vbr_q=helpers.golden_vbr_q(g),
-                          abr=helpers.golden_abr(g))
+    enc = lamehip.Encoder(require_device=False, **helpers.golden_encoder_kwargs(g))
     cfg, tab = enc.config(), enc.tables()
     want = oracle.encode_frames(cfg, tab, pcm, max_frames=nframes)
     n = pcm.shape[1]

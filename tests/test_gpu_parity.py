@@ -20,14 +20,14 @@ def test_wave_primitives_selftest():
 
 
 def _encoder(g, **kw):
-    sr, br, mode, q = helpers.golden_settings(g)
-    return lamehip.Encoder(sr, br, mode, q, vbr_q=helpers.golden_vbr_q(g), abr=helpers.golden_abr(g), **kw)
+    return lamehip.Encoder(**helpers.golden_encoder_kwargs(g), **kw)
 
 
 VBR_GOLDEN = helpers.golden_names(vbr=True)
 
 
-@pytest.mark.parametrize("name", helpers.golden_names() + VBR_GOLDEN + helpers.golden_names(kind="abr"))
+@pytest.mark.parametrize("name", helpers.golden_names() + VBR_GOLDEN + helpers.golden_names(kind="abr")
+                         + helpers.golden_names(kind="mono"))
 def test_batch_payload_and_bytes_match_golden(name):
     g, pcm = helpers.load_golden(name)
     enc = _encoder(g)
@@ -52,7 +52,8 @@ def test_batch_payload_and_bytes_match_golden(name):
                                         ("cbr320_js_48k_bursts", 4000), ("cbr128_js_44k_silence", 1),
                                         ("testcase_wav_vbr2", 1152), ("vbr4_js_44k_white", 2500),
                                         ("vbr0_js_48k_bursts", 600), ("abr128_js_44k", 1152),
-                                        ("abr200_st_48k_bursts", 3000)])
+                                        ("abr200_st_48k_bursts", 3000), ("mono_cbr96_44k", 1152),
+                                        ("mono_vbr2_44k", 2000)])
 def test_lame_encode_buffer_call_sequence(name, chunk):
     """lame_init -> set -> init_params -> N x lame_encode_buffer -> flush, as the
     reference frontend drives it (frontend/lame_main.c:381-470)."""
@@ -355,6 +356,33 @@ def test_long_streams_match_oracle(kw, oracle):
     b.encode()
     for i, x in enumerate(pcms):
         want = oracle.encode_frames(cfg, tab, x)
+        got = b.get_frames(i)
+        assert len(got) == len(want)
+        bad = [f for f in range(len(want)) if struct_diff(want[f], got[f])]
+        assert not bad, (i, bad[:5])
+        assert b.pack(i) == helpers.pack_frames(enc.lib, cfg, tab, want)
+    b.close()
+    enc.close()
+
+
+@pytest.mark.parametrize("kw", [dict(brate=128), dict(brate=64, samplerate=32000), dict(brate=320, samplerate=48000, quality=0),
+                                dict(vbr_q=0, samplerate=48000), dict(vbr_q=4), dict(vbr_q=7, quality=7), dict(abr=90),
+                                dict(abr=256, quality=5)])
+def test_mono_batch_matches_oracle(kw, oracle):
+    """One input channel (MPEG mode mono): ragged batch against the CPU oracle, every frame and the bytes."""
+    sr = kw.get("samplerate", 44100)
+    if kw.get("vbr_q", 0) >= 7:
+        kw = dict(kw, out_samplerate=sr)
+    enc = lamehip.Encoder(channels=1, **kw)
+    cfg, tab = enc.config(), enc.tables()
+    lens = [int(sr * 1.2), int(sr * 0.3) + 11, 1, int(sr * 0.7)]
+    b = lamehip.Batch(enc, len(lens), max(lens))
+    pcms = [helpers.synth_stream(1200 + i, n, sr, 1.0 / 8, white=(i == 3)) for i, n in enumerate(lens)]
+    for i, x in enumerate(pcms):
+        b.set_pcm(i, x[0])
+    b.encode()
+    for i, x in enumerate(pcms):
+        want = oracle.encode_frames(cfg, tab, np.stack([x[0], x[0]]))
         got = b.get_frames(i)
         assert len(got) == len(want)
         bad = [f for f in range(len(want)) if struct_diff(want[f], got[f])]

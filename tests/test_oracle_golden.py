@@ -12,11 +12,12 @@ import lamehip
 from lamehip.types import LhConfig, struct_diff
 
 
-@pytest.mark.parametrize("name", helpers.golden_names() + helpers.golden_names(vbr=True) + helpers.golden_names(kind="abr"))
+@pytest.mark.parametrize("name", helpers.golden_names() + helpers.golden_names(vbr=True) + helpers.golden_names(kind="abr")
+                         + helpers.golden_names(kind="mono"))
 def test_golden(name, oracle):
     g, pcm = helpers.load_golden(name)
     sr, br, mode, q = helpers.golden_settings(g)
-    enc = lamehip.Encoder(sr, br, mode, q, require_device=False, vbr_q=helpers.golden_vbr_q(g), abr=helpers.golden_abr(g))
+    enc = lamehip.Encoder(require_device=False, **helpers.golden_encoder_kwargs(g))
     cfg, tab = enc.config(), enc.tables()
     # resolved constants == the reference's SessionConfig_t subset
     ref_cfg = LhConfig.from_buffer_copy(g["config"].tobytes())
