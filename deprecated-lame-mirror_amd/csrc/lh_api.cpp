@@ -409,7 +409,7 @@ lame_encode_buffer(lame_t g, const short int l[], const short int r[], const int
         return 0;
     if (nsamples < 0)
         return -1;
-    if (g->cfg.channels == 1)
+    if (g->p.channels == 1)
         r = l;                  /* one input channel: buffer_r is not read (reference lame.c:1855-1866) */
     g->hl.insert(g->hl.end(), l, l + nsamples);
     g->hr.insert(g->hr.end(), r, r + nsamples);
@@ -689,7 +689,7 @@ lamehip_batch_set_pcm(lamehip_batch * b, int s, const short *l, const short *r, 
 {
     if (lamehip_batch_set_length(b, s, n) != 0)
         return -1;
-    if (b->cfg.channels == 1)
+    if (b->cfg.channels == 1 && b->cfg.pcm_mix == 0.0f)
         r = l;                  /* mono: the second plane mirrors the first, the kernel never uses it */
     HIPCHK(hipMemcpy(b->d_pcm + ((size_t) s * 2) * (size_t) b->cap, l, (size_t) n * 2, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(b->d_pcm + ((size_t) s * 2 + 1) * (size_t) b->cap, r, (size_t) n * 2, hipMemcpyHostToDevice));
@@ -701,7 +701,7 @@ lamehip_batch_set_pcm_device(lamehip_batch * b, int s, const void *dl, const voi
 {
     if (lamehip_batch_set_length(b, s, n) != 0)
         return -1;
-    if (b->cfg.channels == 1)
+    if (b->cfg.channels == 1 && b->cfg.pcm_mix == 0.0f)
         dr = dl;
     HIPCHK(hipMemcpy(b->d_pcm + ((size_t) s * 2) * (size_t) b->cap, dl, (size_t) n * 2, hipMemcpyDeviceToDevice));
     HIPCHK(hipMemcpy(b->d_pcm + ((size_t) s * 2 + 1) * (size_t) b->cap, dr, (size_t) n * 2, hipMemcpyDeviceToDevice));

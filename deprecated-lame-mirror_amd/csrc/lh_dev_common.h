@@ -369,6 +369,22 @@ lh_stage_window(const LhCtx & c, float (*mf)[LH_MF_NEEDED], long long base)
      * wait, and a frame's window would cost thirty serial HBM round trips per thread. */
     float const scale = c.cfg->pcm_scale;
     long long const last = c.d.nsamples - 1;
+    float const mix = c.cfg->pcm_mix;
+    if (mix != 0.0f) {
+        /* two channels mixed down to one (plain loop: not the configuration the batching below is for) */
+        for (int i = c.tid; i < LH_MF_NEEDED; i += LH_NT) {
+            long long const p = base + i;
+            float   v = 0.0f;
+            if (p >= 0 && p <= last && p >= c.d.pcm_base) {
+                float const xl = (float) c.pcm[c.d.pcm_l + (p - c.d.pcm_base)];
+                float const xr = (float) c.pcm[c.d.pcm_r + (p - c.d.pcm_base)];
+                v = xl * scale + xr * mix;
+            }
+            mf[0][i] = v;
+            mf[1][i] = 0.0f;
+        }
+        return;
+    }
     for (int t0 = c.tid; t0 < 2 * LH_MF_NEEDED; t0 += 6 * LH_NT) {
         int16_t v[6];
 #pragma unroll

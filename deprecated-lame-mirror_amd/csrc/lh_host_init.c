@@ -427,8 +427,23 @@ config_resolve_vbr(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
     return 0;
 }
 
+static int config_resolve_inner(const LhUserParams * p, LhConfig * c, LhInitAux * aux);
+
 int
 lh_config_resolve(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
+{
+    int const rc = config_resolve_inner(p, c, aux);
+    if (rc == 0 && p->channels == 2 && c->channels == 1) {
+        /* two channels in, one out: the transform's first row averages them (reference lame.c:1224-1229) */
+        float const m00 = c->pcm_scale, m01 = 0.0f * c->pcm_scale, m10 = 0.0f * c->pcm_scale, m11 = c->pcm_scale;
+        c->pcm_scale = 0.5f * (m00 + m10);
+        c->pcm_mix = 0.5f * (m01 + m11);
+    }
+    return rc;
+}
+
+static int
+config_resolve_inner(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
 {
     int     r;
     float   scale, ath_lower_db, maskingadjust, maskingadjust_short;
@@ -462,8 +477,6 @@ lh_config_resolve(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
     c->mode = (p->mode < 0) ? LH_MODE_JOINT_STEREO : p->mode;
     if (p->channels == 1)
         c->mode = LH_MODE_MONO; /* one input channel: reference lame.c:598-601 */
-    if (c->mode == LH_MODE_MONO && p->channels == 2)
-        return -1;              /* two channels mixed down to mono: not on this path */
     if (c->mode != LH_MODE_JOINT_STEREO && c->mode != LH_MODE_STEREO && c->mode != LH_MODE_MONO)
         return -1;
     c->channels = (c->mode == LH_MODE_MONO) ? 1 : 2;

@@ -20,7 +20,7 @@ class LhConfig(C.Structure):
         ("masking_lower_long", C.c_float), ("masking_lower_short", C.c_float),
         ("pcm_scale", C.c_float), ("interChRatio", C.c_float),
         ("vbr_q", C.c_int), ("vbr_min_bitrate_index", C.c_int), ("vbr_max_bitrate_index", C.c_int),
-        ("enforce_min_bitrate", C.c_int), ("vbr_avg_bitrate_kbps", C.c_int), ("compression_ratio", C.c_float)]
+        ("enforce_min_bitrate", C.c_int), ("vbr_avg_bitrate_kbps", C.c_int), ("compression_ratio", C.c_float), ("pcm_mix", C.c_float)]
 
 
 class LhPsyBand(C.Structure):

@@ -116,6 +116,9 @@ typedef struct LhConfig {
     /* ABR */
     int     vbr_avg_bitrate_kbps;
     float   compression_ratio;
+    /* two input channels mixed down to one: sample = l * pcm_scale + r * pcm_mix (pcm_transform[0][],
+     * reference lame.c:1209-1234); 0 otherwise */
+    float   pcm_mix;
 } LhConfig;
 
 /* partition -> scalefactor-band mapping, PsyConst_CB2SB_t (reference util.h:188-203) */

@@ -338,8 +338,14 @@ orc_encode_stream(const LhConfig * cfg, const LhTables * tab, const short *l, co
         for (i = 0; i < LH_MF_NEEDED; i++) {
             long    p = base + i;
             if (p >= 0 && p < n) {
-                mf[0][i] = (float) l[p] * cfg->pcm_scale;
-                mf[1][i] = (float) r[p] * cfg->pcm_scale;
+                if (cfg->pcm_mix != 0) {        /* downmix: u = xl * m00 + xr * m01 (reference lame.c:1802-1834) */
+                    mf[0][i] = (float) l[p] * cfg->pcm_scale + (float) r[p] * cfg->pcm_mix;
+                    mf[1][i] = 0;
+                }
+                else {
+                    mf[0][i] = (float) l[p] * cfg->pcm_scale;
+                    mf[1][i] = (float) r[p] * cfg->pcm_scale;
+                }
             }
             else {
                 mf[0][i] = 0;

@@ -462,6 +462,7 @@ refh_get_config(void *hh, LhConfig * c)
     }
     c->vbr_avg_bitrate_kbps = cfg->vbr_avg_bitrate_kbps;
     c->compression_ratio = cfg->compression_ratio;
+    c->pcm_mix = cfg->pcm_transform[0][1];
 }
 
 static void

@@ -33,7 +33,7 @@ def test_pod_sizes_match_bindings():
 
 def test_unsupported_settings_are_refused_loudly():
     lib = lamehip.load_library()
-    for setup in (lambda h: lib.lame_set_mode(h, 3),                  # two channels mixed down to mono
+    for setup in (lambda h: lib.lame_set_num_channels(h, 3),          # neither mono nor stereo
                   lambda h: lib.lame_set_VBR(h, 2),                   # vbr_rh (old VBR loop)
                   lambda h: lib.lame_set_in_samplerate(h, 22050),     # MPEG-2
                   lambda h: lib.lame_set_brate(h, 64)):               # reference would resample to 24 kHz

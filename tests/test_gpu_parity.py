@@ -390,3 +390,26 @@ def test_mono_batch_matches_oracle(kw, oracle):
         assert b.pack(i) == helpers.pack_frames(enc.lib, cfg, tab, want)
     b.close()
     enc.close()
+
+
+@pytest.mark.parametrize("kw", [dict(brate=128), dict(vbr_q=2), dict(abr=120, samplerate=48000)])
+def test_downmix_to_mono_matches_oracle(kw, oracle):
+    """Two input channels, MPEG mode MONO: the window is l * m00 + r * m01 (reference lame.c:1224-1229)."""
+    sr = kw.get("samplerate", 44100)
+    enc = lamehip.Encoder(mode=3, **kw)
+    cfg, tab = enc.config(), enc.tables()
+    assert cfg.channels == 1 and cfg.pcm_mix != 0
+    n = int(sr * 0.9)
+    x = helpers.synth_stream(1300, n, sr, 1.0 / 6)
+    b = lamehip.Batch(enc, 1, n)
+    b.set_pcm(0, x[0], x[1])
+    b.encode()
+    want = oracle.encode_frames(cfg, tab, x)
+    got = b.get_frames(0)
+    assert len(got) == len(want)
+    bad = [f for f in range(len(want)) if struct_diff(want[f], got[f])]
+    assert not bad, bad[:5]
+    out = b"".join(enc.encode(x[0][i:i + 1152], x[1][i:i + 1152]) for i in range(0, n, 1152)) + enc.flush()
+    assert out == b.pack(0) == helpers.pack_frames(enc.lib, cfg, tab, want)
+    b.close()
+    enc.close()

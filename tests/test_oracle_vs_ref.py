@@ -1,6 +1,7 @@
 """Live pinning of the CPU restatement against the compiled reference (only in
 trees where oracle/_ref was built): fresh seeds, several settings, every frame's
 payload and the final bytes."""
+import numpy as np
 import pytest
 
 import helpers
@@ -76,6 +77,36 @@ def test_abr_oracle_matches_reference(sr, kb, mode, q, seed, secs, white, oracle
     enc = lamehip.Encoder(sr, mode=mode, quality=q, require_device=False, abr=kb)
     cfg, tab = enc.config(), enc.tables()
     assert not struct_diff(rcfg, cfg, skip=("bitrate_index",))      # run-time state outside CBR
+    assert not struct_diff(rtab, tab, skip=("fft_window", "fft_window_s", "fht_tw", "ma_max_i1", "ma_max_i2",
+                                            "psy_l_to_s"))
+    frames = oracle.encode_frames(cfg, tab, pcm)
+    assert len(frames) == nf
+    mine = helpers.pack_frames(enc.lib, cfg, tab, frames)
+    helpers.normalize_tables(frames)
+    for f in range(nf):
+        d = struct_diff(rframes[f], frames[f], skip=("frame_bits",))
+        assert not d, (f, d[:4])
+    assert mine == mp3
+    enc.close()
+
+
+@pytest.mark.parametrize("sr,kw,q,nch,mode", [(44100, dict(brate=128), None, 1, None), (48000, dict(brate=64), 5, 1, None),
+                                               (44100, dict(vbr_q=3), None, 1, None), (32000, dict(abr=72), None, 1, None),
+                                               (44100, dict(brate=112), None, 2, 3), (48000, dict(vbr_q=1), None, 2, 3),
+                                               (44100, dict(abr=150), 7, 2, 3)])
+def test_mono_oracle_matches_reference(sr, kw, q, nch, mode, oracle, reference):
+    """One channel out: from one input channel (nch = 1) or from two mixed down (mode 3 = MONO)."""
+    pcm = helpers.synth_stream(61 + sr // 1000, int(sr * 1.3), sr, 1.0 / 7)
+    if nch == 1:
+        pcm = np.stack([pcm[0], pcm[0]])
+    rkw = dict(kw)
+    br = rkw.pop("brate", 0)
+    mp3, nf, rframes, rcfg, rtab = reference.encode(pcm, sr, br, -1 if mode is None else mode, -1 if q is None else q,
+                                                    max_frames=2048, channels=nch, **rkw)
+    enc = lamehip.Encoder(sr, mode=mode, quality=q, require_device=False, channels=nch, **kw)
+    cfg, tab = enc.config(), enc.tables()
+    assert cfg.channels == 1 and (cfg.pcm_mix != 0) == (nch == 2)
+    assert not struct_diff(rcfg, cfg, skip=("bitrate_index",))
     assert not struct_diff(rtab, tab, skip=("fft_window", "fft_window_s", "fht_tw", "ma_max_i1", "ma_max_i2",
                                             "psy_l_to_s"))
     frames = oracle.encode_frames(cfg, tab, pcm)
