@@ -408,7 +408,7 @@ config_resolve_vbr(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
         c->quality = 7;
     apply_quality(c, 0, 0);
     c->sfb21_extra = P.expY ? 0 : (samplerate_out > 44000);
-    c->short_blocks = (c->mode == LH_MODE_MONO) ? 0 : 1;
+    c->short_blocks = (c->mode == LH_MODE_MONO || c->mode == LH_MODE_DUAL) ? 0 : 1;
     c->pcm_scale = 1.0f;
     c->disable_reservoir = 0;
     c->frac_SpF = 0;
@@ -477,7 +477,8 @@ config_resolve_inner(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
     c->mode = (p->mode < 0) ? LH_MODE_JOINT_STEREO : p->mode;
     if (p->channels == 1)
         c->mode = LH_MODE_MONO; /* one input channel: reference lame.c:598-601 */
-    if (c->mode != LH_MODE_JOINT_STEREO && c->mode != LH_MODE_STEREO && c->mode != LH_MODE_MONO)
+    if (c->mode != LH_MODE_JOINT_STEREO && c->mode != LH_MODE_STEREO && c->mode != LH_MODE_MONO
+        && c->mode != LH_MODE_DUAL)
         return -1;
     c->channels = (c->mode == LH_MODE_MONO) ? 1 : 2;
     c->force_ms = 0;
@@ -595,7 +596,7 @@ config_resolve_inner(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
         c->quality = 9;
     apply_quality(c, noise_shaping, 0);
     c->sfb21_extra = 0;
-    c->short_blocks = (c->mode == LH_MODE_MONO) ? 0 : 1;        /* coupled for stereo / joint stereo, reference lame.c:1134-1137 */
+    c->short_blocks = (c->mode == LH_MODE_MONO || c->mode == LH_MODE_DUAL) ? 0 : 1;  /* coupled for stereo / joint stereo, reference lame.c:1134-1137 */
     c->use_temporal_masking = 1;
     c->ATHtype = 4;
     c->ATH_offset_db = 0 - ath_lower_db;

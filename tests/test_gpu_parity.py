@@ -413,3 +413,26 @@ def test_downmix_to_mono_matches_oracle(kw, oracle):
     assert out == b.pack(0) == helpers.pack_frames(enc.lib, cfg, tab, want)
     b.close()
     enc.close()
+
+
+@pytest.mark.parametrize("kw", [dict(brate=160), dict(vbr_q=3, samplerate=48000), dict(abr=128)])
+def test_dual_channel_uncoupled_blocks_match_oracle(kw, oracle):
+    """MPEG mode 2: two independent channels, attacks in the left one only, so that the channels of a
+    granule take different block types (never the case in the stereo modes, which couple them)."""
+    sr = kw.get("samplerate", 44100)
+    enc = lamehip.Encoder(mode=2, **kw)
+    cfg, tab = enc.config(), enc.tables()
+    n = int(sr * 1.0)
+    x = helpers.synth_stream(99, n, sr, 1.0 / 11)
+    pcm = np.stack([x[0], (8000 * np.sin(2 * np.pi * 440 * np.arange(n) / sr)).astype(np.int16)])
+    b = lamehip.Batch(enc, 1, n)
+    b.set_pcm(0, pcm[0], pcm[1])
+    b.encode()
+    want = oracle.encode_frames(cfg, tab, pcm)
+    got = b.get_frames(0)
+    assert sum(fr.gr[g][0].block_type != fr.gr[g][1].block_type for fr in want for g in range(2)) > 5
+    bad = [f for f in range(len(want)) if struct_diff(want[f], got[f])]
+    assert len(got) == len(want) and not bad, bad[:5]
+    assert b.pack(0) == helpers.pack_frames(enc.lib, cfg, tab, want)
+    b.close()
+    enc.close()

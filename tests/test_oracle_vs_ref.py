@@ -120,6 +120,24 @@ def test_mono_oracle_matches_reference(sr, kw, q, nch, mode, oracle, reference):
     enc.close()
 
 
+@pytest.mark.parametrize("sr,kw", [(44100, dict(brate=160)), (48000, dict(vbr_q=3)), (32000, dict(abr=128))])
+def test_dual_channel_oracle_matches_reference(sr, kw, oracle, reference):
+    """MPEG mode 2 (dual channel): no M/S, block types not coupled -- attacks in one channel only."""
+    n = int(sr * 1.0)
+    x = helpers.synth_stream(99, n, sr, 1.0 / 11)
+    pcm = np.stack([x[0], (8000 * np.sin(2 * np.pi * 440 * np.arange(n) / sr)).astype(np.int16)])
+    rkw = dict(kw)
+    br = rkw.pop("brate", 0)
+    mp3, nf, rframes, rcfg, rtab = reference.encode(pcm, sr, br, 2, -1, max_frames=2048, **rkw)
+    enc = lamehip.Encoder(sr, mode=2, require_device=False, **kw)
+    cfg, tab = enc.config(), enc.tables()
+    assert not struct_diff(rcfg, cfg, skip=("bitrate_index",))
+    frames = oracle.encode_frames(cfg, tab, pcm)
+    assert sum(fr.gr[g][0].block_type != fr.gr[g][1].block_type for fr in frames for g in range(2)) > 5
+    assert helpers.pack_frames(enc.lib, cfg, tab, frames) == mp3
+    enc.close()
+
+
 def test_odd_lengths_and_flush_framing(oracle, reference):
     for n in (1, 500, 1151, 1152, 1153, 1152 * 3, 1152 * 3 + 17, 5000):
         pcm = helpers.synth_stream(n, n)
