@@ -220,6 +220,85 @@ lame_set_VBR_q(lame_t g, int q)
 }
 
 GETTER(lame_get_VBR_q, g->inited ? g->cfg.vbr_q : g->p.vbr_q, int)
+SETTER(lame_set_force_ms, p.force_ms, int)
+GETTER(lame_get_force_ms, g->p.force_ms, int)
+SETTER(lame_set_disable_reservoir, p.disable_reservoir, int)
+GETTER(lame_get_disable_reservoir, g->p.disable_reservoir, int)
+SETTER(lame_set_error_protection, p.error_protection, int)
+GETTER(lame_get_error_protection, g->p.error_protection, int)
+SETTER(lame_set_copyright, p.copyright, int)
+GETTER(lame_get_copyright, g->p.copyright, int)
+SETTER(lame_set_original, p.original, int)
+GETTER(lame_get_original, g->p.original, int)
+SETTER(lame_set_emphasis, p.emphasis, int)
+GETTER(lame_get_emphasis, g->p.emphasis, int)
+SETTER(lame_set_extension, p.extension, int)
+GETTER(lame_get_extension, g->p.extension, int)
+SETTER(lame_set_strict_ISO, p.strict_ISO, int)
+GETTER(lame_get_strict_ISO, g->p.strict_ISO, int)
+SETTER(lame_set_lowpassfreq, p.lowpassfreq, int)
+GETTER(lame_get_lowpassfreq, g->inited ? g->cfg.lowpassfreq : g->p.lowpassfreq, int)
+SETTER(lame_set_lowpasswidth, p.lowpasswidth, int)
+GETTER(lame_get_lowpasswidth, g->p.lowpasswidth, int)
+
+extern "C" int
+lame_set_scale(lame_t g, float v)
+{
+    if (!valid(g))
+        return -1;
+    g->p.scale = v;
+    return 0;
+}
+
+extern "C" int
+lame_set_scale_left(lame_t g, float v)
+{
+    if (!valid(g))
+        return -1;
+    g->p.scale_left = v;
+    return 0;
+}
+
+extern "C" int
+lame_set_scale_right(lame_t g, float v)
+{
+    if (!valid(g))
+        return -1;
+    g->p.scale_right = v;
+    return 0;
+}
+
+/* short block switches (reference set_get.c:1650-1846) */
+extern "C" int
+lame_set_allow_diff_short(lame_t g, int v)
+{
+    if (!valid(g))
+        return -1;
+    g->p.short_blocks = v ? 0 : 1;
+    return 0;
+}
+
+extern "C" int
+lame_set_no_short_blocks(lame_t g, int v)
+{
+    if (!valid(g) || v < 0 || v > 1)
+        return -1;
+    g->p.short_blocks = v ? 2 : 0;
+    return 0;
+}
+
+extern "C" int
+lame_set_force_short_blocks(lame_t g, int v)
+{
+    if (!valid(g) || v < 0 || v > 1)
+        return -1;
+    if (v == 1)
+        g->p.short_blocks = 3;
+    else if (g->p.short_blocks == 3)
+        g->p.short_blocks = 0;
+    return 0;
+}
+
 SETTER(lame_set_VBR_mean_bitrate_kbps, p.abr_kbps, int)
 GETTER(lame_get_VBR_mean_bitrate_kbps, g->inited ? g->cfg.vbr_avg_bitrate_kbps : g->p.abr_kbps, int)
 

@@ -153,6 +153,8 @@ encode_side_info(LhBitstream * bs, const LhConfig * c, const LhFrameOut * fo, in
     hdr_bits(bs, c->copyright, 1);
     hdr_bits(bs, c->original, 1);
     hdr_bits(bs, c->emphasis, 2);
+    if (c->error_protection)
+        hdr_bits(bs, 0, 16);    /* CRC word, filled in below */
     hdr_bits(bs, mdb, 9);
     hdr_bits(bs, 0, c->channels == 2 ? 3 : 5);  /* private bits (reference bitstream.c:357-360) */
     for (ch = 0; ch < c->channels; ch++)
@@ -187,6 +189,26 @@ encode_side_info(LhBitstream * bs, const LhConfig * c, const LhFrameOut * fo, in
             hdr_bits(bs, gi->scalefac_scale, 1);
             hdr_bits(bs, gi->count1table_select, 1);
         }
+    }
+    if (c->error_protection) {
+        /* CRC-16 (polynomial 0x8005, start 0xffff) over header bytes 2, 3 and the side information
+         * (reference bitstream.c:287-318) */
+        unsigned char *h = (unsigned char *) bs->header[bs->h_ptr].buf;
+        int     crc = 0xffff, i, k;
+        for (i = 2; i < c->sideinfo_len; i++) {
+            int     value;
+            if (i == 4 || i == 5)
+                continue;
+            value = h[i] << 8;
+            for (k = 0; k < 8; k++) {
+                value <<= 1;
+                crc <<= 1;
+                if ((crc ^ value) & 0x10000)
+                    crc ^= 0x8005;
+            }
+        }
+        h[4] = (unsigned char) (crc >> 8);
+        h[5] = (unsigned char) (crc & 255);
     }
     {
         int const old = bs->h_ptr;

@@ -370,6 +370,7 @@ lh_stage_window(const LhCtx & c, float (*mf)[LH_MF_NEEDED], long long base)
     float const scale = c.cfg->pcm_scale;
     long long const last = c.d.nsamples - 1;
     float const mix = c.cfg->pcm_mix;
+    float const scale_r = c.cfg->pcm_scale_r;
     if (mix != 0.0f) {
         /* two channels mixed down to one (plain loop: not the configuration the batching below is for) */
         for (int i = c.tid; i < LH_MF_NEEDED; i += LH_NT) {
@@ -403,7 +404,7 @@ lh_stage_window(const LhCtx & c, float (*mf)[LH_MF_NEEDED], long long base)
             if (t < 2 * LH_MF_NEEDED) {
                 int const ch = t >= LH_MF_NEEDED, i = t - ch * LH_MF_NEEDED;
                 long long const p = base + i;
-                mf[ch][i] = (p < 0 || p > last) ? 0.0f : (float) v[u] * scale;
+                mf[ch][i] = (p < 0 || p > last) ? 0.0f : (float) v[u] * (ch == 0 ? scale : scale_r);
             }
         }
     }

@@ -21,6 +21,13 @@ typedef struct LhUserParams {
     int     vbr_q;               /* VBR quality 0..9 (lame_set_VBR_q), default 4 */
     int     samplerate_out;      /* 0 = let the encoder choose (must come out equal to samplerate) */
     int     abr_kbps;            /* ABR mean bitrate (lame_set_VBR_mean_bitrate_kbps), default 128 */
+    /* frontend-level switches with the reference's defaults (lame.c:2280-2420) */
+    int     force_ms, disable_reservoir, error_protection, copyright, original, emphasis, extension;
+    int     short_blocks;        /* -1 not set, else short_block_t: 0 allowed, 1 coupled, 2 dispensed, 3 forced */
+    int     strict_ISO;          /* 0 MDB_DEFAULT, 1 MDB_STRICT_ISO, 2 MDB_MAXIMUM (default) */
+    int     lowpassfreq;         /* 0 = by bitrate / quality, -1 = none, else Hz */
+    int     lowpasswidth;        /* -1 = default */
+    float   scale, scale_left, scale_right;
 } LhUserParams;
 
 /* values that only feed table generation */

@@ -116,6 +116,11 @@ lh_params_default(LhUserParams * p)
     p->vbr = 0;
     p->vbr_q = 4;               /* reference lame.c:2360 */
     p->abr_kbps = 128;          /* reference lame.c:2361 */
+    p->original = 1;
+    p->short_blocks = -1;
+    p->strict_ISO = 2;          /* MDB_MAXIMUM, reference lame.c:2341 */
+    p->lowpasswidth = -1;
+    p->scale = p->scale_left = p->scale_right = 1.0f;
     p->samplerate_out = 0;
 }
 
@@ -262,14 +267,20 @@ suggested_samplerate(int lp, int samplerate_in)
 }
 
 static void
-lowpass_edges(LhConfig * c, LhInitAux * aux)
+lowpass_edges(LhConfig * c, LhInitAux * aux, int width)
 {
     int const lp = c->lowpassfreq;
     aux->lowpass1 = 0;
     aux->lowpass2 = 0;
     if (lp > 0 && lp < c->samplerate / 2) {
         aux->lowpass2 = 2. * lp;
-        aux->lowpass1 = (1 - 0.00) * 2. * lp;
+        if (width >= 0) {       /* lame_set_lowpasswidth, reference lame.c:880-884 */
+            aux->lowpass1 = 2. * (lp - width);
+            if (aux->lowpass1 < 0)
+                aux->lowpass1 = 0;
+        }
+        else
+            aux->lowpass1 = (1 - 0.00) * 2. * lp;
         aux->lowpass1 /= c->samplerate;
         aux->lowpass2 /= c->samplerate;
     }
@@ -281,7 +292,7 @@ static int
 config_resolve_vbr(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
 {
     static const int lp_by_q[11] = { 24000, 19500, 18500, 18000, 17500, 17000, 16500, 15600, 15200, 7230, 3950 };
-    int     vbr_q = p->vbr_q, samplerate_out = p->samplerate_out, lowpassfreq = 0, i;
+    int     vbr_q = p->vbr_q, samplerate_out = p->samplerate_out, lowpassfreq = p->lowpassfreq, i;
     float   vbr_q_frac = 0;
     LhVbrPreset P, Q;
     float   x;
@@ -338,7 +349,7 @@ config_resolve_vbr(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
     lowpassfreq = (24000 < lowpassfreq) ? 24000 : lowpassfreq;
     lowpassfreq = (samplerate_out / 2 < lowpassfreq) ? samplerate_out / 2 : lowpassfreq;
     c->lowpassfreq = lowpassfreq;
-    lowpass_edges(c, aux);
+    lowpass_edges(c, aux, p->lowpasswidth);
 
     c->bitrate_index = 1;
     c->avg_bitrate = 0;         /* gfp->brate stays 0 in VBR mode */
@@ -383,7 +394,8 @@ config_resolve_vbr(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
     c->msfix = P.msfix;
     c->minval = P.minval;
     {
-        double const y = 10.f * log10(1.0);     /* scale is 1 */
+        double const xs = fabs(p->scale);
+        double const y = (xs > 0.f) ? (10.f * log10(xs)) : 0.f;
         c->ATHfixpoint = P.ath_fixpoint - y;
     }
     c->use_safe_joint_stereo = nspsytune & 2;
@@ -409,7 +421,8 @@ config_resolve_vbr(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
     apply_quality(c, 0, 0);
     c->sfb21_extra = P.expY ? 0 : (samplerate_out > 44000);
     c->short_blocks = (c->mode == LH_MODE_MONO || c->mode == LH_MODE_DUAL) ? 0 : 1;
-    c->pcm_scale = 1.0f;
+    c->pcm_scale = p->scale * p->scale_left;
+    c->pcm_scale_r = p->scale * p->scale_right;
     c->disable_reservoir = 0;
     c->frac_SpF = 0;
     c->vbr_q = vbr_q;
@@ -429,15 +442,58 @@ config_resolve_vbr(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
 
 static int config_resolve_inner(const LhUserParams * p, LhConfig * c, LhInitAux * aux);
 
+/* the frontend-level switches that only overwrite resolved constants */
+static int
+config_apply_switches(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
+{
+    (void) aux;
+    c->copyright = p->copyright != 0;
+    c->original = p->original != 0;
+    c->extension = p->extension != 0;
+    c->emphasis = p->emphasis & 3;
+    c->disable_reservoir = p->disable_reservoir != 0;
+    if (p->force_ms) {
+        if (c->mode != LH_MODE_JOINT_STEREO)
+            return -1;          /* the frontend's -m f: joint stereo with every frame M/S */
+        c->force_ms = 1;
+    }
+    if (p->error_protection) {
+        c->error_protection = 1;
+        c->sideinfo_len += 2;
+    }
+    if (p->short_blocks >= 0) {
+        /* reference lame.c:1113-1130: "allowed" becomes "coupled" for the stereo modes */
+        int     sb = p->short_blocks;
+        if (sb == 0 && (c->mode == LH_MODE_JOINT_STEREO || c->mode == LH_MODE_STEREO))
+            sb = 1;
+        c->short_blocks = sb;
+    }
+    switch (p->strict_ISO) {    /* get_max_frame_buffer_size_by_constraint, reference bitstream.c:91-131 */
+    case 0:
+        c->buffer_constraint = 8 * 1440;
+        break;
+    case 1:
+        c->buffer_constraint = 8 * ((c->version + 1) * 72000 * 320 / c->samplerate);
+        break;
+    default:
+        c->buffer_constraint = 7680 * (c->version + 1);
+        break;
+    }
+    return 0;
+}
+
 int
 lh_config_resolve(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
 {
-    int const rc = config_resolve_inner(p, c, aux);
+    int     rc = config_resolve_inner(p, c, aux);
+    if (rc == 0)
+        rc = config_apply_switches(p, c, aux);
     if (rc == 0 && p->channels == 2 && c->channels == 1) {
         /* two channels in, one out: the transform's first row averages them (reference lame.c:1224-1229) */
-        float const m00 = c->pcm_scale, m01 = 0.0f * c->pcm_scale, m10 = 0.0f * c->pcm_scale, m11 = c->pcm_scale;
+        float const m00 = c->pcm_scale, m01 = 0.0f * c->pcm_scale, m10 = 0.0f * c->pcm_scale_r, m11 = c->pcm_scale_r;
         c->pcm_scale = 0.5f * (m00 + m10);
         c->pcm_mix = 0.5f * (m01 + m11);
+        c->pcm_scale_r = 0;
     }
     return rc;
 }
@@ -527,9 +583,7 @@ config_resolve_inner(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
         int     lp;
         if (c->mode == LH_MODE_MONO)
             lowpass *= 1.5;     /* reference lame.c:758-759 */
-        lp = (int) lowpass;
-        int     suggested;
-        (void) suggested;
+        lp = (p->lowpassfreq != 0) ? p->lowpassfreq : (int) lowpass;   /* lame_set_lowpassfreq: Hz, -1 = none */
         /* the reference would pick a lower output rate and resample for this
          * lowpass (optimum_samplefreq, reference lame.c:273-345); resampling is
          * outside this path, so such settings are refused */
@@ -537,8 +591,7 @@ config_resolve_inner(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
             /* only consulted when the caller left the output rate open (reference lame.c:762-767) */
             if (2 * lp > c->samplerate)
                 lp = c->samplerate / 2;
-            suggested = suggested_samplerate(lp, c->samplerate);
-            if (suggested != c->samplerate)
+            if (suggested_samplerate(lp, c->samplerate) != c->samplerate)
                 return -1;
         }
         if (lp > 20500)
@@ -546,14 +599,7 @@ config_resolve_inner(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
         if (lp > c->samplerate / 2)
             lp = c->samplerate / 2;
         c->lowpassfreq = lp;
-        aux->lowpass1 = 0;
-        aux->lowpass2 = 0;
-        if (lp > 0 && lp < c->samplerate / 2) {
-            aux->lowpass2 = 2. * lp;
-            aux->lowpass1 = (1 - 0.00) * 2. * lp;
-            aux->lowpass1 /= c->samplerate;
-            aux->lowpass2 /= c->samplerate;
-        }
+        lowpass_edges(c, aux, p->lowpasswidth);
     }
 
     c->sideinfo_len = (c->channels == 1) ? 4 + 17 : 4 + 32;
@@ -570,7 +616,7 @@ config_resolve_inner(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
     c->msfix = abr_map[r].nsmsfix;
     aux->attackthre = abr_map[r].st_lrm;
     aux->attackthre_s = abr_map[r].st_s;
-    scale = 1.0f * abr_map[r].scale;
+    scale = p->scale * abr_map[r].scale;
     maskingadjust = abr_map[r].masking_adj;
     if (abr_map[r].masking_adj > 0)
         maskingadjust_short = abr_map[r].masking_adj * .9;
@@ -602,7 +648,8 @@ config_resolve_inner(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
     c->ATH_offset_db = 0 - ath_lower_db;
     c->ATH_offset_factor = powf(10.f, c->ATH_offset_db * 0.1f);
     c->ATHfixpoint = 0;
-    c->pcm_scale = scale;
+    c->pcm_scale = scale * p->scale_left;
+    c->pcm_scale_r = scale * p->scale_right;
     c->disable_reservoir = 0;
     c->frac_SpF = (c->vbr == 0) ? (int) (((c->version + 1) * 72000L * c->avg_bitrate) % c->samplerate) : 0;
     return 0;

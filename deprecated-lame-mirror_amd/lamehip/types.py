@@ -20,7 +20,8 @@ class LhConfig(C.Structure):
         ("masking_lower_long", C.c_float), ("masking_lower_short", C.c_float),
         ("pcm_scale", C.c_float), ("interChRatio", C.c_float),
         ("vbr_q", C.c_int), ("vbr_min_bitrate_index", C.c_int), ("vbr_max_bitrate_index", C.c_int),
-        ("enforce_min_bitrate", C.c_int), ("vbr_avg_bitrate_kbps", C.c_int), ("compression_ratio", C.c_float), ("pcm_mix", C.c_float)]
+        ("enforce_min_bitrate", C.c_int), ("vbr_avg_bitrate_kbps", C.c_int), ("compression_ratio", C.c_float), ("pcm_mix", C.c_float),
+        ("pcm_scale_r", C.c_float)]
 
 
 class LhPsyBand(C.Structure):
@@ -80,7 +81,10 @@ class LhFrameOut(C.Structure):
 
 
 class LhUserParams(C.Structure):
-    _fields_ = [(n, C.c_int) for n in "samplerate channels brate mode quality vbr vbr_q samplerate_out abr_kbps".split()]
+    _fields_ = [(n, C.c_int) for n in ("samplerate channels brate mode quality vbr vbr_q samplerate_out abr_kbps "
+                                       "force_ms disable_reservoir error_protection copyright original emphasis extension "
+                                       "short_blocks strict_ISO lowpassfreq lowpasswidth").split()] + [
+        ("scale", C.c_float), ("scale_left", C.c_float), ("scale_right", C.c_float)]
 
 
 class LhInitAux(C.Structure):

@@ -65,6 +65,34 @@ int     lame_get_VBR_mean_bitrate_kbps(const lame_t);                /* lame.h:4
 int     lame_set_bWriteVbrTag(lame_t, int);                          /* lame.h:240 (default 1, as in the reference) */
 int     lame_get_bWriteVbrTag(const lame_t);                         /* lame.h:241 */
 int     lame_set_findReplayGain(lame_t, int);                        /* lame.h:296 (accepted, ignored) */
+/* frontend switches (-m f, --nores, -p, -c, -o, -e, --strictly-enforce-ISO, --lowpass, --scale*,
+ * --noshort, --shortblocks); values and defaults are the reference's */
+int     lame_set_force_ms(lame_t, int);                              /* lame.h:288 (joint stereo only) */
+int     lame_get_force_ms(const lame_t);
+int     lame_set_disable_reservoir(lame_t, int);                     /* lame.h:400 */
+int     lame_get_disable_reservoir(const lame_t);
+int     lame_set_error_protection(lame_t, int);                      /* lame.h:376 (CRC-16 after the header) */
+int     lame_get_error_protection(const lame_t);
+int     lame_set_copyright(lame_t, int);                             /* lame.h:368 */
+int     lame_get_copyright(const lame_t);
+int     lame_set_original(lame_t, int);                              /* lame.h:372 */
+int     lame_get_original(const lame_t);
+int     lame_set_emphasis(lame_t, int);                              /* lame.h:558 */
+int     lame_get_emphasis(const lame_t);
+int     lame_set_extension(lame_t, int);                             /* lame.h:387 */
+int     lame_get_extension(const lame_t);
+int     lame_set_strict_ISO(lame_t, int);                            /* lame.h:391 (0 default, 1 strict, 2 maximum) */
+int     lame_get_strict_ISO(const lame_t);
+int     lame_set_lowpassfreq(lame_t, int);                           /* lame.h:470 (Hz; 0 default, -1 none) */
+int     lame_get_lowpassfreq(const lame_t);
+int     lame_set_lowpasswidth(lame_t, int);                          /* lame.h:473 */
+int     lame_get_lowpasswidth(const lame_t);
+int     lame_set_scale(lame_t, float);                               /* lame.h:199 */
+int     lame_set_scale_left(lame_t, float);                          /* lame.h:206 */
+int     lame_set_scale_right(lame_t, float);                         /* lame.h:213 */
+int     lame_set_allow_diff_short(lame_t, int);                      /* lame.h:535 */
+int     lame_set_no_short_blocks(lame_t, int);                       /* lame.h:547 */
+int     lame_set_force_short_blocks(lame_t, int);                    /* lame.h:551 */
 int     lame_init_params(lame_t);                                    /* lame.h:636 */
 int     lame_get_framesize(const lame_t);                            /* lame.h:582 */
 int     lame_get_frameNum(const lame_t);                             /* lame.h:597 */

@@ -119,6 +119,7 @@ typedef struct LhConfig {
     /* two input channels mixed down to one: sample = l * pcm_scale + r * pcm_mix (pcm_transform[0][],
      * reference lame.c:1209-1234); 0 otherwise */
     float   pcm_mix;
+    float   pcm_scale_r;          /* right channel's factor (pcm_transform[1][1]); pcm_scale is the left one's */
 } LhConfig;
 
 /* partition -> scalefactor-band mapping, PsyConst_CB2SB_t (reference util.h:188-203) */

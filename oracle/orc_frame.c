@@ -344,7 +344,7 @@ orc_encode_stream(const LhConfig * cfg, const LhTables * tab, const short *l, co
                 }
                 else {
                     mf[0][i] = (float) l[p] * cfg->pcm_scale;
-                    mf[1][i] = (float) r[p] * cfg->pcm_scale;
+                    mf[1][i] = (float) r[p] * cfg->pcm_scale_r;
                 }
             }
             else {

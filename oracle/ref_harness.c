@@ -43,6 +43,50 @@ refh_set_channels(int n)
     refh_channels = (n == 1) ? 1 : 2;
 }
 
+/* switches applied to the handles opened next (name = the lame_set_* suffix); refh_option(0, 0) clears */
+static struct { char name[32]; float value; } refh_opts[16];
+static int refh_nopts = 0;
+
+void
+refh_option(const char *name, float value)
+{
+    if (!name) {
+        refh_nopts = 0;
+        return;
+    }
+    if (refh_nopts < 16) {
+        strncpy(refh_opts[refh_nopts].name, name, 31);
+        refh_opts[refh_nopts].value = value;
+        refh_nopts++;
+    }
+}
+
+static void
+apply_options(lame_global_flags * gfp)
+{
+    int     i;
+    for (i = 0; i < refh_nopts; i++) {
+        const char *n = refh_opts[i].name;
+        float const v = refh_opts[i].value;
+        if (!strcmp(n, "force_ms")) lame_set_force_ms(gfp, (int) v);
+        else if (!strcmp(n, "disable_reservoir")) lame_set_disable_reservoir(gfp, (int) v);
+        else if (!strcmp(n, "error_protection")) lame_set_error_protection(gfp, (int) v);
+        else if (!strcmp(n, "copyright")) lame_set_copyright(gfp, (int) v);
+        else if (!strcmp(n, "original")) lame_set_original(gfp, (int) v);
+        else if (!strcmp(n, "emphasis")) lame_set_emphasis(gfp, (int) v);
+        else if (!strcmp(n, "extension")) lame_set_extension(gfp, (int) v);
+        else if (!strcmp(n, "strict_ISO")) lame_set_strict_ISO(gfp, (int) v);
+        else if (!strcmp(n, "lowpassfreq")) lame_set_lowpassfreq(gfp, (int) v);
+        else if (!strcmp(n, "lowpasswidth")) lame_set_lowpasswidth(gfp, (int) v);
+        else if (!strcmp(n, "scale")) lame_set_scale(gfp, v);
+        else if (!strcmp(n, "scale_left")) lame_set_scale_left(gfp, v);
+        else if (!strcmp(n, "scale_right")) lame_set_scale_right(gfp, v);
+        else if (!strcmp(n, "allow_diff_short")) lame_set_allow_diff_short(gfp, (int) v);
+        else if (!strcmp(n, "no_short_blocks")) lame_set_no_short_blocks(gfp, (int) v);
+        else if (!strcmp(n, "force_short_blocks")) lame_set_force_short_blocks(gfp, (int) v);
+    }
+}
+
 static void
 quiet(const char *fmt, va_list ap)
 {
@@ -67,6 +111,7 @@ refh_open(int samplerate, int brate, int mode, int quality)
         lame_set_mode(h->gfp, (MPEG_mode) mode);
     if (quality >= 0)
         lame_set_quality(h->gfp, quality);
+    apply_options(h->gfp);
     if (lame_init_params(h->gfp) < 0) {
         lame_close(h->gfp);
         free(h);
@@ -93,6 +138,7 @@ refh_open_tag(int samplerate, int brate, int mode, int quality)
         lame_set_mode(h->gfp, (MPEG_mode) mode);
     if (quality >= 0)
         lame_set_quality(h->gfp, quality);
+    apply_options(h->gfp);
     if (lame_init_params(h->gfp) < 0) {
         lame_close(h->gfp);
         free(h);
@@ -121,6 +167,7 @@ refh_open_vbr(int samplerate, int vbr_q, int mode, int quality, int out_samplera
         lame_set_mode(h->gfp, (MPEG_mode) mode);
     if (quality >= 0)
         lame_set_quality(h->gfp, quality);
+    apply_options(h->gfp);
     if (lame_init_params(h->gfp) < 0) {
         lame_close(h->gfp);
         free(h);
@@ -149,6 +196,7 @@ refh_open_abr(int samplerate, int mean_kbps, int mode, int quality, int out_samp
         lame_set_mode(h->gfp, (MPEG_mode) mode);
     if (quality >= 0)
         lame_set_quality(h->gfp, quality);
+    apply_options(h->gfp);
     if (lame_init_params(h->gfp) < 0) {
         lame_close(h->gfp);
         free(h);
@@ -463,6 +511,7 @@ refh_get_config(void *hh, LhConfig * c)
     c->vbr_avg_bitrate_kbps = cfg->vbr_avg_bitrate_kbps;
     c->compression_ratio = cfg->compression_ratio;
     c->pcm_mix = cfg->pcm_transform[0][1];
+    c->pcm_scale_r = cfg->pcm_transform[1][1];
 }
 
 static void

@@ -1,0 +1,98 @@
+"""Frontend-level switches of lame.h that reach the hot path (-m f, --nores, -p, -c/-o/-e, --strictly-enforce-ISO,
+--lowpass, --scale*, --noshort / --shortblocks): resolved constants, oracle bytes and -- on the GPU -- the
+device payload against the compiled reference / the oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import helpers
+import lamehip
+from lamehip.types import struct_diff
+
+CASES = [
+    (dict(brate=128), {"force_ms": 1}), (dict(vbr_q=3), {"force_ms": 1}),
+    (dict(brate=128), {"disable_reservoir": 1}), (dict(vbr_q=2), {"disable_reservoir": 1}),
+    (dict(abr=150), {"disable_reservoir": 1}),
+    (dict(brate=160), {"error_protection": 1}), (dict(vbr_q=4), {"error_protection": 1}),
+    (dict(brate=128), {"copyright": 1, "original": 0, "emphasis": 1, "extension": 1}),
+    (dict(brate=192), {"strict_ISO": 0}), (dict(vbr_q=0), {"strict_ISO": 1}), (dict(brate=320), {"strict_ISO": 1}),
+    (dict(brate=128), {"lowpassfreq": 16500, "lowpasswidth": 1500}), (dict(vbr_q=2), {"lowpassfreq": 16000}),
+    (dict(brate=256), {"lowpassfreq": -1}),
+    (dict(brate=128), {"scale": 0.7}), (dict(vbr_q=2), {"scale": 1.4}),
+    (dict(abr=128), {"scale_left": 0.5, "scale_right": 1.2}),
+    (dict(brate=128), {"no_short_blocks": 1}), (dict(vbr_q=2), {"force_short_blocks": 1}),
+    (dict(brate=160), {"allow_diff_short": 1}),
+]
+IDS = ["%s-%s" % ("_".join("%s%s" % kv for kv in kw.items()), "_".join(o)) for kw, o in CASES]
+
+
+def open_with(kw, opts, require_device):
+    """lame_init .. lame_init_params through the C ABI with the switches applied."""
+    enc = lamehip.Encoder.__new__(lamehip.Encoder)
+    lib = enc.lib = lamehip.load_library()
+    enc.h = C.c_void_p(lib.lame_init())
+    lib.lame_set_in_samplerate(enc.h, 44100)
+    lib.lame_set_num_channels(enc.h, 2)
+    lib.lame_set_bWriteVbrTag(enc.h, 0)
+    if "brate" in kw:
+        lib.lame_set_brate(enc.h, kw["brate"])
+    if "vbr_q" in kw:
+        lib.lame_set_VBR(enc.h, 4)
+        lib.lame_set_VBR_q(enc.h, kw["vbr_q"])
+    if "abr" in kw:
+        lib.lame_set_VBR(enc.h, 3)
+        lib.lame_set_VBR_mean_bitrate_kbps(enc.h, kw["abr"])
+    for k, v in opts.items():
+        f = getattr(lib, "lame_set_" + k)
+        f.argtypes = [C.c_void_p, C.c_float if k.startswith("scale") else C.c_int]
+        assert f(enc.h, float(v) if k.startswith("scale") else int(v)) == 0
+    enc.rc = lib.lame_init_params(enc.h)
+    assert enc.rc == 0 or (enc.rc == lamehip.ERR_NODEVICE and not require_device), lamehip.last_error()
+    return enc
+
+
+@pytest.mark.skipif(not helpers.have_reference(), reason="needs oracle/_ref (reference sources)")
+@pytest.mark.parametrize("kw,opts", CASES, ids=IDS)
+def test_switch_oracle_matches_reference(kw, opts, oracle, reference):
+    sr = 44100
+    pcm = helpers.synth_stream(500 + len(opts), int(sr * 0.9), sr, 1.0 / 9)
+    lib = reference.lib
+    lib.refh_option.argtypes = [C.c_char_p, C.c_float]
+    lib.refh_option(None, 0)
+    for k, v in opts.items():
+        lib.refh_option(k.encode(), float(v))
+    rkw = dict(kw)
+    br = rkw.pop("brate", 0)
+    try:
+        mp3, nf, rframes, rcfg, rtab = reference.encode(pcm, sr, br, -1, -1, max_frames=2048, **rkw)
+    finally:
+        lib.refh_option(None, 0)
+    enc = open_with(kw, opts, require_device=False)
+    cfg, tab = enc.config(), enc.tables()
+    assert not struct_diff(rcfg, cfg, skip=("bitrate_index",))
+    assert not struct_diff(rtab, tab, skip=("fft_window", "fft_window_s", "fht_tw", "ma_max_i1", "ma_max_i2",
+                                            "psy_l_to_s"))
+    frames = oracle.encode_frames(cfg, tab, pcm)
+    assert len(frames) == nf
+    assert helpers.pack_frames(enc.lib, cfg, tab, frames) == mp3
+    enc.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw,opts", CASES, ids=IDS)
+def test_switch_device_matches_oracle(kw, opts, oracle):
+    sr = 44100
+    pcm = helpers.synth_stream(600 + len(opts), int(sr * 0.9), sr, 1.0 / 9)
+    enc = open_with(kw, opts, require_device=True)
+    cfg, tab = enc.config(), enc.tables()
+    b = lamehip.Batch(enc, 1, pcm.shape[1])
+    b.set_pcm(0, pcm[0], pcm[1])
+    b.encode()
+    want = oracle.encode_frames(cfg, tab, pcm)
+    got = b.get_frames(0)
+    bad = [f for f in range(len(want)) if struct_diff(want[f], got[f])]
+    assert len(got) == len(want) and not bad, bad[:5]
+    assert b.pack(0) == helpers.pack_frames(enc.lib, cfg, tab, want)
+    b.close()
+    enc.close()
