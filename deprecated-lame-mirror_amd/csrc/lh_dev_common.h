@@ -347,19 +347,6 @@ lh_rg_put(const LhCtx & c, const LhQR & R, const LhGrR & g)
     LH_WAVE_SYNC();
 }
 
-/* sample p of the stream as the reference's mfbuf holds it: scaled PCM, zero outside
- * the stream (reference lame.c:1802-1834 scaling; :1671-1775 framing) */
-LH_DEVFN float
-lh_pcm_sample(const LhCtx & c, int ch, long long p)
-{
-    if (p < 0 || p >= c.d.nsamples)
-        return 0.0f;
-    {
-        long long off = (ch == 0 ? c.d.pcm_l : c.d.pcm_r) + (p - c.d.pcm_base);
-        return (float) c.pcm[off] * c.cfg->pcm_scale;
-    }
-}
-
 /* stage the 1904-sample window starting at stream sample `base' into LDS (whole workgroup) */
 LH_DEVFN void
 lh_stage_window(const LhCtx & c, float (*mf)[LH_MF_NEEDED], long long base)

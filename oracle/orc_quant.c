@@ -6,10 +6,6 @@
 #include "orc_common.h"
 #include "../deprecated-lame-mirror_amd/csrc/lh_static_tables.h"
 
-#ifdef ORC_TRACE
-#include <stdio.h>
-static FILE* orc_tf(void){ static FILE* f; if(!f) f=fopen("/tmp/dbg/orc.trace","w"); return f; }
-#endif
 #define MAGIC_FLOAT (65536*(128))
 #define MAGIC_INT 0x4b000000
 #define IPOW20(T,x)  ((T)->ipow20[x])
@@ -378,9 +374,6 @@ count_bits(OrcStream * S, const float *const xr, OrcGr * const gi, OrcNoiseData 
     int    *const ix = gi->l3_enc;
     float const w = (LH_IXMAX) / IPOW20(T, gi->global_gain);
     if (gi->xrpow_max > w) {
-#ifdef ORC_TRACE
-        fprintf(orc_tf(), "CB gg=%d ssc=%d pre=%d xm=%a bits=%d c1=%d bv=%d\n", gi->global_gain, gi->scalefac_scale, gi->preflag, gi->xrpow_max, LH_LARGE_BITS, gi->count1, gi->big_values);
-#endif
         return LH_LARGE_BITS;
     }
     quantize_xrpow(T, xr, ix, IPOW20(T, gi->global_gain), gi, prev_noise);
@@ -401,9 +394,6 @@ count_bits(OrcStream * S, const float *const xr, OrcGr * const gi, OrcNoiseData 
     }
     {
         int r_ = noquant_count_bits(S, gi, prev_noise);
-#ifdef ORC_TRACE
-        fprintf(orc_tf(), "CB gg=%d ssc=%d pre=%d xm=%a bits=%d c1=%d bv=%d\n", gi->global_gain, gi->scalefac_scale, gi->preflag, gi->xrpow_max, r_, gi->count1, gi->big_values);
-#endif
         return r_;
     }
 }
@@ -925,9 +915,6 @@ calc_noise(const LhTables * T, OrcGr const *const cod_info, float const *l3_xmin
     res->tot_noise = tot_noise_db;
     res->over_noise = over_noise_db;
     res->max_noise = max_noise;
-#ifdef ORC_TRACE
-    fprintf(orc_tf(), "CN over=%d tot=%a on=%a max=%a ssd=%d xmin0=%a d0=%a\n", res->over_count, res->tot_noise, res->over_noise, res->max_noise, res->over_SSD, (l3_xmin - cod_info->psymax)[0], (distort - cod_info->psymax)[0]);
-#endif
     return over;
 }
 
