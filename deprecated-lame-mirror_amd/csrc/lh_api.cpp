@@ -20,7 +20,7 @@
 #include "lh_host.h"
 #include "lh_device.h"
 
-extern "C" int lh_launch_encode(const LhConfig * cfg, const LhTables * T, const int16_t * pcm,
+extern "C" int lh_launch_encode(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, const float *pcmf,
                                 const LhStreamDesc * descs, LhStreamState * states,
                                 LhFrameOut * out, int nstreams, void *stream);
 
@@ -87,13 +87,13 @@ struct lame_global_struct {
     LhTables *tab;              /* host copy */
     LhDeviceConst dc;
     /* streaming state of the single-handle path */
-    std::vector < short >hl, hr; /* samples [hist_base, fed) kept on the host */
+    std::vector < float >hl, hr; /* transformed samples [hist_base, fed) kept on the host (in_buffer_0/1) */
     long long hist_base;
     long long fed;
     int     frames_done;
     int     flushed;
     LhStreamState *d_state;
-    int16_t *d_pcm;
+    float  *d_pcm;
     long long d_pcm_cap;
     LhStreamDesc *d_desc;
     LhFrameOut *d_out;
@@ -403,13 +403,13 @@ handle_encode_frames(lame_t g, int upto, unsigned char *mp3buf, int mp3buf_size,
         if (g->d_pcm)
             (void) hipFree(g->d_pcm);
         g->d_pcm_cap = n + 4096;
-        HIPCHK(hipMalloc((void **) &g->d_pcm, (size_t) g->d_pcm_cap * 2 * sizeof(int16_t)));
+        HIPCHK(hipMalloc((void **) &g->d_pcm, (size_t) g->d_pcm_cap * 2 * sizeof(float)));
     }
     if (n > 0) {
-        HIPCHK(hipMemcpyAsync(g->d_pcm, &g->hl[(size_t) (p0 - g->hist_base)], (size_t) n * 2,
+        HIPCHK(hipMemcpyAsync(g->d_pcm, &g->hl[(size_t) (p0 - g->hist_base)], (size_t) n * sizeof(float),
                               hipMemcpyHostToDevice, g->stream));
         HIPCHK(hipMemcpyAsync(g->d_pcm + g->d_pcm_cap, &g->hr[(size_t) (p0 - g->hist_base)],
-                              (size_t) n * 2, hipMemcpyHostToDevice, g->stream));
+                              (size_t) n * sizeof(float), hipMemcpyHostToDevice, g->stream));
     }
     if (nf > g->d_out_cap) {
         if (g->d_out)
@@ -426,7 +426,7 @@ handle_encode_frames(lame_t g, int upto, unsigned char *mp3buf, int mp3buf_size,
     d.frame_end = upto;
     HIPCHK(hipMemcpyAsync(g->d_desc, &d, sizeof(d), hipMemcpyHostToDevice, g->stream));
     {
-        int     rc = lh_launch_encode(g->dc.d_cfg, g->dc.d_tab, g->d_pcm, g->d_desc, g->d_state,
+        int     rc = lh_launch_encode(g->dc.d_cfg, g->dc.d_tab, (const int16_t *) 0, g->d_pcm, g->d_desc, g->d_state,
                                       g->d_out, 1, (void *) g->stream);
         if (rc)
             return set_err("kernel launch", (hipError_t) rc);
@@ -475,9 +475,12 @@ handle_encode_frames(lame_t g, int upto, unsigned char *mp3buf, int mp3buf_size,
     return 0;
 }
 
-extern "C" int
-lame_encode_buffer(lame_t g, const short int l[], const short int r[], const int nsamples,
-                   unsigned char *mp3buf, const int mp3buf_size)
+/* lame_encode_buffer_template + lame_copy_inbuffer (reference lame.c:1786-1872): samples of any
+ * type become sample_t through the transform matrix scaled by the type's norm; the frames that
+ * became complete are encoded */
+template < typename T > static int
+encode_buffer_any(lame_t g, const T * l, const T * r, int nsamples, int jump, float norm, unsigned char *mp3buf,
+                  int mp3buf_size)
 {
     int     written = 0, rc, avail;
     if (!valid(g) || !g->inited)
@@ -490,8 +493,22 @@ lame_encode_buffer(lame_t g, const short int l[], const short int r[], const int
         return -1;
     if (g->p.channels == 1)
         r = l;                  /* one input channel: buffer_r is not read (reference lame.c:1855-1866) */
-    g->hl.insert(g->hl.end(), l, l + nsamples);
-    g->hr.insert(g->hr.end(), r, r + nsamples);
+    if (!l || !r)
+        return 0;
+    {
+        /* pcm_transform: [0] = { pcm_scale, pcm_mix }, [1] = { 0, pcm_scale_r } */
+        float const m00 = norm * g->cfg.pcm_scale, m01 = norm * g->cfg.pcm_mix;
+        float const m10 = norm * (0.0f * g->cfg.pcm_scale), m11 = norm * g->cfg.pcm_scale_r;
+        size_t const at = g->hl.size();
+        g->hl.resize(at + (size_t) nsamples);
+        g->hr.resize(at + (size_t) nsamples);
+        for (int i = 0; i < nsamples; i++) {
+            float const xl = (float) l[(size_t) i * (size_t) jump];
+            float const xr = (float) r[(size_t) i * (size_t) jump];
+            g->hl[at + (size_t) i] = xl * m00 + xr * m01;
+            g->hr[at + (size_t) i] = xl * m10 + xr * m11;
+        }
+    }
     g->fed += nsamples;
     g->flushed = 0;
     /* a frame is encoded whenever 1904 samples are buffered behind the 528-sample
@@ -507,15 +524,80 @@ lame_encode_buffer(lame_t g, const short int l[], const short int r[], const int
 }
 
 extern "C" int
+lame_encode_buffer(lame_t g, const short int l[], const short int r[], const int nsamples,
+                   unsigned char *mp3buf, const int mp3buf_size)
+{
+    return encode_buffer_any(g, l, r, nsamples, 1, 1.0f, mp3buf, mp3buf_size);
+}
+
+extern "C" int
 lame_encode_buffer_interleaved(lame_t g, short int pcm[], int num_samples, unsigned char *mp3buf,
                                int mp3buf_size)
 {
-    std::vector < short >l((size_t) (num_samples > 0 ? num_samples : 0)), r(l.size());
-    for (int i = 0; i < num_samples; i++) {
-        l[(size_t) i] = pcm[2 * i];
-        r[(size_t) i] = pcm[2 * i + 1];
-    }
-    return lame_encode_buffer(g, l.data(), r.data(), num_samples, mp3buf, mp3buf_size);
+    return encode_buffer_any(g, pcm, pcm + 1, num_samples, 2, 1.0f, mp3buf, mp3buf_size);
+}
+
+/* +/- 32768 full scale (reference lame.c:1884-1890) */
+extern "C" int
+lame_encode_buffer_float(lame_t g, const float l[], const float r[], const int nsamples, unsigned char *mp3buf,
+                         const int mp3buf_size)
+{
+    return encode_buffer_any(g, l, r, nsamples, 1, 1.0f, mp3buf, mp3buf_size);
+}
+
+/* +/- 1.0 full scale (reference lame.c:1894-1930) */
+extern "C" int
+lame_encode_buffer_ieee_float(lame_t g, const float l[], const float r[], const int nsamples, unsigned char *mp3buf,
+                              const int mp3buf_size)
+{
+    return encode_buffer_any(g, l, r, nsamples, 1, 32767.0f, mp3buf, mp3buf_size);
+}
+
+extern "C" int
+lame_encode_buffer_interleaved_ieee_float(lame_t g, const float pcm[], const int nsamples, unsigned char *mp3buf,
+                                          const int mp3buf_size)
+{
+    return encode_buffer_any(g, pcm, pcm + 1, nsamples, 2, 32767.0f, mp3buf, mp3buf_size);
+}
+
+extern "C" int
+lame_encode_buffer_ieee_double(lame_t g, const double l[], const double r[], const int nsamples,
+                               unsigned char *mp3buf, const int mp3buf_size)
+{
+    return encode_buffer_any(g, l, r, nsamples, 1, 32767.0f, mp3buf, mp3buf_size);
+}
+
+extern "C" int
+lame_encode_buffer_interleaved_ieee_double(lame_t g, const double pcm[], const int nsamples, unsigned char *mp3buf,
+                                           const int mp3buf_size)
+{
+    return encode_buffer_any(g, pcm, pcm + 1, nsamples, 2, 32767.0f, mp3buf, mp3buf_size);
+}
+
+/* +/- MAX_INT full scale (reference lame.c:1934-1942) */
+extern "C" int
+lame_encode_buffer_int(lame_t g, const int l[], const int r[], const int nsamples, unsigned char *mp3buf,
+                       const int mp3buf_size)
+{
+    float const norm = (float) (1.0 / (1L << (8 * sizeof(int) - 16)));
+    return encode_buffer_any(g, l, r, nsamples, 1, norm, mp3buf, mp3buf_size);
+}
+
+/* +/- MAX_LONG full scale (reference lame.c:1945-1953) */
+extern "C" int
+lame_encode_buffer_long2(lame_t g, const long l[], const long r[], const int nsamples, unsigned char *mp3buf,
+                         const int mp3buf_size)
+{
+    float const norm = (float) (1.0 / (1L << (8 * sizeof(long) - 16)));
+    return encode_buffer_any(g, l, r, nsamples, 1, norm, mp3buf, mp3buf_size);
+}
+
+/* +/- 32768 full scale in a long (reference lame.c:1956-1962) */
+extern "C" int
+lame_encode_buffer_long(lame_t g, const long l[], const long r[], const int nsamples, unsigned char *mp3buf,
+                        const int mp3buf_size)
+{
+    return encode_buffer_any(g, l, r, nsamples, 1, 1.0f, mp3buf, mp3buf_size);
 }
 
 extern "C" int
@@ -837,7 +919,7 @@ lamehip_batch_encode(lamehip_batch * b)
                           hipMemcpyHostToDevice, b->stream));
     HIPCHK(hipEventRecord(b->ev0, b->stream));
     {
-        int     rc = lh_launch_encode(b->dc.d_cfg, b->dc.d_tab, b->d_pcm, b->d_desc, b->d_state,
+        int     rc = lh_launch_encode(b->dc.d_cfg, b->dc.d_tab, b->d_pcm, (const float *) 0, b->d_desc, b->d_state,
                                       b->d_out, b->B, (void *) b->stream);
         if (rc)
             return set_err("kernel launch", (hipError_t) rc);

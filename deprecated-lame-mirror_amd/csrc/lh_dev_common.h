@@ -212,6 +212,7 @@ struct LhCtxShared {
     const LhTables *T;
     LhStreamState *st;
     const int16_t *pcm;
+    const float *pcmf;          /* not null: the window comes from this pool, already transformed (handle API) */
     LhStreamDesc d;
     long long frame_base;       /* stream sample index of mfbuf[0] for the current frame: 1152 f - 528 */
 };
@@ -279,6 +280,7 @@ struct LhCtx {
     const LhTables *T;
     LhStreamState *st;
     const int16_t *pcm;
+    const float *pcmf;
     LhStreamDesc d;
     long long frame_base;       /* stream sample index of mfbuf[0] for the current frame: 1152 f - 528 */
     int     lane, wave, tid;
@@ -328,6 +330,7 @@ lh_ctx_load(void)
     o.T = LH_AS_GLOBAL(const LhTables, lh_lds.ctx.T);
     o.st = LH_AS_GLOBAL(LhStreamState, lh_lds.ctx.st);
     o.pcm = LH_AS_GLOBAL(const int16_t, lh_lds.ctx.pcm);
+    o.pcmf = LH_AS_GLOBAL(const float, lh_lds.ctx.pcmf);
     o.d = lh_lds.ctx.d;
     o.frame_base = lh_lds.ctx.frame_base;
     o.tid = (int) threadIdx.x;
@@ -358,6 +361,19 @@ lh_stage_window(const LhCtx & c, float (*mf)[LH_MF_NEEDED], long long base)
     long long const last = c.d.nsamples - 1;
     float const mix = c.cfg->pcm_mix;
     float const scale_r = c.cfg->pcm_scale_r;
+    if (c.pcmf) {
+        /* float pool of the lame_encode_buffer* handle path: the host applied the sample type's
+         * scale and the pcm_transform matrix (lame_copy_inbuffer, reference lame.c:1786-1834) */
+        for (int t = c.tid; t < 2 * LH_MF_NEEDED; t += LH_NT) {
+            int const ch = t >= LH_MF_NEEDED, i = t - ch * LH_MF_NEEDED;
+            long long const p = base + i;
+            float   v = 0.0f;
+            if (p >= 0 && p <= last && p >= c.d.pcm_base)
+                v = c.pcmf[(ch == 0 ? c.d.pcm_l : c.d.pcm_r) + (p - c.d.pcm_base)];
+            mf[ch][i] = v;
+        }
+        return;
+    }
     if (mix != 0.0f) {
         /* two channels mixed down to one (plain loop: not the configuration the batching below is for) */
         for (int i = c.tid; i < LH_MF_NEEDED; i += LH_NT) {

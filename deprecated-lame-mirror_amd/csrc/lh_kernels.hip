@@ -496,7 +496,7 @@ extern "C" __global__ void __launch_bounds__(LH_NT, 2)
 #else
 void
 #endif
-lh_encode_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm,
+lh_encode_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, const float *pcmf,
                  const LhStreamDesc * descs, LhStreamState * states, LhFrameOut * out,
                  int nstreams)
 {
@@ -518,6 +518,7 @@ lh_encode_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm,
     c.T = T;
     c.st = &states[sidx];
     c.pcm = pcm;
+    c.pcmf = pcmf;
     c.d = descs[sidx];
     c.tid = (int) threadIdx.x;
     c.lane = c.tid & 63;
@@ -528,6 +529,7 @@ lh_encode_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm,
         L.ctx.T = c.T;
         L.ctx.st = c.st;
         L.ctx.pcm = c.pcm;
+        L.ctx.pcmf = c.pcmf;
         L.ctx.d = c.d;
     }
     /* partition start tables (prefix sums of numlines): constant for the launch, kept in LDS */
@@ -610,14 +612,14 @@ lh_launch_selftest(unsigned *d_out, unsigned seed, void *stream)
 
 /* host-side launcher with a C ABI for lh_api.cpp */
 extern "C" int
-lh_launch_encode(const LhConfig * cfg, const LhTables * T, const int16_t * pcm,
+lh_launch_encode(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, const float *pcmf,
                  const LhStreamDesc * descs, LhStreamState * states, LhFrameOut * out,
                  int nstreams, void *stream)
 {
     if (nstreams <= 0)
         return 0;
     hipLaunchKernelGGL(lh_encode_kernel, dim3((unsigned) nstreams), dim3(LH_NT), 0,
-                       (hipStream_t) stream, cfg, T, pcm, descs, states, out, nstreams);
+                       (hipStream_t) stream, cfg, T, pcm, pcmf, descs, states, out, nstreams);
     return (int) hipGetLastError();
 }
 
@@ -655,7 +657,7 @@ lh_emu_encode(const LhConfig * cfg, const LhTables * T, const int16_t * pcm,
 {
     hipemu_dim3 grid = { (unsigned) nstreams, 1, 1 }, block = { LH_NT, 1, 1 };
     hipemu_run(grid, block,[=] () {
-               lh_encode_kernel(cfg, T, pcm, descs, states, out, nstreams);
+               lh_encode_kernel(cfg, T, pcm, (const float *) 0, descs, states, out, nstreams);
                }
     );
     return 0;

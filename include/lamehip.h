@@ -106,6 +106,24 @@ int     lame_encode_buffer(lame_t, const short int buffer_l[], const short int b
                            const int nsamples, unsigned char *mp3buf, const int mp3buf_size);   /* lame.h:715 */
 int     lame_encode_buffer_interleaved(lame_t, short int pcm[], int num_samples,
                                        unsigned char *mp3buf, int mp3buf_size);                  /* lame.h:730 */
+/* the other sample types of the reference (same return codes); each sample goes through the
+ * type's scale and the pcm_transform matrix exactly as lame_copy_inbuffer does */
+int     lame_encode_buffer_float(lame_t, const float l[], const float r[], const int nsamples,
+                                 unsigned char *mp3buf, const int mp3buf_size);                  /* lame.h:746 (+/-32768) */
+int     lame_encode_buffer_ieee_float(lame_t, const float l[], const float r[], const int nsamples,
+                                      unsigned char *mp3buf, const int mp3buf_size);             /* lame.h:758 (+/-1.0) */
+int     lame_encode_buffer_interleaved_ieee_float(lame_t, const float pcm[], const int nsamples,
+                                                  unsigned char *mp3buf, const int mp3buf_size); /* lame.h:765 */
+int     lame_encode_buffer_ieee_double(lame_t, const double l[], const double r[], const int nsamples,
+                                       unsigned char *mp3buf, const int mp3buf_size);            /* lame.h:776 */
+int     lame_encode_buffer_interleaved_ieee_double(lame_t, const double pcm[], const int nsamples,
+                                                   unsigned char *mp3buf, const int mp3buf_size);        /* lame.h:783 */
+int     lame_encode_buffer_long(lame_t, const long l[], const long r[], const int nsamples,
+                                unsigned char *mp3buf, const int mp3buf_size);                   /* lame.h:799 (+/-32768) */
+int     lame_encode_buffer_long2(lame_t, const long l[], const long r[], const int nsamples,
+                                 unsigned char *mp3buf, const int mp3buf_size);                  /* lame.h:813 (+/-2^63) */
+int     lame_encode_buffer_int(lame_t, const int l[], const int r[], const int nsamples,
+                               unsigned char *mp3buf, const int mp3buf_size);                    /* lame.h:831 (+/-2^31) */
 int     lame_encode_flush(lame_t, unsigned char *mp3buf, int size);                              /* lame.h:856 */
 /* final Xing/Info + LAME tag frame that replaces the placeholder at the head of the stream */
 size_t  lame_get_lametag_frame(const lame_t, unsigned char *buffer, size_t size);                /* lame.h:970 */

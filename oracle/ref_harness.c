@@ -229,6 +229,34 @@ refh_encode(void *hh, const short *l, const short *r, int n, unsigned char *out,
     return lame_encode_buffer(h->gfp, l, r, n, out, outsize);
 }
 
+/* the other sample types: kind 1 float (+/-32768), 2 ieee_float, 3 interleaved ieee_float (l = the
+ * interleaved buffer), 4 ieee_double, 5 int, 6 long (+/-32768), 7 long2, 8 interleaved short */
+int
+refh_encode_typed(void *hh, int kind, const void *l, const void *r, int n, unsigned char *out, int outsize)
+{
+    RefH   *h = (RefH *) hh;
+    switch (kind) {
+    case 1:
+        return lame_encode_buffer_float(h->gfp, (const float *) l, (const float *) r, n, out, outsize);
+    case 2:
+        return lame_encode_buffer_ieee_float(h->gfp, (const float *) l, (const float *) r, n, out, outsize);
+    case 3:
+        return lame_encode_buffer_interleaved_ieee_float(h->gfp, (const float *) l, n, out, outsize);
+    case 4:
+        return lame_encode_buffer_ieee_double(h->gfp, (const double *) l, (const double *) r, n, out, outsize);
+    case 5:
+        return lame_encode_buffer_int(h->gfp, (const int *) l, (const int *) r, n, out, outsize);
+    case 6:
+        return lame_encode_buffer_long(h->gfp, (const long *) l, (const long *) r, n, out, outsize);
+    case 7:
+        return lame_encode_buffer_long2(h->gfp, (const long *) l, (const long *) r, n, out, outsize);
+    case 8:
+        return lame_encode_buffer_interleaved(h->gfp, (short *) l, n, out, outsize);
+    default:
+        return lame_encode_buffer(h->gfp, (const short *) l, (const short *) r, n, out, outsize);
+    }
+}
+
 int
 refh_flush(void *hh, unsigned char *out, int outsize)
 {

@@ -436,3 +436,68 @@ def test_dual_channel_uncoupled_blocks_match_oracle(kw, oracle):
     assert b.pack(0) == helpers.pack_frames(enc.lib, cfg, tab, want)
     b.close()
     enc.close()
+
+
+@pytest.mark.skipif(not helpers.have_reference(), reason="needs oracle/_ref (reference sources)")
+@pytest.mark.parametrize("kind,kw", [(1, dict(brate=128)), (2, dict(vbr_q=3)), (3, dict(brate=160)), (4, dict(abr=140)),
+                                     (5, dict(brate=128)), (6, dict(vbr_q=5)), (7, dict(brate=192)), (8, dict(brate=128)),
+                                     (5, dict(brate=96, channels=1)), (2, dict(vbr_q=2, mode=3))])
+def test_typed_buffer_entry_points_match_reference(kind, kw):
+    """lame_encode_buffer_float / _ieee_float / _interleaved_ieee_float / _ieee_double / _int / _long / _long2 /
+    _interleaved, call by call against the compiled reference fed the very same buffers (samples that are
+    not whole 16-bit steps included: the window is float from the host on)."""
+    import ctypes as C
+    sr, n, chunk = 44100, 44100, 1000
+    rng = np.random.Generator(np.random.PCG64(kind))
+    x = helpers.synth_stream(1500 + kind, n, sr, 1.0 / 7).astype(np.float64) + rng.uniform(-0.4, 0.4, (2, n))
+    if kind in (2, 3, 4):
+        x = x / 32767.0
+    dt = {1: np.float32, 2: np.float32, 3: np.float32, 4: np.float64, 5: np.int32, 6: np.int64, 7: np.int64, 8: np.int16}[kind]
+    if kind == 5:
+        x = x * 65536.0
+    if kind == 7:
+        x = x * 2.0 ** 48
+    x = np.ascontiguousarray(x.astype(dt))
+    name = {1: "lame_encode_buffer_float", 2: "lame_encode_buffer_ieee_float", 3: "lame_encode_buffer_interleaved_ieee_float",
+            4: "lame_encode_buffer_ieee_double", 5: "lame_encode_buffer_int", 6: "lame_encode_buffer_long",
+            7: "lame_encode_buffer_long2", 8: "lame_encode_buffer_interleaved"}[kind]
+    ref = helpers.Reference().lib
+    nch = kw.get("channels", 2)
+    ref.refh_set_channels(nch)
+    mode = kw.get("mode", -1)
+    if "vbr_q" in kw:
+        rh = ref.refh_open_vbr(sr, kw["vbr_q"], mode, -1, 0, 0)
+    elif "abr" in kw:
+        rh = ref.refh_open_abr(sr, kw["abr"], mode, -1, 0, 0)
+    else:
+        rh = ref.refh_open(sr, kw["brate"], mode, -1)
+    ref.refh_set_channels(2)
+    assert rh
+    rh = C.c_void_p(rh)
+    enc = lamehip.Encoder(sr, **kw)
+    fn = getattr(enc.lib, name)
+    fn.restype = C.c_int
+    buf = C.create_string_buffer(2 * chunk + 8000)
+    rbuf = C.create_string_buffer(2 * chunk + 8000)
+    mine = theirs = b""
+    for i in range(0, n, chunk):
+        m = min(chunk, n - i)
+        if kind in (3, 8):
+            inter = np.ascontiguousarray(x[:, i:i + m].T.reshape(-1))
+            a = (C.c_void_p(inter.ctypes.data), None)
+        else:
+            a = (C.c_void_p(x[0, i:].ctypes.data), C.c_void_p(x[1, i:].ctypes.data))
+        if kind in (3, 8):
+            k1 = fn(enc.h, a[0], m, buf, len(buf))
+        else:
+            k1 = fn(enc.h, a[0], a[1], m, buf, len(buf))
+        k2 = ref.refh_encode_typed(rh, kind, a[0], a[1], m, rbuf, len(rbuf))
+        assert k1 == k2 >= 0, (i, k1, k2, lamehip.last_error())
+        mine += buf.raw[:k1]
+        theirs += rbuf.raw[:k2]
+    k2 = ref.refh_flush(rh, rbuf, len(rbuf))
+    theirs += rbuf.raw[:k2]
+    mine += enc.flush()
+    ref.refh_close(rh)
+    assert mine == theirs and len(mine) > 1000
+    enc.close()
