@@ -22,7 +22,7 @@
 
 extern "C" int lh_launch_encode(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, const float *pcmf,
                                 const LhStreamDesc * descs, LhStreamState * states,
-                                LhFrameOut * out, int nstreams, void *stream);
+                                LhFrameOut * out, uint8_t * bytes, int nstreams, void *stream);
 
 extern "C" int lh_launch_selftest(unsigned *d_out, unsigned seed, void *stream);
 extern "C" int lh_launch_poison(unsigned pattern, void *stream);
@@ -424,10 +424,12 @@ handle_encode_frames(lame_t g, int upto, unsigned char *mp3buf, int mp3buf_size,
     d.out_index = 0;
     d.frame_begin = f0;
     d.frame_end = upto;
+    d.bytes_base = d.bytes_cap = 0;
+    d.flush = d.pad = 0;
     HIPCHK(hipMemcpyAsync(g->d_desc, &d, sizeof(d), hipMemcpyHostToDevice, g->stream));
     {
         int     rc = lh_launch_encode(g->dc.d_cfg, g->dc.d_tab, (const int16_t *) 0, g->d_pcm, g->d_desc, g->d_state,
-                                      g->d_out, 1, (void *) g->stream);
+                                      g->d_out, (uint8_t *) 0, 1, (void *) g->stream);
         if (rc)
             return set_err("kernel launch", (hipError_t) rc);
     }
@@ -750,6 +752,11 @@ struct lamehip_batch {
     std::vector < long >len;
     std::vector < int >nframes;
     std::vector < long long >out_off;
+    /* device bit packing (lamehip_batch_set_device_packing) */
+    int     dev_pack;
+    uint8_t *d_bytes;
+    long long bytes_cap;
+    std::vector < long long >bytes_off;
     std::vector < LhStreamDesc > h_desc;
     hipStream_t stream;
     hipEvent_t ev0, ev1;
@@ -796,6 +803,10 @@ lamehip_batch_create(const lame_t proto, int nstreams, long capacity_samples)
     b->h_desc.resize((size_t) nstreams);
     b->last_ms = 0;
     b->encoded = 0;
+    b->dev_pack = 0;
+    b->d_bytes = nullptr;
+    b->bytes_cap = 0;
+    b->bytes_off.assign((size_t) nstreams, 0);
     if (b->dc.upload(b->cfg, *b->tab) != 0
         || hipMalloc((void **) &b->d_pcm, (size_t) nstreams * 2 * (size_t) capacity_samples * 2) != hipSuccess
         || hipMalloc((void **) &b->d_state, (size_t) nstreams * sizeof(LhStreamState)) != hipSuccess
@@ -824,6 +835,8 @@ lamehip_batch_destroy(lamehip_batch * b)
         (void) hipFree(b->d_desc);
     if (b->d_out)
         (void) hipFree(b->d_out);
+    if (b->d_bytes)
+        (void) hipFree(b->d_bytes);
     if (b->stream)
         (void) hipStreamDestroy(b->stream);
     if (b->ev0)
@@ -894,9 +907,15 @@ lamehip_batch_reset(lamehip_batch * b)
 extern "C" int
 lamehip_batch_encode(lamehip_batch * b)
 {
-    long long total = 0;
+    long long total = 0, bytes_total = 0;
+    int     max_frame_bytes;
     if (!b)
         return -1;
+    {
+        int const top = (b->cfg.vbr == 0) ? b->cfg.bitrate_index : b->cfg.vbr_max_bitrate_index;
+        static const int kbps[16] = { 0, 32, 40, 48, 56, 64, 80, 96, 112, 128, 160, 192, 224, 256, 320, 0 };
+        max_frame_bytes = (b->cfg.version + 1) * 72000 * kbps[top & 15] / b->cfg.samplerate + 1;
+    }
     for (int s = 0; s < b->B; s++) {
         LhStreamDesc & d = b->h_desc[(size_t) s];
         b->out_off[(size_t) s] = total;
@@ -907,7 +926,20 @@ lamehip_batch_encode(lamehip_batch * b)
         d.out_index = total;
         d.frame_begin = 0;
         d.frame_end = b->nframes[(size_t) s];
+        d.flush = 1;
+        d.pad = 0;
+        d.bytes_base = bytes_total;
+        /* room for every frame at the largest frame size the settings allow (+1 for CBR padding) */
+        d.bytes_cap = b->dev_pack ? (long long) b->nframes[(size_t) s] * max_frame_bytes : 0;
+        b->bytes_off[(size_t) s] = bytes_total;
+        bytes_total += d.bytes_cap;
         total += b->nframes[(size_t) s];
+    }
+    if (b->dev_pack && bytes_total > b->bytes_cap) {
+        if (b->d_bytes)
+            (void) hipFree(b->d_bytes);
+        b->bytes_cap = bytes_total;
+        HIPCHK(hipMalloc((void **) &b->d_bytes, (size_t) bytes_total));
     }
     if (total > b->out_cap) {
         if (b->d_out)
@@ -920,13 +952,49 @@ lamehip_batch_encode(lamehip_batch * b)
     HIPCHK(hipEventRecord(b->ev0, b->stream));
     {
         int     rc = lh_launch_encode(b->dc.d_cfg, b->dc.d_tab, b->d_pcm, (const float *) 0, b->d_desc, b->d_state,
-                                      b->d_out, b->B, (void *) b->stream);
+                                      b->d_out, b->dev_pack ? b->d_bytes : (uint8_t *) 0, b->B, (void *) b->stream);
         if (rc)
             return set_err("kernel launch", (hipError_t) rc);
     }
     HIPCHK(hipEventRecord(b->ev1, b->stream));
     b->encoded = 1;
     return 0;
+}
+
+/* Device bit packing: the kernel also assembles each stream's finished MP3 bytes in HBM
+ * (lh_dev_emit.h); lamehip_batch_get_bytes then copies them out, no host packer involved.
+ * Set before lamehip_batch_encode. */
+extern "C" int
+lamehip_batch_set_device_packing(lamehip_batch * b, int on)
+{
+    if (!b)
+        return -1;
+    b->dev_pack = on != 0;
+    return 0;
+}
+
+/* bytes of one stream as the device packed them (audio frames incl. the final padding, no tag) */
+extern "C" long
+lamehip_batch_get_bytes(lamehip_batch * b, int s, unsigned char *out, long out_size)
+{
+    LhStreamState st;
+    long    n;
+    if (!b || s < 0 || s >= b->B || !b->encoded || !b->dev_pack)
+        return -1;
+    HIPCHK(hipStreamSynchronize(b->stream));
+    HIPCHK(hipMemcpy(&st, b->d_state + s, sizeof(st), hipMemcpyDeviceToHost));
+    if (st.status != 0) {
+        snprintf(g_err, sizeof(g_err), "device bit packer reported status %d for stream %d", st.status, s);
+        return LAMEHIP_ERR_PAYLOAD;
+    }
+    n = (long) st.em_next_header;
+    if (b->nframes[(size_t) s] == 0)
+        n = 0;
+    if (n > out_size)
+        return -1;
+    if (n > 0)
+        HIPCHK(hipMemcpy(out, b->d_bytes + b->bytes_off[(size_t) s], (size_t) n, hipMemcpyDeviceToHost));
+    return n;
 }
 
 extern "C" int

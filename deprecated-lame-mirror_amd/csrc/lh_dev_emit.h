@@ -1,0 +1,447 @@
+/*
+ * lh_dev_emit.h -- the bit packer on the device (optional).
+ *
+ * What it produces is format_bitstream's output (reference libmp3lame/bitstream.c:133-985):
+ * header + side information of every frame at the frame's byte position, and the main data
+ * (scalefactors, Huffman codes, ancillary stuffing) as one continuous bit stream that flows
+ * around the headers, back into the space earlier frames left (the bit reservoir).  The
+ * reference writes that stream bit by bit through putbits(), splicing a header in whenever the
+ * cursor reaches its write_timing.  Here
+ *   - each granule/channel packs its own bits right after it was quantised: one lane per
+ *     scalefactor band / Huffman pair / count1 quadruple computes its code word and length,
+ *     a wave prefix sum gives the bit position, LDS atomic ORs place the words;
+ *   - at the end of the frame, when the reservoir arithmetic has fixed the stuffing, the four
+ *     parts and the stuffing are shifted into one frame-long bit string in LDS, and its bytes
+ *     are scattered to their final positions in the stream's output buffer: position = cursor +
+ *     index + side-info length x (headers crossed), with the few pending header positions kept
+ *     in the stream state;
+ *   - the header itself (a few hundred bits of fields, CRC-16 when asked for) is built by one lane.
+ * The host then copies finished MP3 bytes out of HBM (lamehip_batch_get_bytes) instead of
+ * LhFrameOut records (4.9 KB per frame) that it would have to Huffman-code itself.
+ */
+#ifndef LH_DEV_EMIT_H
+#define LH_DEV_EMIT_H
+
+#include "lh_dev_quant.h"
+
+#define LH_EMIT_WORDS 132       /* 4095 bits of one granule/channel + slack */
+
+/* inclusive prefix sum over the wave */
+LH_DEVFN uint32_t
+lh_wave_scan_u32(uint32_t v)
+{
+#ifdef LH_EMU
+    const uint64_t *x = hipemu_wave_exchange(v);
+    uint32_t s = 0;
+    int const me = lh_lane();
+    for (int i = 0; i <= me; i++)
+        s += (uint32_t) x[i];
+    return s;
+#else
+    /* row_shr 1, 2, 4, 8 inside the 16-lane rows, then row_bcast 15 / 31 across them */
+    v += lh_dpp < 0x111, 0u > (v);
+    v += lh_dpp < 0x112, 0u > (v);
+    v += lh_dpp < 0x114, 0u > (v);
+    v += lh_dpp < 0x118, 0u > (v);
+    v += lh_dpp_rows < 0x142, 0xa, 0u > (v);
+    v += lh_dpp_rows < 0x143, 0xc, 0u > (v);
+    return v;
+#endif
+}
+
+LH_DEVFN void
+lh_lds_or(uint32_t * p, uint32_t v)
+{
+#ifdef LH_EMU
+    *p |= v;
+#else
+    (void) __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+}
+
+/* n (<= 32) bits of v, most significant first, at bit position pos of a word array whose bit 31 comes first */
+LH_DEVFN void
+lh_put_bits(uint32_t * buf, int pos, uint32_t v, int n)
+{
+    if (n > 0) {
+        int const w = pos >> 5, off = pos & 31, room = 32 - off;
+        if (n <= room)
+            lh_lds_or(&buf[w], (n == 32) ? v : (v << (room - n)));
+        else {
+            lh_lds_or(&buf[w], v >> (n - room));
+            lh_lds_or(&buf[w + 1], v << (32 - (n - room)));
+        }
+    }
+}
+
+/* scalefactors + Huffman data of the granule that sits in Q (reference bitstream.c:490-631,
+ * 685-790, MPEG-1) into words[LH_EMIT_WORDS] in HBM; returns the bits written */
+LH_DEVFN int
+lh_emit_part(const LhCtx & c, LhChanLds & Q, const LhQR & R, const LhGrR & g, const float *xr, uint32_t * words)
+{
+    const LhQTabs *qt = LH_QT;
+    uint32_t *buf = (uint32_t *) Q.xrpow;       /* dead after the quantisation loop */
+    const uint32_t *ix2 = (const uint32_t *) Q.ix[0];
+    int const lane = c.lane;
+    int     pos = 0;
+    LH_WAVE_SYNC();
+    for (int i = lane; i < LH_EMIT_WORDS; i += 64)
+        buf[i] = 0u;
+    LH_WAVE_SYNC();
+    {
+        /* part 2: one lane per scalefactor band; -1 = shared with granule 0 through scfsi */
+        int const s1 = (int) ((0x4433322211130000ull >> (4 * g.scalefac_compress)) & 15u);
+        int const s2 = (int) ((0x3232132132103210ull >> (4 * g.scalefac_compress)) & 15u);
+        int const sf = (lane < R.sfbmax) ? Q.sf[0][lane < LH_SFBMAX ? lane : 0] : -1;
+        int const len = (sf < 0) ? 0 : (lane < R.sfbdivide ? s1 : s2);
+        uint32_t const incl = lh_wave_scan_u32((uint32_t) len);
+        lh_put_bits(buf, (int) incl - len, (uint32_t) sf, len);
+        pos = (int) lh_bcast_u32(incl, 63);
+    }
+    {
+        /* part 3a: big values, one lane per pair, five rounds */
+        int const bv2 = g.big_values >> 1;
+        int     r1, r2;
+        if (R.block_type == LH_SHORT_TYPE) {
+            r1 = 3 * (int) qt->sfb_s3;
+            r2 = g.big_values;
+        }
+        else {
+            r1 = qt->sfb_l[g.region0_count + 1];
+            r2 = qt->sfb_l[g.region0_count + g.region1_count + 2];
+        }
+        r1 = (r1 > g.big_values ? g.big_values : r1) >> 1;
+        r2 = (r2 > g.big_values ? g.big_values : r2) >> 1;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            int const p = lane + 64 * k;
+            int const pc = (k < 4 || p < 288) ? p : 287;
+            uint32_t const pair = ix2[pc];
+            int const in = p < bv2;
+            int     t = (p < r1) ? g.table_select[0] : (p < r2) ? g.table_select[1] : g.table_select[2];
+            unsigned x1 = pair & 0xffffu, x2 = pair >> 16;
+            int const n1 = xr[2 * pc] < 0.0f, n2 = xr[2 * pc + 1] < 0.0f;
+            unsigned ext = 0, code = 0;
+            int     cbits = 0, xbits = 0;
+            t = (t == 14) ? 16 : t;     /* table 14 is only a length estimate; 16 carries the code book */
+            if (in && t != 0) {
+                unsigned const linbits = lh_ht_xlen[t];
+                unsigned xlen = linbits;
+                if (x1 != 0u) {
+                    ext = (unsigned) n1;
+                    cbits--;
+                }
+                if (t > 15) {
+                    if (x1 >= 15u) {
+                        ext |= (x1 - 15u) << 1;
+                        xbits = (int) linbits;
+                        x1 = 15u;
+                    }
+                    if (x2 >= 15u) {
+                        ext <<= linbits;
+                        ext |= (x2 - 15u);
+                        xbits += (int) linbits;
+                        x2 = 15u;
+                    }
+                    xlen = 16;
+                }
+                if (x2 != 0u) {
+                    ext <<= 1;
+                    ext |= (unsigned) n2;
+                    cbits--;
+                }
+                {
+                    unsigned const idx = (unsigned) lh_ht_offset[t] + x1 * xlen + x2;
+                    xbits -= cbits;
+                    cbits += lh_ht_len[idx];
+                    code = lh_ht_code[idx];
+                }
+            }
+            {
+                int const len = cbits + xbits;
+                uint32_t const incl = lh_wave_scan_u32((uint32_t) len);
+                int const at = pos + (int) incl - len;
+                lh_put_bits(buf, at, code, cbits);
+                lh_put_bits(buf, at + cbits, ext, xbits);
+                pos += (int) lh_bcast_u32(incl, 63);
+            }
+        }
+    }
+    {
+        /* part 3b: count1 quadruples, three rounds */
+        int const nq = (g.count1 - g.big_values) >> 2;
+        int const t = g.count1table_select + 32;
+        const int16_t *ix = Q.ix[0];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            int const qd = lane + 64 * k;
+            int const in = qd < nq;
+            int const base = in ? g.big_values + 4 * qd : 0;
+            int     p = 0, hb = 0, len = 0;
+            uint32_t val = 0;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                int const v = ix[base + u];
+                if (v) {
+                    p += 8 >> u;
+                    hb = hb * 2 + (xr[base + u] < 0.0f ? 1 : 0);
+                }
+            }
+            if (in) {
+                len = lh_ht_len[lh_ht_offset[t] + p];
+                val = (uint32_t) hb + lh_ht_code[lh_ht_offset[t] + p];
+            }
+            {
+                uint32_t const incl = lh_wave_scan_u32((uint32_t) len);
+                lh_put_bits(buf, pos + (int) incl - len, val, len);
+                pos += (int) lh_bcast_u32(incl, 63);
+            }
+        }
+    }
+    LH_WAVE_SYNC();
+    for (int i = lane; i < LH_EMIT_WORDS; i += 64)
+        words[i] = buf[i];
+    return pos;
+}
+
+/* bit i of `remaining' bits of ancillary stuffing (drain_into_ancillary, reference bitstream.c:223-267):
+ * "LAME", then the version string when at least 32 bits are left after it, then a bit pattern */
+LH_DEVFN int
+lh_anc_bit(int i, int remaining, int flag, int toggling)
+{
+    int const nl = remaining >= 32 ? 4 : (remaining >> 3);              /* bytes of "LAME" */
+    int const rem = remaining - 8 * nl;
+    int const nv = (rem >= 32) ? ((rem >> 3) < 6 ? (rem >> 3) : 6) : 0; /* bytes of "3.99.5" */
+    int const byte = i >> 3;
+    if (byte < nl + nv) {
+        unsigned const ch = (byte < nl) ? ((0x454d414cu >> (8 * byte)) & 255u)         /* 'L' 'A' 'M' 'E' */
+            : ((unsigned) ((0x352e39392e33ull >> (8 * (byte - nl))) & 255ull));         /* '3' '.' '9' '9' '.' '5' */
+        return (int) ((ch >> (7 - (i & 7))) & 1u);
+    }
+    return flag ^ (toggling ? ((i - 8 * (nl + nv)) & 1) : 0);
+}
+
+/* the flag after `remaining' bits of stuffing */
+LH_DEVFN int
+lh_anc_flag_after(int remaining, int flag, int toggling)
+{
+    int const nl = remaining >= 32 ? 4 : (remaining >> 3);
+    int const rem = remaining - 8 * nl;
+    int const nv = (rem >= 32) ? ((rem >> 3) < 6 ? (rem >> 3) : 6) : 0;
+    int const tail = remaining - 8 * (nl + nv);
+    return flag ^ (toggling ? (tail & 1) : 0);
+}
+
+/* header + side information of one frame (reference bitstream.c:320-487, MPEG-1) into h[];
+ * one lane, serial */
+LH_DEVFN void
+lh_emit_header(const LhConfig * cfg, const LhFrameOut * fo, int mdb, int bitrate_index, int padding, int mode_ext,
+               const int scfsi[2][4], unsigned char *h)
+{
+    int     ptr = 0;
+    int const sl = cfg->sideinfo_len;
+    for (int i = 0; i < sl; i++)
+        h[i] = 0;
+#define LH_HB(val, n) do { int v_ = (int) (val), j_ = (n); \
+        while (j_ > 0) { int const k_ = (j_ < 8 - (ptr & 7)) ? j_ : 8 - (ptr & 7); j_ -= k_; \
+            h[ptr >> 3] = (unsigned char) (h[ptr >> 3] | ((v_ >> j_) << (8 - (ptr & 7) - k_))); ptr += k_; } } while (0)
+    LH_HB(0xfff, 12);
+    LH_HB(cfg->version, 1);
+    LH_HB(4 - 3, 2);
+    LH_HB(!cfg->error_protection, 1);
+    LH_HB(bitrate_index, 4);
+    LH_HB(cfg->samplerate_index, 2);
+    LH_HB(padding, 1);
+    LH_HB(cfg->extension, 1);
+    LH_HB(cfg->mode, 2);
+    LH_HB(mode_ext, 2);
+    LH_HB(cfg->copyright, 1);
+    LH_HB(cfg->original, 1);
+    LH_HB(cfg->emphasis, 2);
+    if (cfg->error_protection)
+        LH_HB(0, 16);
+    LH_HB(mdb, 9);
+    LH_HB(0, cfg->channels == 2 ? 3 : 5);
+    for (int ch = 0; ch < cfg->channels; ch++)
+        for (int band = 0; band < 4; band++)
+            LH_HB(scfsi[ch][band], 1);
+    for (int gr = 0; gr < 2; gr++)
+        for (int ch = 0; ch < cfg->channels; ch++) {
+            const LhGranule *gi = &fo->gr[gr][ch];
+            LH_HB(gi->part2_3_length + gi->part2_length, 12);
+            LH_HB(gi->big_values / 2, 9);
+            LH_HB(gi->global_gain, 8);
+            LH_HB(gi->scalefac_compress, 4);
+            if (gi->block_type != LH_NORM_TYPE) {
+                LH_HB(1, 1);
+                LH_HB(gi->block_type, 2);
+                LH_HB(gi->mixed_block_flag, 1);
+                LH_HB(gi->table_select[0] == 14 ? 16 : gi->table_select[0], 5);
+                LH_HB(gi->table_select[1] == 14 ? 16 : gi->table_select[1], 5);
+                LH_HB(gi->subblock_gain[0], 3);
+                LH_HB(gi->subblock_gain[1], 3);
+                LH_HB(gi->subblock_gain[2], 3);
+            }
+            else {
+                LH_HB(0, 1);
+                LH_HB(gi->table_select[0] == 14 ? 16 : gi->table_select[0], 5);
+                LH_HB(gi->table_select[1] == 14 ? 16 : gi->table_select[1], 5);
+                LH_HB(gi->table_select[2] == 14 ? 16 : gi->table_select[2], 5);
+                LH_HB(gi->region0_count, 4);
+                LH_HB(gi->region1_count, 3);
+            }
+            LH_HB(gi->preflag, 1);
+            LH_HB(gi->scalefac_scale, 1);
+            LH_HB(gi->count1table_select, 1);
+        }
+#undef LH_HB
+    if (cfg->error_protection) {
+        int     crc = 0xffff;
+        for (int i = 2; i < sl; i++) {
+            int     value;
+            if (i == 4 || i == 5)
+                continue;
+            value = h[i] << 8;
+            for (int k = 0; k < 8; k++) {
+                value <<= 1;
+                crc <<= 1;
+                if ((crc ^ value) & 0x10000)
+                    crc ^= 0x8005;
+            }
+        }
+        h[4] = (unsigned char) (crc >> 8);
+        h[5] = (unsigned char) (crc & 255);
+    }
+}
+
+/* output position of main-data byte j counted from the cursor: every pending header start that is
+ * reached pushes the rest back by the side-info length */
+LH_DEVFN long long
+lh_emit_pos(long long cursor, long long j, const long long *hq, int nq, int sl)
+{
+    long long p = cursor + j;
+    for (int k = 0; k < nq; k++)
+        if (p >= hq[k])
+            p += sl;
+    return p;
+}
+
+/* One frame's bytes, whole workgroup.  `nbits' = pre + sum of the parts + post (a multiple of 8 by
+ * the reservoir's construction); part k of `np' parts has plen[k] bits in st->em_part[...]. */
+LH_DEVFN void
+lh_emit_frame(const LhCtx & c, const LhFrameOut * fo, uint8_t * bytes, int drain_pre, int drain_post, int frame_bytes,
+              int mdb, int bitrate_index, int padding, int mode_ext, int flush)
+{
+    LhLds & L = lh_lds;
+    const LhConfig *cfg = c.cfg;
+    LhStreamState *st = c.st;
+    uint32_t *fb = (uint32_t *) &L.u.quant.ch[0];      /* the quantiser's working set is dead: 4.6 KB of xrpow + save_xrpow */
+    int const tid = c.tid, nch = cfg->channels, sl = cfg->sideinfo_len;
+    int const toggling = !cfg->disable_reservoir;
+    int     plen[4], poff[4], np = 0, nbits, flag;
+    long long cursor, hq[16];
+    int     nq;
+    uint8_t *out = bytes + c.d.bytes_base;
+
+    LH_SYNC_WG();
+    nbits = drain_pre;
+    for (int gr = 0; gr < 2; gr++)
+        for (int ch = 0; ch < nch; ch++) {
+            const LhGranule *gi = &fo->gr[gr][ch];
+            poff[np] = nbits;
+            plen[np] = gi->part2_3_length + gi->part2_length;
+            nbits += plen[np];
+            np++;
+        }
+    nbits += drain_post;
+    cursor = st->em_cursor;
+    nq = st->em_nq;
+    for (int k = 0; k < 16; k++)
+        hq[k] = (k < nq) ? st->em_hq[k] : 0;
+    flag = st->em_anc_flag;
+    /* this frame's header joins the pending ones */
+    {
+        long long const here = st->em_next_header;
+        if (nq < 16)
+            hq[nq++] = here;
+        LH_SYNC_WG();           /* everyone has read the state */
+        if (tid == 0) {
+            unsigned char h[40];
+            int     scfsi[2][4];
+            for (int ch = 0; ch < 2; ch++)
+                for (int i = 0; i < 4; i++)
+                    scfsi[ch][i] = fo->scfsi[ch][i];
+            lh_emit_header(cfg, fo, mdb, bitrate_index, padding, mode_ext, scfsi, h);
+            if (here + sl <= c.d.bytes_cap)
+                for (int i = 0; i < sl; i++)
+                    out[here + i] = h[i];
+            st->em_next_header = here + frame_bytes;
+        }
+    }
+    for (int round = 0; round < (flush ? 2 : 1); round++) {
+        int     nbytes;
+        if (round == 1) {
+            /* flush_bitstream (reference bitstream.c:863-889): stuffing up to the end of the last frame */
+            long long const end = st->em_next_header;
+            nbits = (int) (8 * (end - cursor - (long long) sl * nq));
+            drain_pre = nbits;
+            drain_post = 0;
+            np = 0;
+            if (nbits <= 0)
+                break;
+        }
+        nbytes = nbits >> 3;
+        for (int i = tid; i < ((nbits + 31) >> 5) + 1; i += LH_NT)
+            fb[i] = 0u;
+        LH_SYNC_WG();
+        /* stuffing before and after the parts; the flag of the bit pattern runs through both */
+        for (int i = tid; i < drain_pre; i += LH_NT)
+            if (lh_anc_bit(i, drain_pre, flag, toggling))
+                lh_lds_or(&fb[i >> 5], 1u << (31 - (i & 31)));
+        {
+            int const f1 = lh_anc_flag_after(drain_pre, flag, toggling);
+            int const at = nbits - drain_post;
+            for (int i = tid; i < drain_post; i += LH_NT)
+                if (lh_anc_bit(i, drain_post, f1, toggling))
+                    lh_lds_or(&fb[(at + i) >> 5], 1u << (31 - ((at + i) & 31)));
+            flag = lh_anc_flag_after(drain_post, f1, toggling);
+        }
+        for (int k = 0; k < np; k++) {
+            const uint32_t *w = st->em_part[k / nch][k % nch];
+            int const nw = (plen[k] + 31) >> 5;
+            for (int i = tid; i < nw; i += LH_NT) {
+                int const n = (plen[k] - 32 * i) < 32 ? (plen[k] - 32 * i) : 32;
+                uint32_t const v = w[i];
+                lh_put_bits(fb, poff[k] + 32 * i, (n == 32) ? v : (v >> (32 - n)), n);
+            }
+        }
+        LH_SYNC_WG();
+        for (int j = tid; j < nbytes; j += LH_NT) {
+            long long const p = lh_emit_pos(cursor, j, hq, nq, sl);
+            if (p < c.d.bytes_cap)
+                out[p] = (uint8_t) ((fb[j >> 2] >> (24 - 8 * (j & 3))) & 255u);
+        }
+        /* cursor and the pending headers behind it */
+        cursor = lh_emit_pos(cursor, nbytes, hq, nq, sl);
+        {
+            int     keep = 0;
+            for (int k = 0; k < nq; k++)
+                if (hq[k] >= cursor)
+                    hq[keep++] = hq[k];
+            nq = keep;
+        }
+        if ((nbits & 7) != 0 && tid == 0)
+            st->status |= 2;    /* the reservoir arithmetic should make every frame's main data whole bytes */
+        LH_SYNC_WG();
+    }
+    if (tid == 0) {
+        st->em_cursor = cursor;
+        st->em_nq = nq;
+        for (int k = 0; k < 16; k++)
+            st->em_hq[k] = (k < nq) ? hq[k] : 0;
+        st->em_anc_flag = flag;
+    }
+    LH_SYNC_WG();
+}
+
+#endif

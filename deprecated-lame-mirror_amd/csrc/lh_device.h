@@ -46,6 +46,15 @@ typedef struct LhStreamState {
     int     primed;
     int     status;                     /* 0 ok; device-detected inconsistencies are reported here */
     int     pad[3];
+    /* on-device bit packing (lh_dev_emit.h): where the next header / main-data byte of the stream go,
+     * the header starts the cursor has not passed yet, the stuffing pattern's flag, and the packed
+     * bits of the frame's granules until the frame is assembled */
+    long long em_next_header;
+    long long em_cursor;
+    long long em_hq[16];
+    int     em_nq;
+    int     em_anc_flag;
+    uint32_t em_part[2][2][132];
     /* per-wave cycle accumulators, only filled by builds with -DLH_PROF (profiling aid) */
     unsigned long long prof[2][LH_NPROF];
 } LhStreamState;
@@ -59,6 +68,10 @@ typedef struct LhStreamDesc {
     long long out_index;        /* first LhFrameOut slot of this launch */
     int     frame_begin;        /* frames [frame_begin, frame_end) are encoded */
     int     frame_end;
+    long long bytes_base;       /* device bit packing: this stream's slice of the byte pool ... */
+    long long bytes_cap;        /* ... and its size */
+    int     flush;              /* pad the last frame out after frame_end - 1 (end of the stream) */
+    int     pad;
 } LhStreamDesc;
 
 void    lh_state_init(LhStreamState * s, const LhConfig * cfg);

@@ -171,6 +171,7 @@ lh_store_granule(const LhCtx & c, const LhChanLds & Q, const LhQR & R, const LhG
     }
 }
 
+#include "lh_dev_emit.h"
 #include "lh_dev_vbr.h"
 
 /* one frame of one stream; executed by the whole workgroup */
@@ -406,6 +407,11 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo)
             g = lh_uniform(L.rg[ch].g);
             LH_PA(6, t_fin);
             lh_store_granule(c, Q, R, g, xr, o);
+            if (c.bytes) {
+                int const nb = lh_emit_part(c, Q, R, g, xr, st->em_part[gr][ch]);
+                if (nb != g.part2_3_length + g.part2_length && lane == 0)
+                    st->status |= 4;    /* the packed bits disagree with the quantiser's count */
+            }
             LH_PA(3, t_q);
             if (lane == 0)
                 L.bits_used[ch] = g.part2_3_length + g.part2_length;
@@ -450,6 +456,7 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo)
         drain_post += stuffingBits;
         ResvSize -= stuffingBits;
     }
+    int const mdb_header = mdb;         /* the back pointer this frame's header carries */
     /* main_data_begin bookkeeping of format_bitstream (reference bitstream.c:917-935) */
     {
         int const bits = 8 * cfg->sideinfo_len + total_bits + drain_post;
@@ -482,6 +489,9 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo)
         if (mdb * 8 != ResvSize)
             st->status |= 1;    /* reservoir inconsistency (reference bitstream.c:947) */
     }
+    if (c.bytes)
+        lh_emit_frame(c, fo, c.bytes, drain_pre, drain_post, frame_bits / 8, mdb_header, bitrate_index, padding, mode_ext,
+                      c.d.flush && (int) ((c.frame_base + LH_MF_START) / 1152) == c.d.frame_end - 1);
     LH_PA(0, t_frame);
     LH_SYNC_WG();
 #if defined(LH_PROF) && !defined(LH_EMU)
@@ -497,7 +507,7 @@ extern "C" __global__ void __launch_bounds__(LH_NT, 2)
 void
 #endif
 lh_encode_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, const float *pcmf,
-                 const LhStreamDesc * descs, LhStreamState * states, LhFrameOut * out,
+                 const LhStreamDesc * descs, LhStreamState * states, LhFrameOut * out, uint8_t * bytes,
                  int nstreams)
 {
     LhLds & L = lh_lds;
@@ -519,6 +529,7 @@ lh_encode_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, 
     c.st = &states[sidx];
     c.pcm = pcm;
     c.pcmf = pcmf;
+    c.bytes = bytes;
     c.d = descs[sidx];
     c.tid = (int) threadIdx.x;
     c.lane = c.tid & 63;
@@ -530,6 +541,7 @@ lh_encode_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, 
         L.ctx.st = c.st;
         L.ctx.pcm = c.pcm;
         L.ctx.pcmf = c.pcmf;
+        L.ctx.bytes = c.bytes;
         L.ctx.d = c.d;
     }
     /* partition start tables (prefix sums of numlines): constant for the launch, kept in LDS */
@@ -613,13 +625,13 @@ lh_launch_selftest(unsigned *d_out, unsigned seed, void *stream)
 /* host-side launcher with a C ABI for lh_api.cpp */
 extern "C" int
 lh_launch_encode(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, const float *pcmf,
-                 const LhStreamDesc * descs, LhStreamState * states, LhFrameOut * out,
+                 const LhStreamDesc * descs, LhStreamState * states, LhFrameOut * out, uint8_t * bytes,
                  int nstreams, void *stream)
 {
     if (nstreams <= 0)
         return 0;
     hipLaunchKernelGGL(lh_encode_kernel, dim3((unsigned) nstreams), dim3(LH_NT), 0,
-                       (hipStream_t) stream, cfg, T, pcm, pcmf, descs, states, out, nstreams);
+                       (hipStream_t) stream, cfg, T, pcm, pcmf, descs, states, out, bytes, nstreams);
     return (int) hipGetLastError();
 }
 
@@ -651,13 +663,22 @@ lh_launch_poison(unsigned pattern, void *stream)
     return (int) hipGetLastError();
 }
 #else
+extern "C" int lh_emu_encode_bytes(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, const LhStreamDesc * descs,
+                                   LhStreamState * states, LhFrameOut * out, uint8_t * bytes, int nstreams);
 extern "C" int
 lh_emu_encode(const LhConfig * cfg, const LhTables * T, const int16_t * pcm,
               const LhStreamDesc * descs, LhStreamState * states, LhFrameOut * out, int nstreams)
 {
+    return lh_emu_encode_bytes(cfg, T, pcm, descs, states, out, (uint8_t *) 0, nstreams);
+}
+
+extern "C" int
+lh_emu_encode_bytes(const LhConfig * cfg, const LhTables * T, const int16_t * pcm,
+                    const LhStreamDesc * descs, LhStreamState * states, LhFrameOut * out, uint8_t * bytes, int nstreams)
+{
     hipemu_dim3 grid = { (unsigned) nstreams, 1, 1 }, block = { LH_NT, 1, 1 };
     hipemu_run(grid, block,[=] () {
-               lh_encode_kernel(cfg, T, pcm, (const float *) 0, descs, states, out, nstreams);
+               lh_encode_kernel(cfg, T, pcm, (const float *) 0, descs, states, out, bytes, nstreams);
                }
     );
     return 0;

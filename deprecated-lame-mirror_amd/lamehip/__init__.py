@@ -180,6 +180,21 @@ class Batch:
     def pcm_device_ptr(self):
         return self.lib.lamehip_batch_pcm_device_ptr(self.b)
 
+    def set_device_packing(self, on=True):
+        """Let the kernel assemble the MP3 bytes in HBM (get_bytes) instead of leaving it to the host packer."""
+        self.lib.lamehip_batch_set_device_packing.argtypes = [C.c_void_p, C.c_int]
+        assert self.lib.lamehip_batch_set_device_packing(self.b, 1 if on else 0) == 0
+
+    def get_bytes(self, s):
+        self.lib.lamehip_batch_get_bytes.restype = C.c_long
+        self.lib.lamehip_batch_get_bytes.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_long]
+        cap = (self.frames(s) + 2) * 1500
+        buf = C.create_string_buffer(cap)
+        k = self.lib.lamehip_batch_get_bytes(self.b, s, buf, cap)
+        if k < 0:
+            raise RuntimeError("lamehip_batch_get_bytes failed (%d): %s" % (k, last_error()))
+        return buf.raw[:k]
+
     def encode(self, sync=True):
         rc = self.lib.lamehip_batch_encode(self.b)
         if rc:

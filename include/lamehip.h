@@ -159,6 +159,13 @@ long    lamehip_batch_pack_tagged(lamehip_batch *, int stream, unsigned char *ou
 /* the same for all streams with `nthreads' host threads (streams are independent; the packer is
  * serial per stream): stream s at out + s * out_stride, sizes[s] = bytes or a negative code */
 int     lamehip_batch_pack_all(lamehip_batch *, int nthreads, unsigned char *out, long out_stride, long *sizes);
+/* Bit packing on the device: with this switched on (before lamehip_batch_encode) the kernel also
+ * assembles every stream's MP3 bytes in HBM -- headers, side information, Huffman data, reservoir
+ * back pointers, final padding (reference bitstream.c:format_bitstream / flush_bitstream) -- and
+ * lamehip_batch_get_bytes copies them out; the host packer is not involved.  Same bytes as
+ * lamehip_batch_pack. */
+int     lamehip_batch_set_device_packing(lamehip_batch *, int on);
+long    lamehip_batch_get_bytes(lamehip_batch *, int stream, unsigned char *out, long out_size);
 /* raw payload access for tests: copies frames [0, n) of a stream (LhFrameOut[]) */
 int     lamehip_batch_get_frames(lamehip_batch *, int stream, void *frames_out, int max_frames);
 /* debug aid: raw per-stream carried state (LhStreamState, csrc/lh_device.h) */

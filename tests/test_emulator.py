@@ -19,7 +19,8 @@ EMU_DIR = os.path.join(helpers.ROOT, "tests", "hipemu")
 class LhStreamDesc(C.Structure):
     _fields_ = [("pcm_l", C.c_longlong), ("pcm_r", C.c_longlong), ("pcm_base", C.c_longlong),
                 ("nsamples", C.c_longlong), ("out_index", C.c_longlong), ("frame_begin", C.c_int),
-                ("frame_end", C.c_int)]
+                ("frame_end", C.c_int), ("bytes_base", C.c_longlong), ("bytes_cap", C.c_longlong),
+                ("flush", C.c_int), ("pad", C.c_int)]
 
 
 @pytest.fixture(scope="module")
@@ -78,4 +79,28 @@ def test_kernel_source_frame_per_launch_with_poisoned_lds(name, nframes, emu, or
     for f in range(nframes):
         d = struct_diff(want[f], got[f])
         assert not d, (f, d[:4])
+    enc.close()
+
+
+@pytest.mark.parametrize("name", ["cbr128_js_44k_silence", "cbr320_js_48k_bursts", "vbr4_js_44k_white", "abr150_js_32k_white_q5",
+                                  "mono_vbr2_44k", "testcase_wav_cbr128"])
+def test_device_bit_packer_source_matches_host_packer(name, emu, oracle):
+    """lh_dev_emit.h under the emulator: the bytes the kernel assembles (headers, side information, Huffman
+    data around the headers, stuffing, final padding) equal the host packer's, i.e. the reference's."""
+    g, pcm = helpers.load_golden(name)
+    enc = lamehip.Encoder(require_device=False, **helpers.golden_encoder_kwargs(g))
+    cfg, tab = enc.config(), enc.tables()
+    nframes = int(g["nframes"])
+    n = pcm.shape[1]
+    pool = np.concatenate([pcm[0], pcm[1]]).astype(np.int16)
+    cap = nframes * 1500
+    desc = LhStreamDesc(0, n, 0, n, 0, 0, nframes, 0, cap, 1, 0)
+    state = C.create_string_buffer(enc.lib.lamehip_abi_sizeof(4))
+    enc.lib.lh_state_init(state, C.byref(cfg))
+    got = (LhFrameOut * nframes)()
+    out = C.create_string_buffer(cap)
+    emu.lh_emu_encode_bytes(C.byref(cfg), C.byref(tab), pool.ctypes.data_as(C.c_void_p), C.byref(desc), state, got, out, 1)
+    want = g["mp3"].tobytes()
+    assert out.raw[:len(want)] == want
+    assert out.raw[len(want):len(want) + 64] == bytes(64)
     enc.close()

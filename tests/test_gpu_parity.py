@@ -501,3 +501,46 @@ def test_typed_buffer_entry_points_match_reference(kind, kw):
     ref.refh_close(rh)
     assert mine == theirs and len(mine) > 1000
     enc.close()
+
+
+@pytest.mark.parametrize("name", helpers.golden_names() + helpers.golden_names(vbr=True) + helpers.golden_names(kind="abr")
+                         + helpers.golden_names(kind="mono"))
+def test_device_bit_packer_matches_golden(name):
+    """lamehip_batch_set_device_packing: the kernel assembles the MP3 bytes itself (lh_dev_emit.h); they equal
+    the reference's bytes and the host packer's."""
+    g, pcm = helpers.load_golden(name)
+    enc = _encoder(g)
+    b = lamehip.Batch(enc, 3, pcm.shape[1] + 16)
+    b.set_device_packing()
+    b.set_pcm(0, pcm[0], pcm[1])
+    b.set_pcm(1, pcm[0][:pcm.shape[1] // 3], pcm[1][:pcm.shape[1] // 3])
+    b.set_pcm(2, pcm[0][:1], pcm[1][:1])
+    b.encode()
+    assert b.get_bytes(0) == g["mp3"].tobytes() == b.pack(0)
+    assert b.get_bytes(1) == b.pack(1)
+    assert b.get_bytes(2) == b.pack(2)
+    b.reset()                       # a second run over the same batch starts from clean packer state
+    b.encode()
+    assert b.get_bytes(0) == g["mp3"].tobytes()
+    b.close()
+    enc.close()
+
+
+@pytest.mark.parametrize("kw", [dict(brate=128), dict(vbr_q=2), dict(abr=160, channels=1), dict(brate=32, samplerate=32000,
+                                                                                             out_samplerate=32000)])
+def test_device_bit_packer_long_streams(kw):
+    """30 s streams, many frames of reservoir back pointers; 32 kb/s has the smallest frames (a 511-byte
+    back pointer then spans several headers)."""
+    sr = kw.get("samplerate", 44100)
+    enc = lamehip.Encoder(**kw)
+    n = sr * 30
+    pcms = [helpers.synth_stream(2000 + i, n - 777 * i, sr, 1.0 / (2 + 3 * i), white=(i == 1)) for i in range(3)]
+    b = lamehip.Batch(enc, len(pcms), n)
+    b.set_device_packing()
+    for i, x in enumerate(pcms):
+        b.set_pcm(i, x[0], x[1])
+    b.encode()
+    for i in range(len(pcms)):
+        assert b.get_bytes(i) == b.pack(i)
+    b.close()
+    enc.close()
