@@ -282,7 +282,6 @@ struct LhCtx {
     LhStreamState *st;
     const int16_t *pcm;
     const float *pcmf;
-    uint8_t *bytes;
     LhStreamDesc d;
     long long frame_base;       /* stream sample index of mfbuf[0] for the current frame: 1152 f - 528 */
     int     lane, wave, tid;
@@ -333,7 +332,6 @@ lh_ctx_load(void)
     o.st = LH_AS_GLOBAL(LhStreamState, lh_lds.ctx.st);
     o.pcm = LH_AS_GLOBAL(const int16_t, lh_lds.ctx.pcm);
     o.pcmf = LH_AS_GLOBAL(const float, lh_lds.ctx.pcmf);
-    o.bytes = LH_AS_GLOBAL(uint8_t, lh_lds.ctx.bytes);
     o.d = lh_lds.ctx.d;
     o.frame_base = lh_lds.ctx.frame_base;
     o.tid = (int) threadIdx.x;

@@ -26,6 +26,14 @@
 
 #define LH_EMIT_WORDS 132       /* 4095 bits of one granule/channel + slack */
 
+/* out of line and marked cold: with the packer switched off nothing of it should sit between the
+ * stages of the encode loop */
+#ifdef LH_EMU
+#define LH_COLDFN static
+#else
+#define LH_COLDFN __device__ __attribute__((noinline, cold))
+#endif
+
 /* inclusive prefix sum over the wave */
 LH_DEVFN uint32_t
 lh_wave_scan_u32(uint32_t v)
@@ -326,12 +334,29 @@ lh_emit_pos(long long cursor, long long j, const long long *hq, int nq, int sl)
     return p;
 }
 
+/* out-of-line entry for the quantisation stages: the granule's R / g come through the wave's LDS slot
+ * (keeps the packer's registers and code out of the loops that run when it is switched off) */
+LH_COLDFN void
+lh_emit_part_stage(int qch, int gr)
+{
+    LhCtx const c = lh_ctx_load();
+    LhQR const R = lh_uniform(lh_lds.rg[qch].R);
+    LhGrR const g = lh_uniform(lh_lds.rg[qch].g);
+    int const nb = lh_emit_part(c, lh_lds.u.quant.ch[qch], R, g, lh_lds.xr[qch][lh_uni_i(gr)],
+                                c.st->em_part[lh_uni_i(gr)][qch]);
+    if (nb != g.part2_3_length + g.part2_length && c.lane == 0)
+        c.st->status |= 4;      /* the packed bits disagree with the quantiser's count */
+}
+
 /* One frame's bytes, whole workgroup.  `nbits' = pre + sum of the parts + post (a multiple of 8 by
  * the reservoir's construction); part k of `np' parts has plen[k] bits in st->em_part[...]. */
-LH_DEVFN void
-lh_emit_frame(const LhCtx & c, const LhFrameOut * fo, uint8_t * bytes, int drain_pre, int drain_post, int frame_bytes,
+LH_COLDFN void
+lh_emit_frame(const LhFrameOut * fo_in, int drain_pre, int drain_post, int frame_bytes,
               int mdb, int bitrate_index, int padding, int mode_ext, int flush)
 {
+    LhCtx const c = lh_ctx_load();
+    const LhFrameOut *fo = LH_AS_GLOBAL(const LhFrameOut, fo_in);
+    uint8_t *bytes = LH_AS_GLOBAL(uint8_t, lh_lds.ctx.bytes);
     LhLds & L = lh_lds;
     const LhConfig *cfg = c.cfg;
     LhStreamState *st = c.st;
@@ -342,6 +367,10 @@ lh_emit_frame(const LhCtx & c, const LhFrameOut * fo, uint8_t * bytes, int drain
     long long cursor, hq[16];
     int     nq;
     uint8_t *out = bytes + c.d.bytes_base;
+    drain_pre = lh_uni_i(drain_pre);
+    drain_post = lh_uni_i(drain_post);
+    frame_bytes = lh_uni_i(frame_bytes);
+    flush = lh_uni_i(flush);
 
     LH_SYNC_WG();
     nbits = drain_pre;

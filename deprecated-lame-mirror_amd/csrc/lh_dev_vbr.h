@@ -803,10 +803,9 @@ lh_vbr_granule(int qch, int gr, int rch, int pass, int gate, int target, int sub
         lh_best_huffman_divide_body(c, Q, R, g);
     LH_PA(6, t_f);
     lh_store_granule(c, Q, R, g, xr, LH_AS_GLOBAL(LhGranule, o));
-    if (c.bytes) {
-        int const nb = lh_emit_part(c, Q, R, g, xr, c.st->em_part[gr][qch]);
-        if (nb != g.part2_3_length + g.part2_length && s == 0)
-            c.st->status |= 4;
+    if (lh_uni_i(lh_lds.ctx.bytes != nullptr)) {
+        lh_rg_put(c, R, g);
+        lh_emit_part_stage(qch, gr);
     }
     LH_PA(3, t_q);
     if (s == 0)

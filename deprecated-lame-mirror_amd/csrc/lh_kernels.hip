@@ -407,11 +407,8 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo)
             g = lh_uniform(L.rg[ch].g);
             LH_PA(6, t_fin);
             lh_store_granule(c, Q, R, g, xr, o);
-            if (c.bytes) {
-                int const nb = lh_emit_part(c, Q, R, g, xr, st->em_part[gr][ch]);
-                if (nb != g.part2_3_length + g.part2_length && lane == 0)
-                    st->status |= 4;    /* the packed bits disagree with the quantiser's count */
-            }
+            if (lh_uni_i(L.ctx.bytes != nullptr))
+                lh_emit_part_stage(ch, gr);     /* R / g are in the wave's LDS slot since the last stage call */
             LH_PA(3, t_q);
             if (lane == 0)
                 L.bits_used[ch] = g.part2_3_length + g.part2_length;
@@ -489,8 +486,8 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo)
         if (mdb * 8 != ResvSize)
             st->status |= 1;    /* reservoir inconsistency (reference bitstream.c:947) */
     }
-    if (c.bytes)
-        lh_emit_frame(c, fo, c.bytes, drain_pre, drain_post, frame_bits / 8, mdb_header, bitrate_index, padding, mode_ext,
+    if (lh_uni_i(L.ctx.bytes != nullptr))
+        lh_emit_frame(fo, drain_pre, drain_post, frame_bits / 8, mdb_header, bitrate_index, padding, mode_ext,
                       c.d.flush && (int) ((c.frame_base + LH_MF_START) / 1152) == c.d.frame_end - 1);
     LH_PA(0, t_frame);
     LH_SYNC_WG();
@@ -529,7 +526,6 @@ lh_encode_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, 
     c.st = &states[sidx];
     c.pcm = pcm;
     c.pcmf = pcmf;
-    c.bytes = bytes;
     c.d = descs[sidx];
     c.tid = (int) threadIdx.x;
     c.lane = c.tid & 63;
@@ -541,7 +537,7 @@ lh_encode_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, 
         L.ctx.st = c.st;
         L.ctx.pcm = c.pcm;
         L.ctx.pcmf = c.pcmf;
-        L.ctx.bytes = c.bytes;
+        L.ctx.bytes = bytes;
         L.ctx.d = c.d;
     }
     /* partition start tables (prefix sums of numlines): constant for the launch, kept in LDS */
