@@ -997,6 +997,34 @@ lamehip_batch_get_bytes(lamehip_batch * b, int s, unsigned char *out, long out_s
     return n;
 }
 
+/* all streams: stream s at out + s * out_stride, sizes[s] = bytes or a negative code */
+extern "C" int
+lamehip_batch_get_bytes_all(lamehip_batch * b, unsigned char *out, long out_stride, long *sizes)
+{
+    std::vector < LhStreamState > st;
+    int     bad = 0;
+    if (!b || !b->encoded || !b->dev_pack || !out || !sizes)
+        return -1;
+    st.resize((size_t) b->B);
+    HIPCHK(hipStreamSynchronize(b->stream));
+    HIPCHK(hipMemcpy(st.data(), b->d_state, st.size() * sizeof(LhStreamState), hipMemcpyDeviceToHost));
+    for (int s = 0; s < b->B; s++) {
+        long    n = (b->nframes[(size_t) s] == 0) ? 0 : (long) st[(size_t) s].em_next_header;
+        if (st[(size_t) s].status != 0)
+            n = LAMEHIP_ERR_PAYLOAD;
+        else if (n > out_stride)
+            n = -1;
+        sizes[s] = n;
+        if (n < 0)
+            bad++;
+        else if (n > 0)
+            HIPCHK(hipMemcpyAsync(out + (size_t) s * (size_t) out_stride, b->d_bytes + b->bytes_off[(size_t) s], (size_t) n,
+                                  hipMemcpyDeviceToHost, b->stream));
+    }
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return bad ? -1 : 0;
+}
+
 extern "C" int
 lamehip_batch_sync(lamehip_batch * b)
 {

@@ -195,6 +195,18 @@ class Batch:
             raise RuntimeError("lamehip_batch_get_bytes failed (%d): %s" % (k, last_error()))
         return buf.raw[:k]
 
+    def get_bytes_all(self, stride=None):
+        """(buffer [B, stride] uint8, sizes) of the device-packed streams."""
+        if stride is None:
+            stride = (max(self.frames(s) for s in range(self.n)) + 2) * 1500
+        out = np.empty((self.n, stride), dtype=np.uint8)
+        sizes = np.zeros(self.n, dtype=np.int64)
+        self.lib.lamehip_batch_get_bytes_all.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]
+        rc = self.lib.lamehip_batch_get_bytes_all(self.b, out.ctypes.data, stride, sizes.ctypes.data)
+        if rc:
+            raise RuntimeError("lamehip_batch_get_bytes_all failed (%d): %s" % (rc, last_error()))
+        return out, sizes
+
     def encode(self, sync=True):
         rc = self.lib.lamehip_batch_encode(self.b)
         if rc:

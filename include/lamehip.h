@@ -166,6 +166,7 @@ int     lamehip_batch_pack_all(lamehip_batch *, int nthreads, unsigned char *out
  * lamehip_batch_pack. */
 int     lamehip_batch_set_device_packing(lamehip_batch *, int on);
 long    lamehip_batch_get_bytes(lamehip_batch *, int stream, unsigned char *out, long out_size);
+int     lamehip_batch_get_bytes_all(lamehip_batch *, unsigned char *out, long out_stride, long *sizes);
 /* raw payload access for tests: copies frames [0, n) of a stream (LhFrameOut[]) */
 int     lamehip_batch_get_frames(lamehip_batch *, int stream, void *frames_out, int max_frames);
 /* debug aid: raw per-stream carried state (LhStreamState, csrc/lh_device.h) */
