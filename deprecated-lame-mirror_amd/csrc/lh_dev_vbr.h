@@ -943,14 +943,25 @@ lh_vbr_budgets(int nch, const int max_bits[2][2], const int use_ch[2][2], const 
  * the four granules (wave = channel), the second pass when the frame does not fit, and the
  * choice of the frame's bitrate.  Leaves ResvSize untouched apart from the bits used (the
  * caller finishes the reservoir bookkeeping with the chosen bitrate_index). */
-LH_DEVFN void
-lh_vbr_frame(const LhCtx & c, LhFrameOut * fo, float pe_use[2][2], int mode_ext, int msoff, int &ResvSize,
-             int &substep, int &bitrate_index, int &total_bits)
+/* out of line: the CBR / ABR frame code keeps its registers (the VBR frame logic inlined there cost
+ * the CBR loop spills).  In: pe_use through L.pe_use; out through L.frame_bits (bitrate index),
+ * L.max_bits (bits used), L.mean_bits (ResvSize after the frame's bits), L.targ_bits[0] (substep). */
+LH_STAGEFN void
+lh_vbr_frame(LhFrameOut * fo_in, int mode_ext, int msoff)
 {
+    LhCtx const c = lh_ctx_load();
+    LhFrameOut *fo = LH_AS_GLOBAL(LhFrameOut, fo_in);
     LhLds & L = lh_lds;
     const LhConfig *cfg = c.cfg;
     int const w = c.wave, tid = c.tid;
+    float   pe_use[2][2] = { {lh_uni_f(L.pe_use[0][0]), lh_uni_f(L.pe_use[0][1])},
+    {lh_uni_f(L.pe_use[1][0]), lh_uni_f(L.pe_use[1][1])}
+    };
+    int     ResvSize = lh_uni_i(c.st->ResvSize), substep = lh_uni_i(c.st->substep_shaping);
+    int     bitrate_index, total_bits;
     int const maxi = cfg->vbr_max_bitrate_index;
+    mode_ext = lh_uni_i(mode_ext);
+    msoff = lh_uni_i(msoff);
     int const nch = cfg->channels;
     int     avg, resv_top, top_bits, dummy;
     int     max_bits[2][2], use_ch[2][2], use_gr[2], use_fr, max_fr = 0, bits = 0;
@@ -1051,6 +1062,14 @@ lh_vbr_frame(const LhCtx & c, LhFrameOut * fo, float pe_use[2][2], int mode_ext,
     }
     ResvSize -= used;
     total_bits = used;
+    LH_SYNC_WG();
+    if (tid == 0) {
+        L.frame_bits = bitrate_index;
+        L.max_bits = total_bits;
+        L.mean_bits = ResvSize;
+        L.targ_bits[0] = substep;
+    }
+    LH_SYNC_WG();
 }
 
 /* ---- ABR (reference quantize.c:1768-1884, calc_target_bits): the bit budget of every

@@ -330,7 +330,17 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo)
     int const vbr_new = (cfg->vbr == 1 || cfg->vbr == 4), abr = (cfg->vbr == 3);
     int     abr_targ[2][2] = { {0, 0}, {0, 0} }, analog_silence_bits = 0;
     if (vbr_new) {
-        lh_vbr_frame(c, fo, pe_use, mode_ext, msoff, ResvSize, substep, bitrate_index, total_bits);
+        LH_SYNC_WG();
+        if (tid == 0)
+            for (int gr = 0; gr < 2; gr++)
+                for (int ch = 0; ch < 2; ch++)
+                    L.pe_use[gr][ch] = pe_use[gr][ch];
+        LH_SYNC_WG();
+        lh_vbr_frame(fo, mode_ext, msoff);
+        bitrate_index = lh_uni_i(L.frame_bits);
+        total_bits = lh_uni_i(L.max_bits);
+        ResvSize = lh_uni_i(L.mean_bits);
+        substep = lh_uni_i(L.targ_bits[0]);
         frame_bits = lh_frame_bits(cfg, bitrate_index, 0);
         mean_bits = (frame_bits - cfg->sideinfo_len * 8) / cfg->mode_gr;
     }
