@@ -44,6 +44,7 @@ def main():
         n = int(sr * secs)
         pcms = [tg._stress_signal(seed0 + i, n - 13 * (i % 31), sr) for i in range(B)]
         b = lamehip.Batch(enc, B, n)
+        b.set_device_packing()
         for s, x in enumerate(pcms):
             b.set_pcm(s, x[0], x[1])
         b.encode()
@@ -61,6 +62,10 @@ def main():
                     bad += 1
                     print("MISMATCH", (sr, br, mode, q), "seed", seed0 + s, "frame", f, d[:3], flush=True)
                     break
+            else:
+                if b.get_bytes(s) != b.pack(s):
+                    bad += 1
+                    print("BYTES MISMATCH (device packer)", (sr, br, mode, q), "seed", seed0 + s, flush=True)
         b.close()
         enc.close()
         print("setting", (sr, br, mode, q), "streams", tot, "bad", bad, "%.0fs" % (time.time() - t0), flush=True)

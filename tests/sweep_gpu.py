@@ -52,6 +52,7 @@ def main():
                     n = int(sr * secs)
                     pcms = [tg._stress_signal(abs(br) + q + 8 * i + i, n - 29 * i, sr) for i in range(B)]
                     b = lamehip.Batch(enc, B, n)
+                    b.set_device_packing()      # the device bit packer is checked against the host packer too
                     if nch == 1:
                         pcms = [np.stack([x[0], x[0]]) for x in pcms]
                     for s, x in enumerate(pcms):
@@ -68,6 +69,9 @@ def main():
                                 ok = False
                                 print("MISMATCH", (sr, br, mode, q), "stream", s, "frame", f, d[:3], flush=True)
                                 break
+                        if ok and b.get_bytes(s) != b.pack(s):
+                            ok = False
+                            print("BYTES MISMATCH (device packer)", (sr, br, mode, q), "stream", s, flush=True)
                         bad += (not ok)
                     b.close()
                     enc.close()
