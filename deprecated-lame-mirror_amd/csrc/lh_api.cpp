@@ -997,6 +997,42 @@ lamehip_batch_get_bytes(lamehip_batch * b, int s, unsigned char *out, long out_s
     return n;
 }
 
+/* device-packed stream as a complete file image: the final Xing/Info + LAME tag frame, then the audio
+ * frames.  The tag's bookkeeping (frame count, bitrate table of contents, music CRC, mode extension of
+ * the last frame) is read back from the frame headers of the bytes themselves. */
+extern "C" long
+lamehip_batch_get_bytes_tagged(lamehip_batch * b, int s, unsigned char *out, long out_size)
+{
+    LhVbrTag v;
+    int     total, last_mode_ext = 0;
+    long    k, pos = 0;
+    if (!b || s < 0 || s >= b->B || !b->encoded || !b->dev_pack)
+        return -1;
+    total = lh_tag_init(&v, &b->cfg);
+    if (out_size < total)
+        return -1;
+    k = lamehip_batch_get_bytes(b, s, out + total, out_size - total);
+    if (k < 0 || total == 0)
+        return k;
+    while (pos + 4 <= k) {
+        const unsigned char *h = out + total + pos;
+        int const bi = h[2] >> 4, pad = (h[2] >> 1) & 1;
+        int const kbps = lh_tag_kbps(bi);
+        int const size = (b->cfg.version + 1) * 72000 * kbps / b->cfg.samplerate + pad;
+        if (h[0] != 0xff || (h[1] & 0xe0) != 0xe0 || kbps <= 0 || size <= 0) {
+            snprintf(g_err, sizeof(g_err), "device-packed stream %d: lost frame sync at byte %ld", s, pos);
+            return LAMEHIP_ERR_PAYLOAD;
+        }
+        lh_tag_add_frame(&v, kbps);
+        last_mode_ext = (h[3] >> 4) & 3;
+        pos += size;
+    }
+    lh_tag_crc(&v, out + total, k);
+    if (lh_tag_frame(&v, &b->cfg, b->cfg.vbr_q, lh_end_padding(b->len[(size_t) s]), last_mode_ext, out, total) != total)
+        memset(out, 0, (size_t) total);         /* no frames: the reference leaves the placeholder */
+    return k + total;
+}
+
 /* all streams: stream s at out + s * out_stride, sizes[s] = bytes or a negative code */
 extern "C" int
 lamehip_batch_get_bytes_all(lamehip_batch * b, unsigned char *out, long out_stride, long *sizes)

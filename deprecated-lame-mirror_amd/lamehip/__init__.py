@@ -195,6 +195,16 @@ class Batch:
             raise RuntimeError("lamehip_batch_get_bytes failed (%d): %s" % (k, last_error()))
         return buf.raw[:k]
 
+    def get_bytes_tagged(self, s):
+        self.lib.lamehip_batch_get_bytes_tagged.restype = C.c_long
+        self.lib.lamehip_batch_get_bytes_tagged.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_long]
+        cap = (self.frames(s) + 4) * 1500
+        buf = C.create_string_buffer(cap)
+        k = self.lib.lamehip_batch_get_bytes_tagged(self.b, s, buf, cap)
+        if k < 0:
+            raise RuntimeError("lamehip_batch_get_bytes_tagged failed (%d): %s" % (k, last_error()))
+        return buf.raw[:k]
+
     def get_bytes_all(self, stride=None):
         """(buffer [B, stride] uint8, sizes) of the device-packed streams."""
         if stride is None:

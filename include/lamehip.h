@@ -167,6 +167,8 @@ int     lamehip_batch_pack_all(lamehip_batch *, int nthreads, unsigned char *out
 int     lamehip_batch_set_device_packing(lamehip_batch *, int on);
 long    lamehip_batch_get_bytes(lamehip_batch *, int stream, unsigned char *out, long out_size);
 int     lamehip_batch_get_bytes_all(lamehip_batch *, unsigned char *out, long out_stride, long *sizes);
+/* tag frame + audio frames, like lamehip_batch_pack_tagged, from the device-packed bytes */
+long    lamehip_batch_get_bytes_tagged(lamehip_batch *, int stream, unsigned char *out, long out_size);
 /* raw payload access for tests: copies frames [0, n) of a stream (LhFrameOut[]) */
 int     lamehip_batch_get_frames(lamehip_batch *, int stream, void *frames_out, int max_frames);
 /* debug aid: raw per-stream carried state (LhStreamState, csrc/lh_device.h) */

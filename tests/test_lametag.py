@@ -98,11 +98,13 @@ def test_batch_pack_tagged_is_the_reference_file_image(vq, abr):
     pcms = [helpers.synth_stream(777 + i, int(sr * (0.8 + 0.37 * i)), sr, 1.0 / 4) for i in range(4)]
     enc = lamehip.Encoder(sr, br, vbr_q=vq, abr=abr)
     b = lamehip.Batch(enc, len(pcms), max(x.shape[1] for x in pcms))
+    b.set_device_packing()
     for s, x in enumerate(pcms):
         b.set_pcm(s, x[0], x[1])
     b.encode()
     for s, x in enumerate(pcms):
         stream, tag = helpers.reference_tagged(x, sr, br, vbr_q=vq, abr=abr)
         assert b.pack_tagged(s) == tag + stream[len(tag):]
+        assert b.get_bytes_tagged(s) == tag + stream[len(tag):]     # the same from the device-packed bytes
     b.close()
     enc.close()
