@@ -107,6 +107,9 @@ struct lame_global_struct {
     LhVbrTag tag;
     int     tag_placeholder_pending;
     int     enc_padding;
+    /* input rate != output rate: the transformed samples pass through this first (lh_resample.c) */
+    LhResampler *rs;
+    std::vector < float >tl, tr;
 };
 
 static int
@@ -322,14 +325,10 @@ lame_init_params(lame_t g)
         return -1;
     if (g->inited)
         return 0;
-    if (g->out_samplerate != 0 && g->out_samplerate != g->p.samplerate) {
-        snprintf(g_err, sizeof(g_err), "resampling is outside the accelerated path");
-        return -1;
-    }
     g->p.samplerate_out = g->out_samplerate;
     if (lh_config_resolve(&g->p, &g->cfg, &aux) != 0) {
         snprintf(g_err, sizeof(g_err),
-                 "unsupported settings for the MI355X path (need MPEG-1 rates, 1 or 2 input channels, CBR / ABR / vbr_mtrh, no resampling)");
+                 "unsupported settings for the MI355X path (need an MPEG-1 output rate, 1 or 2 input channels, CBR / ABR / vbr_mtrh)");
         return -1;
     }
     g->tab = (LhTables *) malloc(sizeof(LhTables));
@@ -341,6 +340,12 @@ lame_init_params(lame_t g)
     }
     if (lh_bs_init(&g->bs) != 0)
         return -2;
+    if (lh_rs_needed(g->p.samplerate, g->cfg.samplerate)) {
+        g->rs = (LhResampler *) malloc(sizeof(LhResampler));
+        if (!g->rs)
+            return -2;
+        lh_rs_init(g->rs, g->p.samplerate, g->cfg.samplerate);
+    }
     g->inited = 1;              /* host constants are valid from here on (lamehip_get_*) */
     /* the tag frame is reserved at the head of the stream (reference InitVbrTag); when it does
      * not fit the reference silently switches it off */
@@ -348,6 +353,7 @@ lame_init_params(lame_t g)
         g->tag_placeholder_pending = 1;
     else
         g->write_vbr_tag = 0;
+    g->tag.samplerate_in = g->p.samplerate;
     if (lamehip_device_count() <= 0) {
         snprintf(g_err, sizeof(g_err), "no HIP device: liblamehip has no CPU encode path");
         g->have_device = 0;
@@ -501,17 +507,39 @@ encode_buffer_any(lame_t g, const T * l, const T * r, int nsamples, int jump, fl
         /* pcm_transform: [0] = { pcm_scale, pcm_mix }, [1] = { 0, pcm_scale_r } */
         float const m00 = norm * g->cfg.pcm_scale, m01 = norm * g->cfg.pcm_mix;
         float const m10 = norm * (0.0f * g->cfg.pcm_scale), m11 = norm * g->cfg.pcm_scale_r;
-        size_t const at = g->hl.size();
-        g->hl.resize(at + (size_t) nsamples);
-        g->hr.resize(at + (size_t) nsamples);
+        std::vector < float >&dl = g->rs ? g->tl : g->hl;
+        std::vector < float >&dr = g->rs ? g->tr : g->hr;
+        size_t const at = g->rs ? 0 : g->hl.size();
+        dl.resize(at + (size_t) nsamples);
+        dr.resize(at + (size_t) nsamples);
         for (int i = 0; i < nsamples; i++) {
             float const xl = (float) l[(size_t) i * (size_t) jump];
             float const xr = (float) r[(size_t) i * (size_t) jump];
-            g->hl[at + (size_t) i] = xl * m00 + xr * m01;
-            g->hr[at + (size_t) i] = xl * m10 + xr * m11;
+            dl[at + (size_t) i] = xl * m00 + xr * m01;
+            dr[at + (size_t) i] = xl * m10 + xr * m11;
         }
     }
-    g->fed += nsamples;
+    if (g->rs) {
+        /* the reference's loop (lame.c:1708-1772, fill_buffer util.c:665-697): blocks of at most one
+         * frame of output until the call's input is used up; every output channel sees the same
+         * block boundaries */
+        int     pos = 0, left = nsamples;
+        while (left > 0) {
+            float   blk[2][1152];
+            int     used = 0, made = 0;
+            for (int ch = 0; ch < g->cfg.channels; ch++)
+                made = lh_rs_block(g->rs, ch, blk[ch], 1152, (ch ? g->tr.data() : g->tl.data()) + pos, left, &used);
+            if (g->cfg.channels == 1)
+                memset(blk[1], 0, sizeof(blk[1]));
+            g->hl.insert(g->hl.end(), blk[0], blk[0] + made);
+            g->hr.insert(g->hr.end(), blk[1], blk[1] + made);
+            g->fed += made;
+            pos += used;
+            left -= used;
+        }
+    }
+    else
+        g->fed += nsamples;
     g->flushed = 0;
     /* a frame is encoded whenever 1904 samples are buffered behind the 528-sample
      * lead-in (reference lame.c:1737-1769) */
@@ -602,16 +630,56 @@ lame_encode_buffer_long(lame_t g, const long l[], const long r[], const int nsam
     return encode_buffer_any(g, l, r, nsamples, 1, 1.0f, mp3buf, mp3buf_size);
 }
 
+static int finish_stream(lame_t g, unsigned char *mp3buf, int size, int written);
+
+/* lame_encode_flush with the resampler in the way (reference lame.c:2075-2120): the number of
+ * frames still owed follows from the samples buffered plus the resampler's delay, and zeros are fed
+ * through lame_encode_buffer -- resampler included -- in bunches sized to complete one frame at a
+ * time until those frames have come out */
+static int
+flush_resampled(lame_t g, unsigned char *mp3buf, int size)
+{
+    static const short zeros[1152] = { 0 };
+    double const ratio = g->rs->ratio;
+    /* mf_samples_to_encode - POSTDELAY, with mf_samples_to_encode = ENCDELAY + POSTDELAY + fed - 1152 frames */
+    int     owed = (int) (576 + g->fed - 1152LL * g->frames_done);
+    int     padding, frames_left, written = 0;
+    owed += 16. / ratio;
+    padding = 1152 - (owed % 1152);
+    if (padding < 576)
+        padding += 1152;
+    g->enc_padding = padding;
+    frames_left = (owed + padding) / 1152;
+    while (frames_left > 0) {
+        int const before = g->frames_done;
+        int     bunch = LH_MF_NEEDED - (int) (LH_MF_START + g->fed - 1152LL * g->frames_done);
+        int     k;
+        bunch *= ratio;
+        if (bunch > 1152)
+            bunch = 1152;
+        if (bunch < 1)
+            bunch = 1;
+        k = encode_buffer_any(g, zeros, zeros, bunch, 1, 1.0f, mp3buf + written, size ? size - written : 0);
+        if (k < 0)
+            return k;
+        written += k;
+        frames_left -= (g->frames_done != before) ? 1 : 0;
+    }
+    return finish_stream(g, mp3buf, size, written);
+}
+
 extern "C" int
 lame_encode_flush(lame_t g, unsigned char *mp3buf, int size)
 {
-    int     written = 0, rc, total, k;
+    int     written = 0, rc, total;
     if (!valid(g) || !g->inited)
         return -3;
     if (!g->have_device)
         return LAMEHIP_ERR_NODEVICE;
     if (g->flushed)
         return 0;               /* reference lame.c:2076-2079 */
+    if (g->rs)
+        return flush_resampled(g, mp3buf, size);
     total = lh_total_frames((long) g->fed);
     g->enc_padding = lh_end_padding((long) g->fed);     /* reference lame.c:2088-2091 */
     if (emit_tag_placeholder(g, mp3buf, size, &written))
@@ -619,6 +687,14 @@ lame_encode_flush(lame_t g, unsigned char *mp3buf, int size)
     rc = handle_encode_frames(g, total, mp3buf, size, &written);
     if (rc)
         return rc;
+    return finish_stream(g, mp3buf, size, written);
+}
+
+/* pad the last frame out and hand over the rest of the bytes (reference lame.c:2122-2160) */
+static int
+finish_stream(lame_t g, unsigned char *mp3buf, int size, int written)
+{
+    int     k;
     lh_bs_flush(&g->bs, &g->cfg, g->have_last ? &g->last_frame : nullptr);
     k = lh_bs_copy(&g->bs, mp3buf + written, size ? size - written : 0);
     if (k < 0)
@@ -671,6 +747,7 @@ lame_close(lame_t g)
     if (g->bs.buf)
         lh_bs_free(&g->bs);
     free(g->tab);
+    free(g->rs);
     delete  g;
     return 0;
 }
@@ -779,6 +856,12 @@ extern "C" lamehip_batch *
 lamehip_batch_create(const lame_t proto, int nstreams, long capacity_samples)
 {
     lamehip_batch *b;
+    if (valid(proto) && proto->rs) {
+        /* the converter's output depends on the caller's lame_encode_buffer call pattern; a batch has none */
+        snprintf(g_err, sizeof(g_err), "lamehip_batch_create: input rate %d != output rate %d; resample through the handle API",
+                 proto->p.samplerate, proto->cfg.samplerate);
+        return nullptr;
+    }
     if (!valid(proto) || !proto->inited || !proto->have_device || nstreams <= 0
         || capacity_samples <= 0) {
         snprintf(g_err, sizeof(g_err), "lamehip_batch_create: need an initialised handle on a HIP device");

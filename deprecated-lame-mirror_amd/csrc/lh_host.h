@@ -19,7 +19,7 @@ typedef struct LhUserParams {
     int     quality;             /* -1 = default (3) */
     int     vbr;                 /* 0 = CBR, 1 / 4 = vbr_mt / vbr_mtrh (the same loop in the reference), 3 = ABR */
     int     vbr_q;               /* VBR quality 0..9 (lame_set_VBR_q), default 4 */
-    int     samplerate_out;      /* 0 = let the encoder choose (must come out equal to samplerate) */
+    int     samplerate_out;      /* 0 = let the encoder choose; != samplerate: the input is resampled (lh_resample.c) */
     int     abr_kbps;            /* ABR mean bitrate (lame_set_VBR_mean_bitrate_kbps), default 128 */
     /* frontend-level switches with the reference's defaults (lame.c:2280-2420) */
     int     force_ms, disable_reservoir, error_protection, copyright, original, emphasis, extension;
@@ -38,6 +38,7 @@ typedef struct LhInitAux {
     float   vbr_q_frac;
     float   athaa_sensitivity;
     float   adjust_sfb21_db;     /* exp_nspsytune bits 20..25, reference lame.c:1196-1203 */
+    int     samplerate_in;       /* the caller's rate; LhConfig.samplerate is the output rate */
 } LhInitAux;
 
 void    lh_params_default(LhUserParams * p);
@@ -92,6 +93,7 @@ typedef struct LhVbrTag {
     unsigned num_frames;
     unsigned long bytes_written;
     uint16_t music_crc;
+    int     samplerate_in;       /* source rate for the tag's info byte (lh_tag_init: the output rate) */
 } LhVbrTag;
 
 int     lh_tag_init(LhVbrTag * v, const LhConfig * c);
@@ -102,6 +104,21 @@ int     lh_tag_placeholder(const LhVbrTag * v, const LhConfig * c, unsigned char
 int     lh_tag_frame(const LhVbrTag * v, const LhConfig * c, int vbr_q, int enc_padding, int last_mode_ext,
                      unsigned char *buf, long size);
 int     lh_end_padding(long nsamples);
+
+/* ---- sample rate conversion in front of the encoder (lh_resample.c; reference util.c:483-697) ---- */
+#define LH_RS_MAXPHASES 320     /* BPC, reference util.h */
+typedef struct LhResampler {
+    int     rate_in, rate_out;
+    double  ratio;               /* input samples per output sample */
+    int     phases, taps;
+    double  clock[2];            /* input time of the next block's first sample, per channel */
+    float   history[2][34];      /* the last taps + 1 input samples of the previous blocks */
+    float   bank[2 * LH_RS_MAXPHASES + 1][34];
+} LhResampler;
+
+int     lh_rs_needed(int rate_in, int rate_out);
+void    lh_rs_init(LhResampler * r, int rate_in, int rate_out);
+int     lh_rs_block(LhResampler * r, int ch, float *out, int want, const float *in, int len, int *used);
 
 #ifdef __cplusplus
 }

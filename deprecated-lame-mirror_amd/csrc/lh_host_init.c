@@ -247,23 +247,57 @@ static const LhVbrPreset vbr_mt_map[11] = {
     {1, 25.00, 300.0, 2.8, 2.8, -25.0, 12.0, -27, 0.0025, 0, 0, 3.500, 0, 93.3}
 };
 
-/* output rate the reference would pick for this lowpass (reference lame.c:273-345);
- * MPEG-1 rates only: anything else means "resample", which this path refuses */
+/* output rate the reference picks for a lowpass and an input rate (reference lame.c:273-345):
+ * the MPEG rate that suits the input, lowered as far as the lowpass allows, but never below the
+ * next MPEG rate above the input */
 static int
 suggested_samplerate(int lp, int samplerate_in)
 {
-    int     suggested = (samplerate_in >= 48000) ? 48000 : (samplerate_in >= 44100) ? 44100 : 32000;
+    static const int mpeg_rates[9] = { 48000, 44100, 32000, 24000, 22050, 16000, 12000, 11025, 8000 };
+    /* a lowpass at or below edge[i] moves the suggestion to mpeg_rates[i + 1] */
+    static const int edge[8] = { 15960, 15250, 11220, 9970, 7230, 5420, 4510, 3970 };
+    int     suggested = 44100, i;
+    for (i = 0; i < 9; i++)
+        if (samplerate_in >= mpeg_rates[i]) {
+            suggested = mpeg_rates[i];
+            break;
+        }
     if (lp == -1)
         return suggested;
-    if (lp <= 15960)
-        suggested = 44100;
-    if (lp <= 15250)
-        suggested = 32000;
-    if (lp <= 11220)
-        suggested = 24000;
-    if (samplerate_in < suggested)
-        suggested = samplerate_in;      /* reference keeps a valid rate >= input */
+    for (i = 0; i < 8; i++)
+        if (lp <= edge[i])
+            suggested = mpeg_rates[i + 1];
+    if (samplerate_in < suggested) {
+        /* the smallest MPEG rate that is not below the input */
+        for (i = 8; i >= 0; i--)
+            if (samplerate_in <= mpeg_rates[i])
+                return mpeg_rates[i];
+        return 48000;
+    }
     return suggested;
+}
+
+/* the stream's rate: MPEG-1 only on this path (MPEG-2 / 2.5 frames have one granule) */
+static int
+set_output_rate(LhConfig * c, int rate)
+{
+    switch (rate) {
+    case 44100:
+        c->samplerate_index = 0;
+        break;
+    case 48000:
+        c->samplerate_index = 1;
+        break;
+    case 32000:
+        c->samplerate_index = 2;
+        break;
+    default:
+        return -1;
+    }
+    c->version = 1;
+    c->samplerate = rate;
+    c->mode_gr = 2;
+    return 0;
 }
 
 static void
@@ -344,8 +378,8 @@ config_resolve_vbr(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
             lowpassfreq = p->samplerate / 2;
         samplerate_out = suggested_samplerate(lowpassfreq, p->samplerate);
     }
-    if (samplerate_out != p->samplerate)
-        return -1;              /* the reference would resample: outside this path */
+    if (set_output_rate(c, samplerate_out) != 0)
+        return -1;              /* MPEG-2 / 2.5 output rates are outside this path */
     lowpassfreq = (24000 < lowpassfreq) ? 24000 : lowpassfreq;
     lowpassfreq = (samplerate_out / 2 < lowpassfreq) ? samplerate_out / 2 : lowpassfreq;
     c->lowpassfreq = lowpassfreq;
@@ -511,23 +545,12 @@ config_resolve_inner(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
         return -1;
     if (p->vbr != 0 && p->vbr != 1 && p->vbr != 3 && p->vbr != 4)
         return -1;              /* the old VBR loop (vbr_rh) is outside this path */
-    if (p->samplerate_out != 0 && p->samplerate_out != p->samplerate)
-        return -1;              /* resampling is outside this path */
-    switch (p->samplerate) {
-    case 44100:
-        c->samplerate_index = 0;
-        break;
-    case 48000:
-        c->samplerate_index = 1;
-        break;
-    case 32000:
-        c->samplerate_index = 2;
-        break;
-    default:
-        return -1;              /* MPEG-2/2.5 rates and resampling are outside this path */
-    }
+    if (p->samplerate <= 0)
+        return -1;
+    /* the output rate follows from the lowpass below when the caller left it open; the input rate
+     * only matters to that choice and to the resampler (lh_resample.c) */
+    aux->samplerate_in = p->samplerate;
     c->version = 1;
-    c->samplerate = p->samplerate;
     c->mode_gr = 2;
     c->vbr = p->vbr;
     c->mode = (p->mode < 0) ? LH_MODE_JOINT_STEREO : p->mode;
@@ -563,7 +586,6 @@ config_resolve_inner(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
         c->vbr_avg_bitrate_kbps = mean < 32 ? 32 : mean;
         c->vbr_min_bitrate_index = 1;
         c->vbr_max_bitrate_index = 14;
-        c->compression_ratio = c->samplerate * 16 * c->channels / (1.e3 * c->vbr_avg_bitrate_kbps);
     }
     else {
         /* bitrate (reference lame.c:904-915) */
@@ -572,7 +594,6 @@ config_resolve_inner(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
             if (lh_bitrate_mpeg1[r] == c->avg_bitrate)
                 c->bitrate_index = r;
         c->vbr_avg_bitrate_kbps = c->avg_bitrate;       /* lame_set_VBR_mean_bitrate_kbps(brate), lame.c:1043 */
-        c->compression_ratio = c->samplerate * 16 * c->channels / (1.e3 * c->avg_bitrate);
     }
     if (c->bitrate_index <= 0)
         return -1;
@@ -584,16 +605,21 @@ config_resolve_inner(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
         if (c->mode == LH_MODE_MONO)
             lowpass *= 1.5;     /* reference lame.c:758-759 */
         lp = (p->lowpassfreq != 0) ? p->lowpassfreq : (int) lowpass;   /* lame_set_lowpassfreq: Hz, -1 = none */
-        /* the reference would pick a lower output rate and resample for this
-         * lowpass (optimum_samplefreq, reference lame.c:273-345); resampling is
-         * outside this path, so such settings are refused */
-        if (p->samplerate_out == 0) {
-            /* only consulted when the caller left the output rate open (reference lame.c:762-767) */
-            if (2 * lp > c->samplerate)
-                lp = c->samplerate / 2;
-            if (suggested_samplerate(lp, c->samplerate) != c->samplerate)
-                return -1;
+        /* an output rate the caller left open follows from the lowpass (optimum_samplefreq,
+         * reference lame.c:273-345, 762-767); when it differs from the input rate the input is
+         * resampled in front of the encoder */
+        {
+            int     out = p->samplerate_out;
+            if (out == 0) {
+                if (2 * lp > p->samplerate)
+                    lp = p->samplerate / 2;
+                out = suggested_samplerate(lp, p->samplerate);
+            }
+            if (set_output_rate(c, out) != 0)
+                return -1;      /* MPEG-2 / 2.5 output rates are outside this path */
         }
+        c->compression_ratio = c->samplerate * 16 * c->channels
+            / (1.e3 * (c->vbr == 3 ? c->vbr_avg_bitrate_kbps : c->avg_bitrate));
         if (lp > 20500)
             lp = 20500;
         if (lp > c->samplerate / 2)

@@ -78,6 +78,7 @@ lh_tag_init(LhVbrTag * v, const LhConfig * c)
     v->want = 1;
     v->size = LH_TAG_BAG;
     v->enabled = 1;
+    v->samplerate_in = c->samplerate;
     return total;
 }
 
@@ -220,18 +221,18 @@ lh_tag_frame(const LhVbrTag * v, const LhConfig * c, int vbr_q, int enc_padding,
         default:
             stereo_mode = 7;
         }
-        if (c->samplerate <= 32000)
+        if (v->samplerate_in <= 32000)
             source_freq = 0;
-        else if (c->samplerate == 48000)
+        else if (v->samplerate_in == 48000)
             source_freq = 2;
-        else if (c->samplerate > 48000)
+        else if (v->samplerate_in > 48000)
             source_freq = 3;
         else
             source_freq = 1;
         /* short_blocks: 2 = dispensed, 3 = forced (lame.h short_block_t) */
         /* (the reference's "-k" test needs lowpass and highpass both at -1; the highpass never is) */
         if (c->short_blocks == 3 || c->short_blocks == 2
-            || (c->disable_reservoir && c->avg_bitrate < 320) || ath_type == 0 || c->samplerate <= 32000)
+            || (c->disable_reservoir && c->avg_bitrate < 320) || ath_type == 0 || v->samplerate_in <= 32000)
             non_optimal = 1;
         put_i4(p + k, (uint32_t) quality);
         k += 4;

@@ -65,7 +65,7 @@ extern "C" {
 /* resolved per-stream constants (subset of SessionConfig_t)           */
 typedef struct LhConfig {
     int     version;              /* 1 = MPEG-1 */
-    int     samplerate;           /* in == out, no resampling on this path */
+    int     samplerate;           /* of the stream (output rate); another input rate is converted on the host first */
     int     samplerate_index;
     int     bitrate_index;
     int     avg_bitrate;          /* kbps */

@@ -8,3 +8,4 @@
 #include "orc_vbr.c"
 #include "orc_abr.c"
 #include "orc_frame.c"
+#include "orc_resample.c"

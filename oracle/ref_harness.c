@@ -84,6 +84,7 @@ apply_options(lame_global_flags * gfp)
         else if (!strcmp(n, "allow_diff_short")) lame_set_allow_diff_short(gfp, (int) v);
         else if (!strcmp(n, "no_short_blocks")) lame_set_no_short_blocks(gfp, (int) v);
         else if (!strcmp(n, "force_short_blocks")) lame_set_force_short_blocks(gfp, (int) v);
+        else if (!strcmp(n, "out_samplerate")) lame_set_out_samplerate(gfp, (int) v);
     }
 }
 
