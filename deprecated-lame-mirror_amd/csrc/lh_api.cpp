@@ -839,7 +839,20 @@ struct lamehip_batch {
     hipEvent_t ev0, ev1;
     float   last_ms;
     int     encoded;
+    /* input rate != output rate: set_pcm converts on the host (as the reference's frontend would have
+     * it: lame_encode_buffer calls of 1152 input samples, then the flush) into a float pool */
+    int     rate_in;
+    LhResampler *rs;
+    float  *d_pcmf;             /* [B][2][capf] */
+    long    capf;
+    std::vector < int >padding; /* encoder_padding per stream (tag frame) */
 };
+
+static int
+batch_padding(const lamehip_batch * b, int s)
+{
+    return b->rate_in ? b->padding[(size_t) s] : lh_end_padding(b->len[(size_t) s]);
+}
 
 static int
 batch_reset_states(lamehip_batch * b)
@@ -856,12 +869,6 @@ extern "C" lamehip_batch *
 lamehip_batch_create(const lame_t proto, int nstreams, long capacity_samples)
 {
     lamehip_batch *b;
-    if (valid(proto) && proto->rs) {
-        /* the converter's output depends on the caller's lame_encode_buffer call pattern; a batch has none */
-        snprintf(g_err, sizeof(g_err), "lamehip_batch_create: input rate %d != output rate %d; resample through the handle API",
-                 proto->p.samplerate, proto->cfg.samplerate);
-        return nullptr;
-    }
     if (!valid(proto) || !proto->inited || !proto->have_device || nstreams <= 0
         || capacity_samples <= 0) {
         snprintf(g_err, sizeof(g_err), "lamehip_batch_create: need an initialised handle on a HIP device");
@@ -890,6 +897,23 @@ lamehip_batch_create(const lame_t proto, int nstreams, long capacity_samples)
     b->d_bytes = nullptr;
     b->bytes_cap = 0;
     b->bytes_off.assign((size_t) nstreams, 0);
+    b->rate_in = 0;
+    b->rs = nullptr;
+    b->d_pcmf = nullptr;
+    b->capf = 0;
+    b->padding.assign((size_t) nstreams, 0);
+    if (proto->rs) {
+        /* the s16 pool shrinks to nothing, the converted signal (plus the flush's tail) lives in a float pool */
+        b->rate_in = proto->p.samplerate;
+        b->rs = (LhResampler *) malloc(sizeof(LhResampler));
+        b->capf = (long) ((double) capacity_samples / proto->rs->ratio) + 4 * 1152 + 64;
+        capacity_samples = 1;
+        if (!b->rs || hipMalloc((void **) &b->d_pcmf, (size_t) nstreams * 2 * (size_t) b->capf * sizeof(float)) != hipSuccess) {
+            snprintf(g_err, sizeof(g_err), "lamehip_batch_create: device allocation failed");
+            lamehip_batch_destroy(b);
+            return nullptr;
+        }
+    }
     if (b->dc.upload(b->cfg, *b->tab) != 0
         || hipMalloc((void **) &b->d_pcm, (size_t) nstreams * 2 * (size_t) capacity_samples * 2) != hipSuccess
         || hipMalloc((void **) &b->d_state, (size_t) nstreams * sizeof(LhStreamState)) != hipSuccess
@@ -920,6 +944,9 @@ lamehip_batch_destroy(lamehip_batch * b)
         (void) hipFree(b->d_out);
     if (b->d_bytes)
         (void) hipFree(b->d_bytes);
+    if (b->d_pcmf)
+        (void) hipFree(b->d_pcmf);
+    free(b->rs);
     if (b->stream)
         (void) hipStreamDestroy(b->stream);
     if (b->ev0)
@@ -934,16 +961,100 @@ lamehip_batch_destroy(lamehip_batch * b)
 extern "C" int
 lamehip_batch_set_length(lamehip_batch * b, int s, long n)
 {
-    if (!b || s < 0 || s >= b->B || n < 0 || n > b->cap)
-        return -1;
+    if (!b || s < 0 || s >= b->B || n < 0 || n > b->cap || b->rate_in)
+        return -1;              /* (a converting batch needs the samples themselves: lamehip_batch_set_pcm) */
     b->len[(size_t) s] = n;
     b->nframes[(size_t) s] = lh_total_frames(n);
+    return 0;
+}
+
+/* A stream of a converting batch: what the reference makes of it when its frontend feeds
+ * lame_encode_buffer 1152 input samples at a time and then flushes (lame.c:1708-1772, 2075-2120;
+ * the same bookkeeping as the handle path above, without a device in the loop). */
+static int
+batch_convert_stream(lamehip_batch * b, int s, const short *l, const short *r, long n)
+{
+    std::vector < float >ol, orr;
+    float   il[1152], ir[1152], blk[2][1152];
+    double const ratio = (double) b->rate_in / (double) b->cfg.samplerate;
+    long    fed = 0, mf_size = LH_MF_START;
+    int     frames = 0, owed, padding, frames_left;
+    float const m00 = b->cfg.pcm_scale, m01 = b->cfg.pcm_mix, m10 = 0.0f * b->cfg.pcm_scale, m11 = b->cfg.pcm_scale_r;
+    auto    feed =[&](int m) {
+        int     at = 0;
+        while (m > 0) {
+            int     used = 0, made = 0;
+            for (int ch = 0; ch < b->cfg.channels; ch++)
+                made = lh_rs_block(b->rs, ch, blk[ch], 1152, (ch ? ir : il) + at, m, &used);
+            if (b->cfg.channels == 1)
+                memset(blk[1], 0, sizeof(blk[1]));
+            ol.insert(ol.end(), blk[0], blk[0] + made);
+            orr.insert(orr.end(), blk[1], blk[1] + made);
+            fed += made;
+            mf_size += made;
+            if (mf_size >= LH_MF_NEEDED) {
+                frames++;
+                mf_size -= 1152;
+            }
+            at += used;
+            m -= used;
+        }
+    };
+    lh_rs_init(b->rs, b->rate_in, b->cfg.samplerate);
+    ol.reserve((size_t) ((double) n / ratio) + 4096);
+    orr.reserve((size_t) ((double) n / ratio) + 4096);
+    for (long pos = 0; pos < n; pos += 1152) {
+        int const m = (n - pos) > 1152 ? 1152 : (int) (n - pos);
+        for (int i = 0; i < m; i++) {
+            float const xl = (float) l[pos + i], xr = (float) r[pos + i];
+            il[i] = xl * m00 + xr * m01;
+            ir[i] = xl * m10 + xr * m11;
+        }
+        feed(m);
+    }
+    owed = (int) (576 + fed - 1152L * frames);
+    owed += 16. / ratio;
+    padding = 1152 - (owed % 1152);
+    if (padding < 576)
+        padding += 1152;
+    frames_left = (owed + padding) / 1152;
+    memset(il, 0, sizeof(il));
+    memset(ir, 0, sizeof(ir));
+    while (frames_left > 0) {
+        int const before = frames;
+        int     bunch = (int) (LH_MF_NEEDED - mf_size);
+        bunch *= ratio;
+        if (bunch > 1152)
+            bunch = 1152;
+        if (bunch < 1)
+            bunch = 1;
+        feed(bunch);
+        frames_left -= (frames != before) ? 1 : 0;
+    }
+    if ((long) ol.size() > b->capf) {
+        snprintf(g_err, sizeof(g_err), "lamehip_batch_set_pcm: converted stream (%ld samples) exceeds the pool", (long) ol.size());
+        return -1;
+    }
+    b->len[(size_t) s] = (long) ol.size();
+    b->nframes[(size_t) s] = frames;
+    b->padding[(size_t) s] = padding;
+    if (!ol.empty()) {
+        HIPCHK(hipMemcpy(b->d_pcmf + ((size_t) s * 2) * (size_t) b->capf, ol.data(), ol.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(b->d_pcmf + ((size_t) s * 2 + 1) * (size_t) b->capf, orr.data(), orr.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     return 0;
 }
 
 extern "C" int
 lamehip_batch_set_pcm(lamehip_batch * b, int s, const short *l, const short *r, long n)
 {
+    if (b && b->rate_in) {
+        if (s < 0 || s >= b->B || n < 0)
+            return -1;
+        if (b->cfg.channels == 1 && b->cfg.pcm_mix == 0.0f)
+            r = l;
+        return batch_convert_stream(b, s, l, r, n);
+    }
     if (lamehip_batch_set_length(b, s, n) != 0)
         return -1;
     if (b->cfg.channels == 1 && b->cfg.pcm_mix == 0.0f)
@@ -968,7 +1079,7 @@ lamehip_batch_set_pcm_device(lamehip_batch * b, int s, const void *dl, const voi
 extern "C" void *
 lamehip_batch_pcm_device_ptr(lamehip_batch * b)
 {
-    return b ? (void *) b->d_pcm : nullptr;
+    return (b && !b->rate_in) ? (void *) b->d_pcm : nullptr;
 }
 
 extern "C" int
@@ -1002,8 +1113,8 @@ lamehip_batch_encode(lamehip_batch * b)
     for (int s = 0; s < b->B; s++) {
         LhStreamDesc & d = b->h_desc[(size_t) s];
         b->out_off[(size_t) s] = total;
-        d.pcm_l = ((long long) s * 2) * b->cap;
-        d.pcm_r = ((long long) s * 2 + 1) * b->cap;
+        d.pcm_l = ((long long) s * 2) * (b->rate_in ? b->capf : b->cap);
+        d.pcm_r = ((long long) s * 2 + 1) * (b->rate_in ? b->capf : b->cap);
         d.pcm_base = 0;
         d.nsamples = b->len[(size_t) s];
         d.out_index = total;
@@ -1034,7 +1145,8 @@ lamehip_batch_encode(lamehip_batch * b)
                           hipMemcpyHostToDevice, b->stream));
     HIPCHK(hipEventRecord(b->ev0, b->stream));
     {
-        int     rc = lh_launch_encode(b->dc.d_cfg, b->dc.d_tab, b->d_pcm, (const float *) 0, b->d_desc, b->d_state,
+        int     rc = lh_launch_encode(b->dc.d_cfg, b->dc.d_tab, b->rate_in ? (const int16_t *) 0 : b->d_pcm,
+                                      b->rate_in ? b->d_pcmf : (const float *) 0, b->d_desc, b->d_state,
                                       b->d_out, b->dev_pack ? b->d_bytes : (uint8_t *) 0, b->B, (void *) b->stream);
         if (rc)
             return set_err("kernel launch", (hipError_t) rc);
@@ -1092,6 +1204,8 @@ lamehip_batch_get_bytes_tagged(lamehip_batch * b, int s, unsigned char *out, lon
     if (!b || s < 0 || s >= b->B || !b->encoded || !b->dev_pack)
         return -1;
     total = lh_tag_init(&v, &b->cfg);
+    if (b->rate_in)
+        v.samplerate_in = b->rate_in;
     if (out_size < total)
         return -1;
     k = lamehip_batch_get_bytes(b, s, out + total, out_size - total);
@@ -1111,7 +1225,7 @@ lamehip_batch_get_bytes_tagged(lamehip_batch * b, int s, unsigned char *out, lon
         pos += size;
     }
     lh_tag_crc(&v, out + total, k);
-    if (lh_tag_frame(&v, &b->cfg, b->cfg.vbr_q, lh_end_padding(b->len[(size_t) s]), last_mode_ext, out, total) != total)
+    if (lh_tag_frame(&v, &b->cfg, b->cfg.vbr_q, batch_padding(b, s), last_mode_ext, out, total) != total)
         memset(out, 0, (size_t) total);         /* no frames: the reference leaves the placeholder */
     return k + total;
 }
@@ -1276,6 +1390,8 @@ lamehip_batch_pack_tagged(lamehip_batch * b, int s, unsigned char *out, long out
     if (!b || s < 0 || s >= b->B || !b->encoded)
         return -1;
     total = lh_tag_init(&v, &b->cfg);
+    if (b->rate_in)
+        v.samplerate_in = b->rate_in;
     if (out_size < total)
         return -1;
     n = b->nframes[(size_t) s];
@@ -1288,7 +1404,7 @@ lamehip_batch_pack_tagged(lamehip_batch * b, int s, unsigned char *out, long out
     for (int i = 0; i < n; i++)
         lh_tag_add_frame(&v, lh_tag_kbps(fr[(size_t) i].bitrate_index));
     lh_tag_crc(&v, out + total, k);
-    if (lh_tag_frame(&v, &b->cfg, b->cfg.vbr_q, lh_end_padding(b->len[(size_t) s]), n > 0 ? fr[(size_t) n - 1].mode_ext : 0,
+    if (lh_tag_frame(&v, &b->cfg, b->cfg.vbr_q, batch_padding(b, s), n > 0 ? fr[(size_t) n - 1].mode_ext : 0,
                      out, total) != total)
         memset(out, 0, (size_t) total);         /* no frames: the reference leaves the placeholder */
     return k + total;

@@ -138,7 +138,10 @@ typedef struct lamehip_batch lamehip_batch;
  * passed lame_init_params); capacity = samples per channel per stream. */
 lamehip_batch *lamehip_batch_create(const lame_t proto, int nstreams, long capacity_samples);
 void    lamehip_batch_destroy(lamehip_batch *);
-/* copy one stream's planar s16 PCM host -> HBM (H2D, synchronous) */
+/* copy one stream's planar s16 PCM host -> HBM (H2D, synchronous).  When proto's input rate differs from
+ * its output rate the stream is converted on the host first, exactly as the reference converts it when
+ * lame_encode_buffer is fed 1152 input samples per call (util.c:520-697; capacity then counts input
+ * samples, and the _device variants below are refused) */
 int     lamehip_batch_set_pcm(lamehip_batch *, int stream, const short *l, const short *r, long nsamples);
 /* same, from planar s16 buffers that already live in HBM (D2D) */
 int     lamehip_batch_set_pcm_device(lamehip_batch *, int stream, const void *dev_l, const void *dev_r, long nsamples);

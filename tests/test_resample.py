@@ -160,13 +160,27 @@ def test_host_converter_equals_oracle_block_by_block(rate_in, rate_out, oracle):
         pos += at
 
 
-def test_batch_refuses_a_resampling_prototype():
-    """the converter's output depends on the caller's call pattern; lamehip_batch_create says so instead of guessing"""
-    enc = open_product(48000, dict(brate=128), 44100, require_device=False)
-    if enc.rc != 0:
-        pytest.skip("no device: batch creation is refused anyway")
-    with pytest.raises(Exception):
-        lamehip.Batch(enc, 1, 1000)
+@pytest.mark.gpu
+@pytest.mark.parametrize("rate_in,kw,out,rate_out", CASES, ids=IDS)
+def test_resampled_batch_matches_reference_frontend_pattern(rate_in, kw, out, rate_out, reference):
+    """A batch converts each stream the way the reference does when its frontend feeds it 1152 input samples per
+    call: host packer and device packer both give the reference's bytes, streams of different lengths."""
+    lens = [int(rate_in * 1.2), 5000, 1, int(rate_in * 0.5) + 13]
+    pcms = [helpers.synth_stream(7200 + i, n, rate_in, 1.0 / 9) for i, n in enumerate(lens)]
+    enc = open_product(rate_in, kw, out, require_device=True)
+    b = lamehip.Batch(enc, len(pcms), max(lens))
+    b.set_device_packing()
+    for s, x in enumerate(pcms):
+        b.set_pcm(s, x[0], x[1])
+    b.encode()
+    for s, x in enumerate(pcms):
+        h = open_reference(reference, rate_in, kw, out)
+        calls, tail = reference_calls(reference, h, x, [1152])
+        reference.lib.refh_close(h)
+        want = b"".join(c[2] for c in calls) + tail
+        assert b.pack(s) == want, "stream %d" % s
+        assert b.get_bytes(s) == want, "stream %d (device packer)" % s
+    b.close()
     enc.close()
 
 
@@ -207,4 +221,11 @@ def test_resampled_tag_frame_matches_reference(reference):
     got += enc.flush()
     assert got == stream
     assert enc.lametag_frame() == tag
+    b = lamehip.Batch(enc, 1, pcm.shape[1])
+    b.set_device_packing()
+    b.set_pcm(0, pcm[0], pcm[1])
+    b.encode()
+    assert b.pack_tagged(0) == tag + stream[len(tag):]
+    assert b.get_bytes_tagged(0) == tag + stream[len(tag):]
+    b.close()
     enc.close()
