@@ -219,8 +219,42 @@ lame_set_VBR_q(lame_t g, int q)
         q = 9;
     }
     g->p.vbr_q = q;
+    g->p.vbr_q_frac = 0;
     return ret;
 }
+
+/* -V n.f (reference set_get.c:1155-1175) */
+extern "C" int
+lame_set_VBR_quality(lame_t g, float q)
+{
+    int     ret = 0;
+    if (!valid(g))
+        return -1;
+    if (0 > q) {
+        ret = -1;
+        q = 0;
+    }
+    if (9.999 < q) {
+        ret = -1;
+        q = 9.999;
+    }
+    g->p.vbr_q = (int) q;
+    g->p.vbr_q_frac = q - g->p.vbr_q;
+    return ret;
+}
+
+extern "C" float
+lame_get_VBR_quality(const lame_t g)
+{
+    return valid(g) ? g->p.vbr_q + g->p.vbr_q_frac : 0;
+}
+
+SETTER(lame_set_VBR_min_bitrate_kbps, p.vbr_min_kbps, int)
+GETTER(lame_get_VBR_min_bitrate_kbps, g->inited && g->cfg.vbr ? lh_tag_kbps(g->cfg.vbr_min_bitrate_index) : g->p.vbr_min_kbps, int)
+SETTER(lame_set_VBR_max_bitrate_kbps, p.vbr_max_kbps, int)
+GETTER(lame_get_VBR_max_bitrate_kbps, g->inited && g->cfg.vbr ? lh_tag_kbps(g->cfg.vbr_max_bitrate_index) : g->p.vbr_max_kbps, int)
+SETTER(lame_set_VBR_hard_min, p.vbr_hard_min, int)
+GETTER(lame_get_VBR_hard_min, g->p.vbr_hard_min, int)
 
 GETTER(lame_get_VBR_q, g->inited ? g->cfg.vbr_q : g->p.vbr_q, int)
 SETTER(lame_set_force_ms, p.force_ms, int)

@@ -28,6 +28,8 @@ typedef struct LhUserParams {
     int     lowpassfreq;         /* 0 = by bitrate / quality, -1 = none, else Hz */
     int     lowpasswidth;        /* -1 = default */
     float   scale, scale_left, scale_right;
+    float   vbr_q_frac;          /* lame_set_VBR_quality: the fractional part of -V n.f */
+    int     vbr_min_kbps, vbr_max_kbps, vbr_hard_min;   /* -b / -B / -F with VBR or ABR; 0 = not set */
 } LhUserParams;
 
 /* values that only feed table generation */

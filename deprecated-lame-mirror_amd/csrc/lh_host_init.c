@@ -320,6 +320,29 @@ lowpass_edges(LhConfig * c, LhInitAux * aux, int width)
     }
 }
 
+/* smallest / largest frame size VBR and ABR may pick (-b / -B / -F; reference lame.c:1064-1085) */
+static int
+vbr_bitrate_limits(const LhUserParams * p, LhConfig * c)
+{
+    int     r;
+    c->vbr_min_bitrate_index = 1;
+    c->vbr_max_bitrate_index = 14;
+    if (p->vbr_min_kbps) {
+        int const k = find_nearest_bitrate_mpeg1(p->vbr_min_kbps);
+        for (r = 1; r <= 14; r++)
+            if (lh_bitrate_mpeg1[r] == k)
+                c->vbr_min_bitrate_index = r;
+    }
+    if (p->vbr_max_kbps) {
+        int const k = find_nearest_bitrate_mpeg1(p->vbr_max_kbps);
+        for (r = 1; r <= 14; r++)
+            if (lh_bitrate_mpeg1[r] == k)
+                c->vbr_max_bitrate_index = r;
+    }
+    c->enforce_min_bitrate = p->vbr_hard_min;
+    return 0;
+}
+
 /* vbr_mt / vbr_mtrh settings (reference lame.c:661-692, 730-744, 770-776, 972-1004, 1064-1094;
  * presets.c:146-213 apply_vbr_preset with every option still at its default) */
 static int
@@ -327,7 +350,7 @@ config_resolve_vbr(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
 {
     static const int lp_by_q[11] = { 24000, 19500, 18500, 18000, 17500, 17000, 16500, 15600, 15200, 7230, 3950 };
     int     vbr_q = p->vbr_q, samplerate_out = p->samplerate_out, lowpassfreq = p->lowpassfreq, i;
-    float   vbr_q_frac = 0;
+    float   vbr_q_frac = p->vbr_q_frac;
     LhVbrPreset P, Q;
     float   x;
     int     nspsytune = 1;
@@ -462,9 +485,8 @@ config_resolve_vbr(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
     c->vbr_q = vbr_q;
     aux->vbr_q = vbr_q;
     aux->vbr_q_frac = vbr_q_frac;
-    c->vbr_min_bitrate_index = 1;
-    c->vbr_max_bitrate_index = 14;
-    c->enforce_min_bitrate = 0;
+    if (vbr_bitrate_limits(p, c) != 0)
+        return -1;
     {
         /* reference lame.c:828-836 */
         static const float cmp[10] = { 5.7, 6.5, 7.3, 8.2, 10, 11.9, 13, 14, 15, 16.5 };
@@ -537,7 +559,7 @@ config_resolve_inner(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
 {
     int     r;
     float   scale, ath_lower_db, maskingadjust, maskingadjust_short;
-    int     noise_shaping = 0;
+    int     noise_shaping = 0, ratio_kbps = 128;
 
     memset(c, 0, sizeof(*c));
     memset(aux, 0, sizeof(*aux));
@@ -584,8 +606,14 @@ config_resolve_inner(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
         c->avg_bitrate = mean;
         c->bitrate_index = 1;
         c->vbr_avg_bitrate_kbps = mean < 32 ? 32 : mean;
-        c->vbr_min_bitrate_index = 1;
-        c->vbr_max_bitrate_index = 14;
+        ratio_kbps = c->vbr_avg_bitrate_kbps;
+        if (vbr_bitrate_limits(p, c) != 0)
+            return -1;
+        /* the mean stays inside the limits (reference lame.c:1086-1091; after compression_ratio was formed) */
+        if (c->vbr_avg_bitrate_kbps > lh_bitrate_mpeg1[c->vbr_max_bitrate_index])
+            c->vbr_avg_bitrate_kbps = lh_bitrate_mpeg1[c->vbr_max_bitrate_index];
+        if (c->vbr_avg_bitrate_kbps < lh_bitrate_mpeg1[c->vbr_min_bitrate_index])
+            c->vbr_avg_bitrate_kbps = lh_bitrate_mpeg1[c->vbr_min_bitrate_index];
     }
     else {
         /* bitrate (reference lame.c:904-915) */
@@ -594,6 +622,7 @@ config_resolve_inner(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
             if (lh_bitrate_mpeg1[r] == c->avg_bitrate)
                 c->bitrate_index = r;
         c->vbr_avg_bitrate_kbps = c->avg_bitrate;       /* lame_set_VBR_mean_bitrate_kbps(brate), lame.c:1043 */
+        ratio_kbps = c->avg_bitrate;
     }
     if (c->bitrate_index <= 0)
         return -1;
@@ -618,8 +647,7 @@ config_resolve_inner(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
             if (set_output_rate(c, out) != 0)
                 return -1;      /* MPEG-2 / 2.5 output rates are outside this path */
         }
-        c->compression_ratio = c->samplerate * 16 * c->channels
-            / (1.e3 * (c->vbr == 3 ? c->vbr_avg_bitrate_kbps : c->avg_bitrate));
+        c->compression_ratio = c->samplerate * 16 * c->channels / (1.e3 * ratio_kbps);
         if (lp > 20500)
             lp = 20500;
         if (lp > c->samplerate / 2)

@@ -60,6 +60,14 @@ int     lame_set_VBR(lame_t, vbr_mode);                              /* lame.h:4
 vbr_mode lame_get_VBR(const lame_t);                                 /* lame.h:433 */
 int     lame_set_VBR_q(lame_t, int);                                 /* lame.h:436 (0 best .. 9; default 4) */
 int     lame_get_VBR_q(const lame_t);                                /* lame.h:437 */
+int     lame_set_VBR_quality(lame_t, float);              /* -V n.f, lame.h:393 */
+float   lame_get_VBR_quality(const lame_t);
+int     lame_set_VBR_min_bitrate_kbps(lame_t, int);       /* -b with VBR / ABR, lame.h:403 */
+int     lame_get_VBR_min_bitrate_kbps(const lame_t);
+int     lame_set_VBR_max_bitrate_kbps(lame_t, int);       /* -B, lame.h:406 */
+int     lame_get_VBR_max_bitrate_kbps(const lame_t);
+int     lame_set_VBR_hard_min(lame_t, int);               /* -F: the minimum also holds for digital silence, lame.h:413 */
+int     lame_get_VBR_hard_min(const lame_t);
 int     lame_set_VBR_mean_bitrate_kbps(lame_t, int);                 /* lame.h:444 (ABR mean, with lame_set_VBR(vbr_abr)) */
 int     lame_get_VBR_mean_bitrate_kbps(const lame_t);                /* lame.h:445 */
 int     lame_set_bWriteVbrTag(lame_t, int);                          /* lame.h:240 (default 1, as in the reference) */

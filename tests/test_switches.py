@@ -23,6 +23,11 @@ CASES = [
     (dict(abr=128), {"scale_left": 0.5, "scale_right": 1.2}),
     (dict(brate=128), {"no_short_blocks": 1}), (dict(vbr_q=2), {"force_short_blocks": 1}),
     (dict(brate=160), {"allow_diff_short": 1}),
+    (dict(vbr_q=2), {"VBR_min_bitrate_kbps": 96}), (dict(vbr_q=4), {"VBR_max_bitrate_kbps": 160}),
+    (dict(vbr_q=5), {"VBR_min_bitrate_kbps": 128, "VBR_hard_min": 1}),
+    (dict(abr=128), {"VBR_min_bitrate_kbps": 64, "VBR_max_bitrate_kbps": 192}),
+    (dict(abr=250), {"VBR_max_bitrate_kbps": 224}),
+    (dict(vbr_q=2), {"VBR_quality": 2.5}), (dict(vbr_q=0), {"VBR_quality": 5.31}),
 ]
 IDS = ["%s-%s" % ("_".join("%s%s" % kv for kv in kw.items()), "_".join(o)) for kw, o in CASES]
 
@@ -45,8 +50,8 @@ def open_with(kw, opts, require_device):
         lib.lame_set_VBR_mean_bitrate_kbps(enc.h, kw["abr"])
     for k, v in opts.items():
         f = getattr(lib, "lame_set_" + k)
-        f.argtypes = [C.c_void_p, C.c_float if k.startswith("scale") else C.c_int]
-        assert f(enc.h, float(v) if k.startswith("scale") else int(v)) == 0
+        f.argtypes = [C.c_void_p, C.c_float if k.startswith("scale") or k == "VBR_quality" else C.c_int]
+        assert f(enc.h, float(v) if k.startswith("scale") or k == "VBR_quality" else int(v)) == 0
     enc.rc = lib.lame_init_params(enc.h)
     assert enc.rc == 0 or (enc.rc == lamehip.ERR_NODEVICE and not require_device), lamehip.last_error()
     return enc
