@@ -110,6 +110,10 @@ struct lame_global_struct {
     /* input rate != output rate: the transformed samples pass through this first (lh_resample.c) */
     LhResampler *rs;
     std::vector < float >tl, tr;
+    /* what the frontend's progress display asks for (reference encoder.c:156-184 updateStats) */
+    unsigned long num_samples;
+    int     hist_mode[16][5];   /* [bitrate index | 15 = all][mode extension | 4 = frames] */
+    int     hist_block[16][6];  /* [bitrate index | 15 = all][block type, 4 = mixed | 5 = granules] */
 };
 
 static int
@@ -127,6 +131,7 @@ lame_init(void)
     g->class_id = LAME_ID;
     lh_params_default(&g->p);
     g->out_samplerate = 0;
+    g->num_samples = 0xFFFFFFFFul;       /* MAX_U_32_NUM, reference lame.c:2336 */
     g->write_vbr_tag = 1;       /* reference default (lame.c:2340) */
     g->inited = 0;
     g->have_device = 0;
@@ -349,6 +354,97 @@ lame_set_findReplayGain(lame_t g, int v)
 GETTER(lame_get_framesize, 576 * 2, int)
 GETTER(lame_get_frameNum, g->frames_done, int)
 GETTER(lame_get_encoder_delay, LH_ENCDELAY, int)
+GETTER(lame_get_encoder_padding, g->enc_padding, int)
+/* ENCDELAY + POSTDELAY + samples taken in - samples encoded; 0 after the flush (reference lame.c:1737-1766, 2117) */
+GETTER(lame_get_mf_samples_to_encode, (!g->inited || g->flushed) ? 0 : (int) (LH_ENCDELAY + LH_POSTDELAY + g->fed - 1152LL * g->frames_done), int)
+
+extern "C" int
+lame_set_num_samples(lame_t g, unsigned long n)
+{
+    if (!valid(g))
+        return -1;
+    g->num_samples = n;
+    return 0;
+}
+
+extern "C" unsigned long
+lame_get_num_samples(const lame_t g)
+{
+    return valid(g) ? g->num_samples : 0;
+}
+
+/* frames the stream will have, from the announced sample count (reference set_get.c:2120-2152) */
+extern "C" int
+lame_get_totalframes(const lame_t g)
+{
+    unsigned long n, padding;
+    if (!valid(g) || !g->inited)
+        return 0;
+    n = g->num_samples;
+    if (n == (0ul - 1ul))
+        return 0;
+    if (g->p.samplerate != g->cfg.samplerate && g->p.samplerate > 0) {
+        double const q = (double) g->cfg.samplerate / g->p.samplerate;
+        n *= q;
+    }
+    n += 576;
+    padding = 1152 - (n % 1152);
+    if (padding < 576)
+        padding += 1152;
+    n += padding;
+    return (int) (n / 1152);
+}
+
+/* histograms over the frames encoded so far (reference lame.c:2461-2610) */
+extern "C" void
+lame_bitrate_kbps(const lame_t g, int bitrate_kbps[14])
+{
+    if (valid(g) && g->inited)
+        for (int i = 0; i < 14; i++)
+            bitrate_kbps[i] = lh_tag_kbps(i + 1);
+}
+
+extern "C" void
+lame_bitrate_hist(const lame_t g, int bitrate_count[14])
+{
+    if (valid(g) && g->inited)
+        for (int i = 0; i < 14; i++)
+            bitrate_count[i] = g->hist_mode[i + 1][4];
+}
+
+extern "C" void
+lame_stereo_mode_hist(const lame_t g, int stmode_count[4])
+{
+    if (valid(g) && g->inited)
+        for (int i = 0; i < 4; i++)
+            stmode_count[i] = g->hist_mode[15][i];
+}
+
+extern "C" void
+lame_bitrate_stereo_mode_hist(const lame_t g, int bitrate_stmode_count[14][4])
+{
+    if (valid(g) && g->inited)
+        for (int j = 0; j < 14; j++)
+            for (int i = 0; i < 4; i++)
+                bitrate_stmode_count[j][i] = g->hist_mode[j + 1][i];
+}
+
+extern "C" void
+lame_block_type_hist(const lame_t g, int btype_count[6])
+{
+    if (valid(g) && g->inited)
+        for (int i = 0; i < 6; i++)
+            btype_count[i] = g->hist_block[15][i];
+}
+
+extern "C" void
+lame_bitrate_block_type_hist(const lame_t g, int bitrate_btype_count[14][6])
+{
+    if (valid(g) && g->inited)
+        for (int j = 0; j < 14; j++)
+            for (int i = 0; i < 6; i++)
+                bitrate_btype_count[j][i] = g->hist_block[j + 1][i];
+}
 GETTER(lame_get_version, g->inited ? g->cfg.version : 1, int)
 
 extern "C" int
@@ -493,6 +589,24 @@ handle_encode_frames(lame_t g, int upto, unsigned char *mp3buf, int mp3buf_size,
         k = lh_bs_copy(&g->bs, mp3buf + *written, mp3buf_size ? mp3buf_size - *written : 0);
         if (k < 0)
             return -1;
+        {
+            const LhFrameOut & fo = g->h_out[(size_t) i];
+            int const bi = fo.bitrate_index & 15, me = fo.mode_ext & 3;
+            g->hist_mode[bi][4]++;
+            g->hist_mode[15][4]++;
+            if (g->cfg.channels == 2) {
+                g->hist_mode[bi][me]++;
+                g->hist_mode[15][me]++;
+            }
+            for (int gr = 0; gr < 2; gr++)
+                for (int ch = 0; ch < g->cfg.channels; ch++) {
+                    int const bt = fo.gr[gr][ch].mixed_block_flag ? 4 : (fo.gr[gr][ch].block_type & 3);
+                    g->hist_block[bi][bt]++;
+                    g->hist_block[bi][5]++;
+                    g->hist_block[15][bt]++;
+                    g->hist_block[15][5]++;
+                }
+        }
         if (g->write_vbr_tag) {
             lh_tag_add_frame(&g->tag, lh_tag_kbps(g->h_out[(size_t) i].bitrate_index));  /* reference encoder.c:550-551 */
             lh_tag_crc(&g->tag, mp3buf + *written, k);          /* reference bitstream.c:1082-1088 */

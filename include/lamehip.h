@@ -105,6 +105,18 @@ int     lame_init_params(lame_t);                                    /* lame.h:6
 int     lame_get_framesize(const lame_t);                            /* lame.h:582 */
 int     lame_get_frameNum(const lame_t);                             /* lame.h:597 */
 int     lame_get_encoder_delay(const lame_t);                        /* lame.h:571 */
+int     lame_get_encoder_padding(const lame_t);                      /* lame.h:579, known after lame_encode_flush */
+int     lame_get_mf_samples_to_encode(const lame_t);                 /* lame.h:585 */
+int     lame_set_num_samples(lame_t, unsigned long);                 /* lame.h:184 */
+unsigned long lame_get_num_samples(const lame_t);
+int     lame_get_totalframes(const lame_t);                          /* lame.h:603 */
+/* histograms over the frames encoded so far, for a frontend's progress display (lame.h:893-960) */
+void    lame_bitrate_kbps(const lame_t, int bitrate_kbps[14]);
+void    lame_bitrate_hist(const lame_t, int bitrate_count[14]);
+void    lame_stereo_mode_hist(const lame_t, int stereo_mode_count[4]);
+void    lame_bitrate_stereo_mode_hist(const lame_t, int bitrate_stmode_count[14][4]);
+void    lame_block_type_hist(const lame_t, int btype_count[6]);
+void    lame_bitrate_block_type_hist(const lame_t, int bitrate_btype_count[14][6]);
 int     lame_get_version(const lame_t);                              /* lame.h:568 */
 
 /* return: bytes written to mp3buf (may be 0); -1 mp3buf too small; -2 alloc;

@@ -99,6 +99,13 @@ quiet(const char *fmt, va_list ap)
     (void) ap;
 }
 
+/* the reference's own handle, for calling its lame_get_* / histogram functions directly */
+void   *
+refh_gfp(void *hh)
+{
+    return ((RefH *) hh)->gfp;
+}
+
 /* mode: -1 default (joint stereo), else MPEG_mode; quality -1 default */
 void   *
 refh_open(int samplerate, int brate, int mode, int quality)
