@@ -112,6 +112,7 @@ struct lame_global_struct {
     std::vector < float >tl, tr;
     /* what the frontend's progress display asks for (reference encoder.c:156-184 updateStats) */
     unsigned long num_samples;
+    int     preset_vbr;         /* lame_set_preset chose a V0..V9 preset */
     int     hist_mode[16][5];   /* [bitrate index | 15 = all][mode extension | 4 = frames] */
     int     hist_block[16][6];  /* [bitrate index | 15 = all][block type, 4 = mixed | 5 = granules] */
 };
@@ -226,6 +227,56 @@ lame_set_VBR_q(lame_t g, int q)
     g->p.vbr_q = q;
     g->p.vbr_q_frac = 0;
     return ret;
+}
+
+/* --preset / lame_set_preset (reference set_get.c:2158-2166, presets.c:319-420): the named presets
+ * and V0..V9 select the new VBR loop's quality, 8..320 an ABR mean, INSANE is CBR 320.  Applied at
+ * call time like the reference, so later lame_set_* calls still override. */
+extern "C" int
+lame_set_preset(lame_t g, int preset)
+{
+    if (!valid(g))
+        return -1;
+    switch (preset) {
+    case 1000:                 /* R3MIX */
+        preset = 470;
+        g->p.vbr = 4;
+        break;
+    case 1006:                 /* MEDIUM, MEDIUM_FAST */
+    case 1007:
+        preset = 460;
+        g->p.vbr = 4;
+        break;
+    case 1001:                 /* STANDARD, STANDARD_FAST */
+    case 1004:
+        preset = 480;
+        g->p.vbr = 4;
+        break;
+    case 1002:                 /* EXTREME, EXTREME_FAST */
+    case 1005:
+        preset = 500;
+        g->p.vbr = 4;
+        break;
+    case 1003:                 /* INSANE */
+        g->p.vbr = 0;
+        g->p.brate = g->p.abr_kbps = 320;
+        g->p.scale *= lh_abr_preset_scale(320);
+        g->preset_vbr = 0;
+        return 320;
+    }
+    if (preset >= 410 && preset <= 500 && preset % 10 == 0) {   /* V9 .. V0 */
+        g->p.vbr_q = (500 - preset) / 10;
+        g->p.vbr_q_frac = 0;
+        g->preset_vbr = 1;      /* its tunings are the VBR loop's: not combined with CBR / ABR here */
+        return preset;
+    }
+    if (8 <= preset && preset <= 320) {
+        g->p.vbr = 3;
+        g->p.abr_kbps = g->p.brate = preset;
+        g->p.scale *= lh_abr_preset_scale(preset);      /* and once more in lame_init_params, like the reference */
+        g->preset_vbr = 0;
+    }
+    return preset;
 }
 
 /* -V n.f (reference set_get.c:1155-1175) */
@@ -456,6 +507,10 @@ lame_init_params(lame_t g)
     if (g->inited)
         return 0;
     g->p.samplerate_out = g->out_samplerate;
+    if (g->preset_vbr && g->p.vbr != 1 && g->p.vbr != 4) {
+        snprintf(g_err, sizeof(g_err), "a V0..V9 preset without lame_set_VBR(vbr_mtrh / vbr_mt) is outside the accelerated path");
+        return -1;
+    }
     if (lh_config_resolve(&g->p, &g->cfg, &aux) != 0) {
         snprintf(g_err, sizeof(g_err),
                  "unsupported settings for the MI355X path (need an MPEG-1 output rate, 1 or 2 input channels, CBR / ABR / vbr_mtrh)");

@@ -45,6 +45,7 @@ typedef struct LhInitAux {
 
 void    lh_params_default(LhUserParams * p);
 int     lh_config_resolve(const LhUserParams * p, LhConfig * c, LhInitAux * aux);
+float   lh_abr_preset_scale(int kbps);
 int     lh_tables_build(LhConfig * c, const LhInitAux * aux, LhTables * t);
 
 /* number of MP3 frames the reference produces for n input samples per channel

@@ -320,6 +320,14 @@ lowpass_edges(LhConfig * c, LhInitAux * aux, int width)
     }
 }
 
+/* input scale of the ABR / CBR tuning row for a bitrate (lame_set_preset applies it at call time on top of
+ * lame_init_params, as the reference does: presets.c:296) */
+float
+lh_abr_preset_scale(int kbps)
+{
+    return abr_map[nearest_full_index(kbps)].scale;
+}
+
 /* smallest / largest frame size VBR and ABR may pick (-b / -B / -F; reference lame.c:1064-1085) */
 static int
 vbr_bitrate_limits(const LhUserParams * p, LhConfig * c)

@@ -60,6 +60,7 @@ int     lame_set_VBR(lame_t, vbr_mode);                              /* lame.h:4
 vbr_mode lame_get_VBR(const lame_t);                                 /* lame.h:433 */
 int     lame_set_VBR_q(lame_t, int);                                 /* lame.h:436 (0 best .. 9; default 4) */
 int     lame_get_VBR_q(const lame_t);                                /* lame.h:437 */
+int     lame_set_preset(lame_t, int);                     /* --preset: V0..V9, named presets, 8..320 = ABR; lame.h:359 */
 int     lame_set_VBR_quality(lame_t, float);              /* -V n.f, lame.h:393 */
 float   lame_get_VBR_quality(const lame_t);
 int     lame_set_VBR_min_bitrate_kbps(lame_t, int);       /* -b with VBR / ABR, lame.h:403 */

@@ -86,6 +86,7 @@ apply_options(lame_global_flags * gfp)
         else if (!strcmp(n, "force_short_blocks")) lame_set_force_short_blocks(gfp, (int) v);
         else if (!strcmp(n, "out_samplerate")) lame_set_out_samplerate(gfp, (int) v);
         else if (!strcmp(n, "VBR_quality")) lame_set_VBR_quality(gfp, v);
+        else if (!strcmp(n, "preset")) lame_set_preset(gfp, (int) v);
         else if (!strcmp(n, "VBR_min_bitrate_kbps")) lame_set_VBR_min_bitrate_kbps(gfp, (int) v);
         else if (!strcmp(n, "VBR_max_bitrate_kbps")) lame_set_VBR_max_bitrate_kbps(gfp, (int) v);
         else if (!strcmp(n, "VBR_hard_min")) lame_set_VBR_hard_min(gfp, (int) v);

@@ -28,6 +28,9 @@ CASES = [
     (dict(abr=128), {"VBR_min_bitrate_kbps": 64, "VBR_max_bitrate_kbps": 192}),
     (dict(abr=250), {"VBR_max_bitrate_kbps": 224}),
     (dict(vbr_q=2), {"VBR_quality": 2.5}), (dict(vbr_q=0), {"VBR_quality": 5.31}),
+    # (brate 0 = left alone, as a frontend that only says --preset does)
+    (dict(brate=0), {"preset": 1001}), (dict(brate=0), {"preset": 1003}), (dict(brate=0), {"preset": 1006}),
+    (dict(brate=0), {"preset": 150}), (dict(vbr_q=4), {"preset": 450}), (dict(brate=0), {"preset": 1002}),
 ]
 IDS = ["%s-%s" % ("_".join("%s%s" % kv for kv in kw.items()), "_".join(o)) for kw, o in CASES]
 
@@ -51,7 +54,8 @@ def open_with(kw, opts, require_device):
     for k, v in opts.items():
         f = getattr(lib, "lame_set_" + k)
         f.argtypes = [C.c_void_p, C.c_float if k.startswith("scale") or k == "VBR_quality" else C.c_int]
-        assert f(enc.h, float(v) if k.startswith("scale") or k == "VBR_quality" else int(v)) == 0
+        rc = f(enc.h, float(v) if k.startswith("scale") or k == "VBR_quality" else int(v))
+        assert rc == 0 or k == "preset"
     enc.rc = lib.lame_init_params(enc.h)
     assert enc.rc == 0 or (enc.rc == lamehip.ERR_NODEVICE and not require_device), lamehip.last_error()
     return enc
