@@ -113,6 +113,7 @@ struct lame_global_struct {
     /* what the frontend's progress display asks for (reference encoder.c:156-184 updateStats) */
     unsigned long num_samples;
     int     preset_vbr;         /* lame_set_preset chose a V0..V9 preset */
+    int     frame_num_base;     /* frames before the last lame_init_bitstream */
     int     hist_mode[16][5];   /* [bitrate index | 15 = all][mode extension | 4 = frames] */
     int     hist_block[16][6];  /* [bitrate index | 15 = all][block type, 4 = mixed | 5 = granules] */
 };
@@ -403,7 +404,7 @@ lame_set_findReplayGain(lame_t g, int v)
 }
 
 GETTER(lame_get_framesize, 576 * 2, int)
-GETTER(lame_get_frameNum, g->frames_done, int)
+GETTER(lame_get_frameNum, g->frames_done - g->frame_num_base, int)
 GETTER(lame_get_encoder_delay, LH_ENCDELAY, int)
 GETTER(lame_get_encoder_padding, g->enc_padding, int)
 /* ENCDELAY + POSTDELAY + samples taken in - samples encoded; 0 after the flush (reference lame.c:1737-1766, 2117) */
@@ -568,7 +569,12 @@ emit_tag_placeholder(lame_t g, unsigned char *mp3buf, int mp3buf_size, int *writ
         return 0;
     if (mp3buf_size != 0 && mp3buf_size - *written < g->tag.total_frame_size)
         return -1;
-    *written += lh_tag_placeholder(&g->tag, &g->cfg, mp3buf + *written);
+    {
+        unsigned char *h = mp3buf + *written;
+        *written += lh_tag_placeholder(&g->tag, &g->cfg, h);
+        if (g->have_last)       /* a later file of a --nogap run: the header carries the last frame's mode extension */
+            h[3] = (unsigned char) ((h[3] & 0xcf) | ((g->last_frame.mode_ext & 3) << 4));
+    }
     g->tag_placeholder_pending = 0;
     return 0;
 }
@@ -916,6 +922,44 @@ finish_stream(lame_t g, unsigned char *mp3buf, int size, int written)
         }
     }
     return written;
+}
+
+/* --nogap: close the bitstream at a file boundary without draining the sample buffers (reference
+ * lame.c:1988-2001): the pending frames are padded out and the reservoir starts from zero, so the
+ * pieces decode on their own and, concatenated, without a gap. */
+extern "C" int
+lame_encode_flush_nogap(lame_t g, unsigned char *mp3buf, int size)
+{
+    int     was, k;
+    if (!valid(g) || !g->inited)
+        return -3;
+    if (!g->have_device)
+        return LAMEHIP_ERR_NODEVICE;
+    was = g->flushed;
+    k = finish_stream(g, mp3buf, size, 0);
+    g->flushed = was;
+    return k;
+}
+
+/* start the next file of a --nogap run: frame counter, histograms and a fresh tag frame
+ * (reference lame.c:2006-2035) */
+extern "C" int
+lame_init_bitstream(lame_t g)
+{
+    if (!valid(g) || !g->inited)
+        return -3;
+    g->frame_num_base = g->frames_done;
+    memset(g->hist_mode, 0, sizeof(g->hist_mode));
+    memset(g->hist_block, 0, sizeof(g->hist_block));
+    {
+        uint16_t const crc = g->tag.music_crc;  /* the reference's music CRC runs on across the files */
+        if (g->write_vbr_tag && lh_tag_init(&g->tag, &g->cfg) > 0) {
+            g->tag.samplerate_in = g->p.samplerate;
+            g->tag.music_crc = crc;
+            g->tag_placeholder_pending = 1;
+        }
+    }
+    return 0;
 }
 
 /* reference lame.h:970, VbrTag.c:900: the final tag frame that replaces the placeholder at the

@@ -146,6 +146,9 @@ int     lame_encode_buffer_long2(lame_t, const long l[], const long r[], const i
 int     lame_encode_buffer_int(lame_t, const int l[], const int r[], const int nsamples,
                                unsigned char *mp3buf, const int mp3buf_size);                    /* lame.h:831 (+/-2^31) */
 int     lame_encode_flush(lame_t, unsigned char *mp3buf, int size);                              /* lame.h:856 */
+/* --nogap: end a file without draining the sample buffers, then start the next one (lame.h:870, 886) */
+int     lame_encode_flush_nogap(lame_t, unsigned char *mp3buf, int size);
+int     lame_init_bitstream(lame_t);
 /* final Xing/Info + LAME tag frame that replaces the placeholder at the head of the stream */
 size_t  lame_get_lametag_frame(const lame_t, unsigned char *buffer, size_t size);                /* lame.h:970 */
 int     lame_close(lame_t);                                                                      /* lame.h:977 */

@@ -278,6 +278,13 @@ refh_flush(void *hh, unsigned char *out, int outsize)
 }
 
 int
+refh_flush_nogap(void *hh, unsigned char *out, int outsize)
+{
+    RefH   *h = (RefH *) hh;
+    return lame_encode_flush_nogap(h->gfp, out, outsize);
+}
+
+int
 refh_frame_number(void *hh)
 {
     RefH   *h = (RefH *) hh;

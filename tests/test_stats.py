@@ -62,3 +62,54 @@ def test_progress_getters_match_reference_call_by_call(rate_in, kw, out, referen
     assert sum(got[1]) == got[6] and got[6] == got[7]                 # every frame counted; the announced count was right
     rlib.refh_close(rh)
     enc.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(brate=128), dict(vbr_q=3), dict(abr=120)], ids=["cbr128", "v3", "abr120"])
+def test_nogap_file_boundary_matches_reference(kw, reference):
+    """--nogap: lame_encode_flush_nogap + lame_init_bitstream between two files of one signal, tag frames included"""
+    sr = 44100
+    pcm = helpers.synth_stream(8300, int(sr * 1.6), sr, 1.0 / 10)
+    cut = 30000
+    rlib = reference.lib
+    rlib.refh_gfp.restype = C.c_void_p
+    rlib.refh_open_tag.restype = C.c_void_p
+    if "abr" in kw:
+        rh = C.c_void_p(rlib.refh_open_abr(sr, kw["abr"], -1, -1, 0, 1))
+    elif "vbr_q" in kw:
+        rh = C.c_void_p(rlib.refh_open_vbr(sr, kw["vbr_q"], -1, -1, 0, 1))
+    else:
+        rh = C.c_void_p(rlib.refh_open_tag(sr, kw["brate"], -1, -1))
+    rg = C.c_void_p(rlib.refh_gfp(rh))
+    enc = lamehip.Encoder(sr, kw.get("brate", 128), write_tag=True, vbr_q=kw.get("vbr_q"), abr=kw.get("abr"))
+    plib = enc.lib
+    buf, tag = C.create_string_buffer(200000), C.create_string_buffer(2880)
+    plib.lame_encode_flush_nogap.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    plib.lame_init_bitstream.argtypes = [C.c_void_p]
+    rlib.lame_init_bitstream.argtypes = [C.c_void_p]
+
+    def feed(a, b):
+        for pos in range(a, b, 1152):
+            l = np.ascontiguousarray(pcm[0][pos:min(pos + 1152, b)])
+            r = np.ascontiguousarray(pcm[1][pos:min(pos + 1152, b)])
+            k = rlib.refh_encode(rh, l.ctypes.data_as(C.c_void_p), r.ctypes.data_as(C.c_void_p), len(l), buf, len(buf))
+            assert enc.encode(l, r) == buf.raw[:k], "call at %d" % pos
+
+    feed(0, cut)
+    k = rlib.refh_flush_nogap(rh, buf, len(buf))
+    want = buf.raw[:k]
+    k = plib.lame_encode_flush_nogap(enc.h, buf, len(buf))
+    assert buf.raw[:k] == want
+    k = rlib.refh_lametag(rh, tag, len(tag))
+    assert enc.lametag_frame() == tag.raw[:k]                           # the first file's tag
+    assert snapshot(plib, enc.h) == snapshot(rlib, rg)
+    assert rlib.lame_init_bitstream(rg) == 0 and plib.lame_init_bitstream(enc.h) == 0
+    assert snapshot(plib, enc.h) == snapshot(rlib, rg)
+    feed(cut, pcm.shape[1])
+    k = rlib.refh_flush(rh, buf, len(buf))
+    assert enc.flush() == buf.raw[:k]
+    k = rlib.refh_lametag(rh, tag, len(tag))
+    assert enc.lametag_frame() == tag.raw[:k]
+    assert snapshot(plib, enc.h) == snapshot(rlib, rg)
+    rlib.refh_close(rh)
+    enc.close()
