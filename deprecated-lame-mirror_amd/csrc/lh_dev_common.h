@@ -86,6 +86,7 @@ struct LhQR {
     int     pn_global_gain, pn_sfb_count1;
     int     substep_shaping;
     int     ath_over;           /* calc_xmin's return value != 0 (only the VBR loop asks: analog silence) */
+    int     s_mnc;              /* band that holds line max_nonzero_coeff (set by the search loop) */
 };
 
 /* copies of R / g that came back from an out-of-line stage through per-lane memory */
@@ -105,6 +106,7 @@ lh_uniform(const LhQR & r)
     o.pn_sfb_count1 = lh_uni_i(r.pn_sfb_count1);
     o.substep_shaping = lh_uni_i(r.substep_shaping);
     o.ath_over = lh_uni_i(r.ath_over);
+    o.s_mnc = lh_uni_i(r.s_mnc);
     return o;
 }
 

@@ -1,0 +1,926 @@
+/*
+ * lh_dev_qloop.h -- the CBR / ABR noise-shaping search (reference quantize.c:367-429,
+ * 540-1197; takehiro.c:113-801; quantize_pvt.c:750-913) with the granule held in
+ * registers.
+ *
+ * Why this shape: one wavefront issues at most one instruction every ~5 cycles on
+ * gfx950 whatever the instruction is (tools/ubench/lat2.hip), and a stream offers
+ * only its two channel-waves, so the length of the serial search is
+ * (instructions per iteration) x 5 cycles + stalls.  The search therefore keeps
+ * everything it touches every iteration in registers --
+ *   lines:  lane l owns the pairs l, l+64, ... (5 slots; |xr|, xrpow, the working
+ *           and the best quantised image as packed 16-bit pairs, the band of each
+ *           pair),
+ *   bands:  lane s owns scalefactor band s (working / best scalefactor, 1/xmin,
+ *           distortion, the calc_noise cache),
+ * and goes to LDS only where lanes have to exchange data: the 0/1 quadruples of
+ * the count1 region, the per-band step of calc_noise, and the squared errors that
+ * the band lanes add up in the reference's order.  Per-band decisions travel as
+ * ballot masks.  The quantised image and the scalefactors are written to the LDS
+ * image (LhChanLds.ix[0], sf[0]) once, when the search is over, where the
+ * out-of-line finishing stages expect them.
+ */
+#ifndef LH_DEV_QLOOP_H
+#define LH_DEV_QLOOP_H
+
+#include "lh_dev_quant.h"
+
+struct LhQS {
+    /* lane = pair slots */
+    float   ax[10];             /* |xr| of lines 2p, 2p+1 of slot k at [2k], [2k+1] */
+    float   xp[10];             /* xrpow */
+    uint32_t pw[5];             /* working image: low half = even line */
+    uint32_t pb[5];             /* best image */
+    int     bnd[5];             /* band of the pair (63: the slot holds no pair) */
+    int     bq[5];              /* the same, but 63 as well when the pair lies above max_nonzero_coeff */
+    float   lmax;               /* the lane's largest xrpow (xrpow_max = the maximum over the lanes) */
+    /* lane = band */
+    int     sfw, sfbest;        /* scalefactor: working, best */
+    float   rxmin;              /* 1 / l3_xmin */
+    int     wid, sta, win, pre; /* geometry of the band, pretab */
+    int     pnstep;             /* calc_noise_data */
+    float   pnnoise, pnlog;
+    float   dist;               /* distort[] of the working image */
+    int     ph;                 /* pseudohalf */
+};
+
+LH_DEVFN int
+lq_bit(uint64_t m, int b)
+{
+    return (int) ((m >> b) & 1ull);
+}
+
+/* step of band `lane' (reference takehiro.c:330-336, quantize_pvt.c:833-836) */
+LH_DEVFN int
+lq_band_step(const LhQS & S, const LhGrR & g)
+{
+    int const pre = g.preflag ? S.pre : 0;
+    return g.global_gain - ((S.sfw + pre) << (g.scalefac_scale + 1)) - lh_sbg(g, S.win) * 8;
+}
+
+/* load the granule into registers; Q.xrpow, Q.l3_xmin and the geometry arrays were written by
+ * lh_init_outer_loop / lh_init_xrpow / lh_calc_xmin */
+LH_DEVFN void
+lq_load(const LhCtx & c, LhQS & S, const LhChanLds & Q, const LhQR & R, const float *xr)
+{
+    const LhQTabs *qt = LH_QT;
+    int const pm = R.mnc >> 1;
+    float   mx = 0.0f;
+    LH_WAVE_SYNC();
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        int const p = c.lane + 64 * k;
+        int const ok = (k < 4 || p < 288);
+        int const pc = ok ? p : 287;
+        lh_f32x2 const a = ((const lh_f32x2 *) xr)[pc];
+        lh_f32x2 const x = ((const lh_f32x2 *) Q.xrpow)[pc];
+        int const b = Q.sfb_of_line[2 * pc];
+        S.ax[2 * k] = ok ? lh_fabsf(a.x) : 0.0f;
+        S.ax[2 * k + 1] = ok ? lh_fabsf(a.y) : 0.0f;
+        S.xp[2 * k] = ok ? x.x : 0.0f;
+        S.xp[2 * k + 1] = ok ? x.y : 0.0f;
+        S.bnd[k] = ok ? b : 63;
+        S.bq[k] = (ok && p <= pm) ? b : 63;
+        S.pw[k] = 0u;
+        S.pb[k] = 0u;
+        mx = S.xp[2 * k] > mx ? S.xp[2 * k] : mx;
+        mx = S.xp[2 * k + 1] > mx ? S.xp[2 * k + 1] : mx;
+    }
+    S.lmax = mx;
+    {
+        int const s = c.lane <= LH_SFBMAX ? c.lane : LH_SFBMAX;
+        S.sfw = 0;
+        S.sfbest = 0;
+        S.rxmin = 1.f / Q.l3_xmin[s];
+        S.wid = Q.width[s];
+        S.sta = Q.start[s];
+        S.win = Q.window[s];
+        S.pre = (c.lane < LH_SBMAX_L) ? (int) qt->pretab[c.lane < 22 ? c.lane : 0] : 0;
+        S.pnstep = 0;
+        S.pnnoise = 0;
+        S.pnlog = 0;
+        S.dist = 0;
+        S.ph = Q.pseudohalf[s];
+    }
+}
+
+/* reference takehiro.c:281-414 (quantize_xrpow) + 654-801 (noquant_count_bits, count_bits) on the
+ * working image */
+template < int USE_PREV > LH_DEVFN int
+lq_count_bits(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
+{
+    LH_PC(10);
+    LH_PT(t_cb);
+    const LhTables *T = c.T;
+    const LhQTabs *qt = LH_QT;
+    int const lane = c.lane;
+    float   istep;
+    if (g.global_gain >= 128)
+        istep = lh_uni_f(qt->ipow20w[g.global_gain - 128]);
+    else
+        istep = lh_uni_f(T->ipow20[g.global_gain]);
+    if (lh_ballot(S.lmax > (LH_IXMAX) / istep))
+        return LH_LARGE_BITS;
+    /* ---- which bands are quantised, and how (lane = band) ---- */
+    uint64_t ncmask, m01mask = 0;
+    int     zero_mnc = 0, plain;
+    int const pm = R.mnc >> 1;
+    {
+        int const sfbmax = (R.block_type == LH_SHORT_TYPE) ? 38 : 21;
+        int const prev_data_use = (USE_PREV && (g.global_gain == R.pn_global_gain));
+        uint64_t const all = (2ull << sfbmax) - 1ull;
+        if (USE_PREV && (prev_data_use || R.pn_sfb_count1 > 0)) {
+            int const s = lane;
+            int const step = lq_band_step(S, g);
+            int const cached = prev_data_use && (S.pnstep == step);
+            /* the band that holds line max_nonzero_coeff never takes the 0/1 comparator (see
+             * lh_count_bits in lh_dev_quant.h) */
+            int const m01 = R.pn_sfb_count1 > 0 && s >= R.pn_sfb_count1 && S.pnstep > 0 && step >= S.pnstep
+                && s != R.s_mnc;
+            ncmask = lh_ballot(s <= sfbmax && !cached);
+            m01mask = lh_ballot(s <= sfbmax && m01);
+            {
+                int const cached_m = !lq_bit(ncmask, R.s_mnc);
+                int const later = (R.s_mnc < 63) ? ((ncmask >> (R.s_mnc + 1)) != 0) : 0;
+                zero_mnc = cached_m && later;
+            }
+        }
+        else
+            ncmask = all;
+        plain = (ncmask == all) && (m01mask == 0);
+    }
+    LH_PA(18, t_cb);
+    /* ---- quantise: all pairs, straight line; the selection follows ---- */
+    {
+        uint32_t nq[5];
+        int     anybig = 0;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            float const a0 = istep * S.xp[2 * k], a1 = istep * S.xp[2 * k + 1];
+            double const d0 = (double) a0 + (double) LH_MAGIC_FLOAT, d1 = (double) a1 + (double) LH_MAGIC_FLOAT;
+            uint32_t const b0 = lh_f32_as_u32((float) d0), b1 = lh_f32_as_u32((float) d1);
+            float const j0 = qt->adj43h[b0 & 255u], j1 = qt->adj43h[b1 & 255u];
+            uint32_t const r0 = lh_f32_as_u32((float) (d0 + j0)), r1 = lh_f32_as_u32((float) (d1 + j1));
+            anybig |= (b0 > (uint32_t) LH_MAGIC_INT + 255u) | (b1 > (uint32_t) LH_MAGIC_INT + 255u);
+            nq[k] = (r0 & 0xffffu) | (r1 << 16);
+        }
+        if (lh_ballot(anybig && 1)) {
+            /* rare: a quantised value >= 256, its rounding offset lives in HBM */
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                int const q0 = lh_quant_line(T, qt, istep, S.xp[2 * k]);
+                int const q1 = lh_quant_line(T, qt, istep, S.xp[2 * k + 1]);
+                nq[k] = (uint32_t) (q0 & 0xffff) | ((uint32_t) q1 << 16);
+            }
+        }
+        if (plain) {
+#pragma unroll
+            for (int k = 0; k < 5; k++)
+                S.pw[k] = (S.bq[k] != 63) ? nq[k] : 0u;
+        }
+        else {
+            float const compareval0 = (1.0f - 0.4054f) / istep;
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                int const p = lane + 64 * k;
+                int const nc = lq_bit(ncmask, S.bq[k]), z1 = lq_bit(m01mask, S.bq[k]);
+                uint32_t const v01 = ((compareval0 > S.xp[2 * k]) ? 0u : 1u)
+                    | (((compareval0 > S.xp[2 * k + 1]) ? 0u : 1u) << 16);
+                uint32_t v = nc ? (z1 ? v01 : nq[k]) : S.pw[k];
+                if (zero_mnc && p == pm)
+                    v &= 0xffffu;
+                S.pw[k] = v;
+            }
+        }
+    }
+    if (R.substep_shaping & 2) {
+        int const gain = g.global_gain + g.scalefac_scale;
+        float const roundfac = (float) (0.634521682242439 / T->ipow20[gain]);
+        uint64_t const phm = lh_ballot(lane < R.sfbmax && S.ph);
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            if (lq_bit(phm, S.bnd[k])) {
+                uint32_t v = S.pw[k];
+                if (!(S.xp[2 * k] >= roundfac))
+                    v &= 0xffff0000u;
+                if (!(S.xp[2 * k + 1] >= roundfac))
+                    v &= 0x0000ffffu;
+                S.pw[k] = v;
+            }
+        }
+    }
+    LH_PA(12, t_cb);
+    /* ---- count ---- */
+    {
+        uint32_t *xbuf = (uint32_t *) Q.ix[1];
+        uint64_t mk[5];
+        int     top_nz, top_big, i, bv, nquad, bits;
+        int     e0, e1, e2, a1, a2;
+        unsigned quads = 0, sfbcnt_in = 0;
+        LH_PT(t_nq);
+        if (USE_PREV)
+            R.pn_sfb_count1 = 0;
+        /* the quadruples of the count1 region pair up neighbouring lanes: through LDS */
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            int const p = lane + 64 * k;
+            if (k < 4 || p < 288)
+                xbuf[p] = S.pw[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+            mk[k] = lh_ballot(S.pw[k] != 0u);
+        top_nz = lh_top_of_masks(mk);
+        i = 2 * top_nz;
+        g.count1 = i;
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+            mk[k] = lh_ballot((S.pw[k] & 0xfffefffeu) != 0u);
+        top_big = lh_top_of_masks(mk);
+        nquad = (i - 2 * top_big) / 4;
+        bv = i - 4 * nquad;
+        g.big_values = bv;
+        if (R.block_type == LH_SHORT_TYPE) {
+            a1 = 3 * (int) qt->sfb_s3;
+            a2 = bv;
+        }
+        else if (R.block_type == LH_NORM_TYPE) {
+            if (bv > 0) {
+                uint32_t const pack = qt->bvpack[(bv >> 1) - 1];
+                g.region0_count = (int) (pack & 15u);
+                g.region1_count = (int) ((pack >> 4) & 15u);
+                a1 = (int) ((pack >> 8) & 1023u);
+                a2 = (int) ((pack >> 18) & 1023u);
+            }
+            else
+                a1 = a2 = 0;
+        }
+        else {
+            if (bv > 0) {
+                g.region0_count = 7;
+                g.region1_count = LH_SBMAX_L - 1 - 7 - 1;
+            }
+            a1 = qt->sfb_l[7 + 1];
+            a2 = bv;
+        }
+        a1 = (a1 < bv) ? a1 : bv;
+        a2 = (a2 < bv) ? a2 : bv;
+        e0 = a1 >> 1;
+        e1 = a2 >> 1;
+        e2 = (R.block_type == LH_NORM_TYPE) ? (bv >> 1) : e1;
+        if (USE_PREV && R.block_type == LH_NORM_TYPE)
+            sfbcnt_in = (lane < LH_SBMAX_L + 1) ? qt->sfb_l[lane] : 576u;
+        LH_PA(19, t_nq);
+        LH_WAVE_SYNC();
+        {
+            unsigned idx[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                int const qd = lane + 64 * k;
+                int const b2 = (bv >> 1) + 2 * qd;
+                int const b2c = b2 < 286 ? b2 : 286;
+                uint32_t const u0 = xbuf[b2c], u1 = xbuf[b2c + 1];
+                idx[k] = ((((u0 & 1u) * 2 + ((u0 >> 16) & 1u)) * 2 + (u1 & 1u)) * 2 + ((u1 >> 16) & 1u));
+            }
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                quads += ((lane + 64 * k) < nquad) ? qt->t3233[idx[k]] : 0u;
+        }
+        LH_PA(20, t_nq);
+        {
+            unsigned m0 = 0, m1 = 0, m2 = 0;
+            unsigned w00, w01, w10, w11, w20, w21;
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                int const p = lane + 64 * k;
+                unsigned const lo = S.pw[k] & 0xffffu, hi = S.pw[k] >> 16;
+                unsigned const m = lo > hi ? lo : hi;
+                if (p < e0)
+                    m0 = m > m0 ? m : m0;
+                else if (p < e1)
+                    m1 = m > m1 ? m : m1;
+                else if (p < e2)
+                    m2 = m > m2 ? m : m2;
+            }
+            m0 = lh_wave_max_u32(m0);
+            m1 = lh_wave_max_u32(m1);
+            m2 = lh_wave_max_u32(m2);
+            LH_PA(21, t_nq);
+            {
+                LhRegionLut l0, l1, l2;
+                l0.pa = qt->lut_pa[m0 < 16u ? m0 : 16u];
+                l0.pb = qt->lut_pb[m0 < 16u ? m0 : 16u];
+                l1.pa = qt->lut_pa[m1 < 16u ? m1 : 16u];
+                l1.pb = qt->lut_pb[m1 < 16u ? m1 : 16u];
+                l2.pa = qt->lut_pa[m2 < 16u ? m2 : 16u];
+                l2.pb = qt->lut_pb[m2 < 16u ? m2 : 16u];
+                unsigned v0[5], v1[5];
+                w00 = w01 = w10 = w11 = w20 = w21 = 0;
+#pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    int const p = lane + 64 * k;
+                    uint32_t const pa = (p < e0) ? l0.pa : (p < e1) ? l1.pa : (p < e2) ? l2.pa : 2u;
+                    uint32_t const pb = (p < e0) ? l0.pb : (p < e1) ? l1.pb : (p < e2) ? l2.pb : 0u;
+                    unsigned const x = S.pw[k] & 0xffffu, y = S.pw[k] >> 16;
+                    unsigned const xc = x < 15u ? x : 15u, yc = y < 15u ? y : 15u;
+                    unsigned const ix_ = xc * (pa & 0xffu) + yc;
+                    unsigned const b1 = qt->ht_len[(pa >> 16) + ix_];
+                    unsigned const b2 = qt->ht_len[(pb & 0xffffu) + ix_];
+                    unsigned const b3 = qt->ht_len[(pb >> 16) + ix_];
+                    unsigned const e = qt->largetbl[ix_ & 255u];
+                    int const esc = (pa >> 8) & 1u;
+                    v0[k] = esc ? e : (b1 | (b2 << 16));
+                    v1[k] = esc ? (unsigned) (x >= 15u) + (unsigned) (y >= 15u) : b3;
+                }
+#pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    int const p = lane + 64 * k;
+                    int const r0 = (p < e0), r1 = (p >= e0 && p < e1), r2 = (p >= e1 && p < e2);
+                    w00 += r0 ? v0[k] : 0u;
+                    w01 += r0 ? v1[k] : 0u;
+                    w10 += r1 ? v0[k] : 0u;
+                    w11 += r1 ? v1[k] : 0u;
+                    w20 += r2 ? v0[k] : 0u;
+                    w21 += r2 ? v1[k] : 0u;
+                }
+            }
+            LH_PA(22, t_nq);
+            quads = lh_wave_sum_u32(quads);
+            w00 = lh_wave_sum_u32(w00);
+            w10 = lh_wave_sum_u32(w10);
+            w20 = lh_wave_sum_u32(w20);
+            {
+                unsigned const wa = lh_wave_sum_u32(w01 | (w11 << 16));
+                w21 = lh_wave_sum_u32(w21);
+                w01 = wa & 0xffffu;
+                w11 = wa >> 16;
+            }
+            LH_PA(23, t_nq);
+            {
+                int const c1a = (int) (quads >> 16), c1b = (int) (quads & 0xffffu);
+                bits = c1a;
+                g.count1table_select = 0;
+                if (c1a > c1b) {
+                    bits = c1b;
+                    g.count1table_select = 1;
+                }
+                g.count1bits = bits;
+            }
+            if (bv != 0) {
+                if (e1 < e2)
+                    g.table_select[2] = lh_region_decide(m2, w20, w21, &bits);
+                if (0 < e0)
+                    g.table_select[0] = lh_region_decide(m0, w00, w01, &bits);
+                if (e0 < e1)
+                    g.table_select[1] = lh_region_decide(m1, w10, w11, &bits);
+            }
+        }
+        if (USE_PREV && R.block_type == LH_NORM_TYPE && bv != 0)
+            R.pn_sfb_count1 = lh_popc64(lh_ballot(lane < LH_SBMAX_L + 1 && (int) sfbcnt_in < bv));
+        LH_PA(11, t_cb);
+        return bits;
+    }
+}
+
+/* reference quantize_pvt.c:750-913 on the working image */
+LH_DEVFN void
+lq_calc_noise(const LhCtx & c, LhQS & S, LhQR & R, const LhGrR & g, LhChanLds & Q, LhNoiseRes & res)
+{
+    const LhTables *T = c.T;
+    const LhQTabs *qt = LH_QT;
+    int const s = c.lane;
+    float  *sq = Q.xrpow;       /* the LDS copy of xrpow is dead while the search runs */
+    float   noise = 0, noise_s = 0;
+    int     st, l = 0, j = 0, fresh, big = 0, maxw;
+    LH_PC(13);
+    LH_PT(t_cn0);
+    st = lq_band_step(S, g);
+    fresh = (s < R.psymax) && !(S.pnstep == st);
+    {
+        float const step = fresh ? T->pow20[st + LH_QMAX2] : 0.0f;
+        if (fresh) {
+            l = S.wid >> 1;
+            j = S.sta;
+            if ((j + S.wid) > R.mnc) {
+                int const usefullsize = R.mnc - j + 1;
+                l = (usefullsize > 0) ? (usefullsize >> 1) : 0;
+            }
+        }
+        if (s <= LH_SFBMAX)
+            Q.sfb_f[s] = step;
+    }
+    maxw = (int) lh_wave_max_u32(fresh ? (unsigned) (2 * l) : 0u);
+    LH_WAVE_SYNC();
+    {
+        float   stp[5], p43[10];
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            unsigned const q0 = S.pw[k] & 0xffffu, q1 = S.pw[k] >> 16;
+            stp[k] = Q.sfb_f[S.bq[k] < LH_SFBMAX ? S.bq[k] : LH_SFBMAX];
+            p43[2 * k] = qt->pow43h[q0 & 255u];
+            p43[2 * k + 1] = qt->pow43h[q1 & 255u];
+            big |= (int) ((q0 | q1) >> 8);
+        }
+        if (lh_ballot(big != 0)) {
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                unsigned const q0 = S.pw[k] & 0xffffu, q1 = S.pw[k] >> 16;
+                if (q0 >= 256u)
+                    p43[2 * k] = T->pow43[q0];
+                if (q1 >= 256u)
+                    p43[2 * k + 1] = T->pow43[q1];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            int const p = c.lane + 64 * k;
+            float const t0 = S.ax[2 * k] - p43[2 * k] * stp[k];
+            float const t1 = S.ax[2 * k + 1] - p43[2 * k + 1] * stp[k];
+            lh_f32x2 v;
+            v.x = t0 * t0;
+            v.y = t1 * t1;
+            if (k < 4 || p < 288)
+                ((lh_f32x2 *) sq)[p] = v;
+        }
+    }
+    LH_WAVE_SYNC();
+    LH_PA(14, t_cn0);
+    {
+        int const n = 2 * l;
+        int const jj = (j < 576) ? j : 0;
+        const lh_f32x2 *sq2 = (const lh_f32x2 *) sq;
+        const lh_f32x2 *zero = (const lh_f32x2 *) Q.zero2;
+        for (int k0 = 0; k0 < maxw; k0 += 8) {
+            lh_f32x2 t[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const lh_f32x2 *src = (k0 + 2 * u < n) ? &sq2[(jj + k0) / 2 + u] : zero;
+                t[u] = *src;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                noise += t[u].x;
+                noise += t[u].y;
+            }
+        }
+    }
+    LH_PA(15, t_cn0);
+    if (s < R.psymax) {
+        float   distort_;
+        if (!fresh) {
+            distort_ = S.rxmin * S.pnnoise;
+            noise = S.pnlog;
+        }
+        else {
+            S.pnstep = st;
+            S.pnnoise = noise;
+            distort_ = S.rxmin * noise;
+            noise = (float) (lh_fast_log2(T->log_table, (distort_ > 1E-20f) ? distort_ : 1E-20f)
+                             * LH_LOG2_OVER_LOG10);
+            S.pnlog = noise;
+        }
+        S.dist = distort_;
+        noise_s = noise;
+    }
+    R.pn_global_gain = g.global_gain;
+    LH_PA(16, t_cn0);
+    {
+        int const mine = (s < R.psymax);
+        int     tmp = 0;
+        if (mine && noise_s > 0.0f) {
+            tmp = (int) (noise_s * 10 + .5);
+            if (tmp < 1)
+                tmp = 1;
+        }
+        res.over_count = lh_popc64(lh_ballot(mine && noise_s > 0.0f));
+        res.over_SSD = (int) lh_wave_sum_u32((unsigned) (tmp * tmp));
+        res.max_noise = lh_wave_max_f32(mine ? noise_s : -20.0f);
+        res.tot_noise = 0;      /* not read by the comparator of this path (quant_comp 9) */
+        res.over_noise = 0;
+    }
+    LH_PA(17, t_cn0);
+}
+
+/* multiply the lines of the bands in `bands' by factor (xrpow only grows, so the lane's maximum
+ * follows) */
+LH_DEVFN void
+lq_scale_mask(LhQS & S, uint64_t bands, float factor)
+{
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        int const on = lq_bit(bands, S.bnd[k]);
+        float const v0 = on ? S.xp[2 * k] * factor : S.xp[2 * k];
+        float const v1 = on ? S.xp[2 * k + 1] * factor : S.xp[2 * k + 1];
+        S.xp[2 * k] = v0;
+        S.xp[2 * k + 1] = v1;
+        S.lmax = v0 > S.lmax ? v0 : S.lmax;
+        S.lmax = v1 > S.lmax ? v1 : S.lmax;
+    }
+}
+
+/* the same with a factor per band: flag / fac are lane = band values, distributed through LDS */
+LH_DEVFN void
+lq_scale_bands(const LhCtx & c, LhQS & S, LhChanLds & Q, int flag, float fac)
+{
+    LH_WAVE_SYNC();
+    if (c.lane <= LH_SFBMAX)
+        Q.sfb_f[c.lane] = flag ? fac : 1.0f;
+    LH_WAVE_SYNC();
+    {
+        uint64_t const bands = lh_ballot(c.lane <= LH_SFBMAX && flag);
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            int const on = lq_bit(bands, S.bnd[k]);
+            float const f = Q.sfb_f[S.bnd[k] < LH_SFBMAX ? S.bnd[k] : LH_SFBMAX];
+            float const v0 = on ? S.xp[2 * k] * f : S.xp[2 * k];
+            float const v1 = on ? S.xp[2 * k + 1] * f : S.xp[2 * k + 1];
+            S.xp[2 * k] = v0;
+            S.xp[2 * k + 1] = v1;
+            S.lmax = v0 > S.lmax ? v0 : S.lmax;
+            S.lmax = v1 > S.lmax ? v1 : S.lmax;
+        }
+    }
+    LH_WAVE_SYNC();
+}
+
+/* reference quantize.c:720-796 */
+LH_DEVFN void
+lq_amp_scalefac_bands(const LhCtx & c, LhQS & S, const LhQR & R, LhGrR & g)
+{
+    float   ifqstep34, trigger;
+    int     last_visited, ret_before = 0;
+    int const s = c.lane;
+    float const dist = (s < R.sfbmax) ? S.dist : 0.0f;
+    uint64_t cand;
+    if (g.scalefac_scale == 0)
+        ifqstep34 = (float) 1.29683955465100964055;
+    else
+        ifqstep34 = (float) 1.68179283050742922612;
+    trigger = lh_u32_as_f32(lh_wave_max_u32(lh_f32_as_u32(dist > 0.0f ? dist : 0.0f)));
+    switch (c.ns_amp) {
+    case 2:
+        break;
+    case 1:
+        if (trigger > 1.0)
+            trigger = (float) sqrt((double) trigger);
+        else
+            trigger = (float) (trigger * .95);
+        break;
+    case 0:
+    default:
+        if (trigger > 1.0)
+            trigger = 1.0;
+        else
+            trigger = (float) (trigger * .95);
+        break;
+    }
+    cand = lh_ballot(s < R.sfbmax && !(dist < trigger));
+    last_visited = R.sfbmax - 1;
+    if (c.ns_amp == 2) {
+        if (cand) {
+            int const sfb = lh_ffs64(cand);
+            last_visited = sfb;
+            if (R.substep_shaping & 2) {
+                uint64_t const ph = lh_ballot(s < R.sfbmax && S.ph);
+                if (lq_bit(ph, sfb))
+                    ret_before = 1;
+            }
+        }
+    }
+    {
+        int     amplify = 0;
+        if (s < R.sfbmax && s <= last_visited && lq_bit(cand, s)) {
+            amplify = 1;
+            if (R.substep_shaping & 2)
+                S.ph = !S.ph;
+            if (ret_before && s == last_visited)
+                amplify = 0;
+            if (amplify)
+                S.sfw++;
+        }
+        lq_scale_mask(S, lh_ballot(amplify), ifqstep34);
+    }
+}
+
+/* reference takehiro.c:1135-1188 (MPEG-1) on the working scalefactors */
+LH_DEVFN int
+lq_scale_bitcount(const LhCtx & c, LhQS & S, const LhQR & R, LhGrR & g)
+{
+    const LhQTabs *qt = LH_QT;
+    int     k, max_slen1, max_slen2;
+    int     v = (c.lane < R.sfbmax) ? S.sfw : 0;
+    if (R.block_type != LH_SHORT_TYPE) {
+        if (!g.preflag) {
+            int const inr = (c.lane >= 11 && c.lane < LH_SBPSY_L);
+            uint64_t const below = lh_ballot(inr && v < S.pre);
+            if (below == 0) {
+                g.preflag = 1;
+                if (inr) {
+                    v -= S.pre;
+                    S.sfw = v;
+                }
+            }
+        }
+    }
+    (void) qt;
+    max_slen1 = (int) lh_wave_max_u32((c.lane < R.sfbdivide && v > 0) ? (unsigned) v : 0u);
+    max_slen2 = (int) lh_wave_max_u32((c.lane >= R.sfbdivide && c.lane < R.sfbmax && v > 0) ? (unsigned) v : 0u);
+    g.part2_length = LH_LARGE_BITS;
+    k = c.lane & 15;
+    {
+        unsigned key = 0xffffffffu, best;
+        int const s1 = (int) ((0x4433322211130000ull >> (4 * k)) & 15u);
+        int const s2 = (int) ((0x3232132132103210ull >> (4 * k)) & 15u);
+        int const sz = (R.block_type == LH_SHORT_TYPE) ? 18 * (s1 + s2) : 11 * s1 + 10 * s2;
+        if (c.lane < 16 && max_slen1 < (1 << s1) && max_slen2 < (1 << s2))
+            key = ((unsigned) sz << 8) | (unsigned) k;
+        best = lh_wave_min_u32(key);
+        if (best != 0xffffffffu) {
+            g.part2_length = (int) (best >> 8);
+            g.scalefac_compress = (int) (best & 255u);
+        }
+    }
+    return g.part2_length == LH_LARGE_BITS;
+}
+
+/* reference quantize.c:808-833 */
+LH_DEVFN void
+lq_inc_scalefac_scale(const LhCtx & c, LhQS & S, const LhQR & R, LhGrR & g)
+{
+    float const ifqstep34 = (float) 1.29683955465100964055;
+    int     amp = 0;
+    if (c.lane < R.sfbmax) {
+        int     s = S.sfw;
+        if (g.preflag)
+            s += S.pre;
+        if (s & 1) {
+            s++;
+            amp = 1;
+        }
+        S.sfw = s >> 1;
+    }
+    g.preflag = 0;
+    g.scalefac_scale = 1;
+    lq_scale_mask(S, lh_ballot(amp), ifqstep34);
+}
+
+/* reference quantize.c:847-921 (short blocks) */
+LH_DEVFN int
+lq_inc_subblock_gain(const LhCtx & c, LhQS & S, LhChanLds & Q, const LhQR & R, LhGrR & g)
+{
+    const LhTables *T = c.T;
+    int const k = c.lane;
+    if (lh_ballot(k < R.sfb_lmax && S.sfw >= 16))
+        return 1;
+    for (int window = 0; window < 3; window++) {
+        int const mine = (k >= R.sfb_lmax + window && k < R.sfbmax && ((k - R.sfb_lmax - window) % 3) == 0);
+        int const s1 = (int) lh_wave_max_u32((mine && k < R.sfbdivide && S.sfw > 0) ? (unsigned) S.sfw : 0u);
+        int const s2 = (int) lh_wave_max_u32((mine && k >= R.sfbdivide && S.sfw > 0) ? (unsigned) S.sfw : 0u);
+        /* the band above the last scalefactor band of this window (the reference's loop variable after
+         * its second loop): the first index >= sfbdivide of the form sfb_lmax + window + 3 n that is
+         * >= sfbmax */
+        int     top = R.sfb_lmax + window;
+        while (top < R.sfbmax)
+            top += 3;
+        if (s1 < 16 && s2 < 8)
+            continue;
+        if (lh_sbg(g, window) >= 7)
+            return 1;
+        g.subblock_gain[0] += (window == 0);
+        g.subblock_gain[1] += (window == 1);
+        g.subblock_gain[2] += (window == 2);
+        {
+            int     mode = 0;
+            float   f = 1.0f;
+            if (mine) {
+                int     s = S.sfw;
+                s = s - (4 >> g.scalefac_scale);
+                if (s >= 0)
+                    S.sfw = s;
+                else {
+                    int const gain = 210 + (s << (g.scalefac_scale + 1));
+                    S.sfw = 0;
+                    mode = 1;
+                    f = T->ipow20[gain];
+                }
+            }
+            else if (k == top && k <= LH_SFBMAX) {
+                mode = 1;
+                f = T->ipow20[202];
+            }
+            lq_scale_bands(c, S, Q, mode, f);
+        }
+    }
+    return 0;
+}
+
+/* reference quantize.c:540-551 */
+LH_DEVFN int
+lq_loop_break(const LhCtx & c, const LhQS & S, const LhQR & R, const LhGrR & g)
+{
+    int const s = c.lane;
+    int const z = (s < R.sfbmax) && (S.sfw + lh_sbg(g, S.win) == 0);
+    return lh_ballot(z) == 0;
+}
+
+/* reference quantize.c:940-988 */
+LH_DEVFN int
+lq_balance_noise(const LhCtx & c, LhQS & S, LhChanLds & Q, const LhQR & R, LhGrR & g)
+{
+    int     status;
+    LH_PT(t_bal);
+    lq_amp_scalefac_bands(c, S, R, g);
+    LH_PA(37, t_bal);
+    status = lq_loop_break(c, S, R, g);
+    LH_PA(38, t_bal);
+    if (status)
+        return 0;
+    status = lq_scale_bitcount(c, S, R, g);
+    LH_PA(39, t_bal);
+    if (!status)
+        return 1;
+    if (c.ns > 1) {
+        S.ph = 0;
+        if (!g.scalefac_scale) {
+            lq_inc_scalefac_scale(c, S, R, g);
+            status = 0;
+        }
+        else {
+            if (R.block_type == LH_SHORT_TYPE && c.subblock_gain > 0)
+                status = lq_inc_subblock_gain(c, S, Q, R, g) || lq_loop_break(c, S, R, g);
+        }
+    }
+    if (!status)
+        status = lq_scale_bitcount(c, S, R, g);
+    return !status;
+}
+
+/* reference quantize.c:367-429 */
+LH_DEVFN int
+lq_bin_search(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q, int desired_rate, int ch)
+{
+    int     nBits;
+    int     CurrentStep = lh_uni_i(c.st->CurrentStep[ch]);
+    int     flag_GoneOver = 0;
+    int const start = lh_uni_i(c.st->OldValue[ch]);
+    int     Direction = 0;
+    g.global_gain = start;
+    desired_rate -= g.part2_length;
+    for (;;) {
+        int     step;
+        nBits = lq_count_bits < 0 > (c, S, R, g, Q);
+        if (CurrentStep == 1 || nBits == desired_rate)
+            break;
+        if (nBits > desired_rate) {
+            if (Direction == 2)
+                flag_GoneOver = 1;
+            if (flag_GoneOver)
+                CurrentStep /= 2;
+            Direction = 1;
+            step = CurrentStep;
+        }
+        else {
+            if (Direction == 1)
+                flag_GoneOver = 1;
+            if (flag_GoneOver)
+                CurrentStep /= 2;
+            Direction = 2;
+            step = -CurrentStep;
+        }
+        g.global_gain += step;
+        if (g.global_gain < 0) {
+            g.global_gain = 0;
+            flag_GoneOver = 1;
+        }
+        if (g.global_gain > 255) {
+            g.global_gain = 255;
+            flag_GoneOver = 1;
+        }
+    }
+    while (nBits > desired_rate && g.global_gain < 255) {
+        g.global_gain++;
+        nBits = lq_count_bits < 0 > (c, S, R, g, Q);
+    }
+    if (c.lane == 0) {
+        c.st->CurrentStep[ch] = (start - g.global_gain >= 4) ? 4 : 2;
+        c.st->OldValue[ch] = g.global_gain;
+    }
+    g.part2_3_length = nBits;
+    return nBits;
+}
+
+/* reference quantize.c:1010-1197; gb = cod_info.  On return the best image and its scalefactors
+ * are in Q.ix[0] / Q.sf[0]. */
+LH_DEVFN int
+lq_outer_loop(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & gb, const float *xr, int ch, int targ_bits)
+{
+    LhQS    S;
+    LhGrR   gw;
+    LhNoiseRes best_noise_info;
+    int     huff_bits, better, age;
+    int     best_part2_3_length = 9999999;
+
+    lq_load(c, S, Q, R, xr);
+    R.s_mnc = lh_uni_i((int) Q.sfb_of_line[R.mnc]);
+    {
+        LH_PT(t_bs);
+        (void) lq_bin_search(c, S, R, gb, Q, targ_bits, ch);
+        LH_PA(7, t_bs);
+    }
+    best_noise_info.over_count = 100;
+    if (c.ns) {
+        R.pn_global_gain = 0;
+        R.pn_sfb_count1 = 0;
+        lq_calc_noise(c, S, R, gb, Q, best_noise_info);
+        best_noise_info.bits = gb.part2_3_length;
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+            S.pb[k] = S.pw[k];
+        S.sfbest = S.sfw;
+        gw = gb;
+        age = 0;
+        do {
+            LhNoiseRes noise_info;
+            int const search_limit = (R.substep_shaping & 2) ? 20 : 3;
+            int     maxggain = 255;
+            {
+                LH_PT(t_bn);
+                int const bn = lq_balance_noise(c, S, Q, R, gw);
+                LH_PA(8, t_bn);
+                if (bn == 0)
+                    break;
+            }
+            if (gw.scalefac_scale)
+                maxggain = 254;
+            huff_bits = targ_bits - gw.part2_length;
+            if (huff_bits <= 0)
+                break;
+            while ((gw.part2_3_length = lq_count_bits < 1 > (c, S, R, gw, Q)) > huff_bits && gw.global_gain <= maxggain)
+                gw.global_gain++;
+            if (gw.global_gain > maxggain)
+                break;
+            if (best_noise_info.over_count == 0) {
+                while ((gw.part2_3_length = lq_count_bits < 1 > (c, S, R, gw, Q)) > best_part2_3_length
+                       && gw.global_gain <= maxggain)
+                    gw.global_gain++;
+                if (gw.global_gain > maxggain)
+                    break;
+            }
+            {
+                LH_PT(t_cn);
+                lq_calc_noise(c, S, R, gw, Q, noise_info);
+                LH_PA(9, t_cn);
+            }
+            noise_info.bits = gw.part2_3_length;
+            better = lh_quant_compare(best_noise_info, noise_info);
+            if (better) {
+                best_part2_3_length = gb.part2_3_length;
+                best_noise_info = noise_info;
+#pragma unroll
+                for (int k = 0; k < 5; k++)
+                    S.pb[k] = S.pw[k];
+                S.sfbest = S.sfw;
+                gb = gw;
+                age = 0;
+            }
+            else {
+                if (c.full_outer_loop == 0) {
+                    if (++age > search_limit && best_noise_info.over_count == 0)
+                        break;
+                }
+            }
+        }
+        while ((gw.global_gain + gw.scalefac_scale) < 255);
+    }
+    else {
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+            S.pb[k] = S.pw[k];
+        S.sfbest = S.sfw;
+    }
+    /* hand the result to the finishing stages through the LDS image */
+    LH_WAVE_SYNC();
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        int const p = c.lane + 64 * k;
+        if (k < 4 || p < 288)
+            ((uint32_t *) Q.ix[0])[p] = S.pb[k];
+    }
+    if (c.lane <= LH_SFBMAX)
+        Q.sf[0][c.lane] = S.sfbest;
+    LH_WAVE_SYNC();
+    return best_noise_info.over_count;
+}
+
+/* out-of-line entry (own register allocation): R / g travel through the wave's LDS slot */
+LH_STAGEFN void
+lq_outer_loop_stage(int qch, int gr, int targ_bits)
+{
+    LhCtx const c = lh_ctx_load();
+    LhQR    R = lh_uniform(lh_lds.rg[qch].R);
+    LhGrR   g = lh_uniform(lh_lds.rg[qch].g);
+    (void) lq_outer_loop(c, lh_lds.u.quant.ch[qch], R, g, lh_lds.xr[qch][lh_uni_i(gr)], qch, lh_uni_i(targ_bits));
+    lh_rg_put(c, R, g);
+}
+
+#endif

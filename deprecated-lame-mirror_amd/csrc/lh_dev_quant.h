@@ -1243,6 +1243,7 @@ lh_init_outer_loop_body(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, flo
     R.pn_sfb_count1 = 0;
     R.substep_shaping = substep;
     R.ath_over = 0;
+    R.s_mnc = 0;
     LH_WAVE_SYNC();
     if (c.lane <= LH_SFBMAX) {
         int const s = c.lane;

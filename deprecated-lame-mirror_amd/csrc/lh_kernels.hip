@@ -36,6 +36,7 @@ extern "C" { int lh_emu_poison_lds = 0; }
 #include "lh_dev_psy.h"
 #include "lh_dev_mdct.h"
 #include "lh_dev_quant.h"
+#include "lh_dev_qloop.h"
 
 /* reference encoder.c:56-137, wave-uniform */
 LH_DEVFN void
@@ -406,7 +407,10 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo)
                 LH_PT(t_ol);
                 if (abr && !R.ath_over)
                     targ_bits[ch] = analog_silence_bits;    /* reference quantize.c:1953-1954 */
-                (void) lh_outer_loop(c, Q, R, g, xr, ch, targ_bits[ch]);
+                lh_rg_put(c, R, g);
+                lq_outer_loop_stage(ch, gr, targ_bits[ch]);
+                R = lh_uniform(L.rg[ch].R);
+                g = lh_uniform(L.rg[ch].g);
                 LH_PA(5, t_ol);
             }
             LH_PT(t_fin);
