@@ -33,6 +33,13 @@
 #define LH_PC(idx) do { } while (0)
 #endif
 
+/* development aid: section markers in the generated assembly (tools/isa_sections.py) */
+#if defined(LH_MARK) && !defined(LH_EMU)
+#define LQ_MARK(name) asm volatile("; LQMARK " name)
+#else
+#define LQ_MARK(name) do { } while (0)
+#endif
+
 LH_DEVFN float
 lh_fabsf(float x)
 {
@@ -145,19 +152,39 @@ struct LhNoiseRes {             /* calc_noise_result */
 /* LDS image of one channel's quantiser working set.  Arrays indexed by band are
  * written by lane == band only (then LH_WAVE_SYNC); line arrays by the lane
  * owning the line. */
+/* Huffman code lengths for the CBR search loop (lh_dev_qloop.h): 16 x 16 grids of dwords indexed
+ * x * 16 + y, each entry = the lengths of a region's (up to) three candidate tables, 10 bits each.
+ * Two big grids (ESC tables 16.. / 24.. + count of values == 15; tables 13 / 14 / 15) and one grid
+ * that holds the small alphabets side by side (LQ_ORG_*: cell of a group's (0,0)). */
+#define LQ_SMALL_CELLS 192
+#define LQ_ORG_T10  0           /* tables 10 / 11 / 12: rows 0..7, columns 0..7 */
+#define LQ_ORG_T7   8           /* tables 7 / 8 / 9: rows 0..5, columns 8..13 */
+#define LQ_ORG_ZERO 104         /* row 6, column 8: an all-zero cell (region maximum 0) */
+#define LQ_ORG_T5   128         /* tables 5 / 6: rows 8..11, columns 0..3 */
+#define LQ_ORG_T2   132         /* tables 2 / 3: rows 8..10, columns 4..6 */
+#define LQ_ORG_T1   136         /* table 1: rows 8..9, columns 8..9 */
+
 struct LhChanLds {
-    float   xrpow[576];
-    float   save_xrpow[576];
+    float   xrpow[576];         /* the CBR search keeps xrpow in registers and uses this as calc_noise's scratch */
+    union {
+        float   save_xrpow[576];        /* scratch of the VBR loop and of best_huffman_divide */
+        uint32_t hl3_big[2][256];       /* while the CBR search runs: [0] = ESC grid, [1] = tables 13..15 */
+    };
     int16_t ix[2][576];         /* [0] = best so far (cod_info), [1] = working copy (cod_info_w) */
     int     sf[2][LH_SFBMAX + 1];       /* scalefactors of the two images */
     int     width[LH_SFBMAX + 1], window[LH_SFBMAX + 1], start[LH_SFBMAX + 1];
     uint8_t sfb_of_line[576];
     float   l3_xmin[LH_SFBMAX + 1];
-    float   distort[LH_SFBMAX + 1];
-    /* calc_noise_data (reference quantize_pvt.h:75-82), per band */
-    int     pn_step[LH_SFBMAX + 1];
-    float   pn_noise[LH_SFBMAX + 1], pn_noise_log[LH_SFBMAX + 1];
-    int     pseudohalf[LH_SFBMAX + 1];
+    union {
+        struct {
+            float   distort[LH_SFBMAX + 1];
+            /* calc_noise_data (reference quantize_pvt.h:75-82), per band */
+            int     pn_step[LH_SFBMAX + 1];
+            float   pn_noise[LH_SFBMAX + 1], pn_noise_log[LH_SFBMAX + 1];
+            int     pseudohalf[LH_SFBMAX + 1];
+        };
+        uint32_t hl3_small[LQ_SMALL_CELLS];     /* while the CBR search runs (it keeps the five arrays in registers) */
+    };
     /* scratch */
     int     sfb_mode[LH_SFBMAX + 1];
     float   sfb_f[LH_SFBMAX + 1];
@@ -180,7 +207,8 @@ struct LhQTabs {
     uint8_t t32l[16], t33l[16];
     uint32_t t3233[16];         /* t32l << 16 | t33l */
     uint8_t pretab[24];
-    float   ipow20w[128];       /* ipow20[128..255]: the step sizes count_bits asks for almost always */
+    uint32_t ctabA[32], ctabB[32];      /* lh_dev_qloop.h: per class of a region maximum, the grid origin of its
+                                         * candidate tables / the tables and their linbits (lq_class_tabs) */
     float   pow43h[256];        /* heads of pow43 / adj43asm: nearly all quantised values are < 256 */
     float   adj43h[256];
 };

@@ -33,6 +33,7 @@ struct LhQS {
     uint32_t pb[5];             /* best image */
     int     bnd[5];             /* band of the pair (63: the slot holds no pair) */
     int     bq[5];              /* the same, but 63 as well when the pair lies above max_nonzero_coeff */
+    uint32_t vm[5];             /* all ones when the pair lies at or below max_nonzero_coeff, else 0 */
     float   lmax;               /* the lane's largest xrpow (xrpow_max = the maximum over the lanes) */
     /* lane = band */
     int     sfw, sfbest;        /* scalefactor: working, best */
@@ -42,6 +43,11 @@ struct LhQS {
     float   pnnoise, pnlog;
     float   dist;               /* distort[] of the working image */
     int     ph;                 /* pseudohalf */
+    /* lane = region (0..2): table_select of the working / best image */
+    int     tselw, tselb;
+    /* lane j = value for global_gain gbase + j: 1 / step size and the xrpow bound of count_bits */
+    float   istepv, thrv;
+    int     gbase;
 };
 
 LH_DEVFN int
@@ -58,10 +64,85 @@ lq_band_step(const LhQS & S, const LhGrR & g)
     return g.global_gain - ((S.sfw + pre) << (g.scalefac_scale + 1)) - lh_sbg(g, S.win) * 8;
 }
 
-/* load the granule into registers; Q.xrpow, Q.l3_xmin and the geometry arrays were written by
- * lh_init_outer_loop / lh_init_xrpow / lh_calc_xmin */
+/* ---- Huffman length grids (layout: LhChanLds in lh_dev_common.h) ---- */
+LH_DEVFN uint32_t
+lq_len3(int t, int n, int idx)
+{
+    /* lengths of tables t, t+1, t+2 at idx; n = how many of them are candidates (the others repeat
+     * the first, which a strict comparison never prefers) */
+    uint32_t const a = lh_ht_len[lh_ht_off(t) + idx];
+    uint32_t const b = (n >= 2) ? lh_ht_len[lh_ht_off(t + 1) + idx] : a;
+    uint32_t const cc = (n >= 3) ? lh_ht_len[lh_ht_off(t + 2) + idx] : a;
+    return a | (b << 10) | (cc << 20);
+}
+
+LH_DEVFN uint32_t
+lq_small_cell(int cell)
+{
+    int const row = cell >> 4, col = cell & 15;
+    if (row < 8 && col < 8)
+        return lq_len3(10, 3, row * 8 + col);
+    if (row < 6 && col >= 8 && col < 14)
+        return lq_len3(7, 3, row * 6 + (col - 8));
+    if (row >= 8 && row < 12 && col < 4)
+        return lq_len3(5, 2, (row - 8) * 4 + col);
+    if (row >= 8 && row < 11 && col >= 4 && col < 7)
+        return lq_len3(2, 2, (row - 8) * 3 + (col - 4));
+    if (row >= 8 && row < 10 && col >= 8 && col < 10)
+        return lq_len3(1, 1, (row - 8) * 2 + (col - 8));
+    return 0u;
+}
+
+/* per class of a region maximum (0..15: the maximum itself; 16 + bit length of max - 15 for the ESC
+ * tables): A = byte offset of the candidate group's (0,0) cell inside LhChanLds | esc << 31,
+ * B = first table | second table << 8 | linbits of the first << 16 | of the second << 24
+ * (reference takehiro.c:618-647, huf_tbl_noESC; the two linear searches over linbits) */
 LH_DEVFN void
-lq_load(const LhCtx & c, LhQS & S, const LhChanLds & Q, const LhQR & R, const float *xr)
+lq_class_tabs(int cls, uint32_t *A, uint32_t *B)
+{
+    uint32_t const big = (uint32_t) __builtin_offsetof(LhChanLds, hl3_big);
+    uint32_t const small = (uint32_t) __builtin_offsetof(LhChanLds, hl3_small);
+    if (cls <= 15) {
+        int const t1 = (cls == 0) ? 0 : lh_huf_noESC((unsigned) cls);
+        uint32_t org;
+        switch (t1) {
+        case 0: org = small + 4 * LQ_ORG_ZERO; break;
+        case 1: org = small + 4 * LQ_ORG_T1; break;
+        case 2: org = small + 4 * LQ_ORG_T2; break;
+        case 5: org = small + 4 * LQ_ORG_T5; break;
+        case 7: org = small + 4 * LQ_ORG_T7; break;
+        case 10: org = small + 4 * LQ_ORG_T10; break;
+        default: org = big + 1024; break;
+        }
+        *A = org;
+        *B = (uint32_t) t1 | ((uint32_t) (t1 + 1) << 8);
+    }
+    else {
+        int const blen = cls - 16;      /* 1..13 */
+        int const t24 = (int) ((0x7777665432100000ull >> (4 * (blen & 15))) & 15u);
+        int const t16 = (int) ((0x7777766554432100ull >> (4 * (blen & 15))) & 15u);
+        int const choice2 = 24 + t24, choice = 16 + (t16 > t24 ? t16 : t24);
+        *A = big | 0x80000000u;
+        *B = (uint32_t) choice | ((uint32_t) choice2 << 8) | (lh_ht_xlen_c(choice) << 16) | (lh_ht_xlen_c(choice2) << 24);
+    }
+}
+
+/* 1 / step and xrpow bound for the gains gbase .. gbase + 63, one per lane */
+LH_DEVFN void
+lq_gain_window(const LhCtx & c, LhQS & S, int gain)
+{
+    int     b = gain - 24;
+    b = b < 0 ? 0 : (b > 192 ? 192 : b);
+    S.gbase = b;
+    S.istepv = c.T->ipow20[b + c.lane];
+    S.thrv = (LH_IXMAX) / S.istepv;
+}
+
+/* load the granule into registers; Q.xrpow, Q.l3_xmin and the geometry arrays were written by
+ * lh_init_outer_loop / lh_init_xrpow / lh_calc_xmin.  Then the arrays the search does not need in
+ * LDS make room for the Huffman length grids. */
+LH_DEVFN void
+lq_load(const LhCtx & c, LhQS & S, LhChanLds & Q, const LhQR & R, const LhGrR & g, const float *xr)
 {
     const LhQTabs *qt = LH_QT;
     int const pm = R.mnc >> 1;
@@ -81,6 +162,7 @@ lq_load(const LhCtx & c, LhQS & S, const LhChanLds & Q, const LhQR & R, const fl
         S.xp[2 * k + 1] = ok ? x.y : 0.0f;
         S.bnd[k] = ok ? b : 63;
         S.bq[k] = (ok && p <= pm) ? b : 63;
+        S.vm[k] = (ok && p <= pm) ? 0xffffffffu : 0u;
         S.pw[k] = 0u;
         S.pb[k] = 0u;
         mx = S.xp[2 * k] > mx ? S.xp[2 * k] : mx;
@@ -102,81 +184,103 @@ lq_load(const LhCtx & c, LhQS & S, const LhChanLds & Q, const LhQR & R, const fl
         S.dist = 0;
         S.ph = Q.pseudohalf[s];
     }
+    S.tselw = (c.lane == 0) ? g.table_select[0] : (c.lane == 1) ? g.table_select[1] : g.table_select[2];
+    S.tselb = S.tselw;
+    S.gbase = -100000;         /* no window yet */
+    S.istepv = 0;
+    S.thrv = 0;
+    LH_WAVE_SYNC();
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int const i = c.lane + 64 * j;
+        uint32_t const e = lh_largetbl[i];
+        Q.hl3_big[0][i] = (e >> 16) | ((e & 0xffffu) << 10)
+            | ((uint32_t) (((i >> 4) == 15) + ((i & 15) == 15)) << 20);
+        Q.hl3_big[1][i] = lq_len3(13, 3, i);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+        Q.hl3_small[c.lane + 64 * j] = lq_small_cell(c.lane + 64 * j);
+    LH_WAVE_SYNC();
 }
 
 /* reference takehiro.c:281-414 (quantize_xrpow) + 654-801 (noquant_count_bits, count_bits) on the
- * working image */
+ * working image.  Returns the bit count; g's count fields follow except table_select, which lives
+ * in S.tselw (lane = region). */
 template < int USE_PREV > LH_DEVFN int
 lq_count_bits(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
 {
     LH_PC(10);
     LH_PT(t_cb);
+    LQ_MARK("cb_begin");
     const LhTables *T = c.T;
     const LhQTabs *qt = LH_QT;
     int const lane = c.lane;
     float   istep;
-    if (g.global_gain >= 128)
-        istep = lh_uni_f(qt->ipow20w[g.global_gain - 128]);
-    else
-        istep = lh_uni_f(T->ipow20[g.global_gain]);
-    if (lh_ballot(S.lmax > (LH_IXMAX) / istep))
-        return LH_LARGE_BITS;
-    /* ---- which bands are quantised, and how (lane = band) ---- */
-    uint64_t ncmask, m01mask = 0;
-    int     zero_mnc = 0, plain;
-    int const pm = R.mnc >> 1;
+    if ((unsigned) (g.global_gain - S.gbase) >= 64u)
+        lq_gain_window(c, S, g.global_gain);
+    istep = lh_u32_as_f32(lh_bcast_u32(lh_f32_as_u32(S.istepv), g.global_gain - S.gbase));
     {
+        float const thr = lh_u32_as_f32(lh_bcast_u32(lh_f32_as_u32(S.thrv), g.global_gain - S.gbase));
+        if (lh_ballot(S.lmax > thr))
+            return LH_LARGE_BITS;
+    }
+    /* ---- which bands are quantised, and how (lane = band) ---- */
+    uint64_t ncmask = 0, m01mask = 0;
+    int     zero_mnc = 0, plain = 1;
+    int const pm = R.mnc >> 1;
+    if (USE_PREV && (g.global_gain == R.pn_global_gain || R.pn_sfb_count1 > 0)) {
         int const sfbmax = (R.block_type == LH_SHORT_TYPE) ? 38 : 21;
-        int const prev_data_use = (USE_PREV && (g.global_gain == R.pn_global_gain));
+        int const prev_data_use = (g.global_gain == R.pn_global_gain);
         uint64_t const all = (2ull << sfbmax) - 1ull;
-        if (USE_PREV && (prev_data_use || R.pn_sfb_count1 > 0)) {
-            int const s = lane;
-            int const step = lq_band_step(S, g);
-            int const cached = prev_data_use && (S.pnstep == step);
-            /* the band that holds line max_nonzero_coeff never takes the 0/1 comparator (see
-             * lh_count_bits in lh_dev_quant.h) */
-            int const m01 = R.pn_sfb_count1 > 0 && s >= R.pn_sfb_count1 && S.pnstep > 0 && step >= S.pnstep
-                && s != R.s_mnc;
-            ncmask = lh_ballot(s <= sfbmax && !cached);
-            m01mask = lh_ballot(s <= sfbmax && m01);
-            {
-                int const cached_m = !lq_bit(ncmask, R.s_mnc);
-                int const later = (R.s_mnc < 63) ? ((ncmask >> (R.s_mnc + 1)) != 0) : 0;
-                zero_mnc = cached_m && later;
-            }
+        int const s = lane;
+        int const step = lq_band_step(S, g);
+        int const cached = prev_data_use && (S.pnstep == step);
+        /* the band that holds line max_nonzero_coeff never takes the 0/1 comparator (see
+         * lh_count_bits in lh_dev_quant.h) */
+        int const m01 = R.pn_sfb_count1 > 0 && s >= R.pn_sfb_count1 && S.pnstep > 0 && step >= S.pnstep
+            && s != R.s_mnc;
+        ncmask = lh_ballot(s <= sfbmax && !cached);
+        m01mask = lh_ballot(s <= sfbmax && m01);
+        {
+            int const cached_m = !lq_bit(ncmask, R.s_mnc);
+            int const later = (R.s_mnc < 63) ? ((ncmask >> (R.s_mnc + 1)) != 0) : 0;
+            zero_mnc = cached_m && later;
         }
-        else
-            ncmask = all;
         plain = (ncmask == all) && (m01mask == 0);
     }
     LH_PA(18, t_cb);
-    /* ---- quantise: all pairs, straight line; the selection follows ---- */
+    LQ_MARK("cb_quant");
+    /* ---- quantise: all pairs, straight line; the selection follows.  The first rounding is a
+     * float addition: (float) ((double) x + 2^23) and x + 2^23f agree for every float x >= 0
+     * (tests/test_quantizer_identity.py) ---- */
     {
         uint32_t nq[5];
-        int     anybig = 0;
+        uint32_t bmax = 0;
 #pragma unroll
         for (int k = 0; k < 5; k++) {
             float const a0 = istep * S.xp[2 * k], a1 = istep * S.xp[2 * k + 1];
-            double const d0 = (double) a0 + (double) LH_MAGIC_FLOAT, d1 = (double) a1 + (double) LH_MAGIC_FLOAT;
-            uint32_t const b0 = lh_f32_as_u32((float) d0), b1 = lh_f32_as_u32((float) d1);
+            uint32_t const b0 = lh_f32_as_u32(a0 + (float) LH_MAGIC_FLOAT), b1 = lh_f32_as_u32(a1 + (float) LH_MAGIC_FLOAT);
             float const j0 = qt->adj43h[b0 & 255u], j1 = qt->adj43h[b1 & 255u];
+            double const d0 = (double) a0 + (double) LH_MAGIC_FLOAT, d1 = (double) a1 + (double) LH_MAGIC_FLOAT;
             uint32_t const r0 = lh_f32_as_u32((float) (d0 + j0)), r1 = lh_f32_as_u32((float) (d1 + j1));
-            anybig |= (b0 > (uint32_t) LH_MAGIC_INT + 255u) | (b1 > (uint32_t) LH_MAGIC_INT + 255u);
-            nq[k] = (r0 & 0xffffu) | (r1 << 16);
+            bmax = b0 > bmax ? b0 : bmax;
+            bmax = b1 > bmax ? b1 : bmax;
+            nq[k] = ((r0 & 0xffffu) | (r1 << 16)) & S.vm[k];
         }
-        if (lh_ballot(anybig && 1)) {
+        if (lh_ballot(bmax > (uint32_t) LH_MAGIC_INT + 255u)) {
             /* rare: a quantised value >= 256, its rounding offset lives in HBM */
 #pragma unroll
             for (int k = 0; k < 5; k++) {
                 int const q0 = lh_quant_line(T, qt, istep, S.xp[2 * k]);
                 int const q1 = lh_quant_line(T, qt, istep, S.xp[2 * k + 1]);
-                nq[k] = (uint32_t) (q0 & 0xffff) | ((uint32_t) q1 << 16);
+                nq[k] = ((uint32_t) (q0 & 0xffff) | ((uint32_t) q1 << 16)) & S.vm[k];
             }
         }
         if (plain) {
 #pragma unroll
             for (int k = 0; k < 5; k++)
-                S.pw[k] = (S.bq[k] != 63) ? nq[k] : 0u;
+                S.pw[k] = nq[k];
         }
         else {
             float const compareval0 = (1.0f - 0.4054f) / istep;
@@ -210,13 +314,13 @@ lq_count_bits(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
         }
     }
     LH_PA(12, t_cb);
+    LQ_MARK("cb_count");
     /* ---- count ---- */
     {
         uint32_t *xbuf = (uint32_t *) Q.ix[1];
-        uint64_t mk[5];
         int     top_nz, top_big, i, bv, nquad, bits;
         int     e0, e1, e2, a1, a2;
-        unsigned quads = 0, sfbcnt_in = 0;
+        unsigned sfbcnt_in = 0;
         LH_PT(t_nq);
         if (USE_PREV)
             R.pn_sfb_count1 = 0;
@@ -227,26 +331,32 @@ lq_count_bits(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
             if (k < 4 || p < 288)
                 xbuf[p] = S.pw[k];
         }
+        {
+            /* highest non-zero pair + 1 and highest pair holding a value > 1 + 1: slots ascend, the
+             * last hit of a lane is its highest; then the maximum over the lanes */
+            uint32_t t[2] = { 0u, 0u };
 #pragma unroll
-        for (int k = 0; k < 5; k++)
-            mk[k] = lh_ballot(S.pw[k] != 0u);
-        top_nz = lh_top_of_masks(mk);
+            for (int k = 0; k < 5; k++) {
+                uint32_t const p1 = (uint32_t) (lane + 64 * k + 1);
+                t[0] = (S.pw[k] != 0u) ? p1 : t[0];
+                t[1] = ((S.pw[k] & 0xfffefffeu) != 0u) ? p1 : t[1];
+            }
+            lh_wave_max_n < 2 > (t);
+            top_nz = (int) t[0];
+            top_big = (int) t[1];
+        }
         i = 2 * top_nz;
         g.count1 = i;
-#pragma unroll
-        for (int k = 0; k < 5; k++)
-            mk[k] = lh_ballot((S.pw[k] & 0xfffefffeu) != 0u);
-        top_big = lh_top_of_masks(mk);
         nquad = (i - 2 * top_big) / 4;
         bv = i - 4 * nquad;
         g.big_values = bv;
         if (R.block_type == LH_SHORT_TYPE) {
-            a1 = 3 * (int) qt->sfb_s3;
+            a1 = 3 * lh_uni_i((int) qt->sfb_s3);
             a2 = bv;
         }
         else if (R.block_type == LH_NORM_TYPE) {
             if (bv > 0) {
-                uint32_t const pack = qt->bvpack[(bv >> 1) - 1];
+                uint32_t const pack = (uint32_t) lh_uni_i((int) qt->bvpack[(bv >> 1) - 1]);
                 g.region0_count = (int) (pack & 15u);
                 g.region1_count = (int) ((pack >> 4) & 15u);
                 a1 = (int) ((pack >> 8) & 1023u);
@@ -260,20 +370,23 @@ lq_count_bits(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
                 g.region0_count = 7;
                 g.region1_count = LH_SBMAX_L - 1 - 7 - 1;
             }
-            a1 = qt->sfb_l[7 + 1];
+            a1 = lh_uni_i((int) qt->sfb_l[7 + 1]);
             a2 = bv;
         }
         a1 = (a1 < bv) ? a1 : bv;
         a2 = (a2 < bv) ? a2 : bv;
-        e0 = a1 >> 1;
-        e1 = a2 >> 1;
+        e0 = lh_uni_i(a1 >> 1);
+        e1 = lh_uni_i(a2 >> 1);
         e2 = (R.block_type == LH_NORM_TYPE) ? (bv >> 1) : e1;
         if (USE_PREV && R.block_type == LH_NORM_TYPE)
             sfbcnt_in = (lane < LH_SBMAX_L + 1) ? qt->sfb_l[lane] : 576u;
         LH_PA(19, t_nq);
+        LQ_MARK("cb_quads");
         LH_WAVE_SYNC();
+        uint32_t red[7];        /* quads, then (a | b << 16) and c of the sums over p < e0, p < e1, p < e2 */
         {
             unsigned idx[3];
+            unsigned quads = 0;
 #pragma unroll
             for (int k = 0; k < 3; k++) {
                 int const qd = lane + 64 * k;
@@ -285,99 +398,104 @@ lq_count_bits(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
 #pragma unroll
             for (int k = 0; k < 3; k++)
                 quads += ((lane + 64 * k) < nquad) ? qt->t3233[idx[k]] : 0u;
+            red[0] = quads;
         }
         LH_PA(20, t_nq);
+        LQ_MARK("cb_max");
+        uint32_t m[3] = { 0u, 0u, 0u };
         {
-            unsigned m0 = 0, m1 = 0, m2 = 0;
-            unsigned w00, w01, w10, w11, w20, w21;
 #pragma unroll
             for (int k = 0; k < 5; k++) {
                 int const p = lane + 64 * k;
-                unsigned const lo = S.pw[k] & 0xffffu, hi = S.pw[k] >> 16;
-                unsigned const m = lo > hi ? lo : hi;
-                if (p < e0)
-                    m0 = m > m0 ? m : m0;
-                else if (p < e1)
-                    m1 = m > m1 ? m : m1;
-                else if (p < e2)
-                    m2 = m > m2 ? m : m2;
+                uint32_t const lo = S.pw[k] & 0xffffu, hi = S.pw[k] >> 16;
+                uint32_t const mx = lo > hi ? lo : hi;
+                int const in0 = p < e0, in1 = p < e1, in2 = p < e2;
+                uint32_t const c0 = in0 ? mx : 0u, c1 = (in1 && !in0) ? mx : 0u, c2 = (in2 && !in1) ? mx : 0u;
+                m[0] = c0 > m[0] ? c0 : m[0];
+                m[1] = c1 > m[1] ? c1 : m[1];
+                m[2] = c2 > m[2] ? c2 : m[2];
             }
-            m0 = lh_wave_max_u32(m0);
-            m1 = lh_wave_max_u32(m1);
-            m2 = lh_wave_max_u32(m2);
-            LH_PA(21, t_nq);
-            {
-                LhRegionLut l0, l1, l2;
-                l0.pa = qt->lut_pa[m0 < 16u ? m0 : 16u];
-                l0.pb = qt->lut_pb[m0 < 16u ? m0 : 16u];
-                l1.pa = qt->lut_pa[m1 < 16u ? m1 : 16u];
-                l1.pb = qt->lut_pb[m1 < 16u ? m1 : 16u];
-                l2.pa = qt->lut_pa[m2 < 16u ? m2 : 16u];
-                l2.pb = qt->lut_pb[m2 < 16u ? m2 : 16u];
-                unsigned v0[5], v1[5];
-                w00 = w01 = w10 = w11 = w20 = w21 = 0;
+            lh_wave_max_n < 3 > (m);
+        }
+        LH_PA(21, t_nq);
+        LQ_MARK("cb_lookup");
+        /* lane r < 3 works out region r's candidate tables; the grid origins go back to all lanes */
+        uint32_t PB, esc;
+        uint32_t G0, G1, G2;
+        {
+            uint32_t const mr = (lane == 0) ? m[0] : (lane == 1) ? m[1] : m[2];
+            uint32_t const d = mr - 15u;
+            uint32_t const cls = (mr > 15u) ? (uint32_t) (16 + 32 - lh_clz32(d)) : mr;
+            uint32_t const PA = qt->ctabA[cls & 31u];
+            PB = qt->ctabB[cls & 31u];
+            esc = PA >> 31;
+            G0 = lh_bcast_u32(PA, 0) & 0xffffu;
+            G1 = lh_bcast_u32(PA, 1) & 0xffffu;
+            G2 = lh_bcast_u32(PA, 2) & 0xffffu;
+        }
+        {
+            uint32_t acc0 = 0, acc1 = 0, acc2 = 0;
+            const char *qb = (const char *) &Q;
 #pragma unroll
-                for (int k = 0; k < 5; k++) {
-                    int const p = lane + 64 * k;
-                    uint32_t const pa = (p < e0) ? l0.pa : (p < e1) ? l1.pa : (p < e2) ? l2.pa : 2u;
-                    uint32_t const pb = (p < e0) ? l0.pb : (p < e1) ? l1.pb : (p < e2) ? l2.pb : 0u;
-                    unsigned const x = S.pw[k] & 0xffffu, y = S.pw[k] >> 16;
-                    unsigned const xc = x < 15u ? x : 15u, yc = y < 15u ? y : 15u;
-                    unsigned const ix_ = xc * (pa & 0xffu) + yc;
-                    unsigned const b1 = qt->ht_len[(pa >> 16) + ix_];
-                    unsigned const b2 = qt->ht_len[(pb & 0xffffu) + ix_];
-                    unsigned const b3 = qt->ht_len[(pb >> 16) + ix_];
-                    unsigned const e = qt->largetbl[ix_ & 255u];
-                    int const esc = (pa >> 8) & 1u;
-                    v0[k] = esc ? e : (b1 | (b2 << 16));
-                    v1[k] = esc ? (unsigned) (x >= 15u) + (unsigned) (y >= 15u) : b3;
-                }
-#pragma unroll
-                for (int k = 0; k < 5; k++) {
-                    int const p = lane + 64 * k;
-                    int const r0 = (p < e0), r1 = (p >= e0 && p < e1), r2 = (p >= e1 && p < e2);
-                    w00 += r0 ? v0[k] : 0u;
-                    w01 += r0 ? v1[k] : 0u;
-                    w10 += r1 ? v0[k] : 0u;
-                    w11 += r1 ? v1[k] : 0u;
-                    w20 += r2 ? v0[k] : 0u;
-                    w21 += r2 ? v1[k] : 0u;
-                }
+            for (int k = 0; k < 5; k++) {
+                int const p = lane + 64 * k;
+                int const in0 = p < e0, in1 = p < e1, in2 = p < e2;
+                uint32_t const cl = lh_pk_min_u16(S.pw[k], 0x000f000fu);
+                uint32_t const off = ((cl << 6) & 0x3c0u) | (cl >> 14);      /* (x * 16 + y) * 4 */
+                uint32_t const go = in0 ? G0 : (in1 ? G1 : G2);
+                uint32_t const v = *(const uint32_t *) (qb + go + off);
+                acc0 += in0 ? v : 0u;
+                acc1 += in1 ? v : 0u;
+                acc2 += in2 ? v : 0u;
             }
-            LH_PA(22, t_nq);
-            quads = lh_wave_sum_u32(quads);
-            w00 = lh_wave_sum_u32(w00);
-            w10 = lh_wave_sum_u32(w10);
-            w20 = lh_wave_sum_u32(w20);
-            {
-                unsigned const wa = lh_wave_sum_u32(w01 | (w11 << 16));
-                w21 = lh_wave_sum_u32(w21);
-                w01 = wa & 0xffffu;
-                w11 = wa >> 16;
+            red[1] = (acc0 & 0x3ffu) | (((acc0 >> 10) & 0x3ffu) << 16);
+            red[2] = acc0 >> 20;
+            red[3] = (acc1 & 0x3ffu) | (((acc1 >> 10) & 0x3ffu) << 16);
+            red[4] = acc1 >> 20;
+            red[5] = (acc2 & 0x3ffu) | (((acc2 >> 10) & 0x3ffu) << 16);
+            red[6] = acc2 >> 20;
+        }
+        LH_PA(22, t_nq);
+        LQ_MARK("cb_sums");
+        lh_wave_sum_n < 7 > (red);
+        LH_PA(23, t_nq);
+        LQ_MARK("cb_decide");
+        {
+            int const c1a = (int) (red[0] >> 16), c1b = (int) (red[0] & 0xffffu);
+            bits = c1a;
+            g.count1table_select = 0;
+            if (c1a > c1b) {
+                bits = c1b;
+                g.count1table_select = 1;
             }
-            LH_PA(23, t_nq);
-            {
-                int const c1a = (int) (quads >> 16), c1b = (int) (quads & 0xffffu);
-                bits = c1a;
-                g.count1table_select = 0;
-                if (c1a > c1b) {
-                    bits = c1b;
-                    g.count1table_select = 1;
-                }
-                g.count1bits = bits;
+            g.count1bits = bits;
+        }
+        {
+            /* lane r: choose_table of region r from its sums (reference takehiro.c:618-647) */
+            uint32_t const Lr = (lane == 0) ? red[1] : (lane == 1) ? (red[3] - red[1]) : (red[5] - red[3]);
+            uint32_t const Hr = (lane == 0) ? red[2] : (lane == 1) ? (red[4] - red[2]) : (red[6] - red[4]);
+            int const ex = (lane == 0) ? (0 < e0) : (lane == 1) ? (e0 < e1) : (e1 < e2);
+            uint32_t const a = Lr & 0xffffu, b = Lr >> 16;
+            uint32_t const tA = PB & 31u, tB = (PB >> 8) & 31u, lin1 = (PB >> 16) & 15u, lin2 = (PB >> 24) & 15u;
+            uint32_t const a2_ = a + Hr * lin1, b2_ = b + Hr * lin2, c2_ = esc ? 0x7fffffffu : Hr;
+            uint32_t best = a2_, t = tA;
+            if (a2_ > b2_) {
+                best = b2_;
+                t = tB;
             }
-            if (bv != 0) {
-                if (e1 < e2)
-                    g.table_select[2] = lh_region_decide(m2, w20, w21, &bits);
-                if (0 < e0)
-                    g.table_select[0] = lh_region_decide(m0, w00, w01, &bits);
-                if (e0 < e1)
-                    g.table_select[1] = lh_region_decide(m1, w10, w11, &bits);
+            if (best > c2_) {
+                best = c2_;
+                t = tA + 2u;
             }
+            if (lane < 3 && ex)
+                S.tselw = (int) t;
+            best = (lane < 3 && ex) ? best : 0u;
+            bits += (int) (lh_bcast_u32(best, 0) + lh_bcast_u32(best, 1) + lh_bcast_u32(best, 2));
         }
         if (USE_PREV && R.block_type == LH_NORM_TYPE && bv != 0)
             R.pn_sfb_count1 = lh_popc64(lh_ballot(lane < LH_SBMAX_L + 1 && (int) sfbcnt_in < bv));
         LH_PA(11, t_cb);
+        LQ_MARK("cb_end");
         return bits;
     }
 }
@@ -820,7 +938,7 @@ lq_outer_loop(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & gb, const float 
     int     huff_bits, better, age;
     int     best_part2_3_length = 9999999;
 
-    lq_load(c, S, Q, R, xr);
+    lq_load(c, S, Q, R, gb, xr);
     R.s_mnc = lh_uni_i((int) Q.sfb_of_line[R.mnc]);
     {
         LH_PT(t_bs);
@@ -837,6 +955,7 @@ lq_outer_loop(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & gb, const float 
         for (int k = 0; k < 5; k++)
             S.pb[k] = S.pw[k];
         S.sfbest = S.sfw;
+        S.tselb = S.tselw;
         gw = gb;
         age = 0;
         do {
@@ -880,6 +999,7 @@ lq_outer_loop(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & gb, const float 
                 for (int k = 0; k < 5; k++)
                     S.pb[k] = S.pw[k];
                 S.sfbest = S.sfw;
+                S.tselb = S.tselw;
                 gb = gw;
                 age = 0;
             }
@@ -897,7 +1017,11 @@ lq_outer_loop(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & gb, const float 
         for (int k = 0; k < 5; k++)
             S.pb[k] = S.pw[k];
         S.sfbest = S.sfw;
+        S.tselb = S.tselw;
     }
+    gb.table_select[0] = (int) lh_bcast_u32((uint32_t) S.tselb, 0);
+    gb.table_select[1] = (int) lh_bcast_u32((uint32_t) S.tselb, 1);
+    gb.table_select[2] = (int) lh_bcast_u32((uint32_t) S.tselb, 2);
     /* hand the result to the finishing stages through the LDS image */
     LH_WAVE_SYNC();
 #pragma unroll

@@ -645,165 +645,6 @@ lh_noquant_count_bits(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, int w
     return bits;
 }
 
-/* reference takehiro.c:281-414 (quantize_xrpow) + 768-798 (count_bits) */
-LH_DEVFN int
-lh_count_bits(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, int which, int use_prev)
-{
-    LH_PC(10);
-    LH_PT(t_cb);
-    const LhTables *T = c.T;
-    const LhQTabs *qt = LH_QT;
-    int16_t *ix = Q.ix[which];
-    uint32_t *ix2 = (uint32_t *) Q.ix[which];
-    const int *sf = Q.sf[which];
-    const float *xrpow = Q.xrpow;
-    /* global_gain is wave-uniform: one LDS word for the usual range, HBM below it */
-    float   istep;
-    if (g.global_gain >= 128)
-        istep = qt->ipow20w[g.global_gain - 128];
-    else
-        istep = T->ipow20[g.global_gain];
-    int const mnc = R.mnc;
-    int const pm = mnc >> 1;            /* last pair that holds a line <= mnc (mnc is odd) */
-    int const sfbmax = (R.block_type == LH_SHORT_TYPE) ? 38 : 21;
-    int const lane = c.lane;
-    uint32_t pk[5];
-    int     sb[5];
-    float   xp[10];
-    uint64_t ncmask, m01mask;
-    int     zero_mnc;
-
-    if (g.xrpow_max > (LH_IXMAX) / istep)
-        return LH_LARGE_BITS;
-    /* Everything a lane needs that does not depend on the band decisions is loaded first.
-     * The loads are unconditional with clamped indices and the results are selected afterwards:
-     * a load under a condition becomes a branch with its own wait, and nothing overlaps. */
-#pragma unroll
-    for (int k = 0; k < 5; k++) {
-        int const p = lane + 64 * k;
-        int const pc = (k < 4 || p < 288) ? p : 287;
-        int const sbv = Q.sfb_of_line[2 * pc];
-        uint32_t const old = ix2[pc];
-        lh_f32x2 const x2 = ((const lh_f32x2 *) xrpow)[pc];
-        sb[k] = (p <= pm) ? sbv : 63;           /* 63: no band; its bit in the masks below is 0 */
-        pk[k] = (k < 4 || p < 288) ? old : 0u;  /* lines above mnc are zero already (lh_zero_tail) */
-        xp[2 * k] = x2.x;
-        xp[2 * k + 1] = x2.y;
-    }
-    /* Per band (lane = band): unchanged step -> keep the old values; count1 region with a
-     * coarser step -> 0/1 comparator; else the full quantiser (reference
-     * quantize_xrpow, takehiro.c:281-414).  The per-band decisions travel as two ballot
-     * masks (scalar registers), not through LDS.
-     * Invariant kept by this file: lines above max_nonzero_coeff (mnc) are zero in both
-     * quantised images from lh_zero_tail() on, which is what the reference's memset
-     * re-establishes on every call; so only lines <= mnc are visited.  One quirk of the
-     * reference survives: when the band that holds line mnc is kept but a later band is
-     * not, its memset clears line mnc itself. */
-    {
-        int const prev_data_use = (use_prev && (g.global_gain == R.pn_global_gain));
-        int const s = lane;
-        int     noncached = 0, m01 = 0;
-        int const s_m = Q.sfb_of_line[mnc];
-        if (s <= sfbmax) {
-            int     step = -1, cached;
-            int const pn_step = Q.pn_step[s];
-            if (prev_data_use || R.block_type == LH_NORM_TYPE) {
-                int const pre = (g.preflag && s < LH_SBMAX_L) ? qt->pretab[s] : 0;
-                step = g.global_gain - ((sf[s] + pre) << (g.scalefac_scale + 1))
-                    - lh_sbg(g, Q.window[s]) * 8;
-            }
-            cached = prev_data_use && (pn_step == step);
-            /* The band that holds line mnc never takes the 0/1 comparator: the reference has
-             * already set sfb = sfbmax + 1 when it tests prev_noise->step[sfb] there
-             * (takehiro.c:366-372), an entry calc_noise never writes (0 for long blocks; for
-             * short blocks the int view of a float noise value, far above any step). */
-            m01 = use_prev && R.pn_sfb_count1 > 0 && s >= R.pn_sfb_count1 && pn_step > 0 && step >= pn_step
-                && s != s_m;
-            noncached = !cached;
-        }
-        ncmask = lh_ballot(noncached);
-        m01mask = lh_ballot(m01);
-        {
-            int const cached_m = !((ncmask >> s_m) & 1);
-            int const later = (s_m < 63) ? ((ncmask >> (s_m + 1)) != 0) : 0;
-            zero_mnc = cached_m && later;
-        }
-    }
-    LH_PA(18, t_cb);
-    {
-        float const compareval0 = (1.0f - 0.4054f) / istep;
-        uint32_t newpk[5] = { 0u, 0u, 0u, 0u, 0u };
-        int     anybig = 0;
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-            int const p = lane + 64 * k;
-            int const nc = (int) ((ncmask >> sb[k]) & 1), z1 = (int) ((m01mask >> sb[k]) & 1);
-            uint32_t v = pk[k];
-            if (k < 3 || 64 * k <= pm) {        /* wave-uniform: upper blocks above mnc cost one branch */
-                /* straight-line code for all three cases (no branch per pair, so the table
-                 * look-ups of all pairs are in flight together); the rounding table comes
-                 * from its LDS head, values beyond it are redone below */
-                int     big0, big1;
-                int const q0 = lh_quant_line_head(qt, istep, xp[2 * k], big0);
-                int const q1 = lh_quant_line_head(qt, istep, xp[2 * k + 1], big1);
-                uint32_t const vq = (uint32_t) (q0 & 0xffff) | ((uint32_t) q1 << 16);
-                uint32_t const v01 = ((compareval0 > xp[2 * k]) ? 0u : 1u)
-                    | (((compareval0 > xp[2 * k + 1]) ? 0u : 1u) << 16);
-                anybig |= (nc && !z1) ? (big0 | big1) : 0;
-                v = nc ? (z1 ? v01 : vq) : v;
-            }
-            if (zero_mnc && p == pm)
-                v &= 0xffffu;
-            newpk[k] = v;
-        }
-        if (lh_ballot(anybig)) {
-            /* rare: some quantised value is >= 256, its rounding offset lives in HBM */
-#pragma unroll
-            for (int k = 0; k < 5; k++) {
-                int const p = lane + 64 * k;
-                int const nc = (int) ((ncmask >> sb[k]) & 1), z1 = (int) ((m01mask >> sb[k]) & 1);
-                if (nc && !z1) {
-                    int const q0 = lh_quant_line(T, qt, istep, xp[2 * k]);
-                    int const q1 = lh_quant_line(T, qt, istep, xp[2 * k + 1]);
-                    uint32_t v = (uint32_t) (q0 & 0xffff) | ((uint32_t) q1 << 16);
-                    if (zero_mnc && p == pm)
-                        v &= 0xffffu;
-                    newpk[k] = v;
-                }
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-            int const p = lane + 64 * k;
-            if (k < 4 || p < 288)
-                ix2[p] = newpk[k];
-            pk[k] = newpk[k];
-        }
-    }
-    if (R.substep_shaping & 2) {
-        int const gain = g.global_gain + g.scalefac_scale;
-        float const roundfac = (float) (0.634521682242439 / T->ipow20[gain]);
-        LH_WAVE_SYNC();
-        for (int i = lane; i < 576; i += 64) {
-            int const s = Q.sfb_of_line[i];
-            if (s < R.sfbmax && Q.pseudohalf[s])
-                ix[i] = (xrpow[i] >= roundfac) ? ix[i] : (int16_t) 0;
-        }
-        LH_WAVE_SYNC();
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-            int const p = lane + 64 * k;
-            pk[k] = (p < 288) ? ix2[p] : 0u;
-        }
-    }
-    LH_PA(12, t_cb);
-    {
-        int const nb = lh_noquant_count_bits(c, Q, R, g, which, use_prev, pk);
-        LH_PA(11, t_cb);
-        return nb;
-    }
-}
-
 /* ---------------------------------------------------------------------- */
 /* reference takehiro.c:1135-1188 (MPEG-1); band s on lane s, maxima by wave reduction */
 LH_DEVFN int
@@ -1004,201 +845,6 @@ lh_calc_xmin(int qch, int gr, int rch)
     LH_WAVE_SYNC();
 }
 
-/* reference quantize_pvt.c:750-913: one lane per band, wave-uniform aggregation */
-LH_DEVFN void
-lh_calc_noise(const LhCtx & c, LhChanLds & Q, LhQR & R, const LhGrR & g, int which,
-              const float *xr, LhNoiseRes & res, int use_prev)
-{
-    const LhTables *T = c.T;
-    const LhQTabs *qt = LH_QT;
-    const int16_t *ix = Q.ix[which];
-    const int *sf = Q.sf[which];
-    int const s = c.lane;
-    float   noise_s = 0.0f;
-    float   noise = 0, step = 0, r_l3_xmin = 0;
-    LH_PC(13);
-    LH_PT(t_cn0);
-    int     st = 0, l = 0, j = 0, fresh = 0, big = 0;
-    LH_WAVE_SYNC();
-    if (s < R.psymax) {
-        int const pre = (g.preflag && s < LH_SBMAX_L) ? qt->pretab[s] : 0;
-        st = g.global_gain - ((sf[s] + pre) << (g.scalefac_scale + 1)) - lh_sbg(g, Q.window[s]) * 8;
-        r_l3_xmin = 1.f / Q.l3_xmin[s];
-        fresh = !(use_prev && (Q.pn_step[s] == st));
-    }
-    if (fresh) {
-        step = T->pow20[st + LH_QMAX2];
-        l = Q.width[s] >> 1;
-        j = Q.start[s];
-        /* the reference's running line index lags behind the band start only after a
-         * band cut at max_nonzero_coeff, where the remaining length is 0 either way */
-        if ((j + Q.width[s]) > R.mnc) {
-            int const usefullsize = R.mnc - j + 1;
-            l = (usefullsize > 0) ? (usefullsize >> 1) : 0;
-        }
-    }
-    /* One formula for the reference's three cases (calc_noise_core_c,
-     * quantize_pvt.c:750-796): above count1 every ix is 0 and pow43[0]*step = 0, so
-     * |xr| - 0 squares to xr*xr; in the count1 region ix is 0/1 and pow43[1] = 1.0f makes
-     * pow43[ix]*step equal to {0, step} exactly. */
-    if (c.ns_amp != 3) {
-        /* Phase A, all lanes: the squared error of every line, (|xr| - pow43[ix] step)^2,
-         * nine lines per lane, no branches; the band's step travels through LDS.
-         * Phase B, lane = band: the reference's serial sum over the band's lines (the order
-         * of the float additions is kept), reading the terms back; the loop bound is the
-         * longest fresh band (wave-uniform) and shorter bands add +0.0f, which leaves a
-         * non-negative sum unchanged. */
-        float  *sq = Q.save_xrpow;
-        int     maxw;
-        if (s <= LH_SFBMAX)
-            Q.sfb_f[s] = fresh ? step : 0.0f;
-        maxw = (int) lh_wave_max_u32(fresh ? (unsigned) (2 * l) : 0u);
-        LH_WAVE_SYNC();
-        {
-            int     q[9], sbv[9];
-            float   xv[9], stp[9], p43[9];
-#pragma unroll
-            for (int k = 0; k < 9; k++) {
-                int const i = c.lane + 64 * k;
-                q[k] = ix[i];
-                xv[k] = xr[i];
-                sbv[k] = Q.sfb_of_line[i];
-            }
-#pragma unroll
-            for (int k = 0; k < 9; k++) {
-                stp[k] = Q.sfb_f[sbv[k]];
-                p43[k] = qt->pow43h[q[k] & 255];
-            }
-#pragma unroll
-            for (int k = 0; k < 9; k++)
-                big |= q[k] >> 8;
-            if (lh_ballot(big != 0)) {
-                /* rare: a quantised value beyond the LDS head of pow43 */
-#pragma unroll
-                for (int k = 0; k < 9; k++)
-                    if (q[k] >= 256)
-                        p43[k] = T->pow43[q[k]];
-            }
-#pragma unroll
-            for (int k = 0; k < 9; k++) {
-                /* lines above mnc are never summed (wave-uniform skip of whole blocks) */
-                if (k < 5 || 64 * k <= R.mnc) {
-                    float const temp = lh_fabsf(xv[k]) - p43[k] * stp[k];
-                    sq[c.lane + 64 * k] = temp * temp;
-                }
-            }
-        }
-        LH_WAVE_SYNC();
-        LH_PA(14, t_cn0);
-        {
-            /* Eight terms are fetched (as four aligned pairs: band starts are even) before the
-             * eight dependent additions, so one LDS round trip is paid per eight lines.  A pair
-             * beyond the band's length is fetched from a pair of zeros instead (one select on
-             * the address), and adding +0.0f leaves the non-negative sum unchanged. */
-            int const n = 2 * l;
-            int const jj = (j < 576) ? j : 0;
-            const lh_f32x2 *sq2 = (const lh_f32x2 *) sq;
-            const lh_f32x2 *zero = (const lh_f32x2 *) Q.zero2;
-            for (int k0 = 0; k0 < maxw; k0 += 8) {
-                lh_f32x2 t[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const lh_f32x2 *src = (k0 + 2 * u < n) ? &sq2[(jj + k0) / 2 + u] : zero;
-                    t[u] = *src;
-                }
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    noise += t[u].x;
-                    noise += t[u].y;
-                }
-            }
-        }
-    }
-    else {
-        if (fresh) {
-#pragma unroll 8
-            for (int k = 0; k < 2 * l; k++) {
-                int const q = ix[j + k];
-                float const temp = lh_fabsf(xr[j + k]) - qt->pow43h[q & 255] * step;
-                big |= q >> 8;
-                noise += temp * temp;
-            }
-        }
-        if (lh_ballot(big != 0)) {
-            if (big) {
-                noise = 0;
-                for (int k = 0; k < 2 * l; k++) {
-                    int const q = ix[j + k];
-                    float const temp = lh_fabsf(xr[j + k]) - T->pow43[q] * step;
-                    noise += temp * temp;
-                }
-            }
-        }
-    }
-    LH_PA(15, t_cn0);
-    if (s < R.psymax) {
-        float   distort_;
-        if (!fresh) {
-            distort_ = r_l3_xmin * Q.pn_noise[s];
-            noise = Q.pn_noise_log[s];
-        }
-        else {
-            if (use_prev) {
-                Q.pn_step[s] = st;
-                Q.pn_noise[s] = noise;
-            }
-            distort_ = r_l3_xmin * noise;
-            noise = (float) (lh_fast_log2(T->log_table, (distort_ > 1E-20f) ? distort_ : 1E-20f)
-                             * LH_LOG2_OVER_LOG10);
-            if (use_prev)
-                Q.pn_noise_log[s] = noise;
-        }
-        Q.distort[s] = distort_;
-        noise_s = noise;
-    }
-    if (use_prev)
-        R.pn_global_gain = g.global_gain;
-    LH_PA(16, t_cn0);
-    {
-        /* Aggregation over the bands (reference quantize_pvt.c:884-911).  Only the two float
-         * sums depend on the band order: every lane forms them itself from the per-band
-         * values in LDS (uniform addresses, loads in flight together; skipped bands add +0.0f
-         * to a non-negative sum).  Count, integer sum and maximum do not depend on the order
-         * and are taken across the lanes. */
-        float   over_noise_db = 0, tot_noise_db = 0;
-        int const mine = (s < R.psymax);
-        int     tmp = 0;
-        if (s <= LH_SFBMAX)
-            Q.sfb_f[s] = noise_s;
-        if (mine && noise_s > 0.0f) {
-            tmp = (int) (noise_s * 10 + .5);
-            if (tmp < 1)
-                tmp = 1;
-        }
-        res.over_count = lh_popc64(lh_ballot(mine && noise_s > 0.0f));
-        res.over_SSD = (int) lh_wave_sum_u32((unsigned) (tmp * tmp));
-        res.max_noise = lh_wave_max_f32(mine ? noise_s : -20.0f);
-        LH_WAVE_SYNC();
-        for (int k0 = 0; k0 < R.psymax; k0 += 8) {
-            float   t[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++)
-                t[u] = Q.sfb_f[(k0 + u < LH_SFBMAX) ? k0 + u : LH_SFBMAX];
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                if (k0 + u < R.psymax) {        /* wave-uniform */
-                    tot_noise_db += t[u];
-                    over_noise_db += (t[u] > 0.0f) ? t[u] : 0.0f;
-                }
-            }
-        }
-        res.tot_noise = tot_noise_db;
-        res.over_noise = over_noise_db;
-    }
-    LH_WAVE_SYNC();
-    LH_PA(17, t_cn0);
-}
-
 /* ---------------------------------------------------------------------- */
 /* geometry of the granule + spectrum re-ordering for short blocks
  * (reference quantize.c:226-346) */
@@ -1380,71 +1026,6 @@ lh_init_xrpow(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g, const f
     return 0;
 }
 
-/* reference quantize.c:367-429 */
-LH_DEVFN int
-lh_bin_search_StepSize(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, int desired_rate, int ch)
-{
-    int     nBits;
-    int     CurrentStep = c.st->CurrentStep[ch];
-    int     flag_GoneOver = 0;
-    int const start = c.st->OldValue[ch];
-    int     Direction = 0;
-    g.global_gain = start;
-    desired_rate -= g.part2_length;
-    for (;;) {
-        int     step;
-        nBits = lh_count_bits(c, Q, R, g, 0, 0);
-        if (CurrentStep == 1 || nBits == desired_rate)
-            break;
-        if (nBits > desired_rate) {
-            if (Direction == 2)
-                flag_GoneOver = 1;
-            if (flag_GoneOver)
-                CurrentStep /= 2;
-            Direction = 1;
-            step = CurrentStep;
-        }
-        else {
-            if (Direction == 1)
-                flag_GoneOver = 1;
-            if (flag_GoneOver)
-                CurrentStep /= 2;
-            Direction = 2;
-            step = -CurrentStep;
-        }
-        g.global_gain += step;
-        if (g.global_gain < 0) {
-            g.global_gain = 0;
-            flag_GoneOver = 1;
-        }
-        if (g.global_gain > 255) {
-            g.global_gain = 255;
-            flag_GoneOver = 1;
-        }
-    }
-    while (nBits > desired_rate && g.global_gain < 255) {
-        g.global_gain++;
-        nBits = lh_count_bits(c, Q, R, g, 0, 0);
-    }
-    LH_WAVE_SYNC();
-    if (c.lane == 0) {
-        c.st->CurrentStep[ch] = (start - g.global_gain >= 4) ? 4 : 2;
-        c.st->OldValue[ch] = g.global_gain;
-    }
-    LH_WAVE_SYNC();
-    g.part2_3_length = nBits;
-    return nBits;
-}
-
-/* reference quantize.c:540-551; caller guarantees sf[] is synced */
-LH_DEVFN int
-lh_loop_break(const LhCtx & c, const LhChanLds & Q, const LhQR & R, const LhGrR & g, int which)
-{
-    int const s = c.lane;
-    int const z = (s < R.sfbmax) && (Q.sf[which][s] + lh_sbg(g, Q.window[s]) == 0);
-    return lh_ballot(z) == 0;
-}
-
 /* reference quantize.c:585-686 (comparator 9, the only one the presets of this path select) */
 LH_DEVFN int
 lh_quant_compare(const LhNoiseRes & best, const LhNoiseRes & calc)
@@ -1462,409 +1043,6 @@ lh_quant_compare(const LhNoiseRes & best, const LhNoiseRes & calc)
     if (best.over_count == 0)
         better = better && calc.bits < best.bits;
     return better;
-}
-
-/* multiply the xrpow lines of the flagged bands (Q.sfb_mode[s] != 0, set by lane s)
- * by their factor Q.sfb_f[s] and refresh xrpow_max; lanes over lines */
-LH_DEVFN void
-lh_scale_bands(const LhCtx & c, LhChanLds & Q, LhGrR & g)
-{
-    unsigned mx = lh_f32_as_u32(g.xrpow_max);
-    int     sb[9], md[9];
-    float   fac[9], xv[9];
-    LH_WAVE_SYNC();
-#pragma unroll
-    for (int k = 0; k < 9; k++)
-        sb[k] = Q.sfb_of_line[c.lane + 64 * k];
-#pragma unroll
-    for (int k = 0; k < 9; k++) {
-        md[k] = Q.sfb_mode[sb[k]];
-        fac[k] = Q.sfb_f[sb[k]];
-        xv[k] = Q.xrpow[c.lane + 64 * k];
-    }
-#pragma unroll
-    for (int k = 0; k < 9; k++) {
-        if (md[k]) {
-            float const v = xv[k] * fac[k];
-            unsigned const u = lh_f32_as_u32(v);
-            Q.xrpow[c.lane + 64 * k] = v;
-            mx = u > mx ? u : mx;
-        }
-    }
-    mx = lh_wave_max_u32(mx);
-    g.xrpow_max = lh_u32_as_f32(mx);
-    LH_WAVE_SYNC();
-}
-
-/* the same when every amplified band gets the same factor: the set of bands travels as a
- * ballot mask in scalar registers instead of per-band LDS arrays (amp_scalefac_bands) */
-LH_DEVFN void
-lh_scale_bands_mask(const LhCtx & c, LhChanLds & Q, LhGrR & g, uint64_t bands, float factor)
-{
-    unsigned mx = lh_f32_as_u32(g.xrpow_max);
-    int     sb[9];
-    float   xv[9];
-#pragma unroll
-    for (int k = 0; k < 9; k++) {
-        sb[k] = Q.sfb_of_line[c.lane + 64 * k];
-        xv[k] = Q.xrpow[c.lane + 64 * k];
-    }
-#pragma unroll
-    for (int k = 0; k < 9; k++) {
-        int const on = (int) ((bands >> sb[k]) & 1);
-        float const v = on ? xv[k] * factor : xv[k];
-        unsigned const u = lh_f32_as_u32(v);
-        Q.xrpow[c.lane + 64 * k] = v;
-        mx = (on && u > mx) ? u : mx;
-    }
-    mx = lh_wave_max_u32(mx);
-    g.xrpow_max = lh_u32_as_f32(mx);
-    LH_WAVE_SYNC();
-}
-
-/* reference quantize.c:720-796; band s on lane s, the serial walk with its early
- * returns is replayed on ballot masks */
-LH_DEVFN void
-lh_amp_scalefac_bands(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g, int which,
-                      int bRefine)
-{
-    const LhConfig *cfg = c.cfg;
-    float   ifqstep34, trigger;
-    int     noise_shaping_amp;
-    int     last_visited, ret_before = 0;
-    int const s = c.lane;
-    float   dist;
-    uint64_t cand;
-    LH_WAVE_SYNC();
-    dist = (s < R.sfbmax) ? Q.distort[s] : 0.0f;
-    if (g.scalefac_scale == 0)
-        ifqstep34 = (float) 1.29683955465100964055;
-    else
-        ifqstep34 = (float) 1.68179283050742922612;
-    /* distort >= 0, so the float maximum is the maximum of the bit patterns */
-    trigger = lh_u32_as_f32(lh_wave_max_u32(lh_f32_as_u32(dist > 0.0f ? dist : 0.0f)));
-    noise_shaping_amp = c.ns_amp;
-    if (noise_shaping_amp == 3)
-        noise_shaping_amp = (bRefine == 1) ? 2 : 1;
-    switch (noise_shaping_amp) {
-    case 2:
-        break;
-    case 1:
-        if (trigger > 1.0)
-            trigger = (float) sqrt((double) trigger);   /* == (float) pow(trigger, .5), see DESIGN.md */
-        else
-            trigger = (float) (trigger * .95);
-        break;
-    case 0:
-    default:
-        if (trigger > 1.0)
-            trigger = 1.0;
-        else
-            trigger = (float) (trigger * .95);
-        break;
-    }
-    cand = lh_ballot(s < R.sfbmax && !(dist < trigger));
-    last_visited = R.sfbmax - 1;
-    if (c.ns_amp == 2) {
-        uint64_t const ph = (R.substep_shaping & 2) ? lh_ballot(s < R.sfbmax && Q.pseudohalf[s]) : 0;
-        uint64_t m = cand;
-        while (m) {
-            int const sfb = lh_ffs64(m);
-            m &= m - 1;
-            if (R.substep_shaping & 2) {
-                int const ph_new = !((ph >> sfb) & 1);
-                if (!ph_new) {
-                    last_visited = sfb;
-                    ret_before = 1;
-                    break;
-                }
-            }
-            last_visited = sfb;
-            break;
-        }
-    }
-    LH_WAVE_SYNC();
-    {
-        int     amplify = 0;
-        if (s < R.sfbmax && s <= last_visited && ((cand >> s) & 1)) {
-            amplify = 1;
-            if (R.substep_shaping & 2)
-                Q.pseudohalf[s] = !Q.pseudohalf[s];
-            if (ret_before && s == last_visited)
-                amplify = 0;
-            if (amplify)
-                Q.sf[which][s]++;
-        }
-        lh_scale_bands_mask(c, Q, g, lh_ballot(amplify), ifqstep34);
-    }
-}
-
-/* reference quantize.c:808-833 */
-LH_DEVFN void
-lh_inc_scalefac_scale(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g, int which)
-{
-    const LhQTabs *qt = LH_QT;
-    float const ifqstep34 = (float) 1.29683955465100964055;
-    LH_WAVE_SYNC();
-    if (c.lane <= LH_SFBMAX) {
-        int const sfb = c.lane;
-        int     amp = 0;
-        if (sfb < R.sfbmax) {
-            int     s = Q.sf[which][sfb];
-            if (g.preflag)
-                s += qt->pretab[sfb];
-            if (s & 1) {
-                s++;
-                amp = 1;
-            }
-            Q.sf[which][sfb] = s >> 1;
-        }
-        Q.sfb_mode[sfb] = amp;
-        Q.sfb_f[sfb] = ifqstep34;
-    }
-    g.preflag = 0;
-    g.scalefac_scale = 1;
-    lh_scale_bands(c, Q, g);
-}
-
-/* reference quantize.c:847-921 */
-LH_DEVFN int
-lh_inc_subblock_gain(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g, int which)
-{
-    const LhTables *T = c.T;
-    const LhQTabs *qt = LH_QT;
-    int    *sf = Q.sf[which];
-    int     sfb, window;
-    LH_WAVE_SYNC();
-    for (sfb = 0; sfb < R.sfb_lmax; sfb++)
-        if (sf[sfb] >= 16)
-            return 1;
-    for (window = 0; window < 3; window++) {
-        int     s1 = 0, s2 = 0, top;
-        for (sfb = R.sfb_lmax + window; sfb < R.sfbdivide; sfb += 3)
-            if (s1 < sf[sfb])
-                s1 = sf[sfb];
-        for (; sfb < R.sfbmax; sfb += 3)
-            if (s2 < sf[sfb])
-                s2 = sf[sfb];
-        top = sfb;              /* the band above the last scalefactor band, for this window */
-        if (s1 < 16 && s2 < 8)
-            continue;
-        if (lh_sbg(g, window) >= 7)
-            return 1;
-        g.subblock_gain[0] += (window == 0);
-        g.subblock_gain[1] += (window == 1);
-        g.subblock_gain[2] += (window == 2);
-        LH_WAVE_SYNC();
-        if (c.lane <= LH_SFBMAX) {
-            int const k = c.lane;
-            int     mode = 0;
-            float   f = 1.0f;
-            if (k >= R.sfb_lmax + window && k < R.sfbmax && ((k - R.sfb_lmax - window) % 3) == 0) {
-                int     s = sf[k];
-                s = s - (4 >> g.scalefac_scale);
-                if (s >= 0)
-                    sf[k] = s;
-                else {
-                    int const gain = 210 + (s << (g.scalefac_scale + 1));
-                    sf[k] = 0;
-                    mode = 1;
-                    f = T->ipow20[gain];
-                }
-            }
-            else if (k == top) {
-                mode = 1;
-                f = T->ipow20[202];
-            }
-            Q.sfb_mode[k] = mode;
-            Q.sfb_f[k] = f;
-        }
-        lh_scale_bands(c, Q, g);
-    }
-    return 0;
-}
-
-/* reference quantize.c:940-988 */
-LH_DEVFN int
-lh_balance_noise(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g, int which, int bRefine)
-{
-    const LhConfig *cfg = c.cfg;
-    int     status;
-    LH_PT(t_bal);
-    lh_amp_scalefac_bands(c, Q, R, g, which, bRefine);
-    LH_PA(37, t_bal);
-    status = lh_loop_break(c, Q, R, g, which);
-    LH_PA(38, t_bal);
-    if (status)
-        return 0;
-    status = lh_scale_bitcount(c, Q, R, g, which);
-    LH_PA(39, t_bal);
-    if (!status)
-        return 1;
-    if (c.ns > 1) {
-        LH_WAVE_SYNC();
-        if (c.lane <= LH_SFBMAX)
-            Q.pseudohalf[c.lane] = 0;
-        LH_WAVE_SYNC();
-        if (!g.scalefac_scale) {
-            lh_inc_scalefac_scale(c, Q, R, g, which);
-            status = 0;
-        }
-        else {
-            if (R.block_type == LH_SHORT_TYPE && c.subblock_gain > 0)
-                status = lh_inc_subblock_gain(c, Q, R, g, which) || lh_loop_break(c, Q, R, g, which);
-        }
-    }
-    if (!status)
-        status = lh_scale_bitcount(c, Q, R, g, which);
-    return !status;
-}
-
-/* copy quantised image + scalefactors between the best (0) and working (1) slots;
- * the register part is copied by the caller */
-LH_DEVFN void
-lh_copy_gr(const LhCtx & c, LhChanLds & Q, int dst, int src)
-{
-    LH_WAVE_SYNC();
-    for (int i = c.lane; i < 288; i += 64)
-        ((uint32_t *) Q.ix[dst])[i] = ((const uint32_t *) Q.ix[src])[i];
-    if (c.lane <= LH_SFBMAX)
-        Q.sf[dst][c.lane] = Q.sf[src][c.lane];
-    LH_WAVE_SYNC();
-}
-
-/* reference quantize.c:1010-1197; gb = cod_info (image 0), returns over_count */
-LH_DEVFN int
-lh_outer_loop(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & gb, const float *xr, int ch,
-              int targ_bits)
-{
-    const LhConfig *cfg = c.cfg;
-    LhGrR   gw;
-    LhNoiseRes best_noise_info;
-    int     huff_bits, better, age;
-    int     best_part2_3_length = 9999999;
-    int     bEndOfSearch = 0, bRefine = 0, best_ggain_pass1 = 0;
-
-    {
-        LH_PT(t_bs);
-        (void) lh_bin_search_StepSize(c, Q, R, gb, targ_bits, ch);
-        LH_PA(7, t_bs);
-    }
-    if (!c.ns)
-        return 100;
-    LH_WAVE_SYNC();
-    if (c.lane <= LH_SFBMAX) {
-        Q.pn_step[c.lane] = 0;
-        Q.pn_noise[c.lane] = 0;
-        Q.pn_noise_log[c.lane] = 0;
-    }
-    R.pn_global_gain = 0;
-    R.pn_sfb_count1 = 0;
-    LH_WAVE_SYNC();
-    lh_calc_noise(c, Q, R, gb, 0, xr, best_noise_info, 1);
-    best_noise_info.bits = gb.part2_3_length;
-    lh_copy_gr(c, Q, 1, 0);
-    gw = gb;
-    age = 0;
-    /* save_xrpow is only ever read back by the refinement pass of noise_shaping_amp 3
-     * (reference quantize.c:1170-1183); otherwise the buffer is calc_noise's scratch */
-    if (c.ns_amp == 3) {
-        for (int i = c.lane; i < 576; i += 64)
-            Q.save_xrpow[i] = Q.xrpow[i];
-    }
-    LH_WAVE_SYNC();
-
-    while (!bEndOfSearch) {
-        do {
-            LhNoiseRes noise_info;
-            int     search_limit;
-            int     maxggain = 255;
-            if (R.substep_shaping & 2)
-                search_limit = 20;
-            else
-                search_limit = 3;
-            if (c.sfb21_extra) {
-                if (Q.distort[R.sfbmax] > 1.0)
-                    break;
-                if (R.block_type == LH_SHORT_TYPE
-                    && (Q.distort[R.sfbmax + 1] > 1.0 || Q.distort[R.sfbmax + 2] > 1.0))
-                    break;
-            }
-            {
-                LH_PT(t_bn);
-                int const bn = lh_balance_noise(c, Q, R, gw, 1, bRefine);
-                LH_PA(8, t_bn);
-                if (bn == 0)
-                    break;
-            }
-            if (gw.scalefac_scale)
-                maxggain = 254;
-            huff_bits = targ_bits - gw.part2_length;
-            if (huff_bits <= 0)
-                break;
-            while ((gw.part2_3_length = lh_count_bits(c, Q, R, gw, 1, 1)) > huff_bits
-                   && gw.global_gain <= maxggain)
-                gw.global_gain++;
-            if (gw.global_gain > maxggain)
-                break;
-            if (best_noise_info.over_count == 0) {
-                while ((gw.part2_3_length = lh_count_bits(c, Q, R, gw, 1, 1)) > best_part2_3_length
-                       && gw.global_gain <= maxggain)
-                    gw.global_gain++;
-                if (gw.global_gain > maxggain)
-                    break;
-            }
-            {
-                LH_PT(t_cn);
-                lh_calc_noise(c, Q, R, gw, 1, xr, noise_info, 1);
-                LH_PA(9, t_cn);
-            }
-            noise_info.bits = gw.part2_3_length;
-            better = lh_quant_compare(best_noise_info, noise_info);
-            if (better) {
-                best_part2_3_length = gb.part2_3_length;
-                best_noise_info = noise_info;
-                lh_copy_gr(c, Q, 0, 1);
-                gb = gw;
-                age = 0;
-                if (c.ns_amp == 3) {
-                    for (int i = c.lane; i < 576; i += 64)
-                        Q.save_xrpow[i] = Q.xrpow[i];
-                }
-                LH_WAVE_SYNC();
-            }
-            else {
-                if (c.full_outer_loop == 0) {
-                    if (++age > search_limit && best_noise_info.over_count == 0)
-                        break;
-                    if ((c.ns_amp == 3) && bRefine && age > 30)
-                        break;
-                    if ((c.ns_amp == 3) && bRefine &&
-                        (gw.global_gain - best_ggain_pass1) > 15)
-                        break;
-                }
-            }
-        }
-        while ((gw.global_gain + gw.scalefac_scale) < 255);
-
-        if (c.ns_amp == 3) {
-            if (!bRefine) {
-                lh_copy_gr(c, Q, 1, 0);
-                gw = gb;
-                for (int i = c.lane; i < 576; i += 64)
-                    Q.xrpow[i] = Q.save_xrpow[i];
-                LH_WAVE_SYNC();
-                age = 0;
-                best_ggain_pass1 = gw.global_gain;
-                bRefine = 1;
-            }
-            else
-                bEndOfSearch = 1;
-        }
-        else
-            bEndOfSearch = 1;
-    }
-    return best_noise_info.over_count;
 }
 
 /* ---------------------------------------------------------------------- */

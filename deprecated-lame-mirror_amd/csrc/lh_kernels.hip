@@ -91,8 +91,6 @@ LH_DEVCONST float lh_pe_fir[9] = {
 LH_DEVFN void
 lh_load_qtabs(const LhCtx & c, LhQTabs & q)
 {
-    if (c.tid < 128)
-        q.ipow20w[c.tid] = c.T->ipow20[128 + c.tid];
     for (int i = c.tid; i < 256; i += LH_NT) {
         q.largetbl[i] = lh_largetbl[i];
         q.pow43h[i] = c.T->pow43[i];
@@ -116,6 +114,8 @@ lh_load_qtabs(const LhCtx & c, LhQTabs & q)
         q.lut_pa[c.tid] = r.pa;
         q.lut_pb[c.tid] = r.pb;
     }
+    if (c.tid < 32)
+        lq_class_tabs(c.tid, &q.ctabA[c.tid], &q.ctabB[c.tid]);
     if (c.tid < 9)
         q.table23[c.tid] = lh_table23[c.tid];
     if (c.tid < 16) {

@@ -125,6 +125,30 @@ lh_wave_max_f32(float v)
     return m;
 }
 
+
+/* several independent reductions at once (the device version interleaves their steps) */
+template < int N > static inline void
+lh_wave_sum_n(uint32_t (&v)[N])
+{
+    for (int i = 0; i < N; i++)
+        v[i] = lh_wave_sum_u32(v[i]);
+}
+
+template < int N > static inline void
+lh_wave_max_n(uint32_t (&v)[N])
+{
+    for (int i = 0; i < N; i++)
+        v[i] = lh_wave_max_u32(v[i]);
+}
+
+/* packed 16-bit minimum of both halves */
+static inline uint32_t
+lh_pk_min_u16(uint32_t a, uint32_t b)
+{
+    uint32_t const al = a & 0xffffu, ah = a >> 16, bl = b & 0xffffu, bh = b >> 16;
+    return (al < bl ? al : bl) | ((ah < bh ? ah : bh) << 16);
+}
+
 static inline void lh_lds_add(int *p, int v) { *p += v; }      /* fibers interleave only at sync points */
 static inline void lh_lds_max(int *p, int v) { if (v > *p) *p = v; }
 static inline void lh_lds_addf(float *p, float v) { *p += v; }
@@ -200,6 +224,47 @@ __device__ __forceinline__ uint32_t lh_wave_sum_u32(uint32_t v) LH_DPP_REDUCE(LH
 __device__ __forceinline__ uint32_t lh_wave_max_u32(uint32_t v) LH_DPP_REDUCE(LH_OP_MAX, 0u)
 __device__ __forceinline__ uint32_t lh_wave_min_u32(uint32_t v) LH_DPP_REDUCE(LH_OP_MIN, 0xffffffffu)
 __device__ __forceinline__ uint32_t lh_wave_or_u32(uint32_t v) LH_DPP_REDUCE(LH_OP_OR, 0u)
+
+
+/* several independent reductions at once: the steps of all chains are issued side by side, so a
+ * chain's DPP latency is covered by the other chains instead of s_nops */
+#define LH_DPP_STEP_N(OP, IDENT, CTRL) \
+    _Pragma("unroll") for (int i_ = 0; i_ < N; i_++) { uint32_t const t_ = lh_dpp < CTRL, IDENT > (v[i_]); v[i_] = OP(v[i_], t_); }
+#define LH_DPP_ROWS_N(OP, IDENT, CTRL, MASK) \
+    _Pragma("unroll") for (int i_ = 0; i_ < N; i_++) { uint32_t const t_ = lh_dpp_rows < CTRL, MASK, IDENT > (v[i_]); v[i_] = OP(v[i_], t_); }
+
+template < int N > __device__ __forceinline__ void
+lh_wave_sum_n(uint32_t (&v)[N])
+{
+    LH_DPP_STEP_N(LH_OP_ADD, 0u, 0xB1) LH_DPP_STEP_N(LH_OP_ADD, 0u, 0x4E)
+    LH_DPP_STEP_N(LH_OP_ADD, 0u, 0x141) LH_DPP_STEP_N(LH_OP_ADD, 0u, 0x140)
+    LH_DPP_ROWS_N(LH_OP_ADD, 0u, 0x142, 0xa) LH_DPP_ROWS_N(LH_OP_ADD, 0u, 0x143, 0xc)
+#pragma unroll
+    for (int i = 0; i < N; i++)
+        v[i] = (uint32_t) __builtin_amdgcn_readlane((int) v[i], 63);
+}
+
+template < int N > __device__ __forceinline__ void
+lh_wave_max_n(uint32_t (&v)[N])
+{
+    LH_DPP_STEP_N(LH_OP_MAX, 0u, 0xB1) LH_DPP_STEP_N(LH_OP_MAX, 0u, 0x4E)
+    LH_DPP_STEP_N(LH_OP_MAX, 0u, 0x141) LH_DPP_STEP_N(LH_OP_MAX, 0u, 0x140)
+    LH_DPP_ROWS_N(LH_OP_MAX, 0u, 0x142, 0xa) LH_DPP_ROWS_N(LH_OP_MAX, 0u, 0x143, 0xc)
+#pragma unroll
+    for (int i = 0; i < N; i++)
+        v[i] = (uint32_t) __builtin_amdgcn_readlane((int) v[i], 63);
+}
+
+__device__ __forceinline__ uint32_t
+lh_pk_min_u16(uint32_t a, uint32_t b)
+{
+    typedef unsigned short lh_u16x2 __attribute__((ext_vector_type(2)));
+    union { uint32_t u; lh_u16x2 v; } x, y, r;
+    x.u = a;
+    y.u = b;
+    r.v = __builtin_elementwise_min(x.v, y.v);
+    return r.u;
+}
 
 typedef float2 lh_f32x2;
 typedef float4 lh_f32x4;
