@@ -207,7 +207,7 @@ lq_load(const LhCtx & c, LhQS & S, LhChanLds & Q, const LhQR & R, const LhGrR & 
 /* reference takehiro.c:281-414 (quantize_xrpow) + 654-801 (noquant_count_bits, count_bits) on the
  * working image.  Returns the bit count; g's count fields follow except table_select, which lives
  * in S.tselw (lane = region). */
-template < int USE_PREV > LH_DEVFN int
+template < int USE_PREV, int NS > LH_DEVFN int
 lq_count_bits(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
 {
     LH_PC(10);
@@ -249,7 +249,6 @@ lq_count_bits(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
         }
         plain = (ncmask == all) && (m01mask == 0);
     }
-    LH_PA(18, t_cb);
     LQ_MARK("cb_quant");
     /* ---- quantise: all pairs, straight line; the selection follows.  The first rounding is a
      * float addition: (float) ((double) x + 2^23) and x + 2^23f agree for every float x >= 0
@@ -258,7 +257,7 @@ lq_count_bits(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
         uint32_t nq[5];
         uint32_t bmax = 0;
 #pragma unroll
-        for (int k = 0; k < 5; k++) {
+        for (int k = 0; k < NS; k++) {
             float const a0 = istep * S.xp[2 * k], a1 = istep * S.xp[2 * k + 1];
             uint32_t const b0 = lh_f32_as_u32(a0 + (float) LH_MAGIC_FLOAT), b1 = lh_f32_as_u32(a1 + (float) LH_MAGIC_FLOAT);
             float const j0 = qt->adj43h[b0 & 255u], j1 = qt->adj43h[b1 & 255u];
@@ -271,7 +270,7 @@ lq_count_bits(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
         if (lh_ballot(bmax > (uint32_t) LH_MAGIC_INT + 255u)) {
             /* rare: a quantised value >= 256, its rounding offset lives in HBM */
 #pragma unroll
-            for (int k = 0; k < 5; k++) {
+            for (int k = 0; k < NS; k++) {
                 int const q0 = lh_quant_line(T, qt, istep, S.xp[2 * k]);
                 int const q1 = lh_quant_line(T, qt, istep, S.xp[2 * k + 1]);
                 nq[k] = ((uint32_t) (q0 & 0xffff) | ((uint32_t) q1 << 16)) & S.vm[k];
@@ -279,13 +278,13 @@ lq_count_bits(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
         }
         if (plain) {
 #pragma unroll
-            for (int k = 0; k < 5; k++)
+            for (int k = 0; k < NS; k++)
                 S.pw[k] = nq[k];
         }
         else {
             float const compareval0 = (1.0f - 0.4054f) / istep;
 #pragma unroll
-            for (int k = 0; k < 5; k++) {
+            for (int k = 0; k < NS; k++) {
                 int const p = lane + 64 * k;
                 int const nc = lq_bit(ncmask, S.bq[k]), z1 = lq_bit(m01mask, S.bq[k]);
                 uint32_t const v01 = ((compareval0 > S.xp[2 * k]) ? 0u : 1u)
@@ -302,7 +301,7 @@ lq_count_bits(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
         float const roundfac = (float) (0.634521682242439 / T->ipow20[gain]);
         uint64_t const phm = lh_ballot(lane < R.sfbmax && S.ph);
 #pragma unroll
-        for (int k = 0; k < 5; k++) {
+        for (int k = 0; k < NS; k++) {
             if (lq_bit(phm, S.bnd[k])) {
                 uint32_t v = S.pw[k];
                 if (!(S.xp[2 * k] >= roundfac))
@@ -313,7 +312,6 @@ lq_count_bits(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
             }
         }
     }
-    LH_PA(12, t_cb);
     LQ_MARK("cb_count");
     /* ---- count ---- */
     {
@@ -321,12 +319,11 @@ lq_count_bits(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
         int     top_nz, top_big, i, bv, nquad, bits;
         int     e0, e1, e2, a1, a2;
         unsigned sfbcnt_in = 0;
-        LH_PT(t_nq);
         if (USE_PREV)
             R.pn_sfb_count1 = 0;
         /* the quadruples of the count1 region pair up neighbouring lanes: through LDS */
 #pragma unroll
-        for (int k = 0; k < 5; k++) {
+        for (int k = 0; k < NS; k++) {
             int const p = lane + 64 * k;
             if (k < 4 || p < 288)
                 xbuf[p] = S.pw[k];
@@ -336,7 +333,7 @@ lq_count_bits(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
              * last hit of a lane is its highest; then the maximum over the lanes */
             uint32_t t[2] = { 0u, 0u };
 #pragma unroll
-            for (int k = 0; k < 5; k++) {
+            for (int k = 0; k < NS; k++) {
                 uint32_t const p1 = (uint32_t) (lane + 64 * k + 1);
                 t[0] = (S.pw[k] != 0u) ? p1 : t[0];
                 t[1] = ((S.pw[k] & 0xfffefffeu) != 0u) ? p1 : t[1];
@@ -380,7 +377,6 @@ lq_count_bits(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
         e2 = (R.block_type == LH_NORM_TYPE) ? (bv >> 1) : e1;
         if (USE_PREV && R.block_type == LH_NORM_TYPE)
             sfbcnt_in = (lane < LH_SBMAX_L + 1) ? qt->sfb_l[lane] : 576u;
-        LH_PA(19, t_nq);
         LQ_MARK("cb_quads");
         LH_WAVE_SYNC();
         uint32_t red[7];        /* quads, then (a | b << 16) and c of the sums over p < e0, p < e1, p < e2 */
@@ -400,12 +396,11 @@ lq_count_bits(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
                 quads += ((lane + 64 * k) < nquad) ? qt->t3233[idx[k]] : 0u;
             red[0] = quads;
         }
-        LH_PA(20, t_nq);
         LQ_MARK("cb_max");
         uint32_t m[3] = { 0u, 0u, 0u };
         {
 #pragma unroll
-            for (int k = 0; k < 5; k++) {
+            for (int k = 0; k < NS; k++) {
                 int const p = lane + 64 * k;
                 uint32_t const lo = S.pw[k] & 0xffffu, hi = S.pw[k] >> 16;
                 uint32_t const mx = lo > hi ? lo : hi;
@@ -417,7 +412,6 @@ lq_count_bits(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
             }
             lh_wave_max_n < 3 > (m);
         }
-        LH_PA(21, t_nq);
         LQ_MARK("cb_lookup");
         /* lane r < 3 works out region r's candidate tables; the grid origins go back to all lanes */
         uint32_t PB, esc;
@@ -437,7 +431,7 @@ lq_count_bits(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
             uint32_t acc0 = 0, acc1 = 0, acc2 = 0;
             const char *qb = (const char *) &Q;
 #pragma unroll
-            for (int k = 0; k < 5; k++) {
+            for (int k = 0; k < NS; k++) {
                 int const p = lane + 64 * k;
                 int const in0 = p < e0, in1 = p < e1, in2 = p < e2;
                 uint32_t const cl = lh_pk_min_u16(S.pw[k], 0x000f000fu);
@@ -455,10 +449,8 @@ lq_count_bits(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
             red[5] = (acc2 & 0x3ffu) | (((acc2 >> 10) & 0x3ffu) << 16);
             red[6] = acc2 >> 20;
         }
-        LH_PA(22, t_nq);
         LQ_MARK("cb_sums");
         lh_wave_sum_n < 7 > (red);
-        LH_PA(23, t_nq);
         LQ_MARK("cb_decide");
         {
             int const c1a = (int) (red[0] >> 16), c1b = (int) (red[0] & 0xffffu);
@@ -501,7 +493,7 @@ lq_count_bits(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
 }
 
 /* reference quantize_pvt.c:750-913 on the working image */
-LH_DEVFN void
+template < int NS > LH_DEVFN void
 lq_calc_noise(const LhCtx & c, LhQS & S, LhQR & R, const LhGrR & g, LhChanLds & Q, LhNoiseRes & res)
 {
     const LhTables *T = c.T;
@@ -511,7 +503,6 @@ lq_calc_noise(const LhCtx & c, LhQS & S, LhQR & R, const LhGrR & g, LhChanLds & 
     float   noise = 0, noise_s = 0;
     int     st, l = 0, j = 0, fresh, big = 0, maxw;
     LH_PC(13);
-    LH_PT(t_cn0);
     st = lq_band_step(S, g);
     fresh = (s < R.psymax) && !(S.pnstep == st);
     {
@@ -532,7 +523,7 @@ lq_calc_noise(const LhCtx & c, LhQS & S, LhQR & R, const LhGrR & g, LhChanLds & 
     {
         float   stp[5], p43[10];
 #pragma unroll
-        for (int k = 0; k < 5; k++) {
+        for (int k = 0; k < NS; k++) {
             unsigned const q0 = S.pw[k] & 0xffffu, q1 = S.pw[k] >> 16;
             stp[k] = Q.sfb_f[S.bq[k] < LH_SFBMAX ? S.bq[k] : LH_SFBMAX];
             p43[2 * k] = qt->pow43h[q0 & 255u];
@@ -541,7 +532,7 @@ lq_calc_noise(const LhCtx & c, LhQS & S, LhQR & R, const LhGrR & g, LhChanLds & 
         }
         if (lh_ballot(big != 0)) {
 #pragma unroll
-            for (int k = 0; k < 5; k++) {
+            for (int k = 0; k < NS; k++) {
                 unsigned const q0 = S.pw[k] & 0xffffu, q1 = S.pw[k] >> 16;
                 if (q0 >= 256u)
                     p43[2 * k] = T->pow43[q0];
@@ -550,7 +541,7 @@ lq_calc_noise(const LhCtx & c, LhQS & S, LhQR & R, const LhGrR & g, LhChanLds & 
             }
         }
 #pragma unroll
-        for (int k = 0; k < 5; k++) {
+        for (int k = 0; k < NS; k++) {
             int const p = c.lane + 64 * k;
             float const t0 = S.ax[2 * k] - p43[2 * k] * stp[k];
             float const t1 = S.ax[2 * k + 1] - p43[2 * k + 1] * stp[k];
@@ -562,7 +553,6 @@ lq_calc_noise(const LhCtx & c, LhQS & S, LhQR & R, const LhGrR & g, LhChanLds & 
         }
     }
     LH_WAVE_SYNC();
-    LH_PA(14, t_cn0);
     {
         int const n = 2 * l;
         int const jj = (j < 576) ? j : 0;
@@ -582,7 +572,6 @@ lq_calc_noise(const LhCtx & c, LhQS & S, LhQR & R, const LhGrR & g, LhChanLds & 
             }
         }
     }
-    LH_PA(15, t_cn0);
     if (s < R.psymax) {
         float   distort_;
         if (!fresh) {
@@ -601,7 +590,6 @@ lq_calc_noise(const LhCtx & c, LhQS & S, LhQR & R, const LhGrR & g, LhChanLds & 
         noise_s = noise;
     }
     R.pn_global_gain = g.global_gain;
-    LH_PA(16, t_cn0);
     {
         int const mine = (s < R.psymax);
         int     tmp = 0;
@@ -616,16 +604,15 @@ lq_calc_noise(const LhCtx & c, LhQS & S, LhQR & R, const LhGrR & g, LhChanLds & 
         res.tot_noise = 0;      /* not read by the comparator of this path (quant_comp 9) */
         res.over_noise = 0;
     }
-    LH_PA(17, t_cn0);
 }
 
 /* multiply the lines of the bands in `bands' by factor (xrpow only grows, so the lane's maximum
  * follows) */
-LH_DEVFN void
+template < int NS > LH_DEVFN void
 lq_scale_mask(LhQS & S, uint64_t bands, float factor)
 {
 #pragma unroll
-    for (int k = 0; k < 5; k++) {
+    for (int k = 0; k < NS; k++) {
         int const on = lq_bit(bands, S.bnd[k]);
         float const v0 = on ? S.xp[2 * k] * factor : S.xp[2 * k];
         float const v1 = on ? S.xp[2 * k + 1] * factor : S.xp[2 * k + 1];
@@ -637,7 +624,7 @@ lq_scale_mask(LhQS & S, uint64_t bands, float factor)
 }
 
 /* the same with a factor per band: flag / fac are lane = band values, distributed through LDS */
-LH_DEVFN void
+template < int NS > LH_DEVFN void
 lq_scale_bands(const LhCtx & c, LhQS & S, LhChanLds & Q, int flag, float fac)
 {
     LH_WAVE_SYNC();
@@ -647,7 +634,7 @@ lq_scale_bands(const LhCtx & c, LhQS & S, LhChanLds & Q, int flag, float fac)
     {
         uint64_t const bands = lh_ballot(c.lane <= LH_SFBMAX && flag);
 #pragma unroll
-        for (int k = 0; k < 5; k++) {
+        for (int k = 0; k < NS; k++) {
             int const on = lq_bit(bands, S.bnd[k]);
             float const f = Q.sfb_f[S.bnd[k] < LH_SFBMAX ? S.bnd[k] : LH_SFBMAX];
             float const v0 = on ? S.xp[2 * k] * f : S.xp[2 * k];
@@ -662,7 +649,7 @@ lq_scale_bands(const LhCtx & c, LhQS & S, LhChanLds & Q, int flag, float fac)
 }
 
 /* reference quantize.c:720-796 */
-LH_DEVFN void
+template < int NS > LH_DEVFN void
 lq_amp_scalefac_bands(const LhCtx & c, LhQS & S, const LhQR & R, LhGrR & g)
 {
     float   ifqstep34, trigger;
@@ -716,7 +703,7 @@ lq_amp_scalefac_bands(const LhCtx & c, LhQS & S, const LhQR & R, LhGrR & g)
             if (amplify)
                 S.sfw++;
         }
-        lq_scale_mask(S, lh_ballot(amplify), ifqstep34);
+        lq_scale_mask < NS > (S, lh_ballot(amplify), ifqstep34);
     }
 }
 
@@ -762,7 +749,7 @@ lq_scale_bitcount(const LhCtx & c, LhQS & S, const LhQR & R, LhGrR & g)
 }
 
 /* reference quantize.c:808-833 */
-LH_DEVFN void
+template < int NS > LH_DEVFN void
 lq_inc_scalefac_scale(const LhCtx & c, LhQS & S, const LhQR & R, LhGrR & g)
 {
     float const ifqstep34 = (float) 1.29683955465100964055;
@@ -779,11 +766,11 @@ lq_inc_scalefac_scale(const LhCtx & c, LhQS & S, const LhQR & R, LhGrR & g)
     }
     g.preflag = 0;
     g.scalefac_scale = 1;
-    lq_scale_mask(S, lh_ballot(amp), ifqstep34);
+    lq_scale_mask < NS > (S, lh_ballot(amp), ifqstep34);
 }
 
 /* reference quantize.c:847-921 (short blocks) */
-LH_DEVFN int
+template < int NS > LH_DEVFN int
 lq_inc_subblock_gain(const LhCtx & c, LhQS & S, LhChanLds & Q, const LhQR & R, LhGrR & g)
 {
     const LhTables *T = c.T;
@@ -826,7 +813,7 @@ lq_inc_subblock_gain(const LhCtx & c, LhQS & S, LhChanLds & Q, const LhQR & R, L
                 mode = 1;
                 f = T->ipow20[202];
             }
-            lq_scale_bands(c, S, Q, mode, f);
+            lq_scale_bands < NS > (c, S, Q, mode, f);
         }
     }
     return 0;
@@ -842,30 +829,26 @@ lq_loop_break(const LhCtx & c, const LhQS & S, const LhQR & R, const LhGrR & g)
 }
 
 /* reference quantize.c:940-988 */
-LH_DEVFN int
+template < int NS > LH_DEVFN int
 lq_balance_noise(const LhCtx & c, LhQS & S, LhChanLds & Q, const LhQR & R, LhGrR & g)
 {
     int     status;
-    LH_PT(t_bal);
-    lq_amp_scalefac_bands(c, S, R, g);
-    LH_PA(37, t_bal);
+    lq_amp_scalefac_bands < NS > (c, S, R, g);
     status = lq_loop_break(c, S, R, g);
-    LH_PA(38, t_bal);
     if (status)
         return 0;
     status = lq_scale_bitcount(c, S, R, g);
-    LH_PA(39, t_bal);
     if (!status)
         return 1;
     if (c.ns > 1) {
         S.ph = 0;
         if (!g.scalefac_scale) {
-            lq_inc_scalefac_scale(c, S, R, g);
+            lq_inc_scalefac_scale < NS > (c, S, R, g);
             status = 0;
         }
         else {
             if (R.block_type == LH_SHORT_TYPE && c.subblock_gain > 0)
-                status = lq_inc_subblock_gain(c, S, Q, R, g) || lq_loop_break(c, S, R, g);
+                status = lq_inc_subblock_gain < NS > (c, S, Q, R, g) || lq_loop_break(c, S, R, g);
         }
     }
     if (!status)
@@ -874,7 +857,7 @@ lq_balance_noise(const LhCtx & c, LhQS & S, LhChanLds & Q, const LhQR & R, LhGrR
 }
 
 /* reference quantize.c:367-429 */
-LH_DEVFN int
+template < int NS > LH_DEVFN int
 lq_bin_search(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q, int desired_rate, int ch)
 {
     int     nBits;
@@ -886,7 +869,7 @@ lq_bin_search(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q, int
     desired_rate -= g.part2_length;
     for (;;) {
         int     step;
-        nBits = lq_count_bits < 0 > (c, S, R, g, Q);
+        nBits = lq_count_bits < 0, NS > (c, S, R, g, Q);
         if (CurrentStep == 1 || nBits == desired_rate)
             break;
         if (nBits > desired_rate) {
@@ -917,7 +900,7 @@ lq_bin_search(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q, int
     }
     while (nBits > desired_rate && g.global_gain < 255) {
         g.global_gain++;
-        nBits = lq_count_bits < 0 > (c, S, R, g, Q);
+        nBits = lq_count_bits < 0, NS > (c, S, R, g, Q);
     }
     if (c.lane == 0) {
         c.st->CurrentStep[ch] = (start - g.global_gain >= 4) ? 4 : 2;
@@ -929,30 +912,27 @@ lq_bin_search(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q, int
 
 /* reference quantize.c:1010-1197; gb = cod_info.  On return the best image and its scalefactors
  * are in Q.ix[0] / Q.sf[0]. */
-LH_DEVFN int
-lq_outer_loop(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & gb, const float *xr, int ch, int targ_bits)
+template < int NS > LH_DEVFN int
+lq_outer_loop(const LhCtx & c, LhQS & S, LhChanLds & Q, LhQR & R, LhGrR & gb, int ch, int targ_bits)
 {
-    LhQS    S;
     LhGrR   gw;
     LhNoiseRes best_noise_info;
     int     huff_bits, better, age;
     int     best_part2_3_length = 9999999;
 
-    lq_load(c, S, Q, R, gb, xr);
-    R.s_mnc = lh_uni_i((int) Q.sfb_of_line[R.mnc]);
     {
         LH_PT(t_bs);
-        (void) lq_bin_search(c, S, R, gb, Q, targ_bits, ch);
+        (void) lq_bin_search < NS > (c, S, R, gb, Q, targ_bits, ch);
         LH_PA(7, t_bs);
     }
     best_noise_info.over_count = 100;
     if (c.ns) {
         R.pn_global_gain = 0;
         R.pn_sfb_count1 = 0;
-        lq_calc_noise(c, S, R, gb, Q, best_noise_info);
+        lq_calc_noise < NS > (c, S, R, gb, Q, best_noise_info);
         best_noise_info.bits = gb.part2_3_length;
 #pragma unroll
-        for (int k = 0; k < 5; k++)
+        for (int k = 0; k < NS; k++)
             S.pb[k] = S.pw[k];
         S.sfbest = S.sfw;
         S.tselb = S.tselw;
@@ -964,7 +944,7 @@ lq_outer_loop(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & gb, const float 
             int     maxggain = 255;
             {
                 LH_PT(t_bn);
-                int const bn = lq_balance_noise(c, S, Q, R, gw);
+                int const bn = lq_balance_noise < NS > (c, S, Q, R, gw);
                 LH_PA(8, t_bn);
                 if (bn == 0)
                     break;
@@ -974,12 +954,12 @@ lq_outer_loop(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & gb, const float 
             huff_bits = targ_bits - gw.part2_length;
             if (huff_bits <= 0)
                 break;
-            while ((gw.part2_3_length = lq_count_bits < 1 > (c, S, R, gw, Q)) > huff_bits && gw.global_gain <= maxggain)
+            while ((gw.part2_3_length = lq_count_bits < 1, NS > (c, S, R, gw, Q)) > huff_bits && gw.global_gain <= maxggain)
                 gw.global_gain++;
             if (gw.global_gain > maxggain)
                 break;
             if (best_noise_info.over_count == 0) {
-                while ((gw.part2_3_length = lq_count_bits < 1 > (c, S, R, gw, Q)) > best_part2_3_length
+                while ((gw.part2_3_length = lq_count_bits < 1, NS > (c, S, R, gw, Q)) > best_part2_3_length
                        && gw.global_gain <= maxggain)
                     gw.global_gain++;
                 if (gw.global_gain > maxggain)
@@ -987,7 +967,7 @@ lq_outer_loop(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & gb, const float 
             }
             {
                 LH_PT(t_cn);
-                lq_calc_noise(c, S, R, gw, Q, noise_info);
+                lq_calc_noise < NS > (c, S, R, gw, Q, noise_info);
                 LH_PA(9, t_cn);
             }
             noise_info.bits = gw.part2_3_length;
@@ -996,7 +976,7 @@ lq_outer_loop(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & gb, const float 
                 best_part2_3_length = gb.part2_3_length;
                 best_noise_info = noise_info;
 #pragma unroll
-                for (int k = 0; k < 5; k++)
+                for (int k = 0; k < NS; k++)
                     S.pb[k] = S.pw[k];
                 S.sfbest = S.sfw;
                 S.tselb = S.tselw;
@@ -1014,7 +994,7 @@ lq_outer_loop(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & gb, const float 
     }
     else {
 #pragma unroll
-        for (int k = 0; k < 5; k++)
+        for (int k = 0; k < NS; k++)
             S.pb[k] = S.pw[k];
         S.sfbest = S.sfw;
         S.tselb = S.tselw;
@@ -1036,15 +1016,42 @@ lq_outer_loop(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & gb, const float 
     return best_noise_info.over_count;
 }
 
-/* out-of-line entry (own register allocation): R / g travel through the wave's LDS slot */
-LH_STAGEFN void
-lq_outer_loop_stage(int qch, int gr, int targ_bits)
+/* out-of-line entries (own register allocation): R / g travel through the wave's LDS slot.  One per
+ * slot count; the fifth slot (lines 512..575) drops out of the search when nothing is quantised
+ * there and its xrpow is all zero (it could otherwise still raise xrpow_max): the usual case below
+ * 20 kHz. */
+template < int NS > LH_DEVFN void
+lq_stage_body(int qch, int gr, int targ_bits)
 {
     LhCtx const c = lh_ctx_load();
     LhQR    R = lh_uniform(lh_lds.rg[qch].R);
     LhGrR   g = lh_uniform(lh_lds.rg[qch].g);
-    (void) lq_outer_loop(c, lh_lds.u.quant.ch[qch], R, g, lh_lds.xr[qch][lh_uni_i(gr)], qch, lh_uni_i(targ_bits));
+    LhChanLds & Q = lh_lds.u.quant.ch[qch];
+    LhQS    S;
+    R.s_mnc = lh_uni_i((int) Q.sfb_of_line[R.mnc]);
+    lq_load(c, S, Q, R, g, lh_lds.xr[qch][lh_uni_i(gr)]);
+    (void) lq_outer_loop < NS > (c, S, Q, R, g, qch, lh_uni_i(targ_bits));
     lh_rg_put(c, R, g);
+}
+
+LH_STAGEFN void
+lq_outer_loop_stage5(int qch, int gr, int targ_bits)
+{
+    lq_stage_body < 5 > (qch, gr, targ_bits);
+}
+
+LH_STAGEFN void
+lq_outer_loop_stage4(int qch, int gr, int targ_bits)
+{
+    lq_stage_body < 4 > (qch, gr, targ_bits);
+}
+
+/* which of the two applies: wave-uniform; Q.xrpow and R.mnc are final (after lh_calc_xmin) */
+LH_DEVFN int
+lq_needs_tail(const LhCtx & c, const LhChanLds & Q, const LhQR & R)
+{
+    int const i = 512 + 2 * (c.lane & 31);
+    return (R.mnc >= 512) || (lh_ballot(Q.xrpow[i] != 0.0f || Q.xrpow[i + 1] != 0.0f) != 0);
 }
 
 #endif

@@ -408,7 +408,10 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo)
                 if (abr && !R.ath_over)
                     targ_bits[ch] = analog_silence_bits;    /* reference quantize.c:1953-1954 */
                 lh_rg_put(c, R, g);
-                lq_outer_loop_stage(ch, gr, targ_bits[ch]);
+                if (lq_needs_tail(c, Q, R))
+                    lq_outer_loop_stage5(ch, gr, targ_bits[ch]);
+                else
+                    lq_outer_loop_stage4(ch, gr, targ_bits[ch]);
                 R = lh_uniform(L.rg[ch].R);
                 g = lh_uniform(L.rg[ch].g);
                 LH_PA(5, t_ol);

@@ -15,7 +15,7 @@ OUT = "/tmp/isa_marks"
 
 
 def main():
-    fn = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "lq_outer_loop_stage"
+    fn = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "lq_outer_loop_stage4"
     os.makedirs(OUT, exist_ok=True)
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-fast-math", "-ffp-contract=off",
            "-fPIC", "-I.", "-I../../include", "-DLH_MARK", "-c", "lh_kernels.hip", "-o", OUT + "/k.o", "-save-temps=obj",
