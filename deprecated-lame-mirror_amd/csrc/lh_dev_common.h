@@ -84,7 +84,12 @@ struct LhGrR {
 LH_DEVFN int
 lh_sbg(const LhGrR & g, int w)
 {
-    return w == 0 ? g.subblock_gain[0] : w == 1 ? g.subblock_gain[1] : w == 2 ? g.subblock_gain[2] : g.subblock_gain[3];
+    /* the four values pass through readfirstlane first: a select between plain loads of the
+     * struct's fields is turned into ONE load from a selected address by the optimiser, and that
+     * dynamic address pins the whole struct (every use of it, everywhere) in scratch memory */
+    int const a = lh_uni_i(g.subblock_gain[0]), b = lh_uni_i(g.subblock_gain[1]), c2 = lh_uni_i(g.subblock_gain[2]),
+        d = lh_uni_i(g.subblock_gain[3]);
+    return w == 0 ? a : w == 1 ? b : w == 2 ? c2 : d;
 }
 
 /* wave-uniform per-granule geometry + the scalar part of calc_noise_data */

@@ -27,12 +27,9 @@
 
 struct LhQS {
     /* lane = pair slots */
-    float   ax[10];             /* |xr| of lines 2p, 2p+1 of slot k at [2k], [2k+1] */
     float   xp[10];             /* xrpow */
     uint32_t pw[5];             /* working image: low half = even line */
-    uint32_t pb[5];             /* best image */
     int     bnd[5];             /* band of the pair (63: the slot holds no pair) */
-    int     bq[5];              /* the same, but 63 as well when the pair lies above max_nonzero_coeff */
     uint32_t vm[5];             /* all ones when the pair lies at or below max_nonzero_coeff, else 0 */
     float   lmax;               /* the lane's largest xrpow (xrpow_max = the maximum over the lanes) */
     /* lane = band */
@@ -45,9 +42,13 @@ struct LhQS {
     int     ph;                 /* pseudohalf */
     /* lane = region (0..2): table_select of the working / best image */
     int     tselw, tselb;
-    /* lane j = value for global_gain gbase + j: 1 / step size and the xrpow bound of count_bits */
+    /* lanes 0..15: ipow20[210 + lane] and IXMAX / ipow20[210 + lane].  ipow20[g] = 2^(-3 (g - 210) / 16) as
+     * the host rounded it, and ipow20[210 + 16 a + b] = ldexp(ipow20[210 + b], -3 a) holds for the
+     * whole table (checked by lh_tables_check() on the host: a power of two scales exactly), so
+     * these 16 values give 1 / step and the xrpow bound of count_bits for every global_gain */
     float   istepv, thrv;
-    int     gbase;
+    int     sbg8;               /* lane = band: 8 * subblock_gain[window] of the working image */
+    float   m0, m1, m2, m3;     /* POW20(210 .. 213): the four mantissas of the step table (wave-uniform) */
 };
 
 LH_DEVFN int
@@ -61,7 +62,7 @@ LH_DEVFN int
 lq_band_step(const LhQS & S, const LhGrR & g)
 {
     int const pre = g.preflag ? S.pre : 0;
-    return g.global_gain - ((S.sfw + pre) << (g.scalefac_scale + 1)) - lh_sbg(g, S.win) * 8;
+    return g.global_gain - ((S.sfw + pre) << (g.scalefac_scale + 1)) - S.sbg8;
 }
 
 /* ---- Huffman length grids (layout: LhChanLds in lh_dev_common.h) ---- */
@@ -127,22 +128,37 @@ lq_class_tabs(int cls, uint32_t *A, uint32_t *B)
     }
 }
 
-/* 1 / step and xrpow bound for the gains gbase .. gbase + 63, one per lane */
-LH_DEVFN void
-lq_gain_window(const LhCtx & c, LhQS & S, int gain)
+/* ldexp by a wave-uniform exponent (exact: the results stay normal) */
+LH_DEVFN float
+lq_ldexp(float v, int e)
 {
-    int     b = gain - 24;
-    b = b < 0 ? 0 : (b > 192 ? 192 : b);
-    S.gbase = b;
-    S.istepv = c.T->ipow20[b + c.lane];
-    S.thrv = (LH_IXMAX) / S.istepv;
+#ifdef LH_EMU
+    return ldexpf(v, e);
+#else
+    return __builtin_amdgcn_ldexpf(v, e);
+#endif
+}
+
+/* one line through the quantiser with the rounding table read from HBM only (the rare path for
+ * values >= 256; no LDS / HBM pointer mix, which would make the loads FLAT) */
+LH_DEVFN int
+lq_quant_line_hbm(const LhTables * T, float istep, float xp)
+{
+    double  x0 = (double) (istep * xp);
+    float   f;
+    int     k;
+    x0 += LH_MAGIC_FLOAT;
+    f = (float) x0;
+    k = (int) lh_f32_as_u32(f) - LH_MAGIC_INT;
+    f = (float) (x0 + T->adj43asm[k]);
+    return (int) lh_f32_as_u32(f) - LH_MAGIC_INT;
 }
 
 /* load the granule into registers; Q.xrpow, Q.l3_xmin and the geometry arrays were written by
  * lh_init_outer_loop / lh_init_xrpow / lh_calc_xmin.  Then the arrays the search does not need in
  * LDS make room for the Huffman length grids. */
 LH_DEVFN void
-lq_load(const LhCtx & c, LhQS & S, LhChanLds & Q, const LhQR & R, const LhGrR & g, const float *xr)
+lq_load(const LhCtx & c, LhQS & S, LhChanLds & Q, const LhQR & R, const LhGrR & g)
 {
     const LhQTabs *qt = LH_QT;
     int const pm = R.mnc >> 1;
@@ -153,18 +169,13 @@ lq_load(const LhCtx & c, LhQS & S, LhChanLds & Q, const LhQR & R, const LhGrR & 
         int const p = c.lane + 64 * k;
         int const ok = (k < 4 || p < 288);
         int const pc = ok ? p : 287;
-        lh_f32x2 const a = ((const lh_f32x2 *) xr)[pc];
         lh_f32x2 const x = ((const lh_f32x2 *) Q.xrpow)[pc];
         int const b = Q.sfb_of_line[2 * pc];
-        S.ax[2 * k] = ok ? lh_fabsf(a.x) : 0.0f;
-        S.ax[2 * k + 1] = ok ? lh_fabsf(a.y) : 0.0f;
         S.xp[2 * k] = ok ? x.x : 0.0f;
         S.xp[2 * k + 1] = ok ? x.y : 0.0f;
         S.bnd[k] = ok ? b : 63;
-        S.bq[k] = (ok && p <= pm) ? b : 63;
         S.vm[k] = (ok && p <= pm) ? 0xffffffffu : 0u;
         S.pw[k] = 0u;
-        S.pb[k] = 0u;
         mx = S.xp[2 * k] > mx ? S.xp[2 * k] : mx;
         mx = S.xp[2 * k + 1] > mx ? S.xp[2 * k + 1] : mx;
     }
@@ -184,11 +195,15 @@ lq_load(const LhCtx & c, LhQS & S, LhChanLds & Q, const LhQR & R, const LhGrR & 
         S.dist = 0;
         S.ph = Q.pseudohalf[s];
     }
-    S.tselw = (c.lane == 0) ? g.table_select[0] : (c.lane == 1) ? g.table_select[1] : g.table_select[2];
+    S.tselw = 0;                /* table_select is all zero after lh_init_outer_loop */
     S.tselb = S.tselw;
-    S.gbase = -100000;         /* no window yet */
-    S.istepv = 0;
-    S.thrv = 0;
+    S.m0 = lh_uni_f(c.T->pow20[210 + LH_QMAX2]);
+    S.m1 = lh_uni_f(c.T->pow20[211 + LH_QMAX2]);
+    S.m2 = lh_uni_f(c.T->pow20[212 + LH_QMAX2]);
+    S.m3 = lh_uni_f(c.T->pow20[213 + LH_QMAX2]);
+    S.istepv = c.T->ipow20[210 + (c.lane & 15)];
+    S.thrv = (LH_IXMAX) / S.istepv;
+    S.sbg8 = 0;                 /* so is subblock_gain */
     LH_WAVE_SYNC();
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -217,11 +232,10 @@ lq_count_bits(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
     const LhQTabs *qt = LH_QT;
     int const lane = c.lane;
     float   istep;
-    if ((unsigned) (g.global_gain - S.gbase) >= 64u)
-        lq_gain_window(c, S, g.global_gain);
-    istep = lh_u32_as_f32(lh_bcast_u32(lh_f32_as_u32(S.istepv), g.global_gain - S.gbase));
     {
-        float const thr = lh_u32_as_f32(lh_bcast_u32(lh_f32_as_u32(S.thrv), g.global_gain - S.gbase));
+        int const d = g.global_gain - 210, ga = d >> 4, gb_ = d & 15;
+        float const thr = lq_ldexp(lh_u32_as_f32(lh_bcast_u32(lh_f32_as_u32(S.thrv), gb_)), 3 * ga);
+        istep = lq_ldexp(lh_u32_as_f32(lh_bcast_u32(lh_f32_as_u32(S.istepv), gb_)), -3 * ga);
         if (lh_ballot(S.lmax > thr))
             return LH_LARGE_BITS;
     }
@@ -271,8 +285,8 @@ lq_count_bits(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
             /* rare: a quantised value >= 256, its rounding offset lives in HBM */
 #pragma unroll
             for (int k = 0; k < NS; k++) {
-                int const q0 = lh_quant_line(T, qt, istep, S.xp[2 * k]);
-                int const q1 = lh_quant_line(T, qt, istep, S.xp[2 * k + 1]);
+                int const q0 = lq_quant_line_hbm(T, istep, S.xp[2 * k]);
+                int const q1 = lq_quant_line_hbm(T, istep, S.xp[2 * k + 1]);
                 nq[k] = ((uint32_t) (q0 & 0xffff) | ((uint32_t) q1 << 16)) & S.vm[k];
             }
         }
@@ -286,9 +300,9 @@ lq_count_bits(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
 #pragma unroll
             for (int k = 0; k < NS; k++) {
                 int const p = lane + 64 * k;
-                int const nc = lq_bit(ncmask, S.bq[k]), z1 = lq_bit(m01mask, S.bq[k]);
-                uint32_t const v01 = ((compareval0 > S.xp[2 * k]) ? 0u : 1u)
-                    | (((compareval0 > S.xp[2 * k + 1]) ? 0u : 1u) << 16);
+                int const nc = lq_bit(ncmask, S.bnd[k]), z1 = lq_bit(m01mask, S.bnd[k]);
+                uint32_t const v01 = (((compareval0 > S.xp[2 * k]) ? 0u : 1u)
+                                      | (((compareval0 > S.xp[2 * k + 1]) ? 0u : 1u) << 16)) & S.vm[k];
                 uint32_t v = nc ? (z1 ? v01 : nq[k]) : S.pw[k];
                 if (zero_mnc && p == pm)
                     v &= 0xffffu;
@@ -494,42 +508,53 @@ lq_count_bits(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
 
 /* reference quantize_pvt.c:750-913 on the working image */
 template < int NS > LH_DEVFN void
-lq_calc_noise(const LhCtx & c, LhQS & S, LhQR & R, const LhGrR & g, LhChanLds & Q, LhNoiseRes & res)
+lq_calc_noise(const LhCtx & c, LhQS & S, LhQR & R, const LhGrR & g, LhChanLds & Q, const float *xr, LhNoiseRes & res)
 {
     const LhTables *T = c.T;
     const LhQTabs *qt = LH_QT;
     int const s = c.lane;
     float  *sq = Q.xrpow;       /* the LDS copy of xrpow is dead while the search runs */
     float   noise = 0, noise_s = 0;
-    int     st, l = 0, j = 0, fresh, big = 0, maxw;
+    int     l = 0, j = 0, big = 0, maxw;
     LH_PC(13);
-    st = lq_band_step(S, g);
-    fresh = (s < R.psymax) && !(S.pnstep == st);
+    LQ_MARK("cn_begin");
+    int const st = lq_band_step(S, g);
+    int const fresh = (s < R.psymax) && !(S.pnstep == st);
+    /* POW20(st) = 2^((st - 210) / 4): one of four mantissas (the table's own entries for 210..213,
+     * in scalar registers) times a power of two -- pow20[i + 4] = 2 pow20[i] holds for the whole
+     * table (lh_tables_check()), so no table look-up is needed */
+    float   step;
     {
-        float const step = fresh ? T->pow20[st + LH_QMAX2] : 0.0f;
-        if (fresh) {
-            l = S.wid >> 1;
-            j = S.sta;
-            if ((j + S.wid) > R.mnc) {
-                int const usefullsize = R.mnc - j + 1;
-                l = (usefullsize > 0) ? (usefullsize >> 1) : 0;
-            }
-        }
-        if (s <= LH_SFBMAX)
-            Q.sfb_f[s] = step;
+        int const d = st - 210, q = d >> 2, r = d & 3;
+        /* (through readfirstlane: a select between plain loads of S's fields would become one load
+         * from a selected address and pin all of S in scratch memory, see lh_sbg()) */
+        float const m0 = lh_uni_f(S.m0), m1 = lh_uni_f(S.m1), m2 = lh_uni_f(S.m2), m3 = lh_uni_f(S.m3);
+        float const m = (r & 2) ? ((r & 1) ? m3 : m2) : ((r & 1) ? m1 : m0);
+        step = lq_ldexp(m, q);
     }
-    maxw = (int) lh_wave_max_u32(fresh ? (unsigned) (2 * l) : 0u);
-    LH_WAVE_SYNC();
+    if (fresh) {
+        l = S.wid >> 1;
+        j = S.sta;
+        if ((j + S.wid) > R.mnc) {
+            int const usefullsize = R.mnc - j + 1;
+            l = (usefullsize > 0) ? (usefullsize >> 1) : 0;
+        }
+    }
     {
+        /* the band's step goes to its lines with one cross-lane read per slot; the squared errors
+         * of all lines go to LDS, where the band lanes add them up in the reference's order */
         float   stp[5], p43[10];
+        lh_f32x2 ax[5];
 #pragma unroll
         for (int k = 0; k < NS; k++) {
             unsigned const q0 = S.pw[k] & 0xffffu, q1 = S.pw[k] >> 16;
-            stp[k] = Q.sfb_f[S.bq[k] < LH_SFBMAX ? S.bq[k] : LH_SFBMAX];
+            ax[k] = ((const lh_f32x2 *) xr)[(k < 4 || c.lane < 32) ? c.lane + 64 * k : 287];
+            stp[k] = lh_shfl_f32(step, S.bnd[k]);
             p43[2 * k] = qt->pow43h[q0 & 255u];
             p43[2 * k + 1] = qt->pow43h[q1 & 255u];
             big |= (int) ((q0 | q1) >> 8);
         }
+        maxw = (int) lh_wave_max_u32(fresh ? (unsigned) (2 * l) : 0u);
         if (lh_ballot(big != 0)) {
 #pragma unroll
             for (int k = 0; k < NS; k++) {
@@ -543,8 +568,8 @@ lq_calc_noise(const LhCtx & c, LhQS & S, LhQR & R, const LhGrR & g, LhChanLds & 
 #pragma unroll
         for (int k = 0; k < NS; k++) {
             int const p = c.lane + 64 * k;
-            float const t0 = S.ax[2 * k] - p43[2 * k] * stp[k];
-            float const t1 = S.ax[2 * k + 1] - p43[2 * k + 1] * stp[k];
+            float const t0 = lh_fabsf(ax[k].x) - p43[2 * k] * stp[k];
+            float const t1 = lh_fabsf(ax[k].y) - p43[2 * k + 1] * stp[k];
             lh_f32x2 v;
             v.x = t0 * t0;
             v.y = t1 * t1;
@@ -553,18 +578,28 @@ lq_calc_noise(const LhCtx & c, LhQS & S, LhQR & R, const LhGrR & g, LhChanLds & 
         }
     }
     LH_WAVE_SYNC();
+    LQ_MARK("cn_sum");
     {
+        /* eight terms per trip, fetched as four aligned pairs (band starts are even) one trip
+         * ahead of the additions; a pair beyond the band's length comes from a pair of zeros
+         * (adding +0.0f leaves the non-negative sum unchanged) */
         int const n = 2 * l;
-        int const jj = (j < 576) ? j : 0;
+        int const jj = (j < 576) ? (j >> 1) : 0;
         const lh_f32x2 *sq2 = (const lh_f32x2 *) sq;
-        const lh_f32x2 *zero = (const lh_f32x2 *) Q.zero2;
-        for (int k0 = 0; k0 < maxw; k0 += 8) {
-            lh_f32x2 t[4];
+        /* the pair of zeros, as an index from the start of the channel's LDS image (sq = Q.xrpow is
+         * its first member): an index is selected, never a pointer */
+        int const zoff = (int) (__builtin_offsetof(LhChanLds, zero2) / sizeof(lh_f32x2));
+        lh_f32x2 t[4], tn[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const lh_f32x2 *src = (k0 + 2 * u < n) ? &sq2[(jj + k0) / 2 + u] : zero;
-                t[u] = *src;
-            }
+        for (int u = 0; u < 4; u++)
+            tn[u] = sq2[(2 * u < n) ? jj + u : zoff];
+        for (int k0 = 0; k0 < maxw; k0 += 8) {
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                t[u] = tn[u];
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                tn[u] = sq2[(k0 + 8 + 2 * u < n) ? jj + (k0 >> 1) + 4 + u : zoff];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 noise += t[u].x;
@@ -572,6 +607,7 @@ lq_calc_noise(const LhCtx & c, LhQS & S, LhQR & R, const LhGrR & g, LhChanLds & 
             }
         }
     }
+    LQ_MARK("cn_log");
     if (s < R.psymax) {
         float   distort_;
         if (!fresh) {
@@ -590,6 +626,7 @@ lq_calc_noise(const LhCtx & c, LhQS & S, LhQR & R, const LhGrR & g, LhChanLds & 
         noise_s = noise;
     }
     R.pn_global_gain = g.global_gain;
+    LQ_MARK("cn_agg");
     {
         int const mine = (s < R.psymax);
         int     tmp = 0;
@@ -599,11 +636,11 @@ lq_calc_noise(const LhCtx & c, LhQS & S, LhQR & R, const LhGrR & g, LhChanLds & 
                 tmp = 1;
         }
         res.over_count = lh_popc64(lh_ballot(mine && noise_s > 0.0f));
-        res.over_SSD = (int) lh_wave_sum_u32((unsigned) (tmp * tmp));
-        res.max_noise = lh_wave_max_f32(mine ? noise_s : -20.0f);
+        lh_wave_sum_maxf((unsigned) (tmp * tmp), mine ? noise_s : -20.0f, &res.over_SSD, &res.max_noise);
         res.tot_noise = 0;      /* not read by the comparator of this path (quant_comp 9) */
         res.over_noise = 0;
     }
+    LQ_MARK("cn_end");
 }
 
 /* multiply the lines of the bands in `bands' by factor (xrpow only grows, so the lane's maximum
@@ -707,13 +744,16 @@ lq_amp_scalefac_bands(const LhCtx & c, LhQS & S, const LhQR & R, LhGrR & g)
     }
 }
 
-/* reference takehiro.c:1135-1188 (MPEG-1) on the working scalefactors */
+/* reference takehiro.c:1135-1188 (MPEG-1) on the working scalefactors.  The two maxima the
+ * reference takes (slen1 / slen2 part) are only compared with powers of two, so each lane
+ * contributes the thermometer code of its scalefactor's bit length, the parts side by side,
+ * and one OR over the wave replaces two maximum reductions. */
 LH_DEVFN int
 lq_scale_bitcount(const LhCtx & c, LhQS & S, const LhQR & R, LhGrR & g)
 {
-    const LhQTabs *qt = LH_QT;
-    int     k, max_slen1, max_slen2;
+    int     k;
     int     v = (c.lane < R.sfbmax) ? S.sfw : 0;
+    uint32_t th;
     if (R.block_type != LH_SHORT_TYPE) {
         if (!g.preflag) {
             int const inr = (c.lane >= 11 && c.lane < LH_SBPSY_L);
@@ -727,9 +767,13 @@ lq_scale_bitcount(const LhCtx & c, LhQS & S, const LhQR & R, LhGrR & g)
             }
         }
     }
-    (void) qt;
-    max_slen1 = (int) lh_wave_max_u32((c.lane < R.sfbdivide && v > 0) ? (unsigned) v : 0u);
-    max_slen2 = (int) lh_wave_max_u32((c.lane >= R.sfbdivide && c.lane < R.sfbmax && v > 0) ? (unsigned) v : 0u);
+    {
+        int     bl = 32 - lh_clz32((uint32_t) (v > 0 ? v : 0));      /* 0 for v <= 0 */
+        uint32_t t;
+        bl = bl > 8 ? 8 : bl;
+        t = (1u << bl) - 1u;
+        th = lh_wave_or_u32((c.lane < R.sfbdivide) ? t : ((c.lane < R.sfbmax) ? (t << 8) : 0u));
+    }
     g.part2_length = LH_LARGE_BITS;
     k = c.lane & 15;
     {
@@ -737,9 +781,10 @@ lq_scale_bitcount(const LhCtx & c, LhQS & S, const LhQR & R, LhGrR & g)
         int const s1 = (int) ((0x4433322211130000ull >> (4 * k)) & 15u);
         int const s2 = (int) ((0x3232132132103210ull >> (4 * k)) & 15u);
         int const sz = (R.block_type == LH_SHORT_TYPE) ? 18 * (s1 + s2) : 11 * s1 + 10 * s2;
-        if (c.lane < 16 && max_slen1 < (1 << s1) && max_slen2 < (1 << s2))
+        /* max < 2^s  <=>  bit s of the thermometer code is clear */
+        if (c.lane < 16 && !((th >> s1) & 1u) && !((th >> (8 + s2)) & 1u))
             key = ((unsigned) sz << 8) | (unsigned) k;
-        best = lh_wave_min_u32(key);
+        best = lh_row0_min_u32(key);
         if (best != 0xffffffffu) {
             g.part2_length = (int) (best >> 8);
             g.scalefac_compress = (int) (best & 255u);
@@ -794,6 +839,7 @@ lq_inc_subblock_gain(const LhCtx & c, LhQS & S, LhChanLds & Q, const LhQR & R, L
         g.subblock_gain[0] += (window == 0);
         g.subblock_gain[1] += (window == 1);
         g.subblock_gain[2] += (window == 2);
+        S.sbg8 = lh_sbg(g, S.win) * 8;
         {
             int     mode = 0;
             float   f = 1.0f;
@@ -910,10 +956,24 @@ lq_bin_search(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q, int
     return nBits;
 }
 
+/* the working image becomes the best one: it goes to its final place in LDS (Q.ix[0]) */
+template < int NS > LH_DEVFN void
+lq_keep_best(const LhCtx & c, LhQS & S, LhChanLds & Q)
+{
+#pragma unroll
+    for (int k = 0; k < NS; k++) {
+        int const p = c.lane + 64 * k;
+        if (k < 4 || p < 288)
+            ((uint32_t *) Q.ix[0])[p] = S.pw[k];
+    }
+    S.sfbest = S.sfw;
+    S.tselb = S.tselw;
+}
+
 /* reference quantize.c:1010-1197; gb = cod_info.  On return the best image and its scalefactors
  * are in Q.ix[0] / Q.sf[0]. */
 template < int NS > LH_DEVFN int
-lq_outer_loop(const LhCtx & c, LhQS & S, LhChanLds & Q, LhQR & R, LhGrR & gb, int ch, int targ_bits)
+lq_outer_loop(const LhCtx & c, LhQS & S, LhChanLds & Q, LhQR & R, LhGrR & gb, const float *xr, int ch, int targ_bits)
 {
     LhGrR   gw;
     LhNoiseRes best_noise_info;
@@ -929,13 +989,9 @@ lq_outer_loop(const LhCtx & c, LhQS & S, LhChanLds & Q, LhQR & R, LhGrR & gb, in
     if (c.ns) {
         R.pn_global_gain = 0;
         R.pn_sfb_count1 = 0;
-        lq_calc_noise < NS > (c, S, R, gb, Q, best_noise_info);
+        lq_calc_noise < NS > (c, S, R, gb, Q, xr, best_noise_info);
         best_noise_info.bits = gb.part2_3_length;
-#pragma unroll
-        for (int k = 0; k < NS; k++)
-            S.pb[k] = S.pw[k];
-        S.sfbest = S.sfw;
-        S.tselb = S.tselw;
+        lq_keep_best < NS > (c, S, Q);
         gw = gb;
         age = 0;
         do {
@@ -967,7 +1023,7 @@ lq_outer_loop(const LhCtx & c, LhQS & S, LhChanLds & Q, LhQR & R, LhGrR & gb, in
             }
             {
                 LH_PT(t_cn);
-                lq_calc_noise < NS > (c, S, R, gw, Q, noise_info);
+                lq_calc_noise < NS > (c, S, R, gw, Q, xr, noise_info);
                 LH_PA(9, t_cn);
             }
             noise_info.bits = gw.part2_3_length;
@@ -975,11 +1031,7 @@ lq_outer_loop(const LhCtx & c, LhQS & S, LhChanLds & Q, LhQR & R, LhGrR & gb, in
             if (better) {
                 best_part2_3_length = gb.part2_3_length;
                 best_noise_info = noise_info;
-#pragma unroll
-                for (int k = 0; k < NS; k++)
-                    S.pb[k] = S.pw[k];
-                S.sfbest = S.sfw;
-                S.tselb = S.tselw;
+                lq_keep_best < NS > (c, S, Q);
                 gb = gw;
                 age = 0;
             }
@@ -992,24 +1044,14 @@ lq_outer_loop(const LhCtx & c, LhQS & S, LhChanLds & Q, LhQR & R, LhGrR & gb, in
         }
         while ((gw.global_gain + gw.scalefac_scale) < 255);
     }
-    else {
-#pragma unroll
-        for (int k = 0; k < NS; k++)
-            S.pb[k] = S.pw[k];
-        S.sfbest = S.sfw;
-        S.tselb = S.tselw;
-    }
+    else
+        lq_keep_best < NS > (c, S, Q);
     gb.table_select[0] = (int) lh_bcast_u32((uint32_t) S.tselb, 0);
     gb.table_select[1] = (int) lh_bcast_u32((uint32_t) S.tselb, 1);
     gb.table_select[2] = (int) lh_bcast_u32((uint32_t) S.tselb, 2);
-    /* hand the result to the finishing stages through the LDS image */
+    /* hand the result to the finishing stages through the LDS image (the quantised lines are
+     * there already; with four slots the fifth is zero since lq_load) */
     LH_WAVE_SYNC();
-#pragma unroll
-    for (int k = 0; k < 5; k++) {
-        int const p = c.lane + 64 * k;
-        if (k < 4 || p < 288)
-            ((uint32_t *) Q.ix[0])[p] = S.pb[k];
-    }
     if (c.lane <= LH_SFBMAX)
         Q.sf[0][c.lane] = S.sfbest;
     LH_WAVE_SYNC();
@@ -1029,8 +1071,8 @@ lq_stage_body(int qch, int gr, int targ_bits)
     LhChanLds & Q = lh_lds.u.quant.ch[qch];
     LhQS    S;
     R.s_mnc = lh_uni_i((int) Q.sfb_of_line[R.mnc]);
-    lq_load(c, S, Q, R, g, lh_lds.xr[qch][lh_uni_i(gr)]);
-    (void) lq_outer_loop < NS > (c, S, Q, R, g, qch, lh_uni_i(targ_bits));
+    lq_load(c, S, Q, R, g);
+    (void) lq_outer_loop < NS > (c, S, Q, R, g, lh_lds.xr[qch][lh_uni_i(gr)], qch, lh_uni_i(targ_bits));
     lh_rg_put(c, R, g);
 }
 

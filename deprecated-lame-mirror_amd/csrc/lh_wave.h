@@ -149,6 +149,41 @@ lh_pk_min_u16(uint32_t a, uint32_t b)
     return (al < bl ? al : bl) | ((ah < bh ? ah : bh) << 16);
 }
 
+
+/* value of lane `src' (per-lane choice) */
+static inline float
+lh_shfl_f32(float v, int src)
+{
+    union { float f; uint32_t u; } c;
+    const uint64_t *x;
+    c.f = v;
+    x = hipemu_wave_exchange(c.u);
+    c.u = (uint32_t) x[src & 63];
+    return c.f;
+}
+
+
+/* an integer sum and a float maximum (no NaNs) at once */
+static inline void
+lh_wave_sum_maxf(uint32_t a, float m, int *sum, float *mx)
+{
+    *sum = (int) lh_wave_sum_u32(a);
+    *mx = lh_wave_max_f32(m);
+}
+
+
+/* minimum over lanes 0..15 */
+static inline uint32_t
+lh_row0_min_u32(uint32_t v)
+{
+    const uint64_t *x = hipemu_wave_exchange(v);
+    uint32_t s = 0xffffffffu;
+    for (int i = 0; i < 16; i++)
+        if ((uint32_t) x[i] < s)
+            s = (uint32_t) x[i];
+    return s;
+}
+
 static inline void lh_lds_add(int *p, int v) { *p += v; }      /* fibers interleave only at sync points */
 static inline void lh_lds_max(int *p, int v) { if (v > *p) *p = v; }
 static inline void lh_lds_addf(float *p, float v) { *p += v; }
@@ -264,6 +299,44 @@ lh_pk_min_u16(uint32_t a, uint32_t b)
     y.u = b;
     r.v = __builtin_elementwise_min(x.v, y.v);
     return r.u;
+}
+
+
+/* value of lane `src' (per-lane choice): ds_bpermute_b32 */
+__device__ __forceinline__ float
+lh_shfl_f32(float v, int src)
+{
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(v)));
+}
+
+/* an integer sum and a float maximum (no NaNs) at once: the two chains' steps side by side */
+__device__ __forceinline__ void
+lh_wave_sum_maxf(uint32_t a, float m, int *sum, float *mx)
+{
+    /* order-preserving map of the float to an unsigned integer */
+    uint32_t const b = (uint32_t) __float_as_int(m);
+    uint32_t k = b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);
+#define LH_SM_STEP(CTRL) { uint32_t const ta_ = lh_dpp < CTRL, 0u > (a), tk_ = lh_dpp < CTRL, 0u > (k); a += ta_; k = tk_ > k ? tk_ : k; }
+#define LH_SM_ROWS(CTRL, MASK) { uint32_t const ta_ = lh_dpp_rows < CTRL, MASK, 0u > (a), tk_ = lh_dpp_rows < CTRL, MASK, 0u > (k); a += ta_; k = tk_ > k ? tk_ : k; }
+    LH_SM_STEP(0xB1) LH_SM_STEP(0x4E) LH_SM_STEP(0x141) LH_SM_STEP(0x140) LH_SM_ROWS(0x142, 0xa) LH_SM_ROWS(0x143, 0xc)
+#undef LH_SM_STEP
+#undef LH_SM_ROWS
+    *sum = __builtin_amdgcn_readlane((int) a, 63);
+    k = (uint32_t) __builtin_amdgcn_readlane((int) k, 63);
+    *mx = __int_as_float((int) (k ^ ((k >> 31) ? 0x80000000u : 0xffffffffu)));
+}
+
+
+/* minimum over lanes 0..15: the four in-row steps only */
+__device__ __forceinline__ uint32_t
+lh_row0_min_u32(uint32_t v)
+{
+    uint32_t t_;
+    t_ = lh_dpp < 0xB1, 0xffffffffu > (v); v = LH_OP_MIN(v, t_);
+    t_ = lh_dpp < 0x4E, 0xffffffffu > (v); v = LH_OP_MIN(v, t_);
+    t_ = lh_dpp < 0x141, 0xffffffffu > (v); v = LH_OP_MIN(v, t_);
+    t_ = lh_dpp < 0x140, 0xffffffffu > (v); v = LH_OP_MIN(v, t_);
+    return (uint32_t) __builtin_amdgcn_readlane((int) v, 0);
 }
 
 typedef float2 lh_f32x2;
