@@ -1589,7 +1589,7 @@ pack_stream(const lamehip_batch * b, int s, const LhFrameOut * fr, int n, unsign
             lh_bs_free(&bs);
             return LAMEHIP_ERR_PAYLOAD;
         }
-        if (bs.buf_byte_idx + 1 > out_size - pos) {
+        if (lh_bs_pending(&bs) > out_size - pos) {
             lh_bs_free(&bs);
             return -1;
         }
@@ -1599,7 +1599,7 @@ pack_stream(const lamehip_batch * b, int s, const LhFrameOut * fr, int n, unsign
     lh_bs_flush(&bs, &b->cfg, n > 0 ? &fr[n - 1] : nullptr);
     {
         int     k;
-        if (bs.buf_byte_idx + 1 > out_size - pos) {
+        if (lh_bs_pending(&bs) > out_size - pos) {
             lh_bs_free(&bs);
             return -1;
         }

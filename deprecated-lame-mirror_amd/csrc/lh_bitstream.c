@@ -1,16 +1,26 @@
 /*
- * lh_bitstream.c -- serial MPEG-1 Layer III bit packer, host side (plain C).
+ * lh_bitstream.c -- MPEG-1 Layer III frame assembly on the host (plain C).
  *
- * north_star keeps this stage on the host: it consumes the per-frame payload
- * the HIP kernels leave in HBM (LhFrameOut = what the reference's
- * format_bitstream reads from gfc->l3_side, reference bitstream.c:917-985) and
- * produces the byte stream.  Frame headers + side info are built ahead of time
- * into a small ring and spliced into the main-data bit stream when the running
- * bit count reaches their slot, exactly as the standard's bit reservoir
- * requires (reference bitstream.c:133-185, 320-485).
+ * Input: the per-frame payload the HIP kernels leave in HBM (LhFrameOut: quantised lines with
+ * signs, scalefactors, side-information fields, reservoir drains -- what the reference's
+ * format_bitstream reads from gfc->l3_side, reference bitstream.c:917-985).  Output: the byte
+ * stream, identical to the reference's.  The optional device packer (lh_dev_emit.h) produces the
+ * same bytes on the GPU; this file serves the lame_encode_buffer handle path, the batch pack
+ * calls and, in the tests, the cross-check of the device packer.
  *
- * l3_enc arrives as signed 16-bit values: magnitude = quantised line, sign =
- * sign of the spectral line (the reference reads it from xr[], bitstream.c:511,584).
+ * Organisation (this file's own):
+ *   sink    main-data bits are shifted into a 64-bit accumulator and leave it a byte at a time;
+ *           every byte passes sink_byte(), the one place that knows about frame headers;
+ *   queue   a frame's header + side information is finished before its main data and waits in a
+ *           ring until the byte stream reaches the position the bit reservoir assigned to it
+ *           (`due', counted in stream bits); sink_byte() drops it in front of the byte that
+ *           arrives at that position;
+ *   frame   lh_bs_format_frame() = stuffing owed to the previous frame, queue the header, main
+ *           data (scalefactors, big-value pairs, count1 quadruples), stuffing, bookkeeping of the
+ *           back pointer, and the consistency checks against the device's reservoir.
+ * The bit layouts are those of ISO/IEC 11172-3 section 2.4.1; the stuffing bytes and the
+ * order of the drains follow the reference (bitstream.c:223-267, 917-985), because its bytes are
+ * the acceptance test.
  */
 #include <stdlib.h>
 #include <string.h>
@@ -18,9 +28,8 @@
 #include "lh_host.h"
 #include "lh_static_tables.h"
 
-static const int slen1_tab[16] = { 0, 0, 0, 0, 3, 1, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4 };
-static const int slen2_tab[16] = { 0, 1, 2, 3, 0, 1, 2, 3, 1, 2, 3, 1, 2, 3, 2, 3 };
-static const char lh_short_version[] = "3.99.5";   /* reference version.c:86-110: spliced into ancillary padding */
+/* error codes left in LhBitstream.error */
+enum { BS_FULL = 1, BS_QUEUE = 2, BS_COUNT = 3, BS_BACKPTR = 4, BS_FLUSH = 5, BS_PAYLOAD = 6, BS_ALIGN = 7 };
 
 int
 lh_bs_init(LhBitstream * bs)
@@ -28,14 +37,7 @@ lh_bs_init(LhBitstream * bs)
     memset(bs, 0, sizeof(*bs));
     bs->buf_size = LH_BS_BUFSIZE;
     bs->buf = (unsigned char *) calloc((size_t) bs->buf_size, 1);
-    if (!bs->buf)
-        return -2;
-    bs->buf_byte_idx = -1;
-    bs->buf_bit_idx = 0;
-    bs->totbit = 0;
-    bs->h_ptr = bs->w_ptr = 0;
-    bs->header[0].write_timing = 0;
-    return 0;
+    return bs->buf ? 0 : -2;
 }
 
 void
@@ -45,438 +47,431 @@ lh_bs_free(LhBitstream * bs)
     bs->buf = 0;
 }
 
-static void
-splice_header(LhBitstream * bs, int sideinfo_len)
+int
+lh_bs_pending(const LhBitstream * bs)
 {
-    memcpy(&bs->buf[bs->buf_byte_idx], bs->header[bs->w_ptr].buf, (size_t) sideinfo_len);
-    bs->buf_byte_idx += sideinfo_len;
-    bs->totbit += sideinfo_len * 8;
-    bs->w_ptr = (bs->w_ptr + 1) & (LH_MAX_HEADER_BUF - 1);
+    return bs->fill;
 }
 
-/* append j bits of val (reference bitstream.c:152-185) */
+/* ---- sink ------------------------------------------------------------------------------ */
+
+/* one finished main-data byte enters the stream; a header whose position has come goes first */
 static void
-putbits(LhBitstream * bs, int sideinfo_len, int val, int j)
+sink_byte(LhBitstream * bs, unsigned byte)
 {
-    while (j > 0) {
-        int     k;
-        if (bs->buf_bit_idx == 0) {
-            bs->buf_bit_idx = 8;
-            bs->buf_byte_idx++;
-            if (bs->buf_byte_idx + LH_MAX_HEADER_LEN + 1 >= bs->buf_size) {
-                bs->error = 1;  /* caller did not drain the buffer */
-                return;
-            }
-            if (bs->header[bs->w_ptr].write_timing == bs->totbit)
-                splice_header(bs, sideinfo_len);
-            bs->buf[bs->buf_byte_idx] = 0;
-        }
-        k = (j < bs->buf_bit_idx) ? j : bs->buf_bit_idx;
-        j -= k;
-        bs->buf_bit_idx -= k;
-        bs->buf[bs->buf_byte_idx] |= ((val >> j) << bs->buf_bit_idx);
-        bs->totbit += k;
+    LhQueuedHeader const *h = &bs->queue[bs->q_out];
+    if (bs->fill + LH_MAX_HEADER_LEN + 2 >= bs->buf_size) {
+        bs->error = BS_FULL;    /* the caller did not drain the buffer */
+        return;
+    }
+    if (h->due == bs->stream_bits) {
+        memcpy(bs->buf + bs->fill, h->bytes, (size_t) bs->hdr_len);
+        bs->fill += bs->hdr_len;
+        bs->stream_bits += 8 * bs->hdr_len;
+        bs->q_out = (bs->q_out + 1) % LH_MAX_HEADER_BUF;
+    }
+    bs->buf[bs->fill++] = (unsigned char) byte;
+    bs->stream_bits += 8;
+}
+
+/* append the low n bits of v, most significant first (n <= 32) */
+static void
+sink(LhBitstream * bs, unsigned v, int n)
+{
+    if (n <= 0)
+        return;
+    bs->acc = (bs->acc << n) | ((unsigned long long) v & ((1ull << n) - 1ull));
+    bs->acc_bits += n;
+    while (bs->acc_bits >= 8) {
+        bs->acc_bits -= 8;
+        sink_byte(bs, (unsigned) (bs->acc >> bs->acc_bits) & 0xffu);
     }
 }
 
-/* ancillary stuffing (reference bitstream.c:223-267) */
-static void
-drain_into_ancillary(LhBitstream * bs, const LhConfig * c, int remainingBits)
+/* stream position in bits, counting the bits still in the accumulator */
+static int
+sink_position(const LhBitstream * bs)
 {
+    return bs->stream_bits + bs->acc_bits;
+}
+
+/* Reservoir stuffing: the encoder's signature first ("LAME" + version, as far as whole bytes
+ * fit), then single bits that alternate unless the reservoir is disabled. */
+static void
+sink_stuffing(LhBitstream * bs, const LhConfig * c, int nbits)
+{
+    static const char mark[] = "LAME", version[] = "3.99.5";
     int     i;
-    int const sl = c->sideinfo_len;
-    if (remainingBits >= 8) {
-        putbits(bs, sl, 0x4c, 8);
-        remainingBits -= 8;
+    for (i = 0; i < 4 && nbits >= 8; i++, nbits -= 8)
+        sink(bs, (unsigned char) mark[i], 8);
+    if (nbits >= 32)
+        for (i = 0; version[i] && nbits >= 8; i++, nbits -= 8)
+            sink(bs, (unsigned char) version[i], 8);
+    while (nbits-- > 0) {
+        sink(bs, (unsigned) bs->stuff_bit, 1);
+        if (!c->disable_reservoir)
+            bs->stuff_bit ^= 1;
     }
-    if (remainingBits >= 8) {
-        putbits(bs, sl, 0x41, 8);
-        remainingBits -= 8;
+}
+
+/* ---- header queue ------------------------------------------------------------------------ */
+
+typedef struct {
+    unsigned char *at;
+    int     used;               /* bits */
+} HdrWriter;
+
+static void
+hdr(HdrWriter * w, unsigned v, int n)
+{
+    while (n-- > 0) {
+        if ((v >> n) & 1u)
+            w->at[w->used >> 3] |= (unsigned char) (0x80u >> (w->used & 7));
+        w->used++;
     }
-    if (remainingBits >= 8) {
-        putbits(bs, sl, 0x4d, 8);
-        remainingBits -= 8;
-    }
-    if (remainingBits >= 8) {
-        putbits(bs, sl, 0x45, 8);
-        remainingBits -= 8;
-    }
-    if (remainingBits >= 32) {
-        for (i = 0; i < (int) strlen(lh_short_version) && remainingBits >= 8; ++i) {
-            remainingBits -= 8;
-            putbits(bs, sl, lh_short_version[i], 8);
+}
+
+/* the encoder counts table 14 as an estimate of 16: what is signalled is 16 */
+static unsigned
+signalled_table(int t)
+{
+    return (unsigned) (t == 14 ? 16 : t);
+}
+
+/* CRC-16 of the protected part: header bytes 2..3 and the side information (polynomial 0x8005,
+ * preset 0xffff, ISO/IEC 11172-3 section 2.4.3.1) */
+static unsigned
+header_crc(const unsigned char *h, int len)
+{
+    unsigned crc = 0xffffu;
+    int     i, b;
+    for (i = 2; i < len; i++) {
+        if (i == 4 || i == 5)
+            continue;           /* the CRC word itself */
+        for (b = 7; b >= 0; b--) {
+            unsigned const in = (h[i] >> b) & 1u, top = (crc >> 15) & 1u;
+            crc = (crc << 1) & 0xffffu;
+            if (in ^ top)
+                crc ^= 0x8005u;
         }
     }
-    for (; remainingBits >= 1; remainingBits -= 1) {
-        putbits(bs, sl, bs->ancillary_flag, 1);
-        bs->ancillary_flag ^= !c->disable_reservoir;
-    }
+    return crc;
 }
 
-/* header + side info into the ring (reference bitstream.c:270-285, 320-485) */
+/* build frame header + side information in the ring's next slot; it becomes due one frame length
+ * after its predecessor */
 static void
-hdr_bits(LhBitstream * bs, int val, int j)
+queue_header(LhBitstream * bs, const LhConfig * c, const LhFrameOut * fo, int back_pointer)
 {
-    int     ptr = bs->header[bs->h_ptr].ptr;
-    while (j > 0) {
-        int const k = (j < 8 - (ptr & 7)) ? j : 8 - (ptr & 7);
-        j -= k;
-        bs->header[bs->h_ptr].buf[ptr >> 3] |= ((val >> j)) << (8 - (ptr & 7) - k);
-        ptr += k;
-    }
-    bs->header[bs->h_ptr].ptr = ptr;
-}
-
-static int
-tsel(int t)
-{
-    return (t == 14) ? 16 : t;  /* table 14 is only a length estimate; 16 carries the same code book */
-}
-
-static void
-encode_side_info(LhBitstream * bs, const LhConfig * c, const LhFrameOut * fo, int mdb,
-                 int bitsPerFrame)
-{
-    int     gr, ch, band;
-    bs->header[bs->h_ptr].ptr = 0;
-    memset(bs->header[bs->h_ptr].buf, 0, (size_t) c->sideinfo_len);
-    hdr_bits(bs, 0xfff, 12);
-    hdr_bits(bs, c->version, 1);
-    hdr_bits(bs, 4 - 3, 2);
-    hdr_bits(bs, !c->error_protection, 1);
-    hdr_bits(bs, fo->bitrate_index, 4);
-    hdr_bits(bs, c->samplerate_index, 2);
-    hdr_bits(bs, fo->padding, 1);
-    hdr_bits(bs, c->extension, 1);
-    hdr_bits(bs, c->mode, 2);
-    hdr_bits(bs, fo->mode_ext, 2);
-    hdr_bits(bs, c->copyright, 1);
-    hdr_bits(bs, c->original, 1);
-    hdr_bits(bs, c->emphasis, 2);
+    LhQueuedHeader *slot = &bs->queue[bs->q_in];
+    int const nch = c->channels;
+    HdrWriter w;
+    int     gr, ch, k, next;
+    memset(slot->bytes, 0, sizeof(slot->bytes));
+    w.at = slot->bytes;
+    w.used = 0;
+    /* header: syncword, ID, layer III, protection, bitrate, sampling frequency, padding, private,
+     * mode, mode extension, copyright, original, emphasis */
+    hdr(&w, 0xfffu, 12);
+    hdr(&w, (unsigned) c->version, 1);
+    hdr(&w, 1u, 2);
+    hdr(&w, c->error_protection ? 0u : 1u, 1);
+    hdr(&w, (unsigned) fo->bitrate_index, 4);
+    hdr(&w, (unsigned) c->samplerate_index, 2);
+    hdr(&w, (unsigned) fo->padding, 1);
+    hdr(&w, (unsigned) c->extension, 1);
+    hdr(&w, (unsigned) c->mode, 2);
+    hdr(&w, (unsigned) fo->mode_ext, 2);
+    hdr(&w, (unsigned) c->copyright, 1);
+    hdr(&w, (unsigned) c->original, 1);
+    hdr(&w, (unsigned) c->emphasis, 2);
     if (c->error_protection)
-        hdr_bits(bs, 0, 16);    /* CRC word, filled in below */
-    hdr_bits(bs, mdb, 9);
-    hdr_bits(bs, 0, c->channels == 2 ? 3 : 5);  /* private bits (reference bitstream.c:357-360) */
-    for (ch = 0; ch < c->channels; ch++)
-        for (band = 0; band < 4; band++)
-            hdr_bits(bs, fo->scfsi[ch][band], 1);
-    for (gr = 0; gr < 2; gr++) {
-        for (ch = 0; ch < c->channels; ch++) {
-            const LhGranule *gi = &fo->gr[gr][ch];
-            hdr_bits(bs, gi->part2_3_length + gi->part2_length, 12);
-            hdr_bits(bs, gi->big_values / 2, 9);
-            hdr_bits(bs, gi->global_gain, 8);
-            hdr_bits(bs, gi->scalefac_compress, 4);
-            if (gi->block_type != LH_NORM_TYPE) {
-                hdr_bits(bs, 1, 1);
-                hdr_bits(bs, gi->block_type, 2);
-                hdr_bits(bs, gi->mixed_block_flag, 1);
-                hdr_bits(bs, tsel(gi->table_select[0]), 5);
-                hdr_bits(bs, tsel(gi->table_select[1]), 5);
-                hdr_bits(bs, gi->subblock_gain[0], 3);
-                hdr_bits(bs, gi->subblock_gain[1], 3);
-                hdr_bits(bs, gi->subblock_gain[2], 3);
+        w.used += 16;           /* room for the CRC word */
+    /* side information: main_data_begin, private bits, scfsi, then the granules */
+    hdr(&w, (unsigned) back_pointer, 9);
+    w.used += (nch == 2) ? 3 : 5;
+    for (ch = 0; ch < nch; ch++)
+        for (k = 0; k < 4; k++)
+            hdr(&w, (unsigned) fo->scfsi[ch][k], 1);
+    for (gr = 0; gr < 2; gr++)
+        for (ch = 0; ch < nch; ch++) {
+            const LhGranule *g = &fo->gr[gr][ch];
+            int const switched = (g->block_type != LH_NORM_TYPE);
+            hdr(&w, (unsigned) (g->part2_3_length + g->part2_length), 12);
+            hdr(&w, (unsigned) (g->big_values / 2), 9);
+            hdr(&w, (unsigned) g->global_gain, 8);
+            hdr(&w, (unsigned) g->scalefac_compress, 4);
+            hdr(&w, (unsigned) switched, 1);
+            if (switched) {
+                hdr(&w, (unsigned) g->block_type, 2);
+                hdr(&w, (unsigned) g->mixed_block_flag, 1);
+                for (k = 0; k < 2; k++)
+                    hdr(&w, signalled_table(g->table_select[k]), 5);
+                for (k = 0; k < 3; k++)
+                    hdr(&w, (unsigned) g->subblock_gain[k], 3);
             }
             else {
-                hdr_bits(bs, 0, 1);
-                hdr_bits(bs, tsel(gi->table_select[0]), 5);
-                hdr_bits(bs, tsel(gi->table_select[1]), 5);
-                hdr_bits(bs, tsel(gi->table_select[2]), 5);
-                hdr_bits(bs, gi->region0_count, 4);
-                hdr_bits(bs, gi->region1_count, 3);
+                for (k = 0; k < 3; k++)
+                    hdr(&w, signalled_table(g->table_select[k]), 5);
+                hdr(&w, (unsigned) g->region0_count, 4);
+                hdr(&w, (unsigned) g->region1_count, 3);
             }
-            hdr_bits(bs, gi->preflag, 1);
-            hdr_bits(bs, gi->scalefac_scale, 1);
-            hdr_bits(bs, gi->count1table_select, 1);
+            hdr(&w, (unsigned) g->preflag, 1);
+            hdr(&w, (unsigned) g->scalefac_scale, 1);
+            hdr(&w, (unsigned) g->count1table_select, 1);
         }
-    }
     if (c->error_protection) {
-        /* CRC-16 (polynomial 0x8005, start 0xffff) over header bytes 2, 3 and the side information
-         * (reference bitstream.c:287-318) */
-        unsigned char *h = (unsigned char *) bs->header[bs->h_ptr].buf;
-        int     crc = 0xffff, i, k;
-        for (i = 2; i < c->sideinfo_len; i++) {
-            int     value;
-            if (i == 4 || i == 5)
-                continue;
-            value = h[i] << 8;
-            for (k = 0; k < 8; k++) {
-                value <<= 1;
-                crc <<= 1;
-                if ((crc ^ value) & 0x10000)
-                    crc ^= 0x8005;
-            }
-        }
-        h[4] = (unsigned char) (crc >> 8);
-        h[5] = (unsigned char) (crc & 255);
+        unsigned const crc = header_crc(slot->bytes, c->sideinfo_len);
+        slot->bytes[4] = (unsigned char) (crc >> 8);
+        slot->bytes[5] = (unsigned char) (crc & 0xffu);
     }
+    bs->hdr_len = c->sideinfo_len;
+    next = (bs->q_in + 1) % LH_MAX_HEADER_BUF;
+    bs->queue[next].due = slot->due + fo->frame_bits;
+    bs->q_in = next;
+    if (next == bs->q_out)
+        bs->error = BS_QUEUE;   /* more headers waiting than the ring holds */
+}
+
+/* bits that still have to be produced before the stream ends on a frame boundary: up to the
+ * position of the last queued header, plus the headers still waiting, plus that frame */
+static int
+bits_to_frame_end(const LhBitstream * bs, int frame_bits)
+{
+    int const newest = (bs->q_in + LH_MAX_HEADER_BUF - 1) % LH_MAX_HEADER_BUF;
+    int     gap = bs->queue[newest].due - sink_position(bs);
+    if (gap >= 0) {
+        int const waiting = (newest - bs->q_out + LH_MAX_HEADER_BUF) % LH_MAX_HEADER_BUF + 1;
+        gap -= waiting * 8 * bs->hdr_len;
+    }
+    return gap + frame_bits;
+}
+
+/* ---- main data ----------------------------------------------------------------------------- */
+
+static const unsigned char slen_bits[2][16] = {
+    {0, 0, 0, 0, 3, 1, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4},
+    {0, 1, 2, 3, 0, 1, 2, 3, 1, 2, 3, 1, 2, 3, 2, 3}
+};
+
+/* scalefactors of one granule: the first `divide' bands with slen1 bits, the rest with slen2;
+ * -1 marks a band shared with granule 0 through scfsi */
+static int
+put_scalefactors(LhBitstream * bs, const LhGranule * g)
+{
+    int     band, written = 0;
+    for (band = 0; band < g->sfbmax; band++) {
+        int const width = slen_bits[band >= g->sfbdivide][g->scalefac_compress];
+        if (g->scalefac[band] < 0)
+            continue;
+        sink(bs, (unsigned) g->scalefac[band], width);
+        written += width;
+    }
+    return written;
+}
+
+/* big-value pairs [from, to) with code book `book': code word, then per non-zero value its
+ * linbits (ESC books, values >= 15) and its sign, x before y */
+static int
+put_pairs(LhBitstream * bs, unsigned book, int from, int to, const LhGranule * g)
+{
+    int     i, written = 0;
+    if (book == 0 || from >= to)
+        return 0;
     {
-        int const old = bs->h_ptr;
-        bs->h_ptr = (old + 1) & (LH_MAX_HEADER_BUF - 1);
-        bs->header[bs->h_ptr].write_timing = bs->header[old].write_timing + bitsPerFrame;
-        if (bs->h_ptr == bs->w_ptr)
-            bs->error = 2;      /* header ring overflow */
-    }
-}
-
-/* big-value pairs (reference bitstream.c:560-631) */
-static int
-huffman_pairs(LhBitstream * bs, int sl, unsigned int tableindex, int start, int end,
-              const LhGranule * gi)
-{
-    unsigned int const linbits = lh_ht_xlen[tableindex];
-    const uint16_t *codes;
-    const uint8_t *lens;
-    int     i, bits = 0;
-    if (!tableindex)
-        return bits;
-    codes = lh_ht_code + lh_ht_offset[tableindex];
-    lens = lh_ht_len + lh_ht_offset[tableindex];
-    for (i = start; i < end; i += 2) {
-        int16_t cbits = 0;
-        uint16_t xbits = 0;
-        unsigned int xlen = lh_ht_xlen[tableindex];
-        unsigned int ext = 0;
-        int const v1 = gi->l3_enc[i], v2 = gi->l3_enc[i + 1];
-        unsigned int x1 = (unsigned int) (v1 < 0 ? -v1 : v1);
-        unsigned int x2 = (unsigned int) (v2 < 0 ? -v2 : v2);
-        if (x1 != 0u) {
-            if (v1 < 0)
-                ext++;
-            cbits--;
-        }
-        if (tableindex > 15u) {
-            if (x1 >= 15u) {
-                uint16_t const linbits_x1 = (uint16_t) (x1 - 15u);
-                ext |= (unsigned int) linbits_x1 << 1u;
-                xbits = (uint16_t) linbits;
-                x1 = 15u;
+        unsigned const esc = book > 15u;
+        unsigned const linbits = esc ? lh_ht_xlen[book] : 0u;
+        unsigned const side = esc ? 16u : lh_ht_xlen[book];
+        const uint16_t *code = lh_ht_code + lh_ht_offset[book];
+        const uint8_t *length = lh_ht_len + lh_ht_offset[book];       /* code length + one per non-zero value */
+        for (i = from; i < to; i += 2) {
+            int const sx = g->l3_enc[i], sy = g->l3_enc[i + 1];
+            unsigned const ax = (unsigned) (sx < 0 ? -sx : sx), ay = (unsigned) (sy < 0 ? -sy : sy);
+            unsigned const cx = (esc && ax > 15u) ? 15u : ax, cy = (esc && ay > 15u) ? 15u : ay;
+            unsigned const cell = cx * side + cy;
+            int const signs = (ax != 0u) + (ay != 0u);
+            sink(bs, code[cell], (int) length[cell] - signs);
+            written += length[cell];
+            if (ax != 0u) {
+                if (esc && ax >= 15u) {
+                    sink(bs, ax - 15u, (int) linbits);
+                    written += (int) linbits;
+                }
+                sink(bs, sx < 0, 1);
             }
-            if (x2 >= 15u) {
-                uint16_t const linbits_x2 = (uint16_t) (x2 - 15u);
-                ext <<= linbits;
-                ext |= linbits_x2;
-                xbits = (uint16_t) (xbits + linbits);
-                x2 = 15u;
+            if (ay != 0u) {
+                if (esc && ay >= 15u) {
+                    sink(bs, ay - 15u, (int) linbits);
+                    written += (int) linbits;
+                }
+                sink(bs, sy < 0, 1);
             }
-            xlen = 16;
         }
-        if (x2 != 0u) {
-            ext <<= 1;
-            if (v2 < 0)
-                ext++;
-            cbits--;
-        }
-        x1 = x1 * xlen + x2;
-        xbits = (uint16_t) (xbits - cbits);
-        cbits = (int16_t) (cbits + lens[x1]);
-        putbits(bs, sl, codes[x1], cbits);
-        putbits(bs, sl, (int) ext, xbits);
-        bits += cbits + xbits;
     }
-    return bits;
+    return written;
 }
 
-/* count1 quadruples (reference bitstream.c:490-551) */
+/* count1 region: quadruples of 0 / +-1 with book A or B; the table entry leaves room for the
+ * signs of the non-zero values below the code word */
 static int
-huffman_quads(LhBitstream * bs, int sl, const LhGranule * gi)
+put_quadruples(LhBitstream * bs, const LhGranule * g)
 {
-    int const t = gi->count1table_select + 32;
-    const uint16_t *codes = lh_ht_code + lh_ht_offset[t];
-    const uint8_t *lens = lh_ht_len + lh_ht_offset[t];
-    int     i, bits = 0;
-    const int16_t *ix = &gi->l3_enc[gi->big_values];
-    for (i = (gi->count1 - gi->big_values) / 4; i > 0; --i) {
-        int     huffbits = 0;
-        int     p = 0;
-        if (ix[0]) {
-            p += 8;
-            if (ix[0] < 0)
-                huffbits++;
+    int const book = 32 + g->count1table_select;
+    const uint16_t *code = lh_ht_code + lh_ht_offset[book];
+    const uint8_t *length = lh_ht_len + lh_ht_offset[book];
+    int     i, k, written = 0;
+    for (i = g->big_values; i + 4 <= g->count1; i += 4) {
+        unsigned pattern = 0, signs = 0;
+        for (k = 0; k < 4; k++) {
+            int const v = g->l3_enc[i + k];
+            pattern <<= 1;
+            if (v != 0) {
+                pattern |= 1u;
+                signs = (signs << 1) | (unsigned) (v < 0);
+            }
         }
-        if (ix[1]) {
-            p += 4;
-            huffbits *= 2;
-            if (ix[1] < 0)
-                huffbits++;
-        }
-        if (ix[2]) {
-            p += 2;
-            huffbits *= 2;
-            if (ix[2] < 0)
-                huffbits++;
-        }
-        if (ix[3]) {
-            p++;
-            huffbits *= 2;
-            if (ix[3] < 0)
-                huffbits++;
-        }
-        ix += 4;
-        putbits(bs, sl, huffbits + codes[p], lens[p]);
-        bits += lens[p];
+        sink(bs, code[pattern] + signs, length[pattern]);
+        written += length[pattern];
     }
-    return bits;
+    return written;
 }
 
-/* scalefactors + Huffman data of one frame (reference bitstream.c:685-790, MPEG-1) */
-static int
-write_main_data(LhBitstream * bs, const LhConfig * c, const LhTables * t, const LhFrameOut * fo)
+/* where the big-value regions of a granule end (in lines), clipped to big_values */
+static void
+region_ends(const LhGranule * g, const LhTables * t, int end[3])
 {
-    int     gr, ch, sfb, data_bits, tot_bits = 0;
-    int const sl = c->sideinfo_len;
-    for (gr = 0; gr < 2; gr++) {
+    int     k;
+    if (g->block_type == LH_SHORT_TYPE) {
+        end[0] = 3 * t->sfb_s[3];
+        end[1] = end[2] = g->big_values;
+    }
+    else {
+        int const b1 = g->region0_count + 1, b2 = b1 + g->region1_count + 1;
+        end[0] = t->sfb_l[b1];
+        end[1] = t->sfb_l[b2];
+        end[2] = g->big_values;
+    }
+    for (k = 0; k < 2; k++)
+        if (end[k] > g->big_values)
+            end[k] = g->big_values;
+}
+
+static int
+put_main_data(LhBitstream * bs, const LhConfig * c, const LhTables * t, const LhFrameOut * fo)
+{
+    int     gr, ch, total = 0;
+    for (gr = 0; gr < 2; gr++)
         for (ch = 0; ch < c->channels; ch++) {
-            const LhGranule *gi = &fo->gr[gr][ch];
-            int const slen1 = slen1_tab[gi->scalefac_compress];
-            int const slen2 = slen2_tab[gi->scalefac_compress];
-            int     bigvalues = gi->big_values;
-            data_bits = 0;
-            for (sfb = 0; sfb < gi->sfbdivide; sfb++) {
-                if (gi->scalefac[sfb] == -1)
-                    continue;
-                putbits(bs, sl, gi->scalefac[sfb], slen1);
-                data_bits += slen1;
+            const LhGranule *g = &fo->gr[gr][ch];
+            int     end[3], bits, k, from = 0;
+            bits = put_scalefactors(bs, g);
+            region_ends(g, t, end);
+            for (k = 0; k < 3; k++) {
+                /* switched blocks signal two books; their third region is empty by construction */
+                if (k < 2 || g->block_type == LH_NORM_TYPE)
+                    bits += put_pairs(bs, signalled_table(g->table_select[k]), from, end[k], g);
+                from = end[k];
             }
-            for (; sfb < gi->sfbmax; sfb++) {
-                if (gi->scalefac[sfb] == -1)
-                    continue;
-                putbits(bs, sl, gi->scalefac[sfb], slen2);
-                data_bits += slen2;
-            }
-            if (gi->block_type == LH_SHORT_TYPE) {
-                int     region1Start = 3 * t->sfb_s[3];
-                if (region1Start > bigvalues)
-                    region1Start = bigvalues;
-                data_bits += huffman_pairs(bs, sl, (unsigned) tsel(gi->table_select[0]), 0, region1Start, gi);
-                data_bits += huffman_pairs(bs, sl, (unsigned) tsel(gi->table_select[1]), region1Start, bigvalues, gi);
-            }
-            else {
-                int     i = gi->region0_count + 1;
-                int     region1Start = t->sfb_l[i], region2Start;
-                i += gi->region1_count + 1;
-                region2Start = t->sfb_l[i];
-                if (region1Start > bigvalues)
-                    region1Start = bigvalues;
-                if (region2Start > bigvalues)
-                    region2Start = bigvalues;
-                data_bits += huffman_pairs(bs, sl, (unsigned) tsel(gi->table_select[0]), 0, region1Start, gi);
-                data_bits += huffman_pairs(bs, sl, (unsigned) tsel(gi->table_select[1]), region1Start, region2Start, gi);
-                data_bits += huffman_pairs(bs, sl, (unsigned) tsel(gi->table_select[2]), region2Start, bigvalues, gi);
-            }
-            data_bits += huffman_quads(bs, sl, gi);
-            /* the quantiser's bit count must agree with what was written (reference bitstream.c:728) */
-            if (data_bits != gi->part2_3_length + gi->part2_length)
-                bs->error = 3;
-            tot_bits += data_bits;
+            bits += put_quadruples(bs, g);
+            /* what was written must be what the quantiser counted */
+            if (bits != g->part2_3_length + g->part2_length)
+                bs->error = BS_COUNT;
+            total += bits;
         }
-    }
-    return tot_bits;
+    return total;
 }
 
-/* reference bitstream.c:804-858 */
+/* ---- frame ----------------------------------------------------------------------------------- */
+
+/* a payload whose fields would index outside the code books or the band tables is refused */
 static int
-compute_flushbits(const LhBitstream * bs, const LhConfig * c, int frame_bits)
+payload_plausible(const LhConfig * c, const LhFrameOut * fo)
 {
-    int     flushbits, remaining_headers;
-    int     last_ptr, first_ptr;
-    first_ptr = bs->w_ptr;
-    last_ptr = bs->h_ptr - 1;
-    if (last_ptr == -1)
-        last_ptr = LH_MAX_HEADER_BUF - 1;
-    flushbits = bs->header[last_ptr].write_timing - bs->totbit;
-    if (flushbits >= 0) {
-        remaining_headers = 1 + last_ptr - first_ptr;
-        if (last_ptr < first_ptr)
-            remaining_headers = 1 + last_ptr - first_ptr + LH_MAX_HEADER_BUF;
-        flushbits -= remaining_headers * 8 * c->sideinfo_len;
-    }
-    flushbits += frame_bits;
-    return flushbits;
+    int     gr, ch, k;
+    if (fo->frame_bits <= 0 || fo->frame_bits > 8 * 2880 || fo->resvDrain_pre < 0 || fo->resvDrain_post < 0)
+        return 0;
+    for (gr = 0; gr < 2; gr++)
+        for (ch = 0; ch < c->channels; ch++) {
+            const LhGranule *g = &fo->gr[gr][ch];
+            if (g->big_values < 0 || g->big_values > 576 || (g->big_values & 1))
+                return 0;
+            if (g->count1 < g->big_values || g->count1 > 576 || ((g->count1 - g->big_values) & 3))
+                return 0;
+            if ((unsigned) g->region0_count > 15u || (unsigned) g->region1_count > 15u)
+                return 0;
+            if ((unsigned) g->count1table_select > 1u || (unsigned) g->block_type > 3u || (unsigned) g->global_gain > 255u)
+                return 0;
+            if ((unsigned) g->scalefac_compress > 15u || g->sfbmax < 0 || g->sfbmax > LH_SFBMAX || g->sfbdivide < 0)
+                return 0;
+            for (k = 0; k < 3; k++)
+                if ((unsigned) g->table_select[k] > 31u || g->table_select[k] == 4)
+                    return 0;
+        }
+    return 1;
 }
 
+/* appends one frame; returns 0, or the negated error code */
 int
 lh_bs_format_frame(LhBitstream * bs, const LhConfig * c, const LhTables * t, const LhFrameOut * fo)
 {
-    int     bits, mdb;
-    int const bitsPerFrame = fo->frame_bits;
-
-    /* refuse a payload whose fields would index outside the Huffman tables */
-    {
-        int     gr, ch, k;
-        for (gr = 0; gr < 2; gr++)
-            for (ch = 0; ch < c->channels; ch++) {
-                const LhGranule *gi = &fo->gr[gr][ch];
-                int     bad = gi->big_values < 0 || gi->big_values > 576 || gi->count1 < gi->big_values
-                    || gi->count1 > 576 || (gi->big_values & 1) || ((gi->count1 - gi->big_values) & 3)
-                    || gi->region0_count < 0 || gi->region0_count > 15 || gi->region1_count < 0
-                    || gi->region1_count > 15 || (unsigned) gi->count1table_select > 1u
-                    || (unsigned) gi->block_type > 3u || (unsigned) gi->global_gain > 255u;
-                for (k = 0; k < 3; k++)
-                    bad |= (unsigned) gi->table_select[k] > 31u || gi->table_select[k] == 4;
-                if (bad) {
-                    bs->error = 6;
-                    return -1;
-                }
-            }
-        if (bitsPerFrame <= 0 || bitsPerFrame > 8 * 2880 || fo->resvDrain_pre < 0 || fo->resvDrain_post < 0) {
-            bs->error = 6;
-            return -1;
-        }
+    int     back_pointer, produced;
+    if (!payload_plausible(c, fo)) {
+        bs->error = BS_PAYLOAD;
+        return -1;
     }
-    drain_into_ancillary(bs, c, fo->resvDrain_pre);
-    /* ResvFrameEnd moved resvDrain_pre/8 bytes out of the reservoir before the
-     * header was built (reference reservoir.c:279-289) */
-    mdb = bs->main_data_begin - fo->resvDrain_pre / 8;
-    encode_side_info(bs, c, fo, mdb, bitsPerFrame);
-    bits = 8 * c->sideinfo_len;
-    bits += write_main_data(bs, c, t, fo);
-    drain_into_ancillary(bs, c, fo->resvDrain_post);
-    bits += fo->resvDrain_post;
-    bs->main_data_begin = mdb + (bitsPerFrame - bits) / 8;
-    /* consistency with the device-side reservoir (reference bitstream.c:940-972) */
+    bs->hdr_len = c->sideinfo_len;
+    /* whole bytes of the first drain were taken out of the reservoir before this frame's header was
+     * built (reference reservoir.c:279-289), so the back pointer shrinks by them */
+    sink_stuffing(bs, c, fo->resvDrain_pre);
+    back_pointer = bs->main_data_begin - fo->resvDrain_pre / 8;
+    queue_header(bs, c, fo, back_pointer);
+    produced = 8 * c->sideinfo_len + put_main_data(bs, c, t, fo);
+    sink_stuffing(bs, c, fo->resvDrain_post);
+    produced += fo->resvDrain_post;
+    bs->main_data_begin = back_pointer + (fo->frame_bits - produced) / 8;
+    /* the device kept the same books (reference bitstream.c:940-972) */
     if (bs->main_data_begin != fo->main_data_begin || bs->main_data_begin * 8 != fo->resv_size)
-        bs->error = 4;
-    if (compute_flushbits(bs, c, bitsPerFrame) != fo->resv_size)
-        bs->error = 5;
-    if (bs->totbit > 1000000000) {
+        bs->error = BS_BACKPTR;
+    if (bits_to_frame_end(bs, fo->frame_bits) != fo->resv_size)
+        bs->error = BS_FLUSH;
+    if (bs->acc_bits != 0)
+        bs->error = BS_ALIGN;   /* a frame's data ends on a byte */
+    if (bs->stream_bits > 1000000000) {
+        /* keep the position counters small on very long streams */
         int     i;
-        for (i = 0; i < LH_MAX_HEADER_BUF; ++i)
-            bs->header[i].write_timing -= bs->totbit;
-        bs->totbit = 0;
+        for (i = 0; i < LH_MAX_HEADER_BUF; i++)
+            bs->queue[i].due -= bs->stream_bits;
+        bs->stream_bits = 0;
     }
     return bs->error ? -bs->error : 0;
 }
 
-/* reference bitstream.c:863-889 */
+/* end of stream: stuff up to the end of the last frame (reference bitstream.c:863-889) */
 void
 lh_bs_flush(LhBitstream * bs, const LhConfig * c, const LhFrameOut * last)
 {
-    int     flushbits;
-    int     frame_bits;
-    if (last)
-        frame_bits = last->frame_bits;
-    else
-        frame_bits = 8 * ((c->version + 1) * 72000 * c->avg_bitrate / c->samplerate);
-    if ((flushbits = compute_flushbits(bs, c, frame_bits)) < 0)
+    int const frame_bits = last ? last->frame_bits
+        : 8 * ((c->version + 1) * 72000 * c->avg_bitrate / c->samplerate);
+    int const missing = bits_to_frame_end(bs, frame_bits);
+    if (missing < 0)
         return;
-    drain_into_ancillary(bs, c, flushbits);
+    bs->hdr_len = c->sideinfo_len;
+    sink_stuffing(bs, c, missing);
     bs->main_data_begin = 0;
 }
 
-/* reference bitstream.c:1045-1060 */
+/* hands the finished bytes over; -1 if size != 0 and too small (then nothing is taken) */
 int
 lh_bs_copy(LhBitstream * bs, unsigned char *out, int size)
 {
-    int const minimum = bs->buf_byte_idx + 1;
-    if (minimum <= 0)
+    int const n = bs->fill;
+    if (n <= 0)
         return 0;
-    if (size != 0 && minimum > size)
+    if (size != 0 && n > size)
         return -1;
-    memcpy(out, bs->buf, (size_t) minimum);
-    bs->buf_byte_idx = -1;
-    bs->buf_bit_idx = 0;
-    return minimum;
+    memcpy(out, bs->buf, (size_t) n);
+    bs->fill = 0;
+    return n;
 }
 
 /* reference lame.c:1671-1775 + 2041-2120: frames produced for n samples followed by a flush */
@@ -484,7 +479,7 @@ int
 lh_total_frames(long n)
 {
     long    mf_size = LH_MF_START, to_encode = LH_ENCDELAY + LH_POSTDELAY;
-    long    frames = 0, fed = 0;
+    long    frames = 0;
     int     end_padding, frames_left;
     to_encode += n;
     if (n > 0) {
@@ -492,7 +487,6 @@ lh_total_frames(long n)
         long    total = mf_size + n;
         if (total >= LH_MF_NEEDED)
             frames = (total - LH_MF_NEEDED) / 1152 + 1;
-        (void) fed;
         to_encode -= 1152 * frames;
     }
     to_encode -= LH_POSTDELAY;

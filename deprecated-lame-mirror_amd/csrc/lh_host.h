@@ -58,19 +58,23 @@ int     lh_total_frames(long nsamples);
 #define LH_MAX_HEADER_LEN 40
 #define LH_BS_BUFSIZE (16384 + 147456)   /* LAME_MAXMP3BUFFER, reference lame.h */
 
+/* a frame header + side information waiting for its place in the byte stream */
+typedef struct LhQueuedHeader {
+    int     due;                 /* stream position (bits) at which it is inserted */
+    unsigned char bytes[LH_MAX_HEADER_LEN];
+} LhQueuedHeader;
+
 typedef struct LhBitstream {
-    unsigned char *buf;
+    unsigned char *buf;          /* finished bytes not yet handed to the caller */
     int     buf_size;
-    int     totbit;
-    int     buf_byte_idx;
-    int     buf_bit_idx;
-    struct {
-        int     write_timing;
-        int     ptr;
-        char    buf[LH_MAX_HEADER_LEN];
-    } header[LH_MAX_HEADER_BUF];
-    int     h_ptr, w_ptr;
-    int     ancillary_flag;
+    int     fill;                /* how many there are */
+    unsigned long long acc;      /* main-data bits on their way into whole bytes */
+    int     acc_bits;
+    int     stream_bits;         /* bits in the stream so far (whole bytes, headers included) */
+    LhQueuedHeader queue[LH_MAX_HEADER_BUF];
+    int     q_in, q_out;         /* ring: next free slot, oldest waiting header */
+    int     hdr_len;             /* header + side information, bytes */
+    int     stuff_bit;
     int     main_data_begin;     /* packer's own running value, cross-checked with the device's */
     int     error;
 } LhBitstream;
@@ -83,6 +87,8 @@ int     lh_bs_format_frame(LhBitstream * bs, const LhConfig * c, const LhTables 
 void    lh_bs_flush(LhBitstream * bs, const LhConfig * c, const LhFrameOut * last);
 /* moves the finished bytes out (reference copy_buffer); -1 if size!=0 and too small */
 int     lh_bs_copy(LhBitstream * bs, unsigned char *out, int size);
+/* bytes waiting to be copied out */
+int     lh_bs_pending(const LhBitstream * bs);
 
 
 /* ---- Xing/Info + LAME tag bookkeeping (lh_vbrtag.c; reference VbrTag.c) ---- */

@@ -17,6 +17,7 @@
  * fallback).
  */
 #include <math.h>
+#include <stddef.h>
 #include <string.h>
 #include <float.h>
 
@@ -374,29 +375,30 @@ config_resolve_vbr(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
             {16000, 9.01, 9.4, 4.9, 6.5}, {12000, 9.4, 9.6, 4.5, 6.0}, {11025, 9.6, 9.9, 5.1, 6.5},
             {8000, 9.9, 10., 4.9, 6.5}
         };
+        /* Above a rate's knee (qa) the quality scale is stretched: [0, qa) keeps the input rate with
+         * qualities 0 .. ta, [qa, qb) switches the output rate to sr_a with qualities ta .. tb.  The
+         * first row whose interval holds the value decides. */
         float const qval = vbr_q + vbr_q_frac;
         for (i = 0; i < 7; ++i) {
-            if (p->samplerate == m[i].sr_a) {
-                if (qval < m[i].qa) {
-                    double  d = qval / m[i].qa;
-                    d = d * m[i].ta;
-                    vbr_q = (int) d;
-                    vbr_q_frac = d - vbr_q;
-                }
+            double  stretched = -1;
+            int const here = (p->samplerate == m[i].sr_a), above = (p->samplerate >= m[i].sr_a);
+            int const inside = (m[i].qa <= qval && qval < m[i].qb);
+            if (here && qval < m[i].qa) {
+                stretched = qval / m[i].qa;
+                stretched = stretched * m[i].ta;
             }
-            if (p->samplerate >= m[i].sr_a) {
-                if (m[i].qa <= qval && qval < m[i].qb) {
-                    float const q_ = m[i].qb - m[i].qa;
-                    float const t_ = m[i].tb - m[i].ta;
-                    double  d = m[i].ta + t_ * (qval - m[i].qa) / q_;
-                    vbr_q = (int) d;
-                    vbr_q_frac = d - vbr_q;
-                    samplerate_out = m[i].sr_a;
-                    if (lowpassfreq == 0)
-                        lowpassfreq = -1;
-                    break;
-                }
+            if (above && inside) {
+                float const dq = m[i].qb - m[i].qa, dt = m[i].tb - m[i].ta;
+                stretched = m[i].ta + dt * (qval - m[i].qa) / dq;
+                samplerate_out = m[i].sr_a;
+                lowpassfreq = lowpassfreq == 0 ? -1 : lowpassfreq;
             }
+            if (stretched >= 0) {
+                vbr_q = (int) stretched;
+                vbr_q_frac = stretched - vbr_q;
+            }
+            if (above && inside)
+                break;
         }
     }
     if (lowpassfreq == 0) {
@@ -426,20 +428,23 @@ config_resolve_vbr(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
     P = vbr_mt_map[vbr_q];
     Q = vbr_mt_map[vbr_q + 1];
     x = vbr_q_frac;
-#define LERP(f) (P.f = P.f + x * (Q.f - P.f))
-    LERP(st_lrm);
-    LERP(st_s);
-    LERP(masking_adj);
-    LERP(masking_adj_short);
-    LERP(ath_lower);
-    LERP(ath_curve);
-    LERP(ath_sensitivity);
-    LERP(interch);
-    LERP(sfb21mod);
-    LERP(msfix);
-    LERP(minval);
-    LERP(ath_fixpoint);
-#undef LERP
+    {
+        /* every tuning value moves towards the next row's by the fractional quality */
+        static const size_t field[11] = {
+            offsetof(LhVbrPreset, st_lrm), offsetof(LhVbrPreset, st_s), offsetof(LhVbrPreset, masking_adj),
+            offsetof(LhVbrPreset, masking_adj_short), offsetof(LhVbrPreset, ath_lower), offsetof(LhVbrPreset, ath_curve),
+            offsetof(LhVbrPreset, ath_sensitivity), offsetof(LhVbrPreset, interch),
+            offsetof(LhVbrPreset, msfix), offsetof(LhVbrPreset, minval), offsetof(LhVbrPreset, ath_fixpoint)
+        };
+        int     k;
+        for (k = 0; k < 11; k++) {
+            float  *mine = (float *) ((char *) &P + field[k]);
+            float const next = *(const float *) ((const char *) &Q + field[k]);
+            *mine = *mine + x * (next - *mine);
+        }
+        /* the one integer among them (dB tenths for the band above sfb 21): truncated after the blend */
+        P.sfb21mod = (int) (P.sfb21mod + x * (Q.sfb21mod - P.sfb21mod));
+    }
     c->quant_comp = 9;
     c->quant_comp_short = 9;
     aux->attackthre = P.st_lrm;
@@ -717,467 +722,508 @@ config_resolve_inner(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
     return 0;
 }
 
-/* ---------------------------------------------------------------------- */
-/* ATH formula (reference util.c:197-264) */
-static float
-ath_formula_gb(float f, float value, float f_min, float f_max)
-{
-    float   ath;
-    if (f < -.3)
-        f = 3410;
-    f /= 1000;
-    f = (f_min > f) ? f_min : f;
-    f = (f_max < f) ? f_max : f;
-    ath = 3.640 * pow(f, -0.8)
-        - 6.800 * exp(-0.6 * pow(f - 3.4, 2.0))
-        + 6.000 * exp(-0.15 * pow(f - 8.7, 2.0))
-        + (0.6 + 0.04 * value) * 0.001 * pow(f, 4.0);
-    return ath;
-}
+/* ====================================================================== */
+/* Tables, organised per table.  Every value must equal the reference's to the last bit (a one-ulp
+ * difference changes integer decisions downstream), so each expression keeps the reference's mix
+ * of float and double operands and its order of operations; what is this file's own is the
+ * decomposition: small pure functions for the curves, one builder per table, shared walkers for
+ * "minimum over the lines of a band" and "partition of the spectrum". */
 
-static float
-ath_formula(const LhConfig * c, float f)
+/* ---- the threshold in quiet ------------------------------------------------------------ */
+
+/* one of the reference's curve variants (util.c:197-264): a shape parameter, the frequency range
+ * it is clamped to (kHz) and a level shift */
+typedef struct QuietCurve {
+    float   shape, khz_lo, khz_hi;
+    int     lift_db;
+} QuietCurve;
+
+static QuietCurve
+quiet_curve(const LhConfig * c)
 {
+    QuietCurve q = { 0.f, 0.1f, 24.0f, 0 };
     switch (c->ATHtype) {
     case 0:
-        return ath_formula_gb(f, 9, 0.1f, 24.0f);
+        q.shape = 9;
+        break;
     case 1:
-        return ath_formula_gb(f, -1, 0.1f, 24.0f);
-    case 2:
-        return ath_formula_gb(f, 0, 0.1f, 24.0f);
+        q.shape = -1;
+        break;
     case 3:
-        return ath_formula_gb(f, 1, 0.1f, 24.0f) + 6;
+        q.shape = 1;
+        q.lift_db = 6;
+        break;
     case 4:
-        return ath_formula_gb(f, c->ATHcurve, 0.1f, 24.0f);
+        q.shape = c->ATHcurve;
+        break;
     case 5:
-        return ath_formula_gb(f, c->ATHcurve, 3.41f, 16.1f);
-    default:
-        return ath_formula_gb(f, 0, 0.1f, 24.0f);
+        q.shape = c->ATHcurve;
+        q.khz_lo = 3.41f;
+        q.khz_hi = 16.1f;
+        break;
+    default:                   /* 2 and anything unknown: shape 0 */
+        break;
     }
+    return q;
 }
 
-/* reference util.c:268-282 */
+/* level of the threshold in quiet at `hz' in dB (negative hz: the level at the curve's minimum,
+ * 3.41 kHz); four terms in double: the low-frequency rise, the ear-canal dip, a bump near 8.7 kHz
+ * and the high-frequency rise whose weight is the shape parameter */
 static float
-freq2bark(float freq)
+quiet_level_db(const LhConfig * c, float hz)
 {
-    if (freq < 0)
-        freq = 0;
-    freq = freq * 0.001;
-    return 13.0 * atan(.76 * freq) + 3.5 * atan(freq * freq / (7.5 * 7.5));
+    QuietCurve const q = quiet_curve(c);
+    float   khz = hz, level;
+    double  low, dip, bump, high;
+    if (khz < -.3)
+        khz = 3410;
+    khz /= 1000;
+    khz = (q.khz_lo > khz) ? q.khz_lo : khz;
+    khz = (q.khz_hi < khz) ? q.khz_hi : khz;
+    low = 3.640 * pow(khz, -0.8);
+    dip = 6.800 * exp(-0.6 * pow(khz - 3.4, 2.0));
+    bump = 6.000 * exp(-0.15 * pow(khz - 8.7, 2.0));
+    high = (0.6 + 0.04 * q.shape) * 0.001 * pow(khz, 4.0);
+    level = low - dip + bump + high;
+    if (q.lift_db)
+        level = level + q.lift_db;
+    return level;
 }
 
-/* reference quantize_pvt.c:210-228 */
+/* the same as the energy the quantiser compares MDCT lines with (reference quantize_pvt.c:210-228) */
 static float
-ath_mdct(const LhConfig * c, float f)
+quiet_energy(const LhConfig * c, float hz)
 {
-    float   ath = ath_formula(c, f);
-    if (c->ATHfixpoint > 0)
-        ath -= c->ATHfixpoint;
-    else
-        ath -= LH_NSATHSCALE;
-    ath += c->ATH_offset_db;
-    ath = powf(10.0f, ath * 0.1f);
-    return ath;
+    float   db = quiet_level_db(c, hz);
+    db -= (c->ATHfixpoint > 0) ? c->ATHfixpoint : LH_NSATHSCALE;
+    db += c->ATH_offset_db;
+    return powf(10.0f, db * 0.1f);
 }
 
-/* reference quantize_pvt.c:230-321 */
+/* the quietest line of [from, to) when `lines' MDCT lines span half the sampling rate */
+static float
+quietest_line(const LhConfig * c, int from, int to, int lines)
+{
+    float const rate = c->samplerate;
+    float   least = FLT_MAX;
+    int     k;
+    for (k = from; k < to; k++) {
+        float const e = quiet_energy(c, k * rate / (2 * lines));
+        least = (least < e) ? least : e;
+    }
+    return least;
+}
+
+/* ATH per scalefactor band: long, short (times the band width: three windows share it) and the
+ * partial bands above sfb21 / sfb12 (reference quantize_pvt.c:230-321) */
 static void
-compute_ath(const LhConfig * c, LhTables * t)
+build_band_thresholds(const LhConfig * c, LhTables * t)
 {
-    int     sfb, i, start, end;
-    float   ath_f;
-    float const samp_freq = c->samplerate;
-
-    for (sfb = 0; sfb < LH_SBMAX_L; sfb++) {
-        start = t->sfb_l[sfb];
-        end = t->sfb_l[sfb + 1];
-        t->ath_l[sfb] = FLT_MAX;
-        for (i = start; i < end; i++) {
-            float const freq = i * samp_freq / (2 * 576);
-            ath_f = ath_mdct(c, freq);
-            t->ath_l[sfb] = (t->ath_l[sfb] < ath_f) ? t->ath_l[sfb] : ath_f;
-        }
+    int     b;
+    for (b = 0; b < LH_SBMAX_L; b++)
+        t->ath_l[b] = quietest_line(c, t->sfb_l[b], t->sfb_l[b + 1], 576);
+    for (b = 0; b < LH_PSFB21; b++)
+        t->ath_psfb21[b] = quietest_line(c, t->psfb21[b], t->psfb21[b + 1], 576);
+    for (b = 0; b < LH_SBMAX_S; b++) {
+        t->ath_s[b] = quietest_line(c, t->sfb_s[b], t->sfb_s[b + 1], 192);
+        t->ath_s[b] *= (t->sfb_s[b + 1] - t->sfb_s[b]);
     }
-    for (sfb = 0; sfb < LH_PSFB21; sfb++) {
-        start = t->psfb21[sfb];
-        end = t->psfb21[sfb + 1];
-        t->ath_psfb21[sfb] = FLT_MAX;
-        for (i = start; i < end; i++) {
-            float const freq = i * samp_freq / (2 * 576);
-            ath_f = ath_mdct(c, freq);
-            t->ath_psfb21[sfb] = (t->ath_psfb21[sfb] < ath_f) ? t->ath_psfb21[sfb] : ath_f;
-        }
+    for (b = 0; b < LH_PSFB12; b++) {
+        t->ath_psfb12[b] = quietest_line(c, t->psfb12[b], t->psfb12[b + 1], 192);
+        t->ath_psfb12[b] *= (t->sfb_s[13] - t->sfb_s[12]);
     }
-    for (sfb = 0; sfb < LH_SBMAX_S; sfb++) {
-        start = t->sfb_s[sfb];
-        end = t->sfb_s[sfb + 1];
-        t->ath_s[sfb] = FLT_MAX;
-        for (i = start; i < end; i++) {
-            float const freq = i * samp_freq / (2 * 192);
-            ath_f = ath_mdct(c, freq);
-            t->ath_s[sfb] = (t->ath_s[sfb] < ath_f) ? t->ath_s[sfb] : ath_f;
-        }
-        t->ath_s[sfb] *= (t->sfb_s[sfb + 1] - t->sfb_s[sfb]);
-    }
-    for (sfb = 0; sfb < LH_PSFB12; sfb++) {
-        start = t->psfb12[sfb];
-        end = t->psfb12[sfb + 1];
-        t->ath_psfb12[sfb] = FLT_MAX;
-        for (i = start; i < end; i++) {
-            float const freq = i * samp_freq / (2 * 192);
-            ath_f = ath_mdct(c, freq);
-            t->ath_psfb12[sfb] = (t->ath_psfb12[sfb] < ath_f) ? t->ath_psfb12[sfb] : ath_f;
-        }
-        t->ath_psfb12[sfb] *= (t->sfb_s[13] - t->sfb_s[12]);
-    }
-    t->ath_floor = 10. * log10(ath_mdct(c, -1.));
+    t->ath_floor = 10. * log10(quiet_energy(c, -1.));
 }
 
-/* region split lookup (reference takehiro.c:38-88 subdv_table, 1334-1375 huffman_init) */
-static const signed char subdv[23][2] = {
+/* ---- quantiser tables ------------------------------------------------------------------- */
+
+/* x^(4/3), the rounding offsets of the x^(3/4) quantiser and the two step tables
+ * (reference quantize_pvt.c:350-366) */
+static void
+build_power_tables(LhTables * t)
+{
+    int     k;
+    t->pow43[0] = 0.0;
+    t->adj43asm[0] = 0.0;
+    for (k = 1; k < LH_PRECALC; k++)
+        t->pow43[k] = pow((float) k, 4.0 / 3.0);
+    for (k = 1; k < LH_PRECALC; k++)
+        t->adj43asm[k] = k - 0.5 - pow(0.5 * (t->pow43[k - 1] + t->pow43[k]), 0.75);
+    for (k = 0; k < LH_QMAX; k++)
+        t->ipow20[k] = pow(2.0, (double) (k - 210) * -0.1875);
+    for (k = 0; k <= LH_QMAX + LH_QMAX2; k++)
+        t->pow20[k] = pow(2.0, (double) (k - 210 - LH_QMAX2) * 0.25);
+}
+
+/* The device derives steps from a few mantissas and a power of two instead of reading these
+ * tables (lh_dev_qloop.h): that needs pow20[k + 4] == 2 pow20[k] and ipow20[k + 16] == ipow20[k] / 8
+ * to hold exactly, which they do whenever the host's pow() is correctly rounded here.  Checked
+ * once per table build; a libm that breaks it makes lame_init_params fail instead of producing
+ * different bytes. */
+static int
+power_tables_scale_exactly(const LhTables * t)
+{
+    int     k;
+    for (k = 0; k + 4 <= LH_QMAX + LH_QMAX2; k++)
+        if (t->pow20[k + 4] != 2.0f * t->pow20[k])
+            return 0;
+    for (k = 0; k + 16 < LH_QMAX; k++)
+        if (t->ipow20[k + 16] != t->ipow20[k] * 0.125f)
+            return 0;
+    return 1;
+}
+
+/* Region split of a long block by big_values (reference takehiro.c:38-88, 1334-1375): per number of
+ * bands below big_values, a first guess for the band counts of regions 0 and 1, which is then
+ * lowered until the region ends at or below big_values. */
+static const signed char region_guess[23][2] = {
     {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 1}, {1, 1}, {1, 1}, {1, 2}, {2, 2}, {2, 3},
     {2, 3}, {3, 4}, {3, 4}, {3, 4}, {4, 5}, {4, 5}, {4, 6}, {5, 6}, {5, 6}, {5, 7}, {6, 7},
     {6, 7}
 };
 
-static void
-build_bv_scf(LhTables * t)
-{
-    int     i;
-    for (i = 2; i <= 576; i += 2) {
-        int     scfb_anz = 0, bv_index;
-        while (t->sfb_l[++scfb_anz] < i);
-        bv_index = subdv[scfb_anz][0];
-        while (t->sfb_l[bv_index + 1] > i)
-            bv_index--;
-        if (bv_index < 0)
-            bv_index = subdv[scfb_anz][0];
-        t->bv_scf[i - 2] = bv_index;
-        bv_index = subdv[scfb_anz][1];
-        while (t->sfb_l[bv_index + t->bv_scf[i - 2] + 2] > i)
-            bv_index--;
-        if (bv_index < 0)
-            bv_index = subdv[scfb_anz][1];
-        t->bv_scf[i - 1] = bv_index;
-    }
-}
-
-/* reference quantize_pvt.c:336-417 */
-static void
-iteration_tables(const LhConfig * c, const LhInitAux * aux, LhTables * t)
-{
-    static float const payload_long[4] = { -0.500f, -0.250f, -0.025f, +0.500f };
-    static float const payload_short[4] = { -2.000f, -1.000f, -0.050f, +0.500f };
-    /* adjust_{bass,alto,treble}_db are 0 on this path (exp_nspsytune bits 2..19 are clear); the VBR
-     * presets set the sfb21 bits */
-    float const adj_bass = 0.f, adj_alto = 0.f, adj_treble = 0.f, adj_sfb21 = aux->adjust_sfb21_db;
-    float   adjust, db;
-    int     i;
-
-    compute_ath(c, t);
-    t->pow43[0] = 0.0;
-    for (i = 1; i < LH_PRECALC; i++)
-        t->pow43[i] = pow((float) i, 4.0 / 3.0);
-    t->adj43asm[0] = 0.0;
-    for (i = 1; i < LH_PRECALC; i++)
-        t->adj43asm[i] = i - 0.5 - pow(0.5 * (t->pow43[i - 1] + t->pow43[i]), 0.75);
-    for (i = 0; i < LH_QMAX; i++)
-        t->ipow20[i] = pow(2.0, (double) (i - 210) * -0.1875);
-    for (i = 0; i <= LH_QMAX + LH_QMAX2; i++)
-        t->pow20[i] = pow(2.0, (double) (i - 210 - LH_QMAX2) * 0.25);
-    build_bv_scf(t);
-
-    db = adj_bass + payload_long[0];
-    adjust = powf(10.f, db * 0.1f);
-    for (i = 0; i <= 6; ++i)
-        t->longfact[i] = adjust;
-    db = adj_alto + payload_long[1];
-    adjust = powf(10.f, db * 0.1f);
-    for (; i <= 13; ++i)
-        t->longfact[i] = adjust;
-    db = adj_treble + payload_long[2];
-    adjust = powf(10.f, db * 0.1f);
-    for (; i <= 20; ++i)
-        t->longfact[i] = adjust;
-    db = adj_sfb21 + payload_long[3];
-    adjust = powf(10.f, db * 0.1f);
-    for (; i < LH_SBMAX_L; ++i)
-        t->longfact[i] = adjust;
-
-    db = adj_bass + payload_short[0];
-    adjust = powf(10.f, db * 0.1f);
-    for (i = 0; i <= 2; ++i)
-        t->shortfact[i] = adjust;
-    db = adj_alto + payload_short[1];
-    adjust = powf(10.f, db * 0.1f);
-    for (; i <= 6; ++i)
-        t->shortfact[i] = adjust;
-    db = adj_treble + payload_short[2];
-    adjust = powf(10.f, db * 0.1f);
-    for (; i <= 11; ++i)
-        t->shortfact[i] = adjust;
-    db = adj_sfb21 + payload_short[3];
-    adjust = powf(10.f, db * 0.1f);
-    for (; i < LH_SBMAX_S; ++i)
-        t->shortfact[i] = adjust;
-}
-
-/* ---------------------------------------------------------------------- */
-/* psycho-acoustic constants (reference psymodel.c:1605-2157)               */
-
-static float
-s3_func(float bark)
-{
-    float   tempx, x, tempy, temp;
-    tempx = bark;
-    if (tempx >= 0)
-        tempx *= 3;
-    else
-        tempx *= 1.5;
-
-    if (tempx >= 0.5 && tempx <= 2.5) {
-        temp = tempx - 0.5;
-        x = 8.0 * (temp * temp - 2.0 * temp);
-    }
-    else
-        x = 0.0;
-    tempx += 0.474;
-    tempy = 15.811389 + 7.5 * tempx - 17.5 * sqrt(1.0 + tempx * tempx);
-    if (tempy <= -60.0)
-        return 0.0;
-    tempx = exp((x + tempy) * (LH_LOG10 / 10));
-    tempx /= .6609193;
-    return tempx;
-}
-
-static float
-stereo_demask(double f)
-{
-    double  arg = freq2bark(f);
-    arg = ((arg < 15.5 ? arg : 15.5) / 15.5);
-    return pow(10.0, 1.25 * (1 - cos(LH_PI * arg)) - 2.5);
-}
-
-static void
-init_numline(LhPsyBand * gd, float sfreq, int fft_size, int mdct_size, int sbmax,
-             int const *scalepos)
-{
-    float   b_frq[LH_CBANDS + 1];
-    float const mdct_freq_frac = sfreq / (2.0f * mdct_size);
-    float const deltafreq = fft_size / (2.0f * mdct_size);
-    int     partition[LH_HBLKSIZE];
-    int     i, j, ni, sfb;
-
-    memset(partition, 0, sizeof(partition));
-    memset(b_frq, 0, sizeof(b_frq));
-    sfreq /= fft_size;
-    j = 0;
-    ni = 0;
-    for (i = 0; i < LH_CBANDS; i++) {
-        float   bark1;
-        int     j2, nl;
-        bark1 = freq2bark(sfreq * j);
-        b_frq[i] = sfreq * j;
-        for (j2 = j; freq2bark(sfreq * j2) - bark1 < LH_DELBARK && j2 <= fft_size / 2; j2++);
-        nl = j2 - j;
-        gd->numlines[i] = nl;
-        gd->rnumlines[i] = (nl > 0) ? (1.0f / nl) : 0;
-        ni = i + 1;
-        while (j < j2)
-            partition[j++] = i;
-        if (j > fft_size / 2) {
-            j = fft_size / 2;
-            ++i;
-            break;
-        }
-    }
-    b_frq[i] = sfreq * j;
-    gd->n_sb = sbmax;
-    gd->npart = ni;
-    j = 0;
-    for (i = 0; i < gd->npart; i++) {
-        int const nl = gd->numlines[i];
-        float const freq = sfreq * (j + nl / 2);
-        gd->mld_cb[i] = stereo_demask(freq);
-        j += nl;
-    }
-    for (; i < LH_CBANDS; ++i)
-        gd->mld_cb[i] = 1;
-    for (sfb = 0; sfb < sbmax; sfb++) {
-        int     i1, i2, bo;
-        int     start = scalepos[sfb];
-        int     end = scalepos[sfb + 1];
-        i1 = floor(.5 + deltafreq * (start - .5));
-        if (i1 < 0)
-            i1 = 0;
-        i2 = floor(.5 + deltafreq * (end - .5));
-        if (i2 > fft_size / 2)
-            i2 = fft_size / 2;
-        bo = partition[i2];
-        gd->bm[sfb] = (partition[i1] + partition[i2]) / 2;
-        gd->bo[sfb] = bo;
-        {
-            float const f_tmp = mdct_freq_frac * end;
-            float   bo_w = (f_tmp - b_frq[bo]) / (b_frq[bo + 1] - b_frq[bo]);
-            if (bo_w < 0)
-                bo_w = 0;
-            else if (bo_w > 1)
-                bo_w = 1;
-            gd->bo_weight[sfb] = bo_w;
-        }
-        gd->mld[sfb] = stereo_demask(mdct_freq_frac * start);
-    }
-}
-
-static void
-compute_bark_values(LhPsyBand const *gd, float sfreq, int fft_size, float *bval, float *bval_width)
-{
-    int     k, j = 0, ni = gd->npart;
-    sfreq /= fft_size;
-    for (k = 0; k < ni; k++) {
-        int const w = gd->numlines[k];
-        float   bark1, bark2;
-        bark1 = freq2bark(sfreq * (j));
-        bark2 = freq2bark(sfreq * (j + w - 1));
-        bval[k] = .5 * (bark1 + bark2);
-        bark1 = freq2bark(sfreq * (j - .5));
-        bark2 = freq2bark(sfreq * (j + w - .5));
-        bval_width[k] = bark2 - bark1;
-        j += w;
-    }
-}
-
+/* largest count <= guess with edge[base + count] <= limit; the guess itself when there is none */
 static int
-init_s3_values(LhPsyBand * gd, float const *bval, float const *bval_width, float const *norm)
+lower_until_inside(const int *edge, int base, int guess, int limit)
 {
-    static float s3[LH_CBANDS][LH_CBANDS];
-    int     i, j, k, npart = gd->npart;
-    int     nonzero = 0;
+    int     n = guess;
+    while (n >= 0 && edge[base + n] > limit)
+        n--;
+    return n < 0 ? guess : n;
+}
 
-    memset(&s3[0][0], 0, sizeof(s3));
-    for (i = 0; i < npart; i++) {
-        for (j = 0; j < npart; j++) {
-            float   v = s3_func(bval[i] - bval[j]) * bval_width[j];
-            s3[i][j] = v * norm[i];
+static void
+build_region_split(LhTables * t)
+{
+    int     bv;
+    for (bv = 2; bv <= 576; bv += 2) {
+        int     below = 1, r0;
+        while (t->sfb_l[below] < bv)
+            below++;            /* bands that start below big_values */
+        r0 = lower_until_inside(t->sfb_l, 1, region_guess[below][0], bv);
+        t->bv_scf[bv - 2] = r0;
+        t->bv_scf[bv - 1] = lower_until_inside(t->sfb_l, r0 + 2, region_guess[below][1], bv);
+    }
+}
+
+/* per-band weights on the masking threshold: four groups of bands (bass, alto, treble, the band
+ * above the last scalefactor band), each 10^(dB / 10) (reference quantize_pvt.c:375-417; the
+ * bass / alto / treble adjustments of exp_nspsytune are 0 on this path, the VBR presets set
+ * the sfb21 one) */
+static void
+build_band_weights(const LhInitAux * aux, LhTables * t)
+{
+    static float const group_db_long[4] = { -0.500f, -0.250f, -0.025f, +0.500f };
+    static float const group_db_short[4] = { -2.000f, -1.000f, -0.050f, +0.500f };
+    static int const last_long[4] = { 6, 13, 20, LH_SBMAX_L - 1 };
+    static int const last_short[4] = { 2, 6, 11, LH_SBMAX_S - 1 };
+    float const tune[4] = { 0.f, 0.f, 0.f, aux->adjust_sfb21_db };
+    int     g, b;
+    for (g = 0, b = 0; g < 4; g++) {
+        float const db = tune[g] + group_db_long[g];
+        float const w = powf(10.f, db * 0.1f);
+        for (; b <= last_long[g]; b++)
+            t->longfact[b] = w;
+    }
+    for (g = 0, b = 0; g < 4; g++) {
+        float const db = tune[g] + group_db_short[g];
+        float const w = powf(10.f, db * 0.1f);
+        for (; b <= last_short[g]; b++)
+            t->shortfact[b] = w;
+    }
+}
+
+/* ---- psycho-acoustic constants (reference psymodel.c:1605-2157) --------------------------- */
+
+/* critical-band rate of a frequency (Hz -> Bark; reference util.c:268-282) */
+static float
+bark_of(float hz)
+{
+    float   khz = hz < 0 ? 0 : hz;
+    khz = khz * 0.001;
+    return 13.0 * atan(.76 * khz) + 3.5 * atan(khz * khz / (7.5 * 7.5));
+}
+
+/* masking level difference between mid/side and left/right at a frequency */
+static float
+mld_at(double hz)
+{
+    double  z = bark_of(hz);
+    z = ((z < 15.5 ? z : 15.5) / 15.5);
+    return pow(10.0, 1.25 * (1 - cos(LH_PI * z)) - 2.5);
+}
+
+/* the spreading function at a distance of `dz' Bark from the masker: a slope pair with a dip
+ * between 0.5 and 2.5 (scaled) Bark above the masker, cut at -60 dB, normalised */
+static float
+spread_at(float dz)
+{
+    float   z = dz, dip = 0.0, slopes;
+    if (z >= 0)
+        z *= 3;
+    else
+        z *= 1.5;
+    if (z >= 0.5 && z <= 2.5) {
+        float const u = z - 0.5;
+        dip = 8.0 * (u * u - 2.0 * u);
+    }
+    z += 0.474;
+    slopes = 15.811389 + 7.5 * z - 17.5 * sqrt(1.0 + z * z);
+    if (slopes <= -60.0)
+        return 0.0;
+    z = exp((dip + slopes) * (LH_LOG10 / 10));
+    z /= .6609193;
+    return z;
+}
+
+/* Partition of the FFT lines 0 .. n/2 into bands about a third of a Bark wide: first[p] is the
+ * first line of partition p, first[count] one past the last line (it can be n/2 + 1). */
+typedef struct Partitioning {
+    int     count;
+    int     first[LH_CBANDS + 1];
+    int     of_line[LH_HBLKSIZE + 1];
+    float   hz_per_line;
+} Partitioning;
+
+static void
+partition_spectrum(Partitioning * P, float rate, int n)
+{
+    int const half = n / 2;
+    float   z[LH_HBLKSIZE + 2];
+    int     line, p;
+    P->hz_per_line = rate / n;
+    for (line = 0; line <= half + 1; line++)
+        z[line] = bark_of(P->hz_per_line * line);
+    memset(P->of_line, 0, sizeof(P->of_line));
+    P->first[0] = 0;
+    for (p = 0; p < LH_CBANDS;) {
+        int     end = P->first[p];
+        while (z[end] - z[P->first[p]] < LH_DELBARK && end <= half)
+            end++;
+        for (line = P->first[p]; line < end; line++)
+            P->of_line[line] = p;
+        P->first[++p] = end;
+        if (end > half)
+            break;
+    }
+    P->count = p;
+}
+
+/* numlines, their reciprocals, the M/S masking level difference per partition, and the mapping
+ * of partitions to the scalefactor bands whose edges are edge[0..nbands] on a grid of `lines'
+ * MDCT lines: last partition of a band (bo), a middle one (bm), and how far into partition bo the
+ * band's upper edge reaches (bo_weight) */
+static void
+build_partition_tables(LhPsyBand * d, float rate, int n, int lines, int nbands, int const *edge)
+{
+    Partitioning P;
+    int const half = n / 2;
+    float const line_ratio = n / (2.0f * lines);        /* FFT lines per MDCT line */
+    float const hz_per_mdct_line = rate / (2.0f * lines);
+    float   hz_first[LH_CBANDS + 1];
+    int     p, b;
+    partition_spectrum(&P, rate, n);
+    d->npart = P.count;
+    d->n_sb = nbands;
+    memset(hz_first, 0, sizeof(hz_first));
+    for (p = 0; p <= P.count; p++)
+        hz_first[p] = P.hz_per_line * ((p == P.count && P.first[p] > half) ? half : P.first[p]);
+    for (p = 0; p < P.count; p++) {
+        int const nl = P.first[p + 1] - P.first[p];
+        d->numlines[p] = nl;
+        d->rnumlines[p] = (nl > 0) ? (1.0f / nl) : 0;
+        d->mld_cb[p] = mld_at(P.hz_per_line * (P.first[p] + nl / 2));
+    }
+    for (; p < LH_CBANDS; p++)
+        d->mld_cb[p] = 1;
+    for (b = 0; b < nbands; b++) {
+        int     lo = floor(.5 + line_ratio * (edge[b] - .5));
+        int     hi = floor(.5 + line_ratio * (edge[b + 1] - .5));
+        int     last;
+        float   reach;
+        if (lo < 0)
+            lo = 0;
+        if (hi > half)
+            hi = half;
+        last = P.of_line[hi];
+        d->bo[b] = last;
+        d->bm[b] = (P.of_line[lo] + last) / 2;
+        reach = (hz_per_mdct_line * edge[b + 1] - hz_first[last]) / (hz_first[last + 1] - hz_first[last]);
+        d->bo_weight[b] = reach < 0 ? 0 : (reach > 1 ? 1 : reach);
+        d->mld[b] = mld_at(hz_per_mdct_line * edge[b]);
+    }
+}
+
+/* centre and width of each partition on the Bark scale */
+static void
+partition_barks(const LhPsyBand * d, float rate, int n, float *centre, float *width)
+{
+    float const hz_per_line = rate / n;
+    int     p, line = 0;
+    for (p = 0; p < d->npart; p++) {
+        int const nl = d->numlines[p];
+        float const z_lo = bark_of(hz_per_line * (line)), z_hi = bark_of(hz_per_line * (line + nl - 1));
+        float const e_lo = bark_of(hz_per_line * (line - .5)), e_hi = bark_of(hz_per_line * (line + nl - .5));
+        centre[p] = .5 * (z_lo + z_hi);
+        width[p] = e_hi - e_lo;
+        line += nl;
+    }
+}
+
+/* spreading matrix, stored as the run of positive entries of each row: s3[s3_row[i] ..] holds the
+ * columns s3ind[i][0] .. s3ind[i][1] of row i = spread(centre_i - centre_j) width_j gain_i */
+static int
+build_spreading(LhPsyBand * d, float const *centre, float const *width, float const *gain)
+{
+    int const np = d->npart;
+    int     i, j, used = 0;
+    for (i = 0; i < np; i++) {
+        float   row[LH_CBANDS];
+        int     lo, hi;
+        for (j = 0; j < np; j++) {
+            float const v = spread_at(centre[i] - centre[j]) * width[j];
+            row[j] = v * gain[i];
         }
+        for (lo = 0; lo < np && !(row[lo] > 0.0f); lo++);
+        for (hi = np - 1; hi > 0 && !(row[hi] > 0.0f); hi--);
+        d->s3ind[i][0] = lo;
+        d->s3ind[i][1] = hi;
+        d->s3_row[i] = used;
+        if (used + (hi - lo + 1) > LH_S3_MAX)
+            return -1;
+        for (j = lo; j <= hi; j++)
+            d->s3[used++] = row[j];
     }
-    for (i = 0; i < npart; i++) {
-        for (j = 0; j < npart; j++)
-            if (s3[i][j] > 0.0f)
-                break;
-        gd->s3ind[i][0] = j;
-        for (j = npart - 1; j > 0; j--)
-            if (s3[i][j] > 0.0f)
-                break;
-        gd->s3ind[i][1] = j;
-        nonzero += (gd->s3ind[i][1] - gd->s3ind[i][0] + 1);
-    }
-    if (nonzero > LH_S3_MAX)
-        return -1;
-    k = 0;
-    for (i = 0; i < npart; i++) {
-        gd->s3_row[i] = k;
-        for (j = gd->s3ind[i][0]; j <= gd->s3ind[i][1]; j++)
-            gd->s3[k++] = s3[i][j];
-    }
-    gd->s3_count = k;
+    d->s3_count = used;
     return 0;
+}
+
+/* signal-to-mask gain of a partition: `below' dB up to 13 Bark, then a line to `above' dB at 24 */
+static float
+snr_gain(float z, float below, float above)
+{
+    float const z0 = 13, z1 = 24;
+    double  snr = below;
+    if (z >= z0)
+        snr = above * (z - z0) / (z1 - z0) + below * (z1 - z) / (z1 - z0);
+    return pow(10.0, snr / 10.0);
+}
+
+/* threshold in quiet per partition: the quietest FFT line's level, 20 dB down, times the line
+ * count; lines are spaced rate / n apart */
+static void
+build_partition_quiet(const LhConfig * c, const LhPsyBand * d, int n, float *out)
+{
+    float const rate = c->samplerate;
+    int     p, k, line = 0;
+    for (p = 0; p < d->npart; p++) {
+        double  least = FLT_MAX;
+        for (k = 0; k < d->numlines[p]; k++, line++) {
+            float const khz = rate * line / (1000.0 * n);
+            float   e = quiet_level_db(c, khz * 1000) - 20;
+            e = pow(10., 0.1 * e);
+            e *= d->numlines[p];
+            if (least > e)
+                least = e;
+        }
+        out[p] = least;
+    }
+}
+
+/* floor of the masking threshold relative to the partition's energy: from a tonality estimate
+ * that follows the Bark value (`shape': 0 = long blocks, 1 = short blocks), limited by the
+ * preset's minval */
+static float
+masking_floor(const LhConfig * c, float z, int nl, int shape)
+{
+    float const lowest = (0.f - c->minval);
+    double  x;
+    if (shape == 0)
+        x = 20.0 * (z / 10 - 1.0);
+    else {
+        float const knee = 12;
+        x = 7.0 * (z / knee - 1.0);
+        if (z > knee)
+            x *= 1 + log(1 + x) * 3.1;
+        if (z < knee)
+            x *= 1 + log(1 - x) * 2.3;
+    }
+    if (x > 6)
+        x = 30;
+    if (x < lowest)
+        x = lowest;
+    if (c->samplerate < 44000)
+        x = 30;
+    x -= 8.;
+    return pow(10.0, x / 10.) * nl;
+}
+
+/* lowering of the masking threshold towards high partitions (the VBR quality's "sk" slope) */
+static void
+build_masking_lower(LhPsyBand * d, float slope)
+{
+    int     p;
+    for (p = 0; p < d->npart; p++) {
+        float const m = (float) (d->npart - p) / d->npart;
+        d->masking_lower[p] = powf(10.f, slope * m * 0.1f);
+    }
+    for (; p < LH_CBANDS; p++)
+        d->masking_lower[p] = 1.f;
+}
+
+/* loudness weights of the 512 FFT lines (inverse threshold in quiet), normalised to sum 1 */
+static void
+build_loudness_weights(const LhConfig * c, LhTables * t)
+{
+    float const step = (float) c->samplerate / (float) (LH_BLKSIZE);
+    float   hz = 0.0, total = 0.0;
+    int     k;
+    for (k = 0; k < LH_BLKSIZE / 2; ++k) {
+        hz += step;
+        t->ath_eql_w[k] = 1. / pow(10, quiet_level_db(c, hz) / 10);
+        total += t->ath_eql_w[k];
+    }
+    total = 1.0 / total;
+    for (k = LH_BLKSIZE / 2; --k >= 0;)
+        t->ath_eql_w[k] *= total;
 }
 
 static int
 psymodel_tables(LhConfig * c, const LhInitAux * aux, LhTables * t)
 {
-    int     i, j, b, k;
-    float   bvl_a = 13, bvl_b = 24;
-    float   snr_l_a = 0, snr_l_b = 0;
-    float   snr_s_a = -8.25, snr_s_b = -4.5;
-    float   bval[LH_CBANDS], bval_width[LH_CBANDS], norm[LH_CBANDS];
-    float const sfreq = c->samplerate;
-    float   xav = 10, xbv = 12;
-    float const minval_low = (0.f - c->minval);
-    LhPsyBand *gl = &t->psy_l, *gs = &t->psy_s;
+    float const rate = c->samplerate;
+    float   centre[LH_CBANDS], width[LH_CBANDS], gain[LH_CBANDS];
+    LhPsyBand *L = &t->psy_l, *S = &t->psy_s;
+    int     p;
 
-    memset(norm, 0, sizeof(norm));
-    init_numline(gl, sfreq, LH_BLKSIZE, 576, LH_SBMAX_L, t->sfb_l);
-    compute_bark_values(gl, sfreq, LH_BLKSIZE, bval, bval_width);
-    for (i = 0; i < gl->npart; i++) {
-        double  snr = snr_l_a;
-        if (bval[i] >= bvl_a) {
-            snr = snr_l_b * (bval[i] - bvl_a) / (bvl_b - bvl_a)
-                + snr_l_a * (bvl_b - bval[i]) / (bvl_b - bvl_a);
-        }
-        norm[i] = pow(10.0, snr / 10.0);
-    }
-    if (init_s3_values(gl, bval, bval_width, norm))
+    /* long blocks: 1024-point FFT over 576 MDCT lines */
+    memset(gain, 0, sizeof(gain));
+    build_partition_tables(L, rate, LH_BLKSIZE, 576, LH_SBMAX_L, t->sfb_l);
+    partition_barks(L, rate, LH_BLKSIZE, centre, width);
+    for (p = 0; p < L->npart; p++)
+        gain[p] = snr_gain(centre[p], 0, 0);
+    if (build_spreading(L, centre, width, gain))
         return -1;
-    j = 0;
-    for (i = 0; i < gl->npart; i++) {
-        double  x;
-        x = FLT_MAX;
-        for (k = 0; k < gl->numlines[i]; k++, j++) {
-            float const freq = sfreq * j / (1000.0 * LH_BLKSIZE);
-            float   level;
-            level = ath_formula(c, freq * 1000) - 20;
-            level = pow(10., 0.1 * level);
-            level *= gl->numlines[i];
-            if (x > level)
-                x = level;
-        }
-        t->ath_cb_l[i] = x;
-        x = 20.0 * (bval[i] / xav - 1.0);
-        if (x > 6)
-            x = 30;
-        if (x < minval_low)
-            x = minval_low;
-        if (c->samplerate < 44000)
-            x = 30;
-        x -= 8.;
-        gl->minval[i] = pow(10.0, x / 10.) * gl->numlines[i];
-    }
+    build_partition_quiet(c, L, LH_BLKSIZE, t->ath_cb_l);
+    for (p = 0; p < L->npart; p++)
+        L->minval[p] = masking_floor(c, centre[p], L->numlines[p], 0);
 
-    init_numline(gs, sfreq, LH_BLKSIZE_S, 192, LH_SBMAX_S, t->sfb_s);
-    compute_bark_values(gs, sfreq, LH_BLKSIZE_S, bval, bval_width);
-    j = 0;
-    for (i = 0; i < gs->npart; i++) {
-        double  x;
-        double  snr = snr_s_a;
-        if (bval[i] >= bvl_a) {
-            snr = snr_s_b * (bval[i] - bvl_a) / (bvl_b - bvl_a)
-                + snr_s_a * (bvl_b - bval[i]) / (bvl_b - bvl_a);
-        }
-        norm[i] = pow(10.0, snr / 10.0);
-        x = FLT_MAX;
-        for (k = 0; k < gs->numlines[i]; k++, j++) {
-            float const freq = sfreq * j / (1000.0 * LH_BLKSIZE_S);
-            float   level;
-            level = ath_formula(c, freq * 1000) - 20;
-            level = pow(10., 0.1 * level);
-            level *= gs->numlines[i];
-            if (x > level)
-                x = level;
-        }
-        t->ath_cb_s[i] = x;
-        x = 7.0 * (bval[i] / xbv - 1.0);
-        if (bval[i] > xbv)
-            x *= 1 + log(1 + x) * 3.1;
-        if (bval[i] < xbv)
-            x *= 1 + log(1 - x) * 2.3;
-        if (x > 6)
-            x = 30;
-        if (x < minval_low)
-            x = minval_low;
-        if (c->samplerate < 44000)
-            x = 30;
-        x -= 8;
-        gs->minval[i] = pow(10.0, x / 10) * gs->numlines[i];
-    }
-    if (init_s3_values(gs, bval, bval_width, norm))
+    /* short blocks: 256-point FFT over 192 MDCT lines */
+    build_partition_tables(S, rate, LH_BLKSIZE_S, 192, LH_SBMAX_S, t->sfb_s);
+    partition_barks(S, rate, LH_BLKSIZE_S, centre, width);
+    for (p = 0; p < S->npart; p++)
+        gain[p] = snr_gain(centre[p], -8.25, -4.5);
+    build_partition_quiet(c, S, LH_BLKSIZE_S, t->ath_cb_s);
+    for (p = 0; p < S->npart; p++)
+        S->minval[p] = masking_floor(c, centre[p], S->numlines[p], 1);
+    if (build_spreading(S, centre, width, gain))
         return -1;
 
+    /* limits of the masking-addition table indices, temporal decay of the short-block thresholds */
     t->ma_max_i1 = pow(10, (8 + 1) / 16.0);
     t->ma_max_i2 = pow(10, (23 + 1) / 16.0);
-
-    t->decay = exp(-1.0 * LH_LOG10 / (0.01 * sfreq / 192.0));
+    t->decay = exp(-1.0 * LH_LOG10 / (0.01 * rate / 192.0));
     {
         float   msfix = 3.5;    /* NS_MSFIX */
         if (c->use_safe_joint_stereo)
@@ -1185,63 +1231,34 @@ psymodel_tables(LhConfig * c, const LhInitAux * aux, LhTables * t)
         if (fabs(c->msfix) > 0.0)
             msfix = c->msfix;
         c->msfix = msfix;
-        for (b = 0; b < gl->npart; b++)
-            if (gl->s3ind[b][1] > gl->npart - 1)
-                gl->s3ind[b][1] = gl->npart - 1;
     }
-    t->ath_decay = pow(10., -12. / 10. * (576. * c->mode_gr / sfreq));
+    for (p = 0; p < L->npart; p++)
+        if (L->s3ind[p][1] > L->npart - 1)
+            L->s3ind[p][1] = L->npart - 1;
+    /* ATH auto-adjustment and the loudness measure it follows */
+    t->ath_decay = pow(10., -12. / 10. * (576. * c->mode_gr / rate));
     t->ath_use_adjust = 3;
     t->aa_sensitivity_p = pow(10.0, aux->athaa_sensitivity / -10.0);
+    build_loudness_weights(c, t);
+    /* attack detection thresholds: the three sub-windows share one, the fourth has its own */
     {
-        float   freq;
-        float const freq_inc = (float) c->samplerate / (float) (LH_BLKSIZE);
-        float   eql_balance = 0.0;
-        freq = 0.0;
-        for (i = 0; i < LH_BLKSIZE / 2; ++i) {
-            freq += freq_inc;
-            t->ath_eql_w[i] = 1. / pow(10, ath_formula(c, freq) / 10);
-            eql_balance += t->ath_eql_w[i];
-        }
-        eql_balance = 1.0 / eql_balance;
-        for (i = LH_BLKSIZE / 2; --i >= 0;)
-            t->ath_eql_w[i] *= eql_balance;
+        float const usual = aux->attackthre < 0 ? (float) 4.4 : aux->attackthre;
+        float const late = aux->attackthre_s < 0 ? (float) 25 : aux->attackthre_s;
+        t->attack_threshold[0] = t->attack_threshold[1] = t->attack_threshold[2] = usual;
+        t->attack_threshold[3] = late;
     }
     {
-        float   x = aux->attackthre;
-        float   y = aux->attackthre_s;
-        if (x < 0)
-            x = 4.4;
-        if (y < 0)
-            y = 25;
-        t->attack_threshold[0] = t->attack_threshold[1] = t->attack_threshold[2] = x;
-        t->attack_threshold[3] = y;
+        /* slope by VBR quality (4 on the CBR path), interpolated for fractional qualities */
+        static float const sk[] = { -7.4, -7.4, -7.4, -9.5, -7.4, -6.1, -5.5, -4.7, -4.7, -4.7, -4.7 };
+        float const slope = (aux->vbr_q < 4) ? sk[0]
+            : sk[aux->vbr_q] + aux->vbr_q_frac * (sk[aux->vbr_q] - sk[aux->vbr_q + 1]);
+        build_masking_lower(S, slope);
+        build_masking_lower(L, slope);
     }
-    {
-        /* VBR_q stays at its default 4 on the CBR path */
-        float   sk_s, sk_l;
-        static float const sk[] =
-            { -7.4, -7.4, -7.4, -9.5, -7.4, -6.1, -5.5, -4.7, -4.7, -4.7, -4.7 };
-        if (aux->vbr_q < 4)
-            sk_l = sk_s = sk[0];
-        else
-            sk_l = sk_s = sk[aux->vbr_q] + aux->vbr_q_frac * (sk[aux->vbr_q] - sk[aux->vbr_q + 1]);
-        b = 0;
-        for (; b < gs->npart; b++) {
-            float   m = (float) (gs->npart - b) / gs->npart;
-            gs->masking_lower[b] = powf(10.f, sk_s * m * 0.1f);
-        }
-        for (; b < LH_CBANDS; ++b)
-            gs->masking_lower[b] = 1.f;
-        b = 0;
-        for (; b < gl->npart; b++) {
-            float   m = (float) (gl->npart - b) / gl->npart;
-            gl->masking_lower[b] = powf(10.f, sk_l * m * 0.1f);
-        }
-        for (; b < LH_CBANDS; ++b)
-            gl->masking_lower[b] = 1.f;
-    }
-    memcpy(&t->psy_l_to_s, gl, sizeof(LhPsyBand));
-    init_numline(&t->psy_l_to_s, sfreq, LH_BLKSIZE, 192, LH_SBMAX_S, t->sfb_s);
+    /* long-block partitions mapped onto the short scalefactor bands (for the thresholds a
+     * short granule inherits from a long analysis) */
+    memcpy(&t->psy_l_to_s, L, sizeof(LhPsyBand));
+    build_partition_tables(&t->psy_l_to_s, rate, LH_BLKSIZE, 192, LH_SBMAX_S, t->sfb_s);
     return 0;
 }
 
@@ -1369,7 +1386,12 @@ lh_tables_build(LhConfig * c, const LhInitAux * aux, LhTables * t)
     t->psfb12[LH_PSFB12] = 192;
 
     ppflt_tables(aux, t);
-    iteration_tables(c, aux, t);
+    build_band_thresholds(c, t);
+    build_power_tables(t);
+    if (!power_tables_scale_exactly(t))
+        return -1;
+    build_region_split(t);
+    build_band_weights(aux, t);
     if (psymodel_tables(c, aux, t))
         return -1;
     fft_tables(t);

@@ -82,26 +82,26 @@ lh_tag_init(LhVbrTag * v, const LhConfig * c)
     return total;
 }
 
-/* reference VbrTag.c:124-148 */
+/* Seek-point bookkeeping (reference VbrTag.c:124-148): the running sum of the frames' bit rates is
+ * sampled every `want' frames into a bag of fixed size; a full bag keeps every second sample and
+ * the sampling distance doubles, so the bag always spans the whole stream evenly. */
 void
 lh_tag_add_frame(LhVbrTag * v, int kbps)
 {
-    int     i;
     v->num_frames++;
     v->sum += kbps;
-    v->seen++;
-    if (v->seen < v->want)
+    if (++v->seen < v->want)
         return;
     if (v->pos < v->size) {
-        v->bag[v->pos] = v->sum;
-        v->pos++;
+        v->bag[v->pos++] = v->sum;
         v->seen = 0;
     }
     if (v->pos == v->size) {
-        for (i = 1; i < v->size; i += 2)
-            v->bag[i / 2] = v->bag[i];
-        v->want *= 2;
+        int     keep;
+        for (keep = 0; 2 * keep + 1 < v->size; keep++)
+            v->bag[keep] = v->bag[2 * keep + 1];
         v->pos /= 2;
+        v->want += v->want;
     }
 }
 
@@ -163,19 +163,17 @@ lh_tag_frame(const LhVbrTag * v, const LhConfig * c, int vbr_q, int enc_padding,
     tag_frame_header(c, last_mode_ext, buf);
     memset(toc, 0, sizeof(toc));
     for (i = 1; i < 100; ++i) {
-        /* reference Xing_seek_table: float index, float bag / sum, double scaling */
-        float const j = i / (float) 100;
-        float   act, sum;
-        int     indx = (int) (floor(j * v->pos));
-        int     seek_point;
-        if (indx > v->pos - 1)
-            indx = v->pos - 1;
-        act = (float) v->bag[indx];
-        sum = (float) v->sum;
-        seek_point = (int) (256. * act / sum);
-        if (seek_point > 255)
-            seek_point = 255;
-        toc[i] = (unsigned char) seek_point;
+        /* entry i = where i percent of the playing time lies, in 1/256 of the byte count: the
+         * bag sample nearest below, relative to the final sum (float index and ratio, double
+         * scaling, as the reference's Xing_seek_table evaluates them) */
+        float const percent = i / (float) 100;
+        int     slot = (int) (floor(percent * v->pos)), where;
+        float   upto, all;
+        slot = slot > v->pos - 1 ? v->pos - 1 : slot;
+        upto = (float) v->bag[slot];
+        all = (float) v->sum;
+        where = (int) (256. * upto / all);
+        toc[i] = (unsigned char) (where > 255 ? 255 : where);
     }
     n = c->sideinfo_len;
     if (c->error_protection)

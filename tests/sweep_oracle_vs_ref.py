@@ -46,6 +46,11 @@ def main():
                     unsup += 1
                     continue
                 cfg, tab = enc.config(), enc.tables()
+                if cfg.samplerate != sr:
+                    # the reference converts the input rate first: tests/sweep_resample.py covers those
+                    unsup += 1
+                    enc.close()
+                    continue
                 n = int(sr * 1.2)
                 for k in range(nsig):
                     x = tg._stress_signal(sum(kw.values()) + 7 * k + q + nch, n - 41 * k, sr)
