@@ -1,18 +1,26 @@
 #!/usr/bin/env python
 """bench.py -- headline benchmark of the MI355X-native MP3 encode inner loop.
 
-Metric (BASELINE.json): encoded audio seconds per wall-clock second (x real-time)
-at 44.1 kHz stereo CBR 128 kb/s.  A "step" is one pass of the hot path (psycho-
-acoustics + polyphase/MDCT + quantisation loop -> side-info payload in HBM) over
-one batch of synthetic streams whose PCM is already resident in HBM
-(BASELINE config[1]: batch = 1024 streams x 60 s per GPU).  With --gpus N each
-rank encodes its own 1024 streams (static sharding, no collective in the data
-path; weak scaling); rank 0 prints ONE JSON line with the whole-job aggregate.
+Metric (BASELINE.json): encoded audio seconds per wall-clock second (x real-time) at 44.1 kHz
+stereo CBR 128 kb/s.  A "step" is one pass of the hot path (psycho-acoustics + polyphase/MDCT +
+quantisation loop -> side-info payload in HBM) over one batch of synthetic streams whose PCM is
+already resident in HBM (BASELINE config[1]: batch = 1024 streams x 60 s per GPU).
+
+Multi-GPU: streams are independent, so a batch of N x 1024 streams is sharded
+statically, rank r owning the contiguous block lamehip.shard_streams(N * 1024, N, r); there is no
+collective anywhere on the data path and no RCCL.  `python bench.py --gpus N` spawns the N ranks
+itself (one process per device, a directory of marker files as the barrier); when a launcher has
+already created the ranks (python -m torch.distributed.run ... bench.py --gpus N: WORLD_SIZE / RANK /
+LOCAL_RANK in the environment) the ranks only use torch.distributed's gloo backend on the CPU for
+the barrier and the maximum of the times.  Either way rank 0 prints ONE JSON line with the
+whole-job aggregate.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -21,16 +29,19 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 ALG_BYTES_PER_FRAME = 9792          # 4608 B PCM in + 5184 B side info out
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+CHECKED_STREAMS = 4                 # streams whose payload is compared with the CPU oracle after the timed region
+CPU_SAMPLE_SECONDS = 20.0           # audio per stream in the CPU leg
 
 
-def synth_on_device(torch, batch, n, sr, seed0, device, chunk=32):
-    """Seeded music-like stereo s16 PCM generated on the GPU (no dataset access):
-    8 partials with independent phases per channel + low-level noise + decaying
-    noise bursts every 1/3 s.  Returns an int16 tensor [batch, 2, n] on device."""
+def synth_on_device(torch, batch, n, sr, seed0, device, chunk=32, bursts_per_s=3.0):
+    """Seeded music-like stereo s16 PCM generated on the GPU (no dataset access): 8 partials with
+    independent phases per channel + low-level noise + decaying noise bursts (castanet-like, they
+    trigger short blocks) bursts_per_s times a second.  Returns an int16 tensor [batch, 2, n]."""
     out = torch.empty((batch, 2, n), dtype=torch.int16, device=device)
     t = torch.arange(n, device=device, dtype=torch.float32) / sr
-    step = sr // 3
-    env = torch.exp(-torch.arange(2000, device=device, dtype=torch.float32) / 300.0)
+    step = max(int(sr / bursts_per_s), 1)
+    blen = min(2000, step)
+    env = torch.exp(-torch.arange(blen, device=device, dtype=torch.float32) / 300.0)
     for b0 in range(0, batch, chunk):
         b1 = min(batch, b0 + chunk)
         g = torch.Generator(device=device)
@@ -41,24 +52,29 @@ def synth_on_device(torch, batch, n, sr, seed0, device, chunk=32):
             ph = torch.rand((b1 - b0, 2, 1), generator=g, device=device) * 6.2831853
             x += (0.5 / (k + 1)) * torch.sin(6.2831853 * f * t + ph)
         x += 0.01 * torch.randn((b1 - b0, 2, n), generator=g, device=device)
-        for s in range(step // 2, n - 2000, step):
-            x[:, :, s:s + 2000] += 0.6 * env * torch.randn((b1 - b0, 2, 2000), generator=g, device=device)
+        for s in range(step // 2, n - blen, step):
+            x[:, :, s:s + blen] += 0.6 * env * torch.randn((b1 - b0, 2, blen), generator=g, device=device)
         x = x / x.abs().amax(dim=(1, 2), keepdim=True) * (0.8 * 32767)
         out[b0:b1] = x.to(torch.int16)
     return out
 
 
-def cpu_baseline(sr, brate, seconds_budget=12.0, vbr_q=None, abr=None):
-    """Time the compiled reference (oracle/_ref, kind 'reference') -- or the CPU
-    restatement (kind 'port') when the reference build is absent -- on ONE host
-    core over a bounded sample of the same workload."""
-    import helpers
+# ---------------------------------------------------------------------------------------------
+# CPU leg: the compiled reference (oracle/_ref) on the host's physical cores, one process per core,
+# each encoding one of the SAME streams the GPU leg encodes (their first 20 s).
+def _cpu_worker(job):
+    """One process of the CPU leg (spawned: no GPU context): encode stream `idx' of the saved PCM
+    over and over for about `budget' seconds; returns (audio seconds encoded, elapsed)."""
+    path, idx, sr, brate, vbr_q, abr, budget, kind = job
     import numpy as np
-    n = sr * 20
-    pcm = helpers.synth_stream(12345, n, sr)
-    if helpers.have_reference():
+    sys.path.insert(0, os.path.join(ROOT, "deprecated-lame-mirror_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers
+    pcm = np.load(path, mmap_mode="r")[idx]
+    pcm = np.ascontiguousarray(pcm)
+    seconds = pcm.shape[1] / float(sr)
+    if kind == "reference":
         ref = helpers.Reference()
-        kind = "reference"
 
         def run():
             ref.encode(pcm, sr, brate, vbr_q=vbr_q, abr=abr)
@@ -67,34 +83,385 @@ def cpu_baseline(sr, brate, seconds_budget=12.0, vbr_q=None, abr=None):
         orc = helpers.Oracle()
         enc = lamehip.Encoder(sr, brate, require_device=False, vbr_q=vbr_q, abr=abr)
         cfg, tab = enc.config(), enc.tables()
-        kind = "port"
 
         def run():
             orc.encode_frames(cfg, tab, pcm)
-    t0 = time.time()
-    reps = 0
+    run()                       # first touch (page-in) outside the clock
+    t0 = time.perf_counter()
+    done = 0
     while True:
         run()
-        reps += 1
-        if time.time() - t0 > seconds_budget or reps >= 8:
+        done += 1
+        if time.perf_counter() - t0 >= budget:
             break
-    dt = time.time() - t0
-    return {"value": round(reps * 20.0 / dt, 2), "unit": "x real-time", "cores": 1, "kind": kind,
-            "sample": "%d x 20 s seeded synthetic 44.1 kHz stereo, %s, one host core"
-                      % (reps, ("ABR %d" % abr) if abr is not None else ("CBR %d" % brate) if vbr_q is None
-                         else ("VBR -V%d" % vbr_q))}
+    return done * seconds, time.perf_counter() - t0
+
+
+def _physical_cores():
+    try:
+        import psutil
+        n = psutil.cpu_count(logical=False)
+        if n:
+            return int(n)
+    except Exception:
+        pass
+    return max(1, (os.cpu_count() or 2) // 2)
+
+
+def _cpu_allowance():
+    """CPUs this process may actually use at once: the affinity mask and the cgroup's CPU quota
+    (a container on a big host is often limited to a fraction of its cores)."""
+    allowed = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return allowed, quota
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(host_pcm, sr, brate, vbr_q=None, abr=None, budget=10.0):
+    """P concurrent encodes, P = physical cores (at most as many as there are saved streams),
+    plus one process alone for the per-core figure."""
+    import multiprocessing as mp
+    import numpy as np
+    import helpers
+    kind = "reference" if helpers.have_reference() else "port"
+    cores = _physical_cores()
+    allowed, quota = _cpu_allowance()
+    usable = min(cores, allowed, int(quota) if quota and quota >= 1 else cores)
+    procs = max(1, min(usable, host_pcm.shape[0]))
+    tmp = tempfile.NamedTemporaryFile(suffix=".npy", delete=False)
+    tmp.close()
+    np.save(tmp.name, host_pcm)
+    try:
+        ctx = mp.get_context("spawn")
+        with ctx.Pool(1) as pool:
+            a, t = pool.map(_cpu_worker, [(tmp.name, 0, sr, brate, vbr_q, abr, min(budget, 4.0), kind)])[0]
+        single = a / t
+        with ctx.Pool(procs) as pool:
+            res = pool.map(_cpu_worker, [(tmp.name, i, sr, brate, vbr_q, abr, budget, kind) for i in range(procs)],
+                           chunksize=1)
+    finally:
+        os.unlink(tmp.name)
+    aggregate = sum(a / t for a, t in res)
+    what = ("ABR %d" % abr) if abr is not None else ("CBR %d" % brate) if vbr_q is None else ("VBR -V%d" % vbr_q)
+    return {"value": round(aggregate, 1), "unit": "x real-time", "cores": procs, "kind": kind,
+            "per_core": round(aggregate / procs, 2), "one_process_alone": round(single, 2),
+            "physical_cores": cores, "logical_cpus": os.cpu_count(), "cpus_in_affinity_mask": allowed,
+            "cgroup_cpu_quota": quota, "cpu_model": _cpu_model(),
+            "sample": "%d processes at once, each encoding the first %.0f s of one of the GPU leg's streams "
+                      "(%s, %d Hz) repeatedly for %.0f s" % (procs, host_pcm.shape[2] / float(sr), what, sr, budget)}
+
+
+# ---------------------------------------------------------------------------------------------
+class FileRendezvous:
+    """Barrier and maximum over ranks through marker files in a directory (ranks spawned by bench.py
+    itself: no torch.distributed, no RCCL)."""
+
+    def __init__(self, path, rank, world):
+        self.path, self.rank, self.world, self.n = path, rank, world, 0
+
+    def _all(self, tag, value):
+        self.n += 1
+        name = os.path.join(self.path, "%s.%d" % (tag, self.n))
+        with open("%s.%d.tmp" % (name, self.rank), "w") as f:
+            f.write(repr(float(value)))
+        os.rename("%s.%d.tmp" % (name, self.rank), "%s.%d" % (name, self.rank))
+        vals = []
+        t0 = time.time()
+        for r in range(self.world):
+            while not os.path.exists("%s.%d" % (name, r)):
+                if time.time() - t0 > 1800:
+                    raise RuntimeError("rank %d never reached %s" % (r, tag))
+                time.sleep(0.0005)
+            vals.append(float(open("%s.%d" % (name, r)).read()))
+        return vals
+
+    def barrier(self):
+        self._all("barrier", 0.0)
+
+    def max(self, value):
+        return max(self._all("max", value))
+
+    def close(self):
+        pass
+
+
+class GlooRendezvous:
+    """The same through torch.distributed on the CPU (ranks created by a launcher)."""
+
+    def __init__(self, rank, world):
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        self.dist = dist
+
+    def barrier(self):
+        self.dist.barrier()
+
+    def max(self, value):
+        import torch
+        t = torch.tensor([value], dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        self.dist.destroy_process_group()
+
+
+class Alone:
+    def barrier(self):
+        pass
+
+    def max(self, value):
+        return value
+
+    def close(self):
+        pass
+
+
+def spawn_ranks(args, argv):
+    """python bench.py --gpus N without a launcher: start the N ranks, pass their lines through."""
+    rdv = tempfile.mkdtemp(prefix="lamehip_bench_")
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, WORLD_SIZE=str(args.gpus), RANK=str(r), LOCAL_RANK=str(r), LAMEHIP_BENCH_RDV=rdv)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    for p in procs:
+        rc = rc or p.wait()
+    for f in os.listdir(rdv):
+        os.unlink(os.path.join(rdv, f))
+    os.rmdir(rdv)
+    return rc
+
+
+def recorded(name):
+    """A measurement that needs its own profiler pass (PMC counters), recorded under profiles/ with
+    the commit and date it was taken at; bench.py quotes it, it does not re-measure it."""
+    path = os.path.join(ROOT, "profiles", name)
+    if os.path.exists(path):
+        try:
+            return json.load(open(path))
+        except ValueError:
+            return None
+    return None
+
+
+def check_against_oracle(batch, enc, host_streams, which):
+    """Payload of a few bench streams against the CPU oracle (test infrastructure, used here only as
+    the checker, after the timed region); raises on the first difference."""
+    import helpers
+    from lamehip.types import struct_diff
+    orc = helpers.Oracle()
+    cfg, tab = enc.config(), enc.tables()
+    for s, pcm in zip(which, host_streams):
+        got = batch.get_frames(s)
+        want = orc.encode_frames(cfg, tab, pcm)
+        if len(got) != len(want):
+            raise SystemExit("bench stream %d: %d frames from the GPU, %d from the oracle" % (s, len(got), len(want)))
+        for f in range(len(got)):
+            if bytes(got[f]) != bytes(want[f]):
+                d = struct_diff(want[f], got[f])
+                if d:
+                    raise SystemExit("bench stream %d frame %d differs from the oracle: %r" % (s, f, d[:4]))
+    return {"streams": list(which), "frames_each": len(batch.get_frames(which[0])), "result": "identical"}
+
+
+def short_run(torch, lamehip, dev, device_index, sr, B, seconds, steps, seed, bursts_per_s, **enc_kw):
+    """A small batch of another configuration (extras; never the headline value)."""
+    n = int(seconds * sr)
+    enc = lamehip.Encoder(sr, device=device_index, **enc_kw)
+    b = lamehip.Batch(enc, B, n, device=device_index)
+    pcm = synth_on_device(torch, B, n, sr, seed, dev, bursts_per_s=bursts_per_s)
+    for s in range(B):
+        b.set_pcm_device(s, pcm[s, 0].data_ptr(), pcm[s, 1].data_ptr(), n)
+    del pcm
+    b.encode(sync=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        b.encode(sync=True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert len(b.pack(0)) > 0
+    b.close()
+    enc.close()
+    v = B * seconds * steps / dt
+    return {"value": round(v, 1), "unit": "x real-time", "per_stream_x_realtime": round(v / B, 2),
+            "workload": "batch=%d x %.0f s, %d Hz" % (B, seconds, sr), "steps": steps}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--streams", type=int, default=1024, help="streams per GPU")
+    ap.add_argument("--seconds", type=float, default=60.0, help="audio seconds per stream")
+    ap.add_argument("--samplerate", type=int, default=44100)
+    ap.add_argument("--brate", type=int, default=128)
+    ap.add_argument("--vbr", type=int, default=None, metavar="Q",
+                    help="vbr_mtrh at quality Q (BASELINE config[2] is -V2) instead of CBR; not the default line")
+    ap.add_argument("--abr", type=int, default=None, metavar="KBPS", help="ABR at a mean of KBPS instead of CBR")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the short runs of BASELINE configs [2] and [4]")
+    ap.add_argument("--end-to-end", action="store_true",
+                    help="also time host PCM -> H2D -> kernel -> D2H -> bytes on a 5 s sample; an extra object, "
+                         "never `value`")
+    args = ap.parse_args()
+
+    launched = "WORLD_SIZE" in os.environ
+    if not launched and args.gpus > 1:
+        sys.exit(spawn_ranks(args, sys.argv[1:]))
+
+    import torch
+    import lamehip
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback in the product path)"
+    ndev = torch.cuda.device_count()
+    device_index = local_rank % ndev            # more ranks than devices (a 1-GPU box): they share
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
+    if world == 1:
+        rdv = Alone()
+    elif "LAMEHIP_BENCH_RDV" in os.environ:
+        rdv = FileRendezvous(os.environ["LAMEHIP_BENCH_RDV"], rank, world)
+    else:
+        rdv = GlooRendezvous(rank, world)
+
+    sr, B = args.samplerate, args.streams
+    n = int(args.seconds * sr)
+    lo, hi = lamehip.shard_streams(world * B, world, rank)      # this rank's block of the global batch
+    assert hi - lo == B
+    enc = lamehip.Encoder(sr, args.brate, vbr_q=args.vbr, abr=args.abr, device=device_index)
+    batch = lamehip.Batch(enc, B, n, device=device_index)
+    pcm = synth_on_device(torch, B, n, sr, lo, dev)             # seeds follow the global stream index
+    torch.cuda.synchronize()
+    for s in range(B):
+        batch.set_pcm_device(s, pcm[s, 0].data_ptr(), pcm[s, 1].data_ptr(), n)
+    # host copies for the checks / the CPU leg (rank 0 only): a few whole streams, and the first 20 s of
+    # as many streams as there are physical cores
+    which = sorted(set([0, 1, B // 2, B - 1]))[:CHECKED_STREAMS] if B >= 2 else [0]
+    host_streams, host_cpu = [], None
+    if rank == 0:
+        host_streams = [pcm[s].cpu().numpy() for s in which]
+        if not args.no_cpu_baseline and world == 1:
+            k = min(_physical_cores(), B)
+            host_cpu = pcm[:k, :, :min(n, int(CPU_SAMPLE_SECONDS * sr))].cpu().numpy()
+    del pcm
+    torch.cuda.synchronize()
+    frames = sum(batch.frames(s) for s in range(B))
+
+    def barrier():
+        torch.cuda.synchronize()
+        rdv.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        batch.encode()
+    kernel_ms = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        batch.encode(sync=True)         # (an encoded batch starts over from the initial state by itself)
+        kernel_ms.append(batch.kernel_ms())
+    barrier()
+    dt = rdv.max(time.perf_counter() - t0)
+
+    if rank == 0:
+        checked = check_against_oracle(batch, enc, host_streams, which)
+        assert len(batch.pack(0)) > 0           # and the payload survives the host packer's consistency checks
+        audio_s = world * B * args.seconds * args.steps
+        value = audio_s / dt
+        kavg = sum(kernel_ms) / len(kernel_ms) / 1e3
+        achieved = frames * ALG_BYTES_PER_FRAME / kavg / 1e9
+        pmc = recorded("r02_pmc.json") or {}
+        what = ("ABR%d" % args.abr if args.abr is not None else "CBR128" if args.vbr is None else "VBR -V%d" % args.vbr)
+        res = {
+            "metric": "encoded audio seconds/sec (x real-time) at 44.1kHz stereo " + what,
+            "value": round(value, 1), "unit": "x real-time", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": ("batch=%d synthetic %.1f kHz stereo streams x %.0f s, CBR %d kb/s, "
+                                    "per GPU (BASELINE config[1])" % (B, sr / 1000.0, args.seconds, args.brate))
+                       if args.vbr is None and args.abr is None else
+                       ("batch=%d synthetic %.1f kHz stereo streams x %.0f s, ABR %d kb/s, per GPU"
+                        % (B, sr / 1000.0, args.seconds, args.abr)) if args.abr is not None else
+                       ("batch=%d synthetic %.1f kHz stereo streams x %.0f s, VBR -V%d (vbrquantize.c path), "
+                        "per GPU (BASELINE config[2])" % (B, sr / 1000.0, args.seconds, args.vbr)),
+                       "streams_per_gpu": B, "seconds_per_stream": args.seconds,
+                       "per_stream_x_realtime": round(value / (world * B), 2),
+                       "parallelism": "static sharding: rank r owns the contiguous block shard_streams(N*B, N, r); "
+                                      "no collective, no RCCL",
+                       "ranks": "spawned by bench.py (file barrier)" if "LAMEHIP_BENCH_RDV" in os.environ
+                       else ("launcher (gloo barrier on the CPU)" if world > 1 else "single process"),
+                       "devices_visible": ndev},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+                         "traffic": pmc.get("hbm_bytes_per_launch"),
+                         "traffic_note": ("recorded with rocprofv3 --pmc on %s (commit %s), workload %s; bench.py "
+                                          "does not run the profiler" % (pmc.get("date"), pmc.get("commit"),
+                                                                         pmc.get("workload")))
+                         if pmc else "no recorded PMC profile in profiles/",
+                         "valu_frac": pmc.get("valu_frac"), "issue_active_frac": pmc.get("issue_active_frac"),
+                         "bound_in_practice": "instruction issue of a serial search: one wave issues at most one "
+                                              "instruction per ~5 cycles (tools/ubench/lat2.hip), two waves per stream",
+                         "kernel": "lh_encode_kernel", "kernel_ms_avg": round(kavg * 1e3, 3),
+                         "alg_bytes_per_frame": ALG_BYTES_PER_FRAME, "frames_per_launch": frames},
+            "checked_against_oracle": checked,
+        }
+        if host_cpu is not None:
+            res["cpu_baseline"] = cpu_baseline(host_cpu, sr, args.brate, vbr_q=args.vbr, abr=args.abr)
+        if not args.no_extras and world == 1 and args.vbr is None and args.abr is None:
+            batch.close()
+            batch = None
+            res["extra"] = {
+                "vbr_v2_config2": short_run(torch, lamehip, dev, device_index, 44100, 1024, 5.0, 2, 5000, 3.0, vbr_q=2),
+                "cbr320_48k_bursts_config4": short_run(torch, lamehip, dev, device_index, 48000, 1024, 5.0, 2, 9000,
+                                                       40.0, brate=320, mode=1),
+            }
+        if args.end_to_end and world == 1:
+            res["end_to_end"] = end_to_end(torch, lamehip, enc, B, sr, dev)
+        print(json.dumps(res))
+    rdv.barrier()
+    rdv.close()
 
 
 def end_to_end(torch, lamehip, enc, B, sr, dev, seconds=5.0):
-    """SURVEY.md 8(d) region R2: s16 PCM in host memory -> H2D -> kernel -> D2H -> host bit packing
-    to mp3 bytes in memory, all host cores packing.  A separate, smaller sample (B x 5 s)."""
+    """SURVEY.md 8(d) region R2: s16 PCM in host memory -> H2D -> kernel -> D2H -> mp3 bytes in
+    memory, once with the host packer on all cores and once with the device packer."""
     n = int(seconds * sr)
     host = synth_on_device(torch, B, n, sr, 777, dev).cpu().numpy()
-    threads = min(32, os.cpu_count() or 1)      # measured best on the 256-thread host: 32
+    threads = min(32, os.cpu_count() or 1)
     b = lamehip.Batch(enc, B, n)
     best = None
     for _ in range(2):
-        b.reset()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for s in range(B):
@@ -105,11 +472,9 @@ def end_to_end(torch, lamehip, enc, B, sr, dev, seconds=5.0):
         t2 = time.perf_counter()
         if best is None or t2 - t0 < best[0]:
             best = (t2 - t0, t1 - t0, t2 - t1, int(sizes.sum()))
-    # the same with the bit packer on the device: D2H of finished bytes, no host packing
     stride = (b.frames(0) + 2) * (1500 if enc.config().vbr else 1100)
     dbest = None
     for _ in range(2):
-        b.reset()
         b.set_device_packing()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -128,117 +493,6 @@ def end_to_end(torch, lamehip, enc, B, sr, dev, seconds=5.0):
                               "h2d_plus_kernel_s": round(dbest[1], 3), "d2h_s": round(dbest[2], 3),
                               "mp3_bytes": dbest[3]},
             "sample": "%d streams x %.0f s, host s16 in -> mp3 bytes out" % (B, seconds)}
-
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--streams", type=int, default=1024, help="streams per GPU")
-    ap.add_argument("--seconds", type=float, default=60.0, help="audio seconds per stream")
-    ap.add_argument("--samplerate", type=int, default=44100)
-    ap.add_argument("--brate", type=int, default=128)
-    ap.add_argument("--vbr", type=int, default=None, metavar="Q",
-                    help="vbr_mtrh at quality Q (BASELINE config[2] is -V2) instead of CBR; not the default line")
-    ap.add_argument("--abr", type=int, default=None, metavar="KBPS", help="ABR at a mean of KBPS instead of CBR")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--end-to-end", action="store_true",
-                    help="also time host PCM -> H2D -> kernel -> D2H -> host bit packing (threads) on a "
-                         "5 s sample; reported as an extra object, never as `value`")
-    args = ap.parse_args()
-
-    import torch
-    import torch.distributed as dist
-    import lamehip
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback in the product path)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-
-    sr, B = args.samplerate, args.streams
-    n = int(args.seconds * sr)
-    enc = lamehip.Encoder(sr, args.brate, vbr_q=args.vbr, abr=args.abr)
-    batch = lamehip.Batch(enc, B, n)
-    # static sharding: rank r owns global streams [r*B, (r+1)*B); seeds follow the global index
-    pcm = synth_on_device(torch, B, n, sr, rank * B, dev)
-    torch.cuda.synchronize()
-    for s in range(B):
-        batch.set_pcm_device(s, pcm[s, 0].data_ptr(), pcm[s, 1].data_ptr(), n)
-    del pcm
-    torch.cuda.synchronize()
-    frames = sum(batch.frames(s) for s in range(B))
-
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        batch.reset()
-        batch.encode()
-    kernel_ms = []
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        batch.reset()
-        batch.encode(sync=True)
-        kernel_ms.append(batch.kernel_ms())
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-
-    # sanity outside the timed region: the payload must survive the host packer's checks
-    nbytes = len(batch.pack(0))
-    assert nbytes > 0
-
-    if rank == 0:
-        audio_s = world * B * args.seconds * args.steps
-        value = audio_s / dt
-        kavg = sum(kernel_ms) / len(kernel_ms) / 1e3
-        achieved = frames * ALG_BYTES_PER_FRAME / kavg / 1e9
-        res = {
-            "metric": "encoded audio seconds/sec (x real-time) at 44.1kHz stereo "
-                      + ("ABR%d" % args.abr if args.abr is not None else "CBR128" if args.vbr is None
-                         else "VBR -V%d" % args.vbr),
-            "value": round(value, 1), "unit": "x real-time", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": ("batch=%d synthetic %.1f kHz stereo streams x %.0f s, CBR %d kb/s, "
-                                    "per GPU (BASELINE config[1])" % (B, sr / 1000.0, args.seconds, args.brate))
-                       if args.vbr is None and args.abr is None else
-                       ("batch=%d synthetic %.1f kHz stereo streams x %.0f s, ABR %d kb/s, per GPU"
-                        % (B, sr / 1000.0, args.seconds, args.abr)) if args.abr is not None else
-                       ("batch=%d synthetic %.1f kHz stereo streams x %.0f s, VBR -V%d (vbrquantize.c path), "
-                        "per GPU (BASELINE config[2])" % (B, sr / 1000.0, args.seconds, args.vbr)),
-                       "streams_per_gpu": B, "seconds_per_stream": args.seconds,
-                       "per_stream_x_realtime": round(value / (world * B), 2),
-                       "parallelism": "static stream sharding, no collective"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
-                         "traffic_note": "not collected here (needs rocprofv3 --pmc passes); offline measurement on the "
-                                         "1024 x 5 s workload: profiles/r01_traffic.json, DESIGN.md section 4",
-                         "kernel": "lh_encode_kernel", "kernel_ms_avg": round(kavg * 1e3, 3),
-                         "alg_bytes_per_frame": ALG_BYTES_PER_FRAME, "frames_per_launch": frames},
-        }
-        if not args.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline(sr, args.brate, vbr_q=args.vbr, abr=args.abr)
-        if args.end_to_end and world == 1:
-            res["end_to_end"] = end_to_end(torch, lamehip, enc, B, sr, dev)
-        print(json.dumps(res))
-    if world > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -76,8 +76,25 @@ struct LhDeviceConst {
     }
 };
 
+/* Every handle and batch belongs to one HIP device: the one that was current when it was set up, or
+ * the one named by lamehip_set_device / lamehip_batch_create_on.  Entry points that touch the device
+ * make it current for the duration of the call and put the caller's device back afterwards. */
+struct LhDeviceScope {
+    int     prev = -1, mine = -1;
+    explicit LhDeviceScope(int dev) {
+        if (dev >= 0 && hipGetDevice(&prev) == hipSuccess && prev != dev && hipSetDevice(dev) == hipSuccess)
+            mine = dev;
+    }
+    ~LhDeviceScope() {
+        if (mine >= 0)
+            (void) hipSetDevice(prev);
+    }
+};
+
 struct lame_global_struct {
     unsigned class_id;
+    int     device;             /* -1 until lame_init_params or lamehip_set_device fixes it */
+    int     init_rc;            /* what lame_init_params returned */
     LhUserParams p;
     int     out_samplerate;
     int     write_vbr_tag;
@@ -131,6 +148,8 @@ lame_init(void)
     if (!g)
         return nullptr;
     g->class_id = LAME_ID;
+    g->device = -1;
+    g->init_rc = 0;
     lh_params_default(&g->p);
     g->out_samplerate = 0;
     g->num_samples = 0xFFFFFFFFul;       /* MAX_U_32_NUM, reference lame.c:2336 */
@@ -499,14 +518,26 @@ lame_bitrate_block_type_hist(const lame_t g, int bitrate_btype_count[14][6])
 }
 GETTER(lame_get_version, g->inited ? g->cfg.version : 1, int)
 
+static int init_params_once(lame_t g);
+
 extern "C" int
 lame_init_params(lame_t g)
 {
-    LhInitAux aux;
+    int     rc;
     if (!valid(g))
         return -1;
     if (g->inited)
-        return 0;
+        return g->init_rc;      /* a second call reports what the first one found (also its failure) */
+    rc = init_params_once(g);
+    if (g->inited)
+        g->init_rc = rc;
+    return rc;
+}
+
+static int
+init_params_once(lame_t g)
+{
+    LhInitAux aux;
     g->p.samplerate_out = g->out_samplerate;
     if (g->preset_vbr && g->p.vbr != 1 && g->p.vbr != 4) {
         snprintf(g_err, sizeof(g_err), "a V0..V9 preset without lame_set_VBR(vbr_mtrh / vbr_mt) is outside the accelerated path");
@@ -545,7 +576,14 @@ lame_init_params(lame_t g)
         g->have_device = 0;
         return LAMEHIP_ERR_NODEVICE;
     }
+    if (g->device < 0 && hipGetDevice(&g->device) != hipSuccess)
+        g->device = 0;
+    if (g->device >= lamehip_device_count()) {
+        snprintf(g_err, sizeof(g_err), "lamehip_set_device: no HIP device %d", g->device);
+        return LAMEHIP_ERR_NODEVICE;
+    }
     {
+        LhDeviceScope const on_device(g->device);
         int     rc = g->dc.upload(g->cfg, *g->tab);
         LhStreamState s0;
         if (rc)
@@ -699,6 +737,7 @@ template < typename T > static int
 encode_buffer_any(lame_t g, const T * l, const T * r, int nsamples, int jump, float norm, unsigned char *mp3buf,
                   int mp3buf_size)
 {
+    LhDeviceScope const on_device(valid(g) ? g->device : -1);
     int     written = 0, rc, avail;
     if (!valid(g) || !g->inited)
         return -3;
@@ -880,6 +919,7 @@ flush_resampled(lame_t g, unsigned char *mp3buf, int size)
 extern "C" int
 lame_encode_flush(lame_t g, unsigned char *mp3buf, int size)
 {
+    LhDeviceScope const on_device(valid(g) ? g->device : -1);
     int     written = 0, rc, total;
     if (!valid(g) || !g->inited)
         return -3;
@@ -930,6 +970,7 @@ finish_stream(lame_t g, unsigned char *mp3buf, int size, int written)
 extern "C" int
 lame_encode_flush_nogap(lame_t g, unsigned char *mp3buf, int size)
 {
+    LhDeviceScope const on_device(valid(g) ? g->device : -1);
     int     was, k;
     if (!valid(g) || !g->inited)
         return -3;
@@ -977,6 +1018,7 @@ lame_get_lametag_frame(const lame_t g, unsigned char *buffer, size_t size)
 extern "C" int
 lame_close(lame_t g)
 {
+    LhDeviceScope const on_device(valid(g) ? g->device : -1);
     if (!valid(g))
         return -3;
     g->class_id = 0;
@@ -1063,6 +1105,7 @@ lamehip_get_tables(const lame_t g, void *out, int size)
 /* batch extension                                                          */
 
 struct lamehip_batch {
+    int     device;
     LhConfig cfg;
     LhTables *tab;
     LhDeviceConst dc;
@@ -1112,10 +1155,38 @@ batch_reset_states(lamehip_batch * b)
     return 0;
 }
 
+/* the handle's device for its own launches; call before lame_init_params (reference: none -- the
+ * reference has no devices; the frontend's handle simply lives on the current device by default) */
+extern "C" int
+lamehip_set_device(lame_t g, int device)
+{
+    if (!valid(g) || g->inited || device < 0)
+        return -1;
+    g->device = device;
+    return 0;
+}
+
 extern "C" lamehip_batch *
 lamehip_batch_create(const lame_t proto, int nstreams, long capacity_samples)
 {
+    int     dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess)
+        dev = 0;
+    return lamehip_batch_create_on(dev, proto, nstreams, capacity_samples);
+}
+
+/* a batch on HIP device `device' (its pools, state, stream and launches live there whatever device
+ * is current in the calling thread); the handle only provides the settings and may belong to
+ * another device */
+extern "C" lamehip_batch *
+lamehip_batch_create_on(int device, const lame_t proto, int nstreams, long capacity_samples)
+{
     lamehip_batch *b;
+    if (device < 0 || device >= lamehip_device_count()) {
+        snprintf(g_err, sizeof(g_err), "lamehip_batch_create_on: no HIP device %d", device);
+        return nullptr;
+    }
+    LhDeviceScope const on_device(device);
     if (!valid(proto) || !proto->inited || !proto->have_device || nstreams <= 0
         || capacity_samples <= 0) {
         snprintf(g_err, sizeof(g_err), "lamehip_batch_create: need an initialised handle on a HIP device");
@@ -1124,8 +1195,13 @@ lamehip_batch_create(const lame_t proto, int nstreams, long capacity_samples)
     b = new(std::nothrow) lamehip_batch();
     if (!b)
         return nullptr;
+    b->device = device;
     b->cfg = proto->cfg;
     b->tab = (LhTables *) malloc(sizeof(LhTables));
+    if (!b->tab) {
+        delete  b;
+        return nullptr;
+    }
     memcpy(b->tab, proto->tab, sizeof(LhTables));
     b->B = nstreams;
     b->cap = capacity_samples;
@@ -1179,6 +1255,7 @@ lamehip_batch_create(const lame_t proto, int nstreams, long capacity_samples)
 extern "C" void
 lamehip_batch_destroy(lamehip_batch * b)
 {
+    LhDeviceScope const on_device(b ? b->device : -1);
     if (!b)
         return;
     if (b->d_pcm)
@@ -1295,6 +1372,7 @@ batch_convert_stream(lamehip_batch * b, int s, const short *l, const short *r, l
 extern "C" int
 lamehip_batch_set_pcm(lamehip_batch * b, int s, const short *l, const short *r, long n)
 {
+    LhDeviceScope const on_device(b ? b->device : -1);
     if (b && b->rate_in) {
         if (s < 0 || s >= b->B || n < 0)
             return -1;
@@ -1314,6 +1392,7 @@ lamehip_batch_set_pcm(lamehip_batch * b, int s, const short *l, const short *r, 
 extern "C" int
 lamehip_batch_set_pcm_device(lamehip_batch * b, int s, const void *dl, const void *dr, long n)
 {
+    LhDeviceScope const on_device(b ? b->device : -1);
     if (lamehip_batch_set_length(b, s, n) != 0)
         return -1;
     if (b->cfg.channels == 1 && b->cfg.pcm_mix == 0.0f)
@@ -1340,6 +1419,7 @@ lamehip_batch_frames(lamehip_batch * b, int s)
 extern "C" int
 lamehip_batch_reset(lamehip_batch * b)
 {
+    LhDeviceScope const on_device(b ? b->device : -1);
     if (!b)
         return -1;
     return batch_reset_states(b);
@@ -1348,10 +1428,15 @@ lamehip_batch_reset(lamehip_batch * b)
 extern "C" int
 lamehip_batch_encode(lamehip_batch * b)
 {
+    LhDeviceScope const on_device(b ? b->device : -1);
     long long total = 0, bytes_total = 0;
     int     max_frame_bytes;
     if (!b)
         return -1;
+    /* a batch that has been encoded starts over: every call encodes the streams from their first
+     * sample, so the carried state must be the initial one */
+    if (b->encoded && batch_reset_states(b) != 0)
+        return LAMEHIP_ERR_DEVICE;
     {
         int const top = (b->cfg.vbr == 0) ? b->cfg.bitrate_index : b->cfg.vbr_max_bitrate_index;
         static const int kbps[16] = { 0, 32, 40, 48, 56, 64, 80, 96, 112, 128, 160, 192, 224, 256, 320, 0 };
@@ -1419,6 +1504,7 @@ lamehip_batch_set_device_packing(lamehip_batch * b, int on)
 extern "C" long
 lamehip_batch_get_bytes(lamehip_batch * b, int s, unsigned char *out, long out_size)
 {
+    LhDeviceScope const on_device(b ? b->device : -1);
     LhStreamState st;
     long    n;
     if (!b || s < 0 || s >= b->B || !b->encoded || !b->dev_pack)
@@ -1481,6 +1567,7 @@ lamehip_batch_get_bytes_tagged(lamehip_batch * b, int s, unsigned char *out, lon
 extern "C" int
 lamehip_batch_get_bytes_all(lamehip_batch * b, unsigned char *out, long out_stride, long *sizes)
 {
+    LhDeviceScope const on_device(b ? b->device : -1);
     std::vector < LhStreamState > st;
     int     bad = 0;
     if (!b || !b->encoded || !b->dev_pack || !out || !sizes)
@@ -1508,6 +1595,7 @@ lamehip_batch_get_bytes_all(lamehip_batch * b, unsigned char *out, long out_stri
 extern "C" int
 lamehip_batch_sync(lamehip_batch * b)
 {
+    LhDeviceScope const on_device(b ? b->device : -1);
     if (!b)
         return -1;
     HIPCHK(hipStreamSynchronize(b->stream));
@@ -1528,6 +1616,7 @@ lamehip_batch_last_kernel_ms(lamehip_batch * b)
 extern "C" int
 lamehip_batch_get_frames(lamehip_batch * b, int s, void *frames_out, int max_frames)
 {
+    LhDeviceScope const on_device(b ? b->device : -1);
     int     n;
     if (!b || s < 0 || s >= b->B || !b->encoded)
         return -1;
@@ -1555,6 +1644,7 @@ lamehip_debug_poison(unsigned pattern)
 extern "C" int
 lamehip_get_state(const lame_t g, void *out, int size)
 {
+    LhDeviceScope const on_device(valid(g) ? g->device : -1);
     if (!g || !g->have_device || size < (int) sizeof(LhStreamState))
         return -1;
     HIPCHK(hipStreamSynchronize(g->stream));
@@ -1566,6 +1656,7 @@ lamehip_get_state(const lame_t g, void *out, int size)
 extern "C" int
 lamehip_batch_get_state(lamehip_batch * b, int s, void *out, int size)
 {
+    LhDeviceScope const on_device(b ? b->device : -1);
     if (!b || s < 0 || s >= b->B || size < (int) sizeof(LhStreamState))
         return -1;
     HIPCHK(hipStreamSynchronize(b->stream));
@@ -1664,6 +1755,7 @@ lamehip_batch_pack_tagged(lamehip_batch * b, int s, unsigned char *out, long out
 extern "C" int
 lamehip_batch_pack_all(lamehip_batch * b, int nthreads, unsigned char *out, long out_stride, long *sizes)
 {
+    LhDeviceScope const on_device(b ? b->device : -1);
     int     dev = 0, maxf = 0;
     std::atomic < int >failed(0);
     if (!b || !b->encoded || !out || !sizes || out_stride <= 0)

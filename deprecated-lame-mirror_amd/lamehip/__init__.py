@@ -47,6 +47,9 @@ def load_library():
     lib.lamehip_get_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     lib.lamehip_batch_create.restype = C.c_void_p
     lib.lamehip_batch_create.argtypes = [C.c_void_p, C.c_int, C.c_long]
+    lib.lamehip_batch_create_on.restype = C.c_void_p
+    lib.lamehip_batch_create_on.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_long]
+    lib.lamehip_set_device.argtypes = [C.c_void_p, C.c_int]
     lib.lamehip_batch_destroy.argtypes = [C.c_void_p]
     lib.lamehip_batch_set_pcm.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_long]
     lib.lamehip_batch_set_pcm_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_long]
@@ -76,9 +79,11 @@ class Encoder:
     """One stream behind the lame.h call sequence."""
 
     def __init__(self, samplerate=44100, brate=128, mode=None, quality=None, require_device=True, write_tag=False,
-                 vbr_q=None, out_samplerate=0, abr=None, channels=2):
+                 vbr_q=None, out_samplerate=0, abr=None, channels=2, device=None):
         self.lib = load_library()
         self.h = C.c_void_p(self.lib.lame_init())
+        if device is not None:      # HIP device of the handle's own launches (lamehip_set_device)
+            self.lib.lamehip_set_device(self.h, int(device))
         self.lib.lame_set_in_samplerate(self.h, samplerate)
         if out_samplerate:
             self.lib.lame_set_out_samplerate(self.h, out_samplerate)
@@ -153,12 +158,17 @@ class Encoder:
 class Batch:
     """B independent streams with common settings, encoded by one kernel launch."""
 
-    def __init__(self, enc, nstreams, capacity):
+    def __init__(self, enc, nstreams, capacity, device=None):
+        """device: HIP device index the batch lives on (lamehip_batch_create_on); None = the calling
+        thread's current device."""
         self.lib = enc.lib
         self.enc = enc
         self.n = nstreams
         self.capacity = capacity
-        self.b = C.c_void_p(self.lib.lamehip_batch_create(enc.h, nstreams, capacity))
+        if device is None:
+            self.b = C.c_void_p(self.lib.lamehip_batch_create(enc.h, nstreams, capacity))
+        else:
+            self.b = C.c_void_p(self.lib.lamehip_batch_create_on(int(device), enc.h, nstreams, capacity))
         if not self.b:
             raise RuntimeError("lamehip_batch_create failed: %s" % last_error())
 
@@ -290,3 +300,15 @@ class Batch:
             self.close()
         except Exception:
             pass
+
+
+def shard_streams(total_streams, world_size, rank):
+    """Static sharding of a batch of independent streams over the GPUs of a node:
+    rank r of world_size owns the contiguous block [lo, hi) of global stream indices; blocks differ
+    by at most one stream and cover the batch exactly.  No collective is involved anywhere on the
+    data path -- a stream's state never leaves its device."""
+    if world_size <= 0 or not (0 <= rank < world_size) or total_streams < 0:
+        raise ValueError("shard_streams(%r, %r, %r)" % (total_streams, world_size, rank))
+    base, extra = divmod(total_streams, world_size)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)

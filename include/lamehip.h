@@ -161,6 +161,14 @@ typedef struct lamehip_batch lamehip_batch;
 /* B independent streams that share the settings of `proto' (which must have
  * passed lame_init_params); capacity = samples per channel per stream. */
 lamehip_batch *lamehip_batch_create(const lame_t proto, int nstreams, long capacity_samples);
+/* the same on HIP device `device' (0 .. lamehip_device_count() - 1) instead of the calling thread's
+ * current one.  A batch keeps its device: every later call on it runs there and leaves the
+ * caller's current device as it was.  This is what one host thread per GPU uses to shard a batch
+ * of independent streams over the GPUs of a node (no inter-device traffic). */
+lamehip_batch *lamehip_batch_create_on(int device, const lame_t proto, int nstreams, long capacity_samples);
+/* device of a handle's own (per-frame) launches; before lame_init_params.  Default: the device
+ * that is current when lame_init_params runs. */
+int     lamehip_set_device(lame_t, int device);
 void    lamehip_batch_destroy(lamehip_batch *);
 /* copy one stream's planar s16 PCM host -> HBM (H2D, synchronous).  When proto's input rate differs from
  * its output rate the stream is converted on the host first, exactly as the reference converts it when

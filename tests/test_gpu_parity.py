@@ -3,6 +3,7 @@ C ABI of liblamehip.so; the checkers are the committed golden vectors, the CPU
 oracle and -- when it travelled with the tree -- the compiled reference."""
 import ctypes as C
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -542,5 +543,53 @@ def test_device_bit_packer_long_streams(kw):
     b.encode()
     for i in range(len(pcms)):
         assert b.get_bytes(i) == b.pack(i)
+    b.close()
+    enc.close()
+
+
+@pytest.mark.gpu
+def test_bench_spawns_its_own_ranks():
+    """python bench.py --gpus 2 without a launcher: two ranks (sharing this box's device when it has
+    one), a file barrier, ONE JSON line with the aggregate of both."""
+    import json
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(helpers.ROOT, "bench.py"), "--gpus", "2", "--streams", "16",
+                          "--seconds", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-extras"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900,
+                         env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["config"]["streams_per_gpu"] == 16
+    assert res["checked_against_oracle"]["result"] == "identical"
+
+
+@pytest.mark.gpu
+def test_batch_on_named_device_and_reuse():
+    """lamehip_batch_create_on + a batch encoded twice with different PCM equals fresh batches (the
+    carried state starts over by itself)."""
+    g, pcm = helpers.load_golden("cbr128_js_44k")
+    enc = lamehip.Encoder(require_device=True, device=0, **helpers.golden_encoder_kwargs(g))
+    n = pcm.shape[1]
+    other = helpers.synth_stream(4242, n)
+    b = lamehip.Batch(enc, 2, n, device=0)
+    fresh = []
+    for x in (pcm, other):
+        f = lamehip.Batch(enc, 1, n)
+        f.set_pcm(0, x[0], x[1])
+        f.encode(sync=True)
+        fresh.append(f.pack(0))
+        f.close()
+    b.set_pcm(0, pcm[0], pcm[1])
+    b.set_pcm(1, other[0], other[1])
+    b.encode(sync=True)
+    assert b.pack(0) == fresh[0] and b.pack(1) == fresh[1]
+    b.set_pcm(0, other[0], other[1])
+    b.set_pcm(1, pcm[0], pcm[1])
+    b.encode(sync=True)             # no reset() in between
+    assert b.pack(0) == fresh[1] and b.pack(1) == fresh[0]
+    assert fresh[0] == g["mp3"].tobytes()
     b.close()
     enc.close()

@@ -1,7 +1,7 @@
-"""N>1 path on CPU: two gloo ranks shard a batch of independent streams
-statically (no data-path collective), each encodes its shard with the CPU checker
-standing in for the device, and the gathered per-stream digests equal a
-single-process run -- the same partition function bench.py uses per rank."""
+"""N>1 path on CPU: two gloo ranks take their blocks of a batch of independent streams from the
+package's partition function (lamehip.shard_streams, the one bench.py calls per rank), each
+encodes its block with the CPU checker standing in for the device (no data-path collective), and
+the gathered per-stream digests equal a single-process run."""
 import hashlib
 import os
 import subprocess
@@ -16,12 +16,12 @@ import torch, torch.distributed as dist
 import helpers, lamehip
 dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
 rank, world = dist.get_rank(), dist.get_world_size()
-B = 6                                   # global batch; rank r owns streams [r*B/world, (r+1)*B/world)
-per = B // world
+B = 7                                   # global batch (odd on purpose: blocks of 4 and 3)
+lo, hi = lamehip.shard_streams(B, world, rank)
 enc = lamehip.Encoder(44100, 128, require_device=False)
 orc = helpers.Oracle()
 mine = {}
-for s in range(rank * per, (rank + 1) * per):
+for s in range(lo, hi):
     pcm = helpers.synth_stream(1000 + s, 4000)
     fr = orc.encode_frames(enc.config(), enc.tables(), pcm)
     mine[s] = hashlib.sha256(b"".join(bytes(f) for f in fr)).hexdigest()
@@ -52,7 +52,20 @@ def test_two_rank_static_sharding_equals_single_process(tmp_path, oracle):
     assert len(digest) == 1
     enc = lamehip.Encoder(44100, 128, require_device=False)
     single = ""
-    for s in range(6):
+    for s in range(7):
         fr = oracle.encode_frames(enc.config(), enc.tables(), helpers.synth_stream(1000 + s, 4000))
         single += hashlib.sha256(b"".join(bytes(f) for f in fr)).hexdigest()
     assert hashlib.sha256(single.encode()).hexdigest() == digest[0]
+
+
+def test_shard_streams_partitions_exactly():
+    import lamehip
+    for total in (0, 1, 5, 1024, 8192, 8191):
+        for world in (1, 2, 3, 8):
+            blocks = [lamehip.shard_streams(total, world, r) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == total
+            for (a, b), (c, d) in zip(blocks, blocks[1:]):
+                assert b == c and a <= b
+            sizes = [b - a for a, b in blocks]
+            assert max(sizes) - min(sizes) <= 1
+    assert lamehip.shard_streams(8192, 8, 3) == (3072, 4096)       # BASELINE config[3]: 1024 per GPU
