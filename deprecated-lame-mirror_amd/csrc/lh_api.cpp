@@ -9,6 +9,7 @@
  */
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdarg.h>
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
@@ -25,7 +26,6 @@ extern "C" int lh_launch_encode(const LhConfig * cfg, const LhTables * T, const 
                                 LhFrameOut * out, uint8_t * bytes, int nstreams, void *stream);
 
 extern "C" int lh_launch_selftest(unsigned *d_out, unsigned seed, void *stream);
-extern "C" int lh_launch_poison(unsigned pattern, void *stream);
 
 #define LAME_ID 0xFFF88E3Bu     /* reference util.h:482 */
 
@@ -95,6 +95,9 @@ struct lame_global_struct {
     unsigned class_id;
     int     device;             /* -1 until lame_init_params or lamehip_set_device fixes it */
     int     init_rc;            /* what lame_init_params returned */
+    /* message callbacks (reference lame.h:346-348, util.c:707-760): errors of this library's calls on the
+     * handle go to report_err; nullptr silences them */
+    lame_report_function report_err, report_dbg, report_msg;
     LhUserParams p;
     int     out_samplerate;
     int     write_vbr_tag;
@@ -141,6 +144,61 @@ valid(const lame_t g)
     return g && g->class_id == LAME_ID;
 }
 
+/* the reference's default message sink (util.c:707-716) */
+static void
+report_to_stderr(const char *format, va_list ap)
+{
+    (void) vfprintf(stderr, format, ap);
+    fflush(stderr);
+}
+
+static void
+report_through(lame_report_function f, const char *format, ...)
+{
+    va_list ap;
+    if (!f)
+        return;
+    va_start(ap, format);
+    f(format, ap);
+    va_end(ap);
+}
+
+/* a failed call on a handle: what lamehip_last_error() holds also goes to the handle's errorf */
+static int
+report_failure(lame_t g, int rc)
+{
+    if (rc < 0 && g && g_err[0])
+        report_through(g->report_err, "lamehip: %s\n", g_err);
+    return rc;
+}
+
+extern "C" int
+lame_set_errorf(lame_t g, lame_report_function f)
+{
+    if (!valid(g))
+        return -1;
+    g->report_err = f;
+    return 0;
+}
+
+extern "C" int
+lame_set_debugf(lame_t g, lame_report_function f)
+{
+    if (!valid(g))
+        return -1;
+    g->report_dbg = f;
+    return 0;
+}
+
+extern "C" int
+lame_set_msgf(lame_t g, lame_report_function f)
+{
+    if (!valid(g))
+        return -1;
+    g->report_msg = f;
+    return 0;
+}
+
 extern "C" lame_t
 lame_init(void)
 {
@@ -150,6 +208,7 @@ lame_init(void)
     g->class_id = LAME_ID;
     g->device = -1;
     g->init_rc = 0;
+    g->report_err = g->report_dbg = g->report_msg = report_to_stderr;
     lh_params_default(&g->p);
     g->out_samplerate = 0;
     g->num_samples = 0xFFFFFFFFul;       /* MAX_U_32_NUM, reference lame.c:2336 */
@@ -531,7 +590,7 @@ lame_init_params(lame_t g)
     rc = init_params_once(g);
     if (g->inited)
         g->init_rc = rc;
-    return rc;
+    return report_failure(g, rc);
 }
 
 static int
@@ -733,9 +792,20 @@ handle_encode_frames(lame_t g, int upto, unsigned char *mp3buf, int mp3buf_size,
 /* lame_encode_buffer_template + lame_copy_inbuffer (reference lame.c:1786-1872): samples of any
  * type become sample_t through the transform matrix scaled by the type's norm; the frames that
  * became complete are encoded */
+template < typename T > static int encode_buffer_impl(lame_t g, const T * l, const T * r, int nsamples, int jump,
+                                                      float norm, unsigned char *mp3buf, int mp3buf_size);
+
 template < typename T > static int
 encode_buffer_any(lame_t g, const T * l, const T * r, int nsamples, int jump, float norm, unsigned char *mp3buf,
                   int mp3buf_size)
+{
+    g_err[0] = 0;
+    return report_failure(g, encode_buffer_impl(g, l, r, nsamples, jump, norm, mp3buf, mp3buf_size));
+}
+
+template < typename T > static int
+encode_buffer_impl(lame_t g, const T * l, const T * r, int nsamples, int jump, float norm, unsigned char *mp3buf,
+                   int mp3buf_size)
 {
     LhDeviceScope const on_device(valid(g) ? g->device : -1);
     int     written = 0, rc, avail;
@@ -1629,16 +1699,6 @@ lamehip_batch_get_frames(lamehip_batch * b, int s, void *frames_out, int max_fra
     return n;
 }
 
-/* test aid: fill registers, LDS and scratch of the whole device with a garbage pattern */
-extern "C" int
-lamehip_debug_poison(unsigned pattern)
-{
-    int     rc = lh_launch_poison(pattern, nullptr);
-    if (rc)
-        return set_err("poison launch", (hipError_t) rc);
-    HIPCHK(hipDeviceSynchronize());
-    return 0;
-}
 
 /* debug aid: raw LhStreamState carried by a single-stream handle between launches */
 extern "C" int

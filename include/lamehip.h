@@ -21,6 +21,7 @@
 
 #include <stdint.h>
 #include <stddef.h>
+#include <stdarg.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -118,6 +119,13 @@ void    lame_stereo_mode_hist(const lame_t, int stereo_mode_count[4]);
 void    lame_bitrate_stereo_mode_hist(const lame_t, int bitrate_stmode_count[14][4]);
 void    lame_block_type_hist(const lame_t, int btype_count[6]);
 void    lame_bitrate_block_type_hist(const lame_t, int bitrate_btype_count[14][6]);
+/* message callbacks (lame.h:346-348): a failed call on the handle hands its explanation -- the text
+ * lamehip_last_error() returns -- to errorf; the default prints to stderr like the reference's,
+ * NULL silences.  debugf / msgf are stored for the frontend's sake (this library is quiet). */
+typedef void (*lame_report_function)(const char *format, va_list ap);
+int     lame_set_errorf(lame_t, lame_report_function);                   /* lame.h:346 */
+int     lame_set_debugf(lame_t, lame_report_function);                   /* lame.h:347 */
+int     lame_set_msgf(lame_t, lame_report_function);                     /* lame.h:348 */
 int     lame_get_version(const lame_t);                              /* lame.h:568 */
 
 /* return: bytes written to mp3buf (may be 0); -1 mp3buf too small; -2 alloc;
@@ -208,7 +216,6 @@ long    lamehip_batch_get_bytes_tagged(lamehip_batch *, int stream, unsigned cha
 int     lamehip_batch_get_frames(lamehip_batch *, int stream, void *frames_out, int max_frames);
 /* debug aid: raw per-stream carried state (LhStreamState, csrc/lh_device.h) */
 int     lamehip_batch_get_state(lamehip_batch *, int stream, void *out, int size);
-int     lamehip_debug_poison(unsigned pattern);   /* test aid: garbage in all VGPRs/LDS/scratch of the device */
 int     lamehip_get_state(const lame_t, void *out, int size);   /* same for a single-stream handle */
 /* elapsed GPU time of the last lamehip_batch_encode in ms (HIP events on the batch stream) */
 float   lamehip_batch_last_kernel_ms(lamehip_batch *);

@@ -52,3 +52,29 @@ def test_encode_before_init_params_is_minus_3():
     z = (C.c_short * 1152)()
     assert lib.lame_encode_buffer(h, z, z, 1152, buf, 8192) == -3   # reference lame.h:687-692
     lib.lame_close(h)
+
+
+def test_error_callback_receives_failures():
+    """lame_set_errorf (reference lame.h:346): a failed call on the handle reports through the
+    callback; NULL silences; the handle keeps reporting the first lame_init_params result."""
+    import ctypes as C
+    import lamehip
+    lib = lamehip.load_library()
+    seen = []
+    CB = C.CFUNCTYPE(None, C.c_char_p, C.c_void_p)
+    cb = CB(lambda fmt, ap: seen.append(fmt))
+    lib.lame_set_errorf.argtypes = [C.c_void_p, CB]
+    h = C.c_void_p(lib.lame_init())
+    assert lib.lame_set_errorf(h, cb) == 0
+    lib.lame_set_in_samplerate(h, 16000)        # MPEG-2 output rate: outside this path
+    lib.lame_set_brate(h, 64)
+    rc = lib.lame_init_params(h)
+    assert rc < 0 and len(seen) == 1 and seen[0] == b"lamehip: %s\n"
+    assert b"unsupported" in lib.lamehip_last_error()
+    lib.lame_close(h)
+    h = C.c_void_p(lib.lame_init())
+    lib.lame_set_errorf.argtypes = [C.c_void_p, C.c_void_p]
+    assert lib.lame_set_errorf(h, None) == 0
+    lib.lame_set_in_samplerate(h, 16000)
+    assert lib.lame_init_params(h) < 0 and len(seen) == 1
+    lib.lame_close(h)

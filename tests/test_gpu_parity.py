@@ -12,6 +12,12 @@ import helpers
 import lamehip
 from lamehip.types import struct_diff
 
+
+def _poison_tool():
+    """tests/gpu_tools/liblamehip_testtools.so (built by __graft_entry__.build()): garbage in every VGPR,
+    in LDS and in scratch memory of the device."""
+    return C.CDLL(os.path.join(helpers.ROOT, "tests", "gpu_tools", "liblamehip_testtools.so"))
+
 pytestmark = pytest.mark.gpu
 
 
@@ -159,7 +165,7 @@ def test_full_batch_size_properties():
 @pytest.mark.parametrize("name", ["testcase_wav_cbr128", "cbr320_js_48k_bursts", "cbr128_js_44k_q0"])
 def test_no_dependence_on_uninitialised_device_state(name):
     """Registers, LDS and scratch memory are not cleared between kernels.  Fill all of them
-    with garbage (lamehip_debug_poison) before every launch: the payload must still be the
+    with garbage (the poison tool of tests/gpu_tools) before every launch: the payload must still be the
     reference's, frame by frame, on the batch path and on the one-launch-per-call path."""
     g, pcm = helpers.load_golden(name)
     enc = _encoder(g)
@@ -168,7 +174,7 @@ def test_no_dependence_on_uninitialised_device_state(name):
     for pattern in (0xA5A5A580, 0xFFFFFFFF):
         b = lamehip.Batch(enc, 1, pcm.shape[1] + 16)
         b.set_pcm(0, pcm[0], pcm[1])
-        assert lib.lamehip_debug_poison(C.c_uint(pattern)) == 0
+        assert _poison_tool().lamehip_test_poison(C.c_uint(pattern)) == 0
         b.encode()
         frames = b.get_frames(0)
         helpers.normalize_tables(frames)
@@ -180,7 +186,7 @@ def test_no_dependence_on_uninitialised_device_state(name):
     out = b""
     n = min(pcm.shape[1], 1152 * 40)
     for i in range(0, n, 1152):
-        assert lib.lamehip_debug_poison(C.c_uint(0xA5A5A580 + i)) == 0
+        assert _poison_tool().lamehip_test_poison(C.c_uint(0xA5A5A580 + i)) == 0
         out += enc.encode(pcm[0][i:min(n, i + 1152)], pcm[1][i:min(n, i + 1152)])
     ref = g["mp3"].tobytes()
     assert len(out) > 0 and out == ref[:len(out)]
