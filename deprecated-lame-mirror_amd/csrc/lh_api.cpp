@@ -26,6 +26,8 @@ extern "C" int lh_launch_encode(const LhConfig * cfg, const LhTables * T, const 
                                 LhFrameOut * out, uint8_t * bytes, int nstreams, void *stream);
 
 extern "C" int lh_launch_selftest(unsigned *d_out, unsigned seed, void *stream);
+extern "C" int lh_launch_scatter(const int16_t * stage, long stage_stride, int16_t * pool, long cap, const int *meta,
+                                 int nstreams, void *stream);
 
 #define LAME_ID 0xFFF88E3Bu     /* reference util.h:482 */
 
@@ -1206,6 +1208,20 @@ struct lamehip_batch {
     float  *d_pcmf;             /* [B][2][capf] */
     long    capf;
     std::vector < int >padding; /* encoder_padding per stream (tag frame) */
+    /* incremental use (lamehip_batch_append ...): samples in the pool / frames encoded per stream, a
+     * packer and the bytes not yet drained per stream, and the pinned staging area of the next
+     * lamehip_batch_encode_available: [descriptors][meta][rows], mirrored in HBM by one copy */
+    int     incremental;
+    std::vector < long >fed;
+    std::vector < int >done;
+    std::vector < int >staged;
+    std::vector < LhBitstream > packer;
+    std::vector < std::vector < unsigned char > >pending;
+    std::vector < LhFrameOut > last;
+    std::vector < char >have_last;
+    unsigned char *h_stage, *d_stage;
+    long    stage_rows_at, stage_stride, stage_bytes;
+    std::vector < LhFrameOut > h_new;
 };
 
 static int
@@ -1295,6 +1311,9 @@ lamehip_batch_create_on(int device, const lame_t proto, int nstreams, long capac
     b->d_pcmf = nullptr;
     b->capf = 0;
     b->padding.assign((size_t) nstreams, 0);
+    b->incremental = 0;
+    b->h_stage = b->d_stage = nullptr;
+    b->stage_rows_at = b->stage_stride = b->stage_bytes = 0;
     if (proto->rs) {
         /* the s16 pool shrinks to nothing, the converted signal (plus the flush's tail) lives in a float pool */
         b->rate_in = proto->p.samplerate;
@@ -1341,6 +1360,12 @@ lamehip_batch_destroy(lamehip_batch * b)
     if (b->d_pcmf)
         (void) hipFree(b->d_pcmf);
     free(b->rs);
+    if (b->h_stage)
+        (void) hipHostFree(b->h_stage);
+    if (b->d_stage)
+        (void) hipFree(b->d_stage);
+    for (size_t i = 0; i < b->packer.size(); i++)
+        lh_bs_free(&b->packer[i]);
     if (b->stream)
         (void) hipStreamDestroy(b->stream);
     if (b->ev0)
@@ -1476,6 +1501,268 @@ extern "C" void *
 lamehip_batch_pcm_device_ptr(lamehip_batch * b)
 {
     return (b && !b->rate_in) ? (void *) b->d_pcm : nullptr;
+}
+
+
+/* ---- incremental use of a batch: lame_encode_buffer semantics for many streams at once -------
+ * (reference lame.c:1672-1775: every call appends samples to a stream and encodes the frames that
+ * became complete; the output lags the input by the priming).  lamehip_batch_append stages a chunk
+ * per stream in pinned host memory, lamehip_batch_encode_available moves all staged chunks to HBM
+ * with ONE asynchronous copy, encodes every stream's newly complete frames with ONE launch and packs
+ * them, lamehip_batch_drain hands a stream's new bytes over -- the bytes lame_encode_buffer would
+ * have returned for the same calls --, lamehip_batch_finish is lame_encode_flush for all streams. */
+static int
+batch_incremental_begin(lamehip_batch * b)
+{
+    if (b->incremental)
+        return 0;
+    if (b->rate_in || b->dev_pack) {
+        snprintf(g_err, sizeof(g_err), "incremental batches take the encoder's own input rate and the host packer");
+        return -1;
+    }
+    if (batch_reset_states(b) != 0)
+        return LAMEHIP_ERR_DEVICE;
+    b->fed.assign((size_t) b->B, 0);
+    b->done.assign((size_t) b->B, 0);
+    b->staged.assign((size_t) b->B, 0);
+    b->pending.assign((size_t) b->B, std::vector < unsigned char >());
+    b->last.resize((size_t) b->B);
+    b->have_last.assign((size_t) b->B, 0);
+    b->packer.resize((size_t) b->B);
+    for (int s = 0; s < b->B; s++)
+        if (lh_bs_init_sized(&b->packer[(size_t) s], 65536) != 0)
+            return -2;
+    b->incremental = 1;
+    return 0;
+}
+
+/* (re)shape the staging area for rows of `stride' samples, keeping what is staged */
+static int
+batch_stage_reserve(lamehip_batch * b, long stride)
+{
+    long const rows_at = ((long) b->B * (long) (sizeof(LhStreamDesc) + 2 * sizeof(int)) + 63) & ~63L;
+    long const bytes = rows_at + (long) b->B * 2 * stride * 2;
+    unsigned char *h = nullptr, *d = nullptr;
+    if (stride <= b->stage_stride)
+        return 0;
+    if (hipHostMalloc((void **) &h, (size_t) bytes, hipHostMallocDefault) != hipSuccess
+        || hipMalloc((void **) &d, (size_t) bytes) != hipSuccess) {
+        if (h)
+            (void) hipHostFree(h);
+        return set_err("staging allocation", hipErrorOutOfMemory);
+    }
+    for (int s = 0; s < b->B && b->h_stage; s++)
+        for (int ch = 0; ch < 2; ch++)
+            memcpy(h + rows_at + ((long) (2 * s + ch) * stride) * 2,
+                   b->h_stage + b->stage_rows_at + ((long) (2 * s + ch) * b->stage_stride) * 2,
+                   (size_t) b->staged[(size_t) s] * 2);
+    if (b->h_stage)
+        (void) hipHostFree(b->h_stage);
+    if (b->d_stage)
+        (void) hipFree(b->d_stage);
+    b->h_stage = h;
+    b->d_stage = d;
+    b->stage_rows_at = rows_at;
+    b->stage_stride = stride;
+    b->stage_bytes = bytes;
+    return 0;
+}
+
+extern "C" int
+lamehip_batch_append(lamehip_batch * b, int s, const short *l, const short *r, int n)
+{
+    LhDeviceScope const on_device(b ? b->device : -1);
+    int     rc;
+    if (!b || s < 0 || s >= b->B || n < 0 || (n > 0 && !l))
+        return -1;
+    if ((rc = batch_incremental_begin(b)) != 0)
+        return rc;
+    if (b->cfg.channels == 1 && b->cfg.pcm_mix == 0.0f)
+        r = l;
+    if (n > 0 && !r)
+        return -1;
+    if (b->fed[(size_t) s] + b->staged[(size_t) s] + n > b->cap) {
+        snprintf(g_err, sizeof(g_err), "lamehip_batch_append: stream %d would exceed the batch's capacity of %ld samples", s, b->cap);
+        return -1;
+    }
+    if (b->staged[(size_t) s] + n > b->stage_stride) {
+        long    want = 2304;
+        while (want < b->staged[(size_t) s] + n)
+            want *= 2;
+        if ((rc = batch_stage_reserve(b, want)) != 0)
+            return rc;
+    }
+    {
+        unsigned char *rows = b->h_stage + b->stage_rows_at;
+        long const at = b->staged[(size_t) s];
+        memcpy(rows + ((long) (2 * s) * b->stage_stride + at) * 2, l, (size_t) n * 2);
+        memcpy(rows + ((long) (2 * s + 1) * b->stage_stride + at) * 2, r, (size_t) n * 2);
+    }
+    b->staged[(size_t) s] += n;
+    return 0;
+}
+
+/* frames of a stream that are complete once `fed' samples are in: frame f reads 1904 samples from
+ * 1152 f - 528 on (reference lame.c:1737-1766) */
+static int
+frames_complete(long fed)
+{
+    long const have = fed + LH_MF_START;
+    return have >= LH_MF_NEEDED ? (int) ((have - LH_MF_NEEDED) / 1152 + 1) : 0;
+}
+
+/* encode frames [done, upto[s]) of every stream and pack them into pending[]; `end' marks the
+ * streams' last frames (flush) */
+static int
+batch_encode_range(lamehip_batch * b, const std::vector < int >&upto, int end)
+{
+    LhStreamDesc *descs = (LhStreamDesc *) b->h_stage;
+    int    *meta = (int *) (b->h_stage + (size_t) b->B * sizeof(LhStreamDesc));
+    long long total = 0;
+    for (int s = 0; s < b->B; s++) {
+        LhStreamDesc & d = descs[s];
+        int const nf = upto[(size_t) s] - b->done[(size_t) s];
+        memset(&d, 0, sizeof(d));
+        d.pcm_l = ((long long) s * 2) * b->cap;
+        d.pcm_r = ((long long) s * 2 + 1) * b->cap;
+        d.pcm_base = 0;
+        d.nsamples = b->fed[(size_t) s] + b->staged[(size_t) s];
+        d.out_index = total;
+        d.frame_begin = b->done[(size_t) s];
+        d.frame_end = upto[(size_t) s];
+        d.flush = end;
+        meta[2 * s] = (int) b->fed[(size_t) s];
+        meta[2 * s + 1] = b->staged[(size_t) s];
+        total += nf > 0 ? nf : 0;
+    }
+    if (total > b->out_cap) {
+        if (b->d_out)
+            (void) hipFree(b->d_out);
+        b->out_cap = total + 1024;
+        HIPCHK(hipMalloc((void **) &b->d_out, (size_t) b->out_cap * sizeof(LhFrameOut)));
+    }
+    /* one copy: descriptors, chunk positions and the staged samples of all streams */
+    HIPCHK(hipMemcpyAsync(b->d_stage, b->h_stage, (size_t) b->stage_bytes, hipMemcpyHostToDevice, b->stream));
+    {
+        int     rc = lh_launch_scatter((const int16_t *) (b->d_stage + b->stage_rows_at), b->stage_stride, b->d_pcm, b->cap,
+                                       (const int *) (b->d_stage + (size_t) b->B * sizeof(LhStreamDesc)), b->B,
+                                       (void *) b->stream);
+        if (rc)
+            return set_err("scatter launch", (hipError_t) rc);
+    }
+    for (int s = 0; s < b->B; s++) {
+        b->fed[(size_t) s] += b->staged[(size_t) s];
+        b->staged[(size_t) s] = 0;
+    }
+    if (total == 0) {
+        HIPCHK(hipStreamSynchronize(b->stream));
+        return 0;
+    }
+    HIPCHK(hipEventRecord(b->ev0, b->stream));
+    {
+        int     rc = lh_launch_encode(b->dc.d_cfg, b->dc.d_tab, b->d_pcm, (const float *) 0, (const LhStreamDesc *) b->d_stage,
+                                      b->d_state, b->d_out, (uint8_t *) 0, b->B, (void *) b->stream);
+        if (rc)
+            return set_err("kernel launch", (hipError_t) rc);
+    }
+    HIPCHK(hipEventRecord(b->ev1, b->stream));
+    b->h_new.resize((size_t) total);
+    HIPCHK(hipMemcpyAsync(b->h_new.data(), b->d_out, (size_t) total * sizeof(LhFrameOut), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    for (int s = 0; s < b->B; s++) {
+        LhBitstream *bs = &b->packer[(size_t) s];
+        std::vector < unsigned char >&out = b->pending[(size_t) s];
+        for (int f = b->done[(size_t) s]; f < upto[(size_t) s]; f++) {
+            const LhFrameOut & fo = b->h_new[(size_t) (descs[s].out_index + (f - descs[s].frame_begin))];
+            size_t  at;
+            int     k;
+            if (lh_bs_format_frame(bs, &b->cfg, b->tab, &fo) != 0) {
+                snprintf(g_err, sizeof(g_err), "inconsistent device payload (packer check %d) stream %d frame %d", bs->error, s, f);
+                return LAMEHIP_ERR_PAYLOAD;
+            }
+            at = out.size();
+            out.resize(at + (size_t) lh_bs_pending(bs));
+            k = lh_bs_copy(bs, out.data() + at, 0);
+            out.resize(at + (size_t) (k > 0 ? k : 0));
+            b->last[(size_t) s] = fo;
+            b->have_last[(size_t) s] = 1;
+        }
+        if (upto[(size_t) s] > b->done[(size_t) s])
+            b->done[(size_t) s] = upto[(size_t) s];
+    }
+    return (int) total;
+}
+
+extern "C" int
+lamehip_batch_encode_available(lamehip_batch * b)
+{
+    LhDeviceScope const on_device(b ? b->device : -1);
+    std::vector < int >upto;
+    int     rc;
+    if (!b)
+        return -1;
+    if ((rc = batch_incremental_begin(b)) != 0)
+        return rc;
+    if ((rc = batch_stage_reserve(b, 2304)) != 0)
+        return rc;
+    upto.resize((size_t) b->B);
+    for (int s = 0; s < b->B; s++)
+        upto[(size_t) s] = frames_complete(b->fed[(size_t) s] + b->staged[(size_t) s]);
+    return batch_encode_range(b, upto, 0);
+}
+
+/* lame_encode_flush for every stream of an incremental batch: the frames still owed for the samples
+ * fed (with the reference's end padding), then the stuffing that completes the last frame */
+extern "C" int
+lamehip_batch_finish(lamehip_batch * b)
+{
+    LhDeviceScope const on_device(b ? b->device : -1);
+    std::vector < int >upto;
+    int     rc, n;
+    if (!b)
+        return -1;
+    if ((rc = batch_incremental_begin(b)) != 0)
+        return rc;
+    if ((rc = batch_stage_reserve(b, 2304)) != 0)
+        return rc;
+    upto.resize((size_t) b->B);
+    for (int s = 0; s < b->B; s++) {
+        long const len = b->fed[(size_t) s] + b->staged[(size_t) s];
+        b->len[(size_t) s] = len;
+        b->nframes[(size_t) s] = lh_total_frames(len);
+        upto[(size_t) s] = b->nframes[(size_t) s];
+    }
+    n = batch_encode_range(b, upto, 1);
+    if (n < 0)
+        return n;
+    for (int s = 0; s < b->B; s++) {
+        LhBitstream *bs = &b->packer[(size_t) s];
+        std::vector < unsigned char >&out = b->pending[(size_t) s];
+        size_t  at = out.size();
+        int     k;
+        lh_bs_flush(bs, &b->cfg, b->have_last[(size_t) s] ? &b->last[(size_t) s] : nullptr);
+        out.resize(at + (size_t) lh_bs_pending(bs));
+        k = lh_bs_copy(bs, out.data() + at, 0);
+        out.resize(at + (size_t) (k > 0 ? k : 0));
+    }
+    return n;
+}
+
+/* bytes of stream s produced since the last drain; -1 (and nothing taken) when they do not fit */
+extern "C" int
+lamehip_batch_drain(lamehip_batch * b, int s, unsigned char *out, int cap)
+{
+    int     n;
+    if (!b || !b->incremental || s < 0 || s >= b->B)
+        return -1;
+    n = (int) b->pending[(size_t) s].size();
+    if (n == 0)
+        return 0;
+    if (!out || cap < n)
+        return -1;
+    memcpy(out, b->pending[(size_t) s].data(), (size_t) n);
+    b->pending[(size_t) s].clear();
+    return n;
 }
 
 extern "C" int

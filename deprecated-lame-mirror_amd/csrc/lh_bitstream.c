@@ -34,8 +34,16 @@ enum { BS_FULL = 1, BS_QUEUE = 2, BS_COUNT = 3, BS_BACKPTR = 4, BS_FLUSH = 5, BS
 int
 lh_bs_init(LhBitstream * bs)
 {
+    return lh_bs_init_sized(bs, LH_BS_BUFSIZE);
+}
+
+/* with room for `size' finished bytes between two lh_bs_copy calls (a stream of a batch is drained
+ * after every few frames and needs far less than a handle that may be fed a minute at once) */
+int
+lh_bs_init_sized(LhBitstream * bs, int size)
+{
     memset(bs, 0, sizeof(*bs));
-    bs->buf_size = LH_BS_BUFSIZE;
+    bs->buf_size = size;
     bs->buf = (unsigned char *) calloc((size_t) bs->buf_size, 1);
     return bs->buf ? 0 : -2;
 }

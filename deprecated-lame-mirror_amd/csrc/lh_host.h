@@ -80,6 +80,7 @@ typedef struct LhBitstream {
 } LhBitstream;
 
 int     lh_bs_init(LhBitstream * bs);
+int     lh_bs_init_sized(LhBitstream * bs, int size);
 void    lh_bs_free(LhBitstream * bs);
 /* appends one frame; returns 0, or <0 when the device payload is inconsistent */
 int     lh_bs_format_frame(LhBitstream * bs, const LhConfig * c, const LhTables * t,

@@ -635,6 +635,30 @@ lh_launch_selftest(unsigned *d_out, unsigned seed, void *stream)
     return (int) hipGetLastError();
 }
 
+/* Incremental batches (lamehip_batch_append / _encode_available): the chunks the host staged for the
+ * streams, rows [stream][channel][stage_stride] of one pinned buffer that reached HBM with a single
+ * copy, go to their places in the PCM pool.  meta[2 s] = where stream s's chunk starts in its pool
+ * row, meta[2 s + 1] = its length. */
+extern "C" __global__ void __launch_bounds__(256)
+lh_scatter_kernel(const int16_t * stage, long stage_stride, int16_t * pool, long cap, const int *meta)
+{
+    long const row = (long) blockIdx.x;         /* 2 * stream + channel */
+    int const at = meta[2 * (row >> 1)], n = meta[2 * (row >> 1) + 1];
+    for (int i = (int) threadIdx.x; i < n; i += 256)
+        pool[row * cap + at + i] = stage[row * stage_stride + i];
+}
+
+extern "C" int
+lh_launch_scatter(const int16_t * stage, long stage_stride, int16_t * pool, long cap, const int *meta, int nstreams,
+                  void *stream)
+{
+    if (nstreams <= 0)
+        return 0;
+    hipLaunchKernelGGL(lh_scatter_kernel, dim3((unsigned) (2 * nstreams)), dim3(256), 0, (hipStream_t) stream, stage,
+                       stage_stride, pool, cap, meta);
+    return (int) hipGetLastError();
+}
+
 /* host-side launcher with a C ABI for lh_api.cpp */
 extern "C" int
 lh_launch_encode(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, const float *pcmf,

@@ -184,6 +184,42 @@ class Batch:
         if rc:
             raise RuntimeError("lamehip_batch_set_pcm_device failed (%d): %s" % (rc, last_error()))
 
+    # ---- incremental use: lame_encode_buffer semantics for all streams of the batch ----
+    def append(self, s, left, right=None):
+        """Stage more samples of stream s (any number, also 0); encode_available() moves everything
+        staged to the GPU with one copy."""
+        left = np.ascontiguousarray(left, dtype=np.int16)
+        right = left if right is None else np.ascontiguousarray(right, dtype=np.int16)
+        self.lib.lamehip_batch_append.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        rc = self.lib.lamehip_batch_append(self.b, s, left.ctypes.data, right.ctypes.data, len(left))
+        if rc:
+            raise RuntimeError("lamehip_batch_append failed (%d): %s" % (rc, last_error()))
+
+    def encode_available(self):
+        """Encode every stream's newly complete frames (one launch); returns how many there were."""
+        self.lib.lamehip_batch_encode_available.argtypes = [C.c_void_p]
+        n = self.lib.lamehip_batch_encode_available(self.b)
+        if n < 0:
+            raise RuntimeError("lamehip_batch_encode_available failed (%d): %s" % (n, last_error()))
+        return n
+
+    def finish(self):
+        """lame_encode_flush for every stream."""
+        self.lib.lamehip_batch_finish.argtypes = [C.c_void_p]
+        n = self.lib.lamehip_batch_finish(self.b)
+        if n < 0:
+            raise RuntimeError("lamehip_batch_finish failed (%d): %s" % (n, last_error()))
+        return n
+
+    def drain(self, s, cap=1 << 20):
+        """Bytes stream s has produced since its last drain."""
+        self.lib.lamehip_batch_drain.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        buf = C.create_string_buffer(cap)
+        k = self.lib.lamehip_batch_drain(self.b, s, buf, cap)
+        if k < 0:
+            raise RuntimeError("lamehip_batch_drain: buffer of %d bytes too small" % cap)
+        return buf.raw[:k]
+
     def set_length(self, s, n):
         assert self.lib.lamehip_batch_set_length(self.b, s, n) == 0
 

@@ -189,6 +189,22 @@ int     lamehip_batch_set_pcm_device(lamehip_batch *, int stream, const void *de
  * that already lives on the GPU fill it in place (then declare lengths) */
 void   *lamehip_batch_pcm_device_ptr(lamehip_batch *);
 int     lamehip_batch_set_length(lamehip_batch *, int stream, long nsamples);
+
+/* Incremental use -- lame_encode_buffer (lame.h:715-722, lame.c:1672-1775) for all streams of a batch at once:
+ *   lamehip_batch_append            stage n more samples of one stream (host, pinned memory; any n >= 0, ragged
+ *                                   across streams; several calls per stream may precede one encode)
+ *   lamehip_batch_encode_available  ONE asynchronous H2D copy of everything staged, ONE launch that encodes
+ *                                   every stream's newly complete frames, packing; returns the frame count
+ *   lamehip_batch_drain             the bytes a stream has produced since its last drain: what the
+ *                                   reference's lame_encode_buffer returns for the same calls (the output
+ *                                   lags the input by the priming: the first 1152 samples yield 0 bytes)
+ *   lamehip_batch_finish            lame_encode_flush (lame.h:869, lame.c:2041-2175) for every stream
+ * The first append switches the batch to this mode (its capacity still bounds a stream's total length).
+ * Return codes as lame_encode_buffer's: >= 0, -1 a buffer or the capacity is too small, -2 allocation. */
+int     lamehip_batch_append(lamehip_batch *, int stream, const short *l, const short *r, int nsamples);
+int     lamehip_batch_encode_available(lamehip_batch *);
+int     lamehip_batch_drain(lamehip_batch *, int stream, unsigned char *out, int out_size);
+int     lamehip_batch_finish(lamehip_batch *);
 /* encode every stream completely (all frames incl. the flush frames), payload
  * stays in HBM; asynchronous on the batch's HIP stream */
 int     lamehip_batch_encode(lamehip_batch *);

@@ -599,3 +599,53 @@ def test_batch_on_named_device_and_reuse():
     assert fresh[0] == g["mp3"].tobytes()
     b.close()
     enc.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(brate=128), dict(vbr_q=2)])
+def test_incremental_batch_matches_reference_call_by_call(reference, kw):
+    """lamehip_batch_append / _encode_available / _drain: eight streams fed in ragged chunks (also
+    empty ones), one launch per round; what every stream drains after a round is what the
+    reference's lame_encode_buffer returns for that stream's call of the round, and
+    lamehip_batch_finish is its lame_encode_flush."""
+    sr, B = 44100, 8
+    rng = np.random.default_rng(77)
+    lens = [int(sr * 0.9) + 37 * s for s in range(B)]
+    pcms = [helpers.synth_stream(600 + s, lens[s], sr, 1.0 / 7) for s in range(B)]
+    lib = reference.lib
+    lib.refh_open.restype = C.c_void_p
+    lib.refh_open_vbr.restype = C.c_void_p
+    if "vbr_q" in kw:
+        hs = [C.c_void_p(lib.refh_open_vbr(sr, kw["vbr_q"], -1, -1, 0, 0)) for _ in range(B)]
+    else:
+        hs = [C.c_void_p(lib.refh_open(sr, kw["brate"], -1, -1)) for _ in range(B)]
+    enc = lamehip.Encoder(sr, **kw)
+    b = lamehip.Batch(enc, B, max(lens) + 16)
+    buf = C.create_string_buffer(400000)
+    pos = [0] * B
+    rounds = 0
+    while any(pos[s] < lens[s] for s in range(B)):
+        want = []
+        for s in range(B):
+            n = int(rng.choice([0, 1, 575, 1152, 1153, 4000, 9000]))
+            n = min(n, lens[s] - pos[s])
+            l = np.ascontiguousarray(pcms[s][0][pos[s]:pos[s] + n])
+            r = np.ascontiguousarray(pcms[s][1][pos[s]:pos[s] + n])
+            k = lib.refh_encode(hs[s], l.ctypes.data_as(C.c_void_p), r.ctypes.data_as(C.c_void_p), n, buf, len(buf))
+            assert k >= 0
+            want.append(buf.raw[:k])
+            if n:
+                b.append(s, l, r)
+            pos[s] += n
+        b.encode_available()
+        for s in range(B):
+            assert b.drain(s) == want[s], "round %d stream %d" % (rounds, s)
+        rounds += 1
+    b.finish()
+    for s in range(B):
+        k = lib.refh_flush(hs[s], buf, len(buf))
+        assert b.drain(s) == buf.raw[:k], "flush of stream %d" % s
+        lib.refh_close(hs[s])
+    assert rounds > 3
+    b.close()
+    enc.close()
