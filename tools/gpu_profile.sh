@@ -6,7 +6,7 @@
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 TAG=$1; shift
-ARGS=${*:---streams 1024 --seconds 5 --steps 2 --warmup 1 --no-cpu-baseline}
+ARGS=${*:---streams 1024 --seconds 5 --steps 2 --warmup 1 --no-cpu-baseline --no-extras}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -24,5 +24,6 @@ done
 { echo "# rocprofv3 --pmc <set> --kernel-trace -- python bench.py $ARGS   (one pass per set; sums over the launches of the run)";
   for j in 1 2 3 4 5; do python $ROOT/tools/pmc_summary.py $OUT/pmc_${TAG}_$j lh_encode; done; } > $OUT/summ_${TAG}_pmc.txt
 rm -rf $OUT/kt_$TAG $OUT/pmc_${TAG}_[0-9]   # raw traces are large; the summaries are what is kept
+python $ROOT/tools/pmc_to_json.py $OUT/summ_${TAG}_pmc.txt $OUT/summ_${TAG}_kernel_stats.txt "bench.py $ARGS" > $OUT/summ_${TAG}_pmc.json
 cat $OUT/summ_${TAG}_kernel_stats.txt | cut -c1-250 | head -12
 cat $OUT/summ_${TAG}_pmc.txt
