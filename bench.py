@@ -424,10 +424,13 @@ def main():
                        "devices_visible": ndev},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                         "traffic": pmc.get("hbm_bytes_per_launch"),
-                         "traffic_note": ("recorded with rocprofv3 --pmc on %s (commit %s), workload %s; bench.py "
-                                          "does not run the profiler" % (pmc.get("date"), pmc.get("commit"),
-                                                                         pmc.get("workload")))
+                         "traffic": (int(pmc["hbm_bytes_per_frame"] * frames) if pmc.get("hbm_bytes_per_frame")
+                                     else None),
+                         "traffic_note": ("%.1f KB per frame x the frames of this launch; per-frame figure recorded "
+                                          "with rocprofv3 --pmc (FETCH_SIZE x 2 + WRITE_SIZE) on %s, commit %s, "
+                                          "workload `%s'; bench.py does not run the profiler"
+                                          % (pmc.get("hbm_bytes_per_frame", 0) / 1e3, pmc.get("date"), pmc.get("commit"),
+                                             pmc.get("workload")))
                          if pmc else "no recorded PMC profile in profiles/",
                          "valu_frac": pmc.get("valu_frac"), "issue_active_frac": pmc.get("issue_active_frac"),
                          "bound_in_practice": "instruction issue of a serial search: one wave issues at most one "

@@ -39,6 +39,11 @@ def main(pmc, stats, workload):
     if "SQ_ACTIVE_INST_ANY" in v and "SQ_WAVE_CYCLES" in v:
         out["issue_active_frac"] = round(per("SQ_ACTIVE_INST_ANY") / per("SQ_WAVE_CYCLES"), 4)
     for line in open(stats):
+        if line.startswith("{"):
+            try:
+                out["frames_per_launch"] = json.loads(line)["roofline"]["frames_per_launch"]
+            except (ValueError, KeyError):
+                pass
         if "lh_encode_kernel" in line and "," in line:
             f = [x.strip('"') for x in line.split(",")]
             try:
@@ -48,6 +53,8 @@ def main(pmc, stats, workload):
     if "SQ_INSTS_VALU" in v and "kernel_avg_ns" in out:
         cycles = out["kernel_avg_ns"] * 1e-9 * 2.4e9        # at the 2.4 GHz peak clock: a lower bound of the fraction
         out["valu_frac"] = round(per("SQ_INSTS_VALU") * 2 / (1024 * cycles), 4)
+    if "hbm_bytes_per_launch" in out and out.get("frames_per_launch"):
+        out["hbm_bytes_per_frame"] = round(out["hbm_bytes_per_launch"] / out["frames_per_launch"], 1)
     print(json.dumps(out, indent=1))
 
 
