@@ -392,23 +392,21 @@ lq_count_bits(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
         if (USE_PREV && R.block_type == LH_NORM_TYPE)
             sfbcnt_in = (lane < LH_SBMAX_L + 1) ? qt->sfb_l[lane] : 576u;
         LQ_MARK("cb_quads");
-        LH_WAVE_SYNC();
+        LH_WAVE_ORDER();
         uint32_t red[7];        /* quads, then (a | b << 16) and c of the sums over p < e0, p < e1, p < e2 */
+        uint32_t qlen[3];       /* t32 << 16 | t33 code lengths of this lane's (up to) three quadruples:
+                                 * looked up now, added up after the region maxima (the LDS round trips
+                                 * run under that arithmetic) */
         {
-            unsigned idx[3];
-            unsigned quads = 0;
 #pragma unroll
             for (int k = 0; k < 3; k++) {
                 int const qd = lane + 64 * k;
                 int const b2 = (bv >> 1) + 2 * qd;
                 int const b2c = b2 < 286 ? b2 : 286;
                 uint32_t const u0 = xbuf[b2c], u1 = xbuf[b2c + 1];
-                idx[k] = ((((u0 & 1u) * 2 + ((u0 >> 16) & 1u)) * 2 + (u1 & 1u)) * 2 + ((u1 >> 16) & 1u));
+                unsigned const idx = ((((u0 & 1u) * 2 + ((u0 >> 16) & 1u)) * 2 + (u1 & 1u)) * 2 + ((u1 >> 16) & 1u));
+                qlen[k] = qt->t3233[idx];
             }
-#pragma unroll
-            for (int k = 0; k < 3; k++)
-                quads += ((lane + 64 * k) < nquad) ? qt->t3233[idx[k]] : 0u;
-            red[0] = quads;
         }
         LQ_MARK("cb_max");
         uint32_t m[3] = { 0u, 0u, 0u };
@@ -425,6 +423,13 @@ lq_count_bits(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
                 m[2] = c2 > m[2] ? c2 : m[2];
             }
             lh_wave_max_n < 3 > (m);
+        }
+        {
+            unsigned quads = 0;
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                quads += ((lane + 64 * k) < nquad) ? qlen[k] : 0u;
+            red[0] = quads;
         }
         LQ_MARK("cb_lookup");
         /* lane r < 3 works out region r's candidate tables; the grid origins go back to all lanes */
@@ -456,15 +461,25 @@ lq_count_bits(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
                 acc1 += in1 ? v : 0u;
                 acc2 += in2 ? v : 0u;
             }
-            red[1] = (acc0 & 0x3ffu) | (((acc0 >> 10) & 0x3ffu) << 16);
-            red[2] = acc0 >> 20;
-            red[3] = (acc1 & 0x3ffu) | (((acc1 >> 10) & 0x3ffu) << 16);
-            red[4] = acc1 >> 20;
-            red[5] = (acc2 & 0x3ffu) | (((acc2 >> 10) & 0x3ffu) << 16);
-            red[6] = acc2 >> 20;
+            /* no code is longer than 21 bits (sign bits included), so the 10-bit fields hold the sums
+             * over 8 lanes x 5 pairs: three reduction steps run on the packed words before the fields
+             * are spread out for the rest */
+            uint32_t acc[3] = { acc0, acc1, acc2 };
+            lh_wave_sum_head3 < 3 > (acc);
+            red[1] = (acc[0] & 0x3ffu) | (((acc[0] >> 10) & 0x3ffu) << 16);
+            red[2] = acc[0] >> 20;
+            red[3] = (acc[1] & 0x3ffu) | (((acc[1] >> 10) & 0x3ffu) << 16);
+            red[4] = acc[1] >> 20;
+            red[5] = (acc[2] & 0x3ffu) | (((acc[2] >> 10) & 0x3ffu) << 16);
+            red[6] = acc[2] >> 20;
         }
         LQ_MARK("cb_sums");
-        lh_wave_sum_n < 7 > (red);
+        {
+            uint32_t q1[1] = { red[0] };
+            lh_wave_sum_head3 < 1 > (q1);
+            red[0] = q1[0];
+        }
+        lh_wave_sum_tail3 < 7 > (red);
         LQ_MARK("cb_decide");
         {
             int const c1a = (int) (red[0] >> 16), c1b = (int) (red[0] & 0xffffu);
@@ -577,7 +592,7 @@ lq_calc_noise(const LhCtx & c, LhQS & S, LhQR & R, const LhGrR & g, LhChanLds & 
                 ((lh_f32x2 *) sq)[p] = v;
         }
     }
-    LH_WAVE_SYNC();
+    LH_WAVE_ORDER();
     LQ_MARK("cn_sum");
     {
         /* eight terms per trip, fetched as four aligned pairs (band starts are even) one trip

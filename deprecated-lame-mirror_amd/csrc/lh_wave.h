@@ -23,6 +23,7 @@ static inline int lh_lane(void) { return hipemu_lane(); }
 static inline int lh_wave_id(void) { return hipemu_wave(); }
 #define LH_WAVE_SYNC() hipemu_wave_sync()
 #define LH_WAVE_SYNC_MEM() hipemu_wave_sync()
+#define LH_WAVE_ORDER() hipemu_wave_sync()
 
 static inline uint32_t
 lh_wave_sum_u32(uint32_t v)
@@ -184,6 +185,34 @@ lh_row0_min_u32(uint32_t v)
     return s;
 }
 
+
+/* a wave sum in two halves: the first three butterfly steps leave every lane with the sum over its
+ * group of eight lanes, the second half finishes the wave total */
+template < int N > static inline void
+lh_wave_sum_head3(uint32_t (&v)[N])
+{
+    for (int i = 0; i < N; i++) {
+        const uint64_t *x = hipemu_wave_exchange(v[i]);
+        uint32_t s = 0;
+        int const g = hipemu_lane() & ~7;
+        for (int k = 0; k < 8; k++)
+            s += (uint32_t) x[g + k];
+        v[i] = s;
+    }
+}
+
+template < int N > static inline void
+lh_wave_sum_tail3(uint32_t (&v)[N])
+{
+    for (int i = 0; i < N; i++) {
+        const uint64_t *x = hipemu_wave_exchange(v[i]);
+        uint32_t s = 0;
+        for (int k = 0; k < 64; k += 8)
+            s += (uint32_t) x[k];
+        v[i] = s;
+    }
+}
+
 static inline void lh_lds_add(int *p, int v) { *p += v; }      /* fibers interleave only at sync points */
 static inline void lh_lds_max(int *p, int v) { if (v > *p) *p = v; }
 static inline void lh_lds_addf(float *p, float v) { *p += v; }
@@ -213,6 +242,12 @@ __device__ __forceinline__ int lh_wave_id(void) { return (int) (threadIdx.x >> 6
 #define LH_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local"); \
                             __builtin_amdgcn_wave_barrier(); } while (0)
 #endif
+/* LDS exchange inside one wave without draining it: a wave's DS instructions are executed in the
+ * order they were issued, so a read that follows another lane's write in program order sees it;
+ * all that is needed is that the compiler keeps that order (no s_waitcnt here -- the reads can be
+ * in flight together with whatever follows) */
+#define LH_WAVE_ORDER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); \
+                             asm volatile("" ::: "memory"); } while (0)
 /* same, for phases whose lanes also exchange data through the stream state in HBM (the
  * psycho-acoustic model): orders and drains global accesses as well */
 #define LH_WAVE_SYNC_MEM() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); \
@@ -285,6 +320,25 @@ lh_wave_max_n(uint32_t (&v)[N])
     LH_DPP_STEP_N(LH_OP_MAX, 0u, 0xB1) LH_DPP_STEP_N(LH_OP_MAX, 0u, 0x4E)
     LH_DPP_STEP_N(LH_OP_MAX, 0u, 0x141) LH_DPP_STEP_N(LH_OP_MAX, 0u, 0x140)
     LH_DPP_ROWS_N(LH_OP_MAX, 0u, 0x142, 0xa) LH_DPP_ROWS_N(LH_OP_MAX, 0u, 0x143, 0xc)
+#pragma unroll
+    for (int i = 0; i < N; i++)
+        v[i] = (uint32_t) __builtin_amdgcn_readlane((int) v[i], 63);
+}
+
+
+/* a wave sum in two halves (see lh_wave_sum_n): after the first three steps every lane holds the sum
+ * over its group of eight lanes -- packed fields can be widened between the halves */
+template < int N > __device__ __forceinline__ void
+lh_wave_sum_head3(uint32_t (&v)[N])
+{
+    LH_DPP_STEP_N(LH_OP_ADD, 0u, 0xB1) LH_DPP_STEP_N(LH_OP_ADD, 0u, 0x4E) LH_DPP_STEP_N(LH_OP_ADD, 0u, 0x141)
+}
+
+template < int N > __device__ __forceinline__ void
+lh_wave_sum_tail3(uint32_t (&v)[N])
+{
+    LH_DPP_STEP_N(LH_OP_ADD, 0u, 0x140)
+    LH_DPP_ROWS_N(LH_OP_ADD, 0u, 0x142, 0xa) LH_DPP_ROWS_N(LH_OP_ADD, 0u, 0x143, 0xc)
 #pragma unroll
     for (int i = 0; i < N; i++)
         v[i] = (uint32_t) __builtin_amdgcn_readlane((int) v[i], 63);
