@@ -58,10 +58,7 @@ struct LhPsyLds {
         } b;
     };
     float   eb[4 * 64];
-    float   thr[4 * 64];
-    float   smax[2][64];
-    float   savg[2][64];
-    int     sidx[2][64];
+    float   thr[4 * 64];        /* lh_compute_masking parks a channel's tonality indices here until its thresholds are known */
 };
 
 struct LhMdctLds {
@@ -177,7 +174,9 @@ struct LhChanLds {
     };
     int16_t ix[2][576];         /* [0] = best so far (cod_info), [1] = working copy (cod_info_w) */
     int     sf[2][LH_SFBMAX + 1];       /* scalefactors of the two images */
-    int     width[LH_SFBMAX + 1], window[LH_SFBMAX + 1], start[LH_SFBMAX + 1];
+    uint16_t width[LH_SFBMAX + 1], start[LH_SFBMAX + 1];
+    uint8_t window[LH_SFBMAX + 1];
+    uint8_t sfb_mode[LH_SFBMAX + 1];    /* scratch: flags per band */
     uint8_t sfb_of_line[576];
     float   l3_xmin[LH_SFBMAX + 1];
     union {
@@ -191,7 +190,6 @@ struct LhChanLds {
         uint32_t hl3_small[LQ_SMALL_CELLS];     /* while the CBR search runs (it keeps the five arrays in registers) */
     };
     /* scratch */
-    int     sfb_mode[LH_SFBMAX + 1];
     float   sfb_f[LH_SFBMAX + 1];
     float   zero2[2];           /* two zeros on an 8-byte boundary: where masked-out term loads are redirected */
     float   pad2[2];            /* keeps sizeof a multiple of 16 */
@@ -200,7 +198,6 @@ struct LhChanLds {
 /* hot lookup tables of the quantiser, staged into LDS for the iteration-loop phase
  * (they live behind xr in the region the PCM window occupied earlier in the frame) */
 struct LhQTabs {
-    uint32_t largetbl[256];     /* packed lengths of the two ESC code books */
     uint32_t table23[9], table56[16];
     uint16_t sfb_l[24];
     uint8_t ht_len[1124];       /* code lengths of tables 1..15 back to back (lh_ht_off()); the ESC
@@ -208,7 +205,6 @@ struct LhQTabs {
     uint32_t bvpack[288];       /* big_values/2 - 1 -> region0_count | region1_count << 4 | end of region 0 << 8
                                  * | end of region 1 << 18 (reference takehiro.c:1334-1375 folded with sfb_l) */
     uint16_t sfb_s3, pad;       /* sfb_s[3] */
-    uint32_t lut_pa[17], lut_pb[17];    /* lh_region_lut() of a region maximum 0..15, 16 = ESC classes */
     uint8_t t32l[16], t33l[16];
     uint32_t t3233[16];         /* t32l << 16 | t33l */
     uint8_t pretab[24];
@@ -232,7 +228,6 @@ struct LhVbrSave {
 
 struct LhQuantLds {
     LhChanLds ch[2];
-    LhVbrSave vbr[2][2];        /* [gr][ch]; fits in the tail the larger psy image leaves free */
 };
 
 /* VBR only: the step tables of the scalefactor search, ipow20[0..255] and pow20[116..371]
@@ -259,9 +254,33 @@ struct LhRgSlot {
     LhGrR   g;
 };
 
+/* Per-stream state a wave carries in registers from frame to frame of a launch (loaded from
+ * LhStreamState when the launch starts, stored when it ends: lh_encode_kernel).  Lane-local, so no
+ * exchange is ever needed:
+ *   n1 / n2 [pass]  the psy model's spread partition energies of the last two long-block calls for
+ *                   pseudo-channel wave + 2 pass, lane = partition (lh_compute_masking);
+ *   sb[k]           the polyphase output of the last granule of the previous frame, which the MDCT
+ *                   overlaps with (reference sb_sample[ch][0], newmdct.c:943-1040): value
+ *                   lane + 64 k of channel `wave'. */
+struct LhPsyCarry {
+    float   n1[2], n2[2];
+};
+struct LhWaveCarry {
+    LhPsyCarry nb;
+    float   sb[9];
+};
+
 struct LhLds {
-    float   ratio_en[2][4][LH_XMIN_N];  /* [gr][L,R,M,S]: the delayed psy output of each granule */
-    float   ratio_thm[2][4][LH_XMIN_N];
+    /* Band energies / thresholds of the psy model, [L,R,M,S] each: a ring of three slots.  The model's
+     * output is used one granule late (reference psymodel.c:1397-1460 hands back last call's values), so
+     * with c = psy_slot at the start of a frame: slot c = what the previous frame's second granule
+     * produced = the ratios of this frame's granule 0; granule 0 writes slot c + 1 = the ratios of
+     * granule 1; granule 1 writes slot c + 2 = the next frame's slot c.  Nothing is copied, and the
+     * values never leave LDS during a launch (LhStreamState.en / thm are read at the start of the
+     * launch and written at its end). */
+    float   psy_en[3][4][LH_XMIN_N];
+    float   psy_thm[3][4][LH_XMIN_N];
+    int     psy_slot;
     float   pe[2][4];
     float   tot_ener[2][4];
     float   loudness_sq[2][2];
@@ -292,6 +311,7 @@ struct LhLds {
         struct {
             float   xr[2][2][576];      /* [ch][gr] MDCT spectra; written after the last read of mf */
             LhQTabs qt;                 /* loaded after the MDCT, used by the iteration loop */
+            LhVbrSave vbr[2][2];        /* [gr][ch]; in the tail the longer PCM window leaves free */
         };
     };
     union __attribute__((aligned(16))) {

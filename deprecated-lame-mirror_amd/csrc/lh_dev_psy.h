@@ -365,40 +365,41 @@ lh_partition2sfb_wave(LhPsyBand const *gd, float const *eb, float const *thr, fl
     }
 }
 
-/* tonality index of partition b (reference psymodel.c:583-652 / 958-1028) */
+/* tonality index of partition b (reference psymodel.c:583-652 / 958-1028) from the maxima / averages of
+ * the partition itself (m1, a1) and of its neighbours below (m0, a0) and above (m2, a2) */
 LH_DEVFN int
-lh_mask_index(LhPsyBand const *gd, float const *mx, float const *avg, int b)
+lh_mask_index(LhPsyBand const *gd, int b, float m0, float m1, float m2, float a0, float a1, float a2)
 {
     float   m, a;
     int     k, nl;
     int const np = gd->npart;
     if (b == 0) {
-        a = avg[0] + avg[1];
-        m = mx[0];
-        if (m < mx[1])
-            m = mx[1];
+        a = a1 + a2;
+        m = m1;
+        if (m < m2)
+            m = m2;
         nl = gd->numlines[0] + gd->numlines[1] - 1;
         if (!(a > 0.0f))
             return 0;
         a = 20.0f * (m * 2.0f - a) / (a * nl);
     }
     else if (b == np - 1) {
-        a = avg[b - 1] + avg[b];
-        m = mx[b - 1];
-        if (m < mx[b])
-            m = mx[b];
+        a = a0 + a1;
+        m = m0;
+        if (m < m1)
+            m = m1;
         nl = gd->numlines[b - 1] + gd->numlines[b] - 1;
         if (!(a > 0.0f))
             return 0;
         a = 20.0f * (m * 2.0f - a) / (a * nl);
     }
     else {
-        a = avg[b - 1] + avg[b] + avg[b + 1];
-        m = mx[b - 1];
-        if (m < mx[b])
-            m = mx[b];
-        if (m < mx[b + 1])
-            m = mx[b + 1];
+        a = a0 + a1 + a2;
+        m = m0;
+        if (m < m1)
+            m = m1;
+        if (m < m2)
+            m = m2;
         nl = gd->numlines[b - 1] + gd->numlines[b] + gd->numlines[b + 1] - 1;
         if (!(a > 0.0f))
             return 0;
@@ -416,9 +417,13 @@ lh_mask_index(LhPsyBand const *gd, float const *mx, float const *avg, int b)
  * short-block variant (:1031-1131).  energy = power spectrum in LDS. */
 LH_DEVFN void
 lh_compute_masking(const LhCtx & c, int chn, int is_long, const float *energy, float *eb,
-                   float *thr, float *smax, float *savg, int *sidx, const uint16_t *pstart,
-                   const float *s3, const float *log_table, const float *psy_tab, const float *table2)
+                   float *thr, const uint16_t *pstart,
+                   const float *s3, const float *log_table, const float *psy_tab, const float *table2,
+                   float &nb1, float &nb2)
 {
+    /* nb1 / nb2: this partition's spread energy of the last and the last but one long-block call
+     * (reference PsyStateVar_t.nb_l1 / nb_l2, psymodel.c:1235-1256), lane = partition: lane-local, so
+     * they live in a register of the lane for the whole launch (lh_encode_kernel) */
     /* s3 / log_table / psy_tab / table2: the spreading matrix and the small tables of the
      * masking addition, either in HBM (LhTables, constants) or staged in LDS by the caller: the
      * spreading loop makes three to four dependent look-ups in them per step */
@@ -426,7 +431,7 @@ lh_compute_masking(const LhCtx & c, int chn, int is_long, const float *energy, f
     LhPsyBand const *gd = is_long ? &c.T->psy_l : &c.T->psy_s;
     int const b = c.lane;
     int const np = gd->npart;
-    float   ebb = 0, m = 0;
+    float   ebb = 0, m = 0, avg = 0, th = 0;
     if (b < np) {
         int const n = gd->numlines[b];
         int     j = pstart[b];
@@ -436,30 +441,36 @@ lh_compute_masking(const LhCtx & c, int chn, int is_long, const float *energy, f
             if (m < el)
                 m = el;
         }
-        eb[b] = ebb;
-        smax[b] = m;
-        savg[b] = ebb * gd->rnumlines[b];
+        avg = ebb * gd->rnumlines[b];
+    }
+    eb[b] = ebb;                /* 0 above the last partition */
+    {
+        /* The tonality index needs the neighbours' maximum and average: lane exchanges.  The indices
+         * of the whole channel then sit in thr[] (as bit patterns) until the thresholds, which each
+         * lane writes over its own index when every lane is through with the spreading, replace them. */
+        int const lo = (b > 0) ? b - 1 : 0, hi = (b < 63) ? b + 1 : 63;
+        float const m0 = lh_shfl_f32(m, lo), m2 = lh_shfl_f32(m, hi);
+        float const a0 = lh_shfl_f32(avg, lo), a2 = lh_shfl_f32(avg, hi);
+        int const k = (b < np) ? lh_mask_index(gd, b, m0, m, m2, a0, avg, a2) : 0;
+        thr[b] = lh_u32_as_f32((unsigned) k);
     }
     LH_WAVE_SYNC_MEM();
-    if (b < np)
-        sidx[b] = lh_mask_index(gd, smax, savg, b);
-    LH_WAVE_SYNC_MEM();
+#define LH_SIDX(i) ((int) lh_f32_as_u32(thr[i]))
     if (b < np) {
         float   x, ecb, avg_mask, t;
         float const masking_lower = gd->masking_lower[b] * c.st->masking_lower;
         int     k = gd->s3_row[b];
         int     kk = gd->s3ind[b][0];
         int const last = gd->s3ind[b][1];
-        int const delta = lh_mask_add_delta[sidx[b]];
+        int const delta = lh_mask_add_delta[LH_SIDX(b)];
         int     dd, dd_n = 1;
-        float   th;
-        dd = sidx[kk];
-        ecb = s3[k] * eb[kk] * psy_tab[sidx[kk]];
+        dd = LH_SIDX(kk);
+        ecb = s3[k] * eb[kk] * psy_tab[LH_SIDX(kk)];
         ++k, ++kk;
         while (kk <= last) {
-            dd += sidx[kk];
+            dd += LH_SIDX(kk);
             dd_n += 1;
-            x = s3[k] * eb[kk] * psy_tab[sidx[kk]];
+            x = s3[k] * eb[kk] * psy_tab[LH_SIDX(kk)];
             t = lh_mask_add(log_table, table2, ma_max_i1, ma_max_i2, ecb, x, kk - b, delta);
             ecb = t;
             ++k, ++kk;
@@ -469,7 +480,7 @@ lh_compute_masking(const LhCtx & c, int chn, int is_long, const float *energy, f
         ecb *= avg_mask;
         if (is_long) {
             int const bt_old = c.st->blocktype_old[chn & 1];
-            float const n1 = c.st->nb_l1[chn][b], n2 = c.st->nb_l2[chn][b];
+            float const n1 = nb1, n2 = nb2;
             if (bt_old == LH_SHORT_TYPE) {
                 float const ecb_limit = LH_RPELEV * n1;
                 if (ecb_limit > 0)
@@ -493,8 +504,8 @@ lh_compute_masking(const LhCtx & c, int chn, int is_long, const float *energy, f
                     ecb_limit = ecb_limit_1;
                 th = (ecb < ecb_limit) ? ecb : ecb_limit;
             }
-            c.st->nb_l2[chn][b] = n1;
-            c.st->nb_l1[chn][b] = ecb;
+            nb2 = n1;
+            nb1 = ecb;
         }
         else
             th = ecb;
@@ -509,12 +520,10 @@ lh_compute_masking(const LhCtx & c, int chn, int is_long, const float *energy, f
             th = ebb;
         if (masking_lower < 1)
             th *= masking_lower;
-        thr[b] = th;
     }
-    else {
-        eb[b] = 0;
-        thr[b] = 0;
-    }
+#undef LH_SIDX
+    LH_WAVE_SYNC_MEM();         /* every lane has read the indices it needs */
+    thr[b] = th;                /* 0 above the last partition */
     LH_WAVE_SYNC_MEM();
 }
 
@@ -619,8 +628,8 @@ lh_pecalc(const LhTables * T, const float *en, const float *thm, float masking_l
 /* ------------------------------------------------------------------ */
 /* One granule of the psycho-acoustic model for the whole workgroup     */
 /* (reference L3psycho_anal_vbr, psymodel.c:1397-1597).                 */
-LH_STAGEFN void
-lh_psy_granule(int gr)
+LH_STAGEFN LhPsyCarry
+lh_psy_granule(int gr, LhPsyCarry nb)
 {
     LhCtx const c = lh_ctx_load();
     LhLds & L = lh_lds;
@@ -634,12 +643,11 @@ lh_psy_granule(int gr)
     int const n_chn_psy = (cfg->mode == LH_MODE_JOINT_STEREO) ? 4 : cfg->channels;
     int const bufbase = 576 + gr * 576 - LH_FFTOFFSET;      /* bufp[ch] = &inbuf[ch][bufbase] */
 
-    /* (1) one-granule delay: hand last call's en/thm to the caller and keep them as last_thm */
-    for (int t = c.tid; t < 4 * LH_XMIN_N; t += LH_NT) {
-        int const chn = t / LH_XMIN_N, i = t - chn * LH_XMIN_N;
-        L.ratio_en[gr][chn][i] = st->en[chn][i];
-        L.ratio_thm[gr][chn][i] = st->thm[chn][i];
-    }
+    /* (1) one-granule delay: what the last call computed (ring slot `was') are this granule's ratios
+     * and its last_thm; this call's band energies / thresholds go to slot `now' (see LhLds.psy_en).
+     * Every band of a channel the model runs on is rewritten by each call (22 long bands, then the
+     * long->short estimate or the short-block values for the other 39), so nothing needs copying. */
+    int const was = (lh_uni_i(L.psy_slot) + gr) % 3, now = (was + 1) % 3;
     if (c.tid < 4)
         L.tot_ener[gr][c.tid] = st->tot_ener[c.tid];
 
@@ -853,7 +861,8 @@ lh_psy_granule(int gr)
         int const chn = w + 2 * pass;
         if (chn < n_chn_psy)
             lh_compute_masking(c, chn, 1, P.b.energy[chn], &P.eb[chn * 64], &P.thr[chn * 64],
-                               P.smax[w], P.savg[w], P.sidx[w], L.pstart_l, stg_s3, stg_log, stg_psy, stg_t2);
+                               L.pstart_l, stg_s3, stg_log, stg_psy, stg_t2,
+                               nb.n1[pass], nb.n2[pass]);
     }
     LH_SYNC_WG();
     if (cfg->mode == LH_MODE_JOINT_STEREO && (L.uselongblock[0] + L.uselongblock[1]) == 2) {
@@ -872,11 +881,11 @@ lh_psy_granule(int gr)
         int const act = chn < n_chn_psy;
         int const cc = act ? chn : w;
         if ((t & 1) == 0)
-            lh_partition2sfb_wave(&T->psy_l, &P.eb[cc * 64], &P.thr[cc * 64], &st->en[cc][0],
-                                  &st->thm[cc][0], 1, -1.0f, 0, lane, act, P.sidx[w]);
+            lh_partition2sfb_wave(&T->psy_l, &P.eb[cc * 64], &P.thr[cc * 64], &L.psy_en[now][cc][0],
+                                  &L.psy_thm[now][cc][0], 1, -1.0f, 0, lane, act, (int *) P.b.energy[w]);
         else
-            lh_partition2sfb_wave(&T->psy_l_to_s, &P.eb[cc * 64], &P.thr[cc * 64], &st->en[cc][22],
-                                  &st->thm[cc][22], 3, (float) (1. / 64.f), 1, lane, act, P.sidx[w]);
+            lh_partition2sfb_wave(&T->psy_l_to_s, &P.eb[cc * 64], &P.thr[cc * 64], &L.psy_en[now][cc][22],
+                                  &L.psy_thm[now][cc][22], 3, (float) (1. / 64.f), 1, lane, act, (int *) P.b.energy[w]);
     }
     LH_SYNC_WG();
     LH_PA(34, t_psy0);
@@ -892,8 +901,8 @@ lh_psy_granule(int gr)
                               &P.wsamp[1][sblock * LH_BLKSIZE_S], LH_BLKSIZE_S, P.b.energy[chn]);
                 LH_WAVE_SYNC_MEM();
                 lh_compute_masking(c, chn, 0, P.b.energy[chn], &P.eb[chn * 64], &P.thr[chn * 64],
-                                   P.smax[w], P.savg[w], P.sidx[w], L.pstart_s, T->psy_s.s3, T->log_table, lh_psy_tab,
-                                   lh_mask_table2);
+                                   L.pstart_s, T->psy_s.s3, T->log_table, lh_psy_tab,
+                                   lh_mask_table2, nb.n1[pass], nb.n2[pass]);    /* short: left alone */
             }
         }
         LH_SYNC_WG();
@@ -909,8 +918,8 @@ lh_psy_granule(int gr)
             int const chn = w + 2 * t;
             int const act = chn < n_chn_psy && !L.uselongblock[chn & 1];
             int const cc = (chn < n_chn_psy) ? chn : w;
-            lh_partition2sfb_wave(&T->psy_s, &P.eb[cc * 64], &P.thr[cc * 64], &st->en[cc][22 + sblock],
-                                  &st->thm[cc][22 + sblock], 3, -1.0f, 0, lane, act, P.sidx[w]);
+            lh_partition2sfb_wave(&T->psy_s, &P.eb[cc * 64], &P.thr[cc * 64], &L.psy_en[now][cc][22 + sblock],
+                                  &L.psy_thm[now][cc][22 + sblock], 3, -1.0f, 0, lane, act, (int *) P.b.energy[w]);
         }
         LH_SYNC_WG();
     }
@@ -920,12 +929,12 @@ lh_psy_granule(int gr)
         float const pcfact = 0.6f;
         for (int t = c.tid; t < n_chn_psy * LH_SBMAX_S; t += LH_NT) {
             int const chn = t / LH_SBMAX_S, sb = t - chn * LH_SBMAX_S;
-            const float *last_thm = &L.ratio_thm[gr][chn][22 + sb * 3];
+            const float *last_thm = &L.psy_thm[was][chn][22 + sb * 3];
             float   new_thmm[3], prev_thm, t1, t2, thmm;
             int const last_att = st->last_attacks[chn];
             for (int sblock = 0; sblock < 3; sblock++) {
                 int const a0 = L.ns_attacks[chn][sblock], a1 = L.ns_attacks[chn][sblock + 1];
-                thmm = st->thm[chn][22 + sb * 3 + sblock];
+                thmm = L.psy_thm[now][chn][22 + sb * 3 + sblock];
                 thmm = (float) (thmm * LH_PREECHO_ATT0);
                 t1 = t2 = thmm;
                 if (sblock > 0)
@@ -958,7 +967,7 @@ lh_psy_granule(int gr)
                 new_thmm[sblock] = thmm;
             }
             for (int sblock = 0; sblock < 3; sblock++)
-                st->thm[chn][22 + sb * 3 + sblock] = new_thmm[sblock];
+                L.psy_thm[now][chn][22 + sb * 3 + sblock] = new_thmm[sblock];
         }
     }
     LH_SYNC_WG();
@@ -1011,11 +1020,11 @@ lh_psy_granule(int gr)
             if (lane < nterms) {
                 int const idx = is_short ? 22 + lane : lane;
                 float const coef = is_short ? lh_regcoef_s[lane / 3] : lh_regcoef_l[lane];
-                float const t = L.ratio_thm[gr][chn][idx];
+                float const t = L.psy_thm[was][chn][idx];
                 double  term = 0.0;
                 if (t > 0.0f) {
                     float const x = t * st->masking_lower;
-                    float const e = L.ratio_en[gr][chn][idx];
+                    float const e = L.psy_en[was][chn][idx];
                     if (e > x) {
                         if (e > x * 1e10f)
                             term = coef * (10.0f * 2.30258509299404568402);
@@ -1036,6 +1045,7 @@ lh_psy_granule(int gr)
         }
     }
     LH_SYNC_WG();
+    return nb;
 }
 
 #endif

@@ -242,7 +242,7 @@ lh_choose_table_wave(const LhCtx & c, const int v[5][2], int lo, int hi, int *bi
                     y = 15u;
                     w1++;
                 }
-                e = qt->largetbl[(x << 4) + y];
+                e = lh_largetbl[(x << 4) + y];     /* the constant in HBM: not a hot path */
                 w0 += e;        /* high half: table 16.. lengths, low half: table 24.. lengths */
             }
         }
@@ -345,7 +345,7 @@ lh_choose_table_lane(const LhQTabs * qt, const int16_t * ix, int lo, int hi, int
                 y = 15u;
                 n15++;
             }
-            e = qt->largetbl[(x << 4) + y];
+            e = lh_largetbl[(x << 4) + y];     /* the constant in HBM: not a hot path */
             sa += e >> 16;
             sb += e & 0xffffu;
         }
@@ -563,12 +563,9 @@ lh_noquant_count_bits(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, int w
              * and the results are added to the accumulators of the pair's region.  Blocks of
              * 64 pairs above big_values are skipped (wave-uniform). */
             LhRegionLut l0, l1, l2;     /* = lh_region_lut(m), tabulated in LDS */
-            l0.pa = qt->lut_pa[m0 < 16u ? m0 : 16u];
-            l0.pb = qt->lut_pb[m0 < 16u ? m0 : 16u];
-            l1.pa = qt->lut_pa[m1 < 16u ? m1 : 16u];
-            l1.pb = qt->lut_pb[m1 < 16u ? m1 : 16u];
-            l2.pa = qt->lut_pa[m2 < 16u ? m2 : 16u];
-            l2.pb = qt->lut_pb[m2 < 16u ? m2 : 16u];
+            l0 = lh_region_lut(m0);
+            l1 = lh_region_lut(m1);
+            l2 = lh_region_lut(m2);
             unsigned v0[5], v1[5];
             w00 = w01 = w10 = w11 = w20 = w21 = 0;
 #pragma unroll
@@ -584,7 +581,7 @@ lh_noquant_count_bits(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, int w
                     unsigned const b1 = qt->ht_len[(pa >> 16) + idx];
                     unsigned const b2 = qt->ht_len[(pb & 0xffffu) + idx];
                     unsigned const b3 = qt->ht_len[(pb >> 16) + idx];
-                    unsigned const e = qt->largetbl[idx & 255u];
+                    unsigned const e = lh_largetbl[idx & 255u];
                     int const esc = (pa >> 8) & 1u;
                     v0[k] = esc ? e : (b1 | (b2 << 16));
                     v1[k] = esc ? (unsigned) (x >= 15u) + (unsigned) (y >= 15u) : b3;
@@ -838,8 +835,11 @@ lh_calc_xmin(int qch, int gr, int rch)
 {
     LhCtx const c = lh_ctx_load();
     LhQR    R = lh_uniform(lh_lds.rg[qch].R);
-    lh_calc_xmin_body(c, lh_lds.u.quant.ch[qch], R, lh_lds.xr[qch][gr], lh_lds.ratio_en[gr][rch],
-                      lh_lds.ratio_thm[gr][rch]);
+    {
+        int const slot = (lh_uni_i(lh_lds.psy_slot) + gr) % 3;   /* the granule's ratios: see LhLds.psy_en */
+        lh_calc_xmin_body(c, lh_lds.u.quant.ch[qch], R, lh_lds.xr[qch][gr], lh_lds.psy_en[slot][rch],
+                          lh_lds.psy_thm[slot][rch]);
+    }
     if (c.lane == 0)
         lh_lds.rg[qch].R = R;
     LH_WAVE_SYNC();
@@ -1203,7 +1203,7 @@ lh_bhd_pair_words(const LhQTabs * qt, unsigned x, unsigned y, unsigned w[LH_BHD_
     w[4] = (v8 ? t10 : 0u) | ((v8 ? t11 : 0u) << 16);
     w[5] = (v8 ? t12 : 0u) | ((v16 ? t13 : 0u) << 16);
     w[6] = (v16 ? t14 : 0u) | ((v16 ? t15 : 0u) << 16);
-    w[7] = qt->largetbl[i16];
+    w[7] = lh_largetbl[i16];
     w[8] = (unsigned) (x >= 15u) + (unsigned) (y >= 15u);
     w[9] = (m != 0u);
 }

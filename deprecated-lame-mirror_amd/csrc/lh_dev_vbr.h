@@ -713,7 +713,7 @@ lh_vbr_granule(int qch, int gr, int rch, int pass, int gate, int target, int sub
     LhCtx const c = lh_ctx_load();
     LhLds & L = lh_lds;
     LhChanLds & Q = L.u.quant.ch[qch];
-    LhVbrSave & sv = L.u.quant.vbr[gr][qch];
+    LhVbrSave & sv = L.vbr[gr][qch];
     float  *xr = L.xr[qch][gr];
     int const s = c.lane;
     int const sc = s < LH_SFBMAX ? s : LH_SFBMAX;
@@ -730,7 +730,10 @@ lh_vbr_granule(int qch, int gr, int rch, int pass, int gate, int target, int sub
     lh_init_outer_loop_body(c, Q, R, g, xr, lh_uni_i(L.block_type[gr][qch]), lh_uni_i(substep), pass == 0);
     LH_PA(15, t_a);
     if (pass == 0) {
-        lh_calc_xmin_body(c, Q, R, xr, L.ratio_en[gr][rch], L.ratio_thm[gr][rch]);
+        {
+            int const slot = (lh_uni_i(L.psy_slot) + gr) % 3;
+            lh_calc_xmin_body(c, Q, R, xr, L.psy_en[slot][rch], L.psy_thm[slot][rch]);
+        }
     }
     else
         R.mnc = lh_uni_i(sv.mnc);
@@ -1008,7 +1011,7 @@ lh_vbr_frame(LhFrameOut * fo_in, int mode_ext, int msoff)
         use_gr[gr] = 0;
         use_ch[gr][1] = 0;
         for (int ch = 0; ch < nch; ch++) {
-            LhVbrSave const &sv = L.u.quant.vbr[gr][ch];
+            LhVbrSave const &sv = L.vbr[gr][ch];
             if (lh_uni_i(sv.ath_over))
                 analog_silence = 0;
             if (!lh_uni_i(sv.nonzero))
@@ -1042,7 +1045,7 @@ lh_vbr_frame(LhFrameOut * fo_in, int mode_ext, int msoff)
         used = 0;
         for (int gr = 0; gr < 2; gr++)
             for (int ch = 0; ch < nch; ch++)
-                used += lh_uni_i(L.u.quant.vbr[gr][ch].use_bits);
+                used += lh_uni_i(L.vbr[gr][ch].use_bits);
     }
     /* smallest frame that holds the bits; a larger one while the reservoir could not take the rest */
     {

@@ -92,7 +92,6 @@ LH_DEVFN void
 lh_load_qtabs(const LhCtx & c, LhQTabs & q)
 {
     for (int i = c.tid; i < 256; i += LH_NT) {
-        q.largetbl[i] = lh_largetbl[i];
         q.pow43h[i] = c.T->pow43[i];
         q.adj43h[i] = c.T->adj43asm[i];
     }
@@ -108,11 +107,6 @@ lh_load_qtabs(const LhCtx & c, LhQTabs & q)
     if (c.tid == 0) {
         q.sfb_s3 = (uint16_t) c.T->sfb_s[3];
         q.pad = 0;
-    }
-    if (c.tid < 17) {
-        LhRegionLut const r = lh_region_lut((unsigned) c.tid);
-        q.lut_pa[c.tid] = r.pa;
-        q.lut_pb[c.tid] = r.pb;
     }
     if (c.tid < 32)
         lq_class_tabs(c.tid, &q.ctabA[c.tid], &q.ctabB[c.tid]);
@@ -177,7 +171,7 @@ lh_store_granule(const LhCtx & c, const LhChanLds & Q, const LhQR & R, const LhG
 
 /* one frame of one stream; executed by the whole workgroup */
 LH_DEVFN void
-lh_encode_frame(LhCtx & c, LhFrameOut * fo)
+lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
 {
     LhLds & L = lh_lds;
     const LhConfig *cfg = c.cfg;
@@ -198,8 +192,9 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo)
         lh_stage_window(c, L.mf, c.frame_base - 1152);
         LH_SYNC_WG();
         lh_polyphase(w);
-        for (int i = lane; i < 576; i += 64)
-            st->sb_prev[w][i] = L.u.mdct.sb[w][2][i];
+#pragma unroll
+        for (int k = 0; k < 9; k++)
+            carry.sb[k] = L.u.mdct.sb[w][2][lane + 64 * k];
         LH_SYNC_WG();
         if (tid == 0)
             st->primed = 1;
@@ -211,7 +206,10 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo)
 
     /* ---- padding (reference encoder.c:348-352) ---- */
     int     padding = 0;
-    int     slot_lag = st->slot_lag - cfg->frac_SpF;
+    /* Frame-level scalars are the same in every lane; lh_uni_*() says so to the compiler, which then
+     * keeps them in scalar registers across the stage calls instead of in vector registers that
+     * the stages would have to save to scratch memory (scratch that falls out of the L2 is HBM traffic). */
+    int     slot_lag = lh_uni_i(st->slot_lag) - lh_uni_i(cfg->frac_SpF);
     if (slot_lag < 0) {
         slot_lag += cfg->samplerate;
         padding = 1;
@@ -222,7 +220,7 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo)
     /* ---- stage 1: psycho-acoustic model, two granules ---- */
     LH_PT(t_psy);
     for (int gr = 0; gr < 2; gr++)
-        lh_psy_granule(gr);
+        carry.nb = lh_psy_granule(gr, carry.nb);
     LH_PA(1, t_psy);
 
     float   ms_ener_ratio[2] = { .5f, .5f };
@@ -231,7 +229,7 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo)
             float   r = L.tot_ener[gr][2] + L.tot_ener[gr][3];
             if (r > 0)
                 r = L.tot_ener[gr][3] / r;
-            ms_ener_ratio[gr] = r;
+            ms_ener_ratio[gr] = lh_uni_f(r);
         }
     }
 
@@ -256,13 +254,15 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo)
     LH_PA(25, t_frame);
     /* ---- stage 2: polyphase + MDCT (reference encoder.c:405) ---- */
     LH_PT(t_mdct);
-    for (int i = lane; i < 576; i += 64)
-        L.u.mdct.sb[w][0][i] = st->sb_prev[w][i];
+#pragma unroll
+    for (int k = 0; k < 9; k++)
+        L.u.mdct.sb[w][0][lane + 64 * k] = carry.sb[k];
     lh_polyphase(w);
     LH_SYNC_WG();               /* last read of mf (both channels) before xr overwrites it */
     lh_mdct_granules(w);
-    for (int i = lane; i < 576; i += 64)
-        st->sb_prev[w][i] = L.u.mdct.sb[w][2][i];
+#pragma unroll
+    for (int k = 0; k < 9; k++)
+        carry.sb[k] = L.u.mdct.sb[w][2][lane + 64 * k];
     LH_SYNC_WG();
     LH_PA(2, t_mdct);
     lh_load_qtabs(c, L.qt);     /* mf is dead; xr stays */
@@ -291,6 +291,7 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo)
                 mode_ext = LH_MPG_MD_MS_LR;
         }
     }
+    mode_ext = lh_uni_i(mode_ext);
     int const msoff = (mode_ext == LH_MPG_MD_MS_LR) ? 2 : 0;
 
     /* ---- PE smoothing FIR (reference encoder.c:489-518) ---- */
@@ -314,7 +315,7 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo)
         f = (670 * 5 * 2 * nch) / f;
         for (int gr = 0; gr < 2; gr++)
             for (int ch = 0; ch < nch; ch++)
-                pe_use[gr][ch] *= f;
+                pe_use[gr][ch] = lh_uni_f(pe_use[gr][ch] * f);
         LH_SYNC_WG();
         if (tid < 19)
             st->pefirbuf[tid] = buf[tid];
@@ -322,11 +323,11 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo)
 
     LH_PA(26, t_frame);
     /* ---- stage 4: CBR iteration loop (reference quantize.c:1988-2050) ---- */
-    int     ResvSize = st->ResvSize, ResvMax, mdb = st->main_data_begin;
-    int     substep = st->substep_shaping;
-    int     bitrate_index = cfg->bitrate_index;
-    int     frame_bits = lh_frame_bits(cfg, bitrate_index, padding);
-    int     mean_bits = (frame_bits - cfg->sideinfo_len * 8) / cfg->mode_gr;
+    int     ResvSize = lh_uni_i(st->ResvSize), ResvMax, mdb = lh_uni_i(st->main_data_begin);
+    int     substep = lh_uni_i(st->substep_shaping);
+    int     bitrate_index = lh_uni_i(cfg->bitrate_index);
+    int     frame_bits = lh_uni_i(lh_frame_bits(cfg, bitrate_index, padding));
+    int     mean_bits = lh_uni_i((frame_bits - cfg->sideinfo_len * 8) / cfg->mode_gr);
     int     total_bits = 0;
     int const vbr_new = (cfg->vbr == 1 || cfg->vbr == 4), abr = (cfg->vbr == 3);
     int     abr_targ[2][2] = { {0, 0}, {0, 0} }, analog_silence_bits = 0;
@@ -357,13 +358,20 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo)
             ResvMax = resvLimit;
         if (ResvMax < 0 || cfg->disable_reservoir)
             ResvMax = 0;
+        ResvMax = lh_uni_i(ResvMax);
     }
+    if (abr)
+        for (int gr = 0; gr < 2; gr++)
+            for (int ch = 0; ch < 2; ch++)
+                abr_targ[gr][ch] = lh_uni_i(abr_targ[gr][ch]);
+    analog_silence_bits = lh_uni_i(analog_silence_bits);
     for (int gr = 0; gr < 2 && !vbr_new; gr++) {
         int     targ_bits[2] = { abr_targ[gr][0], abr_targ[gr][1] };
         int     max_bits = 0;
         if (!abr)
             max_bits = lh_on_pe(cfg, ResvSize, ResvMax, &substep, pe_use[gr], targ_bits, mean_bits, gr);
         LH_SYNC_WG();
+        substep = lh_uni_i(substep);
         if (mode_ext == LH_MPG_MD_MS_LR) {
             float const k = (float) (LH_SQRT2 * 0.5);
             for (int i = tid; i < 576; i += LH_NT) {
@@ -375,6 +383,8 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo)
             if (!abr)
                 lh_reduce_side(targ_bits, ms_ener_ratio[gr], mean_bits, max_bits);
         }
+        targ_bits[0] = lh_uni_i(targ_bits[0]);
+        targ_bits[1] = lh_uni_i(targ_bits[1]);
         LH_SYNC_WG();
         if (w >= nch) {
             /* no second channel: its payload slot is all zero */
@@ -431,8 +441,11 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo)
                 L.bits_used[ch] = g.part2_3_length + g.part2_length;
         }
         LH_SYNC_WG();
-        ResvSize -= L.bits_used[0] + L.bits_used[1];
-        total_bits += L.bits_used[0] + L.bits_used[1];
+        {
+            int const used = lh_uni_i(L.bits_used[0] + L.bits_used[1]);
+            ResvSize -= used;
+            total_bits += used;
+        }
         LH_SYNC_WG();
     }
     if (abr) {
@@ -544,6 +557,17 @@ lh_encode_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, 
     c.pcm = pcm;
     c.pcmf = pcmf;
     c.d = descs[sidx];
+    /* the descriptor is the same for the whole workgroup: scalar registers (see lh_encode_frame) */
+    c.d.pcm_l = lh_uni_ll(c.d.pcm_l);
+    c.d.pcm_r = lh_uni_ll(c.d.pcm_r);
+    c.d.pcm_base = lh_uni_ll(c.d.pcm_base);
+    c.d.nsamples = lh_uni_ll(c.d.nsamples);
+    c.d.out_index = lh_uni_ll(c.d.out_index);
+    c.d.frame_begin = lh_uni_i(c.d.frame_begin);
+    c.d.frame_end = lh_uni_i(c.d.frame_end);
+    c.d.bytes_base = lh_uni_ll(c.d.bytes_base);
+    c.d.bytes_cap = lh_uni_ll(c.d.bytes_cap);
+    c.d.flush = lh_uni_i(c.d.flush);
     c.tid = (int) threadIdx.x;
     c.lane = c.tid & 63;
     c.wave = lh_uni_i(c.tid >> 6);      /* scalar: everything indexed by the wave id gets scalar addressing */
@@ -567,11 +591,44 @@ lh_encode_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, 
         L.pstart_l[c.tid] = (uint16_t) a;
         L.pstart_s[c.tid] = (uint16_t) b;
     }
+    /* State that is rewritten every frame stays on the chip for the whole launch: the polyphase
+     * overlap and the psy model's previous partition energies in registers (LhWaveCarry), its band
+     * energies / thresholds in the LDS ring (LhLds.psy_en).  HBM sees them once per launch. */
+    LhWaveCarry carry;
+    LhStreamState *st = c.st;
+    for (int p = 0; p < 2; p++) {
+        carry.nb.n1[p] = st->nb_l1[c.wave + 2 * p][c.lane];
+        carry.nb.n2[p] = st->nb_l2[c.wave + 2 * p][c.lane];
+    }
+#pragma unroll
+    for (int k = 0; k < 9; k++)
+        carry.sb[k] = st->sb_prev[c.wave][c.lane + 64 * k];
+    for (int t = c.tid; t < 4 * LH_XMIN_N; t += LH_NT) {
+        int const chn = t / LH_XMIN_N, i = t - chn * LH_XMIN_N;
+        L.psy_en[0][chn][i] = st->en[chn][i];
+        L.psy_thm[0][chn][i] = st->thm[chn][i];
+    }
+    int     slot = 0;           /* ring slot holding the ratios of the frame's first granule */
     for (int f = c.d.frame_begin; f < c.d.frame_end; f++) {
         c.frame_base = 1152LL * f - LH_MF_START;
-        if (c.tid == 0)
+        if (c.tid == 0) {
             L.ctx.frame_base = c.frame_base;    /* read by the stages after the next workgroup barrier */
-        lh_encode_frame(c, &out[c.d.out_index + (f - c.d.frame_begin)]);
+            L.psy_slot = slot;
+        }
+        lh_encode_frame(c, &out[c.d.out_index + (f - c.d.frame_begin)], carry);
+        slot = (slot + 2) % 3;
+    }
+    for (int p = 0; p < 2; p++) {
+        st->nb_l1[c.wave + 2 * p][c.lane] = carry.nb.n1[p];
+        st->nb_l2[c.wave + 2 * p][c.lane] = carry.nb.n2[p];
+    }
+#pragma unroll
+    for (int k = 0; k < 9; k++)
+        st->sb_prev[c.wave][c.lane + 64 * k] = carry.sb[k];
+    for (int t = c.tid; t < 4 * LH_XMIN_N; t += LH_NT) {
+        int const chn = t / LH_XMIN_N, i = t - chn * LH_XMIN_N;
+        st->en[chn][i] = L.psy_en[slot][chn][i];
+        st->thm[chn][i] = L.psy_thm[slot][chn][i];
     }
 }
 

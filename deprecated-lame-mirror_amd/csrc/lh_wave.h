@@ -218,6 +218,7 @@ static inline void lh_lds_max(int *p, int v) { if (v > *p) *p = v; }
 static inline void lh_lds_addf(float *p, float v) { *p += v; }
 static inline int lh_uni_i(int v) { return v; }
 static inline float lh_uni_f(float v) { return v; }
+static inline long long lh_uni_ll(long long v) { return v; }
 static inline int lh_ffs64(uint64_t m) { return m ? __builtin_ctzll(m) : -1; }
 static inline int lh_popc64(uint64_t m) { return __builtin_popcountll(m); }
 static inline int lh_clz64(uint64_t m) { return m ? __builtin_clzll(m) : 64; }
@@ -439,6 +440,12 @@ __device__ __forceinline__ void lh_lds_addf(float *p, float v) { (void) __hip_at
  * register and everything derived from it -- branches, address arithmetic -- is scalar. */
 __device__ __forceinline__ int lh_uni_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ float lh_uni_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ __forceinline__ long long lh_uni_ll(long long v)
+{
+    unsigned const lo = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) (unsigned long long) v);
+    unsigned const hi = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) ((unsigned long long) v >> 32));
+    return (long long) (((unsigned long long) hi << 32) | lo);
+}
 __device__ __forceinline__ int lh_ffs64(uint64_t m) { return m ? (__ffsll((long long) m) - 1) : -1; }
 __device__ __forceinline__ int lh_popc64(uint64_t m) { return __popcll(m); }
 __device__ __forceinline__ int lh_clz64(uint64_t m) { return __clzll((long long) m); }

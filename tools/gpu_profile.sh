@@ -10,6 +10,17 @@ ARGS=${*:---streams 1024 --seconds 5 --steps 2 --warmup 1 --no-cpu-baseline --no
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+if [ "${TRAFFIC_ONLY:-0}" = 1 ]; then
+  # only the two memory-side passes: bytes the L2 exchanged with the fabric per launch
+  for set in FETCH_SIZE WRITE_SIZE; do
+    timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/pmc_${TAG}_$set -- python $ROOT/bench.py $ARGS > $OUT/pmc_${TAG}_$set.log 2>&1
+    python $ROOT/tools/pmc_summary.py $OUT/pmc_${TAG}_$set lh_encode
+    rm -rf $OUT/pmc_${TAG}_$set
+  done > $OUT/summ_${TAG}_traffic.txt
+  tail -1 $OUT/pmc_${TAG}_WRITE_SIZE.log | cut -c1-300 >> $OUT/summ_${TAG}_traffic.txt
+  cat $OUT/summ_${TAG}_traffic.txt
+  exit 0
+fi
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$TAG -- python $ROOT/bench.py $ARGS > $OUT/kt_$TAG.log 2>&1
 f=$(find $OUT/kt_$TAG -name '*kernel_stats.csv' | head -1)
 { echo "# rocprofv3 --kernel-trace --stats -- python bench.py $ARGS"; [ -n "$f" ] && cat "$f"; tail -1 $OUT/kt_$TAG.log; } > $OUT/summ_${TAG}_kernel_stats.txt
