@@ -44,7 +44,7 @@ struct LhQS {
     int     tselw, tselb;
     /* lanes 0..15: ipow20[210 + lane] and IXMAX / ipow20[210 + lane].  ipow20[g] = 2^(-3 (g - 210) / 16) as
      * the host rounded it, and ipow20[210 + 16 a + b] = ldexp(ipow20[210 + b], -3 a) holds for the
-     * whole table (checked by lh_tables_check() on the host: a power of two scales exactly), so
+     * whole table (checked by power_tables_scale_exactly() in lh_host_init.c: a power of two scales exactly), so
      * these 16 values give 1 / step and the xrpow bound of count_bits for every global_gain */
     float   istepv, thrv;
     int     sbg8;               /* lane = band: 8 * subblock_gain[window] of the working image */
@@ -537,7 +537,7 @@ lq_calc_noise(const LhCtx & c, LhQS & S, LhQR & R, const LhGrR & g, LhChanLds & 
     int const fresh = (s < R.psymax) && !(S.pnstep == st);
     /* POW20(st) = 2^((st - 210) / 4): one of four mantissas (the table's own entries for 210..213,
      * in scalar registers) times a power of two -- pow20[i + 4] = 2 pow20[i] holds for the whole
-     * table (lh_tables_check()), so no table look-up is needed */
+     * table (power_tables_scale_exactly(), lh_host_init.c), so no table look-up is needed */
     float   step;
     {
         int const d = st - 210, q = d >> 2, r = d & 3;

@@ -1,0 +1,36 @@
+"""Arithmetic identities the CBR search (lh_dev_qloop.h) relies on instead of restating the reference's
+expression literally.  Each is checked here exhaustively over the domain the kernel uses it on.
+
+1. First rounding of the quantiser (reference takehiro.c:227-253, TAKEHIRO_IEEE754_HACK): the
+   reference forms (float) ((double) x + 8388608.0); the kernel forms x + 8388608.0f.  Equal for every
+   float 0 <= x < 8206.0 (IXMAX_VAL + 14: larger values are rejected before quantising).
+2. The step tables scale by exact powers of two: pow20[k + 4] == 2 pow20[k], ipow20[k + 16] ==
+   ipow20[k] / 8, which is what lets the kernel rebuild any entry from a few mantissas with ldexp
+   (the host refuses to initialise otherwise: power_tables_scale_exactly, lh_host_init.c).
+"""
+import numpy as np
+
+import helpers  # noqa: F401  (puts the package on sys.path)
+
+
+def test_float_addition_equals_the_double_rounding_for_every_quantisable_float():
+    magic = np.float32(8388608.0)
+    top = int(np.float32(8206.0).view(np.uint32))
+    chunk = 1 << 24
+    bad = 0
+    for lo in range(0, top + 1, chunk):
+        x = np.arange(lo, min(lo + chunk, top + 1), dtype=np.uint32).view(np.float32)
+        ref = (x.astype(np.float64) + 8388608.0).astype(np.float32)
+        mine = x + magic
+        bad += int(np.count_nonzero(ref.view(np.uint32) != mine.view(np.uint32)))
+    assert bad == 0
+
+
+def test_step_tables_scale_by_exact_powers_of_two():
+    import lamehip
+    enc = lamehip.Encoder(44100, 128, require_device=False)
+    T = enc.tables()
+    pow20 = np.ctypeslib.as_array(T.pow20).astype(np.float32)
+    ipow20 = np.ctypeslib.as_array(T.ipow20).astype(np.float32)
+    assert np.array_equal(pow20[4:], pow20[:-4] * np.float32(2.0))
+    assert np.array_equal(ipow20[16:], ipow20[:-16] / np.float32(8.0))
