@@ -46,6 +46,29 @@ lh_fabsf(float x)
     return lh_u32_as_f32(lh_f32_as_u32(x) & 0x7fffffffu);
 }
 
+/* inclusive prefix sum over the wave */
+LH_DEVFN uint32_t
+lh_wave_scan_u32(uint32_t v)
+{
+#ifdef LH_EMU
+    const uint64_t *x = hipemu_wave_exchange(v);
+    uint32_t s = 0;
+    int const me = lh_lane();
+    for (int i = 0; i <= me; i++)
+        s += (uint32_t) x[i];
+    return s;
+#else
+    /* row_shr 1, 2, 4, 8 inside the 16-lane rows, then row_bcast 15 / 31 across them */
+    v += lh_dpp < 0x111, 0u > (v);
+    v += lh_dpp < 0x112, 0u > (v);
+    v += lh_dpp < 0x114, 0u > (v);
+    v += lh_dpp < 0x118, 0u > (v);
+    v += lh_dpp_rows < 0x142, 0xa, 0u > (v);
+    v += lh_dpp_rows < 0x143, 0xc, 0u > (v);
+    return v;
+#endif
+}
+
 /* ---- LDS layout ---------------------------------------------------- */
 struct LhPsyLds {
     float   wsamp[2][LH_BLKSIZE];       /* FHT work buffers of L and R (3x256 for short blocks) */
@@ -444,6 +467,39 @@ lh_stage_window(const LhCtx & c, float (*mf)[LH_MF_NEEDED], long long base)
             mf[1][i] = 0.0f;
         }
         return;
+    }
+    {
+        /* The usual frame: the whole window lies inside the stream and inside the pool, and both planes
+         * start on an even element -- no clamping, two samples per load, all loads of a thread in
+         * flight at once (16 dwords: 952 pairs per channel over 128 threads). */
+        long long const lo = base, hi = base + LH_MF_NEEDED - 1;
+        long long const ol = c.d.pcm_l + (base - c.d.pcm_base), orr = c.d.pcm_r + (base - c.d.pcm_base);
+        int const inside = lo >= 0 && lo >= c.d.pcm_base && hi <= last && ((ol | orr) & 1) == 0;
+        if (lh_uni_i(inside)) {
+            const uint32_t *pl = (const uint32_t *) (c.pcm + ol), *pr = (const uint32_t *) (c.pcm + orr);
+            uint32_t v[16];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                int const j = c.tid + LH_NT * u;
+                int const jj = j < LH_MF_NEEDED / 2 ? j : LH_MF_NEEDED / 2 - 1;
+                v[u] = pl[jj];
+                v[8 + u] = pr[jj];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                int const j = c.tid + LH_NT * u;
+                if (j < LH_MF_NEEDED / 2) {
+                    lh_f32x2 a, b;
+                    a.x = (float) (int16_t) (v[u] & 0xffffu) * scale;
+                    a.y = (float) (int16_t) (v[u] >> 16) * scale;
+                    b.x = (float) (int16_t) (v[8 + u] & 0xffffu) * scale_r;
+                    b.y = (float) (int16_t) (v[8 + u] >> 16) * scale_r;
+                    ((lh_f32x2 *) mf[0])[j] = a;
+                    ((lh_f32x2 *) mf[1])[j] = b;
+                }
+            }
+            return;
+        }
     }
     for (int t0 = c.tid; t0 < 2 * LH_MF_NEEDED; t0 += 6 * LH_NT) {
         int16_t v[6];

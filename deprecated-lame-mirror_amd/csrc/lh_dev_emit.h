@@ -34,29 +34,6 @@
 #define LH_COLDFN __device__ __attribute__((noinline, cold))
 #endif
 
-/* inclusive prefix sum over the wave */
-LH_DEVFN uint32_t
-lh_wave_scan_u32(uint32_t v)
-{
-#ifdef LH_EMU
-    const uint64_t *x = hipemu_wave_exchange(v);
-    uint32_t s = 0;
-    int const me = lh_lane();
-    for (int i = 0; i <= me; i++)
-        s += (uint32_t) x[i];
-    return s;
-#else
-    /* row_shr 1, 2, 4, 8 inside the 16-lane rows, then row_bcast 15 / 31 across them */
-    v += lh_dpp < 0x111, 0u > (v);
-    v += lh_dpp < 0x112, 0u > (v);
-    v += lh_dpp < 0x114, 0u > (v);
-    v += lh_dpp < 0x118, 0u > (v);
-    v += lh_dpp_rows < 0x142, 0xa, 0u > (v);
-    v += lh_dpp_rows < 0x143, 0xc, 0u > (v);
-    return v;
-#endif
-}
-
 LH_DEVFN void
 lh_lds_or(uint32_t * p, uint32_t v)
 {

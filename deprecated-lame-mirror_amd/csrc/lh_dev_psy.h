@@ -411,6 +411,31 @@ lh_mask_index(LhPsyBand const *gd, int b, float m0, float m1, float m2, float a0
     return k;
 }
 
+/* lh_mask_add() for a partition outside the band around the diagonal (|kk - b| > delta), where the
+ * reference only asks whether the ratio of the two maskers is below ma_max_i2: larger + smaller, or
+ * the larger alone (psymodel.c:294-341, the tail after the `b <= delta' block).  The ratio itself
+ * is not needed for that: with t = c * lo, hi < t (1 - 2^-20) implies hi / lo < pred(c), so the
+ * correctly rounded quotient is < c, and hi > t (1 + 2^-20) implies hi / lo > c, so it is >= c; in
+ * between (or when t is not a normal number) the quotient is formed as the reference forms it.
+ * No division and no table on the chain, which is what the wave waits for. */
+LH_DEVFN float
+lh_mask_add_far(float m1, float m2, float c)
+{
+    float const a = (m1 < 0) ? 0.0f : m1, b = (m2 < 0) ? 0.0f : m2;
+    float const hi = (a < b) ? b : a, lo = (a < b) ? a : b;
+    float const t = c * lo;
+    int const sure_lt = hi < t * 0.99999905f, sure_ge = hi > t * 1.00000095f;
+    float   res = sure_lt ? (a + b) : hi;
+    int const unsure = (lo > 0) && (!(sure_lt || sure_ge) || lo < 1e-30f || hi > 1e30f);
+    if (lh_ballot(unsure)) {
+        if (unsure) {
+            float const ratio = (b > a) ? b / a : a / b;
+            res = (ratio < c) ? (a + b) : hi;
+        }
+    }
+    return res;
+}
+
 /* Partition energies + tonality + spreading for one pseudo-channel, one lane per
  * partition.  is_long selects the long-block variant with the pre-echo clamp
  * against the two previous granules (reference psymodel.c:1134-1262) or the
@@ -425,56 +450,129 @@ lh_compute_masking(const LhCtx & c, int chn, int is_long, const float *energy, f
      * (reference PsyStateVar_t.nb_l1 / nb_l2, psymodel.c:1235-1256), lane = partition: lane-local, so
      * they live in a register of the lane for the whole launch (lh_encode_kernel) */
     /* s3 / log_table / psy_tab / table2: the spreading matrix and the small tables of the
-     * masking addition, either in HBM (LhTables, constants) or staged in LDS by the caller: the
-     * spreading loop makes three to four dependent look-ups in them per step */
+     * masking addition, either in HBM (LhTables, constants) or staged in LDS by the caller */
     float const ma_max_i1 = c.T->ma_max_i1, ma_max_i2 = c.T->ma_max_i2;
     LhPsyBand const *gd = is_long ? &c.T->psy_l : &c.T->psy_s;
     int const b = c.lane;
     int const np = gd->npart;
+    int const on = b < np;
     float   ebb = 0, m = 0, avg = 0, th = 0;
-    if (b < np) {
-        int const n = gd->numlines[b];
-        int     j = pstart[b];
-        for (int i = 0; i < n; ++i, ++j) {
-            float const el = energy[j];
-            ebb += el;
-            if (m < el)
-                m = el;
+    int     tone;
+    LH_PT(t_mk);
+    LQ_MARK("mk_sums");
+    {
+        /* A partition's energy is the sum of its lines in order (up to 83 of them for the widest
+         * one); the loads do not depend on the sum, so eight go out together and the additions follow. */
+        int const n = on ? gd->numlines[b] : 0;
+        int const j0 = on ? pstart[b] : 0;
+        float const rn = on ? gd->rnumlines[b] : 0.0f;
+        int const nmax = lh_uni_i((int) lh_wave_max_u32((uint32_t) n));
+        for (int i = 0; i < nmax; i += 8) {
+            float   el[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+                el[q] = energy[j0 + ((i + q < n) ? i + q : 0)];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                /* a term beyond the partition's end is replaced by +0.0f: sum and maximum (both
+                 * non-negative) stay as they are */
+                float const e = (i + q < n) ? el[q] : 0.0f;
+                ebb += e;
+                m = __builtin_fmaxf(m, e);
+            }
         }
-        avg = ebb * gd->rnumlines[b];
+        avg = ebb * rn;
     }
     eb[b] = ebb;                /* 0 above the last partition */
+    LH_PA(14, t_mk);
+    LQ_MARK("mk_tone");
     {
-        /* The tonality index needs the neighbours' maximum and average: lane exchanges.  The indices
-         * of the whole channel then sit in thr[] (as bit patterns) until the thresholds, which each
-         * lane writes over its own index when every lane is through with the spreading, replace them. */
+        /* The tonality index needs the neighbours' maximum and average: lane exchanges.  What the
+         * spreading reads of a partition kk is its energy and the factor psy_tab[index[kk]]: the
+         * factors of the whole channel sit in thr[] until the thresholds, which each lane writes
+         * over its own factor when every lane is through with the spreading, replace them. */
         int const lo = (b > 0) ? b - 1 : 0, hi = (b < 63) ? b + 1 : 63;
         float const m0 = lh_shfl_f32(m, lo), m2 = lh_shfl_f32(m, hi);
         float const a0 = lh_shfl_f32(avg, lo), a2 = lh_shfl_f32(avg, hi);
-        int const k = (b < np) ? lh_mask_index(gd, b, m0, m, m2, a0, avg, a2) : 0;
-        thr[b] = lh_u32_as_f32((unsigned) k);
+        tone = on ? lh_mask_index(gd, b, m0, m, m2, a0, avg, a2) : 0;
+        thr[b] = psy_tab[tone];
+    }
+    /* The reference walks kk = s3ind[b][0] .. s3ind[b][1], adding partition kk's spread energy to the
+     * running sum with mask_add(), whose expensive branch (a division, fast_log2, table2) only applies
+     * within delta = 2, 1, 0 or -1 partitions of b.  All lanes walk together and the diagonal comes at
+     * a different step for each, so the walk is laid out relative to the diagonal: n1 steps ending at
+     * kk = b - 3 (cheap rule), the five steps kk = b - 2 .. b + 2 (expensive rule where |kk - b| <=
+     * delta), n3 steps from kk = b + 3 (cheap rule); a lane sits out the steps outside its own range.
+     * The order of a lane's additions is the reference's. */
+    int const first = on ? gd->s3ind[b][0] : 1, last = on ? gd->s3ind[b][1] : 0;
+    int const krel = (on ? gd->s3_row[b] : 0) - first;  /* s3 index of partition kk = krel + kk */
+    int const delta = lh_mask_add_delta[tone];
+    float   ecb = 0;
+    int     dd, n1, n3;
+    {
+        /* sum of the indices over the lane's range, from the wave's prefix sums; trip counts */
+        uint32_t const P = lh_wave_scan_u32((uint32_t) tone);
+        uint32_t const pl = lh_shfl_u32(P, last & 63), pf = lh_shfl_u32(P, (first - 1) & 63);
+        uint32_t t[2];
+        dd = (int) (pl - ((first > 0) ? pf : 0u));
+        t[0] = (uint32_t) ((on && b - 3 - first > 0) ? b - 3 - first : 0);
+        t[1] = (uint32_t) ((on && last - b - 2 > 0) ? last - b - 2 : 0);
+        lh_wave_max_n < 2 > (t);
+        n1 = lh_uni_i((int) t[0]);
+        n3 = lh_uni_i((int) t[1]);
     }
     LH_WAVE_SYNC_MEM();
-#define LH_SIDX(i) ((int) lh_f32_as_u32(thr[i]))
-    if (b < np) {
-        float   x, ecb, avg_mask, t;
-        float const masking_lower = gd->masking_lower[b] * c.st->masking_lower;
-        int     k = gd->s3_row[b];
-        int     kk = gd->s3ind[b][0];
-        int const last = gd->s3ind[b][1];
-        int const delta = lh_mask_add_delta[LH_SIDX(b)];
-        int     dd, dd_n = 1;
-        dd = LH_SIDX(kk);
-        ecb = s3[k] * eb[kk] * psy_tab[LH_SIDX(kk)];
-        ++k, ++kk;
-        while (kk <= last) {
-            dd += LH_SIDX(kk);
-            dd_n += 1;
-            x = s3[k] * eb[kk] * psy_tab[LH_SIDX(kk)];
-            t = lh_mask_add(log_table, table2, ma_max_i1, ma_max_i2, ecb, x, kk - b, delta);
-            ecb = t;
-            ++k, ++kk;
+#define LH_SPREAD_X(kk_) (s3[krel + (kk_)] * eb[(kk_)] * thr[(kk_)])
+    if (on)
+        ecb = LH_SPREAD_X(first);
+    {
+        int     kk = b - 2 - n1;
+        int     act = kk > first && kk <= last;
+        float   x = LH_SPREAD_X(act ? kk : first);
+        for (int j = 0; j < n1; j++) {
+            int const act_n = (kk + 1 > first) && (kk + 1 <= last) && (j + 1 < n1);
+            float const xn = LH_SPREAD_X(act_n ? kk + 1 : first);
+            float const r = lh_mask_add_far(ecb, x, ma_max_i2);
+            ecb = act ? r : ecb;
+            x = xn;
+            act = act_n;
+            ++kk;
         }
+    }
+    for (int j = 0; j < 5; j++) {
+        int const kk = b - 2 + j;
+        int const act = kk > first && kk <= last;
+        int const d = (j < 2) ? 2 - j : j - 2;          /* |kk - b| */
+        int const near = act && d <= delta;
+        float const x = LH_SPREAD_X(act ? kk : first);
+        float   r = lh_mask_add_far(ecb, x, ma_max_i2);
+        if (lh_ballot(near)) {
+            if (near)
+                r = lh_mask_add(log_table, table2, ma_max_i1, ma_max_i2, ecb, x, d, delta);
+        }
+        ecb = act ? r : ecb;
+    }
+    {
+        int     kk = b + 3;
+        int     act = kk > first && kk <= last;
+        float   x = LH_SPREAD_X(act ? kk : first);
+        for (int j = 0; j < n3; j++) {
+            int const act_n = (kk + 1 > first) && (kk + 1 <= last);
+            float const xn = LH_SPREAD_X(act_n ? kk + 1 : first);
+            float const r = lh_mask_add_far(ecb, x, ma_max_i2);
+            ecb = act ? r : ecb;
+            x = xn;
+            act = act_n;
+            ++kk;
+        }
+    }
+#undef LH_SPREAD_X
+    LH_PA(16, t_mk);
+    LQ_MARK("mk_tail");
+    if (on) {
+        float   x, avg_mask;
+        float const masking_lower = gd->masking_lower[b] * c.st->masking_lower;
+        int const dd_n = last - first + 1;
         dd = (1 + 2 * dd) / (2 * dd_n);
         avg_mask = psy_tab[dd] * 0.5f;
         ecb *= avg_mask;
@@ -521,10 +619,11 @@ lh_compute_masking(const LhCtx & c, int chn, int is_long, const float *energy, f
         if (masking_lower < 1)
             th *= masking_lower;
     }
-#undef LH_SIDX
-    LH_WAVE_SYNC_MEM();         /* every lane has read the indices it needs */
+    LH_WAVE_SYNC_MEM();         /* every lane has read the factors it needs */
     thr[b] = th;                /* 0 above the last partition */
     LH_WAVE_SYNC_MEM();
+    LH_PA(17, t_mk);
+    LQ_MARK("mk_end");
 }
 
 /* reference psymodel.c:1326-1388; one lane per partition, eb/thr are [4][64] in LDS */
@@ -816,34 +915,47 @@ lh_psy_granule(int gr, LhPsyCarry nb)
     LH_PA(31, t_psy0);
     /* (5) serial sums: total energy (bins 11..512) and loudness (reference psymodel.c:213-226,
      * 690-696): lane 0/1 = tot_ener of chn w / w+2, lane 2 = loudness of channel w */
-    if (lane < 3) {
+    {
+        /* Lane 0 / 1 add up the power spectrum of chn w / w + 2 in bin order, lane 2 the products
+         * energy[w][j] * eql_w[j].  The products are independent of each other: all lanes form them
+         * (256 at a time, into the partition arrays, which are idle until stage 6) so that the three
+         * chains have nothing but LDS reads and their own additions on the critical path.  Terms
+         * outside a sum's range are replaced by +0.0f, which leaves a non-negative sum unchanged. */
         int const chn = (lane == 1) ? w + 2 : w;
-        if (chn < n_chn_psy) {
-            /* One instruction stream for the three sums: acc += e[j] * m[j], with m = 1.0f for
-             * the energy sums (x * 1.0f is x) and m = eql_w for the loudness; terms outside a
-             * sum's range are replaced by +0.0f, which leaves a non-negative sum unchanged.
-             * Four terms per load keep the dependent additions, not the loads, on the
-             * critical path. */
-            const float *e = P.b.energy[chn];
-            const float *ew = T->ath_eql_w;
-            int const loud = (lane == 2);
-            int const lo = loud ? 0 : 11;
-            float   acc = 0.0f;
-            for (int j = 0; j < 12; j++) {
-                float const m = loud ? ew[j] : 1.0f;
-                float const t = e[j] * m;
-                acc += (j >= lo) ? t : 0.0f;
+        int const summing = lane < 3 && chn < n_chn_psy;
+        int const loud = (lane == 2);
+        int const lo = loud ? 0 : 11;
+        float  *prod = (w == 0) ? P.eb : P.thr;         /* [256] per wave */
+        const float *ew = T->ath_eql_w;
+        const float *e = P.b.energy[summing ? chn : w];
+        float   acc = 0.0f;
+        for (int h = 0; h < 2; h++) {
+            int const j0 = 256 * h;
+            LH_WAVE_SYNC_MEM();
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                int const j = j0 + lane + 64 * q;
+                prod[j - j0] = P.b.energy[w][j] * ew[j];
             }
-            for (int j = 12; j < LH_BLKSIZE / 2; j += 4) {
-                lh_f32x4 const v = *(const lh_f32x4 *) &e[j];
-                lh_f32x4 m = *(const lh_f32x4 *) &ew[j];
-                if (!loud)
-                    m.x = m.y = m.z = m.w = 1.0f;
-                acc += v.x * m.x;
-                acc += v.y * m.y;
-                acc += v.z * m.z;
-                acc += v.w * m.w;
+            LH_WAVE_SYNC_MEM();
+            if (summing) {
+                const float *src = loud ? prod - j0 : e;
+                int     j = j0;
+                if (h == 0) {
+                    for (; j < 12; j++)
+                        acc += (j >= lo) ? src[j] : 0.0f;
+                }
+#pragma unroll 4
+                for (; j < j0 + 256; j += 4) {
+                    lh_f32x4 const u = *(const lh_f32x4 *) &src[j];
+                    acc += u.x;
+                    acc += u.y;
+                    acc += u.z;
+                    acc += u.w;
+                }
             }
+        }
+        if (summing) {
             if (!loud) {
                 acc += e[LH_BLKSIZE / 2];
                 st->tot_ener[chn] = acc;
@@ -854,6 +966,7 @@ lh_psy_granule(int gr, LhPsyCarry nb)
                 st->loudness_sq_save[w] = acc;
             }
         }
+        LH_WAVE_SYNC_MEM();
     }
     LH_PA(32, t_psy0);
     /* (6) masking thresholds, long blocks */

@@ -163,6 +163,13 @@ lh_shfl_f32(float v, int src)
     return c.f;
 }
 
+static inline uint32_t
+lh_shfl_u32(uint32_t v, int src)
+{
+    const uint64_t *x = hipemu_wave_exchange(v);
+    return (uint32_t) x[src & 63];
+}
+
 
 /* an integer sum and a float maximum (no NaNs) at once */
 static inline void
@@ -362,6 +369,12 @@ __device__ __forceinline__ float
 lh_shfl_f32(float v, int src)
 {
     return __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(v)));
+}
+
+__device__ __forceinline__ uint32_t
+lh_shfl_u32(uint32_t v, int src)
+{
+    return (uint32_t) __builtin_amdgcn_ds_bpermute(src << 2, (int) v);
 }
 
 /* an integer sum and a float maximum (no NaNs) at once: the two chains' steps side by side */
