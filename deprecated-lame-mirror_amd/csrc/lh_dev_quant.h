@@ -1249,17 +1249,12 @@ lh_bhd_build(const LhCtx & c, LhChanLds & Q, int bigv, int *tab, int *bmx)
     LH_WAVE_SYNC();
 }
 
-/* choose_table for the bands [blo, bhi) from the prefix tables; qw != 0: the pair whose words are
- * qw (it lies in band bq) is taken out again and band bq's maximum is mq */
+/* choose_table for the bands [blo, bhi), whose largest value is mx, from the prefix tables; qw != 0:
+ * the pair whose words are qw is taken out again */
 LH_DEVFN int
-lh_bhd_region(const int *tab, const int *bmx, int blo, int bhi, const unsigned *qw, int bq, int mq, int *bits)
+lh_bhd_region(const int *tab, unsigned mx, int blo, int bhi, const unsigned *qw, int *bits)
 {
-    unsigned mx = 0, w0, w1, d[LH_BHD_NW];
-    for (int b = 0; b < LH_SBMAX_L; b++) {
-        unsigned const m = (unsigned) ((qw && b == bq) ? mq : bmx[b]);
-        if (b >= blo && b < bhi && m > mx)
-            mx = m;
-    }
+    unsigned w0, w1, d[LH_BHD_NW];
     if (mx == 0)
         return 0;
 #pragma unroll
@@ -1296,22 +1291,57 @@ lh_bhd_region(const int *tab, const int *bmx, int blo, int bhi, const unsigned *
     return lh_region_decide(mx, w0, w1, bits);
 }
 
+/* lane l holds v[l]: *below = max(v[0 .. l)), *from = max(v[l .. 63]) (log-step scans through lane
+ * exchanges; the two chains run side by side) */
+LH_DEVFN void
+lh_bhd_scan_max(int lane, unsigned v, unsigned *below, unsigned *from)
+{
+    unsigned p = v, q = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        unsigned const tp = lh_shfl_u32(p, (lane - d) & 63), tq = lh_shfl_u32(q, (lane + d) & 63);
+        p = (lane >= d && tp > p) ? tp : p;
+        q = (lane + d < 64 && tq > q) ? tq : q;
+    }
+    {
+        unsigned const e = lh_shfl_u32(p, (lane - 1) & 63);
+        *below = lane > 0 ? e : 0u;
+    }
+    *from = q;
+}
+
+/* exclusive running minimum over the lanes: min(v[0 .. l)) (0x7fffffff for lane 0) */
+LH_DEVFN unsigned
+lh_bhd_scan_min_excl(int lane, unsigned v)
+{
+    unsigned p = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        unsigned const tp = lh_shfl_u32(p, (lane - d) & 63);
+        p = (lane >= d && tp < p) ? tp : p;
+    }
+    {
+        unsigned const e = lh_shfl_u32(p, (lane - 1) & 63);
+        return lane > 0 ? e : 0x7fffffffu;
+    }
+}
+
 LH_DEVFN void
 lh_best_huffman_divide_body(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g)
 {
-    const LhTables *T = c.T;
     const LhQTabs *qt = LH_QT;
     const int16_t *ix = Q.ix[0];
-    int    *r01_bits = (int *) Q.save_xrpow + 400;      /* [23]; save_xrpow is dead here: scratch */
-    int    *r01_div = r01_bits + 24;    /* [23] */
-    int    *r0_tbl = r01_bits + 48;     /* [23] */
-    int    *r1_tbl = r01_bits + 72;     /* [23] */
+    int const lane = c.lane;
     int const bigv0 = g.big_values;
     int const count1bits0 = g.count1bits;
-    int     i, a1, a2;
     int    *tab = (int *) Q.xrpow;      /* xrpow is dead after the outer loop: per-band length sums */
     int    *bmx = tab + LH_BHD_NW * LH_BHD_STRIDE;
+    /* what lane s keeps for the region split with r0 + r1 = s (recalc_divide_init's r01_bits / r01_div /
+     * r0_tbl / r1_tbl, reference takehiro.c:809-870) */
+    int     s_bits = LH_LARGE_BITS, s_div = 0, s_t0 = 0, s_t1 = 0;
+    unsigned band_max = 0, max_from = 0;        /* lane = band: its maximum; the maximum of the bands from it on */
 
+    LH_PT(t_bhd);
     LH_WAVE_SYNC();
     if (R.block_type == LH_NORM_TYPE) {
         /* recalc_divide_init: lanes 0..15 cost region 0 for r0 = lane; then each of the
@@ -1320,56 +1350,78 @@ lh_best_huffman_divide_body(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGr
         int    *r0t_a = r0bits_a + 16;                /* [16] */
         int    *comb_bits = r0bits_a + 32;            /* [128] */
         int    *comb_tbl = comb_bits + 128;           /* [128] */
+        unsigned max_below;
+        int     nr0;
         lh_bhd_build(c, Q, bigv0, tab, bmx);
-        if (c.lane < 16) {
-            int const r0 = c.lane;
-            int const e1 = qt->sfb_l[r0 + 1];
-            int     b = 0, t = 0;
-            if (e1 < bigv0)
-                t = lh_bhd_region(tab, bmx, 0, r0 + 1, 0, 0, 0, &b);
-            r0bits_a[r0] = b;
-            r0t_a[r0] = t;
+        LH_PA(18, t_bhd);
+        band_max = (lane < LH_SBMAX_L) ? (unsigned) bmx[lane] : 0u;
+        lh_bhd_scan_max(lane, band_max, &max_below, &max_from);
+        /* the reference's loops over r0 stop at the first band boundary >= big_values: boundaries ascend */
+        nr0 = lh_popc64(lh_ballot(lane < 16 && (int) qt->sfb_l[lane < 16 ? lane + 1 : 0] < bigv0));
+        {
+            /* region 0 = bands [0, r0]: its maximum is the next lane's `below' (exchanged by all lanes:
+             * a lane that sits out cannot be read from) */
+            unsigned const mx0 = lh_shfl_u32(max_below, (lane + 1) & 63);
+            if (lane < 16) {
+                int const r0 = lane;
+                int     b = 0, t = 0;
+                if (r0 < nr0)
+                    t = lh_bhd_region(tab, mx0, 0, r0 + 1, 0, &b);
+                r0bits_a[r0] = b;
+                r0t_a[r0] = t;
+            }
         }
         LH_WAVE_SYNC();
-        for (int cmb = c.lane; cmb < 128; cmb += 64) {
+        LH_PA(19, t_bhd);
+        for (int cmb = lane; cmb < 128; cmb += 64) {
             int const r0 = cmb >> 3, r1 = cmb & 7;
-            int const e1 = qt->sfb_l[r0 + 1];
-            int const e2 = qt->sfb_l[r0 + r1 + 2];
+            int const hi = r0 + r1 + 2;
+            int const e2 = qt->sfb_l[hi < 23 ? hi : 23];
             int     b = LH_LARGE_BITS, t = 0;
-            if (e1 < bigv0 && e2 < bigv0) {
+            if (r0 < nr0 && e2 < bigv0) {
+                unsigned mx = 0;
+                for (int bd = r0 + 1; bd < hi; bd++) {
+                    unsigned const m = (unsigned) bmx[bd];
+                    mx = m > mx ? m : mx;
+                }
                 b = r0bits_a[r0];
-                t = lh_bhd_region(tab, bmx, r0 + 1, r0 + r1 + 2, 0, 0, 0, &b);
+                t = lh_bhd_region(tab, mx, r0 + 1, hi, 0, &b);
             }
             comb_bits[cmb] = b;
             comb_tbl[cmb] = t;
         }
         LH_WAVE_SYNC();
-        if (c.lane < 23) {
-            /* first minimum in (r0 ascending, r1 ascending) order for r0 + r1 = lane */
-            int const sidx = c.lane;
-            int     bestb = LH_LARGE_BITS, bd = 0, bt0 = 0, bt1 = 0;
-            for (int r0 = 0; r0 < 16; r0++) {
-                int const r1 = sidx - r0;
-                /* the reference's loops stop at the first boundary >= bigv */
-                if (qt->sfb_l[r0 + 1] >= bigv0)
-                    break;
-                if (r1 < 0 || r1 > 7)
-                    continue;
-                if (qt->sfb_l[r0 + r1 + 2] >= bigv0)
-                    continue;
-                if (bestb > comb_bits[r0 * 8 + r1]) {
-                    bestb = comb_bits[r0 * 8 + r1];
-                    bd = r0;
-                    bt0 = r0t_a[r0];
-                    bt1 = comb_tbl[r0 * 8 + r1];
+        LH_PA(20, t_bhd);
+        if (lane < 23) {
+            /* first minimum in (r0 ascending) order over the splits with r0 + r1 = lane: r0 runs over
+             * at most eight values, and whether region 1 ends below big_values depends on the sum only */
+            int const sidx = lane;
+            int const ok2 = (int) qt->sfb_l[sidx + 2 < 23 ? sidx + 2 : 23] < bigv0;
+            int const lo = sidx > 7 ? sidx - 7 : 0, hi = (sidx < nr0 - 1) ? sidx : nr0 - 1;
+            int     v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                int const r0 = (lo + u <= hi) ? lo + u : lo;
+                v[u] = comb_bits[(r0 * 8 + sidx - r0) & 127];
+            }
+            if (ok2) {
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    if (lo + u <= hi && s_bits > v[u]) {
+                        s_bits = v[u];
+                        s_div = lo + u;
+                    }
                 }
             }
-            r01_bits[sidx] = bestb;
-            r01_div[sidx] = bd;
-            r0_tbl[sidx] = bt0;
-            r1_tbl[sidx] = bt1;
+            if (s_bits < LH_LARGE_BITS) {
+                s_t0 = r0t_a[s_div];
+                s_t1 = comb_tbl[s_div * 8 + sidx - s_div];
+            }
+            else
+                s_div = 0;
         }
         LH_WAVE_SYNC();
+        LH_PA(21, t_bhd);
     }
     /* recalc_divide_sub against (bigv, count1bits): first with the original counts,
      * then (maybe) with one more quadruple moved into the count1 region */
@@ -1384,19 +1436,33 @@ lh_best_huffman_divide_body(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGr
             c1sel = g.count1table_select;
         }
         else {
-            i = bigv0;
+            int     i = bigv0, a1, a2, nq;
             if (i == 0 || (unsigned) (ix[i - 2] | ix[i - 1]) > 1)
                 return;
             i = g.count1 + 2;
             if (i > 576)
                 return;
             c1 = i;
-            a1 = a2 = 0;
-            for (; i > g.big_values; i -= 4) {
-                int const p = ((ix[i - 4] * 2 + ix[i - 3]) * 2 + ix[i - 2]) * 2 + ix[i - 1];
-                a1 += qt->t32l[p];
-                a2 += qt->t33l[p];
+            /* the quadruples from c1 down to big_values, counted with both count1 tables: one lane
+             * per quadruple (up to 144 of them) */
+            nq = (c1 - g.big_values + 3) >> 2;
+            {
+                const uint32_t *ix2 = (const uint32_t *) ix;
+                unsigned acc = 0;
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    int const q = lane + 64 * k;
+                    int const top = c1 - 4 * q;                 /* the quadruple is ix[top - 4 .. top - 1] */
+                    int const tc = (q < nq) ? top : 4;
+                    uint32_t const u0 = ix2[(tc - 4) >> 1], u1 = ix2[(tc - 2) >> 1];
+                    unsigned const idx = ((((u0 & 1u) * 2 + ((u0 >> 16) & 1u)) * 2 + (u1 & 1u)) * 2 + ((u1 >> 16) & 1u));
+                    acc += (q < nq) ? qt->t3233[idx] : 0u;
+                }
+                acc = lh_wave_sum_u32(acc);
+                a1 = (int) (acc >> 16);
+                a2 = (int) (acc & 0xffffu);
             }
+            i = c1 - 4 * nq;
             bigv = i;
             c1sel = 0;
             if (a1 > a2) {
@@ -1410,7 +1476,7 @@ lh_best_huffman_divide_body(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGr
                 int     p23 = a1, t0 = g.table_select[0], t1 = g.table_select[1];
 #pragma unroll
                 for (int k = 0; k < 5; k++) {
-                    int const p = c.lane + 64 * k;
+                    int const p = lane + 64 * k;
                     v[k][0] = (p < 288) ? ix[2 * p] : 0;
                     v[k][1] = (p < 288) ? ix[2 * p + 1] : 0;
                 }
@@ -1434,65 +1500,69 @@ lh_best_huffman_divide_body(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGr
             }
         }
         {
-            /* lane r2 costs region 2 = [sfb_l[r2], bigv) */
-            int    *r2bits = (int *) Q.save_xrpow + 320;      /* [23] */
-            int    *r2tbl = r2bits + 32;                      /* [23] */
-            /* second pass: the pair [bigv, bigv0) has moved to the count1 region; it is taken
-             * out of the band sums (its values are 0/1, so its band's maximum can only drop
-             * from 1 to 0, and only when it was the band's last non-zero pair) */
+            /* lane r2 costs region 2 = [sfb_l[r2], bigv).  Second pass: the pair [bigv, bigv0) has moved
+             * to the count1 region; it is taken out of the band sums (its values are 0/1, so its
+             * band's maximum can only drop from 1 to 0, and only when it was the band's last
+             * non-zero pair) */
             unsigned qw[LH_BHD_NW];
             int const minus_q = (pass == 1 && bigv == bigv0 - 2);
-            int     bq = 0, mq = 0;
-            if (minus_q) {
+            unsigned mfrom = max_from;
+            int     r2b = 0, r2t = 0, lower, live;
+            if (pass == 1) {
+                /* (always the case for long blocks: big_values and count1 differ by whole quadruples) */
                 uint32_t const v = ((const uint32_t *) ix)[(bigv0 >> 1) - 1];
-                bq = Q.sfb_of_line[bigv0 - 2];
+                int const bq = Q.sfb_of_line[bigv0 - 2];
+                unsigned below;
+                int     mq;
                 lh_bhd_pair_words(qt, v & 0xffffu, v >> 16, qw);
                 mq = bmx[bq];
                 if (mq == 1 && v != 0u
                     && tab[9 * LH_BHD_STRIDE + bq + 1] - tab[9 * LH_BHD_STRIDE + bq] == 1)
                     mq = 0;
+                lh_bhd_scan_max(lane, (lane == bq) ? (unsigned) mq : band_max, &below, &mfrom);
+                if (!minus_q)
+                    return;     /* not reachable for long blocks; the reference's general case is not built */
             }
-            LH_WAVE_SYNC();
-            if (c.lane >= 2 && c.lane < LH_SBMAX_L + 1) {
-                int const r2 = c.lane;
-                int const e2 = qt->sfb_l[r2];
-                int     b = 0, t = 0;
-                if (e2 < bigv) {
-                    b = r01_bits[r2 - 2] + c1bits;
-                    if (r01_bits[r2 - 2] < LH_LARGE_BITS) {
-                        if (pass == 0 || minus_q)
-                            t = lh_bhd_region(tab, bmx, r2, LH_SBMAX_L, minus_q ? qw : 0, bq, mq, &b);
-                        else
-                            t = lh_choose_table_lane(LH_QT, ix, e2, bigv, &b);
-                    }
+            /* the sum r0 + r1 = r2 - 2 is lane r2 - 2's */
+            lower = (int) lh_shfl_u32((uint32_t) s_bits, (lane - 2) & 63);
+            live = lane >= 2 && lane < LH_SBMAX_L + 1 && (int) qt->sfb_l[(lane >= 2 && lane < 23) ? lane : 0] < bigv;
+            if (live) {
+                r2b = lower + c1bits;
+                if (lower < LH_LARGE_BITS)
+                    r2t = lh_bhd_region(tab, mfrom, lane, LH_SBMAX_L, pass == 1 ? qw : 0, &r2b);
+            }
+            lower += c1bits;
+            {
+                /* The reference walks r2 = 2, 3, ... and stops at the first boundary >= bigv, or when
+                 * the best length so far is <= r01_bits + count1bits; in between it takes every strictly
+                 * better total.  So: the running minimum before each lane, the first lane that stops
+                 * the walk, the first lane below it that reaches the minimum. */
+                unsigned const key = live ? (unsigned) r2b : 0x7fffffffu;
+                unsigned const before0 = lh_bhd_scan_min_excl(lane, (lane >= 2) ? key : 0x7fffffffu);
+                unsigned const p0 = (unsigned) g.part2_3_length;
+                unsigned const before = before0 < p0 ? before0 : p0;
+                uint64_t const stop = lh_ballot(lane >= 2 && (!live || before <= (unsigned) lower));
+                int const brk = lh_ffs64(stop);         /* lane 23 is never live: there is always a stop */
+                unsigned const mine = (lane >= 2 && lane < brk) ? key : 0x7fffffffu;
+                unsigned const best = lh_wave_min_u32(mine);
+                if (best < p0) {
+                    int const sel = lh_ffs64(lh_ballot(mine == best));
+                    g.part2_3_length = (int) best;
+                    g.big_values = bigv;
+                    g.count1 = c1;
+                    g.count1bits = c1bits;
+                    g.count1table_select = c1sel;
+                    g.region0_count = (int) lh_bcast_u32((uint32_t) s_div, sel - 2);
+                    g.region1_count = sel - 2 - g.region0_count;
+                    g.table_select[0] = (int) lh_bcast_u32((uint32_t) s_t0, sel - 2);
+                    g.table_select[1] = (int) lh_bcast_u32((uint32_t) s_t1, sel - 2);
+                    g.table_select[2] = (int) lh_bcast_u32((uint32_t) r2t, sel);
                 }
-                r2bits[r2] = b;
-                r2tbl[r2] = t;
             }
-            LH_WAVE_SYNC();
-            for (int r2 = 2; r2 < LH_SBMAX_L + 1; r2++) {
-                int const e2 = qt->sfb_l[r2];
-                int     bits;
-                if (e2 >= bigv)
-                    break;
-                bits = r01_bits[r2 - 2] + c1bits;
-                if (g.part2_3_length <= bits)
-                    break;
-                bits = r2bits[r2];
-                if (g.part2_3_length <= bits)
-                    continue;
-                g.part2_3_length = bits;
-                g.big_values = bigv;
-                g.count1 = c1;
-                g.count1bits = c1bits;
-                g.count1table_select = c1sel;
-                g.region0_count = r01_div[r2 - 2];
-                g.region1_count = r2 - 2 - r01_div[r2 - 2];
-                g.table_select[0] = r0_tbl[r2 - 2];
-                g.table_select[1] = r1_tbl[r2 - 2];
-                g.table_select[2] = r2tbl[r2];
-            }
-            LH_WAVE_SYNC();
+            if (pass == 0)
+                LH_PA(22, t_bhd);
+            else
+                LH_PA(23, t_bhd);
         }
     }
 }

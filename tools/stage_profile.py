@@ -17,9 +17,9 @@ import lamehip  # noqa: E402
 NAMES = ["frame total", "psy (2 granules)", "polyphase+mdct", "quant total (2 gr)", "init+xrpow+xmin",
          "outer_loop", "scalefac_store+huffman_divide", "  bin_search", "  balance_noise", "  calc_noise",
          "count_bits calls", "count_bits total", "  quantise part", "calc_noise calls", "  mask: partition sums",
-         "  mask: + tonality, prefix sums", "  mask: + spreading", "  mask: total (all calls)", "  cb: loads+band decisions",
-         "  nq: count1/big_values/regions", "  nq: + quads", "  nq: + region maxima", "  nq: + table look-ups",
-         "  nq: + sums", "t: window staged (+ barrier skew)", "t: psy + ATH adjust done",
+         "  mask: + tonality, prefix sums", "  mask: + spreading", "  mask: total (all calls)", "  bhd: band tables built",
+         "  bhd: + region 0 (16 lanes)", "  bhd: + region 1 (128 pairs)", "  bhd: + best (r0, r1) per sum", "  bhd: + first pass done",
+         "  bhd: + second pass done (when it ran to the end)", "t: window staged (+ barrier skew)", "t: psy + ATH adjust done",
          "t: mdct, qtabs, M/S, PE FIR done", "t: granule loop done", "-", "  psy: attack detection", "  psy: + long FFT",
          "  psy: + power spectra, table staging", "  psy: + energy/loudness sums", "  psy: + long masking (+MS)",
          "  psy: + partition->sfb", "  psy: + short blocks", "  psy: + pre-echo",
