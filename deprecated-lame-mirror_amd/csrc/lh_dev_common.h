@@ -69,6 +69,35 @@ lh_wave_scan_u32(uint32_t v)
 #endif
 }
 
+/* inclusive running maximum over the wave (unsigned) */
+LH_DEVFN uint32_t
+lh_wave_scan_max_u32(uint32_t v)
+{
+#ifdef LH_EMU
+    const uint64_t *x = hipemu_wave_exchange(v);
+    uint32_t s = 0;
+    int const me = lh_lane();
+    for (int i = 0; i <= me; i++)
+        s = (uint32_t) x[i] > s ? (uint32_t) x[i] : s;
+    return s;
+#else
+    uint32_t t;
+    t = lh_dpp < 0x111, 0u > (v);
+    v = t > v ? t : v;
+    t = lh_dpp < 0x112, 0u > (v);
+    v = t > v ? t : v;
+    t = lh_dpp < 0x114, 0u > (v);
+    v = t > v ? t : v;
+    t = lh_dpp < 0x118, 0u > (v);
+    v = t > v ? t : v;
+    t = lh_dpp_rows < 0x142, 0xa, 0u > (v);
+    v = t > v ? t : v;
+    t = lh_dpp_rows < 0x143, 0xc, 0u > (v);
+    v = t > v ? t : v;
+    return v;
+#endif
+}
+
 /* ---- LDS layout ---------------------------------------------------- */
 struct LhPsyLds {
     float   wsamp[2][LH_BLKSIZE];       /* FHT work buffers of L and R (3x256 for short blocks) */

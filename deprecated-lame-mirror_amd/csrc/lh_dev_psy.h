@@ -307,28 +307,26 @@ lh_fft_energy(const LhCtx & c, int chn, const float *wl, const float *wr, int n,
  * form b_sb = sb + max(0, max_{k<sb}(bl_k - k)); the band is zero-filled when an earlier band
  * already ran into npart (b_sb - 1 >= npart), and otherwise its sums start from the
  * w_next-weighted value of partition b_sb - 1.  The float additions inside the band keep the
- * reference's order.  `walk' is per-wave LDS scratch of at least n_sb ints; all lanes of the
- * wave must call. */
+ * reference's order.  All lanes of the wave must call. */
 LH_DEVFN void
 lh_partition2sfb_wave(LhPsyBand const *gd, float const *eb, float const *thr, float *enn_out,
                       float *thm_out, int out_stride, float thm_scale, int replicate3, int lane,
-                      int active, int *walk)
+                      int active)
 {
     int const npart = gd->npart;
     int const n_sb = gd->n_sb;
     int const sb = lane;
     float   enn = 0.0f, thmm = 0.0f, tv;
-    int     b, live, m = 0;
-    LH_WAVE_SYNC_MEM();
-    if (lane < n_sb) {
-        int const bo_k = gd->bo[lane];
-        walk[lane] = (bo_k < npart ? bo_k : npart) - lane;
+    int     b, live, m;
+    {
+        /* max_{k < sb} (bl_k - k), at least 0: a running maximum over the lanes, shifted by one */
+        int const bo_k = gd->bo[lane < n_sb ? lane : 0];
+        int const d = (bo_k < npart ? bo_k : npart) - lane;
+        uint32_t const run = lh_wave_scan_max_u32((lane < n_sb && d > 0) ? (uint32_t) d : 0u);
+        uint32_t const prev = lh_shfl_u32(run, (lane - 1) & 63);
+        m = lane > 0 ? (int) prev : 0;
     }
     LH_WAVE_SYNC_MEM();
-    for (int k = 0; k < LH_SBMAX_L; k++) {
-        int const d = walk[k];
-        m = (k < sb && k < n_sb && d > m) ? d : m;
-    }
     b = sb + m;
     live = (sb == 0) || (b - 1 < npart);
     if (!active || sb >= n_sb)
@@ -995,18 +993,23 @@ lh_psy_granule(int gr, LhPsyCarry nb)
         int const cc = act ? chn : w;
         if ((t & 1) == 0)
             lh_partition2sfb_wave(&T->psy_l, &P.eb[cc * 64], &P.thr[cc * 64], &L.psy_en[now][cc][0],
-                                  &L.psy_thm[now][cc][0], 1, -1.0f, 0, lane, act, (int *) P.b.energy[w]);
+                                  &L.psy_thm[now][cc][0], 1, -1.0f, 0, lane, act);
         else
             lh_partition2sfb_wave(&T->psy_l_to_s, &P.eb[cc * 64], &P.thr[cc * 64], &L.psy_en[now][cc][22],
-                                  &L.psy_thm[now][cc][22], 3, (float) (1. / 64.f), 1, lane, act, (int *) P.b.energy[w]);
+                                  &L.psy_thm[now][cc][22], 3, (float) (1. / 64.f), 1, lane, act);
     }
     LH_SYNC_WG();
     LH_PA(34, t_psy0);
     /* (8) short blocks (reference psymodel.c:1470-1500) */
-    if (!L.uselongblock[w])
-        lh_fft_short(c, w, bufbase, &P.wsamp[w][0]);
-    LH_SYNC_WG();
-    for (int sblock = 0; sblock < 3; sblock++) {
+    /* (nothing of it runs when both channels keep long blocks -- the usual granule: the values the
+     * short transforms would replace are the long->short estimates of stage 7) */
+    int const any_short = lh_uni_i(!(L.uselongblock[0] && L.uselongblock[1]));
+    if (any_short) {
+        if (!L.uselongblock[w])
+            lh_fft_short(c, w, bufbase, &P.wsamp[w][0]);
+        LH_SYNC_WG();
+    }
+    for (int sblock = 0; any_short && sblock < 3; sblock++) {
         for (int pass = 0; pass < 2; pass++) {
             int const chn = w + 2 * pass;
             if (chn < n_chn_psy && !L.uselongblock[chn & 1]) {
@@ -1032,7 +1035,7 @@ lh_psy_granule(int gr, LhPsyCarry nb)
             int const act = chn < n_chn_psy && !L.uselongblock[chn & 1];
             int const cc = (chn < n_chn_psy) ? chn : w;
             lh_partition2sfb_wave(&T->psy_s, &P.eb[cc * 64], &P.thr[cc * 64], &L.psy_en[now][cc][22 + sblock],
-                                  &L.psy_thm[now][cc][22 + sblock], 3, -1.0f, 0, lane, act, (int *) P.b.energy[w]);
+                                  &L.psy_thm[now][cc][22 + sblock], 3, -1.0f, 0, lane, act);
         }
         LH_SYNC_WG();
     }
