@@ -322,7 +322,42 @@ struct LhWaveCarry {
     float   sb[9];
 };
 
+/* The stream's small state words (the members of LhStreamState from loudness_sq_save to
+ * ath_adjust_limit and from pefirbuf to status, same order): in LDS for the whole launch, so that
+ * nothing on a frame's dependency chains waits for HBM (read at the start of the launch, written back
+ * at its end by lh_encode_kernel, word for word). */
+struct LhSmallState {
+    float   loudness_sq_save[2];
+    float   tot_ener[4];
+    float   last_en_subshort[4][9];
+    int     last_attacks[4];
+    int     blocktype_old[2];
+    float   ath_adjust_factor;
+    float   ath_adjust_limit;
+    /* -- second run of members -- */
+    float   pefirbuf[19];
+    int     slot_lag;
+    int     ResvSize;
+    int     ResvMax;
+    int     main_data_begin;
+    int     OldValue[2];
+    int     CurrentStep[2];
+    float   masking_lower;
+    int     substep_shaping;
+    int     frame_number;
+    int     primed;
+    int     status;
+};
+#define LH_SS_WORDS_A 50        /* loudness_sq_save .. ath_adjust_limit */
+#define LH_SS_WORDS_B 32        /* pefirbuf .. status */
+static_assert(sizeof(LhSmallState) == 4 * (LH_SS_WORDS_A + LH_SS_WORDS_B), "LhSmallState is two runs of words");
+static_assert(__builtin_offsetof(LhStreamState, ath_adjust_limit) - __builtin_offsetof(LhStreamState, loudness_sq_save)
+              == 4 * (LH_SS_WORDS_A - 1), "first run of LhStreamState's small members");
+static_assert(__builtin_offsetof(LhStreamState, status) - __builtin_offsetof(LhStreamState, pefirbuf)
+              == 4 * (LH_SS_WORDS_B - 1), "second run of LhStreamState's small members");
+
 struct LhLds {
+    LhSmallState ss;
     /* Band energies / thresholds of the psy model, [L,R,M,S] each: a ring of three slots.  The model's
      * output is used one granule late (reference psymodel.c:1397-1460 hands back last call's values), so
      * with c = psy_slot at the start of a frame: slot c = what the previous frame's second granule
@@ -337,12 +372,11 @@ struct LhLds {
     float   tot_ener[2][4];
     float   loudness_sq[2][2];
     float   sub_short_factor[4][3];
-    int     ns_attacks[4][4];
+    int8_t  ns_attacks[4][4];
     int     ns_uselong[4];
     int     uselongblock[2];
     int     next_blocktype[2];
     int     block_type[2][2];   /* [gr][ch] */
-    uint16_t pstart_l[64], pstart_s[64];
     /* frame scalars */
     int     mode_ext, padding, mean_bits, max_bits, frame_bits;
     int     targ_bits[2];

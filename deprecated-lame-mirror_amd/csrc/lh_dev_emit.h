@@ -322,7 +322,7 @@ lh_emit_part_stage(int qch, int gr)
     int const nb = lh_emit_part(c, lh_lds.u.quant.ch[qch], R, g, lh_lds.xr[qch][lh_uni_i(gr)],
                                 c.st->em_part[lh_uni_i(gr)][qch]);
     if (nb != g.part2_3_length + g.part2_length && c.lane == 0)
-        c.st->status |= 4;      /* the packed bits disagree with the quantiser's count */
+        lh_lds.ss.status |= 4;      /* the packed bits disagree with the quantiser's count */
 }
 
 /* One frame's bytes, whole workgroup.  `nbits' = pre + sum of the parts + post (a multiple of 8 by
@@ -437,7 +437,7 @@ lh_emit_frame(const LhFrameOut * fo_in, int drain_pre, int drain_post, int frame
             nq = keep;
         }
         if ((nbits & 7) != 0 && tid == 0)
-            st->status |= 2;    /* the reservoir arithmetic should make every frame's main data whole bytes */
+            lh_lds.ss.status |= 2;    /* the reservoir arithmetic should make every frame's main data whole bytes */
         LH_SYNC_WG();
     }
     if (tid == 0) {

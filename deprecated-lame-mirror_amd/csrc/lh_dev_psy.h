@@ -440,7 +440,7 @@ lh_mask_add_far(float m1, float m2, float c)
  * short-block variant (:1031-1131).  energy = power spectrum in LDS. */
 LH_DEVFN void
 lh_compute_masking(const LhCtx & c, int chn, int is_long, const float *energy, float *eb,
-                   float *thr, const uint16_t *pstart,
+                   float *thr,
                    const float *s3, const float *log_table, const float *psy_tab, const float *table2,
                    float &nb1, float &nb2)
 {
@@ -462,7 +462,7 @@ lh_compute_masking(const LhCtx & c, int chn, int is_long, const float *energy, f
         /* A partition's energy is the sum of its lines in order (up to 83 of them for the widest
          * one); the loads do not depend on the sum, so eight go out together and the additions follow. */
         int const n = on ? gd->numlines[b] : 0;
-        int const j0 = on ? pstart[b] : 0;
+        int const j0 = (int) lh_wave_scan_u32((uint32_t) n) - n;      /* the partition's first line */
         float const rn = on ? gd->rnumlines[b] : 0.0f;
         int const nmax = lh_uni_i((int) lh_wave_max_u32((uint32_t) n));
         for (int i = 0; i < nmax; i += 8) {
@@ -569,13 +569,13 @@ lh_compute_masking(const LhCtx & c, int chn, int is_long, const float *energy, f
     LQ_MARK("mk_tail");
     if (on) {
         float   x, avg_mask;
-        float const masking_lower = gd->masking_lower[b] * c.st->masking_lower;
+        float const masking_lower = gd->masking_lower[b] * lh_lds.ss.masking_lower;
         int const dd_n = last - first + 1;
         dd = (1 + 2 * dd) / (2 * dd_n);
         avg_mask = psy_tab[dd] * 0.5f;
         ecb *= avg_mask;
         if (is_long) {
-            int const bt_old = c.st->blocktype_old[chn & 1];
+            int const bt_old = lh_lds.ss.blocktype_old[chn & 1];
             float const n1 = nb1, n2 = nb2;
             if (bt_old == LH_SHORT_TYPE) {
                 float const ecb_limit = LH_RPELEV * n1;
@@ -746,7 +746,7 @@ lh_psy_granule(int gr, LhPsyCarry nb)
      * long->short estimate or the short-block values for the other 39), so nothing needs copying. */
     int const was = (lh_uni_i(L.psy_slot) + gr) % 3, now = (was + 1) % 3;
     if (c.tid < 4)
-        L.tot_ener[gr][c.tid] = st->tot_ener[c.tid];
+        L.tot_ener[gr][c.tid] = lh_lds.ss.tot_ener[c.tid];
 
     LH_PT(t_psy0);
     /* (2) attack detection (reference psymodel.c:759-940) */
@@ -792,17 +792,17 @@ lh_psy_granule(int gr, LhPsyCarry nb)
                 float   en_short[4] = { 0, 0, 0, 0 };
                 int     nsa[4] = { 0, 0, 0, 0 };
                 int     ns_uselongblock = 1;
-                int const last_att = st->last_attacks[chn];
+                int const last_att = lh_lds.ss.last_attacks[chn];
                 for (int i = 0; i < 3; i++) {
-                    en_subshort[i] = st->last_en_subshort[chn][i + 6];
-                    attack_intensity[i] = en_subshort[i] / st->last_en_subshort[chn][i + 4];
+                    en_subshort[i] = lh_lds.ss.last_en_subshort[chn][i + 6];
+                    attack_intensity[i] = en_subshort[i] / lh_lds.ss.last_en_subshort[chn][i + 4];
                     en_short[0] += en_subshort[i];
                 }
                 LH_WAVE_SYNC_MEM();
                 for (int i = 0; i < 9; i++) {
                     float   p = peak[i];
                     if (lane == 0)
-                        st->last_en_subshort[chn][i] = p;
+                        lh_lds.ss.last_en_subshort[chn][i] = p;
                     en_subshort[i + 3] = p;
                     en_short[1 + i / 3] += p;
                     if (p > en_subshort[i + 3 - 2])
@@ -956,12 +956,12 @@ lh_psy_granule(int gr, LhPsyCarry nb)
         if (summing) {
             if (!loud) {
                 acc += e[LH_BLKSIZE / 2];
-                st->tot_ener[chn] = acc;
+                lh_lds.ss.tot_ener[chn] = acc;
             }
             else {
                 acc = (float) (acc * LH_VO_SCALE);
-                L.loudness_sq[gr][w] = st->loudness_sq_save[w];
-                st->loudness_sq_save[w] = acc;
+                L.loudness_sq[gr][w] = lh_lds.ss.loudness_sq_save[w];
+                lh_lds.ss.loudness_sq_save[w] = acc;
             }
         }
         LH_WAVE_SYNC_MEM();
@@ -972,13 +972,13 @@ lh_psy_granule(int gr, LhPsyCarry nb)
         int const chn = w + 2 * pass;
         if (chn < n_chn_psy)
             lh_compute_masking(c, chn, 1, P.b.energy[chn], &P.eb[chn * 64], &P.thr[chn * 64],
-                               L.pstart_l, stg_s3, stg_log, stg_psy, stg_t2,
+                               stg_s3, stg_log, stg_psy, stg_t2,
                                nb.n1[pass], nb.n2[pass]);
     }
     LH_SYNC_WG();
     if (cfg->mode == LH_MODE_JOINT_STEREO && (L.uselongblock[0] + L.uselongblock[1]) == 2) {
         float const ath_factor =
-            (cfg->msfix > 0.f) ? (cfg->ATH_offset_factor * st->ath_adjust_factor) : 1.f;
+            (cfg->msfix > 0.f) ? (cfg->ATH_offset_factor * lh_lds.ss.ath_adjust_factor) : 1.f;
         if (w == 0)
             lh_ms_thresholds(c, P.eb, P.thr, T->psy_l.mld_cb, T->ath_cb_l, ath_factor, cfg->msfix,
                              T->psy_l.npart);
@@ -1017,14 +1017,14 @@ lh_psy_granule(int gr, LhPsyCarry nb)
                               &P.wsamp[1][sblock * LH_BLKSIZE_S], LH_BLKSIZE_S, P.b.energy[chn]);
                 LH_WAVE_SYNC_MEM();
                 lh_compute_masking(c, chn, 0, P.b.energy[chn], &P.eb[chn * 64], &P.thr[chn * 64],
-                                   L.pstart_s, T->psy_s.s3, T->log_table, lh_psy_tab,
+                                   T->psy_s.s3, T->log_table, lh_psy_tab,
                                    lh_mask_table2, nb.n1[pass], nb.n2[pass]);    /* short: left alone */
             }
         }
         LH_SYNC_WG();
         if (cfg->mode == LH_MODE_JOINT_STEREO && (L.uselongblock[0] + L.uselongblock[1]) == 0) {
             float const ath_factor =
-                (cfg->msfix > 0.f) ? (cfg->ATH_offset_factor * st->ath_adjust_factor) : 1.f;
+                (cfg->msfix > 0.f) ? (cfg->ATH_offset_factor * lh_lds.ss.ath_adjust_factor) : 1.f;
             if (w == 0)
                 lh_ms_thresholds(c, P.eb, P.thr, T->psy_s.mld_cb, T->ath_cb_s, ath_factor,
                                  cfg->msfix, T->psy_s.npart);
@@ -1047,7 +1047,7 @@ lh_psy_granule(int gr, LhPsyCarry nb)
             int const chn = t / LH_SBMAX_S, sb = t - chn * LH_SBMAX_S;
             const float *last_thm = &L.psy_thm[was][chn][22 + sb * 3];
             float   new_thmm[3], prev_thm, t1, t2, thmm;
-            int const last_att = st->last_attacks[chn];
+            int const last_att = lh_lds.ss.last_attacks[chn];
             for (int sblock = 0; sblock < 3; sblock++) {
                 int const a0 = L.ns_attacks[chn][sblock], a1 = L.ns_attacks[chn][sblock + 1];
                 thmm = L.psy_thm[now][chn][22 + sb * 3 + sblock];
@@ -1093,7 +1093,7 @@ lh_psy_granule(int gr, LhPsyCarry nb)
         int     btd[2];
         for (int chn = 0; chn < 2; chn++) {
             int     blocktype = LH_NORM_TYPE;
-            int     old = st->blocktype_old[chn];
+            int     old = lh_lds.ss.blocktype_old[chn];
             if (L.uselongblock[chn]) {
                 if (old == LH_SHORT_TYPE)
                     blocktype = LH_STOP_TYPE;
@@ -1110,7 +1110,7 @@ lh_psy_granule(int gr, LhPsyCarry nb)
         }
         LH_SYNC_WG();
         if (c.tid < 2) {
-            st->blocktype_old[c.tid] = L.next_blocktype[c.tid];
+            lh_lds.ss.blocktype_old[c.tid] = L.next_blocktype[c.tid];
             L.block_type[gr][c.tid] = btd[c.tid];
         }
         /* Perceptual entropy (reference psymodel.c:458-553): the terms coef * log10(en / thr)
@@ -1139,7 +1139,7 @@ lh_psy_granule(int gr, LhPsyCarry nb)
                 float const t = L.psy_thm[was][chn][idx];
                 double  term = 0.0;
                 if (t > 0.0f) {
-                    float const x = t * st->masking_lower;
+                    float const x = t * lh_lds.ss.masking_lower;
                     float const e = L.psy_en[was][chn][idx];
                     if (e > x) {
                         if (e > x * 1e10f)
@@ -1156,7 +1156,7 @@ lh_psy_granule(int gr, LhPsyCarry nb)
                 for (int i = 0; i < nterms; i++)
                     pe = (float) (pe + tmp[i]);
                 L.pe[gr][chn] = pe;
-                st->last_attacks[chn] = L.ns_attacks[chn][2];
+                lh_lds.ss.last_attacks[chn] = L.ns_attacks[chn][2];
             }
         }
     }

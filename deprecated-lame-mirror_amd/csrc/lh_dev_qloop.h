@@ -922,9 +922,9 @@ template < int NS > LH_DEVFN int
 lq_bin_search(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q, int desired_rate, int ch)
 {
     int     nBits;
-    int     CurrentStep = lh_uni_i(c.st->CurrentStep[ch]);
+    int     CurrentStep = lh_uni_i(lh_lds.ss.CurrentStep[ch]);
     int     flag_GoneOver = 0;
-    int const start = lh_uni_i(c.st->OldValue[ch]);
+    int const start = lh_uni_i(lh_lds.ss.OldValue[ch]);
     int     Direction = 0;
     g.global_gain = start;
     desired_rate -= g.part2_length;
@@ -964,8 +964,8 @@ lq_bin_search(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q, int
         nBits = lq_count_bits < 0, NS > (c, S, R, g, Q);
     }
     if (c.lane == 0) {
-        c.st->CurrentStep[ch] = (start - g.global_gain >= 4) ? 4 : 2;
-        c.st->OldValue[ch] = g.global_gain;
+        lh_lds.ss.CurrentStep[ch] = (start - g.global_gain >= 4) ? 4 : 2;
+        lh_lds.ss.OldValue[ch] = g.global_gain;
     }
     g.part2_3_length = nBits;
     return nBits;

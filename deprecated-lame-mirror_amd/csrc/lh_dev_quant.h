@@ -718,7 +718,7 @@ lh_calc_xmin_body(const LhCtx & c, LhChanLds & Q, LhQR & R, const float *xr, con
     const LhTables *T = c.T;
     const LhQTabs *qt = LH_QT;
     int const s = c.lane;
-    float const adj = c.st->ath_adjust_factor;
+    float const adj = lh_lds.ss.ath_adjust_factor;
     int     over = 0;
     if (s < R.psymax) {
         int const is_long = (s < R.psy_lmax);

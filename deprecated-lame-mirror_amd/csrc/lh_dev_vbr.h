@@ -960,7 +960,7 @@ lh_vbr_frame(LhFrameOut * fo_in, int mode_ext, int msoff)
     float   pe_use[2][2] = { {lh_uni_f(L.pe_use[0][0]), lh_uni_f(L.pe_use[0][1])},
     {lh_uni_f(L.pe_use[1][0]), lh_uni_f(L.pe_use[1][1])}
     };
-    int     ResvSize = lh_uni_i(c.st->ResvSize), substep = lh_uni_i(c.st->substep_shaping);
+    int     ResvSize = lh_uni_i(lh_lds.ss.ResvSize), substep = lh_uni_i(lh_lds.ss.substep_shaping);
     int     bitrate_index, total_bits;
     int const maxi = cfg->vbr_max_bitrate_index;
     mode_ext = lh_uni_i(mode_ext);

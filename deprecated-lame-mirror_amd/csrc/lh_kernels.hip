@@ -188,7 +188,7 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
         L.prof[w][lane] = 0;
 #endif
     LH_PT(t_frame);
-    if (!st->primed) {
+    if (!lh_lds.ss.primed) {
         lh_stage_window(c, L.mf, c.frame_base - 1152);
         LH_SYNC_WG();
         lh_polyphase(w);
@@ -197,7 +197,7 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
             carry.sb[k] = L.u.mdct.sb[w][2][lane + 64 * k];
         LH_SYNC_WG();
         if (tid == 0)
-            st->primed = 1;
+            lh_lds.ss.primed = 1;
     }
     LH_SYNC_WG();
 
@@ -209,7 +209,7 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
     /* Frame-level scalars are the same in every lane; lh_uni_*() says so to the compiler, which then
      * keeps them in scalar registers across the stage calls instead of in vector registers that
      * the stages would have to save to scratch memory (scratch that falls out of the L2 is HBM traffic). */
-    int     slot_lag = lh_uni_i(st->slot_lag) - lh_uni_i(cfg->frac_SpF);
+    int     slot_lag = lh_uni_i(lh_lds.ss.slot_lag) - lh_uni_i(cfg->frac_SpF);
     if (slot_lag < 0) {
         slot_lag += cfg->samplerate;
         padding = 1;
@@ -235,7 +235,7 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
 
     /* ---- ATH auto adjustment (reference encoder.c:397) ---- */
     {
-        float   factor = st->ath_adjust_factor, limit = st->ath_adjust_limit;
+        float   factor = lh_lds.ss.ath_adjust_factor, limit = lh_lds.ss.ath_adjust_limit;
         float   loud[2][2];
         loud[0][0] = L.loudness_sq[0][0];
         loud[1][0] = L.loudness_sq[1][0];
@@ -245,8 +245,8 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
         lh_adjust_ATH(T, loud, &factor, &limit);
         LH_SYNC_WG();
         if (tid == 0) {
-            st->ath_adjust_factor = factor;
-            st->ath_adjust_limit = limit;
+            lh_lds.ss.ath_adjust_factor = factor;
+            lh_lds.ss.ath_adjust_limit = limit;
         }
     }
     LH_SYNC_WG();
@@ -299,7 +299,7 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
     {
         float   buf[19], f;
         for (int i = 0; i < 18; i++)
-            buf[i] = st->pefirbuf[i + 1];
+            buf[i] = lh_lds.ss.pefirbuf[i + 1];
         f = 0.0;
         for (int gr = 0; gr < 2; gr++) {
             pe_use[gr][1] = 0.0f;
@@ -318,13 +318,13 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
                 pe_use[gr][ch] = lh_uni_f(pe_use[gr][ch] * f);
         LH_SYNC_WG();
         if (tid < 19)
-            st->pefirbuf[tid] = buf[tid];
+            lh_lds.ss.pefirbuf[tid] = buf[tid];
     }
 
     LH_PA(26, t_frame);
     /* ---- stage 4: CBR iteration loop (reference quantize.c:1988-2050) ---- */
-    int     ResvSize = lh_uni_i(st->ResvSize), ResvMax, mdb = lh_uni_i(st->main_data_begin);
-    int     substep = lh_uni_i(st->substep_shaping);
+    int     ResvSize = lh_uni_i(lh_lds.ss.ResvSize), ResvMax, mdb = lh_uni_i(lh_lds.ss.main_data_begin);
+    int     substep = lh_uni_i(lh_lds.ss.substep_shaping);
     int     bitrate_index = lh_uni_i(cfg->bitrate_index);
     int     frame_bits = lh_uni_i(lh_frame_bits(cfg, bitrate_index, padding));
     int     mean_bits = lh_uni_i((frame_bits - cfg->sideinfo_len * 8) / cfg->mode_gr);
@@ -503,18 +503,18 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
             fo->pad[i] = 0;
         fo->resv_size = ResvSize;
         fo->frame_bits = frame_bits;
-        st->slot_lag = slot_lag;
-        st->ResvSize = ResvSize;
-        st->ResvMax = ResvMax;
-        st->main_data_begin = mdb;
-        st->substep_shaping = substep;
+        lh_lds.ss.slot_lag = slot_lag;
+        lh_lds.ss.ResvSize = ResvSize;
+        lh_lds.ss.ResvMax = ResvMax;
+        lh_lds.ss.main_data_begin = mdb;
+        lh_lds.ss.substep_shaping = substep;
         /* what the next frame's psy model finds in sv_qnt.masking_lower: the CBR loop leaves the value
          * of its last granule/channel (channel 0 for mono), the VBR loop always the long-block one (reference quantize.c:1622) */
-        st->masking_lower = (vbr_new || L.block_type[1][nch - 1] != LH_SHORT_TYPE) ? cfg->masking_lower_long
+        lh_lds.ss.masking_lower = (vbr_new || L.block_type[1][nch - 1] != LH_SHORT_TYPE) ? cfg->masking_lower_long
             : cfg->masking_lower_short;
-        st->frame_number = st->frame_number + 1;
+        lh_lds.ss.frame_number = lh_lds.ss.frame_number + 1;
         if (mdb * 8 != ResvSize)
-            st->status |= 1;    /* reservoir inconsistency (reference bitstream.c:947) */
+            lh_lds.ss.status |= 1;    /* reservoir inconsistency (reference bitstream.c:947) */
     }
     if (lh_uni_i(L.ctx.bytes != nullptr))
         lh_emit_frame(fo, drain_pre, drain_post, frame_bits / 8, mdb_header, bitrate_index, padding, mode_ext,
@@ -581,16 +581,6 @@ lh_encode_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, 
         L.ctx.bytes = bytes;
         L.ctx.d = c.d;
     }
-    /* partition start tables (prefix sums of numlines): constant for the launch, kept in LDS */
-    if (c.tid < 64) {
-        int     a = 0, b = 0;
-        for (int k = 0; k < c.tid; k++) {
-            a += T->psy_l.numlines[k];
-            b += T->psy_s.numlines[k];
-        }
-        L.pstart_l[c.tid] = (uint16_t) a;
-        L.pstart_s[c.tid] = (uint16_t) b;
-    }
     /* State that is rewritten every frame stays on the chip for the whole launch: the polyphase
      * overlap and the psy model's previous partition energies in registers (LhWaveCarry), its band
      * energies / thresholds in the LDS ring (LhLds.psy_en).  HBM sees them once per launch. */
@@ -608,6 +598,11 @@ lh_encode_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, 
         L.psy_en[0][chn][i] = st->en[chn][i];
         L.psy_thm[0][chn][i] = st->thm[chn][i];
     }
+    if (c.tid < LH_SS_WORDS_A)
+        ((uint32_t *) &L.ss)[c.tid] = ((const uint32_t *) &st->loudness_sq_save[0])[c.tid];
+    else if (c.tid < LH_SS_WORDS_A + LH_SS_WORDS_B)
+        ((uint32_t *) &L.ss)[c.tid] = ((const uint32_t *) &st->pefirbuf[0])[c.tid - LH_SS_WORDS_A];
+    LH_SYNC_WG();               /* the state words are read by every thread from here on */
     int     slot = 0;           /* ring slot holding the ratios of the frame's first granule */
     for (int f = c.d.frame_begin; f < c.d.frame_end; f++) {
         c.frame_base = 1152LL * f - LH_MF_START;
@@ -618,6 +613,10 @@ lh_encode_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, 
         lh_encode_frame(c, &out[c.d.out_index + (f - c.d.frame_begin)], carry);
         slot = (slot + 2) % 3;
     }
+    if (c.tid < LH_SS_WORDS_A)
+        ((uint32_t *) &st->loudness_sq_save[0])[c.tid] = ((const uint32_t *) &L.ss)[c.tid];
+    else if (c.tid < LH_SS_WORDS_A + LH_SS_WORDS_B)
+        ((uint32_t *) &st->pefirbuf[0])[c.tid - LH_SS_WORDS_A] = ((const uint32_t *) &L.ss)[c.tid];
     for (int p = 0; p < 2; p++) {
         st->nb_l1[c.wave + 2 * p][c.lane] = carry.nb.n1[p];
         st->nb_l2[c.wave + 2 * p][c.lane] = carry.nb.n2[p];
