@@ -13,6 +13,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+#include <mutex>
 #include <thread>
 #include <atomic>
 
@@ -2105,6 +2106,10 @@ lamehip_batch_pack_all(lamehip_batch * b, int nthreads, unsigned char *out, long
     LhDeviceScope const on_device(b ? b->device : -1);
     int     dev = 0, maxf = 0;
     std::atomic < int >failed(0);
+    /* the first failure of any worker: its code and its message (g_err is per thread) reach the caller */
+    std::mutex first_lock;
+    int     first_code = 0;
+    char    first_text[sizeof(g_err)] = "";
     if (!b || !b->encoded || !out || !sizes || out_stride <= 0)
         return -1;
     if (nthreads < 1)
@@ -2118,13 +2123,21 @@ lamehip_batch_pack_all(lamehip_batch * b, int nthreads, unsigned char *out, long
     {
         std::vector < std::thread > pool;
         for (int t = 0; t < nthreads; t++)
-            pool.emplace_back([=, &failed] () {
+            pool.emplace_back([=, &failed, &first_lock, &first_code, &first_text] () {
+                auto note = [&](long code, const char *text) {
+                    std::lock_guard < std::mutex > hold(first_lock);
+                    if (first_code == 0) {
+                        first_code = (int) code;
+                        snprintf(first_text, sizeof(first_text), "%s", text);
+                    }
+                    failed = 1;
+                };
                 LhFrameOut *h = nullptr;
                 hipStream_t st = nullptr;
                 if (hipSetDevice(dev) != hipSuccess
                     || hipHostMalloc((void **) &h, (size_t) (maxf > 0 ? maxf : 1) * sizeof(LhFrameOut), 0) != hipSuccess
                     || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
-                    failed = 1;
+                    note(LAMEHIP_ERR_DEVICE, "pack_all: a worker could not set up its device staging");
                     for (int s = t; s < b->B; s += nthreads)
                         sizes[s] = LAMEHIP_ERR_DEVICE;
                     if (h)
@@ -2137,12 +2150,18 @@ lamehip_batch_pack_all(lamehip_batch * b, int nthreads, unsigned char *out, long
                     if (n > 0 && (hipMemcpyAsync(h, b->d_out + b->out_off[(size_t) s], (size_t) n * sizeof(LhFrameOut),
                                                  hipMemcpyDeviceToHost, st) != hipSuccess
                                   || hipStreamSynchronize(st) != hipSuccess))
+                    {
                         r = LAMEHIP_ERR_DEVICE;
+                        snprintf(g_err, sizeof(g_err), "pack_all: copying stream %d's frames from the device failed", s);
+                    }
                     else
                         r = pack_stream(b, s, h, n, out + (size_t) s * (size_t) out_stride, out_stride);
                     sizes[s] = r;
-                    if (r < 0)
-                        failed = 1;
+                    if (r < 0) {
+                        if (r == -1)
+                            snprintf(g_err, sizeof(g_err), "pack_all: out_stride %ld is too small for stream %d", out_stride, s);
+                        note(r, g_err);
+                    }
                 }
                 (void) hipStreamDestroy(st);
                 (void) hipHostFree(h);
@@ -2150,5 +2169,9 @@ lamehip_batch_pack_all(lamehip_batch * b, int nthreads, unsigned char *out, long
         for (auto & th:pool)
             th.join();
     }
-    return failed ? LAMEHIP_ERR_PAYLOAD : 0;
+    if (failed) {
+        snprintf(g_err, sizeof(g_err), "%s", first_text);
+        return first_code;
+    }
+    return 0;
 }

@@ -148,8 +148,8 @@ signalled_table(int t)
 
 /* CRC-16 of the protected part: header bytes 2..3 and the side information (polynomial 0x8005,
  * preset 0xffff, ISO/IEC 11172-3 section 2.4.3.1) */
-static unsigned
-header_crc(const unsigned char *h, int len)
+unsigned
+lh_header_crc(const unsigned char *h, int len)
 {
     unsigned crc = 0xffffu;
     int     i, b;
@@ -229,7 +229,7 @@ queue_header(LhBitstream * bs, const LhConfig * c, const LhFrameOut * fo, int ba
             hdr(&w, (unsigned) g->count1table_select, 1);
         }
     if (c->error_protection) {
-        unsigned const crc = header_crc(slot->bytes, c->sideinfo_len);
+        unsigned const crc = lh_header_crc(slot->bytes, c->sideinfo_len);
         slot->bytes[4] = (unsigned char) (crc >> 8);
         slot->bytes[5] = (unsigned char) (crc & 0xffu);
     }

@@ -322,7 +322,7 @@ lh_emit_part_stage(int qch, int gr)
     int const nb = lh_emit_part(c, lh_lds.u.quant.ch[qch], R, g, lh_lds.xr[qch][lh_uni_i(gr)],
                                 c.st->em_part[lh_uni_i(gr)][qch]);
     if (nb != g.part2_3_length + g.part2_length && c.lane == 0)
-        lh_lds.ss.status |= 4;      /* the packed bits disagree with the quantiser's count */
+        lh_lds_or((uint32_t *) &lh_lds.ss.status, 4u);      /* the packed bits disagree with the quantiser's count */
 }
 
 /* One frame's bytes, whole workgroup.  `nbits' = pre + sum of the parts + post (a multiple of 8 by
@@ -368,10 +368,15 @@ lh_emit_frame(const LhFrameOut * fo_in, int drain_pre, int drain_post, int frame
     /* this frame's header joins the pending ones */
     {
         long long const here = st->em_next_header;
-        if (nq < 16)
+        int const queue_full = nq >= 16;
+        if (!queue_full)
             hq[nq++] = here;
         LH_SYNC_WG();           /* everyone has read the state */
         if (tid == 0) {
+            /* status bit 8: something could not be written (slice of the byte pool too small, or more
+             * than 16 headers pending): the host refuses the stream's bytes */
+            if (queue_full || here + sl > c.d.bytes_cap)
+                lh_lds_or((uint32_t *) &lh_lds.ss.status, 8u);
             unsigned char h[40];
             int     scfsi[2][4];
             for (int ch = 0; ch < 2; ch++)
@@ -426,6 +431,8 @@ lh_emit_frame(const LhFrameOut * fo_in, int drain_pre, int drain_post, int frame
             long long const p = lh_emit_pos(cursor, j, hq, nq, sl);
             if (p < c.d.bytes_cap)
                 out[p] = (uint8_t) ((fb[j >> 2] >> (24 - 8 * (j & 3))) & 255u);
+            else
+                lh_lds_or((uint32_t *) &lh_lds.ss.status, 8u);
         }
         /* cursor and the pending headers behind it */
         cursor = lh_emit_pos(cursor, nbytes, hq, nq, sl);
@@ -437,7 +444,7 @@ lh_emit_frame(const LhFrameOut * fo_in, int drain_pre, int drain_post, int frame
             nq = keep;
         }
         if ((nbits & 7) != 0 && tid == 0)
-            lh_lds.ss.status |= 2;    /* the reservoir arithmetic should make every frame's main data whole bytes */
+            lh_lds_or((uint32_t *) &lh_lds.ss.status, 2u);    /* the reservoir arithmetic should make every frame's main data whole bytes */
         LH_SYNC_WG();
     }
     if (tid == 0) {

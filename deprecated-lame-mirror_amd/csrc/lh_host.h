@@ -81,6 +81,9 @@ typedef struct LhBitstream {
 
 int     lh_bs_init(LhBitstream * bs);
 int     lh_bs_init_sized(LhBitstream * bs, int size);
+/* CRC-16 of a frame's protected part: header bytes 2..3 and 6..len-1 (ISO/IEC 11172-3 2.4.3.1; reference
+ * bitstream.c:304-318 CRC_writeheader); the caller stores it big-endian in bytes 4..5 */
+unsigned lh_header_crc(const unsigned char *h, int len);
 void    lh_bs_free(LhBitstream * bs);
 /* appends one frame; returns 0, or <0 when the device payload is inconsistent */
 int     lh_bs_format_frame(LhBitstream * bs, const LhConfig * c, const LhTables * t,

@@ -188,6 +188,13 @@ lh_tag_frame(const LhVbrTag * v, const LhConfig * c, int vbr_q, int enc_padding,
     n += 4;
     memcpy(buf + n, toc, sizeof(toc));
     n += (int) sizeof(toc);
+    if (c->error_protection) {
+        /* the tag frame carries a header CRC like any other frame (reference VbrTag.c:996-999); it
+         * covers the first bytes of the tag, which start two bytes early in this case */
+        unsigned const hc = lh_header_crc(buf, c->sideinfo_len);
+        buf[4] = (unsigned char) (hc >> 8);
+        buf[5] = (unsigned char) (hc & 255u);
+    }
     for (i = 0; i < n; i++)
         crc = crc16_update(buf[i], crc);
     {

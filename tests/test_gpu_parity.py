@@ -258,6 +258,13 @@ def test_pack_all_threads_equals_per_stream_pack():
     single = [b.pack(s) for s in range(len(pcms))]
     for nt in (1, 5, 64):
         assert b.pack_all(nt) == single
+    # a worker's failure reaches the caller: its code and its message (the error text is per thread)
+    stride = 512
+    buf = np.empty(len(pcms) * stride, dtype=np.uint8)
+    sizes = np.zeros(len(pcms), dtype=np.int64)
+    rc = b.lib.lamehip_batch_pack_all(b.b, 4, buf.ctypes.data, stride, sizes.ctypes.data)
+    assert rc == -1 and (sizes < 0).any()
+    assert "out_stride 512 is too small for stream" in lamehip.last_error()
     b.close()
     enc.close()
 

@@ -108,3 +108,58 @@ def test_batch_pack_tagged_is_the_reference_file_image(vq, abr):
         assert b.get_bytes_tagged(s) == tag + stream[len(tag):]     # the same from the device-packed bytes
     b.close()
     enc.close()
+
+
+@pytest.mark.parametrize("kw", [dict(brate=160), dict(vbr_q=4)], ids=["cbr160", "v4"])
+def test_tag_frame_with_error_protection_matches_reference(kw):
+    """-p: the tag frame carries a header CRC too (it covers the first bytes of the tag, which starts two
+    bytes early), and the LAME tag's own CRC runs over it (reference VbrTag.c:964-1008)."""
+    sr = 44100
+    n = int(sr * 0.8)
+    pcm = helpers.synth_stream(777, n, sr, 1.0 / 5)
+    ref = helpers.Reference()
+    ref.lib.refh_option.argtypes = [C.c_char_p, C.c_float]
+    ref.lib.refh_option(None, 0)
+    ref.lib.refh_option(b"error_protection", 1.0)
+    try:
+        stream, tag = helpers.reference_tagged(pcm, sr, kw.get("brate", 0), vbr_q=kw.get("vbr_q"))
+    finally:
+        ref.lib.refh_option(None, 0)
+    lib = lamehip.load_library()
+    h = C.c_void_p(lib.lame_init())
+    lib.lame_set_in_samplerate(h, sr)
+    lib.lame_set_num_channels(h, 2)
+    if "brate" in kw:
+        lib.lame_set_brate(h, kw["brate"])
+    else:
+        lib.lame_set_VBR(h, 4)
+        lib.lame_set_VBR_q(h, kw["vbr_q"])
+    lib.lame_set_error_protection(h, 1)
+    rc = lib.lame_init_params(h)
+    assert rc in (0, lamehip.ERR_NODEVICE)
+    enc = lamehip.Encoder.__new__(lamehip.Encoder)
+    enc.lib, enc.h = lib, h
+    cfg = enc.config()
+    assert cfg.error_protection == 1
+    v = LhVbrTag()
+    total = lib.lh_tag_init(C.byref(v), C.byref(cfg))
+    assert total == len(tag) > 0
+    ph = C.create_string_buffer(total)
+    assert lib.lh_tag_placeholder(C.byref(v), C.byref(cfg), ph) == total
+    assert ph.raw == stream[:total]
+    audio = stream[total:]
+    nframes = lib.lh_total_frames(C.c_long(n))
+    fr = helpers.Oracle().encode_frames(cfg, enc.tables(), pcm)
+    assert len(fr) == nframes
+    for f in range(nframes):
+        lib.lh_tag_add_frame(C.byref(v), lib.lh_tag_kbps(int(fr[f].bitrate_index)))
+    lib.lh_tag_crc.argtypes = [C.c_void_p, C.c_char_p, C.c_long]
+    lib.lh_tag_crc(C.byref(v), audio, len(audio))
+    out = C.create_string_buffer(2880)
+    lib.lh_tag_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_long]
+    k = lib.lh_tag_frame(C.byref(v), C.byref(cfg), cfg.vbr_q, lib.lh_end_padding(C.c_long(n)),
+                         fr[nframes - 1].mode_ext, out, len(out))
+    assert k == total
+    assert out.raw[4:6] != b"\0\0"
+    assert out.raw[:k] == tag
+    lib.lame_close(h)
