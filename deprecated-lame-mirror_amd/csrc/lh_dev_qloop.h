@@ -719,7 +719,9 @@ lq_amp_scalefac_bands(const LhCtx & c, LhQS & S, const LhQR & R, LhGrR & g)
         break;
     case 1:
         if (trigger > 1.0)
-            trigger = (float) sqrt((double) trigger);
+            trigger = sqrtf(trigger);   /* = (float) sqrt((double) trigger), reference quantize.c:744: a correctly
+                                         * rounded double root rounded again to float is the correctly rounded
+                                         * float root (53 >= 2 * 24 + 2; tests/test_quantizer_identity.py) */
         else
             trigger = (float) (trigger * .95);
         break;

@@ -34,3 +34,14 @@ def test_step_tables_scale_by_exact_powers_of_two():
     ipow20 = np.ctypeslib.as_array(T.ipow20).astype(np.float32)
     assert np.array_equal(pow20[4:], pow20[:-4] * np.float32(2.0))
     assert np.array_equal(ipow20[16:], ipow20[:-16] / np.float32(8.0))
+
+
+def test_float_root_equals_the_rounded_double_root():
+    """amp_scalefac_bands forms (float) sqrt((double) trigger) (reference quantize.c:744); the kernel takes the
+    correctly rounded float root.  Two binades exhaustively (the mantissa pattern repeats every two), plus
+    a random sample of the range the trigger lives in."""
+    x = np.arange(0x3f800000, 0x3f800000 + (1 << 24), dtype=np.uint32).view(np.float32)     # [1, 4)
+    assert np.array_equal(np.sqrt(x.astype(np.float64)).astype(np.float32), np.sqrt(x))
+    rng = np.random.default_rng(5)
+    y = (rng.random(4_000_000, dtype=np.float32) * np.float32(1e9) + np.float32(1.0)).astype(np.float32)
+    assert np.array_equal(np.sqrt(y.astype(np.float64)).astype(np.float32), np.sqrt(y))
