@@ -34,6 +34,20 @@ LH_DEVCONST float lh_psy_tab[9] = {
     1.0f, 0.79433f, 0.63096f, 0.63096f, 0.63096f, 0.63096f, 0.63096f, 0.25119f, 0.11749f
 };
 LH_DEVCONST int lh_mask_add_delta[9] = { 2, 2, 2, 1, 1, 1, 0, 0, -1 };
+/* lh_psy_tab[i] / lh_mask_add_delta[i] for a per-lane index 0..8 without a memory access (the tables'
+ * values as immediates: both sit on dependency chains of the masking spread) */
+LH_DEVFN float
+lh_psy_tab_at(int i)
+{
+    return (i == 0) ? 1.0f : (i == 1) ? 0.79433f : (i < 7) ? 0.63096f : (i == 7) ? 0.25119f : 0.11749f;
+}
+
+LH_DEVFN int
+lh_mask_add_delta_at(int i)
+{
+    return (i < 3) ? 2 : (i < 6) ? 1 : (i < 8) ? 0 : -1;
+}
+
 LH_DEVCONST float lh_mask_table2[10] = {
     (float) (1.33352 * 1.33352), (float) (1.35879 * 1.35879), (float) (1.38454 * 1.38454),
     (float) (1.39497 * 1.39497), (float) (1.40548 * 1.40548), (float) (1.3537 * 1.3537),
@@ -53,39 +67,25 @@ LH_DEVCONST float lh_regcoef_l[21] = {
     46.8f, 56.5f, 60.7f, 73.9f, 85.7f, 93.4f, 126.1f
 };
 
-/* reference psymodel.c:294-341 */
+/* reference psymodel.c:294-341, as straight-line selects: the walk of lh_compute_masking calls it for
+ * all lanes at once, and a lane that takes another of the reference's exits would make the whole
+ * wave run every branch anyway */
 LH_DEVFN float
 lh_mask_add(const float *log_table, const float *table2, float ma_max_i1, float ma_max_i2, float m1, float m2,
             int b, int delta)
 {
-    float   ratio;
-    if (m1 < 0)
-        m1 = 0;
-    if (m2 < 0)
-        m2 = 0;
-    if (m1 <= 0)
-        return m2;
-    if (m2 <= 0)
-        return m1;
-    if (m2 > m1)
-        ratio = m2 / m1;
-    else
-        ratio = m1 / m2;
-    if (b < 0)
-        b = -b;
-    if (b <= delta) {
-        if (ratio >= ma_max_i1)
-            return m1 + m2;
-        else {
-            int     i = (int) (lh_fast_log2(log_table, ratio) * (LH_LOG2_OVER_LOG10 * (16.0f)));
-            return (m1 + m2) * table2[i];
-        }
-    }
-    if (ratio < ma_max_i2)
-        return m1 + m2;
-    if (m1 < m2)
-        m1 = m2;
-    return m1;
+    float const a = (m1 < 0) ? 0.0f : m1, c = (m2 < 0) ? 0.0f : m2;
+    float const hi = (c > a) ? c : a, lo = (c > a) ? a : c;
+    int const one = !(lo > 0);                  /* m1 <= 0: return m2; m2 <= 0: return m1 */
+    float const ratio = hi / (one ? 1.0f : lo); /* m2 > m1 ? m2 / m1 : m1 / m2 */
+    float const sum = a + c;
+    int const near = ((b < 0) ? -b : b) <= delta;
+    /* the table index is only formed where the reference forms it; elsewhere a harmless ratio */
+    int const tab = near && !one && ratio < ma_max_i1;
+    int const i = (int) (lh_fast_log2(log_table, tab ? ratio : 1.0f) * (LH_LOG2_OVER_LOG10 * (16.0f)));
+    float const scaled = sum * table2[i];
+    float   res = near ? (tab ? scaled : sum) : ((ratio < ma_max_i2) ? sum : hi);
+    return one ? hi : res;
 }
 
 /* reference psymodel.c:443-454 */
@@ -456,14 +456,18 @@ lh_compute_masking(const LhCtx & c, int chn, int is_long, const float *energy, f
     int const on = b < np;
     float   ebb = 0, m = 0, avg = 0, th = 0;
     int     tone;
+    /* the lane's table entries (HBM, L2-resident): all requested up front, one wait */
+    int const bc = on ? b : 0;
+    int const t_numlines = gd->numlines[bc], t_first = gd->s3ind[bc][0], t_last = gd->s3ind[bc][1], t_row = gd->s3_row[bc];
+    float const t_rnum = gd->rnumlines[bc], t_mlow = gd->masking_lower[bc], t_minval = gd->minval[bc];
     LH_PT(t_mk);
     LQ_MARK("mk_sums");
     {
         /* A partition's energy is the sum of its lines in order (up to 83 of them for the widest
          * one); the loads do not depend on the sum, so eight go out together and the additions follow. */
-        int const n = on ? gd->numlines[b] : 0;
+        int const n = on ? t_numlines : 0;
         int const j0 = (int) lh_wave_scan_u32((uint32_t) n) - n;      /* the partition's first line */
-        float const rn = on ? gd->rnumlines[b] : 0.0f;
+        float const rn = on ? t_rnum : 0.0f;
         int const nmax = lh_uni_i((int) lh_wave_max_u32((uint32_t) n));
         for (int i = 0; i < nmax; i += 8) {
             float   el[8];
@@ -493,7 +497,7 @@ lh_compute_masking(const LhCtx & c, int chn, int is_long, const float *energy, f
         float const m0 = lh_shfl_f32(m, lo), m2 = lh_shfl_f32(m, hi);
         float const a0 = lh_shfl_f32(avg, lo), a2 = lh_shfl_f32(avg, hi);
         tone = on ? lh_mask_index(gd, b, m0, m, m2, a0, avg, a2) : 0;
-        thr[b] = psy_tab[tone];
+        thr[b] = lh_psy_tab_at(tone);
     }
     /* The reference walks kk = s3ind[b][0] .. s3ind[b][1], adding partition kk's spread energy to the
      * running sum with mask_add(), whose expensive branch (a division, fast_log2, table2) only applies
@@ -502,9 +506,9 @@ lh_compute_masking(const LhCtx & c, int chn, int is_long, const float *energy, f
      * kk = b - 3 (cheap rule), the five steps kk = b - 2 .. b + 2 (expensive rule where |kk - b| <=
      * delta), n3 steps from kk = b + 3 (cheap rule); a lane sits out the steps outside its own range.
      * The order of a lane's additions is the reference's. */
-    int const first = on ? gd->s3ind[b][0] : 1, last = on ? gd->s3ind[b][1] : 0;
-    int const krel = (on ? gd->s3_row[b] : 0) - first;  /* s3 index of partition kk = krel + kk */
-    int const delta = lh_mask_add_delta[tone];
+    int const first = on ? t_first : 1, last = on ? t_last : 0;
+    int const krel = (on ? t_row : 0) - first;  /* s3 index of partition kk = krel + kk */
+    int const delta = lh_mask_add_delta_at(tone);
     float   ecb = 0;
     int     dd, n1, n3;
     {
@@ -569,10 +573,10 @@ lh_compute_masking(const LhCtx & c, int chn, int is_long, const float *energy, f
     LQ_MARK("mk_tail");
     if (on) {
         float   x, avg_mask;
-        float const masking_lower = gd->masking_lower[b] * lh_lds.ss.masking_lower;
+        float const masking_lower = t_mlow * lh_lds.ss.masking_lower;
         int const dd_n = last - first + 1;
         dd = (1 + 2 * dd) / (2 * dd_n);
-        avg_mask = psy_tab[dd] * 0.5f;
+        avg_mask = lh_psy_tab_at(dd) * 0.5f;
         ecb *= avg_mask;
         if (is_long) {
             int const bt_old = lh_lds.ss.blocktype_old[chn & 1];
@@ -606,7 +610,7 @@ lh_compute_masking(const LhCtx & c, int chn, int is_long, const float *energy, f
         else
             th = ecb;
         x = m;
-        x *= gd->minval[b];
+        x *= t_minval;
         x *= avg_mask;
         if (th > x)
             th = x;
