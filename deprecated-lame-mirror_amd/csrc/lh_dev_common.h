@@ -17,10 +17,22 @@
 #define LH_NT 128               /* threads per workgroup: wave 0 = left/mid, wave 1 = right/side */
 #define LH_SQRT2 1.41421356237309504880
 
+/* LH_SYNC_WG(): workgroup barrier with a full fence (LDS and HBM: __syncthreads()).
+ * LH_SYNC_WG_LDS(): the same for phases whose waves exchange data through LDS only (the psy model,
+ * the transforms): global loads in flight -- table look-ups, the next phase's prefetches -- are not
+ * drained at the barrier. */
 #ifdef LH_EMU
 #define LH_SYNC_WG() __syncthreads()
+#define LH_SYNC_WG_LDS() __syncthreads()
 #else
 #define LH_SYNC_WG() __syncthreads()
+#if defined(LH_FULL_FENCE)
+#define LH_SYNC_WG_LDS() __syncthreads()
+#else
+#define LH_SYNC_WG_LDS() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); \
+                              __builtin_amdgcn_s_barrier(); \
+                              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); } while (0)
+#endif
 #endif
 
 #if defined(LH_PROF) && !defined(LH_EMU)

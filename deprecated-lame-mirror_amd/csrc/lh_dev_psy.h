@@ -106,7 +106,7 @@ lh_ns_interp(float x, float y, float r)
  * dealt to the lanes.  `unit0'/`nunits' let the three short transforms share
  * one call. */
 LH_DEVFN void
-lh_fht_unit(const LhTables * T, float *fz, int stage, int k1, int u)
+lh_fht_unit(lh_f32x4 tw, float *fz, int k1, int u)
 {
     int const kx = k1 >> 1;
     int const k2 = k1 << 1, k3 = k2 + k1, k4 = k2 << 1;
@@ -133,8 +133,7 @@ lh_fht_unit(const LhTables * T, float *fz, int stage, int k1, int u)
         gi[k1] = f1 + f3;
     }
     else {
-        float const c1 = T->fht_tw[stage][i][0], s1 = T->fht_tw[stage][i][1];
-        float const c2 = T->fht_tw[stage][i][2], s2 = T->fht_tw[stage][i][3];
+        float const c1 = tw.x, s1 = tw.y, c2 = tw.z, s2 = tw.w;
         float  *fi = fz + blk * k4 + i;
         float  *gi = fz + blk * k4 + k1 - i;
         float   a, b, g0, f0, f1, g1, f2, g2, f3, g3;
@@ -210,11 +209,26 @@ lh_fft_long(const LhCtx & c, int ch, int base, float *x)
         o[LH_BLKSIZE / 2 + 1] = f1 + f3;
         o[LH_BLKSIZE / 2 + 3] = f1 - f3;
     }
-    LH_WAVE_SYNC_MEM();
-    for (int stage = 0, k1 = 4; stage < 4; stage++, k1 <<= 2) {
-        for (int u = lane; u < LH_BLKSIZE / 8; u += 64)
-            lh_fht_unit(c.T, x, stage, k1, u);
+    {
+        /* the twiddle factors of all four passes (HBM, 16 bytes per butterfly unit) are requested
+         * before the first pass: they arrive while the passes before theirs run */
+        lh_f32x4 tw[4][2];
+#pragma unroll
+        for (int stage = 0; stage < 4; stage++) {
+            int const kx = 2 << (2 * stage);
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+                tw[stage][q] = *(const lh_f32x4 *) c.T->fht_tw[stage][(lane + 64 * q) % kx];
+        }
         LH_WAVE_SYNC_MEM();
+#pragma unroll
+        for (int stage = 0; stage < 4; stage++) {
+            int const k1 = 4 << (2 * stage);
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+                lh_fht_unit(tw[stage][q], x, k1, lane + 64 * q);
+            LH_WAVE_SYNC_MEM();
+        }
     }
 }
 
@@ -259,7 +273,8 @@ lh_fft_short(const LhCtx & c, int ch, int base, float *x)
     for (int stage = 0, k1 = 4; stage < 3; stage++, k1 <<= 2) {
         for (int t = lane; t < 3 * (LH_BLKSIZE_S / 8); t += 64) {
             int const b = t >> 5, u = t & 31;
-            lh_fht_unit(c.T, x + b * LH_BLKSIZE_S, stage, k1, u);
+            lh_f32x4 const tw = *(const lh_f32x4 *) c.T->fht_tw[stage][u % (k1 >> 1)];
+            lh_fht_unit(tw, x + b * LH_BLKSIZE_S, k1, u);
         }
         LH_WAVE_SYNC_MEM();
     }
@@ -769,7 +784,7 @@ lh_psy_granule(int gr, LhPsyCarry nb)
             P.a.hpf[w][i] = sum1 + sum2;
         }
     }
-    LH_SYNC_WG();
+    LH_SYNC_WG_LDS();
     for (int pass = 0; pass < 2; pass++) {
         int const chn = w + 2 * pass;
         if (chn < n_chn_psy) {
@@ -865,7 +880,7 @@ lh_psy_granule(int gr, LhPsyCarry nb)
         }
         LH_WAVE_SYNC_MEM();
     }
-    LH_SYNC_WG();
+    LH_SYNC_WG_LDS();
     {
         /* uselongblock[] resolution (reference psymodel.c:926-933, 1265-1286) */
         int     ul0 = L.ns_uselong[0], ul1 = (cfg->channels == 2) ? L.ns_uselong[1] : 1;
@@ -878,18 +893,18 @@ lh_psy_granule(int gr, LhPsyCarry nb)
             ul0 = ul1 = 1;
         if (cfg->short_blocks == 3)
             ul0 = ul1 = 0;
-        LH_SYNC_WG();
+        LH_SYNC_WG_LDS();
         if (c.tid == 0) {
             L.uselongblock[0] = ul0;
             L.uselongblock[1] = ul1;
         }
     }
-    LH_SYNC_WG();
+    LH_SYNC_WG_LDS();
 
     LH_PA(29, t_psy0);
     /* (3) long FFTs of L (wave 0) and R (wave 1) */
     lh_fft_long(c, w, bufbase, P.wsamp[w]);
-    LH_SYNC_WG();
+    LH_SYNC_WG_LDS();
     LH_PA(30, t_psy0);
     /* (4) power spectra of this wave's two pseudo-channels */
     for (int pass = 0; pass < 2; pass++) {
@@ -904,7 +919,7 @@ lh_psy_granule(int gr, LhPsyCarry nb)
     float  *stg_log = stg_s3 + LH_S3_MAX;               /* [513] */
     float  *stg_psy = stg_log + 516;                    /* [9] */
     float  *stg_t2 = stg_psy + 12;                      /* [10] */
-    LH_SYNC_WG();
+    LH_SYNC_WG_LDS();
     for (int i = c.tid; i < T->psy_l.s3_count; i += LH_NT)
         stg_s3[i] = T->psy_l.s3[i];
     for (int i = c.tid; i < 513; i += LH_NT)
@@ -913,7 +928,7 @@ lh_psy_granule(int gr, LhPsyCarry nb)
         stg_psy[c.tid] = lh_psy_tab[c.tid];
     if (c.tid < 10)
         stg_t2[c.tid] = lh_mask_table2[c.tid];
-    LH_SYNC_WG();
+    LH_SYNC_WG_LDS();
     LH_PA(31, t_psy0);
     /* (5) serial sums: total energy (bins 11..512) and loudness (reference psymodel.c:213-226,
      * 690-696): lane 0/1 = tot_ener of chn w / w+2, lane 2 = loudness of channel w */
@@ -979,7 +994,7 @@ lh_psy_granule(int gr, LhPsyCarry nb)
                                stg_s3, stg_log, stg_psy, stg_t2,
                                nb.n1[pass], nb.n2[pass]);
     }
-    LH_SYNC_WG();
+    LH_SYNC_WG_LDS();
     if (cfg->mode == LH_MODE_JOINT_STEREO && (L.uselongblock[0] + L.uselongblock[1]) == 2) {
         float const ath_factor =
             (cfg->msfix > 0.f) ? (cfg->ATH_offset_factor * lh_lds.ss.ath_adjust_factor) : 1.f;
@@ -987,7 +1002,7 @@ lh_psy_granule(int gr, LhPsyCarry nb)
             lh_ms_thresholds(c, P.eb, P.thr, T->psy_l.mld_cb, T->ath_cb_l, ath_factor, cfg->msfix,
                              T->psy_l.npart);
     }
-    LH_SYNC_WG();
+    LH_SYNC_WG_LDS();
     LH_PA(33, t_psy0);
     /* (7) partitions -> scalefactor bands, long and long->short estimates
      * (reference psymodel.c:411-439); 4 serial chains per wave */
@@ -1002,7 +1017,7 @@ lh_psy_granule(int gr, LhPsyCarry nb)
             lh_partition2sfb_wave(&T->psy_l_to_s, &P.eb[cc * 64], &P.thr[cc * 64], &L.psy_en[now][cc][22],
                                   &L.psy_thm[now][cc][22], 3, (float) (1. / 64.f), 1, lane, act);
     }
-    LH_SYNC_WG();
+    LH_SYNC_WG_LDS();
     LH_PA(34, t_psy0);
     /* (8) short blocks (reference psymodel.c:1470-1500) */
     /* (nothing of it runs when both channels keep long blocks -- the usual granule: the values the
@@ -1011,7 +1026,7 @@ lh_psy_granule(int gr, LhPsyCarry nb)
     if (any_short) {
         if (!L.uselongblock[w])
             lh_fft_short(c, w, bufbase, &P.wsamp[w][0]);
-        LH_SYNC_WG();
+        LH_SYNC_WG_LDS();
     }
     for (int sblock = 0; any_short && sblock < 3; sblock++) {
         for (int pass = 0; pass < 2; pass++) {
@@ -1025,7 +1040,7 @@ lh_psy_granule(int gr, LhPsyCarry nb)
                                    lh_mask_table2, nb.n1[pass], nb.n2[pass]);    /* short: left alone */
             }
         }
-        LH_SYNC_WG();
+        LH_SYNC_WG_LDS();
         if (cfg->mode == LH_MODE_JOINT_STEREO && (L.uselongblock[0] + L.uselongblock[1]) == 0) {
             float const ath_factor =
                 (cfg->msfix > 0.f) ? (cfg->ATH_offset_factor * lh_lds.ss.ath_adjust_factor) : 1.f;
@@ -1033,7 +1048,7 @@ lh_psy_granule(int gr, LhPsyCarry nb)
                 lh_ms_thresholds(c, P.eb, P.thr, T->psy_s.mld_cb, T->ath_cb_s, ath_factor,
                                  cfg->msfix, T->psy_s.npart);
         }
-        LH_SYNC_WG();
+        LH_SYNC_WG_LDS();
         for (int t = 0; t < 2; t++) {
             int const chn = w + 2 * t;
             int const act = chn < n_chn_psy && !L.uselongblock[chn & 1];
@@ -1041,7 +1056,7 @@ lh_psy_granule(int gr, LhPsyCarry nb)
             lh_partition2sfb_wave(&T->psy_s, &P.eb[cc * 64], &P.thr[cc * 64], &L.psy_en[now][cc][22 + sblock],
                                   &L.psy_thm[now][cc][22 + sblock], 3, -1.0f, 0, lane, act);
         }
-        LH_SYNC_WG();
+        LH_SYNC_WG_LDS();
     }
     LH_PA(35, t_psy0);
     /* (9) short block pre-echo control (reference psymodel.c:1502-1553): one lane per (chn, sb) */
@@ -1090,7 +1105,7 @@ lh_psy_granule(int gr, LhPsyCarry nb)
                 L.psy_thm[now][chn][22 + sb * 3 + sblock] = new_thmm[sblock];
         }
     }
-    LH_SYNC_WG();
+    LH_SYNC_WG_LDS();
     LH_PA(36, t_psy0);
     /* (10) block type state machine (reference psymodel.c:1289-1319) + PE (:1568-1595) */
     {
@@ -1112,7 +1127,7 @@ lh_psy_granule(int gr, LhPsyCarry nb)
             btd[chn] = old;
             L.next_blocktype[chn] = blocktype;
         }
-        LH_SYNC_WG();
+        LH_SYNC_WG_LDS();
         if (c.tid < 2) {
             lh_lds.ss.blocktype_old[c.tid] = L.next_blocktype[c.tid];
             L.block_type[gr][c.tid] = btd[c.tid];
@@ -1164,7 +1179,7 @@ lh_psy_granule(int gr, LhPsyCarry nb)
             }
         }
     }
-    LH_SYNC_WG();
+    LH_SYNC_WG_LDS();
     return nb;
 }
 

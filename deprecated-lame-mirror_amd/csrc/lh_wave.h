@@ -256,10 +256,10 @@ __device__ __forceinline__ int lh_wave_id(void) { return (int) (threadIdx.x >> 6
  * in flight together with whatever follows) */
 #define LH_WAVE_ORDER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); \
                              asm volatile("" ::: "memory"); } while (0)
-/* same, for phases whose lanes also exchange data through the stream state in HBM (the
- * psycho-acoustic model): orders and drains global accesses as well */
-#define LH_WAVE_SYNC_MEM() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); \
-                                __builtin_amdgcn_wave_barrier(); } while (0)
+/* (the psycho-acoustic model's name for the same thing: its lanes once exchanged data through the stream
+ * state in HBM and needed global accesses drained; that state lives in LDS now, and draining the
+ * table loads in flight at every phase change was what the model waited for) */
+#define LH_WAVE_SYNC_MEM() LH_WAVE_SYNC()
 
 /* Wave reductions on the DPP cross-lane network (no LDS round trips): four
  * full-permutation steps (quad_perm [1,0,3,2], quad_perm [2,3,0,1],
