@@ -493,9 +493,12 @@ lq_count_bits(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
         }
         {
             /* lane r: choose_table of region r from its sums (reference takehiro.c:618-647) */
-            uint32_t const Lr = (lane == 0) ? red[1] : (lane == 1) ? (red[3] - red[1]) : (red[5] - red[3]);
-            uint32_t const Hr = (lane == 0) ? red[2] : (lane == 1) ? (red[4] - red[2]) : (red[6] - red[4]);
-            int const ex = (lane == 0) ? (0 < e0) : (lane == 1) ? (e0 < e1) : (e1 < e2);
+            uint32_t const l0 = lh_vec_u32(red[1]), l1 = lh_vec_u32(red[3] - red[1]), l2 = lh_vec_u32(red[5] - red[3]);
+            uint32_t const h0 = lh_vec_u32(red[2]), h1 = lh_vec_u32(red[4] - red[2]), h2 = lh_vec_u32(red[6] - red[4]);
+            uint32_t const x0 = lh_vec_u32((uint32_t) (0 < e0)), x1 = lh_vec_u32((uint32_t) (e0 < e1)), x2 = lh_vec_u32((uint32_t) (e1 < e2));
+            uint32_t const Lr = (lane == 0) ? l0 : (lane == 1) ? l1 : l2;
+            uint32_t const Hr = (lane == 0) ? h0 : (lane == 1) ? h1 : h2;
+            int const ex = (int) ((lane == 0) ? x0 : (lane == 1) ? x1 : x2);
             uint32_t const a = Lr & 0xffffu, b = Lr >> 16;
             uint32_t const tA = PB & 31u, tB = (PB >> 8) & 31u, lin1 = (PB >> 16) & 15u, lin2 = (PB >> 24) & 15u;
             uint32_t const a2_ = a + Hr * lin1, b2_ = b + Hr * lin2, c2_ = esc ? 0x7fffffffu : Hr;

@@ -224,6 +224,7 @@ static inline void lh_lds_add(int *p, int v) { *p += v; }      /* fibers interle
 static inline void lh_lds_max(int *p, int v) { if (v > *p) *p = v; }
 static inline void lh_lds_addf(float *p, float v) { *p += v; }
 static inline int lh_uni_i(int v) { return v; }
+static inline uint32_t lh_vec_u32(uint32_t v) { return v; }
 static inline float lh_uni_f(float v) { return v; }
 static inline long long lh_uni_ll(long long v) { return v; }
 static inline int lh_ffs64(uint64_t m) { return m ? __builtin_ctzll(m) : -1; }
@@ -452,6 +453,11 @@ __device__ __forceinline__ void lh_lds_addf(float *p, float v) { (void) __hip_at
  * per-lane memory, which the compiler must treat as divergent): the value moves to a scalar
  * register and everything derived from it -- branches, address arithmetic -- is scalar. */
 __device__ __forceinline__ int lh_uni_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+/* The opposite: a wave-uniform value that is about to be selected per lane.  With the operands in
+ * scalar registers the compiler turns `lane == 0 ? a : lane == 1 ? b : c' into EXEC-mask branches
+ * (a dozen scalar instructions and two branches per select); from vector registers it is two
+ * v_cndmask. */
+__device__ __forceinline__ uint32_t lh_vec_u32(uint32_t v) { asm volatile("" : "+v"(v)); return v; }
 __device__ __forceinline__ float lh_uni_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 __device__ __forceinline__ long long lh_uni_ll(long long v)
 {
