@@ -890,7 +890,7 @@ LH_DEVFN int
 lq_loop_break(const LhCtx & c, const LhQS & S, const LhQR & R, const LhGrR & g)
 {
     int const s = c.lane;
-    int const z = (s < R.sfbmax) && (S.sfw + lh_sbg(g, S.win) == 0);
+    int const z = (s < R.sfbmax) && (S.sfw + (S.sbg8 >> 3) == 0);        /* sbg8 = 8 subblock_gain[window of the band] */
     return lh_ballot(z) == 0;
 }
 
