@@ -104,3 +104,32 @@ def test_device_bit_packer_source_matches_host_packer(name, emu, oracle):
     assert out.raw[:len(want)] == want
     assert out.raw[len(want):len(want) + 64] == bytes(64)
     enc.close()
+
+
+def test_device_bit_packer_flags_a_slice_that_is_too_small(emu):
+    """A stream whose slice of the byte pool cannot hold its frames: nothing is written past the slice and
+    the state's status says so (bit 8), which makes lamehip_batch_get_bytes refuse the stream."""
+    g, pcm = helpers.load_golden("cbr128_js_44k_silence")
+    enc = lamehip.Encoder(require_device=False, **helpers.golden_encoder_kwargs(g))
+    cfg, tab = enc.config(), enc.tables()
+    nframes = int(g["nframes"])
+    n = pcm.shape[1]
+    pool = np.concatenate([pcm[0], pcm[1]]).astype(np.int16)
+    want = g["mp3"].tobytes()
+    cap = len(want) // 2
+    desc = LhStreamDesc(0, n, 0, n, 0, 0, nframes, 0, cap, 1, 0)
+    ssz = enc.lib.lamehip_abi_sizeof(4)
+    state = C.create_string_buffer(ssz)
+    enc.lib.lh_state_init(state, C.byref(cfg))
+    got = (LhFrameOut * nframes)()
+    out = C.create_string_buffer(cap + 4096)
+    emu.lh_emu_encode_bytes(C.byref(cfg), C.byref(tab), pool.ctypes.data_as(C.c_void_p), C.byref(desc), state, got, out, 1)
+    assert out.raw[cap:] == bytes(4096)
+    # LhStreamState (lh_device.h): ... pefirbuf[19], slot_lag, ResvSize, ResvMax, main_data_begin, OldValue[2],
+    # CurrentStep[2], masking_lower, substep_shaping, frame_number, primed, status, pad[3], em_*
+    off_pefir = 4 * (4 * 4 * 64 + 2 + 4 + 36 + 4 + 2 + 2 + 2 * 576)
+    words = np.frombuffer(state.raw[off_pefir + 19 * 4:off_pefir + 19 * 4 + 13 * 4], dtype=np.int32)
+    frame_number, primed, status = int(words[10]), int(words[11]), int(words[12])
+    assert frame_number == nframes and primed == 1      # (the offsets are right)
+    assert status & 8
+    enc.close()
