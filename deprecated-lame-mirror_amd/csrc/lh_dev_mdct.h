@@ -30,6 +30,20 @@
 #define LH_FS(p,q)    do { float xr_ = a[p]; a[p] += a[q]; a[q] -= xr_; } while (0)
 #define LH_CH0(p,q)   do { xr = a[p] - a[q]; a[p] = xr; } while (0)
 #define LH_CH(p)      do { xr = a[p] - xr; a[p] = xr; } while (0)
+/* the remaining step kinds of the 32-point network (reference newmdct.c:552-705), so that the whole
+ * network reads as one list of steps:
+ *   SUB(p,q)   a[p] -= a[q]
+ *   XS(m,s)    difference scaled by sqrt 2 in double, sum in place
+ *   XS2(m,s)   the same, minus the new sum
+ *   NYD(s,m)   sqrt 2 * (a[m] - a[s]) minus the new sum   (the difference is formed as -a[s] + a[m])
+ *   MYD(s,m)   -sqrt 2 * (a[s] - a[m]) minus the new sum
+ *   MYP(s,m)   -sqrt 2 * (a[s] + a[m]) minus the new difference */
+#define LH_SUB(p,q)   do { a[p] -= a[q]; } while (0)
+#define LH_XS(m,s)    do { float d_ = a[m] - a[s]; a[s] += a[m]; a[m] = (float) (d_ * LH_SQRT2); } while (0)
+#define LH_XS2(m,s)   do { float d_ = a[m] - a[s]; a[s] += a[m]; a[m] = (float) (d_ * LH_SQRT2 - a[s]); } while (0)
+#define LH_NYD(s,m)   do { float d_ = (float) (LH_SQRT2 * (-a[s] + a[m])); a[s] += a[m]; a[m] = d_ - a[s]; } while (0)
+#define LH_MYD(s,m)   do { float d_ = (float) (-LH_SQRT2 * (a[s] - a[m])); a[s] += a[m]; a[m] = d_ - a[s]; } while (0)
+#define LH_MYP(s,m)   do { float d_ = (float) (-LH_SQRT2 * (a[s] + a[m])); a[s] -= a[m]; a[m] = d_ - a[s]; } while (0)
 
 /* Polyphase time slot, split in two for the GPU (reference newmdct.c:430-814):
  * stage 1 -- the 16 independent tap sums of a slot (15 folded window rows + the
@@ -113,15 +127,11 @@ lh_subband_network(int ch, int g, int slot)
     LH_BX(27, 3, LH_WK(4));
     LH_BX(24, 4, LH_WK(6));
     LH_BX(25, 5, LH_WK(6));
-    xr = a[22] - a[6];
-    a[6] += a[22];
-    a[22] = (float) (xr * LH_SQRT2);
-    xr = a[23] - a[7];
-    a[7] += a[23];
-    a[23] = (float) (xr * LH_SQRT2 - a[7]);
-    a[7] -= a[6];
-    a[22] -= a[7];
-    a[23] -= a[22];
+    LH_XS(22, 6);
+    LH_XS2(23, 7);
+    LH_SUB(7, 6);
+    LH_SUB(22, 7);
+    LH_SUB(23, 22);
     LH_SW(6, 31);
     LH_SW(7, 30);
     LH_SW(22, 15);
@@ -142,64 +152,37 @@ lh_subband_network(int ch, int g, int slot)
     LH_BX(29, 17, LH_WK(4));
     LH_BYD(2, 10);
     LH_BYD(3, 11);
-    xr = (float) (LH_SQRT2 * (-a[18] + a[26]));
-    a[18] += a[26];
-    a[26] = xr - a[18];
-    xr = (float) (LH_SQRT2 * (-a[19] + a[27]));
-    a[19] += a[27];
-    a[27] = xr - a[19];
-
-    xr = a[2];
-    a[19] -= a[3];
-    a[3] -= xr;
-    a[2] = a[31] - xr;
-    a[31] += xr;
-    xr = a[3];
-    a[11] -= a[19];
-    a[18] -= xr;
-    a[3] = a[30] - xr;
-    a[30] += xr;
-    xr = a[18];
-    a[27] -= a[11];
-    a[19] -= xr;
-    a[18] = a[15] - xr;
-    a[15] += xr;
-    xr = a[19];
-    a[10] -= xr;
-    a[19] = a[14] - xr;
-    a[14] += xr;
-    xr = a[10];
-    a[11] -= xr;
-    a[10] = a[23] - xr;
-    a[23] += xr;
-    xr = a[11];
-    a[26] -= xr;
-    a[11] = a[22] - xr;
-    a[22] += xr;
-    xr = a[26];
-    a[27] -= xr;
-    a[26] = a[7] - xr;
-    a[7] += xr;
-    xr = a[27];
-    a[27] = a[6] - xr;
-    a[6] += xr;
+    LH_NYD(18, 26);
+    LH_NYD(19, 27);
+    /* a chain of eight exchanges (value p against r: a[p] = a[r] - a[p], a[r] += old a[p]), each
+     * preceded by the subtractions that still need the old values */
+    LH_SUB(19, 3);
+    LH_SUB(3, 2);
+    LH_SW(2, 31);
+    LH_SUB(11, 19);
+    LH_SUB(18, 3);
+    LH_SW(3, 30);
+    LH_SUB(27, 11);
+    LH_SUB(19, 18);
+    LH_SW(18, 15);
+    LH_SUB(10, 19);
+    LH_SW(19, 14);
+    LH_SUB(11, 10);
+    LH_SW(10, 23);
+    LH_SUB(26, 11);
+    LH_SW(11, 22);
+    LH_SUB(27, 26);
+    LH_SW(26, 7);
+    LH_SW(27, 6);
 
     LH_BYD(0, 4);
     LH_BYD(1, 5);
     LH_BYD(16, 20);
     LH_BYD(17, 21);
-    xr = (float) (-LH_SQRT2 * (a[8] - a[12]));
-    a[8] += a[12];
-    a[12] = xr - a[8];
-    xr = (float) (-LH_SQRT2 * (a[9] - a[13]));
-    a[9] += a[13];
-    a[13] = xr - a[9];
-    xr = (float) (-LH_SQRT2 * (a[25] - a[29]));
-    a[25] += a[29];
-    a[29] = xr - a[25];
-    xr = (float) (-LH_SQRT2 * (a[24] + a[28]));
-    a[24] -= a[28];
-    a[28] = xr - a[24];
+    LH_MYD(8, 12);
+    LH_MYD(9, 13);
+    LH_MYD(25, 29);
+    LH_MYP(24, 28);
 
     LH_CH0(24, 16);
     LH_CH(20);
@@ -251,98 +234,105 @@ lh_subband_network(int ch, int g, int slot)
         io[i] = a[i];
 }
 
-/* reference newmdct.c:832-867, in place on 18 values */
+/* Three 6-point transforms of a short block, in place on 18 interleaved values (value i of window l at
+ * [3 i + l]; reference newmdct.c:832-867).  Per window: the six inputs fold into two sums and two
+ * differences and a scaled middle pair, which then rotate by 30 / 60 degrees.  The constants and the
+ * order of the double-precision products are the reference's (the results are compared bit for bit). */
 LH_DEVFN void
 lh_mdct_short(float *inout)
 {
+    float const w0 = LH_WIN(LH_SHORT_TYPE, 0), w1 = LH_WIN(LH_SHORT_TYPE, 1), w2 = LH_WIN(LH_SHORT_TYPE, 2);
+    double const k_mid = 2.069978111953089e-11, k_a = 1.907525191737280e-11, k_b = 1.907525191737281e-11;
+    double const cos30 = 0.86602540378443870761;
     for (int l = 0; l < 3; l++) {
-        float   tc0, tc1, tc2, ts0, ts1, ts2;
-        float  *p = inout + l;
-        ts0 = p[2 * 3] * LH_WIN(LH_SHORT_TYPE, 0) - p[5 * 3];
-        tc0 = p[0 * 3] * LH_WIN(LH_SHORT_TYPE, 2) - p[3 * 3];
-        tc1 = ts0 + tc0;
-        tc2 = ts0 - tc0;
-        ts0 = p[5 * 3] * LH_WIN(LH_SHORT_TYPE, 0) + p[2 * 3];
-        tc0 = p[3 * 3] * LH_WIN(LH_SHORT_TYPE, 2) + p[0 * 3];
-        ts1 = ts0 + tc0;
-        ts2 = -ts0 + tc0;
-        tc0 = (float) ((p[1 * 3] * LH_WIN(LH_SHORT_TYPE, 1) - p[4 * 3]) * 2.069978111953089e-11);
-        ts0 = (float) ((p[4 * 3] * LH_WIN(LH_SHORT_TYPE, 1) + p[1 * 3]) * 2.069978111953089e-11);
-        p[3 * 0] = (float) (tc1 * 1.907525191737280e-11 + tc0);
-        p[3 * 5] = (float) (-ts1 * 1.907525191737280e-11 + ts0);
-        tc2 = (float) (tc2 * 0.86602540378443870761 * 1.907525191737281e-11);
-        ts1 = (float) (ts1 * 0.5 * 1.907525191737281e-11 + ts0);
-        p[3 * 1] = tc2 - ts1;
-        p[3 * 2] = tc2 + ts1;
-        tc1 = (float) (tc1 * 0.5 * 1.907525191737281e-11 - tc0);
-        ts2 = (float) (ts2 * 0.86602540378443870761 * 1.907525191737281e-11);
-        p[3 * 3] = tc1 + ts2;
-        p[3 * 4] = tc1 - ts2;
+        float  *v = inout + l;
+        float const x0 = v[0], x1 = v[3], x2 = v[6], x3 = v[9], x4 = v[12], x5 = v[15];
+        float const lo_a = x2 * w0 - x5, lo_b = x0 * w2 - x3;
+        float const hi_a = x5 * w0 + x2, hi_b = x3 * w2 + x0;
+        float const lo_sum = lo_a + lo_b, lo_dif = lo_a - lo_b;
+        float const hi_sum = hi_a + hi_b, hi_dif = -hi_a + hi_b;
+        float const mid_lo = (float) ((x1 * w1 - x4) * k_mid);
+        float const mid_hi = (float) ((x4 * w1 + x1) * k_mid);
+        float const r1 = (float) (lo_dif * cos30 * k_b);
+        float const q1 = (float) (hi_sum * 0.5 * k_b + mid_hi);
+        float const r2 = (float) (lo_sum * 0.5 * k_b - mid_lo);
+        float const q2 = (float) (hi_dif * cos30 * k_b);
+        v[0] = (float) (lo_sum * k_a + mid_lo);
+        v[15] = (float) (-hi_sum * k_a + mid_hi);
+        v[3] = r1 - q1;
+        v[6] = r1 + q1;
+        v[9] = r2 + q2;
+        v[12] = r2 - q2;
     }
 }
 
-/* reference newmdct.c:869-941 */
+/* a x[ia] (+/-) y (+/-) b x[ib] (+/-) c x[ic], summed left to right: one row of the 9-point rotations of
+ * lh_mdct_long.  neg_* say which terms enter negated (x - y and x + (-y) are the same float). */
+LH_DEVFN float
+lh_mdct_row(float a, int ia, int neg_a, float y, int neg_y, float b, int ib, int neg_b, float c, int ic, int neg_c)
+{
+    float const ta = a * LH_CX(ia), tb = b * LH_CX(ib), tc = c * LH_CX(ic);
+    float   acc = neg_a ? -ta : ta;
+    acc = neg_y ? acc - y : acc + y;
+    acc = neg_b ? acc - tb : acc + tb;
+    acc = neg_c ? acc - tc : acc + tc;
+    return acc;
+}
+
+/* 18-point MDCT of a long block (reference newmdct.c:869-941): the windowed input folds into four
+ * differences and four sums per half; each half yields one direct pair, then three pairs from the rows of
+ * a 3 x 3 rotation whose coefficients are permutations of LH_CX(0..2) / LH_CX(3..5). */
 LH_DEVFN void
 lh_mdct_long(float *out, float const *in)
 {
-    float   ct, st;
+    float const cx6 = LH_CX(6), cx7 = LH_CX(7);
     {
-        float   tc1, tc2, tc3, tc4, ts5, ts6, ts7, ts8;
-        tc1 = in[17] - in[9];
-        tc3 = in[15] - in[11];
-        tc4 = in[14] - in[12];
-        ts5 = in[0] + in[8];
-        ts6 = in[1] + in[7];
-        ts7 = in[2] + in[6];
-        ts8 = in[3] + in[5];
-        out[17] = (ts5 + ts7 - ts8) - (ts6 - in[4]);
-        st = (ts5 + ts7 - ts8) * LH_CX(7) + (ts6 - in[4]);
-        ct = (tc1 - tc3 - tc4) * LH_CX(6);
-        out[5] = ct + st;
-        out[6] = ct - st;
-        tc2 = (in[16] - in[10]) * LH_CX(6);
-        ts6 = ts6 * LH_CX(7) + in[4];
-        ct = tc1 * LH_CX(0) + tc2 + tc3 * LH_CX(1) + tc4 * LH_CX(2);
-        st = -ts5 * LH_CX(4) + ts6 - ts7 * LH_CX(5) + ts8 * LH_CX(3);
-        out[1] = ct + st;
-        out[2] = ct - st;
-        ct = tc1 * LH_CX(1) - tc2 - tc3 * LH_CX(2) + tc4 * LH_CX(0);
-        st = -ts5 * LH_CX(5) + ts6 - ts7 * LH_CX(3) + ts8 * LH_CX(4);
-        out[9] = ct + st;
-        out[10] = ct - st;
-        ct = tc1 * LH_CX(2) - tc2 + tc3 * LH_CX(0) - tc4 * LH_CX(1);
-        st = ts5 * LH_CX(3) - ts6 + ts7 * LH_CX(4) - ts8 * LH_CX(5);
-        out[13] = ct + st;
-        out[14] = ct - st;
+        /* differences of the upper nine, sums of the lower nine */
+        float const d1 = in[17] - in[9], d3 = in[15] - in[11], d4 = in[14] - in[12];
+        float const s5 = in[0] + in[8], s6 = in[1] + in[7], s7 = in[2] + in[6], s8 = in[3] + in[5];
+        float const even = s5 + s7 - s8, odd = s6 - in[4];
+        float const cd = (d1 - d3 - d4) * cx6, sd = even * cx7 + odd;
+        float const d2 = (in[16] - in[10]) * cx6, s6m = s6 * cx7 + in[4];
+        float   cr, sr;
+        out[17] = even - odd;
+        out[5] = cd + sd;
+        out[6] = cd - sd;
+        cr = lh_mdct_row(d1, 0, 0, d2, 0, d3, 1, 0, d4, 2, 0);
+        sr = lh_mdct_row(s5, 4, 1, s6m, 0, s7, 5, 1, s8, 3, 0);
+        out[1] = cr + sr;
+        out[2] = cr - sr;
+        cr = lh_mdct_row(d1, 1, 0, d2, 1, d3, 2, 1, d4, 0, 0);
+        sr = lh_mdct_row(s5, 5, 1, s6m, 0, s7, 3, 1, s8, 4, 0);
+        out[9] = cr + sr;
+        out[10] = cr - sr;
+        cr = lh_mdct_row(d1, 2, 0, d2, 1, d3, 0, 0, d4, 1, 1);
+        sr = lh_mdct_row(s5, 3, 0, s6m, 1, s7, 4, 0, s8, 5, 1);
+        out[13] = cr + sr;
+        out[14] = cr - sr;
     }
     {
-        float   ts1, ts2, ts3, ts4, tc5, tc6, tc7, tc8;
-        ts1 = in[8] - in[0];
-        ts3 = in[6] - in[2];
-        ts4 = in[5] - in[3];
-        tc5 = in[17] + in[9];
-        tc6 = in[16] + in[10];
-        tc7 = in[15] + in[11];
-        tc8 = in[14] + in[12];
-        out[0] = (tc5 + tc7 + tc8) + (tc6 + in[13]);
-        ct = (tc5 + tc7 + tc8) * LH_CX(7) - (tc6 + in[13]);
-        st = (ts1 - ts3 + ts4) * LH_CX(6);
-        out[11] = ct + st;
-        out[12] = ct - st;
-        ts2 = (in[7] - in[1]) * LH_CX(6);
-        tc6 = in[13] - tc6 * LH_CX(7);
-        ct = tc5 * LH_CX(3) - tc6 + tc7 * LH_CX(4) + tc8 * LH_CX(5);
-        st = ts1 * LH_CX(2) + ts2 + ts3 * LH_CX(0) + ts4 * LH_CX(1);
-        out[3] = ct + st;
-        out[4] = ct - st;
-        ct = -tc5 * LH_CX(5) + tc6 - tc7 * LH_CX(3) - tc8 * LH_CX(4);
-        st = ts1 * LH_CX(1) + ts2 - ts3 * LH_CX(2) - ts4 * LH_CX(0);
-        out[7] = ct + st;
-        out[8] = ct - st;
-        ct = -tc5 * LH_CX(4) + tc6 - tc7 * LH_CX(5) - tc8 * LH_CX(3);
-        st = ts1 * LH_CX(0) - ts2 + ts3 * LH_CX(1) - ts4 * LH_CX(2);
-        out[15] = ct + st;
-        out[16] = ct - st;
+        /* differences of the lower nine, sums of the upper nine */
+        float const e1 = in[8] - in[0], e3 = in[6] - in[2], e4 = in[5] - in[3];
+        float const t5 = in[17] + in[9], t6 = in[16] + in[10], t7 = in[15] + in[11], t8 = in[14] + in[12];
+        float const even = t5 + t7 + t8, odd = t6 + in[13];
+        float const cd = even * cx7 - odd, sd = (e1 - e3 + e4) * cx6;
+        float const e2 = (in[7] - in[1]) * cx6, t6m = in[13] - t6 * cx7;
+        float   cr, sr;
+        out[0] = even + odd;
+        out[11] = cd + sd;
+        out[12] = cd - sd;
+        cr = lh_mdct_row(t5, 3, 0, t6m, 1, t7, 4, 0, t8, 5, 0);
+        sr = lh_mdct_row(e1, 2, 0, e2, 0, e3, 0, 0, e4, 1, 0);
+        out[3] = cr + sr;
+        out[4] = cr - sr;
+        cr = lh_mdct_row(t5, 5, 1, t6m, 0, t7, 3, 1, t8, 4, 1);
+        sr = lh_mdct_row(e1, 1, 0, e2, 0, e3, 2, 1, e4, 0, 1);
+        out[7] = cr + sr;
+        out[8] = cr - sr;
+        cr = lh_mdct_row(t5, 4, 1, t6m, 0, t7, 5, 1, t8, 3, 1);
+        sr = lh_mdct_row(e1, 0, 0, e2, 1, e3, 1, 0, e4, 2, 1);
+        out[15] = cr + sr;
+        out[16] = cr - sr;
     }
 }
 

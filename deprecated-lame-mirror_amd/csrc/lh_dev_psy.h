@@ -105,6 +105,21 @@ lh_ns_interp(float x, float y, float r)
  * pass (reference fft.c:70-146, one unit = one trip of an inner do-while) are
  * dealt to the lanes.  `unit0'/`nunits' let the three short transforms share
  * one call. */
+/* plane rotation of (x, y) by the angle whose cosine / sine are c / s: the component along the new
+ * axis and the one across it */
+struct LhRot {
+    float   along, across;
+};
+
+LH_DEVFN LhRot
+lh_rot(float c, float s, float x, float y)
+{
+    LhRot   r;
+    r.along = c * x + s * y;
+    r.across = s * x - c * y;
+    return r;
+}
+
 LH_DEVFN void
 lh_fht_unit(lh_f32x4 tw, float *fz, int k1, int u)
 {
@@ -112,55 +127,44 @@ lh_fht_unit(lh_f32x4 tw, float *fz, int k1, int u)
     int const k2 = k1 << 1, k3 = k2 + k1, k4 = k2 << 1;
     int const blk = u / kx, i = u - blk * kx;
     if (i == 0) {
-        float  *fi = fz + blk * k4;
-        float  *gi = fi + kx;
-        float   f0, f1, f2, f3;
-        f1 = fi[0] - fi[k1];
-        f0 = fi[0] + fi[k1];
-        f3 = fi[k2] - fi[k3];
-        f2 = fi[k2] + fi[k3];
-        fi[k2] = f0 - f2;
-        fi[0] = f0 + f2;
-        fi[k3] = f1 - f3;
-        fi[k1] = f1 + f3;
-        f1 = gi[0] - gi[k1];
-        f0 = gi[0] + gi[k1];
-        f3 = (float) (LH_SQRT2 * gi[k3]);
-        f2 = (float) (LH_SQRT2 * gi[k2]);
-        gi[k2] = f0 - f2;
-        gi[0] = f0 + f2;
-        gi[k3] = f1 - f3;
-        gi[k1] = f1 + f3;
+        /* the unit on the block's axes: no rotation, the mirrored quarter only scales by sqrt 2 */
+        float  *lo = fz + blk * k4;
+        float  *hi = lo + kx;
+        float const p0 = lo[0], p1 = lo[k1], p2 = lo[k2], p3 = lo[k3];
+        float const s01 = p0 + p1, d01 = p0 - p1, s23 = p2 + p3, d23 = p2 - p3;
+        float const q0 = hi[0], q1 = hi[k1];
+        float const r2 = (float) (LH_SQRT2 * hi[k2]), r3 = (float) (LH_SQRT2 * hi[k3]);
+        float const t01 = q0 + q1, u01 = q0 - q1;
+        lo[0] = s01 + s23;
+        lo[k1] = d01 + d23;
+        lo[k2] = s01 - s23;
+        lo[k3] = d01 - d23;
+        hi[0] = t01 + r2;
+        hi[k1] = u01 + r3;
+        hi[k2] = t01 - r2;
+        hi[k3] = u01 - r3;
     }
     else {
-        float const c1 = tw.x, s1 = tw.y, c2 = tw.z, s2 = tw.w;
-        float  *fi = fz + blk * k4 + i;
-        float  *gi = fz + blk * k4 + k1 - i;
-        float   a, b, g0, f0, f1, g1, f2, g2, f3, g3;
-        b = s2 * fi[k1] - c2 * gi[k1];
-        a = c2 * fi[k1] + s2 * gi[k1];
-        f1 = fi[0] - a;
-        f0 = fi[0] + a;
-        g1 = gi[0] - b;
-        g0 = gi[0] + b;
-        b = s2 * fi[k3] - c2 * gi[k3];
-        a = c2 * fi[k3] + s2 * gi[k3];
-        f3 = fi[k2] - a;
-        f2 = fi[k2] + a;
-        g3 = gi[k2] - b;
-        g2 = gi[k2] + b;
-        b = s1 * f2 - c1 * g3;
-        a = c1 * f2 + s1 * g3;
-        fi[k2] = f0 - a;
-        fi[0] = f0 + a;
-        gi[k3] = g1 - b;
-        gi[k1] = g1 + b;
-        b = c1 * g2 - s1 * f3;
-        a = s1 * g2 + c1 * f3;
-        gi[k2] = g0 - a;
-        gi[0] = g0 + a;
-        fi[k3] = f1 - b;
-        fi[k1] = f1 + b;
+        /* position i and its mirror k1 - i: the second and fourth quarters turn by the double angle
+         * (tw.z, tw.w), then the two half-sums turn by the single angle (tw.x, tw.y) */
+        float  *lo = fz + blk * k4 + i;
+        float  *hi = fz + blk * k4 + k1 - i;
+        LhRot const q1 = lh_rot(tw.z, tw.w, lo[k1], hi[k1]);
+        LhRot const q3 = lh_rot(tw.z, tw.w, lo[k3], hi[k3]);
+        float const le = lo[0] + q1.along, lm = lo[0] - q1.along;
+        float const he = hi[0] + q1.across, hm = hi[0] - q1.across;
+        float const l2e = lo[k2] + q3.along, l2m = lo[k2] - q3.along;
+        float const h2e = hi[k2] + q3.across, h2m = hi[k2] - q3.across;
+        LhRot const ra = lh_rot(tw.x, tw.y, l2e, h2m);
+        LhRot const rb = lh_rot(tw.y, tw.x, h2e, l2m);
+        lo[0] = le + ra.along;
+        lo[k2] = le - ra.along;
+        hi[k1] = hm + ra.across;
+        hi[k3] = hm - ra.across;
+        hi[0] = he + rb.along;
+        hi[k2] = he - rb.along;
+        lo[k1] = lm + rb.across;
+        lo[k3] = lm - rb.across;
     }
 }
 
@@ -819,29 +823,23 @@ lh_psy_granule(int gr, LhPsyCarry nb)
                 }
                 LH_WAVE_SYNC_MEM();
                 for (int i = 0; i < 9; i++) {
-                    float   p = peak[i];
+                    /* a sub-block's peak against the one two sub-blocks earlier: a rise counts by its
+                     * ratio, a fall only beyond 10 x (reference psymodel.c:836-850) */
+                    float const now = peak[i], then = en_subshort[i + 1];
                     if (lane == 0)
-                        lh_lds.ss.last_en_subshort[chn][i] = p;
-                    en_subshort[i + 3] = p;
-                    en_short[1 + i / 3] += p;
-                    if (p > en_subshort[i + 3 - 2])
-                        p = p / en_subshort[i + 3 - 2];
-                    else if (en_subshort[i + 3 - 2] > p * 10.0f)
-                        p = en_subshort[i + 3 - 2] / (p * 10.0f);
-                    else
-                        p = 0.0;
-                    attack_intensity[i + 3] = p;
+                        lh_lds.ss.last_en_subshort[chn][i] = now;
+                    en_subshort[i + 3] = now;
+                    en_short[1 + i / 3] += now;
+                    attack_intensity[i + 3] = (now > then) ? now / then : (then > now * 10.0f) ? then / (now * 10.0f) : 0.0f;
                 }
-                for (int i = 0; i < 3; ++i) {
-                    float const enn =
-                        en_subshort[i * 3 + 3] + en_subshort[i * 3 + 4] + en_subshort[i * 3 + 5];
-                    float   factor = 1.f;
-                    if (en_subshort[i * 3 + 5] * 6 < enn) {
-                        factor *= 0.5f;
-                        if (en_subshort[i * 3 + 4] * 6 < enn)
-                            factor *= 0.5f;
-                    }
-                    L.sub_short_factor[chn][i] = factor;
+                for (int blk = 0; blk < 3; ++blk) {
+                    /* a short block whose energy sits in its first sub-blocks gets a lower threshold
+                     * (reference psymodel.c:853-864): halve once, or twice, when a later sub-block holds
+                     * less than a sixth of the block */
+                    float const e0 = en_subshort[3 * blk + 3], e1 = en_subshort[3 * blk + 4], e2 = en_subshort[3 * blk + 5];
+                    float const whole = e0 + e1 + e2;
+                    int const tail_low = e2 * 6 < whole, mid_low = e1 * 6 < whole;
+                    L.sub_short_factor[chn][blk] = tail_low ? (mid_low ? 0.25f : 0.5f) : 1.0f;
                 }
                 {
                     float const x = T->attack_threshold[chn];
