@@ -922,58 +922,48 @@ lq_balance_noise(const LhCtx & c, LhQS & S, LhChanLds & Q, const LhQR & R, LhGrR
     return !status;
 }
 
-/* reference quantize.c:367-429 */
+/* The global gain at which the granule just fits (reference quantize.c:367-429, bin_search): start from
+ * the gain the channel's previous granule ended at and walk towards the target in steps of 4 or 2; once
+ * the walk has crossed the target (or hit an end of the range) every further step halves, and a step
+ * of 1 ends the search.  Should the last trial be over the budget, the gain rises one by one until it fits.  The
+ * channel remembers where it ended and whether it had to move far (lh_lds.ss.OldValue / CurrentStep). */
 template < int NS > LH_DEVFN int
 lq_bin_search(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q, int desired_rate, int ch)
 {
-    int     nBits;
-    int     CurrentStep = lh_uni_i(lh_lds.ss.CurrentStep[ch]);
-    int     flag_GoneOver = 0;
-    int const start = lh_uni_i(lh_lds.ss.OldValue[ch]);
-    int     Direction = 0;
-    g.global_gain = start;
-    desired_rate -= g.part2_length;
+    int const from = lh_uni_i(lh_lds.ss.OldValue[ch]);
+    int const want = desired_rate - g.part2_length;
+    int     stride = lh_uni_i(lh_lds.ss.CurrentStep[ch]);
+    int     last_move = 0;      /* +1: the gain went up (too many bits), -1: down, 0: no trial yet */
+    int     halving = 0;
+    int     bits;
+    g.global_gain = from;
     for (;;) {
-        int     step;
-        nBits = lq_count_bits < 0, NS > (c, S, R, g, Q);
-        if (CurrentStep == 1 || nBits == desired_rate)
+        int     move;
+        bits = lq_count_bits < 0, NS > (c, S, R, g, Q);
+        if (stride == 1 || bits == want)
             break;
-        if (nBits > desired_rate) {
-            if (Direction == 2)
-                flag_GoneOver = 1;
-            if (flag_GoneOver)
-                CurrentStep /= 2;
-            Direction = 1;
-            step = CurrentStep;
-        }
-        else {
-            if (Direction == 1)
-                flag_GoneOver = 1;
-            if (flag_GoneOver)
-                CurrentStep /= 2;
-            Direction = 2;
-            step = -CurrentStep;
-        }
-        g.global_gain += step;
-        if (g.global_gain < 0) {
-            g.global_gain = 0;
-            flag_GoneOver = 1;
-        }
-        if (g.global_gain > 255) {
-            g.global_gain = 255;
-            flag_GoneOver = 1;
+        move = (bits > want) ? 1 : -1;
+        if (last_move == -move)
+            halving = 1;
+        if (halving)
+            stride /= 2;
+        last_move = move;
+        g.global_gain += move * stride;
+        if (g.global_gain < 0 || g.global_gain > 255) {
+            g.global_gain = g.global_gain < 0 ? 0 : 255;
+            halving = 1;
         }
     }
-    while (nBits > desired_rate && g.global_gain < 255) {
+    while (bits > want && g.global_gain < 255) {
         g.global_gain++;
-        nBits = lq_count_bits < 0, NS > (c, S, R, g, Q);
+        bits = lq_count_bits < 0, NS > (c, S, R, g, Q);
     }
     if (c.lane == 0) {
-        lh_lds.ss.CurrentStep[ch] = (start - g.global_gain >= 4) ? 4 : 2;
+        lh_lds.ss.CurrentStep[ch] = (from - g.global_gain >= 4) ? 4 : 2;
         lh_lds.ss.OldValue[ch] = g.global_gain;
     }
-    g.part2_3_length = nBits;
-    return nBits;
+    g.part2_3_length = bits;
+    return bits;
 }
 
 /* the working image becomes the best one: it goes to its final place in LDS (Q.ix[0]) */

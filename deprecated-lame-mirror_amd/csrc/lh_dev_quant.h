@@ -1587,110 +1587,107 @@ lh_frame_bits(const LhConfig * cfg, int bitrate_index, int padding)
     return 8 * ((cfg->version + 1) * 72000 * bit_rate / cfg->samplerate + padding);
 }
 
-LH_DEVFN void
-lh_resv_max_bits(const LhConfig * cfg, int ResvSize, int ResvMax0, int *substep, int mean_bits,
-                 int *targ_bits, int *extra_bits, int cbr)
+/* What the reservoir lets a granule spend (reference reservoir.c:171-218, ResvMaxBits): a target -- the
+ * mean, plus whatever the reservoir holds beyond 90 % of its size, or minus a tenth while it is being
+ * filled -- and a reserve that may be handed out on top (up to 60 % of the reservoir's size).  `flags'
+ * is substep_shaping: bit 0 shrinks the usable reservoir, bit 7 records "draining". */
+struct LhGranuleBudget {
+    int     target, reserve;
+};
+
+LH_DEVFN LhGranuleBudget
+lh_granule_budget(const LhConfig * cfg, int held, int size, int *flags, int mean, int count_mean)
 {
-    int     add_bits, targBits, extraBits;
-    int     ResvMax = ResvMax0;
-    if (cbr)
-        ResvSize += mean_bits;
-    if (*substep & 1)
-        ResvMax = (int) (ResvMax * 0.9);
-    targBits = mean_bits;
-    if (ResvSize * 10 > ResvMax * 9) {
-        add_bits = ResvSize - (ResvMax * 9) / 10;
-        targBits += add_bits;
-        *substep |= 0x80;
+    LhGranuleBudget b;
+    int const usable = (*flags & 1) ? (int) (size * 0.9) : size;
+    int const level = count_mean ? held + mean : held;
+    int const cushion = (size * 6) / 10;
+    int     overflow = 0;
+    b.target = mean;
+    if (level * 10 > usable * 9) {
+        overflow = level - (usable * 9) / 10;
+        b.target += overflow;
+        *flags |= 0x80;
     }
     else {
-        add_bits = 0;
-        *substep &= 0x7f;
-        if (!cfg->disable_reservoir && !(*substep & 1))
-            targBits = (int) (targBits - .1 * mean_bits);
+        *flags &= 0x7f;
+        if (!cfg->disable_reservoir && !(*flags & 1))
+            b.target = (int) (b.target - .1 * mean);
     }
-    extraBits = (ResvSize < (ResvMax0 * 6) / 10 ? ResvSize : (ResvMax0 * 6) / 10);
-    extraBits -= add_bits;
-    if (extraBits < 0)
-        extraBits = 0;
-    *targ_bits = targBits;
-    *extra_bits = extraBits;
+    b.reserve = (level < cushion ? level : cushion) - overflow;
+    if (b.reserve < 0)
+        b.reserve = 0;
+    return b;
 }
 
+/* Split a granule's budget over its channels by perceptual entropy (reference quantize_pvt.c:428-486,
+ * on_pe): every channel starts from an equal share, asks for pe / 700 times that (at most three quarters
+ * of the mean more), the requests are scaled down to the reserve, and the total is capped.  Returns the
+ * granule's ceiling (target + reserve). */
 LH_DEVFN int
 lh_on_pe(const LhConfig * cfg, int ResvSize, int ResvMax, int *substep, const float pe[2],
          int targ_bits[2], int mean_bits, int cbr)
 {
-    int     extra_bits = 0, tbits, bits;
-    int     add_bits[2] = { 0, 0 };
-    int     max_bits, ch;
     int const nch = cfg->channels;
-    lh_resv_max_bits(cfg, ResvSize, ResvMax, substep, mean_bits, &tbits, &extra_bits, cbr);
-    max_bits = tbits + extra_bits;
-    if (max_bits > LH_MAX_BITS_PER_GRANULE)
-        max_bits = LH_MAX_BITS_PER_GRANULE;
+    LhGranuleBudget const budget = lh_granule_budget(cfg, ResvSize, ResvMax, substep, mean_bits, cbr);
+    int const ceiling = (budget.target + budget.reserve > LH_MAX_BITS_PER_GRANULE) ? LH_MAX_BITS_PER_GRANULE
+        : budget.target + budget.reserve;
+    int const share = (LH_MAX_BITS_PER_CHANNEL < budget.target / nch) ? LH_MAX_BITS_PER_CHANNEL : budget.target / nch;
+    int const most = mean_bits * 3 / 4;
+    int     want[2] = { 0, 0 }, wanted = 0, left = budget.reserve, total = 0;
     targ_bits[1] = 0;           /* mono: the second channel has no budget */
-    for (bits = 0, ch = 0; ch < nch; ++ch) {
-        targ_bits[ch] = (LH_MAX_BITS_PER_CHANNEL < tbits / nch) ? LH_MAX_BITS_PER_CHANNEL : tbits / nch;
-        add_bits[ch] = (int) (targ_bits[ch] * pe[ch] / 700.0 - targ_bits[ch]);
-        if (add_bits[ch] > mean_bits * 3 / 4)
-            add_bits[ch] = mean_bits * 3 / 4;
-        if (add_bits[ch] < 0)
-            add_bits[ch] = 0;
-        if (add_bits[ch] + targ_bits[ch] > LH_MAX_BITS_PER_CHANNEL) {
-            int const v = LH_MAX_BITS_PER_CHANNEL - targ_bits[ch];
-            add_bits[ch] = (0 > v) ? 0 : v;
-        }
-        bits += add_bits[ch];
+    for (int ch = 0; ch < nch; ++ch) {
+        int     w = (int) (share * pe[ch] / 700.0 - share);
+        w = w > most ? most : w;
+        w = w < 0 ? 0 : w;
+        if (w + share > LH_MAX_BITS_PER_CHANNEL)
+            w = (LH_MAX_BITS_PER_CHANNEL - share > 0) ? LH_MAX_BITS_PER_CHANNEL - share : 0;
+        want[ch] = w;
+        wanted += w;
     }
-    if (bits > extra_bits && bits > 0)
-        for (ch = 0; ch < nch; ++ch)
-            add_bits[ch] = extra_bits * add_bits[ch] / bits;
-    for (ch = 0; ch < nch; ++ch) {
-        targ_bits[ch] += add_bits[ch];
-        extra_bits -= add_bits[ch];
+    for (int ch = 0; ch < nch; ++ch) {
+        int const granted = (wanted > budget.reserve && wanted > 0) ? budget.reserve * want[ch] / wanted : want[ch];
+        targ_bits[ch] = share + granted;
+        left -= granted;
+        total += targ_bits[ch];
     }
-    for (bits = 0, ch = 0; ch < nch; ++ch)
-        bits += targ_bits[ch];
-    if (bits > LH_MAX_BITS_PER_GRANULE) {
-        for (ch = 0; ch < nch; ++ch) {
-            targ_bits[ch] *= LH_MAX_BITS_PER_GRANULE;
-            targ_bits[ch] /= bits;
-        }
-    }
-    return max_bits;
+    (void) left;
+    if (total > LH_MAX_BITS_PER_GRANULE)
+        for (int ch = 0; ch < nch; ++ch)
+            targ_bits[ch] = targ_bits[ch] * LH_MAX_BITS_PER_GRANULE / total;
+    return ceiling;
 }
 
+/* Mid/side frames: bits move from the side channel to the mid channel according to how little of the
+ * energy the side holds (reference quantize_pvt.c:489-541, reduce_side): up to a third of the side's
+ * share at ms_ener_ratio 0, nothing from 0.5 on; the side keeps at least 125 bits, and the pair stays
+ * within the granule's ceiling. */
 LH_DEVFN void
 lh_reduce_side(int targ_bits[2], float ms_ener_ratio, int mean_bits, int max_bits)
 {
-    int     move_bits;
-    float   fac;
-    fac = (float) (.33 * (.5 - ms_ener_ratio) / .5);
-    if (fac < 0)
-        fac = 0;
-    if (fac > .5)
-        fac = .5;
-    move_bits = (int) (fac * .5 * (targ_bits[0] + targ_bits[1]));
-    if (move_bits > LH_MAX_BITS_PER_CHANNEL - targ_bits[0])
-        move_bits = LH_MAX_BITS_PER_CHANNEL - targ_bits[0];
-    if (move_bits < 0)
-        move_bits = 0;
+    float   tilt = (float) (.33 * (.5 - ms_ener_ratio) / .5);
+    int     shift, both;
+    tilt = tilt < 0 ? 0 : tilt;
+    tilt = tilt > .5 ? .5 : tilt;
+    shift = (int) (tilt * .5 * (targ_bits[0] + targ_bits[1]));
+    if (shift > LH_MAX_BITS_PER_CHANNEL - targ_bits[0])
+        shift = LH_MAX_BITS_PER_CHANNEL - targ_bits[0];
+    shift = shift < 0 ? 0 : shift;
     if (targ_bits[1] >= 125) {
-        if (targ_bits[1] - move_bits > 125) {
-            if (targ_bits[0] < mean_bits)
-                targ_bits[0] += move_bits;
-            targ_bits[1] -= move_bits;
+        int const side_after = targ_bits[1] - shift;
+        if (side_after > 125) {
+            targ_bits[0] += (targ_bits[0] < mean_bits) ? shift : 0;
+            targ_bits[1] = side_after;
         }
         else {
             targ_bits[0] += targ_bits[1] - 125;
             targ_bits[1] = 125;
         }
     }
-    move_bits = targ_bits[0] + targ_bits[1];
-    if (move_bits > max_bits) {
-        targ_bits[0] = (max_bits * targ_bits[0]) / move_bits;
-        targ_bits[1] = (max_bits * targ_bits[1]) / move_bits;
+    both = targ_bits[0] + targ_bits[1];
+    if (both > max_bits) {
+        targ_bits[0] = (max_bits * targ_bits[0]) / both;
+        targ_bits[1] = (max_bits * targ_bits[1]) / both;
     }
 }
 

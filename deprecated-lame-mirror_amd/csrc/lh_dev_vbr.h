@@ -1082,70 +1082,66 @@ LH_DEVFN void
 lh_abr_target_bits(const LhConfig * cfg, int ResvSize, int substep, float pe[2][2], const float ms_ener_ratio[2],
                    const int block_type[2][2], int mode_ext, int targ_bits[2][2], int *analog_silence_bits)
 {
-    float   res_factor;
-    int     totbits, mean_bits, dummy, max_frame_bits;
-    int const framesize = 576 * cfg->mode_gr;
-    int const nch = cfg->channels;
+    int const nch = cfg->channels, parts = cfg->mode_gr * nch;
+    int const side_bits = cfg->sideinfo_len * 8;
+    int     unused_mean, unused_max, frame_cap, per_part, granted = 0;
+    float   base;
     targ_bits[0][1] = targ_bits[1][1] = 0;
-
-    max_frame_bits = lh_vbr_full_bits(cfg, cfg->vbr_max_bitrate_index, ResvSize, &mean_bits, &dummy);
-    mean_bits = lh_frame_bits(cfg, 1, 0) - cfg->sideinfo_len * 8;
-    *analog_silence_bits = mean_bits / (cfg->mode_gr * cfg->channels);
-
-    mean_bits = cfg->vbr_avg_bitrate_kbps * framesize * 1000;
-    if (substep & 1)
-        mean_bits *= 1.09;
-    mean_bits /= cfg->samplerate;
-    mean_bits -= cfg->sideinfo_len * 8;
-    mean_bits /= (cfg->mode_gr * cfg->channels);
-
-    res_factor = .93 + .07 * (11.0 - cfg->compression_ratio) / (11.0 - 5.5);
-    if (res_factor < .90)
-        res_factor = .90;
-    if (res_factor > 1.00)
-        res_factor = 1.00;
+    /* the most a frame may hold (top bitrate + reservoir), and what silence gets (lowest bitrate) */
+    frame_cap = lh_vbr_full_bits(cfg, cfg->vbr_max_bitrate_index, ResvSize, &unused_mean, &unused_max);
+    *analog_silence_bits = (lh_frame_bits(cfg, 1, 0) - side_bits) / parts;
+    {
+        /* a granule-channel's share of the mean bitrate (9 % more while substep bit 0 is set) */
+        int     frame = cfg->vbr_avg_bitrate_kbps * (576 * cfg->mode_gr) * 1000;
+        if (substep & 1)
+            frame *= 1.09;
+        frame /= cfg->samplerate;
+        per_part = (frame - side_bits) / parts;
+    }
+    {
+        /* 93 .. 100 % of it as the base, by compression ratio (the rest feeds the reservoir) */
+        float   f = .93 + .07 * (11.0 - cfg->compression_ratio) / (11.0 - 5.5);
+        f = f < .90 ? .90 : f;
+        f = f > 1.00 ? 1.00 : f;
+        base = f;
+    }
     for (int gr = 0; gr < 2; gr++) {
-        int     sum = 0;
+        int     granule = 0;
         for (int ch = 0; ch < nch; ch++) {
-            targ_bits[gr][ch] = res_factor * mean_bits;
+            int     t = base * per_part;
             if (pe[gr][ch] > 700) {
-                int     add_bits = (pe[gr][ch] - 700) / 1.4;
-                if (block_type[gr][ch] == LH_SHORT_TYPE) {
-                    if (add_bits < mean_bits / 2)
-                        add_bits = mean_bits / 2;
-                }
-                if (add_bits > mean_bits * 3 / 2)
-                    add_bits = mean_bits * 3 / 2;
-                else if (add_bits < 0)
-                    add_bits = 0;
-                targ_bits[gr][ch] += add_bits;
+                /* demanding granules get (pe - 700) / 1.4 more: at least half a share for short
+                 * blocks, at most one and a half */
+                int     more = (pe[gr][ch] - 700) / 1.4;
+                if (block_type[gr][ch] == LH_SHORT_TYPE && more < per_part / 2)
+                    more = per_part / 2;
+                if (more > per_part * 3 / 2)
+                    more = per_part * 3 / 2;
+                else if (more < 0)
+                    more = 0;
+                t += more;
             }
-            if (targ_bits[gr][ch] > LH_MAX_BITS_PER_CHANNEL)
-                targ_bits[gr][ch] = LH_MAX_BITS_PER_CHANNEL;
-            sum += targ_bits[gr][ch];
+            t = t > LH_MAX_BITS_PER_CHANNEL ? LH_MAX_BITS_PER_CHANNEL : t;
+            targ_bits[gr][ch] = t;
+            granule += t;
         }
-        if (sum > LH_MAX_BITS_PER_GRANULE)
-            for (int ch = 0; ch < nch; ++ch) {
-                targ_bits[gr][ch] *= LH_MAX_BITS_PER_GRANULE;
-                targ_bits[gr][ch] /= sum;
-            }
+        if (granule > LH_MAX_BITS_PER_GRANULE)
+            for (int ch = 0; ch < nch; ++ch)
+                targ_bits[gr][ch] = targ_bits[gr][ch] * LH_MAX_BITS_PER_GRANULE / granule;
     }
     if (mode_ext == LH_MPG_MD_MS_LR)
         for (int gr = 0; gr < 2; gr++)
-            lh_reduce_side(targ_bits[gr], ms_ener_ratio[gr], mean_bits * cfg->channels, LH_MAX_BITS_PER_GRANULE);
-    totbits = 0;
+            lh_reduce_side(targ_bits[gr], ms_ener_ratio[gr], per_part * nch, LH_MAX_BITS_PER_GRANULE);
     for (int gr = 0; gr < 2; gr++)
         for (int ch = 0; ch < nch; ch++) {
             if (targ_bits[gr][ch] > LH_MAX_BITS_PER_CHANNEL)
                 targ_bits[gr][ch] = LH_MAX_BITS_PER_CHANNEL;
-            totbits += targ_bits[gr][ch];
+            granted += targ_bits[gr][ch];
         }
-    if (totbits > max_frame_bits && totbits > 0)
+    if (granted > frame_cap && granted > 0)
         for (int gr = 0; gr < 2; gr++)
-            for (int ch = 0; ch < nch; ch++) {
-                targ_bits[gr][ch] *= max_frame_bits;
-                targ_bits[gr][ch] /= totbits;
-            }
+            for (int ch = 0; ch < nch; ch++)
+                targ_bits[gr][ch] = targ_bits[gr][ch] * frame_cap / granted;
 }
 
 #endif
