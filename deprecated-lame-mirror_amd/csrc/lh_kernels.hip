@@ -38,47 +38,42 @@ extern "C" { int lh_emu_poison_lds = 0; }
 #include "lh_dev_quant.h"
 #include "lh_dev_qloop.h"
 
-/* reference encoder.c:56-137, wave-uniform */
+/* The ATH level follows the loudness of the frame (reference encoder.c:56-137, adjust_ATH; wave-uniform):
+ * `factor' scales the threshold in quiet, `limit' is the floor it may not be raised above on the way
+ * back up.  A loud frame (half the louder granule's loudness, times the sensitivity, above 1/32)
+ * snaps the factor back into [limit, 1]; a quiet one pulls it towards 31.98 x that level + 0.000625 --
+ * from above by 7.5 % of the way per frame, from below at once, within the previous limit. */
 LH_DEVFN void
 lh_adjust_ATH(const LhTables * T, const float loud[2][2], float *factor, float *limit)
 {
-    float   gr2_max, max_pow;
-    float   f = *factor, lim = *limit;
+    float const was = *factor, floor_was = *limit;
+    float   level, now, floor_now;
     if (T->ath_use_adjust == 0) {
         *factor = 1.0;
         return;
     }
-    max_pow = loud[0][0];
-    gr2_max = loud[1][0];
-    max_pow += loud[0][1];
-    gr2_max += loud[1][1];
-    max_pow = (max_pow > gr2_max) ? max_pow : gr2_max;
-    max_pow = (float) (max_pow * 0.5);
-    max_pow *= T->aa_sensitivity_p;
-    if (max_pow > 0.03125) {
-        if (f >= 1.0)
-            f = 1.0;
-        else if (f < lim)
-            f = lim;
-        lim = 1.0;
+    {
+        float const first = loud[0][0] + loud[0][1], second = loud[1][0] + loud[1][1];
+        level = (first > second) ? first : second;
+        level = (float) (level * 0.5);
+        level *= T->aa_sensitivity_p;
+    }
+    if (level > 0.03125) {
+        now = (was >= 1.0) ? 1.0f : (was < floor_was) ? floor_was : was;
+        floor_now = 1.0;
     }
     else {
-        float const adj_lim_new = (float) (31.98 * max_pow + 0.000625);
-        if (f >= adj_lim_new) {
-            f = (float) (f * (adj_lim_new * 0.075 + 0.925));
-            if (f < adj_lim_new)
-                f = adj_lim_new;
+        float const quiet = (float) (31.98 * level + 0.000625);
+        if (was >= quiet) {
+            float const eased = (float) (was * (quiet * 0.075 + 0.925));
+            now = (eased < quiet) ? quiet : eased;
         }
-        else {
-            if (lim >= adj_lim_new)
-                f = adj_lim_new;
-            else if (f < lim)
-                f = lim;
-        }
-        lim = adj_lim_new;
+        else
+            now = (floor_was >= quiet) ? quiet : (was < floor_was) ? floor_was : was;
+        floor_now = quiet;
     }
-    *factor = f;
-    *limit = lim;
+    *factor = now;
+    *limit = floor_now;
 }
 
 LH_DEVCONST float lh_pe_fir[9] = {
