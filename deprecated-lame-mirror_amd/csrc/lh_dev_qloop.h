@@ -65,34 +65,8 @@ lq_band_step(const LhQS & S, const LhGrR & g)
     return g.global_gain - ((S.sfw + pre) << (g.scalefac_scale + 1)) - S.sbg8;
 }
 
-/* ---- Huffman length grids (layout: LhChanLds in lh_dev_common.h) ---- */
-LH_DEVFN uint32_t
-lq_len3(int t, int n, int idx)
-{
-    /* lengths of tables t, t+1, t+2 at idx; n = how many of them are candidates (the others repeat
-     * the first, which a strict comparison never prefers) */
-    uint32_t const a = lh_ht_len[lh_ht_off(t) + idx];
-    uint32_t const b = (n >= 2) ? lh_ht_len[lh_ht_off(t + 1) + idx] : a;
-    uint32_t const cc = (n >= 3) ? lh_ht_len[lh_ht_off(t + 2) + idx] : a;
-    return a | (b << 10) | (cc << 20);
-}
-
-LH_DEVFN uint32_t
-lq_small_cell(int cell)
-{
-    int const row = cell >> 4, col = cell & 15;
-    if (row < 8 && col < 8)
-        return lq_len3(10, 3, row * 8 + col);
-    if (row < 6 && col >= 8 && col < 14)
-        return lq_len3(7, 3, row * 6 + (col - 8));
-    if (row >= 8 && row < 12 && col < 4)
-        return lq_len3(5, 2, (row - 8) * 4 + col);
-    if (row >= 8 && row < 11 && col >= 4 && col < 7)
-        return lq_len3(2, 2, (row - 8) * 3 + (col - 4));
-    if (row >= 8 && row < 10 && col >= 8 && col < 10)
-        return lq_len3(1, 1, (row - 8) * 2 + (col - 8));
-    return 0u;
-}
+/* ---- Huffman length grids (layout: LhChanLds in lh_dev_common.h; contents: LhTables.hgrid, built on the
+ * host by build_huffman_grids, lh_host_init.c) ---- */
 
 /* per class of a region maximum (0..15: the maximum itself; 16 + bit length of max - 15 for the ESC
  * tables): A = byte offset of the candidate group's (0,0) cell inside LhChanLds | esc << 31,
@@ -205,17 +179,22 @@ lq_load(const LhCtx & c, LhQS & S, LhChanLds & Q, const LhQR & R, const LhGrR & 
     S.thrv = (LH_IXMAX) / S.istepv;
     S.sbg8 = 0;                 /* so is subblock_gain */
     LH_WAVE_SYNC();
+    {
+        /* the three grids are constants of the launch: 704 words from HBM, issued together */
+        const uint32_t *hg = c.T->hgrid;
+        uint32_t w[11];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        int const i = c.lane + 64 * j;
-        uint32_t const e = lh_largetbl[i];
-        Q.hl3_big[0][i] = (e >> 16) | ((e & 0xffffu) << 10)
-            | ((uint32_t) (((i >> 4) == 15) + ((i & 15) == 15)) << 20);
-        Q.hl3_big[1][i] = lq_len3(13, 3, i);
+        for (int j = 0; j < 11; j++)
+            w[j] = hg[c.lane + 64 * j];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            Q.hl3_big[0][c.lane + 64 * j] = w[j];
+            Q.hl3_big[1][c.lane + 64 * j] = w[4 + j];
+        }
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            Q.hl3_small[c.lane + 64 * j] = w[8 + j];
     }
-#pragma unroll
-    for (int j = 0; j < 3; j++)
-        Q.hl3_small[c.lane + 64 * j] = lq_small_cell(c.lane + 64 * j);
     LH_WAVE_SYNC();
 }
 

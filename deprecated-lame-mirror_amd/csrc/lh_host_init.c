@@ -883,6 +883,49 @@ static const signed char region_guess[23][2] = {
     {6, 7}
 };
 
+/* Code lengths of tables t, t + 1, t + 2 at alphabet position idx, 10 bits each; n = how many of them
+ * are candidates for the same region maximum (the others repeat the first, which a strict comparison
+ * never prefers). */
+static uint32_t
+grid_entry(int t, int n, int idx)
+{
+    uint32_t const first = lh_ht_len[lh_ht_offset[t] + idx];
+    uint32_t const second = (n >= 2) ? lh_ht_len[lh_ht_offset[t + 1] + idx] : first;
+    uint32_t const third = (n >= 3) ? lh_ht_len[lh_ht_offset[t + 2] + idx] : first;
+    return first | (second << 10) | (third << 20);
+}
+
+/* The Huffman length grids of the CBR search (LhTables.hgrid).  The small alphabets share one 16-column
+ * grid: tables 10-12 in rows 0..7 / columns 0..7, 7-9 in rows 0..5 / columns 8..13, 5-6 in rows 8..11 /
+ * columns 0..3, 2-3 in rows 8..10 / columns 4..6, table 1 in rows 8..9 / columns 8..9; every other
+ * cell is zero (one of them serves regions whose maximum is 0). */
+static void
+build_huffman_grids(LhTables * t)
+{
+    int     i;
+    for (i = 0; i < 256; i++) {
+        uint32_t const esc = lh_largetbl[i];    /* lengths with tables 16.. << 16 | with tables 24.. */
+        uint32_t const fifteens = (uint32_t) (((i >> 4) == 15) + ((i & 15) == 15));
+        t->hgrid[i] = (esc >> 16) | ((esc & 0xffffu) << 10) | (fifteens << 20);
+        t->hgrid[256 + i] = grid_entry(13, 3, i);
+    }
+    for (i = 0; i < 192; i++) {
+        int const row = i >> 4, col = i & 15;
+        uint32_t v = 0;
+        if (row < 8 && col < 8)
+            v = grid_entry(10, 3, row * 8 + col);
+        else if (row < 6 && col >= 8 && col < 14)
+            v = grid_entry(7, 3, row * 6 + (col - 8));
+        else if (row >= 8 && row < 12 && col < 4)
+            v = grid_entry(5, 2, (row - 8) * 4 + col);
+        else if (row >= 8 && row < 11 && col >= 4 && col < 7)
+            v = grid_entry(2, 2, (row - 8) * 3 + (col - 4));
+        else if (row >= 8 && row < 10 && col >= 8 && col < 10)
+            v = grid_entry(1, 1, (row - 8) * 2 + (col - 8));
+        t->hgrid[512 + i] = v;
+    }
+}
+
 /* largest count <= guess with edge[base + count] <= limit; the guess itself when there is none */
 static int
 lower_until_inside(const int *edge, int base, int guess, int limit)
@@ -1391,6 +1434,7 @@ lh_tables_build(LhConfig * c, const LhInitAux * aux, LhTables * t)
     if (!power_tables_scale_exactly(t))
         return -1;
     build_region_split(t);
+    build_huffman_grids(t);
     build_band_weights(aux, t);
     if (psymodel_tables(c, aux, t))
         return -1;

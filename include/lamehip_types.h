@@ -184,6 +184,11 @@ typedef struct LhTables {
      * sfb_l / sfb_s; long blocks: 22 bands, short blocks: 39 = 13 x 3 windows, window-major) */
     uint8_t sfb_line_l[576];
     uint8_t sfb_line_s[576];
+    /* Huffman code lengths as the CBR search reads them (lh_dev_qloop.h): three 16 x 16 grids of words
+     * indexed x * 16 + y, each entry the lengths of (up to) three candidate tables, 10 bits each:
+     * [0..255] the ESC tables 16.. | 24.. and the count of values == 15, [256..511] tables 13 / 14 / 15,
+     * [512..703] the small alphabets side by side (LQ_ORG_* in lh_dev_common.h).  Built by lh_tables_init. */
+    uint32_t hgrid[704];
 } LhTables;
 
 /* ------------------------------------------------------------------ */
