@@ -42,3 +42,57 @@ def test_huffman_immediates_and_lds_budget():
                                os.path.join(helpers.ROOT, "tests", "hipemu", "hipemu.cpp"), "-lm"])
         out = subprocess.run([exe], stdout=subprocess.PIPE, text=True)
         assert out.returncode == 0, out.stdout
+
+
+GRID_SRC = r'''
+#define LH_CONST static const
+#include "lh_static_tables.h"
+#include <stdio.h>
+#include <string.h>
+
+/* the grids filled table by table (the host fills them cell by cell): field f of the cell of (x, y) */
+static unsigned grid[704];
+static void put(int base, int cols, int t, int field, int x0, int y0)
+{
+    int n = (t == 14) ? 16 : lh_ht_xlen[t];     /* the reference's ht[14] has no alphabet size of its own: it is read as 16 x 16 next to 13 and 15 (takehiro.c:598-616) */
+    for (int x = 0; x < n; x++)
+        for (int y = 0; y < n; y++) {
+            unsigned len = lh_ht_len[lh_ht_offset[t] + x * n + y];
+            grid[base + (x0 + x) * cols + (y0 + y)] |= len << (10 * field);
+        }
+}
+int main(void)
+{
+    memset(grid, 0, sizeof grid);
+    for (int i = 0; i < 256; i++) {
+        unsigned e = lh_largetbl[i];
+        grid[i] = (e >> 16) | ((e & 0xffffu) << 10) | ((unsigned) (((i >> 4) == 15) + ((i & 15) == 15)) << 20);
+    }
+    put(256, 16, 13, 0, 0, 0); put(256, 16, 14, 1, 0, 0); put(256, 16, 15, 2, 0, 0);
+    put(512, 16, 10, 0, 0, 0); put(512, 16, 11, 1, 0, 0); put(512, 16, 12, 2, 0, 0);
+    put(512, 16, 7, 0, 0, 8); put(512, 16, 8, 1, 0, 8); put(512, 16, 9, 2, 0, 8);
+    put(512, 16, 5, 0, 8, 0); put(512, 16, 6, 1, 8, 0); put(512, 16, 5, 2, 8, 0);
+    put(512, 16, 2, 0, 8, 4); put(512, 16, 3, 1, 8, 4); put(512, 16, 2, 2, 8, 4);
+    put(512, 16, 1, 0, 8, 8); put(512, 16, 1, 1, 8, 8); put(512, 16, 1, 2, 8, 8);
+    for (int i = 0; i < 704; i++) printf("%u\n", grid[i]);
+    return 0;
+}
+'''
+
+
+def test_huffman_length_grids_of_the_search():
+    """LhTables.hgrid (built by lh_host_init.c, copied into LDS by lq_load) against the standard tables, filled
+    here table by table: ESC grid from the packed ESC lengths, tables 13-15, and the small alphabets at their
+    origins (a table with fewer than three candidates repeats its first)."""
+    import numpy as np
+    import lamehip
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "g.c")
+        open(src, "w").write(GRID_SRC)
+        exe = os.path.join(d, "g")
+        subprocess.check_call(["gcc", "-O1", "-I" + os.path.join(helpers.PKG, "csrc"), "-o", exe, src])
+        want = np.array([int(x) for x in subprocess.check_output([exe], text=True).split()], dtype=np.uint32)
+    enc = lamehip.Encoder(44100, 128, require_device=False)
+    got = np.ctypeslib.as_array(enc.tables().hgrid).astype(np.uint32)
+    assert np.array_equal(got, want)
+    enc.close()
