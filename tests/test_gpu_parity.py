@@ -580,6 +580,28 @@ def test_bench_spawns_its_own_ranks():
 
 
 @pytest.mark.gpu
+def test_bench_under_the_torch_launcher():
+    """The command the driver uses for N > 1: python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2
+    (one rank per GPU; on a 1-GPU box both ranks share the device).  Rank 0 prints ONE JSON line with the
+    aggregate; the ranks only meet in gloo for the barrier and the maximum of the times."""
+    import json
+    import subprocess
+    import sys
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29677", os.path.join(helpers.ROOT, "bench.py"),
+           "--gpus", "2", "--streams", "16", "--seconds", "2", "--steps", "1", "--warmup", "1",
+           "--no-cpu-baseline", "--no-extras"]
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900,
+                         env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["config"]["streams_per_gpu"] == 16 and res["scaling"] == "weak"
+    assert res["checked_against_oracle"]["result"] == "identical"
+
+
+@pytest.mark.gpu
 def test_batch_on_named_device_and_reuse():
     """lamehip_batch_create_on + a batch encoded twice with different PCM equals fresh batches (the
     carried state starts over by itself)."""
