@@ -453,34 +453,40 @@ lh_mask_add_far(float m1, float m2, float c)
     return res;
 }
 
-/* Partition energies + tonality + spreading for one pseudo-channel, one lane per
- * partition.  is_long selects the long-block variant with the pre-echo clamp
- * against the two previous granules (reference psymodel.c:1134-1262) or the
- * short-block variant (:1031-1131).  energy = power spectrum in LDS. */
-LH_DEVFN void
-lh_compute_masking(const LhCtx & c, int chn, int is_long, const float *energy, float *eb,
-                   float *thr,
-                   const float *s3, const float *log_table, const float *psy_tab, const float *table2,
-                   float &nb1, float &nb2)
+/* Partition energies + tonality + spreading, one lane per partition, for the NC (1 or 2) pseudo-channels
+ * a wave owns -- side by side: the two channels' chains are independent, so one's table look-ups and
+ * dependent additions fill the other's waits, and the loop control and the partition tables are shared.
+ * is_long selects the long-block variant with the pre-echo clamp against the two previous granules
+ * (reference psymodel.c:1134-1262) or the short-block variant (:1031-1131). */
+struct LhMaskChan {
+    int     chn;
+    const float *energy;        /* power spectrum (LDS) */
+    float  *eb, *thr;           /* partition energies / thresholds out (LDS, 64 each) */
+    float  *nb1, *nb2;          /* long blocks: this partition's spread energy of the last / last but one long call
+                                 * (reference nb_l1 / nb_l2), a register of the lane for the whole launch */
+};
+
+template < int NC > LH_DEVFN void
+lh_compute_masking(const LhCtx & c, int is_long, const LhMaskChan (&ch)[NC], const float *s3, const float *log_table,
+                   const float *table2)
 {
-    /* nb1 / nb2: this partition's spread energy of the last and the last but one long-block call
-     * (reference PsyStateVar_t.nb_l1 / nb_l2, psymodel.c:1235-1256), lane = partition: lane-local, so
-     * they live in a register of the lane for the whole launch (lh_encode_kernel) */
-    /* s3 / log_table / psy_tab / table2: the spreading matrix and the small tables of the
-     * masking addition, either in HBM (LhTables, constants) or staged in LDS by the caller */
+    /* s3 / log_table / table2: the spreading matrix and the tables of the masking addition, either in
+     * HBM (LhTables, constants) or staged in LDS by the caller */
     float const ma_max_i1 = c.T->ma_max_i1, ma_max_i2 = c.T->ma_max_i2;
     LhPsyBand const *gd = is_long ? &c.T->psy_l : &c.T->psy_s;
     int const b = c.lane;
     int const np = gd->npart;
     int const on = b < np;
-    float   ebb = 0, m = 0, avg = 0, th = 0;
-    int     tone;
     /* the lane's table entries (HBM, L2-resident): all requested up front, one wait */
     int const bc = on ? b : 0;
     int const t_numlines = gd->numlines[bc], t_first = gd->s3ind[bc][0], t_last = gd->s3ind[bc][1], t_row = gd->s3_row[bc];
     float const t_rnum = gd->rnumlines[bc], t_mlow = gd->masking_lower[bc], t_minval = gd->minval[bc];
+    float   ebb[NC], m[NC], avg[NC], th[NC], ecb[NC];
+    int     tone[NC], delta[NC], dd[NC];
     LH_PT(t_mk);
-    LQ_MARK("mk_sums");
+#pragma unroll
+    for (int q = 0; q < NC; q++)
+        ebb[q] = m[q] = th[q] = ecb[q] = 0;
     {
         /* A partition's energy is the sum of its lines in order (up to 83 of them for the widest
          * one); the loads do not depend on the sum, so eight go out together and the additions follow. */
@@ -489,34 +495,44 @@ lh_compute_masking(const LhCtx & c, int chn, int is_long, const float *energy, f
         float const rn = on ? t_rnum : 0.0f;
         int const nmax = lh_uni_i((int) lh_wave_max_u32((uint32_t) n));
         for (int i = 0; i < nmax; i += 8) {
-            float   el[8];
+            float   el[NC][8];
 #pragma unroll
-            for (int q = 0; q < 8; q++)
-                el[q] = energy[j0 + ((i + q < n) ? i + q : 0)];
+            for (int q = 0; q < NC; q++)
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
-                /* a term beyond the partition's end is replaced by +0.0f: sum and maximum (both
-                 * non-negative) stay as they are */
-                float const e = (i + q < n) ? el[q] : 0.0f;
-                ebb += e;
-                m = __builtin_fmaxf(m, e);
-            }
+                for (int u = 0; u < 8; u++)
+                    el[q][u] = ch[q].energy[j0 + ((i + u < n) ? i + u : 0)];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+#pragma unroll
+                for (int q = 0; q < NC; q++) {
+                    /* a term beyond the partition's end is replaced by +0.0f: sum and maximum (both
+                     * non-negative) stay as they are */
+                    float const e = (i + u < n) ? el[q][u] : 0.0f;
+                    ebb[q] += e;
+                    m[q] = __builtin_fmaxf(m[q], e);
+                }
         }
-        avg = ebb * rn;
+#pragma unroll
+        for (int q = 0; q < NC; q++) {
+            avg[q] = ebb[q] * rn;
+            ch[q].eb[b] = ebb[q];       /* 0 above the last partition */
+        }
     }
-    eb[b] = ebb;                /* 0 above the last partition */
     LH_PA(14, t_mk);
-    LQ_MARK("mk_tone");
     {
         /* The tonality index needs the neighbours' maximum and average: lane exchanges.  What the
          * spreading reads of a partition kk is its energy and the factor psy_tab[index[kk]]: the
          * factors of the whole channel sit in thr[] until the thresholds, which each lane writes
          * over its own factor when every lane is through with the spreading, replace them. */
         int const lo = (b > 0) ? b - 1 : 0, hi = (b < 63) ? b + 1 : 63;
-        float const m0 = lh_shfl_f32(m, lo), m2 = lh_shfl_f32(m, hi);
-        float const a0 = lh_shfl_f32(avg, lo), a2 = lh_shfl_f32(avg, hi);
-        tone = on ? lh_mask_index(gd, b, m0, m, m2, a0, avg, a2) : 0;
-        thr[b] = lh_psy_tab_at(tone);
+#pragma unroll
+        for (int q = 0; q < NC; q++) {
+            float const m0 = lh_shfl_f32(m[q], lo), m2 = lh_shfl_f32(m[q], hi);
+            float const a0 = lh_shfl_f32(avg[q], lo), a2 = lh_shfl_f32(avg[q], hi);
+            tone[q] = on ? lh_mask_index(gd, b, m0, m[q], m2, a0, avg[q], a2) : 0;
+            ch[q].thr[b] = lh_psy_tab_at(tone[q]);
+            delta[q] = lh_mask_add_delta_at(tone[q]);
+        }
     }
     /* The reference walks kk = s3ind[b][0] .. s3ind[b][1], adding partition kk's spread energy to the
      * running sum with mask_add(), whose expensive branch (a division, fast_log2, table2) only applies
@@ -527,15 +543,16 @@ lh_compute_masking(const LhCtx & c, int chn, int is_long, const float *energy, f
      * The order of a lane's additions is the reference's. */
     int const first = on ? t_first : 1, last = on ? t_last : 0;
     int const krel = (on ? t_row : 0) - first;  /* s3 index of partition kk = krel + kk */
-    int const delta = lh_mask_add_delta_at(tone);
-    float   ecb = 0;
-    int     dd, n1, n3;
+    int     n1, n3;
     {
         /* sum of the indices over the lane's range, from the wave's prefix sums; trip counts */
-        uint32_t const P = lh_wave_scan_u32((uint32_t) tone);
-        uint32_t const pl = lh_shfl_u32(P, last & 63), pf = lh_shfl_u32(P, (first - 1) & 63);
         uint32_t t[2];
-        dd = (int) (pl - ((first > 0) ? pf : 0u));
+#pragma unroll
+        for (int q = 0; q < NC; q++) {
+            uint32_t const P = lh_wave_scan_u32((uint32_t) tone[q]);
+            uint32_t const pl = lh_shfl_u32(P, last & 63), pf = lh_shfl_u32(P, (first - 1) & 63);
+            dd[q] = (int) (pl - ((first > 0) ? pf : 0u));
+        }
         t[0] = (uint32_t) ((on && b - 3 - first > 0) ? b - 3 - first : 0);
         t[1] = (uint32_t) ((on && last - b - 2 > 0) ? last - b - 2 : 0);
         lh_wave_max_n < 2 > (t);
@@ -543,19 +560,28 @@ lh_compute_masking(const LhCtx & c, int chn, int is_long, const float *energy, f
         n3 = lh_uni_i((int) t[1]);
     }
     LH_WAVE_SYNC_MEM();
-#define LH_SPREAD_X(kk_) (s3[krel + (kk_)] * eb[(kk_)] * thr[(kk_)])
-    if (on)
-        ecb = LH_SPREAD_X(first);
+    LH_PA(15, t_mk);
+#define LH_SPREAD_X(q_, kk_) (s3[krel + (kk_)] * ch[q_].eb[(kk_)] * ch[q_].thr[(kk_)])
+#pragma unroll
+    for (int q = 0; q < NC; q++)
+        ecb[q] = on ? LH_SPREAD_X(q, first) : 0.0f;
     {
         int     kk = b - 2 - n1;
         int     act = kk > first && kk <= last;
-        float   x = LH_SPREAD_X(act ? kk : first);
+        float   x[NC];
+#pragma unroll
+        for (int q = 0; q < NC; q++)
+            x[q] = LH_SPREAD_X(q, act ? kk : first);
         for (int j = 0; j < n1; j++) {
             int const act_n = (kk + 1 > first) && (kk + 1 <= last) && (j + 1 < n1);
-            float const xn = LH_SPREAD_X(act_n ? kk + 1 : first);
-            float const r = lh_mask_add_far(ecb, x, ma_max_i2);
-            ecb = act ? r : ecb;
-            x = xn;
+            int const kn = act_n ? kk + 1 : first;
+#pragma unroll
+            for (int q = 0; q < NC; q++) {
+                float const xn = LH_SPREAD_X(q, kn);
+                float const r = lh_mask_add_far(ecb[q], x[q], ma_max_i2);
+                ecb[q] = act ? r : ecb[q];
+                x[q] = xn;
+            }
             act = act_n;
             ++kk;
         }
@@ -564,87 +590,102 @@ lh_compute_masking(const LhCtx & c, int chn, int is_long, const float *energy, f
         int const kk = b - 2 + j;
         int const act = kk > first && kk <= last;
         int const d = (j < 2) ? 2 - j : j - 2;          /* |kk - b| */
-        int const near = act && d <= delta;
-        float const x = LH_SPREAD_X(act ? kk : first);
-        float   r = lh_mask_add_far(ecb, x, ma_max_i2);
-        if (lh_ballot(near)) {
-            if (near)
-                r = lh_mask_add(log_table, table2, ma_max_i1, ma_max_i2, ecb, x, d, delta);
+        int const kc = act ? kk : first;
+#pragma unroll
+        for (int q = 0; q < NC; q++) {
+            int const near = act && d <= delta[q];
+            float const x = LH_SPREAD_X(q, kc);
+            float   r = lh_mask_add_far(ecb[q], x, ma_max_i2);
+            if (lh_ballot(near)) {
+                if (near)
+                    r = lh_mask_add(log_table, table2, ma_max_i1, ma_max_i2, ecb[q], x, d, delta[q]);
+            }
+            ecb[q] = act ? r : ecb[q];
         }
-        ecb = act ? r : ecb;
     }
     {
         int     kk = b + 3;
         int     act = kk > first && kk <= last;
-        float   x = LH_SPREAD_X(act ? kk : first);
+        float   x[NC];
+#pragma unroll
+        for (int q = 0; q < NC; q++)
+            x[q] = LH_SPREAD_X(q, act ? kk : first);
         for (int j = 0; j < n3; j++) {
             int const act_n = (kk + 1 > first) && (kk + 1 <= last);
-            float const xn = LH_SPREAD_X(act_n ? kk + 1 : first);
-            float const r = lh_mask_add_far(ecb, x, ma_max_i2);
-            ecb = act ? r : ecb;
-            x = xn;
+            int const kn = act_n ? kk + 1 : first;
+#pragma unroll
+            for (int q = 0; q < NC; q++) {
+                float const xn = LH_SPREAD_X(q, kn);
+                float const r = lh_mask_add_far(ecb[q], x[q], ma_max_i2);
+                ecb[q] = act ? r : ecb[q];
+                x[q] = xn;
+            }
             act = act_n;
             ++kk;
         }
     }
 #undef LH_SPREAD_X
     LH_PA(16, t_mk);
-    LQ_MARK("mk_tail");
     if (on) {
-        float   x, avg_mask;
         float const masking_lower = t_mlow * lh_lds.ss.masking_lower;
         int const dd_n = last - first + 1;
-        dd = (1 + 2 * dd) / (2 * dd_n);
-        avg_mask = lh_psy_tab_at(dd) * 0.5f;
-        ecb *= avg_mask;
-        if (is_long) {
-            int const bt_old = lh_lds.ss.blocktype_old[chn & 1];
-            float const n1 = nb1, n2 = nb2;
-            if (bt_old == LH_SHORT_TYPE) {
-                float const ecb_limit = LH_RPELEV * n1;
-                if (ecb_limit > 0)
-                    th = (ecb < ecb_limit) ? ecb : ecb_limit;
-                else {
-                    float const alt = (float) (ebb * LH_PREECHO_ATT2);
-                    th = (ecb < alt) ? ecb : alt;
+#pragma unroll
+        for (int q = 0; q < NC; q++) {
+            float   x, avg_mask, e = ecb[q], t;
+            int const di = (1 + 2 * dd[q]) / (2 * dd_n);
+            avg_mask = lh_psy_tab_at(di) * 0.5f;
+            e *= avg_mask;
+            if (is_long) {
+                int const bt_old = lh_lds.ss.blocktype_old[ch[q].chn & 1];
+                float const n1v = *ch[q].nb1, n2v = *ch[q].nb2;
+                if (bt_old == LH_SHORT_TYPE) {
+                    float const ecb_limit = LH_RPELEV * n1v;
+                    if (ecb_limit > 0)
+                        t = (e < ecb_limit) ? e : ecb_limit;
+                    else {
+                        float const alt = (float) (ebb[q] * LH_PREECHO_ATT2);
+                        t = (e < alt) ? e : alt;
+                    }
                 }
+                else {
+                    float   lim2 = LH_RPELEV2 * n2v;
+                    float   lim1 = LH_RPELEV * n1v;
+                    float   lim;
+                    if (lim2 <= 0)
+                        lim2 = e;
+                    if (lim1 <= 0)
+                        lim1 = e;
+                    if (bt_old == LH_NORM_TYPE)
+                        lim = (lim1 < lim2) ? lim1 : lim2;
+                    else
+                        lim = lim1;
+                    t = (e < lim) ? e : lim;
+                }
+                *ch[q].nb2 = n1v;
+                *ch[q].nb1 = e;
             }
-            else {
-                float   ecb_limit_2 = LH_RPELEV2 * n2;
-                float   ecb_limit_1 = LH_RPELEV * n1;
-                float   ecb_limit;
-                if (ecb_limit_2 <= 0)
-                    ecb_limit_2 = ecb;
-                if (ecb_limit_1 <= 0)
-                    ecb_limit_1 = ecb;
-                if (bt_old == LH_NORM_TYPE)
-                    ecb_limit = (ecb_limit_1 < ecb_limit_2) ? ecb_limit_1 : ecb_limit_2;
-                else
-                    ecb_limit = ecb_limit_1;
-                th = (ecb < ecb_limit) ? ecb : ecb_limit;
-            }
-            nb2 = n1;
-            nb1 = ecb;
+            else
+                t = e;
+            x = m[q];
+            x *= t_minval;
+            x *= avg_mask;
+            if (t > x)
+                t = x;
+            if (masking_lower > 1)
+                t *= masking_lower;
+            if (t > ebb[q])
+                t = ebb[q];
+            if (masking_lower < 1)
+                t *= masking_lower;
+            th[q] = t;
         }
-        else
-            th = ecb;
-        x = m;
-        x *= t_minval;
-        x *= avg_mask;
-        if (th > x)
-            th = x;
-        if (masking_lower > 1)
-            th *= masking_lower;
-        if (th > ebb)
-            th = ebb;
-        if (masking_lower < 1)
-            th *= masking_lower;
     }
     LH_WAVE_SYNC_MEM();         /* every lane has read the factors it needs */
-    thr[b] = th;                /* 0 above the last partition */
+#pragma unroll
+    for (int q = 0; q < NC; q++)
+        ch[q].thr[b] = th[q];   /* 0 above the last partition */
     LH_WAVE_SYNC_MEM();
     LH_PA(17, t_mk);
-    LQ_MARK("mk_end");
 }
 
 /* reference psymodel.c:1326-1388; one lane per partition, eb/thr are [4][64] in LDS */
@@ -984,13 +1025,17 @@ lh_psy_granule(int gr, LhPsyCarry nb)
         LH_WAVE_SYNC_MEM();
     }
     LH_PA(32, t_psy0);
-    /* (6) masking thresholds, long blocks */
-    for (int pass = 0; pass < 2; pass++) {
-        int const chn = w + 2 * pass;
-        if (chn < n_chn_psy)
-            lh_compute_masking(c, chn, 1, P.b.energy[chn], &P.eb[chn * 64], &P.thr[chn * 64],
-                               stg_s3, stg_log, stg_psy, stg_t2,
-                               nb.n1[pass], nb.n2[pass]);
+    /* (6) masking thresholds, long blocks: the wave's one or two pseudo-channels together */
+    if (n_chn_psy == 4) {
+        LhMaskChan const two[2] = {
+            {w, P.b.energy[w], &P.eb[w * 64], &P.thr[w * 64], &nb.n1[0], &nb.n2[0]},
+            {w + 2, P.b.energy[w + 2], &P.eb[(w + 2) * 64], &P.thr[(w + 2) * 64], &nb.n1[1], &nb.n2[1]}
+        };
+        lh_compute_masking < 2 > (c, 1, two, stg_s3, stg_log, stg_t2);
+    }
+    else if (w < n_chn_psy) {
+        LhMaskChan const one[1] = { {w, P.b.energy[w], &P.eb[w * 64], &P.thr[w * 64], &nb.n1[0], &nb.n2[0]} };
+        lh_compute_masking < 1 > (c, 1, one, stg_s3, stg_log, stg_t2);
     }
     LH_SYNC_WG_LDS();
     if (cfg->mode == LH_MODE_JOINT_STEREO && (L.uselongblock[0] + L.uselongblock[1]) == 2) {
@@ -1027,15 +1072,25 @@ lh_psy_granule(int gr, LhPsyCarry nb)
         LH_SYNC_WG_LDS();
     }
     for (int sblock = 0; any_short && sblock < 3; sblock++) {
-        for (int pass = 0; pass < 2; pass++) {
-            int const chn = w + 2 * pass;
-            if (chn < n_chn_psy && !L.uselongblock[chn & 1]) {
-                lh_fft_energy(c, chn, &P.wsamp[0][sblock * LH_BLKSIZE_S],
-                              &P.wsamp[1][sblock * LH_BLKSIZE_S], LH_BLKSIZE_S, P.b.energy[chn]);
-                LH_WAVE_SYNC_MEM();
-                lh_compute_masking(c, chn, 0, P.b.energy[chn], &P.eb[chn * 64], &P.thr[chn * 64],
-                                   T->psy_s.s3, T->log_table, lh_psy_tab,
-                                   lh_mask_table2, nb.n1[pass], nb.n2[pass]);    /* short: left alone */
+        if (w < n_chn_psy && !L.uselongblock[w]) {
+            /* (wave w's pseudo-channels w and w + 2 share uselongblock[w]) */
+            int const both = (n_chn_psy == 4);
+            lh_fft_energy(c, w, &P.wsamp[0][sblock * LH_BLKSIZE_S], &P.wsamp[1][sblock * LH_BLKSIZE_S], LH_BLKSIZE_S,
+                          P.b.energy[w]);
+            if (both)
+                lh_fft_energy(c, w + 2, &P.wsamp[0][sblock * LH_BLKSIZE_S], &P.wsamp[1][sblock * LH_BLKSIZE_S],
+                              LH_BLKSIZE_S, P.b.energy[w + 2]);
+            LH_WAVE_SYNC_MEM();
+            if (both) {
+                LhMaskChan const two[2] = {
+                    {w, P.b.energy[w], &P.eb[w * 64], &P.thr[w * 64], &nb.n1[0], &nb.n2[0]},
+                    {w + 2, P.b.energy[w + 2], &P.eb[(w + 2) * 64], &P.thr[(w + 2) * 64], &nb.n1[1], &nb.n2[1]}
+                };
+                lh_compute_masking < 2 > (c, 0, two, T->psy_s.s3, T->log_table, lh_mask_table2);    /* short: nb left alone */
+            }
+            else {
+                LhMaskChan const one[1] = { {w, P.b.energy[w], &P.eb[w * 64], &P.thr[w * 64], &nb.n1[0], &nb.n2[0]} };
+                lh_compute_masking < 1 > (c, 0, one, T->psy_s.s3, T->log_table, lh_mask_table2);
             }
         }
         LH_SYNC_WG_LDS();
