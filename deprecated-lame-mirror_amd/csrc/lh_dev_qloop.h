@@ -372,7 +372,8 @@ lq_count_bits(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
             sfbcnt_in = (lane < LH_SBMAX_L + 1) ? qt->sfb_l[lane] : 576u;
         LQ_MARK("cb_quads");
         LH_WAVE_ORDER();
-        uint32_t red[7];        /* quads, then (a | b << 16) and c of the sums over p < e0, p < e1, p < e2 */
+        uint32_t red[1];        /* the count1 region's lengths with both of its tables, t32 << 16 | t33 */
+        uint32_t pre_l, pre_h, qtot;
         uint32_t qlen[3];       /* t32 << 16 | t33 code lengths of this lane's (up to) three quadruples:
                                  * looked up now, added up after the region maxima (the LDS round trips
                                  * run under that arithmetic) */
@@ -441,27 +442,13 @@ lq_count_bits(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
                 acc2 += in2 ? v : 0u;
             }
             /* no code is longer than 21 bits (sign bits included), so the 10-bit fields hold the sums
-             * over 8 lanes x 5 pairs: three reduction steps run on the packed words before the fields
-             * are spread out for the rest */
-            uint32_t acc[3] = { acc0, acc1, acc2 };
-            lh_wave_sum_head3 < 3 > (acc);
-            red[1] = (acc[0] & 0x3ffu) | (((acc[0] >> 10) & 0x3ffu) << 16);
-            red[2] = acc[0] >> 20;
-            red[3] = (acc[1] & 0x3ffu) | (((acc[1] >> 10) & 0x3ffu) << 16);
-            red[4] = acc[1] >> 20;
-            red[5] = (acc[2] & 0x3ffu) | (((acc[2] >> 10) & 0x3ffu) << 16);
-            red[6] = acc[2] >> 20;
+             * over 8 lanes x 5 pairs; lh_wave_sum_regions() spreads them out on the way */
+            pre_l = pre_h = 0;
+            qtot = lh_wave_sum_regions(acc0, acc1, acc2, red[0], &pre_l, &pre_h);
         }
-        LQ_MARK("cb_sums");
-        {
-            uint32_t q1[1] = { red[0] };
-            lh_wave_sum_head3 < 1 > (q1);
-            red[0] = q1[0];
-        }
-        lh_wave_sum_tail3 < 7 > (red);
         LQ_MARK("cb_decide");
         {
-            int const c1a = (int) (red[0] >> 16), c1b = (int) (red[0] & 0xffffu);
+            int const c1a = (int) (qtot >> 16), c1b = (int) (qtot & 0xffffu);
             bits = c1a;
             g.count1table_select = 0;
             if (c1a > c1b) {
@@ -471,12 +458,10 @@ lq_count_bits(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
             g.count1bits = bits;
         }
         {
-            /* lane r: choose_table of region r from its sums (reference takehiro.c:618-647) */
-            uint32_t const l0 = lh_vec_u32(red[1]), l1 = lh_vec_u32(red[3] - red[1]), l2 = lh_vec_u32(red[5] - red[3]);
-            uint32_t const h0 = lh_vec_u32(red[2]), h1 = lh_vec_u32(red[4] - red[2]), h2 = lh_vec_u32(red[6] - red[4]);
+            /* lane r: choose_table of region r from its sums (reference takehiro.c:618-647).  The sums came
+             * as prefixes (p < e0, p < e1, p < e2): a region's own is its prefix minus the lane below's. */
+            uint32_t const Lr = pre_l - lh_lane_below_u32(pre_l), Hr = pre_h - lh_lane_below_u32(pre_h);
             uint32_t const x0 = lh_vec_u32((uint32_t) (0 < e0)), x1 = lh_vec_u32((uint32_t) (e0 < e1)), x2 = lh_vec_u32((uint32_t) (e1 < e2));
-            uint32_t const Lr = (lane == 0) ? l0 : (lane == 1) ? l1 : l2;
-            uint32_t const Hr = (lane == 0) ? h0 : (lane == 1) ? h1 : h2;
             int const ex = (int) ((lane == 0) ? x0 : (lane == 1) ? x1 : x2);
             uint32_t const a = Lr & 0xffffu, b = Lr >> 16;
             uint32_t const tA = PB & 31u, tB = (PB >> 8) & 31u, lin1 = (PB >> 16) & 15u, lin2 = (PB >> 24) & 15u;

@@ -655,6 +655,35 @@ lh_selftest_kernel(unsigned *out, unsigned seed)
                 rbal |= 1ull << i;
         }
         bad += (lh_wave_sum_u32(x) != rsum);
+        {
+            /* the four-word transposed sum of count_bits: three words of three 10-bit fields (values < 128 per
+             * lane), one of two 16-bit fields */
+            unsigned const p0 = (x & 127u) | (((x >> 7) & 127u) << 10) | (((x >> 14) & 127u) << 20);
+            unsigned const p1 = ((x >> 3) & 127u) | (((x >> 11) & 127u) << 10) | (((x >> 17) & 127u) << 20);
+            unsigned const p2 = ((x >> 5) & 127u) | (((x >> 13) & 127u) << 10) | (((x >> 21) & 127u) << 20);
+            unsigned const q = ((x >> 2) & 255u) | (((x >> 9) & 255u) << 16);
+            unsigned L = 0, H = 0, want_l = 0, want_h = 0, want_q;
+            unsigned const qt = lh_wave_sum_regions(p0, p1, p2, q, &L, &H);
+            unsigned const sh = (lane == 0) ? 0u : (lane == 1) ? 3u : 5u;
+            unsigned const a = lh_wave_sum_u32((x >> sh) & 127u), b = lh_wave_sum_u32((x >> (sh + (lane == 0 ? 7u : 8u))) & 127u),
+                cc = lh_wave_sum_u32((x >> (sh + (lane == 0 ? 14u : lane == 1 ? 14u : 16u))) & 127u);
+            (void) a; (void) b; (void) cc;
+            {
+                /* per-region expectations, formed by every lane for all three regions */
+                unsigned const f[3][3] = { {0u, 7u, 14u}, {3u, 11u, 17u}, {5u, 13u, 21u} };
+                unsigned tot[3][3];
+                for (int r = 0; r < 3; r++)
+                    for (int k = 0; k < 3; k++)
+                        tot[r][k] = lh_wave_sum_u32((x >> f[r][k]) & 127u);
+                want_q = lh_wave_sum_u32((x >> 2) & 255u) | (lh_wave_sum_u32((x >> 9) & 255u) << 16);
+                if (lane < 3) {
+                    want_l = tot[lane][0] | (tot[lane][1] << 16);
+                    want_h = tot[lane][2];
+                    bad += (L != want_l) + (H != want_h);
+                }
+                bad += (qt != want_q);
+            }
+        }
         bad += (lh_wave_max_u32(x) != rmax);
         bad += (lh_wave_min_u32(x) != rmin);
         bad += (lh_wave_or_u32(x) != ror);

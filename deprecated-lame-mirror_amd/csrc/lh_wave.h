@@ -170,6 +170,33 @@ lh_shfl_u32(uint32_t v, int src)
     return (uint32_t) x[src & 63];
 }
 
+/* see the device version below: lane r < 3 gets region r's totals, everyone the quadruples' total */
+static inline uint32_t
+lh_wave_sum_regions(uint32_t p0, uint32_t p1, uint32_t p2, uint32_t q, uint32_t *L, uint32_t *H)
+{
+    uint32_t const p[3] = { p0, p1, p2 };
+    uint32_t lo[3], hi[3], qt;
+    int const me = lh_lane();
+    for (int r = 0; r < 3; r++) {
+        uint32_t const a = lh_wave_sum_u32(p[r] & 0x3ffu), b = lh_wave_sum_u32((p[r] >> 10) & 0x3ffu);
+        lo[r] = a | (b << 16);
+        hi[r] = lh_wave_sum_u32(p[r] >> 20);
+    }
+    qt = lh_wave_sum_u32(q);
+    *L = me < 3 ? lo[me] : 0u;
+    *H = me < 3 ? hi[me] : 0u;
+    return qt;
+}
+
+/* value of the lane below (0 for lane 0) */
+static inline uint32_t
+lh_lane_below_u32(uint32_t v)
+{
+    const uint64_t *x = hipemu_wave_exchange(v);
+    int const me = lh_lane();
+    return me > 0 ? (uint32_t) x[me - 1] : 0u;
+}
+
 
 /* an integer sum and a float maximum (no NaNs) at once */
 static inline void
@@ -376,6 +403,42 @@ __device__ __forceinline__ uint32_t
 lh_shfl_u32(uint32_t v, int src)
 {
     return (uint32_t) __builtin_amdgcn_ds_bpermute(src << 2, (int) v);
+}
+
+/* Wave totals of four packed words at once, delivered where count_bits needs them.  p0..p2 hold three
+ * 10-bit fields a | b << 10 | c << 20 each (per-lane values below 2^7: eight lanes add up without a carry),
+ * q two 16-bit fields.  Three butterfly steps sum every word over the lane's group of eight; then the
+ * eight lanes of a group split the seven values that remain to be added across the groups among themselves
+ * (lane k of a group: fields a | b << 16 of word k & 3 for k < 4, field c of word k & 3 for k >= 4; word 3 is
+ * q) and three more steps on that ONE register finish all of them -- instead of three steps and a
+ * v_readlane on each of seven registers.  Lane r < 3 returns word r's a | b << 16 in *L and its c in *H;
+ * the total of q comes back in every lane. */
+__device__ __forceinline__ uint32_t
+lh_wave_sum_regions(uint32_t p0, uint32_t p1, uint32_t p2, uint32_t q, uint32_t *L, uint32_t *H)
+{
+    enum { N = 4 };
+    uint32_t v[N] = { p0, p1, p2, q };
+    int const lane = lh_lane();
+    LH_DPP_STEP_N(LH_OP_ADD, 0u, 0xB1) LH_DPP_STEP_N(LH_OP_ADD, 0u, 0x4E) LH_DPP_STEP_N(LH_OP_ADD, 0u, 0x141)
+    uint32_t const w01 = (lane & 1) ? v[1] : v[0], w23 = (lane & 1) ? v[3] : v[2];
+    uint32_t const w = (lane & 2) ? w23 : w01;          /* word (lane & 3) */
+    int const is_q = (lane & 3) == 3;
+    uint32_t const ab = is_q ? w : ((w & 0x3ffu) | ((w << 6) & 0x03ff0000u));
+    uint32_t const cc = is_q ? 0u : (w >> 20);
+    uint32_t x = (lane & 4) ? cc : ab;
+    x += lh_dpp < 0x128, 0u > (x);      /* row_ror:8: the other group of eight of the row, same position */
+    x += (uint32_t) __builtin_amdgcn_ds_swizzle((int) x, 0x401F);       /* lane ^ 16 */
+    x += (uint32_t) __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, (int) x);
+    *L = x;
+    *H = lh_dpp < 0x104, 0u > (x);      /* row_shl:4: lane r reads lane r + 4 */
+    return (uint32_t) __builtin_amdgcn_readlane((int) x, 3);
+}
+
+/* value of the lane below (0 for lane 0; within a row of 16, which is all count_bits asks for) */
+__device__ __forceinline__ uint32_t
+lh_lane_below_u32(uint32_t v)
+{
+    return lh_dpp < 0x111, 0u > (v);    /* row_shr:1 */
 }
 
 /* an integer sum and a float maximum (no NaNs) at once: the two chains' steps side by side */
