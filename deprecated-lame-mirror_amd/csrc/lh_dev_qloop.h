@@ -863,11 +863,15 @@ template < int NS > LH_DEVFN int
 lq_balance_noise(const LhCtx & c, LhQS & S, LhChanLds & Q, const LhQR & R, LhGrR & g)
 {
     int     status;
+    LQ_MARK("bn_amp");
     lq_amp_scalefac_bands < NS > (c, S, R, g);
+    LQ_MARK("bn_break");
     status = lq_loop_break(c, S, R, g);
     if (status)
         return 0;
+    LQ_MARK("bn_sbc");
     status = lq_scale_bitcount(c, S, R, g);
+    LQ_MARK("bn_rest");
     if (!status)
         return 1;
     if (c.ns > 1) {
