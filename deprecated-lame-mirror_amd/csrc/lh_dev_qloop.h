@@ -667,65 +667,36 @@ lq_scale_bands(const LhCtx & c, LhQS & S, LhChanLds & Q, int flag, float fac)
     LH_WAVE_SYNC();
 }
 
-/* reference quantize.c:720-796 */
+/* Amplify the bands whose distortion reaches the trigger (reference quantize.c:720-796,
+ * amp_scalefac_bands): the trigger is the largest distortion (noise_shaping_amp 2), its root or
+ * 95 % of it (1), or 1 resp. 95 % (0); with amp 2 only the first such band is taken, and every second time
+ * round a band flagged for substep shaping is passed over.  Written with selects: the cases differ
+ * in a value, not in the work. */
 template < int NS > LH_DEVFN void
 lq_amp_scalefac_bands(const LhCtx & c, LhQS & S, const LhQR & R, LhGrR & g)
 {
-    float   ifqstep34, trigger;
-    int     last_visited, ret_before = 0;
     int const s = c.lane;
-    float const dist = (s < R.sfbmax) ? S.dist : 0.0f;
-    uint64_t cand;
-    if (g.scalefac_scale == 0)
-        ifqstep34 = (float) 1.29683955465100964055;
-    else
-        ifqstep34 = (float) 1.68179283050742922612;
-    trigger = lh_u32_as_f32(lh_wave_max_u32(lh_f32_as_u32(dist > 0.0f ? dist : 0.0f)));
-    switch (c.ns_amp) {
-    case 2:
-        break;
-    case 1:
-        if (trigger > 1.0)
-            trigger = sqrtf(trigger);   /* = (float) sqrt((double) trigger), reference quantize.c:744: a correctly
-                                         * rounded double root rounded again to float is the correctly rounded
-                                         * float root (53 >= 2 * 24 + 2; tests/test_quantizer_identity.py) */
-        else
-            trigger = (float) (trigger * .95);
-        break;
-    case 0:
-    default:
-        if (trigger > 1.0)
-            trigger = 1.0;
-        else
-            trigger = (float) (trigger * .95);
-        break;
-    }
-    cand = lh_ballot(s < R.sfbmax && !(dist < trigger));
-    last_visited = R.sfbmax - 1;
-    if (c.ns_amp == 2) {
-        if (cand) {
-            int const sfb = lh_ffs64(cand);
-            last_visited = sfb;
-            if (R.substep_shaping & 2) {
-                uint64_t const ph = lh_ballot(s < R.sfbmax && S.ph);
-                if (lq_bit(ph, sfb))
-                    ret_before = 1;
-            }
-        }
-    }
-    {
-        int     amplify = 0;
-        if (s < R.sfbmax && s <= last_visited && lq_bit(cand, s)) {
-            amplify = 1;
-            if (R.substep_shaping & 2)
-                S.ph = !S.ph;
-            if (ret_before && s == last_visited)
-                amplify = 0;
-            if (amplify)
-                S.sfw++;
-        }
-        lq_scale_mask < NS > (S, lh_ballot(amplify), ifqstep34);
-    }
+    int const mine = s < R.sfbmax;
+    float const dist = mine ? S.dist : 0.0f;
+    float const widen = g.scalefac_scale ? (float) 1.68179283050742922612 : (float) 1.29683955465100964055;
+    float const peak = lh_u32_as_f32(lh_wave_max_u32(lh_f32_as_u32(dist > 0.0f ? dist : 0.0f)));
+    int const loud = peak > 1.0;
+    float const damped = (float) (peak * .95);
+    float const rooted = loud ? sqrtf(peak) : damped;   /* = (float) sqrt((double) peak): tests/test_quantizer_identity.py */
+    float const capped = loud ? 1.0f : damped;
+    float const trigger = (c.ns_amp == 2) ? peak : (c.ns_amp == 1) ? rooted : capped;
+    uint64_t const cand = lh_ballot(mine && !(dist < trigger));
+    int const only_first = (c.ns_amp == 2) && cand != 0;
+    int const first = only_first ? lh_ffs64(cand) : R.sfbmax - 1;      /* the last band that is looked at */
+    int const shaping = (R.substep_shaping & 2) != 0;
+    uint64_t const flagged = lh_ballot(mine && S.ph);
+    /* amp 2 with substep shaping: a flagged first band only drops its flag this time */
+    int const pass_first = only_first && shaping && lq_bit(flagged, first);
+    int const hit = mine && s <= first && lq_bit(cand, s);
+    int const amplify = hit && !(pass_first && s == first);
+    S.ph = (hit && shaping) ? !S.ph : S.ph;
+    S.sfw += amplify;
+    lq_scale_mask < NS > (S, lh_ballot(amplify), widen);
 }
 
 /* reference takehiro.c:1135-1188 (MPEG-1) on the working scalefactors.  The two maxima the
