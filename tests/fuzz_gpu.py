@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Randomised parity hunt on the GPU box (test tool, not collected by pytest): many short streams
 of awkward signals per setting, HIP payload against the CPU oracle, frame by frame.
-Usage: python tests/fuzz_gpu.py [streams] [seconds] [seed0] [cbr|vbr]"""
+Usage: python tests/fuzz_gpu.py [streams] [seconds] [seed0] [cbr|vbr|abr]"""
 import os
 import sys
 import time
@@ -28,6 +28,11 @@ VBR_SETTINGS = [(44100, -2, None, None), (44100, 0, None, None), (48000, -4, 1, 
                 (44100, -9, None, None), (48000, -7, None, None), (44100, -8, 0, 5), (48000, 0, 0, None)]
 
 
+# bit rate >= 1000: ABR at a mean of rate - 1000 kb/s
+ABR_SETTINGS = [(44100, 1128, None, None), (48000, 1190, 1, None), (32000, 1096, None, 5), (44100, 1256, 0, 2),
+                (44100, 1080, None, 7), (48000, 1313, 0, None)]
+
+
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     secs = float(sys.argv[2]) if len(sys.argv) > 2 else 2.0
@@ -35,8 +40,11 @@ def main():
     orc = helpers.Oracle()
     bad = tot = 0
     t0 = time.time()
-    for sr, br, mode, q in (VBR_SETTINGS if (len(sys.argv) > 4 and sys.argv[4] == "vbr") else SETTINGS):
-        if br > 0:
+    which = sys.argv[4] if len(sys.argv) > 4 else "cbr"
+    for sr, br, mode, q in {"vbr": VBR_SETTINGS, "abr": ABR_SETTINGS}.get(which, SETTINGS):
+        if br >= 1000:
+            enc = lamehip.Encoder(sr, 0, mode, q, abr=br - 1000, out_samplerate=sr)    # (no rate change: the checker is fed the same PCM)
+        elif br > 0:
             enc = lamehip.Encoder(sr, br, mode, q)
         else:
             enc = lamehip.Encoder(sr, mode=mode, quality=q, vbr_q=-br, out_samplerate=sr if -br >= 7 else 0)
