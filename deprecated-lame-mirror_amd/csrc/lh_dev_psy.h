@@ -382,6 +382,95 @@ lh_partition2sfb_wave(LhPsyBand const *gd, float const *eb, float const *thr, fl
     }
 }
 
+/* The same for a long-block granule, all at once: lanes 0..21 take the 22 long bands (table psy_l), lanes
+ * 32..44 the 13 short-band estimates made from the long partitions (psy_l_to_s: threshold / 64, written to
+ * all three windows), and the wave's NC pseudo-channels go side by side -- one pass instead of four.
+ * en / thm: the channel's 61-entry band image (22 long values, then 13 x 3 short ones). */
+struct LhSfbChan {
+    const float *eb, *thr;      /* partition energies / thresholds (LDS, 64 each) */
+    float  *en, *thm;
+};
+
+template < int NC > LH_DEVFN void
+lh_partition2sfb_long(const LhTables * T, const LhSfbChan (&ch)[NC], int lane)
+{
+    int const est = lane >= 32;                 /* the lane works on the long->short estimate */
+    int const sb = est ? lane - 32 : lane;
+    LhPsyBand const *gd = est ? &T->psy_l_to_s : &T->psy_l;
+    int const npart = gd->npart;
+    int const n_sb = est ? T->psy_l_to_s.n_sb : T->psy_l.n_sb;
+    int const mine = sb < n_sb;
+    int const sbc = mine ? sb : 0;
+    int const bo_sb = gd->bo[sbc];
+    float const w_prev = gd->bo_weight[sbc > 0 ? sbc - 1 : 0], w_curr = gd->bo_weight[sbc];
+    int const b_lim = bo_sb < npart ? bo_sb : npart;
+    int     m;
+    {
+        /* where the reference's band walk stands on reaching band sb (see lh_partition2sfb_wave): a running
+         * maximum over the lanes of each table's group, shifted by one lane */
+        int const d = b_lim - sb;
+        uint32_t const v = (mine && d > 0) ? (uint32_t) d : 0u;
+        uint32_t const run_l = lh_wave_scan_max_u32(est ? 0u : v);
+        uint32_t const run_e = lh_wave_scan_max_u32((est && lane >= 32) ? v : 0u);  /* lanes below 32 add nothing */
+        uint32_t const run = est ? run_e : run_l;
+        uint32_t const prev = lh_shfl_u32(run, (lane - 1) & 63);
+        m = (sb > 0) ? (int) prev : 0;
+    }
+    LH_WAVE_SYNC_MEM();
+    {
+        int const b0 = sb + m;
+        int const live = (sb == 0) || (b0 - 1 < npart);
+        int const steps = (mine && live && b_lim > b0) ? b_lim - b0 : 0;
+        int const nmax = lh_uni_i((int) lh_wave_max_u32((uint32_t) steps));
+        int const bend = b0 + steps;            /* where the lane's walk ends */
+        float   enn[NC], thmm[NC];
+#pragma unroll
+        for (int q = 0; q < NC; q++) {
+            int const carry = mine && live && sb > 0;
+            float const cw = 1.0f - w_prev;
+            float const e = ch[q].eb[carry ? b0 - 1 : 0], t = ch[q].thr[carry ? b0 - 1 : 0];
+            enn[q] = carry ? cw * e : 0.0f;
+            thmm[q] = carry ? cw * t : 0.0f;
+        }
+        for (int i = 0; i < nmax; i++) {
+            int const on = i < steps;
+            int const b = on ? b0 + i : 0;
+#pragma unroll
+            for (int q = 0; q < NC; q++) {
+                float const e = ch[q].eb[b], t = ch[q].thr[b];
+                float const se = enn[q] + e, st = thmm[q] + t;
+                enn[q] = on ? se : enn[q];
+                thmm[q] = on ? st : thmm[q];
+            }
+        }
+        {
+            int const tail = mine && live && bend < npart;
+#pragma unroll
+            for (int q = 0; q < NC; q++) {
+                float const e = ch[q].eb[tail ? bend : 0], t = ch[q].thr[tail ? bend : 0];
+                float const se = enn[q] + w_curr * e, st = thmm[q] + w_curr * t;
+                float   ev, tv;
+                enn[q] = tail ? se : enn[q];
+                thmm[q] = tail ? st : thmm[q];
+                ev = live ? enn[q] : 0.0f;
+                tv = live ? thmm[q] : 0.0f;
+                if (est)
+                    tv = tv * (float) (1. / 64.f);
+                if (mine) {
+                    if (est) {
+                        ch[q].en[22 + 3 * sb] = ch[q].en[22 + 3 * sb + 1] = ch[q].en[22 + 3 * sb + 2] = ev;
+                        ch[q].thm[22 + 3 * sb] = ch[q].thm[22 + 3 * sb + 1] = ch[q].thm[22 + 3 * sb + 2] = tv;
+                    }
+                    else {
+                        ch[q].en[sb] = ev;
+                        ch[q].thm[sb] = tv;
+                    }
+                }
+            }
+        }
+    }
+}
+
 /* tonality index of partition b (reference psymodel.c:583-652 / 958-1028) from the maxima / averages of
  * the partition itself (m1, a1) and of its neighbours below (m0, a0) and above (m2, a2) */
 LH_DEVFN int
@@ -1048,17 +1137,17 @@ lh_psy_granule(int gr, LhPsyCarry nb)
     LH_SYNC_WG_LDS();
     LH_PA(33, t_psy0);
     /* (7) partitions -> scalefactor bands, long and long->short estimates
-     * (reference psymodel.c:411-439); 4 serial chains per wave */
-    for (int t = 0; t < 4; t++) {       /* (channel, long | long->short) x lane = band */
-        int const chn = w + 2 * (t >> 1);
-        int const act = chn < n_chn_psy;
-        int const cc = act ? chn : w;
-        if ((t & 1) == 0)
-            lh_partition2sfb_wave(&T->psy_l, &P.eb[cc * 64], &P.thr[cc * 64], &L.psy_en[now][cc][0],
-                                  &L.psy_thm[now][cc][0], 1, -1.0f, 0, lane, act);
-        else
-            lh_partition2sfb_wave(&T->psy_l_to_s, &P.eb[cc * 64], &P.thr[cc * 64], &L.psy_en[now][cc][22],
-                                  &L.psy_thm[now][cc][22], 3, (float) (1. / 64.f), 1, lane, act);
+     * (reference psymodel.c:411-439): both tables and the wave's pseudo-channels in one pass */
+    if (n_chn_psy == 4) {
+        LhSfbChan const two[2] = {
+            {&P.eb[w * 64], &P.thr[w * 64], &L.psy_en[now][w][0], &L.psy_thm[now][w][0]},
+            {&P.eb[(w + 2) * 64], &P.thr[(w + 2) * 64], &L.psy_en[now][w + 2][0], &L.psy_thm[now][w + 2][0]}
+        };
+        lh_partition2sfb_long < 2 > (T, two, lane);
+    }
+    else if (w < n_chn_psy) {
+        LhSfbChan const one[1] = { {&P.eb[w * 64], &P.thr[w * 64], &L.psy_en[now][w][0], &L.psy_thm[now][w][0]} };
+        lh_partition2sfb_long < 1 > (T, one, lane);
     }
     LH_SYNC_WG_LDS();
     LH_PA(34, t_psy0);
