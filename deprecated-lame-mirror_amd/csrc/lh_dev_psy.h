@@ -317,6 +317,23 @@ lh_fft_energy(const LhCtx & c, int chn, const float *wl, const float *wr, int n,
     }
 }
 
+/* the same for the two pseudo-channels wave w owns under joint stereo -- its own channel (L or R) and
+ * mid (w = 0) or side (w = 1) -- from one reading of the two spectra */
+LH_DEVFN void
+lh_fft_energy_pair(const LhCtx & c, int w, const float *wl, const float *wr, int n, float *out_own, float *out_ms)
+{
+    float const sqrt2_half = (float) (LH_SQRT2 * 0.5f);
+    int const h = n >> 1;
+    for (int m = c.lane; m <= h; m += 64) {
+        int const ire = m, iim = (m == 0) ? 0 : (n - m);
+        float const lre = wl[ire], lim = wl[iim], rre = wr[ire], rim = wr[iim];
+        float const ore = w ? rre : lre, oim = w ? rim : lim;
+        float const mre = (w ? lre - rre : lre + rre) * sqrt2_half, mim = (w ? lim - rim : lim + rim) * sqrt2_half;
+        out_own[m] = (m == 0) ? ore * ore : (ore * ore + oim * oim) * 0.5f;
+        out_ms[m] = (m == 0) ? mre * mre : (mre * mre + mim * mim) * 0.5f;
+    }
+}
+
 /* serial partition -> scalefactor band accumulation (reference psymodel.c:350-393);
  * executed by ONE lane per (channel, table) chain */
 /* partitions -> scalefactor bands (reference psymodel.c:350-409), one lane per band.
@@ -1035,11 +1052,10 @@ lh_psy_granule(int gr, LhPsyCarry nb)
     LH_SYNC_WG_LDS();
     LH_PA(30, t_psy0);
     /* (4) power spectra of this wave's two pseudo-channels */
-    for (int pass = 0; pass < 2; pass++) {
-        int const chn = w + 2 * pass;
-        if (chn < n_chn_psy)
-            lh_fft_energy(c, chn, P.wsamp[0], P.wsamp[1], LH_BLKSIZE, P.b.energy[chn]);
-    }
+    if (n_chn_psy == 4)
+        lh_fft_energy_pair(c, w, P.wsamp[0], P.wsamp[1], LH_BLKSIZE, P.b.energy[w], P.b.energy[w + 2]);
+    else if (w < n_chn_psy)
+        lh_fft_energy(c, w, P.wsamp[0], P.wsamp[1], LH_BLKSIZE, P.b.energy[w]);
     /* The FHT buffers are free until the short FFTs: stage the long-block spreading matrix and
      * the tables of the masking addition there (the spreading loop of stage 6 makes three to
      * four dependent look-ups per step; from HBM each costs a few hundred cycles). */
@@ -1164,11 +1180,12 @@ lh_psy_granule(int gr, LhPsyCarry nb)
         if (w < n_chn_psy && !L.uselongblock[w]) {
             /* (wave w's pseudo-channels w and w + 2 share uselongblock[w]) */
             int const both = (n_chn_psy == 4);
-            lh_fft_energy(c, w, &P.wsamp[0][sblock * LH_BLKSIZE_S], &P.wsamp[1][sblock * LH_BLKSIZE_S], LH_BLKSIZE_S,
-                          P.b.energy[w]);
             if (both)
-                lh_fft_energy(c, w + 2, &P.wsamp[0][sblock * LH_BLKSIZE_S], &P.wsamp[1][sblock * LH_BLKSIZE_S],
-                              LH_BLKSIZE_S, P.b.energy[w + 2]);
+                lh_fft_energy_pair(c, w, &P.wsamp[0][sblock * LH_BLKSIZE_S], &P.wsamp[1][sblock * LH_BLKSIZE_S],
+                                   LH_BLKSIZE_S, P.b.energy[w], P.b.energy[w + 2]);
+            else
+                lh_fft_energy(c, w, &P.wsamp[0][sblock * LH_BLKSIZE_S], &P.wsamp[1][sblock * LH_BLKSIZE_S], LH_BLKSIZE_S,
+                              P.b.energy[w]);
             LH_WAVE_SYNC_MEM();
             if (both) {
                 LhMaskChan const two[2] = {
