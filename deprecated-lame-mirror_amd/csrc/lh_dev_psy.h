@@ -919,6 +919,7 @@ lh_psy_granule(int gr, LhPsyCarry nb)
         L.tot_ener[gr][c.tid] = lh_lds.ss.tot_ener[c.tid];
 
     LH_PT(t_psy0);
+    LQ_MARK("ps_attack");
     /* (2) attack detection (reference psymodel.c:759-940) */
     {
         int const firbase = bufbase + 576 - 350 - LH_NSFIRLEN + 192;
@@ -939,7 +940,13 @@ lh_psy_granule(int gr, LhPsyCarry nb)
     for (int pass = 0; pass < 2; pass++) {
         int const chn = w + 2 * pass;
         if (chn < n_chn_psy) {
-            float   peak[9];
+            /* Twelve sub-blocks of 64 samples: three from the previous call, nine new ones (reference
+             * psymodel.c:806-925).  Lane i (< 12) owns sub-block i: its peak, the ratio against the one
+             * two earlier, the sums over its short block.  The nine new peaks are wave maxima: eight come
+             * out of one transposed reduction with peak k in lane k (and move up three lanes), the ninth
+             * from a plain one. */
+            uint32_t pk[8], pk8 = 0;
+            float   e, then, ai;
             for (int k = 0; k < 9; k++) {
                 int const i = lane + 64 * k;
                 float   v;
@@ -949,51 +956,57 @@ lh_psy_granule(int gr, LhPsyCarry nb)
                     v = P.a.hpf[0][i] + P.a.hpf[1][i];
                 else
                     v = P.a.hpf[0][i] - P.a.hpf[1][i];
-                v = lh_fabsf(v);
                 /* p = max(1, max |x|): exact under any evaluation order */
-                peak[k] = lh_u32_as_f32(lh_wave_max_u32(lh_f32_as_u32(v)));
-                if (peak[k] < 1.0f)
-                    peak[k] = 1.0f;
+                if (k < 8)
+                    pk[k] = lh_f32_as_u32(lh_fabsf(v));
+                else
+                    pk8 = lh_f32_as_u32(lh_fabsf(v));
             }
             {
-                /* wave-uniform scalar part */
-                float   attack_intensity[12];
-                float   en_subshort[12];
-                float   en_short[4] = { 0, 0, 0, 0 };
-                int     nsa[4] = { 0, 0, 0, 0 };
-                int     ns_uselongblock = 1;
-                int const last_att = lh_lds.ss.last_attacks[chn];
-                for (int i = 0; i < 3; i++) {
-                    en_subshort[i] = lh_lds.ss.last_en_subshort[chn][i + 6];
-                    attack_intensity[i] = en_subshort[i] / lh_lds.ss.last_en_subshort[chn][i + 4];
-                    en_short[0] += en_subshort[i];
-                }
-                LH_WAVE_SYNC_MEM();
-                for (int i = 0; i < 9; i++) {
-                    /* a sub-block's peak against the one two sub-blocks earlier: a rise counts by its
-                     * ratio, a fall only beyond 10 x (reference psymodel.c:836-850) */
-                    float const now = peak[i], then = en_subshort[i + 1];
-                    if (lane == 0)
-                        lh_lds.ss.last_en_subshort[chn][i] = now;
-                    en_subshort[i + 3] = now;
-                    en_short[1 + i / 3] += now;
-                    attack_intensity[i + 3] = (now > then) ? now / then : (then > now * 10.0f) ? then / (now * 10.0f) : 0.0f;
-                }
-                for (int blk = 0; blk < 3; ++blk) {
-                    /* a short block whose energy sits in its first sub-blocks gets a lower threshold
-                     * (reference psymodel.c:853-864): halve once, or twice, when a later sub-block holds
-                     * less than a sixth of the block */
-                    float const e0 = en_subshort[3 * blk + 3], e1 = en_subshort[3 * blk + 4], e2 = en_subshort[3 * blk + 5];
-                    float const whole = e0 + e1 + e2;
-                    int const tail_low = e2 * 6 < whole, mid_low = e1 * 6 < whole;
-                    L.sub_short_factor[chn][blk] = tail_low ? (mid_low ? 0.25f : 0.5f) : 1.0f;
-                }
+                uint32_t const m8 = lh_wave_max8(pk);           /* lane k: peak k & 7 */
+                uint32_t const m9 = lh_wave_max_u32(pk8);
+                uint32_t const up = lh_lane_minus_u32 < 3 > (m8);       /* lane i: peak i - 3 (i = 3..10) */
+                float const mine = lh_u32_as_f32((lane == 11) ? m9 : up);
+                float const old = lh_lds.ss.last_en_subshort[chn][(lane < 3) ? lane + 6 : 0];
+                float const older = lh_lds.ss.last_en_subshort[chn][(lane < 3) ? lane + 4 : 0];
+                float const fresh = mine < 1.0f ? 1.0f : mine;
+                e = (lane < 3) ? old : fresh;                   /* en_subshort[lane], lanes 0..11 */
                 {
-                    float const x = T->attack_threshold[chn];
-                    for (int i = 0; i < 12; i++)
-                        if (nsa[i / 3] == 0)
-                            if (attack_intensity[i] > x)
-                                nsa[i / 3] = (i % 3) + 1;
+                    float const two_back = lh_u32_as_f32(lh_lane_minus_u32 < 2 > (lh_f32_as_u32(e)));  /* (every lane takes part) */
+                    then = (lane < 3) ? older : two_back;
+                }
+            }
+            LH_WAVE_SYNC_MEM();         /* the old values are read: the new ones may replace them */
+            if (lane >= 3 && lane < 12)
+                lh_lds.ss.last_en_subshort[chn][lane - 3] = e;
+            /* a sub-block's peak against the one two sub-blocks earlier: a rise counts by its ratio, a
+             * fall only beyond 10 x (reference psymodel.c:836-850); the three old ones: plain ratios */
+            ai = (lane < 3) ? e / then : (e > then) ? e / then : (then > e * 10.0f) ? then / (e * 10.0f) : 0.0f;
+            {
+                /* sums over the short blocks (sub-blocks 3 g .. 3 g + 2, added in that order) arrive in
+                 * lane 3 g + 2; a short block whose energy sits in its first sub-blocks gets a lower
+                 * threshold (reference psymodel.c:853-864): halve once, or twice, when a later sub-block
+                 * holds less than a sixth of the block */
+                float const e1 = lh_u32_as_f32(lh_lane_minus_u32 < 1 > (lh_f32_as_u32(e)));
+                float const e0 = lh_u32_as_f32(lh_lane_minus_u32 < 2 > (lh_f32_as_u32(e)));
+                float const whole = e0 + e1 + e;
+                int const tail_low = e * 6 < whole, mid_low = e1 * 6 < whole;
+                float const x = T->attack_threshold[chn];
+                uint64_t const over = lh_ballot(lane < 12 && ai > x);
+                float const en_short0 = lh_u32_as_f32(lh_bcast_u32(lh_f32_as_u32(whole), 2));
+                float const en_short1 = lh_u32_as_f32(lh_bcast_u32(lh_f32_as_u32(whole), 5));
+                float const en_short2 = lh_u32_as_f32(lh_bcast_u32(lh_f32_as_u32(whole), 8));
+                float const en_short3 = lh_u32_as_f32(lh_bcast_u32(lh_f32_as_u32(whole), 11));
+                float const en_short[4] = { en_short0, en_short1, en_short2, en_short3 };
+                int     nsa[4];
+                int     ns_uselongblock = 1;
+                int const last_att = lh_uni_i(lh_lds.ss.last_attacks[chn]);
+                if (lane == 5 || lane == 8 || lane == 11)
+                    L.sub_short_factor[chn][(lane - 5) / 3] = tail_low ? (mid_low ? 0.25f : 0.5f) : 1.0f;
+                for (int gq = 0; gq < 4; gq++) {
+                    /* the first sub-block of the short block whose ratio exceeds the threshold, 1-based */
+                    unsigned const bits = (unsigned) (over >> (3 * gq)) & 7u;
+                    nsa[gq] = bits ? ((bits & 1u) ? 1 : (bits & 2u) ? 2 : 3) : 0;
                 }
                 for (int i = 1; i < 4; i++) {
                     float const u = en_short[i - 1];
@@ -1018,9 +1031,11 @@ lh_psy_granule(int gr, LhPsyCarry nb)
                     if (nsa[3] && nsa[2])
                         nsa[3] = 0;
                 }
-                for (int i = 0; i < 4; i++)
-                    L.ns_attacks[chn][i] = nsa[i];
-                L.ns_uselong[chn] = ns_uselongblock;
+                if (lane == 0) {
+                    for (int i = 0; i < 4; i++)
+                        L.ns_attacks[chn][i] = (int8_t) nsa[i];
+                    L.ns_uselong[chn] = ns_uselongblock;
+                }
             }
         }
         LH_WAVE_SYNC_MEM();
@@ -1047,10 +1062,12 @@ lh_psy_granule(int gr, LhPsyCarry nb)
     LH_SYNC_WG_LDS();
 
     LH_PA(29, t_psy0);
+    LQ_MARK("ps_fft");
     /* (3) long FFTs of L (wave 0) and R (wave 1) */
     lh_fft_long(c, w, bufbase, P.wsamp[w]);
     LH_SYNC_WG_LDS();
     LH_PA(30, t_psy0);
+    LQ_MARK("ps_energy");
     /* (4) power spectra of this wave's two pseudo-channels */
     if (n_chn_psy == 4)
         lh_fft_energy_pair(c, w, P.wsamp[0], P.wsamp[1], LH_BLKSIZE, P.b.energy[w], P.b.energy[w + 2]);
@@ -1074,6 +1091,7 @@ lh_psy_granule(int gr, LhPsyCarry nb)
         stg_t2[c.tid] = lh_mask_table2[c.tid];
     LH_SYNC_WG_LDS();
     LH_PA(31, t_psy0);
+    LQ_MARK("ps_sums");
     /* (5) serial sums: total energy (bins 11..512) and loudness (reference psymodel.c:213-226,
      * 690-696): lane 0/1 = tot_ener of chn w / w+2, lane 2 = loudness of channel w */
     {
@@ -1130,6 +1148,7 @@ lh_psy_granule(int gr, LhPsyCarry nb)
         LH_WAVE_SYNC_MEM();
     }
     LH_PA(32, t_psy0);
+    LQ_MARK("ps_mask");
     /* (6) masking thresholds, long blocks: the wave's one or two pseudo-channels together */
     if (n_chn_psy == 4) {
         LhMaskChan const two[2] = {
@@ -1152,6 +1171,7 @@ lh_psy_granule(int gr, LhPsyCarry nb)
     }
     LH_SYNC_WG_LDS();
     LH_PA(33, t_psy0);
+    LQ_MARK("ps_p2sfb");
     /* (7) partitions -> scalefactor bands, long and long->short estimates
      * (reference psymodel.c:411-439): both tables and the wave's pseudo-channels in one pass */
     if (n_chn_psy == 4) {
@@ -1167,6 +1187,7 @@ lh_psy_granule(int gr, LhPsyCarry nb)
     }
     LH_SYNC_WG_LDS();
     LH_PA(34, t_psy0);
+    LQ_MARK("ps_short");
     /* (8) short blocks (reference psymodel.c:1470-1500) */
     /* (nothing of it runs when both channels keep long blocks -- the usual granule: the values the
      * short transforms would replace are the long->short estimates of stage 7) */
@@ -1218,6 +1239,7 @@ lh_psy_granule(int gr, LhPsyCarry nb)
         LH_SYNC_WG_LDS();
     }
     LH_PA(35, t_psy0);
+    LQ_MARK("ps_preecho");
     /* (9) short block pre-echo control (reference psymodel.c:1502-1553): one lane per (chn, sb) */
     {
         float const pcfact = 0.6f;
@@ -1266,6 +1288,7 @@ lh_psy_granule(int gr, LhPsyCarry nb)
     }
     LH_SYNC_WG_LDS();
     LH_PA(36, t_psy0);
+    LQ_MARK("ps_pe");
     /* (10) block type state machine (reference psymodel.c:1289-1319) + PE (:1568-1595) */
     {
         int     btd[2];

@@ -685,6 +685,19 @@ lh_selftest_kernel(unsigned *out, unsigned seed)
             }
         }
         bad += (lh_wave_max_u32(x) != rmax);
+        {
+            /* eight maxima at once: lane k gets that of word k & 7 (word j of lane i: vals[i] rotated by 3 j bits) */
+            unsigned w8[8], want = 0;
+            for (int j = 0; j < 8; j++)
+                w8[j] = (x >> (3 * j)) | (x << (32 - 3 * j) % 32);
+            for (int i = 0; i < 64; i++) {
+                unsigned const v = vals[i], j = lane & 7u;
+                unsigned const r = (v >> (3 * j)) | (v << (32 - 3 * j) % 32);
+                want = r > want ? r : want;
+            }
+            bad += (lh_wave_max8(w8) != want);
+            bad += (lh_lane_minus_u32 < 2 > (x) != ((lane & 15u) >= 2 ? vals[lane - 2] : 0u));
+        }
         bad += (lh_wave_min_u32(x) != rmin);
         bad += (lh_wave_or_u32(x) != ror);
         bad += (lh_ballot((x & 4u) != 0) != rbal);

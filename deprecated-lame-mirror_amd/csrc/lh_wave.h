@@ -188,6 +188,25 @@ lh_wave_sum_regions(uint32_t p0, uint32_t p1, uint32_t p2, uint32_t q, uint32_t 
     return qt;
 }
 
+/* wave maxima of eight words at once: lane k returns the maximum of word k & 7 (see the device version) */
+static inline uint32_t
+lh_wave_max8(const uint32_t (&v)[8])
+{
+    uint32_t t[8];
+    for (int k = 0; k < 8; k++)
+        t[k] = lh_wave_max_u32(v[k]);
+    return t[lh_lane() & 7];
+}
+
+/* value of lane - n (0 where there is none); n = 1, 2, 3 */
+template < int N > static inline uint32_t
+lh_lane_minus_u32(uint32_t v)
+{
+    const uint64_t *x = hipemu_wave_exchange(v);
+    int const me = lh_lane();
+    return me >= N ? (uint32_t) x[me - N] : 0u;
+}
+
 /* value of the lane below (0 for lane 0) */
 static inline uint32_t
 lh_lane_below_u32(uint32_t v)
@@ -432,6 +451,40 @@ lh_wave_sum_regions(uint32_t p0, uint32_t p1, uint32_t p2, uint32_t q, uint32_t 
     *L = x;
     *H = lh_dpp < 0x104, 0u > (x);      /* row_shl:4: lane r reads lane r + 4 */
     return (uint32_t) __builtin_amdgcn_readlane((int) x, 3);
+}
+
+/* Wave maxima of eight words at once (the transposed scheme of lh_wave_sum_regions): three butterfly steps
+ * per word inside the groups of eight lanes, then lane k of a group carries word k & 7 through the three
+ * steps across the groups.  Lane k returns the maximum of word k & 7. */
+__device__ __forceinline__ uint32_t
+lh_wave_max8(const uint32_t (&w)[8])
+{
+    enum { N = 8 };
+    uint32_t v[N];
+    int const lane = lh_lane();
+#pragma unroll
+    for (int i = 0; i < N; i++)
+        v[i] = w[i];
+    LH_DPP_STEP_N(LH_OP_MAX, 0u, 0xB1) LH_DPP_STEP_N(LH_OP_MAX, 0u, 0x4E) LH_DPP_STEP_N(LH_OP_MAX, 0u, 0x141)
+    uint32_t const a = (lane & 1) ? v[1] : v[0], b = (lane & 1) ? v[3] : v[2];
+    uint32_t const cc = (lane & 1) ? v[5] : v[4], d = (lane & 1) ? v[7] : v[6];
+    uint32_t const ab = (lane & 2) ? b : a, cd = (lane & 2) ? d : cc;
+    uint32_t x = (lane & 4) ? cd : ab;
+    uint32_t t;
+    t = lh_dpp < 0x128, 0u > (x);
+    x = t > x ? t : x;
+    t = (uint32_t) __builtin_amdgcn_ds_swizzle((int) x, 0x401F);
+    x = t > x ? t : x;
+    t = (uint32_t) __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, (int) x);
+    x = t > x ? t : x;
+    return x;
+}
+
+/* value of lane - n inside a row of 16 (0 where there is none); n = 1, 2, 3: row_shr */
+template < int N > __device__ __forceinline__ uint32_t
+lh_lane_minus_u32(uint32_t v)
+{
+    return lh_dpp < 0x110 + N, 0u > (v);
 }
 
 /* value of the lane below (0 for lane 0; within a row of 16, which is all count_bits asks for) */
