@@ -275,7 +275,7 @@ struct LhQTabs {
     uint32_t ctabA[32], ctabB[32];      /* lh_dev_qloop.h: per class of a region maximum, the grid origin of its
                                          * candidate tables / the tables and their linbits (lq_class_tabs) */
     float   pow43h[256];        /* heads of pow43 / adj43asm: nearly all quantised values are < 256 */
-    float   adj43h[256];
+    float   qthr[256];          /* LhTables.qthr: the quantiser's second rounding as a comparison */
 };
 
 

@@ -244,8 +244,9 @@ lq_count_bits(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
     }
     LQ_MARK("cb_quant");
     /* ---- quantise: all pairs, straight line; the selection follows.  The first rounding is a
-     * float addition: (float) ((double) x + 2^23) and x + 2^23f agree for every float x >= 0
-     * (tests/test_quantizer_identity.py) ---- */
+     * float addition: (float) ((double) x + 2^23) and x + 2^23f agree for every float x >= 0; the
+     * second is a comparison with the first float that the reference's expression rounds up to k
+     * (LhTables.qthr; both in tests/test_quantizer_identity.py) ---- */
     {
         uint32_t nq[5];
         uint32_t bmax = 0;
@@ -253,9 +254,8 @@ lq_count_bits(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
         for (int k = 0; k < NS; k++) {
             float const a0 = istep * S.xp[2 * k], a1 = istep * S.xp[2 * k + 1];
             uint32_t const b0 = lh_f32_as_u32(a0 + (float) LH_MAGIC_FLOAT), b1 = lh_f32_as_u32(a1 + (float) LH_MAGIC_FLOAT);
-            float const j0 = qt->adj43h[b0 & 255u], j1 = qt->adj43h[b1 & 255u];
-            double const d0 = (double) a0 + (double) LH_MAGIC_FLOAT, d1 = (double) a1 + (double) LH_MAGIC_FLOAT;
-            uint32_t const r0 = lh_f32_as_u32((float) (d0 + j0)), r1 = lh_f32_as_u32((float) (d1 + j1));
+            float const t0 = qt->qthr[b0 & 255u], t1 = qt->qthr[b1 & 255u];
+            uint32_t const r0 = b0 - (a0 < t0 ? 1u : 0u), r1 = b1 - (a1 < t1 ? 1u : 0u);
             bmax = b0 > bmax ? b0 : bmax;
             bmax = b1 > bmax ? b1 : bmax;
             nq[k] = ((r0 & 0xffffu) | (r1 << 16)) & S.vm[k];

@@ -90,38 +90,17 @@ lh_huf_noESC(unsigned mx)       /* first candidate table for a region maximum 1.
 LH_DEVFN int
 lh_quant_line(const LhTables * T, const LhQTabs * qt, float istep, float xp)
 {
-    double  x0 = (double) (istep * xp);
-    float   f;
-    int     k;
-    x0 += LH_MAGIC_FLOAT;
-    f = (float) x0;
-    k = (int) lh_f32_as_u32(f) - LH_MAGIC_INT;
-    {
-        /* LDS holds the first 256 entries; the rest (rare: large quantised values) comes from
-         * HBM.  Two separate loads: a select between an LDS and a global pointer would turn
-         * every access into a FLAT load. */
-        float   adj = qt->adj43h[k & 255];
-        if (k >= 256)
-            adj = T->adj43asm[k];
-        f = (float) (x0 + adj);
+    /* first roundings below 256 (nearly all): a float addition, then the second rounding as a comparison
+     * (LhTables.qthr, in LDS; tests/test_quantizer_identity.py); the rest follows the reference's
+     * expression with the offset from HBM */
+    float const a = istep * xp;
+    int const k = (int) lh_f32_as_u32(a + (float) LH_MAGIC_FLOAT) - LH_MAGIC_INT;
+    int     q = k - (a < qt->qthr[k & 255] ? 1 : 0);
+    if (k >= 256) {
+        double const x0 = (double) a + LH_MAGIC_FLOAT;
+        q = (int) lh_f32_as_u32((float) (x0 + T->adj43asm[k])) - LH_MAGIC_INT;
     }
-    return (int) lh_f32_as_u32(f) - LH_MAGIC_INT;
-}
-
-/* the same with the rounding table's LDS head only; big = 1 when the first rounding landed
- * beyond the head (the result is then not valid and the caller redoes the line) */
-LH_DEVFN int
-lh_quant_line_head(const LhQTabs * qt, float istep, float xp, int &big)
-{
-    double  x0 = (double) (istep * xp);
-    float   f;
-    int     k;
-    x0 += LH_MAGIC_FLOAT;
-    f = (float) x0;
-    k = (int) lh_f32_as_u32(f) - LH_MAGIC_INT;
-    big = (k >= 256);
-    f = (float) (x0 + qt->adj43h[k & 255]);
-    return (int) lh_f32_as_u32(f) - LH_MAGIC_INT;
+    return q;
 }
 
 /* Huffman cost of the pairs [lo,hi) of ix with the best table; all lanes take

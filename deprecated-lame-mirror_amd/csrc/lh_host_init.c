@@ -926,6 +926,40 @@ build_huffman_grids(LhTables * t)
     }
 }
 
+/* The quantiser's second rounding for a fixed offset: what the reference computes from a scaled line a
+ * once the first rounding has picked adj43asm[k] (reference takehiro.c:166-190) */
+static int
+second_rounding(float a, float offset)
+{
+    double const shifted = (double) a + 8388608.0;
+    union { float f; uint32_t u; } r;
+    r.f = (float) (shifted + offset);
+    return (int) (r.u - 0x4B000000u);
+}
+
+/* LhTables.qthr: per first rounding k the smallest float whose second rounding reaches k.  Positive
+ * floats ascend with their bit patterns and second_rounding() never decreases with a, so the first
+ * pattern is found by bisection between k - 0.75 (gives k - 1) and k + 0.75 (gives at least k). */
+static void
+build_quant_thresholds(LhTables * t)
+{
+    int     k;
+    t->qthr[0] = 0.0f;          /* offset 0: every line of the class quantises to 0 */
+    for (k = 1; k < 256; k++) {
+        union { float f; uint32_t u; } below, reach, mid;
+        below.f = (float) k - 0.75f;
+        reach.f = (float) k + 0.75f;
+        while (reach.u - below.u > 1u) {
+            mid.u = below.u + (reach.u - below.u) / 2u;
+            if (second_rounding(mid.f, t->adj43asm[k]) >= k)
+                reach = mid;
+            else
+                below = mid;
+        }
+        t->qthr[k] = reach.f;
+    }
+}
+
 /* largest count <= guess with edge[base + count] <= limit; the guess itself when there is none */
 static int
 lower_until_inside(const int *edge, int base, int guess, int limit)
@@ -1435,6 +1469,7 @@ lh_tables_build(LhConfig * c, const LhInitAux * aux, LhTables * t)
         return -1;
     build_region_split(t);
     build_huffman_grids(t);
+    build_quant_thresholds(t);
     build_band_weights(aux, t);
     if (psymodel_tables(c, aux, t))
         return -1;

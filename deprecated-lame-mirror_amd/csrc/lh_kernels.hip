@@ -88,7 +88,7 @@ lh_load_qtabs(const LhCtx & c, LhQTabs & q)
 {
     for (int i = c.tid; i < 256; i += LH_NT) {
         q.pow43h[i] = c.T->pow43[i];
-        q.adj43h[i] = c.T->adj43asm[i];
+        q.qthr[i] = c.T->qthr[i];
     }
     for (int i = c.tid; i < (int) sizeof(q.ht_len); i += LH_NT)
         q.ht_len[i] = lh_ht_len[i];

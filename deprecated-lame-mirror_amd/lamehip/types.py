@@ -55,7 +55,8 @@ class LhTables(C.Structure):
         ("fft_window", C.c_float * BLKSIZE), ("fft_window_s", C.c_float * (BLKSIZE_S // 2)),
         ("fht_tw", ((C.c_float * 4) * 128) * 4),
         ("amp_filter", C.c_float * 32), ("log_table", C.c_float * 513),
-        ("sfb_line_l", C.c_uint8 * 576), ("sfb_line_s", C.c_uint8 * 576), ("hgrid", C.c_uint32 * 704)]
+        ("sfb_line_l", C.c_uint8 * 576), ("sfb_line_s", C.c_uint8 * 576), ("hgrid", C.c_uint32 * 704),
+        ("qthr", C.c_float * 256)]
 
 
 class LhGranule(C.Structure):

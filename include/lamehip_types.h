@@ -189,6 +189,12 @@ typedef struct LhTables {
      * [0..255] the ESC tables 16.. | 24.. and the count of values == 15, [256..511] tables 13 / 14 / 15,
      * [512..703] the small alphabets side by side (LQ_ORG_* in lh_dev_common.h).  Built by lh_tables_init. */
     uint32_t hgrid[704];
+    /* The second rounding of the x^(3/4) quantiser (reference takehiro.c:144-200) as a comparison: for a
+     * scaled line a whose first rounding gives k < 256, the quantised value is k - (a < qthr[k]).  The
+     * reference's (float) ((double) a + 2^23 + adj43asm[k]) is non-decreasing in a and, with the offsets of
+     * these k all negative, takes only the values k - 1 and k on the floats that round to k; qthr[k] is the
+     * first float that gives k, found by lh_tables_init with that very expression. */
+    float   qthr[256];
 } LhTables;
 
 /* ------------------------------------------------------------------ */

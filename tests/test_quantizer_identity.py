@@ -7,6 +7,9 @@ expression literally.  Each is checked here exhaustively over the domain the ker
 2. The step tables scale by exact powers of two: pow20[k + 4] == 2 pow20[k], ipow20[k + 16] ==
    ipow20[k] / 8, which is what lets the kernel rebuild any entry from a few mantissas with ldexp
    (the host refuses to initialise otherwise: power_tables_scale_exactly, lh_host_init.c).
+3. Second rounding of the quantiser: the reference adds adj43asm[k] (k = the first rounding) in double and
+   rounds to float again; the kernel forms k - (x < qthr[k]) for k < 256 (LhTables.qthr, lh_host_init.c).
+   Equal for every float whose first rounding is below 256.
 """
 import numpy as np
 
@@ -45,3 +48,26 @@ def test_float_root_equals_the_rounded_double_root():
     rng = np.random.default_rng(5)
     y = (rng.random(4_000_000, dtype=np.float32) * np.float32(1e9) + np.float32(1.0)).astype(np.float32)
     assert np.array_equal(np.sqrt(y.astype(np.float64)).astype(np.float32), np.sqrt(y))
+
+
+def test_threshold_comparison_equals_the_second_rounding_for_every_float_below_256():
+    import lamehip
+    enc = lamehip.Encoder(44100, 128, require_device=False)
+    T = enc.tables()
+    adj = np.ctypeslib.as_array(T.adj43asm).astype(np.float32)
+    thr = np.ctypeslib.as_array(T.qthr).astype(np.float32)
+    enc.close()
+    assert np.all(adj[1:256] < 0)           # what confines the class of k to the values k - 1 and k
+    magic = np.float32(8388608.0)
+    top = int(np.float32(255.5).view(np.uint32))        # 255.5 ties to 256: the last float of class 255 is below it
+    chunk = 1 << 24
+    bad = 0
+    for lo in range(0, top, chunk):
+        x = np.arange(lo, min(lo + chunk, top), dtype=np.uint32).view(np.float32)
+        k = ((x + magic).view(np.uint32) - np.uint32(0x4B000000)).astype(np.int32)
+        assert k.max() < 256
+        ref = ((x.astype(np.float64) + 8388608.0) + adj[k].astype(np.float64)).astype(np.float32)
+        ref = (ref.view(np.uint32) - np.uint32(0x4B000000)).astype(np.int32)
+        mine = k - (x < thr[k]).astype(np.int32)
+        bad += int(np.count_nonzero(ref != mine))
+    assert bad == 0
