@@ -419,6 +419,8 @@ struct LhLds {
     } u;
 };
 
+static_assert(__builtin_offsetof(LhTables, pow43) % 128 == 0 && __builtin_offsetof(LhTables, vqthr) % 128 == 0,
+              "the gathered tables start on cache lines (hipMalloc aligns the struct itself)");
 static_assert(sizeof(LhChanLds) % 16 == 0, "both channels' float2/float4 accesses need 16-byte alignment");
 static_assert(sizeof(LhLds) <= 40960, "four workgroups per CU need <= 40 KiB of the 160 KiB LDS each");
 

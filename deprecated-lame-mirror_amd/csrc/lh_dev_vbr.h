@@ -134,6 +134,24 @@ lh_vbr_geometry(const LhCtx & c, LhChanLds & Q, const LhQR & R)
 #ifndef LH_VBR_MARGIN
 #define LH_VBR_MARGIN 6e-5      /* tests widen it to drive every comparison through the exact chain */
 #endif
+/* table[i] of a table in HBM with the byte offset formed in 32 bits: a wave-uniform base plus a 32-bit lane
+ * offset is one addressing mode of the global load (no 64-bit address arithmetic per lane, and no shared
+ * zero register that would serialise a batch of look-ups) */
+/* -1 (all ones) when x < 0, else 0, as plain vector arithmetic: "a < b" as lh_sign_mask(a - b) is exact (a
+ * float difference is negative exactly when a < b; denormals are kept) and, unlike a comparison, does not
+ * pass through a scalar register pair, where a run of compare / use pairs would queue up */
+LH_DEVFN uint32_t
+lh_sign_mask(float x)
+{
+    return (uint32_t) ((int32_t) lh_f32_as_u32(x) >> 31);
+}
+
+LH_DEVFN float
+lh_gather_f32(const float *table, uint32_t i)
+{
+    return *(const float *) ((const char *) table + (i << 2));
+}
+
 template < int NV > LH_DEVFN void
 lh_vbr_noisy_n(const LhCtx & c, LhChanLds & Q, const LhVbrGeo & G, const float *xr, float xmin, const int sf[3],
                const int want[3], int bad[3])
@@ -182,14 +200,16 @@ lh_vbr_noisy_n(const LhCtx & c, LhChanLds & Q, const LhVbrGeo & G, const float *
                 x34[k] = Q.xrpow[lc];
                 ax[k] = lh_fabsf(xr[lc]);
             }
-            /* straight-line code: both table look-ups of all lines and variants go to HBM (L1/L2
-             * resident, 64 KiB) unconditionally, so that they are in flight together; trial steps
-             * below the final one quantise to large values, which the LDS heads do not cover */
+            /* straight-line code.  The first rounding is a float addition, the second a comparison with
+             * LhTables.vqthr (tests/test_quantizer_identity.py).  Both table look-ups of all lines and
+             * variants go to HBM (L1/L2 resident, 64 KiB) unconditionally, so that they are in flight
+             * together; trial steps below the final one quantise to large values, which LDS heads would
+             * not cover */
             {
                 float   sfpow[NV];
-                double  x0[NV][4];
-                int     k1[NV][4];
-                float   adj[NV][4], p43[NV][4];
+                float   a[NV][4];
+                uint32_t k1[NV][4];
+                float   reach[NV][4], p43[NV][4];
 #pragma unroll
                 for (int v = 0; v < NV; v++) {
                     int const sv = (int) ((pack >> (9 * v)) & 511u);
@@ -198,25 +218,29 @@ lh_vbr_noisy_n(const LhCtx & c, LhChanLds & Q, const LhVbrGeo & G, const float *
                     sfpow[v] = LH_VBR_POW20[svc];
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
-                        x0[v][k] = (double) (sfpow34 * x34[k]) + LH_MAGIC_FLOAT;
-                        k1[v][k] = (int) lh_f32_as_u32((float) x0[v][k]) - LH_MAGIC_INT;
+                        a[v][k] = sfpow34 * x34[k];
+                        k1[v][k] = lh_f32_as_u32(a[v][k] + (float) LH_MAGIC_FLOAT) - (uint32_t) LH_MAGIC_INT;
                     }
                 }
+                LH_SCHED_FENCE();
 #pragma unroll
                 for (int v = 0; v < NV; v++)
 #pragma unroll
                     for (int k = 0; k < 4; k++)
-                        adj[v][k] = T->adj43asm[k1[v][k]];
+                        reach[v][k] = lh_gather_f32(T->vqthr, k1[v][k]);
+                LH_SCHED_FENCE();
 #pragma unroll
                 for (int v = 0; v < NV; v++)
 #pragma unroll
                     for (int k = 0; k < 4; k++)
-                        k1[v][k] = (int) lh_f32_as_u32((float) (x0[v][k] + adj[v][k])) - LH_MAGIC_INT;
+                        k1[v][k] = k1[v][k] + lh_sign_mask(a[v][k] - lh_fabsf(reach[v][k])) + (lh_f32_as_u32(reach[v][k]) >> 31);
+                LH_SCHED_FENCE();
 #pragma unroll
                 for (int v = 0; v < NV; v++)
 #pragma unroll
                     for (int k = 0; k < 4; k++)
-                        p43[v][k] = T->pow43[k1[v][k]];
+                        p43[v][k] = lh_gather_f32(T->pow43, k1[v][k]);
+                LH_SCHED_FENCE();
 #pragma unroll
                 for (int v = 0; v < NV; v++) {
                     double  e[4], gs;

@@ -960,6 +960,75 @@ build_quant_thresholds(LhTables * t)
     }
 }
 
+/* first rounding of the quantiser (reference takehiro.c:166-190) */
+static int
+first_rounding(float a)
+{
+    union { float f; uint32_t u; } r;
+    r.f = (float) ((double) a + 8388608.0);
+    return (int) (r.u - 0x4B000000u);
+}
+
+/* LhTables.vqthr: the floats whose first rounding is k form a run of bit patterns [first, last]; the
+ * second rounding ascends over it.  Returns 0 when a class takes more than two values or leaves
+ * {k - 1, k, k + 1}. */
+static int
+build_vbr_quant_thresholds(LhTables * t)
+{
+    int     k;
+    for (k = 0; k < LH_PRECALC; k++) {
+        union { float f; uint32_t u; } first, last, below, reach, mid;
+        int     v_lo, v_hi, upper;
+        /* ends of the class: bisect the first rounding around k - 0.5 and k + 0.5 */
+        if (k == 0)
+            first.u = 0u;
+        else {
+            below.f = (float) k - 0.75f;
+            reach.f = (float) k + 0.25f;
+            while (reach.u - below.u > 1u) {
+                mid.u = below.u + (reach.u - below.u) / 2u;
+                if (first_rounding(mid.f) >= k)
+                    reach = mid;
+                else
+                    below = mid;
+            }
+            first = reach;
+        }
+        below.f = (float) k + 0.25f;
+        reach.f = (float) k + 0.75f;
+        while (reach.u - below.u > 1u) {
+            mid.u = below.u + (reach.u - below.u) / 2u;
+            if (first_rounding(mid.f) > k)
+                reach = mid;
+            else
+                below = mid;
+        }
+        last = below;
+        v_lo = second_rounding(first.f, t->adj43asm[k]);
+        v_hi = second_rounding(last.f, t->adj43asm[k]);
+        if (v_hi > v_lo + 1 || v_lo < k - 1 || v_hi > k + 1 || v_hi < k)
+            return 0;
+        upper = (v_hi == k + 1);        /* the class takes {k, k + 1}, else {k - 1, k} */
+        if (v_lo == v_hi)
+            reach.u = 0u;       /* no line lies below 0: the whole class takes the higher value */
+        else {
+            below = first;
+            reach = last;
+            while (reach.u - below.u > 1u) {
+                mid.u = below.u + (reach.u - below.u) / 2u;
+                if (second_rounding(mid.f, t->adj43asm[k]) >= v_hi)
+                    reach = mid;
+                else
+                    below = mid;
+            }
+        }
+        if (upper)
+            reach.u |= 0x80000000u;
+        t->vqthr[k] = reach.f;
+    }
+    return 1;
+}
+
 /* largest count <= guess with edge[base + count] <= limit; the guess itself when there is none */
 static int
 lower_until_inside(const int *edge, int base, int guess, int limit)
@@ -1470,6 +1539,8 @@ lh_tables_build(LhConfig * c, const LhInitAux * aux, LhTables * t)
     build_region_split(t);
     build_huffman_grids(t);
     build_quant_thresholds(t);
+    if (!build_vbr_quant_thresholds(t))
+        return -1;
     build_band_weights(aux, t);
     if (psymodel_tables(c, aux, t))
         return -1;

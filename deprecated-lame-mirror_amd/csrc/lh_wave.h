@@ -24,6 +24,7 @@ static inline int lh_wave_id(void) { return hipemu_wave(); }
 #define LH_WAVE_SYNC() hipemu_wave_sync()
 #define LH_WAVE_SYNC_MEM() hipemu_wave_sync()
 #define LH_WAVE_ORDER() hipemu_wave_sync()
+#define LH_SCHED_FENCE() do { } while (0)
 
 static inline uint32_t
 lh_wave_sum_u32(uint32_t v)
@@ -303,6 +304,10 @@ __device__ __forceinline__ int lh_wave_id(void) { return (int) (threadIdx.x >> 6
  * in flight together with whatever follows) */
 #define LH_WAVE_ORDER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); \
                              asm volatile("" ::: "memory"); } while (0)
+/* nothing is scheduled across this point: keeps a batch of independent table look-ups together (all issued
+ * before the first use) where the scheduler, short of registers, would otherwise string them into
+ * load / wait / use chains */
+#define LH_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 /* (the psycho-acoustic model's name for the same thing: its lanes once exchanged data through the stream
  * state in HBM and needed global accesses drained; that state lives in LDS now, and draining the
  * table loads in flight at every phase change was what the model waited for) */

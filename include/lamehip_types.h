@@ -148,7 +148,18 @@ typedef struct LhTables {
     int     psfb21[LH_PSFB21 + 1];
     int     psfb12[LH_PSFB12 + 1];
     /* quantiser power tables, reference quantize_pvt.c:171-179, 350-366 */
+    int     line_pad0[13];        /* pow43 and vqthr start on 128-byte lines of the device copy (checked in
+                                   * lh_dev_common.h): the searches gather mostly small indices from them,
+                                   * which then share one cache line instead of straddling two */
     float   pow43[LH_PRECALC];
+    float   line_pad1[16];
+    /* The second rounding of the quantiser as a comparison (see qthr below) for the VBR noise search, which
+     * meets every k.  Offsets of large k round to small positive
+     * numbers, so a class yields either {k - 1, k} or {k, k + 1}: the quantised value is
+     * k - (a < |vqthr[k]|) + (vqthr[k] carries a minus sign), |vqthr[k]| being the first float of the class
+     * that gives the higher value (0 when the whole class does).  lh_tables_init refuses a table where a
+     * class would take three values. */
+    float   vqthr[LH_PRECALC];
     float   adj43asm[LH_PRECALC];
     float   ipow20[LH_QMAX];
     float   pow20[LH_QMAX + LH_QMAX2 + 1];

@@ -19,7 +19,7 @@ import helpers  # noqa: F401  (puts the package on sys.path)
 def test_float_addition_equals_the_double_rounding_for_every_quantisable_float():
     magic = np.float32(8388608.0)
     top = int(np.float32(8206.0).view(np.uint32))
-    chunk = 1 << 24
+    chunk = 1 << 20
     bad = 0
     for lo in range(0, top + 1, chunk):
         x = np.arange(lo, min(lo + chunk, top + 1), dtype=np.uint32).view(np.float32)
@@ -50,24 +50,32 @@ def test_float_root_equals_the_rounded_double_root():
     assert np.array_equal(np.sqrt(y.astype(np.float64)).astype(np.float32), np.sqrt(y))
 
 
-def test_threshold_comparison_equals_the_second_rounding_for_every_float_below_256():
+def test_threshold_comparison_equals_the_second_rounding_for_every_quantisable_float():
+    """LhTables.qthr (CBR search, k < 256: the quantised value) and LhTables.vqthr (VBR noise search, every k) against the reference's expression, for every float up to IXMAX + 0.5."""
     import lamehip
     enc = lamehip.Encoder(44100, 128, require_device=False)
     T = enc.tables()
     adj = np.ctypeslib.as_array(T.adj43asm).astype(np.float32)
     thr = np.ctypeslib.as_array(T.qthr).astype(np.float32)
+    vqthr = np.ctypeslib.as_array(T.vqthr).astype(np.float32)
     enc.close()
-    assert np.all(adj[1:256] < 0)           # what confines the class of k to the values k - 1 and k
+    assert np.all(adj[1:256] < 0)           # what confines the class of k < 256 to the values k - 1 and k
     magic = np.float32(8388608.0)
-    top = int(np.float32(255.5).view(np.uint32))        # 255.5 ties to 256: the last float of class 255 is below it
-    chunk = 1 << 24
-    bad = 0
-    for lo in range(0, top, chunk):
-        x = np.arange(lo, min(lo + chunk, top), dtype=np.uint32).view(np.float32)
+    top = int(np.float32(8206.5).view(np.uint32))       # IXMAX_VAL + 0.5 (ties to even: 8206)
+    head = int(np.float32(255.5).view(np.uint32))       # 255.5 ties to 256: the last float of class 255 is below it
+    chunk = 1 << 20
+    bad = bad_v = 0
+    for lo in range(0, top + 1, chunk):
+        x = np.arange(lo, min(lo + chunk, top + 1), dtype=np.uint32).view(np.float32)
         k = ((x + magic).view(np.uint32) - np.uint32(0x4B000000)).astype(np.int32)
-        assert k.max() < 256
         ref = ((x.astype(np.float64) + 8388608.0) + adj[k].astype(np.float64)).astype(np.float32)
         ref = (ref.view(np.uint32) - np.uint32(0x4B000000)).astype(np.int32)
-        mine = k - (x < thr[k]).astype(np.int32)
-        bad += int(np.count_nonzero(ref != mine))
-    assert bad == 0
+        e = vqthr[k]
+        mine_v = k - (x < np.abs(e)).astype(np.int32) + np.signbit(e).astype(np.int32)
+        bad_v += int(np.count_nonzero(ref != mine_v))
+        if lo < head:
+            n = min(len(x), head - lo)
+            assert k[:n].max() < 256
+            mine = k[:n] - (x[:n] < thr[k[:n]]).astype(np.int32)
+            bad += int(np.count_nonzero(ref[:n] != mine))
+    assert bad == 0 and bad_v == 0
