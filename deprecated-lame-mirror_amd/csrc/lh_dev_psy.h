@@ -535,28 +535,26 @@ lh_mask_index(LhPsyBand const *gd, int b, float m0, float m1, float m2, float a0
 }
 
 /* lh_mask_add() for a partition outside the band around the diagonal (|kk - b| > delta), where the
- * reference only asks whether the ratio of the two maskers is below ma_max_i2: larger + smaller, or
+ * reference only asks whether the ratio of the two maskers is below c = ma_max_i2: larger + smaller, or
  * the larger alone (psymodel.c:294-341, the tail after the `b <= delta' block).  The ratio itself
- * is not needed for that: with t = c * lo, hi < t (1 - 2^-20) implies hi / lo < pred(c), so the
- * correctly rounded quotient is < c, and hi > t (1 + 2^-20) implies hi / lo > c, so it is >= c; in
- * between (or when t is not a normal number) the quotient is formed as the reference forms it.
- * No division and no table on the chain, which is what the wave waits for. */
-LH_DEVFN float
-lh_mask_add_far(float m1, float m2, float c)
+ * is not needed for that.  The correctly rounded float quotient hi / lo is below c exactly when the true
+ * quotient is below the midpoint of c and its predecessor (the quotient cannot sit on that midpoint: it has
+ * 25 significant bits, so midpoint x lo has at least 25 and is no float), i.e. when hi < midpoint x lo --
+ * and that product, 25 x 24 bits, is exact in double.  lo = 0 (the reference's early exits) falls out as
+ * "the larger alone".  Both maskers are sums and products of non-negative terms here, so the reference's
+ * clamps of negative inputs have nothing to do.  No division, no table and no branch on the chain, which
+ * is what the wave waits for. */
+LH_DEVFN double
+lh_mask_far_bound(float c)
 {
-    float const a = (m1 < 0) ? 0.0f : m1, b = (m2 < 0) ? 0.0f : m2;
-    float const hi = (a < b) ? b : a, lo = (a < b) ? a : b;
-    float const t = c * lo;
-    int const sure_lt = hi < t * 0.99999905f, sure_ge = hi > t * 1.00000095f;
-    float   res = sure_lt ? (a + b) : hi;
-    int const unsure = (lo > 0) && (!(sure_lt || sure_ge) || lo < 1e-30f || hi > 1e30f);
-    if (lh_ballot(unsure)) {
-        if (unsure) {
-            float const ratio = (b > a) ? b / a : a / b;
-            res = (ratio < c) ? (a + b) : hi;
-        }
-    }
-    return res;
+    return 0.5 * ((double) c + (double) lh_u32_as_f32(lh_f32_as_u32(c) - 1u));
+}
+
+LH_DEVFN float
+lh_mask_add_far(float m1, float m2, double bound)
+{
+    float const hi = __builtin_fmaxf(m1, m2), lo = __builtin_fminf(m1, m2);
+    return ((double) hi < bound * (double) lo) ? m1 + m2 : hi;
 }
 
 /* Partition energies + tonality + spreading, one lane per partition, for the NC (1 or 2) pseudo-channels
@@ -579,6 +577,7 @@ lh_compute_masking(const LhCtx & c, int is_long, const LhMaskChan (&ch)[NC], con
     /* s3 / log_table / table2: the spreading matrix and the tables of the masking addition, either in
      * HBM (LhTables, constants) or staged in LDS by the caller */
     float const ma_max_i1 = c.T->ma_max_i1, ma_max_i2 = c.T->ma_max_i2;
+    double const far_bound = lh_mask_far_bound(ma_max_i2);
     LhPsyBand const *gd = is_long ? &c.T->psy_l : &c.T->psy_s;
     int const b = c.lane;
     int const np = gd->npart;
@@ -684,7 +683,7 @@ lh_compute_masking(const LhCtx & c, int is_long, const LhMaskChan (&ch)[NC], con
 #pragma unroll
             for (int q = 0; q < NC; q++) {
                 float const xn = LH_SPREAD_X(q, kn);
-                float const r = lh_mask_add_far(ecb[q], x[q], ma_max_i2);
+                float const r = lh_mask_add_far(ecb[q], x[q], far_bound);
                 ecb[q] = act ? r : ecb[q];
                 x[q] = xn;
             }
@@ -701,7 +700,7 @@ lh_compute_masking(const LhCtx & c, int is_long, const LhMaskChan (&ch)[NC], con
         for (int q = 0; q < NC; q++) {
             int const near = act && d <= delta[q];
             float const x = LH_SPREAD_X(q, kc);
-            float   r = lh_mask_add_far(ecb[q], x, ma_max_i2);
+            float   r = lh_mask_add_far(ecb[q], x, far_bound);
             if (lh_ballot(near)) {
                 if (near)
                     r = lh_mask_add(log_table, table2, ma_max_i1, ma_max_i2, ecb[q], x, d, delta[q]);
@@ -722,7 +721,7 @@ lh_compute_masking(const LhCtx & c, int is_long, const LhMaskChan (&ch)[NC], con
 #pragma unroll
             for (int q = 0; q < NC; q++) {
                 float const xn = LH_SPREAD_X(q, kn);
-                float const r = lh_mask_add_far(ecb[q], x[q], ma_max_i2);
+                float const r = lh_mask_add_far(ecb[q], x[q], far_bound);
                 ecb[q] = act ? r : ecb[q];
                 x[q] = xn;
             }

@@ -10,6 +10,10 @@ expression literally.  Each is checked here exhaustively over the domain the ker
 3. Second rounding of the quantiser: the reference adds adj43asm[k] (k = the first rounding) in double and
    rounds to float again; the kernel forms k - (x < qthr[k]) for k < 256 (LhTables.qthr, lh_host_init.c).
    Equal for every float whose first rounding is below 256.
+4. mask_add outside the band around the diagonal (reference psymodel.c:323-341) asks whether the float
+   quotient larger / smaller is below ma_max_i2; the kernel asks whether larger < midpoint(c, pred c) x smaller
+   in double (lh_mask_add_far, lh_dev_psy.h).  Checked on pairs within a few ulps of the boundary, over the
+   whole exponent range including denormals, and on random pairs.
 """
 import numpy as np
 
@@ -79,3 +83,32 @@ def test_threshold_comparison_equals_the_second_rounding_for_every_quantisable_f
             mine = k[:n] - (x[:n] < thr[k[:n]]).astype(np.int32)
             bad += int(np.count_nonzero(ref[:n] != mine))
     assert bad == 0 and bad_v == 0
+
+
+def test_far_masking_rule_without_the_quotient():
+    import lamehip
+    enc = lamehip.Encoder(44100, 128, require_device=False)
+    cs = [np.float32(enc.tables().ma_max_i2)]
+    enc.close()
+    rng = np.random.default_rng(11)
+    cs += [np.float32(v) for v in (1.0000001, 1.5, 3.1622777, 31.622776, 1000.0)]
+    cs += list(rng.uniform(1.0, 100.0, 8).astype(np.float32))
+    with np.errstate(over="ignore", divide="ignore", invalid="ignore", under="ignore"):
+        for c in cs:
+            below = (np.array([c], np.float32).view(np.uint32) - np.uint32(1)).view(np.float32)[0]
+            bound = 0.5 * (np.float64(c) + np.float64(below))
+            # smaller: every exponent (denormals included) with random mantissas; larger: c x smaller +- 0..40 ulps
+            expo = np.repeat(np.arange(0, 254, dtype=np.uint32), 4000)
+            lo = ((expo << 23) | rng.integers(0, 1 << 23, expo.size, dtype=np.uint32)).view(np.float32)
+            base = (c * lo).astype(np.float32)
+            ok = np.isfinite(base)
+            lo, base = lo[ok], base[ok]
+            hi = (base.view(np.uint32).astype(np.int64) + rng.integers(-40, 41, base.size)).clip(0, 0x7f7fffff).astype(np.uint32).view(np.float32)
+            lo2 = rng.random(2_000_000, dtype=np.float32) * np.float32(1e6)
+            hi2 = lo2 * (rng.random(2_000_000, dtype=np.float32) * np.float32(2.0) * c)
+            lo = np.concatenate([lo, lo2, np.zeros(4, np.float32)])
+            hi = np.concatenate([hi, hi2, np.array([0, 1, 1e-40, 3e38], np.float32)])
+            hi, lo = np.maximum(hi, lo), np.minimum(hi, lo)
+            ref = np.where(lo > 0, (hi / lo).astype(np.float32) < c, False)
+            mine = hi.astype(np.float64) < bound * lo.astype(np.float64)
+            assert np.array_equal(ref, mine), c
