@@ -74,8 +74,10 @@ LH_DEVFN float
 lh_mask_add(const float *log_table, const float *table2, float ma_max_i1, float ma_max_i2, float m1, float m2,
             int b, int delta)
 {
-    float const a = (m1 < 0) ? 0.0f : m1, c = (m2 < 0) ? 0.0f : m2;
-    float const hi = (c > a) ? c : a, lo = (c > a) ? a : c;
+    /* both maskers are sums and products of non-negative, finite terms (the reference's clamps of negative
+     * inputs have nothing to do), so larger / smaller are plain v_max_f32 / v_min_f32 */
+    float const a = m1, c = m2;
+    float const hi = __builtin_fmaxf(a, c), lo = __builtin_fminf(a, c);
     int const one = !(lo > 0);                  /* m1 <= 0: return m2; m2 <= 0: return m1 */
     float const ratio = hi / (one ? 1.0f : lo); /* m2 > m1 ? m2 / m1 : m1 / m2 */
     float const sum = a + c;
@@ -746,10 +748,10 @@ lh_compute_masking(const LhCtx & c, int is_long, const LhMaskChan (&ch)[NC], con
                 if (bt_old == LH_SHORT_TYPE) {
                     float const ecb_limit = LH_RPELEV * n1v;
                     if (ecb_limit > 0)
-                        t = (e < ecb_limit) ? e : ecb_limit;
+                        t = __builtin_fminf(e, ecb_limit);
                     else {
                         float const alt = (float) (ebb[q] * LH_PREECHO_ATT2);
-                        t = (e < alt) ? e : alt;
+                        t = __builtin_fminf(e, alt);
                     }
                 }
                 else {
@@ -761,10 +763,10 @@ lh_compute_masking(const LhCtx & c, int is_long, const LhMaskChan (&ch)[NC], con
                     if (lim1 <= 0)
                         lim1 = e;
                     if (bt_old == LH_NORM_TYPE)
-                        lim = (lim1 < lim2) ? lim1 : lim2;
+                        lim = __builtin_fminf(lim1, lim2);
                     else
                         lim = lim1;
-                    t = (e < lim) ? e : lim;
+                    t = __builtin_fminf(e, lim);
                 }
                 *ch[q].nb2 = n1v;
                 *ch[q].nb1 = e;
@@ -811,10 +813,10 @@ lh_ms_thresholds(const LhCtx & c, const float *eb, float *thr, const float *cb_m
         if (thmL <= 1.58f * thmR && thmR <= 1.58f * thmL) {
             float const mld_m = cb_mld[b] * ebS;
             float const mld_s = cb_mld[b] * ebM;
-            float const tmp_m = (thmS < mld_m) ? thmS : mld_m;
-            float const tmp_s = (thmM < mld_s) ? thmM : mld_s;
-            rmid = (thmM > tmp_m) ? thmM : tmp_m;
-            rside = (thmS > tmp_s) ? thmS : tmp_s;
+            float const tmp_m = __builtin_fminf(thmS, mld_m);
+            float const tmp_s = __builtin_fminf(thmM, mld_s);
+            rmid = __builtin_fmaxf(thmM, tmp_m);
+            rside = __builtin_fmaxf(thmS, tmp_s);
         }
         else {
             rmid = thmM;
@@ -823,19 +825,19 @@ lh_ms_thresholds(const LhCtx & c, const float *eb, float *thr, const float *cb_m
         if (msfix > 0.f) {
             float   thmLR, thmMS;
             float const ath = ath_cb[b] * athlower;
-            float const tmp_l = (thmL > ath) ? thmL : ath;
-            float const tmp_r = (thmR > ath) ? thmR : ath;
-            thmLR = (tmp_l < tmp_r) ? tmp_l : tmp_r;
-            thmM = (rmid > ath) ? rmid : ath;
-            thmS = (rside > ath) ? rside : ath;
+            float const tmp_l = __builtin_fmaxf(thmL, ath);
+            float const tmp_r = __builtin_fmaxf(thmR, ath);
+            thmLR = __builtin_fminf(tmp_l, tmp_r);
+            thmM = __builtin_fmaxf(rmid, ath);
+            thmS = __builtin_fmaxf(rside, ath);
             thmMS = thmM + thmS;
             if (thmMS > 0.f && (thmLR * msfix2) < thmMS) {
                 float const f = thmLR * msfix2 / thmMS;
                 thmM *= f;
                 thmS *= f;
             }
-            rmid = (thmM < rmid) ? thmM : rmid;
-            rside = (thmS < rside) ? thmS : rside;
+            rmid = __builtin_fminf(thmM, rmid);
+            rside = __builtin_fminf(thmS, rside);
         }
         if (rmid > ebM)
             rmid = ebM;

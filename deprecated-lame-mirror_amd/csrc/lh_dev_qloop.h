@@ -637,8 +637,7 @@ lq_scale_mask(LhQS & S, uint64_t bands, float factor)
         float const v1 = on ? S.xp[2 * k + 1] * factor : S.xp[2 * k + 1];
         S.xp[2 * k] = v0;
         S.xp[2 * k + 1] = v1;
-        S.lmax = v0 > S.lmax ? v0 : S.lmax;
-        S.lmax = v1 > S.lmax ? v1 : S.lmax;
+        S.lmax = __builtin_fmaxf(__builtin_fmaxf(v0, v1), S.lmax);      /* (no NaNs here: one v_max3_f32) */
     }
 }
 
@@ -660,8 +659,7 @@ lq_scale_bands(const LhCtx & c, LhQS & S, LhChanLds & Q, int flag, float fac)
             float const v1 = on ? S.xp[2 * k + 1] * f : S.xp[2 * k + 1];
             S.xp[2 * k] = v0;
             S.xp[2 * k + 1] = v1;
-            S.lmax = v0 > S.lmax ? v0 : S.lmax;
-            S.lmax = v1 > S.lmax ? v1 : S.lmax;
+            S.lmax = __builtin_fmaxf(__builtin_fmaxf(v0, v1), S.lmax);
         }
     }
     LH_WAVE_SYNC();
