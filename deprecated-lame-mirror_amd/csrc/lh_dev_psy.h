@@ -48,11 +48,6 @@ lh_mask_add_delta_at(int i)
     return (i < 3) ? 2 : (i < 6) ? 1 : (i < 8) ? 0 : -1;
 }
 
-LH_DEVCONST float lh_mask_table2[10] = {
-    (float) (1.33352 * 1.33352), (float) (1.35879 * 1.35879), (float) (1.38454 * 1.38454),
-    (float) (1.39497 * 1.39497), (float) (1.40548 * 1.40548), (float) (1.3537 * 1.3537),
-    (float) (1.30382 * 1.30382), (float) (1.22321 * 1.22321), (float) (1.14758 * 1.14758), 1.0f
-};
 LH_DEVCONST float lh_hp_fir[10] = {
     (float) (-8.65163e-18 * 2), (float) (-0.00851586 * 2), (float) (-6.74764e-18 * 2),
     (float) (0.0209036 * 2), (float) (-3.36639e-17 * 2), (float) (-0.0438162 * 2),
@@ -67,27 +62,30 @@ LH_DEVCONST float lh_regcoef_l[21] = {
     46.8f, 56.5f, 60.7f, 73.9f, 85.7f, 93.4f, 126.1f
 };
 
-/* reference psymodel.c:294-341, as straight-line selects: the walk of lh_compute_masking calls it for
- * all lanes at once, and a lane that takes another of the reference's exits would make the whole
- * wave run every branch anyway */
+/* lh_mask_add() near the diagonal (|kk - b| <= delta; reference psymodel.c:294-341 up to the end of the
+ * `b <= delta' block): (larger + smaller) x table2[i], i the cell of the ratio larger / smaller, or the plain
+ * sum from ma_max_i1 on.  Neither the quotient nor its logarithm is formed: cell i applies exactly when
+ * larger lies above i of the nine exact products mid[j] x smaller (LhTables.mask_mid; the ninth is the
+ * boundary of ma_max_i1 and stands for a factor of 1).  A masker of 0 -- the reference's early exits --
+ * puts the other above all nine: the sum, which is the other masker.  Both maskers are sums and products
+ * of non-negative, finite terms, so the reference's clamps of negative inputs have nothing to do. */
+#define LH_T2(a_) ((float) ((a_) * (a_)))
 LH_DEVFN float
-lh_mask_add(const float *log_table, const float *table2, float ma_max_i1, float ma_max_i2, float m1, float m2,
-            int b, int delta)
+lh_mask_add_near(const double (&mid)[10], float m1, float m2)
 {
-    /* both maskers are sums and products of non-negative, finite terms (the reference's clamps of negative
-     * inputs have nothing to do), so larger / smaller are plain v_max_f32 / v_min_f32 */
-    float const a = m1, c = m2;
-    float const hi = __builtin_fmaxf(a, c), lo = __builtin_fminf(a, c);
-    int const one = !(lo > 0);                  /* m1 <= 0: return m2; m2 <= 0: return m1 */
-    float const ratio = hi / (one ? 1.0f : lo); /* m2 > m1 ? m2 / m1 : m1 / m2 */
-    float const sum = a + c;
-    int const near = ((b < 0) ? -b : b) <= delta;
-    /* the table index is only formed where the reference forms it; elsewhere a harmless ratio */
-    int const tab = near && !one && ratio < ma_max_i1;
-    int const i = (int) (lh_fast_log2(log_table, tab ? ratio : 1.0f) * (LH_LOG2_OVER_LOG10 * (16.0f)));
-    float const scaled = sum * table2[i];
-    float   res = near ? (tab ? scaled : sum) : ((ratio < ma_max_i2) ? sum : hi);
-    return one ? hi : res;
+    float const hi = __builtin_fmaxf(m1, m2), lo = __builtin_fminf(m1, m2);
+    double const h = (double) hi, l = (double) lo;
+    float   f = LH_T2(1.33352);
+    f = (h > mid[0] * l) ? LH_T2(1.35879) : f;
+    f = (h > mid[1] * l) ? LH_T2(1.38454) : f;
+    f = (h > mid[2] * l) ? LH_T2(1.39497) : f;
+    f = (h > mid[3] * l) ? LH_T2(1.40548) : f;
+    f = (h > mid[4] * l) ? LH_T2(1.3537) : f;
+    f = (h > mid[5] * l) ? LH_T2(1.30382) : f;
+    f = (h > mid[6] * l) ? LH_T2(1.22321) : f;
+    f = (h > mid[7] * l) ? LH_T2(1.14758) : f;
+    f = (h > mid[8] * l) ? 1.0f : f;
+    return (m1 + m2) * f;
 }
 
 /* reference psymodel.c:443-454 */
@@ -545,13 +543,7 @@ lh_mask_index(LhPsyBand const *gd, int b, float m0, float m1, float m2, float a0
  * and that product, 25 x 24 bits, is exact in double.  lo = 0 (the reference's early exits) falls out as
  * "the larger alone".  Both maskers are sums and products of non-negative terms here, so the reference's
  * clamps of negative inputs have nothing to do.  No division, no table and no branch on the chain, which
- * is what the wave waits for. */
-LH_DEVFN double
-lh_mask_far_bound(float c)
-{
-    return 0.5 * ((double) c + (double) lh_u32_as_f32(lh_f32_as_u32(c) - 1u));
-}
-
+ * is what the wave waits for.  (bound = LhTables.mask_mid[9].) */
 LH_DEVFN float
 lh_mask_add_far(float m1, float m2, double bound)
 {
@@ -573,13 +565,14 @@ struct LhMaskChan {
 };
 
 template < int NC > LH_DEVFN void
-lh_compute_masking(const LhCtx & c, int is_long, const LhMaskChan (&ch)[NC], const float *s3, const float *log_table,
-                   const float *table2)
+lh_compute_masking(const LhCtx & c, int is_long, const LhMaskChan (&ch)[NC], const float *s3)
 {
-    /* s3 / log_table / table2: the spreading matrix and the tables of the masking addition, either in
-     * HBM (LhTables, constants) or staged in LDS by the caller */
-    float const ma_max_i1 = c.T->ma_max_i1, ma_max_i2 = c.T->ma_max_i2;
-    double const far_bound = lh_mask_far_bound(ma_max_i2);
+    /* s3: the spreading matrix, either in HBM (LhTables) or staged in LDS by the caller */
+    double  mid[10];            /* wave-uniform: scalar register pairs */
+#pragma unroll
+    for (int j = 0; j < 10; j++)
+        mid[j] = lh_uni_f64(c.T->mask_mid[j]);
+    double const far_bound = mid[9];
     LhPsyBand const *gd = is_long ? &c.T->psy_l : &c.T->psy_s;
     int const b = c.lane;
     int const np = gd->npart;
@@ -704,8 +697,8 @@ lh_compute_masking(const LhCtx & c, int is_long, const LhMaskChan (&ch)[NC], con
             float const x = LH_SPREAD_X(q, kc);
             float   r = lh_mask_add_far(ecb[q], x, far_bound);
             if (lh_ballot(near)) {
-                if (near)
-                    r = lh_mask_add(log_table, table2, ma_max_i1, ma_max_i2, ecb[q], x, d, delta[q]);
+                float const rn = lh_mask_add_near(mid, ecb[q], x);
+                r = near ? rn : r;
             }
             ecb[q] = act ? r : ecb[q];
         }
@@ -1078,18 +1071,9 @@ lh_psy_granule(int gr, LhPsyCarry nb)
      * the tables of the masking addition there (the spreading loop of stage 6 makes three to
      * four dependent look-ups per step; from HBM each costs a few hundred cycles). */
     float  *stg_s3 = &P.wsamp[0][0];                    /* [LH_S3_MAX] */
-    float  *stg_log = stg_s3 + LH_S3_MAX;               /* [513] */
-    float  *stg_psy = stg_log + 516;                    /* [9] */
-    float  *stg_t2 = stg_psy + 12;                      /* [10] */
     LH_SYNC_WG_LDS();
     for (int i = c.tid; i < T->psy_l.s3_count; i += LH_NT)
         stg_s3[i] = T->psy_l.s3[i];
-    for (int i = c.tid; i < 513; i += LH_NT)
-        stg_log[i] = T->log_table[i];
-    if (c.tid < 9)
-        stg_psy[c.tid] = lh_psy_tab[c.tid];
-    if (c.tid < 10)
-        stg_t2[c.tid] = lh_mask_table2[c.tid];
     LH_SYNC_WG_LDS();
     LH_PA(31, t_psy0);
     LQ_MARK("ps_sums");
@@ -1156,11 +1140,11 @@ lh_psy_granule(int gr, LhPsyCarry nb)
             {w, P.b.energy[w], &P.eb[w * 64], &P.thr[w * 64], &nb.n1[0], &nb.n2[0]},
             {w + 2, P.b.energy[w + 2], &P.eb[(w + 2) * 64], &P.thr[(w + 2) * 64], &nb.n1[1], &nb.n2[1]}
         };
-        lh_compute_masking < 2 > (c, 1, two, stg_s3, stg_log, stg_t2);
+        lh_compute_masking < 2 > (c, 1, two, stg_s3);
     }
     else if (w < n_chn_psy) {
         LhMaskChan const one[1] = { {w, P.b.energy[w], &P.eb[w * 64], &P.thr[w * 64], &nb.n1[0], &nb.n2[0]} };
-        lh_compute_masking < 1 > (c, 1, one, stg_s3, stg_log, stg_t2);
+        lh_compute_masking < 1 > (c, 1, one, stg_s3);
     }
     LH_SYNC_WG_LDS();
     if (cfg->mode == LH_MODE_JOINT_STEREO && (L.uselongblock[0] + L.uselongblock[1]) == 2) {
@@ -1214,11 +1198,11 @@ lh_psy_granule(int gr, LhPsyCarry nb)
                     {w, P.b.energy[w], &P.eb[w * 64], &P.thr[w * 64], &nb.n1[0], &nb.n2[0]},
                     {w + 2, P.b.energy[w + 2], &P.eb[(w + 2) * 64], &P.thr[(w + 2) * 64], &nb.n1[1], &nb.n2[1]}
                 };
-                lh_compute_masking < 2 > (c, 0, two, T->psy_s.s3, T->log_table, lh_mask_table2);    /* short: nb left alone */
+                lh_compute_masking < 2 > (c, 0, two, T->psy_s.s3);    /* short: nb left alone */
             }
             else {
                 LhMaskChan const one[1] = { {w, P.b.energy[w], &P.eb[w * 64], &P.thr[w * 64], &nb.n1[0], &nb.n2[0]} };
-                lh_compute_masking < 1 > (c, 0, one, T->psy_s.s3, T->log_table, lh_mask_table2);
+                lh_compute_masking < 1 > (c, 0, one, T->psy_s.s3);
             }
         }
         LH_SYNC_WG_LDS();

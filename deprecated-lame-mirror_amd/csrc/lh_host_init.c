@@ -1029,6 +1029,65 @@ build_vbr_quant_thresholds(LhTables * t)
     return 1;
 }
 
+/* cell of the masking-addition table for a ratio of two maskers: the reference's table-driven log2
+ * (util.c:976-1001) scaled to sixteenths of a decade and truncated (psymodel.c:327-333) */
+static int
+mask_table_cell(const LhTables * t, float ratio)
+{
+    union { float f; uint32_t u; } r;
+    int     mantissa, slot;
+    float   whole, along, lg;
+    r.f = ratio;
+    mantissa = (int) (r.u & 0x7fffffu);
+    whole = (float) ((int) ((r.u >> 23) & 0xffu) - 127);
+    along = (float) (mantissa & 16383);
+    along *= 1.0f / 16384;
+    slot = mantissa >> 14;
+    lg = whole;
+    lg += t->log_table[slot] * (1.0f - along) + t->log_table[slot + 1] * along;
+    return (int) (lg * (0.69314718055994530942 / 2.30258509299404568402 * 16.0f));
+}
+
+/* midpoint of a float and its predecessor: quotients above it round to the float or beyond */
+static double
+rounding_boundary(float v)
+{
+    union { float f; uint32_t u; } below;
+    below.f = v;
+    below.u -= 1u;
+    return 0.5 * ((double) v + (double) below.f);
+}
+
+/* LhTables.mask_mid (needs log_table, ma_max_i1 / _i2).  Returns 0 when the cells do not step up one
+ * at a time between ratio 1 (cell 0) and ma_max_i1 (cell 8 just below it). */
+static int
+build_mask_boundaries(LhTables * t)
+{
+    int     j;
+    union { float f; uint32_t u; } below, reach, mid, top;
+    top.f = t->ma_max_i1;
+    top.u -= 1u;
+    if (mask_table_cell(t, 1.0f) != 0 || mask_table_cell(t, top.f) != 8)
+        return 0;
+    for (j = 1; j <= 8; j++) {
+        below.f = 1.0f;
+        reach = top;
+        while (reach.u - below.u > 1u) {
+            mid.u = below.u + (reach.u - below.u) / 2u;
+            if (mask_table_cell(t, mid.f) >= j)
+                reach = mid;
+            else
+                below = mid;
+        }
+        if (mask_table_cell(t, reach.f) != j || mask_table_cell(t, below.f) != j - 1)
+            return 0;
+        t->mask_mid[j - 1] = rounding_boundary(reach.f);
+    }
+    t->mask_mid[8] = rounding_boundary(t->ma_max_i1);
+    t->mask_mid[9] = rounding_boundary(t->ma_max_i2);
+    return 1;
+}
+
 /* largest count <= guess with edge[base + count] <= limit; the guess itself when there is none */
 static int
 lower_until_inside(const int *edge, int base, int guess, int limit)
@@ -1548,6 +1607,8 @@ lh_tables_build(LhConfig * c, const LhInitAux * aux, LhTables * t)
     /* reference util.c:960-972 */
     for (i = 0; i < 513; i++)
         t->log_table[i] = log(1.0f + i / (float) 512) / log(2.0f);
+    if (!build_mask_boundaries(t))
+        return -1;
     {
         /* band of every line (derived; long: largest sfb with sfb_l[sfb] <= i, short: window-major) */
         int     i, k;

@@ -274,6 +274,7 @@ static inline int lh_uni_i(int v) { return v; }
 static inline uint32_t lh_vec_u32(uint32_t v) { return v; }
 static inline float lh_uni_f(float v) { return v; }
 static inline long long lh_uni_ll(long long v) { return v; }
+static inline double lh_uni_f64(double v) { return v; }
 static inline int lh_ffs64(uint64_t m) { return m ? __builtin_ctzll(m) : -1; }
 static inline int lh_popc64(uint64_t m) { return __builtin_popcountll(m); }
 static inline int lh_clz64(uint64_t m) { return m ? __builtin_clzll(m) : 64; }
@@ -586,6 +587,7 @@ __device__ __forceinline__ long long lh_uni_ll(long long v)
     unsigned const hi = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) ((unsigned long long) v >> 32));
     return (long long) (((unsigned long long) hi << 32) | lo);
 }
+__device__ __forceinline__ double lh_uni_f64(double v) { return __longlong_as_double(lh_uni_ll(__double_as_longlong(v))); }
 __device__ __forceinline__ int lh_ffs64(uint64_t m) { return m ? (__ffsll((long long) m) - 1) : -1; }
 __device__ __forceinline__ int lh_popc64(uint64_t m) { return __popcll(m); }
 __device__ __forceinline__ int lh_clz64(uint64_t m) { return __clzll((long long) m); }

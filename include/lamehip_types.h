@@ -206,6 +206,15 @@ typedef struct LhTables {
      * these k all negative, takes only the values k - 1 and k on the floats that round to k; qthr[k] is the
      * first float that gives k, found by lh_tables_init with that very expression. */
     float   qthr[256];
+    /* The masking addition (reference psymodel.c:294-341) without its quotient.  The reference forms
+     * ratio = larger / smaller in float and asks (a) near the diagonal: which of table2's cells
+     * i = (int) (fast_log2(ratio) * 16 log10(2)) applies, unless ratio >= ma_max_i1, (b) elsewhere: whether
+     * ratio < ma_max_i2.  The index never decreases with the ratio and steps at eight floats r_1 .. r_8
+     * (tests/test_quantizer_identity.py walks every float below ma_max_i1), and a correctly rounded quotient
+     * is >= a float r exactly when larger > midpoint(pred r, r) x smaller -- a product that is exact in
+     * double.  mask_mid[0..7] are those midpoints for r_1 .. r_8, [8] for ma_max_i1, [9] for ma_max_i2;
+     * lh_tables_init finds r_j by bisection with the reference's expression. */
+    double  mask_mid[10];
 } LhTables;
 
 /* ------------------------------------------------------------------ */

@@ -14,6 +14,11 @@ expression literally.  Each is checked here exhaustively over the domain the ker
    quotient larger / smaller is below ma_max_i2; the kernel asks whether larger < midpoint(c, pred c) x smaller
    in double (lh_mask_add_far, lh_dev_psy.h).  Checked on pairs within a few ulps of the boundary, over the
    whole exponent range including denormals, and on random pairs.
+5. mask_add near the diagonal (psymodel.c:323-333) multiplies the sum by table2[i], i = (int) (fast_log2(ratio)
+   * 16 log10 2), or by 1 from ma_max_i1 on; the kernel counts how many of nine exact products
+   LhTables.mask_mid[j] x smaller lie below larger (lh_mask_add_near).  The cell is walked over every float
+   ratio below ma_max_i1 (it never decreases and steps at the eight floats the host found), then the whole
+   rule is compared on boundary and random pairs.
 """
 import numpy as np
 
@@ -89,6 +94,7 @@ def test_far_masking_rule_without_the_quotient():
     import lamehip
     enc = lamehip.Encoder(44100, 128, require_device=False)
     cs = [np.float32(enc.tables().ma_max_i2)]
+    mid_i2 = float(enc.tables().mask_mid[9])
     enc.close()
     rng = np.random.default_rng(11)
     cs += [np.float32(v) for v in (1.0000001, 1.5, 3.1622777, 31.622776, 1000.0)]
@@ -97,6 +103,8 @@ def test_far_masking_rule_without_the_quotient():
         for c in cs:
             below = (np.array([c], np.float32).view(np.uint32) - np.uint32(1)).view(np.float32)[0]
             bound = 0.5 * (np.float64(c) + np.float64(below))
+            if c == cs[0]:
+                assert bound == mid_i2      # what the kernel reads (LhTables.mask_mid[9])
             # smaller: every exponent (denormals included) with random mantissas; larger: c x smaller +- 0..40 ulps
             expo = np.repeat(np.arange(0, 254, dtype=np.uint32), 4000)
             lo = ((expo << 23) | rng.integers(0, 1 << 23, expo.size, dtype=np.uint32)).view(np.float32)
@@ -112,3 +120,67 @@ def test_far_masking_rule_without_the_quotient():
             ref = np.where(lo > 0, (hi / lo).astype(np.float32) < c, False)
             mine = hi.astype(np.float64) < bound * lo.astype(np.float64)
             assert np.array_equal(ref, mine), c
+
+
+def _mask_cell(log_table, ratio):
+    """the reference's table cell for float ratios >= 1 (util.c:976-1001, psymodel.c:331)"""
+    bits = ratio.view(np.uint32)
+    mant = (bits & np.uint32(0x7fffff)).astype(np.int32)
+    whole = (((bits >> np.uint32(23)) & np.uint32(0xff)).astype(np.int32) - 0x7f).astype(np.float32)
+    along = (mant & 16383).astype(np.float32) * np.float32(1.0 / 16384)
+    slot = mant >> 14
+    lg = whole + (log_table[slot] * (np.float32(1.0) - along) + log_table[slot + 1] * along)
+    return (lg.astype(np.float64) * (np.float64(0.69314718055994530942 / 2.30258509299404568402) * np.float64(16.0))).astype(np.int32)
+
+
+def test_near_masking_rule_without_quotient_or_logarithm():
+    import lamehip
+    enc = lamehip.Encoder(44100, 128, require_device=False)
+    T = enc.tables()
+    log_table = np.ctypeslib.as_array(T.log_table).astype(np.float32)
+    mid = np.ctypeslib.as_array(T.mask_mid).astype(np.float64)
+    c1 = np.float32(T.ma_max_i1)
+    enc.close()
+    table2 = np.array([1.33352 ** 2, 1.35879 ** 2, 1.38454 ** 2, 1.39497 ** 2, 1.40548 ** 2, 1.3537 ** 2, 1.30382 ** 2,
+                       1.22321 ** 2, 1.14758 ** 2, 1.0]).astype(np.float32)       # psymodel.c:297-302
+
+    def boundary(v):
+        below = (np.array([v], np.float32).view(np.uint32) - np.uint32(1)).view(np.float32)[0]
+        return 0.5 * (np.float64(v) + np.float64(below))
+
+    # every float ratio in [1, ma_max_i1): cells 0..8, never decreasing, stepping where the host says
+    lo_b, hi_b = int(np.float32(1.0).view(np.uint32)), int(c1.view(np.uint32))
+    ratio = np.arange(lo_b, hi_b, dtype=np.uint32).view(np.float32)
+    cell = _mask_cell(log_table, ratio)
+    assert cell[0] == 0 and cell[-1] == 8 and np.all(np.diff(cell) >= 0)
+    steps = ratio[1:][np.diff(cell) != 0]
+    assert len(steps) == 8
+    assert np.array_equal(np.array([boundary(r) for r in steps]), mid[:8])
+    assert mid[8] == boundary(c1)
+    # the whole rule on pairs around every boundary and on random pairs
+    rng = np.random.default_rng(12)
+    with np.errstate(over="ignore", divide="ignore", invalid="ignore", under="ignore"):
+        los, his = [], []
+        for r in list(steps) + [c1]:
+            expo = np.repeat(np.arange(0, 250, dtype=np.uint32), 800)
+            lo = ((expo << 23) | rng.integers(0, 1 << 23, expo.size, dtype=np.uint32)).view(np.float32)
+            base = (np.float32(r) * lo).astype(np.float32)
+            ok = np.isfinite(base)
+            lo, base = lo[ok], base[ok]
+            hi = (base.view(np.uint32).astype(np.int64) + rng.integers(-40, 41, base.size)).clip(0, 0x7f7fffff).astype(np.uint32).view(np.float32)
+            los.append(lo)
+            his.append(hi)
+        lo2 = rng.random(3_000_000, dtype=np.float32) * np.float32(1e6)
+        los += [lo2, np.zeros(4, np.float32)]
+        his += [lo2 * (rng.random(3_000_000, dtype=np.float32) * np.float32(5.0)), np.array([0, 1, 1e-40, 3e38], np.float32)]
+        a, b = np.concatenate(his), np.concatenate(los)
+        hi, lo = np.maximum(a, b), np.minimum(a, b)
+        total = a + b
+        q = (hi / np.where(lo > 0, lo, np.float32(1.0))).astype(np.float32)
+        safe = np.where((lo > 0) & (q < c1), q, np.float32(1.0))
+        ref = np.where(lo > 0, np.where(q >= c1, total, total * table2[_mask_cell(log_table, safe)]), hi)
+        count = np.zeros(hi.size, np.int64)
+        for j in range(9):
+            count += hi.astype(np.float64) > mid[j] * lo.astype(np.float64)
+        mine = total * table2[count]
+        assert np.array_equal(ref.view(np.uint32), mine.view(np.uint32))
