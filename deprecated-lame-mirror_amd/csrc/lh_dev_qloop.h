@@ -215,7 +215,7 @@ lq_count_bits(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
         int const d = g.global_gain - 210, ga = d >> 4, gb_ = d & 15;
         float const thr = lq_ldexp(lh_u32_as_f32(lh_bcast_u32(lh_f32_as_u32(S.thrv), gb_)), 3 * ga);
         istep = lq_ldexp(lh_u32_as_f32(lh_bcast_u32(lh_f32_as_u32(S.istepv), gb_)), -3 * ga);
-        if (lh_ballot(S.lmax > thr))
+        if (LH_RARE(lh_ballot(S.lmax > thr)))
             return LH_LARGE_BITS;
     }
     /* ---- which bands are quantised, and how (lane = band) ---- */
@@ -260,7 +260,7 @@ lq_count_bits(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
             bmax = b1 > bmax ? b1 : bmax;
             nq[k] = ((r0 & 0xffffu) | (r1 << 16)) & S.vm[k];
         }
-        if (lh_ballot(bmax > (uint32_t) LH_MAGIC_INT + 255u)) {
+        if (LH_RARE(lh_ballot(bmax > (uint32_t) LH_MAGIC_INT + 255u))) {
             /* rare: a quantised value >= 256, its rounding offset lives in HBM */
 #pragma unroll
             for (int k = 0; k < NS; k++) {
@@ -289,7 +289,7 @@ lq_count_bits(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
             }
         }
     }
-    if (R.substep_shaping & 2) {
+    if (LH_RARE(R.substep_shaping & 2)) {
         int const gain = g.global_gain + g.scalefac_scale;
         float const roundfac = (float) (0.634521682242439 / T->ipow20[gain]);
         uint64_t const phm = lh_ballot(lane < R.sfbmax && S.ph);
@@ -537,7 +537,7 @@ lq_calc_noise(const LhCtx & c, LhQS & S, LhQR & R, const LhGrR & g, LhChanLds & 
             big |= (int) ((q0 | q1) >> 8);
         }
         maxw = (int) lh_wave_max_u32(fresh ? (unsigned) (2 * l) : 0u);
-        if (lh_ballot(big != 0)) {
+        if (LH_RARE(lh_ballot(big != 0))) {
 #pragma unroll
             for (int k = 0; k < NS; k++) {
                 unsigned const q0 = S.pw[k] & 0xffffu, q1 = S.pw[k] >> 16;

@@ -271,7 +271,7 @@ lh_vbr_noisy_n(const LhCtx & c, LhChanLds & Q, const LhVbrGeo & G, const float *
             maxng = G.ng > maxng ? G.ng : maxng;
         }
     }
-    if (lh_ballot(ambiguous)) {
+    if (LH_RARE(lh_ballot(ambiguous))) {
         /* exact: lane = band, float accumulator += double group sum, in order */
         float   acc[3] = { 0.0f, 0.0f, 0.0f };
         LH_PC(14);

@@ -15,6 +15,12 @@
 
 #include <stdint.h>
 
+/* a wave-uniform condition that is rarely true: the block behind it moves out of line, so that the common
+ * path falls through its branch (a taken scalar branch costs ~28 cycles, one that falls through ~14:
+ * tools/ubench/branch_cost.hip) */
+#define LH_RARE(x) __builtin_expect(!!(x), 0)
+#define LH_OFTEN(x) __builtin_expect(!!(x), 1)
+
 #ifdef LH_EMU
 /* ------------------------------------------------------------------ */
 #include "hipemu.h"

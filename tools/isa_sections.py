@@ -17,7 +17,7 @@ OUT = "/tmp/isa_marks"
 def main():
     fn = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "lq_outer_loop_stage4"
     os.makedirs(OUT, exist_ok=True)
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-fno-slp-vectorize", "-std=c++17", "-fno-fast-math", "-ffp-contract=off",
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-fno-slp-vectorize", "-falign-functions=256", "-std=c++17", "-fno-fast-math", "-ffp-contract=off",
            "-fPIC", "-I.", "-I../../include", "-DLH_MARK", "-c", "lh_kernels.hip", "-o", OUT + "/k.o", "-save-temps=obj",
            "-Rpass-analysis=kernel-resource-usage"]
     r = subprocess.run(cmd, cwd=CSRC, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
