@@ -31,7 +31,7 @@
 /* stage-level functions are NOT inlined: one giant kernel body made the register
  * allocator spill thousands of dwords; per-stage allocation keeps the kernel at
  * two waves per SIMD */
-#define LH_STAGEFN __device__ __attribute__((noinline))
+#define LH_STAGEFN static __device__ __attribute__((noinline))
 #define LH_DEVCONST __device__ static const
 #endif
 #endif

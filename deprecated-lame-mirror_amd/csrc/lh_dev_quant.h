@@ -1228,17 +1228,21 @@ lh_bhd_build(const LhCtx & c, LhChanLds & Q, int bigv, int *tab, int *bmx)
     LH_WAVE_SYNC();
 }
 
-/* choose_table for the bands [blo, bhi), whose largest value is mx, from the prefix tables; qw != 0:
- * the pair whose words are qw is taken out again */
+/* choose_table for the bands [blo, bhi), whose largest value is mx, from the prefix tables; the pair whose
+ * words are qw is taken out again */
+LH_DEVCONST unsigned lh_bhd_none[LH_BHD_NW] = { 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u };
+
 LH_DEVFN int
-lh_bhd_region(const int *tab, unsigned mx, int blo, int bhi, const unsigned *qw, int *bits)
+lh_bhd_region(const int *tab, unsigned mx, int blo, int bhi, const unsigned (&qw)[LH_BHD_NW], int *bits)
 {
     unsigned w0, w1, d[LH_BHD_NW];
     if (mx == 0)
         return 0;
+    /* (qw is all zero when no pair is taken out: an array by reference stays in registers, a pointer that may
+     * be null put it in scratch memory) */
 #pragma unroll
     for (int j = 0; j < LH_BHD_NW - 1; j++)
-        d[j] = (unsigned) (tab[j * LH_BHD_STRIDE + bhi] - tab[j * LH_BHD_STRIDE + blo]) - (qw ? qw[j] : 0u);
+        d[j] = (unsigned) (tab[j * LH_BHD_STRIDE + bhi] - tab[j * LH_BHD_STRIDE + blo]) - qw[j];
     if (mx > 15u) {
         w0 = d[7];
         w1 = d[8];
@@ -1345,7 +1349,7 @@ lh_best_huffman_divide_body(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGr
                 int const r0 = lane;
                 int     b = 0, t = 0;
                 if (r0 < nr0)
-                    t = lh_bhd_region(tab, mx0, 0, r0 + 1, 0, &b);
+                    t = lh_bhd_region(tab, mx0, 0, r0 + 1, lh_bhd_none, &b);
                 r0bits_a[r0] = b;
                 r0t_a[r0] = t;
             }
@@ -1364,7 +1368,7 @@ lh_best_huffman_divide_body(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGr
                     mx = m > mx ? m : mx;
                 }
                 b = r0bits_a[r0];
-                t = lh_bhd_region(tab, mx, r0 + 1, hi, 0, &b);
+                t = lh_bhd_region(tab, mx, r0 + 1, hi, lh_bhd_none, &b);
             }
             comb_bits[cmb] = b;
             comb_tbl[cmb] = t;
@@ -1483,7 +1487,7 @@ lh_best_huffman_divide_body(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGr
              * to the count1 region; it is taken out of the band sums (its values are 0/1, so its
              * band's maximum can only drop from 1 to 0, and only when it was the band's last
              * non-zero pair) */
-            unsigned qw[LH_BHD_NW];
+            unsigned qw[LH_BHD_NW] = { 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u };     /* first pass: nothing is taken out */
             int const minus_q = (pass == 1 && bigv == bigv0 - 2);
             unsigned mfrom = max_from;
             int     r2b = 0, r2t = 0, lower, live;
@@ -1508,7 +1512,7 @@ lh_best_huffman_divide_body(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGr
             if (live) {
                 r2b = lower + c1bits;
                 if (lower < LH_LARGE_BITS)
-                    r2t = lh_bhd_region(tab, mfrom, lane, LH_SBMAX_L, pass == 1 ? qw : 0, &r2b);
+                    r2t = lh_bhd_region(tab, mfrom, lane, LH_SBMAX_L, qw, &r2b);
             }
             lower += c1bits;
             {

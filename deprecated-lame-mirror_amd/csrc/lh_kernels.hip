@@ -165,7 +165,7 @@ lh_store_granule(const LhCtx & c, const LhChanLds & Q, const LhQR & R, const LhG
 #include "lh_dev_vbr.h"
 
 /* one frame of one stream; executed by the whole workgroup */
-LH_DEVFN void
+LH_STAGEFN void
 lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
 {
     LhLds & L = lh_lds;
@@ -523,12 +523,14 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
 #endif
 }
 
-#ifndef LH_EMU
-extern "C" __global__ void __launch_bounds__(LH_NT, 2)
-#else
-void
+#ifndef LH_WAVES_PER_EU
+#define LH_WAVES_PER_EU 2
 #endif
-lh_encode_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, const float *pcmf,
+/* all frames of one stream (the workgroup's whole job).  Out of line: a kernel body places what it keeps across
+ * calls in registers ABOVE its callees' budget, which is what decides the occupancy; a function keeps
+ * such values in the callee-saved registers inside the budget. */
+LH_STAGEFN void
+lh_encode_stream(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, const float *pcmf,
                  const LhStreamDesc * descs, LhStreamState * states, LhFrameOut * out, uint8_t * bytes,
                  int nstreams)
 {
@@ -624,6 +626,18 @@ lh_encode_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, 
         st->en[chn][i] = L.psy_en[slot][chn][i];
         st->thm[chn][i] = L.psy_thm[slot][chn][i];
     }
+}
+
+#ifndef LH_EMU
+extern "C" __global__ void __launch_bounds__(LH_NT, LH_WAVES_PER_EU)
+#else
+void
+#endif
+lh_encode_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, const float *pcmf,
+                 const LhStreamDesc * descs, LhStreamState * states, LhFrameOut * out, uint8_t * bytes,
+                 int nstreams)
+{
+    lh_encode_stream(cfg, T, pcm, pcmf, descs, states, out, bytes, nstreams);
 }
 
 #ifndef LH_EMU
