@@ -26,6 +26,11 @@ extern "C" int lh_launch_encode(const LhConfig * cfg, const LhTables * T, const 
                                 const LhStreamDesc * descs, LhStreamState * states,
                                 LhFrameOut * out, uint8_t * bytes, int nstreams, void *stream);
 
+/* the same kernel with sibling waves (lh_kernels.hip compiled with -DLH_HELPERS: four waves per stream; CBR / ABR) */
+extern "C" int lh_launch_encode4(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, const float *pcmf,
+                                 const LhStreamDesc * descs, LhStreamState * states,
+                                 LhFrameOut * out, uint8_t * bytes, int nstreams, void *stream);
+
 extern "C" int lh_launch_selftest(unsigned *d_out, unsigned seed, void *stream);
 extern "C" int lh_launch_scatter(const int16_t * stage, long stage_stride, int16_t * pool, long cap, const int *meta,
                                  int nstreams, void *stream);
@@ -62,7 +67,24 @@ lamehip_device_count(void)
 struct LhDeviceConst {
     LhConfig *d_cfg = nullptr;
     LhTables *d_tab = nullptr;
+    int     waves = 2;          /* which kernel encodes with these constants: 2 or 4 waves per stream */
+    /* The default is the kernel with two waves per stream.  LAMEHIP_KERNEL_WAVES=4 (read when the constants are
+     * uploaded) selects the one whose CBR / ABR search runs with a sibling wave per channel (four waves per
+     * stream, <= 128 VGPRs): bit-identical, and on MI355X 11 % slower -- a SIMD does not issue for four busy waves
+     * what it issues for two -- so it stays an option for measurements.  The VBR loop has
+     * no such split. */
+    static int pick_waves(const LhConfig & cfg) {
+        const char *e = getenv("LAMEHIP_KERNEL_WAVES");
+        int const vbr_new = (cfg.vbr == 1 || cfg.vbr == 4);
+        return (e && e[0] == '4' && !vbr_new) ? 4 : 2;
+    }
+    int launch(const int16_t * pcm, const float *pcmf, const LhStreamDesc * descs, LhStreamState * states,
+               LhFrameOut * out, uint8_t * bytes, int nstreams, void *stream) const {
+        return (waves == 4 ? lh_launch_encode4 : lh_launch_encode) (d_cfg, d_tab, pcm, pcmf, descs, states, out, bytes,
+                                                                    nstreams, stream);
+    }
     int upload(const LhConfig & cfg, const LhTables & tab) {
+        waves = pick_waves(cfg);
         HIPCHK(hipMalloc((void **) &d_cfg, sizeof(LhConfig)));
         HIPCHK(hipMalloc((void **) &d_tab, sizeof(LhTables)));
         HIPCHK(hipMemcpy(d_cfg, &cfg, sizeof(LhConfig), hipMemcpyHostToDevice));
@@ -725,8 +747,8 @@ handle_encode_frames(lame_t g, int upto, unsigned char *mp3buf, int mp3buf_size,
     d.flush = d.pad = 0;
     HIPCHK(hipMemcpyAsync(g->d_desc, &d, sizeof(d), hipMemcpyHostToDevice, g->stream));
     {
-        int     rc = lh_launch_encode(g->dc.d_cfg, g->dc.d_tab, (const int16_t *) 0, g->d_pcm, g->d_desc, g->d_state,
-                                      g->d_out, (uint8_t *) 0, 1, (void *) g->stream);
+        int     rc = g->dc.launch((const int16_t *) 0, g->d_pcm, g->d_desc, g->d_state, g->d_out, (uint8_t *) 0, 1,
+                                  (void *) g->stream);
         if (rc)
             return set_err("kernel launch", (hipError_t) rc);
     }
@@ -1661,8 +1683,8 @@ batch_encode_range(lamehip_batch * b, const std::vector < int >&upto, int end)
     }
     HIPCHK(hipEventRecord(b->ev0, b->stream));
     {
-        int     rc = lh_launch_encode(b->dc.d_cfg, b->dc.d_tab, b->d_pcm, (const float *) 0, (const LhStreamDesc *) b->d_stage,
-                                      b->d_state, b->d_out, (uint8_t *) 0, b->B, (void *) b->stream);
+        int     rc = b->dc.launch(b->d_pcm, (const float *) 0, (const LhStreamDesc *) b->d_stage, b->d_state, b->d_out,
+                                  (uint8_t *) 0, b->B, (void *) b->stream);
         if (rc)
             return set_err("kernel launch", (hipError_t) rc);
     }
@@ -1835,9 +1857,9 @@ lamehip_batch_encode(lamehip_batch * b)
                           hipMemcpyHostToDevice, b->stream));
     HIPCHK(hipEventRecord(b->ev0, b->stream));
     {
-        int     rc = lh_launch_encode(b->dc.d_cfg, b->dc.d_tab, b->rate_in ? (const int16_t *) 0 : b->d_pcm,
-                                      b->rate_in ? b->d_pcmf : (const float *) 0, b->d_desc, b->d_state,
-                                      b->d_out, b->dev_pack ? b->d_bytes : (uint8_t *) 0, b->B, (void *) b->stream);
+        int     rc = b->dc.launch(b->rate_in ? (const int16_t *) 0 : b->d_pcm, b->rate_in ? b->d_pcmf : (const float *) 0,
+                                  b->d_desc, b->d_state, b->d_out, b->dev_pack ? b->d_bytes : (uint8_t *) 0, b->B,
+                                  (void *) b->stream);
         if (rc)
             return set_err("kernel launch", (hipError_t) rc);
     }
@@ -1969,6 +1991,12 @@ extern "C" float
 lamehip_batch_last_kernel_ms(lamehip_batch * b)
 {
     return b ? b->last_ms : 0.0f;
+}
+
+extern "C" int
+lamehip_batch_kernel_waves(lamehip_batch * b)
+{
+    return b ? b->dc.waves : 0;
 }
 
 extern "C" int

@@ -131,8 +131,8 @@ lq_quant_line_hbm(const LhTables * T, float istep, float xp)
 /* load the granule into registers; Q.xrpow, Q.l3_xmin and the geometry arrays were written by
  * lh_init_outer_loop / lh_init_xrpow / lh_calc_xmin.  Then the arrays the search does not need in
  * LDS make room for the Huffman length grids. */
-LH_DEVFN void
-lq_load(const LhCtx & c, LhQS & S, LhChanLds & Q, const LhQR & R, const LhGrR & g)
+template < int ROLE > LH_DEVFN void
+lq_load(const LhCtx & c, LhQS & S, LhChanLds & Q, const LhQR & R, const LhGrR & g, int qch)
 {
     const LhQTabs *qt = LH_QT;
     int const pm = R.mnc >> 1;
@@ -179,6 +179,18 @@ lq_load(const LhCtx & c, LhQS & S, LhChanLds & Q, const LhQR & R, const LhGrR & 
     S.thrv = (LH_IXMAX) / S.istepv;
     S.sbg8 = 0;                 /* so is subblock_gain */
     LH_WAVE_SYNC();
+#ifdef LH_HELPERS
+    if (ROLE == 1) {
+        /* the sibling: it never counts bits, so it needs no grids; the counting wave may overwrite the arrays
+         * once this wave has read them, and this wave may use Q.xrpow as calc_noise's scratch once the
+         * counting wave has */
+        LhPairBox & B = lh_lds.box[qch];
+        int const n = lh_uni_i(B.go_seq);
+        lh_flag_post(&B.loaded1, n);
+        lh_flag_wait(&B.loaded0, n);
+        return;
+    }
+#endif
     {
         /* the three grids are constants of the launch: 704 words from HBM, issued together */
         const uint32_t *hg = c.T->hgrid;
@@ -186,6 +198,14 @@ lq_load(const LhCtx & c, LhQS & S, LhChanLds & Q, const LhQR & R, const LhGrR & 
 #pragma unroll
         for (int j = 0; j < 11; j++)
             w[j] = hg[c.lane + 64 * j];
+#ifdef LH_HELPERS
+        if (ROLE == 0) {
+            LhPairBox & B = lh_lds.box[qch];
+            int const n = lh_uni_i(B.go_seq);
+            lh_flag_post(&B.loaded0, n);
+            lh_flag_wait(&B.loaded1, n);
+        }
+#endif
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             Q.hl3_big[0][c.lane + 64 * j] = w[j];
@@ -198,14 +218,12 @@ lq_load(const LhCtx & c, LhQS & S, LhChanLds & Q, const LhQR & R, const LhGrR & 
     LH_WAVE_SYNC();
 }
 
-/* reference takehiro.c:281-414 (quantize_xrpow) + 654-801 (noquant_count_bits, count_bits) on the
- * working image.  Returns the bit count; g's count fields follow except table_select, which lives
- * in S.tselw (lane = region). */
+/* The quantiser half (reference takehiro.c:281-414, quantize_xrpow with its calc_noise_data short cuts): the
+ * working image S.pw at g.global_gain and the working scalefactors.  Returns 0 -- nothing changed -- when
+ * a line is too large for the step (count_bits answers LARGE_BITS then). */
 template < int USE_PREV, int NS > LH_DEVFN int
-lq_count_bits(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
+lq_quantize(const LhCtx & c, LhQS & S, const LhQR & R, const LhGrR & g)
 {
-    LH_PC(10);
-    LH_PT(t_cb);
     LQ_MARK("cb_begin");
     const LhTables *T = c.T;
     const LhQTabs *qt = LH_QT;
@@ -216,7 +234,7 @@ lq_count_bits(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
         float const thr = lq_ldexp(lh_u32_as_f32(lh_bcast_u32(lh_f32_as_u32(S.thrv), gb_)), 3 * ga);
         istep = lq_ldexp(lh_u32_as_f32(lh_bcast_u32(lh_f32_as_u32(S.istepv), gb_)), -3 * ga);
         if (LH_RARE(lh_ballot(S.lmax > thr)))
-            return LH_LARGE_BITS;
+            return 0;
     }
     /* ---- which bands are quantised, and how (lane = band) ---- */
     uint64_t ncmask = 0, m01mask = 0;
@@ -305,6 +323,17 @@ lq_count_bits(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
             }
         }
     }
+    return 1;
+}
+
+/* The counting half (reference takehiro.c:654-801, noquant_count_bits + count_bits' bookkeeping) on the working
+ * image.  Returns the bit count; g's count fields follow except table_select, which lives in S.tselw
+ * (lane = region). */
+template < int USE_PREV, int NS > LH_DEVFN int
+lq_count(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
+{
+    const LhQTabs *qt = LH_QT;
+    int const lane = c.lane;
     LQ_MARK("cb_count");
     /* ---- count ---- */
     {
@@ -482,16 +511,39 @@ lq_count_bits(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
         }
         if (USE_PREV && R.block_type == LH_NORM_TYPE && bv != 0)
             R.pn_sfb_count1 = lh_popc64(lh_ballot(lane < LH_SBMAX_L + 1 && (int) sfbcnt_in < bv));
-        LH_PA(11, t_cb);
         LQ_MARK("cb_end");
         return bits;
     }
 }
 
-/* reference quantize_pvt.c:750-913 on the working image */
-template < int NS > LH_DEVFN void
-lq_calc_noise(const LhCtx & c, LhQS & S, LhQR & R, const LhGrR & g, LhChanLds & Q, const float *xr, LhNoiseRes & res)
+/* reference takehiro.c:768-801, count_bits */
+template < int USE_PREV, int NS > LH_DEVFN int
+lq_count_bits(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
 {
+    int     bits = LH_LARGE_BITS;
+    LH_PC(10);
+    LH_PT(t_cb);
+    if (lq_quantize < USE_PREV, NS > (c, S, R, g))
+        bits = lq_count < USE_PREV, NS > (c, S, R, g, Q);
+    LH_PA(11, t_cb);
+    return bits;
+}
+
+/* What calc_noise finds for the working image, before it is taken over: the band's entry of calc_noise_data
+ * and its distortion (lane = band), and the totals.  The search forms it for every candidate the bit count
+ * looks at (in a sibling wave, when there is one) and takes over the one the reference would have computed. */
+struct LhNoiseTmp {
+    int     pnstep;
+    float   pnnoise, pnlog, dist;
+    LhNoiseRes res;
+};
+
+/* reference quantize_pvt.c:750-913 on the working image: into `t', S and R stay as they are */
+template < int NS > LH_DEVFN void
+lq_calc_noise(const LhCtx & c, const LhQS & S, const LhQR & R, const LhGrR & g, LhChanLds & Q, const float *xr,
+              LhNoiseTmp & t)
+{
+    LhNoiseRes & res = t.res;
     const LhTables *T = c.T;
     const LhQTabs *qt = LH_QT;
     int const s = c.lane;
@@ -590,6 +642,10 @@ lq_calc_noise(const LhCtx & c, LhQS & S, LhQR & R, const LhGrR & g, LhChanLds & 
         }
     }
     LQ_MARK("cn_log");
+    t.pnstep = S.pnstep;
+    t.pnnoise = S.pnnoise;
+    t.pnlog = S.pnlog;
+    t.dist = S.dist;
     if (s < R.psymax) {
         float   distort_;
         if (!fresh) {
@@ -597,17 +653,16 @@ lq_calc_noise(const LhCtx & c, LhQS & S, LhQR & R, const LhGrR & g, LhChanLds & 
             noise = S.pnlog;
         }
         else {
-            S.pnstep = st;
-            S.pnnoise = noise;
+            t.pnstep = st;
+            t.pnnoise = noise;
             distort_ = S.rxmin * noise;
             noise = (float) (lh_fast_log2(T->log_table, (distort_ > 1E-20f) ? distort_ : 1E-20f)
                              * LH_LOG2_OVER_LOG10);
-            S.pnlog = noise;
+            t.pnlog = noise;
         }
-        S.dist = distort_;
+        t.dist = distort_;
         noise_s = noise;
     }
-    R.pn_global_gain = g.global_gain;
     LQ_MARK("cn_agg");
     {
         int const mine = (s < R.psymax);
@@ -623,6 +678,17 @@ lq_calc_noise(const LhCtx & c, LhQS & S, LhQR & R, const LhGrR & g, LhChanLds & 
         res.over_noise = 0;
     }
     LQ_MARK("cn_end");
+}
+
+/* calc_noise's results become the working image's (the point where the reference calls it) */
+LH_DEVFN void
+lq_noise_commit(LhQS & S, LhQR & R, const LhGrR & g, const LhNoiseTmp & t)
+{
+    S.pnstep = t.pnstep;
+    S.pnnoise = t.pnnoise;
+    S.pnlog = t.pnlog;
+    S.dist = t.dist;
+    R.pn_global_gain = g.global_gain;
 }
 
 /* multiply the lines of the bands in `bands' by factor (xrpow only grows, so the lane's maximum
@@ -859,13 +925,84 @@ lq_balance_noise(const LhCtx & c, LhQS & S, LhChanLds & Q, const LhQR & R, LhGrR
     return !status;
 }
 
+/* One candidate of the search: the bit count of the working image at g.global_gain (count_bits), and -- into
+ * `t', for lq_noise_point() to take over if the reference computes it for this candidate -- what calc_noise
+ * finds for that image.
+ *   ROLE -1: one wave does everything; the noise is formed at lq_noise_point().
+ *   ROLE 0 / 1 (LH_HELPERS): two waves hold the same granule in their registers and take every decision of the
+ *   search alike.  Wave 0 counts, wave 1 quantises the same image (the same lq_quantize on the same state)
+ *   and forms its noise meanwhile; then they swap: the bit count and pn_sfb_count1 one way, the bands'
+ *   distortions / steps and the totals the other.  `ev' numbers the candidates of a search. */
+template < int USE_PREV, int NS, int ROLE > LH_DEVFN int
+lq_eval(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q, const float *xr, int qch, int &ev, LhNoiseTmp & t)
+{
+#ifdef LH_HELPERS
+    if (ROLE >= 0) {
+        LhPairBox & B = lh_lds.box[qch];
+        int const band = c.lane <= LH_SFBMAX ? c.lane : LH_SFBMAX;
+        int     bits;
+        ev++;
+        if (ROLE == 0) {
+            bits = lq_count_bits < USE_PREV, NS > (c, S, R, g, Q);
+            if (c.lane == 0) {
+                B.bits = bits;
+                B.sfb_count1 = R.pn_sfb_count1;
+            }
+            lh_flag_post(&B.seq0, ev);
+            lh_flag_wait(&B.seq1, ev);
+            t.dist = (c.lane <= LH_SFBMAX) ? Q.l3_xmin[band] : S.dist;
+            t.pnstep = (c.lane <= LH_SFBMAX) ? Q.sf[1][band] : S.pnstep;
+            t.pnnoise = S.pnnoise;      /* (only the sibling uses these two) */
+            t.pnlog = S.pnlog;
+            t.res.over_count = lh_uni_i(B.over_count);
+            t.res.over_SSD = lh_uni_i(B.over_SSD);
+            t.res.max_noise = lh_uni_f(B.max_noise);
+            t.res.tot_noise = 0;
+            t.res.over_noise = 0;
+            t.res.bits = 0;
+        }
+        else {
+            (void) lq_quantize < USE_PREV, NS > (c, S, R, g);
+            lq_calc_noise < NS > (c, S, R, g, Q, xr, t);
+            lh_flag_wait(&B.seq0, ev);
+            bits = lh_uni_i(B.bits);
+            R.pn_sfb_count1 = lh_uni_i(B.sfb_count1);
+            if (c.lane <= LH_SFBMAX) {
+                Q.l3_xmin[c.lane] = t.dist;
+                Q.sf[1][c.lane] = t.pnstep;
+            }
+            if (c.lane == 0) {
+                B.over_count = t.res.over_count;
+                B.over_SSD = t.res.over_SSD;
+                B.max_noise = t.res.max_noise;
+            }
+            lh_flag_post(&B.seq1, ev);
+        }
+        return bits;
+    }
+#endif
+    return lq_count_bits < USE_PREV, NS > (c, S, R, g, Q);
+}
+
+/* where the reference calls calc_noise: the noise of the candidate counted last becomes the working image's */
+template < int NS, int ROLE > LH_DEVFN void
+lq_noise_point(const LhCtx & c, LhQS & S, LhQR & R, const LhGrR & g, LhChanLds & Q, const float *xr, LhNoiseTmp & t,
+               LhNoiseRes & res)
+{
+    if (ROLE < 0)
+        lq_calc_noise < NS > (c, S, R, g, Q, xr, t);
+    lq_noise_commit(S, R, g, t);
+    res = t.res;
+}
+
 /* The global gain at which the granule just fits (reference quantize.c:367-429, bin_search): start from
  * the gain the channel's previous granule ended at and walk towards the target in steps of 4 or 2; once
  * the walk has crossed the target (or hit an end of the range) every further step halves, and a step
  * of 1 ends the search.  Should the last trial be over the budget, the gain rises one by one until it fits.  The
  * channel remembers where it ended and whether it had to move far (lh_lds.ss.OldValue / CurrentStep). */
-template < int NS > LH_DEVFN int
-lq_bin_search(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q, int desired_rate, int ch)
+template < int NS, int ROLE > LH_DEVFN int
+lq_bin_search(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q, const float *xr, int desired_rate, int ch,
+              int &ev, LhNoiseTmp & t)
 {
     int const from = lh_uni_i(lh_lds.ss.OldValue[ch]);
     int const want = desired_rate - g.part2_length;
@@ -876,7 +1013,7 @@ lq_bin_search(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q, int
     g.global_gain = from;
     for (;;) {
         int     move;
-        bits = lq_count_bits < 0, NS > (c, S, R, g, Q);
+        bits = lq_eval < 0, NS, ROLE > (c, S, R, g, Q, xr, ch, ev, t);
         if (stride == 1 || bits == want)
             break;
         move = (bits > want) ? 1 : -1;
@@ -893,9 +1030,9 @@ lq_bin_search(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q, int
     }
     while (bits > want && g.global_gain < 255) {
         g.global_gain++;
-        bits = lq_count_bits < 0, NS > (c, S, R, g, Q);
+        bits = lq_eval < 0, NS, ROLE > (c, S, R, g, Q, xr, ch, ev, t);
     }
-    if (c.lane == 0) {
+    if (ROLE != 1 && c.lane == 0) {
         lh_lds.ss.CurrentStep[ch] = (from - g.global_gain >= 4) ? 4 : 2;
         lh_lds.ss.OldValue[ch] = g.global_gain;
     }
@@ -919,26 +1056,29 @@ lq_keep_best(const LhCtx & c, LhQS & S, LhChanLds & Q)
 
 /* reference quantize.c:1010-1197; gb = cod_info.  On return the best image and its scalefactors
  * are in Q.ix[0] / Q.sf[0]. */
-template < int NS > LH_DEVFN int
+template < int NS, int ROLE > LH_DEVFN int
 lq_outer_loop(const LhCtx & c, LhQS & S, LhChanLds & Q, LhQR & R, LhGrR & gb, const float *xr, int ch, int targ_bits)
 {
     LhGrR   gw;
     LhNoiseRes best_noise_info;
+    LhNoiseTmp nt;
     int     huff_bits, better, age;
     int     best_part2_3_length = 9999999;
+    int     ev = 0;             /* candidates counted so far (sibling waves number their exchanges with it) */
 
     {
         LH_PT(t_bs);
-        (void) lq_bin_search < NS > (c, S, R, gb, Q, targ_bits, ch);
+        (void) lq_bin_search < NS, ROLE > (c, S, R, gb, Q, xr, targ_bits, ch, ev, nt);
         LH_PA(7, t_bs);
     }
     best_noise_info.over_count = 100;
     if (c.ns) {
         R.pn_global_gain = 0;
         R.pn_sfb_count1 = 0;
-        lq_calc_noise < NS > (c, S, R, gb, Q, xr, best_noise_info);
+        lq_noise_point < NS, ROLE > (c, S, R, gb, Q, xr, nt, best_noise_info);
         best_noise_info.bits = gb.part2_3_length;
-        lq_keep_best < NS > (c, S, Q);
+        if (ROLE != 1)
+            lq_keep_best < NS > (c, S, Q);
         gw = gb;
         age = 0;
         do {
@@ -957,12 +1097,13 @@ lq_outer_loop(const LhCtx & c, LhQS & S, LhChanLds & Q, LhQR & R, LhGrR & gb, co
             huff_bits = targ_bits - gw.part2_length;
             if (huff_bits <= 0)
                 break;
-            while ((gw.part2_3_length = lq_count_bits < 1, NS > (c, S, R, gw, Q)) > huff_bits && gw.global_gain <= maxggain)
+            while ((gw.part2_3_length = lq_eval < 1, NS, ROLE > (c, S, R, gw, Q, xr, ch, ev, nt)) > huff_bits
+                   && gw.global_gain <= maxggain)
                 gw.global_gain++;
             if (gw.global_gain > maxggain)
                 break;
             if (best_noise_info.over_count == 0) {
-                while ((gw.part2_3_length = lq_count_bits < 1, NS > (c, S, R, gw, Q)) > best_part2_3_length
+                while ((gw.part2_3_length = lq_eval < 1, NS, ROLE > (c, S, R, gw, Q, xr, ch, ev, nt)) > best_part2_3_length
                        && gw.global_gain <= maxggain)
                     gw.global_gain++;
                 if (gw.global_gain > maxggain)
@@ -970,7 +1111,7 @@ lq_outer_loop(const LhCtx & c, LhQS & S, LhChanLds & Q, LhQR & R, LhGrR & gb, co
             }
             {
                 LH_PT(t_cn);
-                lq_calc_noise < NS > (c, S, R, gw, Q, xr, noise_info);
+                lq_noise_point < NS, ROLE > (c, S, R, gw, Q, xr, nt, noise_info);
                 LH_PA(9, t_cn);
             }
             noise_info.bits = gw.part2_3_length;
@@ -978,7 +1119,8 @@ lq_outer_loop(const LhCtx & c, LhQS & S, LhChanLds & Q, LhQR & R, LhGrR & gb, co
             if (better) {
                 best_part2_3_length = gb.part2_3_length;
                 best_noise_info = noise_info;
-                lq_keep_best < NS > (c, S, Q);
+                if (ROLE != 1)
+                    lq_keep_best < NS > (c, S, Q);
                 gb = gw;
                 age = 0;
             }
@@ -991,8 +1133,10 @@ lq_outer_loop(const LhCtx & c, LhQS & S, LhChanLds & Q, LhQR & R, LhGrR & gb, co
         }
         while ((gw.global_gain + gw.scalefac_scale) < 255);
     }
-    else
+    else if (ROLE != 1)
         lq_keep_best < NS > (c, S, Q);
+    if (ROLE == 1)
+        return 0;               /* the sibling's copy of the result is not used */
     gb.table_select[0] = (int) lh_bcast_u32((uint32_t) S.tselb, 0);
     gb.table_select[1] = (int) lh_bcast_u32((uint32_t) S.tselb, 1);
     gb.table_select[2] = (int) lh_bcast_u32((uint32_t) S.tselb, 2);
@@ -1005,11 +1149,11 @@ lq_outer_loop(const LhCtx & c, LhQS & S, LhChanLds & Q, LhQR & R, LhGrR & gb, co
     return best_noise_info.over_count;
 }
 
-/* out-of-line entries (own register allocation): R / g travel through the wave's LDS slot.  One per
+/* out-of-line entries (own register allocation): R / g travel through the channel's LDS slot.  One per
  * slot count; the fifth slot (lines 512..575) drops out of the search when nothing is quantised
  * there and its xrpow is all zero (it could otherwise still raise xrpow_max): the usual case below
- * 20 kHz. */
-template < int NS > LH_DEVFN void
+ * 20 kHz.  With LH_HELPERS, one more pair for the sibling wave (ROLE 1), which leaves no results. */
+template < int NS, int ROLE > LH_DEVFN void
 lq_stage_body(int qch, int gr, int targ_bits)
 {
     LhCtx const c = lh_ctx_load();
@@ -1018,21 +1162,39 @@ lq_stage_body(int qch, int gr, int targ_bits)
     LhChanLds & Q = lh_lds.u.quant.ch[qch];
     LhQS    S;
     R.s_mnc = lh_uni_i((int) Q.sfb_of_line[R.mnc]);
-    lq_load(c, S, Q, R, g);
-    (void) lq_outer_loop < NS > (c, S, Q, R, g, lh_lds.xr[qch][lh_uni_i(gr)], qch, lh_uni_i(targ_bits));
-    lh_rg_put(c, R, g);
+    lq_load < ROLE > (c, S, Q, R, g, qch);
+    (void) lq_outer_loop < NS, ROLE > (c, S, Q, R, g, lh_lds.xr[qch][lh_uni_i(gr)], qch, lh_uni_i(targ_bits));
+    if (ROLE != 1)
+        lh_rg_put(c, R, g);
 }
+
+#ifdef LH_HELPERS
+#define LQ_MAIN_ROLE 0
+LH_STAGEFN void
+lq_sibling_stage5(int qch, int gr, int targ_bits)
+{
+    lq_stage_body < 5, 1 > (qch, gr, targ_bits);
+}
+
+LH_STAGEFN void
+lq_sibling_stage4(int qch, int gr, int targ_bits)
+{
+    lq_stage_body < 4, 1 > (qch, gr, targ_bits);
+}
+#else
+#define LQ_MAIN_ROLE (-1)
+#endif
 
 LH_STAGEFN void
 lq_outer_loop_stage5(int qch, int gr, int targ_bits)
 {
-    lq_stage_body < 5 > (qch, gr, targ_bits);
+    lq_stage_body < 5, LQ_MAIN_ROLE > (qch, gr, targ_bits);
 }
 
 LH_STAGEFN void
 lq_outer_loop_stage4(int qch, int gr, int targ_bits)
 {
-    lq_stage_body < 4 > (qch, gr, targ_bits);
+    lq_stage_body < 4, LQ_MAIN_ROLE > (qch, gr, targ_bits);
 }
 
 /* which of the two applies: wave-uniform; Q.xrpow and R.mnc are final (after lh_calc_xmin) */

@@ -29,7 +29,11 @@
 
 #ifdef LH_EMU
 #include <string.h>
+#ifdef LH_HELPERS
+extern "C" { extern int lh_emu_poison_lds; }
+#else
 extern "C" { int lh_emu_poison_lds = 0; }
+#endif
 #endif
 #include "lh_static_tables.h"
 #include "lh_dev_common.h"
@@ -163,6 +167,56 @@ lh_store_granule(const LhCtx & c, const LhChanLds & Q, const LhQR & R, const LhG
 
 #include "lh_dev_emit.h"
 #include "lh_dev_vbr.h"
+
+#ifdef LH_HELPERS
+/* a wave of the frame loop tells its sibling what this granule's search is (slots 4 / 5; 0: there is none) */
+LH_DEVFN void
+lh_sibling_go(const LhCtx & c, int qch, int ns, int gr, int targ)
+{
+    LhPairBox & B = lh_lds.box[qch];
+    int const n = lh_uni_i(B.go_seq) + 1;
+    if (c.lane == 0) {
+        B.go_ns = ns;
+        B.go_gr = gr;
+        B.go_targ = targ;
+        B.seq0 = 0;
+        B.seq1 = 0;
+    }
+    lh_flag_post(&B.go_seq, n);
+}
+
+/* Waves 2 and 3: between searches they only keep the workgroup's barriers company (a barrier waits for every
+ * wave of the workgroup), counting them; behind the barrier the frame loop has named (LhLds.search_at) wave
+ * 2 + ch waits for channel ch's `go' and runs the search beside it. */
+LH_DEVFN void
+lh_helper_waves(int qch)
+{
+    LhPairBox & B = lh_lds.box[qch];
+    int     passed = 0, served = 0;
+#if !defined(LH_EMU)
+    __builtin_amdgcn_s_setprio(0);      /* behind the frame loop's waves when a SIMD has to choose (+6 %) */
+#endif
+    for (;;) {
+        __syncthreads();
+        passed++;
+        if (lh_uni_i(lh_lds.h_quit))
+            break;
+        if (lh_uni_i(lh_lds.search_at) == passed) {
+            served++;
+            lh_flag_wait(&B.go_seq, served);
+            {
+                int const ns = lh_uni_i(B.go_ns), gr = lh_uni_i(B.go_gr), targ = lh_uni_i(B.go_targ);
+                if (ns == 5)
+                    lq_sibling_stage5(qch, gr, targ);
+                else if (ns == 4)
+                    lq_sibling_stage4(qch, gr, targ);
+            }
+        }
+    }
+}
+#else
+#define lh_sibling_go(c, qch, ns, gr, targ) do { } while (0)
+#endif
 
 /* one frame of one stream; executed by the whole workgroup */
 LH_STAGEFN void
@@ -324,7 +378,12 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
     int     frame_bits = lh_uni_i(lh_frame_bits(cfg, bitrate_index, padding));
     int     mean_bits = lh_uni_i((frame_bits - cfg->sideinfo_len * 8) / cfg->mode_gr);
     int     total_bits = 0;
+#ifdef LH_HELPERS
+    int const vbr_new = 0;      /* the host launches the VBR loop with the two-wave kernel only */
+    int const abr = (cfg->vbr == 3);
+#else
     int const vbr_new = (cfg->vbr == 1 || cfg->vbr == 4), abr = (cfg->vbr == 3);
+#endif
     int     abr_targ[2][2] = { {0, 0}, {0, 0} }, analog_silence_bits = 0;
     if (vbr_new) {
         LH_SYNC_WG();
@@ -380,6 +439,11 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
         }
         targ_bits[0] = lh_uni_i(targ_bits[0]);
         targ_bits[1] = lh_uni_i(targ_bits[1]);
+#ifdef LH_HELPERS
+        /* the sibling waves leave their barrier loop behind the next barrier and wait for this granule's `go' */
+        if (tid == 0)
+            L.search_at = L.bar_count + 1;
+#endif
         LH_SYNC_WG();
         if (w >= nch) {
             /* no second channel: its payload slot is all zero */
@@ -388,6 +452,7 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
                 z[i] = 0u;
             if (lane == 0)
                 L.bits_used[w] = 0;
+            lh_sibling_go(c, w, 0, gr, 0);
         }
         else {
             int const ch = w;
@@ -413,14 +478,20 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
                 if (abr && !R.ath_over)
                     targ_bits[ch] = analog_silence_bits;    /* reference quantize.c:1953-1954 */
                 lh_rg_put(c, R, g);
-                if (lq_needs_tail(c, Q, R))
+                if (lq_needs_tail(c, Q, R)) {
+                    lh_sibling_go(c, ch, 5, gr, targ_bits[ch]);
                     lq_outer_loop_stage5(ch, gr, targ_bits[ch]);
-                else
+                }
+                else {
+                    lh_sibling_go(c, ch, 4, gr, targ_bits[ch]);
                     lq_outer_loop_stage4(ch, gr, targ_bits[ch]);
+                }
                 R = lh_uniform(L.rg[ch].R);
                 g = lh_uniform(L.rg[ch].g);
                 LH_PA(5, t_ol);
             }
+            else
+                lh_sibling_go(c, ch, 0, gr, 0);     /* nothing to search in an all-zero granule */
             LH_PT(t_fin);
             lh_rg_put(c, R, g);
             lh_best_scalefac_store(ch, gr, fo->gr[0][ch].scalefac, L.block_type[0][ch]);
@@ -524,7 +595,18 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
 }
 
 #ifndef LH_WAVES_PER_EU
+#ifdef LH_HELPERS
+#define LH_WAVES_PER_EU 4
+#else
 #define LH_WAVES_PER_EU 2
+#endif
+#endif
+/* the LH_HELPERS build of this file is a second object in the same library: its own names */
+#ifdef LH_HELPERS
+#define lh_encode_kernel lh_encode_kernel4
+#define lh_launch_encode lh_launch_encode4
+#define lh_emu_encode lh_emu_encode4
+#define lh_emu_encode_bytes lh_emu_encode_bytes4
 #endif
 /* all frames of one stream (the workgroup's whole job).  Out of line: a kernel body places what it keeps across
  * calls in registers ABOVE its callees' budget, which is what decides the occupancy; a function keeps
@@ -569,6 +651,20 @@ lh_encode_stream(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, 
     c.lane = c.tid & 63;
     c.wave = lh_uni_i(c.tid >> 6);      /* scalar: everything indexed by the wave id gets scalar addressing */
     lh_ctx_hot(c);
+#ifdef LH_HELPERS
+    if (c.tid == 0) {
+        L.bar_count = 0;
+        L.search_at = -1;
+        L.h_quit = 0;
+        for (int k = 0; k < 2; k++) {
+            L.box[k].go_seq = 0;
+            L.box[k].loaded0 = 0;
+            L.box[k].loaded1 = 0;
+            L.box[k].seq0 = 0;
+            L.box[k].seq1 = 0;
+        }
+    }
+#endif
     if (c.tid == 0) {
         L.ctx.cfg = c.cfg;
         L.ctx.T = c.T;
@@ -578,6 +674,15 @@ lh_encode_stream(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, 
         L.ctx.bytes = bytes;
         L.ctx.d = c.d;
     }
+#ifdef LH_HELPERS
+    if (c.wave >= 2) {
+        lh_helper_waves(c.wave - 2);
+        return;
+    }
+#if !defined(LH_EMU)
+    __builtin_amdgcn_s_setprio(3);      /* the frame loop's waves before their siblings */
+#endif
+#endif
     /* State that is rewritten every frame stays on the chip for the whole launch: the polyphase
      * overlap and the psy model's previous partition energies in registers (LhWaveCarry), its band
      * energies / thresholds in the LDS ring (LhLds.psy_en).  HBM sees them once per launch. */
@@ -610,6 +715,11 @@ lh_encode_stream(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, 
         lh_encode_frame(c, &out[c.d.out_index + (f - c.d.frame_begin)], carry);
         slot = (slot + 2) % 3;
     }
+#ifdef LH_HELPERS
+    if (c.tid == 0)
+        L.h_quit = 1;
+    LH_SYNC_WG();
+#endif
     if (c.tid < LH_SS_WORDS_A)
         ((uint32_t *) &st->loudness_sq_save[0])[c.tid] = ((const uint32_t *) &L.ss)[c.tid];
     else if (c.tid < LH_SS_WORDS_A + LH_SS_WORDS_B)
@@ -629,7 +739,7 @@ lh_encode_stream(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, 
 }
 
 #ifndef LH_EMU
-extern "C" __global__ void __launch_bounds__(LH_NT, LH_WAVES_PER_EU)
+extern "C" __global__ void __launch_bounds__(LH_BLOCK, LH_WAVES_PER_EU)
 #else
 void
 #endif
@@ -640,7 +750,7 @@ lh_encode_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, 
     lh_encode_stream(cfg, T, pcm, pcmf, descs, states, out, bytes, nstreams);
 }
 
-#ifndef LH_EMU
+#if !defined(LH_EMU) && !defined(LH_HELPERS)
 /* device self-test of the cross-lane primitives in lh_wave.h: each reduction is
  * compared with a serial evaluation through LDS; out[0] = number of mismatches */
 extern "C" __global__ void __launch_bounds__(64)
@@ -766,6 +876,8 @@ lh_launch_scatter(const int16_t * stage, long stage_stride, int16_t * pool, long
     return (int) hipGetLastError();
 }
 
+#endif
+#ifndef LH_EMU
 /* host-side launcher with a C ABI for lh_api.cpp */
 extern "C" int
 lh_launch_encode(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, const float *pcmf,
@@ -774,7 +886,7 @@ lh_launch_encode(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, 
 {
     if (nstreams <= 0)
         return 0;
-    hipLaunchKernelGGL(lh_encode_kernel, dim3((unsigned) nstreams), dim3(LH_NT), 0,
+    hipLaunchKernelGGL(lh_encode_kernel, dim3((unsigned) nstreams), dim3(LH_BLOCK), 0,
                        (hipStream_t) stream, cfg, T, pcm, pcmf, descs, states, out, bytes, nstreams);
     return (int) hipGetLastError();
 }
@@ -793,7 +905,7 @@ extern "C" int
 lh_emu_encode_bytes(const LhConfig * cfg, const LhTables * T, const int16_t * pcm,
                     const LhStreamDesc * descs, LhStreamState * states, LhFrameOut * out, uint8_t * bytes, int nstreams)
 {
-    hipemu_dim3 grid = { (unsigned) nstreams, 1, 1 }, block = { LH_NT, 1, 1 };
+    hipemu_dim3 grid = { (unsigned) nstreams, 1, 1 }, block = { LH_BLOCK, 1, 1 };
     hipemu_run(grid, block,[=] () {
                lh_encode_kernel(cfg, T, pcm, (const float *) 0, descs, states, out, bytes, nstreams);
                }

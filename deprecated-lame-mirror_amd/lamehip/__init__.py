@@ -67,6 +67,7 @@ def load_library():
     lib.lamehip_batch_get_state.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
     lib.lamehip_batch_last_kernel_ms.restype = C.c_float
     lib.lamehip_batch_last_kernel_ms.argtypes = [C.c_void_p]
+    lib.lamehip_batch_kernel_waves.argtypes = [C.c_void_p]
     _lib = lib
     return lib
 
@@ -280,6 +281,9 @@ class Batch:
 
     def kernel_ms(self):
         return float(self.lib.lamehip_batch_last_kernel_ms(self.b))
+
+    def kernel_waves(self):
+        return int(self.lib.lamehip_batch_kernel_waves(self.b))
 
     def frames(self, s):
         return self.lib.lamehip_batch_frames(self.b, s)
