@@ -129,6 +129,11 @@ def _cpu_allowance():
     return allowed, quota
 
 
+def _cpu_budget():
+    allowed, quota = _cpu_allowance()
+    return max(1, int(min(allowed, quota) if quota else allowed))
+
+
 def _cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -327,9 +332,10 @@ def main():
     ap.add_argument("--abr", type=int, default=None, metavar="KBPS", help="ABR at a mean of KBPS instead of CBR")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the short runs of BASELINE configs [2] and [4]")
-    ap.add_argument("--end-to-end", action="store_true",
-                    help="also time host PCM -> H2D -> kernel -> D2H -> bytes on a 5 s sample; an extra object, "
-                         "never `value`")
+    ap.add_argument("--no-end-to-end", action="store_true",
+                    help="skip the end_to_end object (pinned host PCM -> H2D -> kernel -> D2H -> bytes, pipelined "
+                         "batches of 5 s streams; an extra object, never `value`)")
+    ap.add_argument("--end-to-end", action="store_true", help="(accepted for older command lines; it is the default now)")
     args = ap.parse_args()
 
     launched = "WORLD_SIZE" in os.environ
@@ -449,53 +455,123 @@ def main():
                 "cbr320_48k_bursts_config4": short_run(torch, lamehip, dev, device_index, 48000, 1024, 5.0, 2, 9000,
                                                        40.0, brate=320, mode=1),
             }
-        if args.end_to_end and world == 1:
-            res["end_to_end"] = end_to_end(torch, lamehip, enc, B, sr, dev)
+        if not args.no_end_to_end and not args.no_extras and world == 1:
+            if batch is not None:
+                batch.close()
+                batch = None
+            res["end_to_end"] = end_to_end(torch, lamehip, enc, min(B, 1024), sr, dev)
         print(json.dumps(res))
     rdv.barrier()
     rdv.close()
 
 
-def end_to_end(torch, lamehip, enc, B, sr, dev, seconds=5.0):
-    """SURVEY.md 8(d) region R2: s16 PCM in host memory -> H2D -> kernel -> D2H -> mp3 bytes in
-    memory, once with the host packer on all cores and once with the device packer."""
+def end_to_end(torch, lamehip, enc, B, sr, dev, seconds=5.0, rounds=8, nbatch=2):
+    """SURVEY.md 8(d) region R2: s16 PCM in pinned host memory -> H2D -> kernel -> D2H -> mp3 bytes in host
+    memory, as a pipeline of `nbatch' batch objects (each with its own HIP stream) that are reused round-robin
+    for `rounds' batches of B streams x `seconds': batch n's kernel runs while batch n+1's PCM goes up and batch
+    n-1's bytes come down.  device_packed (the product's path for batches: the kernel assembles the bytes,
+    lh_dev_emit.h) and, for comparison, the host packer on all cores (payload D2H + lamehip_batch_pack_all in a
+    thread per batch).  Before the clock: the PCM is in the batches' pinned mirrors and every object has run
+    once.  Checked: the device-packed bytes of four streams against the host packer's."""
+    import threading
     n = int(seconds * sr)
     host = synth_on_device(torch, B, n, sr, 777, dev).cpu().numpy()
-    threads = min(32, os.cpu_count() or 1)
-    b = lamehip.Batch(enc, B, n)
-    best = None
-    for _ in range(2):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
+    threads = min(32, _cpu_budget())
+    objs = []
+    for k in range(nbatch):
+        b = lamehip.Batch(enc, B, n)
+        b.pcm_host()[:, :, :n] = host           # "pinned host PCM" is where R2 starts
         for s in range(B):
-            b.set_pcm(s, host[s, 0], host[s, 1])
-        b.encode(sync=True)
-        t1 = time.perf_counter()
-        _, _, sizes = b.pack_all(threads, as_bytes=False)
-        t2 = time.perf_counter()
-        if best is None or t2 - t0 < best[0]:
-            best = (t2 - t0, t1 - t0, t2 - t1, int(sizes.sum()))
-    stride = (b.frames(0) + 2) * (1500 if enc.config().vbr else 1100)
-    dbest = None
-    for _ in range(2):
+            b.set_length(s, n)
+        objs.append(b)
+    which = sorted(set([0, 1, B // 2, B - 1]))
+
+    def mark(b):
+        for s in range(B):
+            b.mark_pcm(s)
+
+    # -- device-packed pipeline --
+    for b in objs:
         b.set_device_packing()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for s in range(B):
-            b.set_pcm(s, host[s, 0], host[s, 1])
+        mark(b)
+        b.encode(sync=False)
+        b.fetch()
+    sizes = 0
+    for b in objs:
+        sizes = sum(len(b.bytes_view(s)) for s in range(B))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for r in range(rounds):
+        b = objs[r % nbatch]
+        if r >= nbatch:
+            got = sum(len(b.bytes_view(s)) for s in which)      # the previous batch of this object is home
+            assert got > 0
+        mark(b)
+        b.upload()
+        b.encode(sync=False)
+        b.fetch()
+    for b in objs:
+        b.bytes_view(0)
+    dt_dev = time.perf_counter() - t0
+    dev_bytes = {s: bytes(objs[0].bytes_view(s)) for s in which}
+    # phases of one batch alone (no overlap), for the record
+    b = objs[0]
+    torch.cuda.synchronize()
+    p0 = time.perf_counter()
+    mark(b)
+    b.upload()
+    b.sync()
+    p1 = time.perf_counter()
+    b.encode(sync=True)
+    p2 = time.perf_counter()
+    b.fetch()
+    b.bytes_view(0)
+    p3 = time.perf_counter()
+
+    # -- host-packed pipeline (payload D2H + pack_all on `threads' host threads, one packing thread per batch) --
+    for b in objs:
+        b.set_device_packing(False)
+    res_sizes = [None] * nbatch
+
+    def pack(k):
+        _, _, sz = objs[k].pack_all(threads, as_bytes=False)
+        res_sizes[k] = int(sz.sum())
+
+    for k, b in enumerate(objs):
+        mark(b)
         b.encode(sync=True)
-        t1 = time.perf_counter()
-        _, dsizes = b.get_bytes_all(stride)
-        t2 = time.perf_counter()
-        if dbest is None or t2 - t0 < dbest[0]:
-            dbest = (t2 - t0, t1 - t0, t2 - t1, int(dsizes.sum()))
-    b.close()
-    return {"value": round(B * seconds / best[0], 1), "unit": "x real-time", "host_threads": threads,
-            "h2d_plus_kernel_s": round(best[1], 3), "d2h_plus_pack_s": round(best[2], 3), "mp3_bytes": best[3],
-            "device_packed": {"value": round(B * seconds / dbest[0], 1), "unit": "x real-time",
-                              "h2d_plus_kernel_s": round(dbest[1], 3), "d2h_s": round(dbest[2], 3),
-                              "mp3_bytes": dbest[3]},
-            "sample": "%d streams x %.0f s, host s16 in -> mp3 bytes out" % (B, seconds)}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    workers = [None] * nbatch
+    for r in range(rounds):
+        k = r % nbatch
+        if workers[k] is not None:
+            workers[k].join()
+        b = objs[k]
+        mark(b)
+        b.upload()
+        b.encode(sync=False)
+        workers[k] = threading.Thread(target=pack, args=(k,))
+        workers[k].start()                      # pack_all waits for the batch's stream itself
+    for w in workers:
+        if w is not None:
+            w.join()
+    dt_host = time.perf_counter() - t0
+    same = all(objs[0].pack(s) == dev_bytes[s] for s in which)
+    for b in objs:
+        b.close()
+    if not same:
+        raise SystemExit("end_to_end: device-packed bytes differ from the host packer's")
+    audio = rounds * B * seconds
+    return {"value": round(audio / dt_host, 1), "unit": "x real-time", "host_threads": threads,
+            "mp3_bytes_per_batch": res_sizes[0],
+            "device_packed": {"value": round(audio / dt_dev, 1), "unit": "x real-time", "mp3_bytes_per_batch": int(sizes),
+                              "one_batch_alone_s": {"h2d": round(p1 - p0, 4), "kernel": round(p2 - p1, 4),
+                                                    "d2h": round(p3 - p2, 4)},
+                              "bytes_checked_against_host_packer": {"streams": which, "result": "identical"}},
+            "pipeline": "%d batch objects round-robin over %d batches, each on its own HIP stream" % (nbatch, rounds),
+            "sample": "%d streams x %.0f s per batch, pinned host s16 in -> mp3 bytes in pinned host memory out"
+                      % (B, seconds)}
 
 
 if __name__ == "__main__":

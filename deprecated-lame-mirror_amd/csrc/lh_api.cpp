@@ -32,6 +32,7 @@ extern "C" int lh_launch_encode4(const LhConfig * cfg, const LhTables * T, const
                                  LhFrameOut * out, uint8_t * bytes, int nstreams, void *stream);
 
 extern "C" int lh_launch_selftest(unsigned *d_out, unsigned seed, void *stream);
+extern "C" int lh_launch_summary(const LhStreamState * states, long long *sum, int nstreams, void *stream);
 extern "C" int lh_launch_scatter(const int16_t * stage, long stage_stride, int16_t * pool, long cap, const int *meta,
                                  int nstreams, void *stream);
 
@@ -1208,6 +1209,7 @@ struct lamehip_batch {
     long    cap;
     int16_t *d_pcm;             /* [B][2][cap] */
     LhStreamState *d_state;
+    LhStreamState *d_state0;    /* the streams' initial states (batch_reset_states) */
     LhStreamDesc *d_desc;
     LhFrameOut *d_out;
     long long out_cap;
@@ -1245,6 +1247,23 @@ struct lamehip_batch {
     unsigned char *h_stage, *d_stage;
     long    stage_rows_at, stage_stride, stage_bytes;
     std::vector < LhFrameOut > h_new;
+    /* pinned host side of a pipelined batch (lamehip_batch_pcm_host_ptr / _upload / _fetch): the mirror of the
+     * s16 pool the caller (or lamehip_batch_set_pcm) writes, which reaches HBM with one asynchronous copy on
+     * the batch's stream; the device packer's bytes and a two-word summary per stream (bytes, status) on the
+     * way back.  Another batch's copies and kernel run meanwhile (each batch has its own stream). */
+    int16_t *h_pcm;
+    std::vector < char >row_dirty;      /* streams whose mirror rows are newer than the pool */
+    int     n_dirty;
+    unsigned char *h_bytes;
+    long long h_bytes_cap;
+    long long *d_sum, *h_sum;
+    int     fetched;            /* the bytes of the last encode are in (or on their way into) h_bytes */
+    /* the copies of a pipelined batch have streams of their own (different hardware queues from the kernel's, and
+     * from each other: an upload queued behind the previous round's download on one stream cost 12 % of the
+     * pipeline's throughput), tied to the kernel's stream by events */
+    hipStream_t up_stream, down_stream;
+    hipEvent_t ev_up, ev_sum, ev_down;
+    int     up_pending, down_pending;
 };
 
 static int
@@ -1253,13 +1272,19 @@ batch_padding(const lamehip_batch * b, int s)
     return b->rate_in ? b->padding[(size_t) s] : lh_end_padding(b->len[(size_t) s]);
 }
 
+/* every stream back to its initial state: a device-to-device copy of the pristine image on the batch's own
+ * stream (a host copy on the null stream would wait for every other batch's work in flight) */
 static int
 batch_reset_states(lamehip_batch * b)
 {
-    std::vector < LhStreamState > s((size_t) b->B);
-    for (int i = 0; i < b->B; i++)
-        lh_state_init(&s[(size_t) i], &b->cfg);
-    HIPCHK(hipMemcpy(b->d_state, s.data(), s.size() * sizeof(LhStreamState), hipMemcpyHostToDevice));
+    if (!b->d_state0) {
+        std::vector < LhStreamState > s((size_t) b->B);
+        for (int i = 0; i < b->B; i++)
+            lh_state_init(&s[(size_t) i], &b->cfg);
+        HIPCHK(hipMalloc((void **) &b->d_state0, s.size() * sizeof(LhStreamState)));
+        HIPCHK(hipMemcpy(b->d_state0, s.data(), s.size() * sizeof(LhStreamState), hipMemcpyHostToDevice));
+    }
+    HIPCHK(hipMemcpyAsync(b->d_state, b->d_state0, (size_t) b->B * sizeof(LhStreamState), hipMemcpyDeviceToDevice, b->stream));
     b->encoded = 0;
     return 0;
 }
@@ -1316,6 +1341,7 @@ lamehip_batch_create_on(int device, const lame_t proto, int nstreams, long capac
     b->cap = capacity_samples;
     b->d_pcm = nullptr;
     b->d_state = nullptr;
+    b->d_state0 = nullptr;
     b->d_desc = nullptr;
     b->d_out = nullptr;
     b->out_cap = 0;
@@ -1337,6 +1363,16 @@ lamehip_batch_create_on(int device, const lame_t proto, int nstreams, long capac
     b->incremental = 0;
     b->h_stage = b->d_stage = nullptr;
     b->stage_rows_at = b->stage_stride = b->stage_bytes = 0;
+    b->h_pcm = nullptr;
+    b->row_dirty.assign((size_t) nstreams, 0);
+    b->n_dirty = 0;
+    b->h_bytes = nullptr;
+    b->h_bytes_cap = 0;
+    b->d_sum = b->h_sum = nullptr;
+    b->fetched = 0;
+    b->up_stream = b->down_stream = nullptr;
+    b->ev_up = b->ev_sum = b->ev_down = nullptr;
+    b->up_pending = b->down_pending = 0;
     if (proto->rs) {
         /* the s16 pool shrinks to nothing, the converted signal (plus the flush's tail) lives in a float pool */
         b->rate_in = proto->p.samplerate;
@@ -1374,6 +1410,8 @@ lamehip_batch_destroy(lamehip_batch * b)
         (void) hipFree(b->d_pcm);
     if (b->d_state)
         (void) hipFree(b->d_state);
+    if (b->d_state0)
+        (void) hipFree(b->d_state0);
     if (b->d_desc)
         (void) hipFree(b->d_desc);
     if (b->d_out)
@@ -1387,6 +1425,24 @@ lamehip_batch_destroy(lamehip_batch * b)
         (void) hipHostFree(b->h_stage);
     if (b->d_stage)
         (void) hipFree(b->d_stage);
+    if (b->up_stream)
+        (void) hipStreamDestroy(b->up_stream);
+    if (b->down_stream)
+        (void) hipStreamDestroy(b->down_stream);
+    if (b->ev_up)
+        (void) hipEventDestroy(b->ev_up);
+    if (b->ev_sum)
+        (void) hipEventDestroy(b->ev_sum);
+    if (b->ev_down)
+        (void) hipEventDestroy(b->ev_down);
+    if (b->h_pcm)
+        (void) hipHostFree(b->h_pcm);
+    if (b->h_bytes)
+        (void) hipHostFree(b->h_bytes);
+    if (b->h_sum)
+        (void) hipHostFree(b->h_sum);
+    if (b->d_sum)
+        (void) hipFree(b->d_sum);
     for (size_t i = 0; i < b->packer.size(); i++)
         lh_bs_free(&b->packer[i]);
     if (b->stream)
@@ -1487,6 +1543,23 @@ batch_convert_stream(lamehip_batch * b, int s, const short *l, const short *r, l
     return 0;
 }
 
+extern "C" short *lamehip_batch_pcm_host_ptr(lamehip_batch * b);
+
+/* the mirror for lamehip_batch_set_pcm: made on first use unless the pool is larger than LAMEHIP_PINNED_MAX_MB
+ * (default 4096) of pinned host memory */
+static int16_t *
+batch_host_pool(lamehip_batch * b)
+{
+    if (!b->h_pcm && !b->rate_in) {
+        const char *e = getenv("LAMEHIP_PINNED_MAX_MB");
+        double const limit = (e ? atof(e) : 4096.0) * 1048576.0;
+        if ((double) b->B * 4.0 * (double) b->cap > limit)
+            return nullptr;
+        (void) lamehip_batch_pcm_host_ptr(b);
+    }
+    return b->h_pcm;
+}
+
 extern "C" int
 lamehip_batch_set_pcm(lamehip_batch * b, int s, const short *l, const short *r, long n)
 {
@@ -1502,8 +1575,103 @@ lamehip_batch_set_pcm(lamehip_batch * b, int s, const short *l, const short *r, 
         return -1;
     if (b->cfg.channels == 1 && b->cfg.pcm_mix == 0.0f)
         r = l;                  /* mono: the second plane mirrors the first, the kernel never uses it */
+    if (batch_host_pool(b) != nullptr) {
+        /* into the pinned mirror; the rows travel with the next lamehip_batch_upload / _encode, all streams'
+         * in one asynchronous copy (the reference's seam: lame_encode_buffer copies into mfbuf, lame.c:1672) */
+        memcpy(b->h_pcm + ((size_t) s * 2) * (size_t) b->cap, l, (size_t) n * 2);
+        memcpy(b->h_pcm + ((size_t) s * 2 + 1) * (size_t) b->cap, r, (size_t) n * 2);
+        if (!b->row_dirty[(size_t) s]) {
+            b->row_dirty[(size_t) s] = 1;
+            b->n_dirty++;
+        }
+        return 0;
+    }
+    /* the pool is too large to mirror in pinned memory: straight to HBM, stream by stream */
     HIPCHK(hipMemcpy(b->d_pcm + ((size_t) s * 2) * (size_t) b->cap, l, (size_t) n * 2, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(b->d_pcm + ((size_t) s * 2 + 1) * (size_t) b->cap, r, (size_t) n * 2, hipMemcpyHostToDevice));
+    return 0;
+}
+
+/* The pinned mirror of the batch's s16 pool, [stream][2][capacity] like the pool itself: the caller may
+ * decode straight into it (then lamehip_batch_set_length + lamehip_batch_mark_pcm, or lamehip_batch_set_pcm,
+ * which copies into it).  NULL for a converting batch or when the mirror cannot be had. */
+extern "C" short *
+lamehip_batch_pcm_host_ptr(lamehip_batch * b)
+{
+    LhDeviceScope const on_device(b ? b->device : -1);
+    if (!b)
+        return nullptr;
+    if (!b->h_pcm && !b->rate_in
+        && hipHostMalloc((void **) &b->h_pcm, (size_t) b->B * 2 * (size_t) b->cap * 2, 0) != hipSuccess) {
+        b->h_pcm = nullptr;
+        (void) hipGetLastError();
+    }
+    return b->h_pcm;
+}
+
+/* stream s's rows of the mirror were written by the caller: they travel with the next upload */
+extern "C" int
+lamehip_batch_mark_pcm(lamehip_batch * b, int s)
+{
+    if (!b || s < 0 || s >= b->B || !b->h_pcm)
+        return -1;
+    if (!b->row_dirty[(size_t) s]) {
+        b->row_dirty[(size_t) s] = 1;
+        b->n_dirty++;
+    }
+    return 0;
+}
+
+/* Asynchronous H2D of everything that changed in the mirror, on the batch's stream (lamehip_batch_encode does
+ * this itself when something is pending).  One copy when every stream changed and the streams fill their rows,
+ * else one per row. */
+static int
+batch_copy_streams(lamehip_batch * b)
+{
+    if (!b->up_stream) {
+        HIPCHK(hipStreamCreateWithFlags(&b->up_stream, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&b->down_stream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&b->ev_up, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&b->ev_sum, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&b->ev_down, hipEventDisableTiming));
+    }
+    return 0;
+}
+
+extern "C" int
+lamehip_batch_upload(lamehip_batch * b)
+{
+    LhDeviceScope const on_device(b ? b->device : -1);
+    if (!b)
+        return -1;
+    if (b->n_dirty == 0 || !b->h_pcm)
+        return 0;
+    if (batch_copy_streams(b) != 0)
+        return LAMEHIP_ERR_DEVICE;
+    /* the pool may still be read by the kernel of the previous round */
+    if (b->encoded)
+        HIPCHK(hipStreamWaitEvent(b->up_stream, b->ev1, 0));
+    {
+        long long used = 0;
+        for (int s = 0; s < b->B; s++)
+            used += b->len[(size_t) s];
+        if (b->n_dirty == b->B && used * 10 >= (long long) b->B * b->cap * 9)
+            HIPCHK(hipMemcpyAsync(b->d_pcm, b->h_pcm, (size_t) b->B * 2 * (size_t) b->cap * 2, hipMemcpyHostToDevice, b->up_stream));
+        else
+            for (int s = 0; s < b->B; s++) {
+                size_t const n = (size_t) b->len[(size_t) s] * 2;
+                if (!b->row_dirty[(size_t) s] || n == 0)
+                    continue;
+                for (int ch = 0; ch < 2; ch++) {
+                    size_t const at = ((size_t) s * 2 + (size_t) ch) * (size_t) b->cap;
+                    HIPCHK(hipMemcpyAsync(b->d_pcm + at, b->h_pcm + at, n, hipMemcpyHostToDevice, b->up_stream));
+                }
+            }
+    }
+    HIPCHK(hipEventRecord(b->ev_up, b->up_stream));
+    b->up_pending = 1;
+    b->row_dirty.assign((size_t) b->B, 0);
+    b->n_dirty = 0;
     return 0;
 }
 
@@ -1515,6 +1683,12 @@ lamehip_batch_set_pcm_device(lamehip_batch * b, int s, const void *dl, const voi
         return -1;
     if (b->cfg.channels == 1 && b->cfg.pcm_mix == 0.0f)
         dr = dl;
+    if (b->up_pending)          /* an upload of the mirror is on its way into the same pool */
+        HIPCHK(hipStreamSynchronize(b->up_stream));
+    if (b->row_dirty[(size_t) s]) {     /* what the mirror holds for this stream is superseded */
+        b->row_dirty[(size_t) s] = 0;
+        b->n_dirty--;
+    }
     HIPCHK(hipMemcpy(b->d_pcm + ((size_t) s * 2) * (size_t) b->cap, dl, (size_t) n * 2, hipMemcpyDeviceToDevice));
     HIPCHK(hipMemcpy(b->d_pcm + ((size_t) s * 2 + 1) * (size_t) b->cap, dr, (size_t) n * 2, hipMemcpyDeviceToDevice));
     return 0;
@@ -1853,6 +2027,16 @@ lamehip_batch_encode(lamehip_batch * b)
         b->out_cap = total;
         HIPCHK(hipMalloc((void **) &b->d_out, (size_t) total * sizeof(LhFrameOut)));
     }
+    if (b->n_dirty && lamehip_batch_upload(b) != 0)
+        return LAMEHIP_ERR_DEVICE;
+    if (b->up_pending) {
+        HIPCHK(hipStreamWaitEvent(b->stream, b->ev_up, 0));
+        b->up_pending = 0;
+    }
+    if (b->down_pending) {      /* the previous round's bytes must have left d_bytes */
+        HIPCHK(hipStreamWaitEvent(b->stream, b->ev_down, 0));
+        b->down_pending = 0;
+    }
     HIPCHK(hipMemcpyAsync(b->d_desc, b->h_desc.data(), (size_t) b->B * sizeof(LhStreamDesc),
                           hipMemcpyHostToDevice, b->stream));
     HIPCHK(hipEventRecord(b->ev0, b->stream));
@@ -1865,7 +2049,74 @@ lamehip_batch_encode(lamehip_batch * b)
     }
     HIPCHK(hipEventRecord(b->ev1, b->stream));
     b->encoded = 1;
+    b->fetched = 0;
     return 0;
+}
+
+/* Device-packed batches: start the way back -- per stream (bytes, status), then the bytes themselves, into
+ * pinned host memory, asynchronously on the batch's stream (behind the kernel).  lamehip_batch_bytes_ptr /
+ * lamehip_batch_get_bytes_all wait for it.  Calling it right after lamehip_batch_encode lets the copies of this
+ * batch run under the next batch's kernel. */
+extern "C" int
+lamehip_batch_fetch(lamehip_batch * b)
+{
+    LhDeviceScope const on_device(b ? b->device : -1);
+    long long total = 0;
+    if (!b || !b->encoded || !b->dev_pack)
+        return -1;
+    if (b->fetched)
+        return 0;
+    for (int s = 0; s < b->B; s++)
+        total += b->h_desc[(size_t) s].bytes_cap;
+    if (!b->d_sum) {
+        HIPCHK(hipMalloc((void **) &b->d_sum, (size_t) b->B * 2 * sizeof(long long)));
+        HIPCHK(hipHostMalloc((void **) &b->h_sum, (size_t) b->B * 2 * sizeof(long long), 0));
+    }
+    if (total > b->h_bytes_cap) {
+        unsigned char *nb = nullptr;
+        HIPCHK(hipHostMalloc((void **) &nb, (size_t) (total > 0 ? total : 1), 0));
+        if (b->h_bytes)
+            (void) hipHostFree(b->h_bytes);
+        b->h_bytes = nb;
+        b->h_bytes_cap = total;
+    }
+    if (batch_copy_streams(b) != 0)
+        return LAMEHIP_ERR_DEVICE;
+    {
+        int const rc = lh_launch_summary(b->d_state, b->d_sum, b->B, (void *) b->stream);
+        if (rc)
+            return set_err("summary launch", (hipError_t) rc);
+    }
+    HIPCHK(hipEventRecord(b->ev_sum, b->stream));
+    HIPCHK(hipStreamWaitEvent(b->down_stream, b->ev_sum, 0));
+    HIPCHK(hipMemcpyAsync(b->h_sum, b->d_sum, (size_t) b->B * 2 * sizeof(long long), hipMemcpyDeviceToHost, b->down_stream));
+    if (total > 0)
+        HIPCHK(hipMemcpyAsync(b->h_bytes, b->d_bytes, (size_t) total, hipMemcpyDeviceToHost, b->down_stream));
+    HIPCHK(hipEventRecord(b->ev_down, b->down_stream));
+    b->down_pending = 1;
+    b->fetched = 1;
+    return 0;
+}
+
+/* stream s's finished bytes in the batch's pinned buffer (valid until the batch is encoded again): returns
+ * their number, or a negative code */
+extern "C" long
+lamehip_batch_bytes_ptr(lamehip_batch * b, int s, const unsigned char **p)
+{
+    LhDeviceScope const on_device(b ? b->device : -1);
+    long    n;
+    if (!b || s < 0 || s >= b->B || !b->encoded || !b->dev_pack || !p)
+        return -1;
+    if (!b->fetched && lamehip_batch_fetch(b) != 0)
+        return LAMEHIP_ERR_DEVICE;
+    HIPCHK(hipStreamSynchronize(b->down_stream));
+    if (b->h_sum[2 * s + 1] != 0) {
+        snprintf(g_err, sizeof(g_err), "device bit packer reported status %d for stream %d", (int) b->h_sum[2 * s + 1], s);
+        return LAMEHIP_ERR_PAYLOAD;
+    }
+    n = (b->nframes[(size_t) s] == 0) ? 0 : (long) b->h_sum[2 * s];
+    *p = b->h_bytes + b->bytes_off[(size_t) s];
+    return n;
 }
 
 /* Device bit packing: the kernel also assembles each stream's finished MP3 bytes in HBM
@@ -1948,16 +2199,15 @@ extern "C" int
 lamehip_batch_get_bytes_all(lamehip_batch * b, unsigned char *out, long out_stride, long *sizes)
 {
     LhDeviceScope const on_device(b ? b->device : -1);
-    std::vector < LhStreamState > st;
     int     bad = 0;
     if (!b || !b->encoded || !b->dev_pack || !out || !sizes)
         return -1;
-    st.resize((size_t) b->B);
-    HIPCHK(hipStreamSynchronize(b->stream));
-    HIPCHK(hipMemcpy(st.data(), b->d_state, st.size() * sizeof(LhStreamState), hipMemcpyDeviceToHost));
+    if (lamehip_batch_fetch(b) != 0)
+        return LAMEHIP_ERR_DEVICE;
+    HIPCHK(hipStreamSynchronize(b->down_stream));
     for (int s = 0; s < b->B; s++) {
-        long    n = (b->nframes[(size_t) s] == 0) ? 0 : (long) st[(size_t) s].em_next_header;
-        if (st[(size_t) s].status != 0)
+        long    n = (b->nframes[(size_t) s] == 0) ? 0 : (long) b->h_sum[2 * s];
+        if (b->h_sum[2 * s + 1] != 0)
             n = LAMEHIP_ERR_PAYLOAD;
         else if (n > out_stride)
             n = -1;
@@ -1965,10 +2215,8 @@ lamehip_batch_get_bytes_all(lamehip_batch * b, unsigned char *out, long out_stri
         if (n < 0)
             bad++;
         else if (n > 0)
-            HIPCHK(hipMemcpyAsync(out + (size_t) s * (size_t) out_stride, b->d_bytes + b->bytes_off[(size_t) s], (size_t) n,
-                                  hipMemcpyDeviceToHost, b->stream));
+            memcpy(out + (size_t) s * (size_t) out_stride, b->h_bytes + b->bytes_off[(size_t) s], (size_t) n);
     }
-    HIPCHK(hipStreamSynchronize(b->stream));
     return bad ? -1 : 0;
 }
 
@@ -1978,6 +2226,10 @@ lamehip_batch_sync(lamehip_batch * b)
     LhDeviceScope const on_device(b ? b->device : -1);
     if (!b)
         return -1;
+    if (b->up_stream) {
+        HIPCHK(hipStreamSynchronize(b->up_stream));
+        HIPCHK(hipStreamSynchronize(b->down_stream));
+    }
     HIPCHK(hipStreamSynchronize(b->stream));
     if (b->encoded) {
         float   ms = 0;

@@ -865,6 +865,29 @@ lh_scatter_kernel(const int16_t * stage, long stage_stride, int16_t * pool, long
         pool[row * cap + at + i] = stage[row * stage_stride + i];
 }
 
+/* Device-packed batches: what the host needs to know of each stream before it copies the bytes -- how many there
+ * are (the packer's next header position) and the status word -- as two words per stream instead of the
+ * 12 KB of LhStreamState. */
+extern "C" __global__ void __launch_bounds__(256)
+lh_summary_kernel(const LhStreamState * states, long long *sum, int nstreams)
+{
+    int const s = (int) (blockIdx.x * 256 + threadIdx.x);
+    if (s < nstreams) {
+        sum[2 * s] = states[s].em_next_header;
+        sum[2 * s + 1] = (long long) states[s].status;
+    }
+}
+
+extern "C" int
+lh_launch_summary(const LhStreamState * states, long long *sum, int nstreams, void *stream)
+{
+    if (nstreams <= 0)
+        return 0;
+    hipLaunchKernelGGL(lh_summary_kernel, dim3((unsigned) ((nstreams + 255) / 256)), dim3(256), 0, (hipStream_t) stream, states,
+                       sum, nstreams);
+    return (int) hipGetLastError();
+}
+
 extern "C" int
 lh_launch_scatter(const int16_t * stage, long stage_stride, int16_t * pool, long cap, const int *meta, int nstreams,
                   void *stream)

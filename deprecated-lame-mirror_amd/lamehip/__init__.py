@@ -264,6 +264,43 @@ class Batch:
             raise RuntimeError("lamehip_batch_get_bytes_all failed (%d): %s" % (rc, last_error()))
         return out, sizes
 
+    def pcm_host(self):
+        """The pinned host mirror of the s16 pool as an int16 array [streams, 2, capacity] (no copy): fill it, then
+        set_length(s, n) + mark_pcm(s); upload() / encode() move it to HBM with one asynchronous copy."""
+        self.lib.lamehip_batch_pcm_host_ptr.restype = C.c_void_p
+        self.lib.lamehip_batch_pcm_host_ptr.argtypes = [C.c_void_p]
+        p = self.lib.lamehip_batch_pcm_host_ptr(self.b)
+        if not p:
+            raise RuntimeError("no pinned mirror for this batch: %s" % last_error())
+        buf = (C.c_int16 * (self.n * 2 * self.capacity)).from_address(p)
+        return np.frombuffer(buf, dtype=np.int16).reshape(self.n, 2, self.capacity)
+
+    def mark_pcm(self, s):
+        assert self.lib.lamehip_batch_mark_pcm(self.b, s) == 0
+
+    def upload(self):
+        rc = self.lib.lamehip_batch_upload(self.b)
+        if rc:
+            raise RuntimeError("lamehip_batch_upload failed (%d): %s" % (rc, last_error()))
+
+    def fetch(self):
+        """Start the device-packed bytes' way back to pinned host memory (asynchronous, behind the kernel)."""
+        rc = self.lib.lamehip_batch_fetch(self.b)
+        if rc:
+            raise RuntimeError("lamehip_batch_fetch failed (%d): %s" % (rc, last_error()))
+
+    def bytes_view(self, s):
+        """Stream s's finished bytes in the batch's pinned buffer (waits for fetch()); a uint8 view, no copy."""
+        self.lib.lamehip_batch_bytes_ptr.restype = C.c_long
+        self.lib.lamehip_batch_bytes_ptr.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        p = C.c_void_p()
+        k = self.lib.lamehip_batch_bytes_ptr(self.b, s, C.byref(p))
+        if k < 0:
+            raise RuntimeError("lamehip_batch_bytes_ptr failed (%d): %s" % (k, last_error()))
+        if k == 0:
+            return np.zeros(0, dtype=np.uint8)
+        return np.frombuffer((C.c_uint8 * k).from_address(p.value), dtype=np.uint8)
+
     def encode(self, sync=True):
         rc = self.lib.lamehip_batch_encode(self.b)
         if rc:

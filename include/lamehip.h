@@ -226,6 +226,21 @@ int     lamehip_batch_pack_all(lamehip_batch *, int nthreads, unsigned char *out
 int     lamehip_batch_set_device_packing(lamehip_batch *, int on);
 long    lamehip_batch_get_bytes(lamehip_batch *, int stream, unsigned char *out, long out_size);
 int     lamehip_batch_get_bytes_all(lamehip_batch *, unsigned char *out, long out_stride, long *sizes);
+/* Pipelined use (several batches in flight, each on its own HIP stream; replaces the seam of the reference's
+ * frontend loop lame_encode_buffer -> fwrite, frontend/lame_main.c:449-520, for many streams at once):
+ *   lamehip_batch_pcm_host_ptr   pinned mirror of the s16 pool, short[stream][2][capacity]; write the samples there
+ *                                (then lamehip_batch_set_length + lamehip_batch_mark_pcm) or let lamehip_batch_set_pcm
+ *                                copy them there -- NULL for a batch that converts the sample rate;
+ *   lamehip_batch_upload         one asynchronous H2D copy of what changed (lamehip_batch_encode does it if pending);
+ *   lamehip_batch_fetch          after lamehip_batch_encode of a device-packed batch: bytes and per-stream sizes start
+ *                                their way to pinned host memory behind the kernel, asynchronously;
+ *   lamehip_batch_bytes_ptr      waits for them; stream's bytes in place (valid until the next encode), returns their
+ *                                number or a negative code. */
+short  *lamehip_batch_pcm_host_ptr(lamehip_batch *);
+int     lamehip_batch_mark_pcm(lamehip_batch *, int stream);
+int     lamehip_batch_upload(lamehip_batch *);
+int     lamehip_batch_fetch(lamehip_batch *);
+long    lamehip_batch_bytes_ptr(lamehip_batch *, int stream, const unsigned char **bytes);
 /* tag frame + audio frames, like lamehip_batch_pack_tagged, from the device-packed bytes */
 long    lamehip_batch_get_bytes_tagged(lamehip_batch *, int stream, unsigned char *out, long out_size);
 /* raw payload access for tests: copies frames [0, n) of a stream (LhFrameOut[]) */

@@ -731,3 +731,43 @@ def test_sibling_wave_kernel_long_ragged_streams(oracle, monkeypatch):
             assert not struct_diff(want[f], got[f]), (s, f)
     b.close()
     enc.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(brate=128), dict(vbr_q=2), dict(abr=160, channels=1)])
+def test_pipelined_batches_pinned_upload_and_fetch(kw):
+    """lamehip_batch_pcm_host_ptr / _mark_pcm / _upload / _fetch / _bytes_ptr: three batch objects in flight, reused
+    for a second round with other streams; ragged lengths (one row empty); the device-packed bytes that come back
+    through the pinned buffers equal the host packer's, and a batch filled through lamehip_batch_set_pcm (which
+    now copies into the same mirror) gives the same bytes."""
+    enc = lamehip.Encoder(**kw)
+    sr, cap = 44100, 44100 * 2
+    lens = [cap, cap - 777, 0, 5000]
+    objs = [lamehip.Batch(enc, len(lens), cap) for _ in range(3)]
+    for b in objs:
+        b.set_device_packing()
+    for rnd in range(2):
+        pcms = [[helpers.synth_stream(300 + 16 * rnd + 4 * k + i, n, sr) if n else np.zeros((2, 0), np.int16)
+                 for i, n in enumerate(lens)] for k in range(3)]
+        for k, b in enumerate(objs):
+            h = b.pcm_host()
+            for s, x in enumerate(pcms[k]):
+                h[s, :, :x.shape[1]] = x
+                b.set_length(s, x.shape[1])
+                b.mark_pcm(s)
+            b.upload()
+            b.encode(sync=False)
+            b.fetch()
+        for k, b in enumerate(objs):
+            for s in range(len(lens)):
+                assert bytes(b.bytes_view(s)) == b.pack(s), (rnd, k, s)
+    ref = lamehip.Batch(enc, len(lens), cap)
+    for s, x in enumerate(pcms[2]):
+        ref.set_pcm(s, x[0], x[1] if enc.channels == 2 else None)
+    ref.encode()
+    for s in range(len(lens)):
+        assert ref.pack(s) == bytes(objs[2].bytes_view(s)), s
+    ref.close()
+    for b in objs:
+        b.close()
+    enc.close()
