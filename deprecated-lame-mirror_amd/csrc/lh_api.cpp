@@ -33,8 +33,7 @@ extern "C" int lh_launch_encode4(const LhConfig * cfg, const LhTables * T, const
 
 extern "C" int lh_launch_selftest(unsigned *d_out, unsigned seed, void *stream);
 extern "C" int lh_launch_summary(const LhStreamState * states, long long *sum, int nstreams, void *stream);
-extern "C" int lh_launch_scatter(const int16_t * stage, long stage_stride, int16_t * pool, long cap, const int *meta,
-                                 int nstreams, void *stream);
+extern "C" int lh_launch_scatter(const int16_t * arena, int16_t * pool, long cap, const int *seg, int nseg, void *stream);
 
 #define LAME_ID 0xFFF88E3Bu     /* reference util.h:482 */
 
@@ -613,6 +612,7 @@ lame_init_params(lame_t g)
         return -1;
     if (g->inited)
         return g->init_rc;      /* a second call reports what the first one found (also its failure) */
+    g_err[0] = 0;               /* what the report callback prints is this call's, never an earlier call's */
     rc = init_params_once(g);
     if (g->inited)
         g->init_rc = rc;
@@ -633,19 +633,28 @@ init_params_once(lame_t g)
                  "unsupported settings for the MI355X path (need an MPEG-1 output rate, 1 or 2 input channels, CBR / ABR / vbr_mtrh)");
         return -1;
     }
-    g->tab = (LhTables *) malloc(sizeof(LhTables));
+    /* (a call that failed before g->inited may be repeated: what it had allocated is reused) */
     if (!g->tab)
+        g->tab = (LhTables *) malloc(sizeof(LhTables));
+    if (!g->tab) {
+        snprintf(g_err, sizeof(g_err), "out of memory (tables)");
         return -2;
+    }
     if (lh_tables_build(&g->cfg, &aux, g->tab) != 0) {
         snprintf(g_err, sizeof(g_err), "table generation failed");
         return -1;
     }
-    if (lh_bs_init(&g->bs) != 0)
+    if (!g->bs.buf && lh_bs_init(&g->bs) != 0) {
+        snprintf(g_err, sizeof(g_err), "out of memory (bit stream buffer)");
         return -2;
+    }
     if (lh_rs_needed(g->p.samplerate, g->cfg.samplerate)) {
-        g->rs = (LhResampler *) malloc(sizeof(LhResampler));
         if (!g->rs)
+            g->rs = (LhResampler *) malloc(sizeof(LhResampler));
+        if (!g->rs) {
+            snprintf(g_err, sizeof(g_err), "out of memory (sample rate converter)");
             return -2;
+        }
         lh_rs_init(g->rs, g->p.samplerate, g->cfg.samplerate);
     }
     g->inited = 1;              /* host constants are valid from here on (lamehip_get_*) */
@@ -1235,7 +1244,7 @@ struct lamehip_batch {
     std::vector < int >padding; /* encoder_padding per stream (tag frame) */
     /* incremental use (lamehip_batch_append ...): samples in the pool / frames encoded per stream, a
      * packer and the bytes not yet drained per stream, and the pinned staging area of the next
-     * lamehip_batch_encode_available: [descriptors][meta][rows], mirrored in HBM by one copy */
+     * lamehip_batch_encode_available (see h_stage below) */
     int     incremental;
     std::vector < long >fed;
     std::vector < int >done;
@@ -1244,8 +1253,13 @@ struct lamehip_batch {
     std::vector < std::vector < unsigned char > >pending;
     std::vector < LhFrameOut > last;
     std::vector < char >have_last;
+    /* pinned / HBM: [B descriptors][LH_STAGE_SEGS x 4 ints: the chunks][arena of staged samples, back to back] */
     unsigned char *h_stage, *d_stage;
-    long    stage_rows_at, stage_stride, stage_bytes;
+    long    stage_arena_at;     /* byte offset of the arena */
+    long    stage_cap;          /* samples the arena holds */
+    long    stage_used;         /* samples staged */
+    int     stage_nseg;         /* chunks staged */
+    int     finished;           /* lamehip_batch_finish has run: the streams are closed */
     std::vector < LhFrameOut > h_new;
     /* pinned host side of a pipelined batch (lamehip_batch_pcm_host_ptr / _upload / _fetch): the mirror of the
      * s16 pool the caller (or lamehip_batch_set_pcm) writes, which reaches HBM with one asynchronous copy on
@@ -1362,7 +1376,9 @@ lamehip_batch_create_on(int device, const lame_t proto, int nstreams, long capac
     b->padding.assign((size_t) nstreams, 0);
     b->incremental = 0;
     b->h_stage = b->d_stage = nullptr;
-    b->stage_rows_at = b->stage_stride = b->stage_bytes = 0;
+    b->stage_arena_at = b->stage_cap = b->stage_used = 0;
+    b->stage_nseg = 0;
+    b->finished = 0;
     b->h_pcm = nullptr;
     b->row_dirty.assign((size_t) nstreams, 0);
     b->n_dirty = 0;
@@ -1733,14 +1749,17 @@ batch_incremental_begin(lamehip_batch * b)
     return 0;
 }
 
-/* (re)shape the staging area for rows of `stride' samples, keeping what is staged */
+#define LH_STAGE_SEGS 4096       /* chunks per trip to HBM */
+#define LH_STAGE_SAMPLES (8L << 20)     /* the arena: 8 M samples = 16 MB; what is staged beyond goes to HBM at once */
+
+/* the staging area, made once: descriptors, chunk table, arena */
 static int
-batch_stage_reserve(lamehip_batch * b, long stride)
+batch_stage_reserve(lamehip_batch * b)
 {
-    long const rows_at = ((long) b->B * (long) (sizeof(LhStreamDesc) + 2 * sizeof(int)) + 63) & ~63L;
-    long const bytes = rows_at + (long) b->B * 2 * stride * 2;
+    long const arena_at = ((long) b->B * (long) sizeof(LhStreamDesc) + (long) LH_STAGE_SEGS * 16 + 63) & ~63L;
+    long const bytes = arena_at + LH_STAGE_SAMPLES * 2;
     unsigned char *h = nullptr, *d = nullptr;
-    if (stride <= b->stage_stride)
+    if (b->h_stage)
         return 0;
     if (hipHostMalloc((void **) &h, (size_t) bytes, hipHostMallocDefault) != hipSuccess
         || hipMalloc((void **) &d, (size_t) bytes) != hipSuccess) {
@@ -1748,20 +1767,40 @@ batch_stage_reserve(lamehip_batch * b, long stride)
             (void) hipHostFree(h);
         return set_err("staging allocation", hipErrorOutOfMemory);
     }
-    for (int s = 0; s < b->B && b->h_stage; s++)
-        for (int ch = 0; ch < 2; ch++)
-            memcpy(h + rows_at + ((long) (2 * s + ch) * stride) * 2,
-                   b->h_stage + b->stage_rows_at + ((long) (2 * s + ch) * b->stage_stride) * 2,
-                   (size_t) b->staged[(size_t) s] * 2);
-    if (b->h_stage)
-        (void) hipHostFree(b->h_stage);
-    if (b->d_stage)
-        (void) hipFree(b->d_stage);
     b->h_stage = h;
     b->d_stage = d;
-    b->stage_rows_at = rows_at;
-    b->stage_stride = stride;
-    b->stage_bytes = bytes;
+    b->stage_arena_at = arena_at;
+    b->stage_cap = LH_STAGE_SAMPLES;
+    b->stage_used = 0;
+    b->stage_nseg = 0;
+    return 0;
+}
+
+/* what is staged goes to the pool: one copy of the chunk table and of the arena's bytes in use, one scatter
+ * launch; wait = the arena is free again on return (it is about to be refilled) */
+static int
+batch_stage_flush(lamehip_batch * b, int wait)
+{
+    size_t const segs_at = (size_t) b->B * sizeof(LhStreamDesc);
+    if (b->stage_nseg > 0) {
+        int     rc;
+        HIPCHK(hipMemcpyAsync(b->d_stage + segs_at, b->h_stage + segs_at, (size_t) b->stage_nseg * 16, hipMemcpyHostToDevice,
+                              b->stream));
+        HIPCHK(hipMemcpyAsync(b->d_stage + b->stage_arena_at, b->h_stage + b->stage_arena_at, (size_t) b->stage_used * 2,
+                              hipMemcpyHostToDevice, b->stream));
+        rc = lh_launch_scatter((const int16_t *) (b->d_stage + b->stage_arena_at), b->d_pcm, b->cap,
+                               (const int *) (b->d_stage + segs_at), b->stage_nseg, (void *) b->stream);
+        if (rc)
+            return set_err("scatter launch", (hipError_t) rc);
+        for (int s = 0; s < b->B; s++) {
+            b->fed[(size_t) s] += b->staged[(size_t) s];
+            b->staged[(size_t) s] = 0;
+        }
+        b->stage_nseg = 0;
+        b->stage_used = 0;
+        if (wait)
+            HIPCHK(hipStreamSynchronize(b->stream));
+    }
     return 0;
 }
 
@@ -1772,30 +1811,46 @@ lamehip_batch_append(lamehip_batch * b, int s, const short *l, const short *r, i
     int     rc;
     if (!b || s < 0 || s >= b->B || n < 0 || (n > 0 && !l))
         return -1;
+    if (b->finished) {
+        snprintf(g_err, sizeof(g_err), "lamehip_batch_append: the batch is finished (lamehip_batch_reset starts it over)");
+        return -1;
+    }
     if ((rc = batch_incremental_begin(b)) != 0)
         return rc;
+    if (n == 0)
+        return 0;
     if (b->cfg.channels == 1 && b->cfg.pcm_mix == 0.0f)
         r = l;
-    if (n > 0 && !r)
+    if (!r)
         return -1;
     if (b->fed[(size_t) s] + b->staged[(size_t) s] + n > b->cap) {
         snprintf(g_err, sizeof(g_err), "lamehip_batch_append: stream %d would exceed the batch's capacity of %ld samples", s, b->cap);
         return -1;
     }
-    if (b->staged[(size_t) s] + n > b->stage_stride) {
-        long    want = 2304;
-        while (want < b->staged[(size_t) s] + n)
-            want *= 2;
-        if ((rc = batch_stage_reserve(b, want)) != 0)
-            return rc;
+    if ((rc = batch_stage_reserve(b)) != 0)
+        return rc;
+    /* pieces of at most half the arena; when the arena or the chunk table is full, what is staged leaves for HBM */
+    while (n > 0) {
+        int const piece = ((long) n > b->stage_cap / 4) ? (int) (b->stage_cap / 4) : n;
+        int    *seg;
+        int16_t *arena = (int16_t *) (b->h_stage + b->stage_arena_at);
+        if (b->stage_used + 2L * piece > b->stage_cap || b->stage_nseg == LH_STAGE_SEGS)
+            if ((rc = batch_stage_flush(b, 1)) != 0)
+                return rc;
+        seg = (int *) (b->h_stage + (size_t) b->B * sizeof(LhStreamDesc)) + 4 * b->stage_nseg;
+        seg[0] = (int) b->stage_used;
+        seg[1] = s;
+        seg[2] = (int) (b->fed[(size_t) s] + b->staged[(size_t) s]);
+        seg[3] = piece;
+        memcpy(arena + b->stage_used, l, (size_t) piece * 2);
+        memcpy(arena + b->stage_used + piece, r, (size_t) piece * 2);
+        b->stage_used += 2L * piece;
+        b->stage_nseg++;
+        b->staged[(size_t) s] += piece;
+        l += piece;
+        r += piece;
+        n -= piece;
     }
-    {
-        unsigned char *rows = b->h_stage + b->stage_rows_at;
-        long const at = b->staged[(size_t) s];
-        memcpy(rows + ((long) (2 * s) * b->stage_stride + at) * 2, l, (size_t) n * 2);
-        memcpy(rows + ((long) (2 * s + 1) * b->stage_stride + at) * 2, r, (size_t) n * 2);
-    }
-    b->staged[(size_t) s] += n;
     return 0;
 }
 
@@ -1814,8 +1869,8 @@ static int
 batch_encode_range(lamehip_batch * b, const std::vector < int >&upto, int end)
 {
     LhStreamDesc *descs = (LhStreamDesc *) b->h_stage;
-    int    *meta = (int *) (b->h_stage + (size_t) b->B * sizeof(LhStreamDesc));
     long long total = 0;
+    int     rc;
     for (int s = 0; s < b->B; s++) {
         LhStreamDesc & d = descs[s];
         int const nf = upto[(size_t) s] - b->done[(size_t) s];
@@ -1828,40 +1883,30 @@ batch_encode_range(lamehip_batch * b, const std::vector < int >&upto, int end)
         d.frame_begin = b->done[(size_t) s];
         d.frame_end = upto[(size_t) s];
         d.flush = end;
-        meta[2 * s] = (int) b->fed[(size_t) s];
-        meta[2 * s + 1] = b->staged[(size_t) s];
         total += nf > 0 ? nf : 0;
     }
     if (total > b->out_cap) {
+        /* the new buffer first: a failed allocation leaves the old one (and its size) in place */
+        LhFrameOut *bigger = nullptr;
+        HIPCHK(hipMalloc((void **) &bigger, (size_t) (total + 1024) * sizeof(LhFrameOut)));
         if (b->d_out)
             (void) hipFree(b->d_out);
+        b->d_out = bigger;
         b->out_cap = total + 1024;
-        HIPCHK(hipMalloc((void **) &b->d_out, (size_t) b->out_cap * sizeof(LhFrameOut)));
     }
-    /* one copy: descriptors, chunk positions and the staged samples of all streams */
-    HIPCHK(hipMemcpyAsync(b->d_stage, b->h_stage, (size_t) b->stage_bytes, hipMemcpyHostToDevice, b->stream));
-    {
-        int     rc = lh_launch_scatter((const int16_t *) (b->d_stage + b->stage_rows_at), b->stage_stride, b->d_pcm, b->cap,
-                                       (const int *) (b->d_stage + (size_t) b->B * sizeof(LhStreamDesc)), b->B,
-                                       (void *) b->stream);
-        if (rc)
-            return set_err("scatter launch", (hipError_t) rc);
-    }
-    for (int s = 0; s < b->B; s++) {
-        b->fed[(size_t) s] += b->staged[(size_t) s];
-        b->staged[(size_t) s] = 0;
-    }
+    /* descriptors, then what is staged (chunk table + the arena's bytes in use), then the scatter */
+    HIPCHK(hipMemcpyAsync(b->d_stage, b->h_stage, (size_t) b->B * sizeof(LhStreamDesc), hipMemcpyHostToDevice, b->stream));
+    if ((rc = batch_stage_flush(b, 0)) != 0)
+        return rc;
     if (total == 0) {
         HIPCHK(hipStreamSynchronize(b->stream));
         return 0;
     }
     HIPCHK(hipEventRecord(b->ev0, b->stream));
-    {
-        int     rc = b->dc.launch(b->d_pcm, (const float *) 0, (const LhStreamDesc *) b->d_stage, b->d_state, b->d_out,
-                                  (uint8_t *) 0, b->B, (void *) b->stream);
-        if (rc)
-            return set_err("kernel launch", (hipError_t) rc);
-    }
+    rc = b->dc.launch(b->d_pcm, (const float *) 0, (const LhStreamDesc *) b->d_stage, b->d_state, b->d_out, (uint8_t *) 0, b->B,
+                      (void *) b->stream);
+    if (rc)
+        return set_err("kernel launch", (hipError_t) rc);
     HIPCHK(hipEventRecord(b->ev1, b->stream));
     b->h_new.resize((size_t) total);
     HIPCHK(hipMemcpyAsync(b->h_new.data(), b->d_out, (size_t) total * sizeof(LhFrameOut), hipMemcpyDeviceToHost, b->stream));
@@ -1898,9 +1943,13 @@ lamehip_batch_encode_available(lamehip_batch * b)
     int     rc;
     if (!b)
         return -1;
+    if (b->finished) {
+        snprintf(g_err, sizeof(g_err), "lamehip_batch_encode_available: the batch is finished (lamehip_batch_reset starts it over)");
+        return -1;
+    }
     if ((rc = batch_incremental_begin(b)) != 0)
         return rc;
-    if ((rc = batch_stage_reserve(b, 2304)) != 0)
+    if ((rc = batch_stage_reserve(b)) != 0)
         return rc;
     upto.resize((size_t) b->B);
     for (int s = 0; s < b->B; s++)
@@ -1918,9 +1967,13 @@ lamehip_batch_finish(lamehip_batch * b)
     int     rc, n;
     if (!b)
         return -1;
+    if (b->finished) {
+        snprintf(g_err, sizeof(g_err), "lamehip_batch_finish: the batch is finished already (lamehip_batch_reset starts it over)");
+        return -1;
+    }
     if ((rc = batch_incremental_begin(b)) != 0)
         return rc;
-    if ((rc = batch_stage_reserve(b, 2304)) != 0)
+    if ((rc = batch_stage_reserve(b)) != 0)
         return rc;
     upto.resize((size_t) b->B);
     for (int s = 0; s < b->B; s++) {
@@ -1942,6 +1995,7 @@ lamehip_batch_finish(lamehip_batch * b)
         k = lh_bs_copy(bs, out.data() + at, 0);
         out.resize(at + (size_t) (k > 0 ? k : 0));
     }
+    b->finished = 1;
     return n;
 }
 
@@ -1976,6 +2030,22 @@ lamehip_batch_reset(lamehip_batch * b)
     LhDeviceScope const on_device(b ? b->device : -1);
     if (!b)
         return -1;
+    if (b->incremental) {
+        /* an incremental batch starts over: nothing fed, nothing staged, fresh packers, nothing left to drain */
+        for (int s = 0; s < b->B; s++) {
+            lh_bs_free(&b->packer[(size_t) s]);
+            if (lh_bs_init_sized(&b->packer[(size_t) s], 65536) != 0)
+                return -2;
+            b->pending[(size_t) s].clear();
+        }
+        b->fed.assign((size_t) b->B, 0);
+        b->done.assign((size_t) b->B, 0);
+        b->staged.assign((size_t) b->B, 0);
+        b->have_last.assign((size_t) b->B, 0);
+        b->stage_used = 0;
+        b->stage_nseg = 0;
+        b->finished = 0;
+    }
     return batch_reset_states(b);
 }
 
@@ -1987,6 +2057,10 @@ lamehip_batch_encode(lamehip_batch * b)
     int     max_frame_bytes;
     if (!b)
         return -1;
+    if (b->incremental) {
+        snprintf(g_err, sizeof(g_err), "lamehip_batch_encode: this batch is fed with lamehip_batch_append (incremental use)");
+        return -1;
+    }
     /* a batch that has been encoded starts over: every call encodes the streams from their first
      * sample, so the carried state must be the initial one */
     if (b->encoded && batch_reset_states(b) != 0)
@@ -2015,17 +2089,22 @@ lamehip_batch_encode(lamehip_batch * b)
         bytes_total += d.bytes_cap;
         total += b->nframes[(size_t) s];
     }
+    /* (a new buffer first: a failed allocation leaves the old one and its size in place) */
     if (b->dev_pack && bytes_total > b->bytes_cap) {
+        uint8_t *bigger = nullptr;
+        HIPCHK(hipMalloc((void **) &bigger, (size_t) bytes_total));
         if (b->d_bytes)
             (void) hipFree(b->d_bytes);
+        b->d_bytes = bigger;
         b->bytes_cap = bytes_total;
-        HIPCHK(hipMalloc((void **) &b->d_bytes, (size_t) bytes_total));
     }
     if (total > b->out_cap) {
+        LhFrameOut *bigger = nullptr;
+        HIPCHK(hipMalloc((void **) &bigger, (size_t) total * sizeof(LhFrameOut)));
         if (b->d_out)
             (void) hipFree(b->d_out);
+        b->d_out = bigger;
         b->out_cap = total;
-        HIPCHK(hipMalloc((void **) &b->d_out, (size_t) total * sizeof(LhFrameOut)));
     }
     if (b->n_dirty && lamehip_batch_upload(b) != 0)
         return LAMEHIP_ERR_DEVICE;

@@ -852,17 +852,18 @@ lh_launch_selftest(unsigned *d_out, unsigned seed, void *stream)
     return (int) hipGetLastError();
 }
 
-/* Incremental batches (lamehip_batch_append / _encode_available): the chunks the host staged for the
- * streams, rows [stream][channel][stage_stride] of one pinned buffer that reached HBM with a single
- * copy, go to their places in the PCM pool.  meta[2 s] = where stream s's chunk starts in its pool
- * row, meta[2 s + 1] = its length. */
+/* Incremental batches (lamehip_batch_append / _encode_available): the chunks the host staged go to their
+ * places in the PCM pool.  The chunks lie back to back in one pinned arena (a chunk = its left samples, then
+ * its right samples) that reached HBM with a single copy of the bytes in use; seg[4 k .. 4 k + 3] = where
+ * chunk k starts in the arena (samples), its stream, where it goes in the stream's pool rows, its length. */
 extern "C" __global__ void __launch_bounds__(256)
-lh_scatter_kernel(const int16_t * stage, long stage_stride, int16_t * pool, long cap, const int *meta)
+lh_scatter_kernel(const int16_t * arena, int16_t * pool, long cap, const int *seg)
 {
-    long const row = (long) blockIdx.x;         /* 2 * stream + channel */
-    int const at = meta[2 * (row >> 1)], n = meta[2 * (row >> 1) + 1];
+    int const k = (int) (blockIdx.x >> 1), ch = (int) (blockIdx.x & 1);
+    long const from = (long) seg[4 * k], row = 2L * seg[4 * k + 1] + ch;
+    int const at = seg[4 * k + 2], n = seg[4 * k + 3];
     for (int i = (int) threadIdx.x; i < n; i += 256)
-        pool[row * cap + at + i] = stage[row * stage_stride + i];
+        pool[row * cap + at + i] = arena[from + (long) ch * n + i];
 }
 
 /* Device-packed batches: what the host needs to know of each stream before it copies the bytes -- how many there
@@ -889,13 +890,12 @@ lh_launch_summary(const LhStreamState * states, long long *sum, int nstreams, vo
 }
 
 extern "C" int
-lh_launch_scatter(const int16_t * stage, long stage_stride, int16_t * pool, long cap, const int *meta, int nstreams,
-                  void *stream)
+lh_launch_scatter(const int16_t * arena, int16_t * pool, long cap, const int *seg, int nseg, void *stream)
 {
-    if (nstreams <= 0)
+    if (nseg <= 0)
         return 0;
-    hipLaunchKernelGGL(lh_scatter_kernel, dim3((unsigned) (2 * nstreams)), dim3(256), 0, (hipStream_t) stream, stage,
-                       stage_stride, pool, cap, meta);
+    hipLaunchKernelGGL(lh_scatter_kernel, dim3((unsigned) (2 * nseg)), dim3(256), 0, (hipStream_t) stream, arena, pool, cap,
+                       seg);
     return (int) hipGetLastError();
 }
 

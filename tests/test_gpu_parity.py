@@ -771,3 +771,42 @@ def test_pipelined_batches_pinned_upload_and_fetch(kw):
     for b in objs:
         b.close()
     enc.close()
+
+
+@pytest.mark.gpu
+def test_incremental_batch_lifecycle_and_large_chunks():
+    """lamehip_batch_append with nothing (first call), with one chunk larger than the staging arena allows in one
+    piece (60 s: split and flushed on the way), interleaved small chunks; the bytes equal the one-shot batch's.
+    After lamehip_batch_finish the batch refuses append / encode_available / finish / encode until
+    lamehip_batch_reset, after which the same input gives the same bytes again."""
+    enc = lamehip.Encoder(44100, brate=128)
+    n_long, n_short = 44100 * 60, 44100 * 2 + 123
+    x0 = helpers.synth_stream(501, 44100 * 5)
+    x0 = np.tile(x0, (1, 12))[:, :n_long]
+    x1 = helpers.synth_stream(502, n_short)
+    one = lamehip.Batch(enc, 2, n_long + 16)
+    one.set_pcm(0, x0[0], x0[1])
+    one.set_pcm(1, x1[0], x1[1])
+    one.encode()
+    want = [one.pack(0), one.pack(1)]
+    one.close()
+    b = lamehip.Batch(enc, 2, n_long + 16)
+    for attempt in range(2):
+        b.append(0, np.zeros(0, np.int16), np.zeros(0, np.int16))      # nothing, as the very first call
+        b.append(0, x0[0], x0[1])                                       # 2.6 M samples at once
+        out = [b"", b""]
+        for at in range(0, n_short, 5000):                              # small chunks of the other stream, encoded as they come
+            b.append(1, x1[0, at:at + 5000], x1[1, at:at + 5000])
+            b.encode_available()
+            for s in range(2):
+                out[s] += b.drain(s, 1 << 24)
+        b.finish()
+        for s in range(2):
+            out[s] += b.drain(s, 1 << 24)
+        assert out == want, attempt
+        for call in (lambda: b.append(1, x1[0, :10], x1[1, :10]), b.encode_available, b.finish, b.encode):
+            with pytest.raises(RuntimeError):
+                call()
+        b.reset()
+    b.close()
+    enc.close()
