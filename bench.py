@@ -34,14 +34,18 @@ CPU_SAMPLE_SECONDS = 20.0           # audio per stream in the CPU leg
 
 
 def synth_on_device(torch, batch, n, sr, seed0, device, chunk=32, bursts_per_s=3.0):
-    """Seeded music-like stereo s16 PCM generated on the GPU (no dataset access): 8 partials with
-    independent phases per channel + low-level noise + decaying noise bursts (castanet-like, they
-    trigger short blocks) bursts_per_s times a second.  Returns an int16 tensor [batch, 2, n]."""
+    """SURVEY.md 8(d)'s synthetic signal (the recipe of tests/helpers.py:synth_stream), generated on the GPU with
+    torch's generator (no dataset access): eight partials 220 * 2^(k/2) Hz at 0.5/(k+1) with a 5 Hz vibrato of
+    0.1 % and independent phases per channel, band-limited brown noise (a random walk minus its 200-sample moving
+    average) at 0.02 of full scale, decaying white-noise bursts (castanet-like: they trigger short blocks)
+    bursts_per_s times a second, normalised to 0.8 of full scale.  Returns an int16 tensor [batch, 2, n]."""
     out = torch.empty((batch, 2, n), dtype=torch.int16, device=device)
-    t = torch.arange(n, device=device, dtype=torch.float32) / sr
+    t = torch.arange(n, device=device, dtype=torch.float64) / sr
+    vib = 1.0 + 0.001 * torch.sin(2 * 3.141592653589793 * 5 * t)
     step = max(int(sr / bursts_per_s), 1)
     blen = min(2000, step)
     env = torch.exp(-torch.arange(blen, device=device, dtype=torch.float32) / 300.0)
+    k200 = 200
     for b0 in range(0, batch, chunk):
         b1 = min(batch, b0 + chunk)
         g = torch.Generator(device=device)
@@ -49,14 +53,23 @@ def synth_on_device(torch, batch, n, sr, seed0, device, chunk=32, bursts_per_s=3
         x = torch.zeros((b1 - b0, 2, n), device=device)
         for k in range(8):
             f = 220.0 * 2 ** (k / 2.0)
-            ph = torch.rand((b1 - b0, 2, 1), generator=g, device=device) * 6.2831853
-            x += (0.5 / (k + 1)) * torch.sin(6.2831853 * f * t + ph)
-        x += 0.01 * torch.randn((b1 - b0, 2, n), generator=g, device=device)
+            ph = torch.rand((b1 - b0, 2, 1), generator=g, device=device, dtype=torch.float64) * 6.283185307179586
+            x += ((0.5 / (k + 1)) * torch.sin(6.283185307179586 * f * t * vib + ph)).float()
+        brown = torch.cumsum(torch.randn((b1 - b0, 2, n), generator=g, device=device, dtype=torch.float64), dim=2)
+        padded = torch.cat([brown[:, :, :1].expand(-1, -1, k200), brown], dim=2)
+        cs = torch.cumsum(padded, dim=2)
+        brown = brown - (cs[:, :, k200:] - cs[:, :, :-k200]) / k200
+        x += (0.02 * brown / (brown.abs().amax(dim=(1, 2), keepdim=True) + 1e-9)).float()
+        del brown, padded, cs
         for s in range(step // 2, n - blen, step):
             x[:, :, s:s + blen] += 0.6 * env * torch.randn((b1 - b0, 2, blen), generator=g, device=device)
         x = x / x.abs().amax(dim=(1, 2), keepdim=True) * (0.8 * 32767)
         out[b0:b1] = x.to(torch.int16)
     return out
+
+
+SIGNAL = ("SURVEY 8(d) recipe on the device: 8 partials with 5 Hz vibrato, band-limited brown noise, noise bursts "
+          "%.0f/s, seeded per stream")
 
 
 # ---------------------------------------------------------------------------------------------
@@ -262,15 +275,30 @@ def spawn_ranks(args, argv):
     return rc
 
 
+def csrc_digest():
+    """SHA-256 over the device / host sources of the library (csrc/*.h, *.hip, *.c, *.cpp, Makefile, in name
+    order): what a recorded profile is tied to (there is no git on the GPU box)."""
+    import hashlib
+    d = os.path.join(ROOT, "deprecated-lame-mirror_amd", "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".h", ".hip", ".c", ".cpp")) or name == "Makefile":
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def recorded(name):
-    """A measurement that needs its own profiler pass (PMC counters), recorded under profiles/ with
-    the commit and date it was taken at; bench.py quotes it, it does not re-measure it."""
+    """A measurement that needs its own profiler pass (PMC counters), recorded under profiles/ with the digest
+    of the sources it was taken from; bench.py quotes it only while the sources are the same."""
     path = os.path.join(ROOT, "profiles", name)
     if os.path.exists(path):
         try:
-            return json.load(open(path))
+            rec = json.load(open(path))
         except ValueError:
             return None
+        rec["stale"] = rec.get("csrc_sha256") != csrc_digest()
+        return rec
     return None
 
 
@@ -294,28 +322,63 @@ def check_against_oracle(batch, enc, host_streams, which):
     return {"streams": list(which), "frames_each": len(batch.get_frames(which[0])), "result": "identical"}
 
 
-def short_run(torch, lamehip, dev, device_index, sr, B, seconds, steps, seed, bursts_per_s, **enc_kw):
-    """A small batch of another configuration (extras; never the headline value)."""
+def roofline_block(frames, kavg_s, pmc_name):
+    """HBM roofline of lh_encode_kernel: algorithmic bytes of the launch over the kernel's average time (HIP
+    events on the batch's stream); traffic = the recorded PMC figure per frame x the frames of this launch, only
+    while the record was taken from these very sources."""
+    achieved = frames * ALG_BYTES_PER_FRAME / kavg_s / 1e9
+    pmc = recorded(pmc_name) or {}
+    fresh = bool(pmc) and not pmc.get("stale") and pmc.get("hbm_bytes_per_frame")
+    block = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": round(achieved / HBM_PEAK_GBS, 6),
+             "traffic": int(pmc["hbm_bytes_per_frame"] * frames) if fresh else None,
+             "traffic_note": ("%.1f KB per frame x the frames of this launch; per-frame figure recorded with rocprofv3 "
+                              "--pmc (FETCH_SIZE x 2 + WRITE_SIZE) on %s from these sources (digest %s), workload `%s'; "
+                              "bench.py does not run the profiler"
+                              % (pmc.get("hbm_bytes_per_frame", 0) / 1e3, pmc.get("date"), pmc.get("csrc_sha256"),
+                                 pmc.get("workload"))) if fresh
+             else ("stale profile: profiles/%s was recorded from other sources (digest %s, now %s)"
+                   % (pmc_name, pmc.get("csrc_sha256"), csrc_digest())) if pmc else "no recorded PMC profile in profiles/",
+             "valu_frac": pmc.get("valu_frac") if fresh else None,
+             "issue_active_frac": pmc.get("issue_active_frac") if fresh else None,
+             "bound_in_practice": "instruction issue of a serial search: one wave issues at most one instruction per "
+                                  "~5 cycles (tools/ubench/lat2.hip), two waves per stream; a SIMD does not issue "
+                                  "faster for four busy waves than 1.4 x what it does for two",
+             "kernel": "lh_encode_kernel", "kernel_ms_avg": round(kavg_s * 1e3, 3),
+             "alg_bytes_per_frame": ALG_BYTES_PER_FRAME, "frames_per_launch": frames}
+    return block
+
+
+def short_run(torch, lamehip, dev, device_index, sr, B, seconds, steps, seed, bursts_per_s, pmc_name, **enc_kw):
+    """A small batch of another BASELINE configuration (extras; never the headline value): its own oracle check
+    (two streams, every frame) and its own roofline block."""
     n = int(seconds * sr)
     enc = lamehip.Encoder(sr, device=device_index, **enc_kw)
     b = lamehip.Batch(enc, B, n, device=device_index)
     pcm = synth_on_device(torch, B, n, sr, seed, dev, bursts_per_s=bursts_per_s)
     for s in range(B):
         b.set_pcm_device(s, pcm[s, 0].data_ptr(), pcm[s, 1].data_ptr(), n)
+    which = [0, B - 1] if B > 1 else [0]
+    host_streams = [pcm[s].cpu().numpy() for s in which]
     del pcm
     b.encode(sync=True)
     torch.cuda.synchronize()
+    kms = []
     t0 = time.perf_counter()
     for _ in range(steps):
         b.encode(sync=True)
+        kms.append(b.kernel_ms())
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    checked = check_against_oracle(b, enc, host_streams, which)
     assert len(b.pack(0)) > 0
+    frames = sum(b.frames(s) for s in range(B))
     b.close()
     enc.close()
     v = B * seconds * steps / dt
     return {"value": round(v, 1), "unit": "x real-time", "per_stream_x_realtime": round(v / B, 2),
-            "workload": "batch=%d x %.0f s, %d Hz" % (B, seconds, sr), "steps": steps}
+            "workload": "batch=%d x %.0f s, %d Hz; %s" % (B, seconds, sr, SIGNAL % bursts_per_s), "steps": steps,
+            "checked_against_oracle": checked, "roofline": roofline_block(frames, sum(kms) / len(kms) / 1e3, pmc_name)}
 
 
 def main():
@@ -405,15 +468,13 @@ def main():
         audio_s = world * B * args.seconds * args.steps
         value = audio_s / dt
         kavg = sum(kernel_ms) / len(kernel_ms) / 1e3
-        achieved = frames * ALG_BYTES_PER_FRAME / kavg / 1e9
-        pmc = recorded("r02_pmc.json") or {}
         what = ("ABR%d" % args.abr if args.abr is not None else "CBR128" if args.vbr is None else "VBR -V%d" % args.vbr)
         res = {
             "metric": "encoded audio seconds/sec (x real-time) at 44.1kHz stereo " + what,
             "value": round(value, 1), "unit": "x real-time", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic: " + SIGNAL % 3.0,
             "config": {"workload": ("batch=%d synthetic %.1f kHz stereo streams x %.0f s, CBR %d kb/s, "
                                     "per GPU (BASELINE config[1])" % (B, sr / 1000.0, args.seconds, args.brate))
                        if args.vbr is None and args.abr is None else
@@ -428,21 +489,7 @@ def main():
                        "ranks": "spawned by bench.py (file barrier)" if "LAMEHIP_BENCH_RDV" in os.environ
                        else ("launcher (gloo barrier on the CPU)" if world > 1 else "single process"),
                        "devices_visible": ndev},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                         "traffic": (int(pmc["hbm_bytes_per_frame"] * frames) if pmc.get("hbm_bytes_per_frame")
-                                     else None),
-                         "traffic_note": ("%.1f KB per frame x the frames of this launch; per-frame figure recorded "
-                                          "with rocprofv3 --pmc (FETCH_SIZE x 2 + WRITE_SIZE) on %s, commit %s, "
-                                          "workload `%s'; bench.py does not run the profiler"
-                                          % (pmc.get("hbm_bytes_per_frame", 0) / 1e3, pmc.get("date"), pmc.get("commit"),
-                                             pmc.get("workload")))
-                         if pmc else "no recorded PMC profile in profiles/",
-                         "valu_frac": pmc.get("valu_frac"), "issue_active_frac": pmc.get("issue_active_frac"),
-                         "bound_in_practice": "instruction issue of a serial search: one wave issues at most one "
-                                              "instruction per ~5 cycles (tools/ubench/lat2.hip), two waves per stream",
-                         "kernel": "lh_encode_kernel", "kernel_ms_avg": round(kavg * 1e3, 3),
-                         "alg_bytes_per_frame": ALG_BYTES_PER_FRAME, "frames_per_launch": frames},
+            "roofline": roofline_block(frames, kavg, "r03_pmc.json" if args.vbr is None else "r03_pmc_vbr2.json"),
             "checked_against_oracle": checked,
         }
         if host_cpu is not None:
@@ -451,9 +498,10 @@ def main():
             batch.close()
             batch = None
             res["extra"] = {
-                "vbr_v2_config2": short_run(torch, lamehip, dev, device_index, 44100, 1024, 5.0, 2, 5000, 3.0, vbr_q=2),
+                "vbr_v2_config2": short_run(torch, lamehip, dev, device_index, 44100, 1024, 5.0, 2, 5000, 3.0,
+                                            "r03_pmc_vbr2.json", vbr_q=2),
                 "cbr320_48k_bursts_config4": short_run(torch, lamehip, dev, device_index, 48000, 1024, 5.0, 2, 9000,
-                                                       40.0, brate=320, mode=1),
+                                                       40.0, "r03_pmc_cbr320.json", brate=320, mode=1),
             }
         if not args.no_end_to_end and not args.no_extras and world == 1:
             if batch is not None:
@@ -465,7 +513,7 @@ def main():
     rdv.close()
 
 
-def end_to_end(torch, lamehip, enc, B, sr, dev, seconds=5.0, rounds=8, nbatch=2):
+def end_to_end(torch, lamehip, enc, B, sr, dev, seconds=10.0, rounds=12, nbatch=2):
     """SURVEY.md 8(d) region R2: s16 PCM in pinned host memory -> H2D -> kernel -> D2H -> mp3 bytes in host
     memory, as a pipeline of `nbatch' batch objects (each with its own HIP stream) that are reused round-robin
     for `rounds' batches of B streams x `seconds': batch n's kernel runs while batch n+1's PCM goes up and batch
@@ -489,6 +537,16 @@ def end_to_end(torch, lamehip, enc, B, sr, dev, seconds=5.0, rounds=8, nbatch=2)
     def mark(b):
         for s in range(B):
             b.mark_pcm(s)
+
+    # -- the same batch HBM-resident, payload only (region R1 on this sample: what the pipeline is held against) --
+    b = objs[0]
+    mark(b)
+    b.encode(sync=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        b.encode(sync=True)
+    resident = 3 * B * seconds / (time.perf_counter() - t0)
 
     # -- device-packed pipeline --
     for b in objs:
@@ -564,7 +622,7 @@ def end_to_end(torch, lamehip, enc, B, sr, dev, seconds=5.0, rounds=8, nbatch=2)
         raise SystemExit("end_to_end: device-packed bytes differ from the host packer's")
     audio = rounds * B * seconds
     return {"value": round(audio / dt_host, 1), "unit": "x real-time", "host_threads": threads,
-            "mp3_bytes_per_batch": res_sizes[0],
+            "mp3_bytes_per_batch": res_sizes[0], "hbm_resident_same_sample": round(resident, 1),
             "device_packed": {"value": round(audio / dt_dev, 1), "unit": "x real-time", "mp3_bytes_per_batch": int(sizes),
                               "one_batch_alone_s": {"h2d": round(p1 - p0, 4), "kernel": round(p2 - p1, 4),
                                                     "d2h": round(p3 - p2, 4)},

@@ -148,6 +148,9 @@ struct lame_global_struct {
     int     have_last;
     LhBitstream bs;
     hipStream_t stream;
+    int     nogap_total, nogap_current;         /* the frontend's --nogap bookkeeping (lame_set_nogap_*) */
+    int     find_replaygain;    /* lame_set_findReplayGain: the title's radio gain goes into the LAME tag */
+    LhReplayGain *rg;
     /* Xing/Info + LAME tag (host bookkeeping, lh_vbrtag.c) */
     LhVbrTag tag;
     int     tag_placeholder_pending;
@@ -257,6 +260,9 @@ lame_init(void)
     memset(&g->tag, 0, sizeof(g->tag));
     g->tag_placeholder_pending = 0;
     g->enc_padding = 0;
+    g->nogap_total = g->nogap_current = 0;
+    g->find_replaygain = 0;
+    g->rg = nullptr;
     return g;
 }
 
@@ -277,6 +283,175 @@ SETTER(lame_set_quality, p.quality, int)
 GETTER(lame_get_quality, g->inited ? g->cfg.quality : g->p.quality, int)
 SETTER(lame_set_bWriteVbrTag, write_vbr_tag, int)
 GETTER(lame_get_bWriteVbrTag, g->write_vbr_tag, int)
+
+/* ---- the frontend's tuning switches (reference set_get.c; semantics in lh_host_init.c:config_apply_tuning) ---- */
+#define FSETTER(name, field) \
+    extern "C" int name(lame_t g, float v) { if (!valid(g)) return -1; g->p.field = v; return 0; }
+#define FGETTER(name, field) \
+    extern "C" float name(const lame_t g) { if (!valid(g)) return 0; return g->p.field; }
+SETTER(lame_set_ATHtype, p.ATHtype, int)                /* lame.h:502 */
+GETTER(lame_get_ATHtype, g->inited ? g->cfg.ATHtype : g->p.ATHtype, int)
+FSETTER(lame_set_ATHcurve, ATHcurve)
+FGETTER(lame_get_ATHcurve, ATHcurve)
+FSETTER(lame_set_ATHlower, ATH_lower_db)                /* lame.h:510 */
+FGETTER(lame_get_ATHlower, ATH_lower_db)
+SETTER(lame_set_athaa_type, p.athaa_type, int)          /* lame.h:514 */
+GETTER(lame_get_athaa_type, g->p.athaa_type, int)
+FSETTER(lame_set_athaa_sensitivity, athaa_sensitivity)  /* lame.h:521 */
+FGETTER(lame_get_athaa_sensitivity, athaa_sensitivity)
+SETTER(lame_set_ATHonly, p.ATHonly, int)                /* lame.h:490 */
+GETTER(lame_get_ATHonly, g->p.ATHonly, int)
+SETTER(lame_set_ATHshort, p.ATHshort, int)              /* lame.h:494 */
+GETTER(lame_get_ATHshort, g->p.ATHshort, int)
+SETTER(lame_set_noATH, p.noATH, int)                    /* lame.h:498 */
+GETTER(lame_get_noATH, g->p.noATH, int)
+SETTER(lame_set_highpassfreq, p.highpassfreq, int)      /* lame.h:471 */
+GETTER(lame_get_highpassfreq, g->p.highpassfreq, int)
+SETTER(lame_set_highpasswidth, p.highpasswidth, int)    /* lame.h:475 */
+GETTER(lame_get_highpasswidth, g->p.highpasswidth, int)
+SETTER(lame_set_exp_nspsytune, p.exp_nspsytune, int)    /* lame.h:420 */
+GETTER(lame_get_exp_nspsytune, g->p.exp_nspsytune, int)
+SETTER(lame_set_experimentalY, p.experimentalY, int)    /* lame.h:412 */
+GETTER(lame_get_experimentalY, g->p.experimentalY, int)
+SETTER(lame_set_experimentalZ, p.experimentalZ, int)    /* lame.h:416 */
+GETTER(lame_get_experimentalZ, g->p.experimentalZ, int)
+FSETTER(lame_set_compression_ratio, compression_ratio)  /* lame.h:271 */
+extern "C" float
+lame_get_compression_ratio(const lame_t g)
+{
+    if (!valid(g))
+        return 0;
+    return g->inited ? g->cfg.compression_ratio : g->p.compression_ratio;
+}
+
+extern "C" void
+lame_set_msfix(lame_t g, double msfix)                  /* lame.h:424 */
+{
+    if (valid(g))
+        g->p.msfix = (float) msfix;
+}
+
+extern "C" float
+lame_get_msfix(const lame_t g)
+{
+    return valid(g) ? g->p.msfix : 0;
+}
+
+extern "C" int
+lame_set_interChRatio(lame_t g, float ratio)            /* lame.h:543: 0 .. 1 */
+{
+    if (!valid(g) || !(0 <= ratio && ratio <= 1.0))
+        return -1;
+    g->p.interChRatio = ratio;
+    return 0;
+}
+FGETTER(lame_get_interChRatio, interChRatio)
+
+extern "C" int
+lame_set_useTemporal(lame_t g, int on)                  /* lame.h:538: 0 / 1 */
+{
+    if (!valid(g) || on < 0 || on > 1)
+        return -1;
+    g->p.useTemporal = on;
+    return 0;
+}
+GETTER(lame_get_useTemporal, g->p.useTemporal, int)
+
+extern "C" int
+lame_set_free_format(lame_t g, int on)                  /* lame.h:292: accepted here, refused by lame_init_params */
+{
+    if (!valid(g) || on < 0 || on > 1)
+        return -1;
+    g->p.free_format = on;
+    return 0;
+}
+GETTER(lame_get_free_format, g->p.free_format, int)
+
+/* switches of the reference that have nothing to act on in this library: the decoder (decode_only,
+ * decode_on_the_fly), ReplayGain analysis, assembler variants.  Their setters take the "off" value and refuse
+ * the "on" value; the getters report "off" / 0 like a reference build without those parts. */
+extern "C" int lame_set_decode_only(lame_t g, int v) { return (valid(g) && v == 0) ? 0 : -1; }       /* lame.h:339 */
+extern "C" int lame_get_decode_only(const lame_t) { return 0; }
+extern "C" int lame_set_decode_on_the_fly(lame_t, int) { return -1; }       /* (a reference without DECODE_ON_THE_FLY) */
+extern "C" int lame_get_decode_on_the_fly(const lame_t) { return 0; }
+/* the frontend's default (--replaygain-fast): the input's radio gain is measured on the host beside the encode
+ * (lh_replaygain.c) and stored in the LAME tag */
+extern "C" int
+lame_set_findReplayGain(lame_t g, int on)               /* lame.h:301 */
+{
+    if (!valid(g) || on < 0 || on > 1)
+        return -1;
+    g->find_replaygain = on;
+    return 0;
+}
+GETTER(lame_get_findReplayGain, g->find_replaygain, int)
+GETTER(lame_get_RadioGain, g->tag.radio_gain, int)
+extern "C" int lame_get_AudiophileGain(const lame_t) { return 0; }
+extern "C" float lame_get_PeakSample(const lame_t) { return 0; }
+extern "C" int lame_get_noclipGainChange(const lame_t) { return 0; }
+extern "C" float lame_get_noclipScale(const lame_t) { return 0; }
+extern "C" int lame_set_asm_optimizations(lame_t g, int optim, int) { return valid(g) ? optim : -1; } /* lame.h:325 */
+SETTER(lame_set_nogap_total, nogap_total, int)          /* lame.h:307: bookkeeping of the frontend's --nogap */
+GETTER(lame_get_nogap_total, g->nogap_total, int)
+SETTER(lame_set_nogap_currentindex, nogap_current, int)
+GETTER(lame_get_nogap_currentindex, g->nogap_current, int)
+
+/* reference lame.c: bitrate_table[version][index] */
+extern "C" int
+lame_get_bitrate(int mpeg_version, int table_index)     /* lame.h:1315 */
+{
+    static const int t[3][16] = {
+        {0, 8, 16, 24, 32, 40, 48, 56, 64, 80, 96, 112, 128, 144, 160, -1},
+        {0, 32, 40, 48, 56, 64, 80, 96, 112, 128, 160, 192, 224, 256, 320, -1},
+        {0, 8, 16, 24, 32, 40, 48, 56, 64, -1, -1, -1, -1, -1, -1, -1}
+    };
+    if (0 <= mpeg_version && mpeg_version <= 2 && 0 <= table_index && table_index <= 15)
+        return t[mpeg_version][table_index];
+    return -1;
+}
+
+extern "C" int
+lame_get_samplerate(int mpeg_version, int table_index)  /* lame.h:1319 */
+{
+    static const int t[3][4] = { {22050, 24000, 16000, -1}, {44100, 48000, 32000, -1}, {11025, 12000, 8000, -1} };
+    if (0 <= mpeg_version && mpeg_version <= 2 && 0 <= table_index && table_index <= 3)
+        return t[mpeg_version][table_index];
+    return -1;
+}
+
+/* what this library answers where the reference names itself (version.c): the reference's numbers, since the
+ * streams -- tag frame included -- are the reference's */
+extern "C" const char *get_lame_version(void) { return "3.99.5"; }
+extern "C" const char *get_lame_short_version(void) { return "3.99.5"; }
+extern "C" const char *get_lame_very_short_version(void) { return "LAME3.99r"; }
+extern "C" const char *get_psy_version(void) { return "1.0"; }
+extern "C" const char *get_lame_url(void) { return "http://lame.sf.net"; }
+extern "C" const char *get_lame_os_bitness(void) { return sizeof(void *) == 8 ? "64bits" : sizeof(void *) == 4 ? "32bits" : ""; }
+
+/* lame_print_config / lame_print_internals (lame.h:678, 679): the settings as this library resolved them, through
+ * the handle's msgf (the reference's wording is not reproduced; the frontend only passes the text on) */
+extern "C" void
+lame_print_config(const lame_t g)
+{
+    if (!valid(g) || !g->inited)
+        return;
+    report_through(g->report_msg, "liblamehip (MI355X): %d Hz -> %d Hz, %s, %s, quality %d, lowpass %d Hz\n", g->p.samplerate,
+                   g->cfg.samplerate, g->cfg.mode == LH_MODE_MONO ? "mono" : g->cfg.mode == LH_MODE_JOINT_STEREO ? "joint stereo" :
+                   g->cfg.mode == LH_MODE_DUAL ? "dual channel" : "stereo",
+                   g->cfg.vbr == 0 ? "CBR" : g->cfg.vbr == 3 ? "ABR" : "VBR (new)", g->cfg.quality, g->cfg.lowpassfreq);
+}
+
+extern "C" void
+lame_print_internals(const lame_t g)
+{
+    if (!valid(g) || !g->inited)
+        return;
+    report_through(g->report_msg, "liblamehip internals: bitrate %d kb/s (index %d), noise shaping %d / amp %d / stop %d, "
+                   "best huffman %d, msfix %g, ATH type %d curve %g offset %g dB, temporal masking %d, short blocks %d\n",
+                   g->cfg.avg_bitrate, g->cfg.bitrate_index, g->cfg.noise_shaping, g->cfg.noise_shaping_amp,
+                   g->cfg.noise_shaping_stop, g->cfg.use_best_huffman, (double) g->cfg.msfix, g->cfg.ATHtype,
+                   (double) g->cfg.ATHcurve, (double) g->cfg.ATH_offset_db, g->cfg.use_temporal_masking, g->cfg.short_blocks);
+}
 
 extern "C" int
 lame_set_mode(lame_t g, MPEG_mode m)
@@ -499,13 +674,6 @@ lame_set_force_short_blocks(lame_t g, int v)
 SETTER(lame_set_VBR_mean_bitrate_kbps, p.abr_kbps, int)
 GETTER(lame_get_VBR_mean_bitrate_kbps, g->inited ? g->cfg.vbr_avg_bitrate_kbps : g->p.abr_kbps, int)
 
-extern "C" int
-lame_set_findReplayGain(lame_t g, int v)
-{
-    (void) v;
-    return valid(g) ? 0 : -1;   /* ReplayGain analysis is outside the hot path */
-}
-
 GETTER(lame_get_framesize, 576 * 2, int)
 GETTER(lame_get_frameNum, g->frames_done - g->frame_num_base, int)
 GETTER(lame_get_encoder_delay, LH_ENCDELAY, int)
@@ -657,6 +825,14 @@ init_params_once(lame_t g)
         }
         lh_rs_init(g->rs, g->p.samplerate, g->cfg.samplerate);
     }
+    if (g->find_replaygain) {
+        if (!g->rg)
+            g->rg = (LhReplayGain *) malloc(sizeof(LhReplayGain));
+        if (!g->rg || lh_rg_start(g->rg, g->cfg.samplerate) != 0) {
+            snprintf(g_err, sizeof(g_err), "ReplayGain analysis could not be set up");
+            return -6;          /* the reference's code for it (lame.c:1264-1268) */
+        }
+    }
     g->inited = 1;              /* host constants are valid from here on (lamehip_get_*) */
     /* the tag frame is reserved at the head of the stream (reference InitVbrTag); when it does
      * not fit the reference silently switches it off */
@@ -665,6 +841,10 @@ init_params_once(lame_t g)
     else
         g->write_vbr_tag = 0;
     g->tag.samplerate_in = g->p.samplerate;
+    g->tag.radio_gain_on = g->find_replaygain;
+    g->tag.radio_gain = 0;
+    g->tag.nogap_total = g->nogap_total;
+    g->tag.nogap_current = g->nogap_current;
     if (lamehip_device_count() <= 0) {
         snprintf(g_err, sizeof(g_err), "no HIP device: liblamehip has no CPU encode path");
         g->have_device = 0;
@@ -886,13 +1066,24 @@ encode_buffer_impl(lame_t g, const T * l, const T * r, int nsamples, int jump, f
                 memset(blk[1], 0, sizeof(blk[1]));
             g->hl.insert(g->hl.end(), blk[0], blk[0] + made);
             g->hr.insert(g->hr.end(), blk[1], blk[1] + made);
+            if (g->rg)
+                (void) lh_rg_block(g->rg, blk[0], blk[1], made, g->cfg.channels);       /* reference lame.c:1715-1720 */
             g->fed += made;
             pos += used;
             left -= used;
         }
     }
-    else
+    else {
+        /* (the reference's loop hands the analysis what one fill_buffer call took in: at most a frame's samples) */
+        if (g->rg) {
+            size_t const at = g->hl.size() - (size_t) nsamples;
+            for (int pos = 0; pos < nsamples; pos += 1152) {
+                int const m = nsamples - pos > 1152 ? 1152 : nsamples - pos;
+                (void) lh_rg_block(g->rg, g->hl.data() + at + (size_t) pos, g->hr.data() + at + (size_t) pos, m, g->cfg.channels);
+            }
+        }
         g->fed += nsamples;
+    }
     g->flushed = 0;
     /* a frame is encoded whenever 1904 samples are buffered behind the 528-sample
      * lead-in (reference lame.c:1737-1769) */
@@ -1034,6 +1225,28 @@ lame_encode_flush(lame_t g, unsigned char *mp3buf, int size)
         return 0;               /* reference lame.c:2076-2079 */
     if (g->rs)
         return flush_resampled(g, mp3buf, size);
+    if (g->rg) {
+        /* the reference flushes by feeding zeros through lame_encode_buffer, (mf_needed - mf_size) <= 1152 at a time,
+         * until the frames it owes are out (lame.c:2093-2117); the analysis hears those zeros */
+        static const float zeros[1152] = { 0 };
+        long long fed = g->fed;
+        int     frames = g->frames_done;
+        int const owed = (int) (576 + fed - 1152LL * frames);
+        int     padding = 1152 - (owed % 1152), frames_left;
+        if (padding < 576)
+            padding += 1152;
+        frames_left = (owed + padding) / 1152;
+        while (frames_left > 0) {
+            int     bunch = LH_MF_NEEDED - (int) (LH_MF_START + fed - 1152LL * frames);
+            bunch = bunch > 1152 ? 1152 : (bunch < 1 ? 1 : bunch);
+            (void) lh_rg_block(g->rg, zeros, zeros, bunch, g->cfg.channels);
+            fed += bunch;
+            if (LH_MF_START + fed - 1152LL * frames >= LH_MF_NEEDED) {
+                frames++;
+                frames_left--;
+            }
+        }
+    }
     total = lh_total_frames((long) g->fed);
     g->enc_padding = lh_end_padding((long) g->fed);     /* reference lame.c:2088-2091 */
     if (emit_tag_placeholder(g, mp3buf, size, &written))
@@ -1053,6 +1266,8 @@ finish_stream(lame_t g, unsigned char *mp3buf, int size, int written)
     k = lh_bs_copy(&g->bs, mp3buf + written, size ? size - written : 0);
     if (k < 0)
         return -1;
+    if (g->rg)
+        g->tag.radio_gain = lh_rg_finish(g->rg);        /* save_gain_values, reference lame.c:1565-1580 */
     if (g->write_vbr_tag)
         lh_tag_crc(&g->tag, mp3buf + written, k);
     written += k;
@@ -1116,6 +1331,8 @@ lame_get_lametag_frame(const lame_t g, unsigned char *buffer, size_t size)
 {
     if (!valid(g) || !g->inited || !g->write_vbr_tag)
         return 0;
+    g->tag.nogap_total = g->nogap_total;       /* (the frontend sets these per file, after lame_init_params) */
+    g->tag.nogap_current = g->nogap_current;
     return (size_t) lh_tag_frame(&g->tag, &g->cfg, g->cfg.vbr_q, g->enc_padding,
                                  g->have_last ? g->last_frame.mode_ext : 0, buffer, (long) size);
 }
@@ -1142,6 +1359,7 @@ lame_close(lame_t g)
         lh_bs_free(&g->bs);
     free(g->tab);
     free(g->rs);
+    free(g->rg);
     delete  g;
     return 0;
 }

@@ -30,6 +30,24 @@ typedef struct LhUserParams {
     float   scale, scale_left, scale_right;
     float   vbr_q_frac;          /* lame_set_VBR_quality: the fractional part of -V n.f */
     int     vbr_min_kbps, vbr_max_kbps, vbr_hard_min;   /* -b / -B / -F with VBR or ABR; 0 = not set */
+    /* tuning switches of the frontend's "experimental" section, with the reference's "not set" values
+     * (lame.c:2340-2400): a value the caller left alone takes the bitrate's / quality's preset value
+     * (presets.c SET_OPTION) or the default lame_init_params falls back to (lame.c:1112-1180) */
+    float   msfix;               /* -1 */
+    int     ATHtype;             /* -1 */
+    float   ATHcurve;            /* -1 */
+    float   ATH_lower_db;        /* 0; lame_set_ATHlower */
+    int     athaa_type;          /* -1 */
+    float   athaa_sensitivity;   /* 0 */
+    int     ATHonly, ATHshort, noATH;
+    float   interChRatio;        /* -1 */
+    int     useTemporal;         /* -1 */
+    int     highpassfreq;        /* 0 = none, -1 = off */
+    int     highpasswidth;       /* -1 = default */
+    int     exp_nspsytune;       /* bit 1 safe joint stereo, bits 2.. the bass / alto / treble / sfb21 adjustments */
+    int     experimentalY, experimentalZ;
+    int     free_format;
+    float   compression_ratio;   /* 0 = not set: CBR without a bitrate takes 11.025 (lame.c:622-644) */
 } LhUserParams;
 
 /* values that only feed table generation */
@@ -39,7 +57,10 @@ typedef struct LhInitAux {
     int     vbr_q;               /* VBR_q / VBR_q_frac as psymodel_init sees them (4 / 0 for CBR) */
     float   vbr_q_frac;
     float   athaa_sensitivity;
-    float   adjust_sfb21_db;     /* exp_nspsytune bits 20..25, reference lame.c:1196-1203 */
+    float   adjust_sfb21_db;     /* exp_nspsytune bits 20..25 (+ the treble adjustment), reference lame.c:1196-1203 */
+    float   adjust_bass_db, adjust_alto_db, adjust_treble_db;    /* bits 2..7, 8..13, 14..19 */
+    int     athaa_type;          /* ATH->use_adjust: 3 unless lame_set_athaa_type said otherwise */
+    float   highpass1, highpass2;        /* edges of the polyphase high-pass, as fractions of the Nyquist rate */
     int     samplerate_in;       /* the caller's rate; LhConfig.samplerate is the output rate */
 } LhInitAux;
 
@@ -107,6 +128,8 @@ typedef struct LhVbrTag {
     unsigned long bytes_written;
     uint16_t music_crc;
     int     samplerate_in;       /* source rate for the tag's info byte (lh_tag_init: the output rate) */
+    int     radio_gain_on, radio_gain;   /* lame_set_findReplayGain: the title's gain in tenths of a dB */
+    int     nogap_total, nogap_current;  /* the frontend's --nogap: this title's place in the set */
 } LhVbrTag;
 
 int     lh_tag_init(LhVbrTag * v, const LhConfig * c);
@@ -132,6 +155,22 @@ typedef struct LhResampler {
 int     lh_rs_needed(int rate_in, int rate_out);
 void    lh_rs_init(LhResampler * r, int rate_in, int rate_out);
 int     lh_rs_block(LhResampler * r, int ch, float *out, int want, const float *in, int len, int *used);
+
+/* ---- ReplayGain "radio gain" for the LAME tag (lh_replaygain.c; reference gain_analysis.c) ---- */
+#define LH_RG_BINS 12000        /* 0.01 dB steps up to 120 dB */
+#define LH_RG_MAX_BLOCK 2404    /* a piece never exceeds a 50 ms window at 48 kHz */
+typedef struct LhReplayGain {
+    int     rate_index;          /* row of the filter tables; -1 = off */
+    long    window, filled;      /* samples per 50 ms window / in the current one */
+    double  lsum, rsum;          /* the window's energies so far */
+    float   hist_in[2][10], hist_mid[2][10], hist_out[2][10];   /* the last ten samples before / between / after the filters */
+    uint32_t bins[LH_RG_BINS];
+    float   work[3][10 + LH_RG_MAX_BLOCK];
+} LhReplayGain;
+
+int     lh_rg_start(LhReplayGain * g, int samplerate);
+int     lh_rg_block(LhReplayGain * g, const float *l, const float *r, int n, int channels);
+int     lh_rg_finish(LhReplayGain * g);
 
 #ifdef __cplusplus
 }

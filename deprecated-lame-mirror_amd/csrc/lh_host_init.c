@@ -111,7 +111,7 @@ lh_params_default(LhUserParams * p)
     memset(p, 0, sizeof(*p));
     p->samplerate = 44100;
     p->channels = 2;
-    p->brate = 128;
+    p->brate = 0;               /* reference lame.c:2290: the bitrate then follows from the compression ratio (11.025) */
     p->mode = -1;
     p->quality = -1;
     p->vbr = 0;
@@ -123,6 +123,14 @@ lh_params_default(LhUserParams * p)
     p->lowpasswidth = -1;
     p->scale = p->scale_left = p->scale_right = 1.0f;
     p->samplerate_out = 0;
+    /* "not set" values of the tuning switches (reference lame.c:2355-2384) */
+    p->msfix = -1;
+    p->ATHtype = -1;
+    p->ATHcurve = -1;
+    p->athaa_type = -1;
+    p->interChRatio = -1;
+    p->useTemporal = -1;
+    p->highpasswidth = -1;
 }
 
 /* quality -> algorithm switches (reference lame.c:362-477) */
@@ -352,6 +360,72 @@ vbr_bitrate_limits(const LhUserParams * p, LhConfig * c)
     return 0;
 }
 
+/* The caller's tuning switches on top of what the bitrate's / quality's preset row put into c / aux
+ * (reference presets.c:34-42: a preset value only fills an option the caller left at its "not set" value;
+ * lame.c:1112-1203: what remains unset falls back to a default).  `nspsytune' comes in with the preset's
+ * bits and goes out with the caller's merged in; vbr_new: vbr_mt / vbr_mtrh force ATH type 5 and leave the
+ * temporal masking effect off unless asked for. */
+static int
+config_apply_tuning(const LhUserParams * p, LhConfig * c, LhInitAux * aux, int preset_nspsytune, int preset_sfb21mod,
+                    int vbr_new)
+{
+    int     nsp = p->exp_nspsytune | (preset_nspsytune & 2);
+    if (preset_sfb21mod > 0 && ((nsp >> 20) & 63) == 0)
+        nsp |= preset_sfb21mod << 20;
+    nsp |= 1;
+    if (p->free_format || p->experimentalZ || p->ATHonly)
+        return -1;              /* free format frames, forced short-block analysis, ATH-only thresholds: not on this path */
+    if (fabs(p->msfix - (-1)) > 0)
+        c->msfix = p->msfix;
+    if (fabs(p->ATH_lower_db - 0) > 0) {
+        c->ATH_offset_db = 0 - p->ATH_lower_db;
+        c->ATH_offset_factor = powf(10.f, c->ATH_offset_db * 0.1f);
+    }
+    if (fabs(p->ATHcurve - (-1)) > 0)
+        c->ATHcurve = p->ATHcurve;
+    if (fabs(p->athaa_sensitivity - 0) > 0)
+        aux->athaa_sensitivity = p->athaa_sensitivity;
+    if (fabs(p->interChRatio - (-1)) > 0)
+        c->interChRatio = p->interChRatio;
+    if (c->interChRatio < 0)
+        c->interChRatio = 0;
+    if (!vbr_new && p->ATHtype >= 0)
+        c->ATHtype = p->ATHtype;
+    if (p->useTemporal >= 0)
+        c->use_temporal_masking = p->useTemporal;
+    aux->athaa_type = (p->athaa_type < 0) ? 3 : p->athaa_type;
+    c->ath_flags = (p->noATH ? 1 : 0) | (p->ATHshort ? 4 : 0);
+    c->use_safe_joint_stereo = nsp & 2;
+    {
+        /* six bits each, two's complement, quarter dB (reference lame.c:1181-1203) */
+        float   db[4];
+        int     k;
+        for (k = 0; k < 4; k++) {
+            db[k] = (nsp >> (2 + 6 * k)) & 63;
+            if (db[k] >= 32.f)
+                db[k] -= 64.f;
+            db[k] *= 0.25f;
+        }
+        aux->adjust_bass_db = db[0];
+        aux->adjust_alto_db = db[1];
+        aux->adjust_treble_db = db[2];
+        aux->adjust_sfb21_db = db[3] + db[2];
+    }
+    /* the polyphase high-pass (reference lame.c:859-874) */
+    c->highpassfreq = p->highpassfreq;
+    aux->highpass1 = aux->highpass2 = 0;
+    if (c->highpassfreq > 0) {
+        aux->highpass1 = 2. * c->highpassfreq;
+        if (p->highpasswidth >= 0)
+            aux->highpass2 = 2. * (c->highpassfreq + p->highpasswidth);
+        else
+            aux->highpass2 = (1 + 0.00) * 2. * c->highpassfreq;
+        aux->highpass1 /= c->samplerate;
+        aux->highpass2 /= c->samplerate;
+    }
+    return 0;
+}
+
 /* vbr_mt / vbr_mtrh settings (reference lame.c:661-692, 730-744, 770-776, 972-1004, 1064-1094;
  * presets.c:146-213 apply_vbr_preset with every option still at its default) */
 static int
@@ -459,8 +533,6 @@ config_resolve_vbr(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
     c->interChRatio = (P.interch > 0) ? P.interch : 0;
     if (P.safejoint > 0)
         nspsytune |= 2;
-    if (P.sfb21mod > 0)
-        nspsytune |= P.sfb21mod << 20;
     c->msfix = P.msfix;
     c->minval = P.minval;
     {
@@ -468,14 +540,8 @@ config_resolve_vbr(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
         double const y = (xs > 0.f) ? (10.f * log10(xs)) : 0.f;
         c->ATHfixpoint = P.ath_fixpoint - y;
     }
-    c->use_safe_joint_stereo = nspsytune & 2;
-    {
-        float   db = (nspsytune >> 20) & 63;
-        if (db >= 32.f)
-            db -= 64.f;
-        db *= 0.25f;
-        aux->adjust_sfb21_db = db + 0.f;        /* + adjust_treble_db */
-    }
+    if (config_apply_tuning(p, c, aux, nspsytune, P.sfb21mod, 1) != 0)
+        return -1;
     {
         float   db = c->mask_adjust - 0;
         c->masking_lower_long = pow(10.0, db * 0.1);
@@ -489,7 +555,7 @@ config_resolve_vbr(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
     if (c->quality > 7)
         c->quality = 7;
     apply_quality(c, 0, 0);
-    c->sfb21_extra = P.expY ? 0 : (samplerate_out > 44000);
+    c->sfb21_extra = (P.expY || p->experimentalY) ? 0 : (samplerate_out > 44000);
     c->short_blocks = (c->mode == LH_MODE_MONO || c->mode == LH_MODE_DUAL) ? 0 : 1;
     c->pcm_scale = p->scale * p->scale_left;
     c->pcm_scale_r = p->scale * p->scale_right;
@@ -572,7 +638,7 @@ config_resolve_inner(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
 {
     int     r;
     float   scale, ath_lower_db, maskingadjust, maskingadjust_short;
-    int     noise_shaping = 0, ratio_kbps = 128;
+    int     noise_shaping = 0, ratio_kbps = 128, pinned_out = 0;
 
     memset(c, 0, sizeof(*c));
     memset(aux, 0, sizeof(*aux));
@@ -629,8 +695,31 @@ config_resolve_inner(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
             c->vbr_avg_bitrate_kbps = lh_bitrate_mpeg1[c->vbr_min_bitrate_index];
     }
     else {
-        /* bitrate (reference lame.c:904-915) */
-        c->avg_bitrate = find_nearest_bitrate_mpeg1(p->brate > 0 ? p->brate : 128);
+        /* bitrate (reference lame.c:904-915), or the one that gives the compression ratio the caller asked for
+         * -- 11.025 when there is neither (lame.c:622-644: lame_init leaves brate at 0).  That route also pins the
+         * output rate to the MPEG rate just above 97 % of the input rate */
+        int     brate = (p->brate == 0 && p->abr_kbps != 128) ? p->abr_kbps : p->brate;  /* lame.c:606-607 */
+        double  ratio = p->compression_ratio;
+        if (brate == 0 && ratio == 0)
+            ratio = 11.025;
+        if (ratio > 0) {
+            static const int mpeg_rates[9] = { 8000, 11025, 12000, 16000, 22050, 24000, 32000, 44100, 48000 };
+            int     out = p->samplerate_out, i;
+            if (out == 0) {
+                int const f = (int) (0.97 * p->samplerate);
+                out = 48000;
+                for (i = 0; i < 9; i++)
+                    if (f <= mpeg_rates[i]) {
+                        out = mpeg_rates[i];
+                        break;
+                    }
+            }
+            if (out < 32000)
+                return -1;      /* an MPEG-2 / 2.5 stream: outside this path */
+            brate = out * 16 * c->channels / (1.e3 * ratio);
+            pinned_out = out;
+        }
+        c->avg_bitrate = find_nearest_bitrate_mpeg1(brate);
         for (r = 1; r <= 14; r++)
             if (lh_bitrate_mpeg1[r] == c->avg_bitrate)
                 c->bitrate_index = r;
@@ -651,7 +740,7 @@ config_resolve_inner(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
          * reference lame.c:273-345, 762-767); when it differs from the input rate the input is
          * resampled in front of the encoder */
         {
-            int     out = p->samplerate_out;
+            int     out = p->samplerate_out ? p->samplerate_out : pinned_out;
             if (out == 0) {
                 if (2 * lp > p->samplerate)
                     lp = p->samplerate / 2;
@@ -715,6 +804,8 @@ config_resolve_inner(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
     c->ATH_offset_db = 0 - ath_lower_db;
     c->ATH_offset_factor = powf(10.f, c->ATH_offset_db * 0.1f);
     c->ATHfixpoint = 0;
+    if (config_apply_tuning(p, c, aux, c->use_safe_joint_stereo, 0, 0) != 0)
+        return -1;
     c->pcm_scale = scale * p->scale_left;
     c->pcm_scale_r = scale * p->scale_right;
     c->disable_reservoir = 0;
@@ -834,6 +925,17 @@ build_band_thresholds(const LhConfig * c, LhTables * t)
         t->ath_psfb12[b] *= (t->sfb_s[13] - t->sfb_s[12]);
     }
     t->ath_floor = 10. * log10(quiet_energy(c, -1.));
+    if (c->ath_flags & 1) {
+        /* lame_set_noATH: every band's threshold in quiet at -200 dB (reference quantize_pvt.c:294-307) */
+        for (b = 0; b < LH_SBMAX_L; b++)
+            t->ath_l[b] = 1E-20;
+        for (b = 0; b < LH_PSFB21; b++)
+            t->ath_psfb21[b] = 1E-20;
+        for (b = 0; b < LH_SBMAX_S; b++)
+            t->ath_s[b] = 1E-20;
+        for (b = 0; b < LH_PSFB12; b++)
+            t->ath_psfb12[b] = 1E-20;
+    }
 }
 
 /* ---- quantiser tables ------------------------------------------------------------------- */
@@ -1113,9 +1215,8 @@ build_region_split(LhTables * t)
 }
 
 /* per-band weights on the masking threshold: four groups of bands (bass, alto, treble, the band
- * above the last scalefactor band), each 10^(dB / 10) (reference quantize_pvt.c:375-417; the
- * bass / alto / treble adjustments of exp_nspsytune are 0 on this path, the VBR presets set
- * the sfb21 one) */
+ * above the last scalefactor band), each 10^(dB / 10) (reference quantize_pvt.c:375-417), shifted by
+ * the bass / alto / treble / sfb21 adjustments of lame_set_exp_nspsytune (the VBR presets set the last) */
 static void
 build_band_weights(const LhInitAux * aux, LhTables * t)
 {
@@ -1123,7 +1224,7 @@ build_band_weights(const LhInitAux * aux, LhTables * t)
     static float const group_db_short[4] = { -2.000f, -1.000f, -0.050f, +0.500f };
     static int const last_long[4] = { 6, 13, 20, LH_SBMAX_L - 1 };
     static int const last_short[4] = { 2, 6, 11, LH_SBMAX_S - 1 };
-    float const tune[4] = { 0.f, 0.f, 0.f, aux->adjust_sfb21_db };
+    float const tune[4] = { aux->adjust_bass_db, aux->adjust_alto_db, aux->adjust_treble_db, aux->adjust_sfb21_db };
     int     g, b;
     for (g = 0, b = 0; g < 4; g++) {
         float const db = tune[g] + group_db_long[g];
@@ -1442,7 +1543,7 @@ psymodel_tables(LhConfig * c, const LhInitAux * aux, LhTables * t)
             L->s3ind[p][1] = L->npart - 1;
     /* ATH auto-adjustment and the loudness measure it follows */
     t->ath_decay = pow(10., -12. / 10. * (576. * c->mode_gr / rate));
-    t->ath_use_adjust = 3;
+    t->ath_use_adjust = aux->athaa_type;
     t->aa_sensitivity_p = pow(10.0, aux->athaa_sensitivity / -10.0);
     build_loudness_weights(c, t);
     /* attack detection thresholds: the three sub-windows share one, the fourth has its own */
@@ -1526,6 +1627,7 @@ ppflt_tables(const LhInitAux * aux, LhTables * t)
     float   freq;
     int     lowpass_band = 32;
     float   lowpass1 = aux->lowpass1, lowpass2 = aux->lowpass2;
+    float   highpass1 = aux->highpass1, highpass2 = aux->highpass2;
 
     if (lowpass1 > 0) {
         minband = 999;
@@ -1542,10 +1644,31 @@ ppflt_tables(const LhInitAux * aux, LhTables * t)
             lowpass1 = (minband - .75) / 31.0;
         lowpass2 = lowpass_band / 31.0;
     }
+    /* lame_set_highpassfreq: the bands the filter really has (reference lame.c:140-171) */
+    if (highpass2 > 0 && highpass2 < .9 * (.75 / 31.0))
+        highpass1 = highpass2 = 0;
+    if (highpass2 > 0) {
+        int     maxband = -1, highpass_band = -1;
+        for (band = 0; band <= 31; band++) {
+            freq = band / 31.0;
+            if (freq <= highpass1)
+                highpass_band = highpass_band > band ? highpass_band : band;
+            if (highpass1 < freq && freq < highpass2)
+                maxband = maxband > band ? maxband : band;
+        }
+        highpass1 = highpass_band / 31.0;
+        if (maxband == -1)
+            highpass2 = (highpass_band + .75) / 31.0;
+        else
+            highpass2 = (maxband + .75) / 31.0;
+    }
     for (band = 0; band < 32; band++) {
         float   fc1, fc2;
         freq = band / 31.0f;
-        fc1 = 1.0f;             /* no highpass on this path */
+        if (highpass2 > highpass1)
+            fc1 = filter_coef((highpass2 - freq) / (highpass2 - highpass1 + 1e-20));
+        else
+            fc1 = 1.0f;
         if (lowpass2 > lowpass1)
             fc2 = filter_coef((freq - lowpass1) / (lowpass2 - lowpass1 + 1e-20));
         else

@@ -235,9 +235,9 @@ lh_tag_frame(const LhVbrTag * v, const LhConfig * c, int vbr_q, int enc_padding,
         else
             source_freq = 1;
         /* short_blocks: 2 = dispensed, 3 = forced (lame.h short_block_t) */
-        /* (the reference's "-k" test needs lowpass and highpass both at -1; the highpass never is) */
         if (c->short_blocks == 3 || c->short_blocks == 2
-            || (c->disable_reservoir && c->avg_bitrate < 320) || ath_type == 0 || v->samplerate_in <= 32000)
+            || (c->lowpassfreq == -1 && c->highpassfreq == -1) || (c->disable_reservoir && c->avg_bitrate < 320)
+            || (c->ath_flags & 3) || ath_type == 0 || v->samplerate_in <= 32000)
             non_optimal = 1;
         put_i4(p + k, (uint32_t) quality);
         k += 4;
@@ -248,11 +248,26 @@ lh_tag_frame(const LhVbrTag * v, const LhConfig * c, int vbr_q, int enc_padding,
         p[k++] = lowpass;
         put_i4(p + k, 0);               /* peak signal amplitude: not measured */
         k += 4;
-        put_i2(p + k, 0);               /* radio ReplayGain: not measured */
+        {
+            /* radio ReplayGain (reference VbrTag.c:704-721): name code 1, originator "automatic", sign, |gain| in
+             * tenths of a dB; all zero when it was not measured */
+            unsigned field = 0;
+            if (v->radio_gain_on) {
+                int     rg = v->radio_gain;
+                rg = rg > 0x1FE ? 0x1FE : (rg < -0x1FE ? -0x1FE : rg);
+                field = 0x2000u | 0xC00u | (rg >= 0 ? (unsigned) rg : (0x200u | (unsigned) -rg));
+            }
+            put_i2(p + k, (uint16_t) field);
+        }
         k += 2;
         put_i2(p + k, 0);               /* audiophile ReplayGain */
         k += 2;
-        p[k++] = (unsigned char) (ath_type + (1 << 4) + (safe_joint << 5));
+        {
+            /* --nogap: more titles follow / came before (reference VbrTag.c:728-735) */
+            int const more = (v->nogap_total != -1 && v->nogap_current < v->nogap_total - 1);
+            int const prev = (v->nogap_total != -1 && v->nogap_current > 0);
+            p[k++] = (unsigned char) (ath_type + (1 << 4) + (safe_joint << 5) + (more << 6) + (prev << 7));
+        }
         {
             /* CBR: the bit rate; ABR: the mean; VBR: the lowest allowed one (reference VbrTag.c:679-693) */
             int const abr = (c->vbr == 0) ? c->avg_bitrate : (c->vbr == 3) ? c->vbr_avg_bitrate_kbps

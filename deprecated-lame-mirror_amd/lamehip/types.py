@@ -21,7 +21,7 @@ class LhConfig(C.Structure):
         ("pcm_scale", C.c_float), ("interChRatio", C.c_float),
         ("vbr_q", C.c_int), ("vbr_min_bitrate_index", C.c_int), ("vbr_max_bitrate_index", C.c_int),
         ("enforce_min_bitrate", C.c_int), ("vbr_avg_bitrate_kbps", C.c_int), ("compression_ratio", C.c_float), ("pcm_mix", C.c_float),
-        ("pcm_scale_r", C.c_float)]
+        ("pcm_scale_r", C.c_float), ("highpassfreq", C.c_int), ("ath_flags", C.c_int)]
 
 
 class LhPsyBand(C.Structure):

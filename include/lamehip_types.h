@@ -120,6 +120,8 @@ typedef struct LhConfig {
      * reference lame.c:1209-1234); 0 otherwise */
     float   pcm_mix;
     float   pcm_scale_r;          /* right channel's factor (pcm_transform[1][1]); pcm_scale is the left one's */
+    int     highpassfreq;         /* lame_set_highpassfreq: Hz, 0 = none, -1 = "off" (the tag's -k test) */
+    int     ath_flags;            /* bit 0 noATH, bit 1 ATHonly, bit 2 ATHshort (reference util.h SessionConfig_t) */
 } LhConfig;
 
 /* partition -> scalefactor-band mapping, PsyConst_CB2SB_t (reference util.h:188-203) */

@@ -22,6 +22,7 @@
 #include "tables.h"
 #include "quantize_pvt.h"
 #include "lame_global_flags.h"
+#include "set_get.h"
 #include "psymodel.h"
 #include "newmdct.h"
 #include "fft.h"
@@ -44,7 +45,7 @@ refh_set_channels(int n)
 }
 
 /* switches applied to the handles opened next (name = the lame_set_* suffix); refh_option(0, 0) clears */
-static struct { char name[32]; float value; } refh_opts[16];
+static struct { char name[32]; float value; } refh_opts[24];
 static int refh_nopts = 0;
 
 void
@@ -54,7 +55,7 @@ refh_option(const char *name, float value)
         refh_nopts = 0;
         return;
     }
-    if (refh_nopts < 16) {
+    if (refh_nopts < 24) {
         strncpy(refh_opts[refh_nopts].name, name, 31);
         refh_opts[refh_nopts].value = value;
         refh_nopts++;
@@ -90,6 +91,22 @@ apply_options(lame_global_flags * gfp)
         else if (!strcmp(n, "VBR_min_bitrate_kbps")) lame_set_VBR_min_bitrate_kbps(gfp, (int) v);
         else if (!strcmp(n, "VBR_max_bitrate_kbps")) lame_set_VBR_max_bitrate_kbps(gfp, (int) v);
         else if (!strcmp(n, "VBR_hard_min")) lame_set_VBR_hard_min(gfp, (int) v);
+        else if (!strcmp(n, "msfix")) lame_set_msfix(gfp, v);
+        else if (!strcmp(n, "ATHtype")) lame_set_ATHtype(gfp, (int) v);
+        else if (!strcmp(n, "ATHcurve")) lame_set_ATHcurve(gfp, v);
+        else if (!strcmp(n, "ATHlower")) lame_set_ATHlower(gfp, v);
+        else if (!strcmp(n, "athaa_type")) lame_set_athaa_type(gfp, (int) v);
+        else if (!strcmp(n, "athaa_sensitivity")) lame_set_athaa_sensitivity(gfp, v);
+        else if (!strcmp(n, "ATHonly")) lame_set_ATHonly(gfp, (int) v);
+        else if (!strcmp(n, "ATHshort")) lame_set_ATHshort(gfp, (int) v);
+        else if (!strcmp(n, "noATH")) lame_set_noATH(gfp, (int) v);
+        else if (!strcmp(n, "interChRatio")) lame_set_interChRatio(gfp, v);
+        else if (!strcmp(n, "useTemporal")) lame_set_useTemporal(gfp, (int) v);
+        else if (!strcmp(n, "highpassfreq")) lame_set_highpassfreq(gfp, (int) v);
+        else if (!strcmp(n, "highpasswidth")) lame_set_highpasswidth(gfp, (int) v);
+        else if (!strcmp(n, "exp_nspsytune")) lame_set_exp_nspsytune(gfp, (int) v);
+        else if (!strcmp(n, "experimentalY")) lame_set_experimentalY(gfp, (int) v);
+        else if (!strcmp(n, "compression_ratio")) lame_set_compression_ratio(gfp, v);
     }
 }
 
@@ -560,6 +577,8 @@ refh_get_config(void *hh, LhConfig * c)
     c->compression_ratio = cfg->compression_ratio;
     c->pcm_mix = cfg->pcm_transform[0][1];
     c->pcm_scale_r = cfg->pcm_transform[1][1];
+    c->highpassfreq = cfg->highpassfreq;
+    c->ath_flags = (cfg->noATH ? 1 : 0) | (cfg->ATHonly ? 2 : 0) | (cfg->ATHshort ? 4 : 0);
 }
 
 static void

@@ -14,7 +14,8 @@ pytestmark = pytest.mark.skipif(not helpers.have_reference(), reason="needs orac
 class LhVbrTag(C.Structure):
     _fields_ = [("enabled", C.c_int), ("total_frame_size", C.c_int), ("sum", C.c_int), ("seen", C.c_int),
                 ("want", C.c_int), ("pos", C.c_int), ("size", C.c_int), ("bag", C.c_int * 400),
-                ("num_frames", C.c_uint), ("bytes_written", C.c_ulong), ("music_crc", C.c_uint16)]
+                ("num_frames", C.c_uint), ("bytes_written", C.c_ulong), ("music_crc", C.c_uint16), ("samplerate_in", C.c_int),
+                ("radio_gain_on", C.c_int), ("radio_gain", C.c_int), ("nogap_total", C.c_int), ("nogap_current", C.c_int)]
 
 
 @pytest.mark.parametrize("sr,br,mode,q,secs,vq,abr", [(44100, 128, -1, -1, 0.567, None, None), (48000, 320, 1, -1, 1.3, None, None),

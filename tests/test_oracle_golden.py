@@ -20,7 +20,9 @@ def test_golden(name, oracle):
     enc = lamehip.Encoder(require_device=False, **helpers.golden_encoder_kwargs(g))
     cfg, tab = enc.config(), enc.tables()
     # resolved constants == the reference's SessionConfig_t subset
-    ref_cfg = LhConfig.from_buffer_copy(g["config"].tobytes())
+    # (goldens made before LhConfig grew its trailing highpassfreq / ath_flags words hold the shorter image; both are
+    # 0 for every golden's settings -- no high-pass, no ATH switches)
+    ref_cfg = LhConfig.from_buffer_copy(g["config"].tobytes().ljust(C.sizeof(LhConfig), b"\0"))
     # (captured after the run: in VBR mode bitrate_index is the last frame's, run-time state)
     assert not struct_diff(ref_cfg, cfg, skip=("bitrate_index",) if cfg.vbr else ())
     # generated tables == the reference's

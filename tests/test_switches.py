@@ -31,7 +31,27 @@ CASES = [
     # (brate 0 = left alone, as a frontend that only says --preset does)
     (dict(brate=0), {"preset": 1001}), (dict(brate=0), {"preset": 1003}), (dict(brate=0), {"preset": 1006}),
     (dict(brate=0), {"preset": 150}), (dict(vbr_q=4), {"preset": 450}), (dict(brate=0), {"preset": 1002}),
+    # the frontend's tuning switches (--nsmsfix, --athtype, --athcurve, --athlower, --athaa-type, --athaa-sensitivity,
+    # --noath, --athshort, --interch, --temporal-masking, --highpass / --highpass-width, --ns-bass / -alto / -treble /
+    # -sfb21 / --nssafejoint, -Y, --comp)
+    (dict(brate=128), {"msfix": 2.0}), (dict(vbr_q=2), {"msfix": 0.5}), (dict(abr=160), {"msfix": 0.0}),
+    (dict(brate=128), {"ATHtype": 2}), (dict(brate=192), {"ATHtype": 0}), (dict(vbr_q=3), {"ATHtype": 1}),
+    (dict(brate=128), {"ATHcurve": 7.5}), (dict(vbr_q=2), {"ATHcurve": 1.0}),
+    (dict(brate=160), {"ATHlower": 6.0}), (dict(vbr_q=4), {"ATHlower": -3.5}),
+    (dict(brate=128), {"athaa_type": 0}), (dict(vbr_q=2), {"athaa_type": 1}), (dict(brate=128), {"athaa_sensitivity": 4.0}),
+    (dict(vbr_q=2), {"athaa_sensitivity": -2.5}),
+    (dict(brate=128), {"noATH": 1}), (dict(vbr_q=3), {"noATH": 1}), (dict(brate=128), {"ATHshort": 1}),
+    (dict(brate=128), {"interChRatio": 0.3}), (dict(brate=128), {"useTemporal": 0}), (dict(vbr_q=2), {"useTemporal": 1}),
+    (dict(brate=128), {"highpassfreq": 400}), (dict(vbr_q=2), {"highpassfreq": 1500, "highpasswidth": 700}),
+    (dict(brate=128), {"highpassfreq": 10}), (dict(brate=192), {"highpassfreq": -1, "lowpassfreq": -1}),
+    (dict(brate=128), {"exp_nspsytune": 1 | (8 << 2) | (60 << 8) | (4 << 14)}), (dict(vbr_q=2), {"exp_nspsytune": 1 | 2 | (12 << 20)}),
+    (dict(vbr_q=0), {"exp_nspsytune": 1 | (56 << 20)}), (dict(abr=128), {"exp_nspsytune": 1 | 2}),
+    (dict(vbr_q=0), {"experimentalY": 1}), (dict(brate=128), {"experimentalY": 1}),
+    (dict(brate=0), {"compression_ratio": 8.0}), (dict(brate=0), {"compression_ratio": 5.0}), (dict(brate=128), {"compression_ratio": 14.0}),
+    (dict(brate=0), {}),
 ]
+FLOAT_OPTS = ("scale", "scale_left", "scale_right", "VBR_quality", "ATHcurve", "ATHlower", "athaa_sensitivity", "interChRatio",
+              "compression_ratio")
 IDS = ["%s-%s" % ("_".join("%s%s" % kv for kv in kw.items()), "_".join(o)) for kw, o in CASES]
 
 
@@ -53,8 +73,12 @@ def open_with(kw, opts, require_device):
         lib.lame_set_VBR_mean_bitrate_kbps(enc.h, kw["abr"])
     for k, v in opts.items():
         f = getattr(lib, "lame_set_" + k)
-        f.argtypes = [C.c_void_p, C.c_float if k.startswith("scale") or k == "VBR_quality" else C.c_int]
-        rc = f(enc.h, float(v) if k.startswith("scale") or k == "VBR_quality" else int(v))
+        if k == "msfix":                # void lame_set_msfix(lame_t, double)
+            f.argtypes, f.restype = [C.c_void_p, C.c_double], None
+            f(enc.h, float(v))
+            continue
+        f.argtypes = [C.c_void_p, C.c_float if k in FLOAT_OPTS else C.c_int]
+        rc = f(enc.h, float(v) if k in FLOAT_OPTS else int(v))
         assert rc == 0 or k == "preset"
     enc.rc = lib.lame_init_params(enc.h)
     assert enc.rc == 0 or (enc.rc == lamehip.ERR_NODEVICE and not require_device), lamehip.last_error()

@@ -25,9 +25,12 @@ def main(pmc, stats, workload):
     out = {"date": datetime.date.today().isoformat(), "workload": workload, "kernel": "lh_encode_kernel",
            "launches_profiled": launches}
     try:
-        out["commit"] = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], text=True).strip()
+        out["commit"] = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], text=True, stderr=subprocess.DEVNULL).strip()
     except Exception:
-        out["commit"] = None
+        out["commit"] = None    # (no git on the GPU box: the digest below is what ties the record to its sources)
+    sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+    import bench
+    out["csrc_sha256"] = bench.csrc_digest()
     if fetch is not None and write is not None:
         out["hbm_bytes_per_launch"] = int(fetch * 1024 * 2 + write * 1024)
         out["fetch_kib_reported"] = fetch
