@@ -293,9 +293,9 @@ SETTER(lame_set_ATHtype, p.ATHtype, int)                /* lame.h:502 */
 GETTER(lame_get_ATHtype, g->inited ? g->cfg.ATHtype : g->p.ATHtype, int)
 FSETTER(lame_set_ATHcurve, ATHcurve)
 FGETTER(lame_get_ATHcurve, ATHcurve)
-FSETTER(lame_set_ATHlower, ATH_lower_db)                /* lame.h:510 */
+FSETTER(lame_set_ATHlower, ATH_lower_db)                /* lame.h:506 */
 FGETTER(lame_get_ATHlower, ATH_lower_db)
-SETTER(lame_set_athaa_type, p.athaa_type, int)          /* lame.h:514 */
+SETTER(lame_set_athaa_type, p.athaa_type, int)          /* lame.h:510 */
 GETTER(lame_get_athaa_type, g->p.athaa_type, int)
 FSETTER(lame_set_athaa_sensitivity, athaa_sensitivity)  /* lame.h:521 */
 FGETTER(lame_get_athaa_sensitivity, athaa_sensitivity)
@@ -305,17 +305,17 @@ SETTER(lame_set_ATHshort, p.ATHshort, int)              /* lame.h:494 */
 GETTER(lame_get_ATHshort, g->p.ATHshort, int)
 SETTER(lame_set_noATH, p.noATH, int)                    /* lame.h:498 */
 GETTER(lame_get_noATH, g->p.noATH, int)
-SETTER(lame_set_highpassfreq, p.highpassfreq, int)      /* lame.h:471 */
+SETTER(lame_set_highpassfreq, p.highpassfreq, int)      /* lame.h:477 */
 GETTER(lame_get_highpassfreq, g->p.highpassfreq, int)
-SETTER(lame_set_highpasswidth, p.highpasswidth, int)    /* lame.h:475 */
+SETTER(lame_set_highpasswidth, p.highpasswidth, int)    /* lame.h:480 */
 GETTER(lame_get_highpasswidth, g->p.highpasswidth, int)
-SETTER(lame_set_exp_nspsytune, p.exp_nspsytune, int)    /* lame.h:420 */
+SETTER(lame_set_exp_nspsytune, p.exp_nspsytune, int)    /* lame.h:421 */
 GETTER(lame_get_exp_nspsytune, g->p.exp_nspsytune, int)
-SETTER(lame_set_experimentalY, p.experimentalY, int)    /* lame.h:412 */
+SETTER(lame_set_experimentalY, p.experimentalY, int)    /* lame.h:413 */
 GETTER(lame_get_experimentalY, g->p.experimentalY, int)
-SETTER(lame_set_experimentalZ, p.experimentalZ, int)    /* lame.h:416 */
+SETTER(lame_set_experimentalZ, p.experimentalZ, int)    /* lame.h:417 */
 GETTER(lame_get_experimentalZ, g->p.experimentalZ, int)
-FSETTER(lame_set_compression_ratio, compression_ratio)  /* lame.h:271 */
+FSETTER(lame_set_compression_ratio, compression_ratio)  /* lame.h:355 */
 extern "C" float
 lame_get_compression_ratio(const lame_t g)
 {
@@ -348,7 +348,7 @@ lame_set_interChRatio(lame_t g, float ratio)            /* lame.h:543: 0 .. 1 */
 FGETTER(lame_get_interChRatio, interChRatio)
 
 extern "C" int
-lame_set_useTemporal(lame_t g, int on)                  /* lame.h:538: 0 / 1 */
+lame_set_useTemporal(lame_t g, int on)                  /* lame.h:539: 0 / 1 */
 {
     if (!valid(g) || on < 0 || on > 1)
         return -1;
@@ -370,14 +370,14 @@ GETTER(lame_get_free_format, g->p.free_format, int)
 /* switches of the reference that have nothing to act on in this library: the decoder (decode_only,
  * decode_on_the_fly), ReplayGain analysis, assembler variants.  Their setters take the "off" value and refuse
  * the "on" value; the getters report "off" / 0 like a reference build without those parts. */
-extern "C" int lame_set_decode_only(lame_t g, int v) { return (valid(g) && v == 0) ? 0 : -1; }       /* lame.h:339 */
+extern "C" int lame_set_decode_only(lame_t g, int v) { return (valid(g) && v == 0) ? 0 : -1; }       /* lame.h:244 */
 extern "C" int lame_get_decode_only(const lame_t) { return 0; }
 extern "C" int lame_set_decode_on_the_fly(lame_t, int) { return -1; }       /* (a reference without DECODE_ON_THE_FLY) */
 extern "C" int lame_get_decode_on_the_fly(const lame_t) { return 0; }
 /* the frontend's default (--replaygain-fast): the input's radio gain is measured on the host beside the encode
  * (lh_replaygain.c) and stored in the LAME tag */
 extern "C" int
-lame_set_findReplayGain(lame_t g, int on)               /* lame.h:301 */
+lame_set_findReplayGain(lame_t g, int on)               /* lame.h:296 */
 {
     if (!valid(g) || on < 0 || on > 1)
         return -1;
@@ -390,15 +390,15 @@ extern "C" int lame_get_AudiophileGain(const lame_t) { return 0; }
 extern "C" float lame_get_PeakSample(const lame_t) { return 0; }
 extern "C" int lame_get_noclipGainChange(const lame_t) { return 0; }
 extern "C" float lame_get_noclipScale(const lame_t) { return 0; }
-extern "C" int lame_set_asm_optimizations(lame_t g, int optim, int) { return valid(g) ? optim : -1; } /* lame.h:325 */
-SETTER(lame_set_nogap_total, nogap_total, int)          /* lame.h:307: bookkeeping of the frontend's --nogap */
+extern "C" int lame_set_asm_optimizations(lame_t g, int optim, int) { return valid(g) ? optim : -1; } /* lame.h:360 */
+SETTER(lame_set_nogap_total, nogap_total, int)          /* lame.h:326: bookkeeping of the frontend's --nogap */
 GETTER(lame_get_nogap_total, g->nogap_total, int)
 SETTER(lame_set_nogap_currentindex, nogap_current, int)
 GETTER(lame_get_nogap_currentindex, g->nogap_current, int)
 
 /* reference lame.c: bitrate_table[version][index] */
 extern "C" int
-lame_get_bitrate(int mpeg_version, int table_index)     /* lame.h:1315 */
+lame_get_bitrate(int mpeg_version, int table_index)     /* lame.h:1290 */
 {
     static const int t[3][16] = {
         {0, 8, 16, 24, 32, 40, 48, 56, 64, 80, 96, 112, 128, 144, 160, -1},
@@ -411,7 +411,7 @@ lame_get_bitrate(int mpeg_version, int table_index)     /* lame.h:1315 */
 }
 
 extern "C" int
-lame_get_samplerate(int mpeg_version, int table_index)  /* lame.h:1319 */
+lame_get_samplerate(int mpeg_version, int table_index)  /* lame.h:1291 */
 {
     static const int t[3][4] = { {22050, 24000, 16000, -1}, {44100, 48000, 32000, -1}, {11025, 12000, 8000, -1} };
     if (0 <= mpeg_version && mpeg_version <= 2 && 0 <= table_index && table_index <= 3)

@@ -127,6 +127,53 @@ int     lame_set_errorf(lame_t, lame_report_function);                   /* lame
 int     lame_set_debugf(lame_t, lame_report_function);                   /* lame.h:347 */
 int     lame_set_msgf(lame_t, lame_report_function);                     /* lame.h:348 */
 int     lame_get_version(const lame_t);                              /* lame.h:568 */
+/* The frontend's tuning switches (its "experimental" section).  A value left alone takes the bitrate's / quality's
+ * preset value or the default of lame_init_params, exactly as in the reference (presets.c SET_OPTION, lame.c:1112-1203);
+ * every one only changes constants and tables that reach the kernels.  lame_set_free_format(1), lame_set_experimentalZ
+ * and lame_set_ATHonly(1) are accepted here and make lame_init_params fail (not on this path). */
+void    lame_set_msfix(lame_t, double);                              /* lame.h:424 */
+float   lame_get_msfix(const lame_t);
+int     lame_set_ATHtype(lame_t, int);                               /* lame.h:502 */
+int     lame_get_ATHtype(const lame_t);
+int     lame_set_ATHlower(lame_t, float);                            /* lame.h:506 */
+float   lame_get_ATHlower(const lame_t);
+int     lame_set_athaa_type(lame_t, int);                            /* lame.h:510 */
+int     lame_get_athaa_type(const lame_t);
+int     lame_set_athaa_sensitivity(lame_t, float);                   /* lame.h:521 */
+float   lame_get_athaa_sensitivity(const lame_t);
+int     lame_set_ATHonly(lame_t, int);                               /* lame.h:490 */
+int     lame_set_ATHshort(lame_t, int);                              /* lame.h:494 */
+int     lame_set_noATH(lame_t, int);                                 /* lame.h:498 */
+int     lame_set_interChRatio(lame_t, float);                        /* lame.h:543 */
+int     lame_set_useTemporal(lame_t, int);                           /* lame.h:539 */
+int     lame_set_highpassfreq(lame_t, int);                          /* lame.h:477 */
+int     lame_set_highpasswidth(lame_t, int);                         /* lame.h:480 */
+int     lame_set_exp_nspsytune(lame_t, int);                         /* lame.h:421 */
+int     lame_get_exp_nspsytune(const lame_t);
+int     lame_set_experimentalY(lame_t, int);                         /* lame.h:413 */
+int     lame_set_experimentalZ(lame_t, int);                         /* lame.h:417 */
+int     lame_set_free_format(lame_t, int);                           /* lame.h:292 */
+int     lame_get_free_format(const lame_t);
+int     lame_set_compression_ratio(lame_t, float);                   /* lame.h:355 */
+float   lame_get_compression_ratio(const lame_t);
+/* ReplayGain of the input for the LAME tag (the frontend's default): measured on the host, lh_replaygain.c */
+int     lame_set_findReplayGain(lame_t, int);                        /* lame.h:296 */
+int     lame_get_RadioGain(const lame_t);                            /* lame.h:606 */
+/* parts of the reference this library does not have (decoder, assembler variants): "off" is accepted */
+int     lame_set_decode_only(lame_t, int);                           /* lame.h:244 */
+int     lame_set_asm_optimizations(lame_t, int, int);                /* lame.h:360 */
+int     lame_set_nogap_total(lame_t, int);                           /* lame.h:326 */
+int     lame_set_nogap_currentindex(lame_t, int);                    /* lame.h:329 */
+void    lame_print_config(const lame_t);                             /* lame.h:678 */
+void    lame_print_internals(const lame_t);                          /* lame.h:680 */
+int     lame_get_bitrate(int mpeg_version, int table_index);         /* lame.h:1290 */
+int     lame_get_samplerate(int mpeg_version, int table_index);      /* lame.h:1291 */
+const char *get_lame_version(void);                                  /* lame.h:644 */
+const char *get_lame_short_version(void);
+const char *get_lame_very_short_version(void);
+const char *get_psy_version(void);
+const char *get_lame_url(void);
+const char *get_lame_os_bitness(void);
 
 /* return: bytes written to mp3buf (may be 0); -1 mp3buf too small; -2 alloc;
  * -3 lame_init_params not called; mp3buf_size == 0 disables the size check
