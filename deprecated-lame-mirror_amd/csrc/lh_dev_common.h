@@ -425,6 +425,7 @@ struct LhLds {
     float   pe_use[2][2];
     float   ms_ener_ratio[2];
     int     scfsi[2][4];
+    int     gr0_done[2];        /* frame number + 1 once the channel is through with granule 0 (lh_encode_frame) */
 #if defined(LH_PROF) && !defined(LH_EMU)
     unsigned prof[2][LH_NPROF];         /* profiling builds only; cycles of one frame fit 32 bits */
 #endif

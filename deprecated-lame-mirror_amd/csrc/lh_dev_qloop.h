@@ -614,32 +614,45 @@ lq_calc_noise(const LhCtx & c, const LhQS & S, const LhQR & R, const LhGrR & g, 
     LH_WAVE_ORDER();
     LQ_MARK("cn_sum");
     {
-        /* eight terms per trip, fetched as four aligned pairs (band starts are even) one trip
-         * ahead of the additions; a pair beyond the band's length comes from a pair of zeros
-         * (adding +0.0f leaves the non-negative sum unchanged) */
+        /* Lane = band adds its squares in the reference's order: a serial float sum, so the wave runs as many
+         * steps as the widest band that changed has lines.  Every lane reads on past its own band's end (the next
+         * band's squares, then whatever follows in the channel's LDS image: at most 158 lines beyond a band's start)
+         * and keeps the value its sum had after its own last line -- a compare and a select per pair instead of an
+         * address select per load.  Eight terms per trip from two 16-byte reads (band starts are even, the array is
+         * 16-byte aligned: a band that starts on an odd pair reads its first pair alone). */
         int const n = 2 * l;
         int const jj = (j < 576) ? (j >> 1) : 0;
         const lh_f32x2 *sq2 = (const lh_f32x2 *) sq;
-        /* the pair of zeros, as an index from the start of the channel's LDS image (sq = Q.xrpow is
-         * its first member): an index is selected, never a pointer */
-        int const zoff = (int) (__builtin_offsetof(LhChanLds, zero2) / sizeof(lh_f32x2));
-        lh_f32x2 t[4], tn[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-            tn[u] = sq2[(2 * u < n) ? jj + u : zoff];
-        for (int k0 = 0; k0 < maxw; k0 += 8) {
-#pragma unroll
-            for (int u = 0; u < 4; u++)
-                t[u] = tn[u];
-#pragma unroll
-            for (int u = 0; u < 4; u++)
-                tn[u] = sq2[(k0 + 8 + 2 * u < n) ? jj + (k0 >> 1) + 4 + u : zoff];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                noise += t[u].x;
-                noise += t[u].y;
-            }
+        float   kept = 0.0f;
+        int     at = jj, done = 0;
+        if (lh_ballot(fresh && (jj & 1))) {
+            /* odd starting pair: one pair first, so that the rest is aligned */
+            lh_f32x2 const t = sq2[at];
+            int const odd = jj & 1;
+            float const a = noise + t.x, b = a + t.y;
+            noise = odd ? b : noise;
+            at += odd;
+            done += 2 * odd;
+            kept = (done == n) ? noise : kept;
         }
+        for (int k0 = 0; k0 < maxw; k0 += 8) {
+            lh_f32x4 const u = *(const lh_f32x4 *) &sq2[at], v = *(const lh_f32x4 *) &sq2[at + 2];
+            noise += u.x;
+            noise += u.y;
+            kept = (done + 2 == n) ? noise : kept;
+            noise += u.z;
+            noise += u.w;
+            kept = (done + 4 == n) ? noise : kept;
+            noise += v.x;
+            noise += v.y;
+            kept = (done + 6 == n) ? noise : kept;
+            noise += v.z;
+            noise += v.w;
+            kept = (done + 8 == n) ? noise : kept;
+            at += 4;
+            done += 8;
+        }
+        noise = kept;
     }
     LQ_MARK("cn_log");
     t.pnstep = S.pnstep;

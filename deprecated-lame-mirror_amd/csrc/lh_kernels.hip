@@ -168,6 +168,31 @@ lh_store_granule(const LhCtx & c, const LhChanLds & Q, const LhQR & R, const LhG
 #include "lh_dev_emit.h"
 #include "lh_dev_vbr.h"
 
+/* what a granule's search starts from and what does not depend on its bit budget: geometry (init_outer_loop),
+ * xrpow, the allowed noise per band (calc_xmin); R / g are left in the channel's LDS slot.  Returns 0 for an all-zero
+ * granule.  substep: only bit 1 (a constant of the settings) is looked at downstream. */
+LH_DEVFN int
+lh_prepare_granule(const LhCtx & c, int ch, int gr, int msoff, int substep)
+{
+    LhLds & L = lh_lds;
+    LhChanLds & Q = L.u.quant.ch[ch];
+    LhQR    R;
+    LhGrR   g;
+    int     nonzero;
+    lh_init_outer_loop(ch, gr, L.block_type[gr][ch], substep);
+    R = lh_uniform(L.rg[ch].R);
+    g = lh_uniform(L.rg[ch].g);
+    nonzero = lh_init_xrpow(c, Q, R, g, L.xr[ch][gr]);
+    if (nonzero) {
+        lh_rg_put(c, R, g);
+        lh_calc_xmin(ch, gr, msoff + ch);
+        R = lh_uniform(L.rg[ch].R);
+        lh_zero_tail(c, Q, R);
+    }
+    lh_rg_put(c, R, g);
+    return lh_uni_i(nonzero);
+}
+
 #ifdef LH_HELPERS
 /* a wave of the frame loop tells its sibling what this granule's search is (slots 4 / 5; 0: there is none) */
 LH_DEVFN void
@@ -419,6 +444,20 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
             for (int ch = 0; ch < 2; ch++)
                 abr_targ[gr][ch] = lh_uni_i(abr_targ[gr][ch]);
     analog_silence_bits = lh_uni_i(analog_silence_bits);
+    if (mode_ext == LH_MPG_MD_MS_LR && !vbr_new) {
+        /* mid / side spectra of both granules at once (reference quantize.c:2006-2008 does it granule by granule;
+         * nothing in between reads xr): granule 1's are then there for the channel that is done with granule 0
+         * first (below) */
+        float const k = (float) (LH_SQRT2 * 0.5);
+        for (int i = tid; i < 2 * 576; i += LH_NT) {
+            int const gr = i >= 576, at = i - 576 * gr;
+            float const l = L.xr[0][gr][at];
+            float const r = L.xr[1][gr][at];
+            L.xr[0][gr][at] = (l + r) * k;
+            L.xr[1][gr][at] = (l - r) * k;
+        }
+    }
+    int     prepared = 0, prepared_nonzero = 0;
     for (int gr = 0; gr < 2 && !vbr_new; gr++) {
         int     targ_bits[2] = { abr_targ[gr][0], abr_targ[gr][1] };
         int     max_bits = 0;
@@ -426,17 +465,8 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
             max_bits = lh_on_pe(cfg, ResvSize, ResvMax, &substep, pe_use[gr], targ_bits, mean_bits, gr);
         LH_SYNC_WG();
         substep = lh_uni_i(substep);
-        if (mode_ext == LH_MPG_MD_MS_LR) {
-            float const k = (float) (LH_SQRT2 * 0.5);
-            for (int i = tid; i < 576; i += LH_NT) {
-                float const l = L.xr[0][gr][i];
-                float const r = L.xr[1][gr][i];
-                L.xr[0][gr][i] = (l + r) * k;
-                L.xr[1][gr][i] = (l - r) * k;
-            }
-            if (!abr)
-                lh_reduce_side(targ_bits, ms_ener_ratio[gr], mean_bits, max_bits);
-        }
+        if (mode_ext == LH_MPG_MD_MS_LR && !abr)
+            lh_reduce_side(targ_bits, ms_ener_ratio[gr], mean_bits, max_bits);
         targ_bits[0] = lh_uni_i(targ_bits[0]);
         targ_bits[1] = lh_uni_i(targ_bits[1]);
 #ifdef LH_HELPERS
@@ -465,19 +495,14 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
             /* R and g never have their address taken (they stay in scalar registers through
              * the inlined outer loop); the out-of-line stages exchange them through the wave's
              * LDS slot */
-            lh_init_outer_loop(ch, gr, L.block_type[gr][ch], substep);
+            int const nonzero = prepared ? prepared_nonzero : lh_prepare_granule(c, ch, gr, msoff, substep);
             R = lh_uniform(L.rg[ch].R);
             g = lh_uniform(L.rg[ch].g);
-            if (lh_init_xrpow(c, Q, R, g, xr)) {
-                lh_rg_put(c, R, g);
-                lh_calc_xmin(ch, gr, msoff + ch);
-                R = lh_uniform(L.rg[ch].R);
-                lh_zero_tail(c, Q, R);
+            if (nonzero) {
                 LH_PA(4, t_q);
                 LH_PT(t_ol);
                 if (abr && !R.ath_over)
                     targ_bits[ch] = analog_silence_bits;    /* reference quantize.c:1953-1954 */
-                lh_rg_put(c, R, g);
                 if (lq_needs_tail(c, Q, R)) {
                     lh_sibling_go(c, ch, 5, gr, targ_bits[ch]);
                     lq_outer_loop_stage5(ch, gr, targ_bits[ch]);
@@ -505,6 +530,22 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
             LH_PA(3, t_q);
             if (lane == 0)
                 L.bits_used[ch] = g.part2_3_length + g.part2_length;
+            if (gr == 0 && nch == 2) {
+                /* Granule 1's budget needs what BOTH channels spent on granule 0, but its geometry, xrpow and
+                 * allowed noise do not: the channel that is done first prepares them while it would otherwise
+                 * wait at the barrier for the other (the wait was 8 % of a frame); the one that is done last goes
+                 * straight to the barrier.  "First" = the other channel has not yet left its mark for this frame. */
+                int const stamp = lh_uni_i(lh_lds.ss.frame_number) + 1;
+                int     first;
+                LH_WAVE_SYNC();
+                first = lh_uni_i(*(volatile int *) &L.gr0_done[1 - ch]) != stamp;
+                if (lane == 0)
+                    *(volatile int *) &L.gr0_done[ch] = stamp;
+                if (first) {
+                    prepared_nonzero = lh_prepare_granule(c, ch, 1, msoff, substep);
+                    prepared = 1;
+                }
+            }
         }
         LH_SYNC_WG();
         {
@@ -666,6 +707,7 @@ lh_encode_stream(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, 
     }
 #endif
     if (c.tid == 0) {
+        L.gr0_done[0] = L.gr0_done[1] = 0;
         L.ctx.cfg = c.cfg;
         L.ctx.T = c.T;
         L.ctx.st = c.st;
