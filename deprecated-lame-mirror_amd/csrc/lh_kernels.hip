@@ -243,8 +243,18 @@ lh_helper_waves(int qch)
 #define lh_sibling_go(c, qch, ns, gr, targ) do { } while (0)
 #endif
 
+/* The frame and the stream loop are functions of their own only in the four-wave build: a kernel body keeps what
+ * lives across its calls in registers ABOVE its callees' budget, which decides the occupancy there (128 VGPRs);
+ * in the two-wave build (256 VGPRs) they are inlined -- out of line they saved and restored ~60 registers per
+ * frame through scratch memory, 50 KB of HBM traffic per frame at no gain. */
+#ifdef LH_HELPERS
+#define LH_FRAMEFN LH_STAGEFN
+#else
+#define LH_FRAMEFN LH_DEVFN
+#endif
+
 /* one frame of one stream; executed by the whole workgroup */
-LH_STAGEFN void
+LH_FRAMEFN void
 lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
 {
     LhLds & L = lh_lds;
@@ -652,7 +662,7 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
 /* all frames of one stream (the workgroup's whole job).  Out of line: a kernel body places what it keeps across
  * calls in registers ABOVE its callees' budget, which is what decides the occupancy; a function keeps
  * such values in the callee-saved registers inside the budget. */
-LH_STAGEFN void
+LH_FRAMEFN void
 lh_encode_stream(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, const float *pcmf,
                  const LhStreamDesc * descs, LhStreamState * states, LhFrameOut * out, uint8_t * bytes,
                  int nstreams)

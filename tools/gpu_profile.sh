@@ -17,13 +17,13 @@ if [ "${TRAFFIC_ONLY:-0}" = 1 ]; then
     python $ROOT/tools/pmc_summary.py $OUT/pmc_${TAG}_$set lh_encode
     rm -rf $OUT/pmc_${TAG}_$set
   done > $OUT/summ_${TAG}_traffic.txt
-  tail -1 $OUT/pmc_${TAG}_WRITE_SIZE.log | cut -c1-300 >> $OUT/summ_${TAG}_traffic.txt
+  grep '^{"metric"' $OUT/pmc_${TAG}_WRITE_SIZE.log | tail -1 | cut -c1-300 >> $OUT/summ_${TAG}_traffic.txt
   cat $OUT/summ_${TAG}_traffic.txt
   exit 0
 fi
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$TAG -- python $ROOT/bench.py $ARGS > $OUT/kt_$TAG.log 2>&1
 f=$(find $OUT/kt_$TAG -name '*kernel_stats.csv' | head -1)
-{ echo "# rocprofv3 --kernel-trace --stats -- python bench.py $ARGS"; [ -n "$f" ] && cat "$f"; tail -1 $OUT/kt_$TAG.log; } > $OUT/summ_${TAG}_kernel_stats.txt
+{ echo "# rocprofv3 --kernel-trace --stats -- python bench.py $ARGS"; [ -n "$f" ] && cat "$f"; grep '^{"metric"' $OUT/kt_$TAG.log | tail -1; } > $OUT/summ_${TAG}_kernel_stats.txt
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
            "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_BRANCH" \
