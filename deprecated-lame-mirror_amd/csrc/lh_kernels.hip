@@ -548,7 +548,8 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
                 int const stamp = lh_uni_i(lh_lds.ss.frame_number) + 1;
                 int     first;
                 LH_WAVE_SYNC();
-                first = lh_uni_i(*(volatile int *) &L.gr0_done[1 - ch]) != stamp;
+                /* (lane 0's reading for the whole wave: the other wave may leave its mark at any moment) */
+                first = (int) lh_bcast_u32((uint32_t) *(volatile int *) &L.gr0_done[1 - ch], 0) != stamp;
                 if (lane == 0)
                     *(volatile int *) &L.gr0_done[ch] = stamp;
                 if (first) {
