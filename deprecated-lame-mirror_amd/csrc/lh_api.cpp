@@ -850,6 +850,11 @@ init_params_once(lame_t g)
         g->have_device = 0;
         return LAMEHIP_ERR_NODEVICE;
     }
+    if (g->cfg.vbr == 2) {
+        /* LH_VBR_OLD_PENDING: host constants and oracle are there, the device loop is not yet */
+        snprintf(g_err, sizeof(g_err), "lame_set_VBR(vbr_rh): the old VBR loop is not on the device yet");
+        return -1;
+    }
     if (g->device < 0 && hipGetDevice(&g->device) != hipSuccess)
         g->device = 0;
     if (g->device >= lamehip_device_count()) {

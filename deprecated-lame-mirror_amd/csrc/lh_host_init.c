@@ -256,6 +256,21 @@ static const LhVbrPreset vbr_mt_map[11] = {
     {1, 25.00, 300.0, 2.8, 2.8, -25.0, 12.0, -27, 0.0025, 0, 0, 3.500, 0, 93.3}
 };
 
+/* the same for vbr_rh, reference presets.c:90-104 (vbr_old_switch_map) */
+static const LhVbrPreset vbr_old_map[11] = {
+    {0, 5.20, 125.0, -4.2, -6.3, 4.8, 1, 0, 0, 2, 21, 0.97, 5, 100},
+    {0, 5.30, 125.0, -3.6, -5.6, 4.5, 1.5, 0, 0, 2, 21, 1.35, 5, 100},
+    {0, 5.60, 125.0, -2.2, -3.5, 2.8, 2, 0, 0, 2, 21, 1.49, 5, 100},
+    {1, 5.80, 130.0, -1.8, -2.8, 2.6, 3, -4, 0, 2, 20, 1.64, 5, 100},
+    {1, 6.00, 135.0, -0.7, -1.1, 1.1, 3.5, -8, 0, 2, 0, 1.79, 5, 100},
+    {1, 6.40, 140.0, 0.5, 0.4, -7.5, 4, -12, 0.0002, 0, 0, 1.95, 5, 100},
+    {1, 6.60, 145.0, 0.67, 0.65, -14.7, 6.5, -19, 0.0004, 0, 0, 2.30, 5, 100},
+    {1, 6.60, 145.0, 0.8, 0.75, -19.7, 8, -22, 0.0006, 0, 0, 2.70, 5, 100},
+    {1, 6.60, 145.0, 1.2, 1.15, -27.5, 10, -23, 0.0007, 0, 0, 0, 5, 100},
+    {1, 6.60, 145.0, 1.6, 1.6, -36, 11, -25, 0.0008, 0, 0, 0, 5, 100},
+    {1, 6.60, 145.0, 2.0, 2.0, -36, 12, -25, 0.0008, 0, 0, 0, 5, 100}
+};
+
 /* output rate the reference picks for a lowpass and an input rate (reference lame.c:273-345):
  * the MPEG rate that suits the input, lowered as far as the lowpass allows, but never below the
  * next MPEG rate above the input */
@@ -427,11 +442,17 @@ config_apply_tuning(const LhUserParams * p, LhConfig * c, LhInitAux * aux, int p
 }
 
 /* vbr_mt / vbr_mtrh settings (reference lame.c:661-692, 730-744, 770-776, 972-1004, 1064-1094;
- * presets.c:146-213 apply_vbr_preset with every option still at its default) */
+ * presets.c:146-213 apply_vbr_preset with every option still at its default); vbr_rh (c->vbr == 2) differs
+ * in its tables (lame.c:717-729, presets.c:90-104), takes neither the quality -> output rate mapping nor ATH
+ * type 5, keeps the temporal masking effect on, and its lowpass stops at 20.5 kHz (lame.c:773-775) */
 static int
 config_resolve_vbr(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
 {
-    static const int lp_by_q[11] = { 24000, 19500, 18500, 18000, 17500, 17000, 16500, 15600, 15200, 7230, 3950 };
+    static const int lp_by_q_new[11] = { 24000, 19500, 18500, 18000, 17500, 17000, 16500, 15600, 15200, 7230, 3950 };
+    static const int lp_by_q_old[11] = { 19500, 19000, 18600, 18000, 17500, 16000, 15600, 14900, 12500, 10000, 3950 };
+    int const old = (c->vbr == 2);
+    const int *const lp_by_q = old ? lp_by_q_old : lp_by_q_new;
+    const LhVbrPreset *const map = old ? vbr_old_map : vbr_mt_map;
     int     vbr_q = p->vbr_q, samplerate_out = p->samplerate_out, lowpassfreq = p->lowpassfreq, i;
     float   vbr_q_frac = p->vbr_q_frac;
     LhVbrPreset P, Q;
@@ -442,7 +463,7 @@ config_resolve_vbr(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
         vbr_q = 0;
     if (vbr_q > 9)
         vbr_q = 9;
-    if (samplerate_out == 0) {
+    if (samplerate_out == 0 && !old) {
         /* VBR scale -> internal quality + output rate (reference lame.c:661-692); rows 2.. of its table */
         static const struct { int sr_a; float qa, qb, ta, tb; } m[7] = {
             {32000, 6.5, 8.0, 5.2, 6.5}, {24000, 8.0, 8.5, 5.2, 6.0}, {22050, 8.5, 9.01, 5.2, 6.5},
@@ -487,7 +508,10 @@ config_resolve_vbr(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
     }
     if (set_output_rate(c, samplerate_out) != 0)
         return -1;              /* MPEG-2 / 2.5 output rates are outside this path */
-    lowpassfreq = (24000 < lowpassfreq) ? 24000 : lowpassfreq;
+    {
+        int const top = old ? 20500 : 24000;
+        lowpassfreq = (top < lowpassfreq) ? top : lowpassfreq;
+    }
     lowpassfreq = (samplerate_out / 2 < lowpassfreq) ? samplerate_out / 2 : lowpassfreq;
     c->lowpassfreq = lowpassfreq;
     lowpass_edges(c, aux, p->lowpasswidth);
@@ -496,11 +520,11 @@ config_resolve_vbr(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
     c->avg_bitrate = 0;         /* gfp->brate stays 0 in VBR mode */
     c->sideinfo_len = (c->channels == 1) ? 4 + 17 : 4 + 32;
     c->buffer_constraint = 7680 * (c->version + 1);     /* strict_ISO = MDB_MAXIMUM */
-    c->use_temporal_masking = 0;
+    c->use_temporal_masking = old ? 1 : 0;
 
     /* preset row, interpolated by the fractional quality (reference presets.c:146-171) */
-    P = vbr_mt_map[vbr_q];
-    Q = vbr_mt_map[vbr_q + 1];
+    P = map[vbr_q];
+    Q = map[vbr_q + 1];
     x = vbr_q_frac;
     {
         /* every tuning value moves towards the next row's by the fractional quality */
@@ -525,7 +549,7 @@ config_resolve_vbr(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
     aux->attackthre_s = P.st_s;
     c->mask_adjust = P.masking_adj;
     c->mask_adjust_short = P.masking_adj_short;
-    c->ATHtype = 5;
+    c->ATHtype = old ? 4 : 5;
     c->ATH_offset_db = 0 - P.ath_lower;
     c->ATH_offset_factor = powf(10.f, c->ATH_offset_db * 0.1f);
     c->ATHcurve = P.ath_curve;
@@ -540,7 +564,7 @@ config_resolve_vbr(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
         double const y = (xs > 0.f) ? (10.f * log10(xs)) : 0.f;
         c->ATHfixpoint = P.ath_fixpoint - y;
     }
-    if (config_apply_tuning(p, c, aux, nspsytune, P.sfb21mod, 1) != 0)
+    if (config_apply_tuning(p, c, aux, nspsytune, P.sfb21mod, !old) != 0)
         return -1;
     {
         float   db = c->mask_adjust - 0;
@@ -550,10 +574,17 @@ config_resolve_vbr(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
     }
     /* quality levels of the new VBR code (reference lame.c:985-992) */
     c->quality = (p->quality < 0) ? 3 : p->quality;
-    if (c->quality < 5)
-        c->quality = 0;
-    if (c->quality > 7)
-        c->quality = 7;
+    if (old) {
+        /* the old loop needs the noise measurements: level 6 at least (reference lame.c:1017-1027) */
+        if (c->quality > 6)
+            c->quality = 6;
+    }
+    else {
+        if (c->quality < 5)
+            c->quality = 0;
+        if (c->quality > 7)
+            c->quality = 7;
+    }
     apply_quality(c, 0, 0);
     c->sfb21_extra = (P.expY || p->experimentalY) ? 0 : (samplerate_out > 44000);
     c->short_blocks = (c->mode == LH_MODE_MONO || c->mode == LH_MODE_DUAL) ? 0 : 1;
@@ -571,7 +602,11 @@ config_resolve_vbr(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
         static const float cmp[10] = { 5.7, 6.5, 7.3, 8.2, 10, 11.9, 13, 14, 15, 16.5 };
         c->compression_ratio = cmp[vbr_q];
     }
-    c->vbr_avg_bitrate_kbps = 128;      /* VBR_mean_bitrate_kbps default, inside the MPEG-1 range */
+    c->vbr_avg_bitrate_kbps = 128;      /* VBR_mean_bitrate_kbps default, kept inside the limits (lame.c:1086-1091) */
+    if (c->vbr_avg_bitrate_kbps > lh_bitrate_mpeg1[c->vbr_max_bitrate_index])
+        c->vbr_avg_bitrate_kbps = lh_bitrate_mpeg1[c->vbr_max_bitrate_index];
+    if (c->vbr_avg_bitrate_kbps < lh_bitrate_mpeg1[c->vbr_min_bitrate_index])
+        c->vbr_avg_bitrate_kbps = lh_bitrate_mpeg1[c->vbr_min_bitrate_index];
     return 0;
 }
 
@@ -644,8 +679,8 @@ config_resolve_inner(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
     memset(aux, 0, sizeof(*aux));
     if (p->channels != 1 && p->channels != 2)
         return -1;
-    if (p->vbr != 0 && p->vbr != 1 && p->vbr != 3 && p->vbr != 4)
-        return -1;              /* the old VBR loop (vbr_rh) is outside this path */
+    if (p->vbr < 0 || p->vbr > 4)
+        return -1;
     if (p->samplerate <= 0)
         return -1;
     /* the output rate follows from the lowpass below when the caller left it open; the input rate
@@ -669,7 +704,7 @@ config_resolve_inner(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
     aux->athaa_sensitivity = 0;
     aux->adjust_sfb21_db = 0;
     c->vbr_q = aux->vbr_q;
-    if (c->vbr == 1 || c->vbr == 4)
+    if (c->vbr == 1 || c->vbr == 2 || c->vbr == 4)
         return config_resolve_vbr(p, c, aux);
 
     if (c->vbr == 3) {

@@ -243,8 +243,8 @@ lh_tag_frame(const LhVbrTag * v, const LhConfig * c, int vbr_q, int enc_padding,
         k += 4;
         memcpy(p + k, "LAME3.99r", 9);  /* get_lame_tag_encoder_short_version() of 3.99.5 */
         k += 9;
-        /* tag revision 0 + method (vbr_type_translator, reference VbrTag.c:646): 1 CBR, 5 vbr_mt, 2 ABR, 4 vbr_mtrh */
-        p[k++] = (unsigned char) (c->vbr == 0 ? 1 : (c->vbr == 1 ? 5 : (c->vbr == 3 ? 2 : 4)));
+        /* tag revision 0 + method (vbr_type_translator, reference VbrTag.c:646): 1 CBR, 5 vbr_mt, 3 vbr_rh, 2 ABR, 4 vbr_mtrh */
+        p[k++] = (unsigned char) (c->vbr == 0 ? 1 : (c->vbr == 1 ? 5 : (c->vbr == 2 ? 3 : (c->vbr == 3 ? 2 : 4))));
         p[k++] = lowpass;
         put_i4(p + k, 0);               /* peak signal amplitude: not measured */
         k += 4;

@@ -80,7 +80,7 @@ class Encoder:
     """One stream behind the lame.h call sequence."""
 
     def __init__(self, samplerate=44100, brate=128, mode=None, quality=None, require_device=True, write_tag=False,
-                 vbr_q=None, out_samplerate=0, abr=None, channels=2, device=None):
+                 vbr_q=None, out_samplerate=0, abr=None, channels=2, device=None, vbr_mode=4):
         self.lib = load_library()
         self.h = C.c_void_p(self.lib.lame_init())
         if device is not None:      # HIP device of the handle's own launches (lamehip_set_device)
@@ -95,8 +95,8 @@ class Encoder:
             self.lib.lame_set_VBR_mean_bitrate_kbps(self.h, abr)
         elif vbr_q is None:
             self.lib.lame_set_brate(self.h, brate)
-        else:                       # vbr_mtrh at quality vbr_q (the reference's -V n)
-            self.lib.lame_set_VBR(self.h, 4)
+        else:                       # VBR at quality vbr_q (the reference's -V n): 4 vbr_mtrh, 1 vbr_mt, 2 vbr_rh (--vbr-old)
+            self.lib.lame_set_VBR(self.h, vbr_mode)
             self.lib.lame_set_VBR_q(self.h, vbr_q)
         self.lib.lame_set_bWriteVbrTag(self.h, 1 if write_tag else 0)
         if mode is not None:

@@ -7,5 +7,6 @@
 #include "orc_quant.c"
 #include "orc_vbr.c"
 #include "orc_abr.c"
+#include "orc_vbr_old.c"
 #include "orc_frame.c"
 #include "orc_resample.c"

@@ -114,6 +114,7 @@ typedef struct OrcStream {
     float   masking_lower;
     int     substep_shaping;
     int     pseudohalf[LH_SFBMAX];
+    int     sfb21_off;          /* VBR_encode_granule switches sfb21_extra off near the top of its range (quantize.c:1267-1270) */
     /* frame results */
     int     frame_init_done;
     int     frame_number;
@@ -141,6 +142,7 @@ void    orc_cbr_iteration_loop(OrcStream * S, float pe[2][2], const float ms_ene
                                const OrcRatio ratio[2][2]);
 void    orc_abr_iteration_loop(OrcStream * S, float pe[2][2], const float ms_ener_ratio[2], const OrcRatio ratio[2][2]);
 void    orc_vbr_new_iteration_loop(OrcStream * S, float pe[2][2], const OrcRatio ratio[2][2]);
+void    orc_vbr_old_iteration_loop(OrcStream * S, float pe[2][2], const float ms_ener_ratio[2], const OrcRatio ratio[2][2]);
 float   orc_ath_adjust(const LhTables * t, float a, float x, float athFloor, float ATHfixpoint);
 
 /* orc_frame.c */

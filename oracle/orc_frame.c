@@ -268,6 +268,8 @@ orc_encode_frame(OrcStream * S, const float *inbuf_l, const float *inbuf_r, LhFr
     mdb_header = S->main_data_begin;
     if (cfg->vbr == 3)
         orc_abr_iteration_loop(S, pe_use, ms_ener_ratio, masking);
+    else if (cfg->vbr == 2)
+        orc_vbr_old_iteration_loop(S, pe_use, ms_ener_ratio, masking);
     else if (cfg->vbr)
         orc_vbr_new_iteration_loop(S, pe_use, masking);
     else

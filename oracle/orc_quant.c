@@ -1082,6 +1082,57 @@ reduce_side(int targ_bits[2], float ms_ener_ratio, int mean_bits, int max_bits)
     }
 }
 
+/* reference quantize.c:159-223: the old VBR loop drops what lies below the threshold in quiet at the top of the
+ * spectrum (the parts of scalefactor band 21 / 12), from the highest line downwards, before it looks at a granule */
+static void
+psfb21_analogsilence(OrcStream * S, OrcGr * const cod_info)
+{
+    const LhTables *T = S->tab;
+    float  *const xr = cod_info->xr;
+    if (cod_info->block_type != LH_SHORT_TYPE) {
+        int     gsfb, stop = 0;
+        for (gsfb = LH_PSFB21 - 1; gsfb >= 0 && !stop; gsfb--) {
+            int const start = T->psfb21[gsfb];
+            int const end = T->psfb21[gsfb + 1];
+            int     j;
+            float   ath21 = orc_ath_adjust(T, S->ath_adjust_factor, T->ath_psfb21[gsfb], T->ath_floor, 0);
+            if (T->longfact[21] > 1e-12f)
+                ath21 *= T->longfact[21];
+            for (j = end - 1; j >= start; j--) {
+                if (fabs(xr[j]) < ath21)
+                    xr[j] = 0;
+                else {
+                    stop = 1;
+                    break;
+                }
+            }
+        }
+    }
+    else {
+        int     block;
+        for (block = 0; block < 3; block++) {
+            int     gsfb, stop = 0;
+            for (gsfb = LH_PSFB12 - 1; gsfb >= 0 && !stop; gsfb--) {
+                int const start = T->sfb_s[12] * 3 + (T->sfb_s[13] - T->sfb_s[12]) * block
+                    + (T->psfb12[gsfb] - T->psfb12[0]);
+                int const end = start + (T->psfb12[gsfb + 1] - T->psfb12[gsfb]);
+                int     j;
+                float   ath12 = orc_ath_adjust(T, S->ath_adjust_factor, T->ath_psfb12[gsfb], T->ath_floor, 0);
+                if (T->shortfact[12] > 1e-12f)
+                    ath12 *= T->shortfact[12];
+                for (j = end - 1; j >= start; j--) {
+                    if (fabs(xr[j]) < ath12)
+                        xr[j] = 0;
+                    else {
+                        stop = 1;
+                        break;
+                    }
+                }
+            }
+        }
+    }
+}
+
 /* ---------------------------------------------------------------------- */
 /* reference quantize.c:226-346 */
 static void
@@ -1150,6 +1201,8 @@ init_outer_loop(OrcStream * S, OrcGr * const cod_info)
     cod_info->count1bits = 0;
     cod_info->max_nonzero_coeff = 575;
     memset(cod_info->scalefac, 0, sizeof(cod_info->scalefac));
+    if (S->cfg->vbr == 2)       /* vbr_rh only, reference quantize.c:343-345 */
+        psfb21_analogsilence(S, cod_info);
 }
 
 /* reference quantize.c:72-144 */
@@ -1494,7 +1547,7 @@ outer_loop(OrcStream * S, OrcGr * const cod_info, const float *const l3_xmin, fl
                 search_limit = 20;
             else
                 search_limit = 3;
-            if (cfg->sfb21_extra) {
+            if (cfg->sfb21_extra && !S->sfb21_off) {
                 if (distort[cod_info_w.sfbmax] > 1.0)
                     break;
                 if (cod_info_w.block_type == LH_SHORT_TYPE
@@ -1567,6 +1620,8 @@ outer_loop(OrcStream * S, OrcGr * const cod_info, const float *const l3_xmin, fl
     }
     /* substep_shaping & 1 (trancate_smallspectrums) is never set on the CBR path
      * (quality switch sets 0 or 2, reference lame.c:437-463) */
+    if (cfg->vbr == 2)          /* restore for reuse on next try, reference quantize.c:1188-1190 */
+        memcpy(xrpow, save_xrpow, sizeof(float) * 576);
     return best_noise_info.over_count;
 }
 

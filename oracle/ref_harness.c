@@ -44,6 +44,16 @@ refh_set_channels(int n)
     refh_channels = (n == 1) ? 1 : 2;
 }
 
+/* which VBR loop refh_open_vbr selects for the handles opened next: vbr_mtrh (4, the default), vbr_mt (1) or the old
+ * loop vbr_rh (2) */
+static int refh_vbr_mode = 4;
+
+void
+refh_set_vbr_mode(int m)
+{
+    refh_vbr_mode = (m == 1 || m == 2) ? m : 4;
+}
+
 /* switches applied to the handles opened next (name = the lame_set_* suffix); refh_option(0, 0) clears */
 static struct { char name[32]; float value; } refh_opts[24];
 static int refh_nopts = 0;
@@ -190,7 +200,7 @@ refh_open_vbr(int samplerate, int vbr_q, int mode, int quality, int out_samplera
     if (out_samplerate > 0)
         lame_set_out_samplerate(h->gfp, out_samplerate);
     lame_set_num_channels(h->gfp, refh_channels);
-    lame_set_VBR(h->gfp, vbr_mtrh);
+    lame_set_VBR(h->gfp, (vbr_mode) refh_vbr_mode);
     lame_set_VBR_q(h->gfp, vbr_q);
     lame_set_bWriteVbrTag(h->gfp, tag);
     if (mode >= 0)

@@ -44,6 +44,19 @@ VBR_CASES = [
 ]
 
 
+OLD_CASES = [
+    # the old VBR loop, lame_set_VBR(vbr_rh) / the frontend's --vbr-old: name, samplerate, -V n, mode, quality, seed,
+    # seconds, burst_interval, white
+    ("vbrold2_js_44k", 44100, 2, -1, -1, 501, 1.2, None, False),
+    ("vbrold4_js_44k_white", 44100, 4, -1, -1, 502, 0.8, None, True),
+    ("vbrold0_js_48k_bursts", 48000, 0, -1, -1, 503, 0.8, 1.0 / 40, False),    # sfb21 bands searched, short blocks
+    ("vbrold5_st_32k_q5", 32000, 5, 0, 5, 504, 0.8, None, False),
+    ("vbrold1_js_44k_q0", 44100, 1, -1, 0, 505, 0.6, None, True),              # one band per pass, full search
+    ("vbrold3_js_44k_silence", 44100, 3, -1, -1, -1, 0.5, None, False),
+    ("mono_vbrold4_44k", 44100, 4, 3, -1, 506, 0.8, None, False),
+]
+
+
 ABR_CASES = [
     # name, samplerate, mean kb/s (--abr n), mode, quality, seed, seconds, burst_interval, white
     ("abr128_js_44k", 44100, 128, -1, -1, 301, 1.2, None, False),
@@ -71,8 +84,9 @@ def frame_hash(fr):
 def table_hashes(tab):
     out = {}
     for name, _ in tab._fields_:
-        if name in ("fft_window", "fft_window_s", "fht_tw", "ma_max_i1", "ma_max_i2", "psy_l_to_s"):
-            continue            # file-local in the reference: not visible through the harness
+        if name in ("fft_window", "fft_window_s", "fht_tw", "ma_max_i1", "ma_max_i2", "psy_l_to_s", "hgrid", "qthr", "vqthr",
+                    "line_pad0", "line_pad1", "mask_mid"):
+            continue            # file-local in the reference (not visible through the harness), or derived for the device
         v = getattr(tab, name)
         out[name] = hashlib.sha256(bytes(v) if not isinstance(v, (int, float)) else repr(v).encode()).hexdigest()
     return out
@@ -106,14 +120,25 @@ def main():
         x = np.stack([x[0], x[0]])      # mono: the one channel the encoder reads
         cases.append((name, sr, kw.get("brate", 0), -1, q, (seed, secs, burst, white), x, kw.get("vbr_q", -1),
                       kw.get("abr", -1), 1))
-    for name, sr, br, mode, q, recipe, x, vq, abr, nch in cases:
+    cases = [c + (4,) for c in cases]
+    for name, sr, vq, mode, q, seed, secs, burst, white in OLD_CASES:
+        nn = int(sr * secs)
+        x = np.zeros((2, nn), np.int16) if seed < 0 else helpers.synth_stream(seed, nn, sr, burst, white)
+        nch = 1 if name.startswith("mono_") else 2
+        if nch == 1:
+            x = np.stack([x[0], x[0]])
+        cases.append((name, sr, 0, -1 if nch == 1 else mode, q, (seed, secs, burst, white), x, vq, -1, nch, 2))
+    only = sys.argv[1] if len(sys.argv) > 1 else ""     # make_golden.py [substring]: only the fixtures whose name holds it
+    for name, sr, br, mode, q, recipe, x, vq, abr, nch, vmode in cases:
+        if only not in name:
+            continue
         mp3, nf, frames, cfg, tab = ref.encode(x, sr, br, mode, q, max_frames=4096, vbr_q=None if vq < 0 else vq,
-                                               abr=None if abr < 0 else abr, channels=nch)
+                                               abr=None if abr < 0 else abr, channels=nch, vbr_mode=vmode)
         hashes = [frame_hash(frames[f]) for f in range(nf)]
         th = table_hashes(tab)
         np.savez_compressed(
             os.path.join(HERE, name + ".npz"),
-            samplerate=sr, brate=br, mode=mode, quality=q, vbr_q=vq, abr=abr, channels=nch,
+            samplerate=sr, brate=br, mode=mode, quality=q, vbr_q=vq, abr=abr, channels=nch, vbr_mode=vmode,
             recipe=np.array([-2 if recipe is None else recipe[0],
                              0 if recipe is None else recipe[1],
                              0 if (recipe is None or recipe[2] is None) else recipe[2],

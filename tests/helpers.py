@@ -88,10 +88,11 @@ class Reference:
         self.lib.refh_encode_stream.restype = C.c_long
 
     def encode(self, pcm, sr, brate, mode=-1, quality=-1, max_frames=0, vbr_q=None, out_samplerate=0, abr=None,
-               channels=2):
-        """CBR at `brate', vbr_mtrh at quality vbr_q, or ABR at a mean of `abr' kb/s; channels=1: mono
-        (only pcm[0] is read)."""
+               channels=2, vbr_mode=4):
+        """CBR at `brate', VBR (vbr_mode: 4 vbr_mtrh, 1 vbr_mt, 2 vbr_rh) at quality vbr_q, or ABR at a mean of
+        `abr' kb/s; channels=1: mono (only pcm[0] is read)."""
         self.lib.refh_set_channels(channels)
+        self.lib.refh_set_vbr_mode(vbr_mode)
         left = np.ascontiguousarray(pcm[0], dtype=np.int16)
         right = np.ascontiguousarray(pcm[1], dtype=np.int16)
         n = len(left)
@@ -117,13 +118,14 @@ class Reference:
         return buf.raw[:k], nf.value, frames, cfg, tab
 
 
-def reference_tagged(pcm, sr, brate, mode=-1, quality=-1, chunk=1152, vbr_q=None, abr=None, channels=2):
+def reference_tagged(pcm, sr, brate, mode=-1, quality=-1, chunk=1152, vbr_q=None, abr=None, channels=2, vbr_mode=4):
     """The compiled reference with its default tag handling (bWriteVbrTag = 1): returns
-    (stream bytes incl. the placeholder frame, final tag frame).  vbr_q selects vbr_mtrh."""
+    (stream bytes incl. the placeholder frame, final tag frame).  vbr_q selects VBR (vbr_mode as in Reference.encode)."""
     ref = Reference()
     lib = ref.lib
     lib.refh_open_tag.restype = C.c_void_p
     lib.refh_set_channels(channels)
+    lib.refh_set_vbr_mode(vbr_mode)
     if abr is not None:
         h = lib.refh_open_abr(sr, abr, mode, quality, 0, 1)
     elif vbr_q is None:
@@ -219,7 +221,8 @@ def golden_encoder_kwargs(g):
     """Keyword arguments of lamehip.Encoder for a fixture of any kind."""
     sr, br, mode, q = golden_settings(g)
     return dict(samplerate=sr, brate=br, mode=mode, quality=q, vbr_q=golden_vbr_q(g), abr=golden_abr(g),
-                channels=int(g["channels"]) if "channels" in g else 2)
+                channels=int(g["channels"]) if "channels" in g else 2,
+                vbr_mode=int(g["vbr_mode"]) if "vbr_mode" in g else 4)
 
 
 def golden_abr(g):

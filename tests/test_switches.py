@@ -49,10 +49,17 @@ CASES = [
     (dict(vbr_q=0), {"experimentalY": 1}), (dict(brate=128), {"experimentalY": 1}),
     (dict(brate=0), {"compression_ratio": 8.0}), (dict(brate=0), {"compression_ratio": 5.0}), (dict(brate=128), {"compression_ratio": 14.0}),
     (dict(brate=0), {}),
+    # the old VBR loop (lame_set_VBR(vbr_rh), the frontend's --vbr-old); a low -B makes it raise the allowed noise
+    # and search again (bitpressure_strategy)
+    (dict(vbr_q=2, vbr_mode=2), {}), (dict(vbr_q=4, vbr_mode=2), {"VBR_max_bitrate_kbps": 96}),
+    (dict(vbr_q=0, vbr_mode=2), {"VBR_max_bitrate_kbps": 64}), (dict(vbr_q=5, vbr_mode=2), {"VBR_min_bitrate_kbps": 128, "VBR_hard_min": 1}),
+    (dict(vbr_q=3, vbr_mode=2), {"force_ms": 1}), (dict(vbr_q=6, vbr_mode=2), {"disable_reservoir": 1}),
+    (dict(vbr_q=1, vbr_mode=2), {"ATHtype": 2}), (dict(vbr_q=0, vbr_mode=2), {"experimentalY": 1}),
+    (dict(vbr_q=2, vbr_mode=2), {"VBR_quality": 2.5}), (dict(vbr_q=4, vbr_mode=2), {"force_short_blocks": 1}),
 ]
 FLOAT_OPTS = ("scale", "scale_left", "scale_right", "VBR_quality", "ATHcurve", "ATHlower", "athaa_sensitivity", "interChRatio",
               "compression_ratio")
-IDS = ["%s-%s" % ("_".join("%s%s" % kv for kv in kw.items()), "_".join(o)) for kw, o in CASES]
+IDS = ["%s-%s" % ("_".join("%s%s" % kv for kv in kw.items()).replace("_vbr_mode2", "old"), "_".join(o)) for kw, o in CASES]
 
 
 def open_with(kw, opts, require_device):
@@ -66,7 +73,7 @@ def open_with(kw, opts, require_device):
     if "brate" in kw:
         lib.lame_set_brate(enc.h, kw["brate"])
     if "vbr_q" in kw:
-        lib.lame_set_VBR(enc.h, 4)
+        lib.lame_set_VBR(enc.h, kw.get("vbr_mode", 4))
         lib.lame_set_VBR_q(enc.h, kw["vbr_q"])
     if "abr" in kw:
         lib.lame_set_VBR(enc.h, 3)
