@@ -75,8 +75,8 @@ struct LhDeviceConst {
      * no such split. */
     static int pick_waves(const LhConfig & cfg) {
         const char *e = getenv("LAMEHIP_KERNEL_WAVES");
-        int const vbr_new = (cfg.vbr == 1 || cfg.vbr == 4);
-        return (e && e[0] == '4' && !vbr_new) ? 4 : 2;
+        int const vbr_loop = (cfg.vbr == 1 || cfg.vbr == 2 || cfg.vbr == 4);
+        return (e && e[0] == '4' && !vbr_loop) ? 4 : 2;
     }
     int launch(const int16_t * pcm, const float *pcmf, const LhStreamDesc * descs, LhStreamState * states,
                LhFrameOut * out, uint8_t * bytes, int nstreams, void *stream) const {
@@ -849,11 +849,6 @@ init_params_once(lame_t g)
         snprintf(g_err, sizeof(g_err), "no HIP device: liblamehip has no CPU encode path");
         g->have_device = 0;
         return LAMEHIP_ERR_NODEVICE;
-    }
-    if (g->cfg.vbr == 2) {
-        /* LH_VBR_OLD_PENDING: host constants and oracle are there, the device loop is not yet */
-        snprintf(g_err, sizeof(g_err), "lame_set_VBR(vbr_rh): the old VBR loop is not on the device yet");
-        return -1;
     }
     if (g->device < 0 && hipGetDevice(&g->device) != hipSuccess)
         g->device = 0;

@@ -306,6 +306,17 @@ struct LhVbrSave {
     int     ath_over, nonzero, pad[2];
 };
 
+/* what the old VBR loop (vbr_rh) parks of a granule between its passes over a frame: the granule as the search left
+ * it, before the finishing steps (lh_dev_vbrold.h) */
+struct LhVbrOldSave {
+    LhQR    R;
+    LhGrR   g;
+    uint8_t sf[LH_SFBMAX + 1];
+    float   xmin[LH_SFBMAX + 1];        /* allowed noise, raised by every bit-pressure pass */
+    int     used_bits, fin_bits;        /* part2_3 + part2 lengths after the search / after the finishing steps */
+    int     ath_over, pad;
+};
+
 struct LhQuantLds {
     LhChanLds ch[2];
 };
@@ -446,7 +457,12 @@ struct LhLds {
         struct {
             float   xr[2][2][576];      /* [ch][gr] MDCT spectra; written after the last read of mf */
             LhQTabs qt;                 /* loaded after the MDCT, used by the iteration loop */
-            LhVbrSave vbr[2][2];        /* [gr][ch]; in the tail the longer PCM window leaves free */
+            union {                     /* [gr][ch]; in the tail the longer PCM window leaves free (and a little more) */
+                LhVbrSave vbr[2][2];
+#ifndef LH_HELPERS
+                LhVbrOldSave old[2][2]; /* (the four-wave kernel never runs a VBR loop and has no room for it) */
+#endif
+            };
         };
     };
     union __attribute__((aligned(16))) {

@@ -289,4 +289,60 @@ lh_log10f(float x)
     return z + y * log10_2hi;
 }
 
+/* ---- the two double-precision expressions of the old VBR loop (reference quantize.c:1420-1428) ----
+ *   adjust        = (float) (1.28 / (1 + exp(3.5 - pe / 300.)) - 0.05)        (2.56 .. 0.14 for short blocks)
+ *   masking_lower = (float) pow(10.0, masking_lower_db * 0.1)
+ * Both take one float and give one float, so "equal to the host libm" can be checked for EVERY input: tools/
+ * sweep_vbrold_math.c runs these functions against glibc's exp / pow over all floats of their domains (pe in
+ * [0, 2^17), |db| <= 32) -- tests/test_vbrold_math.py runs a sample of that on every CPU test run.  exp here: the
+ * usual reduction by ln 2 in two parts and a degree-14 Taylor polynomial, about 0.6 ulp in double, which is 2^29
+ * times finer than the float the result is rounded to. */
+LH_DEVFN double
+lh_exp_dd(double hi, double lo)
+{
+    double const INVLN2 = lh_u64_as_f64(0x3ff71547652b82feull), LN2HI = lh_u64_as_f64(0x3fe62e42fee00000ull),
+        LN2LO = lh_u64_as_f64(0x3dea39ef35793c76ull), SHIFT = lh_u64_as_f64(0x4338000000000000ull);
+    double  kd = hi * INVLN2 + SHIFT, r, p;
+    int const k = (int) (uint32_t) lh_f64_as_u64(kd);
+    kd -= SHIFT;
+    r = lh_fma(-kd, LN2HI, hi);
+    r = lh_fma(-kd, LN2LO, r);
+    r += lo;
+    p = lh_u64_as_f64(0x3da93974a8c07c9dull);           /* 1 / 14! */
+    p = p * r + lh_u64_as_f64(0x3de6124613a86d09ull);
+    p = p * r + lh_u64_as_f64(0x3e21eed8eff8d898ull);
+    p = p * r + lh_u64_as_f64(0x3e5ae64567f544e4ull);
+    p = p * r + lh_u64_as_f64(0x3e927e4fb7789f5cull);
+    p = p * r + lh_u64_as_f64(0x3ec71de3a556c734ull);
+    p = p * r + lh_u64_as_f64(0x3efa01a01a01a01aull);
+    p = p * r + lh_u64_as_f64(0x3f2a01a01a01a01aull);
+    p = p * r + lh_u64_as_f64(0x3f56c16c16c16c17ull);
+    p = p * r + lh_u64_as_f64(0x3f81111111111111ull);
+    p = p * r + lh_u64_as_f64(0x3fa5555555555555ull);
+    p = p * r + lh_u64_as_f64(0x3fc5555555555555ull);
+    p = p * r + 0.5;                                    /* 1 / 2! */
+    p = 1.0 + (r + (r * r) * p);
+    if (k < -1000)
+        return 0.0;
+    return lh_u64_as_f64(lh_f64_as_u64(p) + ((uint64_t) (int64_t) k << 52));
+}
+
+LH_DEVFN float
+lh_vbrold_adjust(float pe, int short_block)
+{
+    double const x = 3.5 - (double) pe / 300.;
+    double const e = (x < -700.) ? 0.0 : lh_exp_dd(x, 0.0);
+    return short_block ? (float) (2.56 / (1 + e) - 0.14) : (float) (1.28 / (1 + e) - 0.05);
+}
+
+LH_DEVFN float
+lh_vbrold_masking_lower(float db)
+{
+    double const LN10HI = lh_u64_as_f64(0x40026bb1bbb55516ull), LN10LO = lh_u64_as_f64(0xbcaf48ad494ea3e9ull);
+    double const t = (double) db * 0.1;
+    double const hi = t * LN10HI;
+    double const lo = lh_fma(t, LN10HI, -hi) + t * LN10LO;
+    return (float) lh_exp_dd(hi, lo);
+}
+
 #endif

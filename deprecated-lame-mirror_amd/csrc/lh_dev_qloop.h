@@ -1053,9 +1053,16 @@ lq_bin_search(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q, con
     return bits;
 }
 
+/* what the old VBR loop (OLD = 1) keeps besides: xrpow of the best image, to continue from in the next search of the
+ * same granule (save_xrpow, reference quantize.c:1031, 1155, 1188-1190) */
+struct LhQOld {
+    float   xpb[10];
+    float   lmaxb;
+};
+
 /* the working image becomes the best one: it goes to its final place in LDS (Q.ix[0]) */
-template < int NS > LH_DEVFN void
-lq_keep_best(const LhCtx & c, LhQS & S, LhChanLds & Q)
+template < int NS, int OLD = 0 > LH_DEVFN void
+lq_keep_best(const LhCtx & c, LhQS & S, LhChanLds & Q, LhQOld * keep = nullptr)
 {
 #pragma unroll
     for (int k = 0; k < NS; k++) {
@@ -1065,12 +1072,19 @@ lq_keep_best(const LhCtx & c, LhQS & S, LhChanLds & Q)
     }
     S.sfbest = S.sfw;
     S.tselb = S.tselw;
+    if (OLD) {
+#pragma unroll
+        for (int k = 0; k < 10; k++)
+            keep->xpb[k] = S.xp[k];
+        keep->lmaxb = S.lmax;
+    }
 }
 
 /* reference quantize.c:1010-1197; gb = cod_info.  On return the best image and its scalefactors
  * are in Q.ix[0] / Q.sf[0]. */
-template < int NS, int ROLE > LH_DEVFN int
-lq_outer_loop(const LhCtx & c, LhQS & S, LhChanLds & Q, LhQR & R, LhGrR & gb, const float *xr, int ch, int targ_bits)
+template < int NS, int ROLE, int OLD = 0 > LH_DEVFN int
+lq_outer_loop(const LhCtx & c, LhQS & S, LhChanLds & Q, LhQR & R, LhGrR & gb, const float *xr, int ch, int targ_bits,
+              int sfb21_extra = 0, LhQOld * keep = nullptr)
 {
     LhGrR   gw;
     LhNoiseRes best_noise_info;
@@ -1088,16 +1102,31 @@ lq_outer_loop(const LhCtx & c, LhQS & S, LhChanLds & Q, LhQR & R, LhGrR & gb, co
     if (c.ns) {
         R.pn_global_gain = 0;
         R.pn_sfb_count1 = 0;
+        if (OLD) {
+            /* a fresh calc_noise_data for every search (memset, reference quantize.c:1038) */
+            S.pnstep = 0;
+            S.pnnoise = 0;
+            S.pnlog = 0;
+        }
         lq_noise_point < NS, ROLE > (c, S, R, gb, Q, xr, nt, best_noise_info);
         best_noise_info.bits = gb.part2_3_length;
         if (ROLE != 1)
-            lq_keep_best < NS > (c, S, Q);
+            lq_keep_best < NS, OLD > (c, S, Q, keep);
         gw = gb;
         age = 0;
         do {
             LhNoiseRes noise_info;
             int const search_limit = (R.substep_shaping & 2) ? 20 : 3;
             int     maxggain = 255;
+            if (OLD && sfb21_extra) {
+                /* the bands above the last one with a scalefactor cannot be amplified: once they are distorted
+                 * the search is over (reference quantize.c:1077-1084) */
+                int const s = c.lane;
+                int const hit = (s == R.sfbmax || (R.block_type == LH_SHORT_TYPE && (s == R.sfbmax + 1 || s == R.sfbmax + 2)))
+                    && S.dist > 1.0f;
+                if (lh_ballot(hit) != 0)
+                    break;
+            }
             {
                 LH_PT(t_bn);
                 int const bn = lq_balance_noise < NS > (c, S, Q, R, gw);
@@ -1133,7 +1162,7 @@ lq_outer_loop(const LhCtx & c, LhQS & S, LhChanLds & Q, LhQR & R, LhGrR & gb, co
                 best_part2_3_length = gb.part2_3_length;
                 best_noise_info = noise_info;
                 if (ROLE != 1)
-                    lq_keep_best < NS > (c, S, Q);
+                    lq_keep_best < NS, OLD > (c, S, Q, keep);
                 gb = gw;
                 age = 0;
             }
@@ -1147,9 +1176,19 @@ lq_outer_loop(const LhCtx & c, LhQS & S, LhChanLds & Q, LhQR & R, LhGrR & gb, co
         while ((gw.global_gain + gw.scalefac_scale) < 255);
     }
     else if (ROLE != 1)
-        lq_keep_best < NS > (c, S, Q);
+        lq_keep_best < NS, OLD > (c, S, Q, keep);
     if (ROLE == 1)
         return 0;               /* the sibling's copy of the result is not used */
+    if (OLD) {
+        /* the next search of this granule continues from the best image: its xrpow, scalefactors, subblock gains */
+#pragma unroll
+        for (int k = 0; k < 10; k++)
+            S.xp[k] = keep->xpb[k];
+        S.lmax = keep->lmaxb;
+        S.sfw = S.sfbest;
+        S.tselw = S.tselb;      /* (tables of regions the next count leaves empty stay as they are) */
+        S.sbg8 = 8 * lh_sbg(gb, S.win);
+    }
     gb.table_select[0] = (int) lh_bcast_u32((uint32_t) S.tselb, 0);
     gb.table_select[1] = (int) lh_bcast_u32((uint32_t) S.tselb, 1);
     gb.table_select[2] = (int) lh_bcast_u32((uint32_t) S.tselb, 2);
@@ -1180,6 +1219,117 @@ lq_stage_body(int qch, int gr, int targ_bits)
     if (ROLE != 1)
         lh_rg_put(c, R, g);
 }
+
+#ifndef LH_HELPERS
+/* The old VBR loop's search for one granule (reference quantize.c:1245-1331, VBR_encode_granule): a bisection over
+ * the bit budget between min_bits and max_bits; every trial is the search above at that budget, continuing from the
+ * best quantisation found so far (in registers all the time, and so is the one that fitted with the fewest bits,
+ * which is set aside: image, scalefactors, xrpow).  `cont': the granule comes with the scalefactors
+ * of an earlier pass over the frame (R / g in the channel's slot, Q.sf[0]); xrpow, the allowed noise and the
+ * geometry are fresh in Q as for any search. */
+template < int NS > LH_DEVFN void
+lq_vbrold_body(int qch, int gr, int min_bits, int max_bits, int cont)
+{
+    LhCtx const c = lh_ctx_load();
+    LhQR    R = lh_uniform(lh_lds.rg[qch].R);
+    LhGrR   g = lh_uniform(lh_lds.rg[qch].g);
+    LhChanLds & Q = lh_lds.u.quant.ch[qch];
+    const float *xr = lh_lds.xr[qch][lh_uni_i(gr)];
+    LhQS    S;
+    LhQOld  K;
+    LhGrR   gbst = g;
+    float   xpbst[10], lmaxbst = 0.0f;
+    uint32_t pwbst[5] = { 0u, 0u, 0u, 0u, 0u };
+    int     sfbst = 0, tselbst = 0;
+    int const band = c.lane <= LH_SFBMAX ? c.lane : LH_SFBMAX;
+    int     found = 0, dbits, this_bits;
+    min_bits = lh_uni_i(min_bits);
+    max_bits = lh_uni_i(max_bits);
+    int const top = max_bits;
+    R.s_mnc = lh_uni_i((int) Q.sfb_of_line[R.mnc]);
+    lq_load < -1 > (c, S, Q, R, g, qch);
+    if (lh_uni_i(cont)) {
+        S.sfw = Q.sf[0][band];
+        S.sfbest = S.sfw;
+        S.sbg8 = 8 * lh_sbg(g, S.win);
+        S.tselw = (c.lane == 0) ? g.table_select[0] : (c.lane == 1) ? g.table_select[1] : g.table_select[2];
+        S.tselb = S.tselw;
+    }
+#pragma unroll
+    for (int k = 0; k < 10; k++)
+        xpbst[k] = 0.0f;
+    this_bits = (max_bits + min_bits) / 2;
+    do {
+        int const sfb21 = c.sfb21_extra && !(this_bits > top - 42);
+        int const over = lq_outer_loop < NS, -1, 1 > (c, S, Q, R, g, xr, qch, this_bits, sfb21, &K);
+        if (over <= 0) {
+            /* it can be done with these bits: set it aside, try fewer */
+            found = 1;
+            gbst = g;
+            sfbst = S.sfbest;
+            tselbst = S.tselb;
+            lmaxbst = S.lmax;
+#pragma unroll
+            for (int k = 0; k < 10; k++)
+                xpbst[k] = S.xp[k];
+            LH_WAVE_SYNC();
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                int const p = c.lane + 64 * k;
+                pwbst[k] = ((const uint32_t *) Q.ix[0])[p < 288 ? p : 287];
+            }
+            max_bits = g.part2_3_length - 32;
+            dbits = max_bits - min_bits;
+            this_bits = (max_bits + min_bits) / 2;
+        }
+        else {
+            /* try more, from the best one so far */
+            min_bits = this_bits + 32;
+            dbits = max_bits - min_bits;
+            this_bits = (max_bits + min_bits) / 2;
+            if (found) {
+                found = 2;
+                g = gbst;
+                S.sfbest = sfbst;
+                S.sfw = sfbst;
+                S.tselb = tselbst;
+                S.tselw = tselbst;
+                S.sbg8 = 8 * lh_sbg(g, S.win);
+                S.lmax = lmaxbst;
+#pragma unroll
+                for (int k = 0; k < 10; k++)
+                    S.xp[k] = xpbst[k];
+                LH_WAVE_SYNC();
+#pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    int const p = c.lane + 64 * k;
+                    if (p < 288)
+                        ((uint32_t *) Q.ix[0])[p] = pwbst[k];
+                }
+                LH_WAVE_SYNC();
+            }
+        }
+    }
+    while (dbits > 12);
+    LH_WAVE_SYNC();
+    if (c.lane <= LH_SFBMAX)
+        Q.sf[0][c.lane] = S.sfbest;
+    LH_WAVE_SYNC();
+    lh_rg_put(c, R, g);
+}
+
+LH_STAGEFN void
+lq_vbrold_stage5(int qch, int gr, int min_bits, int max_bits, int cont)
+{
+    lq_vbrold_body < 5 > (qch, gr, min_bits, max_bits, cont);
+}
+
+LH_STAGEFN void
+lq_vbrold_stage4(int qch, int gr, int min_bits, int max_bits, int cont)
+{
+    lq_vbrold_body < 4 > (qch, gr, min_bits, max_bits, cont);
+}
+#endif
 
 #ifdef LH_HELPERS
 #define LQ_MAIN_ROLE 0

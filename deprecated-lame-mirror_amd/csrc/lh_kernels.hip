@@ -167,6 +167,9 @@ lh_store_granule(const LhCtx & c, const LhChanLds & Q, const LhQR & R, const LhG
 
 #include "lh_dev_emit.h"
 #include "lh_dev_vbr.h"
+#ifndef LH_HELPERS
+#include "lh_dev_vbrold.h"
+#endif
 
 /* what a granule's search starts from and what does not depend on its bit budget: geometry (init_outer_loop),
  * xrpow, the allowed noise per band (calc_xmin); R / g are left in the channel's LDS slot.  Returns 0 for an all-zero
@@ -414,10 +417,13 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
     int     mean_bits = lh_uni_i((frame_bits - cfg->sideinfo_len * 8) / cfg->mode_gr);
     int     total_bits = 0;
 #ifdef LH_HELPERS
-    int const vbr_new = 0;      /* the host launches the VBR loop with the two-wave kernel only */
+    int const vbr_new = 0;      /* the host launches the VBR loops with the two-wave kernel only */
     int const abr = (cfg->vbr == 3);
 #else
-    int const vbr_new = (cfg->vbr == 1 || cfg->vbr == 4), abr = (cfg->vbr == 3);
+    int const vbr_old = (cfg->vbr == 2);
+    /* (below, vbr_new stands for both VBR loops: either does the whole iteration stage in a function of its own) */
+    int const vbr_new = (cfg->vbr == 1 || cfg->vbr == 4 || vbr_old), abr = (cfg->vbr == 3);
+    float   masking_lower_left = cfg->masking_lower_long;
 #endif
     int     abr_targ[2][2] = { {0, 0}, {0, 0} }, analog_silence_bits = 0;
     if (vbr_new) {
@@ -427,7 +433,19 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
                 for (int ch = 0; ch < 2; ch++)
                     L.pe_use[gr][ch] = pe_use[gr][ch];
         LH_SYNC_WG();
-        lh_vbr_frame(fo, mode_ext, msoff);
+#ifndef LH_HELPERS
+        if (vbr_old) {
+            if (tid == 0) {
+                L.ms_ener_ratio[0] = ms_ener_ratio[0];
+                L.ms_ener_ratio[1] = ms_ener_ratio[1];
+            }
+            LH_SYNC_WG();
+            lh_vbrold_frame(fo, mode_ext, msoff);
+            masking_lower_left = lh_uni_f(L.pe_use[0][0]);
+        }
+        else
+#endif
+            lh_vbr_frame(fo, mode_ext, msoff);
         bitrate_index = lh_uni_i(L.frame_bits);
         total_bits = lh_uni_i(L.max_bits);
         ResvSize = lh_uni_i(L.mean_bits);
@@ -628,8 +646,11 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
         lh_lds.ss.substep_shaping = substep;
         /* what the next frame's psy model finds in sv_qnt.masking_lower: the CBR loop leaves the value
          * of its last granule/channel (channel 0 for mono), the VBR loop always the long-block one (reference quantize.c:1622) */
-        lh_lds.ss.masking_lower = (vbr_new || L.block_type[1][nch - 1] != LH_SHORT_TYPE) ? cfg->masking_lower_long
-            : cfg->masking_lower_short;
+#ifdef LH_HELPERS
+        float const masking_lower_left = cfg->masking_lower_long;
+#endif
+        lh_lds.ss.masking_lower = vbr_new ? masking_lower_left
+            : (L.block_type[1][nch - 1] != LH_SHORT_TYPE) ? cfg->masking_lower_long : cfg->masking_lower_short;
         lh_lds.ss.frame_number = lh_lds.ss.frame_number + 1;
         if (mdb * 8 != ResvSize)
             lh_lds.ss.status |= 1;    /* reservoir inconsistency (reference bitstream.c:947) */

@@ -10,6 +10,8 @@
  * largest one be too small, the allowed noise is raised and everything runs once more.
  */
 #include "orc_common.h"
+#include <stdio.h>
+#include <stdlib.h>
 
 /* reference quantize.c:1245-1331 */
 static void
@@ -147,6 +149,12 @@ orc_vbr_old_iteration_loop(OrcStream * S, float pe[2][2], const float ms_ener_ra
     int     min_bits[2][2], max_bits[2][2];
     int     ch, gr, analog_silence;
 
+    /* Test hook: the budgets of VBR_old_prepare add up to what the largest frame holds and every search stays inside
+     * its budget, so real input does not reach the second pass (only a search that ends at global_gain 255 could);
+     * LH_TEST_FORCE_PRESSURE=n makes the first n evaluations of a frame fail, here and in the emulator build of
+     * the kernel alike, so that the pass is compared at all. */
+    int     forced = getenv("LH_TEST_FORCE_PRESSURE") ? atoi(getenv("LH_TEST_FORCE_PRESSURE")) : 0;
+
     analog_silence = vbr_old_prepare(S, pe, ms_ener_ratio, ratio, l3_xmin, frameBits, min_bits, max_bits);
     for (;;) {
         used_bits = 0;
@@ -168,7 +176,7 @@ orc_vbr_old_iteration_loop(OrcStream * S, float pe[2][2], const float ms_ener_ra
             if (used_bits <= frameBits[S->bitrate_index])
                 break;
         bits = ResvFrameBegin(S, &mean_bits);
-        if (used_bits <= bits)
+        if (used_bits <= bits && forced-- <= 0)
             break;
         vbr_old_bitpressure(S, l3_xmin, min_bits, max_bits);
     }

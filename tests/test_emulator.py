@@ -33,7 +33,10 @@ def emu():
                                           ("cbr256_js_44k_q2", 5), ("cbr96_js_32k", 6),
                                           ("vbr2_js_44k", 8), ("vbr4_js_44k_white", 8), ("vbr0_js_48k_bursts", 8),
                                           ("vbr5_st_32k", 6), ("abr128_js_44k", 6), ("abr150_js_32k_white_q5", 6),
-                                          ("mono_cbr160_48k_bursts_q5", 6), ("mono_vbr2_44k", 6), ("mono_abr100_44k", 5)])
+                                          ("mono_cbr160_48k_bursts_q5", 6), ("mono_vbr2_44k", 6), ("mono_abr100_44k", 5),
+                                          ("vbrold2_js_44k", 8), ("vbrold4_js_44k_white", 6), ("vbrold0_js_48k_bursts", 8),
+                                          ("vbrold5_st_32k_q5", 6), ("vbrold1_js_44k_q0", 3), ("vbrold3_js_44k_silence", 4),
+                                          ("mono_vbrold4_44k", 6)])
 def test_kernel_source_matches_oracle(name, nframes, emu, oracle):
     g, pcm = helpers.load_golden(name)
     sr, br, mode, q = helpers.golden_settings(g)
@@ -109,7 +112,7 @@ def test_kernel_source_frame_per_launch_with_poisoned_lds(name, nframes, emu, or
 
 
 @pytest.mark.parametrize("name", ["cbr128_js_44k_silence", "cbr320_js_48k_bursts", "vbr4_js_44k_white", "abr150_js_32k_white_q5",
-                                  "mono_vbr2_44k", "testcase_wav_cbr128"])
+                                  "mono_vbr2_44k", "testcase_wav_cbr128", "vbrold0_js_48k_bursts"])
 def test_device_bit_packer_source_matches_host_packer(name, emu, oracle):
     """lh_dev_emit.h under the emulator: the bytes the kernel assembles (headers, side information, Huffman
     data around the headers, stuffing, final padding) equal the host packer's, i.e. the reference's."""
@@ -158,4 +161,34 @@ def test_device_bit_packer_flags_a_slice_that_is_too_small(emu):
     frame_number, primed, status = int(words[10]), int(words[11]), int(words[12])
     assert frame_number == nframes and primed == 1      # (the offsets are right)
     assert status & 8
+    enc.close()
+
+
+@pytest.mark.parametrize("name,nframes,forced", [("vbrold2_js_44k", 3, 1), ("vbrold0_js_48k_bursts", 5, 2), ("vbrold1_js_44k_q0", 2, 2),
+                                                 ("mono_vbrold4_44k", 3, 1)])
+def test_old_vbr_loop_second_pass_source_matches_oracle(name, nframes, forced, emu, oracle, monkeypatch):
+    """The old VBR loop's second pass over a frame (bitpressure_strategy: more noise allowed, smaller budgets, every
+    granule searched again from the scalefactors the last pass left).  The budgets of the first pass add up to what
+    the largest frame holds, so real input never gets there; LH_TEST_FORCE_PRESSURE makes the first `forced'
+    evaluations of every frame fail in the oracle and in the emulator build of the kernel source alike."""
+    monkeypatch.setenv("LH_TEST_FORCE_PRESSURE", str(forced))
+    g, pcm = helpers.load_golden(name)
+    enc = lamehip.Encoder(require_device=False, **helpers.golden_encoder_kwargs(g))
+    cfg, tab = enc.config(), enc.tables()
+    want = oracle.encode_frames(cfg, tab, pcm, max_frames=nframes)
+    plain = None
+    monkeypatch.delenv("LH_TEST_FORCE_PRESSURE")
+    plain = oracle.encode_frames(cfg, tab, pcm, max_frames=nframes)
+    assert any(struct_diff(want[f], plain[f]) for f in range(nframes)), "the forced pass changes the result"
+    monkeypatch.setenv("LH_TEST_FORCE_PRESSURE", str(forced))
+    n = pcm.shape[1]
+    pool = np.concatenate([pcm[0], pcm[1]]).astype(np.int16)
+    desc = LhStreamDesc(0, n, 0, n, 0, 0, nframes)
+    state = C.create_string_buffer(enc.lib.lamehip_abi_sizeof(4))
+    enc.lib.lh_state_init(state, C.byref(cfg))
+    got = (LhFrameOut * nframes)()
+    emu.lh_emu_encode(C.byref(cfg), C.byref(tab), pool.ctypes.data_as(C.c_void_p), C.byref(desc), state, got, 1)
+    for f in range(nframes):
+        d = struct_diff(want[f], got[f])
+        assert not d, (f, d[:4])
     enc.close()

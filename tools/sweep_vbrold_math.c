@@ -1,0 +1,52 @@
+/* Exhaustive check of the old VBR loop's two double-precision expressions as the device evaluates them
+ * (csrc/lh_dev_math.h: lh_vbrold_adjust, lh_vbrold_masking_lower) against this host's libm, float in -> float out:
+ *   adjust:         every float pe in [0, 2^17)        (long and short variant)
+ *   masking_lower:  every float db with |db| <= 32
+ * usage: sweep_vbrold_math [stride]   (stride 1 = all ~6 10^9 evaluations, a few minutes on 16 cores; the test suite
+ * uses a larger stride).  Prints the inputs that differ; exit code 1 if there are any.
+ * build: gcc -O2 -fno-fast-math -ffp-contract=off -fopenmp -DLH_EMU -I deprecated-lame-mirror_amd/csrc -I include \
+ *        tools/sweep_vbrold_math.c -o /tmp/sweep_vbrold_math -lm */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdint.h>
+static inline double lh_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+#define LH_WAVE_H
+#define LH_DEVFN static inline
+#define LH_STAGEFN static
+#define LH_DEVCONST static const
+#include "lh_dev_math.h"
+
+static float from_bits(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static uint32_t to_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+int
+main(int argc, char **argv)
+{
+    long const stride = argc > 1 ? atol(argv[1]) : 1;
+    long    bad = 0, n = 0;
+    uint32_t const pe_top = to_bits(131072.0f), db_top = to_bits(32.0f);
+    long    i;
+#pragma omp parallel for reduction(+:bad,n) schedule(static, 65536)
+    for (i = 0; i <= (long) pe_top; i += stride) {
+        float const pe = from_bits((uint32_t) i);
+        float const w0 = 1.28 / (1 + exp(3.5 - pe / 300.)) - 0.05, w1 = 2.56 / (1 + exp(3.5 - pe / 300.)) - 0.14;
+        float const g0 = lh_vbrold_adjust(pe, 0), g1 = lh_vbrold_adjust(pe, 1);
+        n += 2;
+        if (to_bits(w0) != to_bits(g0)) { bad++; printf("adjust long  pe %a (%#x): libm %a, here %a\n", pe, (unsigned) i, w0, g0); }
+        if (to_bits(w1) != to_bits(g1)) { bad++; printf("adjust short pe %a (%#x): libm %a, here %a\n", pe, (unsigned) i, w1, g1); }
+    }
+#pragma omp parallel for reduction(+:bad,n) schedule(static, 65536)
+    for (i = 0; i <= (long) db_top; i += stride) {
+        int     sgn;
+        for (sgn = 0; sgn < 2; sgn++) {
+            float const db = from_bits((uint32_t) i | (sgn ? 0x80000000u : 0u));
+            float const w = pow(10.0, db * 0.1), g = lh_vbrold_masking_lower(db);
+            n++;
+            if (to_bits(w) != to_bits(g)) { bad++; printf("masking_lower db %a: libm %a, here %a\n", db, w, g); }
+        }
+    }
+    printf("%ld evaluations, %ld differ\n", n, bad);
+    return bad != 0;
+}
