@@ -438,7 +438,7 @@ lame_print_config(const lame_t g)
     report_through(g->report_msg, "liblamehip (MI355X): %d Hz -> %d Hz, %s, %s, quality %d, lowpass %d Hz\n", g->p.samplerate,
                    g->cfg.samplerate, g->cfg.mode == LH_MODE_MONO ? "mono" : g->cfg.mode == LH_MODE_JOINT_STEREO ? "joint stereo" :
                    g->cfg.mode == LH_MODE_DUAL ? "dual channel" : "stereo",
-                   g->cfg.vbr == 0 ? "CBR" : g->cfg.vbr == 3 ? "ABR" : "VBR (new)", g->cfg.quality, g->cfg.lowpassfreq);
+                   g->cfg.vbr == 0 ? "CBR" : g->cfg.vbr == 3 ? "ABR" : g->cfg.vbr == 2 ? "VBR (old)" : "VBR (new)", g->cfg.quality, g->cfg.lowpassfreq);
 }
 
 extern "C" void
@@ -792,13 +792,13 @@ init_params_once(lame_t g)
 {
     LhInitAux aux;
     g->p.samplerate_out = g->out_samplerate;
-    if (g->preset_vbr && g->p.vbr != 1 && g->p.vbr != 4) {
-        snprintf(g_err, sizeof(g_err), "a V0..V9 preset without lame_set_VBR(vbr_mtrh / vbr_mt) is outside the accelerated path");
+    if (g->preset_vbr && g->p.vbr != 1 && g->p.vbr != 2 && g->p.vbr != 4) {
+        snprintf(g_err, sizeof(g_err), "a V0..V9 preset without lame_set_VBR(vbr_mtrh / vbr_mt / vbr_rh) is outside the accelerated path");
         return -1;
     }
     if (lh_config_resolve(&g->p, &g->cfg, &aux) != 0) {
         snprintf(g_err, sizeof(g_err),
-                 "unsupported settings for the MI355X path (need an MPEG-1 output rate, 1 or 2 input channels, CBR / ABR / vbr_mtrh)");
+                 "unsupported settings for the MI355X path (need an MPEG-1 output rate, 1 or 2 input channels)");
         return -1;
     }
     /* (a call that failed before g->inited may be repeated: what it had allocated is reused) */

@@ -43,6 +43,9 @@ COMMANDS = [
     ("synth_b96_resample32", "synth", ["-b", "96", "--resample", "32"]),
     ("synth_V5_dual", "synth", ["-V", "5", "-m", "d"]),
     ("synth_abr128_limits", "synth", ["--abr", "128", "-b", "64", "-B", "192"]),
+    ("testcase_vbr_old_V2", "testcase", ["--vbr-old", "-V", "2"]),       # lame_set_VBR(vbr_rh): the old VBR loop
+    ("synth_vbr_old_V0_q0", "synth", ["--vbr-old", "-V", "0", "-q", "0"]),
+    ("synth_vbr_old_V5_limits_mono", "synth", ["--vbr-old", "-V", "5.5", "-b", "64", "-B", "160", "-m", "m"]),
     # (the frontend's developer switches -- --athtype, --nsmsfix, --ns-bass, --noath, --noshort ... -- are compiled out of
     # a default build of the frontend, parse.c:75-79; the setters behind them are covered by tests/test_switches.py)
 ]

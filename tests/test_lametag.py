@@ -91,20 +91,20 @@ def test_api_default_tag_handling_matches_reference(sr, br, mode, chunk, vq):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("vq,abr", [(None, None), (2, None), (None, 180)])
-def test_batch_pack_tagged_is_the_reference_file_image(vq, abr):
+@pytest.mark.parametrize("vq,abr,vmode", [(None, None, 4), (2, None, 4), (None, 180, 4), (3, None, 2)])
+def test_batch_pack_tagged_is_the_reference_file_image(vq, abr, vmode):
     """Batch path: tag frame + audio == the reference's stream with its placeholder replaced by
     its final tag frame (what the frontend leaves on disk)."""
     sr, br = 44100, 128
     pcms = [helpers.synth_stream(777 + i, int(sr * (0.8 + 0.37 * i)), sr, 1.0 / 4) for i in range(4)]
-    enc = lamehip.Encoder(sr, br, vbr_q=vq, abr=abr)
+    enc = lamehip.Encoder(sr, br, vbr_q=vq, abr=abr, vbr_mode=vmode)   # (vmode 2: the old VBR loop, tag method byte 3)
     b = lamehip.Batch(enc, len(pcms), max(x.shape[1] for x in pcms))
     b.set_device_packing()
     for s, x in enumerate(pcms):
         b.set_pcm(s, x[0], x[1])
     b.encode()
     for s, x in enumerate(pcms):
-        stream, tag = helpers.reference_tagged(x, sr, br, vbr_q=vq, abr=abr)
+        stream, tag = helpers.reference_tagged(x, sr, br, vbr_q=vq, abr=abr, vbr_mode=vmode)
         assert b.pack_tagged(s) == tag + stream[len(tag):]
         assert b.get_bytes_tagged(s) == tag + stream[len(tag):]     # the same from the device-packed bytes
     b.close()
