@@ -78,7 +78,7 @@ SIGNAL = ("SURVEY 8(d) recipe on the device: 8 partials with 5 Hz vibrato, band-
 def _cpu_worker(job):
     """One process of the CPU leg (spawned: no GPU context): encode stream `idx' of the saved PCM
     over and over for about `budget' seconds; returns (audio seconds encoded, elapsed)."""
-    path, idx, sr, brate, vbr_q, abr, budget, kind = job
+    path, idx, sr, brate, vbr_q, abr, budget, kind, vbr_mode = job
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "deprecated-lame-mirror_amd"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -90,11 +90,11 @@ def _cpu_worker(job):
         ref = helpers.Reference()
 
         def run():
-            ref.encode(pcm, sr, brate, vbr_q=vbr_q, abr=abr)
+            ref.encode(pcm, sr, brate, vbr_q=vbr_q, abr=abr, vbr_mode=vbr_mode)
     else:
         import lamehip
         orc = helpers.Oracle()
-        enc = lamehip.Encoder(sr, brate, require_device=False, vbr_q=vbr_q, abr=abr)
+        enc = lamehip.Encoder(sr, brate, require_device=False, vbr_q=vbr_q, abr=abr, vbr_mode=vbr_mode)
         cfg, tab = enc.config(), enc.tables()
 
         def run():
@@ -157,7 +157,7 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline(host_pcm, sr, brate, vbr_q=None, abr=None, budget=10.0):
+def cpu_baseline(host_pcm, sr, brate, vbr_q=None, abr=None, budget=10.0, vbr_mode=4):
     """P concurrent encodes, P = physical cores (at most as many as there are saved streams),
     plus one process alone for the per-core figure."""
     import multiprocessing as mp
@@ -174,15 +174,15 @@ def cpu_baseline(host_pcm, sr, brate, vbr_q=None, abr=None, budget=10.0):
     try:
         ctx = mp.get_context("spawn")
         with ctx.Pool(1) as pool:
-            a, t = pool.map(_cpu_worker, [(tmp.name, 0, sr, brate, vbr_q, abr, min(budget, 4.0), kind)])[0]
+            a, t = pool.map(_cpu_worker, [(tmp.name, 0, sr, brate, vbr_q, abr, min(budget, 4.0), kind, vbr_mode)])[0]
         single = a / t
         with ctx.Pool(procs) as pool:
-            res = pool.map(_cpu_worker, [(tmp.name, i, sr, brate, vbr_q, abr, budget, kind) for i in range(procs)],
+            res = pool.map(_cpu_worker, [(tmp.name, i, sr, brate, vbr_q, abr, budget, kind, vbr_mode) for i in range(procs)],
                            chunksize=1)
     finally:
         os.unlink(tmp.name)
     aggregate = sum(a / t for a, t in res)
-    what = ("ABR %d" % abr) if abr is not None else ("CBR %d" % brate) if vbr_q is None else ("VBR -V%d" % vbr_q)
+    what = ("ABR %d" % abr) if abr is not None else ("CBR %d" % brate) if vbr_q is None else ("VBR -V%d%s" % (vbr_q, " --vbr-old" if vbr_mode == 2 else ""))
     return {"value": round(aggregate, 1), "unit": "x real-time", "cores": procs, "kind": kind,
             "per_core": round(aggregate / procs, 2), "one_process_alone": round(single, 2),
             "physical_cores": cores, "logical_cpus": os.cpu_count(), "cpus_in_affinity_mask": allowed,
@@ -392,6 +392,7 @@ def main():
     ap.add_argument("--brate", type=int, default=128)
     ap.add_argument("--vbr", type=int, default=None, metavar="Q",
                     help="vbr_mtrh at quality Q (BASELINE config[2] is -V2) instead of CBR; not the default line")
+    ap.add_argument("--vbr-old", action="store_true", help="with --vbr Q: the old VBR loop, lame_set_VBR(vbr_rh), instead of vbr_mtrh")
     ap.add_argument("--abr", type=int, default=None, metavar="KBPS", help="ABR at a mean of KBPS instead of CBR")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the short runs of BASELINE configs [2] and [4]")
@@ -427,7 +428,8 @@ def main():
     n = int(args.seconds * sr)
     lo, hi = lamehip.shard_streams(world * B, world, rank)      # this rank's block of the global batch
     assert hi - lo == B
-    enc = lamehip.Encoder(sr, args.brate, vbr_q=args.vbr, abr=args.abr, device=device_index)
+    vbr_mode = 2 if args.vbr_old else 4
+    enc = lamehip.Encoder(sr, args.brate, vbr_q=args.vbr, abr=args.abr, device=device_index, vbr_mode=vbr_mode)
     batch = lamehip.Batch(enc, B, n, device=device_index)
     pcm = synth_on_device(torch, B, n, sr, lo, dev)             # seeds follow the global stream index
     torch.cuda.synchronize()
@@ -468,7 +470,7 @@ def main():
         audio_s = world * B * args.seconds * args.steps
         value = audio_s / dt
         kavg = sum(kernel_ms) / len(kernel_ms) / 1e3
-        what = ("ABR%d" % args.abr if args.abr is not None else "CBR128" if args.vbr is None else "VBR -V%d" % args.vbr)
+        what = ("ABR%d" % args.abr if args.abr is not None else "CBR128" if args.vbr is None else "VBR -V%d%s" % (args.vbr, " --vbr-old" if args.vbr_old else ""))
         res = {
             "metric": "encoded audio seconds/sec (x real-time) at 44.1kHz stereo " + what,
             "value": round(value, 1), "unit": "x real-time", "n_gpus": world, "steps": args.steps,
@@ -481,7 +483,9 @@ def main():
                        ("batch=%d synthetic %.1f kHz stereo streams x %.0f s, ABR %d kb/s, per GPU"
                         % (B, sr / 1000.0, args.seconds, args.abr)) if args.abr is not None else
                        ("batch=%d synthetic %.1f kHz stereo streams x %.0f s, VBR -V%d (vbrquantize.c path), "
-                        "per GPU (BASELINE config[2])" % (B, sr / 1000.0, args.seconds, args.vbr)),
+                        "per GPU (BASELINE config[2])" % (B, sr / 1000.0, args.seconds, args.vbr)) if not args.vbr_old else
+                       ("batch=%d synthetic %.1f kHz stereo streams x %.0f s, VBR -V%d --vbr-old (VBR_old_iteration_loop), "
+                        "per GPU" % (B, sr / 1000.0, args.seconds, args.vbr)),
                        "streams_per_gpu": B, "seconds_per_stream": args.seconds,
                        "per_stream_x_realtime": round(value / (world * B), 2),
                        "parallelism": "static sharding: rank r owns the contiguous block shard_streams(N*B, N, r); "
@@ -489,17 +493,20 @@ def main():
                        "ranks": "spawned by bench.py (file barrier)" if "LAMEHIP_BENCH_RDV" in os.environ
                        else ("launcher (gloo barrier on the CPU)" if world > 1 else "single process"),
                        "devices_visible": ndev},
-            "roofline": roofline_block(frames, kavg, "r03_pmc.json" if args.vbr is None else "r03_pmc_vbr2.json"),
+            "roofline": roofline_block(frames, kavg, "r03_pmc.json" if args.vbr is None else
+                                       "r03_pmc_vbrold2.json" if args.vbr_old else "r03_pmc_vbr2.json"),
             "checked_against_oracle": checked,
         }
         if host_cpu is not None:
-            res["cpu_baseline"] = cpu_baseline(host_cpu, sr, args.brate, vbr_q=args.vbr, abr=args.abr)
+            res["cpu_baseline"] = cpu_baseline(host_cpu, sr, args.brate, vbr_q=args.vbr, abr=args.abr, vbr_mode=vbr_mode)
         if not args.no_extras and world == 1 and args.vbr is None and args.abr is None:
             batch.close()
             batch = None
             res["extra"] = {
                 "vbr_v2_config2": short_run(torch, lamehip, dev, device_index, 44100, 1024, 5.0, 2, 5000, 3.0,
                                             "r03_pmc_vbr2.json", vbr_q=2),
+                "vbr_old_v2": short_run(torch, lamehip, dev, device_index, 44100, 1024, 5.0, 2, 5000, 3.0,
+                                        "r03_pmc_vbrold2.json", vbr_q=2, vbr_mode=2),
                 "cbr320_48k_bursts_config4": short_run(torch, lamehip, dev, device_index, 48000, 1024, 5.0, 2, 9000,
                                                        40.0, "r03_pmc_cbr320.json", brate=320, mode=1),
             }

@@ -306,6 +306,12 @@ struct LhVbrSave {
     int     ath_over, nonzero, pad[2];
 };
 
+/* The old VBR loop is part of the two-wave kernel; the four-wave kernel never runs a VBR loop, and the profiling build's
+ * cycle counters take the LDS its parking area needs. */
+#if !defined(LH_HELPERS) && !(defined(LH_PROF) && !defined(LH_EMU))
+#define LH_VBR_OLD 1
+#endif
+
 /* what the old VBR loop (vbr_rh) parks of a granule between its passes over a frame: the granule as the search left
  * it, before the finishing steps (lh_dev_vbrold.h) */
 struct LhVbrOldSave {
@@ -459,8 +465,8 @@ struct LhLds {
             LhQTabs qt;                 /* loaded after the MDCT, used by the iteration loop */
             union {                     /* [gr][ch]; in the tail the longer PCM window leaves free (and a little more) */
                 LhVbrSave vbr[2][2];
-#ifndef LH_HELPERS
-                LhVbrOldSave old[2][2]; /* (the four-wave kernel never runs a VBR loop and has no room for it) */
+#ifdef LH_VBR_OLD
+                LhVbrOldSave old[2][2];
 #endif
             };
         };

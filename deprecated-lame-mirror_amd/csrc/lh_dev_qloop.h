@@ -1220,7 +1220,7 @@ lq_stage_body(int qch, int gr, int targ_bits)
         lh_rg_put(c, R, g);
 }
 
-#ifndef LH_HELPERS
+#ifdef LH_VBR_OLD
 /* The old VBR loop's search for one granule (reference quantize.c:1245-1331, VBR_encode_granule): a bisection over
  * the bit budget between min_bits and max_bits; every trial is the search above at that budget, continuing from the
  * best quantisation found so far (in registers all the time, and so is the one that fitted with the fewest bits,

@@ -167,7 +167,7 @@ lh_store_granule(const LhCtx & c, const LhChanLds & Q, const LhQR & R, const LhG
 
 #include "lh_dev_emit.h"
 #include "lh_dev_vbr.h"
-#ifndef LH_HELPERS
+#ifdef LH_VBR_OLD
 #include "lh_dev_vbrold.h"
 #endif
 
@@ -420,7 +420,11 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
     int const vbr_new = 0;      /* the host launches the VBR loops with the two-wave kernel only */
     int const abr = (cfg->vbr == 3);
 #else
+#ifdef LH_VBR_OLD
     int const vbr_old = (cfg->vbr == 2);
+#else
+    int const vbr_old = 0;
+#endif
     /* (below, vbr_new stands for both VBR loops: either does the whole iteration stage in a function of its own) */
     int const vbr_new = (cfg->vbr == 1 || cfg->vbr == 4 || vbr_old), abr = (cfg->vbr == 3);
     float   masking_lower_left = cfg->masking_lower_long;
@@ -433,7 +437,7 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
                 for (int ch = 0; ch < 2; ch++)
                     L.pe_use[gr][ch] = pe_use[gr][ch];
         LH_SYNC_WG();
-#ifndef LH_HELPERS
+#ifdef LH_VBR_OLD
         if (vbr_old) {
             if (tid == 0) {
                 L.ms_ener_ratio[0] = ms_ener_ratio[0];

@@ -11,7 +11,7 @@
  * of handles.
  *
  * Everything here is plain C: pointers and sizes only, no torch / HIP types.
- * Unsupported settings (the old VBR loop, MPEG-2 / 2.5 output rates) make
+ * Unsupported settings (MPEG-2 / 2.5 output rates, free format) make
  * lame_init_params() return -1 instead of silently taking another path, and
  * every call fails with LAMEHIP_ERR_NODEVICE when no HIP device is present --
  * there is no CPU fallback inside this library.

@@ -102,6 +102,7 @@ class Reference:
             h = self.lib.refh_open(sr, brate, mode, quality)
         else:
             h = self.lib.refh_open_vbr(sr, vbr_q, mode, quality, out_samplerate, 0)
+        self.lib.refh_set_vbr_mode(4)       # (a setting of the harness, not of the handle: back to the default)
         assert h, "reference refused the settings"
         h = C.c_void_p(h)
         buf = C.create_string_buffer(2 * n + 100000)
@@ -132,6 +133,7 @@ def reference_tagged(pcm, sr, brate, mode=-1, quality=-1, chunk=1152, vbr_q=None
         h = lib.refh_open_tag(sr, brate, mode, quality)
     else:
         h = lib.refh_open_vbr(sr, vbr_q, mode, quality, sr if vbr_q >= 7 else 0, 1)
+    lib.refh_set_vbr_mode(4)
     assert h, "reference refused the settings"
     h = C.c_void_p(h)
     left = np.ascontiguousarray(pcm[0], dtype=np.int16)

@@ -34,7 +34,7 @@ def test_pod_sizes_match_bindings():
 def test_unsupported_settings_are_refused_loudly():
     lib = lamehip.load_library()
     for setup in (lambda h: lib.lame_set_num_channels(h, 3),          # neither mono nor stereo
-                  lambda h: lib.lame_set_VBR(h, 2),                   # vbr_rh (old VBR loop)
+                  lambda h: (lib.lame_set_VBR(h, 2), lib.lame_set_VBR_q(h, 9)),   # vbr_rh -V9: lowpass 10 kHz -> a 24 kHz (MPEG-2) stream
                   lambda h: lib.lame_set_in_samplerate(h, 22050),     # MPEG-2
                   lambda h: lib.lame_set_brate(h, 64)):               # reference would resample to 24 kHz
         h = C.c_void_p(lib.lame_init())
