@@ -293,8 +293,8 @@ lh_log10f(float x)
  *   adjust        = (float) (1.28 / (1 + exp(3.5 - pe / 300.)) - 0.05)        (2.56 .. 0.14 for short blocks)
  *   masking_lower = (float) pow(10.0, masking_lower_db * 0.1)
  * Both take one float and give one float, so "equal to the host libm" can be checked for EVERY input: tools/
- * sweep_vbrold_math.c runs these functions against glibc's exp / pow over all floats of their domains (pe in
- * [0, 2^17), |db| <= 32) -- tests/test_vbrold_math.py runs a sample of that on every CPU test run.  exp here: the
+ * sweep_vbrold_math.c runs these functions against glibc's exp / pow over all floats of their domains (|pe| <
+ * 2^20 -- beyond, exp is 0 or so large that the result no longer moves --, |db| <= 32) -- tests/test_vbrold_math.py runs a sample of that on every CPU test run.  exp here: the
  * usual reduction by ln 2 in two parts and a degree-14 Taylor polynomial, about 0.6 ulp in double, which is 2^29
  * times finer than the float the result is rounded to. */
 LH_DEVFN double
@@ -322,16 +322,20 @@ lh_exp_dd(double hi, double lo)
     p = p * r + lh_u64_as_f64(0x3fc5555555555555ull);
     p = p * r + 0.5;                                    /* 1 / 2! */
     p = 1.0 + (r + (r * r) * p);
-    if (k < -1000)
-        return 0.0;
-    return lh_u64_as_f64(lh_f64_as_u64(p) + ((uint64_t) (int64_t) k << 52));
+    {
+        /* 2^k in two factors: the product overflows to infinity / underflows as IEEE arithmetic has it (pe may be
+         * hugely negative -- the PE smoothing filter's scale can be -- and exp() of the reference is then +inf) */
+        int const k1 = k / 2, k2 = k - k1;
+        double const f1 = lh_u64_as_f64((uint64_t) (1023 + k1) << 52), f2 = lh_u64_as_f64((uint64_t) (1023 + k2) << 52);
+        return (p * f1) * f2;
+    }
 }
 
 LH_DEVFN float
 lh_vbrold_adjust(float pe, int short_block)
 {
     double const x = 3.5 - (double) pe / 300.;
-    double const e = (x < -700.) ? 0.0 : lh_exp_dd(x, 0.0);
+    double const e = (x < -1000.) ? 0.0 : (x > 1000.) ? (double) __builtin_inff() : lh_exp_dd(x, 0.0);
     return short_block ? (float) (2.56 / (1 + e) - 0.14) : (float) (1.28 / (1 + e) - 0.05);
 }
 

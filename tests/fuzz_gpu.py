@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Randomised parity hunt on the GPU box (test tool, not collected by pytest): many short streams
 of awkward signals per setting, HIP payload against the CPU oracle, frame by frame.
-Usage: python tests/fuzz_gpu.py [streams] [seconds] [seed0] [cbr|vbr|abr]"""
+Usage: python tests/fuzz_gpu.py [streams] [seconds] [seed0] [cbr|vbr|abr|old]   (old: the old VBR loop, vbr_rh)"""
 import os
 import sys
 import time
@@ -28,6 +28,12 @@ VBR_SETTINGS = [(44100, -2, None, None), (44100, 0, None, None), (48000, -4, 1, 
                 (44100, -9, None, None), (48000, -7, None, None), (44100, -8, 0, 5), (48000, 0, 0, None)]
 
 
+# the same code for the old VBR loop (vbr_rh); -V 7.. would pick an MPEG-2 output rate
+OLD_SETTINGS = [(44100, -2, None, None), (44100, 0, None, None), (48000, -4, 1, None), (32000, -5, None, None),
+                (44100, -6, 0, None), (44100, -1, None, 5), (48000, -3, None, 6), (32000, -2, 0, None),
+                (48000, -1, None, 0), (44100, -3, 3, None), (48000, 0, 0, 2), (44100, -4, None, 1)]
+
+
 # bit rate >= 1000: ABR at a mean of rate - 1000 kb/s
 ABR_SETTINGS = [(44100, 1128, None, None), (48000, 1190, 1, None), (32000, 1096, None, 5), (44100, 1256, 0, 2),
                 (44100, 1080, None, 7), (48000, 1313, 0, None)]
@@ -41,13 +47,14 @@ def main():
     bad = tot = 0
     t0 = time.time()
     which = sys.argv[4] if len(sys.argv) > 4 else "cbr"
-    for sr, br, mode, q in {"vbr": VBR_SETTINGS, "abr": ABR_SETTINGS}.get(which, SETTINGS):
+    for sr, br, mode, q in {"vbr": VBR_SETTINGS, "abr": ABR_SETTINGS, "old": OLD_SETTINGS}.get(which, SETTINGS):
         if br >= 1000:
             enc = lamehip.Encoder(sr, 0, mode, q, abr=br - 1000, out_samplerate=sr)    # (no rate change: the checker is fed the same PCM)
         elif br > 0:
             enc = lamehip.Encoder(sr, br, mode, q)
         else:
-            enc = lamehip.Encoder(sr, mode=mode, quality=q, vbr_q=-br, out_samplerate=sr if -br >= 7 else 0)
+            enc = lamehip.Encoder(sr, mode=mode, quality=q, vbr_q=-br, out_samplerate=sr if -br >= 7 else 0,
+                                  vbr_mode=2 if which == "old" else 4)
         cfg, tab = enc.config(), enc.tables()
         n = int(sr * secs)
         pcms = [tg._stress_signal(seed0 + i, n - 13 * (i % 31), sr) for i in range(B)]

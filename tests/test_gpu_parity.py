@@ -245,6 +245,31 @@ def test_stress_signals_match_oracle(oracle, sr, br, mode, q):
     enc.close()
 
 
+@pytest.mark.parametrize("sr,vq,mode,q", [(44100, 0, None, None), (48000, 4, 1, None), (32000, 5, None, 5), (44100, 2, 3, 1)])
+def test_stress_signals_match_oracle_old_vbr_loop(oracle, sr, vq, mode, q):
+    """The same for the old VBR loop (vbr_rh).  Seed 7019 at 44.1 kHz -V0 is a regression case of the randomised hunt
+    (tests/fuzz_gpu.py old): a frame whose smoothed perceptual entropy is hugely NEGATIVE, where the reference's exp()
+    of the masking adjustment overflows to +inf."""
+    enc = lamehip.Encoder(sr, mode=mode, quality=q, vbr_q=vq, vbr_mode=2)
+    cfg, tab = enc.config(), enc.tables()
+    n = int(sr * 1.5)
+    pcms = [_stress_signal(s * 8 + k, n - 37 * k, sr) for s in range(2) for k in range(8)]
+    pcms.append(_stress_signal(7019, n - 13 * 19, sr))
+    b = lamehip.Batch(enc, len(pcms), n)
+    for s, x in enumerate(pcms):
+        b.set_pcm(s, x[0], x[1])
+    b.encode()
+    for s, x in enumerate(pcms):
+        got = b.get_frames(s)
+        want = oracle.encode_frames(cfg, tab, x)
+        assert len(got) == len(want)
+        for f in range(len(got)):
+            d = struct_diff(want[f], got[f])
+            assert not d, (s, f, d[:4])
+    b.close()
+    enc.close()
+
+
 def test_pack_all_threads_equals_per_stream_pack():
     """lamehip_batch_pack_all (host threads, one pinned staging buffer each) gives the bytes of
     the per-stream call."""

@@ -1,6 +1,6 @@
 /* Exhaustive check of the old VBR loop's two double-precision expressions as the device evaluates them
  * (csrc/lh_dev_math.h: lh_vbrold_adjust, lh_vbrold_masking_lower) against this host's libm, float in -> float out:
- *   adjust:         every float pe in [0, 2^17)        (long and short variant)
+ *   adjust:         every float pe with |pe| <= 2^20, and some beyond   (long and short variant)
  *   masking_lower:  every float db with |db| <= 32
  * usage: sweep_vbrold_math [stride]   (stride 1 = all ~6 10^9 evaluations, a few minutes on 16 cores; the test suite
  * uses a larger stride).  Prints the inputs that differ; exit code 1 if there are any.
@@ -26,16 +26,30 @@ main(int argc, char **argv)
 {
     long const stride = argc > 1 ? atol(argv[1]) : 1;
     long    bad = 0, n = 0;
-    uint32_t const pe_top = to_bits(131072.0f), db_top = to_bits(32.0f);
+    uint32_t const pe_top = to_bits(1048576.0f), db_top = to_bits(32.0f);
     long    i;
 #pragma omp parallel for reduction(+:bad,n) schedule(static, 65536)
     for (i = 0; i <= (long) pe_top; i += stride) {
-        float const pe = from_bits((uint32_t) i);
-        float const w0 = 1.28 / (1 + exp(3.5 - pe / 300.)) - 0.05, w1 = 2.56 / (1 + exp(3.5 - pe / 300.)) - 0.14;
-        float const g0 = lh_vbrold_adjust(pe, 0), g1 = lh_vbrold_adjust(pe, 1);
-        n += 2;
-        if (to_bits(w0) != to_bits(g0)) { bad++; printf("adjust long  pe %a (%#x): libm %a, here %a\n", pe, (unsigned) i, w0, g0); }
-        if (to_bits(w1) != to_bits(g1)) { bad++; printf("adjust short pe %a (%#x): libm %a, here %a\n", pe, (unsigned) i, w1, g1); }
+        int     sgn;
+        for (sgn = 0; sgn < 2; sgn++) {     /* (the PE smoothing filter's scale can be negative, and so can pe) */
+            float const pe = from_bits((uint32_t) i | (sgn ? 0x80000000u : 0u));
+            float const w0 = 1.28 / (1 + exp(3.5 - pe / 300.)) - 0.05, w1 = 2.56 / (1 + exp(3.5 - pe / 300.)) - 0.14;
+            float const g0 = lh_vbrold_adjust(pe, 0), g1 = lh_vbrold_adjust(pe, 1);
+            n += 2;
+            if (to_bits(w0) != to_bits(g0)) { bad++; printf("adjust long  pe %a: libm %a, here %a\n", pe, w0, g0); }
+            if (to_bits(w1) != to_bits(g1)) { bad++; printf("adjust short pe %a: libm %a, here %a\n", pe, w1, g1); }
+        }
+    }
+    {
+        /* far out: exp() is 0 or +inf there */
+        static const float far_out[] = { 2e6f, 1e9f, 3e38f, -2e6f, -212800.f, -212500.f, -213000.f, -1e9f, -3e38f, __builtin_inff(), -__builtin_inff() };
+        unsigned k;
+        for (k = 0; k < sizeof(far_out) / sizeof(far_out[0]); k++) {
+            float const pe = far_out[k];
+            float const w0 = 1.28 / (1 + exp(3.5 - pe / 300.)) - 0.05, w1 = 2.56 / (1 + exp(3.5 - pe / 300.)) - 0.14;
+            n += 2;
+            if (to_bits(w0) != to_bits(lh_vbrold_adjust(pe, 0)) || to_bits(w1) != to_bits(lh_vbrold_adjust(pe, 1))) { bad++; printf("adjust far out pe %a\n", pe); }
+        }
     }
 #pragma omp parallel for reduction(+:bad,n) schedule(static, 65536)
     for (i = 0; i <= (long) db_top; i += stride) {
