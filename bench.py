@@ -520,7 +520,7 @@ def main():
     rdv.close()
 
 
-def end_to_end(torch, lamehip, enc, B, sr, dev, seconds=10.0, rounds=12, nbatch=2):
+def end_to_end(torch, lamehip, enc, B, sr, dev, seconds=30.0, rounds=6, nbatch=2):
     """SURVEY.md 8(d) region R2: s16 PCM in pinned host memory -> H2D -> kernel -> D2H -> mp3 bytes in host
     memory, as a pipeline of `nbatch' batch objects (each with its own HIP stream) that are reused round-robin
     for `rounds' batches of B streams x `seconds': batch n's kernel runs while batch n+1's PCM goes up and batch
@@ -530,6 +530,8 @@ def end_to_end(torch, lamehip, enc, B, sr, dev, seconds=10.0, rounds=12, nbatch=
     once.  Checked: the device-packed bytes of four streams against the host packer's."""
     import threading
     n = int(seconds * sr)
+    # (two pinned PCM mirrors of B x seconds: 5.4 GB each at 1024 x 30 s; the library's default cap is 4 GB in all)
+    os.environ.setdefault("LAMEHIP_PINNED_MAX_MB", "16384")
     host = synth_on_device(torch, B, n, sr, 777, dev).cpu().numpy()
     threads = min(32, _cpu_budget())
     objs = []
