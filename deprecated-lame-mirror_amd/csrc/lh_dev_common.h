@@ -304,6 +304,9 @@ struct LhVbrSave {
     int     mingain_l, mingain_s[3];
     int     global_gain, mnc, max_bits, use_bits;
     int     ath_over, nonzero, pad[2];
+    /* what a bit count leaves alone when the granule has no big values (region counts) or a region is empty (its table):
+     * the second pass finds them as the first pass left them (reference takehiro.c:700-760 returns early / skips) */
+    int     table_select[3], region0_count, region1_count, pad2[3];
 };
 
 /* The old VBR loop is part of the two-wave kernel; the four-wave kernel never runs a VBR loop, and the profiling build's

@@ -759,8 +759,14 @@ lh_vbr_granule(int qch, int gr, int rch, int pass, int gate, int target, int sub
             lh_calc_xmin_body(c, Q, R, xr, L.psy_en[slot][rch], L.psy_thm[slot][rch]);
         }
     }
-    else
+    else {
         R.mnc = lh_uni_i(sv.mnc);
+        g.table_select[0] = lh_uni_i(sv.table_select[0]);
+        g.table_select[1] = lh_uni_i(sv.table_select[1]);
+        g.table_select[2] = lh_uni_i(sv.table_select[2]);
+        g.region0_count = lh_uni_i(sv.region0_count);
+        g.region1_count = lh_uni_i(sv.region1_count);
+    }
     LH_PA(16, t_a);
     nonzero = lh_init_xrpow(c, Q, R, g, xr);    /* silent granules: all of ix[0] cleared */
     if (pass == 0 && s == 0) {
@@ -829,6 +835,14 @@ lh_vbr_granule(int qch, int gr, int rch, int pass, int gate, int target, int sub
     if (c.cfg->use_best_huffman == 1)
         lh_best_huffman_divide_body(c, Q, R, g);
     LH_PA(6, t_f);
+    if (pass == 0 && s == 0) {
+        /* (the reference's first pass ends with these finishing steps too: the second finds the granule as THEY left it) */
+        sv.table_select[0] = g.table_select[0];
+        sv.table_select[1] = g.table_select[1];
+        sv.table_select[2] = g.table_select[2];
+        sv.region0_count = g.region0_count;
+        sv.region1_count = g.region1_count;
+    }
     lh_store_granule(c, Q, R, g, xr, LH_AS_GLOBAL(LhGranule, o));
     if (lh_uni_i(lh_lds.ctx.bytes != nullptr)) {
         lh_rg_put(c, R, g);

@@ -3,7 +3,8 @@
 control, stereo mode, quality and 1-4 of the switches of tests/test_switches.py; resolved constants, tables, every frame
 and the bytes of the oracle against the compiled reference on the CPU.  With "gpu" as the last argument the device payload
 is compared with the oracle instead (on the GPU box, where /root/reference is not needed).
-Usage: python tests/fuzz_switches.py [cases] [seed] [gpu]"""
+Usage: python tests/fuzz_switches.py [cases] [seed] [cpu|gpu|emu] [only case n]
+(emu: the kernel source under the CPU emulator against the oracle -- slow, meant for one case: the last argument)"""
 import ctypes as C
 import os
 import sys
@@ -40,9 +41,11 @@ def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     gpu = len(sys.argv) > 3 and sys.argv[3] == "gpu"
+    emu = len(sys.argv) > 3 and sys.argv[3] == "emu"
+    only = int(sys.argv[4]) if len(sys.argv) > 4 else -1
     rng = np.random.default_rng(seed)
     orc = helpers.Oracle()
-    ref = None if gpu else helpers.Reference()
+    ref = None if (gpu or emu) else helpers.Reference()
     if ref:
         ref.lib.refh_option.argtypes = [C.c_char_p, C.c_float]
     bad = refused = done = 0
@@ -65,9 +68,15 @@ def main():
             for k in ("VBR_hard_min",):
                 opts.pop(k, None)
         sr = 44100
-        x = tg._stress_signal(int(rng.integers(0, 1 << 30)), int(sr * 1.2), sr)
+        sig = int(rng.integers(0, 1 << 30))
+        if only >= 0 and c != only:
+            continue
+        x = tg._stress_signal(sig, int(sr * 1.2), sr)
         try:
             enc = ts.open_with(kw, opts, require_device=gpu)
+        except RuntimeError:
+            refused += 1
+            continue
         except AssertionError:
             refused += 1            # the library refuses the combination (the reference may not)
             continue
@@ -78,7 +87,23 @@ def main():
         cfg, tab = enc.config(), enc.tables()
         want = orc.encode_frames(cfg, tab, x)
         what = None
-        if gpu:
+        if emu:
+            from test_emulator import LhStreamDesc
+            from lamehip.types import LhFrameOut
+            lib = C.CDLL(os.path.join(ROOT, "tests", "hipemu", "libhipemu_lame.so"))
+            n = x.shape[1]
+            pool = np.concatenate([x[0], x[1]]).astype(np.int16)
+            desc = LhStreamDesc(0, n, 0, n, 0, 0, len(want))
+            state = C.create_string_buffer(enc.lib.lamehip_abi_sizeof(4))
+            enc.lib.lh_state_init(state, C.byref(cfg))
+            got = (LhFrameOut * len(want))()
+            lib.lh_emu_encode(C.byref(cfg), C.byref(tab), pool.ctypes.data_as(C.c_void_p), C.byref(desc), state, got, 1)
+            for f in range(len(want)):
+                d = struct_diff(want[f], got[f])
+                if d:
+                    what = (f, d[:6])
+                    break
+        elif gpu:
             b = lamehip.Batch(enc, 1, x.shape[1])
             b.set_pcm(0, x[0], x[1])
             b.encode()
@@ -123,7 +148,7 @@ def main():
         done += 1
         if what is not None:
             bad += 1
-            print("MISMATCH", kw, opts, what, flush=True)
+            print("MISMATCH case", c, "signal", sig, kw, opts, what, flush=True)
         if (c + 1) % 50 == 0:
             print("cases", c + 1, "compared", done, "refused", refused, "bad", bad, flush=True)
     print("TOTAL compared", done, "refused", refused, "BAD", bad)
