@@ -372,6 +372,10 @@ vbr_bitrate_limits(const LhUserParams * p, LhConfig * c)
                 c->vbr_max_bitrate_index = r;
     }
     c->enforce_min_bitrate = p->vbr_hard_min;
+    /* -b above -B: the reference takes it and, in ABR, then ends every frame with a mean of 0 bits (the loop that picks the
+     * frame size never runs, quantize.c:1963-1968), i.e. with a reservoir that only shrinks -- not a stream; refused here */
+    if (c->vbr_min_bitrate_index > c->vbr_max_bitrate_index)
+        return -1;
     return 0;
 }
 

@@ -142,8 +142,12 @@ def main():
                     what = ("tables", [t[0] for t in dt[:4]])
                 elif len(want) != nf:
                     what = ("frames", nf, len(want))
-                elif helpers.pack_frames(enc.lib, cfg, tab, want) != mp3:
-                    what = ("bytes",)
+                else:
+                    try:
+                        if helpers.pack_frames(enc.lib, cfg, tab, want) != mp3:
+                            what = ("bytes",)
+                    except AssertionError as e:
+                        what = ("packer", str(e))
         enc.close()
         done += 1
         if what is not None:
