@@ -191,3 +191,26 @@ def test_old_vbr_loop_second_pass_source_matches_oracle(name, nframes, forced, e
         d = struct_diff(want[f], got[f])
         assert not d, (f, d[:4])
     enc.close()
+
+
+def test_new_vbr_second_pass_keeps_the_first_pass_side_info(emu, oracle):
+    """A regression case of tests/fuzz_switches.py under the emulator (-V0 -B 96, first frame): the second pass over a frame
+    ends a granule without big values, whose region counts stay what the first pass's finishing steps left."""
+    import test_gpu_parity as tg
+    from test_switches import open_with
+    sr, nframes = 44100, 2
+    pcm = tg._stress_signal(778490755, int(sr * 1.2), sr)
+    enc = open_with(dict(vbr_q=0), {"strict_ISO": 2, "VBR_max_bitrate_kbps": 96}, require_device=False)
+    cfg, tab = enc.config(), enc.tables()
+    want = oracle.encode_frames(cfg, tab, pcm, max_frames=nframes)
+    n = pcm.shape[1]
+    pool = np.concatenate([pcm[0], pcm[1]]).astype(np.int16)
+    desc = LhStreamDesc(0, n, 0, n, 0, 0, nframes)
+    state = C.create_string_buffer(enc.lib.lamehip_abi_sizeof(4))
+    enc.lib.lh_state_init(state, C.byref(cfg))
+    got = (LhFrameOut * nframes)()
+    emu.lh_emu_encode(C.byref(cfg), C.byref(tab), pool.ctypes.data_as(C.c_void_p), C.byref(desc), state, got, 1)
+    for f in range(nframes):
+        d = struct_diff(want[f], got[f])
+        assert not d, (f, d[:4])
+    enc.close()

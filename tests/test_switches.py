@@ -136,3 +136,37 @@ def test_switch_device_matches_oracle(kw, opts, oracle):
     assert b.pack(0) == helpers.pack_frames(enc.lib, cfg, tab, want)
     b.close()
     enc.close()
+
+
+REGRESSIONS = [
+    # found by tests/fuzz_switches.py: the new-VBR loop's second pass (a low -B) ends a granule without big values / with an
+    # empty region, whose region counts / table the bit count then leaves as the FIRST pass's finishing steps set them
+    (dict(vbr_q=0), {"strict_ISO": 2, "VBR_max_bitrate_kbps": 96}, 778490755),
+    (dict(vbr_q=3), {"ATHtype": 0, "lowpassfreq": -1, "VBR_max_bitrate_kbps": 96, "highpassfreq": 2500}, 84886511),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw,opts,signal", REGRESSIONS, ids=["v0_B96", "v3_B96_highpass"])
+def test_fuzz_regressions_device_matches_oracle(kw, opts, signal, oracle):
+    import test_gpu_parity as tg
+    sr = 44100
+    pcm = tg._stress_signal(signal, int(sr * 1.2), sr)
+    enc = open_with(kw, opts, require_device=True)
+    cfg, tab = enc.config(), enc.tables()
+    b = lamehip.Batch(enc, 1, pcm.shape[1])
+    b.set_pcm(0, pcm[0], pcm[1])
+    b.encode()
+    want = oracle.encode_frames(cfg, tab, pcm)
+    got = b.get_frames(0)
+    bad = [(f, struct_diff(want[f], got[f])[:3]) for f in range(len(want)) if struct_diff(want[f], got[f])]
+    assert len(got) == len(want) and not bad, bad[:3]
+    assert b.pack(0) == helpers.pack_frames(enc.lib, cfg, tab, want)
+    b.close()
+    enc.close()
+
+
+def test_lowest_bitrate_above_highest_is_refused():
+    """-b 128 -B 96: the reference takes it and lets the reservoir run negative (ABR); here lame_init_params says no."""
+    with pytest.raises(AssertionError):
+        open_with(dict(abr=158), {"VBR_max_bitrate_kbps": 96, "VBR_min_bitrate_kbps": 128}, require_device=False)
