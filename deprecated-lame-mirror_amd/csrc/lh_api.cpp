@@ -539,6 +539,8 @@ lame_set_preset(lame_t g, int preset)
     case 1003:                 /* INSANE */
         g->p.vbr = 0;
         g->p.brate = g->p.abr_kbps = 320;
+        if (!g->p.preset_kbps)
+            g->p.preset_kbps = 320;
         g->p.scale *= lh_abr_preset_scale(320);
         g->preset_vbr = 0;
         return 320;
@@ -552,6 +554,8 @@ lame_set_preset(lame_t g, int preset)
     if (8 <= preset && preset <= 320) {
         g->p.vbr = 3;
         g->p.abr_kbps = g->p.brate = preset;
+        if (!g->p.preset_kbps)
+            g->p.preset_kbps = preset;  /* (its row's tuning values stay when the bitrate changes afterwards: lh_host_init.c) */
         g->p.scale *= lh_abr_preset_scale(preset);      /* and once more in lame_init_params, like the reference */
         g->preset_vbr = 0;
     }

@@ -48,6 +48,7 @@ typedef struct LhUserParams {
     int     experimentalY, experimentalZ;
     int     free_format;
     float   compression_ratio;   /* 0 = not set: CBR without a bitrate takes 11.025 (lame.c:622-644) */
+    int     preset_kbps;         /* 0, or the bitrate lame_set_preset(8..320 / INSANE) applied its tuning row for at call time */
 } LhUserParams;
 
 /* values that only feed table generation */

@@ -802,25 +802,35 @@ config_resolve_inner(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
 
     /* preset for the bitrate (reference presets.c:215-317) */
     r = nearest_full_index(c->avg_bitrate);
-    if (abr_map[r].safejoint > 0)
-        c->use_safe_joint_stereo = 2;
-    if (abr_map[r].sfscale > 0)
-        noise_shaping = 2;
-    c->quant_comp = 9;
-    c->quant_comp_short = 9;
-    c->msfix = abr_map[r].nsmsfix;
-    aux->attackthre = abr_map[r].st_lrm;
-    aux->attackthre_s = abr_map[r].st_s;
-    scale = p->scale * abr_map[r].scale;
-    maskingadjust = abr_map[r].masking_adj;
-    if (abr_map[r].masking_adj > 0)
-        maskingadjust_short = abr_map[r].masking_adj * .9;
-    else
-        maskingadjust_short = abr_map[r].masking_adj * 1.1;
-    ath_lower_db = abr_map[r].ath_lower;
-    c->ATHcurve = abr_map[r].ath_curve;
-    c->interChRatio = abr_map[r].interch;
-    c->minval = 5. * (abr_map[r].kbps / 320.);
+    {
+        /* lame_set_preset(n) applied row n's values at call time already; lame_init_params then applies the final
+         * bitrate's row, which only fills what is still at its "not set" value (SET_OPTION, presets.c:34-42): msfix, the
+         * short-block thresholds, the ATH curve and the inter-channel ratio stay the first row's, masking adjustment and
+         * ATH lowering too unless the first row's are 0 (= not set); safe joint stereo and sfscale are only ever switched
+         * on; minval and the input scale follow the final row (`--preset insane -b 96', `--preset cbr 160 --comp 11') */
+        int const r1 = p->preset_kbps ? nearest_full_index(p->preset_kbps) : r;
+        int const rm = (abr_map[r1].masking_adj != 0) ? r1 : r;
+        int const ra = (abr_map[r1].ath_lower != 0) ? r1 : r;
+        if (abr_map[r].safejoint > 0 || abr_map[r1].safejoint > 0)
+            c->use_safe_joint_stereo = 2;
+        if (abr_map[r].sfscale > 0 || abr_map[r1].sfscale > 0)
+            noise_shaping = 2;
+        c->quant_comp = 9;
+        c->quant_comp_short = 9;
+        c->msfix = abr_map[r1].nsmsfix;
+        aux->attackthre = abr_map[r1].st_lrm;
+        aux->attackthre_s = abr_map[r1].st_s;
+        scale = p->scale * abr_map[r].scale;
+        maskingadjust = abr_map[rm].masking_adj;
+        if (abr_map[rm].masking_adj > 0)
+            maskingadjust_short = abr_map[rm].masking_adj * .9;
+        else
+            maskingadjust_short = abr_map[rm].masking_adj * 1.1;
+        ath_lower_db = abr_map[ra].ath_lower;
+        c->ATHcurve = abr_map[r1].ath_curve;
+        c->interChRatio = abr_map[r1].interch;
+        c->minval = 5. * (abr_map[r].kbps / 320.);
+    }
 
     c->mask_adjust = maskingadjust;
     c->mask_adjust_short = maskingadjust_short;

@@ -46,6 +46,10 @@ COMMANDS = [
     ("testcase_vbr_old_V2", "testcase", ["--vbr-old", "-V", "2"]),       # lame_set_VBR(vbr_rh): the old VBR loop
     ("synth_vbr_old_V0_q0", "synth", ["--vbr-old", "-V", "0", "-q", "0"]),
     ("synth_vbr_old_V5_limits_mono", "synth", ["--vbr-old", "-V", "5.5", "-b", "64", "-B", "160", "-m", "m"]),
+    # a preset's tuning row stays when the bitrate changes afterwards (found by tests/fuzz_frontend.py)
+    ("synth_preset_insane_b96", "synth", ["--preset", "insane", "-b", "96"]),
+    ("synth_preset_cbr160_comp11", "synth", ["--preset", "cbr", "160", "--comp", "11"]),
+    ("synth_preset_insane_comp7_q1_nores", "synth", ["--preset", "insane", "--comp", "7", "-q", "1", "--nores"]),
     # (the frontend's developer switches -- --athtype, --nsmsfix, --ns-bass, --noath, --noshort ... -- are compiled out of
     # a default build of the frontend, parse.c:75-79; the setters behind them are covered by tests/test_switches.py)
 ]
