@@ -45,6 +45,10 @@ def pick(rng):
     elif rc == 4:
         a += ["--preset", str(rng.choice(["standard", "extreme", "insane", "medium", "fast standard", "192", "cbr 160"]))]
         a = a[:1] + a[1].split()
+    if rng.integers(0, 4) == 0:
+        # a second word on the rate control, after the first (presets apply their values when they are read)
+        a += [["-V", str(int(rng.integers(0, 8)))], ["-b", str(int(rng.choice([112, 160, 256])))], ["--abr", str(int(rng.integers(100, 250)))],
+              ["--preset", str(rng.choice(["standard", "extreme", "medium", "insane", "128"]))], ["--vbr-old"], ["--vbr-new"], ["--cbr"]][int(rng.integers(0, 7))]
     for _ in range(int(rng.integers(0, 4))):
         k = int(rng.integers(0, 16))
         a += [["-m", str(rng.choice(["s", "j", "f", "m", "d"]))], ["-q", str(int(rng.integers(0, 10)))], ["-k"], ["-p"], ["--nores"],
