@@ -800,6 +800,12 @@ init_params_once(lame_t g)
         snprintf(g_err, sizeof(g_err), "a V0..V9 preset without lame_set_VBR(vbr_mtrh / vbr_mt / vbr_rh) is outside the accelerated path");
         return -1;
     }
+    if (g->p.preset_kbps && (g->preset_vbr || g->p.vbr == 1 || g->p.vbr == 2 || g->p.vbr == 4)) {
+        /* e.g. --preset insane --vbr-old, --preset 192 --preset extreme: the reference then runs a VBR loop with what the
+         * bitrate preset's row left in its tuning options -- a combination nobody asks for, not rebuilt here */
+        snprintf(g_err, sizeof(g_err), "a bitrate preset (lame_set_preset 8..320 / INSANE) followed by a VBR mode is outside the accelerated path");
+        return -1;
+    }
     if (lh_config_resolve(&g->p, &g->cfg, &aux) != 0) {
         snprintf(g_err, sizeof(g_err),
                  "unsupported settings for the MI355X path (need an MPEG-1 output rate, 1 or 2 input channels)");

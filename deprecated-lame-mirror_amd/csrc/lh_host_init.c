@@ -677,7 +677,7 @@ config_resolve_inner(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
 {
     int     r;
     float   scale, ath_lower_db, maskingadjust, maskingadjust_short;
-    int     noise_shaping = 0, ratio_kbps = 128, pinned_out = 0;
+    int     noise_shaping = 0, ratio_kbps = 128, pinned_out = 0, brate_asked = 128;
 
     memset(c, 0, sizeof(*c));
     memset(aux, 0, sizeof(*aux));
@@ -704,7 +704,7 @@ config_resolve_inner(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
     c->original = 1;
     /* VBR_q also reaches the CBR path (psymodel_init's masking_lower slope, the tag's quality byte) */
     aux->vbr_q = (p->vbr_q < 0) ? 0 : (p->vbr_q > 9 ? 9 : p->vbr_q);
-    aux->vbr_q_frac = 0;
+    aux->vbr_q_frac = p->vbr_q_frac;    /* (-V 4.7 before --preset 128: lame_set_VBR_quality's fraction stays) */
     aux->athaa_sensitivity = 0;
     aux->adjust_sfb21_db = 0;
     c->vbr_q = aux->vbr_q;
@@ -759,18 +759,20 @@ config_resolve_inner(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
             pinned_out = out;
         }
         c->avg_bitrate = find_nearest_bitrate_mpeg1(brate);
+        brate_asked = (ratio > 0) ? c->avg_bitrate : brate;    /* (the compression-ratio route rounds at once, lame.c:642-643) */
         for (r = 1; r <= 14; r++)
             if (lh_bitrate_mpeg1[r] == c->avg_bitrate)
                 c->bitrate_index = r;
         c->vbr_avg_bitrate_kbps = c->avg_bitrate;       /* lame_set_VBR_mean_bitrate_kbps(brate), lame.c:1043 */
-        ratio_kbps = c->avg_bitrate;
+        ratio_kbps = brate_asked;       /* (lame.c:778 too comes before the rounding) */
     }
     if (c->bitrate_index <= 0)
         return -1;
 
     /* lowpass (reference lame.c:194-260, 700-760, 846-862) */
     {
-        double  lowpass = lowpass_map[nearest_full_index(c->avg_bitrate)];
+        /* (from the bitrate as asked for, before it is rounded to a frame size: lame.c:709-714 precedes :904-915) */
+        double  lowpass = lowpass_map[nearest_full_index(c->vbr == 3 ? c->avg_bitrate : brate_asked)];
         int     lp;
         if (c->mode == LH_MODE_MONO)
             lowpass *= 1.5;     /* reference lame.c:758-759 */

@@ -49,6 +49,8 @@ CASES = [
     (dict(vbr_q=0), {"experimentalY": 1}), (dict(brate=128), {"experimentalY": 1}),
     (dict(brate=0), {"compression_ratio": 8.0}), (dict(brate=0), {"compression_ratio": 5.0}), (dict(brate=128), {"compression_ratio": 14.0}),
     (dict(brate=0), {}),
+    (dict(brate=128), {"VBR_quality": 4.7}), (dict(abr=140), {"VBR_quality": 6.3}),   # the fraction reaches the CBR / ABR tables too
+    (dict(brate=176), {}), (dict(brate=144), {}),      # lowpass from the bitrate as asked, frame size from the rounded one
     # the old VBR loop (lame_set_VBR(vbr_rh), the frontend's --vbr-old); a low -B makes it raise the allowed noise
     # and search again (bitpressure_strategy)
     (dict(vbr_q=2, vbr_mode=2), {}), (dict(vbr_q=4, vbr_mode=2), {"VBR_max_bitrate_kbps": 96}),
