@@ -50,11 +50,13 @@ def pick(rng):
         a += [["-V", str(int(rng.integers(0, 8)))], ["-b", str(int(rng.choice([112, 160, 256])))], ["--abr", str(int(rng.integers(100, 250)))],
               ["--preset", str(rng.choice(["standard", "extreme", "medium", "insane", "128"]))], ["--vbr-old"], ["--vbr-new"], ["--cbr"]][int(rng.integers(0, 7))]
     for _ in range(int(rng.integers(0, 4))):
-        k = int(rng.integers(0, 16))
+        k = int(rng.integers(0, 28))
         a += [["-m", str(rng.choice(["s", "j", "f", "m", "d"]))], ["-q", str(int(rng.integers(0, 10)))], ["-k"], ["-p"], ["--nores"],
               ["--lowpass", str(rng.choice(["14", "16.5", "19"]))], ["--highpass", str(rng.choice(["0.2", "1.2"]))],
               ["--scale", str(rng.choice(["0.6", "1.2"]))], ["-Y"], ["-t"], ["--noreplaygain"], ["--strictly-enforce-ISO"],
-              ["-B", str(int(rng.choice([160, 224, 320])))], ["-b", str(int(rng.choice([64, 96])))], ["-F"], ["--comp", str(rng.choice(["7", "11"]))]][k]
+              ["-B", str(int(rng.choice([160, 224, 320])))], ["-b", str(int(rng.choice([64, 96])))], ["-F"], ["--comp", str(rng.choice(["7", "11"]))],
+              ["--resample", str(rng.choice(["32", "44.1", "48"]))], ["-a"], ["--scale-l", "0.7"], ["--scale-r", "1.3"], ["--lowpass-width", "1"],
+              ["--nogap"], ["-c"], ["-o"], ["-e", str(rng.choice(["n", "5", "c"]))], ["--clipdetect"], ["--replaygain-fast"], ["-S"]][k]
     return a
 
 
