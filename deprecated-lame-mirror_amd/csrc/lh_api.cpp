@@ -539,8 +539,7 @@ lame_set_preset(lame_t g, int preset)
     case 1003:                 /* INSANE */
         g->p.vbr = 0;
         g->p.brate = g->p.abr_kbps = 320;
-        if (!g->p.preset_kbps)
-            g->p.preset_kbps = 320;
+        g->p.preset_kbps = (!g->p.preset_kbps || g->p.preset_kbps == 320) ? 320 : -1;   /* -1: two different ones */
         g->p.scale *= lh_abr_preset_scale(320);
         g->preset_vbr = 0;
         return 320;
@@ -554,8 +553,8 @@ lame_set_preset(lame_t g, int preset)
     if (8 <= preset && preset <= 320) {
         g->p.vbr = 3;
         g->p.abr_kbps = g->p.brate = preset;
-        if (!g->p.preset_kbps)
-            g->p.preset_kbps = preset;  /* (its row's tuning values stay when the bitrate changes afterwards: lh_host_init.c) */
+        /* (its row's tuning values stay when the bitrate changes afterwards: lh_host_init.c) */
+        g->p.preset_kbps = (!g->p.preset_kbps || g->p.preset_kbps == preset) ? preset : -1;
         g->p.scale *= lh_abr_preset_scale(preset);      /* and once more in lame_init_params, like the reference */
         g->preset_vbr = 0;
     }
@@ -798,6 +797,10 @@ init_params_once(lame_t g)
     g->p.samplerate_out = g->out_samplerate;
     if (g->preset_vbr && g->p.vbr != 1 && g->p.vbr != 2 && g->p.vbr != 4) {
         snprintf(g_err, sizeof(g_err), "a V0..V9 preset without lame_set_VBR(vbr_mtrh / vbr_mt / vbr_rh) is outside the accelerated path");
+        return -1;
+    }
+    if (g->p.preset_kbps < 0) {
+        snprintf(g_err, sizeof(g_err), "two different bitrate presets (lame_set_preset 8..320 / INSANE) on one handle are outside the accelerated path");
         return -1;
     }
     if (g->p.preset_kbps && (g->preset_vbr || g->p.vbr == 1 || g->p.vbr == 2 || g->p.vbr == 4)) {
