@@ -45,6 +45,21 @@ def test_unsupported_settings_are_refused_loudly():
         lib.lame_close(h)
 
 
+def test_contradictory_presets_are_refused_loudly():
+    """A bitrate preset followed by a VBR mode or by a different bitrate preset: the reference then encodes with what the first
+    preset's row left in its tuning options; not rebuilt here (found by tests/fuzz_frontend.py), so lame_init_params says no."""
+    lib = lamehip.load_library()
+    for setup in (lambda h: (lib.lame_set_preset(h, 1003), lib.lame_set_VBR(h, 2)),         # --preset insane --vbr-old
+                  lambda h: (lib.lame_set_preset(h, 192), lib.lame_set_preset(h, 500)),      # --preset 192 --preset extreme (V0)
+                  lambda h: (lib.lame_set_preset(h, 1003), lib.lame_set_preset(h, 128))):    # --preset insane --preset 128
+        h = C.c_void_p(lib.lame_init())
+        lib.lame_set_bWriteVbrTag(h, 0)
+        setup(h)
+        assert lib.lame_init_params(h) == -1
+        assert b"preset" in lib.lamehip_last_error()
+        lib.lame_close(h)
+
+
 def test_encode_before_init_params_is_minus_3():
     lib = lamehip.load_library()
     h = C.c_void_p(lib.lame_init())
