@@ -922,10 +922,13 @@ handle_encode_frames(lame_t g, int upto, unsigned char *mp3buf, int mp3buf_size,
         p1 = g->fed;
     n = p1 > p0 ? p1 - p0 : 0;
     if (n > g->d_pcm_cap) {
+        /* the new buffer first: a failed allocation leaves the old one (and its size) in place */
+        float  *bigger = nullptr;
+        HIPCHK(hipMalloc((void **) &bigger, (size_t) (n + 4096) * 2 * sizeof(float)));
         if (g->d_pcm)
             (void) hipFree(g->d_pcm);
+        g->d_pcm = bigger;
         g->d_pcm_cap = n + 4096;
-        HIPCHK(hipMalloc((void **) &g->d_pcm, (size_t) g->d_pcm_cap * 2 * sizeof(float)));
     }
     if (n > 0) {
         HIPCHK(hipMemcpyAsync(g->d_pcm, &g->hl[(size_t) (p0 - g->hist_base)], (size_t) n * sizeof(float),
@@ -934,10 +937,12 @@ handle_encode_frames(lame_t g, int upto, unsigned char *mp3buf, int mp3buf_size,
                               (size_t) n * sizeof(float), hipMemcpyHostToDevice, g->stream));
     }
     if (nf > g->d_out_cap) {
+        LhFrameOut *bigger = nullptr;
+        HIPCHK(hipMalloc((void **) &bigger, (size_t) (nf + 8) * sizeof(LhFrameOut)));
         if (g->d_out)
             (void) hipFree(g->d_out);
+        g->d_out = bigger;
         g->d_out_cap = nf + 8;
-        HIPCHK(hipMalloc((void **) &g->d_out, (size_t) g->d_out_cap * sizeof(LhFrameOut)));
     }
     d.pcm_l = 0;
     d.pcm_r = g->d_pcm_cap;
@@ -1509,6 +1514,8 @@ struct lamehip_batch {
     hipStream_t up_stream, down_stream;
     hipEvent_t ev_up, ev_sum, ev_down;
     int     up_pending, down_pending;
+    int     up_inflight;        /* an H2D copy out of the pinned mirror may still be running (host view: cleared only after ev_up) */
+    int     launched;           /* a kernel was launched on this batch and ev1 recorded (survives lamehip_batch_reset) */
 };
 
 static int
@@ -1620,6 +1627,8 @@ lamehip_batch_create_on(int device, const lame_t proto, int nstreams, long capac
     b->up_stream = b->down_stream = nullptr;
     b->ev_up = b->ev_sum = b->ev_down = nullptr;
     b->up_pending = b->down_pending = 0;
+    b->up_inflight = 0;
+    b->launched = 0;
     if (proto->rs) {
         /* the s16 pool shrinks to nothing, the converted signal (plus the flush's tail) lives in a float pool */
         b->rate_in = proto->p.samplerate;
@@ -1807,6 +1816,18 @@ batch_host_pool(lamehip_batch * b)
     return b->h_pcm;
 }
 
+/* the pinned mirror is about to be rewritten by the host: an upload out of it that is still on its way must have
+ * finished (the device-side wait in lamehip_batch_encode says nothing to the host) */
+static int
+batch_mirror_quiesce(lamehip_batch * b)
+{
+    if (b->up_inflight) {
+        HIPCHK(hipEventSynchronize(b->ev_up));
+        b->up_inflight = 0;
+    }
+    return 0;
+}
+
 extern "C" int
 lamehip_batch_set_pcm(lamehip_batch * b, int s, const short *l, const short *r, long n)
 {
@@ -1823,6 +1844,8 @@ lamehip_batch_set_pcm(lamehip_batch * b, int s, const short *l, const short *r, 
     if (b->cfg.channels == 1 && b->cfg.pcm_mix == 0.0f)
         r = l;                  /* mono: the second plane mirrors the first, the kernel never uses it */
     if (batch_host_pool(b) != nullptr) {
+        if (batch_mirror_quiesce(b) != 0)
+            return LAMEHIP_ERR_DEVICE;
         /* into the pinned mirror; the rows travel with the next lamehip_batch_upload / _encode, all streams'
          * in one asynchronous copy (the reference's seam: lame_encode_buffer copies into mfbuf, lame.c:1672) */
         memcpy(b->h_pcm + ((size_t) s * 2) * (size_t) b->cap, l, (size_t) n * 2);
@@ -1853,6 +1876,11 @@ lamehip_batch_pcm_host_ptr(lamehip_batch * b)
         b->h_pcm = nullptr;
         (void) hipGetLastError();
     }
+    /* whoever asks for the pointer is about to write through it: no upload may still be reading the mirror.  (A caller
+     * that keeps the pointer across rounds asks again -- or calls lamehip_batch_set_pcm -- before it rewrites rows that
+     * an asynchronous lamehip_batch_upload / _encode has taken.) */
+    if (b->h_pcm && batch_mirror_quiesce(b) != 0)
+        return nullptr;
     return b->h_pcm;
 }
 
@@ -1895,8 +1923,8 @@ lamehip_batch_upload(lamehip_batch * b)
         return 0;
     if (batch_copy_streams(b) != 0)
         return LAMEHIP_ERR_DEVICE;
-    /* the pool may still be read by the kernel of the previous round */
-    if (b->encoded)
+    /* the pool may still be read by the kernel of the previous round (also after a reset, which clears `encoded') */
+    if (b->launched)
         HIPCHK(hipStreamWaitEvent(b->up_stream, b->ev1, 0));
     {
         long long used = 0;
@@ -1917,6 +1945,7 @@ lamehip_batch_upload(lamehip_batch * b)
     }
     HIPCHK(hipEventRecord(b->ev_up, b->up_stream));
     b->up_pending = 1;
+    b->up_inflight = 1;
     b->row_dirty.assign((size_t) b->B, 0);
     b->n_dirty = 0;
     return 0;
@@ -1930,8 +1959,10 @@ lamehip_batch_set_pcm_device(lamehip_batch * b, int s, const void *dl, const voi
         return -1;
     if (b->cfg.channels == 1 && b->cfg.pcm_mix == 0.0f)
         dr = dl;
-    if (b->up_pending)          /* an upload of the mirror is on its way into the same pool */
+    if (b->up_pending || b->up_inflight) {      /* an upload of the mirror is on its way into the same pool */
         HIPCHK(hipStreamSynchronize(b->up_stream));
+        b->up_inflight = 0;
+    }
     if (b->row_dirty[(size_t) s]) {     /* what the mirror holds for this stream is superseded */
         b->row_dirty[(size_t) s] = 0;
         b->n_dirty--;
@@ -2139,6 +2170,7 @@ batch_encode_range(lamehip_batch * b, const std::vector < int >&upto, int end)
     if (rc)
         return set_err("kernel launch", (hipError_t) rc);
     HIPCHK(hipEventRecord(b->ev1, b->stream));
+    b->launched = 1;
     b->h_new.resize((size_t) total);
     HIPCHK(hipMemcpyAsync(b->h_new.data(), b->d_out, (size_t) total * sizeof(LhFrameOut), hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
@@ -2358,6 +2390,7 @@ lamehip_batch_encode(lamehip_batch * b)
             return set_err("kernel launch", (hipError_t) rc);
     }
     HIPCHK(hipEventRecord(b->ev1, b->stream));
+    b->launched = 1;
     b->encoded = 1;
     b->fetched = 0;
     return 0;
@@ -2378,10 +2411,10 @@ lamehip_batch_fetch(lamehip_batch * b)
         return 0;
     for (int s = 0; s < b->B; s++)
         total += b->h_desc[(size_t) s].bytes_cap;
-    if (!b->d_sum) {
+    if (!b->d_sum)
         HIPCHK(hipMalloc((void **) &b->d_sum, (size_t) b->B * 2 * sizeof(long long)));
+    if (!b->h_sum)
         HIPCHK(hipHostMalloc((void **) &b->h_sum, (size_t) b->B * 2 * sizeof(long long), 0));
-    }
     if (total > b->h_bytes_cap) {
         unsigned char *nb = nullptr;
         HIPCHK(hipHostMalloc((void **) &nb, (size_t) (total > 0 ? total : 1), 0));
