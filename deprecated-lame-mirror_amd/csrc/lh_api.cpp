@@ -26,11 +26,6 @@ extern "C" int lh_launch_encode(const LhConfig * cfg, const LhTables * T, const 
                                 const LhStreamDesc * descs, LhStreamState * states,
                                 LhFrameOut * out, uint8_t * bytes, int nstreams, void *stream);
 
-/* the same kernel with sibling waves (lh_kernels.hip compiled with -DLH_HELPERS: four waves per stream; CBR / ABR) */
-extern "C" int lh_launch_encode4(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, const float *pcmf,
-                                 const LhStreamDesc * descs, LhStreamState * states,
-                                 LhFrameOut * out, uint8_t * bytes, int nstreams, void *stream);
-
 extern "C" int lh_launch_selftest(unsigned *d_out, unsigned seed, void *stream);
 extern "C" int lh_launch_summary(const LhStreamState * states, long long *sum, int nstreams, void *stream);
 extern "C" int lh_launch_scatter(const int16_t * arena, int16_t * pool, long cap, const int *seg, int nseg, void *stream);
@@ -67,24 +62,11 @@ lamehip_device_count(void)
 struct LhDeviceConst {
     LhConfig *d_cfg = nullptr;
     LhTables *d_tab = nullptr;
-    int     waves = 2;          /* which kernel encodes with these constants: 2 or 4 waves per stream */
-    /* The default is the kernel with two waves per stream.  LAMEHIP_KERNEL_WAVES=4 (read when the constants are
-     * uploaded) selects the one whose CBR / ABR search runs with a sibling wave per channel (four waves per
-     * stream, <= 128 VGPRs): bit-identical, and on MI355X 11 % slower -- a SIMD does not issue for four busy waves
-     * what it issues for two -- so it stays an option for measurements.  The VBR loop has
-     * no such split. */
-    static int pick_waves(const LhConfig & cfg) {
-        const char *e = getenv("LAMEHIP_KERNEL_WAVES");
-        int const vbr_loop = (cfg.vbr == 1 || cfg.vbr == 2 || cfg.vbr == 4);
-        return (e && e[0] == '4' && !vbr_loop) ? 4 : 2;
-    }
     int launch(const int16_t * pcm, const float *pcmf, const LhStreamDesc * descs, LhStreamState * states,
                LhFrameOut * out, uint8_t * bytes, int nstreams, void *stream) const {
-        return (waves == 4 ? lh_launch_encode4 : lh_launch_encode) (d_cfg, d_tab, pcm, pcmf, descs, states, out, bytes,
-                                                                    nstreams, stream);
+        return lh_launch_encode(d_cfg, d_tab, pcm, pcmf, descs, states, out, bytes, nstreams, stream);
     }
     int upload(const LhConfig & cfg, const LhTables & tab) {
-        waves = pick_waves(cfg);
         HIPCHK(hipMalloc((void **) &d_cfg, sizeof(LhConfig)));
         HIPCHK(hipMalloc((void **) &d_tab, sizeof(LhTables)));
         HIPCHK(hipMemcpy(d_cfg, &cfg, sizeof(LhConfig), hipMemcpyHostToDevice));
@@ -2591,7 +2573,7 @@ lamehip_batch_last_kernel_ms(lamehip_batch * b)
 extern "C" int
 lamehip_batch_kernel_waves(lamehip_batch * b)
 {
-    return b ? b->dc.waves : 0;
+    return b ? 2 : 0;
 }
 
 extern "C" int

@@ -15,36 +15,22 @@
 #include "lh_dev_math.h"
 
 #define LH_NT 128               /* threads that walk the frame: wave 0 = left/mid, wave 1 = right/side */
-/* LH_HELPERS: the workgroup has two more waves, 2 and 3, the siblings of waves 0 and 1 in the CBR / ABR search
- * (lh_dev_qloop.h: one wave counts bits while its sibling forms the noise of the same candidate).  Outside the
- * search they only keep the workgroup's barriers company (lh_helper_waves, lh_kernels.hip). */
-#ifdef LH_HELPERS
-#define LH_BLOCK 256
-#else
 #define LH_BLOCK LH_NT
-#endif
 #define LH_SQRT2 1.41421356237309504880
 
 /* LH_SYNC_WG(): workgroup barrier with a full fence (LDS and HBM: __syncthreads()).
  * LH_SYNC_WG_LDS(): the same for phases whose waves exchange data through LDS only (the psy model,
  * the transforms): global loads in flight -- table look-ups, the next phase's prefetches -- are not
  * drained at the barrier. */
-/* With sibling waves every barrier is counted (thread 0, before it arrives): the siblings count the barriers
- * they pass, and the frame loop names the barrier after which a search begins by its number. */
-#ifdef LH_HELPERS
-#define LH_BAR_TICK() do { if (threadIdx.x == 0) lh_lds_add(&lh_lds.bar_count, 1); } while (0)
-#else
-#define LH_BAR_TICK() do { } while (0)
-#endif
 #ifdef LH_EMU
-#define LH_SYNC_WG() do { LH_BAR_TICK(); __syncthreads(); } while (0)
-#define LH_SYNC_WG_LDS() do { LH_BAR_TICK(); __syncthreads(); } while (0)
+#define LH_SYNC_WG() do { __syncthreads(); } while (0)
+#define LH_SYNC_WG_LDS() do { __syncthreads(); } while (0)
 #else
-#define LH_SYNC_WG() do { LH_BAR_TICK(); __syncthreads(); } while (0)
+#define LH_SYNC_WG() do { __syncthreads(); } while (0)
 #if defined(LH_FULL_FENCE)
-#define LH_SYNC_WG_LDS() do { LH_BAR_TICK(); __syncthreads(); } while (0)
+#define LH_SYNC_WG_LDS() do { __syncthreads(); } while (0)
 #else
-#define LH_SYNC_WG_LDS() do { LH_BAR_TICK(); \
+#define LH_SYNC_WG_LDS() do { \
                               __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); \
                               __builtin_amdgcn_s_barrier(); \
                               __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); } while (0)
@@ -309,9 +295,8 @@ struct LhVbrSave {
     int     table_select[3], region0_count, region1_count, pad2[3];
 };
 
-/* The old VBR loop is part of the two-wave kernel; the four-wave kernel never runs a VBR loop, and the profiling build's
- * cycle counters take the LDS its parking area needs. */
-#if !defined(LH_HELPERS) && !(defined(LH_PROF) && !defined(LH_EMU))
+/* The profiling build's cycle counters take the LDS the old VBR loop's parking area needs. */
+#if !(defined(LH_PROF) && !defined(LH_EMU))
 #define LH_VBR_OLD 1
 #endif
 
@@ -404,19 +389,6 @@ static_assert(__builtin_offsetof(LhStreamState, ath_adjust_limit) - __builtin_of
 static_assert(__builtin_offsetof(LhStreamState, status) - __builtin_offsetof(LhStreamState, pefirbuf)
               == 4 * (LH_SS_WORDS_B - 1), "second run of LhStreamState's small members");
 
-/* What a wave of the frame loop and its sibling exchange during a search (LH_HELPERS; one box per channel).
- * Sequence numbers: go_seq counts the granules (a search, or none: go_ns = 0), seq0 / seq1 the candidates of
- * a search (from 1; cleared with every go).  The per-band results travel through two arrays the search leaves
- * free, LhChanLds.l3_xmin (distortions) and sf[1] (steps of calc_noise_data). */
-struct LhPairBox {
-    int     go_seq, go_ns, go_gr, go_targ;      /* frame loop -> sibling: slots of the search (4 / 5), its granule and budget */
-    int     loaded0, loaded1;   /* = go_seq once the wave has the granule in registers (0: frame loop, 1: sibling) */
-    int     seq0, bits, sfb_count1;             /* counting wave -> sibling */
-    int     seq1, over_count, over_SSD;         /* sibling -> counting wave */
-    float   max_noise;
-    int     pad;
-};
-
 struct LhLds {
     LhSmallState ss;
     /* Band energies / thresholds of the psy model, [L,R,M,S] each: a ring of three slots.  The model's
@@ -451,13 +423,6 @@ struct LhLds {
 #endif
     LhCtxShared ctx;
     LhRgSlot rg[2];
-#ifdef LH_HELPERS
-    LhPairBox box[2];
-    int     bar_count;          /* barriers the frame loop has passed (LH_BAR_TICK) */
-    int     search_at;          /* number of the barrier behind which the siblings join a search */
-    int     h_quit;             /* the stream is done */
-    int     hpad;
-#endif
     /* both unions start on 16-byte boundaries: the kernels read float2 / float4 from the arrays
      * inside (ds_read_b64 / b128), and a misaligned wide LDS access is split by the hardware --
      * a layout change that shifted them by 4 bytes once cost 13 % of the whole kernel */

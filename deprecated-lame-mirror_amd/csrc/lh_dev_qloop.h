@@ -131,7 +131,7 @@ lq_quant_line_hbm(const LhTables * T, float istep, float xp)
 /* load the granule into registers; Q.xrpow, Q.l3_xmin and the geometry arrays were written by
  * lh_init_outer_loop / lh_init_xrpow / lh_calc_xmin.  Then the arrays the search does not need in
  * LDS make room for the Huffman length grids. */
-template < int ROLE > LH_DEVFN void
+LH_DEVFN void
 lq_load(const LhCtx & c, LhQS & S, LhChanLds & Q, const LhQR & R, const LhGrR & g, int qch)
 {
     const LhQTabs *qt = LH_QT;
@@ -179,18 +179,6 @@ lq_load(const LhCtx & c, LhQS & S, LhChanLds & Q, const LhQR & R, const LhGrR & 
     S.thrv = (LH_IXMAX) / S.istepv;
     S.sbg8 = 0;                 /* so is subblock_gain */
     LH_WAVE_SYNC();
-#ifdef LH_HELPERS
-    if (ROLE == 1) {
-        /* the sibling: it never counts bits, so it needs no grids; the counting wave may overwrite the arrays
-         * once this wave has read them, and this wave may use Q.xrpow as calc_noise's scratch once the
-         * counting wave has */
-        LhPairBox & B = lh_lds.box[qch];
-        int const n = lh_uni_i(B.go_seq);
-        lh_flag_post(&B.loaded1, n);
-        lh_flag_wait(&B.loaded0, n);
-        return;
-    }
-#endif
     {
         /* the three grids are constants of the launch: 704 words from HBM, issued together */
         const uint32_t *hg = c.T->hgrid;
@@ -198,14 +186,6 @@ lq_load(const LhCtx & c, LhQS & S, LhChanLds & Q, const LhQR & R, const LhGrR & 
 #pragma unroll
         for (int j = 0; j < 11; j++)
             w[j] = hg[c.lane + 64 * j];
-#ifdef LH_HELPERS
-        if (ROLE == 0) {
-            LhPairBox & B = lh_lds.box[qch];
-            int const n = lh_uni_i(B.go_seq);
-            lh_flag_post(&B.loaded0, n);
-            lh_flag_wait(&B.loaded1, n);
-        }
-#endif
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             Q.hl3_big[0][c.lane + 64 * j] = w[j];
@@ -531,7 +511,7 @@ lq_count_bits(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
 
 /* What calc_noise finds for the working image, before it is taken over: the band's entry of calc_noise_data
  * and its distortion (lane = band), and the totals.  The search forms it for every candidate the bit count
- * looks at (in a sibling wave, when there is one) and takes over the one the reference would have computed. */
+ * looks at and takes over the one the reference would have computed. */
 struct LhNoiseTmp {
     int     pnstep;
     float   pnnoise, pnlog, dist;
@@ -938,72 +918,12 @@ lq_balance_noise(const LhCtx & c, LhQS & S, LhChanLds & Q, const LhQR & R, LhGrR
     return !status;
 }
 
-/* One candidate of the search: the bit count of the working image at g.global_gain (count_bits), and -- into
- * `t', for lq_noise_point() to take over if the reference computes it for this candidate -- what calc_noise
- * finds for that image.
- *   ROLE -1: one wave does everything; the noise is formed at lq_noise_point().
- *   ROLE 0 / 1 (LH_HELPERS): two waves hold the same granule in their registers and take every decision of the
- *   search alike.  Wave 0 counts, wave 1 quantises the same image (the same lq_quantize on the same state)
- *   and forms its noise meanwhile; then they swap: the bit count and pn_sfb_count1 one way, the bands'
- *   distortions / steps and the totals the other.  `ev' numbers the candidates of a search. */
-template < int USE_PREV, int NS, int ROLE > LH_DEVFN int
-lq_eval(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q, const float *xr, int qch, int &ev, LhNoiseTmp & t)
-{
-#ifdef LH_HELPERS
-    if (ROLE >= 0) {
-        LhPairBox & B = lh_lds.box[qch];
-        int const band = c.lane <= LH_SFBMAX ? c.lane : LH_SFBMAX;
-        int     bits;
-        ev++;
-        if (ROLE == 0) {
-            bits = lq_count_bits < USE_PREV, NS > (c, S, R, g, Q);
-            if (c.lane == 0) {
-                B.bits = bits;
-                B.sfb_count1 = R.pn_sfb_count1;
-            }
-            lh_flag_post(&B.seq0, ev);
-            lh_flag_wait(&B.seq1, ev);
-            t.dist = (c.lane <= LH_SFBMAX) ? Q.l3_xmin[band] : S.dist;
-            t.pnstep = (c.lane <= LH_SFBMAX) ? Q.sf[1][band] : S.pnstep;
-            t.pnnoise = S.pnnoise;      /* (only the sibling uses these two) */
-            t.pnlog = S.pnlog;
-            t.res.over_count = lh_uni_i(B.over_count);
-            t.res.over_SSD = lh_uni_i(B.over_SSD);
-            t.res.max_noise = lh_uni_f(B.max_noise);
-            t.res.tot_noise = 0;
-            t.res.over_noise = 0;
-            t.res.bits = 0;
-        }
-        else {
-            (void) lq_quantize < USE_PREV, NS > (c, S, R, g);
-            lq_calc_noise < NS > (c, S, R, g, Q, xr, t);
-            lh_flag_wait(&B.seq0, ev);
-            bits = lh_uni_i(B.bits);
-            R.pn_sfb_count1 = lh_uni_i(B.sfb_count1);
-            if (c.lane <= LH_SFBMAX) {
-                Q.l3_xmin[c.lane] = t.dist;
-                Q.sf[1][c.lane] = t.pnstep;
-            }
-            if (c.lane == 0) {
-                B.over_count = t.res.over_count;
-                B.over_SSD = t.res.over_SSD;
-                B.max_noise = t.res.max_noise;
-            }
-            lh_flag_post(&B.seq1, ev);
-        }
-        return bits;
-    }
-#endif
-    return lq_count_bits < USE_PREV, NS > (c, S, R, g, Q);
-}
-
 /* where the reference calls calc_noise: the noise of the candidate counted last becomes the working image's */
-template < int NS, int ROLE > LH_DEVFN void
+template < int NS > LH_DEVFN void
 lq_noise_point(const LhCtx & c, LhQS & S, LhQR & R, const LhGrR & g, LhChanLds & Q, const float *xr, LhNoiseTmp & t,
                LhNoiseRes & res)
 {
-    if (ROLE < 0)
-        lq_calc_noise < NS > (c, S, R, g, Q, xr, t);
+    lq_calc_noise < NS > (c, S, R, g, Q, xr, t);
     lq_noise_commit(S, R, g, t);
     res = t.res;
 }
@@ -1013,9 +933,8 @@ lq_noise_point(const LhCtx & c, LhQS & S, LhQR & R, const LhGrR & g, LhChanLds &
  * the walk has crossed the target (or hit an end of the range) every further step halves, and a step
  * of 1 ends the search.  Should the last trial be over the budget, the gain rises one by one until it fits.  The
  * channel remembers where it ended and whether it had to move far (lh_lds.ss.OldValue / CurrentStep). */
-template < int NS, int ROLE > LH_DEVFN int
-lq_bin_search(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q, const float *xr, int desired_rate, int ch,
-              int &ev, LhNoiseTmp & t)
+template < int NS > LH_DEVFN int
+lq_bin_search(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q, int desired_rate, int ch)
 {
     int const from = lh_uni_i(lh_lds.ss.OldValue[ch]);
     int const want = desired_rate - g.part2_length;
@@ -1026,7 +945,7 @@ lq_bin_search(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q, con
     g.global_gain = from;
     for (;;) {
         int     move;
-        bits = lq_eval < 0, NS, ROLE > (c, S, R, g, Q, xr, ch, ev, t);
+        bits = lq_count_bits < 0, NS > (c, S, R, g, Q);
         if (stride == 1 || bits == want)
             break;
         move = (bits > want) ? 1 : -1;
@@ -1043,9 +962,9 @@ lq_bin_search(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q, con
     }
     while (bits > want && g.global_gain < 255) {
         g.global_gain++;
-        bits = lq_eval < 0, NS, ROLE > (c, S, R, g, Q, xr, ch, ev, t);
+        bits = lq_count_bits < 0, NS > (c, S, R, g, Q);
     }
-    if (ROLE != 1 && c.lane == 0) {
+    if (c.lane == 0) {
         lh_lds.ss.CurrentStep[ch] = (from - g.global_gain >= 4) ? 4 : 2;
         lh_lds.ss.OldValue[ch] = g.global_gain;
     }
@@ -1082,7 +1001,7 @@ lq_keep_best(const LhCtx & c, LhQS & S, LhChanLds & Q, LhQOld * keep = nullptr)
 
 /* reference quantize.c:1010-1197; gb = cod_info.  On return the best image and its scalefactors
  * are in Q.ix[0] / Q.sf[0]. */
-template < int NS, int ROLE, int OLD = 0 > LH_DEVFN int
+template < int NS, int OLD = 0 > LH_DEVFN int
 lq_outer_loop(const LhCtx & c, LhQS & S, LhChanLds & Q, LhQR & R, LhGrR & gb, const float *xr, int ch, int targ_bits,
               int sfb21_extra = 0, LhQOld * keep = nullptr)
 {
@@ -1091,11 +1010,10 @@ lq_outer_loop(const LhCtx & c, LhQS & S, LhChanLds & Q, LhQR & R, LhGrR & gb, co
     LhNoiseTmp nt;
     int     huff_bits, better, age;
     int     best_part2_3_length = 9999999;
-    int     ev = 0;             /* candidates counted so far (sibling waves number their exchanges with it) */
 
     {
         LH_PT(t_bs);
-        (void) lq_bin_search < NS, ROLE > (c, S, R, gb, Q, xr, targ_bits, ch, ev, nt);
+        (void) lq_bin_search < NS > (c, S, R, gb, Q, targ_bits, ch);
         LH_PA(7, t_bs);
     }
     best_noise_info.over_count = 100;
@@ -1108,10 +1026,9 @@ lq_outer_loop(const LhCtx & c, LhQS & S, LhChanLds & Q, LhQR & R, LhGrR & gb, co
             S.pnnoise = 0;
             S.pnlog = 0;
         }
-        lq_noise_point < NS, ROLE > (c, S, R, gb, Q, xr, nt, best_noise_info);
+        lq_noise_point < NS > (c, S, R, gb, Q, xr, nt, best_noise_info);
         best_noise_info.bits = gb.part2_3_length;
-        if (ROLE != 1)
-            lq_keep_best < NS, OLD > (c, S, Q, keep);
+        lq_keep_best < NS, OLD > (c, S, Q, keep);
         gw = gb;
         age = 0;
         do {
@@ -1139,13 +1056,13 @@ lq_outer_loop(const LhCtx & c, LhQS & S, LhChanLds & Q, LhQR & R, LhGrR & gb, co
             huff_bits = targ_bits - gw.part2_length;
             if (huff_bits <= 0)
                 break;
-            while ((gw.part2_3_length = lq_eval < 1, NS, ROLE > (c, S, R, gw, Q, xr, ch, ev, nt)) > huff_bits
+            while ((gw.part2_3_length = lq_count_bits < 1, NS > (c, S, R, gw, Q)) > huff_bits
                    && gw.global_gain <= maxggain)
                 gw.global_gain++;
             if (gw.global_gain > maxggain)
                 break;
             if (best_noise_info.over_count == 0) {
-                while ((gw.part2_3_length = lq_eval < 1, NS, ROLE > (c, S, R, gw, Q, xr, ch, ev, nt)) > best_part2_3_length
+                while ((gw.part2_3_length = lq_count_bits < 1, NS > (c, S, R, gw, Q)) > best_part2_3_length
                        && gw.global_gain <= maxggain)
                     gw.global_gain++;
                 if (gw.global_gain > maxggain)
@@ -1153,7 +1070,7 @@ lq_outer_loop(const LhCtx & c, LhQS & S, LhChanLds & Q, LhQR & R, LhGrR & gb, co
             }
             {
                 LH_PT(t_cn);
-                lq_noise_point < NS, ROLE > (c, S, R, gw, Q, xr, nt, noise_info);
+                lq_noise_point < NS > (c, S, R, gw, Q, xr, nt, noise_info);
                 LH_PA(9, t_cn);
             }
             noise_info.bits = gw.part2_3_length;
@@ -1161,8 +1078,7 @@ lq_outer_loop(const LhCtx & c, LhQS & S, LhChanLds & Q, LhQR & R, LhGrR & gb, co
             if (better) {
                 best_part2_3_length = gb.part2_3_length;
                 best_noise_info = noise_info;
-                if (ROLE != 1)
-                    lq_keep_best < NS, OLD > (c, S, Q, keep);
+                lq_keep_best < NS, OLD > (c, S, Q, keep);
                 gb = gw;
                 age = 0;
             }
@@ -1175,10 +1091,8 @@ lq_outer_loop(const LhCtx & c, LhQS & S, LhChanLds & Q, LhQR & R, LhGrR & gb, co
         }
         while ((gw.global_gain + gw.scalefac_scale) < 255);
     }
-    else if (ROLE != 1)
+    else
         lq_keep_best < NS, OLD > (c, S, Q, keep);
-    if (ROLE == 1)
-        return 0;               /* the sibling's copy of the result is not used */
     if (OLD) {
         /* the next search of this granule continues from the best image: its xrpow, scalefactors, subblock gains */
 #pragma unroll
@@ -1204,8 +1118,8 @@ lq_outer_loop(const LhCtx & c, LhQS & S, LhChanLds & Q, LhQR & R, LhGrR & gb, co
 /* out-of-line entries (own register allocation): R / g travel through the channel's LDS slot.  One per
  * slot count; the fifth slot (lines 512..575) drops out of the search when nothing is quantised
  * there and its xrpow is all zero (it could otherwise still raise xrpow_max): the usual case below
- * 20 kHz.  With LH_HELPERS, one more pair for the sibling wave (ROLE 1), which leaves no results. */
-template < int NS, int ROLE > LH_DEVFN void
+ * 20 kHz. */
+template < int NS > LH_DEVFN void
 lq_stage_body(int qch, int gr, int targ_bits)
 {
     LhCtx const c = lh_ctx_load();
@@ -1214,10 +1128,9 @@ lq_stage_body(int qch, int gr, int targ_bits)
     LhChanLds & Q = lh_lds.u.quant.ch[qch];
     LhQS    S;
     R.s_mnc = lh_uni_i((int) Q.sfb_of_line[R.mnc]);
-    lq_load < ROLE > (c, S, Q, R, g, qch);
-    (void) lq_outer_loop < NS, ROLE > (c, S, Q, R, g, lh_lds.xr[qch][lh_uni_i(gr)], qch, lh_uni_i(targ_bits));
-    if (ROLE != 1)
-        lh_rg_put(c, R, g);
+    lq_load(c, S, Q, R, g, qch);
+    (void) lq_outer_loop < NS > (c, S, Q, R, g, lh_lds.xr[qch][lh_uni_i(gr)], qch, lh_uni_i(targ_bits));
+    lh_rg_put(c, R, g);
 }
 
 #ifdef LH_VBR_OLD
@@ -1247,7 +1160,7 @@ lq_vbrold_body(int qch, int gr, int min_bits, int max_bits, int cont)
     max_bits = lh_uni_i(max_bits);
     int const top = max_bits;
     R.s_mnc = lh_uni_i((int) Q.sfb_of_line[R.mnc]);
-    lq_load < -1 > (c, S, Q, R, g, qch);
+    lq_load(c, S, Q, R, g, qch);
     if (lh_uni_i(cont)) {
         S.sfw = Q.sf[0][band];
         S.sfbest = S.sfw;
@@ -1261,7 +1174,7 @@ lq_vbrold_body(int qch, int gr, int min_bits, int max_bits, int cont)
     this_bits = (max_bits + min_bits) / 2;
     do {
         int const sfb21 = c.sfb21_extra && !(this_bits > top - 42);
-        int const over = lq_outer_loop < NS, -1, 1 > (c, S, Q, R, g, xr, qch, this_bits, sfb21, &K);
+        int const over = lq_outer_loop < NS, 1 > (c, S, Q, R, g, xr, qch, this_bits, sfb21, &K);
         if (over <= 0) {
             /* it can be done with these bits: set it aside, try fewer */
             found = 1;
@@ -1331,33 +1244,17 @@ lq_vbrold_stage4(int qch, int gr, int min_bits, int max_bits, int cont)
 }
 #endif
 
-#ifdef LH_HELPERS
-#define LQ_MAIN_ROLE 0
-LH_STAGEFN void
-lq_sibling_stage5(int qch, int gr, int targ_bits)
-{
-    lq_stage_body < 5, 1 > (qch, gr, targ_bits);
-}
-
-LH_STAGEFN void
-lq_sibling_stage4(int qch, int gr, int targ_bits)
-{
-    lq_stage_body < 4, 1 > (qch, gr, targ_bits);
-}
-#else
-#define LQ_MAIN_ROLE (-1)
-#endif
 
 LH_STAGEFN void
 lq_outer_loop_stage5(int qch, int gr, int targ_bits)
 {
-    lq_stage_body < 5, LQ_MAIN_ROLE > (qch, gr, targ_bits);
+    lq_stage_body < 5 > (qch, gr, targ_bits);
 }
 
 LH_STAGEFN void
 lq_outer_loop_stage4(int qch, int gr, int targ_bits)
 {
-    lq_stage_body < 4, LQ_MAIN_ROLE > (qch, gr, targ_bits);
+    lq_stage_body < 4 > (qch, gr, targ_bits);
 }
 
 /* which of the two applies: wave-uniform; Q.xrpow and R.mnc are final (after lh_calc_xmin) */

@@ -29,11 +29,7 @@
 
 #ifdef LH_EMU
 #include <string.h>
-#ifdef LH_HELPERS
-extern "C" { extern int lh_emu_poison_lds; }
-#else
 extern "C" { int lh_emu_poison_lds = 0; }
-#endif
 #endif
 #include "lh_static_tables.h"
 #include "lh_dev_common.h"
@@ -196,68 +192,12 @@ lh_prepare_granule(const LhCtx & c, int ch, int gr, int msoff, int substep)
     return lh_uni_i(nonzero);
 }
 
-#ifdef LH_HELPERS
-/* a wave of the frame loop tells its sibling what this granule's search is (slots 4 / 5; 0: there is none) */
-LH_DEVFN void
-lh_sibling_go(const LhCtx & c, int qch, int ns, int gr, int targ)
-{
-    LhPairBox & B = lh_lds.box[qch];
-    int const n = lh_uni_i(B.go_seq) + 1;
-    if (c.lane == 0) {
-        B.go_ns = ns;
-        B.go_gr = gr;
-        B.go_targ = targ;
-        B.seq0 = 0;
-        B.seq1 = 0;
-    }
-    lh_flag_post(&B.go_seq, n);
-}
 
-/* Waves 2 and 3: between searches they only keep the workgroup's barriers company (a barrier waits for every
- * wave of the workgroup), counting them; behind the barrier the frame loop has named (LhLds.search_at) wave
- * 2 + ch waits for channel ch's `go' and runs the search beside it. */
-LH_DEVFN void
-lh_helper_waves(int qch)
-{
-    LhPairBox & B = lh_lds.box[qch];
-    int     passed = 0, served = 0;
-#if !defined(LH_EMU)
-    __builtin_amdgcn_s_setprio(0);      /* behind the frame loop's waves when a SIMD has to choose (+6 %) */
-#endif
-    for (;;) {
-        __syncthreads();
-        passed++;
-        if (lh_uni_i(lh_lds.h_quit))
-            break;
-        if (lh_uni_i(lh_lds.search_at) == passed) {
-            served++;
-            lh_flag_wait(&B.go_seq, served);
-            {
-                int const ns = lh_uni_i(B.go_ns), gr = lh_uni_i(B.go_gr), targ = lh_uni_i(B.go_targ);
-                if (ns == 5)
-                    lq_sibling_stage5(qch, gr, targ);
-                else if (ns == 4)
-                    lq_sibling_stage4(qch, gr, targ);
-            }
-        }
-    }
-}
-#else
-#define lh_sibling_go(c, qch, ns, gr, targ) do { } while (0)
-#endif
-
-/* The frame and the stream loop are functions of their own only in the four-wave build: a kernel body keeps what
- * lives across its calls in registers ABOVE its callees' budget, which decides the occupancy there (128 VGPRs);
- * in the two-wave build (256 VGPRs) they are inlined -- out of line they saved and restored ~60 registers per
+/* The frame and the stream loop are inlined into the kernel: out of line they saved and restored ~60 registers per
  * frame through scratch memory, 50 KB of HBM traffic per frame at no gain. */
-#ifdef LH_HELPERS
-#define LH_FRAMEFN LH_STAGEFN
-#else
-#define LH_FRAMEFN LH_DEVFN
-#endif
 
 /* one frame of one stream; executed by the whole workgroup */
-LH_FRAMEFN void
+LH_DEVFN void
 lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
 {
     LhLds & L = lh_lds;
@@ -416,10 +356,6 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
     int     frame_bits = lh_uni_i(lh_frame_bits(cfg, bitrate_index, padding));
     int     mean_bits = lh_uni_i((frame_bits - cfg->sideinfo_len * 8) / cfg->mode_gr);
     int     total_bits = 0;
-#ifdef LH_HELPERS
-    int const vbr_new = 0;      /* the host launches the VBR loops with the two-wave kernel only */
-    int const abr = (cfg->vbr == 3);
-#else
 #ifdef LH_VBR_OLD
     int const vbr_old = (cfg->vbr == 2);
 #else
@@ -428,7 +364,6 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
     /* (below, vbr_new stands for both VBR loops: either does the whole iteration stage in a function of its own) */
     int const vbr_new = (cfg->vbr == 1 || cfg->vbr == 4 || vbr_old), abr = (cfg->vbr == 3);
     float   masking_lower_left = cfg->masking_lower_long;
-#endif
     int     abr_targ[2][2] = { {0, 0}, {0, 0} }, analog_silence_bits = 0;
     if (vbr_new) {
         LH_SYNC_WG();
@@ -501,11 +436,6 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
             lh_reduce_side(targ_bits, ms_ener_ratio[gr], mean_bits, max_bits);
         targ_bits[0] = lh_uni_i(targ_bits[0]);
         targ_bits[1] = lh_uni_i(targ_bits[1]);
-#ifdef LH_HELPERS
-        /* the sibling waves leave their barrier loop behind the next barrier and wait for this granule's `go' */
-        if (tid == 0)
-            L.search_at = L.bar_count + 1;
-#endif
         LH_SYNC_WG();
         if (w >= nch) {
             /* no second channel: its payload slot is all zero */
@@ -514,7 +444,6 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
                 z[i] = 0u;
             if (lane == 0)
                 L.bits_used[w] = 0;
-            lh_sibling_go(c, w, 0, gr, 0);
         }
         else {
             int const ch = w;
@@ -536,11 +465,9 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
                 if (abr && !R.ath_over)
                     targ_bits[ch] = analog_silence_bits;    /* reference quantize.c:1953-1954 */
                 if (lq_needs_tail(c, Q, R)) {
-                    lh_sibling_go(c, ch, 5, gr, targ_bits[ch]);
                     lq_outer_loop_stage5(ch, gr, targ_bits[ch]);
                 }
                 else {
-                    lh_sibling_go(c, ch, 4, gr, targ_bits[ch]);
                     lq_outer_loop_stage4(ch, gr, targ_bits[ch]);
                 }
                 R = lh_uniform(L.rg[ch].R);
@@ -548,7 +475,6 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
                 LH_PA(5, t_ol);
             }
             else
-                lh_sibling_go(c, ch, 0, gr, 0);     /* nothing to search in an all-zero granule */
             LH_PT(t_fin);
             lh_rg_put(c, R, g);
             lh_best_scalefac_store(ch, gr, fo->gr[0][ch].scalefac, L.block_type[0][ch]);
@@ -650,9 +576,6 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
         lh_lds.ss.substep_shaping = substep;
         /* what the next frame's psy model finds in sv_qnt.masking_lower: the CBR loop leaves the value
          * of its last granule/channel (channel 0 for mono), the VBR loop always the long-block one (reference quantize.c:1622) */
-#ifdef LH_HELPERS
-        float const masking_lower_left = cfg->masking_lower_long;
-#endif
         lh_lds.ss.masking_lower = vbr_new ? masking_lower_left
             : (L.block_type[1][nch - 1] != LH_SHORT_TYPE) ? cfg->masking_lower_long : cfg->masking_lower_short;
         lh_lds.ss.frame_number = lh_lds.ss.frame_number + 1;
@@ -672,23 +595,10 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
 }
 
 #ifndef LH_WAVES_PER_EU
-#ifdef LH_HELPERS
-#define LH_WAVES_PER_EU 4
-#else
 #define LH_WAVES_PER_EU 2
 #endif
-#endif
-/* the LH_HELPERS build of this file is a second object in the same library: its own names */
-#ifdef LH_HELPERS
-#define lh_encode_kernel lh_encode_kernel4
-#define lh_launch_encode lh_launch_encode4
-#define lh_emu_encode lh_emu_encode4
-#define lh_emu_encode_bytes lh_emu_encode_bytes4
-#endif
-/* all frames of one stream (the workgroup's whole job).  Out of line: a kernel body places what it keeps across
- * calls in registers ABOVE its callees' budget, which is what decides the occupancy; a function keeps
- * such values in the callee-saved registers inside the budget. */
-LH_FRAMEFN void
+/* all frames of one stream (the workgroup's whole job) */
+LH_DEVFN void
 lh_encode_stream(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, const float *pcmf,
                  const LhStreamDesc * descs, LhStreamState * states, LhFrameOut * out, uint8_t * bytes,
                  int nstreams)
@@ -728,20 +638,6 @@ lh_encode_stream(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, 
     c.lane = c.tid & 63;
     c.wave = lh_uni_i(c.tid >> 6);      /* scalar: everything indexed by the wave id gets scalar addressing */
     lh_ctx_hot(c);
-#ifdef LH_HELPERS
-    if (c.tid == 0) {
-        L.bar_count = 0;
-        L.search_at = -1;
-        L.h_quit = 0;
-        for (int k = 0; k < 2; k++) {
-            L.box[k].go_seq = 0;
-            L.box[k].loaded0 = 0;
-            L.box[k].loaded1 = 0;
-            L.box[k].seq0 = 0;
-            L.box[k].seq1 = 0;
-        }
-    }
-#endif
     if (c.tid == 0) {
         L.gr0_done[0] = L.gr0_done[1] = 0;
         L.ctx.cfg = c.cfg;
@@ -752,15 +648,6 @@ lh_encode_stream(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, 
         L.ctx.bytes = bytes;
         L.ctx.d = c.d;
     }
-#ifdef LH_HELPERS
-    if (c.wave >= 2) {
-        lh_helper_waves(c.wave - 2);
-        return;
-    }
-#if !defined(LH_EMU)
-    __builtin_amdgcn_s_setprio(3);      /* the frame loop's waves before their siblings */
-#endif
-#endif
     /* State that is rewritten every frame stays on the chip for the whole launch: the polyphase
      * overlap and the psy model's previous partition energies in registers (LhWaveCarry), its band
      * energies / thresholds in the LDS ring (LhLds.psy_en).  HBM sees them once per launch. */
@@ -793,11 +680,6 @@ lh_encode_stream(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, 
         lh_encode_frame(c, &out[c.d.out_index + (f - c.d.frame_begin)], carry);
         slot = (slot + 2) % 3;
     }
-#ifdef LH_HELPERS
-    if (c.tid == 0)
-        L.h_quit = 1;
-    LH_SYNC_WG();
-#endif
     if (c.tid < LH_SS_WORDS_A)
         ((uint32_t *) &st->loudness_sq_save[0])[c.tid] = ((const uint32_t *) &L.ss)[c.tid];
     else if (c.tid < LH_SS_WORDS_A + LH_SS_WORDS_B)
@@ -828,7 +710,7 @@ lh_encode_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, 
     lh_encode_stream(cfg, T, pcm, pcmf, descs, states, out, bytes, nstreams);
 }
 
-#if !defined(LH_EMU) && !defined(LH_HELPERS)
+#if !defined(LH_EMU)
 /* device self-test of the cross-lane primitives in lh_wave.h: each reduction is
  * compared with a serial evaluation through LDS; out[0] = number of mismatches */
 extern "C" __global__ void __launch_bounds__(64)

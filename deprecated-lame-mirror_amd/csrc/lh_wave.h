@@ -273,25 +273,6 @@ lh_wave_sum_tail3(uint32_t (&v)[N])
     }
 }
 
-/* A flag in LDS that one wave of the workgroup raises for another (lh_dev_qloop.h: the search's sibling
- * waves).  lh_flag_post(): everything this wave wrote to LDS before is visible to a wave that has seen the
- * flag; lh_flag_wait(): returns once the flag holds v.  Called by all lanes, wave-uniformly. */
-static inline void
-lh_flag_post(int *flag, int v)
-{
-    hipemu_wave_sync();
-    if (hipemu_lane() == 0)
-        *flag = v;
-    hipemu_wave_sync();
-}
-
-static inline void
-lh_flag_wait(const int *flag, int v)
-{
-    while (*(const volatile int *) flag != v)
-        hipemu_yield();
-}
-
 static inline void lh_lds_add(int *p, int v) { *p += v; }      /* fibers interleave only at sync points */
 static inline void lh_lds_max(int *p, int v) { if (v > *p) *p = v; }
 static inline void lh_lds_addf(float *p, float v) { *p += v; }
@@ -588,31 +569,6 @@ __device__ __forceinline__ uint32_t
 lh_bcast_u32(uint32_t v, int src)
 {
     return (uint32_t) __builtin_amdgcn_readlane((int) v, src);
-}
-
-/* A flag in LDS that one wave of the workgroup raises for another (lh_dev_qloop.h: the search's sibling
- * waves).  A wave's DS instructions are executed in the order they were issued, so the flag's write follows
- * the data's and the reader's data reads follow its read of the flag; the fences only keep the compiler from
- * moving LDS accesses across.  The waiting wave sleeps between polls (s_sleep 1 = 64 cycles): it takes no
- * issue slots from the waves it shares the SIMD with. */
-__device__ __forceinline__ void
-lh_flag_post(int *flag, int v)
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    if (lh_lane() == 0)
-        __hip_atomic_store(flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
-__device__ __forceinline__ void
-lh_flag_wait(const int *flag, int v)
-{
-    for (;;) {
-        int const x = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (__builtin_amdgcn_readfirstlane(x) == v)
-            break;
-        __builtin_amdgcn_s_sleep(1);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
 /* LDS atomics without a return value (ds_add_u32 / ds_max_i32) */

@@ -297,8 +297,7 @@ int     lamehip_batch_get_state(lamehip_batch *, int stream, void *out, int size
 int     lamehip_get_state(const lame_t, void *out, int size);   /* same for a single-stream handle */
 /* elapsed GPU time of the last lamehip_batch_encode in ms (HIP events on the batch stream) */
 float   lamehip_batch_last_kernel_ms(lamehip_batch *);
-/* waves per stream of the kernel this batch encodes with: 2, or 4 when the batch was created with
- * LAMEHIP_KERNEL_WAVES=4 in the environment (CBR / ABR: sibling waves in the search, csrc/lh_dev_qloop.h) */
+/* waves per stream of the kernel this batch encodes with: 2 (one per channel) */
 int     lamehip_batch_kernel_waves(lamehip_batch *);
 int     lamehip_batch_reset(lamehip_batch *);   /* re-initialise all stream states for another run */
 

@@ -56,32 +56,6 @@ def test_kernel_source_matches_oracle(name, nframes, emu, oracle):
     enc.close()
 
 
-@pytest.mark.parametrize("name,nframes", [("cbr128_js_44k", 8), ("cbr320_js_48k_bursts", 8), ("cbr256_js_44k_q2", 3),
-                                          ("cbr96_js_32k", 6), ("cbr128_js_44k_q0", 2), ("cbr128_js_44k_white", 5),
-                                          ("abr128_js_44k", 6), ("abr150_js_32k_white_q5", 6),
-                                          ("mono_cbr160_48k_bursts_q5", 6), ("mono_abr100_44k", 5)])
-def test_sibling_wave_kernel_source_matches_oracle(name, nframes, emu, oracle):
-    """The four-wave kernel (-DLH_HELPERS: waves 2 and 3 form the noise of the candidate whose bits waves 0 and 1
-    count; flags in LDS between them, every workgroup barrier counted) under the emulator: the same payload.
-    Two launches, so that the sibling waves' start and exit are both crossed."""
-    g, pcm = helpers.load_golden(name)
-    enc = lamehip.Encoder(require_device=False, **helpers.golden_encoder_kwargs(g))
-    cfg, tab = enc.config(), enc.tables()
-    want = oracle.encode_frames(cfg, tab, pcm, max_frames=nframes)
-    n = pcm.shape[1]
-    pool = np.concatenate([pcm[0], pcm[1]]).astype(np.int16)
-    state = C.create_string_buffer(enc.lib.lamehip_abi_sizeof(4))
-    enc.lib.lh_state_init(state, C.byref(cfg))
-    got = (LhFrameOut * nframes)()
-    for f0, f1 in ((0, nframes // 2), (nframes // 2, nframes)):
-        desc = LhStreamDesc(0, n, 0, n, f0, f0, f1)
-        emu.lh_emu_encode4(C.byref(cfg), C.byref(tab), pool.ctypes.data_as(C.c_void_p), C.byref(desc), state, got, 1)
-    for f in range(nframes):
-        d = struct_diff(want[f], got[f])
-        assert not d, (f, d[:4])
-    enc.close()
-
-
 @pytest.mark.parametrize("name,nframes", [("testcase_wav_cbr128", 6), ("cbr320_js_48k_bursts", 6)])
 def test_kernel_source_frame_per_launch_with_poisoned_lds(name, nframes, emu, oracle):
     """One launch per frame, as lame_encode_buffer drives the device, with the LDS image

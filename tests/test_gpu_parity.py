@@ -706,59 +706,6 @@ def test_incremental_batch_matches_reference_call_by_call(reference, kw):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["cbr128_js_44k", "cbr320_js_48k_bursts", "cbr128_js_44k_q0", "cbr96_js_32k", "testcase_wav_cbr128",
-                                  "abr128_js_44k", "abr320_js_44k_q0", "mono_cbr96_44k", "mono_abr100_44k"])
-def test_sibling_wave_kernel_matches_golden(name, monkeypatch):
-    """LAMEHIP_KERNEL_WAVES=4: the kernel whose search runs with a sibling wave per channel (the noise of every
-    candidate formed beside its bit count, flags in LDS between the waves) gives the two-wave kernel's payload
-    and bytes, through both bit packers."""
-    monkeypatch.setenv("LAMEHIP_KERNEL_WAVES", "4")
-    g, pcm = helpers.load_golden(name)
-    enc = _encoder(g)
-    want = [str(x) for x in g["frame_sha256"]]
-    for dev_pack in (0, 1):
-        b = lamehip.Batch(enc, 3, pcm.shape[1] + 16)
-        if dev_pack:
-            b.set_device_packing()
-        for s in range(3):
-            b.set_pcm(s, pcm[0], pcm[1])
-        b.encode()
-        assert b.kernel_waves() == 4
-        for s in range(3):
-            assert (b.get_bytes(s) if dev_pack else b.pack(s)) == g["mp3"].tobytes()
-        frames = b.get_frames(1)
-        assert len(frames) == int(g["nframes"])
-        helpers.normalize_tables(frames)
-        bad = [i for i, fr in enumerate(frames) if helpers.frame_sha(fr) != want[i]]
-        assert not bad, "frames %s differ from the reference" % bad[:8]
-        b.close()
-    enc.close()
-
-
-@pytest.mark.gpu
-def test_sibling_wave_kernel_long_ragged_streams(oracle, monkeypatch):
-    """streams of different lengths (one empty), four seconds: every frame against the oracle"""
-    monkeypatch.setenv("LAMEHIP_KERNEL_WAVES", "4")
-    enc = lamehip.Encoder(44100, brate=128)
-    cfg, tab = enc.config(), enc.tables()
-    lens = [44100 * 4, 44100 * 3 + 777, 1000, 0, 44100 * 2]
-    pcms = [helpers.synth_stream(70 + i, n) if n else np.zeros((2, 0), np.int16) for i, n in enumerate(lens)]
-    b = lamehip.Batch(enc, len(lens), max(lens) + 16)
-    for s, x in enumerate(pcms):
-        b.set_pcm(s, x[0], x[1])
-    b.encode()
-    assert b.kernel_waves() == 4
-    for s, x in enumerate(pcms):
-        got = b.get_frames(s)
-        want = oracle.encode_frames(cfg, tab, x)
-        assert len(got) == len(want)
-        for f in range(len(got)):
-            assert not struct_diff(want[f], got[f]), (s, f)
-    b.close()
-    enc.close()
-
-
-@pytest.mark.gpu
 @pytest.mark.parametrize("kw", [dict(brate=128), dict(vbr_q=2), dict(abr=160, channels=1)])
 def test_pipelined_batches_pinned_upload_and_fetch(kw):
     """lamehip_batch_pcm_host_ptr / _mark_pcm / _upload / _fetch / _bytes_ptr: three batch objects in flight, reused
