@@ -273,6 +273,7 @@ struct LhQTabs {
     uint16_t sfb_s3, pad;       /* sfb_s[3] */
     uint8_t t32l[16], t33l[16];
     uint32_t t3233[16];         /* t32l << 16 | t33l */
+    uint32_t t3233p[16];        /* the same indexed by v | w << 1 | x << 2 | y << 3 (lq_count: quadruples from two packed pairs) */
     uint8_t pretab[24];
     uint32_t ctabA[32], ctabB[32];      /* lh_dev_qloop.h: per class of a region maximum, the grid origin of its
                                          * candidate tables / the tables and their linbits (lq_class_tabs) */

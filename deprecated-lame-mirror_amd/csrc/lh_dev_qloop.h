@@ -25,6 +25,7 @@
 
 #include "lh_dev_quant.h"
 
+
 struct LhQS {
     /* lane = pair slots */
     float   xp[10];             /* xrpow */
@@ -177,6 +178,8 @@ lq_load(const LhCtx & c, LhQS & S, LhChanLds & Q, const LhQR & R, const LhGrR & 
     S.m3 = lh_uni_f(c.T->pow20[213 + LH_QMAX2]);
     S.istepv = c.T->ipow20[210 + (c.lane & 15)];
     S.thrv = (LH_IXMAX) / S.istepv;
+    if (c.lane >= 32)
+        S.istepv = (1.0f - 0.4054f) / S.istepv;     /* lanes 32..47: the 0/1 comparator's threshold per mantissa */
     S.sbg8 = 0;                 /* so is subblock_gain */
     LH_WAVE_SYNC();
     {
@@ -208,11 +211,12 @@ lq_quantize(const LhCtx & c, LhQS & S, const LhQR & R, const LhGrR & g)
     const LhTables *T = c.T;
     const LhQTabs *qt = LH_QT;
     int const lane = c.lane;
-    float   istep;
+    float   istep, cmpv = 0.0f;
     {
         int const d = g.global_gain - 210, ga = d >> 4, gb_ = d & 15;
         float const thr = lq_ldexp(lh_u32_as_f32(lh_bcast_u32(lh_f32_as_u32(S.thrv), gb_)), 3 * ga);
         istep = lq_ldexp(lh_u32_as_f32(lh_bcast_u32(lh_f32_as_u32(S.istepv), gb_)), -3 * ga);
+        cmpv = lq_ldexp(lh_u32_as_f32(lh_bcast_u32(lh_f32_as_u32(S.istepv), 32 + gb_)), 3 * ga);
         if (LH_RARE(lh_ballot(S.lmax > thr)))
             return 0;
     }
@@ -273,7 +277,9 @@ lq_quantize(const LhCtx & c, LhQS & S, const LhQR & R, const LhGrR & g)
                 S.pw[k] = nq[k];
         }
         else {
-            float const compareval0 = (1.0f - 0.4054f) / istep;
+            /* (1 - 0.4054) / istep: istep is one of 16 mantissas times a power of two, and a correctly rounded quotient
+             * scales exactly -- the 16 quotients sit in lanes 32..47 of S.istepv */
+            float const compareval0 = cmpv;
 #pragma unroll
             for (int k = 0; k < NS; k++) {
                 int const p = lane + 64 * k;
@@ -317,19 +323,11 @@ lq_count(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
     LQ_MARK("cb_count");
     /* ---- count ---- */
     {
-        uint32_t *xbuf = (uint32_t *) Q.ix[1];
         int     top_nz, top_big, i, bv, nquad, bits;
         int     e0, e1, e2, a1, a2;
         unsigned sfbcnt_in = 0;
         if (USE_PREV)
             R.pn_sfb_count1 = 0;
-        /* the quadruples of the count1 region pair up neighbouring lanes: through LDS */
-#pragma unroll
-        for (int k = 0; k < NS; k++) {
-            int const p = lane + 64 * k;
-            if (k < 4 || p < 288)
-                xbuf[p] = S.pw[k];
-        }
         {
             /* highest non-zero pair + 1 and highest pair holding a value > 1 + 1: slots ascend, the
              * last hit of a lane is its highest; then the maximum over the lanes */
@@ -383,18 +381,26 @@ lq_count(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
         LH_WAVE_ORDER();
         uint32_t red[1];        /* the count1 region's lengths with both of its tables, t32 << 16 | t33 */
         uint32_t pre_l, pre_h, qtot;
-        uint32_t qlen[3];       /* t32 << 16 | t33 code lengths of this lane's (up to) three quadruples:
-                                 * looked up now, added up after the region maxima (the LDS round trips
-                                 * run under that arithmetic) */
+        /* The quadruples of the count1 region: lines bv + 4 q .. + 3 = the pairs pb + 2 q and pb + 2 q + 1 (pb = bv / 2),
+         * which lie in neighbouring lanes of the same slot (or in lane 63 and the next slot's lane 0).  The lane of a
+         * quadruple's first pair fetches the second with one wave shift -- no trip through LDS --, forms the index
+         * v | w << 1 | x << 2 | y << 3 from the two packed words (all four values are 0 or 1 there) and looks up both
+         * tables' lengths; lanes whose pair starts no quadruple of the region look up something and drop it. */
+        uint32_t qsum = 0;
         {
+            int const pb = bv >> 1;
+            uint32_t const first = (uint32_t) (lane - pb);      /* pair - pb of slot 0 */
+            /* (a pair at an odd distance from pb starts no quadruple: out of every range) */
+            uint32_t const firstq = (first & 1u) ? 0x7ffff000u : first;
+            uint32_t const n2 = (uint32_t) (2 * nquad);
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
-                int const qd = lane + 64 * k;
-                int const b2 = (bv >> 1) + 2 * qd;
-                int const b2c = b2 < 286 ? b2 : 286;
-                uint32_t const u0 = xbuf[b2c], u1 = xbuf[b2c + 1];
-                unsigned const idx = ((((u0 & 1u) * 2 + ((u0 >> 16) & 1u)) * 2 + (u1 & 1u)) * 2 + ((u1 >> 16) & 1u));
-                qlen[k] = qt->t3233[idx];
+            for (int k = 0; k < NS; k++) {
+                uint32_t const nxt = (k + 1 < NS) ? S.pw[k + 1 < NS ? k + 1 : k] : 0u;
+                uint32_t const u1 = lh_lane_above_u32(S.pw[k], nxt);
+                uint32_t const t = S.pw[k] | (u1 << 2);
+                uint32_t const j = (t | (t >> 15)) & 15u;
+                uint32_t const len = qt->t3233p[j];
+                qsum += ((firstq + 64u * (uint32_t) k) < n2) ? len : 0u;
             }
         }
         LQ_MARK("cb_max");
@@ -413,13 +419,7 @@ lq_count(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
             }
             lh_wave_max_n < 3 > (m);
         }
-        {
-            unsigned quads = 0;
-#pragma unroll
-            for (int k = 0; k < 3; k++)
-                quads += ((lane + 64 * k) < nquad) ? qlen[k] : 0u;
-            red[0] = quads;
-        }
+        red[0] = qsum;
         LQ_MARK("cb_lookup");
         /* lane r < 3 works out region r's candidate tables; the grid origins go back to all lanes */
         uint32_t PB, esc;
@@ -1056,15 +1056,28 @@ lq_outer_loop(const LhCtx & c, LhQS & S, LhChanLds & Q, LhQR & R, LhGrR & gb, co
             huff_bits = targ_bits - gw.part2_length;
             if (huff_bits <= 0)
                 break;
-            while ((gw.part2_3_length = lq_count_bits < 1, NS > (c, S, R, gw, Q)) > huff_bits
-                   && gw.global_gain <= maxggain)
+            int     pn_before;  /* pn_sfb_count1 as the last count found it */
+            for (;;) {
+                pn_before = R.pn_sfb_count1;
+                gw.part2_3_length = lq_count_bits < 1, NS > (c, S, R, gw, Q);
+                if (!(gw.part2_3_length > huff_bits && gw.global_gain <= maxggain))
+                    break;
                 gw.global_gain++;
+            }
             if (gw.global_gain > maxggain)
                 break;
             if (best_noise_info.over_count == 0) {
-                while ((gw.part2_3_length = lq_count_bits < 1, NS > (c, S, R, gw, Q)) > best_part2_3_length
-                       && gw.global_gain <= maxggain)
-                    gw.global_gain++;
+                /* The reference counts the same candidate once more here.  Everything that count reads is what the last
+                 * one read or left -- the image of the cached bands, the tables of empty regions, the fields of gw --
+                 * except pn_sfb_count1, which the last count rewrote and which picks the bands for the 0 / 1 comparator:
+                 * when it came out as it went in, the second count is the first one again, and it is not run. */
+                int const same = (R.pn_sfb_count1 == pn_before);
+                if (!same || (gw.part2_3_length > best_part2_3_length && gw.global_gain <= maxggain)) {
+                    gw.global_gain += same;     /* (the count that was not run said: too many bits) */
+                    while ((gw.part2_3_length = lq_count_bits < 1, NS > (c, S, R, gw, Q)) > best_part2_3_length
+                           && gw.global_gain <= maxggain)
+                        gw.global_gain++;
+                }
                 if (gw.global_gain > maxggain)
                     break;
             }

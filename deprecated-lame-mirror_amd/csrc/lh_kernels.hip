@@ -112,6 +112,10 @@ lh_load_qtabs(const LhCtx & c, LhQTabs & q)
         q.t32l[c.tid] = lh_t32l[c.tid];
         q.t33l[c.tid] = lh_t33l[c.tid];
         q.t3233[c.tid] = ((uint32_t) lh_t32l[c.tid] << 16) | lh_t33l[c.tid];
+        {
+            int const j = c.tid, idx = ((j & 1) << 3) | ((j & 2) << 1) | ((j & 4) >> 1) | ((j & 8) >> 3);
+            q.t3233p[j] = ((uint32_t) lh_t32l[idx] << 16) | lh_t33l[idx];
+        }
     }
     if (c.tid < 24) {
         q.sfb_l[c.tid] = (uint16_t) ((c.tid < 23) ? c.T->sfb_l[c.tid] : 576);
@@ -781,6 +785,7 @@ lh_selftest_kernel(unsigned *out, unsigned seed)
             }
             bad += (lh_wave_max8(w8) != want);
             bad += (lh_lane_minus_u32 < 2 > (x) != ((lane & 15u) >= 2 ? vals[lane - 2] : 0u));
+            bad += (lh_lane_above_u32(x, x ^ 0x5a5a5a5au) != (lane < 63 ? vals[lane + 1] : (vals[0] ^ 0x5a5a5a5au)));
         }
         bad += (lh_wave_min_u32(x) != rmin);
         bad += (lh_wave_or_u32(x) != ror);

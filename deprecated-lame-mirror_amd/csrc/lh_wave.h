@@ -223,6 +223,15 @@ lh_lane_below_u32(uint32_t v)
     return me > 0 ? (uint32_t) x[me - 1] : 0u;
 }
 
+/* value of the lane above; lane 63 gets lane 0's value of `next' (the wave's next slot of a striped array) */
+static inline uint32_t
+lh_lane_above_u32(uint32_t v, uint32_t next)
+{
+    const uint64_t *x = hipemu_wave_exchange(((uint64_t) next << 32) | v);
+    int const me = lh_lane();
+    return me < 63 ? (uint32_t) x[me + 1] : (uint32_t) (x[0] >> 32);
+}
+
 
 /* an integer sum and a float maximum (no NaNs) at once */
 static inline void
@@ -504,6 +513,18 @@ __device__ __forceinline__ uint32_t
 lh_lane_below_u32(uint32_t v)
 {
     return lh_dpp < 0x111, 0u > (v);    /* row_shr:1 */
+}
+
+/* value of the lane above, across the whole wave (wave_shl:1); lane 63 gets lane 0's value of `next' -- the
+ * wave's next slot of an array striped over the lanes (element lane + 64 k) */
+__device__ __forceinline__ uint32_t
+lh_lane_above_u32(uint32_t v, uint32_t next)
+{
+    int const up = __builtin_amdgcn_update_dpp(0, (int) v, 0x130, 0xf, 0xf, true);
+    int     n0 = __builtin_amdgcn_readlane((int) next, 0);
+    /* (pinned: left to itself the compiler moves the v_readlane into a branch taken by lane 63 alone) */
+    asm volatile("" : "+s"(n0));
+    return (lh_lane() == 63) ? (uint32_t) n0 : (uint32_t) up;
 }
 
 /* an integer sum and a float maximum (no NaNs) at once: the two chains' steps side by side */
