@@ -203,7 +203,7 @@ class FileRendezvous:
         self.n += 1
         name = os.path.join(self.path, "%s.%d" % (tag, self.n))
         with open("%s.%d.tmp" % (name, self.rank), "w") as f:
-            f.write(repr(float(value)))
+            f.write(repr([float(x) for x in value] if isinstance(value, (list, tuple)) else float(value)))
         os.rename("%s.%d.tmp" % (name, self.rank), "%s.%d" % (name, self.rank))
         vals = []
         t0 = time.time()
@@ -212,7 +212,7 @@ class FileRendezvous:
                 if time.time() - t0 > 1800:
                     raise RuntimeError("rank %d never reached %s" % (r, tag))
                 time.sleep(0.0005)
-            vals.append(float(open("%s.%d" % (name, r)).read()))
+            vals.append(eval(open("%s.%d" % (name, r)).read(), {"__builtins__": {}}))
         return vals
 
     def barrier(self):
@@ -220,6 +220,10 @@ class FileRendezvous:
 
     def max(self, value):
         return max(self._all("max", value))
+
+    def gather(self, values):
+        """every rank's list of floats, in rank order (all ranks get all of them)"""
+        return self._all("gather", list(values))
 
     def close(self):
         pass
@@ -244,6 +248,13 @@ class GlooRendezvous:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
+    def gather(self, values):
+        import torch
+        mine = torch.tensor(list(values), dtype=torch.float64)
+        out = [torch.zeros_like(mine) for _ in range(self.dist.get_world_size())]
+        self.dist.all_gather(out, mine)         # (gloo, on the CPU: a handful of timing scalars, never stream data)
+        return [[float(x) for x in t] for t in out]
+
     def close(self):
         self.dist.destroy_process_group()
 
@@ -254,6 +265,9 @@ class Alone:
 
     def max(self, value):
         return value
+
+    def gather(self, values):
+        return [list(values)]
 
     def close(self):
         pass
@@ -322,6 +336,15 @@ def check_against_oracle(batch, enc, host_streams, which):
     return {"streams": list(which), "frames_each": len(batch.get_frames(which[0])), "result": "identical"}
 
 
+def pmc_record_for(args):
+    """The committed PMC record of the workload this run benches (recorded with tools/r04_collect.sh)."""
+    if args.vbr is not None:
+        return "r04_pmc_vbrold2.json" if args.vbr_old else "r04_pmc_vbr2.json"
+    if args.brate == 320 and args.samplerate == 48000:
+        return "r04_pmc_cbr320.json"
+    return "r04_pmc.json"
+
+
 def roofline_block(frames, kavg_s, pmc_name):
     """HBM roofline of lh_encode_kernel: algorithmic bytes of the launch over the kernel's average time (HIP
     events on the batch's stream); traffic = the recorded PMC figure per frame x the frames of this launch, only
@@ -341,9 +364,16 @@ def roofline_block(frames, kavg_s, pmc_name):
                    % (pmc_name, pmc.get("csrc_sha256"), csrc_digest())) if pmc else "no recorded PMC profile in profiles/",
              "valu_frac": pmc.get("valu_frac") if fresh else None,
              "issue_active_frac": pmc.get("issue_active_frac") if fresh else None,
+             # the fraction that binds: instructions the SIMDs issued per cycle (all classes, from the same PMC record,
+             # at the clock the counters give) over what tools/ubench/lat2.hip measured a SIMD can issue for the two
+             # waves it hosts (0.43 per cycle)
+             "issue_frac": pmc.get("issue_frac") if fresh else None,
+             "insts_per_cycle_per_simd": pmc.get("insts_per_cycle_per_simd") if fresh else None,
+             "wave_insts_per_frame": pmc.get("wave_insts_per_frame") if fresh else None,
+             "shader_clock_ghz": pmc.get("shader_clock_ghz") if fresh else None,
              "bound_in_practice": "instruction issue of a serial search: one wave issues at most one instruction per "
-                                  "~5 cycles (tools/ubench/lat2.hip), two waves per stream; a SIMD does not issue "
-                                  "faster for four busy waves than 1.4 x what it does for two",
+                                  "~4.6 cycles (tools/ubench/lat2.hip) and a stream offers two chains (its channels), "
+                                  "one SIMD's worth; HBM is idle",
              "kernel": "lh_encode_kernel", "kernel_ms_avg": round(kavg_s * 1e3, 3),
              "alg_bytes_per_frame": ALG_BYTES_PER_FRAME, "frames_per_launch": frames}
     return block
@@ -394,6 +424,8 @@ def main():
                     help="vbr_mtrh at quality Q (BASELINE config[2] is -V2) instead of CBR; not the default line")
     ap.add_argument("--vbr-old", action="store_true", help="with --vbr Q: the old VBR loop, lame_set_VBR(vbr_rh), instead of vbr_mtrh")
     ap.add_argument("--abr", type=int, default=None, metavar="KBPS", help="ABR at a mean of KBPS instead of CBR")
+    ap.add_argument("--bursts", type=float, default=3.0, help="noise bursts per second in the synthetic signal (config[4]: 40)")
+    ap.add_argument("--mode", type=int, default=None, help="MPEG mode (1 = joint stereo); default: the library's")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the short runs of BASELINE configs [2] and [4]")
     ap.add_argument("--no-end-to-end", action="store_true",
@@ -429,9 +461,10 @@ def main():
     lo, hi = lamehip.shard_streams(world * B, world, rank)      # this rank's block of the global batch
     assert hi - lo == B
     vbr_mode = 2 if args.vbr_old else 4
-    enc = lamehip.Encoder(sr, args.brate, vbr_q=args.vbr, abr=args.abr, device=device_index, vbr_mode=vbr_mode)
+    enc_kw = {} if args.mode is None else {"mode": args.mode}
+    enc = lamehip.Encoder(sr, args.brate, vbr_q=args.vbr, abr=args.abr, device=device_index, vbr_mode=vbr_mode, **enc_kw)
     batch = lamehip.Batch(enc, B, n, device=device_index)
-    pcm = synth_on_device(torch, B, n, sr, lo, dev)             # seeds follow the global stream index
+    pcm = synth_on_device(torch, B, n, sr, lo, dev, bursts_per_s=args.bursts)   # seeds follow the global stream index
     torch.cuda.synchronize()
     for s in range(B):
         batch.set_pcm_device(s, pcm[s, 0].data_ptr(), pcm[s, 1].data_ptr(), n)
@@ -458,11 +491,16 @@ def main():
     kernel_ms = []
     barrier()
     t0 = time.perf_counter()
+    c0 = time.process_time()
     for _ in range(args.steps):
         batch.encode(sync=True)         # (an encoded batch starts over from the initial state by itself)
         kernel_ms.append(batch.kernel_ms())
+    own_dt = time.perf_counter() - t0
+    own_cpu = time.process_time() - c0
     barrier()
     dt = rdv.max(time.perf_counter() - t0)
+    # what each rank did, for the one line rank 0 prints (timing scalars only; no stream data ever crosses ranks)
+    per_rank = rdv.gather([rank, device_index, lo, hi, own_dt, own_cpu, sum(kernel_ms) / len(kernel_ms)])
 
     if rank == 0:
         checked = check_against_oracle(batch, enc, host_streams, which)
@@ -476,7 +514,7 @@ def main():
             "value": round(value, 1), "unit": "x real-time", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic: " + SIGNAL % 3.0,
+            "data": "synthetic: " + SIGNAL % args.bursts,
             "config": {"workload": ("batch=%d synthetic %.1f kHz stereo streams x %.0f s, CBR %d kb/s, "
                                     "per GPU (BASELINE config[1])" % (B, sr / 1000.0, args.seconds, args.brate))
                        if args.vbr is None and args.abr is None else
@@ -493,8 +531,15 @@ def main():
                        "ranks": "spawned by bench.py (file barrier)" if "LAMEHIP_BENCH_RDV" in os.environ
                        else ("launcher (gloo barrier on the CPU)" if world > 1 else "single process"),
                        "devices_visible": ndev},
-            "roofline": roofline_block(frames, kavg, "r03_pmc.json" if args.vbr is None else
-                                       "r03_pmc_vbrold2.json" if args.vbr_old else "r03_pmc_vbr2.json"),
+            "per_rank": [{"rank": int(r[0]), "device": int(r[1]), "streams": [int(r[2]), int(r[3])],
+                          "s_per_step": round(r[4] / args.steps, 6),
+                          "value": round((r[3] - r[2]) * args.seconds * args.steps / r[4], 1),
+                          "kernel_ms_avg": round(r[6], 3),
+                          # host CPU seconds this rank's process burned per wall second of its timed region: the
+                          # kernel path needs no host work, the rest is the runtime waiting for the stream
+                          "host_cpu_per_wall_s": round(r[5] / r[4], 3)} for r in per_rank],
+            "collectives_on_data_path": 0,
+            "roofline": roofline_block(frames, kavg, pmc_record_for(args)),
             "checked_against_oracle": checked,
         }
         if host_cpu is not None:
@@ -504,11 +549,11 @@ def main():
             batch = None
             res["extra"] = {
                 "vbr_v2_config2": short_run(torch, lamehip, dev, device_index, 44100, 1024, 5.0, 2, 5000, 3.0,
-                                            "r03_pmc_vbr2.json", vbr_q=2),
+                                            "r04_pmc_vbr2.json", vbr_q=2),
                 "vbr_old_v2": short_run(torch, lamehip, dev, device_index, 44100, 1024, 5.0, 2, 5000, 3.0,
-                                        "r03_pmc_vbrold2.json", vbr_q=2, vbr_mode=2),
+                                        "r04_pmc_vbrold2.json", vbr_q=2, vbr_mode=2),
                 "cbr320_48k_bursts_config4": short_run(torch, lamehip, dev, device_index, 48000, 1024, 5.0, 2, 9000,
-                                                       40.0, "r03_pmc_cbr320.json", brate=320, mode=1),
+                                                       40.0, "r04_pmc_cbr320.json", brate=320, mode=1),
             }
         if not args.no_end_to_end and not args.no_extras and world == 1:
             if batch is not None:

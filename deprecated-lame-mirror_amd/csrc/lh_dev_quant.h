@@ -933,13 +933,13 @@ lh_init_outer_loop_body(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, flo
 }
 
 LH_STAGEFN void
-lh_init_outer_loop(int qch, int gr, int block_type, int substep)
+lh_init_outer_loop(int qch, int gr, int block_type, int substep, int reorder = 1)
 {
     LhCtx const c = lh_ctx_load();
     LhQR    R;
     LhGrR   g;
     lh_init_outer_loop_body(c, lh_lds.u.quant.ch[qch], R, g, lh_lds.xr[qch][gr], lh_uni_i(block_type),
-                            lh_uni_i(substep));
+                            lh_uni_i(substep), lh_uni_i(reorder));
     lh_rg_put(c, R, g);
 }
 

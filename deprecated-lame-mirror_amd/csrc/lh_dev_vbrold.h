@@ -12,6 +12,9 @@
  */
 #ifndef LH_DEV_VBROLD_H
 #define LH_DEV_VBROLD_H
+#ifndef LH_VBROLD_FRAMEFN
+#define LH_VBROLD_FRAMEFN LH_DEVFN
+#endif
 
 /* one span of lines [lo, hi) above the last scalefactor band, made of the parts bound[0..n] (positions counted from
  * bound[0] at line lo) with one threshold each: from the top line downwards everything below its threshold becomes
@@ -81,7 +84,7 @@ lh_psfb21_silence(const LhCtx & c, const LhQR & R, float *xr)
  * pass 0: VBR_old_prepare's per-granule part (geometry, analog silence at the top of the spectrum, allowed noise),
  * then the search and the finishing steps; pass > 0: the search once more from what the last pass parked, with the
  * raised noise allowance (LhVbrOldSave.xmin, scaled by the frame function). */
-LH_STAGEFN void
+LH_DEVFN void
 lh_vbrold_granule(int qch, int gr, int rch, int pass, int min_bits, int max_bits, int substep, LhGranule * o,
                   const int8_t * g0sf)
 {
@@ -100,13 +103,18 @@ lh_vbrold_granule(int qch, int gr, int rch, int pass, int min_bits, int max_bits
     min_bits = lh_uni_i(min_bits);
     max_bits = lh_uni_i(max_bits);
 
-    lh_init_outer_loop_body(c, Q, R, g, xr, lh_uni_i(L.block_type[gr][qch]), lh_uni_i(substep), pass == 0);
+    /* The heavy steps are the out-of-line stages the CBR frame loop uses (R / g travel through the channel's LDS slot):
+     * inlined here they made this function spill and save ~35 callee-saved registers per call through scratch memory,
+     * which at four workgroups per CU falls out of the L2 -- 160 KB of HBM traffic per frame (profiles/r03_pmc_vbrold2.json). */
+    lh_init_outer_loop(qch, gr, lh_uni_i(L.block_type[gr][qch]), lh_uni_i(substep), pass == 0);
     if (pass == 0) {
-        int const slot = (lh_uni_i(L.psy_slot) + gr) % 3;
+        R = lh_uniform(L.rg[qch].R);
         lh_psfb21_silence(c, R, xr);
-        lh_calc_xmin_body(c, Q, R, xr, L.psy_en[slot][rch], L.psy_thm[slot][rch]);
+        lh_calc_xmin(qch, gr, rch);
         if (s <= LH_SFBMAX)
             sv.xmin[s] = Q.l3_xmin[s];
+        R = lh_uniform(L.rg[qch].R);
+        g = lh_uniform(L.rg[qch].g);
     }
     else {
         /* the granule as the last pass left it */
@@ -150,15 +158,15 @@ lh_vbrold_granule(int qch, int gr, int rch, int pass, int min_bits, int max_bits
     }
     LH_WAVE_SYNC();
     /* iteration_finish_one (reference quantize.c:1213-1232) */
-    lh_best_scalefac_store_body(c, Q, R, g, gr, LH_AS_GLOBAL(const int8_t, g0sf), lh_uni_i(L.block_type[0][qch]),
-                                L.scfsi[qch]);
+    lh_rg_put(c, R, g);
+    lh_best_scalefac_store(qch, gr, g0sf, lh_uni_i(L.block_type[0][qch]));
     if (c.cfg->use_best_huffman == 1)
-        lh_best_huffman_divide_body(c, Q, R, g);
+        lh_best_huffman_divide(qch);
+    R = lh_uniform(L.rg[qch].R);
+    g = lh_uniform(L.rg[qch].g);
     lh_store_granule(c, Q, R, g, xr, LH_AS_GLOBAL(LhGranule, o));
-    if (lh_uni_i(lh_lds.ctx.bytes != nullptr)) {
-        lh_rg_put(c, R, g);
-        lh_emit_part_stage(qch, gr);
-    }
+    if (lh_uni_i(lh_lds.ctx.bytes != nullptr))
+        lh_emit_part_stage(qch, gr);        /* R / g are in the wave's LDS slot since the last stage call */
     if (s == 0)
         sv.fin_bits = g.part2_3_length + g.part2_length;
     LH_WAVE_SYNC();
@@ -167,7 +175,7 @@ lh_vbrold_granule(int qch, int gr, int rch, int pass, int min_bits, int max_bits
 /* ---- the frame (all waves).  In: pe_use through L.pe_use, ms_ener_ratio through L.ms_ener_ratio; out through
  * L.frame_bits (bitrate index), L.max_bits (bits used), L.mean_bits (ResvSize after the frame's bits),
  * L.targ_bits[0] (substep), L.pe_use[0][0] (what sv_qnt.masking_lower holds after the frame). ---- */
-LH_STAGEFN void
+LH_VBROLD_FRAMEFN void
 lh_vbrold_frame(LhFrameOut * fo_in, int mode_ext, int msoff)
 {
     LhCtx const c = lh_ctx_load();

@@ -605,6 +605,38 @@ def test_bench_spawns_its_own_ranks():
 
 
 @pytest.mark.gpu
+def test_bench_eight_ranks_shard_a_batch_without_any_collective():
+    """BASELINE config[3]'s shape in small: python bench.py --gpus 8 --streams 32 (eight ranks, oversubscribing this
+    box's device when it has only one): ONE JSON line, n_gpus 8, the eight ranks' blocks are distinct, contiguous and
+    cover streams 0..255 of the global batch, every rank reports its own timing, nothing crosses ranks but timing
+    scalars (no collective on the data path), and the rank processes need (next to) no host CPU while their kernels
+    run -- eight of them fit the 16-CPU container the pool's boxes give."""
+    import json
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(helpers.ROOT, "bench.py"), "--gpus", "8", "--streams", "32",
+                          "--seconds", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-extras"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500,
+                         env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 8 and res["config"]["streams_per_gpu"] == 32 and res["scaling"] == "weak"
+    assert res["collectives_on_data_path"] == 0
+    ranks = sorted(res["per_rank"], key=lambda r: r["rank"])
+    assert [r["rank"] for r in ranks] == list(range(8))
+    assert [tuple(r["streams"]) for r in ranks] == [(32 * k, 32 * k + 32) for k in range(8)]
+    assert all(r["value"] > 0 and r["kernel_ms_avg"] > 0 for r in ranks)
+    # whole-job value = all ranks' audio over the slowest rank's time
+    slowest = max(r["s_per_step"] for r in ranks)
+    assert res["value"] <= 8 * 32 * 2.0 / slowest * 1.001
+    assert res["checked_against_oracle"]["result"] == "identical"
+    # the host side of a rank during the timed region: at most one CPU (the runtime waiting on its stream)
+    assert all(r["host_cpu_per_wall_s"] <= 1.05 for r in ranks), ranks
+
+
+@pytest.mark.gpu
 def test_bench_under_the_torch_launcher():
     """The command the driver uses for N > 1: python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2
     (one rank per GPU; on a 1-GPU box both ranks share the device).  Rank 0 prints ONE JSON line with the

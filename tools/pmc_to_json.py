@@ -11,6 +11,11 @@ import subprocess
 import sys
 
 
+def workload_streams(workload):
+    w = workload.split()
+    return w[w.index("--streams") + 1] if "--streams" in w else 1024
+
+
 def main(pmc, stats, workload):
     v = {}
     for line in open(pmc):
@@ -53,11 +58,34 @@ def main(pmc, stats, workload):
                 out["kernel_avg_ns"] = float(f[3])
             except (ValueError, IndexError):
                 pass
-    if "SQ_INSTS_VALU" in v and "kernel_avg_ns" in out:
-        cycles = out["kernel_avg_ns"] * 1e-9 * 2.4e9        # at the 2.4 GHz peak clock: a lower bound of the fraction
+    for name in ("SQ_INSTS_VMEM", "SQ_INSTS_FLAT", "SQ_INSTS_SMEM", "SQ_WAIT_INST_ANY"):
+        if name in v:
+            out[name] = per(name)
+    if "SQ_INSTS_VALU" in v and "kernel_avg_ns" in out and "SQ_WAVE_CYCLES" in v:
+        # The clock the kernel ran at, from the counters themselves: SQ_WAVE_CYCLES counts quad-cycles per resident
+        # wave, and every wave of this kernel is resident from the launch to its end (1024 workgroups x 2 waves on
+        # 1024 SIMDs, two per SIMD), so 4 x SQ_WAVE_CYCLES / waves = the kernel's length in shader cycles.
+        waves = 2 * int(workload_streams(workload))
+        cycles = 4.0 * per("SQ_WAVE_CYCLES") / waves
+        out["shader_cycles_per_launch"] = round(cycles)
+        out["shader_clock_ghz"] = round(cycles / out["kernel_avg_ns"], 3)
+        # a wave64 VALU instruction occupies its SIMD-32 for two cycles; 1024 SIMDs
         out["valu_frac"] = round(per("SQ_INSTS_VALU") * 2 / (1024 * cycles), 4)
+        insts = sum(per(n) for n in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_BRANCH") if n in v)
+        insts += per("SQ_INSTS_VMEM") if "SQ_INSTS_VMEM" in v else (per("SQ_INSTS_FLAT") or 0)
+        insts += per("SQ_INSTS_SMEM") or 0
+        out["wave_insts_per_launch"] = round(insts)
+        out["insts_per_cycle_per_simd"] = round(insts / (1024 * cycles), 4)
+        # the fraction that binds: what a SIMD issued against what tools/ubench/lat2.hip measured it can issue for two
+        # waves (2 / 4.63 cycles = 0.43 instructions per cycle; four waves: 0.61, eight: 0.76)
+        out["issue_ceiling_2waves"] = 0.43
+        out["issue_frac"] = round(out["insts_per_cycle_per_simd"] / 0.43, 4)
     if "hbm_bytes_per_launch" in out and out.get("frames_per_launch"):
         out["hbm_bytes_per_frame"] = round(out["hbm_bytes_per_launch"] / out["frames_per_launch"], 1)
+    if out.get("wave_insts_per_launch") and out.get("frames_per_launch"):
+        out["wave_insts_per_frame"] = round(out["wave_insts_per_launch"] / out["frames_per_launch"], 1)
+        out["shader_cycles_per_frame"] = round(out["shader_cycles_per_launch"] * int(workload_streams(workload))
+                                               / out["frames_per_launch"], 1)
     print(json.dumps(out, indent=1))
 
 

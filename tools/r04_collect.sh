@@ -1,0 +1,26 @@
+#!/bin/bash
+# Run on the GPU box (gpurun -- 'bash tools/r04_collect.sh'): every profile kept under profiles/r04_* from ONE build --
+# kernel-trace statistics and PMC passes of WHAT THE DRIVER BENCHES (1024 x 60 s CBR 128, one warm-up + one timed launch), of
+# BASELINE configs [2] (VBR -V2) and [4] (48 kHz CBR 320 joint stereo, 40 bursts/s) and of the old VBR loop at the extras' size,
+# the LH_PROF stage profile (make -C deprecated-lame-mirror_amd/csrc prof first), then the bench lines with the fresh records in place.
+set -u
+cd $GRAFT_REPO_ROOT
+X="--no-cpu-baseline --no-extras"
+bash tools/gpu_profile.sh r04 --streams 1024 --seconds 60 --steps 1 --warmup 1 $X > gpurun_out/log_r04.txt 2>&1
+bash tools/gpu_profile.sh r04_vbr2 --streams 1024 --seconds 5 --steps 2 --warmup 1 $X --vbr 2 > gpurun_out/log_r04_vbr2.txt 2>&1
+bash tools/gpu_profile.sh r04_vbrold2 --streams 1024 --seconds 5 --steps 2 --warmup 1 $X --vbr 2 --vbr-old > gpurun_out/log_r04_vbrold2.txt 2>&1
+bash tools/gpu_profile.sh r04_cbr320 --streams 1024 --seconds 5 --steps 2 --warmup 1 $X --samplerate 48000 --brate 320 --mode 1 --bursts 40 > gpurun_out/log_r04_cbr320.txt 2>&1
+for t in "" _vbr2 _vbrold2 _cbr320; do
+  cp gpurun_out/summ_r04${t}_pmc.json profiles/r04_pmc${t}.json
+  cp gpurun_out/summ_r04${t}_pmc.txt profiles/r04${t}_pmc.txt
+  cp gpurun_out/summ_r04${t}_kernel_stats.txt profiles/r04${t}_kernel_stats.txt
+done
+if [ -f deprecated-lame-mirror_amd/lamehip/liblamehip_prof.so ]; then
+  LAMEHIP_LIB=deprecated-lame-mirror_amd/lamehip/liblamehip_prof.so python tools/stage_profile.py 1024 4 > profiles/r04_stage_profile.txt 2>&1
+fi
+python bench.py 2>/dev/null | grep '^{"metric"' > profiles/r04_bench_default.json
+python bench.py --vbr 2 --no-extras 2>/dev/null | grep '^{"metric"' > profiles/r04_bench_vbr2.json
+python bench.py --vbr 2 --vbr-old --no-extras 2>/dev/null | grep '^{"metric"' > profiles/r04_bench_vbrold2.json
+mkdir -p gpurun_out/profiles_r04 && cp profiles/r04* gpurun_out/profiles_r04/
+cut -c1-600 profiles/r04_bench_default.json
+cat profiles/r04_pmc.json
