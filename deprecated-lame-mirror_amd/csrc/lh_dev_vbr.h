@@ -757,6 +757,8 @@ lh_vbr_granule(int qch, int gr, int rch, int pass, int gate, int target, int sub
         {
             int const slot = (lh_uni_i(L.psy_slot) + gr) % 3;
             lh_calc_xmin_body(c, Q, R, xr, L.psy_en[slot][rch], L.psy_thm[slot][rch]);
+            LH_WAVE_SYNC();
+            LH_DBG_XMIN(c, gr, qch, rch, Q, R.psymax);
         }
     }
     else {
@@ -844,6 +846,7 @@ lh_vbr_granule(int qch, int gr, int rch, int pass, int gate, int target, int sub
         sv.region1_count = g.region1_count;
     }
     lh_store_granule(c, Q, R, g, xr, LH_AS_GLOBAL(LhGranule, o));
+    LH_DBG_XR(c, gr, qch, xr);
     if (lh_uni_i(lh_lds.ctx.bytes != nullptr)) {
         lh_rg_put(c, R, g);
         lh_emit_part_stage(qch, gr);

@@ -57,6 +57,20 @@ typedef struct LhStreamState {
     uint32_t em_part[2][2][132];
     /* per-wave cycle accumulators, only filled by builds with -DLH_PROF (profiling aid) */
     unsigned long long prof[2][LH_NPROF];
+#ifdef LH_DEBUG_DUMP
+    /* TEST BUILD ONLY (make dump -> liblamehip_dump.so, tests/test_stage_fixtures.py): what the stages of the last
+     * frame handed on, [gr][ch] -- the spectra as the quantiser left them in place (after the mid/side rotation and the
+     * short-block reordering), the allowed noise calc_xmin formed and the band energies / thresholds it formed it from,
+     * the smoothed perceptual entropies and the bit budgets of the CBR loop */
+    float   dbg_xr[2][2][576];
+    float   dbg_xmin[2][2][LH_SFBMAX + 1];
+    float   dbg_en[2][2][LH_XMIN_N + 3];
+    float   dbg_thm[2][2][LH_XMIN_N + 3];
+    float   dbg_pe[2][2];
+    int     dbg_targ[2][2];
+    int     dbg_mean_bits;
+    int     dbg_pad[3];
+#endif
 } LhStreamState;
 
 /* one stream's work for one launch */

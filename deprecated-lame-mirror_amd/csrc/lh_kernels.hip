@@ -165,6 +165,33 @@ lh_store_granule(const LhCtx & c, const LhChanLds & Q, const LhQR & R, const LhG
     }
 }
 
+#ifdef LH_DEBUG_DUMP
+/* test build: see LhStreamState.dbg_* (lh_device.h) */
+LH_DEVFN void
+lh_dbg_xmin(const LhCtx & c, int gr, int ch, int rch, const LhChanLds & Q, int psymax)
+{
+    int const slot = (lh_uni_i(lh_lds.psy_slot) + gr) % 3;
+    if (c.lane <= LH_SFBMAX)
+        c.st->dbg_xmin[gr][ch][c.lane] = (c.lane < psymax) ? Q.l3_xmin[c.lane < LH_SFBMAX ? c.lane : 0] : 0.0f;
+    if (c.lane < LH_XMIN_N) {
+        c.st->dbg_en[gr][ch][c.lane] = lh_lds.psy_en[slot][rch][c.lane];
+        c.st->dbg_thm[gr][ch][c.lane] = lh_lds.psy_thm[slot][rch][c.lane];
+    }
+}
+
+LH_DEVFN void
+lh_dbg_xr(const LhCtx & c, int gr, int ch, const float *xr)
+{
+    for (int i = c.lane; i < 576; i += 64)
+        c.st->dbg_xr[gr][ch][i] = xr[i];
+}
+#define LH_DBG_XMIN(c, gr, ch, rch, Q, psymax) lh_dbg_xmin(c, gr, ch, rch, Q, psymax)
+#define LH_DBG_XR(c, gr, ch, xr) lh_dbg_xr(c, gr, ch, xr)
+#else
+#define LH_DBG_XMIN(c, gr, ch, rch, Q, psymax) do { } while (0)
+#define LH_DBG_XR(c, gr, ch, xr) do { } while (0)
+#endif
+
 #include "lh_dev_emit.h"
 #include "lh_dev_vbr.h"
 #ifdef LH_VBR_OLD
@@ -190,6 +217,7 @@ lh_prepare_granule(const LhCtx & c, int ch, int gr, int msoff, int substep)
         lh_rg_put(c, R, g);
         lh_calc_xmin(ch, gr, msoff + ch);
         R = lh_uniform(L.rg[ch].R);
+        LH_DBG_XMIN(c, gr, ch, msoff + ch, Q, R.psymax);
         lh_zero_tail(c, Q, R);
     }
     lh_rg_put(c, R, g);
@@ -373,8 +401,12 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
         LH_SYNC_WG();
         if (tid == 0)
             for (int gr = 0; gr < 2; gr++)
-                for (int ch = 0; ch < 2; ch++)
+                for (int ch = 0; ch < 2; ch++) {
                     L.pe_use[gr][ch] = pe_use[gr][ch];
+#ifdef LH_DEBUG_DUMP
+                    st->dbg_pe[gr][ch] = pe_use[gr][ch];
+#endif
+                }
         LH_SYNC_WG();
 #ifdef LH_VBR_OLD
         if (vbr_old) {
@@ -440,6 +472,15 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
             lh_reduce_side(targ_bits, ms_ener_ratio[gr], mean_bits, max_bits);
         targ_bits[0] = lh_uni_i(targ_bits[0]);
         targ_bits[1] = lh_uni_i(targ_bits[1]);
+#ifdef LH_DEBUG_DUMP
+        if (tid == 0) {
+            for (int ch = 0; ch < 2; ch++) {
+                st->dbg_pe[gr][ch] = pe_use[gr][ch];
+                st->dbg_targ[gr][ch] = targ_bits[ch];
+            }
+            st->dbg_mean_bits = mean_bits;
+        }
+#endif
         LH_SYNC_WG();
         if (w >= nch) {
             /* no second channel: its payload slot is all zero */
@@ -487,6 +528,7 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
             g = lh_uniform(L.rg[ch].g);
             LH_PA(6, t_fin);
             lh_store_granule(c, Q, R, g, xr, o);
+            LH_DBG_XR(c, gr, ch, xr);
             if (lh_uni_i(L.ctx.bytes != nullptr))
                 lh_emit_part_stage(ch, gr);     /* R / g are in the wave's LDS slot since the last stage call */
             LH_PA(3, t_q);

@@ -34,6 +34,122 @@ typedef struct RefH {
     lame_global_flags *gfp;
 } RefH;
 
+/* ---- per-stage observation (SURVEY 8(c) "G2") -------------------------------------------------------------
+ * calc_xmin, on_pe and reduce_side are defined in quantize_pvt.c and called from quantize.c: oracle/Makefile
+ * links this library with -Wl,--wrap=<each>, so the calls pass through the three functions below, which call
+ * the reference's own (__real_*) and, when a test asked for it (refh_stage_watch), keep what went in and came
+ * out for the frame being encoded.  Nothing of the reference is changed or replaced; with the watch off the
+ * wrappers only forward. */
+int     __real_calc_xmin(lame_internal_flags const *gfc, III_psy_ratio const *const ratio, gr_info * const cod_info,
+                         FLOAT * pxmin);
+int     __real_on_pe(lame_internal_flags * gfc, const FLOAT pe[][2], int targ_bits[2], int mean_bits, int gr, int cbr);
+void    __real_reduce_side(int targ_bits[2], FLOAT ms_ener_ratio, int mean_bits, int max_bits);
+
+#define REFH_NBAND (SBMAX_l + 3 * SBMAX_s)      /* 22 + 39 */
+static struct {
+    int     on;
+    float   xmin[2][2][SFBMAX];
+    float   en[2][2][REFH_NBAND], thm[2][2][REFH_NBAND];       /* the ratios calc_xmin was given: l[22], then s[13][3] */
+    float   pe[2][2];
+    int     targ[2][2], mean_bits, last_gr;
+    int     n_xmin, n_on_pe;
+} refh_stage;
+
+void
+refh_stage_watch(int on)
+{
+    memset(&refh_stage, 0, sizeof(refh_stage));
+    refh_stage.on = on;
+}
+
+int
+__wrap_calc_xmin(lame_internal_flags const *gfc, III_psy_ratio const *const ratio, gr_info * const cod_info, FLOAT * pxmin)
+{
+    int const r = __real_calc_xmin(gfc, ratio, cod_info, pxmin);
+    if (refh_stage.on) {
+        long const k = (long) (cod_info - &gfc->l3_side.tt[0][0]);      /* gr * 2 + ch */
+        if (k >= 0 && k < 4) {
+            int const gr = (int) (k >> 1), ch = (int) (k & 1);
+            int     i, b;
+            /* (calc_xmin writes psymax entries; the caller's array is not initialised beyond them) */
+            for (i = 0; i < SFBMAX; i++)
+                refh_stage.xmin[gr][ch][i] = (i < cod_info->psymax) ? pxmin[i] : 0.0f;
+            for (i = 0; i < SBMAX_l; i++) {
+                refh_stage.en[gr][ch][i] = ratio->en.l[i];
+                refh_stage.thm[gr][ch][i] = ratio->thm.l[i];
+            }
+            for (i = 0; i < SBMAX_s; i++)
+                for (b = 0; b < 3; b++) {
+                    refh_stage.en[gr][ch][SBMAX_l + 3 * i + b] = ratio->en.s[i][b];
+                    refh_stage.thm[gr][ch][SBMAX_l + 3 * i + b] = ratio->thm.s[i][b];
+                }
+            refh_stage.n_xmin++;
+        }
+    }
+    return r;
+}
+
+int
+__wrap_on_pe(lame_internal_flags * gfc, const FLOAT pe[][2], int targ_bits[2], int mean_bits, int gr, int cbr)
+{
+    int const r = __real_on_pe(gfc, pe, targ_bits, mean_bits, gr, cbr);
+    if (refh_stage.on && gr >= 0 && gr < 2) {
+        refh_stage.pe[gr][0] = pe[gr][0];
+        refh_stage.pe[gr][1] = pe[gr][1];
+        refh_stage.targ[gr][0] = targ_bits[0];
+        refh_stage.targ[gr][1] = targ_bits[1];
+        refh_stage.mean_bits = mean_bits;
+        refh_stage.last_gr = gr;
+        refh_stage.n_on_pe++;
+    }
+    return r;
+}
+
+void
+__wrap_reduce_side(int targ_bits[2], FLOAT ms_ener_ratio, int mean_bits, int max_bits)
+{
+    __real_reduce_side(targ_bits, ms_ener_ratio, mean_bits, max_bits);
+    if (refh_stage.on) {
+        /* (the granule of the on_pe call just before: quantize.c:1410-1412, 1612-1614, 2008-2012) */
+        refh_stage.targ[refh_stage.last_gr][0] = targ_bits[0];
+        refh_stage.targ[refh_stage.last_gr][1] = targ_bits[1];
+    }
+}
+
+/* what the wrappers saw since the last call of this function, flat: xmin[2][2][39], en[2][2][61], thm[2][2][61],
+ * pe[2][2], then as floats targ[2][2], mean_bits, calls of calc_xmin, calls of on_pe; the counters start over */
+int
+refh_stage_get(float *out, int cap)
+{
+    int     n = 0, gr, ch, i;
+    int const need = 4 * (SFBMAX + 2 * REFH_NBAND) + 4 + 4 + 3;
+    if (cap < need)
+        return -need;
+    for (gr = 0; gr < 2; gr++)
+        for (ch = 0; ch < 2; ch++)
+            for (i = 0; i < SFBMAX; i++)
+                out[n++] = refh_stage.xmin[gr][ch][i];
+    for (gr = 0; gr < 2; gr++)
+        for (ch = 0; ch < 2; ch++)
+            for (i = 0; i < REFH_NBAND; i++)
+                out[n++] = refh_stage.en[gr][ch][i];
+    for (gr = 0; gr < 2; gr++)
+        for (ch = 0; ch < 2; ch++)
+            for (i = 0; i < REFH_NBAND; i++)
+                out[n++] = refh_stage.thm[gr][ch][i];
+    for (gr = 0; gr < 2; gr++)
+        for (ch = 0; ch < 2; ch++)
+            out[n++] = refh_stage.pe[gr][ch];
+    for (gr = 0; gr < 2; gr++)
+        for (ch = 0; ch < 2; ch++)
+            out[n++] = (float) refh_stage.targ[gr][ch];
+    out[n++] = (float) refh_stage.mean_bits;
+    out[n++] = (float) refh_stage.n_xmin;
+    out[n++] = (float) refh_stage.n_on_pe;
+    refh_stage.n_xmin = refh_stage.n_on_pe = 0;
+    return n;
+}
+
 /* number of input channels of the handles opened next (1 = mono: the reference then encodes MONO
  * and reads only the left buffer) */
 static int refh_channels = 2;
