@@ -180,7 +180,7 @@ queue_header(LhBitstream * bs, const LhConfig * c, const LhFrameOut * fo, int ba
     w.used = 0;
     /* header: syncword, ID, layer III, protection, bitrate, sampling frequency, padding, private,
      * mode, mode extension, copyright, original, emphasis */
-    hdr(&w, 0xfffu, 12);
+    hdr(&w, (c->samplerate < 16000) ? 0xffeu : 0xfffu, 12);     /* MPEG-2.5: the shortened syncword */
     hdr(&w, (unsigned) c->version, 1);
     hdr(&w, 1u, 2);
     hdr(&w, c->error_protection ? 0u : 1u, 1);
@@ -195,20 +195,28 @@ queue_header(LhBitstream * bs, const LhConfig * c, const LhFrameOut * fo, int ba
     hdr(&w, (unsigned) c->emphasis, 2);
     if (c->error_protection)
         w.used += 16;           /* room for the CRC word */
-    /* side information: main_data_begin, private bits, scfsi, then the granules */
-    hdr(&w, (unsigned) back_pointer, 9);
-    w.used += (nch == 2) ? 3 : 5;
-    for (ch = 0; ch < nch; ch++)
-        for (k = 0; k < 4; k++)
-            hdr(&w, (unsigned) fo->scfsi[ch][k], 1);
-    for (gr = 0; gr < 2; gr++)
+    /* side information: main_data_begin, private bits, (MPEG-1) scfsi, then the granules.  MPEG-2 / 2.5 (reference
+     * bitstream.c:420-467): an 8-bit back pointer, one private bit per channel, one granule, a 9-bit scalefac_compress
+     * and no preflag bit (it is folded into scalefac_compress >= 500) */
+    if (c->version == 1) {
+        hdr(&w, (unsigned) back_pointer, 9);
+        w.used += (nch == 2) ? 3 : 5;
+        for (ch = 0; ch < nch; ch++)
+            for (k = 0; k < 4; k++)
+                hdr(&w, (unsigned) fo->scfsi[ch][k], 1);
+    }
+    else {
+        hdr(&w, (unsigned) back_pointer, 8);
+        w.used += nch;
+    }
+    for (gr = 0; gr < c->mode_gr; gr++)
         for (ch = 0; ch < nch; ch++) {
             const LhGranule *g = &fo->gr[gr][ch];
             int const switched = (g->block_type != LH_NORM_TYPE);
             hdr(&w, (unsigned) (g->part2_3_length + g->part2_length), 12);
             hdr(&w, (unsigned) (g->big_values / 2), 9);
             hdr(&w, (unsigned) g->global_gain, 8);
-            hdr(&w, (unsigned) g->scalefac_compress, 4);
+            hdr(&w, (unsigned) g->scalefac_compress, (c->version == 1) ? 4 : 9);
             hdr(&w, (unsigned) switched, 1);
             if (switched) {
                 hdr(&w, (unsigned) g->block_type, 2);
@@ -224,7 +232,8 @@ queue_header(LhBitstream * bs, const LhConfig * c, const LhFrameOut * fo, int ba
                 hdr(&w, (unsigned) g->region0_count, 4);
                 hdr(&w, (unsigned) g->region1_count, 3);
             }
-            hdr(&w, (unsigned) g->preflag, 1);
+            if (c->version == 1)
+                hdr(&w, (unsigned) g->preflag, 1);
             hdr(&w, (unsigned) g->scalefac_scale, 1);
             hdr(&w, (unsigned) g->count1table_select, 1);
         }
@@ -274,6 +283,47 @@ put_scalefactors(LhBitstream * bs, const LhGranule * g)
             continue;
         sink(bs, (unsigned) g->scalefac[band], width);
         written += width;
+    }
+    return written;
+}
+
+/* MPEG-2 / 2.5: the scalefactors go in four partitions, each with its own width; widths and partition sizes follow from
+ * scalefac_compress the way a decoder reads them (ISO 13818-3 2.4.3.2; what the reference keeps in gr_info.slen[] and
+ * sfb_partition_table, takehiro.c:1266-1296, and writes in bitstream.c:735-770).  Bands shared through scfsi do not
+ * exist here; a negative entry is written as 0. */
+static int
+put_scalefactors_lsf(LhBitstream * bs, const LhGranule * g)
+{
+    int const sc = g->scalefac_compress;
+    int const is_short = (g->block_type == LH_SHORT_TYPE);
+    int     slen[4], table, part, band = 0, written = 0, i;
+    if (sc < 400) {
+        table = 0;
+        slen[0] = (sc >> 4) / 5;
+        slen[1] = (sc >> 4) % 5;
+        slen[2] = (sc >> 2) & 3;
+        slen[3] = sc & 3;
+    }
+    else if (sc < 500) {
+        table = 1;
+        slen[0] = ((sc - 400) >> 2) / 5;
+        slen[1] = ((sc - 400) >> 2) % 5;
+        slen[2] = (sc - 400) & 3;
+        slen[3] = 0;
+    }
+    else {
+        table = 2;
+        slen[0] = (sc - 500) / 3;
+        slen[1] = (sc - 500) % 3;
+        slen[2] = slen[3] = 0;
+    }
+    for (part = 0; part < 4; part++) {
+        int const n = lh_nr_of_sfb_block[(table * 3 + is_short) * 4 + part];
+        for (i = 0; i < n && band < LH_SFBMAX; i++, band++) {
+            int const v = g->scalefac[band] < 0 ? 0 : g->scalefac[band];
+            sink(bs, (unsigned) v, slen[part]);
+            written += slen[part];
+        }
     }
     return written;
 }
@@ -368,11 +418,11 @@ static int
 put_main_data(LhBitstream * bs, const LhConfig * c, const LhTables * t, const LhFrameOut * fo)
 {
     int     gr, ch, total = 0;
-    for (gr = 0; gr < 2; gr++)
+    for (gr = 0; gr < c->mode_gr; gr++)
         for (ch = 0; ch < c->channels; ch++) {
             const LhGranule *g = &fo->gr[gr][ch];
             int     end[3], bits, k, from = 0;
-            bits = put_scalefactors(bs, g);
+            bits = (c->version == 1) ? put_scalefactors(bs, g) : put_scalefactors_lsf(bs, g);
             region_ends(g, t, end);
             for (k = 0; k < 3; k++) {
                 /* switched blocks signal two books; their third region is empty by construction */
@@ -398,7 +448,7 @@ payload_plausible(const LhConfig * c, const LhFrameOut * fo)
     int     gr, ch, k;
     if (fo->frame_bits <= 0 || fo->frame_bits > 8 * 2880 || fo->resvDrain_pre < 0 || fo->resvDrain_post < 0)
         return 0;
-    for (gr = 0; gr < 2; gr++)
+    for (gr = 0; gr < c->mode_gr; gr++)
         for (ch = 0; ch < c->channels; ch++) {
             const LhGranule *g = &fo->gr[gr][ch];
             if (g->big_values < 0 || g->big_values > 576 || (g->big_values & 1))
@@ -409,7 +459,7 @@ payload_plausible(const LhConfig * c, const LhFrameOut * fo)
                 return 0;
             if ((unsigned) g->count1table_select > 1u || (unsigned) g->block_type > 3u || (unsigned) g->global_gain > 255u)
                 return 0;
-            if ((unsigned) g->scalefac_compress > 15u || g->sfbmax < 0 || g->sfbmax > LH_SFBMAX || g->sfbdivide < 0)
+            if ((unsigned) g->scalefac_compress > ((c->version == 1) ? 15u : 511u) || g->sfbmax < 0 || g->sfbmax > LH_SFBMAX || g->sfbdivide < 0)
                 return 0;
             for (k = 0; k < 3; k++)
                 if ((unsigned) g->table_select[k] > 31u || g->table_select[k] == 4)
@@ -482,44 +532,59 @@ lh_bs_copy(LhBitstream * bs, unsigned char *out, int size)
     return n;
 }
 
-/* reference lame.c:1671-1775 + 2041-2120: frames produced for n samples followed by a flush */
+/* reference lame.c:1671-1775 + 2041-2120: frames produced for n samples followed by a flush; fs = samples per frame
+ * (1152, or 576 for MPEG-2 / 2.5): each fill of <= fs samples is followed by one frame whenever BLKSIZE + fs - FFTOFFSET
+ * samples are buffered */
 int
-lh_total_frames(long n)
+lh_total_frames_fs(long n, int fs)
 {
     long    mf_size = LH_MF_START, to_encode = LH_ENCDELAY + LH_POSTDELAY;
     long    frames = 0;
     int     end_padding, frames_left;
+    int const needed = LH_BLKSIZE + fs - LH_FFTOFFSET;
     to_encode += n;
     if (n > 0) {
-        /* each fill of <=1152 samples is followed by one frame whenever 1904 are buffered */
         long    total = mf_size + n;
-        if (total >= LH_MF_NEEDED)
-            frames = (total - LH_MF_NEEDED) / 1152 + 1;
-        to_encode -= 1152 * frames;
+        if (total >= needed)
+            frames = (total - needed) / fs + 1;
+        to_encode -= fs * frames;
     }
     to_encode -= LH_POSTDELAY;
-    end_padding = 1152 - (int) (to_encode % 1152);
+    end_padding = fs - (int) (to_encode % fs);
     if (end_padding < 576)
-        end_padding += 1152;
-    frames_left = (int) ((to_encode + end_padding) / 1152);
+        end_padding += fs;
+    frames_left = (int) ((to_encode + end_padding) / fs);
     return (int) (frames + frames_left);
+}
+
+int
+lh_total_frames(long n)
+{
+    return lh_total_frames_fs(n, 1152);
 }
 
 /* end padding that lame_encode_flush adds after n input samples (reference lame.c:2077-2091);
  * the same arithmetic as in lh_total_frames */
 int
-lh_end_padding(long n)
+lh_end_padding_fs(long n, int fs)
 {
     long    to_encode = LH_ENCDELAY + LH_POSTDELAY + n;
     int     end_padding;
+    int const needed = LH_BLKSIZE + fs - LH_FFTOFFSET;
     if (n > 0) {
         long const total = LH_MF_START + n;
-        if (total >= LH_MF_NEEDED)
-            to_encode -= 1152 * ((total - LH_MF_NEEDED) / 1152 + 1);
+        if (total >= needed)
+            to_encode -= fs * ((total - needed) / fs + 1);
     }
     to_encode -= LH_POSTDELAY;
-    end_padding = 1152 - (int) (to_encode % 1152);
+    end_padding = fs - (int) (to_encode % fs);
     if (end_padding < 576)
-        end_padding += 1152;
+        end_padding += fs;
     return end_padding;
+}
+
+int
+lh_end_padding(long n)
+{
+    return lh_end_padding_fs(n, 1152);
 }

@@ -73,6 +73,8 @@ int     lh_tables_build(LhConfig * c, const LhInitAux * aux, LhTables * t);
 /* number of MP3 frames the reference produces for n input samples per channel
  * when followed by lame_encode_flush (reference lame.c:1671-1775, 2041-2120) */
 int     lh_total_frames(long nsamples);
+int     lh_total_frames_fs(long nsamples, int samples_per_frame);       /* 576 for MPEG-2 / 2.5 */
+const int16_t *lh_bitrate_row(int version);     /* the frame sizes' kb/s of an MPEG version (lh_host_init.c) */
 
 /* ------------------------------------------------------------------ */
 /* serial bit packer (reference bitstream.c), host only                */
@@ -141,6 +143,7 @@ int     lh_tag_placeholder(const LhVbrTag * v, const LhConfig * c, unsigned char
 int     lh_tag_frame(const LhVbrTag * v, const LhConfig * c, int vbr_q, int enc_padding, int last_mode_ext,
                      unsigned char *buf, long size);
 int     lh_end_padding(long nsamples);
+int     lh_end_padding_fs(long nsamples, int samples_per_frame);
 
 /* ---- sample rate conversion in front of the encoder (lh_resample.c; reference util.c:483-697) ---- */
 #define LH_RS_MAXPHASES 320     /* BPC, reference util.h */

@@ -55,20 +55,51 @@ nearest_full_index(int bitrate)
     return upper;
 }
 
-static int
-find_nearest_bitrate_mpeg1(int b)
+/* the bitrate row of a stream: MPEG-1, MPEG-2, or -- only where a bitrate is LOOKED FOR -- the shorter MPEG-2.5 row
+ * (reference util.c:376-440 FindNearestBitrate / BitrateIndex switch to it below 16 kHz; frame sizes always come from
+ * the version's row, bitstream.c:60-88) */
+const int16_t *
+lh_bitrate_row(int version)
 {
-    int     i, best = lh_bitrate_mpeg1[1];
-    for (i = 1; i <= 14; i++) {
-        int     d0 = lh_bitrate_mpeg1[i] - b, d1 = best - b;
-        if (d0 < 0)
-            d0 = -d0;
-        if (d1 < 0)
-            d1 = -d1;
-        if (d0 < d1)
-            best = lh_bitrate_mpeg1[i];
+    return version ? lh_bitrate_mpeg1 : lh_bitrate_mpeg2;
+}
+
+static const int16_t *
+bitrate_search_row(int version, int samplerate)
+{
+    return (samplerate < 16000) ? lh_bitrate_mpeg25 : lh_bitrate_row(version);
+}
+
+/* reference util.c:376-400 */
+static int
+find_nearest_bitrate(int b, int version, int samplerate)
+{
+    const int16_t *row = bitrate_search_row(version, samplerate);
+    int     i, best = row[1];
+    for (i = 2; i <= 14; i++) {
+        if (row[i] > 0) {
+            int     d0 = row[i] - b, d1 = best - b;
+            if (d0 < 0)
+                d0 = -d0;
+            if (d1 < 0)
+                d1 = -d1;
+            if (d0 < d1)
+                best = row[i];
+        }
     }
     return best;
+}
+
+/* reference util.c:421-440: -1 when the row does not hold the rate */
+static int
+bitrate_index_of(int b, int version, int samplerate)
+{
+    const int16_t *row = bitrate_search_row(version, samplerate);
+    int     i;
+    for (i = 0; i <= 14; i++)
+        if (row[i] > 0 && row[i] == b)
+            return i;
+    return -1;
 }
 
 /* ABR/CBR tuning table (reference presets.c:232-250); columns used by this path */
@@ -301,26 +332,30 @@ suggested_samplerate(int lp, int samplerate_in)
     return suggested;
 }
 
-/* the stream's rate: MPEG-1 only on this path (MPEG-2 / 2.5 frames have one granule) */
+/* the stream's rate: version, index into the header's rate field and granules per frame (reference util.c:443-487
+ * SmpFrqIndex, lame.c:797); sideinfo_len follows it (lame.c:949-952) */
 static int
 set_output_rate(LhConfig * c, int rate)
 {
     switch (rate) {
-    case 44100:
-        c->samplerate_index = 0;
-        break;
-    case 48000:
-        c->samplerate_index = 1;
-        break;
-    case 32000:
-        c->samplerate_index = 2;
-        break;
+    case 44100: c->version = 1; c->samplerate_index = 0; break;
+    case 48000: c->version = 1; c->samplerate_index = 1; break;
+    case 32000: c->version = 1; c->samplerate_index = 2; break;
+    case 22050: c->version = 0; c->samplerate_index = 0; break;
+    case 24000: c->version = 0; c->samplerate_index = 1; break;
+    case 16000: c->version = 0; c->samplerate_index = 2; break;
+    case 11025: c->version = 0; c->samplerate_index = 0; break;
+    case 12000: c->version = 0; c->samplerate_index = 1; break;
+    case 8000:  c->version = 0; c->samplerate_index = 2; break;
     default:
         return -1;
     }
-    c->version = 1;
     c->samplerate = rate;
-    c->mode_gr = 2;
+    c->mode_gr = (rate <= 24000) ? 1 : 2;
+    if (c->mode_gr == 2)
+        c->sideinfo_len = (c->channels == 1) ? 4 + 17 : 4 + 32;
+    else
+        c->sideinfo_len = (c->channels == 1) ? 4 + 9 : 4 + 17;
     return 0;
 }
 
@@ -359,17 +394,19 @@ vbr_bitrate_limits(const LhUserParams * p, LhConfig * c)
     int     r;
     c->vbr_min_bitrate_index = 1;
     c->vbr_max_bitrate_index = 14;
+    if (c->samplerate < 16000)
+        c->vbr_max_bitrate_index = 8;   /* 64 kb/s: MPEG-2.5 (reference lame.c:1068-1069) */
     if (p->vbr_min_kbps) {
-        int const k = find_nearest_bitrate_mpeg1(p->vbr_min_kbps);
-        for (r = 1; r <= 14; r++)
-            if (lh_bitrate_mpeg1[r] == k)
-                c->vbr_min_bitrate_index = r;
+        r = bitrate_index_of(find_nearest_bitrate(p->vbr_min_kbps, c->version, c->samplerate), c->version, c->samplerate);
+        if (r < 0)
+            return -1;
+        c->vbr_min_bitrate_index = r;
     }
     if (p->vbr_max_kbps) {
-        int const k = find_nearest_bitrate_mpeg1(p->vbr_max_kbps);
-        for (r = 1; r <= 14; r++)
-            if (lh_bitrate_mpeg1[r] == k)
-                c->vbr_max_bitrate_index = r;
+        r = bitrate_index_of(find_nearest_bitrate(p->vbr_max_kbps, c->version, c->samplerate), c->version, c->samplerate);
+        if (r < 0)
+            return -1;
+        c->vbr_max_bitrate_index = r;
     }
     c->enforce_min_bitrate = p->vbr_hard_min;
     /* -b above -B: the reference takes it and, in ABR, then ends every frame with a mean of 0 bits (the loop that picks the
@@ -511,7 +548,7 @@ config_resolve_vbr(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
         samplerate_out = suggested_samplerate(lowpassfreq, p->samplerate);
     }
     if (set_output_rate(c, samplerate_out) != 0)
-        return -1;              /* MPEG-2 / 2.5 output rates are outside this path */
+        return -1;
     {
         int const top = old ? 20500 : 24000;
         lowpassfreq = (top < lowpassfreq) ? top : lowpassfreq;
@@ -522,7 +559,6 @@ config_resolve_vbr(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
 
     c->bitrate_index = 1;
     c->avg_bitrate = 0;         /* gfp->brate stays 0 in VBR mode */
-    c->sideinfo_len = (c->channels == 1) ? 4 + 17 : 4 + 32;
     c->buffer_constraint = 7680 * (c->version + 1);     /* strict_ISO = MDB_MAXIMUM */
     c->use_temporal_masking = old ? 1 : 0;
 
@@ -607,10 +643,10 @@ config_resolve_vbr(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
         c->compression_ratio = cmp[vbr_q];
     }
     c->vbr_avg_bitrate_kbps = 128;      /* VBR_mean_bitrate_kbps default, kept inside the limits (lame.c:1086-1091) */
-    if (c->vbr_avg_bitrate_kbps > lh_bitrate_mpeg1[c->vbr_max_bitrate_index])
-        c->vbr_avg_bitrate_kbps = lh_bitrate_mpeg1[c->vbr_max_bitrate_index];
-    if (c->vbr_avg_bitrate_kbps < lh_bitrate_mpeg1[c->vbr_min_bitrate_index])
-        c->vbr_avg_bitrate_kbps = lh_bitrate_mpeg1[c->vbr_min_bitrate_index];
+    if (c->vbr_avg_bitrate_kbps > lh_bitrate_row(c->version)[c->vbr_max_bitrate_index])
+        c->vbr_avg_bitrate_kbps = lh_bitrate_row(c->version)[c->vbr_max_bitrate_index];
+    if (c->vbr_avg_bitrate_kbps < lh_bitrate_row(c->version)[c->vbr_min_bitrate_index])
+        c->vbr_avg_bitrate_kbps = lh_bitrate_row(c->version)[c->vbr_min_bitrate_index];
     return 0;
 }
 
@@ -711,75 +747,64 @@ config_resolve_inner(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
     if (c->vbr == 1 || c->vbr == 2 || c->vbr == 4)
         return config_resolve_vbr(p, c, aux);
 
-    if (c->vbr == 3) {
-        /* ABR: any mean bitrate; apply_abr_preset clamps it to 8..320 and leaves it in brate
-         * (reference presets.c:268-272), lame_init_params to the MPEG-1 table range (lame.c:1088-1093) */
-        int     mean = p->abr_kbps;
-        if (p->samplerate_out == 0 && (mean < 8 || mean > 320))
-            return -1;          /* the reference applies no preset at all there (presets.c:411-416) */
-        if (p->samplerate_out)
-            mean = mean < 32 ? 32 : (mean > 320 ? 320 : mean);  /* reference lame.c:654-657 */
-        mean = mean > 320 ? 320 : mean;
-        mean = mean < 8 ? 8 : mean;
-        c->avg_bitrate = mean;
-        c->bitrate_index = 1;
-        c->vbr_avg_bitrate_kbps = mean < 32 ? 32 : mean;
-        ratio_kbps = c->vbr_avg_bitrate_kbps;
-        if (vbr_bitrate_limits(p, c) != 0)
-            return -1;
-        /* the mean stays inside the limits (reference lame.c:1086-1091; after compression_ratio was formed) */
-        if (c->vbr_avg_bitrate_kbps > lh_bitrate_mpeg1[c->vbr_max_bitrate_index])
-            c->vbr_avg_bitrate_kbps = lh_bitrate_mpeg1[c->vbr_max_bitrate_index];
-        if (c->vbr_avg_bitrate_kbps < lh_bitrate_mpeg1[c->vbr_min_bitrate_index])
-            c->vbr_avg_bitrate_kbps = lh_bitrate_mpeg1[c->vbr_min_bitrate_index];
-    }
-    else {
-        /* bitrate (reference lame.c:904-915), or the one that gives the compression ratio the caller asked for
-         * -- 11.025 when there is neither (lame.c:622-644: lame_init leaves brate at 0).  That route also pins the
-         * output rate to the MPEG rate just above 97 % of the input rate */
-        int     brate = (p->brate == 0 && p->abr_kbps != 128) ? p->abr_kbps : p->brate;  /* lame.c:606-607 */
-        double  ratio = p->compression_ratio;
-        if (brate == 0 && ratio == 0)
-            ratio = 11.025;
-        if (ratio > 0) {
-            static const int mpeg_rates[9] = { 8000, 11025, 12000, 16000, 22050, 24000, 32000, 44100, 48000 };
-            int     out = p->samplerate_out, i;
-            if (out == 0) {
-                int const f = (int) (0.97 * p->samplerate);
-                out = 48000;
-                for (i = 0; i < 9; i++)
-                    if (f <= mpeg_rates[i]) {
-                        out = mpeg_rates[i];
-                        break;
-                    }
-            }
-            if (out < 32000)
-                return -1;      /* an MPEG-2 / 2.5 stream: outside this path */
-            brate = out * 16 * c->channels / (1.e3 * ratio);
-            pinned_out = out;
-        }
-        c->avg_bitrate = find_nearest_bitrate_mpeg1(brate);
-        brate_asked = (ratio > 0) ? c->avg_bitrate : brate;    /* (the compression-ratio route rounds at once, lame.c:642-643) */
-        for (r = 1; r <= 14; r++)
-            if (lh_bitrate_mpeg1[r] == c->avg_bitrate)
-                c->bitrate_index = r;
-        c->vbr_avg_bitrate_kbps = c->avg_bitrate;       /* lame_set_VBR_mean_bitrate_kbps(brate), lame.c:1043 */
-        ratio_kbps = brate_asked;       /* (lame.c:778 too comes before the rounding) */
-    }
-    if (c->bitrate_index <= 0)
-        return -1;
-
-    /* lowpass (reference lame.c:194-260, 700-760, 846-862) */
     {
-        /* (from the bitrate as asked for, before it is rounded to a frame size: lame.c:709-714 precedes :904-915) */
-        double  lowpass = lowpass_map[nearest_full_index(c->vbr == 3 ? c->avg_bitrate : brate_asked)];
-        int     lp;
+        /* The reference's order (lame.c:606-660, 700-778, 904-915, 1064-1091): what was asked for -- a bitrate, a mean, or
+         * a compression ratio, which also pins the output rate -- gives the lowpass, the lowpass the output rate the caller
+         * left open, the output rate the MPEG version, and only then is the bitrate rounded to a frame size of that version's
+         * row and are the VBR limits looked up. */
+        int     mean = p->abr_kbps, brate = 0, asked, lp;
+        double  lowpass;
+        if (c->vbr == 3) {
+            /* ABR: any mean; apply_abr_preset clamps it to 8..320 (reference presets.c:268-272) */
+            if (p->samplerate_out == 0 && (mean < 8 || mean > 320))
+                return -1;      /* the reference applies no preset at all there (presets.c:411-416) */
+            mean = mean > 320 ? 320 : mean;
+            mean = mean < 8 ? 8 : mean;
+        }
+        else {
+            double  ratio = p->compression_ratio;
+            brate = (p->brate == 0 && p->abr_kbps != 128) ? p->abr_kbps : p->brate;     /* lame.c:606-607 */
+            if (brate == 0 && ratio == 0)
+                ratio = 11.025; /* lame.c:622-626 */
+            if (ratio > 0) {
+                /* the bitrate that gives the ratio at the MPEG rate just above 97 % of the input rate (lame.c:629-644) */
+                static const int mpeg_rates[9] = { 8000, 11025, 12000, 16000, 22050, 24000, 32000, 44100, 48000 };
+                int     out = p->samplerate_out, i;
+                LhConfig tmp = *c;
+                if (out == 0) {
+                    int const f = (int) (0.97 * p->samplerate);
+                    out = 48000;
+                    for (i = 0; i < 9; i++)
+                        if (f <= mpeg_rates[i]) {
+                            out = mpeg_rates[i];
+                            break;
+                        }
+                }
+                if (set_output_rate(&tmp, out) != 0)
+                    return -1;
+                brate = out * 16 * c->channels / (1.e3 * ratio);
+                brate = find_nearest_bitrate(brate, tmp.version, out);  /* (this route rounds at once, lame.c:642-643) */
+                pinned_out = out;
+            }
+        }
+        {
+            /* an output rate that is known already bounds the mean (lame.c:645-660; VBR_mean_bitrate_kbps is 128 unless
+             * the caller set it, so this only ever shows in ABR) */
+            int const out = p->samplerate_out ? p->samplerate_out : pinned_out;
+            if (out && c->vbr == 3) {
+                int const lo = (out < 32000) ? 8 : 32, hi = (out < 16000) ? 64 : (out < 32000) ? 160 : 320;
+                mean = mean < lo ? lo : (mean > hi ? hi : mean);
+            }
+        }
+        asked = (c->vbr == 3) ? mean : brate;
+        ratio_kbps = asked;     /* (lame.c:778-784 come before the rounding) */
+        /* lowpass (reference lame.c:194-260, 700-760, 846-862) */
+        lowpass = lowpass_map[nearest_full_index(asked)];
         if (c->mode == LH_MODE_MONO)
             lowpass *= 1.5;     /* reference lame.c:758-759 */
         lp = (p->lowpassfreq != 0) ? p->lowpassfreq : (int) lowpass;   /* lame_set_lowpassfreq: Hz, -1 = none */
-        /* an output rate the caller left open follows from the lowpass (optimum_samplefreq,
-         * reference lame.c:273-345, 762-767); when it differs from the input rate the input is
-         * resampled in front of the encoder */
+        /* an output rate the caller left open follows from the lowpass (optimum_samplefreq, reference lame.c:273-345,
+         * 762-767); when it differs from the input rate the input is resampled in front of the encoder */
         {
             int     out = p->samplerate_out ? p->samplerate_out : pinned_out;
             if (out == 0) {
@@ -788,8 +813,10 @@ config_resolve_inner(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
                 out = suggested_samplerate(lp, p->samplerate);
             }
             if (set_output_rate(c, out) != 0)
-                return -1;      /* MPEG-2 / 2.5 output rates are outside this path */
+                return -1;
         }
+        if (ratio_kbps <= 0)
+            return -1;
         c->compression_ratio = c->samplerate * 16 * c->channels / (1.e3 * ratio_kbps);
         if (lp > 20500)
             lp = 20500;
@@ -797,9 +824,29 @@ config_resolve_inner(const LhUserParams * p, LhConfig * c, LhInitAux * aux)
             lp = c->samplerate / 2;
         c->lowpassfreq = lp;
         lowpass_edges(c, aux, p->lowpasswidth);
+        if (c->vbr == 3) {
+            c->avg_bitrate = mean;
+            c->bitrate_index = 1;
+            c->vbr_avg_bitrate_kbps = mean;
+            if (vbr_bitrate_limits(p, c) != 0)
+                return -1;
+            /* the mean stays inside the limits (reference lame.c:1086-1091; after compression_ratio was formed) */
+            if (c->vbr_avg_bitrate_kbps > lh_bitrate_row(c->version)[c->vbr_max_bitrate_index])
+                c->vbr_avg_bitrate_kbps = lh_bitrate_row(c->version)[c->vbr_max_bitrate_index];
+            if (c->vbr_avg_bitrate_kbps < lh_bitrate_row(c->version)[c->vbr_min_bitrate_index])
+                c->vbr_avg_bitrate_kbps = lh_bitrate_row(c->version)[c->vbr_min_bitrate_index];
+        }
+        else {
+            /* lame.c:904-915 */
+            c->avg_bitrate = find_nearest_bitrate(brate, c->version, c->samplerate);
+            c->bitrate_index = bitrate_index_of(c->avg_bitrate, c->version, c->samplerate);
+            c->vbr_avg_bitrate_kbps = c->avg_bitrate;   /* lame_set_VBR_mean_bitrate_kbps(brate), lame.c:1043 */
+        }
+        (void) brate_asked;
     }
+    if (c->bitrate_index <= 0)
+        return -1;
 
-    c->sideinfo_len = (c->channels == 1) ? 4 + 17 : 4 + 32;
     c->buffer_constraint = 7680 * (c->version + 1);     /* MDB_MAXIMUM, reference bitstream.c:91-131 */
 
     /* preset for the bitrate (reference presets.c:215-317) */
@@ -948,7 +995,7 @@ static float
 quietest_line(const LhConfig * c, int from, int to, int lines)
 {
     float const rate = c->samplerate;
-    float   least = FLT_MAX;
+    float   least = 1e37f;     /* (an empty band keeps it: reference machine.h:135 FLOAT_MAX, as the reference is built here) */
     int     k;
     for (k = from; k < to; k++) {
         float const e = quiet_energy(c, k * rate / (2 * lines));
@@ -1735,19 +1782,11 @@ lh_tables_build(LhConfig * c, const LhInitAux * aux, LhTables * t)
     const int16_t *sl, *ss;
 
     memset(t, 0, sizeof(*t));
-    switch (c->samplerate_index) {
-    case 0:
-        sl = lh_sfb_l_0;
-        ss = lh_sfb_s_0;
-        break;
-    case 1:
-        sl = lh_sfb_l_1;
-        ss = lh_sfb_s_1;
-        break;
-    default:
-        sl = lh_sfb_l_2;
-        ss = lh_sfb_s_2;
-        break;
+    {
+        /* the rate's row of the nine scalefactor band tables (reference lame.c:922) */
+        int const j = c->samplerate_index + 3 * c->version + 6 * (c->samplerate < 16000);
+        sl = &lh_sfb_l_all[23 * j];
+        ss = &lh_sfb_s_all[14 * j];
     }
     for (i = 0; i < LH_SBMAX_L + 1; i++)
         t->sfb_l[i] = sl[i];

@@ -33,7 +33,7 @@ abr_target_bits(OrcStream * S, float pe[2][2], const float ms_ener_ratio[2], int
         res_factor = .90;
     if (res_factor > 1.00)
         res_factor = 1.00;
-    for (gr = 0; gr < 2; gr++) {
+    for (gr = 0; gr < S->cfg->mode_gr; gr++) {
         int     sum = 0;
         for (ch = 0; ch < cfg->channels; ch++) {
             targ_bits[gr][ch] = res_factor * mean_bits;
@@ -61,17 +61,17 @@ abr_target_bits(OrcStream * S, float pe[2][2], const float ms_ener_ratio[2], int
             }
     }
     if (S->mode_ext == LH_MPG_MD_MS_LR)
-        for (gr = 0; gr < 2; gr++)
+        for (gr = 0; gr < S->cfg->mode_gr; gr++)
             reduce_side(targ_bits[gr], ms_ener_ratio[gr], mean_bits * cfg->channels, LH_MAX_BITS_PER_GRANULE);
     totbits = 0;
-    for (gr = 0; gr < 2; gr++)
+    for (gr = 0; gr < S->cfg->mode_gr; gr++)
         for (ch = 0; ch < cfg->channels; ch++) {
             if (targ_bits[gr][ch] > LH_MAX_BITS_PER_CHANNEL)
                 targ_bits[gr][ch] = LH_MAX_BITS_PER_CHANNEL;
             totbits += targ_bits[gr][ch];
         }
     if (totbits > *max_frame_bits && totbits > 0)
-        for (gr = 0; gr < 2; gr++)
+        for (gr = 0; gr < S->cfg->mode_gr; gr++)
             for (ch = 0; ch < cfg->channels; ch++) {
                 targ_bits[gr][ch] *= *max_frame_bits;
                 targ_bits[gr][ch] /= totbits;
@@ -88,7 +88,7 @@ orc_abr_iteration_loop(OrcStream * S, float pe[2][2], const float ms_ener_ratio[
     int     mean_bits = 0, max_frame_bits, analog_silence_bits, gr, ch, i;
 
     abr_target_bits(S, pe, ms_ener_ratio, targ_bits, &analog_silence_bits, &max_frame_bits);
-    for (gr = 0; gr < 2; gr++) {
+    for (gr = 0; gr < S->cfg->mode_gr; gr++) {
         if (S->mode_ext == LH_MPG_MD_MS_LR)
             for (i = 0; i < 576; ++i) {         /* ms_convert, reference quantize.c:48-59 */
                 float   l = S->tt[gr][0].xr[i];

@@ -68,7 +68,8 @@ adjust_ATH(OrcStream * S)
         max_pow += max_pow;
         gr2_max += gr2_max;
     }
-    max_pow = (max_pow > gr2_max) ? max_pow : gr2_max;
+    if (S->cfg->mode_gr == 2)
+        max_pow = (max_pow > gr2_max) ? max_pow : gr2_max;
     max_pow *= 0.5;
     max_pow *= T->aa_sensitivity_p;
     if (max_pow > 0.03125) {
@@ -101,7 +102,7 @@ pack_frame(OrcStream * S, LhFrameOut * fo, int mdb_for_header)
     int     gr, ch, i;
     int const nch = S->cfg->channels;
     memset(fo, 0, sizeof(*fo));
-    for (gr = 0; gr < 2; gr++) {
+    for (gr = 0; gr < S->cfg->mode_gr; gr++) {
         for (ch = 0; ch < nch; ch++) {
             OrcGr const *gi = &S->tt[gr][ch];
             LhGranule *g = &fo->gr[gr][ch];
@@ -175,15 +176,15 @@ orc_encode_frame(OrcStream * S, const float *inbuf_l, const float *inbuf_r, LhFr
         S->frame_init_done = 1;
         memset(primebuff0, 0, sizeof(primebuff0));
         memset(primebuff1, 0, sizeof(primebuff1));
-        for (i = 0, j = 0; i < 286 + 576 * (1 + 2); ++i) {
-            if (i >= 1152) {
+        for (i = 0, j = 0; i < 286 + 576 * (1 + cfg->mode_gr); ++i) {
+            if (i >= 576 * cfg->mode_gr) {
                 primebuff0[i] = inbuf[0][j];
                 if (nch == 2)
                     primebuff1[i] = inbuf[1][j];
                 ++j;
             }
         }
-        for (gr = 0; gr < 2; gr++)
+        for (gr = 0; gr < cfg->mode_gr; gr++)
             for (ch = 0; ch < nch; ch++)
                 S->tt[gr][ch].block_type = LH_SHORT_TYPE;
         orc_mdct_sub48(S, primebuff0, primebuff1);
@@ -196,7 +197,7 @@ orc_encode_frame(OrcStream * S, const float *inbuf_l, const float *inbuf_r, LhFr
     {
         const float *bufp[2] = { 0, 0 };
         int     blocktype[2];
-        for (gr = 0; gr < 2; gr++) {
+        for (gr = 0; gr < cfg->mode_gr; gr++) {
             for (ch = 0; ch < nch; ch++)
                 bufp[ch] = &inbuf[ch][576 + gr * 576 - LH_FFTOFFSET];
             orc_psycho_anal(S, bufp, gr, masking_LR, masking_MS, pe[gr], pe_MS[gr], tot_ener[gr],
@@ -221,7 +222,7 @@ orc_encode_frame(OrcStream * S, const float *inbuf_l, const float *inbuf_r, LhFr
     else if (cfg->mode == LH_MODE_JOINT_STEREO) {
         float   sum_pe_MS = 0;
         float   sum_pe_LR = 0;
-        for (gr = 0; gr < 2; gr++) {
+        for (gr = 0; gr < cfg->mode_gr; gr++) {
             for (ch = 0; ch < nch; ch++) {
                 sum_pe_MS += pe_MS[gr][ch];
                 sum_pe_LR += pe[gr][ch];
@@ -229,7 +230,7 @@ orc_encode_frame(OrcStream * S, const float *inbuf_l, const float *inbuf_r, LhFr
         }
         if (sum_pe_MS <= 1.00 * sum_pe_LR) {
             OrcGr const *const gi0 = &S->tt[0][0];
-            OrcGr const *const gi1 = &S->tt[1][0];
+            OrcGr const *const gi1 = &S->tt[cfg->mode_gr - 1][0];
             if (gi0[0].block_type == gi0[1].block_type && gi1[0].block_type == gi1[1].block_type)
                 S->mode_ext = LH_MPG_MD_MS_LR;
         }
@@ -253,15 +254,15 @@ orc_encode_frame(OrcStream * S, const float *inbuf_l, const float *inbuf_r, LhFr
         for (i = 0; i < 18; i++)
             S->pefirbuf[i] = S->pefirbuf[i + 1];
         f = 0.0;
-        for (gr = 0; gr < 2; gr++)
+        for (gr = 0; gr < cfg->mode_gr; gr++)
             for (ch = 0; ch < nch; ch++)
                 f += pe_use[gr][ch];
         S->pefirbuf[18] = f;
         f = S->pefirbuf[9];
         for (i = 0; i < 9; i++)
             f += (S->pefirbuf[i] + S->pefirbuf[18 - i]) * fircoef[i];
-        f = (670 * 5 * 2 * nch) / f;
-        for (gr = 0; gr < 2; gr++)
+        f = (670 * 5 * cfg->mode_gr * nch) / f;
+        for (gr = 0; gr < cfg->mode_gr; gr++)
             for (ch = 0; ch < nch; ch++)
                 pe_use[gr][ch] *= f;
     }
@@ -278,8 +279,8 @@ orc_encode_frame(OrcStream * S, const float *inbuf_l, const float *inbuf_r, LhFr
     {
         /* main_data_begin bookkeeping of format_bitstream, reference bitstream.c:917-935 */
         int     bits = 8 * cfg->sideinfo_len, frame_bits;
-        int     bit_rate = lh_bitrate_mpeg1[S->bitrate_index];
-        for (gr = 0; gr < 2; gr++)
+        int     bit_rate = (cfg->version ? lh_bitrate_mpeg1 : lh_bitrate_mpeg2)[S->bitrate_index];
+        for (gr = 0; gr < cfg->mode_gr; gr++)
             for (ch = 0; ch < nch; ch++)
                 bits += S->tt[gr][ch].part2_3_length + S->tt[gr][ch].part2_length;
         bits += S->resvDrain_post;
@@ -296,32 +297,41 @@ orc_encode_frame(OrcStream * S, const float *inbuf_l, const float *inbuf_r, LhFr
 
 /* number of frames lame_encode_buffer + lame_encode_flush produce for n samples
  * (reference lame.c:1671-1775, 2041-2120) */
+/* (fs = samples per frame: 1152, or 576 for MPEG-2 / 2.5; the window a frame needs is BLKSIZE + fs - FFTOFFSET,
+ * reference lame.c:1627-1648) */
 int
-orc_total_frames(long n)
+orc_total_frames_fs(long n, int fs)
 {
     long    mf_size = LH_MF_START, to_encode = LH_ENCDELAY + LH_POSTDELAY;
     long    frames = 0, fed = 0;
     int     end_padding, frames_left;
+    int const needed = LH_BLKSIZE + fs - LH_FFTOFFSET;
     to_encode += n;
     while (fed < n) {
         long    m = n - fed;
-        if (m > 1152)
-            m = 1152;
-        /* fill_buffer copies min(1152, remaining) samples per inner iteration */
+        if (m > fs)
+            m = fs;
+        /* fill_buffer copies min(framesize, remaining) samples per inner iteration */
         mf_size += m;
         fed += m;
-        if (mf_size >= LH_MF_NEEDED) {
+        if (mf_size >= needed) {
             frames++;
-            mf_size -= 1152;
-            to_encode -= 1152;
+            mf_size -= fs;
+            to_encode -= fs;
         }
     }
     to_encode -= LH_POSTDELAY;
-    end_padding = 1152 - (int) (to_encode % 1152);
+    end_padding = fs - (int) (to_encode % fs);
     if (end_padding < 576)
-        end_padding += 1152;
-    frames_left = (int) ((to_encode + end_padding) / 1152);
+        end_padding += fs;
+    frames_left = (int) ((to_encode + end_padding) / fs);
     return (int) (frames + frames_left);
+}
+
+int
+orc_total_frames(long n)
+{
+    return orc_total_frames_fs(n, 1152);
 }
 
 /* Encode a whole planar s16 stream; window of frame f is pcm[1152 f - 528 ...],
@@ -331,12 +341,13 @@ orc_encode_stream(const LhConfig * cfg, const LhTables * tab, const short *l, co
                   long n, LhFrameOut * frames, int max_frames, float *xr_out)
 {
     OrcStream *S = (OrcStream *) malloc(sizeof(OrcStream));
-    int     nf = orc_total_frames(n), f, i;
+    int const fs = 576 * cfg->mode_gr;
+    int     nf = orc_total_frames_fs(n, fs), f, i;
     static float mf[2][LH_MF_NEEDED];
     orc_stream_init(S, cfg, tab);
     for (f = 0; f < nf; f++) {
         LhFrameOut tmp;
-        long    base = 1152L * f - LH_MF_START;
+        long    base = (long) fs * f - LH_MF_START;
         for (i = 0; i < LH_MF_NEEDED; i++) {
             long    p = base + i;
             if (p >= 0 && p < n) {
@@ -360,7 +371,7 @@ orc_encode_stream(const LhConfig * cfg, const LhTables * tab, const short *l, co
                 frames[f] = tmp;
             if (xr_out) {
                 int     gr, ch;
-                for (gr = 0; gr < 2; gr++)
+                for (gr = 0; gr < cfg->mode_gr; gr++)
                     for (ch = 0; ch < 2; ch++)
                         memcpy(xr_out + ((f * 2 + gr) * 2 + ch) * 576, S->tt[gr][ch].xr,
                                576 * sizeof(float));

@@ -334,7 +334,7 @@ orc_mdct_sub48(OrcStream * S, const float *w0, const float *w1)
     const float *amp = S->tab->amp_filter;
 
     for (ch = 0; ch < S->cfg->channels; ch++) {
-        for (gr = 0; gr < 2; gr++) {
+        for (gr = 0; gr < S->cfg->mode_gr; gr++) {
             int     band;
             OrcGr  *const gi = &S->tt[gr][ch];
             float  *mdct_enc = gi->xr;
@@ -400,5 +400,8 @@ orc_mdct_sub48(OrcStream * S, const float *w0, const float *w1)
             }
         }
         wk = w1 + 286;
+        /* one granule per frame: its sub-band samples are the next frame's overlap (reference newmdct.c:1035-1037) */
+        if (S->cfg->mode_gr == 1)
+            memcpy(S->sb_sample[ch][0], S->sb_sample[ch][1], 576 * sizeof(float));
     }
 }

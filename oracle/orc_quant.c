@@ -471,6 +471,9 @@ best_huffman_divide(OrcStream * S, OrcGr * const gi)
     int     r0_tbl[7 + 15 + 1];
     int     r1_tbl[7 + 15 + 1];
 
+    /* (an LSF short block is left alone: reference takehiro.c:898-900) */
+    if (gi->block_type == LH_SHORT_TYPE && S->cfg->mode_gr == 1)
+        return;
     memcpy(&cod_info2, gi, sizeof(OrcGr));
     if (gi->block_type == LH_NORM_TYPE) {
         recalc_divide_init(S, gi, ix, r01_bits, r01_div, r0_tbl, r1_tbl);
@@ -516,7 +519,7 @@ best_huffman_divide(OrcStream * S, OrcGr * const gi)
 
 /* reference takehiro.c:1135-1188 (MPEG-1) */
 static int
-scale_bitcount(OrcGr * const cod_info)
+mpeg1_scale_bitcount(OrcGr * const cod_info)
 {
     int     k, sfb, max_slen1 = 0, max_slen2 = 0;
     const int *tabp;
@@ -554,6 +557,65 @@ scale_bitcount(OrcGr * const cod_info)
         }
     }
     return cod_info->part2_length == LH_LARGE_BITS;
+}
+
+/* MPEG-2 / 2.5 (reference takehiro.c:1195-1317): the scalefactors travel in four partitions of fixed band counts
+ * (ISO 13818-3 2.4.3.2; lh_nr_of_sfb_block[table][long / short / mixed][partition]), each with its own field width;
+ * scalefac_compress encodes the four widths.  Table 0 without preflag, table 2 with it (table 1 is never chosen, as
+ * in the reference).  Over the range: part2_length stays what it was. */
+static int
+mpeg2_scale_bitcount(OrcGr * const cod_info)
+{
+    static const int max_range_sfac_tab[6][4] = {
+        {15, 15, 7, 7}, {15, 15, 7, 0}, {7, 3, 0, 0}, {15, 31, 31, 0}, {7, 7, 7, 0}, {3, 3, 0, 0}
+    };
+    static const int log2tab[] = { 0, 1, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 4, 4, 4, 4 };
+    int const table_number = cod_info->preflag ? 2 : 0;
+    int const row_in_table = (cod_info->block_type == LH_SHORT_TYPE) ? 1 : 0;
+    const uint8_t *partition_table = &lh_nr_of_sfb_block[(table_number * 3 + row_in_table) * 4];
+    int const *const scalefac = cod_info->scalefac;
+    int     partition, nr_sfb, window, over, i, sfb, max_sfac[4] = { 0, 0, 0, 0 };
+
+    if (row_in_table == 1) {
+        for (sfb = 0, partition = 0; partition < 4; partition++) {
+            nr_sfb = partition_table[partition] / 3;
+            for (i = 0; i < nr_sfb; i++, sfb++)
+                for (window = 0; window < 3; window++)
+                    if (scalefac[sfb * 3 + window] > max_sfac[partition])
+                        max_sfac[partition] = scalefac[sfb * 3 + window];
+        }
+    }
+    else {
+        for (sfb = 0, partition = 0; partition < 4; partition++) {
+            nr_sfb = partition_table[partition];
+            for (i = 0; i < nr_sfb; i++, sfb++)
+                if (scalefac[sfb] > max_sfac[partition])
+                    max_sfac[partition] = scalefac[sfb];
+        }
+    }
+    for (over = 0, partition = 0; partition < 4; partition++)
+        if (max_sfac[partition] > max_range_sfac_tab[table_number][partition])
+            over++;
+    if (!over) {
+        int     slen[4];
+        for (partition = 0; partition < 4; partition++)
+            slen[partition] = log2tab[max_sfac[partition]];
+        if (table_number == 0)
+            cod_info->scalefac_compress = (((slen[0] * 5) + slen[1]) << 4) + (slen[2] << 2) + slen[3];
+        else
+            cod_info->scalefac_compress = 500 + (slen[0] * 3) + slen[1];
+        cod_info->part2_length = 0;
+        for (partition = 0; partition < 4; partition++)
+            cod_info->part2_length += slen[partition] * partition_table[partition];
+    }
+    return over;
+}
+
+/* reference takehiro.c:1319-1329 */
+static int
+scale_bitcount(const OrcStream * S, OrcGr * const cod_info)
+{
+    return (S->cfg->mode_gr == 2) ? mpeg1_scale_bitcount(cod_info) : mpeg2_scale_bitcount(cod_info);
 }
 
 /* reference takehiro.c:964-1014 */
@@ -631,7 +693,7 @@ best_scalefac_store(OrcStream * S, const int gr, const int ch)
             gi->scalefac_scale = recalc = 1;
         }
     }
-    if (!gi->preflag && gi->block_type != LH_SHORT_TYPE) {
+    if (!gi->preflag && gi->block_type != LH_SHORT_TYPE && S->cfg->mode_gr == 2) {
         for (sfb = 11; sfb < LH_SBPSY_L; sfb++)
             if (gi->scalefac[sfb] < lh_pretab[sfb] && gi->scalefac[sfb] != -2)
                 break;
@@ -644,7 +706,7 @@ best_scalefac_store(OrcStream * S, const int gr, const int ch)
     }
     for (i = 0; i < 4; i++)
         S->scfsi[ch][i] = 0;
-    if (gr == 1 && S->tt[0][ch].block_type != LH_SHORT_TYPE
+    if (S->cfg->mode_gr == 2 && gr == 1 && S->tt[0][ch].block_type != LH_SHORT_TYPE
         && S->tt[1][ch].block_type != LH_SHORT_TYPE) {
         scfsi_calc(S, ch);
         recalc = 0;
@@ -653,7 +715,7 @@ best_scalefac_store(OrcStream * S, const int gr, const int ch)
         if (gi->scalefac[sfb] == -2)
             gi->scalefac[sfb] = 0;
     if (recalc)
-        (void) scale_bitcount(gi);
+        (void) scale_bitcount(S, gi);
 }
 
 /* ---------------------------------------------------------------------- */
@@ -740,8 +802,8 @@ calc_xmin(OrcStream * S, OrcRatio const *const ratio, OrcGr * const cod_info, fl
         max_nonzero += 5;
     }
     if (cfg->sfb21_extra == 0 && cfg->samplerate < 44000) {
-        int const sfb_l = 21;
-        int const sfb_s = 12;
+        int const sfb_l = (cfg->samplerate <= 8000) ? 17 : 21;
+        int const sfb_s = (cfg->samplerate <= 8000) ? 9 : 12;
         int     limit = 575;
         if (cod_info->block_type != LH_SHORT_TYPE)
             limit = T->sfb_l[sfb_l] - 1;
@@ -923,7 +985,7 @@ calc_noise(const LhTables * T, OrcGr const *const cod_info, float const *l3_xmin
 static int
 getframebits(OrcStream * S)
 {
-    int     bit_rate = lh_bitrate_mpeg1[S->bitrate_index];
+    int     bit_rate = (S->cfg->version ? lh_bitrate_mpeg1 : lh_bitrate_mpeg2)[S->bitrate_index];
     return 8 * ((S->cfg->version + 1) * 72000 * bit_rate / S->cfg->samplerate + S->padding);
 }
 
@@ -1158,9 +1220,17 @@ init_outer_loop(OrcStream * S, OrcGr * const cod_info)
     cod_info->scalefac_scale = 0;
     cod_info->count1table_select = 0;
     cod_info->part2_length = 0;
-    cod_info->sfb_lmax = LH_SBPSY_L;
-    cod_info->sfb_smin = LH_SBPSY_S;
-    cod_info->psy_lmax = S->cfg->sfb21_extra ? LH_SBMAX_L : LH_SBPSY_L;
+    if (S->cfg->samplerate <= 8000) {
+        /* an 8 kHz stream codes 17 long / 9 short bands (reference quantize.c:252-256) */
+        cod_info->sfb_lmax = 17;
+        cod_info->sfb_smin = 9;
+        cod_info->psy_lmax = 17;
+    }
+    else {
+        cod_info->sfb_lmax = LH_SBPSY_L;
+        cod_info->sfb_smin = LH_SBPSY_S;
+        cod_info->psy_lmax = S->cfg->sfb21_extra ? LH_SBMAX_L : LH_SBPSY_L;
+    }
     cod_info->psymax = cod_info->psy_lmax;
     cod_info->sfbmax = cod_info->sfb_lmax;
     cod_info->sfbdivide = 11;
@@ -1173,9 +1243,15 @@ init_outer_loop(OrcStream * S, OrcGr * const cod_info)
         float  *ix;
         cod_info->sfb_smin = 0;
         cod_info->sfb_lmax = 0;
-        cod_info->psymax = cod_info->sfb_lmax
-            + 3 * ((S->cfg->sfb21_extra ? LH_SBMAX_S : LH_SBPSY_S) - cod_info->sfb_smin);
-        cod_info->sfbmax = cod_info->sfb_lmax + 3 * (LH_SBPSY_S - cod_info->sfb_smin);
+        if (S->cfg->samplerate <= 8000) {
+            cod_info->psymax = cod_info->sfb_lmax + 3 * (9 - cod_info->sfb_smin);
+            cod_info->sfbmax = cod_info->sfb_lmax + 3 * (9 - cod_info->sfb_smin);
+        }
+        else {
+            cod_info->psymax = cod_info->sfb_lmax
+                + 3 * ((S->cfg->sfb21_extra ? LH_SBMAX_S : LH_SBPSY_S) - cod_info->sfb_smin);
+            cod_info->sfbmax = cod_info->sfb_lmax + 3 * (LH_SBPSY_S - cod_info->sfb_smin);
+        }
         cod_info->sfbdivide = cod_info->sfbmax - 18;
         cod_info->psy_lmax = cod_info->sfb_lmax;
         ix = &cod_info->xr[T->sfb_l[cod_info->sfb_lmax]];
@@ -1487,7 +1563,7 @@ balance_noise(OrcStream * S, OrcGr * const cod_info, float const *distort, float
     status = loop_break(cod_info);
     if (status)
         return 0;
-    status = scale_bitcount(cod_info);
+    status = scale_bitcount(S, cod_info);
     if (!status)
         return 1;
     if (cfg->noise_shaping > 1) {
@@ -1502,7 +1578,7 @@ balance_noise(OrcStream * S, OrcGr * const cod_info, float const *distort, float
         }
     }
     if (!status)
-        status = scale_bitcount(cod_info);
+        status = scale_bitcount(S, cod_info);
     return !status;
 }
 
@@ -1638,7 +1714,7 @@ orc_cbr_iteration_loop(OrcStream * S, float pe[2][2], const float ms_ener_ratio[
     int     gr, ch;
 
     (void) ResvFrameBegin(S, &mean_bits);
-    for (gr = 0; gr < 2; gr++) {
+    for (gr = 0; gr < S->cfg->mode_gr; gr++) {
         max_bits = on_pe(S, pe, targ_bits, mean_bits, gr, gr);
         if (S->mode_ext == LH_MPG_MD_MS_LR) {
             /* ms_convert, reference quantize.c:48-59 */

@@ -37,6 +37,10 @@ static const unsigned char orc_range_short[LH_SBMAX_S * 3] = {
 static const unsigned char orc_range_long[LH_SBMAX_L] = {
     15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 0
 };
+/* MPEG-2 / 2.5 with preflag: the scalefactor partitions of table 2 carry 3, 2, 0, 0 bits (reference vbrquantize.c:577-579) */
+static const unsigned char orc_range_long_lsf_pretab[LH_SBMAX_L] = {
+    7, 7, 7, 7, 7, 7, 3, 3, 3, 3, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0
+};
 
 /* one value through the x^(3/4) quantiser (k_34_4 per element, reference vbrquantize.c:162-199) */
 static inline int
@@ -397,7 +401,7 @@ vbr_constrain_short(const OrcVbrGr * V, const int steps[LH_SFBMAX], int vbrmax)
 }
 
 /* long blocks: choose scalefac_scale / preflag (long_block_constrain, reference
- * vbrquantize.c:826-978; MPEG-1, so the pretab variant uses the same ranges) */
+ * vbrquantize.c:826-978) */
 static void
 vbr_constrain_long(const OrcVbrGr * V, const int steps[LH_SFBMAX], int vbrmax)
 {
@@ -406,9 +410,11 @@ vbr_constrain_long(const OrcVbrGr * V, const int steps[LH_SFBMAX], int vbrmax)
     int     over0 = 0, over1 = 0, over0p = 0, over1p = 0, delta = 0, mover, sfb;
     int     pre0 = 1, pre1 = 1;
     int     tmp[LH_SFBMAX];
+    /* the ranges with preflag: MPEG-1's own, or the LSF table's (reference vbrquantize.c:861) */
+    const unsigned char *rangep = (V->S->cfg->mode_gr == 2) ? orc_range_long : orc_range_long_lsf_pretab;
     for (sfb = 0; sfb < gi->psymax; ++sfb) {
         int const v = vbrmax - steps[sfb];
-        int const r = orc_range_long[sfb], rp = orc_range_long[sfb] + lh_pretab[sfb];
+        int const r = orc_range_long[sfb], rp = rangep[sfb] + lh_pretab[sfb];
         if (delta < v)
             delta = v;
         if (over0 < v - 2 * r)
@@ -464,6 +470,7 @@ vbr_constrain_long(const OrcVbrGr * V, const int steps[LH_SFBMAX], int vbrmax)
     if (over0 == 0) {
         gi->scalefac_scale = 0;
         gi->preflag = 0;
+        rangep = orc_range_long;
     }
     else if (over0p == 0) {
         gi->scalefac_scale = 0;
@@ -472,6 +479,7 @@ vbr_constrain_long(const OrcVbrGr * V, const int steps[LH_SFBMAX], int vbrmax)
     else if (over1 == 0) {
         gi->scalefac_scale = 1;
         gi->preflag = 0;
+        rangep = orc_range_long;
     }
     else if (over1p == 0) {
         gi->scalefac_scale = 1;
@@ -480,7 +488,7 @@ vbr_constrain_long(const OrcVbrGr * V, const int steps[LH_SFBMAX], int vbrmax)
     gi->global_gain = vbr_clamp_gain(vbrmax);
     for (sfb = 0; sfb < LH_SFBMAX; ++sfb)
         tmp[sfb] = steps[sfb] - vbrmax;
-    vbr_scalefacs(gi, V->sfmin, tmp, orc_range_long);
+    vbr_scalefacs(gi, V->sfmin, tmp, rangep);
 }
 
 static void
@@ -491,7 +499,7 @@ vbr_constrain(const OrcVbrGr * V, const int steps[LH_SFBMAX], int vbrmax)
     else
         vbr_constrain_long(V, steps, vbrmax);
     /* bitcount(): the scalefactors always fit by construction (reference vbrquantize.c:982-993) */
-    (void) scale_bitcount(V->gi);
+    (void) scale_bitcount(V->S, V->gi);
 }
 
 static int
@@ -663,7 +671,7 @@ vbr_encode_frame(OrcStream * S, float xr34[2][2][576], float xmin[2][2][LH_SFBMA
     int     gr, ch, ok, sum_fr;
     int const nch = S->cfg->channels;
 
-    for (gr = 0; gr < 2; ++gr)
+    for (gr = 0; gr < S->cfg->mode_gr; ++gr)
         for (ch = 0; ch < nch; ++ch) {
             OrcVbrGr *v = &V[gr][ch];
             max_ch[gr][ch] = max_bits[gr][ch];
@@ -676,7 +684,7 @@ vbr_encode_frame(OrcStream * S, float xr34[2][2][576], float xmin[2][2][LH_SFBMA
             v->guess = (S->cfg->full_outer_loop < 0);
         }
     /* scalefactor search */
-    for (gr = 0; gr < 2; ++gr)
+    for (gr = 0; gr < S->cfg->mode_gr; ++gr)
         for (ch = 0; ch < nch; ++ch)
             if (max_bits[gr][ch] > 0) {
                 OrcVbrGr *v = &V[gr][ch];
@@ -685,7 +693,7 @@ vbr_encode_frame(OrcStream * S, float xr34[2][2][576], float xmin[2][2][LH_SFBMA
             }
     /* encode as it is */
     use_fr = 0;
-    for (gr = 0; gr < 2; ++gr) {
+    for (gr = 0; gr < S->cfg->mode_gr; ++gr) {
         use_gr[gr] = 0;
         for (ch = 0; ch < nch; ++ch) {
             if (max_bits[gr][ch] > 0) {
@@ -699,7 +707,7 @@ vbr_encode_frame(OrcStream * S, float xr34[2][2][576], float xmin[2][2][LH_SFBMA
     }
     if (use_fr <= max_fr) {
         ok = 1;
-        for (gr = 0; gr < 2; ++gr) {
+        for (gr = 0; gr < S->cfg->mode_gr; ++gr) {
             if (use_gr[gr] > LH_MAX_BITS_PER_GRANULE)
                 ok = 0;
             for (ch = 0; ch < nch; ++ch)
@@ -712,7 +720,7 @@ vbr_encode_frame(OrcStream * S, float xr34[2][2][576], float xmin[2][2][LH_SFBMA
     /* too many bits: fix a budget per granule and channel */
     ok = 1;
     sum_fr = 0;
-    for (gr = 0; gr < 2; ++gr) {
+    for (gr = 0; gr < S->cfg->mode_gr; ++gr) {
         max_gr[gr] = 0;
         for (ch = 0; ch < nch; ++ch) {
             max_ch[gr][ch] = (use_ch[gr][ch] > LH_MAX_BITS_PER_CHANNEL) ? LH_MAX_BITS_PER_CHANNEL : use_ch[gr][ch];
@@ -745,7 +753,7 @@ vbr_encode_frame(OrcStream * S, float xr34[2][2][576], float xmin[2][2][LH_SFBMA
     if (sum_fr > max_fr) {
         {
             float   f[2] = { 0.0f, 0.0f }, s = 0.0f;
-            for (gr = 0; gr < 2; ++gr) {
+            for (gr = 0; gr < S->cfg->mode_gr; ++gr) {
                 if (max_gr[gr] > 0) {
                     f[gr] = sqrt(max_gr[gr]);
                     s += f[gr];
@@ -753,14 +761,14 @@ vbr_encode_frame(OrcStream * S, float xr34[2][2][576], float xmin[2][2][LH_SFBMA
                 else
                     f[gr] = 0;
             }
-            for (gr = 0; gr < 2; ++gr)
+            for (gr = 0; gr < S->cfg->mode_gr; ++gr)
                 max_gr[gr] = (s > 0) ? (int) (max_fr * f[gr] / s) : 0;
         }
         vbr_share(max_gr, use_gr, 125);
-        for (gr = 0; gr < 2; ++gr)
+        for (gr = 0; gr < S->cfg->mode_gr; ++gr)
             if (max_gr[gr] > LH_MAX_BITS_PER_GRANULE)
                 max_gr[gr] = LH_MAX_BITS_PER_GRANULE;
-        for (gr = 0; gr < 2; ++gr) {
+        for (gr = 0; gr < S->cfg->mode_gr; ++gr) {
             float   f[2] = { 0.0f, 0.0f }, s = 0.0f;
             for (ch = 0; ch < nch; ++ch) {
                 if (max_ch[gr][ch] > 0) {
@@ -781,7 +789,7 @@ vbr_encode_frame(OrcStream * S, float xr34[2][2][576], float xmin[2][2][LH_SFBMA
         }
     }
     sum_fr = 0;
-    for (gr = 0; gr < 2; ++gr) {
+    for (gr = 0; gr < S->cfg->mode_gr; ++gr) {
         int     sum_gr = 0;
         for (ch = 0; ch < nch; ++ch) {
             sum_gr += max_ch[gr][ch];
@@ -795,17 +803,17 @@ vbr_encode_frame(OrcStream * S, float xr34[2][2][576], float xmin[2][2][LH_SFBMA
     if (sum_fr > max_fr)
         ok = 0;
     if (!ok)                    /* fall back to the on_pe split */
-        for (gr = 0; gr < 2; ++gr)
+        for (gr = 0; gr < S->cfg->mode_gr; ++gr)
             for (ch = 0; ch < nch; ++ch)
                 max_ch[gr][ch] = max_bits[gr][ch];
     /* best_scalefac_store ran already: undo its bookkeeping before the second pass */
     for (ch = 0; ch < nch; ++ch)
         S->scfsi[ch][0] = S->scfsi[ch][1] = S->scfsi[ch][2] = S->scfsi[ch][3] = 0;
-    for (gr = 0; gr < 2; ++gr)
+    for (gr = 0; gr < S->cfg->mode_gr; ++gr)
         for (ch = 0; ch < nch; ++ch)
             S->tt[gr][ch].scalefac_compress = 0;
     use_fr = 0;
-    for (gr = 0; gr < 2; ++gr) {
+    for (gr = 0; gr < S->cfg->mode_gr; ++gr) {
         use_gr[gr] = 0;
         for (ch = 0; ch < nch; ++ch) {
             OrcVbrGr *v = &V[gr][ch];
@@ -846,7 +854,7 @@ orc_vbr_new_iteration_loop(OrcStream * S, float pe[2][2], const OrcRatio ratio[2
         frame_bits[i] = ResvFrameBegin(S, &mean_bits);
     }
     top_bits = frame_bits[cfg->vbr_max_bitrate_index];
-    for (gr = 0; gr < 2; gr++) {
+    for (gr = 0; gr < S->cfg->mode_gr; gr++) {
         (void) on_pe(S, pe, max_bits[gr], avg, gr, 0);
         if (S->mode_ext == LH_MPG_MD_MS_LR) {
             for (i = 0; i < 576; ++i) {         /* ms_convert, reference quantize.c:48-59 */
@@ -865,7 +873,7 @@ orc_vbr_new_iteration_loop(OrcStream * S, float pe[2][2], const OrcRatio ratio[2
             bits += max_bits[gr][ch];
         }
     }
-    for (gr = 0; gr < 2; gr++)
+    for (gr = 0; gr < S->cfg->mode_gr; gr++)
         for (ch = 0; ch < cfg->channels; ch++)
             if (bits > top_bits && bits > 0) {
                 max_bits[gr][ch] *= top_bits;
@@ -874,7 +882,7 @@ orc_vbr_new_iteration_loop(OrcStream * S, float pe[2][2], const OrcRatio ratio[2
     if (analog_silence)
         pad = 0;
 
-    for (gr = 0; gr < 2; gr++)
+    for (gr = 0; gr < S->cfg->mode_gr; gr++)
         for (ch = 0; ch < cfg->channels; ch++)
             if (0 == init_xrpow(S, &S->tt[gr][ch], xr34[gr][ch]))
                 max_bits[gr][ch] = 0;   /* silent granule needs no bits */
@@ -897,7 +905,7 @@ orc_vbr_new_iteration_loop(OrcStream * S, float pe[2][2], const OrcRatio ratio[2
     else
         S->bitrate_index = i;
     (void) ResvFrameBegin(S, &mean_bits);
-    for (gr = 0; gr < 2; gr++)
+    for (gr = 0; gr < S->cfg->mode_gr; gr++)
         for (ch = 0; ch < cfg->channels; ch++)
             S->ResvSize -= S->tt[gr][ch].part2_3_length + S->tt[gr][ch].part2_length;  /* ResvAdjust */
     ResvFrameEnd(S, mean_bits);

@@ -450,9 +450,11 @@ refh_encode_stream(void *hh, const short *l, const short *r, long n, unsigned ch
     long    pos = 0, done = 0;
     int     k, last = 0, nf = 0;
     short   zero[2][1152];
-    /* feed in 1152-sample calls so that every call encodes at most one frame */
+    int const fs = 576 * gfc->cfg.mode_gr;      /* samples per frame: 1152, or 576 for MPEG-2 / 2.5 */
+    int const ngr = gfc->cfg.mode_gr;
+    /* feed in frame-sized calls so that every call encodes at most one frame */
     while (done < n) {
-        int     m = (n - done) > 1152 ? 1152 : (int) (n - done);
+        int     m = (n - done) > fs ? fs : (int) (n - done);
         k = lame_encode_buffer(h->gfp, l + done, r + done, m, out + pos, (int) (outsize - pos));
         if (k < 0)
             return k;
@@ -465,7 +467,7 @@ refh_encode_stream(void *hh, const short *l, const short *r, long n, unsigned ch
                     fill_frame(gfc, &frame_out[nf]);
                 if (xr_out) {
                     int     gr, ch;
-                    for (gr = 0; gr < 2; gr++)
+                    for (gr = 0; gr < ngr; gr++)
                         for (ch = 0; ch < 2; ch++)
                             memcpy(xr_out + ((nf * 2 + gr) * 2 + ch) * 576,
                                    gfc->l3_side.tt[gr][ch].xr, 576 * sizeof(float));
@@ -480,13 +482,13 @@ refh_encode_stream(void *hh, const short *l, const short *r, long n, unsigned ch
     {
         EncStateVar_t *esv = &gfc->sv_enc;
         int     samples_to_encode = esv->mf_samples_to_encode - POSTDELAY;
-        int     end_padding = 1152 - (samples_to_encode % 1152);
+        int     end_padding = fs - (samples_to_encode % fs);
         int     frames_left;
         if (end_padding < 576)
-            end_padding += 1152;
-        frames_left = (samples_to_encode + end_padding) / 1152;
+            end_padding += fs;
+        frames_left = (samples_to_encode + end_padding) / fs;
         while (frames_left > 0) {
-            int     bunch = 1904 - esv->mf_size;
+            int     bunch = (BLKSIZE + fs - FFTOFFSET) - esv->mf_size;
             if (bunch > 1152)
                 bunch = 1152;
             if (bunch < 1)
@@ -504,7 +506,7 @@ refh_encode_stream(void *hh, const short *l, const short *r, long n, unsigned ch
                         fill_frame(gfc, &frame_out[nf]);
                     if (xr_out) {
                         int     gr, ch;
-                        for (gr = 0; gr < 2; gr++)
+                        for (gr = 0; gr < ngr; gr++)
                             for (ch = 0; ch < 2; ch++)
                                 memcpy(xr_out + ((nf * 2 + gr) * 2 + ch) * 576,
                                        gfc->l3_side.tt[gr][ch].xr, 576 * sizeof(float));
@@ -535,7 +537,7 @@ fill_frame(lame_internal_flags const *gfc, LhFrameOut * fo)
 {
     int     gr, ch, i;
     memset(fo, 0, sizeof(*fo));
-    for (gr = 0; gr < 2; gr++) {
+    for (gr = 0; gr < gfc->cfg.mode_gr; gr++) {
         for (ch = 0; ch < 2; ch++) {
             gr_info const *gi = &gfc->l3_side.tt[gr][ch];
             LhGranule *g = &fo->gr[gr][ch];

@@ -65,7 +65,7 @@ class Oracle:
         left = np.ascontiguousarray(pcm[0], dtype=np.int16)
         right = np.ascontiguousarray(pcm[1], dtype=np.int16)
         n = len(left)
-        nf = self.lib.orc_total_frames(C.c_long(n))
+        nf = self.lib.orc_total_frames_fs(C.c_long(n), 576 * cfg.mode_gr)
         if max_frames is not None:
             nf = min(nf, max_frames)
         out = (LhFrameOut * nf)()
@@ -184,7 +184,8 @@ def golden_names(vbr=False, kind=None):
 
     def k(f):
         return "mono" if f.startswith("mono_") else "vbr" if "vbr" in f else ("abr" if "abr" in f else "cbr")
-    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and k(f) == kind)
+    # (stages_*.npz are the per-stage fixtures of tests/test_stage_fixtures.py, not whole-stream goldens)
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and not f.startswith("stages_") and k(f) == kind)
 
 
 def load_golden(name):
