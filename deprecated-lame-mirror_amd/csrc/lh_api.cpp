@@ -58,6 +58,20 @@ lamehip_device_count(void)
     return n;
 }
 
+/* samples per frame (1152; 576 for MPEG-2 / 2.5: one granule) and the samples that have to be buffered before a frame can
+ * be encoded (BLKSIZE + framesize - FFTOFFSET: 1904 / 1328; reference lame.c:1627-1648) */
+static inline int
+fs_of(const LhConfig & c)
+{
+    return 576 * c.mode_gr;
+}
+
+static inline int
+mfn_of(const LhConfig & c)
+{
+    return LH_BLKSIZE + 576 * c.mode_gr - LH_FFTOFFSET;
+}
+
 /* device-resident constants shared by a handle or a batch */
 struct LhDeviceConst {
     LhConfig *d_cfg = nullptr;
@@ -659,12 +673,12 @@ lame_set_force_short_blocks(lame_t g, int v)
 SETTER(lame_set_VBR_mean_bitrate_kbps, p.abr_kbps, int)
 GETTER(lame_get_VBR_mean_bitrate_kbps, g->inited ? g->cfg.vbr_avg_bitrate_kbps : g->p.abr_kbps, int)
 
-GETTER(lame_get_framesize, 576 * 2, int)
+GETTER(lame_get_framesize, g->inited ? fs_of(g->cfg) : 576 * 2, int)
 GETTER(lame_get_frameNum, g->frames_done - g->frame_num_base, int)
 GETTER(lame_get_encoder_delay, LH_ENCDELAY, int)
 GETTER(lame_get_encoder_padding, g->enc_padding, int)
 /* ENCDELAY + POSTDELAY + samples taken in - samples encoded; 0 after the flush (reference lame.c:1737-1766, 2117) */
-GETTER(lame_get_mf_samples_to_encode, (!g->inited || g->flushed) ? 0 : (int) (LH_ENCDELAY + LH_POSTDELAY + g->fed - 1152LL * g->frames_done), int)
+GETTER(lame_get_mf_samples_to_encode, (!g->inited || g->flushed) ? 0 : (int) (LH_ENCDELAY + LH_POSTDELAY + g->fed - (long long) fs_of(g->cfg) * g->frames_done), int)
 
 extern "C" int
 lame_set_num_samples(lame_t g, unsigned long n)
@@ -696,11 +710,11 @@ lame_get_totalframes(const lame_t g)
         n *= q;
     }
     n += 576;
-    padding = 1152 - (n % 1152);
+    padding = (unsigned long) fs_of(g->cfg) - (n % (unsigned long) fs_of(g->cfg));
     if (padding < 576)
-        padding += 1152;
+        padding += (unsigned long) fs_of(g->cfg);
     n += padding;
-    return (int) (n / 1152);
+    return (int) (n / (unsigned long) fs_of(g->cfg));
 }
 
 /* histograms over the frames encoded so far (reference lame.c:2461-2610) */
@@ -896,10 +910,10 @@ handle_encode_frames(lame_t g, int upto, unsigned char *mp3buf, int mp3buf_size,
     if (nf <= 0)
         return 0;
     /* samples touched: priming of frame 0 reaches 1152 further back (all zero there) */
-    p0 = 1152LL * f0 - LH_MF_START - 1152;
+    p0 = (long long) fs_of(g->cfg) * f0 - LH_MF_START - fs_of(g->cfg);
     if (p0 < g->hist_base)
         p0 = g->hist_base;
-    p1 = 1152LL * (upto - 1) - LH_MF_START + LH_MF_NEEDED;
+    p1 = (long long) fs_of(g->cfg) * (upto - 1) - LH_MF_START + LH_MF_NEEDED;
     if (p1 > g->fed)
         p1 = g->fed;
     n = p1 > p0 ? p1 - p0 : 0;
@@ -991,7 +1005,7 @@ handle_encode_frames(lame_t g, int upto, unsigned char *mp3buf, int mp3buf_size,
     g->frames_done = upto;
     /* drop history that no later frame (nor its priming) can touch */
     {
-        long long keep = 1152LL * g->frames_done - LH_MF_START - 64;
+        long long keep = (long long) fs_of(g->cfg) * g->frames_done - LH_MF_START - 64;
         if (keep > g->hist_base) {
             size_t  drop = (size_t) (keep - g->hist_base);
             if (drop > g->hl.size())
@@ -1061,7 +1075,7 @@ encode_buffer_impl(lame_t g, const T * l, const T * r, int nsamples, int jump, f
             float   blk[2][1152];
             int     used = 0, made = 0;
             for (int ch = 0; ch < g->cfg.channels; ch++)
-                made = lh_rs_block(g->rs, ch, blk[ch], 1152, (ch ? g->tr.data() : g->tl.data()) + pos, left, &used);
+                made = lh_rs_block(g->rs, ch, blk[ch], fs_of(g->cfg), (ch ? g->tr.data() : g->tl.data()) + pos, left, &used);
             if (g->cfg.channels == 1)
                 memset(blk[1], 0, sizeof(blk[1]));
             g->hl.insert(g->hl.end(), blk[0], blk[0] + made);
@@ -1077,8 +1091,8 @@ encode_buffer_impl(lame_t g, const T * l, const T * r, int nsamples, int jump, f
         /* (the reference's loop hands the analysis what one fill_buffer call took in: at most a frame's samples) */
         if (g->rg) {
             size_t const at = g->hl.size() - (size_t) nsamples;
-            for (int pos = 0; pos < nsamples; pos += 1152) {
-                int const m = nsamples - pos > 1152 ? 1152 : nsamples - pos;
+            for (int pos = 0; pos < nsamples; pos += fs_of(g->cfg)) {
+                int const m = nsamples - pos > fs_of(g->cfg) ? fs_of(g->cfg) : nsamples - pos;
                 (void) lh_rg_block(g->rg, g->hl.data() + at + (size_t) pos, g->hr.data() + at + (size_t) pos, m, g->cfg.channels);
             }
         }
@@ -1087,8 +1101,8 @@ encode_buffer_impl(lame_t g, const T * l, const T * r, int nsamples, int jump, f
     g->flushed = 0;
     /* a frame is encoded whenever 1904 samples are buffered behind the 528-sample
      * lead-in (reference lame.c:1737-1769) */
-    avail = (LH_MF_START + g->fed >= LH_MF_NEEDED)
-        ? (int) ((LH_MF_START + g->fed - LH_MF_NEEDED) / 1152 + 1) : 0;
+    avail = (LH_MF_START + g->fed >= mfn_of(g->cfg))
+        ? (int) ((LH_MF_START + g->fed - mfn_of(g->cfg)) / fs_of(g->cfg) + 1) : 0;
     if (emit_tag_placeholder(g, mp3buf, mp3buf_size, &written))
         return -1;
     rc = handle_encode_frames(g, avail, mp3buf, mp3buf_size, &written);
@@ -1186,17 +1200,17 @@ flush_resampled(lame_t g, unsigned char *mp3buf, int size)
     static const short zeros[1152] = { 0 };
     double const ratio = g->rs->ratio;
     /* mf_samples_to_encode - POSTDELAY, with mf_samples_to_encode = ENCDELAY + POSTDELAY + fed - 1152 frames */
-    int     owed = (int) (576 + g->fed - 1152LL * g->frames_done);
+    int     owed = (int) (576 + g->fed - (long long) fs_of(g->cfg) * g->frames_done);
     int     padding, frames_left, written = 0;
     owed += 16. / ratio;
-    padding = 1152 - (owed % 1152);
+    padding = fs_of(g->cfg) - (owed % fs_of(g->cfg));
     if (padding < 576)
-        padding += 1152;
+        padding += fs_of(g->cfg);
     g->enc_padding = padding;
-    frames_left = (owed + padding) / 1152;
+    frames_left = (owed + padding) / fs_of(g->cfg);
     while (frames_left > 0) {
         int const before = g->frames_done;
-        int     bunch = LH_MF_NEEDED - (int) (LH_MF_START + g->fed - 1152LL * g->frames_done);
+        int     bunch = mfn_of(g->cfg) - (int) (LH_MF_START + g->fed - (long long) fs_of(g->cfg) * g->frames_done);
         int     k;
         bunch *= ratio;
         if (bunch > 1152)
@@ -1231,24 +1245,24 @@ lame_encode_flush(lame_t g, unsigned char *mp3buf, int size)
         static const float zeros[1152] = { 0 };
         long long fed = g->fed;
         int     frames = g->frames_done;
-        int const owed = (int) (576 + fed - 1152LL * frames);
-        int     padding = 1152 - (owed % 1152), frames_left;
+        int const owed = (int) (576 + fed - (long long) fs_of(g->cfg) * frames);
+        int     padding = fs_of(g->cfg) - (owed % fs_of(g->cfg)), frames_left;
         if (padding < 576)
-            padding += 1152;
-        frames_left = (owed + padding) / 1152;
+            padding += fs_of(g->cfg);
+        frames_left = (owed + padding) / fs_of(g->cfg);
         while (frames_left > 0) {
-            int     bunch = LH_MF_NEEDED - (int) (LH_MF_START + fed - 1152LL * frames);
+            int     bunch = mfn_of(g->cfg) - (int) (LH_MF_START + fed - (long long) fs_of(g->cfg) * frames);
             bunch = bunch > 1152 ? 1152 : (bunch < 1 ? 1 : bunch);
             (void) lh_rg_block(g->rg, zeros, zeros, bunch, g->cfg.channels);
             fed += bunch;
-            if (LH_MF_START + fed - 1152LL * frames >= LH_MF_NEEDED) {
+            if (LH_MF_START + fed - (long long) fs_of(g->cfg) * frames >= mfn_of(g->cfg)) {
                 frames++;
                 frames_left--;
             }
         }
     }
-    total = lh_total_frames((long) g->fed);
-    g->enc_padding = lh_end_padding((long) g->fed);     /* reference lame.c:2088-2091 */
+    total = lh_total_frames_fs((long) g->fed, fs_of(g->cfg));
+    g->enc_padding = lh_end_padding_fs((long) g->fed, fs_of(g->cfg));     /* reference lame.c:2088-2091 */
     if (emit_tag_placeholder(g, mp3buf, size, &written))
         return -1;
     rc = handle_encode_frames(g, total, mp3buf, size, &written);
@@ -1503,7 +1517,7 @@ struct lamehip_batch {
 static int
 batch_padding(const lamehip_batch * b, int s)
 {
-    return b->rate_in ? b->padding[(size_t) s] : lh_end_padding(b->len[(size_t) s]);
+    return b->rate_in ? b->padding[(size_t) s] : lh_end_padding_fs(b->len[(size_t) s], fs_of(b->cfg));
 }
 
 /* every stream back to its initial state: a device-to-device copy of the pristine image on the batch's own
@@ -1700,7 +1714,7 @@ lamehip_batch_set_length(lamehip_batch * b, int s, long n)
     if (!b || s < 0 || s >= b->B || n < 0 || n > b->cap || b->rate_in)
         return -1;              /* (a converting batch needs the samples themselves: lamehip_batch_set_pcm) */
     b->len[(size_t) s] = n;
-    b->nframes[(size_t) s] = lh_total_frames(n);
+    b->nframes[(size_t) s] = lh_total_frames_fs(n, fs_of(b->cfg));
     return 0;
 }
 
@@ -1721,16 +1735,16 @@ batch_convert_stream(lamehip_batch * b, int s, const short *l, const short *r, l
         while (m > 0) {
             int     used = 0, made = 0;
             for (int ch = 0; ch < b->cfg.channels; ch++)
-                made = lh_rs_block(b->rs, ch, blk[ch], 1152, (ch ? ir : il) + at, m, &used);
+                made = lh_rs_block(b->rs, ch, blk[ch], fs_of(b->cfg), (ch ? ir : il) + at, m, &used);
             if (b->cfg.channels == 1)
                 memset(blk[1], 0, sizeof(blk[1]));
             ol.insert(ol.end(), blk[0], blk[0] + made);
             orr.insert(orr.end(), blk[1], blk[1] + made);
             fed += made;
             mf_size += made;
-            if (mf_size >= LH_MF_NEEDED) {
+            if (mf_size >= mfn_of(b->cfg)) {
                 frames++;
-                mf_size -= 1152;
+                mf_size -= fs_of(b->cfg);
             }
             at += used;
             m -= used;
@@ -1739,8 +1753,8 @@ batch_convert_stream(lamehip_batch * b, int s, const short *l, const short *r, l
     lh_rs_init(b->rs, b->rate_in, b->cfg.samplerate);
     ol.reserve((size_t) ((double) n / ratio) + 4096);
     orr.reserve((size_t) ((double) n / ratio) + 4096);
-    for (long pos = 0; pos < n; pos += 1152) {
-        int const m = (n - pos) > 1152 ? 1152 : (int) (n - pos);
+    for (long pos = 0; pos < n; pos += fs_of(b->cfg)) {
+        int const m = (n - pos) > fs_of(b->cfg) ? fs_of(b->cfg) : (int) (n - pos);
         for (int i = 0; i < m; i++) {
             float const xl = (float) l[pos + i], xr = (float) r[pos + i];
             il[i] = xl * m00 + xr * m01;
@@ -1748,17 +1762,17 @@ batch_convert_stream(lamehip_batch * b, int s, const short *l, const short *r, l
         }
         feed(m);
     }
-    owed = (int) (576 + fed - 1152L * frames);
+    owed = (int) (576 + fed - (long) fs_of(b->cfg) * frames);
     owed += 16. / ratio;
-    padding = 1152 - (owed % 1152);
+    padding = fs_of(b->cfg) - (owed % fs_of(b->cfg));
     if (padding < 576)
-        padding += 1152;
-    frames_left = (owed + padding) / 1152;
+        padding += fs_of(b->cfg);
+    frames_left = (owed + padding) / fs_of(b->cfg);
     memset(il, 0, sizeof(il));
     memset(ir, 0, sizeof(ir));
     while (frames_left > 0) {
         int const before = frames;
-        int     bunch = (int) (LH_MF_NEEDED - mf_size);
+        int     bunch = (int) (mfn_of(b->cfg) - mf_size);
         bunch *= ratio;
         if (bunch > 1152)
             bunch = 1152;
@@ -2101,10 +2115,10 @@ lamehip_batch_append(lamehip_batch * b, int s, const short *l, const short *r, i
 /* frames of a stream that are complete once `fed' samples are in: frame f reads 1904 samples from
  * 1152 f - 528 on (reference lame.c:1737-1766) */
 static int
-frames_complete(long fed)
+frames_complete(long fed, const LhConfig & c)
 {
     long const have = fed + LH_MF_START;
-    return have >= LH_MF_NEEDED ? (int) ((have - LH_MF_NEEDED) / 1152 + 1) : 0;
+    return have >= mfn_of(c) ? (int) ((have - mfn_of(c)) / fs_of(c) + 1) : 0;
 }
 
 /* encode frames [done, upto[s]) of every stream and pack them into pending[]; `end' marks the
@@ -2198,7 +2212,7 @@ lamehip_batch_encode_available(lamehip_batch * b)
         return rc;
     upto.resize((size_t) b->B);
     for (int s = 0; s < b->B; s++)
-        upto[(size_t) s] = frames_complete(b->fed[(size_t) s] + b->staged[(size_t) s]);
+        upto[(size_t) s] = frames_complete(b->fed[(size_t) s] + b->staged[(size_t) s], b->cfg);
     return batch_encode_range(b, upto, 0);
 }
 
@@ -2224,7 +2238,7 @@ lamehip_batch_finish(lamehip_batch * b)
     for (int s = 0; s < b->B; s++) {
         long const len = b->fed[(size_t) s] + b->staged[(size_t) s];
         b->len[(size_t) s] = len;
-        b->nframes[(size_t) s] = lh_total_frames(len);
+        b->nframes[(size_t) s] = lh_total_frames_fs(len, fs_of(b->cfg));
         upto[(size_t) s] = b->nframes[(size_t) s];
     }
     n = batch_encode_range(b, upto, 1);

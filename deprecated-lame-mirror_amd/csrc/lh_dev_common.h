@@ -471,6 +471,7 @@ struct LhCtx {
     /* the settings the iteration loop tests again and again, read from HBM once (scalar
      * registers) instead of once per use */
     int     ns, ns_amp, sfb21_extra, full_outer_loop, subblock_gain;
+    int     lsf, rate8k;        /* MPEG-2 / 2.5 (one granule per frame, partitioned scalefactors); an 8 kHz stream */
 };
 
 LH_DEVFN void
@@ -481,6 +482,8 @@ lh_ctx_hot(LhCtx & c)
     c.sfb21_extra = lh_uni_i(c.cfg->sfb21_extra);
     c.full_outer_loop = lh_uni_i(c.cfg->full_outer_loop);
     c.subblock_gain = lh_uni_i(c.cfg->subblock_gain);
+    c.lsf = lh_uni_i(c.cfg->mode_gr == 1);
+    c.rate8k = lh_uni_i(c.cfg->samplerate <= 8000);
 }
 
 /* The context reaches an out-of-line stage through per-lane memory, which hides from the

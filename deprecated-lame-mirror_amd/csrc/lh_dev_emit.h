@@ -73,7 +73,24 @@ lh_emit_part(const LhCtx & c, LhChanLds & Q, const LhQR & R, const LhGrR & g, co
     for (int i = lane; i < LH_EMIT_WORDS; i += 64)
         buf[i] = 0u;
     LH_WAVE_SYNC();
-    {
+    if (c.lsf) {
+        /* part 2, MPEG-2 / 2.5 (reference bitstream.c:735-770): four partitions with their own widths, both read from
+         * scalefac_compress the way lh_scale_bitcount_lsf wrote it; every scalefactor of a partition is written (a
+         * negative one as 0) */
+        int const sc = g.scalefac_compress, pre = sc >= 500, sh = (R.block_type == LH_SHORT_TYPE);
+        uint32_t const ends = pre ? (sh ? 0x24242412u : 0x1515150bu) : (sh ? 0x241b1209u : 0x15100b06u);
+        int const w0 = pre ? (sc - 500) / 3 : (sc >> 4) / 5, w1 = pre ? (sc - 500) % 3 : (sc >> 4) % 5;
+        int const w2 = pre ? 0 : (sc >> 2) & 3, w3 = pre ? 0 : sc & 3;
+        int const part = (lane >= (int) (ends & 255u)) + (lane >= (int) ((ends >> 8) & 255u)) + (lane >= (int) ((ends >> 16) & 255u));
+        int const inp = lane < (int) (ends >> 24);
+        int const sfv = (inp && lane < LH_SFBMAX) ? Q.sf[0][lane < LH_SFBMAX ? lane : 0] : 0;
+        int const sf = sfv < 0 ? 0 : sfv;
+        int const len = inp ? (part == 0 ? w0 : part == 1 ? w1 : part == 2 ? w2 : w3) : 0;
+        uint32_t const incl = lh_wave_scan_u32((uint32_t) len);
+        lh_put_bits(buf, (int) incl - len, (uint32_t) sf, len);
+        pos = (int) lh_bcast_u32(incl, 63);
+    }
+    else {
         /* part 2: one lane per scalefactor band; -1 = shared with granule 0 through scfsi */
         int const s1 = (int) ((0x4433322211130000ull >> (4 * g.scalefac_compress)) & 15u);
         int const s2 = (int) ((0x3232132132103210ull >> (4 * g.scalefac_compress)) & 15u);
@@ -230,7 +247,7 @@ lh_emit_header(const LhConfig * cfg, const LhFrameOut * fo, int mdb, int bitrate
 #define LH_HB(val, n) do { int v_ = (int) (val), j_ = (n); \
         while (j_ > 0) { int const k_ = (j_ < 8 - (ptr & 7)) ? j_ : 8 - (ptr & 7); j_ -= k_; \
             h[ptr >> 3] = (unsigned char) (h[ptr >> 3] | ((v_ >> j_) << (8 - (ptr & 7) - k_))); ptr += k_; } } while (0)
-    LH_HB(0xfff, 12);
+    LH_HB(cfg->samplerate < 16000 ? 0xffe : 0xfff, 12);
     LH_HB(cfg->version, 1);
     LH_HB(4 - 3, 2);
     LH_HB(!cfg->error_protection, 1);
@@ -245,18 +262,25 @@ lh_emit_header(const LhConfig * cfg, const LhFrameOut * fo, int mdb, int bitrate
     LH_HB(cfg->emphasis, 2);
     if (cfg->error_protection)
         LH_HB(0, 16);
-    LH_HB(mdb, 9);
-    LH_HB(0, cfg->channels == 2 ? 3 : 5);
-    for (int ch = 0; ch < cfg->channels; ch++)
-        for (int band = 0; band < 4; band++)
-            LH_HB(scfsi[ch][band], 1);
-    for (int gr = 0; gr < 2; gr++)
+    if (cfg->version == 1) {
+        LH_HB(mdb, 9);
+        LH_HB(0, cfg->channels == 2 ? 3 : 5);
+        for (int ch = 0; ch < cfg->channels; ch++)
+            for (int band = 0; band < 4; band++)
+                LH_HB(scfsi[ch][band], 1);
+    }
+    else {
+        /* MPEG-2 / 2.5 (reference bitstream.c:420-467) */
+        LH_HB(mdb, 8);
+        LH_HB(0, cfg->channels);
+    }
+    for (int gr = 0; gr < cfg->mode_gr; gr++)
         for (int ch = 0; ch < cfg->channels; ch++) {
             const LhGranule *gi = &fo->gr[gr][ch];
             LH_HB(gi->part2_3_length + gi->part2_length, 12);
             LH_HB(gi->big_values / 2, 9);
             LH_HB(gi->global_gain, 8);
-            LH_HB(gi->scalefac_compress, 4);
+            LH_HB(gi->scalefac_compress, cfg->version == 1 ? 4 : 9);
             if (gi->block_type != LH_NORM_TYPE) {
                 LH_HB(1, 1);
                 LH_HB(gi->block_type, 2);
@@ -275,7 +299,8 @@ lh_emit_header(const LhConfig * cfg, const LhFrameOut * fo, int mdb, int bitrate
                 LH_HB(gi->region0_count, 4);
                 LH_HB(gi->region1_count, 3);
             }
-            LH_HB(gi->preflag, 1);
+            if (cfg->version == 1)
+                LH_HB(gi->preflag, 1);
             LH_HB(gi->scalefac_scale, 1);
             LH_HB(gi->count1table_select, 1);
         }
@@ -351,7 +376,7 @@ lh_emit_frame(const LhFrameOut * fo_in, int drain_pre, int drain_post, int frame
 
     LH_SYNC_WG();
     nbits = drain_pre;
-    for (int gr = 0; gr < 2; gr++)
+    for (int gr = 0; gr < cfg->mode_gr; gr++)
         for (int ch = 0; ch < nch; ch++) {
             const LhGranule *gi = &fo->gr[gr][ch];
             poff[np] = nbits;

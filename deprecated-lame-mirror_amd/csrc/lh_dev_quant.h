@@ -622,6 +622,42 @@ lh_noquant_count_bits(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, int w
 }
 
 /* ---------------------------------------------------------------------- */
+/* MPEG-2 / 2.5 (reference takehiro.c:1195-1317, mpeg2_scale_bitcount): the scalefactors travel in four partitions of
+ * fixed sizes (ISO 13818-3 2.4.3.2), each with its own field width = the bit length of the partition's largest value;
+ * table 0 without preflag (6 5 5 5 long bands / 9 9 9 9 short values; ranges 15 15 7 7), table 2 with it (11 10 / 18 18;
+ * ranges 7 3).  Lane s holds scalefactor s (`v').  Each lane contributes the thermometer code of its value's bit length
+ * in its partition's byte, one OR over the wave gives all four maxima's bit lengths; the rest is scalar.  Returns the
+ * number of partitions over their range (then g stays as it is, as in the reference). */
+LH_DEVFN int
+lh_scale_bitcount_lsf(const LhCtx & c, const LhQR & R, LhGrR & g, int v)
+{
+    int const sh = (R.block_type == LH_SHORT_TYPE);
+    /* partition ends (in scalefactor values) and range bit lengths, one byte each */
+    uint32_t const ends = g.preflag ? (sh ? 0x24242412u : 0x1515150bu) : (sh ? 0x241b1209u : 0x15100b06u);
+    uint32_t const rbits = g.preflag ? 0x00000203u : 0x03030404u;
+    int const s = c.lane;
+    int const part = (s >= (int) (ends & 255u)) + (s >= (int) ((ends >> 8) & 255u)) + (s >= (int) ((ends >> 16) & 255u));
+    int     bl = 32 - lh_clz32((uint32_t) (v > 0 ? v : 0));
+    uint32_t th;
+    int     over = 0, slen[4], n[4], p, prev = 0;
+    bl = bl > 8 ? 8 : bl;
+    th = lh_wave_or_u32((s < (int) (ends >> 24)) ? (((1u << bl) - 1u) << (8 * part)) : 0u);
+#pragma unroll
+    for (p = 0; p < 4; p++) {
+        int const e = (int) ((ends >> (8 * p)) & 255u);
+        slen[p] = lh_popc64((uint64_t) ((th >> (8 * p)) & 255u));
+        n[p] = e - prev;
+        prev = e;
+        over += slen[p] > (int) ((rbits >> (8 * p)) & 255u);
+    }
+    if (!over) {
+        g.scalefac_compress = g.preflag ? 500 + slen[0] * 3 + slen[1]
+            : (((slen[0] * 5) + slen[1]) << 4) + (slen[2] << 2) + slen[3];
+        g.part2_length = slen[0] * n[0] + slen[1] * n[1] + slen[2] * n[2] + slen[3] * n[3];
+    }
+    return over;
+}
+
 /* reference takehiro.c:1135-1188 (MPEG-1); band s on lane s, maxima by wave reduction */
 LH_DEVFN int
 lh_scale_bitcount(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g, int which)
@@ -632,6 +668,8 @@ lh_scale_bitcount(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g, int
     int     v;
     LH_WAVE_SYNC();
     v = (c.lane < R.sfbmax) ? sf[c.lane] : 0;
+    if (c.lsf)
+        return lh_scale_bitcount_lsf(c, R, g, v);
     if (R.block_type != LH_SHORT_TYPE) {
         if (!g.preflag) {
             int const inr = (c.lane >= 11 && c.lane < LH_SBPSY_L);
@@ -786,9 +824,9 @@ lh_calc_xmin_body(const LhCtx & c, LhChanLds & Q, LhQR & R, const float *xr, con
         if (c.sfb21_extra == 0 && cfg->samplerate < 44000) {
             int     limit;
             if (R.block_type != LH_SHORT_TYPE)
-                limit = qt->sfb_l[21] - 1;
+                limit = qt->sfb_l[c.rate8k ? 17 : 21] - 1;
             else
-                limit = 3 * T->sfb_s[12] - 1;
+                limit = 3 * T->sfb_s[c.rate8k ? 9 : 12] - 1;
             if (max_nonzero > limit)
                 max_nonzero = limit;
         }
@@ -849,17 +887,18 @@ lh_init_outer_loop_body(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, flo
     g.count1bits = 0;
     g.xrpow_max = 0;
     R.block_type = block_type;
-    R.sfb_lmax = LH_SBPSY_L;
-    R.sfb_smin = LH_SBPSY_S;
-    R.psy_lmax = sfb21 ? LH_SBMAX_L : LH_SBPSY_L;
+    /* (an 8 kHz stream codes 17 long / 9 short bands: reference quantize.c:252-256, 284-294) */
+    R.sfb_lmax = c.rate8k ? 17 : LH_SBPSY_L;
+    R.sfb_smin = c.rate8k ? 9 : LH_SBPSY_S;
+    R.psy_lmax = c.rate8k ? 17 : (sfb21 ? LH_SBMAX_L : LH_SBPSY_L);
     R.psymax = R.psy_lmax;
     R.sfbmax = R.sfb_lmax;
     R.sfbdivide = 11;
     if (block_type == LH_SHORT_TYPE) {
         R.sfb_smin = 0;
         R.sfb_lmax = 0;
-        R.psymax = 3 * ((sfb21 ? LH_SBMAX_S : LH_SBPSY_S));
-        R.sfbmax = 3 * LH_SBPSY_S;
+        R.psymax = c.rate8k ? 3 * 9 : 3 * ((sfb21 ? LH_SBMAX_S : LH_SBPSY_S));
+        R.sfbmax = c.rate8k ? 3 * 9 : 3 * LH_SBPSY_S;
         R.sfbdivide = R.sfbmax - 18;
         R.psy_lmax = 0;
     }
@@ -1073,7 +1112,7 @@ lh_best_scalefac_store_body(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGr
             g.scalefac_scale = recalc = 1;
         }
     }
-    if (!g.preflag && R.block_type != LH_SHORT_TYPE) {
+    if (!g.preflag && R.block_type != LH_SHORT_TYPE && !c.lsf) {
         int const hi = (s >= 11 && s < LH_SBPSY_L);
         int const pre = qt->pretab[s < 22 ? s : 0];
         if (!lh_ballot(hi && sfv < pre && sfv != -2)) {
@@ -1083,7 +1122,7 @@ lh_best_scalefac_store_body(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGr
         }
     }
     LH_PA(41, t_bs0);
-    if (gr == 1 && g0_block_type != LH_SHORT_TYPE && R.block_type != LH_SHORT_TYPE) {
+    if (gr == 1 && !c.lsf && g0_block_type != LH_SHORT_TYPE && R.block_type != LH_SHORT_TYPE) {
         /* scfsi_calc: share a group of scalefactors with granule 0 when all of them agree */
         int const in21 = (s < LH_SBPSY_L);
         int const g0 = in21 ? (int) g0sf[s] : 0;
@@ -1313,6 +1352,8 @@ LH_DEVFN void
 lh_best_huffman_divide_body(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g)
 {
     const LhQTabs *qt = LH_QT;
+    if (c.lsf && R.block_type == LH_SHORT_TYPE)
+        return;                 /* an LSF short block is left alone (reference takehiro.c:898-900) */
     const int16_t *ix = Q.ix[0];
     int const lane = c.lane;
     int const bigv0 = g.big_values;
@@ -1566,7 +1607,7 @@ lh_best_huffman_divide(int qch)
 LH_DEVFN int
 lh_frame_bits(const LhConfig * cfg, int bitrate_index, int padding)
 {
-    int const bit_rate = lh_bitrate_mpeg1[bitrate_index];
+    int const bit_rate = cfg->version ? lh_bitrate_mpeg1[bitrate_index] : lh_bitrate_mpeg2[bitrate_index];
     return 8 * ((cfg->version + 1) * 72000 * bit_rate / cfg->samplerate + padding);
 }
 

@@ -457,13 +457,16 @@ lh_vbr_constrain_long(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g,
     int const s = c.lane;
     int const in = s < R.psymax;
     int const r = lh_vbr_range_long(s);
+    /* the range with preflag: MPEG-1's own, or the LSF partitions' 7 7 7 7 7 7 3 3 3 3 3 0 ... (max_range_long_lsf_pretab,
+     * reference vbrquantize.c:577-579, 861) */
+    int const rp = c.lsf ? (s < 6 ? 7 : (s < 11 ? 3 : 0)) : r;
     int const pt = (s < 22) ? (int) qt->pretab[s < 22 ? s : 0] : 0;
     int const v = vbrmax - sfw;
     int     delta = lh_wave_max0(in ? v : 0);
     int     over0 = lh_wave_max0(in ? v - 2 * r : 0);
     int     over1 = lh_wave_max0(in ? v - 4 * r : 0);
-    int     over0p = lh_wave_max0(in ? v - 2 * (r + pt) : 0);
-    int     over1p = lh_wave_max0(in ? v - 4 * (r + pt) : 0);
+    int     over0p = lh_wave_max0(in ? v - 2 * (rp + pt) : 0);
+    int     over1p = lh_wave_max0(in ? v - 4 * (rp + pt) : 0);
     int     pre0, pre1 = 0, mover;
     {
         int const gain = lh_imax(vbrmax - over0p, mingain_l);
@@ -508,7 +511,7 @@ lh_vbr_constrain_long(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g,
         g.preflag = 1;
     }
     g.global_gain = vbrmax < 0 ? 0 : (vbrmax > 255 ? 255 : vbrmax);
-    lh_vbr_scalefacs(c, Q, R, g, sfm, sfw - vbrmax, r);
+    lh_vbr_scalefacs(c, Q, R, g, sfm, sfw - vbrmax, g.preflag ? rp : r);
 }
 
 /* short_block_constrain + set_subblock_gain (reference vbrquantize.c:748-815, 553-642) */
@@ -896,12 +899,12 @@ lh_vbr_share(int share[2], const int use[2], int slack)
 }
 
 LH_DEVFN void
-lh_vbr_budgets(int nch, const int max_bits[2][2], const int use_ch[2][2], const int use_gr[2], int max_fr,
+lh_vbr_budgets(int ngr, int nch, const int max_bits[2][2], const int use_ch[2][2], const int use_gr[2], int max_fr,
                int max_ch[2][2])
 {
     int     max_gr[2], ok = 1, sum_fr = 0;
     max_ch[0][1] = max_ch[1][1] = 0;
-    for (int gr = 0; gr < 2; ++gr) {
+    for (int gr = 0; gr < ngr; ++gr) {
         max_gr[gr] = 0;
         for (int ch = 0; ch < nch; ++ch) {
             max_ch[gr][ch] = (use_ch[gr][ch] > LH_MAX_BITS_PER_CHANNEL) ? LH_MAX_BITS_PER_CHANNEL : use_ch[gr][ch];
@@ -932,20 +935,22 @@ lh_vbr_budgets(int nch, const int max_bits[2][2], const int use_ch[2][2], const 
     if (sum_fr > max_fr) {
         {
             float   f[2] = { 0.0f, 0.0f }, sm = 0.0f;
-            for (int gr = 0; gr < 2; ++gr) {
+            for (int gr = 0; gr < ngr; ++gr) {
                 if (max_gr[gr] > 0) {
                     f[gr] = (float) sqrt((double) max_gr[gr]);
                     sm += f[gr];
                 }
             }
-            for (int gr = 0; gr < 2; ++gr)
+            for (int gr = 0; gr < ngr; ++gr)
                 max_gr[gr] = (sm > 0) ? (int) (max_fr * f[gr] / sm) : 0;
         }
-        lh_vbr_share(max_gr, use_gr, 125);
-        for (int gr = 0; gr < 2; ++gr)
-            if (max_gr[gr] > LH_MAX_BITS_PER_GRANULE)
-                max_gr[gr] = LH_MAX_BITS_PER_GRANULE;
-        for (int gr = 0; gr < 2; ++gr) {
+        if (ngr > 1) {          /* (reference vbrquantize.c:1452-1468: only two granules have a share to pass on) */
+            lh_vbr_share(max_gr, use_gr, 125);
+            for (int gr = 0; gr < ngr; ++gr)
+                if (max_gr[gr] > LH_MAX_BITS_PER_GRANULE)
+                    max_gr[gr] = LH_MAX_BITS_PER_GRANULE;
+        }
+        for (int gr = 0; gr < ngr; ++gr) {
             float   f[2] = { 0.0f, 0.0f }, sm = 0.0f;
             for (int ch = 0; ch < nch; ++ch) {
                 if (max_ch[gr][ch] > 0) {
@@ -964,7 +969,7 @@ lh_vbr_budgets(int nch, const int max_bits[2][2], const int use_ch[2][2], const 
         }
     }
     sum_fr = 0;
-    for (int gr = 0; gr < 2; ++gr) {
+    for (int gr = 0; gr < ngr; ++gr) {
         int     sum_gr = 0;
         for (int ch = 0; ch < nch; ++ch) {
             sum_gr += max_ch[gr][ch];
@@ -978,7 +983,7 @@ lh_vbr_budgets(int nch, const int max_bits[2][2], const int use_ch[2][2], const 
     if (sum_fr > max_fr)
         ok = 0;
     if (!ok)
-        for (int gr = 0; gr < 2; ++gr)
+        for (int gr = 0; gr < ngr; ++gr)
             for (int ch = 0; ch < nch; ++ch)
                 max_ch[gr][ch] = max_bits[gr][ch];
 }
@@ -1006,18 +1011,18 @@ lh_vbr_frame(LhFrameOut * fo_in, int mode_ext, int msoff)
     int const maxi = cfg->vbr_max_bitrate_index;
     mode_ext = lh_uni_i(mode_ext);
     msoff = lh_uni_i(msoff);
-    int const nch = cfg->channels;
+    int const nch = cfg->channels, ngr = lh_uni_i(cfg->mode_gr);
     int     avg, resv_top, top_bits, dummy;
     int     max_bits[2][2], use_ch[2][2], use_gr[2], use_fr, max_fr = 0, bits = 0;
     int     analog_silence, pad, used, ok;
 
     top_bits = lh_vbr_full_bits(cfg, maxi, ResvSize, &avg, &resv_top);
     pad = resv_top;
-    for (int gr = 0; gr < 2; gr++) {
+    for (int gr = 0; gr < ngr; gr++) {
         (void) lh_on_pe(cfg, ResvSize, resv_top, &substep, pe_use[gr], max_bits[gr], avg, 0);
         bits += max_bits[gr][0] + max_bits[gr][1];
     }
-    for (int gr = 0; gr < 2; gr++)
+    for (int gr = 0; gr < ngr; gr++)
         for (int ch = 0; ch < 2; ch++)
             if (bits > top_bits && bits > 0) {
                 max_bits[gr][ch] *= top_bits;
@@ -1035,7 +1040,7 @@ lh_vbr_frame(LhFrameOut * fo_in, int mode_ext, int msoff)
         }
     }
     LH_SYNC_WG();
-    for (int gr = 0; gr < 2; gr++) {
+    for (int gr = 0; gr < ngr; gr++) {
         if (w < nch)
             lh_vbr_granule(w, gr, msoff + w, 0, max_bits[gr][w], 0, substep, &fo->gr[gr][w], fo->gr[0][w].scalefac);
         else {
@@ -1048,7 +1053,7 @@ lh_vbr_frame(LhFrameOut * fo_in, int mode_ext, int msoff)
     LH_SYNC_WG();
     analog_silence = 1;
     use_fr = 0;
-    for (int gr = 0; gr < 2; gr++) {
+    for (int gr = 0; gr < ngr; gr++) {
         use_gr[gr] = 0;
         use_ch[gr][1] = 0;
         for (int ch = 0; ch < nch; ch++) {
@@ -1066,7 +1071,7 @@ lh_vbr_frame(LhFrameOut * fo_in, int mode_ext, int msoff)
     if (analog_silence)
         pad = 0;
     ok = (use_fr <= max_fr);
-    for (int gr = 0; gr < 2; gr++) {
+    for (int gr = 0; gr < ngr; gr++) {
         if (use_gr[gr] > LH_MAX_BITS_PER_GRANULE)
             ok = 0;
         for (int ch = 0; ch < nch; ch++)
@@ -1076,15 +1081,15 @@ lh_vbr_frame(LhFrameOut * fo_in, int mode_ext, int msoff)
     used = use_fr;
     if (!ok) {
         int     max_ch[2][2];
-        lh_vbr_budgets(nch, max_bits, use_ch, use_gr, max_fr, max_ch);
+        lh_vbr_budgets(ngr, nch, max_bits, use_ch, use_gr, max_fr, max_ch);
         LH_SYNC_WG();
-        for (int gr = 0; gr < 2; gr++)
+        for (int gr = 0; gr < ngr; gr++)
             if (w < nch)
                 lh_vbr_granule(w, gr, msoff + w, 1, max_bits[gr][w], max_ch[gr][w], substep, &fo->gr[gr][w],
                                fo->gr[0][w].scalefac);
         LH_SYNC_WG();
         used = 0;
-        for (int gr = 0; gr < 2; gr++)
+        for (int gr = 0; gr < ngr; gr++)
             for (int ch = 0; ch < nch; ch++)
                 used += lh_uni_i(L.vbr[gr][ch].use_bits);
     }
@@ -1146,7 +1151,7 @@ lh_abr_target_bits(const LhConfig * cfg, int ResvSize, int substep, float pe[2][
         f = f > 1.00 ? 1.00 : f;
         base = f;
     }
-    for (int gr = 0; gr < 2; gr++) {
+    for (int gr = 0; gr < cfg->mode_gr; gr++) {
         int     granule = 0;
         for (int ch = 0; ch < nch; ch++) {
             int     t = base * per_part;
@@ -1171,16 +1176,16 @@ lh_abr_target_bits(const LhConfig * cfg, int ResvSize, int substep, float pe[2][
                 targ_bits[gr][ch] = targ_bits[gr][ch] * LH_MAX_BITS_PER_GRANULE / granule;
     }
     if (mode_ext == LH_MPG_MD_MS_LR)
-        for (int gr = 0; gr < 2; gr++)
+        for (int gr = 0; gr < cfg->mode_gr; gr++)
             lh_reduce_side(targ_bits[gr], ms_ener_ratio[gr], per_part * nch, LH_MAX_BITS_PER_GRANULE);
-    for (int gr = 0; gr < 2; gr++)
+    for (int gr = 0; gr < cfg->mode_gr; gr++)
         for (int ch = 0; ch < nch; ch++) {
             if (targ_bits[gr][ch] > LH_MAX_BITS_PER_CHANNEL)
                 targ_bits[gr][ch] = LH_MAX_BITS_PER_CHANNEL;
             granted += targ_bits[gr][ch];
         }
     if (granted > frame_cap && granted > 0)
-        for (int gr = 0; gr < 2; gr++)
+        for (int gr = 0; gr < cfg->mode_gr; gr++)
             for (int ch = 0; ch < nch; ch++)
                 targ_bits[gr][ch] = targ_bits[gr][ch] * frame_cap / granted;
 }

@@ -54,6 +54,7 @@ lh_adjust_ATH(const LhTables * T, const float loud[2][2], float *factor, float *
     }
     {
         float const first = loud[0][0] + loud[0][1], second = loud[1][0] + loud[1][1];
+        /* (MPEG-2 / 2.5: the frame's only granule, reference encoder.c:80-82: loud[1] is passed as loud[0] then) */
         level = (first > second) ? first : second;
         level = (float) (level * 0.5);
         level *= T->aa_sensitivity_p;
@@ -240,6 +241,11 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
     /* mono: wave 1 has no channel; it runs the transforms on the duplicated PCM (never read) and
      * only keeps pace through the barriers of the quantisation stage */
     int const nch = cfg->channels;
+    /* granules per frame: 2, or 1 for MPEG-2 / 2.5 (576 samples per frame; reference lame.c:797).  The transforms
+     * below always run over two granules' worth of the staged window -- the second is the next frame's first and
+     * is thrown away -- so that the one-granule frame needs no code of its own there. */
+    int const ngr = lh_uni_i(cfg->mode_gr);
+    int const fs = 576 * ngr;
 
     /* ---- polyphase priming on the first frame (reference encoder.c:189-236) ---- */
 #if defined(LH_PROF) && !defined(LH_EMU)
@@ -248,12 +254,12 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
 #endif
     LH_PT(t_frame);
     if (!lh_lds.ss.primed) {
-        lh_stage_window(c, L.mf, c.frame_base - 1152);
+        lh_stage_window(c, L.mf, c.frame_base - fs);
         LH_SYNC_WG();
         lh_polyphase(w);
 #pragma unroll
         for (int k = 0; k < 9; k++)
-            carry.sb[k] = L.u.mdct.sb[w][2][lane + 64 * k];
+            carry.sb[k] = L.u.mdct.sb[w][ngr][lane + 64 * k];
         LH_SYNC_WG();
         if (tid == 0)
             lh_lds.ss.primed = 1;
@@ -278,13 +284,19 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
     LH_PA(24, t_frame);
     /* ---- stage 1: psycho-acoustic model, two granules ---- */
     LH_PT(t_psy);
-    for (int gr = 0; gr < 2; gr++)
+    for (int gr = 0; gr < ngr; gr++)
         carry.nb = lh_psy_granule(gr, carry.nb);
+    if (ngr == 1) {
+        /* the transforms below also run over the window's second granule (thrown away): give it a block type */
+        if (tid < 2)
+            L.block_type[1][tid] = LH_NORM_TYPE;
+        LH_SYNC_WG();
+    }
     LH_PA(1, t_psy);
 
     float   ms_ener_ratio[2] = { .5f, .5f };
     if (cfg->mode == LH_MODE_JOINT_STEREO) {
-        for (int gr = 0; gr < 2; gr++) {
+        for (int gr = 0; gr < ngr; gr++) {
             float   r = L.tot_ener[gr][2] + L.tot_ener[gr][3];
             if (r > 0)
                 r = L.tot_ener[gr][3] / r;
@@ -297,10 +309,10 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
         float   factor = lh_lds.ss.ath_adjust_factor, limit = lh_lds.ss.ath_adjust_limit;
         float   loud[2][2];
         loud[0][0] = L.loudness_sq[0][0];
-        loud[1][0] = L.loudness_sq[1][0];
+        loud[1][0] = L.loudness_sq[ngr - 1][0];
         /* one channel counts twice (reference encoder.c:72-79) */
         loud[0][1] = (cfg->channels == 2) ? L.loudness_sq[0][1] : loud[0][0];
-        loud[1][1] = (cfg->channels == 2) ? L.loudness_sq[1][1] : loud[1][0];
+        loud[1][1] = (cfg->channels == 2) ? L.loudness_sq[ngr - 1][1] : loud[1][0];
         lh_adjust_ATH(T, loud, &factor, &limit);
         LH_SYNC_WG();
         if (tid == 0) {
@@ -321,7 +333,7 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
     lh_mdct_granules(w);
 #pragma unroll
     for (int k = 0; k < 9; k++)
-        carry.sb[k] = L.u.mdct.sb[w][2][lane + 64 * k];
+        carry.sb[k] = L.u.mdct.sb[w][ngr][lane + 64 * k];
     LH_SYNC_WG();
     LH_PA(2, t_mdct);
     lh_load_qtabs(c, L.qt);     /* mf is dead; xr stays */
@@ -340,13 +352,13 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
         mode_ext = LH_MPG_MD_MS_LR;
     else if (cfg->mode == LH_MODE_JOINT_STEREO) {
         float   sum_pe_MS = 0, sum_pe_LR = 0;
-        for (int gr = 0; gr < 2; gr++)
+        for (int gr = 0; gr < ngr; gr++)
             for (int ch = 0; ch < 2; ch++) {
                 sum_pe_MS += L.pe[gr][2 + ch];
                 sum_pe_LR += L.pe[gr][ch];
             }
         if (sum_pe_MS <= 1.00 * sum_pe_LR) {
-            if (L.block_type[0][0] == L.block_type[0][1] && L.block_type[1][0] == L.block_type[1][1])
+            if (L.block_type[0][0] == L.block_type[0][1] && L.block_type[ngr - 1][0] == L.block_type[ngr - 1][1])
                 mode_ext = LH_MPG_MD_MS_LR;
         }
     }
@@ -360,7 +372,8 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
         for (int i = 0; i < 18; i++)
             buf[i] = lh_lds.ss.pefirbuf[i + 1];
         f = 0.0;
-        for (int gr = 0; gr < 2; gr++) {
+        pe_use[1][0] = pe_use[1][1] = 0.0f;
+        for (int gr = 0; gr < ngr; gr++) {
             pe_use[gr][1] = 0.0f;
             for (int ch = 0; ch < nch; ch++) {
                 pe_use[gr][ch] = L.pe[gr][msoff + ch];
@@ -371,8 +384,8 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
         f = buf[9];
         for (int i = 0; i < 9; i++)
             f += (buf[i] + buf[18 - i]) * lh_pe_fir[i];
-        f = (670 * 5 * 2 * nch) / f;
-        for (int gr = 0; gr < 2; gr++)
+        f = (670 * 5 * ngr * nch) / f;
+        for (int gr = 0; gr < ngr; gr++)
             for (int ch = 0; ch < nch; ch++)
                 pe_use[gr][ch] = lh_uni_f(pe_use[gr][ch] * f);
         LH_SYNC_WG();
@@ -452,7 +465,7 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
          * nothing in between reads xr): granule 1's are then there for the channel that is done with granule 0
          * first (below) */
         float const k = (float) (LH_SQRT2 * 0.5);
-        for (int i = tid; i < 2 * 576; i += LH_NT) {
+        for (int i = tid; i < ngr * 576; i += LH_NT) {
             int const gr = i >= 576, at = i - 576 * gr;
             float const l = L.xr[0][gr][at];
             float const r = L.xr[1][gr][at];
@@ -460,8 +473,14 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
             L.xr[1][gr][at] = (l - r) * k;
         }
     }
+    if (ngr == 1) {
+        /* the payload's second granule does not exist: all zero (as the checkers leave it) */
+        uint32_t *z = (uint32_t *) &fo->gr[1][w];
+        for (int i = lane; i < (int) (sizeof(LhGranule) / 4); i += 64)
+            z[i] = 0u;
+    }
     int     prepared = 0, prepared_nonzero = 0;
-    for (int gr = 0; gr < 2 && !vbr_new; gr++) {
+    for (int gr = 0; gr < ngr && !vbr_new; gr++) {
         int     targ_bits[2] = { abr_targ[gr][0], abr_targ[gr][1] };
         int     max_bits = 0;
         if (!abr)
@@ -534,7 +553,7 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
             LH_PA(3, t_q);
             if (lane == 0)
                 L.bits_used[ch] = g.part2_3_length + g.part2_length;
-            if (gr == 0 && nch == 2) {
+            if (gr == 0 && nch == 2 && ngr == 2) {
                 /* Granule 1's budget needs what BOTH channels spent on granule 0, but its geometry, xrpow and
                  * allowed noise do not: the channel that is done first prepares them while it would otherwise
                  * wait at the barrier for the other (the wait was 8 % of a frame); the one that is done last goes
@@ -623,14 +642,14 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
         /* what the next frame's psy model finds in sv_qnt.masking_lower: the CBR loop leaves the value
          * of its last granule/channel (channel 0 for mono), the VBR loop always the long-block one (reference quantize.c:1622) */
         lh_lds.ss.masking_lower = vbr_new ? masking_lower_left
-            : (L.block_type[1][nch - 1] != LH_SHORT_TYPE) ? cfg->masking_lower_long : cfg->masking_lower_short;
+            : (L.block_type[ngr - 1][nch - 1] != LH_SHORT_TYPE) ? cfg->masking_lower_long : cfg->masking_lower_short;
         lh_lds.ss.frame_number = lh_lds.ss.frame_number + 1;
         if (mdb * 8 != ResvSize)
             lh_lds.ss.status |= 1;    /* reservoir inconsistency (reference bitstream.c:947) */
     }
     if (lh_uni_i(L.ctx.bytes != nullptr))
         lh_emit_frame(fo, drain_pre, drain_post, frame_bits / 8, mdb_header, bitrate_index, padding, mode_ext,
-                      c.d.flush && (int) ((c.frame_base + LH_MF_START) / 1152) == c.d.frame_end - 1);
+                      c.d.flush && (int) ((c.frame_base + LH_MF_START) / fs) == c.d.frame_end - 1);
     LH_PA(0, t_frame);
     LH_SYNC_WG();
 #if defined(LH_PROF) && !defined(LH_EMU)
@@ -717,14 +736,15 @@ lh_encode_stream(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, 
         ((uint32_t *) &L.ss)[c.tid] = ((const uint32_t *) &st->pefirbuf[0])[c.tid - LH_SS_WORDS_A];
     LH_SYNC_WG();               /* the state words are read by every thread from here on */
     int     slot = 0;           /* ring slot holding the ratios of the frame's first granule */
+    int const ngr = lh_uni_i(cfg->mode_gr), fs = 576 * ngr;     /* granules / samples per frame (1 / 576: MPEG-2, 2.5) */
     for (int f = c.d.frame_begin; f < c.d.frame_end; f++) {
-        c.frame_base = 1152LL * f - LH_MF_START;
+        c.frame_base = (long long) fs * f - LH_MF_START;
         if (c.tid == 0) {
             L.ctx.frame_base = c.frame_base;    /* read by the stages after the next workgroup barrier */
             L.psy_slot = slot;
         }
         lh_encode_frame(c, &out[c.d.out_index + (f - c.d.frame_begin)], carry);
-        slot = (slot + 2) % 3;
+        slot = (slot + ngr) % 3;
     }
     if (c.tid < LH_SS_WORDS_A)
         ((uint32_t *) &st->loudness_sq_save[0])[c.tid] = ((const uint32_t *) &L.ss)[c.tid];

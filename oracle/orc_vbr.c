@@ -764,10 +764,12 @@ vbr_encode_frame(OrcStream * S, float xr34[2][2][576], float xmin[2][2][LH_SFBMA
             for (gr = 0; gr < S->cfg->mode_gr; ++gr)
                 max_gr[gr] = (s > 0) ? (int) (max_fr * f[gr] / s) : 0;
         }
-        vbr_share(max_gr, use_gr, 125);
-        for (gr = 0; gr < S->cfg->mode_gr; ++gr)
-            if (max_gr[gr] > LH_MAX_BITS_PER_GRANULE)
-                max_gr[gr] = LH_MAX_BITS_PER_GRANULE;
+        if (S->cfg->mode_gr > 1) {      /* reference vbrquantize.c:1452-1468 */
+            vbr_share(max_gr, use_gr, 125);
+            for (gr = 0; gr < S->cfg->mode_gr; ++gr)
+                if (max_gr[gr] > LH_MAX_BITS_PER_GRANULE)
+                    max_gr[gr] = LH_MAX_BITS_PER_GRANULE;
+        }
         for (gr = 0; gr < S->cfg->mode_gr; ++gr) {
             float   f[2] = { 0.0f, 0.0f }, s = 0.0f;
             for (ch = 0; ch < nch; ++ch) {

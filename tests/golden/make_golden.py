@@ -30,6 +30,13 @@ CASES = [
     ("cbr256_js_44k_q2", 44100, 256, -1, 2, 107, 0.8, None, False),
     ("cbr160_js_44k_q5", 44100, 160, -1, 5, 108, 0.8, None, False),
     ("cbr128_js_44k_silence", 44100, 128, -1, -1, -1, 0.5, None, False),
+    # MPEG-2 / 2.5 (LSF: one granule per frame, partitioned scalefactors)
+    ("cbr64_js_22k_lsf", 22050, 64, -1, -1, 601, 1.2, None, False),
+    ("cbr56_js_24k_lsf", 24000, 56, -1, -1, 602, 1.0, None, False),
+    ("cbr32_js_16k_bursts_lsf", 16000, 32, -1, -1, 603, 1.2, 1.0 / 12, False),
+    ("cbr32_js_12k_lsf", 12000, 32, -1, -1, 604, 1.2, None, False),             # MPEG-2.5
+    ("cbr16_js_8k_lsf", 8000, 16, -1, -1, 605, 1.5, None, False),               # MPEG-2.5, 17 / 9 coded bands
+    ("cbr160_st_22k_q2_lsf", 22050, 160, 0, 2, 606, 0.8, None, True),
 ]
 
 VBR_CASES = [
@@ -41,6 +48,8 @@ VBR_CASES = [
     ("vbr6_js_44k_q7", 44100, 6, -1, 7, 205, 0.8, None, False),        # guessed scalefactors
     ("vbr3_js_44k_q5", 44100, 3, -1, 5, 206, 0.8, None, False),        # no best-huffman pass
     ("vbr2_js_44k_silence", 44100, 2, -1, -1, -1, 0.5, None, False),
+    ("vbr4_js_22k_lsf", 22050, 4, -1, -1, 607, 1.2, None, False),     # LSF scalefactor ranges with preflag
+    ("vbr6_js_16k_white_lsf", 16000, 6, -1, -1, 608, 1.0, None, True),
 ]
 
 
@@ -54,6 +63,7 @@ OLD_CASES = [
     ("vbrold1_js_44k_q0", 44100, 1, -1, 0, 505, 0.6, None, True),              # one band per pass, full search
     ("vbrold3_js_44k_silence", 44100, 3, -1, -1, -1, 0.5, None, False),
     ("mono_vbrold4_44k", 44100, 4, 3, -1, 506, 0.8, None, False),
+    ("vbrold2_js_24k_lsf", 24000, 2, -1, -1, 611, 1.0, None, False),
 ]
 
 
@@ -64,6 +74,7 @@ ABR_CASES = [
     ("abr150_js_32k_white_q5", 32000, 150, -1, 5, 303, 0.8, None, True),
     ("abr320_js_44k_q0", 44100, 320, -1, 0, 304, 0.8, None, False),
     ("abr112_js_44k_silence", 44100, 112, -1, -1, -1, 0.5, None, False),
+    ("abr56_js_22k_lsf", 22050, 56, -1, -1, 609, 1.0, None, False),
 ]
 
 
@@ -74,6 +85,7 @@ MONO_CASES = [
     ("mono_vbr2_44k", 44100, dict(vbr_q=2), -1, 403, 1.0, None, False),
     ("mono_vbr5_32k_white", 32000, dict(vbr_q=5), -1, 404, 0.8, None, True),
     ("mono_abr100_44k", 44100, dict(abr=100), -1, 405, 1.0, None, False),
+    ("mono_cbr48_22k_lsf", 22050, dict(brate=48), -1, 610, 1.0, None, False),
 ]
 
 

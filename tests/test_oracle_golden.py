@@ -33,7 +33,7 @@ def test_golden(name, oracle):
     # oracle payload, frame by frame
     frames = oracle.encode_frames(cfg, tab, pcm)
     assert len(frames) == int(g["nframes"])
-    assert enc.lib.lh_total_frames(C.c_long(pcm.shape[1])) == int(g["nframes"])
+    assert enc.lib.lh_total_frames_fs(C.c_long(pcm.shape[1]), 576 * cfg.mode_gr) == int(g["nframes"])
     mp3 = helpers.pack_frames(enc.lib, cfg, tab, frames)      # packer keeps table 14 internally
     helpers.normalize_tables(frames)
     got = [helpers.frame_sha(fr) for fr in frames]
