@@ -584,9 +584,9 @@ lame_get_VBR_quality(const lame_t g)
 }
 
 SETTER(lame_set_VBR_min_bitrate_kbps, p.vbr_min_kbps, int)
-GETTER(lame_get_VBR_min_bitrate_kbps, g->inited && g->cfg.vbr ? lh_tag_kbps(g->cfg.vbr_min_bitrate_index) : g->p.vbr_min_kbps, int)
+GETTER(lame_get_VBR_min_bitrate_kbps, g->inited && g->cfg.vbr ? lh_tag_kbps(g->cfg.version, g->cfg.vbr_min_bitrate_index) : g->p.vbr_min_kbps, int)
 SETTER(lame_set_VBR_max_bitrate_kbps, p.vbr_max_kbps, int)
-GETTER(lame_get_VBR_max_bitrate_kbps, g->inited && g->cfg.vbr ? lh_tag_kbps(g->cfg.vbr_max_bitrate_index) : g->p.vbr_max_kbps, int)
+GETTER(lame_get_VBR_max_bitrate_kbps, g->inited && g->cfg.vbr ? lh_tag_kbps(g->cfg.version, g->cfg.vbr_max_bitrate_index) : g->p.vbr_max_kbps, int)
 SETTER(lame_set_VBR_hard_min, p.vbr_hard_min, int)
 GETTER(lame_get_VBR_hard_min, g->p.vbr_hard_min, int)
 
@@ -723,7 +723,7 @@ lame_bitrate_kbps(const lame_t g, int bitrate_kbps[14])
 {
     if (valid(g) && g->inited)
         for (int i = 0; i < 14; i++)
-            bitrate_kbps[i] = lh_tag_kbps(i + 1);
+            bitrate_kbps[i] = lh_tag_kbps(g->inited ? g->cfg.version : 1, i + 1);
 }
 
 extern "C" void
@@ -807,7 +807,7 @@ init_params_once(lame_t g)
     }
     if (lh_config_resolve(&g->p, &g->cfg, &aux) != 0) {
         snprintf(g_err, sizeof(g_err),
-                 "unsupported settings for the MI355X path (need an MPEG-1 output rate, 1 or 2 input channels)");
+                 "unsupported settings for the MI355X path (need an MPEG output rate, 1 or 2 input channels)");
         return -1;
     }
     /* (a call that failed before g->inited may be repeated: what it had allocated is reused) */
@@ -995,7 +995,7 @@ handle_encode_frames(lame_t g, int upto, unsigned char *mp3buf, int mp3buf_size,
                 }
         }
         if (g->write_vbr_tag) {
-            lh_tag_add_frame(&g->tag, lh_tag_kbps(g->h_out[(size_t) i].bitrate_index));  /* reference encoder.c:550-551 */
+            lh_tag_add_frame(&g->tag, lh_tag_kbps(g->cfg.version, g->h_out[(size_t) i].bitrate_index));  /* reference encoder.c:550-551 */
             lh_tag_crc(&g->tag, mp3buf + *written, k);          /* reference bitstream.c:1082-1088 */
         }
         *written += k;
@@ -2517,7 +2517,7 @@ lamehip_batch_get_bytes_tagged(lamehip_batch * b, int s, unsigned char *out, lon
     while (pos + 4 <= k) {
         const unsigned char *h = out + total + pos;
         int const bi = h[2] >> 4, pad = (h[2] >> 1) & 1;
-        int const kbps = lh_tag_kbps(bi);
+        int const kbps = lh_tag_kbps(b->cfg.version, bi);
         int const size = (b->cfg.version + 1) * 72000 * kbps / b->cfg.samplerate + pad;
         if (h[0] != 0xff || (h[1] & 0xe0) != 0xe0 || kbps <= 0 || size <= 0) {
             snprintf(g_err, sizeof(g_err), "device-packed stream %d: lost frame sync at byte %ld", s, pos);
@@ -2707,7 +2707,7 @@ lamehip_batch_pack_tagged(lamehip_batch * b, int s, unsigned char *out, long out
     if (k < 0 || total == 0)
         return k;
     for (int i = 0; i < n; i++)
-        lh_tag_add_frame(&v, lh_tag_kbps(fr[(size_t) i].bitrate_index));
+        lh_tag_add_frame(&v, lh_tag_kbps(b->cfg.version, fr[(size_t) i].bitrate_index));
     lh_tag_crc(&v, out + total, k);
     if (lh_tag_frame(&v, &b->cfg, b->cfg.vbr_q, batch_padding(b, s), n > 0 ? fr[(size_t) n - 1].mode_ext : 0,
                      out, total) != total)

@@ -137,7 +137,7 @@ typedef struct LhVbrTag {
 
 int     lh_tag_init(LhVbrTag * v, const LhConfig * c);
 void    lh_tag_add_frame(LhVbrTag * v, int kbps);
-int     lh_tag_kbps(int bitrate_index);
+int     lh_tag_kbps(int version, int bitrate_index);
 void    lh_tag_crc(LhVbrTag * v, const unsigned char *buf, long n);
 int     lh_tag_placeholder(const LhVbrTag * v, const LhConfig * c, unsigned char *buf);
 int     lh_tag_frame(const LhVbrTag * v, const LhConfig * c, int vbr_q, int enc_padding, int last_mode_ext,

@@ -52,21 +52,42 @@ lh_tag_crc(LhVbrTag * v, const unsigned char *buf, long n)
     v->bytes_written += (unsigned long) n;
 }
 
-static const int lh_tag_bitrate_mpeg1[16] = { 0, 32, 40, 48, 56, 64, 80, 96, 112, 128, 160, 192, 224, 256, 320, -1 };
-
-/* kbps of an MPEG-1 bitrate index (what AddVbrFrame accumulates, reference VbrTag.c:150-158) */
+/* kbps of a bitrate index in the stream's MPEG version (what AddVbrFrame accumulates, reference VbrTag.c:195-201) */
 int
-lh_tag_kbps(int bitrate_index)
+lh_tag_kbps(int version, int bitrate_index)
 {
-    return lh_tag_bitrate_mpeg1[bitrate_index & 15];
+    return lh_bitrate_row(version)[bitrate_index & 15];
+}
+
+/* the bit rate of the tag frame itself (reference VbrTag.c:515-529, 287-300): the stream's own for CBR, else 128 / 64 /
+ * 32 kb/s for MPEG-1 / 2 / 2.5, and its index in the version's row (2.5: the MPEG-2 row holds 32 at the same index) */
+static int
+tag_frame_kbps(const LhConfig * c)
+{
+    if (c->vbr == 0)
+        return c->avg_bitrate;
+    return c->version == 1 ? 128 : (c->samplerate < 16000 ? 32 : 64);
+}
+
+static int
+tag_frame_bitrate_index(const LhConfig * c)
+{
+    int const kbps = tag_frame_kbps(c);
+    int     i;
+    if (c->vbr == 0)
+        return c->bitrate_index;
+    for (i = 1; i <= 14; i++)
+        if (lh_bitrate_row(c->version)[i] == kbps)
+            return i;
+    return 0;
 }
 
 /* reference VbrTag.c:492-559: 0 = the tag does not fit, stays off */
 int
 lh_tag_init(LhVbrTag * v, const LhConfig * c)
 {
-    /* CBR: the stream's own frame size; VBR: a 128 kbps frame (XING_BITRATE1, reference VbrTag.c:515-529) */
-    int const kbps_header = (c->vbr == 0) ? c->avg_bitrate : 128;
+    /* CBR: the stream's own frame size; VBR: a 128 / 64 / 32 kbps frame (XING_BITRATE1 / 2 / 25, reference VbrTag.c:515-529) */
+    int const kbps_header = tag_frame_kbps(c);
     int const total = ((c->version + 1) * 72000 * kbps_header) / c->samplerate;
     int const header_size = c->sideinfo_len + LH_LAMEHEADERSIZE;
     memset(v, 0, sizeof(*v));
@@ -110,11 +131,12 @@ static void
 tag_frame_header(const LhConfig * c, int mode_ext, unsigned char *b)
 {
     b[0] = 0xff;
-    b[1] = (unsigned char) (0xe0 | (1 << 4) | (c->version << 3) | (1 << 1) | (c->error_protection ? 0 : 1));
-    b[1] = (unsigned char) ((b[1] & 0xf1) | 0x0a);
+    b[1] = (unsigned char) (0xe0 | ((c->samplerate < 16000 ? 0 : 1) << 4) | (c->version << 3) | (1 << 1)
+                            | (c->error_protection ? 0 : 1));
+    b[1] = (unsigned char) ((b[1] & 0xf1) | (c->version == 1 ? 0x0a : 0x02));
     b[2] = (unsigned char) (((c->samplerate_index << 2) | (c->extension & 1)) & 0x0d);
-    /* bitrate field: the CBR rate, or 128 kbps (index 9) for VBR streams (reference VbrTag.c:286-303) */
-    b[2] = (unsigned char) (b[2] | (16 * (c->vbr == 0 ? c->bitrate_index : 9)));
+    /* bitrate field: the CBR rate, or the tag frame's own for VBR streams (reference VbrTag.c:286-303) */
+    b[2] = (unsigned char) (b[2] | (16 * tag_frame_bitrate_index(c)));
     b[3] = (unsigned char) ((c->mode << 6) | ((mode_ext & 3) << 4) | ((c->copyright & 1) << 3)
                             | ((c->original & 1) << 2) | (c->emphasis & 3));
 }
@@ -271,7 +293,7 @@ lh_tag_frame(const LhVbrTag * v, const LhConfig * c, int vbr_q, int enc_padding,
         {
             /* CBR: the bit rate; ABR: the mean; VBR: the lowest allowed one (reference VbrTag.c:679-693) */
             int const abr = (c->vbr == 0) ? c->avg_bitrate : (c->vbr == 3) ? c->vbr_avg_bitrate_kbps
-                : lh_tag_bitrate_mpeg1[c->vbr_min_bitrate_index];
+                : lh_bitrate_row(c->version)[c->vbr_min_bitrate_index];
             p[k++] = (unsigned char) (abr >= 255 ? 0xFF : abr);
         }
         p[k] = (unsigned char) (LH_ENCDELAY >> 4);

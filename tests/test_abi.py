@@ -34,9 +34,8 @@ def test_pod_sizes_match_bindings():
 def test_unsupported_settings_are_refused_loudly():
     lib = lamehip.load_library()
     for setup in (lambda h: lib.lame_set_num_channels(h, 3),          # neither mono nor stereo
-                  lambda h: (lib.lame_set_VBR(h, 2), lib.lame_set_VBR_q(h, 9)),   # vbr_rh -V9: lowpass 10 kHz -> a 24 kHz (MPEG-2) stream
-                  lambda h: lib.lame_set_in_samplerate(h, 22050),     # MPEG-2
-                  lambda h: lib.lame_set_brate(h, 64)):               # reference would resample to 24 kHz
+                  lambda h: lib.lame_set_free_format(h, 1),           # free format frames
+                  lambda h: lib.lame_set_out_samplerate(h, 20000)):   # not an MPEG rate
         h = C.c_void_p(lib.lame_init())
         lib.lame_set_bWriteVbrTag(h, 0)
         setup(h)
@@ -81,7 +80,7 @@ def test_error_callback_receives_failures():
     lib.lame_set_errorf.argtypes = [C.c_void_p, CB]
     h = C.c_void_p(lib.lame_init())
     assert lib.lame_set_errorf(h, cb) == 0
-    lib.lame_set_in_samplerate(h, 16000)        # MPEG-2 output rate: outside this path
+    lib.lame_set_out_samplerate(h, 20000)       # not an MPEG rate
     lib.lame_set_brate(h, 64)
     rc = lib.lame_init_params(h)
     assert rc < 0 and len(seen) == 1 and seen[0] == b"lamehip: %s\n"
@@ -90,6 +89,6 @@ def test_error_callback_receives_failures():
     h = C.c_void_p(lib.lame_init())
     lib.lame_set_errorf.argtypes = [C.c_void_p, C.c_void_p]
     assert lib.lame_set_errorf(h, None) == 0
-    lib.lame_set_in_samplerate(h, 16000)
+    lib.lame_set_out_samplerate(h, 20000)
     assert lib.lame_init_params(h) < 0 and len(seen) == 1
     lib.lame_close(h)

@@ -50,6 +50,13 @@ COMMANDS = [
     ("synth_preset_insane_b96", "synth", ["--preset", "insane", "-b", "96"]),
     ("synth_preset_cbr160_comp11", "synth", ["--preset", "cbr", "160", "--comp", "11"]),
     ("synth_preset_insane_comp7_q1_nores", "synth", ["--preset", "insane", "--comp", "7", "-q", "1", "--nores"]),
+    # MPEG-2 / 2.5 streams (one granule per frame): the frontend resamples, or the bitrate asks for a low output rate
+    ("synth_b64_resample22", "synth", ["-b", "64", "--resample", "22.05"]),
+    ("synth_V5_resample22", "synth", ["-V", "5", "--resample", "22.05"]),
+    ("synth_b32_mono_resample16", "synth", ["-b", "32", "-m", "m", "--resample", "16"]),
+    ("synth_b48", "synth", ["-b", "48"]),                                   # the reference picks 22.05 kHz itself
+    ("synth_abr24_resample11", "synth", ["--abr", "24", "--resample", "11.025"]),      # MPEG-2.5
+    ("testcase_b16_resample8", "testcase", ["-b", "16", "--resample", "8"]),
     # (the frontend's developer switches -- --athtype, --nsmsfix, --ns-bass, --noath, --noshort ... -- are compiled out of
     # a default build of the frontend, parse.c:75-79; the setters behind them are covered by tests/test_switches.py)
 ]

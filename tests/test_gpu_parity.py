@@ -60,7 +60,10 @@ def test_batch_payload_and_bytes_match_golden(name):
                                         ("testcase_wav_vbr2", 1152), ("vbr4_js_44k_white", 2500),
                                         ("vbr0_js_48k_bursts", 600), ("abr128_js_44k", 1152),
                                         ("abr200_st_48k_bursts", 3000), ("mono_cbr96_44k", 1152),
-                                        ("mono_vbr2_44k", 2000)])
+                                        ("mono_vbr2_44k", 2000),
+                                        ("cbr64_js_22k_lsf", 576), ("cbr32_js_16k_bursts_lsf", 1152), ("cbr16_js_8k_lsf", 333),
+                                        ("vbr4_js_22k_lsf", 1000), ("abr56_js_22k_lsf", 4000), ("mono_cbr48_22k_lsf", 576),
+                                        ("vbrold2_js_24k_lsf", 700)])
 def test_lame_encode_buffer_call_sequence(name, chunk):
     """lame_init -> set -> init_params -> N x lame_encode_buffer -> flush, as the
     reference frontend drives it (frontend/lame_main.c:381-470)."""
@@ -71,7 +74,7 @@ def test_lame_encode_buffer_call_sequence(name, chunk):
         n = min(n, 3000)                    # one-sample calls: keep it short
     out = b""
     first = enc.encode(pcm[0][:min(chunk, n)], pcm[1][:min(chunk, n)])
-    if chunk <= 1152:
+    if chunk <= 576:
         assert first == b""                 # priming: the first call returns 0 bytes
     out += first
     for i in range(chunk, n, chunk):
@@ -380,7 +383,9 @@ def test_abr_batch_matches_oracle(sr, kb, mode, q, seed, white, oracle):
 
 
 @pytest.mark.parametrize("kw", [dict(brate=128), dict(brate=320, samplerate=48000), dict(vbr_q=2), dict(vbr_q=5, quality=5),
-                                dict(abr=160), dict(vbr_q=0, samplerate=48000)])
+                                dict(abr=160), dict(vbr_q=0, samplerate=48000),
+                                dict(brate=64, samplerate=22050), dict(vbr_q=5, samplerate=24000), dict(abr=40, samplerate=16000),
+                                dict(brate=32, samplerate=12000), dict(vbr_q=4, samplerate=22050, vbr_mode=2)])
 def test_long_streams_match_oracle(kw, oracle):
     """20 s per stream (765+ frames): reservoir, bitrate switching and the psy history over a length
     that the short fixtures do not reach; bytes and every frame's payload against the CPU oracle."""
@@ -406,7 +411,8 @@ def test_long_streams_match_oracle(kw, oracle):
 
 @pytest.mark.parametrize("kw", [dict(brate=128), dict(brate=64, samplerate=32000), dict(brate=320, samplerate=48000, quality=0),
                                 dict(vbr_q=0, samplerate=48000), dict(vbr_q=4), dict(vbr_q=7, quality=7), dict(abr=90),
-                                dict(abr=256, quality=5)])
+                                dict(abr=256, quality=5), dict(brate=32, samplerate=22050), dict(vbr_q=6, samplerate=16000),
+                                dict(brate=16, samplerate=8000)])
 def test_mono_batch_matches_oracle(kw, oracle):
     """One input channel (MPEG mode mono): ragged batch against the CPU oracle, every frame and the bytes."""
     sr = kw.get("samplerate", 44100)

@@ -22,6 +22,8 @@ class LhVbrTag(C.Structure):
                                                        (32000, 96, -1, -1, 2.0, None, None), (44100, 192, 0, 2, 0.9, None, None),
                                                        (44100, 128, -1, 7, 13.0, None, None), (44100, 0, -1, -1, 1.1, 2, None),
                                                        (48000, 0, 0, 5, 0.8, 0, None), (32000, 0, -1, -1, 0.9, 6, None),
+                                                       (22050, 64, -1, -1, 1.0, None, None), (16000, 0, -1, -1, 1.2, 6, None),
+                                                       (12000, 32, -1, -1, 1.5, None, None), (22050, 0, -1, -1, 0.9, None, 56),
                                                        (44100, 0, -1, -1, 12.0, 8, None), (44100, 0, -1, -1, 1.0, None, 150),
                                                        (48000, 0, 0, 5, 0.8, None, 313)])
 @pytest.mark.parametrize("nch", [2, 1])
@@ -47,19 +49,19 @@ def test_tag_module_matches_reference(sr, br, mode, q, secs, vq, abr, nch):
     assert lib.lh_tag_placeholder(C.byref(v), C.byref(cfg), ph) == total
     assert ph.raw == stream[:total]
     audio = stream[total:]
-    nframes = lib.lh_total_frames(C.c_long(n))
+    nframes = lib.lh_total_frames_fs(C.c_long(n), 576 * cfg.mode_gr)
     # bitrate index and mode_ext of the frames come from the payload: take them from the oracle
     fr = helpers.Oracle().encode_frames(cfg, enc.tables(), pcm)
     assert len(fr) == nframes
     for f in range(nframes):
-        lib.lh_tag_add_frame(C.byref(v), lib.lh_tag_kbps(int(fr[f].bitrate_index)))
+        lib.lh_tag_add_frame(C.byref(v), lib.lh_tag_kbps(cfg.version, int(fr[f].bitrate_index)))
     lib.lh_tag_crc.argtypes = [C.c_void_p, C.c_char_p, C.c_long]
     half = len(audio) // 3
     lib.lh_tag_crc(C.byref(v), audio[:half], half)          # the CRC does not depend on the chunking
     lib.lh_tag_crc(C.byref(v), audio[half:], len(audio) - half)
     out = C.create_string_buffer(2880)
     lib.lh_tag_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_long]
-    k = lib.lh_tag_frame(C.byref(v), C.byref(cfg), cfg.vbr_q, lib.lh_end_padding(C.c_long(n)),
+    k = lib.lh_tag_frame(C.byref(v), C.byref(cfg), cfg.vbr_q, lib.lh_end_padding_fs(C.c_long(n), 576 * cfg.mode_gr),
                          fr[nframes - 1].mode_ext, out, len(out))
     assert k == total
     assert out.raw[:k] == tag
@@ -71,7 +73,8 @@ def test_tag_module_matches_reference(sr, br, mode, q, secs, vq, abr, nch):
 @pytest.mark.gpu
 @pytest.mark.parametrize("sr,br,mode,chunk,vq", [(44100, 128, None, 1152, None), (48000, 320, 1, 4000, None),
                                                  (44100, 160, 0, 700, None), (44100, 0, None, 1152, 2),
-                                                 (48000, 0, None, 3000, 5)])
+                                                 (48000, 0, None, 3000, 5), (22050, 56, None, 576, None), (16000, 0, None, 1000, 5),
+                                                 (12000, 24, None, 1152, None)])
 def test_api_default_tag_handling_matches_reference(sr, br, mode, chunk, vq):
     """lame_init with its defaults (bWriteVbrTag = 1): the first call delivers the placeholder
     frame, the stream and lame_get_lametag_frame equal the reference's."""
@@ -153,12 +156,12 @@ def test_tag_frame_with_error_protection_matches_reference(kw):
     fr = helpers.Oracle().encode_frames(cfg, enc.tables(), pcm)
     assert len(fr) == nframes
     for f in range(nframes):
-        lib.lh_tag_add_frame(C.byref(v), lib.lh_tag_kbps(int(fr[f].bitrate_index)))
+        lib.lh_tag_add_frame(C.byref(v), lib.lh_tag_kbps(cfg.version, int(fr[f].bitrate_index)))
     lib.lh_tag_crc.argtypes = [C.c_void_p, C.c_char_p, C.c_long]
     lib.lh_tag_crc(C.byref(v), audio, len(audio))
     out = C.create_string_buffer(2880)
     lib.lh_tag_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_long]
-    k = lib.lh_tag_frame(C.byref(v), C.byref(cfg), cfg.vbr_q, lib.lh_end_padding(C.c_long(n)),
+    k = lib.lh_tag_frame(C.byref(v), C.byref(cfg), cfg.vbr_q, lib.lh_end_padding_fs(C.c_long(n), 576 * cfg.mode_gr),
                          fr[nframes - 1].mode_ext, out, len(out))
     assert k == total
     assert out.raw[4:6] != b"\0\0"
