@@ -508,9 +508,9 @@ def main():
         audio_s = world * B * args.seconds * args.steps
         value = audio_s / dt
         kavg = sum(kernel_ms) / len(kernel_ms) / 1e3
-        what = ("ABR%d" % args.abr if args.abr is not None else "CBR128" if args.vbr is None else "VBR -V%d%s" % (args.vbr, " --vbr-old" if args.vbr_old else ""))
+        what = ("ABR%d" % args.abr if args.abr is not None else "CBR%d" % args.brate if args.vbr is None else "VBR -V%d%s" % (args.vbr, " --vbr-old" if args.vbr_old else ""))
         res = {
-            "metric": "encoded audio seconds/sec (x real-time) at 44.1kHz stereo " + what,
+            "metric": "encoded audio seconds/sec (x real-time) at %gkHz stereo %s" % (sr / 1000.0, what),
             "value": round(value, 1), "unit": "x real-time", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
@@ -554,6 +554,9 @@ def main():
                                         "r04_pmc_vbrold2.json", vbr_q=2, vbr_mode=2),
                 "cbr320_48k_bursts_config4": short_run(torch, lamehip, dev, device_index, 48000, 1024, 5.0, 2, 9000,
                                                        40.0, "r04_pmc_cbr320.json", brate=320, mode=1),
+                # MPEG-2 (one granule of 576 samples per frame): the kernel object compiled with -DLH_LSF
+                "mpeg2_22k_cbr64": short_run(torch, lamehip, dev, device_index, 22050, 1024, 10.0, 2, 7000, 3.0,
+                                             "r04_pmc_lsf.json", brate=64),
             }
         if not args.no_end_to_end and not args.no_extras and world == 1:
             if batch is not None:

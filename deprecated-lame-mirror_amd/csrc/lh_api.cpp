@@ -26,6 +26,11 @@ extern "C" int lh_launch_encode(const LhConfig * cfg, const LhTables * T, const 
                                 const LhStreamDesc * descs, LhStreamState * states,
                                 LhFrameOut * out, uint8_t * bytes, int nstreams, void *stream);
 
+/* the same kernel compiled for MPEG-2 / 2.5 streams (lh_kernels.hip with -DLH_LSF: one granule per frame) */
+extern "C" int lh_launch_encode_lsf(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, const float *pcmf,
+                                    const LhStreamDesc * descs, LhStreamState * states,
+                                    LhFrameOut * out, uint8_t * bytes, int nstreams, void *stream);
+
 extern "C" int lh_launch_selftest(unsigned *d_out, unsigned seed, void *stream);
 extern "C" int lh_launch_summary(const LhStreamState * states, long long *sum, int nstreams, void *stream);
 extern "C" int lh_launch_scatter(const int16_t * arena, int16_t * pool, long cap, const int *seg, int nseg, void *stream);
@@ -76,11 +81,14 @@ mfn_of(const LhConfig & c)
 struct LhDeviceConst {
     LhConfig *d_cfg = nullptr;
     LhTables *d_tab = nullptr;
+    int     lsf = 0;            /* an MPEG-2 / 2.5 stream: the kernel object compiled for one granule per frame */
     int launch(const int16_t * pcm, const float *pcmf, const LhStreamDesc * descs, LhStreamState * states,
                LhFrameOut * out, uint8_t * bytes, int nstreams, void *stream) const {
-        return lh_launch_encode(d_cfg, d_tab, pcm, pcmf, descs, states, out, bytes, nstreams, stream);
+        return (lsf ? lh_launch_encode_lsf : lh_launch_encode) (d_cfg, d_tab, pcm, pcmf, descs, states, out, bytes, nstreams,
+                                                                 stream);
     }
     int upload(const LhConfig & cfg, const LhTables & tab) {
+        lsf = (cfg.mode_gr == 1);
         HIPCHK(hipMalloc((void **) &d_cfg, sizeof(LhConfig)));
         HIPCHK(hipMalloc((void **) &d_tab, sizeof(LhTables)));
         HIPCHK(hipMemcpy(d_cfg, &cfg, sizeof(LhConfig), hipMemcpyHostToDevice));

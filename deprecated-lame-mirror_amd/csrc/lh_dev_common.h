@@ -15,6 +15,19 @@
 #include "lh_dev_math.h"
 
 #define LH_NT 128               /* threads that walk the frame: wave 0 = left/mid, wave 1 = right/side */
+/* The kernel file is compiled twice (csrc/Makefile): for MPEG-1 streams (two granules per frame; the default) and,
+ * with -DLH_LSF, for MPEG-2 / 2.5 streams (one granule of 576 samples per frame, partitioned scalefactors, the 8 kHz
+ * band limits).  The granule count and everything that hangs on it are compile-time constants in either object, so
+ * the MPEG-1 kernel carries no test for the other case (as a run-time switch it cost the headline 5 %). */
+#ifdef LH_LSF
+#define LH_NGR 1
+#define LH_IS_LSF 1
+#define LH_RATE8K(c) ((c).rate8k)
+#else
+#define LH_NGR 2
+#define LH_IS_LSF 0
+#define LH_RATE8K(c) 0
+#endif
 #define LH_BLOCK LH_NT
 #define LH_SQRT2 1.41421356237309504880
 
@@ -471,7 +484,7 @@ struct LhCtx {
     /* the settings the iteration loop tests again and again, read from HBM once (scalar
      * registers) instead of once per use */
     int     ns, ns_amp, sfb21_extra, full_outer_loop, subblock_gain;
-    int     lsf, rate8k;        /* MPEG-2 / 2.5 (one granule per frame, partitioned scalefactors); an 8 kHz stream */
+    int     rate8k;             /* (LH_LSF build) an 8 kHz stream: 17 long / 9 short coded bands */
 };
 
 LH_DEVFN void
@@ -482,8 +495,11 @@ lh_ctx_hot(LhCtx & c)
     c.sfb21_extra = lh_uni_i(c.cfg->sfb21_extra);
     c.full_outer_loop = lh_uni_i(c.cfg->full_outer_loop);
     c.subblock_gain = lh_uni_i(c.cfg->subblock_gain);
-    c.lsf = lh_uni_i(c.cfg->mode_gr == 1);
+#ifdef LH_LSF
     c.rate8k = lh_uni_i(c.cfg->samplerate <= 8000);
+#else
+    c.rate8k = 0;
+#endif
 }
 
 /* The context reaches an out-of-line stage through per-lane memory, which hides from the

@@ -73,7 +73,7 @@ lh_emit_part(const LhCtx & c, LhChanLds & Q, const LhQR & R, const LhGrR & g, co
     for (int i = lane; i < LH_EMIT_WORDS; i += 64)
         buf[i] = 0u;
     LH_WAVE_SYNC();
-    if (c.lsf) {
+    if (LH_IS_LSF) {
         /* part 2, MPEG-2 / 2.5 (reference bitstream.c:735-770): four partitions with their own widths, both read from
          * scalefac_compress the way lh_scale_bitcount_lsf wrote it; every scalefactor of a partition is written (a
          * negative one as 0) */
@@ -274,7 +274,7 @@ lh_emit_header(const LhConfig * cfg, const LhFrameOut * fo, int mdb, int bitrate
         LH_HB(mdb, 8);
         LH_HB(0, cfg->channels);
     }
-    for (int gr = 0; gr < cfg->mode_gr; gr++)
+    for (int gr = 0; gr < LH_NGR; gr++)
         for (int ch = 0; ch < cfg->channels; ch++) {
             const LhGranule *gi = &fo->gr[gr][ch];
             LH_HB(gi->part2_3_length + gi->part2_length, 12);
@@ -376,7 +376,7 @@ lh_emit_frame(const LhFrameOut * fo_in, int drain_pre, int drain_post, int frame
 
     LH_SYNC_WG();
     nbits = drain_pre;
-    for (int gr = 0; gr < cfg->mode_gr; gr++)
+    for (int gr = 0; gr < LH_NGR; gr++)
         for (int ch = 0; ch < nch; ch++) {
             const LhGranule *gi = &fo->gr[gr][ch];
             poff[np] = nbits;

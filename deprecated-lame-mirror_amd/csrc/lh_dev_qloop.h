@@ -766,7 +766,7 @@ lq_scale_bitcount(const LhCtx & c, LhQS & S, const LhQR & R, LhGrR & g)
     int     k;
     int     v = (c.lane < R.sfbmax) ? S.sfw : 0;
     uint32_t th;
-    if (LH_RARE(c.lsf))
+    if (LH_IS_LSF)
         return lh_scale_bitcount_lsf(c, R, g, v);       /* MPEG-2 / 2.5: four partitions, no preflag search */
     if (R.block_type != LH_SHORT_TYPE) {
         if (!g.preflag) {

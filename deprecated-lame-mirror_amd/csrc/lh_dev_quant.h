@@ -668,7 +668,7 @@ lh_scale_bitcount(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g, int
     int     v;
     LH_WAVE_SYNC();
     v = (c.lane < R.sfbmax) ? sf[c.lane] : 0;
-    if (c.lsf)
+    if (LH_IS_LSF)
         return lh_scale_bitcount_lsf(c, R, g, v);
     if (R.block_type != LH_SHORT_TYPE) {
         if (!g.preflag) {
@@ -824,9 +824,9 @@ lh_calc_xmin_body(const LhCtx & c, LhChanLds & Q, LhQR & R, const float *xr, con
         if (c.sfb21_extra == 0 && cfg->samplerate < 44000) {
             int     limit;
             if (R.block_type != LH_SHORT_TYPE)
-                limit = qt->sfb_l[c.rate8k ? 17 : 21] - 1;
+                limit = qt->sfb_l[LH_RATE8K(c) ? 17 : 21] - 1;
             else
-                limit = 3 * T->sfb_s[c.rate8k ? 9 : 12] - 1;
+                limit = 3 * T->sfb_s[LH_RATE8K(c) ? 9 : 12] - 1;
             if (max_nonzero > limit)
                 max_nonzero = limit;
         }
@@ -888,17 +888,17 @@ lh_init_outer_loop_body(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, flo
     g.xrpow_max = 0;
     R.block_type = block_type;
     /* (an 8 kHz stream codes 17 long / 9 short bands: reference quantize.c:252-256, 284-294) */
-    R.sfb_lmax = c.rate8k ? 17 : LH_SBPSY_L;
-    R.sfb_smin = c.rate8k ? 9 : LH_SBPSY_S;
-    R.psy_lmax = c.rate8k ? 17 : (sfb21 ? LH_SBMAX_L : LH_SBPSY_L);
+    R.sfb_lmax = LH_RATE8K(c) ? 17 : LH_SBPSY_L;
+    R.sfb_smin = LH_RATE8K(c) ? 9 : LH_SBPSY_S;
+    R.psy_lmax = LH_RATE8K(c) ? 17 : (sfb21 ? LH_SBMAX_L : LH_SBPSY_L);
     R.psymax = R.psy_lmax;
     R.sfbmax = R.sfb_lmax;
     R.sfbdivide = 11;
     if (block_type == LH_SHORT_TYPE) {
         R.sfb_smin = 0;
         R.sfb_lmax = 0;
-        R.psymax = c.rate8k ? 3 * 9 : 3 * ((sfb21 ? LH_SBMAX_S : LH_SBPSY_S));
-        R.sfbmax = c.rate8k ? 3 * 9 : 3 * LH_SBPSY_S;
+        R.psymax = LH_RATE8K(c) ? 3 * 9 : 3 * ((sfb21 ? LH_SBMAX_S : LH_SBPSY_S));
+        R.sfbmax = LH_RATE8K(c) ? 3 * 9 : 3 * LH_SBPSY_S;
         R.sfbdivide = R.sfbmax - 18;
         R.psy_lmax = 0;
     }
@@ -1112,7 +1112,7 @@ lh_best_scalefac_store_body(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGr
             g.scalefac_scale = recalc = 1;
         }
     }
-    if (!g.preflag && R.block_type != LH_SHORT_TYPE && !c.lsf) {
+    if (!g.preflag && R.block_type != LH_SHORT_TYPE && !LH_IS_LSF) {
         int const hi = (s >= 11 && s < LH_SBPSY_L);
         int const pre = qt->pretab[s < 22 ? s : 0];
         if (!lh_ballot(hi && sfv < pre && sfv != -2)) {
@@ -1122,7 +1122,7 @@ lh_best_scalefac_store_body(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGr
         }
     }
     LH_PA(41, t_bs0);
-    if (gr == 1 && !c.lsf && g0_block_type != LH_SHORT_TYPE && R.block_type != LH_SHORT_TYPE) {
+    if (gr == 1 && !LH_IS_LSF && g0_block_type != LH_SHORT_TYPE && R.block_type != LH_SHORT_TYPE) {
         /* scfsi_calc: share a group of scalefactors with granule 0 when all of them agree */
         int const in21 = (s < LH_SBPSY_L);
         int const g0 = in21 ? (int) g0sf[s] : 0;
@@ -1352,7 +1352,7 @@ LH_DEVFN void
 lh_best_huffman_divide_body(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g)
 {
     const LhQTabs *qt = LH_QT;
-    if (c.lsf && R.block_type == LH_SHORT_TYPE)
+    if (LH_IS_LSF && R.block_type == LH_SHORT_TYPE)
         return;                 /* an LSF short block is left alone (reference takehiro.c:898-900) */
     const int16_t *ix = Q.ix[0];
     int const lane = c.lane;

@@ -459,7 +459,7 @@ lh_vbr_constrain_long(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g,
     int const r = lh_vbr_range_long(s);
     /* the range with preflag: MPEG-1's own, or the LSF partitions' 7 7 7 7 7 7 3 3 3 3 3 0 ... (max_range_long_lsf_pretab,
      * reference vbrquantize.c:577-579, 861) */
-    int const rp = c.lsf ? (s < 6 ? 7 : (s < 11 ? 3 : 0)) : r;
+    int const rp = LH_IS_LSF ? (s < 6 ? 7 : (s < 11 ? 3 : 0)) : r;
     int const pt = (s < 22) ? (int) qt->pretab[s < 22 ? s : 0] : 0;
     int const v = vbrmax - sfw;
     int     delta = lh_wave_max0(in ? v : 0);
@@ -866,14 +866,14 @@ LH_DEVFN int
 lh_vbr_full_bits(const LhConfig * cfg, int index, int ResvSize, int *mean_bits, int *resv_max)
 {
     int const frameLength = lh_frame_bits(cfg, index, 0);
-    int const meanBits = (frameLength - cfg->sideinfo_len * 8) / cfg->mode_gr;
-    int const resvLimit = (8 * 256) * cfg->mode_gr - 8;
+    int const meanBits = (frameLength - cfg->sideinfo_len * 8) / LH_NGR;
+    int const resvLimit = (8 * 256) * LH_NGR - 8;
     int     ResvMax = cfg->buffer_constraint - frameLength, full;
     if (ResvMax > resvLimit)
         ResvMax = resvLimit;
     if (ResvMax < 0 || cfg->disable_reservoir)
         ResvMax = 0;
-    full = meanBits * cfg->mode_gr + (ResvSize < ResvMax ? ResvSize : ResvMax);
+    full = meanBits * LH_NGR + (ResvSize < ResvMax ? ResvSize : ResvMax);
     if (full > cfg->buffer_constraint)
         full = cfg->buffer_constraint;
     *mean_bits = meanBits;
@@ -1011,7 +1011,8 @@ lh_vbr_frame(LhFrameOut * fo_in, int mode_ext, int msoff)
     int const maxi = cfg->vbr_max_bitrate_index;
     mode_ext = lh_uni_i(mode_ext);
     msoff = lh_uni_i(msoff);
-    int const nch = cfg->channels, ngr = lh_uni_i(cfg->mode_gr);
+    int const nch = cfg->channels;
+    constexpr int ngr = LH_NGR;
     int     avg, resv_top, top_bits, dummy;
     int     max_bits[2][2], use_ch[2][2], use_gr[2], use_fr, max_fr = 0, bits = 0;
     int     analog_silence, pad, used, ok;
@@ -1128,7 +1129,7 @@ LH_DEVFN void
 lh_abr_target_bits(const LhConfig * cfg, int ResvSize, int substep, float pe[2][2], const float ms_ener_ratio[2],
                    const int block_type[2][2], int mode_ext, int targ_bits[2][2], int *analog_silence_bits)
 {
-    int const nch = cfg->channels, parts = cfg->mode_gr * nch;
+    int const nch = cfg->channels, parts = LH_NGR * nch;
     int const side_bits = cfg->sideinfo_len * 8;
     int     unused_mean, unused_max, frame_cap, per_part, granted = 0;
     float   base;
@@ -1138,7 +1139,7 @@ lh_abr_target_bits(const LhConfig * cfg, int ResvSize, int substep, float pe[2][
     *analog_silence_bits = (lh_frame_bits(cfg, 1, 0) - side_bits) / parts;
     {
         /* a granule-channel's share of the mean bitrate (9 % more while substep bit 0 is set) */
-        int     frame = cfg->vbr_avg_bitrate_kbps * (576 * cfg->mode_gr) * 1000;
+        int     frame = cfg->vbr_avg_bitrate_kbps * (576 * LH_NGR) * 1000;
         if (substep & 1)
             frame *= 1.09;
         frame /= cfg->samplerate;
@@ -1151,7 +1152,7 @@ lh_abr_target_bits(const LhConfig * cfg, int ResvSize, int substep, float pe[2][
         f = f > 1.00 ? 1.00 : f;
         base = f;
     }
-    for (int gr = 0; gr < cfg->mode_gr; gr++) {
+    for (int gr = 0; gr < LH_NGR; gr++) {
         int     granule = 0;
         for (int ch = 0; ch < nch; ch++) {
             int     t = base * per_part;
@@ -1176,16 +1177,16 @@ lh_abr_target_bits(const LhConfig * cfg, int ResvSize, int substep, float pe[2][
                 targ_bits[gr][ch] = targ_bits[gr][ch] * LH_MAX_BITS_PER_GRANULE / granule;
     }
     if (mode_ext == LH_MPG_MD_MS_LR)
-        for (int gr = 0; gr < cfg->mode_gr; gr++)
+        for (int gr = 0; gr < LH_NGR; gr++)
             lh_reduce_side(targ_bits[gr], ms_ener_ratio[gr], per_part * nch, LH_MAX_BITS_PER_GRANULE);
-    for (int gr = 0; gr < cfg->mode_gr; gr++)
+    for (int gr = 0; gr < LH_NGR; gr++)
         for (int ch = 0; ch < nch; ch++) {
             if (targ_bits[gr][ch] > LH_MAX_BITS_PER_CHANNEL)
                 targ_bits[gr][ch] = LH_MAX_BITS_PER_CHANNEL;
             granted += targ_bits[gr][ch];
         }
     if (granted > frame_cap && granted > 0)
-        for (int gr = 0; gr < cfg->mode_gr; gr++)
+        for (int gr = 0; gr < LH_NGR; gr++)
             for (int ch = 0; ch < nch; ch++)
                 targ_bits[gr][ch] = targ_bits[gr][ch] * frame_cap / granted;
 }

@@ -197,15 +197,15 @@ lh_vbrold_frame(LhFrameOut * fo_in, int mode_ext, int msoff)
 
     /* VBR_old_prepare: the budgets at the largest frame */
     top_bits = lh_vbr_full_bits(cfg, maxi, ResvSize, &dummy, &resv_top);
-    avg = top_bits / cfg->mode_gr;      /* (the reference divides ResvFrameBegin's return value, quantize.c:1409) */
-    for (int gr = 0; gr < c.cfg->mode_gr; gr++) {
+    avg = top_bits / LH_NGR;      /* (the reference divides ResvFrameBegin's return value, quantize.c:1409) */
+    for (int gr = 0; gr < LH_NGR; gr++) {
         int const mxb = lh_on_pe(cfg, ResvSize, resv_top, &substep, pe_use[gr], max_bits[gr], avg, 0);
         if (mode_ext == LH_MPG_MD_MS_LR)
             lh_reduce_side(max_bits[gr], ms_ener_ratio[gr], avg, mxb);
         for (int ch = 0; ch < nch; ch++)
             bits += max_bits[gr][ch];
     }
-    for (int gr = 0; gr < c.cfg->mode_gr; gr++)
+    for (int gr = 0; gr < LH_NGR; gr++)
         for (int ch = 0; ch < 2; ch++) {
             if (ch >= nch)
                 max_bits[gr][ch] = 0;
@@ -221,7 +221,7 @@ lh_vbrold_frame(LhFrameOut * fo_in, int mode_ext, int msoff)
     {
         /* sv_qnt.masking_lower as the frame's last granule / channel leaves it (quantize.c:1420-1428); only the
          * next frame's psycho-acoustic model reads it */
-        int const ch = nch - 1, gl = cfg->mode_gr - 1;
+        int const ch = nch - 1, gl = LH_NGR - 1;
         float const pe = pe_use[gl][ch];
         if (L.block_type[gl][ch] != LH_SHORT_TYPE)
             masking_lower = lh_vbrold_masking_lower(cfg->mask_adjust - lh_vbrold_adjust(pe, 0));
@@ -241,7 +241,7 @@ lh_vbrold_frame(LhFrameOut * fo_in, int mode_ext, int msoff)
     }
     LH_SYNC_WG();
     for (int pass = 0;; pass++) {
-        for (int gr = 0; gr < c.cfg->mode_gr; gr++) {
+        for (int gr = 0; gr < LH_NGR; gr++) {
             if (w < nch)
                 lh_vbrold_granule(w, gr, msoff + w, pass, min_bits[gr][w], max_bits[gr][w], substep, &fo->gr[gr][w],
                                   fo->gr[0][w].scalefac);
@@ -256,7 +256,7 @@ lh_vbrold_frame(LhFrameOut * fo_in, int mode_ext, int msoff)
         used_bits = 0;
         fin = 0;
         analog_silence = 1;
-        for (int gr = 0; gr < c.cfg->mode_gr; gr++)
+        for (int gr = 0; gr < LH_NGR; gr++)
             for (int ch = 0; ch < nch; ch++) {
                 LhVbrOldSave const &sv = L.old[gr][ch];
                 used_bits += lh_uni_i(sv.used_bits);
@@ -290,7 +290,7 @@ lh_vbrold_frame(LhFrameOut * fo_in, int mode_ext, int msoff)
         }
         /* bitpressure_strategy (reference quantize.c:1456-1480): more noise allowed towards the top, smaller budgets */
         LH_SYNC_WG();
-        for (int gr = 0; gr < c.cfg->mode_gr; gr++) {
+        for (int gr = 0; gr < LH_NGR; gr++) {
             if (w < nch) {
                 LhVbrOldSave & sv = L.old[gr][w];
                 int const short_block = lh_uni_i(sv.R.block_type) == LH_SHORT_TYPE;

@@ -29,7 +29,11 @@
 
 #ifdef LH_EMU
 #include <string.h>
+#ifdef LH_LSF
+extern "C" { extern int lh_emu_poison_lds; }
+#else
 extern "C" { int lh_emu_poison_lds = 0; }
+#endif
 #endif
 #include "lh_static_tables.h"
 #include "lh_dev_common.h"
@@ -244,8 +248,7 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
     /* granules per frame: 2, or 1 for MPEG-2 / 2.5 (576 samples per frame; reference lame.c:797).  The transforms
      * below always run over two granules' worth of the staged window -- the second is the next frame's first and
      * is thrown away -- so that the one-granule frame needs no code of its own there. */
-    int const ngr = lh_uni_i(cfg->mode_gr);
-    int const fs = 576 * ngr;
+    constexpr int ngr = LH_NGR, fs = 576 * LH_NGR;
 
     /* ---- polyphase priming on the first frame (reference encoder.c:189-236) ---- */
 #if defined(LH_PROF) && !defined(LH_EMU)
@@ -399,7 +402,7 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
     int     substep = lh_uni_i(lh_lds.ss.substep_shaping);
     int     bitrate_index = lh_uni_i(cfg->bitrate_index);
     int     frame_bits = lh_uni_i(lh_frame_bits(cfg, bitrate_index, padding));
-    int     mean_bits = lh_uni_i((frame_bits - cfg->sideinfo_len * 8) / cfg->mode_gr);
+    int     mean_bits = lh_uni_i((frame_bits - cfg->sideinfo_len * 8) / LH_NGR);
     int     total_bits = 0;
 #ifdef LH_VBR_OLD
     int const vbr_old = (cfg->vbr == 2);
@@ -439,7 +442,7 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
         ResvSize = lh_uni_i(L.mean_bits);
         substep = lh_uni_i(L.targ_bits[0]);
         frame_bits = lh_frame_bits(cfg, bitrate_index, 0);
-        mean_bits = (frame_bits - cfg->sideinfo_len * 8) / cfg->mode_gr;
+        mean_bits = (frame_bits - cfg->sideinfo_len * 8) / LH_NGR;
     }
     if (abr) {
         int const bt[2][2] = { {L.block_type[0][0], L.block_type[0][1]}, {L.block_type[1][0], L.block_type[1][1]} };
@@ -447,7 +450,7 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
     }
     {
         /* ResvFrameBegin */
-        int const resvLimit = (8 * 256) * cfg->mode_gr - 8;
+        int const resvLimit = (8 * 256) * LH_NGR - 8;
         ResvMax = cfg->buffer_constraint - frame_bits;
         if (ResvMax > resvLimit)
             ResvMax = resvLimit;
@@ -597,7 +600,7 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
     int     drain_pre = 0, drain_post = 0;
     {
         int     stuffingBits = 0, over_bits;
-        ResvSize += mean_bits * cfg->mode_gr;
+        ResvSize += mean_bits * LH_NGR;
         if ((over_bits = ResvSize % 8) != 0)
             stuffingBits += over_bits;
         over_bits = (ResvSize - stuffingBits) - ResvMax;
@@ -661,6 +664,13 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
 
 #ifndef LH_WAVES_PER_EU
 #define LH_WAVES_PER_EU 2
+#endif
+/* the LH_LSF build of this file (MPEG-2 / 2.5 streams) is a second object in the same library: its own names */
+#ifdef LH_LSF
+#define lh_encode_kernel lh_encode_kernel_lsf
+#define lh_launch_encode lh_launch_encode_lsf
+#define lh_emu_encode lh_emu_encode_lsf
+#define lh_emu_encode_bytes lh_emu_encode_bytes_lsf
 #endif
 /* all frames of one stream (the workgroup's whole job) */
 LH_DEVFN void
@@ -736,7 +746,7 @@ lh_encode_stream(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, 
         ((uint32_t *) &L.ss)[c.tid] = ((const uint32_t *) &st->pefirbuf[0])[c.tid - LH_SS_WORDS_A];
     LH_SYNC_WG();               /* the state words are read by every thread from here on */
     int     slot = 0;           /* ring slot holding the ratios of the frame's first granule */
-    int const ngr = lh_uni_i(cfg->mode_gr), fs = 576 * ngr;     /* granules / samples per frame (1 / 576: MPEG-2, 2.5) */
+    constexpr int ngr = LH_NGR, fs = 576 * LH_NGR;      /* granules / samples per frame (1 / 576: MPEG-2, 2.5) */
     for (int f = c.d.frame_begin; f < c.d.frame_end; f++) {
         c.frame_base = (long long) fs * f - LH_MF_START;
         if (c.tid == 0) {
@@ -776,7 +786,7 @@ lh_encode_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, 
     lh_encode_stream(cfg, T, pcm, pcmf, descs, states, out, bytes, nstreams);
 }
 
-#if !defined(LH_EMU)
+#if !defined(LH_EMU) && !defined(LH_LSF)
 /* device self-test of the cross-lane primitives in lh_wave.h: each reduction is
  * compared with a serial evaluation through LDS; out[0] = number of mismatches */
 extern "C" __global__ void __launch_bounds__(64)
@@ -951,10 +961,18 @@ lh_emu_encode(const LhConfig * cfg, const LhTables * T, const int16_t * pcm,
     return lh_emu_encode_bytes(cfg, T, pcm, descs, states, out, (uint8_t *) 0, nstreams);
 }
 
+#ifndef LH_LSF
+extern "C" int lh_emu_encode_bytes_lsf(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, const LhStreamDesc * descs,
+                                       LhStreamState * states, LhFrameOut * out, uint8_t * bytes, int nstreams);
+#endif
 extern "C" int
 lh_emu_encode_bytes(const LhConfig * cfg, const LhTables * T, const int16_t * pcm,
                     const LhStreamDesc * descs, LhStreamState * states, LhFrameOut * out, uint8_t * bytes, int nstreams)
 {
+#ifndef LH_LSF
+    if (cfg->mode_gr == 1)      /* an MPEG-2 / 2.5 stream: the other object's kernel (as lh_api.cpp picks the launcher) */
+        return lh_emu_encode_bytes_lsf(cfg, T, pcm, descs, states, out, bytes, nstreams);
+#endif
     hipemu_dim3 grid = { (unsigned) nstreams, 1, 1 }, block = { LH_BLOCK, 1, 1 };
     hipemu_run(grid, block,[=] () {
                lh_encode_kernel(cfg, T, pcm, (const float *) 0, descs, states, out, bytes, nstreams);

@@ -36,7 +36,11 @@ def emu():
                                           ("mono_cbr160_48k_bursts_q5", 6), ("mono_vbr2_44k", 6), ("mono_abr100_44k", 5),
                                           ("vbrold2_js_44k", 8), ("vbrold4_js_44k_white", 6), ("vbrold0_js_48k_bursts", 8),
                                           ("vbrold5_st_32k_q5", 6), ("vbrold1_js_44k_q0", 2), ("vbrold3_js_44k_silence", 4),
-                                          ("mono_vbrold4_44k", 6)])
+                                          ("mono_vbrold4_44k", 6),
+                                          # MPEG-2 / 2.5: one-granule frames, partitioned scalefactors
+                                          ("cbr64_js_22k_lsf", 8), ("cbr32_js_16k_bursts_lsf", 10), ("cbr16_js_8k_lsf", 8),
+                                          ("vbr4_js_22k_lsf", 8), ("abr56_js_22k_lsf", 6), ("mono_cbr48_22k_lsf", 6),
+                                          ("vbrold2_js_24k_lsf", 6)])
 def test_kernel_source_matches_oracle(name, nframes, emu, oracle):
     g, pcm = helpers.load_golden(name)
     sr, br, mode, q = helpers.golden_settings(g)

@@ -10,7 +10,10 @@ from lamehip.types import struct_diff
 
 CASES = [(44100, 128, None, None, 5, 4.0), (48000, 320, 1, None, 6, 2.0), (44100, 192, 0, None, 7, 2.0),
          (32000, 96, None, None, 8, 2.0), (44100, 224, None, 1, 9, 1.5), (44100, 128, None, 4, 10, 2.0),
-         (48000, 128, None, 7, 11, 1.5)]
+         (48000, 128, None, 7, 11, 1.5),
+         # MPEG-2 / 2.5 (one granule per frame)
+         (22050, 64, None, None, 12, 2.0), (24000, 96, 0, None, 13, 1.5), (16000, 32, None, 2, 14, 2.0),
+         (12000, 32, None, None, 15, 2.0), (8000, 16, None, None, 16, 2.5), (11025, 40, None, 5, 17, 2.0)]
 
 
 @pytest.mark.parametrize("sr,br,mode,q,seed,secs", CASES)
@@ -36,7 +39,8 @@ def test_oracle_matches_reference(sr, br, mode, q, seed, secs, oracle, reference
 
 VBR_CASES = [(44100, 2, None, None, 21, 2.0, False), (44100, 4, None, None, 22, 1.5, True),
              (48000, 0, None, None, 23, 1.5, False), (32000, 6, 0, None, 24, 1.5, False),
-             (44100, 5, None, 7, 25, 1.5, False), (44100, 9, None, 5, 26, 1.5, False), (48000, 8, None, None, 27, 1.0, True)]
+             (44100, 5, None, 7, 25, 1.5, False), (44100, 9, None, 5, 26, 1.5, False), (48000, 8, None, None, 27, 1.0, True),
+             (22050, 4, None, None, 28, 2.0, False), (16000, 6, None, None, 29, 1.5, True), (24000, 2, 0, 5, 30, 1.5, False)]
 
 
 @pytest.mark.parametrize("sr,vq,mode,q,seed,secs,white", VBR_CASES)
@@ -65,7 +69,8 @@ def test_vbr_oracle_matches_reference(sr, vq, mode, q, seed, secs, white, oracle
 
 
 ABR_CASES = [(44100, 128, None, None, 51, 1.5, False), (48000, 200, 0, None, 52, 1.2, False),
-             (32000, 96, None, 5, 53, 1.2, True), (44100, 313, None, 0, 54, 1.0, False), (44100, 150, 1, 7, 55, 1.2, False)]
+             (32000, 96, None, 5, 53, 1.2, True), (44100, 313, None, 0, 54, 1.0, False), (44100, 150, 1, 7, 55, 1.2, False),
+             (22050, 56, None, None, 56, 1.5, False), (16000, 40, None, None, 57, 1.5, True)]
 
 
 @pytest.mark.parametrize("sr,kb,mode,q,seed,secs,white", ABR_CASES)
@@ -93,7 +98,7 @@ def test_abr_oracle_matches_reference(sr, kb, mode, q, seed, secs, white, oracle
 @pytest.mark.parametrize("sr,kw,q,nch,mode", [(44100, dict(brate=128), None, 1, None), (48000, dict(brate=64), 5, 1, None),
                                                (44100, dict(vbr_q=3), None, 1, None), (32000, dict(abr=72), None, 1, None),
                                                (44100, dict(brate=112), None, 2, 3), (48000, dict(vbr_q=1), None, 2, 3),
-                                               (44100, dict(abr=150), 7, 2, 3)])
+                                               (44100, dict(abr=150), 7, 2, 3), (22050, dict(brate=48), None, 1, None), (16000, dict(vbr_q=5), None, 1, None)])
 def test_mono_oracle_matches_reference(sr, kw, q, nch, mode, oracle, reference):
     """One channel out: from one input channel (nch = 1) or from two mixed down (mode 3 = MONO)."""
     pcm = helpers.synth_stream(61 + sr // 1000, int(sr * 1.3), sr, 1.0 / 7)
