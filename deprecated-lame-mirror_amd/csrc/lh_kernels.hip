@@ -541,7 +541,6 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
                 g = lh_uniform(L.rg[ch].g);
                 LH_PA(5, t_ol);
             }
-            else
             LH_PT(t_fin);
             lh_rg_put(c, R, g);
             lh_best_scalefac_store(ch, gr, fo->gr[0][ch].scalefac, L.block_type[0][ch]);
@@ -682,6 +681,15 @@ lh_encode_stream(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, 
     int const sidx = (int) blockIdx.x;
     if (sidx >= nstreams)
         return;
+#ifndef LH_VBR_OLD
+    /* a build without the old VBR loop (the profiling variant: its cycle counters take that loop's LDS) must not fall
+     * into the CBR loop with a vbr_rh configuration: status bit 32, nothing encoded */
+    if (cfg->vbr == 2) {
+        if (threadIdx.x == 0)
+            states[sidx].status |= 32;
+        return;
+    }
+#endif
 #ifdef LH_EMU
     /* test aid: LDS does not survive from launch to launch on the device; make any
      * dependence on stale contents visible to the CPU emulation */

@@ -18,16 +18,18 @@ def workload_streams(workload):
 
 def main(pmc, stats, workload):
     v = {}
+    kernel_name = "lh_encode_kernel"
     for line in open(pmc):
         p = line.split()
         if len(p) >= 5 and p[0].startswith("lh_encode"):
             v[p[1]] = (int(p[2]), float(p[3]), float(p[4]))
+            kernel_name = p[0]
     launches = max([x[0] for x in v.values()] + [1])
 
     def per(name):
         return v[name][2] if name in v else None
     fetch, write = per("FETCH_SIZE"), per("WRITE_SIZE")
-    out = {"date": datetime.date.today().isoformat(), "workload": workload, "kernel": "lh_encode_kernel",
+    out = {"date": datetime.date.today().isoformat(), "workload": workload, "kernel": kernel_name,
            "launches_profiled": launches}
     try:
         out["commit"] = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], text=True, stderr=subprocess.DEVNULL).strip()

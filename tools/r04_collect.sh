@@ -10,7 +10,8 @@ bash tools/gpu_profile.sh r04 --streams 1024 --seconds 60 --steps 1 --warmup 1 $
 bash tools/gpu_profile.sh r04_vbr2 --streams 1024 --seconds 5 --steps 2 --warmup 1 $X --vbr 2 > gpurun_out/log_r04_vbr2.txt 2>&1
 bash tools/gpu_profile.sh r04_vbrold2 --streams 1024 --seconds 5 --steps 2 --warmup 1 $X --vbr 2 --vbr-old > gpurun_out/log_r04_vbrold2.txt 2>&1
 bash tools/gpu_profile.sh r04_cbr320 --streams 1024 --seconds 5 --steps 2 --warmup 1 $X --samplerate 48000 --brate 320 --mode 1 --bursts 40 > gpurun_out/log_r04_cbr320.txt 2>&1
-for t in "" _vbr2 _vbrold2 _cbr320; do
+bash tools/gpu_profile.sh r04_lsf --streams 1024 --seconds 10 --steps 2 --warmup 1 $X --samplerate 22050 --brate 64 > gpurun_out/log_r04_lsf.txt 2>&1
+for t in "" _vbr2 _vbrold2 _cbr320 _lsf; do
   cp gpurun_out/summ_r04${t}_pmc.json profiles/r04_pmc${t}.json
   cp gpurun_out/summ_r04${t}_pmc.txt profiles/r04${t}_pmc.txt
   cp gpurun_out/summ_r04${t}_kernel_stats.txt profiles/r04${t}_kernel_stats.txt
