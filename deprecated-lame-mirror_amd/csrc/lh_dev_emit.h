@@ -366,7 +366,11 @@ lh_emit_frame(const LhFrameOut * fo_in, int drain_pre, int drain_post, int frame
     int const tid = c.tid, nch = cfg->channels, sl = cfg->sideinfo_len;
     int const toggling = !cfg->disable_reservoir;
     int     plen[4], poff[4], np = 0, nbits, flag;
-    long long cursor, hq[16];
+    /* Frame headers the main data still has to jump over.  MPEG-1: a frame holds at least 60 bytes of main data and the
+     * back pointer reaches 511 bytes: never more than 10.  MPEG-2 / 2.5: frames of 24 bytes with 21 of side information
+     * exist (8 kb/s at 24 kHz) while the back pointer reaches 255 bytes: up to 85 + the frames in flight. */
+    constexpr int NHQ = LH_IS_LSF ? LH_EMIT_HQ_MAX : 16;
+    long long cursor, hq[NHQ];
     int     nq;
     uint8_t *out = bytes + c.d.bytes_base;
     drain_pre = lh_uni_i(drain_pre);
@@ -387,19 +391,19 @@ lh_emit_frame(const LhFrameOut * fo_in, int drain_pre, int drain_post, int frame
     nbits += drain_post;
     cursor = st->em_cursor;
     nq = st->em_nq;
-    for (int k = 0; k < 16; k++)
+    for (int k = 0; k < NHQ; k++)
         hq[k] = (k < nq) ? st->em_hq[k] : 0;
     flag = st->em_anc_flag;
     /* this frame's header joins the pending ones */
     {
         long long const here = st->em_next_header;
-        int const queue_full = nq >= 16;
+        int const queue_full = nq >= NHQ;
         if (!queue_full)
             hq[nq++] = here;
         LH_SYNC_WG();           /* everyone has read the state */
         if (tid == 0) {
             /* status bit 8: something could not be written (slice of the byte pool too small, or more
-             * than 16 headers pending): the host refuses the stream's bytes */
+             * headers pending than the queue holds): the host refuses the stream's bytes */
             if (queue_full || here + sl > c.d.bytes_cap)
                 lh_lds_or((uint32_t *) &lh_lds.ss.status, 8u);
             unsigned char h[40];
@@ -475,7 +479,7 @@ lh_emit_frame(const LhFrameOut * fo_in, int drain_pre, int drain_post, int frame
     if (tid == 0) {
         st->em_cursor = cursor;
         st->em_nq = nq;
-        for (int k = 0; k < 16; k++)
+        for (int k = 0; k < NHQ; k++)
             st->em_hq[k] = (k < nq) ? hq[k] : 0;
         st->em_anc_flag = flag;
     }

@@ -14,6 +14,7 @@ extern "C" {
 #endif
 
 #define LH_NPROF 44             /* cycle accumulators per wave (profiling builds) */
+#define LH_EMIT_HQ_MAX 128      /* frame headers that can be pending inside a stretch of main data (device bit packer) */
 #define LH_XMIN_N 61            /* 22 long + 13*3 short values of III_psy_xmin */
 
 typedef struct LhStreamState {
@@ -51,7 +52,7 @@ typedef struct LhStreamState {
      * bits of the frame's granules until the frame is assembled */
     long long em_next_header;
     long long em_cursor;
-    long long em_hq[16];
+    long long em_hq[LH_EMIT_HQ_MAX];    /* (16 used by MPEG-1 streams; MPEG-2 / 2.5: see lh_dev_emit.h) */
     int     em_nq;
     int     em_anc_flag;
     uint32_t em_part[2][2][132];

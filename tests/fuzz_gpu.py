@@ -39,6 +39,16 @@ ABR_SETTINGS = [(44100, 1128, None, None), (48000, 1190, 1, None), (32000, 1096,
                 (44100, 1080, None, 7), (48000, 1313, 0, None)]
 
 
+# MPEG-2 / 2.5 output rates (one granule per frame), all four rate controls in one list: the output rate is pinned to the
+# input rate, so that the checker is fed the same PCM; "lsf" on the command line
+LSF_SETTINGS = [(22050, 64, None, None), (24000, 80, None, 2), (16000, 32, None, None), (22050, 160, 0, None),
+                (24000, 64, None, 5), (16000, 64, 1, 0), (12000, 32, None, None), (11025, 40, None, None),
+                (8000, 16, None, None), (8000, 24, 0, 7), (22050, 96, None, 9), (24000, 112, 1, 3),
+                (22050, -4, None, None), (16000, -6, None, None), (24000, -2, 0, 5), (12000, -8, None, None), (8000, -9, None, None),
+                (22050, 1056, None, None), (16000, 1024, None, 5), (11025, 1032, 0, None), (24000, 1120, 1, 2)]
+LSF_OLD_SETTINGS = [(22050, -2, None, None), (24000, -4, None, None), (16000, -5, 0, None), (12000, -6, None, 5), (22050, 0, None, 2)]
+
+
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     secs = float(sys.argv[2]) if len(sys.argv) > 2 else 2.0
@@ -47,14 +57,17 @@ def main():
     bad = tot = 0
     t0 = time.time()
     which = sys.argv[4] if len(sys.argv) > 4 else "cbr"
-    for sr, br, mode, q in {"vbr": VBR_SETTINGS, "abr": ABR_SETTINGS, "old": OLD_SETTINGS}.get(which, SETTINGS):
+    lsf = which.startswith("lsf")
+    old_loop = which in ("old", "lsfold")
+    for sr, br, mode, q in {"vbr": VBR_SETTINGS, "abr": ABR_SETTINGS, "old": OLD_SETTINGS, "lsf": LSF_SETTINGS,
+                            "lsfold": LSF_OLD_SETTINGS}.get(which, SETTINGS):
         if br >= 1000:
             enc = lamehip.Encoder(sr, 0, mode, q, abr=br - 1000, out_samplerate=sr)    # (no rate change: the checker is fed the same PCM)
         elif br > 0:
-            enc = lamehip.Encoder(sr, br, mode, q)
+            enc = lamehip.Encoder(sr, br, mode, q, out_samplerate=sr if lsf else 0)
         else:
-            enc = lamehip.Encoder(sr, mode=mode, quality=q, vbr_q=-br, out_samplerate=sr if -br >= 7 else 0,
-                                  vbr_mode=2 if which == "old" else 4)
+            enc = lamehip.Encoder(sr, mode=mode, quality=q, vbr_q=-br, out_samplerate=sr if (-br >= 7 or lsf) else 0,
+                                  vbr_mode=2 if old_loop else 4)
         cfg, tab = enc.config(), enc.tables()
         n = int(sr * secs)
         pcms = [tg._stress_signal(seed0 + i, n - 13 * (i % 31), sr) for i in range(B)]

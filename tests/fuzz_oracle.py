@@ -25,15 +25,21 @@ def main():
     ref, orc = helpers.Reference(), helpers.Oracle()
     bad = tot = 0
     t0 = time.time()
-    for sr, br, mode, q in {"vbr": fz.VBR_SETTINGS, "abr": fz.ABR_SETTINGS, "old": fz.OLD_SETTINGS}.get(which, fz.SETTINGS):
+    lsf = which.startswith("lsf")
+    old_loop = which in ("old", "lsfold")
+    for sr, br, mode, q in {"vbr": fz.VBR_SETTINGS, "abr": fz.ABR_SETTINGS, "old": fz.OLD_SETTINGS, "lsf": fz.LSF_SETTINGS,
+                            "lsfold": fz.LSF_OLD_SETTINGS}.get(which, fz.SETTINGS):
         kw = dict(mode=mode, quality=q)
         rkw = dict(mode=-1 if mode is None else mode, quality=-1 if q is None else q)
+        if lsf:
+            kw.update(out_samplerate=sr)
+            rkw.update(out_samplerate=sr)
         if br >= 1000:
             kw.update(abr=br - 1000, out_samplerate=sr)
             rkw.update(abr=br - 1000, out_samplerate=sr)
         elif br <= 0:
-            kw.update(vbr_q=-br, out_samplerate=sr if -br >= 7 else 0, vbr_mode=2 if which == "old" else 4)
-            rkw.update(vbr_q=-br, out_samplerate=sr if -br >= 7 else 0, vbr_mode=2 if which == "old" else 4)
+            kw.update(vbr_q=-br, out_samplerate=sr if (-br >= 7 or lsf) else 0, vbr_mode=2 if old_loop else 4)
+            rkw.update(vbr_q=-br, out_samplerate=sr if (-br >= 7 or lsf) else 0, vbr_mode=2 if old_loop else 4)
         enc = lamehip.Encoder(sr, max(br, 0) if br < 1000 else 0, require_device=False, **kw)
         cfg, tab = enc.config(), enc.tables()
         n = int(sr * secs)
