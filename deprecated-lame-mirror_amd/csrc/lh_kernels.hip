@@ -671,6 +671,42 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
 #define lh_emu_encode lh_emu_encode_lsf
 #define lh_emu_encode_bytes lh_emu_encode_bytes_lsf
 #endif
+#if !defined(LH_EMU) && !defined(LH_NO_PRIO)
+/* Issue priority by progress.  At 1024 streams every SIMD hosts two waves of two different streams for the whole launch, and
+ * the SIMD's issue arbiter prefers the older of two ready waves: identical streams finish up to 14 % apart depending on
+ * where the dispatcher put them (tools/stream_balance.py, tools/ubench/hwid.hip), streams that differ in content further
+ * apart still -- and a launch ends with its last stream.  Each wave posts the frames its stream has left at its
+ * (XCC, SE, SH, CU, SIMD, wave slot) and reads the other slot's figure once per frame: the wave with more left takes the
+ * higher priority (s_setprio).  Scheduling only -- results cannot depend on it; a finished stream leaves 0. */
+static __device__ int lh_prio_tab[8 * 8 * 2 * 16 * 4 * 2];
+LH_DEVFN int
+lh_prio_index()
+{
+    unsigned v, x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(v));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    /* HW_ID: wave slot [3:0], SIMD [5:4], CU [11:8], SH [12], SE [15:13] */
+    return (int) ((((((x & 7u) * 8u + ((v >> 13) & 7u)) * 2u + ((v >> 12) & 1u)) * 16u + ((v >> 8) & 15u)) * 4u + ((v >> 4) & 3u)) * 2u
+                  + (v & 1u));
+}
+LH_DEVFN void
+lh_prio_tick(int me, int left)
+{
+    if (lh_lane() == 0)
+        __hip_atomic_store(&lh_prio_tab[me], left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int const other = lh_uni_i(__hip_atomic_load(&lh_prio_tab[me ^ 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    if (left > other)
+        __builtin_amdgcn_s_setprio(1);
+    else
+        __builtin_amdgcn_s_setprio(0);
+}
+#define LH_PRIO_INDEX() lh_prio_index()
+#define LH_PRIO_TICK(me, left) lh_prio_tick(me, left)
+#else
+#define LH_PRIO_INDEX() 0
+#define LH_PRIO_TICK(me, left) do { (void) (me); } while (0)
+#endif
+
 /* all frames of one stream (the workgroup's whole job) */
 LH_DEVFN void
 lh_encode_stream(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, const float *pcmf,
@@ -755,7 +791,9 @@ lh_encode_stream(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, 
     LH_SYNC_WG();               /* the state words are read by every thread from here on */
     int     slot = 0;           /* ring slot holding the ratios of the frame's first granule */
     constexpr int ngr = LH_NGR, fs = 576 * LH_NGR;      /* granules / samples per frame (1 / 576: MPEG-2, 2.5) */
+    int const prio_me = LH_PRIO_INDEX();
     for (int f = c.d.frame_begin; f < c.d.frame_end; f++) {
+        LH_PRIO_TICK(prio_me, c.d.frame_end - f);
         c.frame_base = (long long) fs * f - LH_MF_START;
         if (c.tid == 0) {
             L.ctx.frame_base = c.frame_base;    /* read by the stages after the next workgroup barrier */
@@ -764,6 +802,7 @@ lh_encode_stream(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, 
         lh_encode_frame(c, &out[c.d.out_index + (f - c.d.frame_begin)], carry);
         slot = (slot + ngr) % 3;
     }
+    LH_PRIO_TICK(prio_me, 0);
     if (c.tid < LH_SS_WORDS_A)
         ((uint32_t *) &st->loudness_sq_save[0])[c.tid] = ((const uint32_t *) &L.ss)[c.tid];
     else if (c.tid < LH_SS_WORDS_A + LH_SS_WORDS_B)

@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <map>
 #include <tuple>
+#include <vector>
 __global__ void k(unsigned *out, unsigned *xcc, int spin)
 {
     extern __shared__ char lds[];
@@ -47,6 +48,22 @@ int main(int argc, char **argv)
     printf("distinct SIMDs used: %zu; waves per SIMD histogram:", per.size());
     for (int i = 0; i < 64; i++) if (cnt[i]) printf(" %dx%d", cnt[i], i);
     printf("\n");
+    {   // who shares a CU: workgroup ids, and per wave the SIMD and the wave slot
+        std::map<std::tuple<unsigned, unsigned, unsigned, unsigned>, std::vector<std::tuple<int, int, unsigned, unsigned>>> cus;
+        for (int b = 0; b < B; b++)
+            for (int w = 0; w < W; w++) {
+                unsigned v = h[b * W + w], x = hx[b * W + w] & 15u;
+                cus[std::make_tuple(x, (v >> 13) & 7, (v >> 12) & 1, (v >> 8) & 15)].push_back(std::make_tuple(b, w, (v >> 4) & 3, v & 15));
+            }
+        int shown = 0;
+        for (auto &c : cus) {
+            if (shown++ >= 6) break;
+            printf("xcc %u se %u sh %u cu %u:", std::get<0>(c.first), std::get<1>(c.first), std::get<2>(c.first), std::get<3>(c.first));
+            for (auto &e : c.second) printf("  wg %d w%d simd %u slot %u", std::get<0>(e), std::get<1>(e), std::get<2>(e), std::get<3>(e));
+            printf("\n");
+        }
+        printf("CUs used: %zu\n", cus.size());
+    }
     for (int b = 0; b < 4; b++) { printf("wg %d:", b); for (int w = 0; w < W; w++) printf(" %08x/x%u", h[b * W + w], hx[b * W + w] & 15u); printf("\n"); }
     return 0;
 }
