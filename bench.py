@@ -371,6 +371,9 @@ def roofline_block(frames, kavg_s, pmc_name):
              "insts_per_cycle_per_simd": pmc.get("insts_per_cycle_per_simd") if fresh else None,
              "wave_insts_per_frame": pmc.get("wave_insts_per_frame") if fresh else None,
              "shader_clock_ghz": pmc.get("shader_clock_ghz") if fresh else None,
+             "clock_from": pmc.get("clock_from") if fresh else None,
+             # mean share of the launch a wave is resident: a launch ends with its slowest stream
+             "wave_residency": pmc.get("wave_residency") if fresh else None,
              "bound_in_practice": "instruction issue of a serial search: one wave issues at most one instruction per "
                                   "~4.6 cycles (tools/ubench/lat2.hip) and a stream offers two chains (its channels), "
                                   "one SIMD's worth; HBM is idle",

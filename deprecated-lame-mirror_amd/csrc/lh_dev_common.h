@@ -367,6 +367,7 @@ struct LhPsyCarry {
 struct LhWaveCarry {
     LhPsyCarry nb;
     float   sb[9];
+    int     prio_rel, prio_late;        /* issue priority (lh_prio_apply in lh_kernels.hip): scheduling only */
 };
 
 /* The stream's small state words (the members of LhStreamState from loudness_sq_save to

@@ -230,6 +230,63 @@ lh_prepare_granule(const LhCtx & c, int ch, int gr, int msoff, int substep)
 }
 
 
+#if !defined(LH_EMU) && !defined(LH_NO_PRIO)
+/* Issue priority by progress and by role.  At 1024 streams every SIMD hosts two waves of two different streams for the whole
+ * launch, and the SIMD's issue arbiter prefers the older of two ready waves: identical streams finish up to 14 % apart
+ * depending on where the dispatcher put them (tools/stream_balance.py, tools/ubench/hwid.hip), streams that differ in content
+ * further apart still -- and a launch ends with its last stream.  Each wave posts the frames its stream has left at its
+ * (XCC, SE, SH, CU, SIMD, wave slot) and reads the other slot's figure once per frame: a wave whose stream is more than a
+ * frame behind the other's takes the top priority (s_setprio), one that is more than a frame ahead the bottom one.  In
+ * between the role decides: of a stream's two channels the one that reached the last granule barrier second -- the other
+ * waited for it -- goes first.  Scheduling only: results cannot depend on it; a finished stream leaves 0. */
+static __device__ int lh_prio_tab[8 * 8 * 2 * 16 * 4 * 2];
+LH_DEVFN int
+lh_prio_index()
+{
+    unsigned v, x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(v));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    /* HW_ID: wave slot [3:0], SIMD [5:4], CU [11:8], SH [12], SE [15:13] */
+    return (int) ((((((x & 7u) * 8u + ((v >> 13) & 7u)) * 2u + ((v >> 12) & 1u)) * 16u + ((v >> 8) & 15u)) * 4u + ((v >> 4) & 3u)) * 2u
+                  + (v & 1u));
+}
+LH_DEVFN void
+lh_prio_apply(int rel, int late)
+{
+#ifdef LH_PRIO_NOROLE
+    late = 0;
+#endif
+    int const level = lh_uni_i(rel > 0 ? 3 : rel < 0 ? 0 : 1 + (late != 0));
+    if (level == 3)
+        __builtin_amdgcn_s_setprio(3);
+    else if (level == 2)
+        __builtin_amdgcn_s_setprio(2);
+    else if (level == 1)
+        __builtin_amdgcn_s_setprio(1);
+    else
+        __builtin_amdgcn_s_setprio(0);
+}
+/* frames left against the other slot's: +1 far behind, -1 far ahead, 0 within LH_PRIO_BAND frames */
+#ifndef LH_PRIO_BAND
+#define LH_PRIO_BAND 1
+#endif
+LH_DEVFN int
+lh_prio_tick(int me, int left)
+{
+    if (lh_lane() == 0)
+        __hip_atomic_store(&lh_prio_tab[me], left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int const other = lh_uni_i(__hip_atomic_load(&lh_prio_tab[me ^ 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    return (left > other + LH_PRIO_BAND) ? 1 : (left + LH_PRIO_BAND < other) ? -1 : 0;
+}
+#define LH_PRIO_INDEX() lh_prio_index()
+#define LH_PRIO_TICK(me, left) lh_prio_tick(me, left)
+#define LH_PRIO_APPLY(rel, late) lh_prio_apply(rel, late)
+#else
+#define LH_PRIO_INDEX() 0
+#define LH_PRIO_TICK(me, left) 0
+#define LH_PRIO_APPLY(rel, late) do { } while (0)
+#endif
+
 /* The frame and the stream loop are inlined into the kernel: out of line they saved and restored ~60 registers per
  * frame through scratch memory, 50 KB of HBM traffic per frame at no gain. */
 
@@ -567,13 +624,23 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
                 first = (int) lh_bcast_u32((uint32_t) *(volatile int *) &L.gr0_done[1 - ch], 0) != stamp;
                 if (lane == 0)
                     *(volatile int *) &L.gr0_done[ch] = stamp;
+                carry.prio_late = !first;
                 if (first) {
                     prepared_nonzero = lh_prepare_granule(c, ch, 1, msoff, substep);
                     prepared = 1;
                 }
             }
+            else if (nch == 2) {
+                /* who is last at this barrier (for the issue priority only: see lh_prio_apply) */
+                int const stamp = -(lh_uni_i(lh_lds.ss.frame_number) + 1);
+                LH_WAVE_SYNC();
+                carry.prio_late = (int) lh_bcast_u32((uint32_t) *(volatile int *) &L.gr0_done[1 - ch], 0) == stamp;
+                if (lane == 0)
+                    *(volatile int *) &L.gr0_done[ch] = stamp;
+            }
         }
         LH_SYNC_WG();
+        LH_PRIO_APPLY(carry.prio_rel, carry.prio_late);
         {
             int const used = lh_uni_i(L.bits_used[0] + L.bits_used[1]);
             ResvSize -= used;
@@ -671,42 +738,6 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
 #define lh_emu_encode lh_emu_encode_lsf
 #define lh_emu_encode_bytes lh_emu_encode_bytes_lsf
 #endif
-#if !defined(LH_EMU) && !defined(LH_NO_PRIO)
-/* Issue priority by progress.  At 1024 streams every SIMD hosts two waves of two different streams for the whole launch, and
- * the SIMD's issue arbiter prefers the older of two ready waves: identical streams finish up to 14 % apart depending on
- * where the dispatcher put them (tools/stream_balance.py, tools/ubench/hwid.hip), streams that differ in content further
- * apart still -- and a launch ends with its last stream.  Each wave posts the frames its stream has left at its
- * (XCC, SE, SH, CU, SIMD, wave slot) and reads the other slot's figure once per frame: the wave with more left takes the
- * higher priority (s_setprio).  Scheduling only -- results cannot depend on it; a finished stream leaves 0. */
-static __device__ int lh_prio_tab[8 * 8 * 2 * 16 * 4 * 2];
-LH_DEVFN int
-lh_prio_index()
-{
-    unsigned v, x;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(v));
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
-    /* HW_ID: wave slot [3:0], SIMD [5:4], CU [11:8], SH [12], SE [15:13] */
-    return (int) ((((((x & 7u) * 8u + ((v >> 13) & 7u)) * 2u + ((v >> 12) & 1u)) * 16u + ((v >> 8) & 15u)) * 4u + ((v >> 4) & 3u)) * 2u
-                  + (v & 1u));
-}
-LH_DEVFN void
-lh_prio_tick(int me, int left)
-{
-    if (lh_lane() == 0)
-        __hip_atomic_store(&lh_prio_tab[me], left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int const other = lh_uni_i(__hip_atomic_load(&lh_prio_tab[me ^ 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    if (left > other)
-        __builtin_amdgcn_s_setprio(1);
-    else
-        __builtin_amdgcn_s_setprio(0);
-}
-#define LH_PRIO_INDEX() lh_prio_index()
-#define LH_PRIO_TICK(me, left) lh_prio_tick(me, left)
-#else
-#define LH_PRIO_INDEX() 0
-#define LH_PRIO_TICK(me, left) do { (void) (me); } while (0)
-#endif
-
 /* all frames of one stream (the workgroup's whole job) */
 LH_DEVFN void
 lh_encode_stream(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, const float *pcmf,
@@ -771,6 +802,8 @@ lh_encode_stream(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, 
      * overlap and the psy model's previous partition energies in registers (LhWaveCarry), its band
      * energies / thresholds in the LDS ring (LhLds.psy_en).  HBM sees them once per launch. */
     LhWaveCarry carry;
+    carry.prio_rel = 0;
+    carry.prio_late = 0;
     LhStreamState *st = c.st;
     for (int p = 0; p < 2; p++) {
         carry.nb.n1[p] = st->nb_l1[c.wave + 2 * p][c.lane];
@@ -793,7 +826,8 @@ lh_encode_stream(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, 
     constexpr int ngr = LH_NGR, fs = 576 * LH_NGR;      /* granules / samples per frame (1 / 576: MPEG-2, 2.5) */
     int const prio_me = LH_PRIO_INDEX();
     for (int f = c.d.frame_begin; f < c.d.frame_end; f++) {
-        LH_PRIO_TICK(prio_me, c.d.frame_end - f);
+        carry.prio_rel = LH_PRIO_TICK(prio_me, c.d.frame_end - f);
+        LH_PRIO_APPLY(carry.prio_rel, carry.prio_late);
         c.frame_base = (long long) fs * f - LH_MF_START;
         if (c.tid == 0) {
             L.ctx.frame_base = c.frame_base;    /* read by the stages after the next workgroup barrier */
@@ -802,7 +836,7 @@ lh_encode_stream(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, 
         lh_encode_frame(c, &out[c.d.out_index + (f - c.d.frame_begin)], carry);
         slot = (slot + ngr) % 3;
     }
-    LH_PRIO_TICK(prio_me, 0);
+    (void) LH_PRIO_TICK(prio_me, 0);
     if (c.tid < LH_SS_WORDS_A)
         ((uint32_t *) &st->loudness_sq_save[0])[c.tid] = ((const uint32_t *) &L.ss)[c.tid];
     else if (c.tid < LH_SS_WORDS_A + LH_SS_WORDS_B)

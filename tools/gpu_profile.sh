@@ -28,12 +28,12 @@ i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
            "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_BRANCH" \
            "SQ_INSTS_SMEM SQ_INSTS_FLAT SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_FLAT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_CVT" \
-           "FETCH_SIZE" "WRITE_SIZE"; do
+           "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE GRBM_COUNT"; do
   i=$((i+1))
   timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/pmc_${TAG}_$i -- python $ROOT/bench.py $ARGS > $OUT/pmc_${TAG}_$i.log 2>&1
 done
 { echo "# rocprofv3 --pmc <set> --kernel-trace -- python bench.py $ARGS   (one pass per set; sums over the launches of the run)";
-  for j in 1 2 3 4 5; do python $ROOT/tools/pmc_summary.py $OUT/pmc_${TAG}_$j lh_encode; done; } > $OUT/summ_${TAG}_pmc.txt
+  for j in 1 2 3 4 5 6; do python $ROOT/tools/pmc_summary.py $OUT/pmc_${TAG}_$j lh_encode; done; } > $OUT/summ_${TAG}_pmc.txt
 rm -rf $OUT/kt_$TAG $OUT/pmc_${TAG}_[0-9]   # raw traces are large; the summaries are what is kept
 python $ROOT/tools/pmc_to_json.py $OUT/summ_${TAG}_pmc.txt $OUT/summ_${TAG}_kernel_stats.txt "bench.py $ARGS" > $OUT/summ_${TAG}_pmc.json
 cat $OUT/summ_${TAG}_kernel_stats.txt | cut -c1-250 | head -12

@@ -60,17 +60,35 @@ def main(pmc, stats, workload):
                 out["kernel_avg_ns"] = float(f[3])
             except (ValueError, IndexError):
                 pass
-    for name in ("SQ_INSTS_VMEM", "SQ_INSTS_FLAT", "SQ_INSTS_SMEM", "SQ_WAIT_INST_ANY"):
+    for name in ("SQ_INSTS_VMEM", "SQ_INSTS_FLAT", "SQ_INSTS_SMEM", "SQ_WAIT_INST_ANY", "GRBM_GUI_ACTIVE", "GRBM_COUNT"):
         if name in v:
             out[name] = per(name)
     if "SQ_INSTS_VALU" in v and "kernel_avg_ns" in out and "SQ_WAVE_CYCLES" in v:
-        # The clock the kernel ran at, from the counters themselves: SQ_WAVE_CYCLES counts quad-cycles per resident
-        # wave, and every wave of this kernel is resident from the launch to its end (1024 workgroups x 2 waves on
-        # 1024 SIMDs, two per SIMD), so 4 x SQ_WAVE_CYCLES / waves = the kernel's length in shader cycles.
+        # The clock the kernel ran at, from the counters themselves.  GRBM_GUI_ACTIVE counts the cycles the graphics
+        # engine is busy (one counter per XCD, summed: / 8): for a lone kernel that is its length in shader cycles.
+        # Without that pass: SQ_BUSY_CYCLES (cycles a shader engine holds waves, summed over 32 engines) -- a lower
+        # bound, an engine is idle once its last stream is through.  (Round 3/4's first records took 4 x SQ_WAVE_CYCLES /
+        # waves for the kernel's length: that is the MEAN residence of a wave, 10 % short of the launch at 1024 unequal
+        # streams -- it is reported as wave_residency now.)
         waves = 2 * int(workload_streams(workload))
-        cycles = 4.0 * per("SQ_WAVE_CYCLES") / waves
+        cycles = None
+        if "GRBM_GUI_ACTIVE" in v:
+            for div in (8.0, 1.0, 32.0):
+                ghz = per("GRBM_GUI_ACTIVE") / div / out["kernel_avg_ns"]
+                if 1.2 < ghz < 2.7:
+                    cycles = per("GRBM_GUI_ACTIVE") / div
+                    out["clock_from"] = "GRBM_GUI_ACTIVE / %d" % div
+                    break
+        if cycles is None and "SQ_BUSY_CYCLES" in v:
+            cycles = per("SQ_BUSY_CYCLES") / 32.0
+            out["clock_from"] = "SQ_BUSY_CYCLES / 32 (lower bound)"
+        if cycles is None:
+            cycles = 4.0 * per("SQ_WAVE_CYCLES") / waves
+            out["clock_from"] = "4 x SQ_WAVE_CYCLES / waves (lower bound)"
         out["shader_cycles_per_launch"] = round(cycles)
         out["shader_clock_ghz"] = round(cycles / out["kernel_avg_ns"], 3)
+        # mean share of the launch a wave is resident (a launch ends with its last stream)
+        out["wave_residency"] = round(4.0 * per("SQ_WAVE_CYCLES") / waves / cycles, 4)
         # a wave64 VALU instruction occupies its SIMD-32 for two cycles; 1024 SIMDs
         out["valu_frac"] = round(per("SQ_INSTS_VALU") * 2 / (1024 * cycles), 4)
         insts = sum(per(n) for n in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_BRANCH") if n in v)
