@@ -31,6 +31,12 @@ extern "C" int lh_launch_encode_lsf(const LhConfig * cfg, const LhTables * T, co
                                     const LhStreamDesc * descs, LhStreamState * states,
                                     LhFrameOut * out, uint8_t * bytes, int nstreams, void *stream);
 
+/* the MPEG-1 kernel once more, compiled for the new VBR loop (lh_kernels.hip with -DLH_VBRK: same source, the
+ * instruction scheduling strategy that loop runs best with; csrc/Makefile) */
+extern "C" int lh_launch_encode_vbr(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, const float *pcmf,
+                                    const LhStreamDesc * descs, LhStreamState * states,
+                                    LhFrameOut * out, uint8_t * bytes, int nstreams, void *stream);
+
 extern "C" int lh_launch_selftest(unsigned *d_out, unsigned seed, void *stream);
 extern "C" int lh_launch_summary(const LhStreamState * states, long long *sum, int nstreams, void *stream);
 extern "C" int lh_launch_scatter(const int16_t * arena, int16_t * pool, long cap, const int *seg, int nseg, void *stream);
@@ -82,13 +88,15 @@ struct LhDeviceConst {
     LhConfig *d_cfg = nullptr;
     LhTables *d_tab = nullptr;
     int     lsf = 0;            /* an MPEG-2 / 2.5 stream: the kernel object compiled for one granule per frame */
+    int     vbrk = 0;           /* an MPEG-1 stream in the new VBR loop: the object scheduled for that loop */
     int launch(const int16_t * pcm, const float *pcmf, const LhStreamDesc * descs, LhStreamState * states,
                LhFrameOut * out, uint8_t * bytes, int nstreams, void *stream) const {
-        return (lsf ? lh_launch_encode_lsf : lh_launch_encode) (d_cfg, d_tab, pcm, pcmf, descs, states, out, bytes, nstreams,
-                                                                 stream);
+        return (lsf ? lh_launch_encode_lsf : vbrk ? lh_launch_encode_vbr : lh_launch_encode)
+            (d_cfg, d_tab, pcm, pcmf, descs, states, out, bytes, nstreams, stream);
     }
     int upload(const LhConfig & cfg, const LhTables & tab) {
         lsf = (cfg.mode_gr == 1);
+        vbrk = !lsf && (cfg.vbr == 1 || cfg.vbr == 4);
         HIPCHK(hipMalloc((void **) &d_cfg, sizeof(LhConfig)));
         HIPCHK(hipMalloc((void **) &d_tab, sizeof(LhTables)));
         HIPCHK(hipMemcpy(d_cfg, &cfg, sizeof(LhConfig), hipMemcpyHostToDevice));

@@ -26,6 +26,10 @@
 #include "lh_dev_quant.h"
 
 
+/* A/B switches of the search (tools/build_variants.sh); the values here are the product's */
+#ifndef LH_CN_EXEC
+#define LH_CN_EXEC 1            /* calc_noise: band sums stop by EXEC mask instead of keeping a copy per pair */
+#endif
 struct LhQS {
     /* lane = pair slots */
     float   xp[10];             /* xrpow */
@@ -603,6 +607,48 @@ lq_calc_noise(const LhCtx & c, const LhQS & S, const LhQR & R, const LhGrR & g, 
         int const n = 2 * l;
         int const jj = (j < 576) ? (j >> 1) : 0;
         const lh_f32x2 *sq2 = (const lh_f32x2 *) sq;
+#if LH_CN_EXEC && !defined(LH_EMU)
+        /* On the device the lanes are switched off as their bands end: v_cmpx narrows EXEC after every pair of
+         * terms and a lane that is off keeps its sum -- three instructions per pair of terms instead of five, no copy
+         * to keep.  Sixteen terms per block from four 16-byte reads (ds_read2_b64: a band may start on an odd pair,
+         * the reads need 8-byte alignment only); the reads of the next block are issued before the adds of this one.
+         * EXEC is restored at the end of each block; what is read beyond a band's end is not added. */
+        float   kept;
+        {
+            struct alignas(8) Q4 { float x, y, z, w; };
+            const Q4 *src = (const Q4 *) (sq2 + jj);
+            int     rem = n;            /* terms the lane still has to add (<= 0: none) */
+            Q4      a0 = src[0], a1 = src[1], a2 = src[2], a3 = src[3];
+#define LH_CN_PAIR(K, A, B) "v_cmpx_gt_i32_e64 %[tm], %[rem], " #K "\n\tv_add_f32 %[ns], %[ns], %[" #A "]\n\tv_add_f32 %[ns], %[ns], %[" #B "]\n\t"
+#define LH_CN_BLOCK(U, V, W, X) do { unsigned long long sv_, tm_; \
+                asm volatile("s_mov_b64 %[sv], exec\n\t" \
+                             LH_CN_PAIR(0, a0, a1) LH_CN_PAIR(2, a2, a3) LH_CN_PAIR(4, b0, b1) LH_CN_PAIR(6, b2, b3) \
+                             LH_CN_PAIR(8, c0, c1) LH_CN_PAIR(10, c2, c3) LH_CN_PAIR(12, d0, d1) LH_CN_PAIR(14, d2, d3) \
+                             "s_mov_b64 exec, %[sv]" \
+                             : [ns] "+v"(noise), [sv] "=&s"(sv_), [tm] "=&s"(tm_) \
+                             : [rem] "v"(rem), [a0] "v"(U.x), [a1] "v"(U.y), [a2] "v"(U.z), [a3] "v"(U.w), \
+                               [b0] "v"(V.x), [b1] "v"(V.y), [b2] "v"(V.z), [b3] "v"(V.w), \
+                               [c0] "v"(W.x), [c1] "v"(W.y), [c2] "v"(W.z), [c3] "v"(W.w), \
+                               [d0] "v"(X.x), [d1] "v"(X.y), [d2] "v"(X.z), [d3] "v"(X.w)); } while (0)
+            for (int k0 = 0; k0 < maxw; k0 += 32) {
+                Q4 const b0 = src[4], b1 = src[5], b2 = src[6], b3 = src[7];
+                LH_CN_BLOCK(a0, a1, a2, a3);
+                rem -= 16;
+                if (k0 + 16 >= maxw)
+                    break;
+                a0 = src[8];
+                a1 = src[9];
+                a2 = src[10];
+                a3 = src[11];
+                LH_CN_BLOCK(b0, b1, b2, b3);
+                rem -= 16;
+                src += 8;
+            }
+#undef LH_CN_BLOCK
+#undef LH_CN_PAIR
+            kept = noise;
+        }
+#else
         float   kept = 0.0f;
         int     at = jj, done = 0;
         if (lh_ballot(fresh && (jj & 1))) {
@@ -632,6 +678,7 @@ lq_calc_noise(const LhCtx & c, const LhQS & S, const LhQR & R, const LhGrR & g, 
             at += 4;
             done += 8;
         }
+#endif
         noise = kept;
     }
     LQ_MARK("cn_log");

@@ -738,6 +738,12 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
 #define lh_emu_encode lh_emu_encode_lsf
 #define lh_emu_encode_bytes lh_emu_encode_bytes_lsf
 #endif
+/* and so is the LH_VBRK build: the same MPEG-1 source compiled with the scheduling strategy that suits the new VBR
+ * loop (csrc/Makefile); lh_api.cpp launches it for vbr_mt / vbr_mtrh configurations */
+#ifdef LH_VBRK
+#define lh_encode_kernel lh_encode_kernel_vbr
+#define lh_launch_encode lh_launch_encode_vbr
+#endif
 /* all frames of one stream (the workgroup's whole job) */
 LH_DEVFN void
 lh_encode_stream(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, const float *pcmf,
@@ -867,7 +873,7 @@ lh_encode_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, 
     lh_encode_stream(cfg, T, pcm, pcmf, descs, states, out, bytes, nstreams);
 }
 
-#if !defined(LH_EMU) && !defined(LH_LSF)
+#if !defined(LH_EMU) && !defined(LH_LSF) && !defined(LH_VBRK)
 /* device self-test of the cross-lane primitives in lh_wave.h: each reduction is
  * compared with a serial evaluation through LDS; out[0] = number of mismatches */
 extern "C" __global__ void __launch_bounds__(64)

@@ -2,7 +2,7 @@
 """Development aid: compile lh_kernels.hip with -DLH_MARK and report, for one function of the gfx950
 assembly, the number of instructions between consecutive `; LQMARK <name>` comments (first
 occurrence of each name; static counts, not executed counts), plus a histogram by class.
-usage: tools/isa_sections.py [function-substring] [--keep]"""
+usage: tools/isa_sections.py [function-substring] [--keep] [--asm file.s]"""
 import collections
 import os
 import re
@@ -17,7 +17,10 @@ OUT = "/tmp/isa_marks"
 def main():
     fn = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "lq_outer_loop_stage4"
     os.makedirs(OUT, exist_ok=True)
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-fno-slp-vectorize", "-falign-functions=256", "-std=c++17", "-fno-fast-math", "-ffp-contract=off",
+    asm = None
+    if "--asm" in sys.argv:     # an assembly file made elsewhere (hipcc -S --cuda-device-only -DLH_MARK ...)
+        asm = sys.argv[sys.argv.index("--asm") + 1]
+    cmd = ["true"] if asm else ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-fno-slp-vectorize", "-falign-functions=256", "-std=c++17", "-fno-fast-math", "-ffp-contract=off",
            "-fPIC", "-I.", "-I../../include", "-DLH_MARK", "-c", "lh_kernels.hip", "-o", OUT + "/k.o", "-save-temps=obj",
            "-Rpass-analysis=kernel-resource-usage"]
     r = subprocess.run(cmd, cwd=CSRC, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
@@ -27,7 +30,7 @@ def main():
     for l in r.stdout.splitlines():
         if "lh_encode_kernel" in l or ("VGPRs" in l and "523" in l) or "Spill" in l and "52" in l:
             pass
-    s = open(OUT + "/lh_kernels-hip-amdgcn-amd-amdhsa-gfx950.s").read().splitlines()
+    s = open(asm or OUT + "/lh_kernels-hip-amdgcn-amd-amdhsa-gfx950.s").read().splitlines()
     start = None
     for i, l in enumerate(s):
         if re.match(r"^_Z\w*%s\w*:" % re.escape(fn), l):
