@@ -564,6 +564,10 @@ struct LhMaskChan {
                                  * (reference nb_l1 / nb_l2), a register of the lane for the whole launch */
 };
 
+#ifndef LH_PSY_EXEC
+#define LH_PSY_EXEC 1           /* partition sums: lanes switched off by EXEC as their partitions end (A/B switch) */
+#endif
+
 template < int NC > LH_DEVFN void
 lh_compute_masking(const LhCtx & c, int is_long, const LhMaskChan (&ch)[NC], const float *s3)
 {
@@ -594,6 +598,30 @@ lh_compute_masking(const LhCtx & c, int is_long, const LhMaskChan (&ch)[NC], con
         int const j0 = (int) lh_wave_scan_u32((uint32_t) n) - n;      /* the partition's first line */
         float const rn = on ? t_rnum : 0.0f;
         int const nmax = lh_uni_i((int) lh_wave_max_u32((uint32_t) n));
+#if LH_PSY_EXEC && !defined(LH_EMU)
+        /* On the device the lanes are switched off as their partitions end (v_cmpx narrows EXEC before every term, a
+         * lane that is off keeps sum and maximum): three instructions per term and channel, nothing selected per
+         * load.  The loads run on past a partition's end (the channel's spectrum, then whatever follows it in the
+         * workgroup's image); EXEC is restored after each block of eight terms. */
+        for (int i = 0; i < nmax; i += 8) {
+            int const rem = n - i;
+#pragma unroll
+            for (int q = 0; q < NC; q++) {
+                const float *src = ch[q].energy + j0 + i;
+                float const a0 = src[0], a1 = src[1], a2 = src[2], a3 = src[3], a4 = src[4], a5 = src[5], a6 = src[6], a7 = src[7];
+                unsigned long long sv, tm;
+#define LH_PS_TERM(K, A) "v_cmpx_gt_i32_e64 %[tm], %[rem], " #K "\n\tv_add_f32 %[eb], %[eb], %[" #A "]\n\tv_max_f32 %[mx], %[mx], %[" #A "]\n\t"
+                asm volatile("s_mov_b64 %[sv], exec\n\t"
+                             LH_PS_TERM(0, a0) LH_PS_TERM(1, a1) LH_PS_TERM(2, a2) LH_PS_TERM(3, a3)
+                             LH_PS_TERM(4, a4) LH_PS_TERM(5, a5) LH_PS_TERM(6, a6) LH_PS_TERM(7, a7)
+                             "s_mov_b64 exec, %[sv]"
+                             : [eb] "+v"(ebb[q]), [mx] "+v"(m[q]), [sv] "=&s"(sv), [tm] "=&s"(tm)
+                             : [rem] "v"(rem), [a0] "v"(a0), [a1] "v"(a1), [a2] "v"(a2), [a3] "v"(a3),
+                               [a4] "v"(a4), [a5] "v"(a5), [a6] "v"(a6), [a7] "v"(a7));
+#undef LH_PS_TERM
+            }
+        }
+#else
         for (int i = 0; i < nmax; i += 8) {
             float   el[NC][8];
 #pragma unroll
@@ -612,6 +640,7 @@ lh_compute_masking(const LhCtx & c, int is_long, const LhMaskChan (&ch)[NC], con
                     m[q] = __builtin_fmaxf(m[q], e);
                 }
         }
+#endif
 #pragma unroll
         for (int q = 0; q < NC; q++) {
             avg[q] = ebb[q] * rn;

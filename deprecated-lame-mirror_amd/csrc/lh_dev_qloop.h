@@ -53,6 +53,7 @@ struct LhQS {
      * these 16 values give 1 / step and the xrpow bound of count_bits for every global_gain */
     float   istepv, thrv;
     int     sbg8;               /* lane = band: 8 * subblock_gain[window] of the working image */
+    int     sfbl;               /* lane = long band: its first line (576 from lane 23 on): count_bits' pn_sfb_count1 */
     float   m0, m1, m2, m3;     /* POW20(210 .. 213): the four mantissas of the step table (wave-uniform) */
 };
 
@@ -74,8 +75,8 @@ lq_band_step(const LhQS & S, const LhGrR & g)
  * host by build_huffman_grids, lh_host_init.c) ---- */
 
 /* per class of a region maximum (0..15: the maximum itself; 16 + bit length of max - 15 for the ESC
- * tables): A = byte offset of the candidate group's (0,0) cell inside LhChanLds | esc << 31,
- * B = first table | second table << 8 | linbits of the first << 16 | of the second << 24
+ * tables): A = byte offset of the candidate group's (0,0) cell inside LhChanLds,
+ * B = first table | second table << 8 | linbits of the first << 16 | of the second << 24 | esc << 31
  * (reference takehiro.c:618-647, huf_tbl_noESC; the two linear searches over linbits) */
 LH_DEVFN void
 lq_class_tabs(int cls, uint32_t *A, uint32_t *B)
@@ -102,8 +103,8 @@ lq_class_tabs(int cls, uint32_t *A, uint32_t *B)
         int const t24 = (int) ((0x7777665432100000ull >> (4 * (blen & 15))) & 15u);
         int const t16 = (int) ((0x7777766554432100ull >> (4 * (blen & 15))) & 15u);
         int const choice2 = 24 + t24, choice = 16 + (t16 > t24 ? t16 : t24);
-        *A = big | 0x80000000u;
-        *B = (uint32_t) choice | ((uint32_t) choice2 << 8) | (lh_ht_xlen_c(choice) << 16) | (lh_ht_xlen_c(choice2) << 24);
+        *A = big;
+        *B = (uint32_t) choice | ((uint32_t) choice2 << 8) | (lh_ht_xlen_c(choice) << 16) | (lh_ht_xlen_c(choice2) << 24) | 0x80000000u;
     }
 }
 
@@ -185,6 +186,7 @@ lq_load(const LhCtx & c, LhQS & S, LhChanLds & Q, const LhQR & R, const LhGrR & 
     if (c.lane >= 32)
         S.istepv = (1.0f - 0.4054f) / S.istepv;     /* lanes 32..47: the 0/1 comparator's threshold per mantissa */
     S.sbg8 = 0;                 /* so is subblock_gain */
+    S.sfbl = (c.lane < LH_SBMAX_L + 1) ? (int) qt->sfb_l[c.lane < LH_SBMAX_L + 1 ? c.lane : 0] : 576;
     LH_WAVE_SYNC();
     {
         /* the three grids are constants of the launch: 704 words from HBM, issued together */
@@ -288,8 +290,9 @@ lq_quantize(const LhCtx & c, LhQS & S, const LhQR & R, const LhGrR & g)
             for (int k = 0; k < NS; k++) {
                 int const p = lane + 64 * k;
                 int const nc = lq_bit(ncmask, S.bnd[k]), z1 = lq_bit(m01mask, S.bnd[k]);
-                uint32_t const v01 = (((compareval0 > S.xp[2 * k]) ? 0u : 1u)
-                                      | (((compareval0 > S.xp[2 * k + 1]) ? 0u : 1u) << 16)) & S.vm[k];
+                /* (through lh_vec_u32: formed for every lane, not under an EXEC mask per slot with its branch) */
+                uint32_t const v01 = lh_vec_u32((((compareval0 > S.xp[2 * k]) ? 0u : 1u)
+                                                 | (((compareval0 > S.xp[2 * k + 1]) ? 0u : 1u) << 16)) & S.vm[k]);
                 uint32_t v = nc ? (z1 ? v01 : nq[k]) : S.pw[k];
                 if (zero_mnc && p == pm)
                     v &= 0xffffu;
@@ -329,7 +332,6 @@ lq_count(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
     {
         int     top_nz, top_big, i, bv, nquad, bits;
         int     e0, e1, e2, a1, a2;
-        unsigned sfbcnt_in = 0;
         if (USE_PREV)
             R.pn_sfb_count1 = 0;
         {
@@ -379,8 +381,6 @@ lq_count(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
         e0 = lh_uni_i(a1 >> 1);
         e1 = lh_uni_i(a2 >> 1);
         e2 = (R.block_type == LH_NORM_TYPE) ? (bv >> 1) : e1;
-        if (USE_PREV && R.block_type == LH_NORM_TYPE)
-            sfbcnt_in = (lane < LH_SBMAX_L + 1) ? qt->sfb_l[lane] : 576u;
         LQ_MARK("cb_quads");
         LH_WAVE_ORDER();
         uint32_t red[1];        /* the count1 region's lengths with both of its tables, t32 << 16 | t33 */
@@ -391,12 +391,33 @@ lq_count(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
          * v | w << 1 | x << 2 | y << 3 from the two packed words (all four values are 0 or 1 there) and looks up both
          * tables' lengths; lanes whose pair starts no quadruple of the region look up something and drop it. */
         uint32_t qsum = 0;
+#ifndef LH_EMU
+        uint32_t cl[5];
+#endif
         {
             int const pb = bv >> 1;
             uint32_t const first = (uint32_t) (lane - pb);      /* pair - pb of slot 0 */
             /* (a pair at an odd distance from pb starts no quadruple: out of every range) */
             uint32_t const firstq = (first & 1u) ? 0x7ffff000u : first;
             uint32_t const n2 = (uint32_t) (2 * nquad);
+#ifndef LH_EMU
+            /* On the device the index goes straight into the table's LDS address with one v_dot2_u32_u16: the halves of
+             * t are v + 4 x and w + 4 y, and 4 (v + 2 w + 4 x + 8 y) = 4 lo + 8 hi.  The values are clamped to 15
+             * first (the clamped words serve the grid look-ups below as well), so that the lanes whose pairs hold
+             * larger values -- their result is dropped -- read inside the workgroup's image. */
+            uint32_t const qtab = lh_lds_off(&Q) + (uint32_t) ((const char *) qt->t3233p - (const char *) &Q);
+#pragma unroll
+            for (int k = 0; k < NS; k++)
+                cl[k] = lh_pk_min_u16(S.pw[k], 0x000f000fu);
+#pragma unroll
+            for (int k = 0; k < NS; k++) {
+                uint32_t const nxt = (k + 1 < NS) ? cl[k + 1 < NS ? k + 1 : k] : 0u;
+                uint32_t const u1 = lh_lane_above_u32(cl[k], nxt);
+                uint32_t const t = cl[k] | (u1 << 2);
+                uint32_t const len = lh_lds_read_u32(lh_dot2_u16(t, 4u | (8u << 16), qtab));
+                qsum += ((firstq + 64u * (uint32_t) k) < n2) ? len : 0u;
+            }
+#else
 #pragma unroll
             for (int k = 0; k < NS; k++) {
                 uint32_t const nxt = (k + 1 < NS) ? S.pw[k + 1 < NS ? k + 1 : k] : 0u;
@@ -406,6 +427,7 @@ lq_count(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
                 uint32_t const len = qt->t3233p[j];
                 qsum += ((firstq + 64u * (uint32_t) k) < n2) ? len : 0u;
             }
+#endif
         }
         LQ_MARK("cb_max");
         uint32_t m[3] = { 0u, 0u, 0u };
@@ -432,24 +454,34 @@ lq_count(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
             uint32_t const mr = (lane == 0) ? m[0] : (lane == 1) ? m[1] : m[2];
             uint32_t const d = mr - 15u;
             uint32_t const cls = (mr > 15u) ? (uint32_t) (16 + 32 - lh_clz32(d)) : mr;
-            uint32_t const PA = qt->ctabA[cls & 31u];
+            uint32_t PA = qt->ctabA[cls & 31u];
             PB = qt->ctabB[cls & 31u];
-            esc = PA >> 31;
-            G0 = lh_bcast_u32(PA, 0) & 0xffffu;
-            G1 = lh_bcast_u32(PA, 1) & 0xffffu;
-            G2 = lh_bcast_u32(PA, 2) & 0xffffu;
+            esc = PB >> 31;
+#ifndef LH_EMU
+            PA += lh_lds_off(&Q);       /* the origins as LDS addresses (see the look-ups below) */
+#endif
+            G0 = lh_bcast_u32(PA, 0);
+            G1 = lh_bcast_u32(PA, 1);
+            G2 = lh_bcast_u32(PA, 2);
         }
         {
             uint32_t acc0 = 0, acc1 = 0, acc2 = 0;
             const char *qb = (const char *) &Q;
+            /* (on the device G0..G2 are LDS addresses: a cell's address is then one v_dot2_u32_u16 --
+             * x * 64 + y * 4 + origin -- on the clamped pair) */
 #pragma unroll
             for (int k = 0; k < NS; k++) {
                 int const p = lane + 64 * k;
                 int const in0 = p < e0, in1 = p < e1, in2 = p < e2;
+#ifndef LH_EMU
+                uint32_t const go = in0 ? G0 : (in1 ? G1 : G2);
+                uint32_t const v = lh_lds_read_u32(lh_dot2_u16(cl[k], 64u | (4u << 16), go));
+#else
                 uint32_t const cl = lh_pk_min_u16(S.pw[k], 0x000f000fu);
                 uint32_t const off = ((cl << 6) & 0x3c0u) | (cl >> 14);      /* (x * 16 + y) * 4 */
                 uint32_t const go = in0 ? G0 : (in1 ? G1 : G2);
                 uint32_t const v = *(const uint32_t *) (qb + go + off);
+#endif
                 acc0 += in0 ? v : 0u;
                 acc1 += in1 ? v : 0u;
                 acc2 += in2 ? v : 0u;
@@ -494,7 +526,7 @@ lq_count(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
             bits += (int) (lh_bcast_u32(best, 0) + lh_bcast_u32(best, 1) + lh_bcast_u32(best, 2));
         }
         if (USE_PREV && R.block_type == LH_NORM_TYPE && bv != 0)
-            R.pn_sfb_count1 = lh_popc64(lh_ballot(lane < LH_SBMAX_L + 1 && (int) sfbcnt_in < bv));
+            R.pn_sfb_count1 = lh_popc64(lh_ballot(S.sfbl < bv));    /* (big_values <= 576: lanes from 23 on never count) */
         LQ_MARK("cb_end");
         return bits;
     }

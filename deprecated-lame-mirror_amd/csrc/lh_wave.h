@@ -520,11 +520,10 @@ lh_lane_below_u32(uint32_t v)
 __device__ __forceinline__ uint32_t
 lh_lane_above_u32(uint32_t v, uint32_t next)
 {
-    int const up = __builtin_amdgcn_update_dpp(0, (int) v, 0x130, 0xf, 0xf, true);
-    int     n0 = __builtin_amdgcn_readlane((int) next, 0);
-    /* (pinned: left to itself the compiler moves the v_readlane into a branch taken by lane 63 alone) */
-    asm volatile("" : "+s"(n0));
-    return (lh_lane() == 63) ? (uint32_t) n0 : (uint32_t) up;
+    /* lane 63 has no lane above: without bound_ctrl the shift leaves it what the destination held before -- `next's
+     * lane 0, put there first */
+    int const n0 = __builtin_amdgcn_readlane((int) next, 0);
+    return (uint32_t) __builtin_amdgcn_update_dpp(n0, (int) v, 0x130, 0xf, 0xf, false);
 }
 
 /* an integer sum and a float maximum (no NaNs) at once: the two chains' steps side by side */
@@ -590,6 +589,28 @@ __device__ __forceinline__ uint32_t
 lh_bcast_u32(uint32_t v, int src)
 {
     return (uint32_t) __builtin_amdgcn_readlane((int) v, src);
+}
+
+/* An object of the workgroup's LDS image by its LDS address (32 bits), and a word read through such an address:
+ * address arithmetic on the integer keeps the access a ds_read with no generic-pointer detour */
+__device__ __forceinline__ uint32_t
+lh_lds_off(const void *p)
+{
+    return (uint32_t) (uintptr_t) (const __attribute__((address_space(3))) char *) p;
+}
+
+__device__ __forceinline__ uint32_t
+lh_lds_read_u32(uint32_t off)
+{
+    return *(const __attribute__((address_space(3))) uint32_t *) (uintptr_t) off;
+}
+
+/* a.lo * b.lo + a.hi * b.hi + c on unsigned 16-bit halves (v_dot2_u32_u16) */
+__device__ __forceinline__ uint32_t
+lh_dot2_u16(uint32_t a, uint32_t b, uint32_t c)
+{
+    typedef unsigned short lh_u16x2_ __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(lh_u16x2_, a), __builtin_bit_cast(lh_u16x2_, b), c, false);
 }
 
 /* LDS atomics without a return value (ds_add_u32 / ds_max_i32) */
