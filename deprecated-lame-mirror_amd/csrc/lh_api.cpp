@@ -83,6 +83,19 @@ mfn_of(const LhConfig & c)
     return LH_BLKSIZE + 576 * c.mode_gr - LH_FFTOFFSET;
 }
 
+/* per device: the end of the last launch that filled it (lamehip_batch_encode) */
+struct LhLaunchSerial {
+    std::mutex lock;
+    hipEvent_t ev = nullptr;
+};
+
+static LhLaunchSerial &
+launch_serial(int device)
+{
+    static LhLaunchSerial per_device[64];
+    return per_device[(device >= 0 && device < 64) ? device : 0];
+}
+
 /* device-resident constants shared by a handle or a batch */
 struct LhDeviceConst {
     LhConfig *d_cfg = nullptr;
@@ -2393,15 +2406,44 @@ lamehip_batch_encode(lamehip_batch * b)
     }
     HIPCHK(hipMemcpyAsync(b->d_desc, b->h_desc.data(), (size_t) b->B * sizeof(LhStreamDesc),
                           hipMemcpyHostToDevice, b->stream));
-    HIPCHK(hipEventRecord(b->ev0, b->stream));
     {
+        /* Launches that fill the device run one after the other, in launch order, whatever HIP streams their batches
+         * own: a launch of >= 512 streams keeps every SIMD's register file and every CU's LDS (2 x 256 VGPRs, 4 x 40 KB),
+         * so a second one has nothing to gain from being dispatched early -- and measured on the MI355X it loses: dispatched
+         * while the first still runs, its workgroups end up resident in two rounds (kernel 176 ms alone, 329 ms behind
+         * another launch, every stream's own cycle count unchanged; tools/e2e_diag2.py), which cost the two-batch pipeline a
+         * third of its rate.  Copies on the batches' copy streams overlap the kernels as before. */
+        LhLaunchSerial & ser = launch_serial(b->device);
+        std::lock_guard < std::mutex > hold(ser.lock);
+        int const big = (b->B >= 512);
+        if (big && ser.ev)
+            HIPCHK(hipStreamWaitEvent(b->stream, ser.ev, 0));
+        HIPCHK(hipEventRecord(b->ev0, b->stream));
         int     rc = b->dc.launch(b->rate_in ? (const int16_t *) 0 : b->d_pcm, b->rate_in ? b->d_pcmf : (const float *) 0,
                                   b->d_desc, b->d_state, b->d_out, b->dev_pack ? b->d_bytes : (uint8_t *) 0, b->B,
                                   (void *) b->stream);
         if (rc)
             return set_err("kernel launch", (hipError_t) rc);
+        HIPCHK(hipEventRecord(b->ev1, b->stream));
+        if (b->dev_pack) {
+            /* the two words per stream lamehip_batch_fetch copies first: gathered here, inside the serial order -- as a
+             * launch of its own behind the NEXT batch's kernel it found no free register file until that kernel was over
+             * (all of a launch's streams end within a frame or two of each other), and its batch came home one kernel late */
+            if (batch_copy_streams(b) != 0)
+                return LAMEHIP_ERR_DEVICE;
+            if (!b->d_sum)
+                HIPCHK(hipMalloc((void **) &b->d_sum, (size_t) b->B * 2 * sizeof(long long)));
+            rc = lh_launch_summary(b->d_state, b->d_sum, b->B, (void *) b->stream);
+            if (rc)
+                return set_err("summary launch", (hipError_t) rc);
+            HIPCHK(hipEventRecord(b->ev_sum, b->stream));
+        }
+        if (big) {
+            if (!ser.ev)
+                HIPCHK(hipEventCreateWithFlags(&ser.ev, hipEventDisableTiming));
+            HIPCHK(hipEventRecord(ser.ev, b->stream));
+        }
     }
-    HIPCHK(hipEventRecord(b->ev1, b->stream));
     b->launched = 1;
     b->encoded = 1;
     b->fetched = 0;
@@ -2437,12 +2479,7 @@ lamehip_batch_fetch(lamehip_batch * b)
     }
     if (batch_copy_streams(b) != 0)
         return LAMEHIP_ERR_DEVICE;
-    {
-        int const rc = lh_launch_summary(b->d_state, b->d_sum, b->B, (void *) b->stream);
-        if (rc)
-            return set_err("summary launch", (hipError_t) rc);
-    }
-    HIPCHK(hipEventRecord(b->ev_sum, b->stream));
+    /* (the summary words were gathered right behind the kernel: lamehip_batch_encode) */
     HIPCHK(hipStreamWaitEvent(b->down_stream, b->ev_sum, 0));
     HIPCHK(hipMemcpyAsync(b->h_sum, b->d_sum, (size_t) b->B * 2 * sizeof(long long), hipMemcpyDeviceToHost, b->down_stream));
     if (total > 0)

@@ -15,7 +15,9 @@ import bench  # noqa: E402
 
 
 def main():
-    B, sr, seconds, rounds, nb = 1024, 44100, 5.0, 9, int(sys.argv[1]) if len(sys.argv) > 1 else 3
+    B, sr, rounds, nb = 1024, 44100, 9, int(sys.argv[1]) if len(sys.argv) > 1 else 3
+    seconds = float(sys.argv[2]) if len(sys.argv) > 2 else 5.0
+    os.environ.setdefault("LAMEHIP_PINNED_MAX_MB", "16384")
     n = int(sr * seconds)
     dev = torch.device("cuda", 0)
     enc = lamehip.Encoder(sr, 128)
