@@ -288,15 +288,18 @@ lq_quantize(const LhCtx & c, LhQS & S, const LhQR & R, const LhGrR & g)
             float const compareval0 = cmpv;
 #pragma unroll
             for (int k = 0; k < NS; k++) {
-                int const p = lane + 64 * k;
                 int const nc = lq_bit(ncmask, S.bnd[k]), z1 = lq_bit(m01mask, S.bnd[k]);
                 /* (through lh_vec_u32: formed for every lane, not under an EXEC mask per slot with its branch) */
                 uint32_t const v01 = lh_vec_u32((((compareval0 > S.xp[2 * k]) ? 0u : 1u)
                                                  | (((compareval0 > S.xp[2 * k + 1]) ? 0u : 1u) << 16)) & S.vm[k]);
-                uint32_t v = nc ? (z1 ? v01 : nq[k]) : S.pw[k];
-                if (zero_mnc && p == pm)
-                    v &= 0xffffu;
-                S.pw[k] = v;
+                S.pw[k] = nc ? (z1 ? v01 : nq[k]) : S.pw[k];
+            }
+            if (LH_RARE(zero_mnc)) {
+                /* (rare and wave-uniform: a branch that falls through instead of four selects on every call) */
+#pragma unroll
+                for (int k = 0; k < NS; k++)
+                    if (lane + 64 * k == pm)
+                        S.pw[k] &= 0xffffu;
             }
         }
     }
@@ -770,9 +773,9 @@ lq_scale_mask(LhQS & S, uint64_t bands, float factor)
 {
 #pragma unroll
     for (int k = 0; k < NS; k++) {
-        int const on = lq_bit(bands, S.bnd[k]);
-        float const v0 = on ? S.xp[2 * k] * factor : S.xp[2 * k];
-        float const v1 = on ? S.xp[2 * k + 1] * factor : S.xp[2 * k + 1];
+        /* (x * 1.0f == x for every float: one select on the factor instead of one per line) */
+        float const f = lq_bit(bands, S.bnd[k]) ? factor : 1.0f;
+        float const v0 = S.xp[2 * k] * f, v1 = S.xp[2 * k + 1] * f;
         S.xp[2 * k] = v0;
         S.xp[2 * k + 1] = v1;
         S.lmax = __builtin_fmaxf(__builtin_fmaxf(v0, v1), S.lmax);      /* (no NaNs here: one v_max3_f32) */
