@@ -334,6 +334,17 @@ struct LhQuantLds {
 #define LH_VBR_IPOW20 ((float *) lh_lds.u.quant.ch[0].ix[1])
 #define LH_VBR_POW20  ((float *) lh_lds.u.quant.ch[1].ix[1])
 
+/* CBR / ABR / old VBR: the 513 entries of LhTables.log_table that calc_noise's logarithm interpolates between
+ * (reference util.c:976-1001), staged over the same unused second image once per frame -- 288 entries behind channel 0's
+ * first image, the rest behind channel 1's -- so that the look-up on the search's dependent chain is an LDS round trip
+ * (~64 cycles) and not one to the vector cache (~250 with two waves on the SIMD; 65 look-ups per channel and frame) */
+#define LH_LOGT_SPLIT 288
+#define LH_LOGT_LDS(m) (((const float *) lh_lds.u.quant.ch[0].ix[1]) \
+                        [(m) + ((m) >= LH_LOGT_SPLIT ? (int) ((sizeof(LhChanLds) - 4 * LH_LOGT_SPLIT) / 4) : 0)])
+#define LH_LOGT_LDS_W(m) (((float *) lh_lds.u.quant.ch[0].ix[1]) \
+                          [(m) + ((m) >= LH_LOGT_SPLIT ? (int) ((sizeof(LhChanLds) - 4 * LH_LOGT_SPLIT) / 4) : 0)])
+static_assert(sizeof(((LhChanLds *) 0)->ix[1]) == 4 * LH_LOGT_SPLIT && 2 * LH_LOGT_SPLIT >= 513, "log table over the second images");
+
 /* launch context of the workgroup, written once per launch (frame_base per frame) by thread 0;
  * out-of-line stages read it from here instead of receiving a per-lane copy */
 struct LhCtxShared {

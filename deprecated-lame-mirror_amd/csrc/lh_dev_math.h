@@ -201,6 +201,18 @@ lh_fast_log2(const float *log_table, float x)
     return log2val;
 }
 
+/* the same with the table read through `tab(i)' (an LDS copy: LH_LOGT_LDS in lh_dev_common.h) */
+#define LH_FAST_LOG2_VIA(tab, x, out) do { \
+        uint32_t const bits_ = lh_f32_as_u32(x); \
+        int     man_ = (int) (bits_ & 0x7fffffu); \
+        float   l2_ = (float) ((int) ((bits_ >> 23) & 0xFFu) - 0x7f); \
+        float   part_ = (float) (man_ & ((1 << 14) - 1)); \
+        part_ *= 1.0f / ((1 << 14)); \
+        man_ >>= 14; \
+        l2_ += tab(man_) * (1.0f - part_) + tab(man_ + 1) * part_; \
+        (out) = l2_; \
+    } while (0)
+
 #define LH_LOG2_OVER_LOG10 (0.69314718055994530942 / 2.30258509299404568402)
 
 /* ---- logf / log10f as the host libm computes them (glibc 2.35: logf = the table-driven double

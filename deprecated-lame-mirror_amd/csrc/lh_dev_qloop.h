@@ -27,6 +27,9 @@
 
 
 /* A/B switches of the search (tools/build_variants.sh); the values here are the product's */
+#ifndef LH_LOGT
+#define LH_LOGT 1               /* calc_noise: the logarithm's table from its LDS copy (lh_dev_common.h) instead of HBM */
+#endif
 #ifndef LH_CN_EXEC
 #define LH_CN_EXEC 1            /* calc_noise: band sums stop by EXEC mask instead of keeping a copy per pair */
 #endif
@@ -731,8 +734,14 @@ lq_calc_noise(const LhCtx & c, const LhQS & S, const LhQR & R, const LhGrR & g, 
             t.pnstep = st;
             t.pnnoise = noise;
             distort_ = S.rxmin * noise;
+#if LH_LOGT
+            float   l2;
+            LH_FAST_LOG2_VIA(LH_LOGT_LDS, (distort_ > 1E-20f) ? distort_ : 1E-20f, l2);
+            noise = (float) (l2 * LH_LOG2_OVER_LOG10);
+#else
             noise = (float) (lh_fast_log2(T->log_table, (distort_ > 1E-20f) ? distort_ : 1E-20f)
                              * LH_LOG2_OVER_LOG10);
+#endif
             t.pnlog = noise;
         }
         t.dist = distort_;

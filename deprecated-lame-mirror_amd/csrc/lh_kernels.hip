@@ -404,6 +404,11 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
             LH_VBR_POW20[i] = T->pow20[i + LH_QMAX2];
         }
     }
+    else {
+        /* the other loops: calc_noise's log table (in the same place) */
+        for (int i = tid; i < 513; i += LH_NT)
+            LH_LOGT_LDS_W(i) = T->log_table[i];
+    }
     LH_SYNC_WG();
 
     /* ---- stage 3: M/S decision (reference encoder.c:413-461) ---- */
