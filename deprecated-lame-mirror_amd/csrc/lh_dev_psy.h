@@ -564,6 +564,9 @@ struct LhMaskChan {
                                  * (reference nb_l1 / nb_l2), a register of the lane for the whole launch */
 };
 
+#ifndef LH_PSY_PREFETCH
+#define LH_PSY_PREFETCH 1       /* serial sums of the spectrum: the next block's reads before this block's additions (A/B switch) */
+#endif
 #ifndef LH_PSY_EXEC
 #define LH_PSY_EXEC 1           /* partition sums: lanes switched off by EXEC as their partitions end (A/B switch) */
 #endif
@@ -603,12 +606,35 @@ lh_compute_masking(const LhCtx & c, int is_long, const LhMaskChan (&ch)[NC], con
          * lane that is off keeps sum and maximum): three instructions per term and channel, nothing selected per
          * load.  The loads run on past a partition's end (the channel's spectrum, then whatever follows it in the
          * workgroup's image); EXEC is restored after each block of eight terms. */
+#if LH_PSY_PREFETCH
+        float   nx[NC][8];
+#pragma unroll
+        for (int q = 0; q < NC; q++)
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                nx[q][u] = ch[q].energy[j0 + u];
+#endif
         for (int i = 0; i < nmax; i += 8) {
             int const rem = n - i;
+#if LH_PSY_PREFETCH
+            /* the next block's terms are read before this block's additions (the last trip reads a block nobody adds) */
+            float   cu[NC][8];
+#pragma unroll
+            for (int q = 0; q < NC; q++)
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    cu[q][u] = nx[q][u];
+                    nx[q][u] = ch[q].energy[j0 + i + 8 + u];
+                }
+#endif
 #pragma unroll
             for (int q = 0; q < NC; q++) {
+#if LH_PSY_PREFETCH
+                float const a0 = cu[q][0], a1 = cu[q][1], a2 = cu[q][2], a3 = cu[q][3], a4 = cu[q][4], a5 = cu[q][5], a6 = cu[q][6], a7 = cu[q][7];
+#else
                 const float *src = ch[q].energy + j0 + i;
                 float const a0 = src[0], a1 = src[1], a2 = src[2], a3 = src[3], a4 = src[4], a5 = src[5], a6 = src[6], a7 = src[7];
+#endif
                 unsigned long long sv, tm;
 #define LH_PS_TERM(K, A) "v_cmpx_gt_i32_e64 %[tm], %[rem], " #K "\n\tv_add_f32 %[eb], %[eb], %[" #A "]\n\tv_max_f32 %[mx], %[mx], %[" #A "]\n\t"
                 asm volatile("s_mov_b64 %[sv], exec\n\t"
@@ -1118,6 +1144,7 @@ lh_psy_granule(int gr, LhPsyCarry nb)
         int const summing = lane < 3 && chn < n_chn_psy;
         int const loud = (lane == 2);
         int const lo = loud ? 0 : 11;
+        (void) lo;
         float  *prod = (w == 0) ? P.eb : P.thr;         /* [256] per wave */
         const float *ew = T->ath_eql_w;
         const float *e = P.b.energy[summing ? chn : w];
@@ -1131,6 +1158,43 @@ lh_psy_granule(int gr, LhPsyCarry nb)
                 prod[j - j0] = P.b.energy[w][j] * ew[j];
             }
             LH_WAVE_SYNC_MEM();
+#if LH_PSY_PREFETCH
+            if (summing) {
+                /* sixteen terms per trip; the next sixteen are read before this trip's additions, so the chain waits
+                 * for its own additions only (a read issued when its terms are due costs the chain ~20 cycles a term) */
+                const lh_f32x4 *s4 = (const lh_f32x4 *) ((loud ? prod - j0 : e) + j0);
+                lh_f32x4 a0 = s4[0], a1 = s4[1], a2 = s4[2], a3 = s4[3];
+                if (h == 0 && !loud) {
+                    /* bins 0..10 are not part of the total energy */
+                    a0.x = a0.y = a0.z = a0.w = 0.0f;
+                    a1.x = a1.y = a1.z = a1.w = 0.0f;
+                    a2.x = a2.y = a2.z = 0.0f;
+                }
+                for (int g = 0; g < 64; g += 4) {
+                    int const n = (g + 4 < 64) ? g + 4 : g;
+                    lh_f32x4 const b0 = s4[n], b1 = s4[n + 1], b2 = s4[n + 2], b3 = s4[n + 3];
+#ifndef LH_EMU
+                    /* (one statement, so that the four reads above stay ahead of the sixteen additions) */
+                    asm volatile("v_add_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %2\n\tv_add_f32 %0, %0, %3\n\tv_add_f32 %0, %0, %4\n\t"
+                                 "v_add_f32 %0, %0, %5\n\tv_add_f32 %0, %0, %6\n\tv_add_f32 %0, %0, %7\n\tv_add_f32 %0, %0, %8\n\t"
+                                 "v_add_f32 %0, %0, %9\n\tv_add_f32 %0, %0, %10\n\tv_add_f32 %0, %0, %11\n\tv_add_f32 %0, %0, %12\n\t"
+                                 "v_add_f32 %0, %0, %13\n\tv_add_f32 %0, %0, %14\n\tv_add_f32 %0, %0, %15\n\tv_add_f32 %0, %0, %16"
+                                 : "+v"(acc)
+                                 : "v"(a0.x), "v"(a0.y), "v"(a0.z), "v"(a0.w), "v"(a1.x), "v"(a1.y), "v"(a1.z), "v"(a1.w),
+                                   "v"(a2.x), "v"(a2.y), "v"(a2.z), "v"(a2.w), "v"(a3.x), "v"(a3.y), "v"(a3.z), "v"(a3.w));
+#else
+                    acc += a0.x; acc += a0.y; acc += a0.z; acc += a0.w;
+                    acc += a1.x; acc += a1.y; acc += a1.z; acc += a1.w;
+                    acc += a2.x; acc += a2.y; acc += a2.z; acc += a2.w;
+                    acc += a3.x; acc += a3.y; acc += a3.z; acc += a3.w;
+#endif
+                    a0 = b0;
+                    a1 = b1;
+                    a2 = b2;
+                    a3 = b3;
+                }
+            }
+#else
             if (summing) {
                 const float *src = loud ? prod - j0 : e;
                 int     j = j0;
@@ -1147,6 +1211,7 @@ lh_psy_granule(int gr, LhPsyCarry nb)
                     acc += u.w;
                 }
             }
+#endif
         }
         if (summing) {
             if (!loud) {
