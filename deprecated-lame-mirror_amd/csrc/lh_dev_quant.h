@@ -766,8 +766,29 @@ lh_calc_xmin_body(const LhCtx & c, LhChanLds & Q, LhQR & R, const float *xr, con
             const lh_f32x2 *xp = (const lh_f32x2 *) (xr + j);
             int const np = width >> 1;
             int     p = 0;
+            /* (the next trip's four pairs are read before this trip's additions; the last trip reads four pairs
+             * beyond the band that nobody adds) */
+            lh_f32x2 n0 = xp[0], n1 = xp[1], n2 = xp[2], n3 = xp[3];
             for (; p + 4 <= np; p += 4) {
-                lh_f32x2 const a0 = xp[p], a1 = xp[p + 1], a2 = xp[p + 2], a3 = xp[p + 3];
+                lh_f32x2 const a0 = n0, a1 = n1, a2 = n2, a3 = n3;
+                n0 = xp[p + 4];
+                n1 = xp[p + 5];
+                n2 = xp[p + 6];
+                n3 = xp[p + 7];
+#ifndef LH_EMU
+                {
+                    /* one statement, so that the reads above stay ahead of it; min(x2, rh1) is (x2 < rh1) ? x2 : rh1 for
+                     * every pair of floats (equal values have equal bits here: both are positive) */
+                    float   t_;
+#define LH_XM_TERM(X) "v_mul_f32 %[t], %[" #X "], %[" #X "]\n\tv_add_f32 %[en], %[en], %[t]\n\tv_min_f32 %[t], %[t], %[rh1]\n\tv_add_f32 %[rh2], %[rh2], %[t]\n\t"
+                    asm volatile(LH_XM_TERM(a0) LH_XM_TERM(a1) LH_XM_TERM(a2) LH_XM_TERM(a3)
+                                 LH_XM_TERM(a4) LH_XM_TERM(a5) LH_XM_TERM(a6) LH_XM_TERM(a7)
+                                 : [en] "+v"(en0), [rh2] "+v"(rh2), [t] "=&v"(t_)
+                                 : [rh1] "v"(rh1), [a0] "v"(a0.x), [a1] "v"(a0.y), [a2] "v"(a1.x), [a3] "v"(a1.y),
+                                   [a4] "v"(a2.x), [a5] "v"(a2.y), [a6] "v"(a3.x), [a7] "v"(a3.y));
+#undef LH_XM_TERM
+                }
+#else
                 float const v[8] = { a0.x, a0.y, a1.x, a1.y, a2.x, a2.y, a3.x, a3.y };
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
@@ -775,6 +796,7 @@ lh_calc_xmin_body(const LhCtx & c, LhChanLds & Q, LhQR & R, const float *xr, con
                     en0 += x2;
                     rh2 += (x2 < rh1) ? x2 : rh1;
                 }
+#endif
             }
             for (; p < np; p++) {
                 lh_f32x2 const a0 = xp[p];
