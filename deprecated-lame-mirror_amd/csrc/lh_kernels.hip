@@ -868,6 +868,9 @@ lh_encode_stream(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, 
 
 #ifndef LH_EMU
 extern "C" __global__ void __launch_bounds__(LH_BLOCK, LH_WAVES_PER_EU)
+#ifdef LH_NOTAIL
+__attribute__((disable_tail_calls))
+#endif
 #else
 void
 #endif
