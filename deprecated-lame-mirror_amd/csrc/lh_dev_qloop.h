@@ -27,6 +27,9 @@
 
 
 /* A/B switches of the search (tools/build_variants.sh); the values here are the product's */
+#ifndef LH_CN_ZERO
+#define LH_CN_ZERO 1            /* calc_noise: all-zero bands take their noise from a constant of the granule */
+#endif
 #ifndef LH_LOGT
 #define LH_LOGT 1               /* calc_noise: the logarithm's table from its LDS copy (lh_dev_common.h) instead of HBM */
 #endif
@@ -58,6 +61,10 @@ struct LhQS {
     int     sbg8;               /* lane = band: 8 * subblock_gain[window] of the working image */
     int     sfbl;               /* lane = long band: its first line (576 from lane 23 on): count_bits' pn_sfb_count1 */
     float   m0, m1, m2, m3;     /* POW20(210 .. 213): the four mantissas of the step table (wave-uniform) */
+    /* lane = band: what calc_noise finds for the band while every line of it is quantised to zero -- the sum of the
+     * squares of its lines, a constant of the granule (lq_zero_band_noise) */
+    float   zk;
+    int     nzend;              /* wave-uniform: the lines from here on are zero in the working image (set by every count) */
 };
 
 LH_DEVFN int
@@ -178,6 +185,8 @@ lq_load(const LhCtx & c, LhQS & S, LhChanLds & Q, const LhQR & R, const LhGrR & 
         S.dist = 0;
         S.ph = Q.pseudohalf[s];
     }
+    S.zk = 0;
+    S.nzend = 0;                /* (the working image starts all zero) */
     S.tselw = 0;                /* table_select is all zero after lh_init_outer_loop */
     S.tselb = S.tselw;
     S.m0 = lh_uni_f(c.T->pow20[210 + LH_QMAX2]);
@@ -356,6 +365,7 @@ lq_count(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
         }
         i = 2 * top_nz;
         g.count1 = i;
+        S.nzend = i;
         nquad = (i - 2 * top_big) / 4;
         bv = i - 4 * nquad;
         g.big_values = bv;
@@ -551,90 +561,12 @@ lq_count_bits(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
     return bits;
 }
 
-/* What calc_noise finds for the working image, before it is taken over: the band's entry of calc_noise_data
- * and its distortion (lane = band), and the totals.  The search forms it for every candidate the bit count
- * looks at and takes over the one the reference would have computed. */
-struct LhNoiseTmp {
-    int     pnstep;
-    float   pnnoise, pnlog, dist;
-    LhNoiseRes res;
-};
-
-/* reference quantize_pvt.c:750-913 on the working image: into `t', S and R stay as they are */
-template < int NS > LH_DEVFN void
-lq_calc_noise(const LhCtx & c, const LhQS & S, const LhQR & R, const LhGrR & g, LhChanLds & Q, const float *xr,
-              LhNoiseTmp & t)
+/* Lane = band: the sum of the band's n squares (sq + 2 jj on), added in the reference's order; maxw = the largest n of
+ * the wave (wave-uniform).  Shared by calc_noise and by the constants of all-zero bands (lq_zero_band_noise). */
+LH_DEVFN float
+lq_band_sums(const float *sq, int n, int jj, int maxw, int fresh)
 {
-    LhNoiseRes & res = t.res;
-    const LhTables *T = c.T;
-    const LhQTabs *qt = LH_QT;
-    int const s = c.lane;
-    float  *sq = Q.xrpow;       /* the LDS copy of xrpow is dead while the search runs */
-    float   noise = 0, noise_s = 0;
-    int     l = 0, j = 0, big = 0, maxw;
-    LH_PC(13);
-    LQ_MARK("cn_begin");
-    int const st = lq_band_step(S, g);
-    int const fresh = (s < R.psymax) && !(S.pnstep == st);
-    /* POW20(st) = 2^((st - 210) / 4): one of four mantissas (the table's own entries for 210..213,
-     * in scalar registers) times a power of two -- pow20[i + 4] = 2 pow20[i] holds for the whole
-     * table (power_tables_scale_exactly(), lh_host_init.c), so no table look-up is needed */
-    float   step;
-    {
-        int const d = st - 210, q = d >> 2, r = d & 3;
-        /* (through readfirstlane: a select between plain loads of S's fields would become one load
-         * from a selected address and pin all of S in scratch memory, see lh_sbg()) */
-        float const m0 = lh_uni_f(S.m0), m1 = lh_uni_f(S.m1), m2 = lh_uni_f(S.m2), m3 = lh_uni_f(S.m3);
-        float const m = (r & 2) ? ((r & 1) ? m3 : m2) : ((r & 1) ? m1 : m0);
-        step = lq_ldexp(m, q);
-    }
-    if (fresh) {
-        l = S.wid >> 1;
-        j = S.sta;
-        if ((j + S.wid) > R.mnc) {
-            int const usefullsize = R.mnc - j + 1;
-            l = (usefullsize > 0) ? (usefullsize >> 1) : 0;
-        }
-    }
-    {
-        /* the band's step goes to its lines with one cross-lane read per slot; the squared errors
-         * of all lines go to LDS, where the band lanes add them up in the reference's order */
-        float   stp[5], p43[10];
-        lh_f32x2 ax[5];
-#pragma unroll
-        for (int k = 0; k < NS; k++) {
-            unsigned const q0 = S.pw[k] & 0xffffu, q1 = S.pw[k] >> 16;
-            ax[k] = ((const lh_f32x2 *) xr)[(k < 4 || c.lane < 32) ? c.lane + 64 * k : 287];
-            stp[k] = lh_shfl_f32(step, S.bnd[k]);
-            p43[2 * k] = qt->pow43h[q0 & 255u];
-            p43[2 * k + 1] = qt->pow43h[q1 & 255u];
-            big |= (int) ((q0 | q1) >> 8);
-        }
-        maxw = (int) lh_wave_max_u32(fresh ? (unsigned) (2 * l) : 0u);
-        if (LH_RARE(lh_ballot(big != 0))) {
-#pragma unroll
-            for (int k = 0; k < NS; k++) {
-                unsigned const q0 = S.pw[k] & 0xffffu, q1 = S.pw[k] >> 16;
-                if (q0 >= 256u)
-                    p43[2 * k] = T->pow43[q0];
-                if (q1 >= 256u)
-                    p43[2 * k + 1] = T->pow43[q1];
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < NS; k++) {
-            int const p = c.lane + 64 * k;
-            float const t0 = lh_fabsf(ax[k].x) - p43[2 * k] * stp[k];
-            float const t1 = lh_fabsf(ax[k].y) - p43[2 * k + 1] * stp[k];
-            lh_f32x2 v;
-            v.x = t0 * t0;
-            v.y = t1 * t1;
-            if (k < 4 || p < 288)
-                ((lh_f32x2 *) sq)[p] = v;
-        }
-    }
-    LH_WAVE_ORDER();
-    LQ_MARK("cn_sum");
+    float   noise = 0;
     {
         /* Lane = band adds its squares in the reference's order: a serial float sum, so the wave runs as many
          * steps as the widest band that changed has lines.  Every lane reads on past its own band's end (the next
@@ -642,8 +574,6 @@ lq_calc_noise(const LhCtx & c, const LhQS & S, const LhQR & R, const LhGrR & g, 
          * and keeps the value its sum had after its own last line -- a compare and a select per pair instead of an
          * address select per load.  Eight terms per trip from two 16-byte reads (band starts are even, the array is
          * 16-byte aligned: a band that starts on an odd pair reads its first pair alone). */
-        int const n = 2 * l;
-        int const jj = (j < 576) ? (j >> 1) : 0;
         const lh_f32x2 *sq2 = (const lh_f32x2 *) sq;
 #if LH_CN_EXEC && !defined(LH_EMU)
         /* On the device the lanes are switched off as their bands end: v_cmpx narrows EXEC after every pair of
@@ -718,6 +648,148 @@ lq_calc_noise(const LhCtx & c, const LhQS & S, const LhQR & R, const LhGrR & g, 
         }
 #endif
         noise = kept;
+    }
+    return noise;
+}
+
+/* The noise of every band for the case that all of its lines are quantised to zero (reference quantize_pvt.c:750-790 with
+ * ix = 0: temp = |xr| - pow43[0] * step = |xr|, whatever the step): the squares of the band's lines added in order, over
+ * as many lines as calc_noise looks at (max_nonzero_coeff cuts the last band short).  Once per search, after lq_load. */
+template < int NS > LH_DEVFN void
+lq_zero_band_noise(const LhCtx & c, LhQS & S, const LhQR & R, LhChanLds & Q, const float *xr)
+{
+#if LH_CN_ZERO
+    float  *sq = Q.xrpow;
+    int const s = c.lane;
+    int const mine = (s < R.psymax);
+    int     l = 0, j = 0, maxw;
+    if (mine) {
+        l = S.wid >> 1;
+        j = S.sta;
+        if ((j + S.wid) > R.mnc) {
+            int const usefullsize = R.mnc - j + 1;
+            l = (usefullsize > 0) ? (usefullsize >> 1) : 0;
+        }
+    }
+    LH_WAVE_SYNC();
+#pragma unroll
+    for (int k = 0; k < NS; k++) {
+        int const p = c.lane + 64 * k;
+        lh_f32x2 const ax = ((const lh_f32x2 *) xr)[(k < 4 || c.lane < 32) ? c.lane + 64 * k : 287];
+        float const t0 = lh_fabsf(ax.x), t1 = lh_fabsf(ax.y);
+        lh_f32x2 v;
+        v.x = t0 * t0;
+        v.y = t1 * t1;
+        if (k < 4 || p < 288)
+            ((lh_f32x2 *) sq)[p] = v;
+    }
+    LH_WAVE_ORDER();
+    maxw = (int) lh_wave_max_u32(mine ? (unsigned) (2 * l) : 0u);
+    S.zk = lq_band_sums(sq, 2 * l, (j < 576) ? (j >> 1) : 0, maxw, mine);
+    LH_WAVE_SYNC();
+#endif
+}
+
+/* What calc_noise finds for the working image, before it is taken over: the band's entry of calc_noise_data
+ * and its distortion (lane = band), and the totals.  The search forms it for every candidate the bit count
+ * looks at and takes over the one the reference would have computed. */
+struct LhNoiseTmp {
+    int     pnstep;
+    float   pnnoise, pnlog, dist;
+    LhNoiseRes res;
+};
+
+/* reference quantize_pvt.c:750-913 on the working image: into `t', S and R stay as they are */
+template < int NS > LH_DEVFN void
+lq_calc_noise(const LhCtx & c, const LhQS & S, const LhQR & R, const LhGrR & g, LhChanLds & Q, const float *xr,
+              LhNoiseTmp & t)
+{
+    LhNoiseRes & res = t.res;
+    const LhTables *T = c.T;
+    const LhQTabs *qt = LH_QT;
+    int const s = c.lane;
+    float  *sq = Q.xrpow;       /* the LDS copy of xrpow is dead while the search runs */
+    float   noise = 0, noise_s = 0;
+    int     l = 0, j = 0, big = 0, maxw;
+    LH_PC(13);
+    LQ_MARK("cn_begin");
+    int const st = lq_band_step(S, g);
+    int const fresh = (s < R.psymax) && !(S.pnstep == st);
+#if LH_CN_ZERO
+    int const zb = fresh && (S.sta >= S.nzend);
+#endif
+    /* POW20(st) = 2^((st - 210) / 4): one of four mantissas (the table's own entries for 210..213,
+     * in scalar registers) times a power of two -- pow20[i + 4] = 2 pow20[i] holds for the whole
+     * table (power_tables_scale_exactly(), lh_host_init.c), so no table look-up is needed */
+    float   step;
+    {
+        int const d = st - 210, q = d >> 2, r = d & 3;
+        /* (through readfirstlane: a select between plain loads of S's fields would become one load
+         * from a selected address and pin all of S in scratch memory, see lh_sbg()) */
+        float const m0 = lh_uni_f(S.m0), m1 = lh_uni_f(S.m1), m2 = lh_uni_f(S.m2), m3 = lh_uni_f(S.m3);
+        float const m = (r & 2) ? ((r & 1) ? m3 : m2) : ((r & 1) ? m1 : m0);
+        step = lq_ldexp(m, q);
+    }
+    if (fresh) {
+        l = S.wid >> 1;
+        j = S.sta;
+        if ((j + S.wid) > R.mnc) {
+            int const usefullsize = R.mnc - j + 1;
+            l = (usefullsize > 0) ? (usefullsize >> 1) : 0;
+        }
+    }
+    {
+        /* the band's step goes to its lines with one cross-lane read per slot; the squared errors
+         * of all lines go to LDS, where the band lanes add them up in the reference's order */
+        float   stp[5], p43[10];
+        lh_f32x2 ax[5];
+#pragma unroll
+        for (int k = 0; k < NS; k++) {
+            unsigned const q0 = S.pw[k] & 0xffffu, q1 = S.pw[k] >> 16;
+            ax[k] = ((const lh_f32x2 *) xr)[(k < 4 || c.lane < 32) ? c.lane + 64 * k : 287];
+            stp[k] = lh_shfl_f32(step, S.bnd[k]);
+            p43[2 * k] = qt->pow43h[q0 & 255u];
+            p43[2 * k + 1] = qt->pow43h[q1 & 255u];
+            big |= (int) ((q0 | q1) >> 8);
+        }
+#if LH_CN_ZERO
+        /* a band that starts at or above the end of the non-zero lines adds up the squares of its own lines, whatever
+         * the step: the constant is there since lq_zero_band_noise, and the band sits out the serial sum below (the
+         * widest bands are at the top of the spectrum, where little is quantised to anything else) */
+        l = zb ? 0 : l;
+#endif
+        maxw = (int) lh_wave_max_u32(fresh ? (unsigned) (2 * l) : 0u);
+        if (LH_RARE(lh_ballot(big != 0))) {
+#pragma unroll
+            for (int k = 0; k < NS; k++) {
+                unsigned const q0 = S.pw[k] & 0xffffu, q1 = S.pw[k] >> 16;
+                if (q0 >= 256u)
+                    p43[2 * k] = T->pow43[q0];
+                if (q1 >= 256u)
+                    p43[2 * k + 1] = T->pow43[q1];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NS; k++) {
+            int const p = c.lane + 64 * k;
+            float const t0 = lh_fabsf(ax[k].x) - p43[2 * k] * stp[k];
+            float const t1 = lh_fabsf(ax[k].y) - p43[2 * k + 1] * stp[k];
+            lh_f32x2 v;
+            v.x = t0 * t0;
+            v.y = t1 * t1;
+            if (k < 4 || p < 288)
+                ((lh_f32x2 *) sq)[p] = v;
+        }
+    }
+    LH_WAVE_ORDER();
+    LQ_MARK("cn_sum");
+    {
+        int const n = 2 * l;
+        int const jj = (j < 576) ? (j >> 1) : 0;
+        noise = lq_band_sums(sq, n, jj, maxw, fresh);
+#if LH_CN_ZERO
+        noise = zb ? S.zk : noise;
+#endif
     }
     LQ_MARK("cn_log");
     t.pnstep = S.pnstep;
@@ -1235,6 +1307,7 @@ lq_stage_body(int qch, int gr, int targ_bits)
     LhQS    S;
     R.s_mnc = lh_uni_i((int) Q.sfb_of_line[R.mnc]);
     lq_load(c, S, Q, R, g, qch);
+    lq_zero_band_noise < NS > (c, S, R, Q, lh_lds.xr[qch][lh_uni_i(gr)]);
     (void) lq_outer_loop < NS > (c, S, Q, R, g, lh_lds.xr[qch][lh_uni_i(gr)], qch, lh_uni_i(targ_bits));
     lh_rg_put(c, R, g);
 }
@@ -1267,6 +1340,7 @@ lq_vbrold_body(int qch, int gr, int min_bits, int max_bits, int cont)
     int const top = max_bits;
     R.s_mnc = lh_uni_i((int) Q.sfb_of_line[R.mnc]);
     lq_load(c, S, Q, R, g, qch);
+    lq_zero_band_noise < NS > (c, S, R, Q, xr);
     if (lh_uni_i(cont)) {
         S.sfw = Q.sf[0][band];
         S.sfbest = S.sfw;
