@@ -27,6 +27,9 @@
 
 
 /* A/B switches of the search (tools/build_variants.sh); the values here are the product's */
+#ifndef LH_QUANT_EARLY
+#define LH_QUANT_EARLY 1        /* quantiser: products and threshold look-ups issued ahead of the band-mask logic */
+#endif
 #ifndef LH_CN_ZERO
 #define LH_CN_ZERO 1            /* calc_noise: all-zero bands take their noise from a constant of the granule */
 #endif
@@ -238,6 +241,21 @@ lq_quantize(const LhCtx & c, LhQS & S, const LhQR & R, const LhGrR & g)
         if (LH_RARE(lh_ballot(S.lmax > thr)))
             return 0;
     }
+#if LH_QUANT_EARLY
+    /* the products, their first rounding and the look-ups of the second one go out BEFORE the band masks are formed
+     * (scalar work with branches of its own): the masks then fill the look-ups' LDS round trip instead of preceding it */
+    float   qa[10], qt_[10];
+    uint32_t qb[10];
+#pragma unroll
+    for (int k = 0; k < NS; k++) {
+        qa[2 * k] = istep * S.xp[2 * k];
+        qa[2 * k + 1] = istep * S.xp[2 * k + 1];
+        qb[2 * k] = lh_f32_as_u32(qa[2 * k] + (float) LH_MAGIC_FLOAT);
+        qb[2 * k + 1] = lh_f32_as_u32(qa[2 * k + 1] + (float) LH_MAGIC_FLOAT);
+        qt_[2 * k] = qt->qthr[qb[2 * k] & 255u];
+        qt_[2 * k + 1] = qt->qthr[qb[2 * k + 1] & 255u];
+    }
+#endif
     /* ---- which bands are quantised, and how (lane = band) ---- */
     uint64_t ncmask = 0, m01mask = 0;
     int     zero_mnc = 0, plain = 1;
@@ -272,9 +290,15 @@ lq_quantize(const LhCtx & c, LhQS & S, const LhQR & R, const LhGrR & g)
         uint32_t bmax = 0;
 #pragma unroll
         for (int k = 0; k < NS; k++) {
+#if LH_QUANT_EARLY
+            float const a0 = qa[2 * k], a1 = qa[2 * k + 1];
+            uint32_t const b0 = qb[2 * k], b1 = qb[2 * k + 1];
+            float const t0 = qt_[2 * k], t1 = qt_[2 * k + 1];
+#else
             float const a0 = istep * S.xp[2 * k], a1 = istep * S.xp[2 * k + 1];
             uint32_t const b0 = lh_f32_as_u32(a0 + (float) LH_MAGIC_FLOAT), b1 = lh_f32_as_u32(a1 + (float) LH_MAGIC_FLOAT);
             float const t0 = qt->qthr[b0 & 255u], t1 = qt->qthr[b1 & 255u];
+#endif
             uint32_t const r0 = b0 - (a0 < t0 ? 1u : 0u), r1 = b1 - (a1 < t1 ? 1u : 0u);
             bmax = b0 > bmax ? b0 : bmax;
             bmax = b1 > bmax ? b1 : bmax;
