@@ -1310,6 +1310,12 @@ build_region_split(LhTables * t)
         t->bv_scf[bv - 2] = r0;
         t->bv_scf[bv - 1] = lower_until_inside(t->sfb_l, r0 + 2, region_guess[below][1], bv);
     }
+    for (bv = 2; bv <= 576; bv += 2) {
+        /* the same folded with the band edges (LhTables.bvpack) */
+        int const r0 = t->bv_scf[bv - 2], r1 = t->bv_scf[bv - 1];
+        int const a1 = t->sfb_l[r0 + 1], a2 = t->sfb_l[(r0 + r1 + 2 < LH_SBMAX_L) ? r0 + r1 + 2 : LH_SBMAX_L];
+        t->bvpack[bv / 2 - 1] = (uint32_t) r0 | ((uint32_t) r1 << 4) | ((uint32_t) a1 << 8) | ((uint32_t) a2 << 18);
+    }
 }
 
 /* per-band weights on the masking threshold: four groups of bands (bass, alto, treble, the band

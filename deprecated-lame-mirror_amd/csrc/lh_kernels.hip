@@ -95,15 +95,29 @@ lh_load_qtabs(const LhCtx & c, LhQTabs & q)
         q.pow43h[i] = c.T->pow43[i];
         q.qthr[i] = c.T->qthr[i];
     }
+    static_assert(sizeof(q.ht_len) % 4 == 0 && __builtin_offsetof(LhQTabs, ht_len) % 4 == 0, "ht_len is copied by words");
+    for (int i = c.tid; i < (int) sizeof(q.ht_len) / 4; i += LH_NT)
+        ((uint32_t *) q.ht_len)[i] = ((const uint32_t *) lh_ht_len)[i];
+#ifdef LH_QTABS_OLD             /* (A/B: the staging as it was -- two dependent pairs of loads per entry, code lengths by bytes) */
     for (int i = c.tid; i < (int) sizeof(q.ht_len); i += LH_NT)
         q.ht_len[i] = lh_ht_len[i];
     for (int i = c.tid; i < 288; i += LH_NT) {
-        /* big_values = 2 i + 2: the region split the reference looks up with bv_scf[bv - 2], [bv - 1] */
         int const bv = 2 * i + 2;
         int const r0 = c.T->bv_scf[bv - 2], r1 = c.T->bv_scf[bv - 1];
         int const a1 = c.T->sfb_l[r0 + 1], a2 = c.T->sfb_l[(r0 + r1 + 2 < LH_SBMAX_L) ? r0 + r1 + 2 : LH_SBMAX_L];
         q.bvpack[i] = (uint32_t) r0 | ((uint32_t) r1 << 4) | ((uint32_t) a1 << 8) | ((uint32_t) a2 << 18);
     }
+#else
+    {
+        /* the region split by big_values, folded with the band edges by the host (LhTables.bvpack): three loads in
+         * flight per thread instead of two dependent pairs per entry */
+        uint32_t const b0 = c.T->bvpack[c.tid], b1 = c.T->bvpack[c.tid + LH_NT], b2 = c.T->bvpack[256 + (c.tid & 31)];
+        q.bvpack[c.tid] = b0;
+        q.bvpack[c.tid + LH_NT] = b1;
+        if (c.tid < 32)
+            q.bvpack[256 + c.tid] = b2;
+    }
+#endif
     if (c.tid == 0) {
         q.sfb_s3 = (uint16_t) c.T->sfb_s[3];
         q.pad = 0;
@@ -397,6 +411,10 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
     LH_SYNC_WG();
     LH_PA(2, t_mdct);
     lh_load_qtabs(c, L.qt);     /* mf is dead; xr stays */
+#ifdef LH_QTABS_TWICE
+    LH_SYNC_WG();               /* (timing experiment: what the staging costs) */
+    lh_load_qtabs(c, L.qt);
+#endif
     if (cfg->vbr == 1 || cfg->vbr == 4) {
         /* step tables of the VBR scalefactor search (over the unused second quantised image) */
         for (int i = tid; i < 256; i += LH_NT) {

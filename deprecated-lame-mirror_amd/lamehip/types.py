@@ -57,7 +57,7 @@ class LhTables(C.Structure):
         ("fht_tw", ((C.c_float * 4) * 128) * 4),
         ("amp_filter", C.c_float * 32), ("log_table", C.c_float * 513),
         ("sfb_line_l", C.c_uint8 * 576), ("sfb_line_s", C.c_uint8 * 576), ("hgrid", C.c_uint32 * 704),
-        ("qthr", C.c_float * 256), ("mask_mid", C.c_double * 10)]
+        ("qthr", C.c_float * 256), ("mask_mid", C.c_double * 10), ("bvpack", C.c_uint32 * 288)]
 
 
 class LhGranule(C.Structure):

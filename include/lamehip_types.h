@@ -217,6 +217,10 @@ typedef struct LhTables {
      * double.  mask_mid[0..7] are those midpoints for r_1 .. r_8, [8] for ma_max_i1, [9] for ma_max_i2;
      * lh_tables_init finds r_j by bisection with the reference's expression. */
     double  mask_mid[10];
+    /* The region split of a long block by big_values (reference takehiro.c:1334-1375, bv_scf above) folded with the band
+     * edges, as the CBR search reads it: entry big_values / 2 - 1 = region0_count | region1_count << 4 | end of region 0
+     * << 8 | end of region 1 << 18 (lines).  Built by lh_tables_init; the kernel copies it into LDS once per frame. */
+    uint32_t bvpack[288];
 } LhTables;
 
 /* ------------------------------------------------------------------ */
