@@ -411,10 +411,6 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
     LH_SYNC_WG();
     LH_PA(2, t_mdct);
     lh_load_qtabs(c, L.qt);     /* mf is dead; xr stays */
-#ifdef LH_QTABS_TWICE
-    LH_SYNC_WG();               /* (timing experiment: what the staging costs) */
-    lh_load_qtabs(c, L.qt);
-#endif
     if (cfg->vbr == 1 || cfg->vbr == 4) {
         /* step tables of the VBR scalefactor search (over the unused second quantised image) */
         for (int i = tid; i < 256; i += LH_NT) {
