@@ -165,6 +165,34 @@ def test_full_batch_size_properties():
     enc.close()
 
 
+def test_full_batch_every_stream_matches_oracle():
+    """BASELINE config[1]'s batch (1024 streams, CBR 128, 44.1 kHz stereo) with 1024 DIFFERENT signals of the bench's recipe,
+    1.5 s each: every frame of every stream against the oracle (payload structs, then the device packer's bytes against the
+    host packer's for every 16th stream).  The launch is the headline's -- 1024 workgroups, two waves per SIMD, every SIMD
+    shared by two streams -- only shorter; bench.py's own post-check compares four streams of the 60 s launch."""
+    enc = lamehip.Encoder(44100, 128)
+    cfg, tab = enc.config(), enc.tables()
+    orc = helpers.Oracle()
+    B, n = 1024, 44100 * 3 // 2
+    pcms = [helpers.synth_stream(91000 + i, n - 7 * (i % 13), 44100, 1.0 / 3) for i in range(B)]
+    b = lamehip.Batch(enc, B, n)
+    b.set_device_packing()
+    for s, x in enumerate(pcms):
+        b.set_pcm(s, x[0], x[1])
+    b.encode()
+    bad = []
+    for s, x in enumerate(pcms):
+        got = b.get_frames(s)
+        want = orc.encode_frames(cfg, tab, x)
+        if len(got) != len(want) or any(struct_diff(want[f], got[f]) for f in range(len(want))):
+            bad.append(s)
+        elif s % 16 == 0 and b.get_bytes(s) != b.pack(s):
+            bad.append(-s - 1)
+    b.close()
+    enc.close()
+    assert not bad, bad[:10]
+
+
 @pytest.mark.parametrize("name", ["testcase_wav_cbr128", "cbr320_js_48k_bursts", "cbr128_js_44k_q0"])
 def test_no_dependence_on_uninitialised_device_state(name):
     """Registers, LDS and scratch memory are not cleared between kernels.  Fill all of them
