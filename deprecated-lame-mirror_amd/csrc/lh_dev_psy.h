@@ -120,6 +120,52 @@ lh_rot(float c, float s, float x, float y)
     return r;
 }
 
+#ifndef LH_FHT_UNIFIED
+#define LH_FHT_UNIFIED 1        /* FHT units on and off a block's axes through one set of loads and stores (A/B switch) */
+#endif
+#if LH_FHT_UNIFIED
+/* One radix-4 butterfly unit.  A unit on its block's axes (i == 0) and one off them read and write the same eight places --
+ * lo + {0, k1, k2, k3} and hi + {0, k1, k2, k3} with hi = lo + kx on the axes and the mirror position k1 - i off them -- and
+ * differ in the arithmetic in between; a wave has both kinds in every pass.  Both are computed from ONE set of loads and the
+ * lane keeps its own (a select per result): as a branch the two kinds ran one after the other, each with its own loads, its
+ * own wait for them and its own stores. */
+LH_DEVFN void
+lh_fht_unit(lh_f32x4 tw, float *fz, int k1, int u)
+{
+    int const kx = k1 >> 1;
+    int const k2 = k1 << 1, k3 = k2 + k1, k4 = k2 << 1;
+    int const blk = u / kx, i = u - blk * kx;
+    int const axis = (i == 0);
+    float  *lo = fz + blk * k4 + i;
+    float  *hi = fz + blk * k4 + (axis ? kx : k1 - i);
+    float const p0 = lo[0], p1 = lo[k1], p2 = lo[k2], p3 = lo[k3];
+    float const q0 = hi[0], q1 = hi[k1], q2 = hi[k2], q3 = hi[k3];
+    /* on the axes: no rotation, the mirrored quarter only scales by sqrt 2 */
+    float const s01 = p0 + p1, d01 = p0 - p1, s23 = p2 + p3, d23 = p2 - p3;
+    float const r2 = (float) (LH_SQRT2 * q2), r3 = (float) (LH_SQRT2 * q3);
+    float const t01 = q0 + q1, u01 = q0 - q1;
+    float const a_l0 = s01 + s23, a_l1 = d01 + d23, a_l2 = s01 - s23, a_l3 = d01 - d23;
+    float const a_h0 = t01 + r2, a_h1 = u01 + r3, a_h2 = t01 - r2, a_h3 = u01 - r3;
+    /* off the axes: the second and fourth quarters turn by the double angle (tw.z, tw.w), then the two half-sums turn by
+     * the single angle (tw.x, tw.y) */
+    LhRot const rq1 = lh_rot(tw.z, tw.w, p1, q1);
+    LhRot const rq3 = lh_rot(tw.z, tw.w, p3, q3);
+    float const le = p0 + rq1.along, lm = p0 - rq1.along;
+    float const he = q0 + rq1.across, hm = q0 - rq1.across;
+    float const l2e = p2 + rq3.along, l2m = p2 - rq3.along;
+    float const h2e = q2 + rq3.across, h2m = q2 - rq3.across;
+    LhRot const ra = lh_rot(tw.x, tw.y, l2e, h2m);
+    LhRot const rb = lh_rot(tw.y, tw.x, h2e, l2m);
+    lo[0] = axis ? a_l0 : le + ra.along;
+    lo[k1] = axis ? a_l1 : lm + rb.across;
+    lo[k2] = axis ? a_l2 : le - ra.along;
+    lo[k3] = axis ? a_l3 : lm - rb.across;
+    hi[0] = axis ? a_h0 : he + rb.along;
+    hi[k1] = axis ? a_h1 : hm + ra.across;
+    hi[k2] = axis ? a_h2 : he - rb.along;
+    hi[k3] = axis ? a_h3 : hm - ra.across;
+}
+#else
 LH_DEVFN void
 lh_fht_unit(lh_f32x4 tw, float *fz, int k1, int u)
 {
@@ -167,6 +213,7 @@ lh_fht_unit(lh_f32x4 tw, float *fz, int k1, int u)
         lo[k3] = lm - rb.across;
     }
 }
+#endif
 
 LH_DEVFN unsigned
 lh_rev8(unsigned v)
