@@ -1293,6 +1293,9 @@ lh_bhd_build(const LhCtx & c, LhChanLds & Q, int bigv, int *tab, int *bmx)
  * words are qw is taken out again */
 LH_DEVCONST unsigned lh_bhd_none[LH_BHD_NW] = { 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u };
 
+#ifndef LH_BHD_DPP
+#define LH_BHD_DPP 1            /* best_huffman_divide: the two maximum scans over the bands on the DPP network (A/B switch) */
+#endif
 LH_DEVFN int
 lh_bhd_region(const int *tab, unsigned mx, int blo, int bhi, const unsigned (&qw)[LH_BHD_NW], int *bits)
 {
@@ -1304,6 +1307,18 @@ lh_bhd_region(const int *tab, unsigned mx, int blo, int bhi, const unsigned (&qw
 #pragma unroll
     for (int j = 0; j < LH_BHD_NW - 1; j++)
         d[j] = (unsigned) (tab[j * LH_BHD_STRIDE + bhi] - tab[j * LH_BHD_STRIDE + blo]) - qw[j];
+#if LH_BHD_DPP
+    {
+        /* (the words of the region's candidate tables picked by selects: the lanes of a wave hold all kinds of maxima, and
+         * as a chain of branches every kind present ran on its own) */
+        unsigned const c2 = (d[0] >> 16) | ((d[1] & 0xffffu) << 16), c3 = (d[1] >> 16) | ((d[2] & 0xffffu) << 16);
+        unsigned const c45 = (d[2] >> 16) | ((d[3] & 0xffffu) << 16), c8 = (d[5] >> 16) | ((d[6] & 0xffffu) << 16);
+        w0 = (mx > 15u) ? d[7] : (mx >= 8u) ? c8 : (mx >= 6u) ? d[4] : (mx >= 4u) ? c45
+            : (mx == 3u) ? c3 : (mx == 2u) ? c2 : (d[0] & 0xffffu);
+        w1 = (mx > 15u) ? d[8] : (mx >= 8u) ? (d[6] >> 16) : (mx >= 6u) ? (d[5] & 0xffffu) : (mx >= 4u) ? (d[3] >> 16) : 0u;
+        return lh_region_decide(mx, w0, w1, bits);
+    }
+#endif
     if (mx > 15u) {
         w0 = d[7];
         w1 = d[8];
@@ -1340,6 +1355,30 @@ lh_bhd_region(const int *tab, unsigned mx, int blo, int bhi, const unsigned (&qw
 LH_DEVFN void
 lh_bhd_scan_max(int lane, unsigned v, unsigned *below, unsigned *from)
 {
+#if LH_BHD_DPP && !defined(LH_EMU)
+    /* On the device, for the caller there is (v = 0 from lane 32 on: 22 bands): both scans on the DPP network instead of
+     * thirteen round trips through the LDS crossbar.  The running maximum is lh_wave_scan_max_u32 and a shift by one
+     * lane; the maximum from a lane on is a scan towards lower lanes inside the rows of sixteen (row_shl 1, 2, 4, 8), and
+     * row 0 takes row 1's total (its lane 16) on top. */
+    {
+        unsigned const p_ = lh_wave_scan_max_u32(v);
+        unsigned q_ = v, t_;
+        *below = lh_dpp < 0x138, 0u > (p_);     /* wave_shr:1 -- lane 0 has nobody below it */
+        t_ = lh_dpp < 0x101, 0u > (q_);
+        q_ = t_ > q_ ? t_ : q_;
+        t_ = lh_dpp < 0x102, 0u > (q_);
+        q_ = t_ > q_ ? t_ : q_;
+        t_ = lh_dpp < 0x104, 0u > (q_);
+        q_ = t_ > q_ ? t_ : q_;
+        t_ = lh_dpp < 0x108, 0u > (q_);
+        q_ = t_ > q_ ? t_ : q_;
+        {
+            unsigned const row1 = (unsigned) __builtin_amdgcn_readlane((int) q_, 16);
+            *from = (lane < 16 && row1 > q_) ? row1 : q_;
+        }
+        return;
+    }
+#endif
     unsigned p = v, q = v;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -1358,6 +1397,26 @@ lh_bhd_scan_max(int lane, unsigned v, unsigned *below, unsigned *from)
 LH_DEVFN unsigned
 lh_bhd_scan_min_excl(int lane, unsigned v)
 {
+#if LH_BHD_DPP && !defined(LH_EMU)
+    {
+        /* the same on the DPP network: row_shr 1, 2, 4, 8, row_bcast 15 / 31, then one lane up (seven round trips
+         * through the LDS crossbar otherwise) */
+        unsigned p_ = v, t_;
+        t_ = lh_dpp < 0x111, 0xffffffffu > (p_);
+        p_ = t_ < p_ ? t_ : p_;
+        t_ = lh_dpp < 0x112, 0xffffffffu > (p_);
+        p_ = t_ < p_ ? t_ : p_;
+        t_ = lh_dpp < 0x114, 0xffffffffu > (p_);
+        p_ = t_ < p_ ? t_ : p_;
+        t_ = lh_dpp < 0x118, 0xffffffffu > (p_);
+        p_ = t_ < p_ ? t_ : p_;
+        t_ = lh_dpp_rows < 0x142, 0xa, 0xffffffffu > (p_);
+        p_ = t_ < p_ ? t_ : p_;
+        t_ = lh_dpp_rows < 0x143, 0xc, 0xffffffffu > (p_);
+        p_ = t_ < p_ ? t_ : p_;
+        return lh_dpp < 0x138, 0x7fffffffu > (p_);
+    }
+#endif
     unsigned p = v;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -1407,7 +1466,11 @@ lh_best_huffman_divide_body(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGr
         {
             /* region 0 = bands [0, r0]: its maximum is the next lane's `below' (exchanged by all lanes:
              * a lane that sits out cannot be read from) */
+#if LH_BHD_DPP && !defined(LH_EMU)
+            unsigned const mx0 = lh_dpp < 0x130, 0u > (max_below);      /* wave_shl:1 (lanes 0..15 are looked at) */
+#else
             unsigned const mx0 = lh_shfl_u32(max_below, (lane + 1) & 63);
+#endif
             if (lane < 16) {
                 int const r0 = lane;
                 int     b = 0, t = 0;
@@ -1570,7 +1633,12 @@ lh_best_huffman_divide_body(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGr
                     return;     /* not reachable for long blocks; the reference's general case is not built */
             }
             /* the sum r0 + r1 = r2 - 2 is lane r2 - 2's */
+#if LH_BHD_DPP && !defined(LH_EMU)
+            /* (two lanes up on the DPP network; lanes 0 and 1 are not looked at) */
+            lower = (int) lh_dpp < 0x138, 0u > (lh_dpp < 0x138, 0u > ((uint32_t) s_bits));
+#else
             lower = (int) lh_shfl_u32((uint32_t) s_bits, (lane - 2) & 63);
+#endif
             live = lane >= 2 && lane < LH_SBMAX_L + 1 && (int) qt->sfb_l[(lane >= 2 && lane < 23) ? lane : 0] < bigv;
             if (live) {
                 r2b = lower + c1bits;
