@@ -1219,6 +1219,9 @@ lh_best_scalefac_store(int qch, int gr, const int8_t * g0sf, int g0_block_type)
  * choose_table (takehiro.c:546-650) becomes a difference of prefix sums per candidate table.
  * Ten words per band: seven hold two tables each (16 bits per half: a band has < 2^16 bits),
  * then the ESC pair (largetbl layout), the count of values >= 15 and the count of non-zero pairs. */
+#ifndef LH_BHD_DPP
+#define LH_BHD_DPP 1            /* best_huffman_divide: scans and lane shifts on the DPP network, table words by selects (A/B switch) */
+#endif
 #define LH_BHD_NW 10
 #define LH_BHD_STRIDE 24
 
@@ -1293,9 +1296,6 @@ lh_bhd_build(const LhCtx & c, LhChanLds & Q, int bigv, int *tab, int *bmx)
  * words are qw is taken out again */
 LH_DEVCONST unsigned lh_bhd_none[LH_BHD_NW] = { 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u };
 
-#ifndef LH_BHD_DPP
-#define LH_BHD_DPP 1            /* best_huffman_divide: the two maximum scans over the bands on the DPP network (A/B switch) */
-#endif
 LH_DEVFN int
 lh_bhd_region(const int *tab, unsigned mx, int blo, int bhi, const unsigned (&qw)[LH_BHD_NW], int *bits)
 {
