@@ -120,6 +120,9 @@ lh_rot(float c, float s, float x, float y)
     return r;
 }
 
+#ifndef LH_PE_REGS
+#define LH_PE_REGS 1            /* perceptual entropy: the terms from their lanes' registers instead of an LDS array walked by one lane (A/B switch) */
+#endif
 #ifndef LH_FHT_UNIFIED
 #define LH_FHT_UNIFIED 1        /* FHT units on and off a block's axes through one set of loads and stores (A/B switch) */
 #endif
@@ -1460,6 +1463,46 @@ lh_psy_granule(int gr, LhPsyCarry nb)
             is_short = (type == LH_SHORT_TYPE);
             nterms = is_short ? 3 * (LH_SBMAX_S - 1) : LH_SBMAX_L - 1;
             LH_WAVE_SYNC_MEM();
+#if LH_PE_REGS
+            {
+                /* The terms stay in their lanes' registers (0.0 beyond the last one) and the accumulation -- a chain of
+                 * float <- double additions in band order, the same in every lane -- takes term i from lane i with two
+                 * v_readlane: as one lane walking an LDS array the chain paid a round trip per term (21 or 36 of them, twice
+                 * per granule and wave).  Adding 0.0 leaves pe unchanged, so the long case may stop at 21. */
+                double  term = 0.0;
+                (void) tmp;
+                if (lane < nterms) {
+                    int const idx = is_short ? 22 + lane : lane;
+                    float const coef = is_short ? lh_regcoef_s[lane / 3] : lh_regcoef_l[lane];
+                    float const t = L.psy_thm[was][chn][idx];
+                    if (t > 0.0f) {
+                        float const x = t * lh_lds.ss.masking_lower;
+                        float const e = L.psy_en[was][chn][idx];
+                        if (e > x) {
+                            if (e > x * 1e10f)
+                                term = coef * (10.0f * 2.30258509299404568402);
+                            else
+                                term = coef * (lh_fast_log2(T->log_table, e / x) * LH_LOG2_OVER_LOG10);
+                        }
+                    }
+                }
+                uint64_t const tb = lh_f64_as_u64(term);
+                uint32_t const tlo = (uint32_t) tb, thi = (uint32_t) (tb >> 32);
+                float   pe = is_short ? 1236.28f / 4 : 1124.23f / 4;
+#pragma unroll
+                for (int i = 0; i < LH_SBMAX_L - 1; i++)
+                    pe = (float) (pe + lh_u64_as_f64((uint64_t) lh_bcast_u32(tlo, i) | ((uint64_t) lh_bcast_u32(thi, i) << 32)));
+                if (is_short) {
+#pragma unroll
+                    for (int i = LH_SBMAX_L - 1; i < 3 * (LH_SBMAX_S - 1); i++)
+                        pe = (float) (pe + lh_u64_as_f64((uint64_t) lh_bcast_u32(tlo, i) | ((uint64_t) lh_bcast_u32(thi, i) << 32)));
+                }
+                if (lane == 0) {
+                    L.pe[gr][chn] = pe;
+                    lh_lds.ss.last_attacks[chn] = L.ns_attacks[chn][2];
+                }
+            }
+#else
             if (lane < nterms) {
                 int const idx = is_short ? 22 + lane : lane;
                 float const coef = is_short ? lh_regcoef_s[lane / 3] : lh_regcoef_l[lane];
@@ -1485,6 +1528,7 @@ lh_psy_granule(int gr, LhPsyCarry nb)
                 L.pe[gr][chn] = pe;
                 lh_lds.ss.last_attacks[chn] = L.ns_attacks[chn][2];
             }
+#endif
         }
     }
     LH_SYNC_WG_LDS();
