@@ -120,6 +120,9 @@ lh_rot(float c, float s, float x, float y)
     return r;
 }
 
+#ifndef LH_FIR_BLOCKED
+#define LH_FIR_BLOCKED 1        /* attack detection: a lane filters nine consecutive samples from one set of 30 reads (A/B switch) */
+#endif
 #ifndef LH_PE_REGS
 #define LH_PE_REGS 1            /* perceptual entropy: the terms from their lanes' registers instead of an LDS array walked by one lane (A/B switch) */
 #endif
@@ -1022,6 +1025,28 @@ lh_psy_granule(int gr, LhPsyCarry nb)
     /* (2) attack detection (reference psymodel.c:759-940) */
     {
         int const firbase = bufbase + 576 - 350 - LH_NSFIRLEN + 192;
+#if LH_FIR_BLOCKED
+        {
+            /* A lane filters NINE CONSECUTIVE samples: their 22-sample windows overlap in all but one place, so the lane reads
+             * 30 samples once (15 two-word reads, conflict-free at a stride of nine words) instead of 21 per output -- 189 --,
+             * and every output's additions keep the reference's order. */
+            int const i0 = 9 * lane;
+            float   x[30];
+#pragma unroll
+            for (int t = 0; t < 30; t++)
+                x[t] = lh_smp(c, w, firbase + i0 + t);
+#pragma unroll
+            for (int m = 0; m < 9; m++) {
+                float   sum1 = x[m + 10], sum2 = 0.0;
+#pragma unroll
+                for (int j = 0; j < ((LH_NSFIRLEN - 1) / 2) - 1; j += 2) {
+                    sum1 += lh_hp_fir[j] * (x[m + j] + x[m + LH_NSFIRLEN - j]);
+                    sum2 += lh_hp_fir[j + 1] * (x[m + j + 1] + x[m + LH_NSFIRLEN - j - 1]);
+                }
+                P.a.hpf[w][i0 + m] = sum1 + sum2;
+            }
+        }
+#else
         for (int i = lane; i < 576; i += 64) {
             float   sum1, sum2;
             sum1 = lh_smp(c, w, firbase + i + 10);
@@ -1034,6 +1059,7 @@ lh_psy_granule(int gr, LhPsyCarry nb)
             }
             P.a.hpf[w][i] = sum1 + sum2;
         }
+#endif
     }
     LH_SYNC_WG_LDS();
     for (int pass = 0; pass < 2; pass++) {
