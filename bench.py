@@ -491,13 +491,14 @@ def main():
 
     for _ in range(args.warmup):
         batch.encode()
-    kernel_ms = []
+    kernel_ms, parts_ms = [], []
     barrier()
     t0 = time.perf_counter()
     c0 = time.process_time()
     for _ in range(args.steps):
         batch.encode(sync=True)         # (an encoded batch starts over from the initial state by itself)
         kernel_ms.append(batch.kernel_ms())
+        parts_ms.append(batch.kernel_parts_ms())
     own_dt = time.perf_counter() - t0
     own_cpu = time.process_time() - c0
     barrier()
@@ -542,6 +543,9 @@ def main():
                           # kernel path needs no host work, the rest is the runtime waiting for the stream
                           "host_cpu_per_wall_s": round(r[5] / r[4], 3)} for r in per_rank],
             "collectives_on_data_path": 0,
+            "pipeline": ({"kind": "split", "kernels_ms_avg": dict(zip(("analysis", "subband", "encode"),
+                          [round(sum(p[1][k] for p in parts_ms) / len(parts_ms), 3) for k in range(3)]))}
+                         if parts_ms and parts_ms[0][0] else {"kind": "fused"}),
             "roofline": roofline_block(frames, kavg, pmc_record_for(args)),
             "checked_against_oracle": checked,
         }

@@ -1,0 +1,600 @@
+/*
+ * lh_analysis.hip -- the frame-parallel part of the psycho-acoustic model (gfx950).
+ *
+ * The encode kernel (lh_kernels.hip) walks a stream's frames in order because the bit reservoir chains them together.
+ * Most of the psycho-acoustic model (reference psymodel.c:1397-1600) is not part of that chain: the high-pass filter and
+ * sub-block peaks of the attack detection (:759-830), the windowed FHTs (fft.c:193-289), the power spectra and their
+ * sums (:655-737, :213-226), and the partition energies, tonality and spreading convolution (:1031-1262 up to the
+ * pre-echo clamp) depend on the PCM alone.  The kernels of this file compute them for ALL frames of a launch at once --
+ * one workgroup per (stream, granule), many workgroups per CU instead of the encode kernel's two waves per SIMD -- and
+ * park the results in HBM (lh_device.h: LhMidSmall / LhMidLong / LhMidShort); the encode kernel of the split pipeline
+ * (-DLH_SPLIT) starts from there and keeps only the recurrences.
+ *
+ *   lh_attack_kernel        (stream, granule): high-pass FIR, the nine sub-block peaks of L, R, M, S
+ *   lh_attack_scan_kernel   (stream): the attack verdicts, long / short decision and block types -- the one short
+ *                           recurrence (last_attacks, blocktype_old) that the transforms below depend on
+ *   lh_analysis_kernel      (stream, granule): FHT-1024, spectra, sums, long masking; for a granule with a short-block
+ *                           channel also the three FHT-256 and their masking
+ *
+ * The arithmetic is the fused kernel's (same device functions, same evaluation order): the results are bit-identical.
+ */
+#include <stdint.h>
+#include <math.h>
+
+#ifdef LH_EMU
+#include "hipemu.h"
+#define LH_CONST static const
+#else
+#include <hip/hip_runtime.h>
+#define LH_CONST __device__ static const
+#endif
+
+#define LH_CUSTOM_LDS "lh_lds_analysis.h"
+#define LH_CUSTOM_SMP
+#include "lh_static_tables.h"
+#include "lh_dev_common.h"
+
+/* The 1024 samples a granule's transforms read (from bufp = frame window + 576 gr + 304 on, reference psymodel.c:1420) are
+ * staged as scaled floats where the power spectra will go once the long transform is done: channel ch at
+ * energy[0][1024 ch ..]; sample i of that span */
+#define LH_SPAN ((float *) lh_lds.u.psy.b.energy)
+static_assert(sizeof(lh_lds.u.psy.b.energy) >= 2 * LH_BLKSIZE * sizeof(float), "both channels' sample spans fit the spectra's place");
+LH_DEVFN float
+lh_smp(const LhCtx & c, int ch, int i)
+{
+    return LH_SPAN[ch * LH_BLKSIZE + i];
+}
+
+#include "lh_dev_psy_core.h"
+
+/* N samples of both channels from stream sample `base' on, scaled as lh_stage_window scales the frame window (same three
+ * sources: s16 pool, float pool of the handle / resampling paths, two channels mixed down), zero outside the stream;
+ * NT threads */
+template < int N, int NT > LH_DEVFN void
+lh_stage_span(const LhCtx & c, float *d0, float *d1, long long base)
+{
+    float const scale = c.cfg->pcm_scale;
+    long long const last = c.d.nsamples - 1;
+    float const mix = c.cfg->pcm_mix;
+    float const scale_r = c.cfg->pcm_scale_r;
+    if (c.pcmf) {
+        for (int t = c.tid; t < 2 * N; t += NT) {
+            int const ch = t >= N, i = t - ch * N;
+            long long const p = base + i;
+            float   v = 0.0f;
+            if (p >= 0 && p <= last && p >= c.d.pcm_base)
+                v = c.pcmf[(ch == 0 ? c.d.pcm_l : c.d.pcm_r) + (p - c.d.pcm_base)];
+            (ch ? d1 : d0)[i] = v;
+        }
+        return;
+    }
+    if (mix != 0.0f) {
+        for (int i = c.tid; i < N; i += NT) {
+            long long const p = base + i;
+            float   v = 0.0f;
+            if (p >= 0 && p <= last && p >= c.d.pcm_base) {
+                float const xl = (float) c.pcm[c.d.pcm_l + (p - c.d.pcm_base)];
+                float const xr = (float) c.pcm[c.d.pcm_r + (p - c.d.pcm_base)];
+                v = xl * scale + xr * mix;
+            }
+            d0[i] = v;
+            d1[i] = 0.0f;
+        }
+        return;
+    }
+    {
+        /* the usual span: inside the stream and the pool, both planes on an even element -- two samples per load */
+        long long const lo = base, hi = base + N - 1;
+        long long const ol = c.d.pcm_l + (base - c.d.pcm_base), orr = c.d.pcm_r + (base - c.d.pcm_base);
+        int const inside = lo >= 0 && lo >= c.d.pcm_base && hi <= last && ((ol | orr) & 1) == 0;
+        static_assert((N / 2) % NT == 0, "pairs per thread");
+        constexpr int U = N / 2 / NT;
+        if (lh_uni_i(inside)) {
+            const uint32_t *pl = (const uint32_t *) (c.pcm + ol), *pr = (const uint32_t *) (c.pcm + orr);
+            uint32_t v[2 * U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                v[u] = pl[c.tid + NT * u];
+                v[U + u] = pr[c.tid + NT * u];
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                int const j = c.tid + NT * u;
+                lh_f32x2 a, b;
+                a.x = (float) (int16_t) (v[u] & 0xffffu) * scale;
+                a.y = (float) (int16_t) (v[u] >> 16) * scale;
+                b.x = (float) (int16_t) (v[U + u] & 0xffffu) * scale_r;
+                b.y = (float) (int16_t) (v[U + u] >> 16) * scale_r;
+                ((lh_f32x2 *) d0)[j] = a;
+                ((lh_f32x2 *) d1)[j] = b;
+            }
+            return;
+        }
+    }
+    for (int t = c.tid; t < 2 * N; t += NT) {
+        int const ch = t >= N, i = t - ch * N;
+        long long const p0 = base + i;
+        long long p = p0 < 0 ? 0 : (p0 > last ? last : p0);
+        int16_t v;
+        p = p < c.d.pcm_base ? c.d.pcm_base : p;        /* never before the pool (also nsamples == 0) */
+        v = (c.d.nsamples > 0) ? c.pcm[(ch == 0 ? c.d.pcm_l : c.d.pcm_r) + (p - c.d.pcm_base)] : (int16_t) 0;
+        (ch ? d1 : d0)[i] = (p0 < 0 || p0 > last) ? 0.0f : (float) v * (ch == 0 ? scale : scale_r);
+    }
+}
+
+/* which granule of which frame a workgroup of the (granule, stream) grid works on */
+struct LhGranuleAt {
+    int     live;
+    int     gr;                 /* granule of the frame */
+    long long at;               /* the frame's record in the pools */
+    long long frame_base;       /* stream sample index of the frame window's first sample (1152 f - 528) */
+};
+
+LH_DEVFN LhGranuleAt
+lh_granule_at(const LhStreamDesc & d, int g)
+{
+    LhGranuleAt o;
+    int const nf = d.frame_end - d.frame_begin;
+    int const fr = g / LH_NGR;
+    o.live = g < LH_NGR * nf;
+    o.gr = g - fr * LH_NGR;
+    o.at = d.out_index + fr;
+    o.frame_base = (long long) (576 * LH_NGR) * (d.frame_begin + fr) - LH_MF_START;
+    return o;
+}
+
+LH_DEVFN LhStreamDesc
+lh_desc_uniform(const LhStreamDesc * descs, int sidx)
+{
+    LhStreamDesc d = descs[sidx];
+    d.pcm_l = lh_uni_ll(d.pcm_l);
+    d.pcm_r = lh_uni_ll(d.pcm_r);
+    d.pcm_base = lh_uni_ll(d.pcm_base);
+    d.nsamples = lh_uni_ll(d.nsamples);
+    d.out_index = lh_uni_ll(d.out_index);
+    d.frame_begin = lh_uni_i(d.frame_begin);
+    d.frame_end = lh_uni_i(d.frame_end);
+    return d;
+}
+
+#ifdef LH_LSF
+#define lh_attack_kernel lh_attack_kernel_lsf
+#define lh_attack_scan_kernel lh_attack_scan_kernel_lsf
+#define lh_analysis_kernel lh_analysis_kernel_lsf
+#define lh_launch_analysis lh_launch_analysis_lsf
+#define lh_emu_analysis lh_emu_analysis_lsf
+#endif
+
+#define LH_FIR_SPAN 640         /* 576 + 21 samples are read; staged in pairs by 64 threads */
+
+/* ---- attack detection, part 1: the high-passed granule and its sub-block peaks (reference psymodel.c:759-830) ---- */
+#ifndef LH_EMU
+extern "C" __global__ void __launch_bounds__(64)
+#else
+void
+#endif
+lh_attack_kernel(const LhConfig * cfg, const int16_t * pcm, const float *pcmf, const LhStreamDesc * descs, LhMidSmall * small,
+                 int nstreams)
+{
+    /* [2][LH_FIR_SPAN] samples, then (in place) [2][576] filtered ones: 5 KB of its own, not the analysis kernel's image --
+     * one wave per workgroup, and what limits the waves per CU is the LDS a workgroup takes */
+    __shared__ float span[2 * LH_FIR_SPAN];
+    int const sidx = (int) blockIdx.y;
+    LhCtx   c;
+    c.cfg = cfg;
+    c.T = nullptr;
+    c.st = nullptr;
+    c.pcm = pcm;
+    c.pcmf = pcmf;
+    c.d = lh_desc_uniform(descs, sidx);
+    c.tid = (int) threadIdx.x;
+    c.lane = c.tid;
+    c.wave = 0;
+    LhGranuleAt const ga = lh_granule_at(c.d, (int) blockIdx.x);
+    if (!ga.live)
+        return;
+    int const lane = c.lane;
+    int const n_chn_psy = (cfg->mode == LH_MODE_JOINT_STEREO) ? 4 : cfg->channels;
+    int const bufbase = 576 + ga.gr * 576 - LH_FFTOFFSET;
+    int const firbase = bufbase + 576 - 350 - LH_NSFIRLEN + 192;
+    LhMidGr *mg = &small[ga.at].gr[ga.gr];
+    lh_stage_span < LH_FIR_SPAN, 64 > (c, span, span + LH_FIR_SPAN, ga.frame_base + firbase);
+    LH_WAVE_SYNC();
+    {
+        /* a lane filters nine consecutive samples of either channel (as the fused kernel does: lh_dev_psy.h); every lane
+         * has its 30 samples in registers before the first filtered one replaces a sample */
+        int const i0 = 9 * lane;
+        float   x[2][30], y[2][9];
+#pragma unroll
+        for (int ch = 0; ch < 2; ch++)
+#pragma unroll
+            for (int t = 0; t < 30; t++)
+                x[ch][t] = span[ch * LH_FIR_SPAN + i0 + t];
+#pragma unroll
+        for (int ch = 0; ch < 2; ch++)
+#pragma unroll
+            for (int m = 0; m < 9; m++) {
+                float   sum1 = x[ch][m + 10], sum2 = 0.0;
+#pragma unroll
+                for (int j = 0; j < ((LH_NSFIRLEN - 1) / 2) - 1; j += 2) {
+                    sum1 += lh_hp_fir[j] * (x[ch][m + j] + x[ch][m + LH_NSFIRLEN - j]);
+                    sum2 += lh_hp_fir[j + 1] * (x[ch][m + j + 1] + x[ch][m + LH_NSFIRLEN - j - 1]);
+                }
+                y[ch][m] = sum1 + sum2;
+            }
+        LH_WAVE_SYNC();
+#pragma unroll
+        for (int ch = 0; ch < 2; ch++)
+#pragma unroll
+            for (int m = 0; m < 9; m++)
+                span[ch * LH_FIR_SPAN + i0 + m] = y[ch][m];
+    }
+    LH_WAVE_SYNC();
+    for (int chn = 0; chn < n_chn_psy; chn++) {
+        /* peak k = the largest magnitude among samples 64 k .. 64 k + 63 (exact under any order) */
+        uint32_t pk[8], pk8 = 0;
+        for (int k = 0; k < 9; k++) {
+            int const i = lane + 64 * k;
+            float const l = span[i], r = span[LH_FIR_SPAN + i];
+            float const v = (chn == 0) ? l : (chn == 1) ? r : (chn == 2) ? l + r : l - r;
+            if (k < 8)
+                pk[k] = lh_f32_as_u32(lh_fabsf(v));
+            else
+                pk8 = lh_f32_as_u32(lh_fabsf(v));
+        }
+        {
+            uint32_t const m8 = lh_wave_max8(pk);       /* lane k: peak k & 7 */
+            uint32_t const m9 = lh_wave_max_u32(pk8);
+            if (lane < 9)
+                mg->peak[chn][lane] = lh_u32_as_f32(lane == 8 ? m9 : m8);
+        }
+    }
+}
+
+/* ---- attack detection, part 2: the verdicts (reference psymodel.c:806-933, 1265-1319); one wave per stream ---- */
+#ifndef LH_EMU
+extern "C" __global__ void __launch_bounds__(64)
+#else
+void
+#endif
+lh_attack_scan_kernel(const LhConfig * cfg, const LhTables * T, const LhStreamDesc * descs, const LhStreamState * states,
+                      LhMidSmall * small, int nstreams)
+{
+    int const sidx = (int) blockIdx.x;
+    int const lane = (int) threadIdx.x;
+    LhStreamDesc const d = lh_desc_uniform(descs, sidx);
+    int const nf = d.frame_end - d.frame_begin;
+    if (nf <= 0)
+        return;
+    const LhStreamState *st = &states[sidx];
+    int const n_chn_psy = lh_uni_i((cfg->mode == LH_MODE_JOINT_STEREO) ? 4 : cfg->channels);
+    int const channels = lh_uni_i(cfg->channels), short_blocks = lh_uni_i(cfg->short_blocks);
+    /* what the previous launch left: lane k < 9 holds last_en_subshort[chn][k]; the scalars in every lane */
+    float   le[4];
+    int     last_att[4], bt_old[2];
+    float   thresh[4];
+    for (int chn = 0; chn < 4; chn++) {
+        le[chn] = st->last_en_subshort[chn][lane < 9 ? lane : 0];
+        last_att[chn] = lh_uni_i(st->last_attacks[chn]);
+        thresh[chn] = lh_uni_f(T->attack_threshold[chn]);
+    }
+    bt_old[0] = lh_uni_i(st->blocktype_old[0]);
+    bt_old[1] = lh_uni_i(st->blocktype_old[1]);
+    /* the peaks of the next granule are requested while this one's verdicts are formed */
+    float   pk_next[4];
+    {
+        const LhMidGr *m0 = &small[d.out_index].gr[0];
+        for (int chn = 0; chn < 4; chn++)
+            pk_next[chn] = m0->peak[chn][lane < 9 ? lane : 0];
+    }
+    for (int g = 0; g < LH_NGR * nf; g++) {
+        int const fr = g / LH_NGR, gr = g - fr * LH_NGR;
+        LhMidGr *mg = &small[d.out_index + fr].gr[gr];
+        float   pk[4];
+        int     ns_uselong[4] = { 1, 1, 1, 1 };
+        for (int chn = 0; chn < 4; chn++)
+            pk[chn] = pk_next[chn];
+        if (g + 1 < LH_NGR * nf) {
+            int const f2 = (g + 1) / LH_NGR, g2 = (g + 1) - f2 * LH_NGR;
+            const LhMidGr *m2 = &small[d.out_index + f2].gr[g2];
+            for (int chn = 0; chn < 4; chn++)
+                pk_next[chn] = m2->peak[chn][lane < 9 ? lane : 0];
+        }
+        for (int chn = 0; chn < 4; chn++) {
+            int     nsa[4] = { 0, 0, 0, 0 };
+            float   ssf = 1.0f;
+            if (chn < n_chn_psy) {
+                /* twelve sub-blocks: three from the previous granule, nine new ones; lane i (< 12) owns sub-block i */
+                float const fresh = pk[chn] < 1.0f ? 1.0f : pk[chn];          /* lane k < 9: the new sub-block k */
+                float const old = lh_shfl_f32(le[chn], (lane + 6) & 63), older = lh_shfl_f32(le[chn], (lane + 4) & 63);
+                float const mine = lh_shfl_f32(fresh, (lane - 3) & 63);
+                float const e = (lane < 3) ? old : mine;
+                float const two_back = lh_shfl_f32(e, (lane - 2) & 63);
+                float const then = (lane < 3) ? older : two_back;
+                float const ai = (lane < 3) ? e / then : (e > then) ? e / then : (then > e * 10.0f) ? then / (e * 10.0f) : 0.0f;
+                float const e1 = lh_shfl_f32(e, (lane - 1) & 63), e0 = lh_shfl_f32(e, (lane - 2) & 63);
+                float const whole = e0 + e1 + e;
+                int const tail_low = e * 6 < whole, mid_low = e1 * 6 < whole;
+                uint64_t const over = lh_ballot(lane < 12 && ai > thresh[chn]);
+                float   en_short[4];
+                en_short[0] = lh_u32_as_f32(lh_bcast_u32(lh_f32_as_u32(whole), 2));
+                en_short[1] = lh_u32_as_f32(lh_bcast_u32(lh_f32_as_u32(whole), 5));
+                en_short[2] = lh_u32_as_f32(lh_bcast_u32(lh_f32_as_u32(whole), 8));
+                en_short[3] = lh_u32_as_f32(lh_bcast_u32(lh_f32_as_u32(whole), 11));
+                ssf = tail_low ? (mid_low ? 0.25f : 0.5f) : 1.0f;   /* lanes 5, 8, 11: sub_short_factor[0..2] */
+                le[chn] = fresh;
+                for (int gq = 0; gq < 4; gq++) {
+                    unsigned const bits = (unsigned) (over >> (3 * gq)) & 7u;
+                    nsa[gq] = bits ? ((bits & 1u) ? 1 : (bits & 2u) ? 2 : 3) : 0;
+                }
+                for (int i = 1; i < 4; i++) {
+                    float const u = en_short[i - 1];
+                    float const v = en_short[i];
+                    float const m = (u > v) ? u : v;
+                    if (m < 40000) {
+                        if (u < 1.7f * v && v < 1.7f * u) {
+                            if (i == 1 && nsa[0] <= nsa[i])
+                                nsa[0] = 0;
+                            nsa[i] = 0;
+                        }
+                    }
+                }
+                if (nsa[0] <= last_att[chn])
+                    nsa[0] = 0;
+                if (last_att[chn] == 3 || nsa[0] + nsa[1] + nsa[2] + nsa[3]) {
+                    ns_uselong[chn] = 0;
+                    if (nsa[1] && nsa[0])
+                        nsa[1] = 0;
+                    if (nsa[2] && nsa[1])
+                        nsa[2] = 0;
+                    if (nsa[3] && nsa[2])
+                        nsa[3] = 0;
+                }
+                last_att[chn] = lh_uni_i(nsa[2]);
+            }
+            if (lane == 5 || lane == 8 || lane == 11)
+                mg->sub_short_factor[chn][(lane - 5) / 3] = ssf;
+            if (lane < 4)
+                mg->ns_attacks[chn][lane] = (int8_t) (lane == 0 ? nsa[0] : lane == 1 ? nsa[1] : lane == 2 ? nsa[2] : nsa[3]);
+        }
+        {
+            /* uselongblock[] (reference psymodel.c:926-933, 1265-1286) and the block types (:1289-1319) */
+            int     ul0 = ns_uselong[0], ul1 = (channels == 2) ? ns_uselong[1] : 1;
+            int     btd[2];
+            for (int chn = 2; chn < n_chn_psy; chn++)
+                if (ns_uselong[chn] == 0)
+                    ul0 = ul1 = 0;
+            if (short_blocks == 1 && !(ul0 && ul1))
+                ul0 = ul1 = 0;
+            if (short_blocks == 2)
+                ul0 = ul1 = 1;
+            if (short_blocks == 3)
+                ul0 = ul1 = 0;
+            for (int chn = 0; chn < 2; chn++) {
+                int     blocktype = LH_NORM_TYPE;
+                int     old = bt_old[chn];
+                if (chn ? ul1 : ul0) {
+                    if (old == LH_SHORT_TYPE)
+                        blocktype = LH_STOP_TYPE;
+                }
+                else {
+                    blocktype = LH_SHORT_TYPE;
+                    if (old == LH_NORM_TYPE)
+                        old = LH_START_TYPE;
+                    if (old == LH_STOP_TYPE)
+                        old = LH_SHORT_TYPE;
+                }
+                btd[chn] = old;
+                bt_old[chn] = lh_uni_i(blocktype);
+            }
+            if (lane < 2) {
+                mg->uselong[lane] = (int8_t) (lane ? ul1 : ul0);
+                mg->block_type[lane] = (int8_t) (lane ? btd[1] : btd[0]);
+            }
+        }
+    }
+}
+
+/* ---- transforms, spectra, masking up to the recurrences; one workgroup (wave = channel) per (stream, granule) ---- */
+#ifndef LH_EMU
+extern "C" __global__ void __launch_bounds__(LH_NT, 4)
+#else
+void
+#endif
+lh_analysis_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, const float *pcmf, const LhStreamDesc * descs,
+                   LhMidSmall * small, LhMidLong * lng, LhMidShort * shrt, int nstreams)
+{
+    LhLds & L = lh_lds;
+    LhPsyLds & P = L.u.psy;
+    int const sidx = (int) blockIdx.y;
+    LhCtx   c;
+    c.cfg = cfg;
+    c.T = T;
+    c.st = nullptr;
+    c.pcm = pcm;
+    c.pcmf = pcmf;
+    c.d = lh_desc_uniform(descs, sidx);
+    c.tid = (int) threadIdx.x;
+    c.lane = c.tid & 63;
+    c.wave = lh_uni_i(c.tid >> 6);
+    LhGranuleAt const ga = lh_granule_at(c.d, (int) blockIdx.x);
+    if (!ga.live)
+        return;
+    int const lane = c.lane, w = c.wave, gr = ga.gr;
+    int const n_chn_psy = (cfg->mode == LH_MODE_JOINT_STEREO) ? 4 : cfg->channels;
+    int const bufbase = 576 + gr * 576 - LH_FFTOFFSET;
+    LhMidGr *mg = &small[ga.at].gr[gr];
+    if (c.tid < 2)
+        L.uselong[c.tid] = mg->uselong[c.tid];
+    lh_stage_span < LH_BLKSIZE, LH_NT > (c, LH_SPAN, LH_SPAN + LH_BLKSIZE, ga.frame_base + bufbase);
+    LH_SYNC_WG_LDS();
+    /* long FFTs of L (wave 0) and R (wave 1) */
+    if (w < cfg->channels)
+        lh_fft_long(c, w, 0, P.wsamp[w]);
+    LH_SYNC_WG_LDS();
+    /* power spectra of this wave's one or two pseudo-channels (over the sample spans, which are done with) */
+    if (n_chn_psy == 4)
+        lh_fft_energy_pair(c, w, P.wsamp[0], P.wsamp[1], LH_BLKSIZE, P.b.energy[w], P.b.energy[w + 2]);
+    else if (w < n_chn_psy)
+        lh_fft_energy(c, w, P.wsamp[0], P.wsamp[1], LH_BLKSIZE, P.b.energy[w]);
+    /* the FHT buffers are free: the long-block spreading matrix goes there (as in the fused kernel) */
+    float  *stg_s3 = &P.wsamp[0][0];
+    LH_SYNC_WG_LDS();
+    for (int i = c.tid; i < T->psy_l.s3_count; i += LH_NT)
+        stg_s3[i] = T->psy_l.s3[i];
+    LH_SYNC_WG_LDS();
+    /* serial sums: total energy (bins 11..512) of chn w (lane 0) and w + 2 (lane 1), loudness of channel w (lane 2), in
+     * bin order (reference psymodel.c:213-226, 690-696); see the fused kernel for the layout */
+    {
+        int const chn = (lane == 1) ? w + 2 : w;
+        int const summing = lane < 3 && chn < n_chn_psy;
+        int const loud = (lane == 2);
+        float  *prod = (w == 0) ? P.eb : P.thr; /* [256] per wave */
+        const float *ew = T->ath_eql_w;
+        const float *e = P.b.energy[summing ? chn : w];
+        float   acc = 0.0f;
+        for (int h = 0; h < 2; h++) {
+            int const j0 = 256 * h;
+            LH_WAVE_SYNC_MEM();
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                int const j = j0 + lane + 64 * q;
+                prod[j - j0] = P.b.energy[w][j] * ew[j];
+            }
+            LH_WAVE_SYNC_MEM();
+            if (summing) {
+                const lh_f32x4 *s4 = (const lh_f32x4 *) ((loud ? prod - j0 : e) + j0);
+                lh_f32x4 a0 = s4[0], a1 = s4[1], a2 = s4[2], a3 = s4[3];
+                if (h == 0 && !loud) {
+                    /* bins 0..10 are not part of the total energy */
+                    a0.x = a0.y = a0.z = a0.w = 0.0f;
+                    a1.x = a1.y = a1.z = a1.w = 0.0f;
+                    a2.x = a2.y = a2.z = 0.0f;
+                }
+                for (int g = 0; g < 64; g += 4) {
+                    int const n = (g + 4 < 64) ? g + 4 : g;
+                    lh_f32x4 const b0 = s4[n], b1 = s4[n + 1], b2 = s4[n + 2], b3 = s4[n + 3];
+#ifndef LH_EMU
+                    asm volatile("v_add_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %2\n\tv_add_f32 %0, %0, %3\n\tv_add_f32 %0, %0, %4\n\t"
+                                 "v_add_f32 %0, %0, %5\n\tv_add_f32 %0, %0, %6\n\tv_add_f32 %0, %0, %7\n\tv_add_f32 %0, %0, %8\n\t"
+                                 "v_add_f32 %0, %0, %9\n\tv_add_f32 %0, %0, %10\n\tv_add_f32 %0, %0, %11\n\tv_add_f32 %0, %0, %12\n\t"
+                                 "v_add_f32 %0, %0, %13\n\tv_add_f32 %0, %0, %14\n\tv_add_f32 %0, %0, %15\n\tv_add_f32 %0, %0, %16"
+                                 : "+v"(acc)
+                                 : "v"(a0.x), "v"(a0.y), "v"(a0.z), "v"(a0.w), "v"(a1.x), "v"(a1.y), "v"(a1.z), "v"(a1.w),
+                                   "v"(a2.x), "v"(a2.y), "v"(a2.z), "v"(a2.w), "v"(a3.x), "v"(a3.y), "v"(a3.z), "v"(a3.w));
+#else
+                    acc += a0.x; acc += a0.y; acc += a0.z; acc += a0.w;
+                    acc += a1.x; acc += a1.y; acc += a1.z; acc += a1.w;
+                    acc += a2.x; acc += a2.y; acc += a2.z; acc += a2.w;
+                    acc += a3.x; acc += a3.y; acc += a3.z; acc += a3.w;
+#endif
+                    a0 = b0;
+                    a1 = b1;
+                    a2 = b2;
+                    a3 = b3;
+                }
+            }
+        }
+        if (summing) {
+            if (!loud) {
+                acc += e[LH_BLKSIZE / 2];
+                mg->tot_ener[chn] = acc;
+            }
+            else {
+                acc = (float) (acc * LH_VO_SCALE);
+                mg->loud[w] = acc;
+            }
+        }
+        LH_WAVE_SYNC_MEM();
+    }
+    /* masking, long blocks, up to the recurrences: the wave's one or two pseudo-channels together */
+    {
+        LhMidLong *ml = &lng[ga.at];
+        if (n_chn_psy == 4) {
+            LhMaskChan const two[2] = {
+                {w, P.b.energy[w], &P.eb[w * 64], &P.thr[w * 64], nullptr, nullptr, &ml->m[gr][w]},
+                {w + 2, P.b.energy[w + 2], &P.eb[(w + 2) * 64], &P.thr[(w + 2) * 64], nullptr, nullptr, &ml->m[gr][w + 2]}
+            };
+            lh_compute_masking < 2, 1 > (c, 1, two, stg_s3);
+        }
+        else if (w < n_chn_psy) {
+            LhMaskChan const one[1] = { {w, P.b.energy[w], &P.eb[w * 64], &P.thr[w * 64], nullptr, nullptr, &ml->m[gr][w]} };
+            lh_compute_masking < 1, 1 > (c, 1, one, stg_s3);
+        }
+    }
+    /* short blocks (reference psymodel.c:1470-1500): only for a granule in which a channel switches */
+    int const any_short = lh_uni_i(!(L.uselong[0] && L.uselong[1]));
+    if (!any_short)
+        return;
+    LH_SYNC_WG_LDS();           /* the long spectra and the staged matrix are done with */
+    lh_stage_span < LH_BLKSIZE, LH_NT > (c, LH_SPAN, LH_SPAN + LH_BLKSIZE, ga.frame_base + bufbase);
+    LH_SYNC_WG_LDS();
+    if (!L.uselong[w])
+        lh_fft_short(c, w, 0, &P.wsamp[w][0]);
+    LH_SYNC_WG_LDS();
+    for (int sblock = 0; sblock < 3; sblock++) {
+        if (w < n_chn_psy && !L.uselong[w]) {
+            LhMidShort *ms = &shrt[ga.at];
+            int const both = (n_chn_psy == 4);
+            if (both)
+                lh_fft_energy_pair(c, w, &P.wsamp[0][sblock * LH_BLKSIZE_S], &P.wsamp[1][sblock * LH_BLKSIZE_S],
+                                   LH_BLKSIZE_S, P.b.energy[w], P.b.energy[w + 2]);
+            else
+                lh_fft_energy(c, w, &P.wsamp[0][sblock * LH_BLKSIZE_S], &P.wsamp[1][sblock * LH_BLKSIZE_S], LH_BLKSIZE_S,
+                              P.b.energy[w]);
+            LH_WAVE_SYNC_MEM();
+            if (both) {
+                LhMaskChan const two[2] = {
+                    {w, P.b.energy[w], &P.eb[w * 64], &P.thr[w * 64], nullptr, nullptr, &ms->m[gr][sblock][w]},
+                    {w + 2, P.b.energy[w + 2], &P.eb[(w + 2) * 64], &P.thr[(w + 2) * 64], nullptr, nullptr, &ms->m[gr][sblock][w + 2]}
+                };
+                lh_compute_masking < 2, 1 > (c, 0, two, T->psy_s.s3);
+            }
+            else {
+                LhMaskChan const one[1] = { {w, P.b.energy[w], &P.eb[w * 64], &P.thr[w * 64], nullptr, nullptr, &ms->m[gr][sblock][w]} };
+                lh_compute_masking < 1, 1 > (c, 0, one, T->psy_s.s3);
+            }
+        }
+        LH_SYNC_WG_LDS();
+    }
+}
+
+#ifndef LH_EMU
+/* all three in order on one HIP stream; max_frames = the longest frame range of the launch */
+extern "C" int
+lh_launch_analysis(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, const float *pcmf, const LhStreamDesc * descs,
+                   const LhStreamState * states, LhMidPools mid, int nstreams, int max_frames, void *stream)
+{
+    if (nstreams <= 0 || max_frames <= 0)
+        return 0;
+    dim3 const grid((unsigned) (LH_NGR * max_frames), (unsigned) nstreams);
+    hipLaunchKernelGGL(lh_attack_kernel, grid, dim3(64), 0, (hipStream_t) stream, cfg, pcm, pcmf, descs, mid.small, nstreams);
+    hipLaunchKernelGGL(lh_attack_scan_kernel, dim3((unsigned) nstreams), dim3(64), 0, (hipStream_t) stream, cfg, T, descs, states,
+                       mid.small, nstreams);
+    hipLaunchKernelGGL(lh_analysis_kernel, grid, dim3(LH_NT), 0, (hipStream_t) stream, cfg, T, pcm, pcmf, descs, mid.small, mid.lng,
+                       mid.shrt, nstreams);
+    return (int) hipGetLastError();
+}
+#else
+extern "C" int
+lh_emu_analysis(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, const float *pcmf, const LhStreamDesc * descs,
+                const LhStreamState * states, const LhMidPools * pools, int nstreams, int max_frames)
+{
+    LhMidPools const mid = *pools;
+    hipemu_dim3 grid = { (unsigned) (LH_NGR * max_frames), (unsigned) nstreams, 1 }, b64 = { 64, 1, 1 }, b128 = { LH_NT, 1, 1 };
+    hipemu_dim3 grid1 = { (unsigned) nstreams, 1, 1 };
+    hipemu_run(grid, b64,[=] () {
+               lh_attack_kernel(cfg, pcm, pcmf, descs, mid.small, nstreams);
+               }
+    );
+    hipemu_run(grid1, b64,[=] () {
+               lh_attack_scan_kernel(cfg, T, descs, states, mid.small, nstreams);
+               }
+    );
+    hipemu_run(grid, b128,[=] () {
+               lh_analysis_kernel(cfg, T, pcm, pcmf, descs, mid.small, mid.lng, mid.shrt, nstreams);
+               }
+    );
+    return 0;
+}
+#endif

@@ -37,6 +37,26 @@ extern "C" int lh_launch_encode_vbr(const LhConfig * cfg, const LhTables * T, co
                                     const LhStreamDesc * descs, LhStreamState * states,
                                     LhFrameOut * out, uint8_t * bytes, int nstreams, void *stream);
 
+/* the split pipeline: the analysis kernels (lh_analysis.hip, lh_subband.hip), which do everything of a
+ * frame that depends on the PCM alone for all frames of a launch at once, and the encode kernels compiled to start from
+ * their output (lh_kernels.hip with -DLH_SPLIT); one set per frame geometry / scheduling variant as above */
+#define LH_DECL_SPLIT(sfx) \
+    extern "C" int lh_launch_analysis##sfx(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, const float *pcmf, \
+                                           const LhStreamDesc * descs, const LhStreamState * states, LhMidPools mid, \
+                                           int nstreams, int max_frames, void *stream); \
+    extern "C" int lh_launch_subband##sfx(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, const float *pcmf, \
+                                          const LhStreamDesc * descs, LhStreamState * states, LhMidPools mid, \
+                                          int nstreams, int max_frames, void *stream);
+LH_DECL_SPLIT()
+LH_DECL_SPLIT(_lsf)
+#define LH_DECL_Q(sfx) \
+    extern "C" int lh_launch_encode_q##sfx(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, const float *pcmf, \
+                                           const LhStreamDesc * descs, LhStreamState * states, LhFrameOut * out, \
+                                           uint8_t * bytes, int nstreams, void *stream, LhMidPools mid);
+LH_DECL_Q()
+LH_DECL_Q(_vbr)
+LH_DECL_Q(_lsf)
+
 extern "C" int lh_launch_selftest(unsigned *d_out, unsigned seed, void *stream);
 extern "C" int lh_launch_summary(const LhStreamState * states, long long *sum, int nstreams, void *stream);
 extern "C" int lh_launch_scatter(const int16_t * arena, int16_t * pool, long cap, const int *seg, int nseg, void *stream);
@@ -106,6 +126,25 @@ struct LhDeviceConst {
                LhFrameOut * out, uint8_t * bytes, int nstreams, void *stream) const {
         return (lsf ? lh_launch_encode_lsf : vbrk ? lh_launch_encode_vbr : lh_launch_encode)
             (d_cfg, d_tab, pcm, pcmf, descs, states, out, bytes, nstreams, stream);
+    }
+    /* The split pipeline: analysis kernels for every frame of the launch, then the encode kernel that starts from what they
+     * left in `mid'.  ev[0..1], when given, are recorded behind the analysis and the sub-band kernels (per-kernel times). */
+    int launch_split(const int16_t * pcm, const float *pcmf, const LhStreamDesc * descs, LhStreamState * states,
+                     LhFrameOut * out, uint8_t * bytes, int nstreams, int max_frames, const LhMidPools & mid, void *stream,
+                     hipEvent_t * ev) const {
+        int     rc;
+        rc = (lsf ? lh_launch_analysis_lsf : lh_launch_analysis) (d_cfg, d_tab, pcm, pcmf, descs, states, mid, nstreams, max_frames, stream);
+        if (rc)
+            return rc;
+        if (ev && hipEventRecord(ev[0], (hipStream_t) stream) != hipSuccess)
+            return (int) hipGetLastError();
+        rc = (lsf ? lh_launch_subband_lsf : lh_launch_subband) (d_cfg, d_tab, pcm, pcmf, descs, states, mid, nstreams, max_frames, stream);
+        if (rc)
+            return rc;
+        if (ev && hipEventRecord(ev[1], (hipStream_t) stream) != hipSuccess)
+            return (int) hipGetLastError();
+        return (lsf ? lh_launch_encode_q_lsf : vbrk ? lh_launch_encode_q_vbr : lh_launch_encode_q)
+            (d_cfg, d_tab, pcm, pcmf, descs, states, out, bytes, nstreams, stream, mid);
     }
     int upload(const LhConfig & cfg, const LhTables & tab) {
         lsf = (cfg.mode_gr == 1);
@@ -1470,6 +1509,15 @@ lamehip_get_tables(const lame_t g, void *out, int size)
 /* ====================================================================== */
 /* batch extension                                                          */
 
+/* Batches go through the split pipeline unless LAMEHIP_FUSED=1 asks for the single fused kernel (A/B measurements; the
+ * handle API always uses the fused kernel: one frame per launch has nothing to analyse ahead). */
+static int
+batch_use_split(void)
+{
+    const char *e = getenv("LAMEHIP_FUSED");
+    return !(e && e[0] == '1');
+}
+
 struct lamehip_batch {
     int     device;
     LhConfig cfg;
@@ -1541,7 +1589,95 @@ struct lamehip_batch {
     int     up_pending, down_pending;
     int     up_inflight;        /* an H2D copy out of the pinned mirror may still be running (host view: cleared only after ev_up) */
     int     launched;           /* a kernel was launched on this batch and ev1 recorded (survives lamehip_batch_reset) */
+    /* the split pipeline's pools (one record of each per frame of a launch, like d_out) and the events between its kernels */
+    LhMidPools mid;
+    long long mid_cap;
+    int     split;              /* this batch's launches go through the split pipeline (batch_use_split) */
+    hipEvent_t ev_part[2];
+    float   part_ms[3];         /* analysis, sub-band, encode kernel of the last launch (0: fused launch) */
+    int     last_split;
 };
+
+/* room for `total' frames in the split pipeline's pools; a failed allocation (or a launch too long for the device's
+ * memory) leaves the batch on the fused kernel for this launch */
+static int
+batch_mid_reserve(lamehip_batch * b, long long total)
+{
+    if (total <= b->mid_cap)
+        return 0;
+    size_t  free_b = 0, total_b = 0;
+    size_t const per_frame = sizeof(LhMidSmall) + sizeof(LhMidLong) + sizeof(LhMidShort) + sizeof(LhMidXr);
+    long long const want = total + 64;
+    if (b->mid.small)
+        (void) hipFree(b->mid.small);
+    if (b->mid.lng)
+        (void) hipFree(b->mid.lng);
+    if (b->mid.shrt)
+        (void) hipFree(b->mid.shrt);
+    if (b->mid.xr)
+        (void) hipFree(b->mid.xr);
+    b->mid.small = nullptr;
+    b->mid.lng = nullptr;
+    b->mid.shrt = nullptr;
+    b->mid.xr = nullptr;
+    b->mid_cap = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (double) want * (double) per_frame > 0.8 * (double) free_b)
+        return -1;
+    if (hipMalloc((void **) &b->mid.small, (size_t) want * sizeof(LhMidSmall)) != hipSuccess
+        || hipMalloc((void **) &b->mid.lng, (size_t) want * sizeof(LhMidLong)) != hipSuccess
+        || hipMalloc((void **) &b->mid.shrt, (size_t) want * sizeof(LhMidShort)) != hipSuccess
+        || hipMalloc((void **) &b->mid.xr, (size_t) want * sizeof(LhMidXr)) != hipSuccess) {
+        (void) hipGetLastError();
+        if (b->mid.small)
+            (void) hipFree(b->mid.small);
+        if (b->mid.lng)
+            (void) hipFree(b->mid.lng);
+        if (b->mid.shrt)
+            (void) hipFree(b->mid.shrt);
+        if (b->mid.xr)
+            (void) hipFree(b->mid.xr);
+        b->mid.small = nullptr;
+        b->mid.lng = nullptr;
+        b->mid.shrt = nullptr;
+        b->mid.xr = nullptr;
+        return -1;
+    }
+    b->mid_cap = want;
+    return 0;
+}
+
+/* one launch of the batch's frames [frame_begin, frame_end) per stream, as `descs' (device copy) / `h_descs' say, between
+ * ev0 and ev1 on the batch's stream: the split pipeline when the batch uses it and its pools can be had, else the fused kernel */
+static int
+batch_launch(lamehip_batch * b, const int16_t * pcm, const float *pcmf, const LhStreamDesc * descs, const LhStreamDesc * h_descs,
+             uint8_t * bytes)
+{
+    long long total = 0;
+    int     max_frames = 0, rc;
+    for (int s = 0; s < b->B; s++) {
+        int const nf = h_descs[s].frame_end - h_descs[s].frame_begin;
+        if (nf > 0) {
+            total += nf;
+            if (nf > max_frames)
+                max_frames = nf;
+        }
+    }
+    int     split = b->split && total > 0 && batch_mid_reserve(b, total) == 0;
+    if (split && !b->ev_part[0]) {
+        if (hipEventCreate(&b->ev_part[0]) != hipSuccess || hipEventCreate(&b->ev_part[1]) != hipSuccess)
+            split = 0;
+    }
+    HIPCHK(hipEventRecord(b->ev0, b->stream));
+    if (split)
+        rc = b->dc.launch_split(pcm, pcmf, descs, b->d_state, b->d_out, bytes, b->B, max_frames, b->mid, (void *) b->stream, b->ev_part);
+    else
+        rc = b->dc.launch(pcm, pcmf, descs, b->d_state, b->d_out, bytes, b->B, (void *) b->stream);
+    if (rc)
+        return set_err("kernel launch", (hipError_t) rc);
+    HIPCHK(hipEventRecord(b->ev1, b->stream));
+    b->last_split = split;
+    return 0;
+}
 
 static int
 batch_padding(const lamehip_batch * b, int s)
@@ -1654,6 +1790,15 @@ lamehip_batch_create_on(int device, const lame_t proto, int nstreams, long capac
     b->up_pending = b->down_pending = 0;
     b->up_inflight = 0;
     b->launched = 0;
+    b->mid.small = nullptr;
+    b->mid.lng = nullptr;
+    b->mid.shrt = nullptr;
+    b->mid.xr = nullptr;
+    b->mid_cap = 0;
+    b->split = batch_use_split();
+    b->ev_part[0] = b->ev_part[1] = nullptr;
+    b->part_ms[0] = b->part_ms[1] = b->part_ms[2] = 0;
+    b->last_split = 0;
     if (proto->rs) {
         /* the s16 pool shrinks to nothing, the converted signal (plus the flush's tail) lives in a float pool */
         b->rate_in = proto->p.samplerate;
@@ -1701,6 +1846,18 @@ lamehip_batch_destroy(lamehip_batch * b)
         (void) hipFree(b->d_bytes);
     if (b->d_pcmf)
         (void) hipFree(b->d_pcmf);
+    if (b->mid.small)
+        (void) hipFree(b->mid.small);
+    if (b->mid.lng)
+        (void) hipFree(b->mid.lng);
+    if (b->mid.shrt)
+        (void) hipFree(b->mid.shrt);
+    if (b->mid.xr)
+        (void) hipFree(b->mid.xr);
+    if (b->ev_part[0])
+        (void) hipEventDestroy(b->ev_part[0]);
+    if (b->ev_part[1])
+        (void) hipEventDestroy(b->ev_part[1]);
     free(b->rs);
     if (b->h_stage)
         (void) hipHostFree(b->h_stage);
@@ -2189,12 +2346,8 @@ batch_encode_range(lamehip_batch * b, const std::vector < int >&upto, int end)
         HIPCHK(hipStreamSynchronize(b->stream));
         return 0;
     }
-    HIPCHK(hipEventRecord(b->ev0, b->stream));
-    rc = b->dc.launch(b->d_pcm, (const float *) 0, (const LhStreamDesc *) b->d_stage, b->d_state, b->d_out, (uint8_t *) 0, b->B,
-                      (void *) b->stream);
-    if (rc)
-        return set_err("kernel launch", (hipError_t) rc);
-    HIPCHK(hipEventRecord(b->ev1, b->stream));
+    if ((rc = batch_launch(b, b->d_pcm, (const float *) 0, (const LhStreamDesc *) b->d_stage, descs, (uint8_t *) 0)) != 0)
+        return rc;
     b->launched = 1;
     b->h_new.resize((size_t) total);
     HIPCHK(hipMemcpyAsync(b->h_new.data(), b->d_out, (size_t) total * sizeof(LhFrameOut), hipMemcpyDeviceToHost, b->stream));
@@ -2418,13 +2571,10 @@ lamehip_batch_encode(lamehip_batch * b)
         int const big = (b->B >= 512);
         if (big && ser.ev)
             HIPCHK(hipStreamWaitEvent(b->stream, ser.ev, 0));
-        HIPCHK(hipEventRecord(b->ev0, b->stream));
-        int     rc = b->dc.launch(b->rate_in ? (const int16_t *) 0 : b->d_pcm, b->rate_in ? b->d_pcmf : (const float *) 0,
-                                  b->d_desc, b->d_state, b->d_out, b->dev_pack ? b->d_bytes : (uint8_t *) 0, b->B,
-                                  (void *) b->stream);
+        int     rc = batch_launch(b, b->rate_in ? (const int16_t *) 0 : b->d_pcm, b->rate_in ? b->d_pcmf : (const float *) 0,
+                                  b->d_desc, b->h_desc.data(), b->dev_pack ? b->d_bytes : (uint8_t *) 0);
         if (rc)
-            return set_err("kernel launch", (hipError_t) rc);
-        HIPCHK(hipEventRecord(b->ev1, b->stream));
+            return rc;
         if (b->dev_pack) {
             /* the two words per stream lamehip_batch_fetch copies first: gathered here, inside the serial order -- as a
              * launch of its own behind the NEXT batch's kernel it found no free register file until that kernel was over
@@ -2627,6 +2777,12 @@ lamehip_batch_sync(lamehip_batch * b)
         float   ms = 0;
         if (hipEventElapsedTime(&ms, b->ev0, b->ev1) == hipSuccess)
             b->last_ms = ms;
+        b->part_ms[0] = b->part_ms[1] = b->part_ms[2] = 0;
+        if (b->last_split) {
+            (void) hipEventElapsedTime(&b->part_ms[0], b->ev0, b->ev_part[0]);
+            (void) hipEventElapsedTime(&b->part_ms[1], b->ev_part[0], b->ev_part[1]);
+            (void) hipEventElapsedTime(&b->part_ms[2], b->ev_part[1], b->ev1);
+        }
     }
     return 0;
 }
@@ -2635,6 +2791,19 @@ extern "C" float
 lamehip_batch_last_kernel_ms(lamehip_batch * b)
 {
     return b ? b->last_ms : 0.0f;
+}
+
+/* the last launch kernel by kernel (split pipeline): analysis kernels, sub-band kernel, encode kernel, in ms; returns 1 when
+ * the launch went through the split pipeline, 0 for the fused kernel (all of lamehip_batch_last_kernel_ms is that one kernel) */
+extern "C" int
+lamehip_batch_last_kernel_parts_ms(lamehip_batch * b, float *parts3)
+{
+    if (!b || !parts3)
+        return -1;
+    parts3[0] = b->part_ms[0];
+    parts3[1] = b->part_ms[1];
+    parts3[2] = b->part_ms[2];
+    return b->last_split;
 }
 
 extern "C" int

@@ -328,6 +328,9 @@ struct LhVbrOldSave {
 struct LhQuantLds {
     LhChanLds ch[2];
 };
+static_assert(__builtin_offsetof(LhTables, pow43) % 128 == 0 && __builtin_offsetof(LhTables, vqthr) % 128 == 0,
+              "the gathered tables start on cache lines (hipMalloc aligns the struct itself)");
+static_assert(sizeof(LhChanLds) % 16 == 0, "both channels' float2/float4 accesses need 16-byte alignment");
 
 /* VBR only: the step tables of the scalefactor search, ipow20[0..255] and pow20[116..371]
  * (= pow20[sf + Q_MAX2]), staged over the second quantised image, which that loop never uses */
@@ -356,6 +359,13 @@ struct LhCtxShared {
     uint8_t *bytes;             /* not null: finished MP3 bytes are assembled here (lh_dev_emit.h) */
     LhStreamDesc d;
     long long frame_base;       /* stream sample index of mfbuf[0] for the current frame: 1152 f - 528 */
+#ifdef LH_SPLIT
+    /* the encode kernel of the split pipeline: the current frame's records of the analysis kernels' output (lh_device.h) */
+    const LhMidSmall *mid_small;
+    const LhMidLong *mid_long;
+    const LhMidShort *mid_short;
+    const LhMidXr *mid_xr;
+#endif
 };
 
 /* per-granule scalars on their way into / out of an out-of-line stage (one slot per wave) */
@@ -415,6 +425,9 @@ static_assert(__builtin_offsetof(LhStreamState, ath_adjust_limit) - __builtin_of
 static_assert(__builtin_offsetof(LhStreamState, status) - __builtin_offsetof(LhStreamState, pefirbuf)
               == 4 * (LH_SS_WORDS_B - 1), "second run of LhStreamState's small members");
 
+#ifdef LH_CUSTOM_LDS              /* (the analysis kernels' translation units bring their own, smaller image: a header's name) */
+#include LH_CUSTOM_LDS
+#else
 struct LhLds {
     LhSmallState ss;
     /* Band energies / thresholds of the psy model, [L,R,M,S] each: a ring of three slots.  The model's
@@ -472,9 +485,6 @@ struct LhLds {
     } u;
 };
 
-static_assert(__builtin_offsetof(LhTables, pow43) % 128 == 0 && __builtin_offsetof(LhTables, vqthr) % 128 == 0,
-              "the gathered tables start on cache lines (hipMalloc aligns the struct itself)");
-static_assert(sizeof(LhChanLds) % 16 == 0, "both channels' float2/float4 accesses need 16-byte alignment");
 static_assert(sizeof(LhLds) <= 40960, "four workgroups per CU need <= 40 KiB of the 160 KiB LDS each");
 
 /* The workgroup's LDS image (one stream), at file scope: every device function, in line or
@@ -482,6 +492,7 @@ static_assert(sizeof(LhLds) <= 40960, "four workgroups per CU need <= 40 KiB of 
  * out-of-line stages by reference made all their accesses generic FLAT loads. */
 __shared__ LhLds lh_lds __attribute__((aligned(16)));
 #define LH_QT (&lh_lds.qt)
+#endif                          /* !LH_CUSTOM_LDS */
 
 /* ---- launch context -------------------------------------------------- */
 struct LhCtx {
@@ -662,10 +673,12 @@ lh_stage_window(const LhCtx & c, float (*mf)[LH_MF_NEEDED], long long base)
 }
 
 /* sample i of the current frame window */
+#ifndef LH_CUSTOM_SMP
 LH_DEVFN float
 lh_smp(const LhCtx & c, int ch, int i)
 {
     return lh_lds.mf[ch][i];
 }
+#endif
 
 #endif

@@ -89,6 +89,54 @@ typedef struct LhStreamDesc {
     int     pad;
 } LhStreamDesc;
 
+/* ---- what the analysis kernels hand to the encode kernel ("mid" data; lh_analysis.hip, lh_subband.hip) ----
+ * Everything of the psycho-acoustic model, the polyphase filter and the MDCT that depends on the PCM alone is computed
+ * for all frames of a launch at once, at high occupancy, and parked in HBM; the encode kernel's frame prologue only
+ * runs the recurrences (pre-echo clamp against the previous granules, ATH level, thresholds under the masking adjustment
+ * the last frame's loop left, partition -> band sums, perceptual entropy).  One record of each pool per frame of the launch,
+ * at LhStreamDesc.out_index + (frame - frame_begin) like the payload. */
+typedef struct LhMidGr {
+    float   peak[4][12];        /* [chn L,R,M,S][k < 9]: largest |high-passed sample| of the granule's nine sub-blocks of 64 samples
+                                 * (reference psymodel.c:806-830 before the clamp to 1) */
+    float   tot_ener[4];        /* total energy of the long spectrum, bins 11..512 (psymodel.c:690-696) */
+    float   loud[2];            /* loudness of L / R (psymodel.c:213-226) */
+    float   sub_short_factor[4][3];
+    int8_t  ns_attacks[4][4];   /* the attack scan's verdicts (psymodel.c:866-925) */
+    int8_t  uselong[2];         /* uselongblock[ch] after the channels are coupled (psymodel.c:926-933, 1265-1286) */
+    int8_t  block_type[2];      /* the granule's block type per channel (psymodel.c:1289-1319) */
+    int8_t  pad[4];
+} LhMidGr;
+
+typedef struct LhMidSmall {
+    LhMidGr gr[2];
+} LhMidSmall;
+
+/* masking of one pseudo-channel before the recurrences, lane = partition (psymodel.c:1134-1262 up to the pre-echo clamp):
+ * v[0] = the partition's energy eb, v[1] = its spread energy x the tonality-dependent weight (ecb), v[2] = the cap
+ * max x minval x weight */
+typedef struct LhMidMask {
+    float   v[3][LH_CBANDS];
+} LhMidMask;
+
+typedef struct LhMidLong {
+    LhMidMask m[2][4];          /* [gr][chn] */
+} LhMidLong;
+
+typedef struct LhMidShort {
+    LhMidMask m[2][3][4];       /* [gr][sub-block][chn]; only written for granules with a short-block channel */
+} LhMidShort;
+
+typedef struct LhMidXr {
+    float   xr[2][2][576];      /* [ch][gr] MDCT spectra of L / R (before the mid/side rotation) */
+} LhMidXr;
+
+typedef struct LhMidPools {
+    LhMidSmall *small;
+    LhMidLong *lng;
+    LhMidShort *shrt;
+    LhMidXr *xr;
+} LhMidPools;
+
 void    lh_state_init(LhStreamState * s, const LhConfig * cfg);
 
 #ifdef __cplusplus

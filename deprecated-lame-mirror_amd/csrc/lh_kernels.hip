@@ -29,7 +29,7 @@
 
 #ifdef LH_EMU
 #include <string.h>
-#ifdef LH_LSF
+#if defined(LH_LSF) || defined(LH_SPLIT)
 extern "C" { extern int lh_emu_poison_lds; }
 #else
 extern "C" { int lh_emu_poison_lds = 0; }
@@ -327,6 +327,12 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
         L.prof[w][lane] = 0;
 #endif
     LH_PT(t_frame);
+#ifdef LH_SPLIT
+    /* the split pipeline: the PCM was read by the analysis kernels (lh_analysis.hip, lh_subband.hip), whose output for this
+     * frame the stages below pick up from HBM (L.ctx.mid_*) */
+    if (tid == 0)
+        lh_lds.ss.primed = 1;
+#else
     if (!lh_lds.ss.primed) {
         lh_stage_window(c, L.mf, c.frame_base - fs);
         LH_SYNC_WG();
@@ -342,6 +348,7 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
 
     lh_stage_window(c, L.mf, c.frame_base);
     LH_SYNC_WG();
+#endif
 
     /* ---- padding (reference encoder.c:348-352) ---- */
     int     padding = 0;
@@ -399,6 +406,22 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
     LH_PA(25, t_frame);
     /* ---- stage 2: polyphase + MDCT (reference encoder.c:405) ---- */
     LH_PT(t_mdct);
+#ifdef LH_SPLIT
+    {
+        /* the MDCT spectra of both granules, as lh_subband_kernel left them (L / R; the mid/side rotation follows below) */
+        const lh_f32x4 *src = (const lh_f32x4 *) L.ctx.mid_xr->xr;
+        lh_f32x4 *dst = (lh_f32x4 *) L.xr;
+        lh_f32x4 v[5];
+#pragma unroll
+        for (int u = 0; u < 5; u++)
+            v[u] = src[(tid + LH_NT * u < 576) ? tid + LH_NT * u : 575];
+#pragma unroll
+        for (int u = 0; u < 5; u++)
+            if (tid + LH_NT * u < 576)
+                dst[tid + LH_NT * u] = v[u];
+    }
+    LH_SYNC_WG();
+#else
 #pragma unroll
     for (int k = 0; k < 9; k++)
         L.u.mdct.sb[w][0][lane + 64 * k] = carry.sb[k];
@@ -409,6 +432,7 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
     for (int k = 0; k < 9; k++)
         carry.sb[k] = L.u.mdct.sb[w][ngr][lane + 64 * k];
     LH_SYNC_WG();
+#endif
     LH_PA(2, t_mdct);
     lh_load_qtabs(c, L.qt);     /* mf is dead; xr stays */
     if (cfg->vbr == 1 || cfg->vbr == 4) {
@@ -751,7 +775,7 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
 #define LH_WAVES_PER_EU 2
 #endif
 /* the LH_LSF build of this file (MPEG-2 / 2.5 streams) is a second object in the same library: its own names */
-#ifdef LH_LSF
+#if defined(LH_LSF) && !defined(LH_SPLIT)
 #define lh_encode_kernel lh_encode_kernel_lsf
 #define lh_launch_encode lh_launch_encode_lsf
 #define lh_emu_encode lh_emu_encode_lsf
@@ -759,15 +783,35 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
 #endif
 /* and so is the LH_VBRK build: the same MPEG-1 source compiled with the scheduling strategy that suits the new VBR
  * loop (csrc/Makefile); lh_api.cpp launches it for vbr_mt / vbr_mtrh configurations */
-#ifdef LH_VBRK
+#if defined(LH_VBRK) && !defined(LH_SPLIT)
 #define lh_encode_kernel lh_encode_kernel_vbr
 #define lh_launch_encode lh_launch_encode_vbr
+#endif
+/* and the LH_SPLIT builds of all three: the encode kernel of the split pipeline, which starts from the analysis kernels'
+ * output (LhMidPools) instead of the PCM */
+#ifdef LH_SPLIT
+#if defined(LH_LSF)
+#define lh_encode_kernel lh_encode_kernel_q_lsf
+#define lh_launch_encode lh_launch_encode_q_lsf
+#define lh_emu_encode_q lh_emu_encode_q_lsf
+#elif defined(LH_VBRK)
+#define lh_encode_kernel lh_encode_kernel_q_vbr
+#define lh_launch_encode lh_launch_encode_q_vbr
+#else
+#define lh_encode_kernel lh_encode_kernel_q
+#define lh_launch_encode lh_launch_encode_q
+#endif
+#define LH_MID_PARAM , LhMidPools mid
+#define LH_MID_ARG , mid
+#else
+#define LH_MID_PARAM
+#define LH_MID_ARG
 #endif
 /* all frames of one stream (the workgroup's whole job) */
 LH_DEVFN void
 lh_encode_stream(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, const float *pcmf,
                  const LhStreamDesc * descs, LhStreamState * states, LhFrameOut * out, uint8_t * bytes,
-                 int nstreams)
+                 int nstreams LH_MID_PARAM)
 {
     LhLds & L = lh_lds;
     int const sidx = (int) blockIdx.x;
@@ -834,9 +878,11 @@ lh_encode_stream(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, 
         carry.nb.n1[p] = st->nb_l1[c.wave + 2 * p][c.lane];
         carry.nb.n2[p] = st->nb_l2[c.wave + 2 * p][c.lane];
     }
+#ifndef LH_SPLIT
 #pragma unroll
     for (int k = 0; k < 9; k++)
         carry.sb[k] = st->sb_prev[c.wave][c.lane + 64 * k];
+#endif
     for (int t = c.tid; t < 4 * LH_XMIN_N; t += LH_NT) {
         int const chn = t / LH_XMIN_N, i = t - chn * LH_XMIN_N;
         L.psy_en[0][chn][i] = st->en[chn][i];
@@ -857,7 +903,19 @@ lh_encode_stream(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, 
         if (c.tid == 0) {
             L.ctx.frame_base = c.frame_base;    /* read by the stages after the next workgroup barrier */
             L.psy_slot = slot;
+#ifdef LH_SPLIT
+            {
+                long long const at = c.d.out_index + (f - c.d.frame_begin);
+                L.ctx.mid_small = mid.small + at;
+                L.ctx.mid_long = mid.lng + at;
+                L.ctx.mid_short = mid.shrt + at;
+                L.ctx.mid_xr = mid.xr + at;
+            }
+#endif
         }
+#ifdef LH_SPLIT
+        LH_SYNC_WG();           /* (the fused kernel's first barrier of a frame follows the window's staging) */
+#endif
         lh_encode_frame(c, &out[c.d.out_index + (f - c.d.frame_begin)], carry);
         slot = (slot + ngr) % 3;
     }
@@ -870,9 +928,11 @@ lh_encode_stream(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, 
         st->nb_l1[c.wave + 2 * p][c.lane] = carry.nb.n1[p];
         st->nb_l2[c.wave + 2 * p][c.lane] = carry.nb.n2[p];
     }
+#ifndef LH_SPLIT                /* (split pipeline: lh_subband_kernel leaves the stream's polyphase overlap there) */
 #pragma unroll
     for (int k = 0; k < 9; k++)
         st->sb_prev[c.wave][c.lane + 64 * k] = carry.sb[k];
+#endif
     for (int t = c.tid; t < 4 * LH_XMIN_N; t += LH_NT) {
         int const chn = t / LH_XMIN_N, i = t - chn * LH_XMIN_N;
         st->en[chn][i] = L.psy_en[slot][chn][i];
@@ -890,12 +950,12 @@ void
 #endif
 lh_encode_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, const float *pcmf,
                  const LhStreamDesc * descs, LhStreamState * states, LhFrameOut * out, uint8_t * bytes,
-                 int nstreams)
+                 int nstreams LH_MID_PARAM)
 {
-    lh_encode_stream(cfg, T, pcm, pcmf, descs, states, out, bytes, nstreams);
+    lh_encode_stream(cfg, T, pcm, pcmf, descs, states, out, bytes, nstreams LH_MID_ARG);
 }
 
-#if !defined(LH_EMU) && !defined(LH_LSF) && !defined(LH_VBRK)
+#if !defined(LH_EMU) && !defined(LH_LSF) && !defined(LH_VBRK) && !defined(LH_SPLIT)
 /* device self-test of the cross-lane primitives in lh_wave.h: each reduction is
  * compared with a serial evaluation through LDS; out[0] = number of mismatches */
 extern "C" __global__ void __launch_bounds__(64)
@@ -1051,15 +1111,30 @@ lh_launch_scatter(const int16_t * arena, int16_t * pool, long cap, const int *se
 extern "C" int
 lh_launch_encode(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, const float *pcmf,
                  const LhStreamDesc * descs, LhStreamState * states, LhFrameOut * out, uint8_t * bytes,
-                 int nstreams, void *stream)
+                 int nstreams, void *stream LH_MID_PARAM)
 {
     if (nstreams <= 0)
         return 0;
     hipLaunchKernelGGL(lh_encode_kernel, dim3((unsigned) nstreams), dim3(LH_BLOCK), 0,
-                       (hipStream_t) stream, cfg, T, pcm, pcmf, descs, states, out, bytes, nstreams);
+                       (hipStream_t) stream, cfg, T, pcm, pcmf, descs, states, out, bytes, nstreams LH_MID_ARG);
     return (int) hipGetLastError();
 }
 
+#elif defined(LH_SPLIT)
+/* (emulator, split pipeline: the encode kernel alone; tests/test_emulator.py runs the analysis kernels' twins first) */
+extern "C" int
+lh_emu_encode_q(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, const float *pcmf,
+                const LhStreamDesc * descs, LhStreamState * states, LhFrameOut * out, uint8_t * bytes, int nstreams,
+                const LhMidPools * pools)
+{
+    hipemu_dim3 grid = { (unsigned) nstreams, 1, 1 }, block = { LH_BLOCK, 1, 1 };
+    LhMidPools const mid = *pools;
+    hipemu_run(grid, block,[=] () {
+               lh_encode_kernel(cfg, T, pcm, pcmf, descs, states, out, bytes, nstreams, mid);
+               }
+    );
+    return 0;
+}
 #else
 extern "C" int lh_emu_encode_bytes(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, const LhStreamDesc * descs,
                                    LhStreamState * states, LhFrameOut * out, uint8_t * bytes, int nstreams);

@@ -67,6 +67,8 @@ def load_library():
     lib.lamehip_batch_get_state.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
     lib.lamehip_batch_last_kernel_ms.restype = C.c_float
     lib.lamehip_batch_last_kernel_ms.argtypes = [C.c_void_p]
+    lib.lamehip_batch_last_kernel_parts_ms.restype = C.c_int
+    lib.lamehip_batch_last_kernel_parts_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     lib.lamehip_batch_kernel_waves.argtypes = [C.c_void_p]
     _lib = lib
     return lib
@@ -318,6 +320,12 @@ class Batch:
 
     def kernel_ms(self):
         return float(self.lib.lamehip_batch_last_kernel_ms(self.b))
+
+    def kernel_parts_ms(self):
+        """The last launch kernel by kernel: (split, [analysis, sub-band, encode] in ms); split = False: one fused kernel."""
+        parts = (C.c_float * 3)()
+        split = self.lib.lamehip_batch_last_kernel_parts_ms(self.b, parts)
+        return bool(split == 1), [float(parts[0]), float(parts[1]), float(parts[2])]
 
     def kernel_waves(self):
         return int(self.lib.lamehip_batch_kernel_waves(self.b))

@@ -297,6 +297,11 @@ int     lamehip_batch_get_state(lamehip_batch *, int stream, void *out, int size
 int     lamehip_get_state(const lame_t, void *out, int size);   /* same for a single-stream handle */
 /* elapsed GPU time of the last lamehip_batch_encode in ms (HIP events on the batch stream) */
 float   lamehip_batch_last_kernel_ms(lamehip_batch *);
+/* the same launch kernel by kernel: a batch's frames go through the split pipeline -- analysis kernels over all frames at
+ * once (attack detection, FHTs, spectra, masking up to the recurrences: csrc/lh_analysis.hip), the sub-band kernel
+ * (polyphase + MDCT: csrc/lh_subband.hip), then the per-stream encode kernel -- parts3[0..2] = their times in ms.  Returns 1,
+ * or 0 when the launch was the single fused kernel (environment LAMEHIP_FUSED=1, or no memory for the pools). */
+int     lamehip_batch_last_kernel_parts_ms(lamehip_batch *, float *parts3);
 /* waves per stream of the kernel this batch encodes with: 2 (one per channel) */
 int     lamehip_batch_kernel_waves(lamehip_batch *);
 int     lamehip_batch_reset(lamehip_batch *);   /* re-initialise all stream states for another run */

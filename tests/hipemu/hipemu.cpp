@@ -28,9 +28,13 @@ hipemu_run(hipemu_dim3 grid, hipemu_dim3 block, std::function < void () > body)
         for (auto & f:st.fibers)
             f.stack = (char *) malloc(STACK);
     }
-    for (unsigned b = 0; b < grid.x; b++) {
+    /* (grids of one or two dimensions) */
+    unsigned const gy = grid.y ? grid.y : 1;
+    for (unsigned bb = 0; bb < grid.x * gy; bb++) {
+        unsigned const b = bb % grid.x;
         st.bid.x = b;
-        st.bid.y = st.bid.z = 0;
+        st.bid.y = bb / grid.x;
+        st.bid.z = 0;
         memset(&st.block_bar, 0, sizeof(st.block_bar));
         memset(st.wave_bar, 0, sizeof(st.wave_bar));
         for (unsigned t = 0; t < block.x; t++) {

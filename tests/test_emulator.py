@@ -60,6 +60,82 @@ def test_kernel_source_matches_oracle(name, nframes, emu, oracle):
     enc.close()
 
 
+class LhMidPools(C.Structure):
+    _fields_ = [("small", C.c_void_p), ("lng", C.c_void_p), ("shrt", C.c_void_p), ("xr", C.c_void_p)]
+
+
+# sizes of the analysis kernels' per-frame records (csrc/lh_device.h: LhMidSmall, LhMidLong, LhMidShort, LhMidXr)
+MID_SIZES = (2 * 288, 2 * 4 * 3 * 64 * 4, 2 * 3 * 4 * 3 * 64 * 4, 2 * 2 * 576 * 4)
+
+
+def split_encode(emu, cfg, tab, pool, descs, states, got, nstreams, max_frames, total_frames, poison=0x5a):
+    """The split pipeline under the emulator: attack / scan / analysis kernels, the sub-band kernel, then the encode
+    kernel that starts from their output.  The pools are filled with a poison pattern first: whatever the encode
+    kernel reads must have been written by the analysis kernels of THIS launch."""
+    lsf = cfg.mode_gr == 1
+    bufs = [np.full(total_frames * sz + 64, poison, dtype=np.uint8) for sz in MID_SIZES]
+    pools = LhMidPools(*[b.ctypes.data for b in bufs])
+    sfx = "_lsf" if lsf else ""
+    pcm = pool.ctypes.data_as(C.c_void_p)
+    getattr(emu, "lh_emu_analysis" + sfx)(C.byref(cfg), C.byref(tab), pcm, None, descs, states, C.byref(pools), nstreams, max_frames)
+    getattr(emu, "lh_emu_subband" + sfx)(C.byref(cfg), C.byref(tab), pcm, None, descs, states, C.byref(pools), nstreams, max_frames)
+    getattr(emu, "lh_emu_encode_q" + sfx)(C.byref(cfg), C.byref(tab), pcm, None, descs, states, got, None, nstreams, C.byref(pools))
+
+
+SPLIT_CASES = [("cbr128_js_44k", 8), ("cbr320_js_48k_bursts", 8), ("cbr96_js_32k", 6), ("vbr2_js_44k", 8),
+               ("vbr0_js_48k_bursts", 8), ("vbr5_st_32k", 6), ("abr150_js_32k_white_q5", 6),
+               ("mono_cbr160_48k_bursts_q5", 6), ("mono_vbr2_44k", 6), ("vbrold0_js_48k_bursts", 8),
+               ("vbrold5_st_32k_q5", 6), ("cbr32_js_16k_bursts_lsf", 10), ("vbr4_js_22k_lsf", 8),
+               ("mono_cbr48_22k_lsf", 6), ("vbrold2_js_24k_lsf", 6)]
+
+
+@pytest.mark.parametrize("name,nframes", SPLIT_CASES)
+def test_split_pipeline_source_matches_oracle(name, nframes, emu, oracle):
+    """Analysis kernels + sub-band kernel + the -DLH_SPLIT encode kernel == oracle, frame for frame; in two launches
+    (the second picks the stream up from LhStreamState alone), the second one ending on an odd frame count."""
+    g, pcm = helpers.load_golden(name)
+    enc = lamehip.Encoder(require_device=False, **helpers.golden_encoder_kwargs(g))
+    cfg, tab = enc.config(), enc.tables()
+    want = oracle.encode_frames(cfg, tab, pcm, max_frames=nframes)
+    n = pcm.shape[1]
+    pool = np.concatenate([pcm[0], pcm[1]]).astype(np.int16)
+    state = C.create_string_buffer(enc.lib.lamehip_abi_sizeof(4))
+    enc.lib.lh_state_init(state, C.byref(cfg))
+    got = (LhFrameOut * nframes)()
+    cut = 3
+    for a, b in ((0, cut), (cut, nframes)):
+        desc = LhStreamDesc(0, n, 0, n, a, a, b)
+        split_encode(emu, cfg, tab, pool, C.byref(desc), state, got, 1, b - a, nframes)
+    for f in range(nframes):
+        d = struct_diff(want[f], got[f])
+        assert not d, (f, d[:4])
+    enc.close()
+
+
+def test_split_and_fused_kernels_take_turns_on_one_stream(emu, oracle):
+    """Either kernel leaves LhStreamState as the other expects it: fused, split, fused over consecutive frame ranges."""
+    g, pcm = helpers.load_golden("cbr320_js_48k_bursts")
+    enc = lamehip.Encoder(require_device=False, **helpers.golden_encoder_kwargs(g))
+    cfg, tab = enc.config(), enc.tables()
+    nframes = 9
+    want = oracle.encode_frames(cfg, tab, pcm, max_frames=nframes)
+    n = pcm.shape[1]
+    pool = np.concatenate([pcm[0], pcm[1]]).astype(np.int16)
+    state = C.create_string_buffer(enc.lib.lamehip_abi_sizeof(4))
+    enc.lib.lh_state_init(state, C.byref(cfg))
+    got = (LhFrameOut * nframes)()
+    for k, (a, b) in enumerate(((0, 3), (3, 6), (6, 9))):
+        desc = LhStreamDesc(0, n, 0, n, a, a, b)
+        if k == 1:
+            split_encode(emu, cfg, tab, pool, C.byref(desc), state, got, 1, b - a, nframes)
+        else:
+            emu.lh_emu_encode(C.byref(cfg), C.byref(tab), pool.ctypes.data_as(C.c_void_p), C.byref(desc), state, got, 1)
+    for f in range(nframes):
+        d = struct_diff(want[f], got[f])
+        assert not d, (f, d[:4])
+    enc.close()
+
+
 @pytest.mark.parametrize("name,nframes", [("testcase_wav_cbr128", 6), ("cbr320_js_48k_bursts", 6)])
 def test_kernel_source_frame_per_launch_with_poisoned_lds(name, nframes, emu, oracle):
     """One launch per frame, as lame_encode_buffer drives the device, with the LDS image
