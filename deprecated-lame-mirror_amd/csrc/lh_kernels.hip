@@ -142,6 +142,27 @@ lh_load_qtabs(const LhCtx & c, LhQTabs & q)
     }
 }
 
+/* what the iteration loops look up on their dependent chains, into LDS: the quantiser tables (behind xr, where the fused
+ * kernel's PCM window lies earlier in a frame) and, over the second quantised image, the step tables of the VBR
+ * scalefactor search or calc_noise's log table.  Whole workgroup; the caller's barrier follows.  The fused kernel does
+ * this once per frame (its psy model and its window use the same LDS), the split pipeline's encode kernel once per launch. */
+LH_DEVFN void
+lh_stage_loop_tables(const LhCtx & c)
+{
+    const LhTables *T = c.T;
+    lh_load_qtabs(c, lh_lds.qt);
+    if (c.cfg->vbr == 1 || c.cfg->vbr == 4) {
+        for (int i = c.tid; i < 256; i += LH_NT) {
+            LH_VBR_IPOW20[i] = T->ipow20[i];
+            LH_VBR_POW20[i] = T->pow20[i + LH_QMAX2];
+        }
+    }
+    else {
+        for (int i = c.tid; i < 513; i += LH_NT)
+            LH_LOGT_LDS_W(i) = T->log_table[i];
+    }
+}
+
 /* write one granule of one channel to the payload; one wave */
 LH_DEVFN void
 lh_store_granule(const LhCtx & c, const LhChanLds & Q, const LhQR & R, const LhGrR & g,
@@ -434,20 +455,10 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
     LH_SYNC_WG();
 #endif
     LH_PA(2, t_mdct);
-    lh_load_qtabs(c, L.qt);     /* mf is dead; xr stays */
-    if (cfg->vbr == 1 || cfg->vbr == 4) {
-        /* step tables of the VBR scalefactor search (over the unused second quantised image) */
-        for (int i = tid; i < 256; i += LH_NT) {
-            LH_VBR_IPOW20[i] = T->ipow20[i];
-            LH_VBR_POW20[i] = T->pow20[i + LH_QMAX2];
-        }
-    }
-    else {
-        /* the other loops: calc_noise's log table (in the same place) */
-        for (int i = tid; i < 513; i += LH_NT)
-            LH_LOGT_LDS_W(i) = T->log_table[i];
-    }
+#ifndef LH_SPLIT                /* (split pipeline: staged once per launch, nothing overwrites them between frames) */
+    lh_stage_loop_tables(c);    /* mf is dead; xr stays */
     LH_SYNC_WG();
+#endif
 
     /* ---- stage 3: M/S decision (reference encoder.c:413-461) ---- */
     int     mode_ext = LH_MPG_MD_LR_LR;
@@ -892,6 +903,9 @@ lh_encode_stream(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, 
         ((uint32_t *) &L.ss)[c.tid] = ((const uint32_t *) &st->loudness_sq_save[0])[c.tid];
     else if (c.tid < LH_SS_WORDS_A + LH_SS_WORDS_B)
         ((uint32_t *) &L.ss)[c.tid] = ((const uint32_t *) &st->pefirbuf[0])[c.tid - LH_SS_WORDS_A];
+#ifdef LH_SPLIT
+    lh_stage_loop_tables(c);
+#endif
     LH_SYNC_WG();               /* the state words are read by every thread from here on */
     int     slot = 0;           /* ring slot holding the ratios of the frame's first granule */
     constexpr int ngr = LH_NGR, fs = 576 * LH_NGR;      /* granules / samples per frame (1 / 576: MPEG-2, 2.5) */
