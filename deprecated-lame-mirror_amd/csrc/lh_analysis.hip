@@ -47,81 +47,6 @@ lh_smp(const LhCtx & c, int ch, int i)
 
 #include "lh_dev_psy_core.h"
 
-/* N samples of both channels from stream sample `base' on, scaled as lh_stage_window scales the frame window (same three
- * sources: s16 pool, float pool of the handle / resampling paths, two channels mixed down), zero outside the stream;
- * NT threads */
-template < int N, int NT > LH_DEVFN void
-lh_stage_span(const LhCtx & c, float *d0, float *d1, long long base)
-{
-    float const scale = c.cfg->pcm_scale;
-    long long const last = c.d.nsamples - 1;
-    float const mix = c.cfg->pcm_mix;
-    float const scale_r = c.cfg->pcm_scale_r;
-    if (c.pcmf) {
-        for (int t = c.tid; t < 2 * N; t += NT) {
-            int const ch = t >= N, i = t - ch * N;
-            long long const p = base + i;
-            float   v = 0.0f;
-            if (p >= 0 && p <= last && p >= c.d.pcm_base)
-                v = c.pcmf[(ch == 0 ? c.d.pcm_l : c.d.pcm_r) + (p - c.d.pcm_base)];
-            (ch ? d1 : d0)[i] = v;
-        }
-        return;
-    }
-    if (mix != 0.0f) {
-        for (int i = c.tid; i < N; i += NT) {
-            long long const p = base + i;
-            float   v = 0.0f;
-            if (p >= 0 && p <= last && p >= c.d.pcm_base) {
-                float const xl = (float) c.pcm[c.d.pcm_l + (p - c.d.pcm_base)];
-                float const xr = (float) c.pcm[c.d.pcm_r + (p - c.d.pcm_base)];
-                v = xl * scale + xr * mix;
-            }
-            d0[i] = v;
-            d1[i] = 0.0f;
-        }
-        return;
-    }
-    {
-        /* the usual span: inside the stream and the pool, both planes on an even element -- two samples per load */
-        long long const lo = base, hi = base + N - 1;
-        long long const ol = c.d.pcm_l + (base - c.d.pcm_base), orr = c.d.pcm_r + (base - c.d.pcm_base);
-        int const inside = lo >= 0 && lo >= c.d.pcm_base && hi <= last && ((ol | orr) & 1) == 0;
-        static_assert((N / 2) % NT == 0, "pairs per thread");
-        constexpr int U = N / 2 / NT;
-        if (lh_uni_i(inside)) {
-            const uint32_t *pl = (const uint32_t *) (c.pcm + ol), *pr = (const uint32_t *) (c.pcm + orr);
-            uint32_t v[2 * U];
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                v[u] = pl[c.tid + NT * u];
-                v[U + u] = pr[c.tid + NT * u];
-            }
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                int const j = c.tid + NT * u;
-                lh_f32x2 a, b;
-                a.x = (float) (int16_t) (v[u] & 0xffffu) * scale;
-                a.y = (float) (int16_t) (v[u] >> 16) * scale;
-                b.x = (float) (int16_t) (v[U + u] & 0xffffu) * scale_r;
-                b.y = (float) (int16_t) (v[U + u] >> 16) * scale_r;
-                ((lh_f32x2 *) d0)[j] = a;
-                ((lh_f32x2 *) d1)[j] = b;
-            }
-            return;
-        }
-    }
-    for (int t = c.tid; t < 2 * N; t += NT) {
-        int const ch = t >= N, i = t - ch * N;
-        long long const p0 = base + i;
-        long long p = p0 < 0 ? 0 : (p0 > last ? last : p0);
-        int16_t v;
-        p = p < c.d.pcm_base ? c.d.pcm_base : p;        /* never before the pool (also nsamples == 0) */
-        v = (c.d.nsamples > 0) ? c.pcm[(ch == 0 ? c.d.pcm_l : c.d.pcm_r) + (p - c.d.pcm_base)] : (int16_t) 0;
-        (ch ? d1 : d0)[i] = (p0 < 0 || p0 > last) ? 0.0f : (float) v * (ch == 0 ? scale : scale_r);
-    }
-}
-
 /* which granule of which frame a workgroup of the (granule, stream) grid works on */
 struct LhGranuleAt {
     int     live;
@@ -173,7 +98,7 @@ extern "C" __global__ void __launch_bounds__(64)
 #else
 void
 #endif
-lh_attack_kernel(const LhConfig * cfg, const int16_t * pcm, const float *pcmf, const LhStreamDesc * descs, LhMidSmall * small,
+lh_attack_kernel(const LhConfig * cfg, const int16_t * pcm, const float *pcmf, const LhStreamDesc * descs, LhMidFrame * frames,
                  int nstreams)
 {
     /* [2][LH_FIR_SPAN] samples, then (in place) [2][576] filtered ones: 5 KB of its own, not the analysis kernel's image --
@@ -197,7 +122,7 @@ lh_attack_kernel(const LhConfig * cfg, const int16_t * pcm, const float *pcmf, c
     int const n_chn_psy = (cfg->mode == LH_MODE_JOINT_STEREO) ? 4 : cfg->channels;
     int const bufbase = 576 + ga.gr * 576 - LH_FFTOFFSET;
     int const firbase = bufbase + 576 - 350 - LH_NSFIRLEN + 192;
-    LhMidGr *mg = &small[ga.at].gr[ga.gr];
+    LhMidGr *mg = &frames[ga.at].small.gr[ga.gr];
     lh_stage_span < LH_FIR_SPAN, 64 > (c, span, span + LH_FIR_SPAN, ga.frame_base + firbase);
     LH_WAVE_SYNC();
     {
@@ -251,14 +176,18 @@ lh_attack_kernel(const LhConfig * cfg, const int16_t * pcm, const float *pcmf, c
     }
 }
 
-/* ---- attack detection, part 2: the verdicts (reference psymodel.c:806-933, 1265-1319); one wave per stream ---- */
+/* ---- attack detection, part 2: the verdicts (reference psymodel.c:806-933, 1265-1319); one wave per stream ----
+ * The only part of the analysis that is a recurrence over a stream's granules (last_attacks, blocktype_old), and it is short:
+ * the four pseudo-channels sit side by side in the wave -- lane 16 chn + i (i < 12) owns sub-block i of channel chn, every
+ * lane of a group of 16 forms its channel's verdicts (the same in all of them) --, and the next granule's peaks are on their
+ * way while this one's verdicts are formed. */
 #ifndef LH_EMU
 extern "C" __global__ void __launch_bounds__(64)
 #else
 void
 #endif
 lh_attack_scan_kernel(const LhConfig * cfg, const LhTables * T, const LhStreamDesc * descs, const LhStreamState * states,
-                      LhMidSmall * small, int nstreams)
+                      LhMidFrame * frames, int nstreams)
 {
     int const sidx = (int) blockIdx.x;
     int const lane = (int) threadIdx.x;
@@ -269,123 +198,115 @@ lh_attack_scan_kernel(const LhConfig * cfg, const LhTables * T, const LhStreamDe
     const LhStreamState *st = &states[sidx];
     int const n_chn_psy = lh_uni_i((cfg->mode == LH_MODE_JOINT_STEREO) ? 4 : cfg->channels);
     int const channels = lh_uni_i(cfg->channels), short_blocks = lh_uni_i(cfg->short_blocks);
-    /* what the previous launch left: lane k < 9 holds last_en_subshort[chn][k]; the scalars in every lane */
-    float   le[4];
-    int     last_att[4], bt_old[2];
-    float   thresh[4];
-    for (int chn = 0; chn < 4; chn++) {
-        le[chn] = st->last_en_subshort[chn][lane < 9 ? lane : 0];
-        last_att[chn] = lh_uni_i(st->last_attacks[chn]);
-        thresh[chn] = lh_uni_f(T->attack_threshold[chn]);
-    }
-    bt_old[0] = lh_uni_i(st->blocktype_old[0]);
-    bt_old[1] = lh_uni_i(st->blocktype_old[1]);
-    /* the peaks of the next granule are requested while this one's verdicts are formed */
-    float   pk_next[4];
-    {
-        const LhMidGr *m0 = &small[d.out_index].gr[0];
-        for (int chn = 0; chn < 4; chn++)
-            pk_next[chn] = m0->peak[chn][lane < 9 ? lane : 0];
-    }
+    int const chn = lane >> 4, i = lane & 15, grp = lane & 48;
+    int const mine = chn < n_chn_psy;
+    /* what the previous launch left: lane 16 chn + k (k < 9) holds last_en_subshort[chn][k]; the scalars in every lane of
+     * their channel's group */
+    float   le = st->last_en_subshort[chn][i < 9 ? i : 0];
+    int     last_att = st->last_attacks[chn];
+    float const thresh = T->attack_threshold[chn];
+    int     bt_old0 = lh_uni_i(st->blocktype_old[0]), bt_old1 = lh_uni_i(st->blocktype_old[1]);
+    float   pk_next = frames[d.out_index].small.gr[0].peak[chn][i < 9 ? i : 0];
     for (int g = 0; g < LH_NGR * nf; g++) {
         int const fr = g / LH_NGR, gr = g - fr * LH_NGR;
-        LhMidGr *mg = &small[d.out_index + fr].gr[gr];
-        float   pk[4];
-        int     ns_uselong[4] = { 1, 1, 1, 1 };
-        for (int chn = 0; chn < 4; chn++)
-            pk[chn] = pk_next[chn];
+        LhMidGr *mg = &frames[d.out_index + fr].small.gr[gr];
+        float const pk = pk_next;
         if (g + 1 < LH_NGR * nf) {
             int const f2 = (g + 1) / LH_NGR, g2 = (g + 1) - f2 * LH_NGR;
-            const LhMidGr *m2 = &small[d.out_index + f2].gr[g2];
-            for (int chn = 0; chn < 4; chn++)
-                pk_next[chn] = m2->peak[chn][lane < 9 ? lane : 0];
+            pk_next = frames[d.out_index + f2].small.gr[g2].peak[chn][i < 9 ? i : 0];
         }
-        for (int chn = 0; chn < 4; chn++) {
-            int     nsa[4] = { 0, 0, 0, 0 };
-            float   ssf = 1.0f;
-            if (chn < n_chn_psy) {
-                /* twelve sub-blocks: three from the previous granule, nine new ones; lane i (< 12) owns sub-block i */
-                float const fresh = pk[chn] < 1.0f ? 1.0f : pk[chn];          /* lane k < 9: the new sub-block k */
-                float const old = lh_shfl_f32(le[chn], (lane + 6) & 63), older = lh_shfl_f32(le[chn], (lane + 4) & 63);
-                float const mine = lh_shfl_f32(fresh, (lane - 3) & 63);
-                float const e = (lane < 3) ? old : mine;
-                float const two_back = lh_shfl_f32(e, (lane - 2) & 63);
-                float const then = (lane < 3) ? older : two_back;
-                float const ai = (lane < 3) ? e / then : (e > then) ? e / then : (then > e * 10.0f) ? then / (e * 10.0f) : 0.0f;
-                float const e1 = lh_shfl_f32(e, (lane - 1) & 63), e0 = lh_shfl_f32(e, (lane - 2) & 63);
-                float const whole = e0 + e1 + e;
-                int const tail_low = e * 6 < whole, mid_low = e1 * 6 < whole;
-                uint64_t const over = lh_ballot(lane < 12 && ai > thresh[chn]);
-                float   en_short[4];
-                en_short[0] = lh_u32_as_f32(lh_bcast_u32(lh_f32_as_u32(whole), 2));
-                en_short[1] = lh_u32_as_f32(lh_bcast_u32(lh_f32_as_u32(whole), 5));
-                en_short[2] = lh_u32_as_f32(lh_bcast_u32(lh_f32_as_u32(whole), 8));
-                en_short[3] = lh_u32_as_f32(lh_bcast_u32(lh_f32_as_u32(whole), 11));
-                ssf = tail_low ? (mid_low ? 0.25f : 0.5f) : 1.0f;   /* lanes 5, 8, 11: sub_short_factor[0..2] */
-                le[chn] = fresh;
-                for (int gq = 0; gq < 4; gq++) {
-                    unsigned const bits = (unsigned) (over >> (3 * gq)) & 7u;
-                    nsa[gq] = bits ? ((bits & 1u) ? 1 : (bits & 2u) ? 2 : 3) : 0;
+        /* twelve sub-blocks per channel: three from the previous granule, nine new ones */
+        float const fresh = pk < 1.0f ? 1.0f : pk;      /* lane k < 9 of the group: the new sub-block k */
+        float const old = lh_shfl_f32(le, grp + ((i + 6) & 15)), older = lh_shfl_f32(le, grp + ((i + 4) & 15));
+        float const got = lh_shfl_f32(fresh, grp + ((i - 3) & 15));
+        float const e = (i < 3) ? old : got;
+        float const e1 = lh_shfl_f32(e, grp + ((i - 1) & 15)), e0 = lh_shfl_f32(e, grp + ((i - 2) & 15));
+        float const then = (i < 3) ? older : e0;
+        float const ai = (i < 3) ? e / then : (e > then) ? e / then : (then > e * 10.0f) ? then / (e * 10.0f) : 0.0f;
+        float const whole = e0 + e1 + e;
+        int const tail_low = e * 6 < whole, mid_low = e1 * 6 < whole;
+        uint64_t const over_all = lh_ballot(i < 12 && ai > thresh);
+        unsigned const over = (unsigned) (over_all >> (16 * chn)) & 0xfffu;    /* this channel's twelve bits */
+        float   en_short[4];
+        en_short[0] = lh_shfl_f32(whole, grp + 2);
+        en_short[1] = lh_shfl_f32(whole, grp + 5);
+        en_short[2] = lh_shfl_f32(whole, grp + 8);
+        en_short[3] = lh_shfl_f32(whole, grp + 11);
+        float const ssf = tail_low ? (mid_low ? 0.25f : 0.5f) : 1.0f;   /* lanes 5, 8, 11 of a group: sub_short_factor[0..2] */
+        int     nsa[4];
+        int     uselong = 1;
+        le = fresh;
+        for (int gq = 0; gq < 4; gq++) {
+            /* the first sub-block of the short block whose ratio exceeds the threshold, 1-based */
+            unsigned const bits = (over >> (3 * gq)) & 7u;
+            nsa[gq] = bits ? ((bits & 1u) ? 1 : (bits & 2u) ? 2 : 3) : 0;
+        }
+        for (int q = 1; q < 4; q++) {
+            float const u = en_short[q - 1];
+            float const v = en_short[q];
+            float const m = (u > v) ? u : v;
+            if (m < 40000) {
+                if (u < 1.7f * v && v < 1.7f * u) {
+                    if (q == 1 && nsa[0] <= nsa[q])
+                        nsa[0] = 0;
+                    nsa[q] = 0;
                 }
-                for (int i = 1; i < 4; i++) {
-                    float const u = en_short[i - 1];
-                    float const v = en_short[i];
-                    float const m = (u > v) ? u : v;
-                    if (m < 40000) {
-                        if (u < 1.7f * v && v < 1.7f * u) {
-                            if (i == 1 && nsa[0] <= nsa[i])
-                                nsa[0] = 0;
-                            nsa[i] = 0;
-                        }
-                    }
-                }
-                if (nsa[0] <= last_att[chn])
-                    nsa[0] = 0;
-                if (last_att[chn] == 3 || nsa[0] + nsa[1] + nsa[2] + nsa[3]) {
-                    ns_uselong[chn] = 0;
-                    if (nsa[1] && nsa[0])
-                        nsa[1] = 0;
-                    if (nsa[2] && nsa[1])
-                        nsa[2] = 0;
-                    if (nsa[3] && nsa[2])
-                        nsa[3] = 0;
-                }
-                last_att[chn] = lh_uni_i(nsa[2]);
             }
-            if (lane == 5 || lane == 8 || lane == 11)
-                mg->sub_short_factor[chn][(lane - 5) / 3] = ssf;
-            if (lane < 4)
-                mg->ns_attacks[chn][lane] = (int8_t) (lane == 0 ? nsa[0] : lane == 1 ? nsa[1] : lane == 2 ? nsa[2] : nsa[3]);
         }
+        if (nsa[0] <= last_att)
+            nsa[0] = 0;
+        if (last_att == 3 || nsa[0] + nsa[1] + nsa[2] + nsa[3]) {
+            uselong = 0;
+            if (nsa[1] && nsa[0])
+                nsa[1] = 0;
+            if (nsa[2] && nsa[1])
+                nsa[2] = 0;
+            if (nsa[3] && nsa[2])
+                nsa[3] = 0;
+        }
+        if (!mine) {
+            nsa[0] = nsa[1] = nsa[2] = nsa[3] = 0;
+            uselong = 1;
+        }
+        else
+            last_att = nsa[2];
+        if (i == 5 || i == 8 || i == 11)
+            mg->sub_short_factor[chn][(i - 5) / 3] = mine ? ssf : 1.0f;
+        if (i < 4)
+            mg->ns_attacks[chn][i] = (int8_t) (i == 0 ? nsa[0] : i == 1 ? nsa[1] : i == 2 ? nsa[2] : nsa[3]);
         {
-            /* uselongblock[] (reference psymodel.c:926-933, 1265-1286) and the block types (:1289-1319) */
-            int     ul0 = ns_uselong[0], ul1 = (channels == 2) ? ns_uselong[1] : 1;
+            /* uselongblock[] (reference psymodel.c:926-933, 1265-1286) and the block types (:1289-1319): wave-uniform */
+            uint64_t const shorts = lh_ballot(!uselong);
+            int const s0 = (int) (shorts & 1u), s1 = (int) ((shorts >> 16) & 1u), s23 = (int) ((shorts >> 32) & 0x10001u) != 0;
+            int     ul0 = !s0, ul1 = (channels == 2) ? !s1 : 1;
             int     btd[2];
-            for (int chn = 2; chn < n_chn_psy; chn++)
-                if (ns_uselong[chn] == 0)
-                    ul0 = ul1 = 0;
+            if (s23)
+                ul0 = ul1 = 0;
             if (short_blocks == 1 && !(ul0 && ul1))
                 ul0 = ul1 = 0;
             if (short_blocks == 2)
                 ul0 = ul1 = 1;
             if (short_blocks == 3)
                 ul0 = ul1 = 0;
-            for (int chn = 0; chn < 2; chn++) {
+            for (int ch = 0; ch < 2; ch++) {
                 int     blocktype = LH_NORM_TYPE;
-                int     old = bt_old[chn];
-                if (chn ? ul1 : ul0) {
-                    if (old == LH_SHORT_TYPE)
+                int     was = ch ? bt_old1 : bt_old0;
+                if (ch ? ul1 : ul0) {
+                    if (was == LH_SHORT_TYPE)
                         blocktype = LH_STOP_TYPE;
                 }
                 else {
                     blocktype = LH_SHORT_TYPE;
-                    if (old == LH_NORM_TYPE)
-                        old = LH_START_TYPE;
-                    if (old == LH_STOP_TYPE)
-                        old = LH_SHORT_TYPE;
+                    if (was == LH_NORM_TYPE)
+                        was = LH_START_TYPE;
+                    if (was == LH_STOP_TYPE)
+                        was = LH_SHORT_TYPE;
                 }
-                btd[chn] = old;
-                bt_old[chn] = lh_uni_i(blocktype);
+                btd[ch] = was;
+                if (ch)
+                    bt_old1 = lh_uni_i(blocktype);
+                else
+                    bt_old0 = lh_uni_i(blocktype);
             }
             if (lane < 2) {
                 mg->uselong[lane] = (int8_t) (lane ? ul1 : ul0);
@@ -402,7 +323,7 @@ extern "C" __global__ void __launch_bounds__(LH_NT, 4)
 void
 #endif
 lh_analysis_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, const float *pcmf, const LhStreamDesc * descs,
-                   LhMidSmall * small, LhMidLong * lng, LhMidShort * shrt, int nstreams)
+                   LhMidFrame * frames, int nstreams)
 {
     LhLds & L = lh_lds;
     LhPsyLds & P = L.u.psy;
@@ -423,7 +344,7 @@ lh_analysis_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm
     int const lane = c.lane, w = c.wave, gr = ga.gr;
     int const n_chn_psy = (cfg->mode == LH_MODE_JOINT_STEREO) ? 4 : cfg->channels;
     int const bufbase = 576 + gr * 576 - LH_FFTOFFSET;
-    LhMidGr *mg = &small[ga.at].gr[gr];
+    LhMidGr *mg = &frames[ga.at].small.gr[gr];
     if (c.tid < 2)
         L.uselong[c.tid] = mg->uselong[c.tid];
     lh_stage_span < LH_BLKSIZE, LH_NT > (c, LH_SPAN, LH_SPAN + LH_BLKSIZE, ga.frame_base + bufbase);
@@ -507,9 +428,11 @@ lh_analysis_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm
         }
         LH_WAVE_SYNC_MEM();
     }
+    /* (the products a wave's loudness lane adds up lie in the partition arrays the OTHER wave's masking is about to write) */
+    LH_SYNC_WG_LDS();
     /* masking, long blocks, up to the recurrences: the wave's one or two pseudo-channels together */
     {
-        LhMidLong *ml = &lng[ga.at];
+        LhMidLong *ml = &frames[ga.at].lng;
         if (n_chn_psy == 4) {
             LhMaskChan const two[2] = {
                 {w, P.b.energy[w], &P.eb[w * 64], &P.thr[w * 64], nullptr, nullptr, &ml->m[gr][w]},
@@ -534,7 +457,7 @@ lh_analysis_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm
     LH_SYNC_WG_LDS();
     for (int sblock = 0; sblock < 3; sblock++) {
         if (w < n_chn_psy && !L.uselong[w]) {
-            LhMidShort *ms = &shrt[ga.at];
+            LhMidShort *ms = &frames[ga.at].shrt;
             int const both = (n_chn_psy == 4);
             if (both)
                 lh_fft_energy_pair(c, w, &P.wsamp[0][sblock * LH_BLKSIZE_S], &P.wsamp[1][sblock * LH_BLKSIZE_S],
@@ -568,11 +491,10 @@ lh_launch_analysis(const LhConfig * cfg, const LhTables * T, const int16_t * pcm
     if (nstreams <= 0 || max_frames <= 0)
         return 0;
     dim3 const grid((unsigned) (LH_NGR * max_frames), (unsigned) nstreams);
-    hipLaunchKernelGGL(lh_attack_kernel, grid, dim3(64), 0, (hipStream_t) stream, cfg, pcm, pcmf, descs, mid.small, nstreams);
+    hipLaunchKernelGGL(lh_attack_kernel, grid, dim3(64), 0, (hipStream_t) stream, cfg, pcm, pcmf, descs, mid.frames, nstreams);
     hipLaunchKernelGGL(lh_attack_scan_kernel, dim3((unsigned) nstreams), dim3(64), 0, (hipStream_t) stream, cfg, T, descs, states,
-                       mid.small, nstreams);
-    hipLaunchKernelGGL(lh_analysis_kernel, grid, dim3(LH_NT), 0, (hipStream_t) stream, cfg, T, pcm, pcmf, descs, mid.small, mid.lng,
-                       mid.shrt, nstreams);
+                       mid.frames, nstreams);
+    hipLaunchKernelGGL(lh_analysis_kernel, grid, dim3(LH_NT), 0, (hipStream_t) stream, cfg, T, pcm, pcmf, descs, mid.frames, nstreams);
     return (int) hipGetLastError();
 }
 #else
@@ -584,15 +506,15 @@ lh_emu_analysis(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, c
     hipemu_dim3 grid = { (unsigned) (LH_NGR * max_frames), (unsigned) nstreams, 1 }, b64 = { 64, 1, 1 }, b128 = { LH_NT, 1, 1 };
     hipemu_dim3 grid1 = { (unsigned) nstreams, 1, 1 };
     hipemu_run(grid, b64,[=] () {
-               lh_attack_kernel(cfg, pcm, pcmf, descs, mid.small, nstreams);
+               lh_attack_kernel(cfg, pcm, pcmf, descs, mid.frames, nstreams);
                }
     );
     hipemu_run(grid1, b64,[=] () {
-               lh_attack_scan_kernel(cfg, T, descs, states, mid.small, nstreams);
+               lh_attack_scan_kernel(cfg, T, descs, states, mid.frames, nstreams);
                }
     );
     hipemu_run(grid, b128,[=] () {
-               lh_analysis_kernel(cfg, T, pcm, pcmf, descs, mid.small, mid.lng, mid.shrt, nstreams);
+               lh_analysis_kernel(cfg, T, pcm, pcmf, descs, mid.frames, nstreams);
                }
     );
     return 0;

@@ -1606,40 +1606,16 @@ batch_mid_reserve(lamehip_batch * b, long long total)
     if (total <= b->mid_cap)
         return 0;
     size_t  free_b = 0, total_b = 0;
-    size_t const per_frame = sizeof(LhMidSmall) + sizeof(LhMidLong) + sizeof(LhMidShort) + sizeof(LhMidXr);
     long long const want = total + 64;
-    if (b->mid.small)
-        (void) hipFree(b->mid.small);
-    if (b->mid.lng)
-        (void) hipFree(b->mid.lng);
-    if (b->mid.shrt)
-        (void) hipFree(b->mid.shrt);
-    if (b->mid.xr)
-        (void) hipFree(b->mid.xr);
-    b->mid.small = nullptr;
-    b->mid.lng = nullptr;
-    b->mid.shrt = nullptr;
-    b->mid.xr = nullptr;
+    if (b->mid.frames)
+        (void) hipFree(b->mid.frames);
+    b->mid.frames = nullptr;
     b->mid_cap = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (double) want * (double) per_frame > 0.8 * (double) free_b)
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (double) want * (double) sizeof(LhMidFrame) > 0.8 * (double) free_b)
         return -1;
-    if (hipMalloc((void **) &b->mid.small, (size_t) want * sizeof(LhMidSmall)) != hipSuccess
-        || hipMalloc((void **) &b->mid.lng, (size_t) want * sizeof(LhMidLong)) != hipSuccess
-        || hipMalloc((void **) &b->mid.shrt, (size_t) want * sizeof(LhMidShort)) != hipSuccess
-        || hipMalloc((void **) &b->mid.xr, (size_t) want * sizeof(LhMidXr)) != hipSuccess) {
+    if (hipMalloc((void **) &b->mid.frames, (size_t) want * sizeof(LhMidFrame)) != hipSuccess) {
         (void) hipGetLastError();
-        if (b->mid.small)
-            (void) hipFree(b->mid.small);
-        if (b->mid.lng)
-            (void) hipFree(b->mid.lng);
-        if (b->mid.shrt)
-            (void) hipFree(b->mid.shrt);
-        if (b->mid.xr)
-            (void) hipFree(b->mid.xr);
-        b->mid.small = nullptr;
-        b->mid.lng = nullptr;
-        b->mid.shrt = nullptr;
-        b->mid.xr = nullptr;
+        b->mid.frames = nullptr;
         return -1;
     }
     b->mid_cap = want;
@@ -1790,10 +1766,7 @@ lamehip_batch_create_on(int device, const lame_t proto, int nstreams, long capac
     b->up_pending = b->down_pending = 0;
     b->up_inflight = 0;
     b->launched = 0;
-    b->mid.small = nullptr;
-    b->mid.lng = nullptr;
-    b->mid.shrt = nullptr;
-    b->mid.xr = nullptr;
+    b->mid.frames = nullptr;
     b->mid_cap = 0;
     b->split = batch_use_split();
     b->ev_part[0] = b->ev_part[1] = nullptr;
@@ -1846,14 +1819,8 @@ lamehip_batch_destroy(lamehip_batch * b)
         (void) hipFree(b->d_bytes);
     if (b->d_pcmf)
         (void) hipFree(b->d_pcmf);
-    if (b->mid.small)
-        (void) hipFree(b->mid.small);
-    if (b->mid.lng)
-        (void) hipFree(b->mid.lng);
-    if (b->mid.shrt)
-        (void) hipFree(b->mid.shrt);
-    if (b->mid.xr)
-        (void) hipFree(b->mid.xr);
+    if (b->mid.frames)
+        (void) hipFree(b->mid.frames);
     if (b->ev_part[0])
         (void) hipEventDestroy(b->ev_part[0]);
     if (b->ev_part[1])

@@ -127,21 +127,36 @@ lh_wave_scan_max_u32(uint32_t v)
 
 /* ---- LDS layout ---------------------------------------------------- */
 struct LhPsyLds {
-    float   wsamp[2][LH_BLKSIZE];       /* FHT work buffers of L and R (3x256 for short blocks) */
     union {
         struct {
-            float   hpf[2][576];        /* high-passed samples for attack detection */
-        } a;
-        struct {
-            float   energy[4][LH_HBLKSIZE + 3];   /* power spectra of L,R,M,S */
-        } b;
+            float   wsamp[2][LH_BLKSIZE];       /* FHT work buffers of L and R (3x256 for short blocks) */
+            union {
+                struct {
+                    float   hpf[2][576];        /* high-passed samples for attack detection */
+                } a;
+                struct {
+                    float   energy[4][LH_HBLKSIZE + 3];   /* power spectra of L,R,M,S */
+                } b;
+            };
+        };
+        struct {                        /* split pipeline's encode kernel: the frame's small record and long-block masking, */
+            float   keep[1728];         /* brought in from HBM in one batch at the top of the frame (lh_encode_frame); behind */
+            LhMidSmall small;           /* channel 0's second quantised image, where the loop tables stay for the whole launch */
+            LhMidLong lng;
+        } mid;
     };
     float   eb[4 * 64];
     float   thr[4 * 64];        /* lh_compute_masking parks a channel's tonality indices here until its thresholds are known */
 };
 
+/* words between the time slots of the sub-band samples: 32 in the encode kernel; lh_subband.hip pads to 33, which spreads
+ * the slots -- one per lane in the butterfly network -- over the LDS banks */
+#ifndef LH_SB_STRIDE
+#define LH_SB_STRIDE 32
+#endif
+#define LH_SB_GRANULE (18 * LH_SB_STRIDE)
 struct LhMdctLds {
-    float   sb[2][3][576];      /* [ch][0 = previous granule, 1 = gr0, 2 = gr1][slot*32 + band] */
+    float   sb[2][3][LH_SB_GRANULE];    /* [ch][0 = previous granule, 1 = gr0, 2 = gr1][slot * LH_SB_STRIDE + band] */
 };
 
 /* wave-uniform scalar image of gr_info (reference l3side.h:47-84): every lane holds
@@ -331,6 +346,10 @@ struct LhQuantLds {
 static_assert(__builtin_offsetof(LhTables, pow43) % 128 == 0 && __builtin_offsetof(LhTables, vqthr) % 128 == 0,
               "the gathered tables start on cache lines (hipMalloc aligns the struct itself)");
 static_assert(sizeof(LhChanLds) % 16 == 0, "both channels' float2/float4 accesses need 16-byte alignment");
+static_assert(__builtin_offsetof(LhPsyLds, mid.small) >= __builtin_offsetof(LhChanLds, ix[1]) + sizeof(((LhChanLds *) 0)->ix[1])
+              && __builtin_offsetof(LhPsyLds, mid.lng) + sizeof(LhMidLong) <= sizeof(LhChanLds) + __builtin_offsetof(LhChanLds, ix[1])
+              && __builtin_offsetof(LhPsyLds, mid.small) % 16 == 0,
+              "the staged mid record lies between the two channels' second images (log table / VBR step tables)");
 
 /* VBR only: the step tables of the scalefactor search, ipow20[0..255] and pow20[116..371]
  * (= pow20[sf + Q_MAX2]), staged over the second quantised image, which that loop never uses */
@@ -360,11 +379,8 @@ struct LhCtxShared {
     LhStreamDesc d;
     long long frame_base;       /* stream sample index of mfbuf[0] for the current frame: 1152 f - 528 */
 #ifdef LH_SPLIT
-    /* the encode kernel of the split pipeline: the current frame's records of the analysis kernels' output (lh_device.h) */
-    const LhMidSmall *mid_small;
-    const LhMidLong *mid_long;
-    const LhMidShort *mid_short;
-    const LhMidXr *mid_xr;
+    /* the encode kernel of the split pipeline: the current frame's record of the analysis kernels' output (lh_device.h) */
+    const LhMidFrame *mid;
 #endif
 };
 
@@ -669,6 +685,89 @@ lh_stage_window(const LhCtx & c, float (*mf)[LH_MF_NEEDED], long long base)
                 mf[ch][i] = (p < 0 || p > last) ? 0.0f : (float) v[u] * (ch == 0 ? scale : scale_r);
             }
         }
+    }
+}
+
+/* N samples of both channels from stream sample `base' on, scaled as lh_stage_window scales the frame window (same three
+ * sources: s16 pool, float pool of the handle / resampling paths, two channels mixed down), zero outside the stream;
+ * NT threads (the analysis kernels: lh_analysis.hip, lh_subband.hip).  LH_STAGE_IDX(i): where sample i of the span goes
+ * (even i stay even: lh_subband.hip's bank swizzle). */
+#ifndef LH_STAGE_IDX
+#define LH_STAGE_IDX(i) (i)
+#endif
+template < int N, int NT > LH_DEVFN void
+lh_stage_span(const LhCtx & c, float *d0, float *d1, long long base)
+{
+    float const scale = c.cfg->pcm_scale;
+    long long const last = c.d.nsamples - 1;
+    float const mix = c.cfg->pcm_mix;
+    float const scale_r = c.cfg->pcm_scale_r;
+    if (c.pcmf) {
+        for (int t = c.tid; t < 2 * N; t += NT) {
+            int const ch = t >= N, i = t - ch * N;
+            long long const p = base + i;
+            float   v = 0.0f;
+            if (p >= 0 && p <= last && p >= c.d.pcm_base)
+                v = c.pcmf[(ch == 0 ? c.d.pcm_l : c.d.pcm_r) + (p - c.d.pcm_base)];
+            (ch ? d1 : d0)[LH_STAGE_IDX(i)] = v;
+        }
+        return;
+    }
+    if (mix != 0.0f) {
+        for (int i = c.tid; i < N; i += NT) {
+            long long const p = base + i;
+            float   v = 0.0f;
+            if (p >= 0 && p <= last && p >= c.d.pcm_base) {
+                float const xl = (float) c.pcm[c.d.pcm_l + (p - c.d.pcm_base)];
+                float const xr = (float) c.pcm[c.d.pcm_r + (p - c.d.pcm_base)];
+                v = xl * scale + xr * mix;
+            }
+            d0[LH_STAGE_IDX(i)] = v;
+            d1[LH_STAGE_IDX(i)] = 0.0f;
+        }
+        return;
+    }
+    {
+        /* the usual span: inside the stream and the pool, both planes on an even element -- two samples per load */
+        long long const lo = base, hi = base + N - 1;
+        long long const ol = c.d.pcm_l + (base - c.d.pcm_base), orr = c.d.pcm_r + (base - c.d.pcm_base);
+        int const inside = lo >= 0 && lo >= c.d.pcm_base && hi <= last && ((ol | orr) & 1) == 0;
+        static_assert(N % 2 == 0, "pairs");
+        constexpr int U = (N / 2 + NT - 1) / NT;
+        if (lh_uni_i(inside)) {
+            const uint32_t *pl = (const uint32_t *) (c.pcm + ol), *pr = (const uint32_t *) (c.pcm + orr);
+            uint32_t v[2 * U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                int const j = c.tid + NT * u;
+                int const jj = j < N / 2 ? j : N / 2 - 1;
+                v[u] = pl[jj];
+                v[U + u] = pr[jj];
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                int const j = c.tid + NT * u;
+                if (j < N / 2) {
+                    lh_f32x2 a, b;
+                    a.x = (float) (int16_t) (v[u] & 0xffffu) * scale;
+                    a.y = (float) (int16_t) (v[u] >> 16) * scale;
+                    b.x = (float) (int16_t) (v[U + u] & 0xffffu) * scale_r;
+                    b.y = (float) (int16_t) (v[U + u] >> 16) * scale_r;
+                    *(lh_f32x2 *) &d0[LH_STAGE_IDX(2 * j)] = a;
+                    *(lh_f32x2 *) &d1[LH_STAGE_IDX(2 * j)] = b;
+                }
+            }
+            return;
+        }
+    }
+    for (int t = c.tid; t < 2 * N; t += NT) {
+        int const ch = t >= N, i = t - ch * N;
+        long long const p0 = base + i;
+        long long p = p0 < 0 ? 0 : (p0 > last ? last : p0);
+        int16_t v;
+        p = p < c.d.pcm_base ? c.d.pcm_base : p;        /* never before the pool (also nsamples == 0) */
+        v = (c.d.nsamples > 0) ? c.pcm[(ch == 0 ? c.d.pcm_l : c.d.pcm_r) + (p - c.d.pcm_base)] : (int16_t) 0;
+        (ch ? d1 : d0)[LH_STAGE_IDX(i)] = (p0 < 0 || p0 > last) ? 0.0f : (float) v * (ch == 0 ? scale : scale_r);
     }
 }
 

@@ -49,28 +49,41 @@
  * stage 1 -- the 16 independent tap sums of a slot (15 folded window rows + the
  * centre row), one (slot, row) unit per lane-iteration, written to pre[32];
  * stage 2 -- the fixed 32-point butterfly network, one slot per lane, in place. */
+/* LH_MF_SWZ(i): where sample i of the staged window lies in mf[ch][].  The rows of a slot read 32 samples at a stride of 64,
+ * neighbouring rows neighbouring samples, neighbouring slots samples 32 apart -- the four slots of a wave's trip land on the
+ * same 15 LDS banks.  lh_subband.hip stores the window with bit 4 of the index flipped in every odd block of 32
+ * (i ^ ((i >> 1) & 16)): odd slots then use the other half of the banks, and an offset of a multiple of 64 commutes with the
+ * swizzle, so the strided reads keep their immediate offsets.  The fused kernel (whose psy model reads the same window) keeps
+ * the plain layout. */
+#ifndef LH_MF_SWZ
+#define LH_MF_SWZ(i) (i)
+#endif
 LH_DEVFN void
 lh_subband_taps(const LhCtx & c, int ch, int x, int n, float *pre)
 {
+    const float *mf = lh_lds.mf[ch];
     if (n < 15) {
         int const x1 = x - n;
         int const x2 = x - 62 + n;
         const float *wp = LH_ENW + 10 + 18 * n;
+        /* the four strided runs (bases; + / - 64 k from there) */
+        const float *a2 = mf + LH_MF_SWZ(x2 - 224), *a1 = mf + LH_MF_SWZ(x1 + 224 - 448);
+        const float *b1 = mf + LH_MF_SWZ(x1 - 256), *b2 = mf + LH_MF_SWZ(x2 + 256 - 448);
         float   w, s, t;
         w = wp[-10];
-        s = lh_smp(c, ch, x2 - 224) * w;
-        t = lh_smp(c, ch, x1 + 224) * w;
+        s = a2[0] * w;
+        t = a1[448] * w;
 #pragma unroll
         for (int k = 1; k < 8; k++) {
             w = wp[-10 + k];
-            s += lh_smp(c, ch, x2 - 224 + 64 * k) * w;
-            t += lh_smp(c, ch, x1 + 224 - 64 * k) * w;
+            s += a2[64 * k] * w;
+            t += a1[448 - 64 * k] * w;
         }
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             w = wp[-2 + k];
-            s += lh_smp(c, ch, x1 - 256 + 64 * k) * w;
-            t -= lh_smp(c, ch, x2 + 256 - 64 * k) * w;
+            s += b1[64 * k] * w;
+            t -= b2[448 - 64 * k] * w;
         }
         s *= wp[6];
         w = t - s;
@@ -81,22 +94,24 @@ lh_subband_taps(const LhCtx & c, int ch, int x, int n, float *pre)
         int const x1 = x - 15;
         const float *wp = LH_ENW + 280;
         float   s, t;
-        t = lh_smp(c, ch, x1 - 16) * wp[-10];
-        s = lh_smp(c, ch, x1 - 32) * wp[-2];
-        t += (lh_smp(c, ch, x1 - 48) - lh_smp(c, ch, x1 + 16)) * wp[-9];
-        s += lh_smp(c, ch, x1 - 96) * wp[-1];
-        t += (lh_smp(c, ch, x1 - 80) + lh_smp(c, ch, x1 + 48)) * wp[-8];
-        s += lh_smp(c, ch, x1 - 160) * wp[0];
-        t += (lh_smp(c, ch, x1 - 112) - lh_smp(c, ch, x1 + 80)) * wp[-7];
-        s += lh_smp(c, ch, x1 - 224) * wp[1];
-        t += (lh_smp(c, ch, x1 - 144) + lh_smp(c, ch, x1 + 112)) * wp[-6];
-        s -= lh_smp(c, ch, x1 + 32) * wp[2];
-        t += (lh_smp(c, ch, x1 - 176) - lh_smp(c, ch, x1 + 144)) * wp[-5];
-        s -= lh_smp(c, ch, x1 + 96) * wp[3];
-        t += (lh_smp(c, ch, x1 - 208) + lh_smp(c, ch, x1 + 176)) * wp[-4];
-        s -= lh_smp(c, ch, x1 + 160) * wp[4];
-        t += (lh_smp(c, ch, x1 - 240) - lh_smp(c, ch, x1 + 208)) * wp[-3];
-        s -= lh_smp(c, ch, x1 + 224);
+#define LH_MFS(i) mf[LH_MF_SWZ(i)]
+        t = LH_MFS(x1 - 16) * wp[-10];
+        s = LH_MFS(x1 - 32) * wp[-2];
+        t += (LH_MFS(x1 - 48) - LH_MFS(x1 + 16)) * wp[-9];
+        s += LH_MFS(x1 - 96) * wp[-1];
+        t += (LH_MFS(x1 - 80) + LH_MFS(x1 + 48)) * wp[-8];
+        s += LH_MFS(x1 - 160) * wp[0];
+        t += (LH_MFS(x1 - 112) - LH_MFS(x1 + 80)) * wp[-7];
+        s += LH_MFS(x1 - 224) * wp[1];
+        t += (LH_MFS(x1 - 144) + LH_MFS(x1 + 112)) * wp[-6];
+        s -= LH_MFS(x1 + 32) * wp[2];
+        t += (LH_MFS(x1 - 176) - LH_MFS(x1 + 144)) * wp[-5];
+        s -= LH_MFS(x1 + 96) * wp[3];
+        t += (LH_MFS(x1 - 208) + LH_MFS(x1 + 176)) * wp[-4];
+        s -= LH_MFS(x1 + 160) * wp[4];
+        t += (LH_MFS(x1 - 240) - LH_MFS(x1 + 208)) * wp[-3];
+        s -= LH_MFS(x1 + 224);
+#undef LH_MFS
         /* u = s - t and v = s + t, combined with rows 14/15 at the start of stage 2 */
         pre[30] = s - t;
         pre[31] = s + t;
@@ -106,7 +121,7 @@ lh_subband_taps(const LhCtx & c, int ch, int x, int n, float *pre)
 LH_STAGEFN void
 lh_subband_network(int ch, int g, int slot)
 {
-    float  *io = &lh_lds.u.mdct.sb[ch][g][slot * 32];
+    float  *io = &lh_lds.u.mdct.sb[ch][g][slot * LH_SB_STRIDE];
     float   a[32];
     float   xr;
 #pragma unroll
@@ -342,20 +357,20 @@ LH_STAGEFN void
 lh_polyphase(int ch)
 {
     LhCtx const c = lh_ctx_load();
-    float   (*sb)[576] = lh_lds.u.mdct.sb[ch];
+    float   (*sb)[LH_SB_GRANULE] = lh_lds.u.mdct.sb[ch];
     const float *amp = c.T->amp_filter;
     /* stage 1: 36 slots x 16 tap rows */
     for (int u = c.lane; u < 36 * 16; u += 64) {
         int const s = u >> 4, n = u & 15;
         int const gr = s / 18, slot = s - gr * 18;
-        lh_subband_taps(c, ch, 286 + 32 * s, n, &sb[1 + gr][slot * 32]);
+        lh_subband_taps(c, ch, 286 + 32 * s, n, &sb[1 + gr][slot * LH_SB_STRIDE]);
     }
     LH_WAVE_SYNC();
     /* stage 2: butterfly network per slot */
     if (c.lane < 36) {
         int const s = c.lane;
         int const gr = s / 18, slot = s - gr * 18;
-        float  *out = &sb[1 + gr][slot * 32];
+        float  *out = &sb[1 + gr][slot * LH_SB_STRIDE];
         lh_subband_network(ch, 1 + gr, slot);
         if (slot & 1) {
             /* compensate for the inversion in the analysis filter */
@@ -366,8 +381,8 @@ lh_polyphase(int ch)
     LH_WAVE_SYNC();
     /* lowpass: scale each new sub-band sample once (it is reused as band0 next granule) */
     for (int i = c.lane; i < 2 * 576; i += 64) {
-        int const g = i / 576, r = i - g * 576;
-        int const col = r & 31;
+        int const g = i / 576, r0 = i - g * 576;
+        int const col = r0 & 31, r = (r0 >> 5) * LH_SB_STRIDE + col;
         /* band index of this storage column: sb[...][k*32 + order[band]] */
         int     band = 0;
         for (int b = 0; b < 32; b++)
@@ -386,7 +401,7 @@ lh_mdct_granules(int ch)
 {
     LhCtx const c = lh_ctx_load();
     LhLds & L = lh_lds;
-    float   (*sb)[576] = lh_lds.u.mdct.sb[ch];
+    float   (*sb)[LH_SB_GRANULE] = lh_lds.u.mdct.sb[ch];
     const float *amp = c.T->amp_filter;
     int const gr = c.lane >> 5, band = c.lane & 31;
     int const type = L.block_type[gr][ch];
@@ -402,12 +417,12 @@ lh_mdct_granules(int ch)
 #pragma unroll
         for (int k = -3; k < 0; k++) {
             float const w = LH_WIN(LH_SHORT_TYPE, k + 3);
-            tmp[k * 3 + 9] = band0[(9 + k) * 32] * w - band0[(8 - k) * 32];
-            tmp[k * 3 + 18] = band0[(14 - k) * 32] * w + band0[(15 + k) * 32];
-            tmp[k * 3 + 10] = band0[(15 + k) * 32] * w - band0[(14 - k) * 32];
-            tmp[k * 3 + 19] = band1[(2 - k) * 32] * w + band1[(3 + k) * 32];
-            tmp[k * 3 + 11] = band1[(3 + k) * 32] * w - band1[(2 - k) * 32];
-            tmp[k * 3 + 20] = band1[(8 - k) * 32] * w + band1[(9 + k) * 32];
+            tmp[k * 3 + 9] = band0[(9 + k) * LH_SB_STRIDE] * w - band0[(8 - k) * LH_SB_STRIDE];
+            tmp[k * 3 + 18] = band0[(14 - k) * LH_SB_STRIDE] * w + band0[(15 + k) * LH_SB_STRIDE];
+            tmp[k * 3 + 10] = band0[(15 + k) * LH_SB_STRIDE] * w - band0[(14 - k) * LH_SB_STRIDE];
+            tmp[k * 3 + 19] = band1[(2 - k) * LH_SB_STRIDE] * w + band1[(3 + k) * LH_SB_STRIDE];
+            tmp[k * 3 + 11] = band1[(3 + k) * LH_SB_STRIDE] * w - band1[(2 - k) * LH_SB_STRIDE];
+            tmp[k * 3 + 20] = band1[(8 - k) * LH_SB_STRIDE] * w + band1[(9 + k) * LH_SB_STRIDE];
         }
         lh_mdct_short(tmp);
 #pragma unroll
@@ -419,10 +434,10 @@ lh_mdct_granules(int ch)
 #pragma unroll
         for (int k = -9; k < 0; k++) {
             float   a, b;
-            a = LH_WIN(type, k + 27) * band1[(k + 9) * 32]
-                + LH_WIN(type, k + 36) * band1[(8 - k) * 32];
-            b = LH_WIN(type, k + 9) * band0[(k + 9) * 32]
-                - LH_WIN(type, k + 18) * band0[(8 - k) * 32];
+            a = LH_WIN(type, k + 27) * band1[(k + 9) * LH_SB_STRIDE]
+                + LH_WIN(type, k + 36) * band1[(8 - k) * LH_SB_STRIDE];
+            b = LH_WIN(type, k + 9) * band0[(k + 9) * LH_SB_STRIDE]
+                - LH_WIN(type, k + 18) * band0[(8 - k) * LH_SB_STRIDE];
             work[k + 9] = a - b * LH_TANTAB(k + 9);
             work[k + 18] = a * LH_TANTAB(k + 9) + b;
         }

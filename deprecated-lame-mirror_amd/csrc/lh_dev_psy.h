@@ -222,9 +222,10 @@ lh_psy_granule(int gr, LhPsyCarry nb)
     /* (2) - (5) attack detection, the long transforms, spectra and their sums: done by the analysis kernels; what this
      * granule has of them is in its LhMidGr record.  The state words the fused kernel keeps up to date are kept up to date
      * here as well (either kernel may take the stream's next launch). */
-    const LhMidGr *mg = &LH_AS_GLOBAL(const LhMidSmall, lh_lds.ctx.mid_small)->gr[gr];
-    const LhMidLong *mlong = LH_AS_GLOBAL(const LhMidLong, lh_lds.ctx.mid_long);
-    const LhMidShort *mshort = LH_AS_GLOBAL(const LhMidShort, lh_lds.ctx.mid_short);
+    const LhMidFrame *mid = LH_AS_GLOBAL(const LhMidFrame, lh_lds.ctx.mid);
+    const LhMidGr *mg = &P.mid.small.gr[gr];            /* (staged into LDS at the top of the frame) */
+    const LhMidLong *mlong = &P.mid.lng;
+    const LhMidShort *mshort = &mid->shrt;              /* (HBM: short-block granules only) */
     LH_SYNC_WG_LDS();           /* the previous call's total energies are read */
     for (int pass = 0; pass < 2; pass++) {
         int const chn = w + 2 * pass;
@@ -528,6 +529,9 @@ lh_psy_granule(int gr, LhPsyCarry nb)
         }
         LH_WAVE_SYNC_MEM();
     }
+    /* (the products a wave's loudness lane adds up lie in the partition arrays the OTHER wave's masking is about to write:
+     * found when the same code ran at four waves per SIMD in lh_analysis.hip, where the two waves drift far enough apart) */
+    LH_SYNC_WG_LDS();
 #endif                          /* !LH_SPLIT */
     LH_PA(32, t_psy0);
     LQ_MARK("ps_mask");

@@ -93,7 +93,7 @@ typedef struct LhStreamDesc {
  * Everything of the psycho-acoustic model, the polyphase filter and the MDCT that depends on the PCM alone is computed
  * for all frames of a launch at once, at high occupancy, and parked in HBM; the encode kernel's frame prologue only
  * runs the recurrences (pre-echo clamp against the previous granules, ATH level, thresholds under the masking adjustment
- * the last frame's loop left, partition -> band sums, perceptual entropy).  One record of each pool per frame of the launch,
+ * the last frame's loop left, partition -> band sums, perceptual entropy).  One record (LhMidFrame) per frame of the launch,
  * at LhStreamDesc.out_index + (frame - frame_begin) like the payload. */
 typedef struct LhMidGr {
     float   peak[4][12];        /* [chn L,R,M,S][k < 9]: largest |high-passed sample| of the granule's nine sub-blocks of 64 samples
@@ -130,11 +130,16 @@ typedef struct LhMidXr {
     float   xr[2][2][576];      /* [ch][gr] MDCT spectra of L / R (before the mid/side rotation) */
 } LhMidXr;
 
+/* one frame's record: what the pools of a launch are made of */
+typedef struct LhMidFrame {
+    LhMidSmall small;
+    LhMidLong lng;
+    LhMidShort shrt;
+    LhMidXr xr;
+} LhMidFrame;
+
 typedef struct LhMidPools {
-    LhMidSmall *small;
-    LhMidLong *lng;
-    LhMidShort *shrt;
-    LhMidXr *xr;
+    LhMidFrame *frames;         /* [frames of the launch] */
 } LhMidPools;
 
 void    lh_state_init(LhStreamState * s, const LhConfig * cfg);

@@ -353,6 +353,32 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
      * frame the stages below pick up from HBM (L.ctx.mid_*) */
     if (tid == 0)
         lh_lds.ss.primed = 1;
+    {
+        /* Everything the prologue needs from HBM in one batch, so that the frame waits for HBM once: the MDCT spectra of
+         * both granules (L / R as lh_subband_kernel left them; the mid/side rotation follows below) to their place, the
+         * small record and the long-block masking to the psy model's scratch. */
+        const LhMidFrame *rec = LH_AS_GLOBAL(const LhMidFrame, L.ctx.mid);
+        const lh_f32x4 *sx = (const lh_f32x4 *) rec->xr.xr, *sm = (const lh_f32x4 *) &rec->small;
+        lh_f32x4 *dx = (lh_f32x4 *) L.xr, *dm = (lh_f32x4 *) &L.u.psy.mid.small;
+        constexpr int NM = (int) ((sizeof(LhMidSmall) + sizeof(LhMidLong)) / 16);      /* 420 */
+        static_assert(__builtin_offsetof(LhMidFrame, lng) == sizeof(LhMidSmall) && sizeof(LhMidSmall) % 16 == 0, "small and lng are one run");
+        lh_f32x4 v[5], m[4];
+#pragma unroll
+        for (int u = 0; u < 5; u++)
+            v[u] = sx[(tid + LH_NT * u < 576) ? tid + LH_NT * u : 575];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            m[u] = sm[(tid + LH_NT * u < NM) ? tid + LH_NT * u : NM - 1];
+#pragma unroll
+        for (int u = 0; u < 5; u++)
+            if (tid + LH_NT * u < 576)
+                dx[tid + LH_NT * u] = v[u];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (tid + LH_NT * u < NM)
+                dm[tid + LH_NT * u] = m[u];
+    }
+    LH_SYNC_WG();
 #else
     if (!lh_lds.ss.primed) {
         lh_stage_window(c, L.mf, c.frame_base - fs);
@@ -427,22 +453,7 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
     LH_PA(25, t_frame);
     /* ---- stage 2: polyphase + MDCT (reference encoder.c:405) ---- */
     LH_PT(t_mdct);
-#ifdef LH_SPLIT
-    {
-        /* the MDCT spectra of both granules, as lh_subband_kernel left them (L / R; the mid/side rotation follows below) */
-        const lh_f32x4 *src = (const lh_f32x4 *) L.ctx.mid_xr->xr;
-        lh_f32x4 *dst = (lh_f32x4 *) L.xr;
-        lh_f32x4 v[5];
-#pragma unroll
-        for (int u = 0; u < 5; u++)
-            v[u] = src[(tid + LH_NT * u < 576) ? tid + LH_NT * u : 575];
-#pragma unroll
-        for (int u = 0; u < 5; u++)
-            if (tid + LH_NT * u < 576)
-                dst[tid + LH_NT * u] = v[u];
-    }
-    LH_SYNC_WG();
-#else
+#ifndef LH_SPLIT                /* (split pipeline: the spectra are in place since the top of the frame) */
 #pragma unroll
     for (int k = 0; k < 9; k++)
         L.u.mdct.sb[w][0][lane + 64 * k] = carry.sb[k];
@@ -918,13 +929,7 @@ lh_encode_stream(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, 
             L.ctx.frame_base = c.frame_base;    /* read by the stages after the next workgroup barrier */
             L.psy_slot = slot;
 #ifdef LH_SPLIT
-            {
-                long long const at = c.d.out_index + (f - c.d.frame_begin);
-                L.ctx.mid_small = mid.small + at;
-                L.ctx.mid_long = mid.lng + at;
-                L.ctx.mid_short = mid.shrt + at;
-                L.ctx.mid_xr = mid.xr + at;
-            }
+            L.ctx.mid = mid.frames + (c.d.out_index + (f - c.d.frame_begin));
 #endif
         }
 #ifdef LH_SPLIT

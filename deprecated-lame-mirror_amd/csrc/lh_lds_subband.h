@@ -7,7 +7,7 @@ struct LhLds {
     LhRgSlot rg[2];
     int     block_type[2][2];   /* [gr][ch] */
     union __attribute__((aligned(16))) {
-        float   mf[2][LH_MF_NEEDED];
+        float   mf[2][LH_MF_PADDED];  /* (swizzled: LH_MF_SWZ) */
         float   xr[2][2][576];
     };
     union __attribute__((aligned(16))) {

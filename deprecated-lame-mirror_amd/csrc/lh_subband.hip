@@ -22,11 +22,18 @@
 #endif
 
 #define LH_CUSTOM_LDS "lh_lds_subband.h"
+/* LDS bank conflicts were three quarters of this kernel's LDS time (profiles/r05*): the frame window is stored with bit 4 of
+ * the sample index flipped in odd blocks of 32 (lh_dev_mdct.h: LH_MF_SWZ), the time slots of the sub-band samples 33 words apart */
+#define LH_MF_SWZ(i) ((i) ^ (((i) >> 1) & 16))
+#define LH_STAGE_IDX(i) LH_MF_SWZ(i)
+#define LH_SB_STRIDE 33
+#define LH_MF_PADDED ((LH_MF_NEEDED + 63) / 64 * 64)
 #include "lh_static_tables.h"
 #include "lh_dev_common.h"
 
 #include "lh_dev_mdct.h"
 
+#define LH_SB_CARRY ((LH_SB_GRANULE + 63) / 64)
 #ifndef LH_SB_RUN
 #define LH_SB_RUN 8             /* frames per workgroup: one recomputed granule per run */
 #endif
@@ -43,7 +50,7 @@ extern "C" __global__ void __launch_bounds__(LH_NT, 2)
 void
 #endif
 lh_subband_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, const float *pcmf, const LhStreamDesc * descs,
-                  LhStreamState * states, const LhMidSmall * small, LhMidXr * xrs, int nstreams)
+                  LhStreamState * states, LhMidFrame * frames, int nstreams)
 {
     LhLds & L = lh_lds;
     int const sidx = (int) blockIdx.y;
@@ -81,36 +88,37 @@ lh_subband_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm,
         L.ctx.d = c.d;
         L.ctx.frame_base = 0;
     }
-    float   sb[9];
+    float   sb[LH_SB_CARRY];
     /* the granule before the run (reference encoder.c:189-236 primes the filterbank the same way on a stream's first frame) */
-    lh_stage_window(c, L.mf, (long long) fs * f0 - LH_MF_START - fs);
+    lh_stage_span < LH_MF_NEEDED, LH_NT > (c, L.mf[0], L.mf[1], (long long) fs * f0 - LH_MF_START - fs);
     LH_SYNC_WG();
     lh_polyphase(w);
 #pragma unroll
-    for (int k = 0; k < 9; k++)
-        sb[k] = L.u.mdct.sb[w][ngr][lane + 64 * k];
+    for (int k = 0; k < LH_SB_CARRY; k++)
+        sb[k] = L.u.mdct.sb[w][ngr][(lane + 64 * k < LH_SB_GRANULE) ? lane + 64 * k : 0];
     LH_SYNC_WG();
     for (int f = f0; f < f1; f++) {
         long long const at = c.d.out_index + (f - c.d.frame_begin);
-        lh_stage_window(c, L.mf, (long long) fs * f - LH_MF_START);
+        lh_stage_span < LH_MF_NEEDED, LH_NT > (c, L.mf[0], L.mf[1], (long long) fs * f - LH_MF_START);
         if (tid < 4) {
             /* (a one-granule frame: the transforms also run over the window's second granule, which is thrown away) */
             int const gr = tid >> 1, ch = tid & 1;
-            L.block_type[gr][ch] = (gr < ngr) ? (int) small[at].gr[gr].block_type[ch] : LH_NORM_TYPE;
+            L.block_type[gr][ch] = (gr < ngr) ? (int) frames[at].small.gr[gr].block_type[ch] : LH_NORM_TYPE;
         }
 #pragma unroll
-        for (int k = 0; k < 9; k++)
-            L.u.mdct.sb[w][0][lane + 64 * k] = sb[k];
+        for (int k = 0; k < LH_SB_CARRY; k++)
+            if (lane + 64 * k < LH_SB_GRANULE)
+                L.u.mdct.sb[w][0][lane + 64 * k] = sb[k];
         LH_SYNC_WG();
         lh_polyphase(w);
         LH_SYNC_WG();           /* last read of mf (both channels) before xr overwrites it */
         lh_mdct_granules(w);
 #pragma unroll
-        for (int k = 0; k < 9; k++)
-            sb[k] = L.u.mdct.sb[w][ngr][lane + 64 * k];
+        for (int k = 0; k < LH_SB_CARRY; k++)
+            sb[k] = L.u.mdct.sb[w][ngr][(lane + 64 * k < LH_SB_GRANULE) ? lane + 64 * k : 0];
         LH_SYNC_WG();
         {
-            lh_f32x4 *dst = (lh_f32x4 *) xrs[at].xr;
+            lh_f32x4 *dst = (lh_f32x4 *) frames[at].xr.xr;
             const lh_f32x4 *src = (const lh_f32x4 *) L.xr;
             for (int i = tid; i < 576; i += LH_NT)
                 dst[i] = src[i];
@@ -118,9 +126,13 @@ lh_subband_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm,
         LH_SYNC_WG();
     }
     if (f1 == c.d.frame_end) {
+        /* (LhStreamState keeps the plain layout: slot * 32 + band) */
 #pragma unroll
-        for (int k = 0; k < 9; k++)
-            c.st->sb_prev[w][lane + 64 * k] = sb[k];
+        for (int k = 0; k < LH_SB_CARRY; k++) {
+            int const i = lane + 64 * k, slot = i / LH_SB_STRIDE, col = i - slot * LH_SB_STRIDE;
+            if (i < LH_SB_GRANULE && col < 32)
+                c.st->sb_prev[w][slot * 32 + col] = sb[k];
+        }
     }
 }
 
@@ -132,7 +144,7 @@ lh_launch_subband(const LhConfig * cfg, const LhTables * T, const int16_t * pcm,
     if (nstreams <= 0 || max_frames <= 0)
         return 0;
     hipLaunchKernelGGL(lh_subband_kernel, dim3((unsigned) ((max_frames + LH_SB_RUN - 1) / LH_SB_RUN), (unsigned) nstreams),
-                       dim3(LH_NT), 0, (hipStream_t) stream, cfg, T, pcm, pcmf, descs, states, mid.small, mid.xr, nstreams);
+                       dim3(LH_NT), 0, (hipStream_t) stream, cfg, T, pcm, pcmf, descs, states, mid.frames, nstreams);
     return (int) hipGetLastError();
 }
 #else
@@ -143,7 +155,7 @@ lh_emu_subband(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, co
     LhMidPools const mid = *pools;
     hipemu_dim3 grid = { (unsigned) ((max_frames + LH_SB_RUN - 1) / LH_SB_RUN), (unsigned) nstreams, 1 }, block = { LH_NT, 1, 1 };
     hipemu_run(grid, block,[=] () {
-               lh_subband_kernel(cfg, T, pcm, pcmf, descs, states, mid.small, mid.xr, nstreams);
+               lh_subband_kernel(cfg, T, pcm, pcmf, descs, states, mid.frames, nstreams);
                }
     );
     return 0;

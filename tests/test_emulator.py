@@ -61,20 +61,20 @@ def test_kernel_source_matches_oracle(name, nframes, emu, oracle):
 
 
 class LhMidPools(C.Structure):
-    _fields_ = [("small", C.c_void_p), ("lng", C.c_void_p), ("shrt", C.c_void_p), ("xr", C.c_void_p)]
+    _fields_ = [("frames", C.c_void_p)]
 
 
-# sizes of the analysis kernels' per-frame records (csrc/lh_device.h: LhMidSmall, LhMidLong, LhMidShort, LhMidXr)
-MID_SIZES = (2 * 288, 2 * 4 * 3 * 64 * 4, 2 * 3 * 4 * 3 * 64 * 4, 2 * 2 * 576 * 4)
+# size of the analysis kernels' per-frame record (csrc/lh_device.h: LhMidFrame = LhMidSmall, LhMidLong, LhMidShort, LhMidXr)
+MID_FRAME = 2 * 288 + 2 * 4 * 3 * 64 * 4 + 2 * 3 * 4 * 3 * 64 * 4 + 2 * 2 * 576 * 4
 
 
 def split_encode(emu, cfg, tab, pool, descs, states, got, nstreams, max_frames, total_frames, poison=0x5a):
     """The split pipeline under the emulator: attack / scan / analysis kernels, the sub-band kernel, then the encode
-    kernel that starts from their output.  The pools are filled with a poison pattern first: whatever the encode
+    kernel that starts from their output.  The pool is filled with a poison pattern first: whatever the encode
     kernel reads must have been written by the analysis kernels of THIS launch."""
     lsf = cfg.mode_gr == 1
-    bufs = [np.full(total_frames * sz + 64, poison, dtype=np.uint8) for sz in MID_SIZES]
-    pools = LhMidPools(*[b.ctypes.data for b in bufs])
+    buf = np.full(total_frames * MID_FRAME + 64, poison, dtype=np.uint8)
+    pools = LhMidPools(buf.ctypes.data)
     sfx = "_lsf" if lsf else ""
     pcm = pool.ctypes.data_as(C.c_void_p)
     getattr(emu, "lh_emu_analysis" + sfx)(C.byref(cfg), C.byref(tab), pcm, None, descs, states, C.byref(pools), nstreams, max_frames)
