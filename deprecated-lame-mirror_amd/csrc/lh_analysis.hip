@@ -90,6 +90,14 @@ lh_desc_uniform(const LhStreamDesc * descs, int sidx)
 #define lh_emu_analysis lh_emu_analysis_lsf
 #endif
 
+/* development aid (-DLH_APROF, tools/an_profile.py): cycles per phase, added up per stream in LhStreamState.prof[wave][k] */
+#if defined(LH_APROF) && !defined(LH_EMU)
+#define LH_AP_T0() unsigned long long ap_t = clock64()
+#define LH_AP(k) do { unsigned long long const n_ = clock64(); if (c.lane == 0) atomicAdd(&aprof[64 * 0 + LH_NPROF * c.wave + (k)], n_ - ap_t); ap_t = n_; } while (0)
+#else
+#define LH_AP_T0() do { } while (0)
+#define LH_AP(k) do { } while (0)
+#endif
 #define LH_FIR_SPAN 640         /* 576 + 21 samples are read; staged in pairs by 64 threads */
 
 /* ---- attack detection, part 1: the high-passed granule and its sub-block peaks (reference psymodel.c:759-830) ---- */
@@ -323,8 +331,12 @@ extern "C" __global__ void __launch_bounds__(LH_NT, 4)
 void
 #endif
 lh_analysis_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, const float *pcmf, const LhStreamDesc * descs,
-                   LhMidFrame * frames, int nstreams)
+                   LhMidFrame * frames, int nstreams, LhStreamState * states)
 {
+#if defined(LH_APROF) && !defined(LH_EMU)
+    unsigned long long *aprof = &states[blockIdx.y].prof[0][0];
+#endif
+    LH_AP_T0();
     LhLds & L = lh_lds;
     LhPsyLds & P = L.u.psy;
     int const sidx = (int) blockIdx.y;
@@ -347,12 +359,15 @@ lh_analysis_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm
     LhMidGr *mg = &frames[ga.at].small.gr[gr];
     if (c.tid < 2)
         L.uselong[c.tid] = mg->uselong[c.tid];
+    LH_AP(0);
     lh_stage_span < LH_BLKSIZE, LH_NT > (c, LH_SPAN, LH_SPAN + LH_BLKSIZE, ga.frame_base + bufbase);
     LH_SYNC_WG_LDS();
+    LH_AP(1);
     /* long FFTs of L (wave 0) and R (wave 1) */
     if (w < cfg->channels)
         lh_fft_long(c, w, 0, P.wsamp[w]);
     LH_SYNC_WG_LDS();
+    LH_AP(2);
     /* power spectra of this wave's one or two pseudo-channels (over the sample spans, which are done with) */
     if (n_chn_psy == 4)
         lh_fft_energy_pair(c, w, P.wsamp[0], P.wsamp[1], LH_BLKSIZE, P.b.energy[w], P.b.energy[w + 2]);
@@ -361,9 +376,11 @@ lh_analysis_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm
     /* the FHT buffers are free: the long-block spreading matrix goes there (as in the fused kernel) */
     float  *stg_s3 = &P.wsamp[0][0];
     LH_SYNC_WG_LDS();
+    LH_AP(3);
     for (int i = c.tid; i < T->psy_l.s3_count; i += LH_NT)
         stg_s3[i] = T->psy_l.s3[i];
     LH_SYNC_WG_LDS();
+    LH_AP(4);
     /* serial sums: total energy (bins 11..512) of chn w (lane 0) and w + 2 (lane 1), loudness of channel w (lane 2), in
      * bin order (reference psymodel.c:213-226, 690-696); see the fused kernel for the layout */
     {
@@ -430,6 +447,7 @@ lh_analysis_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm
     }
     /* (the products a wave's loudness lane adds up lie in the partition arrays the OTHER wave's masking is about to write) */
     LH_SYNC_WG_LDS();
+    LH_AP(5);
     /* masking, long blocks, up to the recurrences: the wave's one or two pseudo-channels together */
     {
         LhMidLong *ml = &frames[ga.at].lng;
@@ -446,6 +464,7 @@ lh_analysis_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm
         }
     }
     /* short blocks (reference psymodel.c:1470-1500): only for a granule in which a channel switches */
+    LH_AP(6);
     int const any_short = lh_uni_i(!(L.uselong[0] && L.uselong[1]));
     if (!any_short)
         return;
@@ -480,6 +499,7 @@ lh_analysis_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm
         }
         LH_SYNC_WG_LDS();
     }
+    LH_AP(7);
 }
 
 #ifndef LH_EMU
@@ -494,7 +514,8 @@ lh_launch_analysis(const LhConfig * cfg, const LhTables * T, const int16_t * pcm
     hipLaunchKernelGGL(lh_attack_kernel, grid, dim3(64), 0, (hipStream_t) stream, cfg, pcm, pcmf, descs, mid.frames, nstreams);
     hipLaunchKernelGGL(lh_attack_scan_kernel, dim3((unsigned) nstreams), dim3(64), 0, (hipStream_t) stream, cfg, T, descs, states,
                        mid.frames, nstreams);
-    hipLaunchKernelGGL(lh_analysis_kernel, grid, dim3(LH_NT), 0, (hipStream_t) stream, cfg, T, pcm, pcmf, descs, mid.frames, nstreams);
+    hipLaunchKernelGGL(lh_analysis_kernel, grid, dim3(LH_NT), 0, (hipStream_t) stream, cfg, T, pcm, pcmf, descs, mid.frames, nstreams,
+                       (LhStreamState *) states);
     return (int) hipGetLastError();
 }
 #else
@@ -514,7 +535,7 @@ lh_emu_analysis(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, c
                }
     );
     hipemu_run(grid, b128,[=] () {
-               lh_analysis_kernel(cfg, T, pcm, pcmf, descs, mid.frames, nstreams);
+               lh_analysis_kernel(cfg, T, pcm, pcmf, descs, mid.frames, nstreams, (LhStreamState *) states);
                }
     );
     return 0;

@@ -379,17 +379,18 @@ lh_polyphase(int ch)
         }
     }
     LH_WAVE_SYNC();
-    /* lowpass: scale each new sub-band sample once (it is reused as band0 next granule) */
-    for (int i = c.lane; i < 2 * 576; i += 64) {
-        int const g = i / 576, r0 = i - g * 576;
-        int const col = r0 & 31, r = (r0 >> 5) * LH_SB_STRIDE + col;
-        /* band index of this storage column: sb[...][k*32 + order[band]] */
-        int     band = 0;
-        for (int b = 0; b < 32; b++)
-            if (lh_sb_order[b] == col)
-                band = b;
-        if (!(amp[band] < 1e-12) && amp[band] < 1.0)
-            sb[1 + g][r] *= amp[band];
+    /* lowpass: scale each new sub-band sample once (it is reused as band0 next granule).  A lane's storage column is the same
+     * on every trip (64 apart), and the column order -- bits 1..4 of the band reversed -- is its own inverse: the band and
+     * its factor are found once, and bands the filter leaves alone (factor 1: all below the lowpass) take no trip at all. */
+    {
+        int const col = c.lane & 31;
+        float const a = amp[lh_sb_order[col]];
+        if (!(a < 1e-12) && a < 1.0) {
+            for (int i = c.lane; i < 2 * 576; i += 64) {
+                int const g = i / 576, r0 = i - g * 576;
+                sb[1 + g][(r0 >> 5) * LH_SB_STRIDE + col] *= a;
+            }
+        }
     }
     LH_WAVE_SYNC();
 }

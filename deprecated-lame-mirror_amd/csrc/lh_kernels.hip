@@ -363,6 +363,17 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
         constexpr int NM = (int) ((sizeof(LhMidSmall) + sizeof(LhMidLong)) / 16);      /* 420 */
         static_assert(__builtin_offsetof(LhMidFrame, lng) == sizeof(LhMidSmall) && sizeof(LhMidSmall) % 16 == 0, "small and lng are one run");
         lh_f32x4 v[5], m[4];
+#if !defined(LH_EMU) && !defined(LH_NO_MID_PREFETCH)
+        /* and the NEXT frame's record is asked for now, one word per cache line (a load nobody uses: it only brings the
+         * lines into the L2 / the memory-side cache, a frame's time before the batch above is issued for them; the pool has
+         * a margin of records behind the launch's last frame).  Issued first, so it has returned when the loads below have. */
+        uint32_t touched;
+        {
+            int const line = tid < 53 ? tid : (tid < 125 ? tid - 53 : 0);
+            const char *nx = (const char *) (rec + 1) + (tid < 53 ? 0 : __builtin_offsetof(LhMidFrame, xr)) + 128 * line;
+            asm volatile("global_load_dword %0, %1, off" : "=v"(touched) : "v"(nx) : "memory");
+        }
+#endif
 #pragma unroll
         for (int u = 0; u < 5; u++)
             v[u] = sx[(tid + LH_NT * u < 576) ? tid + LH_NT * u : 575];
@@ -377,6 +388,9 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
         for (int u = 0; u < 4; u++)
             if (tid + LH_NT * u < NM)
                 dm[tid + LH_NT * u] = m[u];
+#if !defined(LH_EMU) && !defined(LH_NO_MID_PREFETCH)
+        asm volatile("" :: "v"(touched));       /* (its register is the load's until here) */
+#endif
     }
     LH_SYNC_WG();
 #else

@@ -33,6 +33,13 @@
 
 #include "lh_dev_mdct.h"
 
+#if defined(LH_APROF) && !defined(LH_EMU)
+#define LH_AP_T0() unsigned long long ap_t = clock64()
+#define LH_AP(k) do { unsigned long long const n_ = clock64(); if (c.lane == 0) atomicAdd(&c.st->prof[c.wave][(k)], n_ - ap_t); ap_t = n_; } while (0)
+#else
+#define LH_AP_T0() do { } while (0)
+#define LH_AP(k) do { } while (0)
+#endif
 #define LH_SB_CARRY ((LH_SB_GRANULE + 63) / 64)
 #ifndef LH_SB_RUN
 #define LH_SB_RUN 8             /* frames per workgroup: one recomputed granule per run */
@@ -89,14 +96,16 @@ lh_subband_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm,
         L.ctx.frame_base = 0;
     }
     float   sb[LH_SB_CARRY];
+    LH_AP_T0();
     /* the granule before the run (reference encoder.c:189-236 primes the filterbank the same way on a stream's first frame) */
     lh_stage_span < LH_MF_NEEDED, LH_NT > (c, L.mf[0], L.mf[1], (long long) fs * f0 - LH_MF_START - fs);
-    LH_SYNC_WG();
+    LH_SYNC_WG_LDS();
     lh_polyphase(w);
 #pragma unroll
     for (int k = 0; k < LH_SB_CARRY; k++)
         sb[k] = L.u.mdct.sb[w][ngr][(lane + 64 * k < LH_SB_GRANULE) ? lane + 64 * k : 0];
-    LH_SYNC_WG();
+    LH_SYNC_WG_LDS();
+    LH_AP(8);
     for (int f = f0; f < f1; f++) {
         long long const at = c.d.out_index + (f - c.d.frame_begin);
         lh_stage_span < LH_MF_NEEDED, LH_NT > (c, L.mf[0], L.mf[1], (long long) fs * f - LH_MF_START);
@@ -109,21 +118,25 @@ lh_subband_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm,
         for (int k = 0; k < LH_SB_CARRY; k++)
             if (lane + 64 * k < LH_SB_GRANULE)
                 L.u.mdct.sb[w][0][lane + 64 * k] = sb[k];
-        LH_SYNC_WG();
+        LH_SYNC_WG_LDS();
+        LH_AP(9);
         lh_polyphase(w);
-        LH_SYNC_WG();           /* last read of mf (both channels) before xr overwrites it */
+        LH_SYNC_WG_LDS();           /* last read of mf (both channels) before xr overwrites it */
+        LH_AP(10);
         lh_mdct_granules(w);
 #pragma unroll
         for (int k = 0; k < LH_SB_CARRY; k++)
             sb[k] = L.u.mdct.sb[w][ngr][(lane + 64 * k < LH_SB_GRANULE) ? lane + 64 * k : 0];
-        LH_SYNC_WG();
+        LH_SYNC_WG_LDS();
+        LH_AP(11);
         {
             lh_f32x4 *dst = (lh_f32x4 *) frames[at].xr.xr;
             const lh_f32x4 *src = (const lh_f32x4 *) L.xr;
             for (int i = tid; i < 576; i += LH_NT)
                 dst[i] = src[i];
         }
-        LH_SYNC_WG();
+        LH_SYNC_WG_LDS();
+        LH_AP(12);
     }
     if (f1 == c.d.frame_end) {
         /* (LhStreamState keeps the plain layout: slot * 32 + band) */
