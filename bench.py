@@ -27,9 +27,29 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "deprecated-lame-mirror_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-ALG_BYTES_PER_FRAME = 9792          # 4608 B PCM in + 5184 B side info out
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E ~8 TB/s
-CHECKED_STREAMS = 4                 # streams whose payload is compared with the CPU oracle after the timed region
+CHECKED_STREAMS = 64                # streams whose payload is compared with the CPU oracle after the timed region (rank 0; every
+                                    # other rank checks the first and the last stream of its own block)
+# what tools/ubench/lat2.hip measured a SIMD can issue per cycle (all instruction classes): for the two waves the encode kernel
+# gives it, and for eight
+ISSUE_CEILING_2_WAVES = 0.43
+ISSUE_CEILING_8_WAVES = 0.76
+
+
+def alg_bytes_per_frame(sr):
+    """PCM in + side-info payload out per frame of the whole path -- 4608 + 5184 B for the two-granule
+    frames of MPEG-1 (32 / 44.1 / 48 kHz), 2304 + 2624 B for the one-granule frames of MPEG-2 / 2.5."""
+    return 9792 if sr >= 32000 else 4928
+
+
+def alg_bytes_by_kernel(sr):
+    """The same per kernel of the split pipeline (csrc/lh_device.h): the analysis kernels read the PCM and leave the small
+    record and the long-block masking (576 + 6144 B; the short-block masking only for granules that switch), the sub-band
+    kernel reads the PCM and leaves the spectra (9216 B), the encode kernel reads both and leaves the payload."""
+    g = 2 if sr >= 32000 else 1
+    pcm, payload = 2304 * g, 2592 * g if g == 2 else 2624
+    small, lng, xr = 576, 6144, 9216
+    return {"analysis": pcm + small + lng, "subband": pcm + xr, "encode": small + lng + xr + payload}
 CPU_SAMPLE_SECONDS = 20.0           # audio per stream in the CPU leg
 
 
@@ -203,7 +223,7 @@ class FileRendezvous:
         self.n += 1
         name = os.path.join(self.path, "%s.%d" % (tag, self.n))
         with open("%s.%d.tmp" % (name, self.rank), "w") as f:
-            f.write(repr([float(x) for x in value] if isinstance(value, (list, tuple)) else float(value)))
+            json.dump([float(x) for x in value] if isinstance(value, (list, tuple)) else float(value), f)
         os.rename("%s.%d.tmp" % (name, self.rank), "%s.%d" % (name, self.rank))
         vals = []
         t0 = time.time()
@@ -212,7 +232,7 @@ class FileRendezvous:
                 if time.time() - t0 > 1800:
                     raise RuntimeError("rank %d never reached %s" % (r, tag))
                 time.sleep(0.0005)
-            vals.append(eval(open("%s.%d" % (name, r)).read(), {"__builtins__": {}}))
+            vals.append(json.load(open("%s.%d" % (name, r))))
         return vals
 
     def barrier(self):
@@ -316,59 +336,121 @@ def recorded(name):
     return None
 
 
-def check_against_oracle(batch, enc, host_streams, which):
-    """Payload of a few bench streams against the CPU oracle (test infrastructure, used here only as
-    the checker, after the timed region); raises on the first difference."""
+def _check_worker(job):
+    """One process of the post-check (spawned: no GPU context): the oracle's payload of one saved stream against the
+    bytes the GPU left; returns None or a description of the first difference."""
+    pcm_path, idx, stream, frames_path, enc_args = job
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "deprecated-lame-mirror_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     import helpers
-    from lamehip.types import struct_diff
-    orc = helpers.Oracle()
-    cfg, tab = enc.config(), enc.tables()
-    for s, pcm in zip(which, host_streams):
-        got = batch.get_frames(s)
-        want = orc.encode_frames(cfg, tab, pcm)
-        if len(got) != len(want):
-            raise SystemExit("bench stream %d: %d frames from the GPU, %d from the oracle" % (s, len(got), len(want)))
-        for f in range(len(got)):
-            if bytes(got[f]) != bytes(want[f]):
-                d = struct_diff(want[f], got[f])
-                if d:
-                    raise SystemExit("bench stream %d frame %d differs from the oracle: %r" % (s, f, d[:4]))
-    return {"streams": list(which), "frames_each": len(batch.get_frames(which[0])), "result": "identical"}
+    import lamehip
+    from lamehip.types import LhFrameOut, struct_diff
+    import ctypes as C
+    pcm = np.ascontiguousarray(np.load(pcm_path, mmap_mode="r")[idx])
+    enc = lamehip.Encoder(*enc_args[0], require_device=False, **enc_args[1])
+    want = helpers.Oracle().encode_frames(enc.config(), enc.tables(), pcm)
+    got = open(frames_path, "rb").read()
+    fsz = C.sizeof(LhFrameOut)
+    if len(got) != len(want) * fsz:
+        return "stream %d: %d frames from the GPU, %d from the oracle" % (stream, len(got) // fsz, len(want))
+    for f in range(len(want)):
+        if got[f * fsz:(f + 1) * fsz] != bytes(want[f]):
+            d = struct_diff(want[f], LhFrameOut.from_buffer_copy(got[f * fsz:(f + 1) * fsz]))
+            if d:
+                return "stream %d frame %d differs from the oracle: %r" % (stream, f, d[:4])
+    return None
+
+
+def check_against_oracle(batch, enc_args, host_streams, which, procs=1):
+    """Payload of some of the bench's streams, every frame, against the CPU oracle (test infrastructure, used here only
+    as the checker, after the timed region), in `procs' processes at once; raises on the first difference."""
+    import multiprocessing as mp
+    import numpy as np
+    tmpd = tempfile.mkdtemp(prefix="lamehip_check_")
+    try:
+        pcm_path = os.path.join(tmpd, "pcm.npy")
+        np.save(pcm_path, np.stack(host_streams))
+        jobs = []
+        for i, s in enumerate(which):
+            fp = os.path.join(tmpd, "frames_%d.bin" % s)
+            with open(fp, "wb") as f:
+                f.write(bytes(batch.get_frames(s)))
+            jobs.append((pcm_path, i, s, fp, enc_args))
+        if procs > 1 and len(jobs) > 1:
+            with mp.get_context("spawn").Pool(min(procs, len(jobs))) as pool:
+                res = pool.map(_check_worker, jobs, chunksize=1)
+        else:
+            res = [_check_worker(j) for j in jobs]
+    finally:
+        for f in os.listdir(tmpd):
+            os.unlink(os.path.join(tmpd, f))
+        os.rmdir(tmpd)
+    bad = [r for r in res if r]
+    if bad:
+        raise SystemExit("bench: " + bad[0])
+    return {"streams": len(which), "first_last": [int(which[0]), int(which[-1])], "frames_each": int(batch.frames(which[0])),
+            "processes": min(procs, len(jobs)), "result": "identical"}
 
 
 def pmc_record_for(args):
-    """The committed PMC record of the workload this run benches (recorded with tools/r04_collect.sh)."""
+    """The committed PMC record of the workload this run benches (recorded with tools/r05_collect.sh)."""
     if args.vbr is not None:
-        return "r04_pmc_vbrold2.json" if args.vbr_old else "r04_pmc_vbr2.json"
+        return "r05_pmc_vbrold2.json" if args.vbr_old else "r05_pmc_vbr2.json"
     if args.brate == 320 and args.samplerate == 48000:
-        return "r04_pmc_cbr320.json"
-    return "r04_pmc.json"
+        return "r05_pmc_cbr320.json"
+    if args.samplerate < 32000:
+        return "r05_pmc_lsf.json"
+    return "r05_pmc.json"
 
 
-def roofline_block(frames, kavg_s, pmc_name):
-    """HBM roofline of lh_encode_kernel: algorithmic bytes of the launch over the kernel's average time (HIP
-    events on the batch's stream); traffic = the recorded PMC figure per frame x the frames of this launch, only
-    while the record was taken from these very sources."""
-    achieved = frames * ALG_BYTES_PER_FRAME / kavg_s / 1e9
+def roofline_block(frames, sr, kavg_s, parts, pmc_name):
+    """HBM roofline of the launch, kernel by kernel: algorithmic bytes over the kernel's average time (HIP events on the
+    batch's stream, recorded between the kernels: lamehip_batch_last_kernel_parts_ms).  The block's own achieved / frac are
+    the dominant kernel's (the encode kernel: lh_encode_kernel_q of the split pipeline, or the fused lh_encode_kernel);
+    `whole_launch' prices the whole path's bytes over the whole launch.  traffic = the recorded PMC figure per
+    frame x the frames of this launch, only while the record was taken from these very sources."""
+    split = bool(parts) and parts[0]
+    whole = frames * alg_bytes_per_frame(sr) / kavg_s / 1e9
+    kernels = []
+    if split:
+        by = alg_bytes_by_kernel(sr)
+        names = {"analysis": "lh_attack_kernel + lh_attack_scan_kernel + lh_analysis_kernel", "subband": "lh_subband_kernel",
+                 "encode": "lh_encode_kernel_q"}
+        for k, ms in zip(("analysis", "subband", "encode"), parts[1]):
+            a = frames * by[k] / (ms / 1e3) / 1e9 if ms > 0 else 0.0
+            kernels.append({"kernel": names[k], "ms_avg": round(ms, 3), "alg_bytes_per_frame": by[k], "achieved": round(a, 3),
+                            "frac": round(a / HBM_PEAK_GBS, 6)})
+        dom = kernels[2]
+        achieved, dom_name, dom_ms, dom_bytes = dom["achieved"], dom["kernel"], dom["ms_avg"], dom["alg_bytes_per_frame"]
+    else:
+        achieved, dom_name, dom_ms, dom_bytes = whole, "lh_encode_kernel", kavg_s * 1e3, alg_bytes_per_frame(sr)
     pmc = recorded(pmc_name) or {}
     fresh = bool(pmc) and not pmc.get("stale") and pmc.get("hbm_bytes_per_frame")
+    ipc = pmc.get("insts_per_cycle_per_simd") if fresh else None
     block = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": round(achieved / HBM_PEAK_GBS, 6),
              "traffic": int(pmc["hbm_bytes_per_frame"] * frames) if fresh else None,
-             "traffic_note": ("%.1f KB per frame x the frames of this launch; per-frame figure recorded with rocprofv3 "
-                              "--pmc (FETCH_SIZE x 2 + WRITE_SIZE) on %s from these sources (digest %s), workload `%s'; "
-                              "bench.py does not run the profiler"
+             "traffic_note": ("%.1f KB per frame x the frames of this launch (all kernels of the launch); per-frame figure "
+                              "recorded with rocprofv3 --pmc (FETCH_SIZE x 2 + WRITE_SIZE) on %s from these sources (digest %s), "
+                              "workload `%s'; bench.py does not run the profiler"
                               % (pmc.get("hbm_bytes_per_frame", 0) / 1e3, pmc.get("date"), pmc.get("csrc_sha256"),
                                  pmc.get("workload"))) if fresh
              else ("stale profile: profiles/%s was recorded from other sources (digest %s, now %s)"
                    % (pmc_name, pmc.get("csrc_sha256"), csrc_digest())) if pmc else "no recorded PMC profile in profiles/",
+             "kernel": dom_name, "kernel_ms_avg": round(dom_ms, 3), "alg_bytes_per_frame": dom_bytes,
+             "frames_per_launch": frames,
+             "kernels": kernels if split else None,
+             "whole_launch": {"ms_avg": round(kavg_s * 1e3, 3), "alg_bytes_per_frame": alg_bytes_per_frame(sr),
+                              "achieved": round(whole, 3), "frac": round(whole / HBM_PEAK_GBS, 6)},
              "valu_frac": pmc.get("valu_frac") if fresh else None,
              "issue_active_frac": pmc.get("issue_active_frac") if fresh else None,
-             # the fraction that binds: instructions the SIMDs issued per cycle (all classes, from the same PMC record,
-             # at the clock the counters give) over what tools/ubench/lat2.hip measured a SIMD can issue for the two
-             # waves it hosts (0.43 per cycle)
-             "issue_frac": pmc.get("issue_frac") if fresh else None,
-             "insts_per_cycle_per_simd": pmc.get("insts_per_cycle_per_simd") if fresh else None,
+             # the fraction that binds: instructions the encode kernel's SIMDs issued per cycle (all classes, from the same
+             # PMC record, at the clock the counters give) over what tools/ubench/lat2.hip measured a SIMD can issue -- for the
+             # two waves that kernel gives it (how good those two waves are) and for eight (how idle the SIMD is)
+             "insts_per_cycle_per_simd": ipc,
+             "issue_frac": round(ipc / ISSUE_CEILING_2_WAVES, 3) if ipc else None,
+             "issue_frac_of_8_wave_ceiling": round(ipc / ISSUE_CEILING_8_WAVES, 3) if ipc else None,
              "wave_insts_per_frame": pmc.get("wave_insts_per_frame") if fresh else None,
              "shader_clock_ghz": pmc.get("shader_clock_ghz") if fresh else None,
              "clock_from": pmc.get("clock_from") if fresh else None,
@@ -376,10 +458,15 @@ def roofline_block(frames, kavg_s, pmc_name):
              "wave_residency": pmc.get("wave_residency") if fresh else None,
              "bound_in_practice": "instruction issue of a serial search: one wave issues at most one instruction per "
                                   "~4.6 cycles (tools/ubench/lat2.hip) and a stream offers two chains (its channels), "
-                                  "one SIMD's worth; HBM is idle",
-             "kernel": "lh_encode_kernel", "kernel_ms_avg": round(kavg_s * 1e3, 3),
-             "alg_bytes_per_frame": ALG_BYTES_PER_FRAME, "frames_per_launch": frames}
+                                  "one SIMD's worth; HBM is idle"}
     return block
+
+
+def mean_parts(parts):
+    """[(split, [analysis, subband, encode] ms), ...] of several launches -> one such pair of means"""
+    if not parts:
+        return None
+    return parts[0][0], [sum(p[1][k] for p in parts) / len(parts) for k in range(3)]
 
 
 def short_run(torch, lamehip, dev, device_index, sr, B, seconds, steps, seed, bursts_per_s, pmc_name, **enc_kw):
@@ -391,19 +478,20 @@ def short_run(torch, lamehip, dev, device_index, sr, B, seconds, steps, seed, bu
     pcm = synth_on_device(torch, B, n, sr, seed, dev, bursts_per_s=bursts_per_s)
     for s in range(B):
         b.set_pcm_device(s, pcm[s, 0].data_ptr(), pcm[s, 1].data_ptr(), n)
-    which = [0, B - 1] if B > 1 else [0]
+    which = sorted(set(int(round(k * (B - 1) / 7.0)) for k in range(8))) if B > 1 else [0]
     host_streams = [pcm[s].cpu().numpy() for s in which]
     del pcm
     b.encode(sync=True)
     torch.cuda.synchronize()
-    kms = []
+    kms, parts = [], []
     t0 = time.perf_counter()
     for _ in range(steps):
         b.encode(sync=True)
         kms.append(b.kernel_ms())
+        parts.append(b.kernel_parts_ms())
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    checked = check_against_oracle(b, enc, host_streams, which)
+    checked = check_against_oracle(b, ((sr,), dict(enc_kw)), host_streams, which, procs=min(_cpu_budget(), 8))
     assert len(b.pack(0)) > 0
     frames = sum(b.frames(s) for s in range(B))
     b.close()
@@ -411,7 +499,8 @@ def short_run(torch, lamehip, dev, device_index, sr, B, seconds, steps, seed, bu
     v = B * seconds * steps / dt
     return {"value": round(v, 1), "unit": "x real-time", "per_stream_x_realtime": round(v / B, 2),
             "workload": "batch=%d x %.0f s, %d Hz; %s" % (B, seconds, sr, SIGNAL % bursts_per_s), "steps": steps,
-            "checked_against_oracle": checked, "roofline": roofline_block(frames, sum(kms) / len(kms) / 1e3, pmc_name)}
+            "checked_against_oracle": checked,
+            "roofline": roofline_block(frames, sr, sum(kms) / len(kms) / 1e3, mean_parts(parts), pmc_name)}
 
 
 def main():
@@ -473,10 +562,16 @@ def main():
         batch.set_pcm_device(s, pcm[s, 0].data_ptr(), pcm[s, 1].data_ptr(), n)
     # host copies for the checks / the CPU leg (rank 0 only): a few whole streams, and the first 20 s of
     # as many streams as there are physical cores
-    which = sorted(set([0, 1, B // 2, B - 1]))[:CHECKED_STREAMS] if B >= 2 else [0]
-    host_streams, host_cpu = [], None
+    # rank 0: CHECKED_STREAMS streams spread over its block (first and last among them); every other rank: the first and the
+    # last stream of ITS OWN block -- on a node with N devices the output of each is compared with the oracle by its own rank
     if rank == 0:
-        host_streams = [pcm[s].cpu().numpy() for s in which]
+        nck = min(CHECKED_STREAMS, B)
+        which = sorted(set(int(round(k * (B - 1) / max(nck - 1, 1))) for k in range(nck)))
+    else:
+        which = sorted(set([0, B - 1]))
+    enc_args = ((sr, args.brate), dict(vbr_q=args.vbr, abr=args.abr, vbr_mode=vbr_mode, **enc_kw))
+    host_streams, host_cpu = [pcm[s].cpu().numpy() for s in which], None
+    if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             k = min(_physical_cores(), B)
             host_cpu = pcm[:k, :, :min(n, int(CPU_SAMPLE_SECONDS * sr))].cpu().numpy()
@@ -504,10 +599,11 @@ def main():
     barrier()
     dt = rdv.max(time.perf_counter() - t0)
     # what each rank did, for the one line rank 0 prints (timing scalars only; no stream data ever crosses ranks)
-    per_rank = rdv.gather([rank, device_index, lo, hi, own_dt, own_cpu, sum(kernel_ms) / len(kernel_ms)])
+    # every rank checks its own streams (after the timed region; a difference ends the rank with an error, and with it the run)
+    checked = check_against_oracle(batch, enc_args, host_streams, which, procs=_cpu_budget() if rank == 0 else 1)
+    per_rank = rdv.gather([rank, device_index, lo, hi, own_dt, own_cpu, sum(kernel_ms) / len(kernel_ms), float(checked["streams"])])
 
     if rank == 0:
-        checked = check_against_oracle(batch, enc, host_streams, which)
         assert len(batch.pack(0)) > 0           # and the payload survives the host packer's consistency checks
         audio_s = world * B * args.seconds * args.steps
         value = audio_s / dt
@@ -541,12 +637,15 @@ def main():
                           "kernel_ms_avg": round(r[6], 3),
                           # host CPU seconds this rank's process burned per wall second of its timed region: the
                           # kernel path needs no host work, the rest is the runtime waiting for the stream
-                          "host_cpu_per_wall_s": round(r[5] / r[4], 3)} for r in per_rank],
+                          "host_cpu_per_wall_s": round(r[5] / r[4], 3),
+                          # streams of this rank's own block that its own process compared with the oracle after the timed
+                          # region (a difference would have ended the run)
+                          "checked_streams": int(r[7]), "checked": "identical"} for r in per_rank],
             "collectives_on_data_path": 0,
             "pipeline": ({"kind": "split", "kernels_ms_avg": dict(zip(("analysis", "subband", "encode"),
                           [round(sum(p[1][k] for p in parts_ms) / len(parts_ms), 3) for k in range(3)]))}
                          if parts_ms and parts_ms[0][0] else {"kind": "fused"}),
-            "roofline": roofline_block(frames, kavg, pmc_record_for(args)),
+            "roofline": roofline_block(frames, sr, kavg, mean_parts(parts_ms), pmc_record_for(args)),
             "checked_against_oracle": checked,
         }
         if host_cpu is not None:
@@ -556,14 +655,14 @@ def main():
             batch = None
             res["extra"] = {
                 "vbr_v2_config2": short_run(torch, lamehip, dev, device_index, 44100, 1024, 5.0, 2, 5000, 3.0,
-                                            "r04_pmc_vbr2.json", vbr_q=2),
+                                            "r05_pmc_vbr2.json", vbr_q=2),
                 "vbr_old_v2": short_run(torch, lamehip, dev, device_index, 44100, 1024, 5.0, 2, 5000, 3.0,
-                                        "r04_pmc_vbrold2.json", vbr_q=2, vbr_mode=2),
+                                        "r05_pmc_vbrold2.json", vbr_q=2, vbr_mode=2),
                 "cbr320_48k_bursts_config4": short_run(torch, lamehip, dev, device_index, 48000, 1024, 5.0, 2, 9000,
-                                                       40.0, "r04_pmc_cbr320.json", brate=320, mode=1),
+                                                       40.0, "r05_pmc_cbr320.json", brate=320, mode=1),
                 # MPEG-2 (one granule of 576 samples per frame): the kernel object compiled with -DLH_LSF
                 "mpeg2_22k_cbr64": short_run(torch, lamehip, dev, device_index, 22050, 1024, 10.0, 2, 7000, 3.0,
-                                             "r04_pmc_lsf.json", brate=64),
+                                             "r05_pmc_lsf.json", brate=64),
             }
         if not args.no_end_to_end and not args.no_extras and world == 1:
             if batch is not None:

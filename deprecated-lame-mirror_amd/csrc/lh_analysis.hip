@@ -373,6 +373,7 @@ lh_analysis_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm
         lh_fft_energy_pair(c, w, P.wsamp[0], P.wsamp[1], LH_BLKSIZE, P.b.energy[w], P.b.energy[w + 2]);
     else if (w < n_chn_psy)
         lh_fft_energy(c, w, P.wsamp[0], P.wsamp[1], LH_BLKSIZE, P.b.energy[w]);
+#ifdef LH_AN_STAGE_S3
     /* the FHT buffers are free: the long-block spreading matrix goes there (as in the fused kernel) */
     float  *stg_s3 = &P.wsamp[0][0];
     LH_SYNC_WG_LDS();
@@ -381,6 +382,14 @@ lh_analysis_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm
         stg_s3[i] = T->psy_l.s3[i];
     LH_SYNC_WG_LDS();
     LH_AP(4);
+#else
+    /* (the long-block spreading matrix is read where it lies, in the L2: with four waves per SIMD its look-ups hide behind
+     * the other waves, and staging it cost a granule two barriers and an HBM round trip) */
+    const float *stg_s3 = T->psy_l.s3;
+    LH_WAVE_SYNC_MEM();
+    LH_AP(3);
+    LH_AP(4);
+#endif
     /* serial sums: total energy (bins 11..512) of chn w (lane 0) and w + 2 (lane 1), loudness of channel w (lane 2), in
      * bin order (reference psymodel.c:213-226, 690-696); see the fused kernel for the layout */
     {

@@ -12,6 +12,7 @@
 #include <stdarg.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <vector>
 #include <mutex>
 #include <thread>
@@ -1594,6 +1595,8 @@ struct lamehip_batch {
     long long mid_cap;
     int     split;              /* this batch's launches go through the split pipeline (batch_use_split) */
     hipEvent_t ev_part[2];
+    hipEvent_t ev_wait;         /* behind the launch, with hipEventBlockingSync: the host thread sleeps in lamehip_batch_sync instead of
+                                 * spinning on the stream (a rank per GPU must not burn a CPU per rank while its kernel runs) */
     float   part_ms[3];         /* analysis, sub-band, encode kernel of the last launch (0: fused launch) */
     int     last_split;
 };
@@ -1651,6 +1654,12 @@ batch_launch(lamehip_batch * b, const int16_t * pcm, const float *pcmf, const Lh
     if (rc)
         return set_err("kernel launch", (hipError_t) rc);
     HIPCHK(hipEventRecord(b->ev1, b->stream));
+    if (!b->ev_wait && hipEventCreateWithFlags(&b->ev_wait, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) {
+        (void) hipGetLastError();
+        b->ev_wait = nullptr;
+    }
+    if (b->ev_wait)
+        HIPCHK(hipEventRecord(b->ev_wait, b->stream));
     b->last_split = split;
     return 0;
 }
@@ -1770,6 +1779,7 @@ lamehip_batch_create_on(int device, const lame_t proto, int nstreams, long capac
     b->mid_cap = 0;
     b->split = batch_use_split();
     b->ev_part[0] = b->ev_part[1] = nullptr;
+    b->ev_wait = nullptr;
     b->part_ms[0] = b->part_ms[1] = b->part_ms[2] = 0;
     b->last_split = 0;
     if (proto->rs) {
@@ -1821,6 +1831,8 @@ lamehip_batch_destroy(lamehip_batch * b)
         (void) hipFree(b->d_pcmf);
     if (b->mid.frames)
         (void) hipFree(b->mid.frames);
+    if (b->ev_wait)
+        (void) hipEventDestroy(b->ev_wait);
     if (b->ev_part[0])
         (void) hipEventDestroy(b->ev_part[0]);
     if (b->ev_part[1])
@@ -2735,6 +2747,17 @@ lamehip_batch_sync(lamehip_batch * b)
     LhDeviceScope const on_device(b ? b->device : -1);
     if (!b)
         return -1;
+    if (b->ev_wait && b->launched) {
+        /* The wait for the launch: the runtime's own waits spin on the stream's signal whatever the event's flags say
+         * (measured: one CPU per rank for the whole launch), so the event is polled between short sleeps -- at most 100 us
+         * late on a launch of tens to hundreds of milliseconds, and the CPU is free meanwhile. */
+        hipError_t q;
+        struct timespec nap = { 0, 100000 };
+        while ((q = hipEventQuery(b->ev_wait)) == hipErrorNotReady)
+            nanosleep(&nap, nullptr);
+        if (q != hipSuccess)
+            return set_err("hipEventQuery", q);
+    }
     if (b->up_stream) {
         HIPCHK(hipStreamSynchronize(b->up_stream));
         HIPCHK(hipStreamSynchronize(b->down_stream));

@@ -42,7 +42,7 @@
 #endif
 #define LH_SB_CARRY ((LH_SB_GRANULE + 63) / 64)
 #ifndef LH_SB_RUN
-#define LH_SB_RUN 8             /* frames per workgroup: one recomputed granule per run */
+#define LH_SB_RUN 16            /* frames per workgroup: one recomputed granule per run */
 #endif
 
 #ifdef LH_LSF
