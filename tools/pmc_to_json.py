@@ -18,12 +18,15 @@ def workload_streams(workload):
 
 def main(pmc, stats, workload):
     v = {}
+    others = {}                 # the split pipeline's analysis kernels: counters per kernel
     kernel_name = "lh_encode_kernel"
     for line in open(pmc):
         p = line.split()
         if len(p) >= 5 and p[0].startswith("lh_encode"):
             v[p[1]] = (int(p[2]), float(p[3]), float(p[4]))
             kernel_name = p[0]
+        elif len(p) >= 5 and p[0].startswith("lh_") and not p[0].startswith("lh_summary"):
+            others.setdefault(p[0], {})[p[1]] = float(p[4])
     launches = max([x[0] for x in v.values()] + [1])
 
     def per(name):
@@ -39,9 +42,13 @@ def main(pmc, stats, workload):
     import bench
     out["csrc_sha256"] = bench.csrc_digest()
     if fetch is not None and write is not None:
-        out["hbm_bytes_per_launch"] = int(fetch * 1024 * 2 + write * 1024)
-        out["fetch_kib_reported"] = fetch
-        out["write_kib_reported"] = write
+        # (all kernels of a launch: the analysis kernels' traffic is part of the launch's)
+        ofetch = sum(o.get("FETCH_SIZE", 0.0) for o in others.values())
+        owrite = sum(o.get("WRITE_SIZE", 0.0) for o in others.values())
+        out["hbm_bytes_per_launch"] = int((fetch + ofetch) * 1024 * 2 + (write + owrite) * 1024)
+        out["hbm_bytes_per_launch_encode_kernel"] = int(fetch * 1024 * 2 + write * 1024)
+        out["fetch_kib_reported"] = fetch + ofetch
+        out["write_kib_reported"] = write + owrite
     for name in ("SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_BRANCH",
                  "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "SQ_LDS_BANK_CONFLICT", "SQ_ACTIVE_INST_LDS"):
         if name in v:
@@ -58,6 +65,12 @@ def main(pmc, stats, workload):
             f = [x.strip('"') for x in line.split(",")]
             try:
                 out["kernel_avg_ns"] = float(f[3])
+            except (ValueError, IndexError):
+                pass
+        elif line.startswith('"lh_') and "," in line:
+            f = [x.strip('"') for x in line.split(",")]
+            try:
+                others.setdefault(f[0], {})["avg_ns"] = float(f[3])
             except (ValueError, IndexError):
                 pass
     for name in ("SQ_INSTS_VMEM", "SQ_INSTS_FLAT", "SQ_INSTS_SMEM", "SQ_WAIT_INST_ANY", "GRBM_GUI_ACTIVE", "GRBM_COUNT"):
@@ -106,6 +119,27 @@ def main(pmc, stats, workload):
         out["wave_insts_per_frame"] = round(out["wave_insts_per_launch"] / out["frames_per_launch"], 1)
         out["shader_cycles_per_frame"] = round(out["shader_cycles_per_launch"] * int(workload_streams(workload))
                                                / out["frames_per_launch"], 1)
+    if others:
+        ks = {}
+        for name, o in sorted(others.items()):
+            k = {"avg_ns": o.get("avg_ns")}
+            insts = sum(o.get(n, 0.0) for n in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_BRANCH", "SQ_INSTS_VMEM",
+                                                "SQ_INSTS_SMEM"))
+            k["wave_insts_per_launch"] = round(insts)
+            if o.get("avg_ns") and out.get("shader_clock_ghz"):
+                cyc = o["avg_ns"] * out["shader_clock_ghz"]
+                k["insts_per_cycle_per_simd"] = round(insts / (1024 * cyc), 4)
+            if "SQ_WAVE_CYCLES" in o and o["SQ_WAVE_CYCLES"] > 0:
+                k["wait_frac"] = round(o.get("SQ_WAIT_ANY", 0.0) / o["SQ_WAVE_CYCLES"], 4)
+            if "SQ_ACTIVE_INST_LDS" in o:
+                k["lds_busy_quad_cycles"] = round(o["SQ_ACTIVE_INST_LDS"])
+                k["lds_bank_conflict_quad_cycles"] = round(o.get("SQ_LDS_BANK_CONFLICT", 0.0))
+            if "FETCH_SIZE" in o and "WRITE_SIZE" in o:
+                k["hbm_bytes_per_launch"] = int(o["FETCH_SIZE"] * 2048 + o["WRITE_SIZE"] * 1024)
+                if out.get("frames_per_launch"):
+                    k["hbm_bytes_per_frame"] = round(k["hbm_bytes_per_launch"] / out["frames_per_launch"], 1)
+            ks[name] = k
+        out["analysis_kernels"] = ks
     print(json.dumps(out, indent=1))
 
 
