@@ -40,14 +40,10 @@
 #define LH_SYNC_WG_LDS() do { __syncthreads(); } while (0)
 #else
 #define LH_SYNC_WG() do { __syncthreads(); } while (0)
-#if defined(LH_FULL_FENCE)
-#define LH_SYNC_WG_LDS() do { __syncthreads(); } while (0)
-#else
 #define LH_SYNC_WG_LDS() do { \
                               __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); \
                               __builtin_amdgcn_s_barrier(); \
                               __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); } while (0)
-#endif
 #endif
 
 #if defined(LH_PROF) && !defined(LH_EMU)

@@ -252,7 +252,6 @@ lh_psy_granule(int gr, LhPsyCarry nb)
     /* (2) attack detection (reference psymodel.c:759-940) */
     {
         int const firbase = bufbase + 576 - 350 - LH_NSFIRLEN + 192;
-#if LH_FIR_BLOCKED
         {
             /* A lane filters NINE CONSECUTIVE samples: their 22-sample windows overlap in all but one place, so the lane reads
              * 30 samples once (15 two-word reads, conflict-free at a stride of nine words) instead of 21 per output -- 189 --,
@@ -273,20 +272,6 @@ lh_psy_granule(int gr, LhPsyCarry nb)
                 P.a.hpf[w][i0 + m] = sum1 + sum2;
             }
         }
-#else
-        for (int i = lane; i < 576; i += 64) {
-            float   sum1, sum2;
-            sum1 = lh_smp(c, w, firbase + i + 10);
-            sum2 = 0.0;
-            for (int j = 0; j < ((LH_NSFIRLEN - 1) / 2) - 1; j += 2) {
-                sum1 += lh_hp_fir[j] * (lh_smp(c, w, firbase + i + j) +
-                                        lh_smp(c, w, firbase + i + LH_NSFIRLEN - j));
-                sum2 += lh_hp_fir[j + 1] * (lh_smp(c, w, firbase + i + j + 1) +
-                                            lh_smp(c, w, firbase + i + LH_NSFIRLEN - j - 1));
-            }
-            P.a.hpf[w][i] = sum1 + sum2;
-        }
-#endif
     }
     LH_SYNC_WG_LDS();
     for (int pass = 0; pass < 2; pass++) {
@@ -461,7 +446,6 @@ lh_psy_granule(int gr, LhPsyCarry nb)
                 prod[j - j0] = P.b.energy[w][j] * ew[j];
             }
             LH_WAVE_SYNC_MEM();
-#if LH_PSY_PREFETCH
             if (summing) {
                 /* sixteen terms per trip; the next sixteen are read before this trip's additions, so the chain waits
                  * for its own additions only (a read issued when its terms are due costs the chain ~20 cycles a term) */
@@ -497,24 +481,6 @@ lh_psy_granule(int gr, LhPsyCarry nb)
                     a3 = b3;
                 }
             }
-#else
-            if (summing) {
-                const float *src = loud ? prod - j0 : e;
-                int     j = j0;
-                if (h == 0) {
-                    for (; j < 12; j++)
-                        acc += (j >= lo) ? src[j] : 0.0f;
-                }
-#pragma unroll 4
-                for (; j < j0 + 256; j += 4) {
-                    lh_f32x4 const u = *(const lh_f32x4 *) &src[j];
-                    acc += u.x;
-                    acc += u.y;
-                    acc += u.z;
-                    acc += u.w;
-                }
-            }
-#endif
         }
         if (summing) {
             if (!loud) {
@@ -751,7 +717,6 @@ lh_psy_granule(int gr, LhPsyCarry nb)
             is_short = (type == LH_SHORT_TYPE);
             nterms = is_short ? 3 * (LH_SBMAX_S - 1) : LH_SBMAX_L - 1;
             LH_WAVE_SYNC_MEM();
-#if LH_PE_REGS
             {
                 /* The terms stay in their lanes' registers (0.0 beyond the last one) and the accumulation -- a chain of
                  * float <- double additions in band order, the same in every lane -- takes term i from lane i with two
@@ -790,33 +755,6 @@ lh_psy_granule(int gr, LhPsyCarry nb)
                     lh_lds.ss.last_attacks[chn] = L.ns_attacks[chn][2];
                 }
             }
-#else
-            if (lane < nterms) {
-                int const idx = is_short ? 22 + lane : lane;
-                float const coef = is_short ? lh_regcoef_s[lane / 3] : lh_regcoef_l[lane];
-                float const t = L.psy_thm[was][chn][idx];
-                double  term = 0.0;
-                if (t > 0.0f) {
-                    float const x = t * lh_lds.ss.masking_lower;
-                    float const e = L.psy_en[was][chn][idx];
-                    if (e > x) {
-                        if (e > x * 1e10f)
-                            term = coef * (10.0f * 2.30258509299404568402);
-                        else
-                            term = coef * (lh_fast_log2(T->log_table, e / x) * LH_LOG2_OVER_LOG10);
-                    }
-                }
-                tmp[lane] = term;
-            }
-            LH_WAVE_SYNC_MEM();
-            if (lane == 0) {
-                float   pe = is_short ? 1236.28f / 4 : 1124.23f / 4;
-                for (int i = 0; i < nterms; i++)
-                    pe = (float) (pe + tmp[i]);
-                L.pe[gr][chn] = pe;
-                lh_lds.ss.last_attacks[chn] = L.ns_attacks[chn][2];
-            }
-#endif
         }
     }
     LH_SYNC_WG_LDS();

@@ -124,16 +124,6 @@ lh_rot(float c, float s, float x, float y)
     return r;
 }
 
-#ifndef LH_FIR_BLOCKED
-#define LH_FIR_BLOCKED 1        /* attack detection: a lane filters nine consecutive samples from one set of 30 reads (A/B switch) */
-#endif
-#ifndef LH_PE_REGS
-#define LH_PE_REGS 1            /* perceptual entropy: the terms from their lanes' registers instead of an LDS array walked by one lane (A/B switch) */
-#endif
-#ifndef LH_FHT_UNIFIED
-#define LH_FHT_UNIFIED 1        /* FHT units on and off a block's axes through one set of loads and stores (A/B switch) */
-#endif
-#if LH_FHT_UNIFIED
 /* One radix-4 butterfly unit.  A unit on its block's axes (i == 0) and one off them read and write the same eight places --
  * lo + {0, k1, k2, k3} and hi + {0, k1, k2, k3} with hi = lo + kx on the axes and the mirror position k1 - i off them -- and
  * differ in the arithmetic in between; a wave has both kinds in every pass.  Both are computed from ONE set of loads and the
@@ -175,55 +165,6 @@ lh_fht_unit(lh_f32x4 tw, float *fz, int k1, int u)
     hi[k2] = axis ? a_h2 : he - rb.along;
     hi[k3] = axis ? a_h3 : hm - ra.across;
 }
-#else
-LH_DEVFN void
-lh_fht_unit(lh_f32x4 tw, float *fz, int k1, int u)
-{
-    int const kx = k1 >> 1;
-    int const k2 = k1 << 1, k3 = k2 + k1, k4 = k2 << 1;
-    int const blk = u / kx, i = u - blk * kx;
-    if (i == 0) {
-        /* the unit on the block's axes: no rotation, the mirrored quarter only scales by sqrt 2 */
-        float  *lo = fz + blk * k4;
-        float  *hi = lo + kx;
-        float const p0 = lo[0], p1 = lo[k1], p2 = lo[k2], p3 = lo[k3];
-        float const s01 = p0 + p1, d01 = p0 - p1, s23 = p2 + p3, d23 = p2 - p3;
-        float const q0 = hi[0], q1 = hi[k1];
-        float const r2 = (float) (LH_SQRT2 * hi[k2]), r3 = (float) (LH_SQRT2 * hi[k3]);
-        float const t01 = q0 + q1, u01 = q0 - q1;
-        lo[0] = s01 + s23;
-        lo[k1] = d01 + d23;
-        lo[k2] = s01 - s23;
-        lo[k3] = d01 - d23;
-        hi[0] = t01 + r2;
-        hi[k1] = u01 + r3;
-        hi[k2] = t01 - r2;
-        hi[k3] = u01 - r3;
-    }
-    else {
-        /* position i and its mirror k1 - i: the second and fourth quarters turn by the double angle
-         * (tw.z, tw.w), then the two half-sums turn by the single angle (tw.x, tw.y) */
-        float  *lo = fz + blk * k4 + i;
-        float  *hi = fz + blk * k4 + k1 - i;
-        LhRot const q1 = lh_rot(tw.z, tw.w, lo[k1], hi[k1]);
-        LhRot const q3 = lh_rot(tw.z, tw.w, lo[k3], hi[k3]);
-        float const le = lo[0] + q1.along, lm = lo[0] - q1.along;
-        float const he = hi[0] + q1.across, hm = hi[0] - q1.across;
-        float const l2e = lo[k2] + q3.along, l2m = lo[k2] - q3.along;
-        float const h2e = hi[k2] + q3.across, h2m = hi[k2] - q3.across;
-        LhRot const ra = lh_rot(tw.x, tw.y, l2e, h2m);
-        LhRot const rb = lh_rot(tw.y, tw.x, h2e, l2m);
-        lo[0] = le + ra.along;
-        lo[k2] = le - ra.along;
-        hi[k1] = hm + ra.across;
-        hi[k3] = hm - ra.across;
-        hi[0] = he + rb.along;
-        hi[k2] = he - rb.along;
-        lo[k1] = lm + rb.across;
-        lo[k3] = lm - rb.across;
-    }
-}
-#endif
 
 LH_DEVFN unsigned
 lh_rev8(unsigned v)
@@ -622,12 +563,6 @@ struct LhMaskChan {
     LhMidMask *raw;             /* analysis kernels (FRONT): where the values before the recurrences go (HBM), see LhMidMask */
 };
 
-#ifndef LH_PSY_PREFETCH
-#define LH_PSY_PREFETCH 1       /* serial sums of the spectrum: the next block's reads before this block's additions (A/B switch) */
-#endif
-#ifndef LH_PSY_EXEC
-#define LH_PSY_EXEC 1           /* partition sums: lanes switched off by EXEC as their partitions end (A/B switch) */
-#endif
 
 /* FRONT = 1 (analysis kernels, lh_analysis.hip): everything up to the recurrences -- the partition's energy, its spread
  * energy x weight and its cap go to ch[].raw (HBM); the encode kernel's lh_masking_tail (lh_dev_psy.h) takes it from there.
@@ -662,22 +597,19 @@ lh_compute_masking(const LhCtx & c, int is_long, const LhMaskChan (&ch)[NC], con
         int const j0 = (int) lh_wave_scan_u32((uint32_t) n) - n;      /* the partition's first line */
         float const rn = on ? t_rnum : 0.0f;
         int const nmax = lh_uni_i((int) lh_wave_max_u32((uint32_t) n));
-#if LH_PSY_EXEC && !defined(LH_EMU)
+#if !defined(LH_EMU)
         /* On the device the lanes are switched off as their partitions end (v_cmpx narrows EXEC before every term, a
          * lane that is off keeps sum and maximum): three instructions per term and channel, nothing selected per
          * load.  The loads run on past a partition's end (the channel's spectrum, then whatever follows it in the
          * workgroup's image); EXEC is restored after each block of eight terms. */
-#if LH_PSY_PREFETCH
         float   nx[NC][8];
 #pragma unroll
         for (int q = 0; q < NC; q++)
 #pragma unroll
             for (int u = 0; u < 8; u++)
                 nx[q][u] = ch[q].energy[j0 + u];
-#endif
         for (int i = 0; i < nmax; i += 8) {
             int const rem = n - i;
-#if LH_PSY_PREFETCH
             /* the next block's terms are read before this block's additions (the last trip reads a block nobody adds) */
             float   cu[NC][8];
 #pragma unroll
@@ -687,15 +619,9 @@ lh_compute_masking(const LhCtx & c, int is_long, const LhMaskChan (&ch)[NC], con
                     cu[q][u] = nx[q][u];
                     nx[q][u] = ch[q].energy[j0 + i + 8 + u];
                 }
-#endif
 #pragma unroll
             for (int q = 0; q < NC; q++) {
-#if LH_PSY_PREFETCH
                 float const a0 = cu[q][0], a1 = cu[q][1], a2 = cu[q][2], a3 = cu[q][3], a4 = cu[q][4], a5 = cu[q][5], a6 = cu[q][6], a7 = cu[q][7];
-#else
-                const float *src = ch[q].energy + j0 + i;
-                float const a0 = src[0], a1 = src[1], a2 = src[2], a3 = src[3], a4 = src[4], a5 = src[5], a6 = src[6], a7 = src[7];
-#endif
                 unsigned long long sv, tm;
 #define LH_PS_TERM(K, A) "v_cmpx_gt_i32_e64 %[tm], %[rem], " #K "\n\tv_add_f32 %[eb], %[eb], %[" #A "]\n\tv_max_f32 %[mx], %[mx], %[" #A "]\n\t"
                 asm volatile("s_mov_b64 %[sv], exec\n\t"

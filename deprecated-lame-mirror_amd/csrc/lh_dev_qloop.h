@@ -26,19 +26,6 @@
 #include "lh_dev_quant.h"
 
 
-/* A/B switches of the search (tools/build_variants.sh); the values here are the product's */
-#ifndef LH_QUANT_EARLY
-#define LH_QUANT_EARLY 1        /* quantiser: products and threshold look-ups issued ahead of the band-mask logic */
-#endif
-#ifndef LH_CN_ZERO
-#define LH_CN_ZERO 1            /* calc_noise: all-zero bands take their noise from a constant of the granule */
-#endif
-#ifndef LH_LOGT
-#define LH_LOGT 1               /* calc_noise: the logarithm's table from its LDS copy (lh_dev_common.h) instead of HBM */
-#endif
-#ifndef LH_CN_EXEC
-#define LH_CN_EXEC 1            /* calc_noise: band sums stop by EXEC mask instead of keeping a copy per pair */
-#endif
 struct LhQS {
     /* lane = pair slots */
     float   xp[10];             /* xrpow */
@@ -241,7 +228,6 @@ lq_quantize(const LhCtx & c, LhQS & S, const LhQR & R, const LhGrR & g)
         if (LH_RARE(lh_ballot(S.lmax > thr)))
             return 0;
     }
-#if LH_QUANT_EARLY
     /* the products, their first rounding and the look-ups of the second one go out BEFORE the band masks are formed
      * (scalar work with branches of its own): the masks then fill the look-ups' LDS round trip instead of preceding it */
     float   qa[10], qt_[10];
@@ -255,7 +241,6 @@ lq_quantize(const LhCtx & c, LhQS & S, const LhQR & R, const LhGrR & g)
         qt_[2 * k] = qt->qthr[qb[2 * k] & 255u];
         qt_[2 * k + 1] = qt->qthr[qb[2 * k + 1] & 255u];
     }
-#endif
     /* ---- which bands are quantised, and how (lane = band) ---- */
     uint64_t ncmask = 0, m01mask = 0;
     int     zero_mnc = 0, plain = 1;
@@ -290,15 +275,9 @@ lq_quantize(const LhCtx & c, LhQS & S, const LhQR & R, const LhGrR & g)
         uint32_t bmax = 0;
 #pragma unroll
         for (int k = 0; k < NS; k++) {
-#if LH_QUANT_EARLY
             float const a0 = qa[2 * k], a1 = qa[2 * k + 1];
             uint32_t const b0 = qb[2 * k], b1 = qb[2 * k + 1];
             float const t0 = qt_[2 * k], t1 = qt_[2 * k + 1];
-#else
-            float const a0 = istep * S.xp[2 * k], a1 = istep * S.xp[2 * k + 1];
-            uint32_t const b0 = lh_f32_as_u32(a0 + (float) LH_MAGIC_FLOAT), b1 = lh_f32_as_u32(a1 + (float) LH_MAGIC_FLOAT);
-            float const t0 = qt->qthr[b0 & 255u], t1 = qt->qthr[b1 & 255u];
-#endif
             uint32_t const r0 = b0 - (a0 < t0 ? 1u : 0u), r1 = b1 - (a1 < t1 ? 1u : 0u);
             bmax = b0 > bmax ? b0 : bmax;
             bmax = b1 > bmax ? b1 : bmax;
@@ -599,7 +578,7 @@ lq_band_sums(const float *sq, int n, int jj, int maxw, int fresh)
          * address select per load.  Eight terms per trip from two 16-byte reads (band starts are even, the array is
          * 16-byte aligned: a band that starts on an odd pair reads its first pair alone). */
         const lh_f32x2 *sq2 = (const lh_f32x2 *) sq;
-#if LH_CN_EXEC && !defined(LH_EMU)
+#if !defined(LH_EMU)
         /* On the device the lanes are switched off as their bands end: v_cmpx narrows EXEC after every pair of
          * terms and a lane that is off keeps its sum -- three instructions per pair of terms instead of five, no copy
          * to keep.  Sixteen terms per block from four 16-byte reads (ds_read2_b64: a band may start on an odd pair,
@@ -682,7 +661,6 @@ lq_band_sums(const float *sq, int n, int jj, int maxw, int fresh)
 template < int NS > LH_DEVFN void
 lq_zero_band_noise(const LhCtx & c, LhQS & S, const LhQR & R, LhChanLds & Q, const float *xr)
 {
-#if LH_CN_ZERO
     float  *sq = Q.xrpow;
     int const s = c.lane;
     int const mine = (s < R.psymax);
@@ -711,7 +689,6 @@ lq_zero_band_noise(const LhCtx & c, LhQS & S, const LhQR & R, LhChanLds & Q, con
     maxw = (int) lh_wave_max_u32(mine ? (unsigned) (2 * l) : 0u);
     S.zk = lq_band_sums(sq, 2 * l, (j < 576) ? (j >> 1) : 0, maxw, mine);
     LH_WAVE_SYNC();
-#endif
 }
 
 /* What calc_noise finds for the working image, before it is taken over: the band's entry of calc_noise_data
@@ -739,9 +716,7 @@ lq_calc_noise(const LhCtx & c, const LhQS & S, const LhQR & R, const LhGrR & g, 
     LQ_MARK("cn_begin");
     int const st = lq_band_step(S, g);
     int const fresh = (s < R.psymax) && !(S.pnstep == st);
-#if LH_CN_ZERO
     int const zb = fresh && (S.sta >= S.nzend);
-#endif
     /* POW20(st) = 2^((st - 210) / 4): one of four mantissas (the table's own entries for 210..213,
      * in scalar registers) times a power of two -- pow20[i + 4] = 2 pow20[i] holds for the whole
      * table (power_tables_scale_exactly(), lh_host_init.c), so no table look-up is needed */
@@ -776,12 +751,10 @@ lq_calc_noise(const LhCtx & c, const LhQS & S, const LhQR & R, const LhGrR & g, 
             p43[2 * k + 1] = qt->pow43h[q1 & 255u];
             big |= (int) ((q0 | q1) >> 8);
         }
-#if LH_CN_ZERO
         /* a band that starts at or above the end of the non-zero lines adds up the squares of its own lines, whatever
          * the step: the constant is there since lq_zero_band_noise, and the band sits out the serial sum below (the
          * widest bands are at the top of the spectrum, where little is quantised to anything else) */
         l = zb ? 0 : l;
-#endif
         maxw = (int) lh_wave_max_u32(fresh ? (unsigned) (2 * l) : 0u);
         if (LH_RARE(lh_ballot(big != 0))) {
 #pragma unroll
@@ -811,9 +784,7 @@ lq_calc_noise(const LhCtx & c, const LhQS & S, const LhQR & R, const LhGrR & g, 
         int const n = 2 * l;
         int const jj = (j < 576) ? (j >> 1) : 0;
         noise = lq_band_sums(sq, n, jj, maxw, fresh);
-#if LH_CN_ZERO
         noise = zb ? S.zk : noise;
-#endif
     }
     LQ_MARK("cn_log");
     t.pnstep = S.pnstep;
@@ -830,14 +801,9 @@ lq_calc_noise(const LhCtx & c, const LhQS & S, const LhQR & R, const LhGrR & g, 
             t.pnstep = st;
             t.pnnoise = noise;
             distort_ = S.rxmin * noise;
-#if LH_LOGT
             float   l2;
             LH_FAST_LOG2_VIA(LH_LOGT_LDS, (distort_ > 1E-20f) ? distort_ : 1E-20f, l2);
             noise = (float) (l2 * LH_LOG2_OVER_LOG10);
-#else
-            noise = (float) (lh_fast_log2(T->log_table, (distort_ > 1E-20f) ? distort_ : 1E-20f)
-                             * LH_LOG2_OVER_LOG10);
-#endif
             t.pnlog = noise;
         }
         t.dist = distort_;

@@ -1219,9 +1219,6 @@ lh_best_scalefac_store(int qch, int gr, const int8_t * g0sf, int g0_block_type)
  * choose_table (takehiro.c:546-650) becomes a difference of prefix sums per candidate table.
  * Ten words per band: seven hold two tables each (16 bits per half: a band has < 2^16 bits),
  * then the ESC pair (largetbl layout), the count of values >= 15 and the count of non-zero pairs. */
-#ifndef LH_BHD_DPP
-#define LH_BHD_DPP 1            /* best_huffman_divide: scans and lane shifts on the DPP network, table words by selects (A/B switch) */
-#endif
 #define LH_BHD_NW 10
 #define LH_BHD_STRIDE 24
 
@@ -1307,7 +1304,6 @@ lh_bhd_region(const int *tab, unsigned mx, int blo, int bhi, const unsigned (&qw
 #pragma unroll
     for (int j = 0; j < LH_BHD_NW - 1; j++)
         d[j] = (unsigned) (tab[j * LH_BHD_STRIDE + bhi] - tab[j * LH_BHD_STRIDE + blo]) - qw[j];
-#if LH_BHD_DPP
     {
         /* (the words of the region's candidate tables picked by selects: the lanes of a wave hold all kinds of maxima, and
          * as a chain of branches every kind present ran on its own) */
@@ -1318,36 +1314,6 @@ lh_bhd_region(const int *tab, unsigned mx, int blo, int bhi, const unsigned (&qw
         w1 = (mx > 15u) ? d[8] : (mx >= 8u) ? (d[6] >> 16) : (mx >= 6u) ? (d[5] & 0xffffu) : (mx >= 4u) ? (d[3] >> 16) : 0u;
         return lh_region_decide(mx, w0, w1, bits);
     }
-#endif
-    if (mx > 15u) {
-        w0 = d[7];
-        w1 = d[8];
-    }
-    else if (mx == 1u) {
-        w0 = d[0] & 0xffffu;
-        w1 = 0;
-    }
-    else if (mx == 2u) {
-        w0 = (d[0] >> 16) | ((d[1] & 0xffffu) << 16);
-        w1 = 0;
-    }
-    else if (mx == 3u) {
-        w0 = (d[1] >> 16) | ((d[2] & 0xffffu) << 16);
-        w1 = 0;
-    }
-    else if (mx <= 5u) {
-        w0 = (d[2] >> 16) | ((d[3] & 0xffffu) << 16);
-        w1 = d[3] >> 16;
-    }
-    else if (mx <= 7u) {
-        w0 = d[4];
-        w1 = d[5] & 0xffffu;
-    }
-    else {
-        w0 = (d[5] >> 16) | ((d[6] & 0xffffu) << 16);
-        w1 = d[6] >> 16;
-    }
-    return lh_region_decide(mx, w0, w1, bits);
 }
 
 /* lane l holds v[l]: *below = max(v[0 .. l)), *from = max(v[l .. 63]) (log-step scans through lane
@@ -1355,7 +1321,7 @@ lh_bhd_region(const int *tab, unsigned mx, int blo, int bhi, const unsigned (&qw
 LH_DEVFN void
 lh_bhd_scan_max(int lane, unsigned v, unsigned *below, unsigned *from)
 {
-#if LH_BHD_DPP && !defined(LH_EMU)
+#if !defined(LH_EMU)
     /* On the device, for the caller there is (v = 0 from lane 32 on: 22 bands): both scans on the DPP network instead of
      * thirteen round trips through the LDS crossbar.  The running maximum is lh_wave_scan_max_u32 and a shift by one
      * lane; the maximum from a lane on is a scan towards lower lanes inside the rows of sixteen (row_shl 1, 2, 4, 8), and
@@ -1397,7 +1363,7 @@ lh_bhd_scan_max(int lane, unsigned v, unsigned *below, unsigned *from)
 LH_DEVFN unsigned
 lh_bhd_scan_min_excl(int lane, unsigned v)
 {
-#if LH_BHD_DPP && !defined(LH_EMU)
+#if !defined(LH_EMU)
     {
         /* the same on the DPP network: row_shr 1, 2, 4, 8, row_bcast 15 / 31, then one lane up (seven round trips
          * through the LDS crossbar otherwise) */
@@ -1466,7 +1432,7 @@ lh_best_huffman_divide_body(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGr
         {
             /* region 0 = bands [0, r0]: its maximum is the next lane's `below' (exchanged by all lanes:
              * a lane that sits out cannot be read from) */
-#if LH_BHD_DPP && !defined(LH_EMU)
+#if !defined(LH_EMU)
             unsigned const mx0 = lh_dpp < 0x130, 0u > (max_below);      /* wave_shl:1 (lanes 0..15 are looked at) */
 #else
             unsigned const mx0 = lh_shfl_u32(max_below, (lane + 1) & 63);
@@ -1633,7 +1599,7 @@ lh_best_huffman_divide_body(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGr
                     return;     /* not reachable for long blocks; the reference's general case is not built */
             }
             /* the sum r0 + r1 = r2 - 2 is lane r2 - 2's */
-#if LH_BHD_DPP && !defined(LH_EMU)
+#if !defined(LH_EMU)
             /* (two lanes up on the DPP network; lanes 0 and 1 are not looked at) */
             lower = (int) lh_dpp < 0x138, 0u > (lh_dpp < 0x138, 0u > ((uint32_t) s_bits));
 #else

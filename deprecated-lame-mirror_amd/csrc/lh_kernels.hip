@@ -98,16 +98,6 @@ lh_load_qtabs(const LhCtx & c, LhQTabs & q)
     static_assert(sizeof(q.ht_len) % 4 == 0 && __builtin_offsetof(LhQTabs, ht_len) % 4 == 0, "ht_len is copied by words");
     for (int i = c.tid; i < (int) sizeof(q.ht_len) / 4; i += LH_NT)
         ((uint32_t *) q.ht_len)[i] = ((const uint32_t *) lh_ht_len)[i];
-#ifdef LH_QTABS_OLD             /* (A/B: the staging as it was -- two dependent pairs of loads per entry, code lengths by bytes) */
-    for (int i = c.tid; i < (int) sizeof(q.ht_len); i += LH_NT)
-        q.ht_len[i] = lh_ht_len[i];
-    for (int i = c.tid; i < 288; i += LH_NT) {
-        int const bv = 2 * i + 2;
-        int const r0 = c.T->bv_scf[bv - 2], r1 = c.T->bv_scf[bv - 1];
-        int const a1 = c.T->sfb_l[r0 + 1], a2 = c.T->sfb_l[(r0 + r1 + 2 < LH_SBMAX_L) ? r0 + r1 + 2 : LH_SBMAX_L];
-        q.bvpack[i] = (uint32_t) r0 | ((uint32_t) r1 << 4) | ((uint32_t) a1 << 8) | ((uint32_t) a2 << 18);
-    }
-#else
     {
         /* the region split by big_values, folded with the band edges by the host (LhTables.bvpack): three loads in
          * flight per thread instead of two dependent pairs per entry */
@@ -117,7 +107,6 @@ lh_load_qtabs(const LhCtx & c, LhQTabs & q)
         if (c.tid < 32)
             q.bvpack[256 + c.tid] = b2;
     }
-#endif
     if (c.tid == 0) {
         q.sfb_s3 = (uint16_t) c.T->sfb_s[3];
         q.pad = 0;
@@ -265,7 +254,7 @@ lh_prepare_granule(const LhCtx & c, int ch, int gr, int msoff, int substep)
 }
 
 
-#if !defined(LH_EMU) && !defined(LH_NO_PRIO)
+#if !defined(LH_EMU)
 /* Issue priority by progress and by role.  At 1024 streams every SIMD hosts two waves of two different streams for the whole
  * launch, and the SIMD's issue arbiter prefers the older of two ready waves: identical streams finish up to 14 % apart
  * depending on where the dispatcher put them (tools/stream_balance.py, tools/ubench/hwid.hip), streams that differ in content
@@ -288,9 +277,6 @@ lh_prio_index()
 LH_DEVFN void
 lh_prio_apply(int rel, int late)
 {
-#ifdef LH_PRIO_NOROLE
-    late = 0;
-#endif
     int const level = lh_uni_i(rel > 0 ? 3 : rel < 0 ? 0 : 1 + (late != 0));
     if (level == 3)
         __builtin_amdgcn_s_setprio(3);
@@ -975,9 +961,6 @@ lh_encode_stream(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, 
 
 #ifndef LH_EMU
 extern "C" __global__ void __launch_bounds__(LH_BLOCK, LH_WAVES_PER_EU)
-#ifdef LH_NOTAIL
-__attribute__((disable_tail_calls))
-#endif
 #else
 void
 #endif

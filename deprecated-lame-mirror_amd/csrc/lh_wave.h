@@ -307,13 +307,8 @@ __device__ __forceinline__ int lh_wave_id(void) { return (int) (threadIdx.x >> 6
  * from moving LDS accesses across the point where lanes exchange data through
  * LDS, and waits for outstanding LDS operations.  The fence names the LDS address space
  * only: HBM loads in flight (table look-ups) are not drained by it. */
-#ifdef LH_FULL_FENCE
-#define LH_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); \
-                            __builtin_amdgcn_wave_barrier(); } while (0)
-#else
 #define LH_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local"); \
                             __builtin_amdgcn_wave_barrier(); } while (0)
-#endif
 /* LDS exchange inside one wave without draining it: a wave's DS instructions are executed in the
  * order they were issued, so a read that follows another lane's write in program order sees it;
  * all that is needed is that the compiler keeps that order (no s_waitcnt here -- the reads can be
@@ -445,9 +440,6 @@ lh_shfl_u32(uint32_t v, int src)
     return (uint32_t) __builtin_amdgcn_ds_bpermute(src << 2, (int) v);
 }
 
-#ifndef LH_PERMLANE_SWAP
-#define LH_PERMLANE_SWAP 1      /* the transposed reductions' last two steps by v_permlane16_swap / v_permlane32_swap (A/B switch) */
-#endif
 /* Wave totals of four packed words at once, delivered where count_bits needs them.  p0..p2 hold three
  * 10-bit fields a | b << 10 | c << 20 each (per-lane values below 2^7: eight lanes add up without a carry),
  * q two 16-bit fields.  Three butterfly steps sum every word over the lane's group of eight; then the
@@ -470,7 +462,6 @@ lh_wave_sum_regions(uint32_t p0, uint32_t p1, uint32_t p2, uint32_t q, uint32_t 
     uint32_t const cc = is_q ? 0u : (w >> 20);
     uint32_t x = (lane & 4) ? cc : ab;
     x += lh_dpp < 0x128, 0u > (x);      /* row_ror:8: the other group of eight of the row, same position */
-#if LH_PERMLANE_SWAP
     /* lane ^ 16 and lane ^ 32 on the vector unit (gfx950's row / half swaps of two registers: with the value in both, one
      * comes back as "mine or my partner's lower copy", the other as the upper copy, and their sum is the pair's total in
      * every lane) -- two instructions and a copy each instead of a round trip through the LDS crossbar on count_bits' chain */
@@ -480,10 +471,6 @@ lh_wave_sum_regions(uint32_t p0, uint32_t p1, uint32_t p2, uint32_t q, uint32_t 
         auto const r32 = __builtin_amdgcn_permlane32_swap(x, x, false, false);
         x = r32[0] + r32[1];
     }
-#else
-    x += (uint32_t) __builtin_amdgcn_ds_swizzle((int) x, 0x401F);       /* lane ^ 16 */
-    x += (uint32_t) __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, (int) x);
-#endif
     *L = x;
     *H = lh_dpp < 0x104, 0u > (x);      /* row_shl:4: lane r reads lane r + 4 */
     return (uint32_t) __builtin_amdgcn_readlane((int) x, 3);
@@ -509,19 +496,12 @@ lh_wave_max8(const uint32_t (&w)[8])
     uint32_t t;
     t = lh_dpp < 0x128, 0u > (x);
     x = t > x ? t : x;
-#if LH_PERMLANE_SWAP
     {
         auto const r16 = __builtin_amdgcn_permlane16_swap(x, x, false, false);
         x = r16[0] > r16[1] ? r16[0] : r16[1];
         auto const r32 = __builtin_amdgcn_permlane32_swap(x, x, false, false);
         x = r32[0] > r32[1] ? r32[0] : r32[1];
     }
-#else
-    t = (uint32_t) __builtin_amdgcn_ds_swizzle((int) x, 0x401F);
-    x = t > x ? t : x;
-    t = (uint32_t) __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, (int) x);
-    x = t > x ? t : x;
-#endif
     return x;
 }
 
