@@ -2487,8 +2487,8 @@ lamehip_batch_encode(lamehip_batch * b)
         return LAMEHIP_ERR_DEVICE;
     {
         int const top = (b->cfg.vbr == 0) ? b->cfg.bitrate_index : b->cfg.vbr_max_bitrate_index;
-        static const int kbps[16] = { 0, 32, 40, 48, 56, 64, 80, 96, 112, 128, 160, 192, 224, 256, 320, 0 };
-        max_frame_bytes = (b->cfg.version + 1) * 72000 * kbps[top & 15] / b->cfg.samplerate + 1;
+        /* (the row of the stream's MPEG version: an MPEG-2 / 2.5 index stands for half the MPEG-1 rate or less) */
+        max_frame_bytes = (b->cfg.version + 1) * 72000 * lh_tag_kbps(b->cfg.version, top & 15) / b->cfg.samplerate + 1;
     }
     for (int s = 0; s < b->B; s++) {
         LhStreamDesc & d = b->h_desc[(size_t) s];

@@ -14,7 +14,7 @@ extern "C" {
 #endif
 
 #define LH_NPROF 44             /* cycle accumulators per wave (profiling builds) */
-#define LH_EMIT_HQ_MAX 128      /* frame headers that can be pending inside a stretch of main data (device bit packer) */
+#define LH_EMIT_HQ_MAX 256      /* frame headers that can be pending inside a stretch of main data (device bit packer; the host packer and the reference hold 256 as well: MAX_HEADER_BUF) */
 #define LH_XMIN_N 61            /* 22 long + 13*3 short values of III_psy_xmin */
 
 typedef struct LhStreamState {

@@ -82,7 +82,7 @@ class Encoder:
     """One stream behind the lame.h call sequence."""
 
     def __init__(self, samplerate=44100, brate=128, mode=None, quality=None, require_device=True, write_tag=False,
-                 vbr_q=None, out_samplerate=0, abr=None, channels=2, device=None, vbr_mode=4):
+                 vbr_q=None, out_samplerate=0, abr=None, channels=2, device=None, vbr_mode=4, error_protection=False):
         self.lib = load_library()
         self.h = C.c_void_p(self.lib.lame_init())
         if device is not None:      # HIP device of the handle's own launches (lamehip_set_device)
@@ -101,6 +101,8 @@ class Encoder:
             self.lib.lame_set_VBR(self.h, vbr_mode)
             self.lib.lame_set_VBR_q(self.h, vbr_q)
         self.lib.lame_set_bWriteVbrTag(self.h, 1 if write_tag else 0)
+        if error_protection:        # CRC-16 behind the header (the reference's -p)
+            self.lib.lame_set_error_protection(self.h, 1)
         if mode is not None:
             self.lib.lame_set_mode(self.h, mode)
         if quality is not None:

@@ -620,6 +620,27 @@ def test_device_bit_packer_long_streams(kw):
 
 
 @pytest.mark.gpu
+def test_device_bit_packer_holds_every_pending_header_of_the_smallest_frames():
+    """24 kHz, 8 kb/s, stereo, CRC: frames of 24 bytes with 23 of header + side information, one byte of main data each --
+    digital silence fills the 255-byte reservoir, so up to 255 frame headers lie inside one stretch of main data.  The
+    device packer's queue of pending headers holds 256 like the host packer's and the reference's (MAX_HEADER_BUF); with
+    128 the kernel raised status bit 8 and the stream was refused."""
+    enc = lamehip.Encoder(24000, 8, error_protection=True)
+    n = 24000 * 20
+    pcms = [np.zeros((2, n), np.int16), helpers.synth_stream(77, n, 24000, 0.25)]
+    pcms[1][:, n // 3:] = 0                             # music, then silence
+    b = lamehip.Batch(enc, len(pcms), n)
+    b.set_device_packing()
+    for i, x in enumerate(pcms):
+        b.set_pcm(i, x[0], x[1])
+    b.encode()
+    for i in range(len(pcms)):
+        assert b.get_bytes(i) == b.pack(i)
+    b.close()
+    enc.close()
+
+
+@pytest.mark.gpu
 def test_bench_spawns_its_own_ranks():
     """python bench.py --gpus 2 without a launcher: two ranks (sharing this box's device when it has
     one), a file barrier, ONE JSON line with the aggregate of both."""

@@ -57,6 +57,10 @@ def main():
         prof = np.frombuffer(buf.raw[-2 * NP * 8:], dtype=np.uint64).reshape(2, NP)
         tot += prof
     frames = b.frames(0)
+    if not tot.any():
+        sys.exit("stage_profile: every counter is zero -- this library's kernel for these settings was not built with -DLH_PROF "
+                 "(liblamehip_prof.so profiles the MPEG-1 CBR / ABR objects, fused and split; the VBR and MPEG-2 / 2.5 objects are "
+                 "the product's)")
     print("batch %d x %.1f s: kernel %.2f ms, %d frames/stream" % (B, secs, ms, frames))
     for w in range(2):
         print("wave %d (cycles per frame, share of frame):" % w)
