@@ -35,10 +35,8 @@
 #include "lh_dev_common.h"
 
 /* The 1024 samples a granule's transforms read (from bufp = frame window + 576 gr + 304 on, reference psymodel.c:1420) are
- * staged as scaled floats where the power spectra will go once the long transform is done: channel ch at
- * energy[0][1024 ch ..]; sample i of that span */
-#define LH_SPAN ((float *) lh_lds.u.psy.b.energy)
-static_assert(sizeof(lh_lds.u.psy.b.energy) >= 2 * LH_BLKSIZE * sizeof(float), "both channels' sample spans fit the spectra's place");
+ * staged as scaled floats in the work area, channel ch at work[1024 ch ..], and transformed in place; sample i of that span */
+#define LH_SPAN (lh_lds.work)
 LH_DEVFN float
 lh_smp(const LhCtx & c, int ch, int i)
 {
@@ -324,9 +322,176 @@ lh_attack_scan_kernel(const LhConfig * cfg, const LhTables * T, const LhStreamDe
     }
 }
 
+/* The windowed first pass of the long transform (reference fft.c:245-289; lh_fft_long in lh_dev_psy_core.h) IN PLACE: a lane
+ * reads the sixteen samples of its two trips before the first of its sums replaces a sample, the later passes are in place
+ * anyway.  One wave, its own channel's span x[1024]. */
+LH_DEVFN void
+lh_fft_long_inplace(const LhCtx & c, float *x)
+{
+    const float *w = c.T->fft_window;
+    int const lane = c.lane;
+    float   o[2][8];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        int const jj = lane + 64 * q;
+        int const i = (int) lh_rev8((unsigned) jj);
+        float   f0, f1, f2, f3, ww;
+        f0 = w[i] * x[i];
+        ww = w[i + 0x200] * x[i + 0x200];
+        f1 = f0 - ww;
+        f0 = f0 + ww;
+        f2 = w[i + 0x100] * x[i + 0x100];
+        ww = w[i + 0x300] * x[i + 0x300];
+        f3 = f2 - ww;
+        f2 = f2 + ww;
+        o[q][0] = f0 + f2;
+        o[q][2] = f0 - f2;
+        o[q][1] = f1 + f3;
+        o[q][3] = f1 - f3;
+        f0 = w[i + 0x001] * x[i + 0x001];
+        ww = w[i + 0x201] * x[i + 0x201];
+        f1 = f0 - ww;
+        f0 = f0 + ww;
+        f2 = w[i + 0x101] * x[i + 0x101];
+        ww = w[i + 0x301] * x[i + 0x301];
+        f3 = f2 - ww;
+        f2 = f2 + ww;
+        o[q][4] = f0 + f2;
+        o[q][6] = f0 - f2;
+        o[q][5] = f1 + f3;
+        o[q][7] = f1 - f3;
+    }
+    {
+        lh_f32x4 tw[4][2];
+#pragma unroll
+        for (int stage = 0; stage < 4; stage++) {
+            int const kx = 2 << (2 * stage);
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+                tw[stage][q] = *(const lh_f32x4 *) c.T->fht_tw[stage][(lane + 64 * q) % kx];
+        }
+        LH_WAVE_SYNC_MEM();     /* every lane has read its samples */
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            float  *d = x + 4 * (lane + 64 * q);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                d[k] = o[q][k];
+                d[LH_BLKSIZE / 2 + k] = o[q][4 + k];
+            }
+        }
+        LH_WAVE_SYNC_MEM();
+#pragma unroll
+        for (int stage = 0; stage < 4; stage++) {
+            int const k1 = 4 << (2 * stage);
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+                lh_fht_unit(tw[stage][q], x, k1, lane + 64 * q);
+            LH_WAVE_SYNC_MEM();
+        }
+    }
+}
+
+/* the same for the three short transforms (reference fft.c:193-243; lh_fft_short): x[1024] holds the span and receives the
+ * three transforms at x[0 / 256 / 512 ..] */
+LH_DEVFN void
+lh_fft_short_inplace(const LhCtx & c, float *x)
+{
+    const float *ws = c.T->fft_window_s;
+    int const lane = c.lane;
+    float   o[2][8];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        int const t = lane + 64 * q, tt = t < 3 * (LH_BLKSIZE_S / 8) ? t : 0;
+        int const b = tt >> 5, j = tt & 31;
+        int const k = (576 / 3) * (b + 1);
+        int const i = (int) lh_rev8((unsigned) (j << 2));
+        float   f0, f1, f2, f3, w;
+        f0 = ws[i] * x[i + k];
+        w = ws[0x7f - i] * x[i + k + 0x80];
+        f1 = f0 - w;
+        f0 = f0 + w;
+        f2 = ws[i + 0x40] * x[i + k + 0x40];
+        w = ws[0x3f - i] * x[i + k + 0xc0];
+        f3 = f2 - w;
+        f2 = f2 + w;
+        o[q][0] = f0 + f2;
+        o[q][2] = f0 - f2;
+        o[q][1] = f1 + f3;
+        o[q][3] = f1 - f3;
+        f0 = ws[i + 0x01] * x[i + k + 0x01];
+        w = ws[0x7e - i] * x[i + k + 0x81];
+        f1 = f0 - w;
+        f0 = f0 + w;
+        f2 = ws[i + 0x41] * x[i + k + 0x41];
+        w = ws[0x3e - i] * x[i + k + 0xc1];
+        f3 = f2 - w;
+        f2 = f2 + w;
+        o[q][4] = f0 + f2;
+        o[q][6] = f0 - f2;
+        o[q][5] = f1 + f3;
+        o[q][7] = f1 - f3;
+    }
+    LH_WAVE_SYNC_MEM();         /* every lane has read its samples */
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        int const t = lane + 64 * q;
+        if (t < 3 * (LH_BLKSIZE_S / 8)) {
+            float  *d = x + (t >> 5) * LH_BLKSIZE_S + 4 * (t & 31);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                d[k] = o[q][k];
+                d[LH_BLKSIZE_S / 2 + k] = o[q][4 + k];
+            }
+        }
+    }
+    LH_WAVE_SYNC_MEM();
+    for (int stage = 0, k1 = 4; stage < 3; stage++, k1 <<= 2) {
+        for (int t = lane; t < 3 * (LH_BLKSIZE_S / 8); t += 64) {
+            int const b = t >> 5, u = t & 31;
+            lh_f32x4 const tw = *(const lh_f32x4 *) c.T->fht_tw[stage][u % (k1 >> 1)];
+            lh_fht_unit(tw, x + b * LH_BLKSIZE_S, k1, u);
+        }
+        LH_WAVE_SYNC_MEM();
+    }
+}
+
+/* The long power spectra (reference psymodel.c:664-688; lh_fft_energy / lh_fft_energy_pair) IN PLACE: rows of LH_AN_ROW
+ * floats per pseudo-channel over the two transforms they are formed from.  Both waves read everything they need of both
+ * transforms into registers, the workgroup meets, then the rows are written.  Wave w: its own channel, and with `ms' the mid
+ * (w = 0) or side (w = 1) channel.  Every thread of the workgroup must call. */
+LH_DEVFN void
+lh_an_spectra(const LhCtx & c, int w, int own, int ms, float *work)
+{
+    float const sqrt2_half = (float) (LH_SQRT2 * 0.5f);
+    const float *wl = work, *wr = work + LH_BLKSIZE;
+    float   eo[9], em[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        int const m0 = c.lane + 64 * k, m = m0 <= LH_BLKSIZE / 2 ? m0 : LH_BLKSIZE / 2;
+        int const ire = m, iim = (m == 0) ? 0 : (LH_BLKSIZE - m);
+        float const lre = wl[ire], lim = wl[iim], rre = wr[ire], rim = wr[iim];
+        float const ore = w ? rre : lre, oim = w ? rim : lim;
+        float const mre = (w ? lre - rre : lre + rre) * sqrt2_half, mim = (w ? lim - rim : lim + rim) * sqrt2_half;
+        eo[k] = (m == 0) ? ore * ore : (ore * ore + oim * oim) * 0.5f;
+        em[k] = (m == 0) ? mre * mre : (mre * mre + mim * mim) * 0.5f;
+    }
+    LH_SYNC_WG_LDS();           /* both waves have read both transforms */
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        int const m = c.lane + 64 * k;
+        if (m <= LH_BLKSIZE / 2) {
+            if (own)
+                work[w * LH_AN_ROW + m] = eo[k];
+            if (ms)
+                work[(w + 2) * LH_AN_ROW + m] = em[k];
+        }
+    }
+}
+
 /* ---- transforms, spectra, masking up to the recurrences; one workgroup (wave = channel) per (stream, granule) ---- */
 #ifndef LH_EMU
-extern "C" __global__ void __launch_bounds__(LH_NT, 4)
+extern "C" __global__ void __launch_bounds__(LH_NT, 6)
 #else
 void
 #endif
@@ -338,7 +503,9 @@ lh_analysis_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm
 #endif
     LH_AP_T0();
     LhLds & L = lh_lds;
-    LhPsyLds & P = L.u.psy;
+    LhLds & P = L;              /* (eb / thr) */
+    float  *const work = L.work;
+#define LH_AN_E(chn) (work + (chn) * LH_AN_ROW)
     int const sidx = (int) blockIdx.y;
     LhCtx   c;
     c.cfg = cfg;
@@ -363,33 +530,20 @@ lh_analysis_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm
     lh_stage_span < LH_BLKSIZE, LH_NT > (c, LH_SPAN, LH_SPAN + LH_BLKSIZE, ga.frame_base + bufbase);
     LH_SYNC_WG_LDS();
     LH_AP(1);
-    /* long FFTs of L (wave 0) and R (wave 1) */
+    /* long FFTs of L (wave 0) and R (wave 1), in place over their spans */
     if (w < cfg->channels)
-        lh_fft_long(c, w, 0, P.wsamp[w]);
+        lh_fft_long_inplace(c, work + w * LH_BLKSIZE);
     LH_SYNC_WG_LDS();
     LH_AP(2);
-    /* power spectra of this wave's one or two pseudo-channels (over the sample spans, which are done with) */
-    if (n_chn_psy == 4)
-        lh_fft_energy_pair(c, w, P.wsamp[0], P.wsamp[1], LH_BLKSIZE, P.b.energy[w], P.b.energy[w + 2]);
-    else if (w < n_chn_psy)
-        lh_fft_energy(c, w, P.wsamp[0], P.wsamp[1], LH_BLKSIZE, P.b.energy[w]);
-#ifdef LH_AN_STAGE_S3
-    /* the FHT buffers are free: the long-block spreading matrix goes there (as in the fused kernel) */
-    float  *stg_s3 = &P.wsamp[0][0];
-    LH_SYNC_WG_LDS();
-    LH_AP(3);
-    for (int i = c.tid; i < T->psy_l.s3_count; i += LH_NT)
-        stg_s3[i] = T->psy_l.s3[i];
-    LH_SYNC_WG_LDS();
-    LH_AP(4);
-#else
+    /* power spectra of this wave's one or two pseudo-channels, in place over the transforms */
+    lh_an_spectra(c, w, w < n_chn_psy, n_chn_psy == 4, work);
+    LH_WAVE_SYNC_MEM();
     /* (the long-block spreading matrix is read where it lies, in the L2: with four waves per SIMD its look-ups hide behind
      * the other waves, and staging it cost a granule two barriers and an HBM round trip) */
     const float *stg_s3 = T->psy_l.s3;
     LH_WAVE_SYNC_MEM();
     LH_AP(3);
     LH_AP(4);
-#endif
     /* serial sums: total energy (bins 11..512) of chn w (lane 0) and w + 2 (lane 1), loudness of channel w (lane 2), in
      * bin order (reference psymodel.c:213-226, 690-696); see the fused kernel for the layout */
     {
@@ -398,7 +552,7 @@ lh_analysis_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm
         int const loud = (lane == 2);
         float  *prod = (w == 0) ? P.eb : P.thr; /* [256] per wave */
         const float *ew = T->ath_eql_w;
-        const float *e = P.b.energy[summing ? chn : w];
+        const float *e = LH_AN_E(summing ? chn : w);
         float   acc = 0.0f;
         for (int h = 0; h < 2; h++) {
             int const j0 = 256 * h;
@@ -406,7 +560,7 @@ lh_analysis_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 int const j = j0 + lane + 64 * q;
-                prod[j - j0] = P.b.energy[w][j] * ew[j];
+                prod[j - j0] = LH_AN_E(w)[j] * ew[j];
             }
             LH_WAVE_SYNC_MEM();
             if (summing) {
@@ -462,13 +616,13 @@ lh_analysis_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm
         LhMidLong *ml = &frames[ga.at].lng;
         if (n_chn_psy == 4) {
             LhMaskChan const two[2] = {
-                {w, P.b.energy[w], &P.eb[w * 64], &P.thr[w * 64], nullptr, nullptr, &ml->m[gr][w]},
-                {w + 2, P.b.energy[w + 2], &P.eb[(w + 2) * 64], &P.thr[(w + 2) * 64], nullptr, nullptr, &ml->m[gr][w + 2]}
+                {w, LH_AN_E(w), &P.eb[w * 64], &P.thr[w * 64], nullptr, nullptr, &ml->m[gr][w]},
+                {w + 2, LH_AN_E(w + 2), &P.eb[(w + 2) * 64], &P.thr[(w + 2) * 64], nullptr, nullptr, &ml->m[gr][w + 2]}
             };
             lh_compute_masking < 2, 1 > (c, 1, two, stg_s3);
         }
         else if (w < n_chn_psy) {
-            LhMaskChan const one[1] = { {w, P.b.energy[w], &P.eb[w * 64], &P.thr[w * 64], nullptr, nullptr, &ml->m[gr][w]} };
+            LhMaskChan const one[1] = { {w, LH_AN_E(w), &P.eb[w * 64], &P.thr[w * 64], nullptr, nullptr, &ml->m[gr][w]} };
             lh_compute_masking < 1, 1 > (c, 1, one, stg_s3);
         }
     }
@@ -481,28 +635,27 @@ lh_analysis_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm
     lh_stage_span < LH_BLKSIZE, LH_NT > (c, LH_SPAN, LH_SPAN + LH_BLKSIZE, ga.frame_base + bufbase);
     LH_SYNC_WG_LDS();
     if (!L.uselong[w])
-        lh_fft_short(c, w, 0, &P.wsamp[w][0]);
+        lh_fft_short_inplace(c, work + w * LH_BLKSIZE);
     LH_SYNC_WG_LDS();
     for (int sblock = 0; sblock < 3; sblock++) {
         if (w < n_chn_psy && !L.uselong[w]) {
             LhMidShort *ms = &frames[ga.at].shrt;
             int const both = (n_chn_psy == 4);
+            const float *wl = work + sblock * LH_BLKSIZE_S, *wr = work + LH_BLKSIZE + sblock * LH_BLKSIZE_S;
             if (both)
-                lh_fft_energy_pair(c, w, &P.wsamp[0][sblock * LH_BLKSIZE_S], &P.wsamp[1][sblock * LH_BLKSIZE_S],
-                                   LH_BLKSIZE_S, P.b.energy[w], P.b.energy[w + 2]);
+                lh_fft_energy_pair(c, w, wl, wr, LH_BLKSIZE_S, L.eshort[w], L.eshort[w + 2]);
             else
-                lh_fft_energy(c, w, &P.wsamp[0][sblock * LH_BLKSIZE_S], &P.wsamp[1][sblock * LH_BLKSIZE_S], LH_BLKSIZE_S,
-                              P.b.energy[w]);
+                lh_fft_energy(c, w, wl, wr, LH_BLKSIZE_S, L.eshort[w]);
             LH_WAVE_SYNC_MEM();
             if (both) {
                 LhMaskChan const two[2] = {
-                    {w, P.b.energy[w], &P.eb[w * 64], &P.thr[w * 64], nullptr, nullptr, &ms->m[gr][sblock][w]},
-                    {w + 2, P.b.energy[w + 2], &P.eb[(w + 2) * 64], &P.thr[(w + 2) * 64], nullptr, nullptr, &ms->m[gr][sblock][w + 2]}
+                    {w, L.eshort[w], &P.eb[w * 64], &P.thr[w * 64], nullptr, nullptr, &ms->m[gr][sblock][w]},
+                    {w + 2, L.eshort[w + 2], &P.eb[(w + 2) * 64], &P.thr[(w + 2) * 64], nullptr, nullptr, &ms->m[gr][sblock][w + 2]}
                 };
                 lh_compute_masking < 2, 1 > (c, 0, two, T->psy_s.s3);
             }
             else {
-                LhMaskChan const one[1] = { {w, P.b.energy[w], &P.eb[w * 64], &P.thr[w * 64], nullptr, nullptr, &ms->m[gr][sblock][w]} };
+                LhMaskChan const one[1] = { {w, L.eshort[w], &P.eb[w * 64], &P.thr[w * 64], nullptr, nullptr, &ms->m[gr][sblock][w]} };
                 lh_compute_masking < 1, 1 > (c, 0, one, T->psy_s.s3);
             }
         }

@@ -17,6 +17,12 @@
 
 #define LH_ENW lh_enwindow
 #define LH_WIN(t,i) lh_mdct_win[(t)*36+(i)]
+/* the same where the index differs from lane to lane (the window of a lane's block type, the alias butterflies' constants):
+ * vector loads -- lh_subband.hip keeps a copy of the table in LDS for them (LH_MDCT_WIN); constant indices stay immediates */
+#ifndef LH_MDCT_WIN
+#define LH_MDCT_WIN lh_mdct_win
+#endif
+#define LH_WINV(t,i) LH_MDCT_WIN[(t)*36+(i)]
 #define LH_TANTAB(i) LH_WIN(LH_SHORT_TYPE, 3 + (i))
 #define LH_CX(i) LH_WIN(LH_SHORT_TYPE, 12 + (i))
 #define LH_CA(i) LH_WIN(LH_SHORT_TYPE, 20 + (i))
@@ -58,6 +64,12 @@
 #ifndef LH_MF_SWZ
 #define LH_MF_SWZ(i) (i)
 #endif
+/* LH_ENW_TAPS: where the tap sums read the window's coefficients (a row per lane: vector loads).  The encode kernel reads
+ * the constant table; lh_subband.hip -- whose 36 x 16 tap sums per channel and frame made it bound by the vector-memory
+ * path, 32 coefficient loads per sum -- keeps a copy in LDS (rows 18 words apart: no two of the fifteen share a bank). */
+#ifndef LH_ENW_TAPS
+#define LH_ENW_TAPS LH_ENW
+#endif
 LH_DEVFN void
 lh_subband_taps(const LhCtx & c, int ch, int x, int n, float *pre)
 {
@@ -65,7 +77,7 @@ lh_subband_taps(const LhCtx & c, int ch, int x, int n, float *pre)
     if (n < 15) {
         int const x1 = x - n;
         int const x2 = x - 62 + n;
-        const float *wp = LH_ENW + 10 + 18 * n;
+        const float *wp = LH_ENW_TAPS + 10 + 18 * n;
         /* the four strided runs (bases; + / - 64 k from there) */
         const float *a2 = mf + LH_MF_SWZ(x2 - 224), *a1 = mf + LH_MF_SWZ(x1 + 224 - 448);
         const float *b1 = mf + LH_MF_SWZ(x1 - 256), *b2 = mf + LH_MF_SWZ(x2 + 256 - 448);
@@ -92,7 +104,7 @@ lh_subband_taps(const LhCtx & c, int ch, int x, int n, float *pre)
     }
     else {
         int const x1 = x - 15;
-        const float *wp = LH_ENW + 280;
+        const float *wp = LH_ENW_TAPS + 280;
         float   s, t;
 #define LH_MFS(i) mf[LH_MF_SWZ(i)]
         t = LH_MFS(x1 - 16) * wp[-10];
@@ -435,10 +447,10 @@ lh_mdct_granules(int ch)
 #pragma unroll
         for (int k = -9; k < 0; k++) {
             float   a, b;
-            a = LH_WIN(type, k + 27) * band1[(k + 9) * LH_SB_STRIDE]
-                + LH_WIN(type, k + 36) * band1[(8 - k) * LH_SB_STRIDE];
-            b = LH_WIN(type, k + 9) * band0[(k + 9) * LH_SB_STRIDE]
-                - LH_WIN(type, k + 18) * band0[(8 - k) * LH_SB_STRIDE];
+            a = LH_WINV(type, k + 27) * band1[(k + 9) * LH_SB_STRIDE]
+                + LH_WINV(type, k + 36) * band1[(8 - k) * LH_SB_STRIDE];
+            b = LH_WINV(type, k + 9) * band0[(k + 9) * LH_SB_STRIDE]
+                - LH_WINV(type, k + 18) * band0[(8 - k) * LH_SB_STRIDE];
             work[k + 9] = a - b * LH_TANTAB(k + 9);
             work[k + 18] = a * LH_TANTAB(k + 9) + b;
         }
@@ -455,8 +467,9 @@ lh_mdct_granules(int ch)
         if (L.block_type[g][ch] != LH_SHORT_TYPE) {
             float  *p = &L.xr[ch][g][bnd * 18];
             float   bu, bd;
-            bu = p[k] * LH_CA(k) + p[-1 - k] * LH_CS(k);
-            bd = p[k] * LH_CS(k) - p[-1 - k] * LH_CA(k);
+            float const ca = LH_WINV(LH_SHORT_TYPE, 20 + k), cs = LH_WINV(LH_SHORT_TYPE, 28 + k);
+            bu = p[k] * ca + p[-1 - k] * cs;
+            bd = p[k] * cs - p[-1 - k] * ca;
             p[-1 - k] = bu;
             p[k] = bd;
         }

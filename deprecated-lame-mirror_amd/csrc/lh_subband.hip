@@ -27,6 +27,8 @@
 #define LH_MF_SWZ(i) ((i) ^ (((i) >> 1) & 16))
 #define LH_STAGE_IDX(i) LH_MF_SWZ(i)
 #define LH_SB_STRIDE 33
+#define LH_ENW_TAPS (lh_lds.enw)
+#define LH_MDCT_WIN (lh_lds.mwin)
 #define LH_MF_PADDED ((LH_MF_NEEDED + 63) / 64 * 64)
 #include "lh_static_tables.h"
 #include "lh_dev_common.h"
@@ -97,6 +99,10 @@ lh_subband_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm,
     }
     float   sb[LH_SB_CARRY];
     LH_AP_T0();
+    for (int i = tid; i < 288; i += LH_NT)
+        L.enw[i] = lh_enwindow[i < 285 ? i : 284];
+    for (int i = tid; i < 4 * 36; i += LH_NT)
+        L.mwin[i] = lh_mdct_win[i];
     /* the granule before the run (reference encoder.c:189-236 primes the filterbank the same way on a stream's first frame) */
     lh_stage_span < LH_MF_NEEDED, LH_NT > (c, L.mf[0], L.mf[1], (long long) fs * f0 - LH_MF_START - fs);
     LH_SYNC_WG_LDS();
