@@ -31,6 +31,16 @@
 
 #define LH_CUSTOM_LDS "lh_lds_analysis.h"
 #define LH_CUSTOM_SMP
+/* The transform buffers are stored bank-swizzled: word i of a channel's 1024 at i ^ X(i), X = bit 5 -> bit 1, bit 6 -> bit 3,
+ * bit 7 -> bits 2 and 4.  The radix-4 passes walk them at strides of 8, 16 and 64 words and the first pass in bit-reversed
+ * order; in the plain layout a wave's 64 addresses fell on 4 or 8 of the 32 banks, and with twelve workgroups per CU the
+ * transforms were what the LDS pipe spent most of its time on (profiles/r05_*: three quarters of the kernel's LDS cycles were
+ * bank conflicts).  Found by a search over linear swizzles of the passes' address patterns: 1280 -> 416 bank cycles per
+ * transform (320 = no conflict at all).  Bit 0 is left alone (samples are staged in pairs), bits 8, 9 do not take part
+ * (offsets of 256 words commute with it). */
+#define LH_FZ_X(i) ((((i) >> 4) & 2) | (((i) >> 3) & 24) | (((i) >> 5) & 4))
+#define LH_FZ(i) ((i) ^ LH_FZ_X(i))
+#define LH_STAGE_IDX(i) LH_FZ(i)
 #include "lh_static_tables.h"
 #include "lh_dev_common.h"
 
@@ -40,7 +50,7 @@
 LH_DEVFN float
 lh_smp(const LhCtx & c, int ch, int i)
 {
-    return LH_SPAN[ch * LH_BLKSIZE + i];
+    return LH_SPAN[ch * LH_BLKSIZE + LH_FZ(i)];
 }
 
 #include "lh_dev_psy_core.h"
@@ -129,7 +139,7 @@ lh_attack_kernel(const LhConfig * cfg, const int16_t * pcm, const float *pcmf, c
     int const bufbase = 576 + ga.gr * 576 - LH_FFTOFFSET;
     int const firbase = bufbase + 576 - 350 - LH_NSFIRLEN + 192;
     LhMidGr *mg = &frames[ga.at].small.gr[ga.gr];
-    lh_stage_span < LH_FIR_SPAN, 64 > (c, span, span + LH_FIR_SPAN, ga.frame_base + firbase);
+    lh_stage_span < LH_FIR_SPAN, 64, 1 > (c, span, span + LH_FIR_SPAN, ga.frame_base + firbase);
     LH_WAVE_SYNC();
     {
         /* a lane filters nine consecutive samples of either channel (as the fused kernel does: lh_dev_psy.h); every lane
@@ -322,9 +332,81 @@ lh_attack_scan_kernel(const LhConfig * cfg, const LhTables * T, const LhStreamDe
     }
 }
 
-/* The windowed first pass of the long transform (reference fft.c:245-289; lh_fft_long in lh_dev_psy_core.h) IN PLACE: a lane
- * reads the sixteen samples of its two trips before the first of its sums replaces a sample, the later passes are in place
- * anyway.  One wave, its own channel's span x[1024]. */
+/* One radix-4 butterfly unit (lh_fht_unit, lh_dev_psy_core.h) on a swizzled buffer.  The eight places of a unit are
+ * lo + j K1 and hi + j K1; which bits above bit 4 an offset changes -- and with them the swizzle -- is known per pass. */
+template < int K1 > LH_DEVFN void
+lh_fht_unit_fz(lh_f32x4 tw, float *fz, int u)
+{
+    constexpr int kx = K1 >> 1, k2 = K1 << 1, k3 = k2 + K1, k4 = k2 << 1;
+    int const blk = u / kx, i = u - blk * kx;
+    int const axis = (i == 0);
+    int const lo = blk * k4 + i;
+    int const hi = blk * k4 + (axis ? kx : K1 - i);
+    int     al[4], ah[4];
+    if (K1 == 4) {
+        /* a unit stays inside 16 words: one swizzle for all eight */
+        int const x = LH_FZ_X(lo);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            al[j] = (lo + j * K1) ^ x;
+            ah[j] = (hi + j * K1) ^ x;
+        }
+    }
+    else if (K1 == 16) {
+        /* inside 64 words: the upper two of either quadruple lie beyond bit 5 */
+        int const x = LH_FZ_X(blk * k4);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            al[j] = (lo + j * K1) ^ x ^ (j >= 2 ? 2 : 0);
+            ah[j] = (hi + j * K1) ^ x ^ (j >= 2 ? 2 : 0);
+        }
+    }
+    else if (K1 == 64) {
+        /* lo below word 32 of its 256, hi in 32 .. 63: bits 6 and 7 are the offset's */
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            al[j] = (lo + j * K1) ^ LH_FZ_X(64 * j);
+            ah[j] = (hi + j * K1) ^ (2 ^ LH_FZ_X(64 * j));
+        }
+    }
+    else {
+        int const xl = LH_FZ_X(lo), xh = LH_FZ_X(hi);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            al[j] = (lo + j * K1) ^ xl;
+            ah[j] = (hi + j * K1) ^ xh;
+        }
+    }
+    float const p0 = fz[al[0]], p1 = fz[al[1]], p2 = fz[al[2]], p3 = fz[al[3]];
+    float const q0 = fz[ah[0]], q1 = fz[ah[1]], q2 = fz[ah[2]], q3 = fz[ah[3]];
+    /* on the axes: no rotation, the mirrored quarter only scales by sqrt 2 */
+    float const s01 = p0 + p1, d01 = p0 - p1, s23 = p2 + p3, d23 = p2 - p3;
+    float const r2 = (float) (LH_SQRT2 * q2), r3 = (float) (LH_SQRT2 * q3);
+    float const t01 = q0 + q1, u01 = q0 - q1;
+    float const a_l0 = s01 + s23, a_l1 = d01 + d23, a_l2 = s01 - s23, a_l3 = d01 - d23;
+    float const a_h0 = t01 + r2, a_h1 = u01 + r3, a_h2 = t01 - r2, a_h3 = u01 - r3;
+    /* off the axes: the second and fourth quarters turn by the double angle, then the two half-sums by the single angle */
+    LhRot const rq1 = lh_rot(tw.z, tw.w, p1, q1);
+    LhRot const rq3 = lh_rot(tw.z, tw.w, p3, q3);
+    float const le = p0 + rq1.along, lm = p0 - rq1.along;
+    float const he = q0 + rq1.across, hm = q0 - rq1.across;
+    float const l2e = p2 + rq3.along, l2m = p2 - rq3.along;
+    float const h2e = q2 + rq3.across, h2m = q2 - rq3.across;
+    LhRot const ra = lh_rot(tw.x, tw.y, l2e, h2m);
+    LhRot const rb = lh_rot(tw.y, tw.x, h2e, l2m);
+    fz[al[0]] = axis ? a_l0 : le + ra.along;
+    fz[al[1]] = axis ? a_l1 : lm + rb.across;
+    fz[al[2]] = axis ? a_l2 : le - ra.along;
+    fz[al[3]] = axis ? a_l3 : lm - rb.across;
+    fz[ah[0]] = axis ? a_h0 : he + rb.along;
+    fz[ah[1]] = axis ? a_h1 : hm + ra.across;
+    fz[ah[2]] = axis ? a_h2 : he - rb.along;
+    fz[ah[3]] = axis ? a_h3 : hm - ra.across;
+}
+
+/* The windowed long transform (reference fft.c:245-289; lh_fft_long in lh_dev_psy_core.h) IN PLACE on a swizzled buffer: a
+ * lane reads the sixteen samples of its two trips before the first of its sums replaces a sample.  One wave, its own
+ * channel's span x[1024]. */
 LH_DEVFN void
 lh_fft_long_inplace(const LhCtx & c, float *x)
 {
@@ -335,25 +417,26 @@ lh_fft_long_inplace(const LhCtx & c, float *x)
     for (int q = 0; q < 2; q++) {
         int const jj = lane + 64 * q;
         int const i = (int) lh_rev8((unsigned) jj);
+        const float *xs = x + (i ^ LH_FZ_X(i));         /* (the eight offsets touch bits 0, 8 and 9 only) */
         float   f0, f1, f2, f3, ww;
-        f0 = w[i] * x[i];
-        ww = w[i + 0x200] * x[i + 0x200];
+        f0 = w[i] * xs[0];
+        ww = w[i + 0x200] * xs[0x200];
         f1 = f0 - ww;
         f0 = f0 + ww;
-        f2 = w[i + 0x100] * x[i + 0x100];
-        ww = w[i + 0x300] * x[i + 0x300];
+        f2 = w[i + 0x100] * xs[0x100];
+        ww = w[i + 0x300] * xs[0x300];
         f3 = f2 - ww;
         f2 = f2 + ww;
         o[q][0] = f0 + f2;
         o[q][2] = f0 - f2;
         o[q][1] = f1 + f3;
         o[q][3] = f1 - f3;
-        f0 = w[i + 0x001] * x[i + 0x001];
-        ww = w[i + 0x201] * x[i + 0x201];
+        f0 = w[i + 0x001] * xs[0x001];
+        ww = w[i + 0x201] * xs[0x201];
         f1 = f0 - ww;
         f0 = f0 + ww;
-        f2 = w[i + 0x101] * x[i + 0x101];
-        ww = w[i + 0x301] * x[i + 0x301];
+        f2 = w[i + 0x101] * xs[0x101];
+        ww = w[i + 0x301] * xs[0x301];
         f3 = f2 - ww;
         f2 = f2 + ww;
         o[q][4] = f0 + f2;
@@ -373,22 +456,30 @@ lh_fft_long_inplace(const LhCtx & c, float *x)
         LH_WAVE_SYNC_MEM();     /* every lane has read its samples */
 #pragma unroll
         for (int q = 0; q < 2; q++) {
-            float  *d = x + 4 * (lane + 64 * q);
+            int const at = 4 * (lane + 64 * q), xa = LH_FZ_X(at);   /* (the eight offsets touch bits 0, 1 and 9 only) */
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                d[k] = o[q][k];
-                d[LH_BLKSIZE / 2 + k] = o[q][4 + k];
+                x[(at + k) ^ xa] = o[q][k];
+                x[(at + k + LH_BLKSIZE / 2) ^ xa] = o[q][4 + k];
             }
         }
         LH_WAVE_SYNC_MEM();
 #pragma unroll
-        for (int stage = 0; stage < 4; stage++) {
-            int const k1 = 4 << (2 * stage);
+        for (int q = 0; q < 2; q++)
+            lh_fht_unit_fz < 4 > (tw[0][q], x, lane + 64 * q);
+        LH_WAVE_SYNC_MEM();
 #pragma unroll
-            for (int q = 0; q < 2; q++)
-                lh_fht_unit(tw[stage][q], x, k1, lane + 64 * q);
-            LH_WAVE_SYNC_MEM();
-        }
+        for (int q = 0; q < 2; q++)
+            lh_fht_unit_fz < 16 > (tw[1][q], x, lane + 64 * q);
+        LH_WAVE_SYNC_MEM();
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+            lh_fht_unit_fz < 64 > (tw[2][q], x, lane + 64 * q);
+        LH_WAVE_SYNC_MEM();
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+            lh_fht_unit_fz < 256 > (tw[3][q], x, lane + 64 * q);
+        LH_WAVE_SYNC_MEM();
     }
 }
 
@@ -407,24 +498,24 @@ lh_fft_short_inplace(const LhCtx & c, float *x)
         int const k = (576 / 3) * (b + 1);
         int const i = (int) lh_rev8((unsigned) (j << 2));
         float   f0, f1, f2, f3, w;
-        f0 = ws[i] * x[i + k];
-        w = ws[0x7f - i] * x[i + k + 0x80];
+        f0 = ws[i] * x[LH_FZ(i + k)];
+        w = ws[0x7f - i] * x[LH_FZ(i + k + 0x80)];
         f1 = f0 - w;
         f0 = f0 + w;
-        f2 = ws[i + 0x40] * x[i + k + 0x40];
-        w = ws[0x3f - i] * x[i + k + 0xc0];
+        f2 = ws[i + 0x40] * x[LH_FZ(i + k + 0x40)];
+        w = ws[0x3f - i] * x[LH_FZ(i + k + 0xc0)];
         f3 = f2 - w;
         f2 = f2 + w;
         o[q][0] = f0 + f2;
         o[q][2] = f0 - f2;
         o[q][1] = f1 + f3;
         o[q][3] = f1 - f3;
-        f0 = ws[i + 0x01] * x[i + k + 0x01];
-        w = ws[0x7e - i] * x[i + k + 0x81];
+        f0 = ws[i + 0x01] * x[LH_FZ(i + k + 0x01)];
+        w = ws[0x7e - i] * x[LH_FZ(i + k + 0x81)];
         f1 = f0 - w;
         f0 = f0 + w;
-        f2 = ws[i + 0x41] * x[i + k + 0x41];
-        w = ws[0x3e - i] * x[i + k + 0xc1];
+        f2 = ws[i + 0x41] * x[LH_FZ(i + k + 0x41)];
+        w = ws[0x3e - i] * x[LH_FZ(i + k + 0xc1)];
         f3 = f2 - w;
         f2 = f2 + w;
         o[q][4] = f0 + f2;
@@ -437,22 +528,47 @@ lh_fft_short_inplace(const LhCtx & c, float *x)
     for (int q = 0; q < 2; q++) {
         int const t = lane + 64 * q;
         if (t < 3 * (LH_BLKSIZE_S / 8)) {
-            float  *d = x + (t >> 5) * LH_BLKSIZE_S + 4 * (t & 31);
+            int const at = (t >> 5) * LH_BLKSIZE_S + 4 * (t & 31);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                d[k] = o[q][k];
-                d[LH_BLKSIZE_S / 2 + k] = o[q][4 + k];
+                x[LH_FZ(at + k)] = o[q][k];
+                x[LH_FZ(at + k + LH_BLKSIZE_S / 2)] = o[q][4 + k];
             }
         }
     }
     LH_WAVE_SYNC_MEM();
-    for (int stage = 0, k1 = 4; stage < 3; stage++, k1 <<= 2) {
-        for (int t = lane; t < 3 * (LH_BLKSIZE_S / 8); t += 64) {
-            int const b = t >> 5, u = t & 31;
-            lh_f32x4 const tw = *(const lh_f32x4 *) c.T->fht_tw[stage][u % (k1 >> 1)];
-            lh_fht_unit(tw, x + b * LH_BLKSIZE_S, k1, u);
-        }
-        LH_WAVE_SYNC_MEM();
+    for (int t = lane; t < 3 * (LH_BLKSIZE_S / 8); t += 64) {
+        int const b = t >> 5, u = t & 31;
+        lh_fht_unit_fz < 4 > (*(const lh_f32x4 *) c.T->fht_tw[0][u % 2], x + b * LH_BLKSIZE_S, u);
+    }
+    LH_WAVE_SYNC_MEM();
+    for (int t = lane; t < 3 * (LH_BLKSIZE_S / 8); t += 64) {
+        int const b = t >> 5, u = t & 31;
+        lh_fht_unit_fz < 16 > (*(const lh_f32x4 *) c.T->fht_tw[1][u % 8], x + b * LH_BLKSIZE_S, u);
+    }
+    LH_WAVE_SYNC_MEM();
+    for (int t = lane; t < 3 * (LH_BLKSIZE_S / 8); t += 64) {
+        int const b = t >> 5, u = t & 31;
+        lh_fht_unit_fz < 64 > (*(const lh_f32x4 *) c.T->fht_tw[2][u % 32], x + b * LH_BLKSIZE_S, u);
+    }
+    LH_WAVE_SYNC_MEM();
+}
+
+/* power spectrum of one or two pseudo-channels from two SWIZZLED transforms of n points at wl / wr + first (lh_fft_energy,
+ * lh_fft_energy_pair: reference psymodel.c:664-688, 713-736): for the short transforms, whose spectra have a place of their own */
+LH_DEVFN void
+lh_an_spectra_short(const LhCtx & c, int w, int both, const float *wl, const float *wr, int first, float *out_own, float *out_ms)
+{
+    float const sqrt2_half = (float) (LH_SQRT2 * 0.5f);
+    int const n = LH_BLKSIZE_S, h = n >> 1;
+    for (int m = c.lane; m <= h; m += 64) {
+        int const ire = first + m, iim = first + ((m == 0) ? 0 : (n - m));
+        float const lre = wl[LH_FZ(ire)], lim = wl[LH_FZ(iim)], rre = wr[LH_FZ(ire)], rim = wr[LH_FZ(iim)];
+        float const ore = w ? rre : lre, oim = w ? rim : lim;
+        float const mre = (w ? lre - rre : lre + rre) * sqrt2_half, mim = (w ? lim - rim : lim + rim) * sqrt2_half;
+        out_own[m] = (m == 0) ? ore * ore : (ore * ore + oim * oim) * 0.5f;
+        if (both)
+            out_ms[m] = (m == 0) ? mre * mre : (mre * mre + mim * mim) * 0.5f;
     }
 }
 
@@ -470,7 +586,7 @@ lh_an_spectra(const LhCtx & c, int w, int own, int ms, float *work)
     for (int k = 0; k < 9; k++) {
         int const m0 = c.lane + 64 * k, m = m0 <= LH_BLKSIZE / 2 ? m0 : LH_BLKSIZE / 2;
         int const ire = m, iim = (m == 0) ? 0 : (LH_BLKSIZE - m);
-        float const lre = wl[ire], lim = wl[iim], rre = wr[ire], rim = wr[iim];
+        float const lre = wl[LH_FZ(ire)], lim = wl[LH_FZ(iim)], rre = wr[LH_FZ(ire)], rim = wr[LH_FZ(iim)];
         float const ore = w ? rre : lre, oim = w ? rim : lim;
         float const mre = (w ? lre - rre : lre + rre) * sqrt2_half, mim = (w ? lim - rim : lim + rim) * sqrt2_half;
         eo[k] = (m == 0) ? ore * ore : (ore * ore + oim * oim) * 0.5f;
@@ -641,11 +757,7 @@ lh_analysis_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm
         if (w < n_chn_psy && !L.uselong[w]) {
             LhMidShort *ms = &frames[ga.at].shrt;
             int const both = (n_chn_psy == 4);
-            const float *wl = work + sblock * LH_BLKSIZE_S, *wr = work + LH_BLKSIZE + sblock * LH_BLKSIZE_S;
-            if (both)
-                lh_fft_energy_pair(c, w, wl, wr, LH_BLKSIZE_S, L.eshort[w], L.eshort[w + 2]);
-            else
-                lh_fft_energy(c, w, wl, wr, LH_BLKSIZE_S, L.eshort[w]);
+            lh_an_spectra_short(c, w, both, work, work + LH_BLKSIZE, sblock * LH_BLKSIZE_S, L.eshort[w], L.eshort[w + 2 < 4 ? w + 2 : 3]);
             LH_WAVE_SYNC_MEM();
             if (both) {
                 LhMaskChan const two[2] = {

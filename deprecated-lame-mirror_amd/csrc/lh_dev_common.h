@@ -687,13 +687,14 @@ lh_stage_window(const LhCtx & c, float (*mf)[LH_MF_NEEDED], long long base)
 /* N samples of both channels from stream sample `base' on, scaled as lh_stage_window scales the frame window (same three
  * sources: s16 pool, float pool of the handle / resampling paths, two channels mixed down), zero outside the stream;
  * NT threads (the analysis kernels: lh_analysis.hip, lh_subband.hip).  LH_STAGE_IDX(i): where sample i of the span goes
- * (even i stay even: lh_subband.hip's bank swizzle). */
+ * (even i stay even: the bank swizzles of lh_subband.hip and of lh_analysis.hip's transform buffers); PLAIN = 1: as it comes. */
 #ifndef LH_STAGE_IDX
 #define LH_STAGE_IDX(i) (i)
 #endif
-template < int N, int NT > LH_DEVFN void
+template < int N, int NT, int PLAIN = 0 > LH_DEVFN void
 lh_stage_span(const LhCtx & c, float *d0, float *d1, long long base)
 {
+#define LH_STAGE_AT(i) (PLAIN ? (i) : LH_STAGE_IDX(i))
     float const scale = c.cfg->pcm_scale;
     long long const last = c.d.nsamples - 1;
     float const mix = c.cfg->pcm_mix;
@@ -705,7 +706,7 @@ lh_stage_span(const LhCtx & c, float *d0, float *d1, long long base)
             float   v = 0.0f;
             if (p >= 0 && p <= last && p >= c.d.pcm_base)
                 v = c.pcmf[(ch == 0 ? c.d.pcm_l : c.d.pcm_r) + (p - c.d.pcm_base)];
-            (ch ? d1 : d0)[LH_STAGE_IDX(i)] = v;
+            (ch ? d1 : d0)[LH_STAGE_AT(i)] = v;
         }
         return;
     }
@@ -718,8 +719,8 @@ lh_stage_span(const LhCtx & c, float *d0, float *d1, long long base)
                 float const xr = (float) c.pcm[c.d.pcm_r + (p - c.d.pcm_base)];
                 v = xl * scale + xr * mix;
             }
-            d0[LH_STAGE_IDX(i)] = v;
-            d1[LH_STAGE_IDX(i)] = 0.0f;
+            d0[LH_STAGE_AT(i)] = v;
+            d1[LH_STAGE_AT(i)] = 0.0f;
         }
         return;
     }
@@ -749,8 +750,8 @@ lh_stage_span(const LhCtx & c, float *d0, float *d1, long long base)
                     a.y = (float) (int16_t) (v[u] >> 16) * scale;
                     b.x = (float) (int16_t) (v[U + u] & 0xffffu) * scale_r;
                     b.y = (float) (int16_t) (v[U + u] >> 16) * scale_r;
-                    *(lh_f32x2 *) &d0[LH_STAGE_IDX(2 * j)] = a;
-                    *(lh_f32x2 *) &d1[LH_STAGE_IDX(2 * j)] = b;
+                    *(lh_f32x2 *) &d0[LH_STAGE_AT(2 * j)] = a;
+                    *(lh_f32x2 *) &d1[LH_STAGE_AT(2 * j)] = b;
                 }
             }
             return;
@@ -763,9 +764,10 @@ lh_stage_span(const LhCtx & c, float *d0, float *d1, long long base)
         int16_t v;
         p = p < c.d.pcm_base ? c.d.pcm_base : p;        /* never before the pool (also nsamples == 0) */
         v = (c.d.nsamples > 0) ? c.pcm[(ch == 0 ? c.d.pcm_l : c.d.pcm_r) + (p - c.d.pcm_base)] : (int16_t) 0;
-        (ch ? d1 : d0)[LH_STAGE_IDX(i)] = (p0 < 0 || p0 > last) ? 0.0f : (float) v * (ch == 0 ? scale : scale_r);
+        (ch ? d1 : d0)[LH_STAGE_AT(i)] = (p0 < 0 || p0 > last) ? 0.0f : (float) v * (ch == 0 ? scale : scale_r);
     }
 }
+#undef LH_STAGE_AT
 
 /* sample i of the current frame window */
 #ifndef LH_CUSTOM_SMP
