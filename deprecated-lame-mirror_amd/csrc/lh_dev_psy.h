@@ -701,9 +701,11 @@ lh_psy_granule(int gr, LhPsyCarry nb)
          * are independent of each other -- one lane per term, in double as the reference forms
          * them -- and only the accumulation pe = (float) (pe + term) runs in band order (a band
          * that contributes nothing adds 0.0, which leaves pe unchanged).  Wave w: channels w, w+2. */
+#ifdef LH_SPLIT
+        int const logt_lds = lh_uni_i(!(cfg->vbr == 1 || cfg->vbr == 4));
+#endif
         for (int pass = 0; pass < 2; pass++) {
             int const chn = w + 2 * pass;
-            double *tmp = (double *) P.eb + 40 * chn;       /* eb / thr are dead by now: 4 x 40 doubles */
             int     type, is_short, nterms;
             if (chn >= n_chn_psy)
                 continue;
@@ -723,7 +725,7 @@ lh_psy_granule(int gr, LhPsyCarry nb)
                  * v_readlane: as one lane walking an LDS array the chain paid a round trip per term (21 or 36 of them, twice
                  * per granule and wave).  Adding 0.0 leaves pe unchanged, so the long case may stop at 21. */
                 double  term = 0.0;
-                (void) tmp;
+
                 if (lane < nterms) {
                     int const idx = is_short ? 22 + lane : lane;
                     float const coef = is_short ? lh_regcoef_s[lane / 3] : lh_regcoef_l[lane];
@@ -734,8 +736,21 @@ lh_psy_granule(int gr, LhPsyCarry nb)
                         if (e > x) {
                             if (e > x * 1e10f)
                                 term = coef * (10.0f * 2.30258509299404568402);
-                            else
+                            else {
+#ifdef LH_SPLIT
+                                /* (the split pipeline's encode kernel keeps calc_noise's copy of the table in LDS for the
+                                 * whole launch -- except in the new VBR loop, whose step tables lie there) */
+                                float   l2;
+                                if (logt_lds) {
+                                    LH_FAST_LOG2_VIA(LH_LOGT_LDS, e / x, l2);
+                                }
+                                else
+                                    l2 = lh_fast_log2(T->log_table, e / x);
+                                term = coef * (l2 * LH_LOG2_OVER_LOG10);
+#else
                                 term = coef * (lh_fast_log2(T->log_table, e / x) * LH_LOG2_OVER_LOG10);
+#endif
+                            }
                         }
                     }
                 }
