@@ -2741,6 +2741,48 @@ lamehip_batch_get_bytes_all(lamehip_batch * b, unsigned char *out, long out_stri
     return bad ? -1 : 0;
 }
 
+/* The buffers a launch of the batch's present streams needs -- payload, the analysis kernels' pool (split pipeline), the byte
+ * pool of the device packer -- allocated now instead of by the first lamehip_batch_encode (81 GB of pool at 1024 x 60 s: a
+ * caller that times its first launch calls this first). */
+extern "C" int
+lamehip_batch_reserve(lamehip_batch * b)
+{
+    LhDeviceScope const on_device(b ? b->device : -1);
+    long long total = 0, bytes_total = 0;
+    int     max_frame_bytes;
+    if (!b)
+        return -1;
+    if (b->incremental)
+        return 0;               /* (incremental batches launch what has arrived: sized per launch) */
+    {
+        int const top = (b->cfg.vbr == 0) ? b->cfg.bitrate_index : b->cfg.vbr_max_bitrate_index;
+        max_frame_bytes = (b->cfg.version + 1) * 72000 * lh_tag_kbps(b->cfg.version, top & 15) / b->cfg.samplerate + 1;
+    }
+    for (int s = 0; s < b->B; s++) {
+        total += b->nframes[(size_t) s];
+        bytes_total += b->dev_pack ? (long long) b->nframes[(size_t) s] * max_frame_bytes : 0;
+    }
+    if (b->dev_pack && bytes_total > b->bytes_cap) {
+        uint8_t *bigger = nullptr;
+        HIPCHK(hipMalloc((void **) &bigger, (size_t) bytes_total));
+        if (b->d_bytes)
+            (void) hipFree(b->d_bytes);
+        b->d_bytes = bigger;
+        b->bytes_cap = bytes_total;
+    }
+    if (total > b->out_cap) {
+        LhFrameOut *bigger = nullptr;
+        HIPCHK(hipMalloc((void **) &bigger, (size_t) total * sizeof(LhFrameOut)));
+        if (b->d_out)
+            (void) hipFree(b->d_out);
+        b->d_out = bigger;
+        b->out_cap = total;
+    }
+    if (b->split && total > 0)
+        (void) batch_mid_reserve(b, total);     /* (no room: the launch will take the fused kernel) */
+    return 0;
+}
+
 extern "C" int
 lamehip_batch_sync(lamehip_batch * b)
 {

@@ -312,6 +312,13 @@ class Batch:
         if sync:
             self.sync()
 
+    def reserve(self):
+        """Allocate the launch's buffers now (payload, analysis pool) instead of in the first encode()."""
+        self.lib.lamehip_batch_reserve.argtypes = [C.c_void_p]
+        rc = self.lib.lamehip_batch_reserve(self.b)
+        if rc:
+            raise RuntimeError("lamehip_batch_reserve failed (%d): %s" % (rc, last_error()))
+
     def sync(self):
         rc = self.lib.lamehip_batch_sync(self.b)
         if rc:

@@ -295,6 +295,9 @@ int     lamehip_batch_get_frames(lamehip_batch *, int stream, void *frames_out, 
 /* debug aid: raw per-stream carried state (LhStreamState, csrc/lh_device.h) */
 int     lamehip_batch_get_state(lamehip_batch *, int stream, void *out, int size);
 int     lamehip_get_state(const lame_t, void *out, int size);   /* same for a single-stream handle */
+/* allocate what a launch of the batch's present streams needs (payload, analysis pool, byte pool) now rather than in the first
+ * lamehip_batch_encode */
+int     lamehip_batch_reserve(lamehip_batch *);
 /* elapsed GPU time of the last lamehip_batch_encode in ms (HIP events on the batch stream) */
 float   lamehip_batch_last_kernel_ms(lamehip_batch *);
 /* the same launch kernel by kernel: a batch's frames go through the split pipeline -- analysis kernels over all frames at
