@@ -524,6 +524,11 @@ def main():
                     help="skip the end_to_end object (pinned host PCM -> H2D -> kernel -> D2H -> bytes, pipelined "
                          "batches of 5 s streams; an extra object, never `value`)")
     ap.add_argument("--end-to-end", action="store_true", help="(accepted for older command lines; it is the default now)")
+    ap.add_argument("--check-streams", type=int, default=CHECKED_STREAMS,
+                    help="streams of the timed launch compared with the oracle afterwards (rank 0; default %d)" % CHECKED_STREAMS)
+    ap.add_argument("--check-procs", type=int, default=0,
+                    help="processes of that comparison (0 = the CPUs this process may use; 1 = in this process: under a "
+                         "profiler, which would otherwise attach to every child)")
     args = ap.parse_args()
 
     launched = "WORLD_SIZE" in os.environ
@@ -565,7 +570,7 @@ def main():
     # rank 0: CHECKED_STREAMS streams spread over its block (first and last among them); every other rank: the first and the
     # last stream of ITS OWN block -- on a node with N devices the output of each is compared with the oracle by its own rank
     if rank == 0:
-        nck = min(CHECKED_STREAMS, B)
+        nck = max(1, min(args.check_streams, B))
         which = sorted(set(int(round(k * (B - 1) / max(nck - 1, 1))) for k in range(nck)))
     else:
         which = sorted(set([0, B - 1]))
@@ -601,7 +606,8 @@ def main():
     dt = rdv.max(time.perf_counter() - t0)
     # what each rank did, for the one line rank 0 prints (timing scalars only; no stream data ever crosses ranks)
     # every rank checks its own streams (after the timed region; a difference ends the rank with an error, and with it the run)
-    checked = check_against_oracle(batch, enc_args, host_streams, which, procs=_cpu_budget() if rank == 0 else 1)
+    checked = check_against_oracle(batch, enc_args, host_streams, which,
+                                   procs=(args.check_procs or _cpu_budget()) if rank == 0 else 1)
     per_rank = rdv.gather([rank, device_index, lo, hi, own_dt, own_cpu, sum(kernel_ms) / len(kernel_ms), float(checked["streams"])])
 
     if rank == 0:

@@ -1185,12 +1185,6 @@ lq_outer_loop(const LhCtx & c, LhQS & S, LhChanLds & Q, LhQR & R, LhGrR & gb, co
         best_noise_info.bits = gb.part2_3_length;
         lq_keep_best < NS, OLD > (c, S, Q, keep);
         gw = gb;
-        /* The best candidate's side information waits in the wave's LDS slot, not in twenty scalar registers beside the
-         * working candidate's: the loop reads one field of it (its bit count) and replaces it only when a candidate is
-         * better; the scalar register file is what this loop runs out of. */
-        int     best_bits = gb.part2_3_length;
-        if (c.lane == 0)
-            lh_lds.rg[ch].g = gb;
         age = 0;
         do {
             LhNoiseRes noise_info;
@@ -1250,12 +1244,10 @@ lq_outer_loop(const LhCtx & c, LhQS & S, LhChanLds & Q, LhQR & R, LhGrR & gb, co
             noise_info.bits = gw.part2_3_length;
             better = lh_quant_compare(best_noise_info, noise_info);
             if (better) {
-                best_part2_3_length = best_bits;
+                best_part2_3_length = gb.part2_3_length;
                 best_noise_info = noise_info;
                 lq_keep_best < NS, OLD > (c, S, Q, keep);
-                best_bits = gw.part2_3_length;
-                if (c.lane == 0)
-                    lh_lds.rg[ch].g = gw;
+                gb = gw;
                 age = 0;
             }
             else {
@@ -1266,8 +1258,6 @@ lq_outer_loop(const LhCtx & c, LhQS & S, LhChanLds & Q, LhQR & R, LhGrR & gb, co
             }
         }
         while ((gw.global_gain + gw.scalefac_scale) < 255);
-        LH_WAVE_SYNC();
-        gb = lh_uniform(lh_lds.rg[ch].g);
     }
     else
         lq_keep_best < NS, OLD > (c, S, Q, keep);

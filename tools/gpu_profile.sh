@@ -6,7 +6,7 @@
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 TAG=$1; shift
-ARGS=${*:---streams 1024 --seconds 5 --steps 2 --warmup 1 --no-cpu-baseline --no-extras}
+ARGS="${*:---streams 1024 --seconds 5 --steps 2 --warmup 1 --no-cpu-baseline --no-extras} --no-end-to-end --check-streams 4 --check-procs 1"   # (no child processes under the profiler: it attaches to each)
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
