@@ -681,7 +681,7 @@ def main():
     rdv.close()
 
 
-def end_to_end(torch, lamehip, enc, B, sr, dev, seconds=30.0, rounds=6, nbatch=2):
+def end_to_end(torch, lamehip, enc, B, sr, dev, seconds=30.0, rounds=8, nbatch=2):
     """SURVEY.md 8(d) region R2: s16 PCM in pinned host memory -> H2D -> kernel -> D2H -> mp3 bytes in host
     memory, as a pipeline of `nbatch' batch objects (each with its own HIP stream) that are reused round-robin
     for `rounds' batches of B streams x `seconds': batch n's kernel runs while batch n+1's PCM goes up and batch
@@ -729,18 +729,24 @@ def end_to_end(torch, lamehip, enc, B, sr, dev, seconds=30.0, rounds=6, nbatch=2
         sizes = sum(len(b.bytes_view(s)) for s in range(B))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    home = []                   # when each batch's bytes were in host memory
     for r in range(rounds):
         b = objs[r % nbatch]
         if r >= nbatch:
             got = sum(len(b.bytes_view(s)) for s in which)      # the previous batch of this object is home
             assert got > 0
+            home.append(time.perf_counter())
         mark(b)
         b.upload()
         b.encode(sync=False)
         b.fetch()
-    for b in objs:
-        b.bytes_view(0)
+    for k in range(nbatch):
+        objs[(rounds + k) % nbatch].bytes_view(0)
+        home.append(time.perf_counter())
     dt_dev = time.perf_counter() - t0
+    # batch to batch once the pipeline is full: from the first batch's arrival to the last one's (the whole-run figure above
+    # also holds the first upload and the last fetch, which nothing overlaps)
+    steady = (len(home) - 1) * B * seconds / (home[-1] - home[0])
     dev_bytes = {s: bytes(objs[0].bytes_view(s)) for s in which}
     # phases of one batch alone (no overlap), for the record
     b = objs[0]
@@ -794,6 +800,10 @@ def end_to_end(torch, lamehip, enc, B, sr, dev, seconds=30.0, rounds=6, nbatch=2
     return {"value": round(audio / dt_host, 1), "unit": "x real-time", "host_threads": threads,
             "mp3_bytes_per_batch": res_sizes[0], "hbm_resident_same_sample": round(resident, 1),
             "device_packed": {"value": round(audio / dt_dev, 1), "unit": "x real-time", "mp3_bytes_per_batch": int(sizes),
+                              "steady_state": round(steady, 1),
+                              "steady_state_note": "batches per second between the first and the last batch's arrival in host "
+                                                   "memory (pipeline full); `value' is the whole run of %d batches, fill and "
+                                                   "drain included" % rounds,
                               "one_batch_alone_s": {"h2d": round(p1 - p0, 4), "kernel": round(p2 - p1, 4),
                                                     "d2h": round(p3 - p2, 4)},
                               "bytes_checked_against_host_packer": {"streams": which, "result": "identical"}},
