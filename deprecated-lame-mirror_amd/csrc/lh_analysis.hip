@@ -171,12 +171,18 @@ lh_attack_kernel(const LhConfig * cfg, const int16_t * pcm, const float *pcmf, c
                 span[ch * LH_FIR_SPAN + i0 + m] = y[ch][m];
     }
     LH_WAVE_SYNC();
+    float   fl[9], fr[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        fl[k] = span[lane + 64 * k];
+        fr[k] = span[LH_FIR_SPAN + lane + 64 * k];
+    }
     for (int chn = 0; chn < n_chn_psy; chn++) {
         /* peak k = the largest magnitude among samples 64 k .. 64 k + 63 (exact under any order) */
         uint32_t pk[8], pk8 = 0;
+#pragma unroll
         for (int k = 0; k < 9; k++) {
-            int const i = lane + 64 * k;
-            float const l = span[i], r = span[LH_FIR_SPAN + i];
+            float const l = fl[k], r = fr[k];
             float const v = (chn == 0) ? l : (chn == 1) ? r : (chn == 2) ? l + r : l - r;
             if (k < 8)
                 pk[k] = lh_f32_as_u32(lh_fabsf(v));
@@ -197,6 +203,9 @@ lh_attack_kernel(const LhConfig * cfg, const int16_t * pcm, const float *pcmf, c
  * the four pseudo-channels sit side by side in the wave -- lane 16 chn + i (i < 12) owns sub-block i of channel chn, every
  * lane of a group of 16 forms its channel's verdicts (the same in all of them) --, and the next granule's peaks are on their
  * way while this one's verdicts are formed. */
+#ifndef LH_SCAN_BLOCK
+#define LH_SCAN_BLOCK 4
+#endif
 #ifndef LH_EMU
 extern "C" __global__ void __launch_bounds__(64)
 #else
@@ -222,111 +231,135 @@ lh_attack_scan_kernel(const LhConfig * cfg, const LhTables * T, const LhStreamDe
     int     last_att = st->last_attacks[chn];
     float const thresh = T->attack_threshold[chn];
     int     bt_old0 = lh_uni_i(st->blocktype_old[0]), bt_old1 = lh_uni_i(st->blocktype_old[1]);
-    float   pk_next = frames[d.out_index].small.gr[0].peak[chn][i < 9 ? i : 0];
-    for (int g = 0; g < LH_NGR * nf; g++) {
-        int const fr = g / LH_NGR, gr = g - fr * LH_NGR;
-        LhMidGr *mg = &frames[d.out_index + fr].small.gr[gr];
-        float const pk = pk_next;
-        if (g + 1 < LH_NGR * nf) {
-            int const f2 = (g + 1) / LH_NGR, g2 = (g + 1) - f2 * LH_NGR;
-            pk_next = frames[d.out_index + f2].small.gr[g2].peak[chn][i < 9 ? i : 0];
+    /* Only the last few steps of a granule's verdicts depend on the granule before (last_attacks, the block types): everything
+     * up to there -- the ratios, the votes, the 1.7 rule -- is formed for LH_SCAN_BLOCK granules side by side, so that the
+     * cross-lane latencies of one granule hide behind the others', and the short dependent tails follow one another. */
+    int const ng = LH_NGR * nf;
+    float   pk_blk[LH_SCAN_BLOCK];
+#pragma unroll
+    for (int j = 0; j < LH_SCAN_BLOCK; j++) {
+        int const g = (j < ng) ? j : 0;
+        pk_blk[j] = frames[d.out_index + g / LH_NGR].small.gr[g % LH_NGR].peak[chn][i < 9 ? i : 0];
+    }
+    for (int g0 = 0; g0 < ng; g0 += LH_SCAN_BLOCK) {
+        float   pk_cur[LH_SCAN_BLOCK], ssf_blk[LH_SCAN_BLOCK];
+        int     nsa_blk[LH_SCAN_BLOCK][4];
+#pragma unroll
+        for (int j = 0; j < LH_SCAN_BLOCK; j++) {
+            int const gn = g0 + LH_SCAN_BLOCK + j, g = (gn < ng) ? gn : 0;
+            pk_cur[j] = pk_blk[j];
+            pk_blk[j] = frames[d.out_index + g / LH_NGR].small.gr[g % LH_NGR].peak[chn][i < 9 ? i : 0];
         }
-        /* twelve sub-blocks per channel: three from the previous granule, nine new ones */
-        float const fresh = pk < 1.0f ? 1.0f : pk;      /* lane k < 9 of the group: the new sub-block k */
-        float const old = lh_shfl_f32(le, grp + ((i + 6) & 15)), older = lh_shfl_f32(le, grp + ((i + 4) & 15));
-        float const got = lh_shfl_f32(fresh, grp + ((i - 3) & 15));
-        float const e = (i < 3) ? old : got;
-        float const e1 = lh_shfl_f32(e, grp + ((i - 1) & 15)), e0 = lh_shfl_f32(e, grp + ((i - 2) & 15));
-        float const then = (i < 3) ? older : e0;
-        float const ai = (i < 3) ? e / then : (e > then) ? e / then : (then > e * 10.0f) ? then / (e * 10.0f) : 0.0f;
-        float const whole = e0 + e1 + e;
-        int const tail_low = e * 6 < whole, mid_low = e1 * 6 < whole;
-        uint64_t const over_all = lh_ballot(i < 12 && ai > thresh);
-        unsigned const over = (unsigned) (over_all >> (16 * chn)) & 0xfffu;    /* this channel's twelve bits */
-        float   en_short[4];
-        en_short[0] = lh_shfl_f32(whole, grp + 2);
-        en_short[1] = lh_shfl_f32(whole, grp + 5);
-        en_short[2] = lh_shfl_f32(whole, grp + 8);
-        en_short[3] = lh_shfl_f32(whole, grp + 11);
-        float const ssf = tail_low ? (mid_low ? 0.25f : 0.5f) : 1.0f;   /* lanes 5, 8, 11 of a group: sub_short_factor[0..2] */
-        int     nsa[4];
-        int     uselong = 1;
-        le = fresh;
-        for (int gq = 0; gq < 4; gq++) {
-            /* the first sub-block of the short block whose ratio exceeds the threshold, 1-based */
-            unsigned const bits = (over >> (3 * gq)) & 7u;
-            nsa[gq] = bits ? ((bits & 1u) ? 1 : (bits & 2u) ? 2 : 3) : 0;
-        }
-        for (int q = 1; q < 4; q++) {
-            float const u = en_short[q - 1];
-            float const v = en_short[q];
-            float const m = (u > v) ? u : v;
-            if (m < 40000) {
-                if (u < 1.7f * v && v < 1.7f * u) {
-                    if (q == 1 && nsa[0] <= nsa[q])
-                        nsa[0] = 0;
-                    nsa[q] = 0;
+#pragma unroll
+        for (int j = 0; j < LH_SCAN_BLOCK; j++) {
+            float const pk = pk_cur[j];
+            /* twelve sub-blocks per channel: three from the previous granule, nine new ones */
+            float const fresh = pk < 1.0f ? 1.0f : pk;  /* lane k < 9 of the group: the new sub-block k */
+            float const old = lh_shfl_f32(le, grp + ((i + 6) & 15)), older = lh_shfl_f32(le, grp + ((i + 4) & 15));
+            float const got = lh_shfl_f32(fresh, grp + ((i - 3) & 15));
+            float const e = (i < 3) ? old : got;
+            float const e1 = lh_shfl_f32(e, grp + ((i - 1) & 15)), e0 = lh_shfl_f32(e, grp + ((i - 2) & 15));
+            float const then = (i < 3) ? older : e0;
+            float const ai = (i < 3) ? e / then : (e > then) ? e / then : (then > e * 10.0f) ? then / (e * 10.0f) : 0.0f;
+            float const whole = e0 + e1 + e;
+            int const tail_low = e * 6 < whole, mid_low = e1 * 6 < whole;
+            uint64_t const over_all = lh_ballot(i < 12 && ai > thresh);
+            unsigned const over = (unsigned) (over_all >> (16 * chn)) & 0xfffu;        /* this channel's twelve bits */
+            float   en_short[4];
+            en_short[0] = lh_shfl_f32(whole, grp + 2);
+            en_short[1] = lh_shfl_f32(whole, grp + 5);
+            en_short[2] = lh_shfl_f32(whole, grp + 8);
+            en_short[3] = lh_shfl_f32(whole, grp + 11);
+            ssf_blk[j] = tail_low ? (mid_low ? 0.25f : 0.5f) : 1.0f;   /* lanes 5, 8, 11 of a group: sub_short_factor[0..2] */
+            int    *nsa = nsa_blk[j];
+            le = fresh;
+            for (int gq = 0; gq < 4; gq++) {
+                /* the first sub-block of the short block whose ratio exceeds the threshold, 1-based */
+                unsigned const bits = (over >> (3 * gq)) & 7u;
+                nsa[gq] = bits ? ((bits & 1u) ? 1 : (bits & 2u) ? 2 : 3) : 0;
+            }
+            for (int q = 1; q < 4; q++) {
+                float const u = en_short[q - 1];
+                float const v = en_short[q];
+                float const m = (u > v) ? u : v;
+                if (m < 40000) {
+                    if (u < 1.7f * v && v < 1.7f * u) {
+                        if (q == 1 && nsa[0] <= nsa[q])
+                            nsa[0] = 0;
+                        nsa[q] = 0;
+                    }
                 }
             }
         }
-        if (nsa[0] <= last_att)
-            nsa[0] = 0;
-        if (last_att == 3 || nsa[0] + nsa[1] + nsa[2] + nsa[3]) {
-            uselong = 0;
-            if (nsa[1] && nsa[0])
-                nsa[1] = 0;
-            if (nsa[2] && nsa[1])
-                nsa[2] = 0;
-            if (nsa[3] && nsa[2])
-                nsa[3] = 0;
-        }
-        if (!mine) {
-            nsa[0] = nsa[1] = nsa[2] = nsa[3] = 0;
-            uselong = 1;
-        }
-        else
-            last_att = nsa[2];
-        if (i == 5 || i == 8 || i == 11)
-            mg->sub_short_factor[chn][(i - 5) / 3] = mine ? ssf : 1.0f;
-        if (i < 4)
-            mg->ns_attacks[chn][i] = (int8_t) (i == 0 ? nsa[0] : i == 1 ? nsa[1] : i == 2 ? nsa[2] : nsa[3]);
-        {
-            /* uselongblock[] (reference psymodel.c:926-933, 1265-1286) and the block types (:1289-1319): wave-uniform */
-            uint64_t const shorts = lh_ballot(!uselong);
-            int const s0 = (int) (shorts & 1u), s1 = (int) ((shorts >> 16) & 1u), s23 = (int) ((shorts >> 32) & 0x10001u) != 0;
-            int     ul0 = !s0, ul1 = (channels == 2) ? !s1 : 1;
-            int     btd[2];
-            if (s23)
-                ul0 = ul1 = 0;
-            if (short_blocks == 1 && !(ul0 && ul1))
-                ul0 = ul1 = 0;
-            if (short_blocks == 2)
-                ul0 = ul1 = 1;
-            if (short_blocks == 3)
-                ul0 = ul1 = 0;
-            for (int ch = 0; ch < 2; ch++) {
-                int     blocktype = LH_NORM_TYPE;
-                int     was = ch ? bt_old1 : bt_old0;
-                if (ch ? ul1 : ul0) {
-                    if (was == LH_SHORT_TYPE)
-                        blocktype = LH_STOP_TYPE;
-                }
-                else {
-                    blocktype = LH_SHORT_TYPE;
-                    if (was == LH_NORM_TYPE)
-                        was = LH_START_TYPE;
-                    if (was == LH_STOP_TYPE)
-                        was = LH_SHORT_TYPE;
-                }
-                btd[ch] = was;
-                if (ch)
-                    bt_old1 = lh_uni_i(blocktype);
-                else
-                    bt_old0 = lh_uni_i(blocktype);
+#pragma unroll
+        for (int j = 0; j < LH_SCAN_BLOCK; j++) {
+            int const g = g0 + j;
+            if (g >= ng)
+                break;
+            int const fr = g / LH_NGR, gr = g - fr * LH_NGR;
+            LhMidGr *mg = &frames[d.out_index + fr].small.gr[gr];
+            int    *nsa = nsa_blk[j];
+            float const ssf = ssf_blk[j];
+            int     uselong = 1;
+            if (nsa[0] <= last_att)
+                nsa[0] = 0;
+            if (last_att == 3 || nsa[0] + nsa[1] + nsa[2] + nsa[3]) {
+                uselong = 0;
+                if (nsa[1] && nsa[0])
+                    nsa[1] = 0;
+                if (nsa[2] && nsa[1])
+                    nsa[2] = 0;
+                if (nsa[3] && nsa[2])
+                    nsa[3] = 0;
             }
-            if (lane < 2) {
-                mg->uselong[lane] = (int8_t) (lane ? ul1 : ul0);
-                mg->block_type[lane] = (int8_t) (lane ? btd[1] : btd[0]);
+            if (!mine) {
+                nsa[0] = nsa[1] = nsa[2] = nsa[3] = 0;
+                uselong = 1;
+            }
+            else
+                last_att = nsa[2];
+            if (i == 5 || i == 8 || i == 11)
+                mg->sub_short_factor[chn][(i - 5) / 3] = mine ? ssf : 1.0f;
+            if (i < 4)
+                mg->ns_attacks[chn][i] = (int8_t) (i == 0 ? nsa[0] : i == 1 ? nsa[1] : i == 2 ? nsa[2] : nsa[3]);
+            {
+                /* uselongblock[] (reference psymodel.c:926-933, 1265-1286) and the block types (:1289-1319): wave-uniform */
+                uint64_t const shorts = lh_ballot(!uselong);
+                int const s0 = (int) (shorts & 1u), s1 = (int) ((shorts >> 16) & 1u), s23 = (int) ((shorts >> 32) & 0x10001u) != 0;
+                int     ul0 = !s0, ul1 = (channels == 2) ? !s1 : 1;
+                int     btd[2];
+                if (s23)
+                    ul0 = ul1 = 0;
+                if (short_blocks == 1 && !(ul0 && ul1))
+                    ul0 = ul1 = 0;
+                if (short_blocks == 2)
+                    ul0 = ul1 = 1;
+                if (short_blocks == 3)
+                    ul0 = ul1 = 0;
+                for (int ch = 0; ch < 2; ch++) {
+                    int     blocktype = LH_NORM_TYPE;
+                    int     was = ch ? bt_old1 : bt_old0;
+                    if (ch ? ul1 : ul0) {
+                        if (was == LH_SHORT_TYPE)
+                            blocktype = LH_STOP_TYPE;
+                    }
+                    else {
+                        blocktype = LH_SHORT_TYPE;
+                        if (was == LH_NORM_TYPE)
+                            was = LH_START_TYPE;
+                        if (was == LH_STOP_TYPE)
+                            was = LH_SHORT_TYPE;
+                    }
+                    btd[ch] = was;
+                    if (ch)
+                        bt_old1 = lh_uni_i(blocktype);
+                    else
+                        bt_old0 = lh_uni_i(blocktype);
+                }
+                if (lane < 2) {
+                    mg->uselong[lane] = (int8_t) (lane ? ul1 : ul0);
+                    mg->block_type[lane] = (int8_t) (lane ? btd[1] : btd[0]);
+                }
             }
         }
     }

@@ -339,7 +339,8 @@ struct LhVbrOldSave {
 struct LhQuantLds {
     LhChanLds ch[2];
 };
-static_assert(__builtin_offsetof(LhTables, pow43) % 128 == 0 && __builtin_offsetof(LhTables, vqthr) % 128 == 0,
+static_assert(__builtin_offsetof(LhTables, pow43) % 128 == 0 && __builtin_offsetof(LhTables, vqthr) % 128 == 0
+              && __builtin_offsetof(LhTables, vq3) % 128 == 0,
               "the gathered tables start on cache lines (hipMalloc aligns the struct itself)");
 static_assert(sizeof(LhChanLds) % 16 == 0, "both channels' float2/float4 accesses need 16-byte alignment");
 static_assert(__builtin_offsetof(LhPsyLds, mid.small) >= __builtin_offsetof(LhChanLds, ix[1]) + sizeof(((LhChanLds *) 0)->ix[1])

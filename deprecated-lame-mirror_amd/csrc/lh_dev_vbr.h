@@ -134,9 +134,6 @@ lh_vbr_geometry(const LhCtx & c, LhChanLds & Q, const LhQR & R)
 #ifndef LH_VBR_MARGIN
 #define LH_VBR_MARGIN 6e-5      /* tests widen it to drive every comparison through the exact chain */
 #endif
-/* table[i] of a table in HBM with the byte offset formed in 32 bits: a wave-uniform base plus a 32-bit lane
- * offset is one addressing mode of the global load (no 64-bit address arithmetic per lane, and no shared
- * zero register that would serialise a batch of look-ups) */
 /* -1 (all ones) when x < 0, else 0, as plain vector arithmetic: "a < b" as lh_sign_mask(a - b) is exact (a
  * float difference is negative exactly when a < b; denormals are kept) and, unlike a comparison, does not
  * pass through a scalar register pair, where a run of compare / use pairs would queue up */
@@ -146,10 +143,50 @@ lh_sign_mask(float x)
     return (uint32_t) ((int32_t) lh_f32_as_u32(x) >> 31);
 }
 
-LH_DEVFN float
-lh_gather_f32(const float *table, uint32_t i)
+/* Inclusive sums of f[] over runs of equal keys (the lanes of a run are neighbours, keys < 2^32 - 1): afterwards the last
+ * lane of a run holds the run's sums.  Four row_shr steps inside the rows of 16, then the rows' last lanes carried over: lanes
+ * 15 and 47 into rows 1 and 3, lane 31 into rows 2 and 3 -- cross-lane network and scalar reads only, no LDS.  The additions
+ * form a tree; for sums whose use tolerates any order (non-negative terms: relative error <= 7 x 2^-24). */
+template < int N > LH_DEVFN void
+lh_seg_scan_addf(float (&f)[N], uint32_t key)
 {
-    return *(const float *) ((const char *) table + (i << 2));
+    uint32_t const k = key + 1u;        /* a lane without a source reads 0, which is no key */
+    int const row = lh_lane() >> 4;
+#define LH_SEG_STEP(D) { \
+        uint32_t const kd_ = lh_row_shr_u32 < D > (k); \
+        _Pragma("unroll") for (int i_ = 0; i_ < N; i_++) { \
+            float const fd_ = lh_u32_as_f32(lh_row_shr_u32 < D > (lh_f32_as_u32(f[i_]))); \
+            f[i_] += (kd_ == k) ? fd_ : 0.0f; } }
+    LH_SEG_STEP(1) LH_SEG_STEP(2) LH_SEG_STEP(4) LH_SEG_STEP(8)
+#undef LH_SEG_STEP
+    {
+        uint32_t const k15 = lh_bcast_u32(k, 15), k47 = lh_bcast_u32(k, 47);
+        int const take = (row == 1 && k15 == k) || (row == 3 && k47 == k);
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            float const f15 = lh_u32_as_f32(lh_bcast_u32(lh_f32_as_u32(f[i]), 15));
+            float const f47 = lh_u32_as_f32(lh_bcast_u32(lh_f32_as_u32(f[i]), 47));
+            f[i] += take ? (row == 1 ? f15 : f47) : 0.0f;
+        }
+    }
+    {
+        uint32_t const k31 = lh_bcast_u32(k, 31);
+        int const take = row >= 2 && k31 == k;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            float const f31 = lh_u32_as_f32(lh_bcast_u32(lh_f32_as_u32(f[i]), 31));
+            f[i] += take ? f31 : 0.0f;
+        }
+    }
+}
+
+/* table[i] of a table in HBM with the byte offset formed in 32 bits: a wave-uniform base plus a 32-bit lane
+ * offset is one addressing mode of the global load (no 64-bit address arithmetic per lane, and no shared
+ * zero register that would serialise a batch of look-ups) */
+LH_DEVFN lh_f32x4
+lh_gather_f32x4(const float *table, uint32_t i)
+{
+    return *(const lh_f32x4 *) ((const char *) table + (i << 4));
 }
 
 template < int NV > LH_DEVFN void
@@ -200,16 +237,16 @@ lh_vbr_noisy_n(const LhCtx & c, LhChanLds & Q, const LhVbrGeo & G, const float *
                 x34[k] = Q.xrpow[lc];
                 ax[k] = lh_fabsf(xr[lc]);
             }
-            /* straight-line code.  The first rounding is a float addition, the second a comparison with
-             * LhTables.vqthr (tests/test_quantizer_identity.py).  Both table look-ups of all lines and
-             * variants go to HBM (L1/L2 resident, 64 KiB) unconditionally, so that they are in flight
-             * together; trial steps below the final one quantise to large values, which LDS heads would
+            /* straight-line code.  The first rounding is a float addition, the second a comparison with the class's
+             * threshold (LhTables.vq3, tests/test_quantizer_identity.py), which sits beside the two values of pow43 the class
+             * can take: ONE 16-byte look-up per line and variant, all of them in flight together.  They go to HBM (L1/L2
+             * resident) unconditionally; trial steps below the final one quantise to large values, which LDS heads would
              * not cover */
             {
                 float   sfpow[NV];
                 float   a[NV][4];
-                uint32_t k1[NV][4];
-                float   reach[NV][4], p43[NV][4];
+                lh_f32x4 cls[NV][4];
+                float   p43[NV][4], part[NV];
 #pragma unroll
                 for (int v = 0; v < NV; v++) {
                     int const sv = (int) ((pack >> (9 * v)) & 511u);
@@ -219,7 +256,8 @@ lh_vbr_noisy_n(const LhCtx & c, LhChanLds & Q, const LhVbrGeo & G, const float *
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         a[v][k] = sfpow34 * x34[k];
-                        k1[v][k] = lh_f32_as_u32(a[v][k] + (float) LH_MAGIC_FLOAT) - (uint32_t) LH_MAGIC_INT;
+                        uint32_t const k1 = lh_f32_as_u32(a[v][k] + (float) LH_MAGIC_FLOAT) - (uint32_t) LH_MAGIC_INT;
+                        cls[v][k] = lh_gather_f32x4(&T->vq3[0][0], k1);
                     }
                 }
                 LH_SCHED_FENCE();
@@ -227,19 +265,10 @@ lh_vbr_noisy_n(const LhCtx & c, LhChanLds & Q, const LhVbrGeo & G, const float *
                 for (int v = 0; v < NV; v++)
 #pragma unroll
                     for (int k = 0; k < 4; k++)
-                        reach[v][k] = lh_gather_f32(T->vqthr, k1[v][k]);
-                LH_SCHED_FENCE();
-#pragma unroll
-                for (int v = 0; v < NV; v++)
-#pragma unroll
-                    for (int k = 0; k < 4; k++)
-                        k1[v][k] = k1[v][k] + lh_sign_mask(a[v][k] - lh_fabsf(reach[v][k])) + (lh_f32_as_u32(reach[v][k]) >> 31);
-                LH_SCHED_FENCE();
-#pragma unroll
-                for (int v = 0; v < NV; v++)
-#pragma unroll
-                    for (int k = 0; k < 4; k++)
-                        p43[v][k] = lh_gather_f32(T->pow43, k1[v][k]);
+                        {
+                        uint32_t const below = lh_sign_mask(a[v][k] - cls[v][k].x);
+                        p43[v][k] = lh_u32_as_f32((lh_f32_as_u32(cls[v][k].y) & below) | (lh_f32_as_u32(cls[v][k].z) & ~below));
+                    }
                 LH_SCHED_FENCE();
 #pragma unroll
                 for (int v = 0; v < NV; v++) {
@@ -250,10 +279,18 @@ lh_vbr_noisy_n(const LhCtx & c, LhChanLds & Q, const LhVbrGeo & G, const float *
                         e[k] = (k < cnt) ? (double) d : 0.0;
                     }
                     gs = (e[0] * e[0] + e[1] * e[1]) + (e[2] * e[2] + e[3] * e[3]);
-                    if (gi < G.ngroups) {
+                    if (gi < G.ngroups)
                         gsum[v * G.ngroups + gi] = gs;
-                        lh_lds_addf(&approx[v][b], (float) gs);
-                    }
+                    part[v] = (gi < G.ngroups) ? (float) gs : 0.0f;
+                }
+                /* the approximate band sums: a band's groups are neighbouring lanes -- summed over the cross-lane network, and
+                 * the band's last lane of the round adds the total (64 lanes adding to a handful of LDS words one after the
+                 * other was a fifth of the VBR frame: profiles/r05_vbr_stage_profile.txt) */
+                lh_seg_scan_addf < NV > (part, (gi < G.ngroups) ? (uint32_t) b : 0xfffffff0u);
+                if (gi < G.ngroups && (s == 63 || cnt <= 4)) {
+#pragma unroll
+                    for (int v = 0; v < NV; v++)
+                        lh_lds_addf(&approx[v][b], part[v]);
                 }
             }
         }

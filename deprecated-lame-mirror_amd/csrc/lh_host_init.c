@@ -1222,6 +1222,10 @@ build_vbr_quant_thresholds(LhTables * t)
                     below = mid;
             }
         }
+        t->vq3[k][0] = reach.f;
+        t->vq3[k][1] = (v_hi >= 1 && v_hi - 1 < LH_PRECALC) ? t->pow43[v_hi - 1] : 0.0f;
+        t->vq3[k][2] = (v_hi < LH_PRECALC) ? t->pow43[v_hi] : 0.0f;
+        t->vq3[k][3] = 0.0f;
         if (upper)
             reach.u |= 0x80000000u;
         t->vqthr[k] = reach.f;

@@ -1044,6 +1044,25 @@ lh_selftest_kernel(unsigned *out, unsigned seed)
             bad += (lh_lane_minus_u32 < 2 > (x) != ((lane & 15u) >= 2 ? vals[lane - 2] : 0u));
             bad += (lh_lane_above_u32(x, x ^ 0x5a5a5a5au) != (lane < 63 ? vals[lane + 1] : (vals[0] ^ 0x5a5a5a5au)));
         }
+        {
+            /* sums over runs of equal keys (lh_seg_scan_addf, lh_dev_vbr.h): runs of 1 .. 40 lanes from the round's bits, small
+             * integers as floats (exact under any order); checked at the last lane of every run */
+            __shared__ unsigned keys[64];
+            unsigned const len = 1u + (seed + round * 7u) % 40u;
+            unsigned const key = (lane + (round & 7u)) / len;
+            float   f[2] = { (float) (x & 1023u), (float) ((x >> 10) & 255u) };
+            keys[lane] = key;
+            __syncthreads();
+            lh_seg_scan_addf < 2 > (f, key);
+            if (lane == 63 || keys[lane + 1 < 64 ? lane + 1 : 63] != key) {
+                float   w0 = 0.0f, w1 = 0.0f;
+                for (int i = (int) lane; i >= 0 && keys[i] == key; i--) {
+                    w0 += (float) (vals[i] & 1023u);
+                    w1 += (float) ((vals[i] >> 10) & 255u);
+                }
+                bad += (f[0] != w0) + (f[1] != w1);
+            }
+        }
         bad += (lh_wave_min_u32(x) != rmin);
         bad += (lh_wave_or_u32(x) != ror);
         bad += (lh_ballot((x & 4u) != 0) != rbal);

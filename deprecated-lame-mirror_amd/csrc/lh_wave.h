@@ -214,6 +214,15 @@ lh_lane_minus_u32(uint32_t v)
     return me >= N ? (uint32_t) x[me - N] : 0u;
 }
 
+/* value of lane - D of the same row of 16 lanes (0 where there is none): the device's row_shr */
+template < int D > static inline uint32_t
+lh_row_shr_u32(uint32_t v)
+{
+    const uint64_t *x = hipemu_wave_exchange(v);
+    int const me = lh_lane();
+    return (me & 15) >= D ? (uint32_t) x[me - D] : 0u;
+}
+
 /* value of the lane below (0 for lane 0) */
 static inline uint32_t
 lh_lane_below_u32(uint32_t v)
@@ -510,6 +519,12 @@ template < int N > __device__ __forceinline__ uint32_t
 lh_lane_minus_u32(uint32_t v)
 {
     return lh_dpp < 0x110 + N, 0u > (v);
+}
+
+template < int D > __device__ __forceinline__ uint32_t
+lh_row_shr_u32(uint32_t v)
+{
+    return lh_dpp < 0x110 + D, 0u > (v);
 }
 
 /* value of the lane below (0 for lane 0; within a row of 16, which is all count_bits asks for) */

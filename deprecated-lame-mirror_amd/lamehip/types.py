@@ -40,7 +40,8 @@ class LhTables(C.Structure):
         ("sfb_l", C.c_int * (SBMAX_L + 1)), ("sfb_s", C.c_int * (SBMAX_S + 1)),
         ("psfb21", C.c_int * (PSFB21 + 1)), ("psfb12", C.c_int * (PSFB12 + 1)),
         ("line_pad0", C.c_int * 13), ("pow43", C.c_float * PRECALC), ("line_pad1", C.c_float * 16),
-        ("vqthr", C.c_float * PRECALC), ("adj43asm", C.c_float * PRECALC),
+        ("vqthr", C.c_float * PRECALC), ("line_pad2", C.c_float * 16), ("vq3", (C.c_float * 4) * PRECALC),
+        ("adj43asm", C.c_float * PRECALC),
         ("ipow20", C.c_float * QMAX), ("pow20", C.c_float * (QMAX + QMAX2 + 1)),
         ("bv_scf", C.c_int * 576),
         ("ath_l", C.c_float * SBMAX_L), ("ath_s", C.c_float * SBMAX_S),

@@ -162,6 +162,11 @@ typedef struct LhTables {
      * that gives the higher value (0 when the whole class does).  lh_tables_init refuses a table where a
      * class would take three values. */
     float   vqthr[LH_PRECALC];
+    float   line_pad2[16];
+    /* vqthr and the two values of pow43 a class can take, side by side (one 16-byte look-up of the VBR noise search instead of
+     * two dependent ones): { |vqthr[k]|, pow43[higher - 1], pow43[higher], 0 }, higher = k or k + 1 as vqthr's sign says --
+     * the line's pow43 is [1] when a < [0], else [2] */
+    float   vq3[LH_PRECALC][4];
     float   adj43asm[LH_PRECALC];
     float   ipow20[LH_QMAX];
     float   pow20[LH_QMAX + LH_QMAX2 + 1];

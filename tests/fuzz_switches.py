@@ -135,7 +135,7 @@ def main():
             if mp3 is not None:
                 dc = struct_diff(rcfg, cfg, skip=("bitrate_index",))
                 dt = struct_diff(rtab, tab, skip=("fft_window", "fft_window_s", "fht_tw", "ma_max_i1", "ma_max_i2", "psy_l_to_s", "hgrid",
-                                                  "qthr", "vqthr", "line_pad0", "line_pad1", "mask_mid", "bvpack"))
+                                                  "qthr", "vqthr", "vq3", "line_pad0", "line_pad1", "line_pad2", "mask_mid", "bvpack"))
                 if dc:
                     what = ("config", dc[:4])
                 elif dt:

@@ -96,8 +96,8 @@ def frame_hash(fr):
 def table_hashes(tab):
     out = {}
     for name, _ in tab._fields_:
-        if name in ("fft_window", "fft_window_s", "fht_tw", "ma_max_i1", "ma_max_i2", "psy_l_to_s", "hgrid", "qthr", "vqthr",
-                    "line_pad0", "line_pad1", "mask_mid"):
+        if name in ("fft_window", "fft_window_s", "fht_tw", "ma_max_i1", "ma_max_i2", "psy_l_to_s", "hgrid", "qthr", "vqthr", "vq3",
+                    "line_pad0", "line_pad1", "line_pad2", "mask_mid"):
             continue            # file-local in the reference (not visible through the harness), or derived for the device
         v = getattr(tab, name)
         out[name] = hashlib.sha256(bytes(v) if not isinstance(v, (int, float)) else repr(v).encode()).hexdigest()

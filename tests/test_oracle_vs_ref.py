@@ -25,7 +25,7 @@ def test_oracle_matches_reference(sr, br, mode, q, seed, secs, oracle, reference
     cfg, tab = enc.config(), enc.tables()
     assert not struct_diff(rcfg, cfg)
     assert not struct_diff(rtab, tab, skip=("fft_window", "fft_window_s", "fht_tw", "ma_max_i1", "ma_max_i2",
-                                            "psy_l_to_s", "hgrid", "qthr", "vqthr", "line_pad0", "line_pad1", "mask_mid", "bvpack"))
+                                            "psy_l_to_s", "hgrid", "qthr", "vqthr", "vq3", "line_pad0", "line_pad1", "line_pad2", "mask_mid", "bvpack"))
     frames = oracle.encode_frames(cfg, tab, pcm)
     assert len(frames) == nf
     mine = helpers.pack_frames(enc.lib, cfg, tab, frames)
@@ -55,7 +55,7 @@ def test_vbr_oracle_matches_reference(sr, vq, mode, q, seed, secs, white, oracle
     cfg, tab = enc.config(), enc.tables()
     assert not struct_diff(rcfg, cfg, skip=("bitrate_index",))      # run-time state in VBR mode
     assert not struct_diff(rtab, tab, skip=("fft_window", "fft_window_s", "fht_tw", "ma_max_i1", "ma_max_i2",
-                                            "psy_l_to_s", "hgrid", "qthr", "vqthr", "line_pad0", "line_pad1", "mask_mid", "bvpack"))
+                                            "psy_l_to_s", "hgrid", "qthr", "vqthr", "vq3", "line_pad0", "line_pad1", "line_pad2", "mask_mid", "bvpack"))
     frames = oracle.encode_frames(cfg, tab, pcm)
     assert len(frames) == nf
     mine = helpers.pack_frames(enc.lib, cfg, tab, frames)
@@ -83,7 +83,7 @@ def test_abr_oracle_matches_reference(sr, kb, mode, q, seed, secs, white, oracle
     cfg, tab = enc.config(), enc.tables()
     assert not struct_diff(rcfg, cfg, skip=("bitrate_index",))      # run-time state outside CBR
     assert not struct_diff(rtab, tab, skip=("fft_window", "fft_window_s", "fht_tw", "ma_max_i1", "ma_max_i2",
-                                            "psy_l_to_s", "hgrid", "qthr", "vqthr", "line_pad0", "line_pad1", "mask_mid", "bvpack"))
+                                            "psy_l_to_s", "hgrid", "qthr", "vqthr", "vq3", "line_pad0", "line_pad1", "line_pad2", "mask_mid", "bvpack"))
     frames = oracle.encode_frames(cfg, tab, pcm)
     assert len(frames) == nf
     mine = helpers.pack_frames(enc.lib, cfg, tab, frames)
@@ -113,7 +113,7 @@ def test_mono_oracle_matches_reference(sr, kw, q, nch, mode, oracle, reference):
     assert cfg.channels == 1 and (cfg.pcm_mix != 0) == (nch == 2)
     assert not struct_diff(rcfg, cfg, skip=("bitrate_index",))
     assert not struct_diff(rtab, tab, skip=("fft_window", "fft_window_s", "fht_tw", "ma_max_i1", "ma_max_i2",
-                                            "psy_l_to_s", "hgrid", "qthr", "vqthr", "line_pad0", "line_pad1", "mask_mid", "bvpack"))
+                                            "psy_l_to_s", "hgrid", "qthr", "vqthr", "vq3", "line_pad0", "line_pad1", "line_pad2", "mask_mid", "bvpack"))
     frames = oracle.encode_frames(cfg, tab, pcm)
     assert len(frames) == nf
     mine = helpers.pack_frames(enc.lib, cfg, tab, frames)

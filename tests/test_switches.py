@@ -114,7 +114,7 @@ def test_switch_oracle_matches_reference(kw, opts, oracle, reference):
     cfg, tab = enc.config(), enc.tables()
     assert not struct_diff(rcfg, cfg, skip=("bitrate_index",))
     assert not struct_diff(rtab, tab, skip=("fft_window", "fft_window_s", "fht_tw", "ma_max_i1", "ma_max_i2",
-                                            "psy_l_to_s", "hgrid", "qthr", "vqthr", "line_pad0", "line_pad1", "mask_mid", "bvpack"))
+                                            "psy_l_to_s", "hgrid", "qthr", "vqthr", "vq3", "line_pad0", "line_pad1", "line_pad2", "mask_mid", "bvpack"))
     frames = oracle.encode_frames(cfg, tab, pcm)
     assert len(frames) == nf
     assert helpers.pack_frames(enc.lib, cfg, tab, frames) == mp3
