@@ -143,15 +143,13 @@ lh_sign_mask(float x)
     return (uint32_t) ((int32_t) lh_f32_as_u32(x) >> 31);
 }
 
-/* Inclusive sums of f[] over runs of equal keys (the lanes of a run are neighbours, keys < 2^32 - 1): afterwards the last
- * lane of a run holds the run's sums.  Four row_shr steps inside the rows of 16, then the rows' last lanes carried over: lanes
- * 15 and 47 into rows 1 and 3, lane 31 into rows 2 and 3 -- cross-lane network and scalar reads only, no LDS.  The additions
- * form a tree; for sums whose use tolerates any order (non-negative terms: relative error <= 7 x 2^-24). */
+/* Inclusive sums of f[] over runs of equal keys inside the rows of 16 lanes (the lanes of a run are neighbours, keys < 2^32 - 1):
+ * afterwards the last lane a run has in a row holds the sums over the run's lanes of that row.  Four row_shr steps on the
+ * cross-lane network, no LDS.  The additions form a tree; for sums whose use tolerates any order. */
 template < int N > LH_DEVFN void
-lh_seg_scan_addf(float (&f)[N], uint32_t key)
+lh_row_seg_scan_addf(float (&f)[N], uint32_t key)
 {
     uint32_t const k = key + 1u;        /* a lane without a source reads 0, which is no key */
-    int const row = lh_lane() >> 4;
 #define LH_SEG_STEP(D) { \
         uint32_t const kd_ = lh_row_shr_u32 < D > (k); \
         _Pragma("unroll") for (int i_ = 0; i_ < N; i_++) { \
@@ -159,25 +157,6 @@ lh_seg_scan_addf(float (&f)[N], uint32_t key)
             f[i_] += (kd_ == k) ? fd_ : 0.0f; } }
     LH_SEG_STEP(1) LH_SEG_STEP(2) LH_SEG_STEP(4) LH_SEG_STEP(8)
 #undef LH_SEG_STEP
-    {
-        uint32_t const k15 = lh_bcast_u32(k, 15), k47 = lh_bcast_u32(k, 47);
-        int const take = (row == 1 && k15 == k) || (row == 3 && k47 == k);
-#pragma unroll
-        for (int i = 0; i < N; i++) {
-            float const f15 = lh_u32_as_f32(lh_bcast_u32(lh_f32_as_u32(f[i]), 15));
-            float const f47 = lh_u32_as_f32(lh_bcast_u32(lh_f32_as_u32(f[i]), 47));
-            f[i] += take ? (row == 1 ? f15 : f47) : 0.0f;
-        }
-    }
-    {
-        uint32_t const k31 = lh_bcast_u32(k, 31);
-        int const take = row >= 2 && k31 == k;
-#pragma unroll
-        for (int i = 0; i < N; i++) {
-            float const f31 = lh_u32_as_f32(lh_bcast_u32(lh_f32_as_u32(f[i]), 31));
-            f[i] += take ? f31 : 0.0f;
-        }
-    }
 }
 
 /* table[i] of a table in HBM with the byte offset formed in 32 bits: a wave-uniform base plus a 32-bit lane
@@ -283,11 +262,11 @@ lh_vbr_noisy_n(const LhCtx & c, LhChanLds & Q, const LhVbrGeo & G, const float *
                         gsum[v * G.ngroups + gi] = gs;
                     part[v] = (gi < G.ngroups) ? (float) gs : 0.0f;
                 }
-                /* the approximate band sums: a band's groups are neighbouring lanes -- summed over the cross-lane network, and
-                 * the band's last lane of the round adds the total (64 lanes adding to a handful of LDS words one after the
-                 * other was a fifth of the VBR frame: profiles/r05_vbr_stage_profile.txt) */
-                lh_seg_scan_addf < NV > (part, (gi < G.ngroups) ? (uint32_t) b : 0xfffffff0u);
-                if (gi < G.ngroups && (s == 63 || cnt <= 4)) {
+                /* the approximate band sums: a band's groups are neighbouring lanes -- summed over the cross-lane network inside
+                 * the rows of 16 lanes, and the last lane a band has in a row adds the row's share (64 lanes adding to a handful
+                 * of LDS words one after the other was a fifth of the VBR frame: profiles/r05_vbr_stage_profile.txt) */
+                lh_row_seg_scan_addf < NV > (part, (gi < G.ngroups) ? (uint32_t) b : 0xfffffff0u);
+                if (gi < G.ngroups && ((s & 15) == 15 || cnt <= 4)) {
 #pragma unroll
                     for (int v = 0; v < NV; v++)
                         lh_lds_addf(&approx[v][b], part[v]);

@@ -1045,18 +1045,19 @@ lh_selftest_kernel(unsigned *out, unsigned seed)
             bad += (lh_lane_above_u32(x, x ^ 0x5a5a5a5au) != (lane < 63 ? vals[lane + 1] : (vals[0] ^ 0x5a5a5a5au)));
         }
         {
-            /* sums over runs of equal keys (lh_seg_scan_addf, lh_dev_vbr.h): runs of 1 .. 40 lanes from the round's bits, small
-             * integers as floats (exact under any order); checked at the last lane of every run */
+            /* sums over runs of equal keys inside the rows of 16 lanes (lh_row_seg_scan_addf, lh_dev_vbr.h): runs of 1 .. 40
+             * lanes from the round's bits, small integers as floats (exact under any order); checked at the last lane every run
+             * has in a row */
             __shared__ unsigned keys[64];
             unsigned const len = 1u + (seed + round * 7u) % 40u;
             unsigned const key = (lane + (round & 7u)) / len;
             float   f[2] = { (float) (x & 1023u), (float) ((x >> 10) & 255u) };
             keys[lane] = key;
             __syncthreads();
-            lh_seg_scan_addf < 2 > (f, key);
-            if (lane == 63 || keys[lane + 1 < 64 ? lane + 1 : 63] != key) {
+            lh_row_seg_scan_addf < 2 > (f, key);
+            if ((lane & 15u) == 15u || keys[lane + 1] != key) {
                 float   w0 = 0.0f, w1 = 0.0f;
-                for (int i = (int) lane; i >= 0 && keys[i] == key; i--) {
+                for (int i = (int) lane; i >= (int) (lane & 48u) && keys[i] == key; i--) {
                     w0 += (float) (vals[i] & 1023u);
                     w1 += (float) ((vals[i] >> 10) & 255u);
                 }
