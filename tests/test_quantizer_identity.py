@@ -60,13 +60,15 @@ def test_float_root_equals_the_rounded_double_root():
 
 
 def test_threshold_comparison_equals_the_second_rounding_for_every_quantisable_float():
-    """LhTables.qthr (CBR search, k < 256: the quantised value) and LhTables.vqthr (VBR noise search, every k) against the reference's expression, for every float up to IXMAX + 0.5."""
+    """LhTables.qthr (CBR search, k < 256: the quantised value), LhTables.vqthr and LhTables.vq3 (VBR noise search, every k; vq3 = threshold and the class's two values of pow43, what the kernel reads) against the reference's expression, for every float up to IXMAX + 0.5."""
     import lamehip
     enc = lamehip.Encoder(44100, 128, require_device=False)
     T = enc.tables()
     adj = np.ctypeslib.as_array(T.adj43asm).astype(np.float32)
     thr = np.ctypeslib.as_array(T.qthr).astype(np.float32)
     vqthr = np.ctypeslib.as_array(T.vqthr).astype(np.float32)
+    vq3 = np.ctypeslib.as_array(T.vq3).astype(np.float32).reshape(-1, 4)
+    pow43 = np.ctypeslib.as_array(T.pow43).astype(np.float32)
     enc.close()
     assert np.all(adj[1:256] < 0)           # what confines the class of k < 256 to the values k - 1 and k
     magic = np.float32(8388608.0)
@@ -82,6 +84,9 @@ def test_threshold_comparison_equals_the_second_rounding_for_every_quantisable_f
         e = vqthr[k]
         mine_v = k - (x < np.abs(e)).astype(np.int32) + np.signbit(e).astype(np.int32)
         bad_v += int(np.count_nonzero(ref != mine_v))
+        # LhTables.vq3: the same decision with the class's two values of pow43 beside the threshold (what the kernel reads)
+        c = vq3[k]
+        bad_v += int(np.count_nonzero(np.where(x < c[:, 0], c[:, 1], c[:, 2]) != pow43[ref]))
         if lo < head:
             n = min(len(x), head - lo)
             assert k[:n].max() < 256

@@ -18,6 +18,7 @@ for t in "" _vbr2 _vbrold2 _cbr320 _lsf; do
 done
 if [ -f deprecated-lame-mirror_amd/lamehip/liblamehip_prof.so ]; then
   LAMEHIP_LIB=deprecated-lame-mirror_amd/lamehip/liblamehip_prof.so python tools/stage_profile.py 1024 4 > profiles/r05_stage_profile.txt 2>&1
+  LAMEHIP_LIB=deprecated-lame-mirror_amd/lamehip/liblamehip_prof.so python tools/stage_profile.py 1024 5 2 > profiles/r05_vbr_stage_profile.txt 2>&1
 fi
 python bench.py 2>/dev/null | grep '^{"metric"' > profiles/r05_bench_default.json
 python bench.py --vbr 2 --no-extras 2>/dev/null | grep '^{"metric"' > profiles/r05_bench_vbr2.json
