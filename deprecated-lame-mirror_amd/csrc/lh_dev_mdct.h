@@ -70,64 +70,65 @@
 #ifndef LH_ENW_TAPS
 #define LH_ENW_TAPS LH_ENW
 #endif
+/* one of the fifteen folded rows (n < 15) of a slot; w[] = the row's eighteen coefficients (LH_ENW_TAPS + 18 n), which a lane
+ * -- always at the same row -- holds in registers for all slots of a frame */
 LH_DEVFN void
-lh_subband_taps(const LhCtx & c, int ch, int x, int n, float *pre)
+lh_subband_row(int ch, int x, int n, const float (&w)[18], float *pre)
 {
     const float *mf = lh_lds.mf[ch];
-    if (n < 15) {
-        int const x1 = x - n;
-        int const x2 = x - 62 + n;
-        const float *wp = LH_ENW_TAPS + 10 + 18 * n;
-        /* the four strided runs (bases; + / - 64 k from there) */
-        const float *a2 = mf + LH_MF_SWZ(x2 - 224), *a1 = mf + LH_MF_SWZ(x1 + 224 - 448);
-        const float *b1 = mf + LH_MF_SWZ(x1 - 256), *b2 = mf + LH_MF_SWZ(x2 + 256 - 448);
-        float   w, s, t;
-        w = wp[-10];
-        s = a2[0] * w;
-        t = a1[448] * w;
+    int const x1 = x - n;
+    int const x2 = x - 62 + n;
+    /* the four strided runs (bases; + / - 64 k from there) */
+    const float *a2 = mf + LH_MF_SWZ(x2 - 224), *a1 = mf + LH_MF_SWZ(x1 + 224 - 448);
+    const float *b1 = mf + LH_MF_SWZ(x1 - 256), *b2 = mf + LH_MF_SWZ(x2 + 256 - 448);
+    float   s, t, d;
+    s = a2[0] * w[0];
+    t = a1[448] * w[0];
 #pragma unroll
-        for (int k = 1; k < 8; k++) {
-            w = wp[-10 + k];
-            s += a2[64 * k] * w;
-            t += a1[448 - 64 * k] * w;
-        }
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            w = wp[-2 + k];
-            s += b1[64 * k] * w;
-            t -= b2[448 - 64 * k] * w;
-        }
-        s *= wp[6];
-        w = t - s;
-        pre[2 * n] = t + s;
-        pre[2 * n + 1] = wp[7] * w;
+    for (int k = 1; k < 8; k++) {
+        s += a2[64 * k] * w[k];
+        t += a1[448 - 64 * k] * w[k];
     }
-    else {
-        int const x1 = x - 15;
-        const float *wp = LH_ENW_TAPS + 280;
-        float   s, t;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        s += b1[64 * k] * w[8 + k];
+        t -= b2[448 - 64 * k] * w[8 + k];
+    }
+    s *= w[16];
+    d = t - s;
+    pre[2 * n] = t + s;
+    pre[2 * n + 1] = w[17] * d;
+}
+
+/* the centre row of a slot */
+LH_DEVFN void
+lh_subband_centre(int ch, int x, float *pre)
+{
+    const float *mf = lh_lds.mf[ch];
+    int const x1 = x - 15;
+    const float *wp = LH_ENW_TAPS + 280;
+    float   s, t;
 #define LH_MFS(i) mf[LH_MF_SWZ(i)]
-        t = LH_MFS(x1 - 16) * wp[-10];
-        s = LH_MFS(x1 - 32) * wp[-2];
-        t += (LH_MFS(x1 - 48) - LH_MFS(x1 + 16)) * wp[-9];
-        s += LH_MFS(x1 - 96) * wp[-1];
-        t += (LH_MFS(x1 - 80) + LH_MFS(x1 + 48)) * wp[-8];
-        s += LH_MFS(x1 - 160) * wp[0];
-        t += (LH_MFS(x1 - 112) - LH_MFS(x1 + 80)) * wp[-7];
-        s += LH_MFS(x1 - 224) * wp[1];
-        t += (LH_MFS(x1 - 144) + LH_MFS(x1 + 112)) * wp[-6];
-        s -= LH_MFS(x1 + 32) * wp[2];
-        t += (LH_MFS(x1 - 176) - LH_MFS(x1 + 144)) * wp[-5];
-        s -= LH_MFS(x1 + 96) * wp[3];
-        t += (LH_MFS(x1 - 208) + LH_MFS(x1 + 176)) * wp[-4];
-        s -= LH_MFS(x1 + 160) * wp[4];
-        t += (LH_MFS(x1 - 240) - LH_MFS(x1 + 208)) * wp[-3];
-        s -= LH_MFS(x1 + 224);
+    t = LH_MFS(x1 - 16) * wp[-10];
+    s = LH_MFS(x1 - 32) * wp[-2];
+    t += (LH_MFS(x1 - 48) - LH_MFS(x1 + 16)) * wp[-9];
+    s += LH_MFS(x1 - 96) * wp[-1];
+    t += (LH_MFS(x1 - 80) + LH_MFS(x1 + 48)) * wp[-8];
+    s += LH_MFS(x1 - 160) * wp[0];
+    t += (LH_MFS(x1 - 112) - LH_MFS(x1 + 80)) * wp[-7];
+    s += LH_MFS(x1 - 224) * wp[1];
+    t += (LH_MFS(x1 - 144) + LH_MFS(x1 + 112)) * wp[-6];
+    s -= LH_MFS(x1 + 32) * wp[2];
+    t += (LH_MFS(x1 - 176) - LH_MFS(x1 + 144)) * wp[-5];
+    s -= LH_MFS(x1 + 96) * wp[3];
+    t += (LH_MFS(x1 - 208) + LH_MFS(x1 + 176)) * wp[-4];
+    s -= LH_MFS(x1 + 160) * wp[4];
+    t += (LH_MFS(x1 - 240) - LH_MFS(x1 + 208)) * wp[-3];
+    s -= LH_MFS(x1 + 224);
 #undef LH_MFS
-        /* u = s - t and v = s + t, combined with rows 14/15 at the start of stage 2 */
-        pre[30] = s - t;
-        pre[31] = s + t;
-    }
+    /* u = s - t and v = s + t, combined with rows 14/15 at the start of stage 2 */
+    pre[30] = s - t;
+    pre[31] = s + t;
 }
 
 LH_STAGEFN void
@@ -371,11 +372,27 @@ lh_polyphase(int ch)
     LhCtx const c = lh_ctx_load();
     float   (*sb)[LH_SB_GRANULE] = lh_lds.u.mdct.sb[ch];
     const float *amp = c.T->amp_filter;
-    /* stage 1: 36 slots x 16 tap rows */
-    for (int u = c.lane; u < 36 * 16; u += 64) {
-        int const s = u >> 4, n = u & 15;
-        int const gr = s / 18, slot = s - gr * 18;
-        lh_subband_taps(c, ch, 286 + 32 * s, n, &sb[1 + gr][slot * LH_SB_STRIDE]);
+    /* stage 1: 36 slots x 16 tap rows.  A lane's units (lane + 64 k) are all at row lane & 15: the fifteen folded rows take
+     * the loop with their coefficients in registers (the loads cannot be moved out of it by the compiler: the loop stores),
+     * the lanes of row 15 sit it out, and the 36 centre rows follow as one trip of 36 lanes -- not nine trips in which every
+     * wave walked through both kinds of row */
+    {
+        int const n = c.lane & 15;
+        float   w[18];
+#pragma unroll
+        for (int k = 0; k < 18; k++)
+            w[k] = LH_ENW_TAPS[18 * (n < 15 ? n : 0) + k];
+        if (n < 15) {
+            for (int s = c.lane >> 4; s < 36; s += 4) {
+                int const gr = s / 18, slot = s - gr * 18;
+                lh_subband_row(ch, 286 + 32 * s, n, w, &sb[1 + gr][slot * LH_SB_STRIDE]);
+            }
+        }
+        if (c.lane < 36) {
+            int const s = c.lane;
+            int const gr = s / 18, slot = s - gr * 18;
+            lh_subband_centre(ch, 286 + 32 * s, &sb[1 + gr][slot * LH_SB_STRIDE]);
+        }
     }
     LH_WAVE_SYNC();
     /* stage 2: butterfly network per slot */
