@@ -18,7 +18,17 @@ for t in "" _vbr2 _vbrold2 _cbr320 _lsf; do
 done
 if [ -f deprecated-lame-mirror_amd/lamehip/liblamehip_prof.so ]; then
   LAMEHIP_LIB=deprecated-lame-mirror_amd/lamehip/liblamehip_prof.so python tools/stage_profile.py 1024 4 > profiles/r05_stage_profile.txt 2>&1
-  LAMEHIP_LIB=deprecated-lame-mirror_amd/lamehip/liblamehip_prof.so python tools/stage_profile.py 1024 5 2 > profiles/r05_vbr_stage_profile.txt 2>&1
+  { cat <<'HDR'
+# LH_PROF build, VBR -V2 (vbr_mtrh), 1024 x 5 s: LAMEHIP_LIB=.../liblamehip_prof.so python tools/stage_profile.py 1024 5 2
+# With a VBR quality the slots mean: "outer_loop" = geometry + scalefactor search, "count_bits total" = lh_vbr_noisy_n (16 calls
+# per frame and wave: "calc_noise calls"), "quantise part" = its phase A (error sums of the groups of four lines at up to three
+# trial steps), "calc_noise" = quantise + count of the final steps, "bin_search" = geometry, "balance_noise" = constrain + bitcount.
+# BEFORE commit e2a09ba (the band sums as 64-lane ds_add_f32 to the bands' words; same command, same box class):
+#    frame total 410 315   outer_loop 199 556   count_bits total 172 497   quantise part 155 506   kernel 44.40 ms (with marks)
+# Experiments on that build (results wrong, times telling): every look-up to address 0: quantise part 102 412; band sums stored
+# instead of added: 76 213 (kernel 33.35 ms); on this build with every look-up issued twice: 141 792 (from 92 200).
+HDR
+    LAMEHIP_LIB=deprecated-lame-mirror_amd/lamehip/liblamehip_prof.so python tools/stage_profile.py 1024 5 2; } > profiles/r05_vbr_stage_profile.txt 2>&1
 fi
 python bench.py 2>/dev/null | grep '^{"metric"' > profiles/r05_bench_default.json
 python bench.py --vbr 2 --no-extras 2>/dev/null | grep '^{"metric"' > profiles/r05_bench_vbr2.json
