@@ -29,6 +29,13 @@
 #define LH_CONST __device__ static const
 #endif
 
+#if defined(LH_APROF) && !defined(LH_EMU)
+/* the shared device functions' own marks (lh_compute_masking: slots 14 .. 16) land 20 slots up in the stream's accumulators */
+__shared__ unsigned long long *lh_ap_base;
+#define LH_PT(var) unsigned long long var = clock64()
+#define LH_PA(idx, var) do { if (c.lane == 0) atomicAdd(&lh_ap_base[LH_NPROF * c.wave + 20 + (idx)], clock64() - var); } while (0)
+#define LH_PC(idx) do { } while (0)
+#endif
 #define LH_CUSTOM_LDS "lh_lds_analysis.h"
 #define LH_CUSTOM_SMP
 /* The transform buffers are stored bank-swizzled: word i of a channel's 1024 at i ^ X(i), X = bit 5 -> bit 1, bit 6 -> bit 3,
@@ -649,6 +656,8 @@ lh_analysis_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm
 {
 #if defined(LH_APROF) && !defined(LH_EMU)
     unsigned long long *aprof = &states[blockIdx.y].prof[0][0];
+    if (threadIdx.x == 0)
+        lh_ap_base = aprof;
 #endif
     LH_AP_T0();
     LhLds & L = lh_lds;

@@ -50,7 +50,7 @@
 #define LH_PT(var) unsigned long long var = clock64()
 #define LH_PA(idx, var) do { if (c.lane == 0 && c.wave < 2) lh_lds.prof[c.wave][idx] += (unsigned) (clock64() - var); } while (0)
 #define LH_PC(idx) do { if (c.lane == 0 && c.wave < 2) lh_lds.prof[c.wave][idx] += 1; } while (0)
-#else
+#elif !defined(LH_PT)           /* (lh_analysis.hip brings its own with -DLH_APROF) */
 #define LH_PT(var) do { } while (0)
 #define LH_PA(idx, var) do { } while (0)
 #define LH_PC(idx) do { } while (0)

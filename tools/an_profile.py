@@ -13,7 +13,8 @@ import helpers  # noqa: E402
 
 NAMES = {0: "an: start-up (descriptor, addresses)", 1: "an: samples staged", 2: "an: long FHT", 3: "an: power spectra",
          4: "an: spreading matrix staged", 5: "an: energy / loudness sums", 6: "an: long masking", 7: "an: short blocks",
-         8: "sb: priming (window + polyphase)", 9: "sb: window staged", 10: "sb: polyphase", 11: "sb: MDCT + alias", 12: "sb: spectra stored"}
+         8: "sb: priming (window + polyphase)", 9: "sb: window staged", 10: "sb: polyphase", 11: "sb: MDCT + alias", 12: "sb: spectra stored",
+         34: "an: masking: partition sums", 35: "an: masking: + tonality, prefix sums", 36: "an: masking: + spreading walk"}
 
 
 def main():
