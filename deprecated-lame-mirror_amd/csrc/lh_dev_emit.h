@@ -114,90 +114,136 @@ lh_emit_part(const LhCtx & c, LhChanLds & Q, const LhQR & R, const LhGrR & g, co
         }
         r1 = (r1 > g.big_values ? g.big_values : r1) >> 1;
         r2 = (r2 > g.big_values ? g.big_values : r2) >> 1;
+        /* The code tables are in HBM: what depends on a look-up is kept apart from what does not, so that the look-ups of all
+         * five rounds (and of the three rounds of quadruples behind them) are in flight together -- round by round every
+         * round waited for two dependent ones, 16 trips per granule.  The three regions' tables first (wave-uniform). */
+        int     tsel[3], toff[3];
+        unsigned tlin[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            int const t = g.table_select[r];
+            tsel[r] = (t == 14) ? 16 : t;       /* table 14 is only a length estimate; 16 carries the code book */
+            tlin[r] = lh_ht_xlen[tsel[r]];
+            toff[r] = lh_ht_offset[tsel[r]];
+        }
+        int const nq = (g.count1 - g.big_values) >> 2;
+        int const t1 = g.count1table_select + 32;
+        int const off1 = lh_ht_offset[t1];
+        unsigned ext[5], code[5], idx[5];
+        int     cbits[5], xbits[5], live[5];
+        int     qlen[3], qidx[3], qhb[3];
+        uint32_t qval[3];
 #pragma unroll
         for (int k = 0; k < 5; k++) {
             int const p = lane + 64 * k;
             int const pc = (k < 4 || p < 288) ? p : 287;
             uint32_t const pair = ix2[pc];
             int const in = p < bv2;
-            int     t = (p < r1) ? g.table_select[0] : (p < r2) ? g.table_select[1] : g.table_select[2];
+            int const reg = (p < r1) ? 0 : (p < r2) ? 1 : 2;
+            int const t = reg == 0 ? tsel[0] : reg == 1 ? tsel[1] : tsel[2];
+            unsigned const linbits = reg == 0 ? tlin[0] : reg == 1 ? tlin[1] : tlin[2];
+            int const off = reg == 0 ? toff[0] : reg == 1 ? toff[1] : toff[2];
             unsigned x1 = pair & 0xffffu, x2 = pair >> 16;
             int const n1 = xr[2 * pc] < 0.0f, n2 = xr[2 * pc + 1] < 0.0f;
-            unsigned ext = 0, code = 0;
-            int     cbits = 0, xbits = 0;
-            t = (t == 14) ? 16 : t;     /* table 14 is only a length estimate; 16 carries the code book */
-            if (in && t != 0) {
-                unsigned const linbits = lh_ht_xlen[t];
-                unsigned xlen = linbits;
+            unsigned xlen = linbits;
+            ext[k] = 0;
+            cbits[k] = 0;
+            xbits[k] = 0;
+            live[k] = in && t != 0;
+            if (live[k]) {
                 if (x1 != 0u) {
-                    ext = (unsigned) n1;
-                    cbits--;
+                    ext[k] = (unsigned) n1;
+                    cbits[k]--;
                 }
                 if (t > 15) {
                     if (x1 >= 15u) {
-                        ext |= (x1 - 15u) << 1;
-                        xbits = (int) linbits;
+                        ext[k] |= (x1 - 15u) << 1;
+                        xbits[k] = (int) linbits;
                         x1 = 15u;
                     }
                     if (x2 >= 15u) {
-                        ext <<= linbits;
-                        ext |= (x2 - 15u);
-                        xbits += (int) linbits;
+                        ext[k] <<= linbits;
+                        ext[k] |= (x2 - 15u);
+                        xbits[k] += (int) linbits;
                         x2 = 15u;
                     }
                     xlen = 16;
                 }
                 if (x2 != 0u) {
-                    ext <<= 1;
-                    ext |= (unsigned) n2;
-                    cbits--;
-                }
-                {
-                    unsigned const idx = (unsigned) lh_ht_offset[t] + x1 * xlen + x2;
-                    xbits -= cbits;
-                    cbits += lh_ht_len[idx];
-                    code = lh_ht_code[idx];
+                    ext[k] <<= 1;
+                    ext[k] |= (unsigned) n2;
+                    cbits[k]--;
                 }
             }
-            {
-                int const len = cbits + xbits;
-                uint32_t const incl = lh_wave_scan_u32((uint32_t) len);
-                int const at = pos + (int) incl - len;
-                lh_put_bits(buf, at, code, cbits);
-                lh_put_bits(buf, at + cbits, ext, xbits);
-                pos += (int) lh_bcast_u32(incl, 63);
+            idx[k] = live[k] ? (unsigned) off + x1 * xlen + x2 : 0u;
+        }
+        {
+            /* part 3b's indices: count1 quadruples, three rounds */
+            const int16_t *ix = Q.ix[0];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                int const qd = lane + 64 * k;
+                int const in = qd < nq;
+                int const base = in ? g.big_values + 4 * qd : 0;
+                int     p = 0, hb = 0;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    int const v = ix[base + u];
+                    if (v) {
+                        p += 8 >> u;
+                        hb = hb * 2 + (xr[base + u] < 0.0f ? 1 : 0);
+                    }
+                }
+                qidx[k] = in ? off1 + p : -1;
+                qhb[k] = hb;
             }
         }
-    }
-    {
-        /* part 3b: count1 quadruples, three rounds */
-        int const nq = (g.count1 - g.big_values) >> 2;
-        int const t = g.count1table_select + 32;
-        const int16_t *ix = Q.ix[0];
+        {
+            /* every look-up of the granule */
+            unsigned hl[5], hc[5];
+            int     ql[3];
+            unsigned qc[3];
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            int const qd = lane + 64 * k;
-            int const in = qd < nq;
-            int const base = in ? g.big_values + 4 * qd : 0;
-            int     p = 0, hb = 0, len = 0;
-            uint32_t val = 0;
+            for (int k = 0; k < 5; k++) {
+                hl[k] = lh_ht_len[idx[k]];
+                hc[k] = lh_ht_code[idx[k]];
+            }
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                int const v = ix[base + u];
-                if (v) {
-                    p += 8 >> u;
-                    hb = hb * 2 + (xr[base + u] < 0.0f ? 1 : 0);
+            for (int k = 0; k < 3; k++) {
+                ql[k] = lh_ht_len[qidx[k] < 0 ? 0 : qidx[k]];
+                qc[k] = lh_ht_code[qidx[k] < 0 ? 0 : qidx[k]];
+            }
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                code[k] = 0;
+                if (live[k]) {
+                    xbits[k] -= cbits[k];
+                    cbits[k] += (int) hl[k];
+                    code[k] = hc[k];
                 }
             }
-            if (in) {
-                len = lh_ht_len[lh_ht_offset[t] + p];
-                val = (uint32_t) hb + lh_ht_code[lh_ht_offset[t] + p];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                qlen[k] = qidx[k] < 0 ? 0 : ql[k];
+                qval[k] = qidx[k] < 0 ? 0u : (uint32_t) qhb[k] + qc[k];
             }
-            {
-                uint32_t const incl = lh_wave_scan_u32((uint32_t) len);
-                lh_put_bits(buf, pos + (int) incl - len, val, len);
-                pos += (int) lh_bcast_u32(incl, 63);
-            }
+        }
+        /* part 3a: big values, one lane per pair, five rounds */
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            int const len = cbits[k] + xbits[k];
+            uint32_t const incl = lh_wave_scan_u32((uint32_t) len);
+            int const at = pos + (int) incl - len;
+            lh_put_bits(buf, at, code[k], cbits[k]);
+            lh_put_bits(buf, at + cbits[k], ext[k], xbits[k]);
+            pos += (int) lh_bcast_u32(incl, 63);
+        }
+        /* part 3b: count1 quadruples, three rounds */
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            uint32_t const incl = lh_wave_scan_u32((uint32_t) qlen[k]);
+            lh_put_bits(buf, pos + (int) incl - qlen[k], qval[k], qlen[k]);
+            pos += (int) lh_bcast_u32(incl, 63);
         }
     }
     LH_WAVE_SYNC();
@@ -234,19 +280,35 @@ lh_anc_flag_after(int remaining, int flag, int toggling)
     return flag ^ (toggling ? (tail & 1) : 0);
 }
 
-/* header + side information of one frame (reference bitstream.c:320-487, MPEG-1) into h[];
- * one lane, serial */
+/* the side information of a granule as LhGranule carries it behind the quantised lines and the scalefactors: eight words,
+ * which lh_emit_frame brings into LDS for all granules of the frame at once (the header's one lane then reads LDS, not ~60
+ * fields of HBM one after the other) */
+struct LhSideInfo {
+    int16_t part2_3_length, part2_length, big_values, count1, global_gain, scalefac_compress;
+    int8_t  block_type, mixed_block_flag, table_select[3], subblock_gain[3];
+    int8_t  region0_count, region1_count, preflag, scalefac_scale, count1table_select, sfbmax, sfbdivide, pad1;
+    int16_t count1bits, pad2;
+};
+#define LH_SIDE_OFF ((int) __builtin_offsetof(LhGranule, part2_3_length))
+static_assert(sizeof(LhSideInfo) == 32 && LH_SIDE_OFF % 4 == 0 && sizeof(LhGranule) == LH_SIDE_OFF + 32 && sizeof(LhGranule) % 4 == 0
+              && __builtin_offsetof(LhGranule, count1bits) - LH_SIDE_OFF == __builtin_offsetof(LhSideInfo, count1bits)
+              && __builtin_offsetof(LhGranule, region0_count) - LH_SIDE_OFF == __builtin_offsetof(LhSideInfo, region0_count),
+              "LhSideInfo mirrors the tail of LhGranule");
+
+/* header + side information of one frame (reference bitstream.c:320-487) into hw[] (big-endian words: byte i of the header is
+ * bits 31 - 8 (i & 3) .. of hw[i >> 2]); one lane, serial.  The fields run through a 64-bit accumulator in registers and leave
+ * it a word at a time -- a byte array indexed by the running bit position sits in scratch memory, where every field was a
+ * dependent load + store through the vector memory path: 80 k cycles per frame, nine tenths of what the packer cost. */
 LH_DEVFN void
-lh_emit_header(const LhConfig * cfg, const LhFrameOut * fo, int mdb, int bitrate_index, int padding, int mode_ext,
-               const int scfsi[2][4], unsigned char *h)
+lh_emit_header(const LhConfig * cfg, const LhSideInfo * si, int mdb, int bitrate_index, int padding, int mode_ext,
+               const int8_t * scfsi, uint32_t * hw)
 {
-    int     ptr = 0;
+    unsigned long long acc = 0;
+    int     nacc = 0, wi = 0;
     int const sl = cfg->sideinfo_len;
-    for (int i = 0; i < sl; i++)
-        h[i] = 0;
-#define LH_HB(val, n) do { int v_ = (int) (val), j_ = (n); \
-        while (j_ > 0) { int const k_ = (j_ < 8 - (ptr & 7)) ? j_ : 8 - (ptr & 7); j_ -= k_; \
-            h[ptr >> 3] = (unsigned char) (h[ptr >> 3] | ((v_ >> j_) << (8 - (ptr & 7) - k_))); ptr += k_; } } while (0)
+#define LH_HB(val, n) do { int const n_ = (n); \
+        if (n_ > 0) { acc = (acc << n_) | ((unsigned long long) (unsigned) (val) & ((1ull << n_) - 1ull)); nacc += n_; \
+            if (nacc >= 32) { hw[wi++] = (uint32_t) (acc >> (nacc - 32)); nacc -= 32; } } } while (0)
     LH_HB(cfg->samplerate < 16000 ? 0xffe : 0xfff, 12);
     LH_HB(cfg->version, 1);
     LH_HB(4 - 3, 2);
@@ -267,7 +329,7 @@ lh_emit_header(const LhConfig * cfg, const LhFrameOut * fo, int mdb, int bitrate
         LH_HB(0, cfg->channels == 2 ? 3 : 5);
         for (int ch = 0; ch < cfg->channels; ch++)
             for (int band = 0; band < 4; band++)
-                LH_HB(scfsi[ch][band], 1);
+                LH_HB(scfsi[4 * ch + band], 1);
     }
     else {
         /* MPEG-2 / 2.5 (reference bitstream.c:420-467) */
@@ -276,7 +338,7 @@ lh_emit_header(const LhConfig * cfg, const LhFrameOut * fo, int mdb, int bitrate
     }
     for (int gr = 0; gr < LH_NGR; gr++)
         for (int ch = 0; ch < cfg->channels; ch++) {
-            const LhGranule *gi = &fo->gr[gr][ch];
+            const LhSideInfo *gi = &si[gr * cfg->channels + ch];
             LH_HB(gi->part2_3_length + gi->part2_length, 12);
             LH_HB(gi->big_values / 2, 9);
             LH_HB(gi->global_gain, 8);
@@ -305,13 +367,17 @@ lh_emit_header(const LhConfig * cfg, const LhFrameOut * fo, int mdb, int bitrate
             LH_HB(gi->count1table_select, 1);
         }
 #undef LH_HB
+    if (nacc > 0)
+        hw[wi++] = (uint32_t) (acc << (32 - nacc));
+    while (wi < (sl + 3) / 4 + 1)
+        hw[wi++] = 0u;
     if (cfg->error_protection) {
         int     crc = 0xffff;
         for (int i = 2; i < sl; i++) {
             int     value;
             if (i == 4 || i == 5)
                 continue;
-            value = h[i] << 8;
+            value = (int) ((hw[i >> 2] >> (24 - 8 * (i & 3))) & 255u) << 8;
             for (int k = 0; k < 8; k++) {
                 value <<= 1;
                 crc <<= 1;
@@ -319,8 +385,7 @@ lh_emit_header(const LhConfig * cfg, const LhFrameOut * fo, int mdb, int bitrate
                     crc ^= 0x8005;
             }
         }
-        h[4] = (unsigned char) (crc >> 8);
-        h[5] = (unsigned char) (crc & 255);
+        hw[1] = (hw[1] & 0x0000ffffu) | ((uint32_t) (crc & 0xffff) << 16);    /* bytes 4 and 5 */
     }
 }
 
@@ -363,6 +428,9 @@ lh_emit_frame(const LhFrameOut * fo_in, int drain_pre, int drain_post, int frame
     const LhConfig *cfg = c.cfg;
     LhStreamState *st = c.st;
     uint32_t *fb = (uint32_t *) &L.u.quant.ch[0];      /* the quantiser's working set is dead: 4.6 KB of xrpow + save_xrpow */
+    uint32_t *hw = (uint32_t *) &L.u.quant.ch[1];      /* (the other channel's: the header's words, the frame's side information) */
+    uint32_t *hs = hw + 16;
+    const LhSideInfo *si = (const LhSideInfo *) hs;
     int const tid = c.tid, nch = cfg->channels, sl = cfg->sideinfo_len;
     int const toggling = !cfg->disable_reservoir;
     int     plen[4], poff[4], np = 0, nbits, flag;
@@ -378,11 +446,22 @@ lh_emit_frame(const LhFrameOut * fo_in, int drain_pre, int drain_post, int frame
     frame_bytes = lh_uni_i(frame_bytes);
     flush = lh_uni_i(flush);
 
+    LH_PT(t_em);
+    LH_SYNC_WG();
+    LH_PA(14, t_em);
+    /* the frame's side information (eight words per granule and channel) and scfsi, from the record the granules' last stage
+     * wrote, into LDS */
+    if (tid < 8 * LH_NGR * nch) {
+        int const k = tid >> 3, gr = k / nch, ch = k - gr * nch;
+        hs[tid] = ((const uint32_t *) ((const char *) &fo->gr[gr][ch] + LH_SIDE_OFF))[tid & 7];
+    }
+    else if (tid < 8 * LH_NGR * nch + 2)
+        hs[32 + (tid - 8 * LH_NGR * nch)] = ((const uint32_t *) &fo->scfsi[0][0])[tid - 8 * LH_NGR * nch];
     LH_SYNC_WG();
     nbits = drain_pre;
     for (int gr = 0; gr < LH_NGR; gr++)
         for (int ch = 0; ch < nch; ch++) {
-            const LhGranule *gi = &fo->gr[gr][ch];
+            const LhSideInfo *gi = &si[gr * nch + ch];
             poff[np] = nbits;
             plen[np] = gi->part2_3_length + gi->part2_length;
             nbits += plen[np];
@@ -406,18 +485,15 @@ lh_emit_frame(const LhFrameOut * fo_in, int drain_pre, int drain_post, int frame
              * headers pending than the queue holds): the host refuses the stream's bytes */
             if (queue_full || here + sl > c.d.bytes_cap)
                 lh_lds_or((uint32_t *) &lh_lds.ss.status, 8u);
-            unsigned char h[40];
-            int     scfsi[2][4];
-            for (int ch = 0; ch < 2; ch++)
-                for (int i = 0; i < 4; i++)
-                    scfsi[ch][i] = fo->scfsi[ch][i];
-            lh_emit_header(cfg, fo, mdb, bitrate_index, padding, mode_ext, scfsi, h);
-            if (here + sl <= c.d.bytes_cap)
-                for (int i = 0; i < sl; i++)
-                    out[here + i] = h[i];
+            lh_emit_header(cfg, si, mdb, bitrate_index, padding, mode_ext, (const int8_t *) (hs + 32), hw);
             st->em_next_header = here + frame_bytes;
         }
+        LH_SYNC_WG();
+        /* a lane per header byte */
+        if (tid < sl && here + sl <= c.d.bytes_cap)
+            out[here + tid] = (uint8_t) ((hw[tid >> 2] >> (24 - 8 * (tid & 3))) & 255u);
     }
+    LH_PA(15, t_em);
     for (int round = 0; round < (flush ? 2 : 1); round++) {
         int     nbytes;
         if (round == 1) {
@@ -456,6 +532,7 @@ lh_emit_frame(const LhFrameOut * fo_in, int drain_pre, int drain_post, int frame
             }
         }
         LH_SYNC_WG();
+        LH_PA(16, t_em);
         for (int j = tid; j < nbytes; j += LH_NT) {
             long long const p = lh_emit_pos(cursor, j, hq, nq, sl);
             if (p < c.d.bytes_cap)
@@ -476,6 +553,7 @@ lh_emit_frame(const LhFrameOut * fo_in, int drain_pre, int drain_post, int frame
             lh_lds_or((uint32_t *) &lh_lds.ss.status, 2u);    /* the reservoir arithmetic should make every frame's main data whole bytes */
         LH_SYNC_WG();
     }
+    LH_PA(17, t_em);
     if (tid == 0) {
         st->em_cursor = cursor;
         st->em_nq = nq;

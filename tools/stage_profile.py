@@ -46,6 +46,11 @@ def main():
         base.append((x / np.abs(x).max() * 0.8 * 32767).astype(np.int16))
     for s in range(B):
         b.set_pcm(s, base[s % 8][0], base[s % 8][1])
+    if os.environ.get("LAMEHIP_PROFILE_PACK"):
+        b.set_device_packing(True)       # the device bit packer's share: compare with a run without it
+        # (the split pipeline's encode kernel leaves the masking slots free: lh_emit_frame's marks are there)
+        NAMES[14:18] = ["  emit_frame: entry barrier", "  emit_frame: + side info, state, header", "  emit_frame: + frame bit string",
+                        "  emit_frame: + bytes scattered"]
     b.encode()
     ms = b.kernel_ms()
     ssz = enc.lib.lamehip_abi_sizeof(4)
