@@ -46,12 +46,22 @@ def synth_stream(seed, n, sr=44100, burst_interval=None, white=False):
     return x.astype(np.int16)
 
 
+def locked_make(args, cwd):
+    """make under a file lock: pytest-xdist workers that find the same target stale would otherwise build it at once"""
+    import fcntl
+    with open(os.path.join(cwd, ".make.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            subprocess.check_call(["make"] + list(args), cwd=cwd, stdout=subprocess.DEVNULL)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
 def build_oracle():
     if not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < max(
             os.path.getmtime(os.path.join(ROOT, "oracle", f)) for f in os.listdir(os.path.join(ROOT, "oracle"))
             if f.endswith((".c", ".h"))):
-        subprocess.check_call(["make", "oracle"], cwd=os.path.join(ROOT, "oracle"),
-                              stdout=subprocess.DEVNULL)
+        locked_make(["oracle"], os.path.join(ROOT, "oracle"))
     return ORACLE_SO
 
 

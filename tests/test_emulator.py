@@ -25,7 +25,7 @@ class LhStreamDesc(C.Structure):
 
 @pytest.fixture(scope="module")
 def emu():
-    subprocess.check_call(["make"], cwd=EMU_DIR, stdout=subprocess.DEVNULL)
+    helpers.locked_make([], EMU_DIR)
     return C.CDLL(os.path.join(EMU_DIR, "libhipemu_lame.so"))
 
 

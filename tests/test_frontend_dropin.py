@@ -77,7 +77,7 @@ def input_files(directory):
 def test_reference_frontend_links_against_liblamehip():
     """`make frontend' links with -Wl,--no-undefined: every lame_* / get_lame_* symbol the frontend objects ask for is
     exported by liblamehip.so (the id3tag_* ones by the shim); and without a device it refuses to encode."""
-    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "frontend"], stdout=subprocess.DEVNULL)
+    helpers.locked_make(["frontend"], os.path.join(ROOT, "oracle"))
     assert os.path.exists(EXE)
     objs = [os.path.join(ROOT, "oracle", "_ref", "fe_%s.o" % n) for n in
             "lame_main parse get_audio main timestatus brhist console lametime".split()]
