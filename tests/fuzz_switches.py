@@ -118,6 +118,16 @@ def main():
                         break
                 if what is None and b.pack(0) != helpers.pack_frames(enc.lib, cfg, tab, want):
                     what = ("bytes",)
+            if what is None:
+                # the same stream once more with the bit packer on the device (lh_dev_emit.h): its bytes against the host packer's
+                host_bytes = b.pack(0)
+                b2 = lamehip.Batch(enc, 1, x.shape[1])
+                b2.set_device_packing(True)
+                b2.set_pcm(0, x[0], x[1])
+                b2.encode()
+                if b2.get_bytes(0) != host_bytes:
+                    what = ("device-packed bytes",)
+                b2.close()
             b.close()
         else:
             ref.lib.refh_option(None, 0)
