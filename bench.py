@@ -205,6 +205,9 @@ def cpu_baseline(host_pcm, sr, brate, vbr_q=None, abr=None, budget=10.0, vbr_mod
     what = ("ABR %d" % abr) if abr is not None else ("CBR %d" % brate) if vbr_q is None else ("VBR -V%d%s" % (vbr_q, " --vbr-old" if vbr_mode == 2 else ""))
     return {"value": round(aggregate, 1), "unit": "x real-time", "cores": procs, "kind": kind,
             "per_core": round(aggregate / procs, 2), "one_process_alone": round(single, 2),
+            # what the whole host would give if every physical core ran at the measured per-core rate (the container is
+            # limited to `cores' of them): an extrapolation, labelled as such
+            "host_physical_cores_estimate": round(aggregate / procs * cores, 1),
             "physical_cores": cores, "logical_cpus": os.cpu_count(), "cpus_in_affinity_mask": allowed,
             "cgroup_cpu_quota": quota, "cpu_model": _cpu_model(),
             "sample": "%d processes at once, each encoding the first %.0f s of one of the GPU leg's streams "
@@ -421,8 +424,12 @@ def roofline_block(frames, sr, kavg_s, parts, pmc_name):
             a = frames * by[k] / (ms / 1e3) / 1e9 if ms > 0 else 0.0
             kernels.append({"kernel": names[k], "ms_avg": round(ms, 3), "alg_bytes_per_frame": by[k], "achieved": round(a, 3),
                             "frac": round(a / HBM_PEAK_GBS, 6)})
+        # the block's own figure follows SURVEY 8(d) to the letter: the PATH's algorithmic bytes per frame (9 792 B for MPEG-1)
+        # x the frames of the launch over the dominant kernel's average time; the bytes each kernel of the split pipeline
+        # moves by design (the records between them included) price the entries of `kernels' only
         dom = kernels[2]
-        achieved, dom_name, dom_ms, dom_bytes = dom["achieved"], dom["kernel"], dom["ms_avg"], dom["alg_bytes_per_frame"]
+        dom_name, dom_ms, dom_bytes = dom["kernel"], dom["ms_avg"], alg_bytes_per_frame(sr)
+        achieved = frames * dom_bytes / (dom_ms / 1e3) / 1e9 if dom_ms > 0 else 0.0
     else:
         achieved, dom_name, dom_ms, dom_bytes = whole, "lh_encode_kernel", kavg_s * 1e3, alg_bytes_per_frame(sr)
     pmc = recorded(pmc_name) or {}
@@ -431,6 +438,8 @@ def roofline_block(frames, sr, kavg_s, parts, pmc_name):
     block = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": round(achieved / HBM_PEAK_GBS, 6),
              "traffic": int(pmc["hbm_bytes_per_frame"] * frames) if fresh else None,
+             # HBM bytes moved (all kernels of the launch) over the path's algorithmic bytes: 1.0 = nothing re-read or spilled
+             "traffic_ratio": round(pmc["hbm_bytes_per_frame"] / alg_bytes_per_frame(sr), 2) if fresh else None,
              "traffic_note": ("%.1f KB per frame x the frames of this launch (all kernels of the launch); per-frame figure "
                               "recorded with rocprofv3 --pmc (FETCH_SIZE x 2 + WRITE_SIZE) on %s from these sources (digest %s), "
                               "workload `%s'; bench.py does not run the profiler"

@@ -137,13 +137,19 @@ struct LhDeviceConst {
         rc = (lsf ? lh_launch_analysis_lsf : lh_launch_analysis) (d_cfg, d_tab, pcm, pcmf, descs, states, mid, nstreams, max_frames, stream);
         if (rc)
             return rc;
-        if (ev && hipEventRecord(ev[0], (hipStream_t) stream) != hipSuccess)
-            return (int) hipGetLastError();
+        if (ev) {
+            hipError_t const e = hipEventRecord(ev[0], (hipStream_t) stream);
+            if (e != hipSuccess)
+                return (int) e;
+        }
         rc = (lsf ? lh_launch_subband_lsf : lh_launch_subband) (d_cfg, d_tab, pcm, pcmf, descs, states, mid, nstreams, max_frames, stream);
         if (rc)
             return rc;
-        if (ev && hipEventRecord(ev[1], (hipStream_t) stream) != hipSuccess)
-            return (int) hipGetLastError();
+        if (ev) {
+            hipError_t const e = hipEventRecord(ev[1], (hipStream_t) stream);
+            if (e != hipSuccess)
+                return (int) e;
+        }
         return (lsf ? lh_launch_encode_q_lsf : vbrk ? lh_launch_encode_q_vbr : lh_launch_encode_q)
             (d_cfg, d_tab, pcm, pcmf, descs, states, out, bytes, nstreams, stream, mid);
     }
@@ -1519,6 +1525,15 @@ batch_use_split(void)
     return !(e && e[0] == '1');
 }
 
+/* LAMEHIP_SPLIT_DENY=1, looked at before every launch: this launch takes the fused kernel as if the pools could not be had
+ * (test aid: a batch whose launches change kernels mid-stream, tests/test_gpu_parity.py) */
+static int
+batch_split_denied(void)
+{
+    const char *e = getenv("LAMEHIP_SPLIT_DENY");
+    return e && e[0] == '1';
+}
+
 struct lamehip_batch {
     int     device;
     LhConfig cfg;
@@ -1595,8 +1610,9 @@ struct lamehip_batch {
     long long mid_cap;
     int     split;              /* this batch's launches go through the split pipeline (batch_use_split) */
     hipEvent_t ev_part[2];
-    hipEvent_t ev_wait;         /* behind the launch, with hipEventBlockingSync: the host thread sleeps in lamehip_batch_sync instead of
-                                 * spinning on the stream (a rank per GPU must not burn a CPU per rank while its kernel runs) */
+    hipEvent_t ev_wait;         /* behind the launch; only ever polled (hipEventQuery between short sleeps in lamehip_batch_sync): the
+                                 * host thread sleeps instead of spinning on the stream (a rank per GPU must not burn a CPU per rank
+                                 * while its kernel runs) */
     float   part_ms[3];         /* analysis, sub-band, encode kernel of the last launch (0: fused launch) */
     int     last_split;
 };
@@ -1606,7 +1622,10 @@ struct lamehip_batch {
 static int
 batch_mid_reserve(lamehip_batch * b, long long total)
 {
-    if (total <= b->mid_cap)
+    /* (the encode kernel touches the record BEHIND the one it works on, the launch's last frame included: one spare
+     * record has to exist whatever the launch's total is -- a later launch whose total equals the capacity must not
+     * read past the pool) */
+    if (total + 1 <= b->mid_cap)
         return 0;
     size_t  free_b = 0, total_b = 0;
     long long const want = total + 64;
@@ -1641,7 +1660,9 @@ batch_launch(lamehip_batch * b, const int16_t * pcm, const float *pcmf, const Lh
                 max_frames = nf;
         }
     }
-    int     split = b->split && total > 0 && batch_mid_reserve(b, total) == 0;
+    /* (the analysis and sub-band kernels index the stream by blockIdx.y, which ends at 65535: a larger batch keeps the
+     * fused kernel, whose grid is one-dimensional) */
+    int     split = b->split && total > 0 && b->B <= 65535 && !batch_split_denied() && batch_mid_reserve(b, total) == 0;
     if (split && !b->ev_part[0]) {
         if (hipEventCreate(&b->ev_part[0]) != hipSuccess || hipEventCreate(&b->ev_part[1]) != hipSuccess)
             split = 0;
@@ -1654,7 +1675,7 @@ batch_launch(lamehip_batch * b, const int16_t * pcm, const float *pcmf, const Lh
     if (rc)
         return set_err("kernel launch", (hipError_t) rc);
     HIPCHK(hipEventRecord(b->ev1, b->stream));
-    if (!b->ev_wait && hipEventCreateWithFlags(&b->ev_wait, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) {
+    if (!b->ev_wait && hipEventCreateWithFlags(&b->ev_wait, hipEventDisableTiming) != hipSuccess) {
         (void) hipGetLastError();
         b->ev_wait = nullptr;
     }
@@ -2811,9 +2832,12 @@ lamehip_batch_sync(lamehip_batch * b)
             b->last_ms = ms;
         b->part_ms[0] = b->part_ms[1] = b->part_ms[2] = 0;
         if (b->last_split) {
-            (void) hipEventElapsedTime(&b->part_ms[0], b->ev0, b->ev_part[0]);
-            (void) hipEventElapsedTime(&b->part_ms[1], b->ev_part[0], b->ev_part[1]);
-            (void) hipEventElapsedTime(&b->part_ms[2], b->ev_part[1], b->ev1);
+            if (hipEventElapsedTime(&b->part_ms[0], b->ev0, b->ev_part[0]) != hipSuccess
+                || hipEventElapsedTime(&b->part_ms[1], b->ev_part[0], b->ev_part[1]) != hipSuccess
+                || hipEventElapsedTime(&b->part_ms[2], b->ev_part[1], b->ev1) != hipSuccess) {
+                (void) hipGetLastError();
+                b->part_ms[0] = b->part_ms[1] = b->part_ms[2] = 0.0f;   /* (never a stale figure of an earlier launch) */
+            }
         }
     }
     return 0;
