@@ -63,6 +63,52 @@
 #define LQ_MARK(name) do { } while (0)
 #endif
 
+/* development aid (-DLH_TRACE, tools/trace_profile.py; profiles/r06_wait_breakdown.txt): where a search iteration's cycles go.
+ * A mark reads the clock (s_memtime, then s_waitcnt lgkmcnt(0): every LDS operation in flight is waited for at a mark, which
+ * is what makes the segments add up) and adds the cycles since the wave's previous mark -- whichever it was -- to the
+ * segment that ENDS at this mark: lane `id' of one vector register holds segment id's cycles, lane id of a second its
+ * visits; no memory is touched until the search stage returns (lh_tr_flush: one atomic per lane into lh_trace_buf).  A mark
+ * costs ~75 cycles (measured by a pair of adjacent marks: segment 63); the tool takes that off per visit. */
+#if defined(LH_TRACE) && !defined(LH_EMU)
+#define LH_NTRACE 64
+__device__ unsigned long long lh_trace_buf[2][2][LH_NTRACE];   /* [wave][cycles | visits][segment] over all streams */
+struct LhTr {
+    uint32_t acc, cnt, last;
+};
+LH_DEVFN void
+lh_tr_mark(LhTr & t, int id)
+{
+    unsigned long long now;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now) :: "memory");
+    uint32_t const lo = (uint32_t) now;
+    int const me = ((int) (threadIdx.x & 63u) == id);
+    t.acc += me ? lo - t.last : 0u;
+    t.cnt += me ? 1u : 0u;
+    t.last = lo;
+}
+LH_DEVFN void
+lh_tr_begin(LhTr & t)
+{
+    unsigned long long now;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now) :: "memory");
+    t.acc = 0;
+    t.cnt = 0;
+    t.last = (uint32_t) now;
+}
+LH_DEVFN void
+lh_tr_flush(const LhTr & t, int wave)
+{
+    int const lane = (int) (threadIdx.x & 63u);
+    if (wave < 2 && t.cnt) {
+        atomicAdd(&lh_trace_buf[wave][0][lane], (unsigned long long) t.acc);
+        atomicAdd(&lh_trace_buf[wave][1][lane], (unsigned long long) t.cnt);
+    }
+}
+#define LQ_T(S, id) lh_tr_mark((S).tr, id)
+#else
+#define LQ_T(S, id) do { } while (0)
+#endif
+
 LH_DEVFN float
 lh_fabsf(float x)
 {

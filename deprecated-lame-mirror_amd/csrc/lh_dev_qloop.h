@@ -55,6 +55,9 @@ struct LhQS {
      * squares of its lines, a constant of the granule (lq_zero_band_noise) */
     float   zk;
     int     nzend;              /* wave-uniform: the lines from here on are zero in the working image (set by every count) */
+#if defined(LH_TRACE) && !defined(LH_EMU)
+    mutable LhTr tr;            /* development aid: cycles per segment of the search (lh_dev_common.h) */
+#endif
 };
 
 LH_DEVFN int
@@ -216,6 +219,7 @@ template < int USE_PREV, int NS > LH_DEVFN int
 lq_quantize(const LhCtx & c, LhQS & S, const LhQR & R, const LhGrR & g)
 {
     LQ_MARK("cb_begin");
+    LQ_T(S, 1);
     const LhTables *T = c.T;
     const LhQTabs *qt = LH_QT;
     int const lane = c.lane;
@@ -266,6 +270,7 @@ lq_quantize(const LhCtx & c, LhQS & S, const LhQR & R, const LhGrR & g)
         plain = (ncmask == all) && (m01mask == 0);
     }
     LQ_MARK("cb_quant");
+    LQ_T(S, 2);
     /* ---- quantise: all pairs, straight line; the selection follows.  The first rounding is a
      * float addition: (float) ((double) x + 2^23) and x + 2^23f agree for every float x >= 0; the
      * second is a comparison with the first float that the reference's expression rounds up to k
@@ -346,6 +351,7 @@ lq_count(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
     const LhQTabs *qt = LH_QT;
     int const lane = c.lane;
     LQ_MARK("cb_count");
+    LQ_T(S, 3);
     /* ---- count ---- */
     {
         int     top_nz, top_big, i, bv, nquad, bits;
@@ -401,6 +407,7 @@ lq_count(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
         e1 = lh_uni_i(a2 >> 1);
         e2 = (R.block_type == LH_NORM_TYPE) ? (bv >> 1) : e1;
         LQ_MARK("cb_quads");
+        LQ_T(S, 4);
         LH_WAVE_ORDER();
         uint32_t red[1];        /* the count1 region's lengths with both of its tables, t32 << 16 | t33 */
         uint32_t pre_l, pre_h, qtot;
@@ -466,6 +473,7 @@ lq_count(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
         }
         red[0] = qsum;
         LQ_MARK("cb_lookup");
+        LQ_T(S, 5);
         /* lane r < 3 works out region r's candidate tables; the grid origins go back to all lanes */
         uint32_t PB, esc;
         uint32_t G0, G1, G2;
@@ -511,6 +519,7 @@ lq_count(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
             qtot = lh_wave_sum_regions(acc0, acc1, acc2, red[0], &pre_l, &pre_h);
         }
         LQ_MARK("cb_decide");
+        LQ_T(S, 6);
         {
             int const c1a = (int) (qtot >> 16), c1b = (int) (qtot & 0xffffu);
             bits = c1a;
@@ -547,6 +556,7 @@ lq_count(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
         if (USE_PREV && R.block_type == LH_NORM_TYPE && bv != 0)
             R.pn_sfb_count1 = lh_popc64(lh_ballot(S.sfbl < bv));    /* (big_values <= 576: lanes from 23 on never count) */
         LQ_MARK("cb_end");
+        LQ_T(S, 7);
         return bits;
     }
 }
@@ -714,6 +724,7 @@ lq_calc_noise(const LhCtx & c, const LhQS & S, const LhQR & R, const LhGrR & g, 
     int     l = 0, j = 0, big = 0, maxw;
     LH_PC(13);
     LQ_MARK("cn_begin");
+    LQ_T(S, 10);
     int const st = lq_band_step(S, g);
     int const fresh = (s < R.psymax) && !(S.pnstep == st);
     int const zb = fresh && (S.sta >= S.nzend);
@@ -780,6 +791,7 @@ lq_calc_noise(const LhCtx & c, const LhQS & S, const LhQR & R, const LhGrR & g, 
     }
     LH_WAVE_ORDER();
     LQ_MARK("cn_sum");
+    LQ_T(S, 11);
     {
         int const n = 2 * l;
         int const jj = (j < 576) ? (j >> 1) : 0;
@@ -787,6 +799,7 @@ lq_calc_noise(const LhCtx & c, const LhQS & S, const LhQR & R, const LhGrR & g, 
         noise = zb ? S.zk : noise;
     }
     LQ_MARK("cn_log");
+    LQ_T(S, 12);
     t.pnstep = S.pnstep;
     t.pnnoise = S.pnnoise;
     t.pnlog = S.pnlog;
@@ -810,6 +823,7 @@ lq_calc_noise(const LhCtx & c, const LhQS & S, const LhQR & R, const LhGrR & g, 
         noise_s = noise;
     }
     LQ_MARK("cn_agg");
+    LQ_T(S, 13);
     {
         int const mine = (s < R.psymax);
         int     tmp = 0;
@@ -824,6 +838,7 @@ lq_calc_noise(const LhCtx & c, const LhQS & S, const LhQR & R, const LhGrR & g, 
         res.over_noise = 0;
     }
     LQ_MARK("cn_end");
+    LQ_T(S, 14);
 }
 
 /* calc_noise's results become the working image's (the point where the reference calls it) */
@@ -1047,14 +1062,18 @@ lq_balance_noise(const LhCtx & c, LhQS & S, LhChanLds & Q, const LhQR & R, LhGrR
 {
     int     status;
     LQ_MARK("bn_amp");
+    LQ_T(S, 20);
     lq_amp_scalefac_bands < NS > (c, S, R, g);
     LQ_MARK("bn_break");
+    LQ_T(S, 21);
     status = lq_loop_break(c, S, R, g);
     if (status)
         return 0;
     LQ_MARK("bn_sbc");
+    LQ_T(S, 22);
     status = lq_scale_bitcount(c, S, R, g);
     LQ_MARK("bn_rest");
+    LQ_T(S, 23);
     if (!status)
         return 1;
     if (c.ns > 1) {
@@ -1168,7 +1187,9 @@ lq_outer_loop(const LhCtx & c, LhQS & S, LhChanLds & Q, LhQR & R, LhGrR & gb, co
 
     {
         LH_PT(t_bs);
+        LQ_T(S, 40);
         (void) lq_bin_search < NS > (c, S, R, gb, Q, targ_bits, ch);
+        LQ_T(S, 41);
         LH_PA(7, t_bs);
     }
     best_noise_info.over_count = 100;
@@ -1186,6 +1207,7 @@ lq_outer_loop(const LhCtx & c, LhQS & S, LhChanLds & Q, LhQR & R, LhGrR & gb, co
         lq_keep_best < NS, OLD > (c, S, Q, keep);
         gw = gb;
         age = 0;
+        LQ_T(S, 42);
         do {
             LhNoiseRes noise_info;
             int const search_limit = (R.substep_shaping & 2) ? 20 : 3;
@@ -1201,7 +1223,9 @@ lq_outer_loop(const LhCtx & c, LhQS & S, LhChanLds & Q, LhQR & R, LhGrR & gb, co
             }
             {
                 LH_PT(t_bn);
+                LQ_T(S, 33);            /* loop top: what lies between the comparison's outcome and the next balance_noise */
                 int const bn = lq_balance_noise < NS > (c, S, Q, R, gw);
+                LQ_T(S, 24);
                 LH_PA(8, t_bn);
                 if (bn == 0)
                     break;
@@ -1212,13 +1236,23 @@ lq_outer_loop(const LhCtx & c, LhQS & S, LhChanLds & Q, LhQR & R, LhGrR & gb, co
             if (huff_bits <= 0)
                 break;
             int     pn_before;  /* pn_sfb_count1 as the last count found it */
+#if defined(LH_TRACE) && !defined(LH_EMU)
+            int     tr_retries = 0;
+#endif
             for (;;) {
                 pn_before = R.pn_sfb_count1;
                 gw.part2_3_length = lq_count_bits < 1, NS > (c, S, R, gw, Q);
                 if (!(gw.part2_3_length > huff_bits && gw.global_gain <= maxggain))
                     break;
                 gw.global_gain++;
+#if defined(LH_TRACE) && !defined(LH_EMU)
+                tr_retries++;
+#endif
             }
+#if defined(LH_TRACE) && !defined(LH_EMU)
+            /* (segments 34 .. 38: how many times the gain had to rise before the candidate fitted: 0, 1, 2, 3, more) */
+            LQ_T(S, 34 + (tr_retries < 4 ? tr_retries : 4));
+#endif
             if (gw.global_gain > maxggain)
                 break;
             if (best_noise_info.over_count == 0) {
@@ -1238,17 +1272,20 @@ lq_outer_loop(const LhCtx & c, LhQS & S, LhChanLds & Q, LhQR & R, LhGrR & gb, co
             }
             {
                 LH_PT(t_cn);
+                LQ_T(S, 30);            /* the gain loop's exit checks, the recount rule */
                 lq_noise_point < NS > (c, S, R, gw, Q, xr, nt, noise_info);
                 LH_PA(9, t_cn);
             }
             noise_info.bits = gw.part2_3_length;
             better = lh_quant_compare(best_noise_info, noise_info);
+            LQ_T(S, 31);                /* commit + comparison */
             if (better) {
                 best_part2_3_length = gb.part2_3_length;
                 best_noise_info = noise_info;
                 lq_keep_best < NS, OLD > (c, S, Q, keep);
                 gb = gw;
                 age = 0;
+                LQ_T(S, 32);            /* the candidate kept as the best */
             }
             else {
                 if (c.full_outer_loop == 0) {
@@ -1296,10 +1333,20 @@ lq_stage_body(int qch, int gr, int targ_bits)
     LhChanLds & Q = lh_lds.u.quant.ch[qch];
     LhQS    S;
     R.s_mnc = lh_uni_i((int) Q.sfb_of_line[R.mnc]);
+#if defined(LH_TRACE) && !defined(LH_EMU)
+    lh_tr_begin(S.tr);
+#endif
     lq_load(c, S, Q, R, g, qch);
+    LQ_T(S, 51);
     lq_zero_band_noise < NS > (c, S, R, Q, lh_lds.xr[qch][lh_uni_i(gr)]);
+    LQ_T(S, 52);
     (void) lq_outer_loop < NS > (c, S, Q, R, g, lh_lds.xr[qch][lh_uni_i(gr)], qch, lh_uni_i(targ_bits));
+    LQ_T(S, 53);
+    LQ_T(S, 63);                /* (nothing between two marks: what a mark costs) */
     lh_rg_put(c, R, g);
+#if defined(LH_TRACE) && !defined(LH_EMU)
+    lh_tr_flush(S.tr, c.wave);
+#endif
 }
 
 #ifdef LH_VBR_OLD

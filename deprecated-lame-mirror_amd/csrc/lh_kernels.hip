@@ -1142,6 +1142,17 @@ lh_launch_scatter(const int16_t * arena, int16_t * pool, long cap, const int *se
 }
 
 #endif
+#if defined(LH_TRACE) && !defined(LH_EMU)
+/* development aid (tools/trace_profile.py): the search's segment counters since the last call, [wave][cycles | visits][segment] */
+extern "C" int
+lh_trace_fetch(unsigned long long *dst)
+{
+    static unsigned long long zero[2][2][LH_NTRACE];
+    if (hipMemcpyFromSymbol(dst, HIP_SYMBOL(lh_trace_buf), sizeof(zero)) != hipSuccess)
+        return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(lh_trace_buf), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+}
+#endif
 #ifndef LH_EMU
 /* host-side launcher with a C ABI for lh_api.cpp */
 extern "C" int
