@@ -311,6 +311,15 @@ lh_prio_tick(int me, int left)
 /* The frame and the stream loop are inlined into the kernel: out of line they saved and restored ~60 registers per
  * frame through scratch memory, 50 KB of HBM traffic per frame at no gain. */
 
+/* The frame's barriers between stages that hand data on through LDS only (LH_SYNC_FRAME): an LDS-only fence.  A full
+ * __syncthreads() also drains the wave's global stores -- the payload of the granule just finished -- which nobody in the
+ * workgroup reads. */
+#if defined(LH_BAR_LDS) && !defined(LH_EMU)
+#define LH_SYNC_FRAME() LH_SYNC_WG_LDS()
+#else
+#define LH_SYNC_FRAME() LH_SYNC_WG()
+#endif
+
 /* one frame of one stream; executed by the whole workgroup */
 LH_DEVFN void
 lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
@@ -349,8 +358,10 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
         constexpr int NM = (int) ((sizeof(LhMidSmall) + sizeof(LhMidLong)) / 16);      /* 420 */
         static_assert(__builtin_offsetof(LhMidFrame, lng) == sizeof(LhMidSmall) && sizeof(LhMidSmall) % 16 == 0, "small and lng are one run");
         lh_f32x4 v[5], m[4];
-#if !defined(LH_EMU) && !defined(LH_NO_MID_PREFETCH)
-        /* and the NEXT frame's record is asked for now, one word per cache line (a load nobody uses: it only brings the
+#if !defined(LH_EMU) && defined(LH_MID_PREFETCH)
+        /* (off since round 6: the touched lines did not survive a frame's time in the 4 MB of an XCD's L2 beside 128 streams' scratch
+         * and payload lines and were fetched again -- 12.7 KB of the 31.6 KB the kernel read per frame -- for 0.3 % of its time:
+         * profiles/r06_traffic_ab.txt)  The NEXT frame's record is asked for now, one word per cache line (a load nobody uses: it only brings the
          * lines into the L2 / the memory-side cache, a frame's time before the batch above is issued for them; the pool has
          * a margin of records behind the launch's last frame).  Issued first, so it has returned when the loads below have. */
         uint32_t touched;
@@ -374,11 +385,11 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
         for (int u = 0; u < 4; u++)
             if (tid + LH_NT * u < NM)
                 dm[tid + LH_NT * u] = m[u];
-#if !defined(LH_EMU) && !defined(LH_NO_MID_PREFETCH)
+#if !defined(LH_EMU) && defined(LH_MID_PREFETCH)
         asm volatile("" :: "v"(touched));       /* (its register is the load's until here) */
 #endif
     }
-    LH_SYNC_WG();
+    LH_SYNC_FRAME();
 #else
     if (!lh_lds.ss.primed) {
         lh_stage_window(c, L.mf, c.frame_base - fs);
@@ -442,13 +453,13 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
         loud[0][1] = (cfg->channels == 2) ? L.loudness_sq[0][1] : loud[0][0];
         loud[1][1] = (cfg->channels == 2) ? L.loudness_sq[ngr - 1][1] : loud[1][0];
         lh_adjust_ATH(T, loud, &factor, &limit);
-        LH_SYNC_WG();
+        LH_SYNC_FRAME();
         if (tid == 0) {
             lh_lds.ss.ath_adjust_factor = factor;
             lh_lds.ss.ath_adjust_limit = limit;
         }
     }
-    LH_SYNC_WG();
+    LH_SYNC_FRAME();
 
     LH_PA(25, t_frame);
     /* ---- stage 2: polyphase + MDCT (reference encoder.c:405) ---- */
@@ -513,7 +524,7 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
         for (int gr = 0; gr < ngr; gr++)
             for (int ch = 0; ch < nch; ch++)
                 pe_use[gr][ch] = lh_uni_f(pe_use[gr][ch] * f);
-        LH_SYNC_WG();
+        LH_SYNC_FRAME();
         if (tid < 19)
             lh_lds.ss.pefirbuf[tid] = buf[tid];
     }
@@ -610,7 +621,7 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
         int     max_bits = 0;
         if (!abr)
             max_bits = lh_on_pe(cfg, ResvSize, ResvMax, &substep, pe_use[gr], targ_bits, mean_bits, gr);
-        LH_SYNC_WG();
+        LH_SYNC_FRAME();
         substep = lh_uni_i(substep);
         if (mode_ext == LH_MPG_MD_MS_LR && !abr)
             lh_reduce_side(targ_bits, ms_ener_ratio[gr], mean_bits, max_bits);
@@ -625,7 +636,7 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
             st->dbg_mean_bits = mean_bits;
         }
 #endif
-        LH_SYNC_WG();
+        LH_SYNC_FRAME();
         if (w >= nch) {
             /* no second channel: its payload slot is all zero */
             uint32_t *z = (uint32_t *) &fo->gr[gr][w];
@@ -704,14 +715,14 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
                     *(volatile int *) &L.gr0_done[ch] = stamp;
             }
         }
-        LH_SYNC_WG();
+        LH_SYNC_FRAME();
         LH_PRIO_APPLY(carry.prio_rel, carry.prio_late);
         {
             int const used = lh_uni_i(L.bits_used[0] + L.bits_used[1]);
             ResvSize -= used;
             total_bits += used;
         }
-        LH_SYNC_WG();
+        LH_SYNC_FRAME();
     }
     if (abr) {
         /* the smallest frame that brings the reservoir back to a non-negative size
@@ -785,7 +796,7 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
         lh_emit_frame(fo, drain_pre, drain_post, frame_bits / 8, mdb_header, bitrate_index, padding, mode_ext,
                       c.d.flush && (int) ((c.frame_base + LH_MF_START) / fs) == c.d.frame_end - 1);
     LH_PA(0, t_frame);
-    LH_SYNC_WG();
+    LH_SYNC_FRAME();
 #if defined(LH_PROF) && !defined(LH_EMU)
     if (lane < LH_NPROF)
         st->prof[w][lane] += L.prof[w][lane];
