@@ -561,15 +561,24 @@ lq_count(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
     }
 }
 
+template < int NS > LH_DEVFN void lq_noise_squares(const LhCtx & c, const LhQS & S, const LhGrR & g, LhChanLds & Q, const float *xr);
+
 /* reference takehiro.c:768-801, count_bits */
 template < int USE_PREV, int NS > LH_DEVFN int
-lq_count_bits(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
+lq_count_bits(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q, const float *xr = nullptr)
 {
     int     bits = LH_LARGE_BITS;
     LH_PC(10);
     LH_PT(t_cb);
-    if (lq_quantize < USE_PREV, NS > (c, S, R, g))
+    if (lq_quantize < USE_PREV, NS > (c, S, R, g)) {
+#if defined(LH_NOISE_EARLY) && !defined(LH_EMU)
+        /* (experiment of round 6, DESIGN.md section 4: calc_noise's first half beside the count's reductions and look-ups,
+         * in one instruction stream; wasted when the candidate does not fit and the gain rises) */
+        if (USE_PREV)
+            lq_noise_squares < NS > (c, S, g, Q, xr);
+#endif
         bits = lq_count < USE_PREV, NS > (c, S, R, g, Q);
+    }
     LH_PA(11, t_cb);
     return bits;
 }
@@ -710,36 +719,84 @@ struct LhNoiseTmp {
     LhNoiseRes res;
 };
 
-/* reference quantize_pvt.c:750-913 on the working image: into `t', S and R stay as they are */
+/* POW20(st) = 2^((st - 210) / 4) for the band step of lane = band: one of four mantissas (the table's own entries for
+ * 210..213, in scalar registers) times a power of two -- pow20[i + 4] = 2 pow20[i] holds for the whole table
+ * (power_tables_scale_exactly(), lh_host_init.c), so no table look-up is needed */
+LH_DEVFN float
+lq_pow20_of_step(const LhQS & S, int st)
+{
+    int const d = st - 210, q = d >> 2, r = d & 3;
+    /* (through readfirstlane: a select between plain loads of S's fields would become one load
+     * from a selected address and pin all of S in scratch memory, see lh_sbg()) */
+    float const m0 = lh_uni_f(S.m0), m1 = lh_uni_f(S.m1), m2 = lh_uni_f(S.m2), m3 = lh_uni_f(S.m3);
+    float const m = (r & 2) ? ((r & 1) ? m3 : m2) : ((r & 1) ? m1 : m0);
+    return lq_ldexp(m, q);
+}
+
+/* calc_noise's first half: the squared error of every line of the working image at the working steps, to LDS (sq = the
+ * channel's dead xrpow copy), where the band lanes add them up.  A function of the image, the scalefactors and the gain
+ * only -- with LH_NOISE_EARLY the bit count that produced the image issues it beside its own reductions and look-ups. */
 template < int NS > LH_DEVFN void
+lq_noise_squares(const LhCtx & c, const LhQS & S, const LhGrR & g, LhChanLds & Q, const float *xr)
+{
+    const LhTables *T = c.T;
+    const LhQTabs *qt = LH_QT;
+    float  *sq = Q.xrpow;       /* the LDS copy of xrpow is dead while the search runs */
+    float const step = lq_pow20_of_step(S, lq_band_step(S, g));
+    int     big = 0;
+    /* the band's step goes to its lines with one cross-lane read per slot; the squared errors
+     * of all lines go to LDS, where the band lanes add them up in the reference's order */
+    float   stp[5], p43[10];
+    lh_f32x2 ax[5];
+#pragma unroll
+    for (int k = 0; k < NS; k++) {
+        unsigned const q0 = S.pw[k] & 0xffffu, q1 = S.pw[k] >> 16;
+        ax[k] = ((const lh_f32x2 *) xr)[(k < 4 || c.lane < 32) ? c.lane + 64 * k : 287];
+        stp[k] = lh_shfl_f32(step, S.bnd[k]);
+        p43[2 * k] = qt->pow43h[q0 & 255u];
+        p43[2 * k + 1] = qt->pow43h[q1 & 255u];
+        big |= (int) ((q0 | q1) >> 8);
+    }
+    if (LH_RARE(lh_ballot(big != 0))) {
+#pragma unroll
+        for (int k = 0; k < NS; k++) {
+            unsigned const q0 = S.pw[k] & 0xffffu, q1 = S.pw[k] >> 16;
+            if (q0 >= 256u)
+                p43[2 * k] = T->pow43[q0];
+            if (q1 >= 256u)
+                p43[2 * k + 1] = T->pow43[q1];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NS; k++) {
+        int const p = c.lane + 64 * k;
+        float const t0 = lh_fabsf(ax[k].x) - p43[2 * k] * stp[k];
+        float const t1 = lh_fabsf(ax[k].y) - p43[2 * k + 1] * stp[k];
+        lh_f32x2 v;
+        v.x = t0 * t0;
+        v.y = t1 * t1;
+        if (k < 4 || p < 288)
+            ((lh_f32x2 *) sq)[p] = v;
+    }
+}
+
+/* reference quantize_pvt.c:750-913 on the working image: into `t', S and R stay as they are.  HAVE_SQ: the squared
+ * errors are in LDS already (lq_noise_squares ran with the bit count of this very image). */
+template < int NS, int HAVE_SQ = 0 > LH_DEVFN void
 lq_calc_noise(const LhCtx & c, const LhQS & S, const LhQR & R, const LhGrR & g, LhChanLds & Q, const float *xr,
               LhNoiseTmp & t)
 {
     LhNoiseRes & res = t.res;
-    const LhTables *T = c.T;
-    const LhQTabs *qt = LH_QT;
     int const s = c.lane;
     float  *sq = Q.xrpow;       /* the LDS copy of xrpow is dead while the search runs */
     float   noise = 0, noise_s = 0;
-    int     l = 0, j = 0, big = 0, maxw;
+    int     l = 0, j = 0, maxw;
     LH_PC(13);
     LQ_MARK("cn_begin");
     LQ_T(S, 10);
     int const st = lq_band_step(S, g);
     int const fresh = (s < R.psymax) && !(S.pnstep == st);
     int const zb = fresh && (S.sta >= S.nzend);
-    /* POW20(st) = 2^((st - 210) / 4): one of four mantissas (the table's own entries for 210..213,
-     * in scalar registers) times a power of two -- pow20[i + 4] = 2 pow20[i] holds for the whole
-     * table (power_tables_scale_exactly(), lh_host_init.c), so no table look-up is needed */
-    float   step;
-    {
-        int const d = st - 210, q = d >> 2, r = d & 3;
-        /* (through readfirstlane: a select between plain loads of S's fields would become one load
-         * from a selected address and pin all of S in scratch memory, see lh_sbg()) */
-        float const m0 = lh_uni_f(S.m0), m1 = lh_uni_f(S.m1), m2 = lh_uni_f(S.m2), m3 = lh_uni_f(S.m3);
-        float const m = (r & 2) ? ((r & 1) ? m3 : m2) : ((r & 1) ? m1 : m0);
-        step = lq_ldexp(m, q);
-    }
     if (fresh) {
         l = S.wid >> 1;
         j = S.sta;
@@ -748,47 +805,13 @@ lq_calc_noise(const LhCtx & c, const LhQS & S, const LhQR & R, const LhGrR & g, 
             l = (usefullsize > 0) ? (usefullsize >> 1) : 0;
         }
     }
-    {
-        /* the band's step goes to its lines with one cross-lane read per slot; the squared errors
-         * of all lines go to LDS, where the band lanes add them up in the reference's order */
-        float   stp[5], p43[10];
-        lh_f32x2 ax[5];
-#pragma unroll
-        for (int k = 0; k < NS; k++) {
-            unsigned const q0 = S.pw[k] & 0xffffu, q1 = S.pw[k] >> 16;
-            ax[k] = ((const lh_f32x2 *) xr)[(k < 4 || c.lane < 32) ? c.lane + 64 * k : 287];
-            stp[k] = lh_shfl_f32(step, S.bnd[k]);
-            p43[2 * k] = qt->pow43h[q0 & 255u];
-            p43[2 * k + 1] = qt->pow43h[q1 & 255u];
-            big |= (int) ((q0 | q1) >> 8);
-        }
-        /* a band that starts at or above the end of the non-zero lines adds up the squares of its own lines, whatever
-         * the step: the constant is there since lq_zero_band_noise, and the band sits out the serial sum below (the
-         * widest bands are at the top of the spectrum, where little is quantised to anything else) */
-        l = zb ? 0 : l;
-        maxw = (int) lh_wave_max_u32(fresh ? (unsigned) (2 * l) : 0u);
-        if (LH_RARE(lh_ballot(big != 0))) {
-#pragma unroll
-            for (int k = 0; k < NS; k++) {
-                unsigned const q0 = S.pw[k] & 0xffffu, q1 = S.pw[k] >> 16;
-                if (q0 >= 256u)
-                    p43[2 * k] = T->pow43[q0];
-                if (q1 >= 256u)
-                    p43[2 * k + 1] = T->pow43[q1];
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < NS; k++) {
-            int const p = c.lane + 64 * k;
-            float const t0 = lh_fabsf(ax[k].x) - p43[2 * k] * stp[k];
-            float const t1 = lh_fabsf(ax[k].y) - p43[2 * k + 1] * stp[k];
-            lh_f32x2 v;
-            v.x = t0 * t0;
-            v.y = t1 * t1;
-            if (k < 4 || p < 288)
-                ((lh_f32x2 *) sq)[p] = v;
-        }
-    }
+    if (!HAVE_SQ)
+        lq_noise_squares < NS > (c, S, g, Q, xr);
+    /* a band that starts at or above the end of the non-zero lines adds up the squares of its own lines, whatever
+     * the step: the constant is there since lq_zero_band_noise, and the band sits out the serial sum below (the
+     * widest bands are at the top of the spectrum, where little is quantised to anything else) */
+    l = zb ? 0 : l;
+    maxw = (int) lh_wave_max_u32(fresh ? (unsigned) (2 * l) : 0u);
     LH_WAVE_ORDER();
     LQ_MARK("cn_sum");
     LQ_T(S, 11);
@@ -1093,11 +1116,11 @@ lq_balance_noise(const LhCtx & c, LhQS & S, LhChanLds & Q, const LhQR & R, LhGrR
 }
 
 /* where the reference calls calc_noise: the noise of the candidate counted last becomes the working image's */
-template < int NS > LH_DEVFN void
+template < int NS, int HAVE_SQ = 0 > LH_DEVFN void
 lq_noise_point(const LhCtx & c, LhQS & S, LhQR & R, const LhGrR & g, LhChanLds & Q, const float *xr, LhNoiseTmp & t,
                LhNoiseRes & res)
 {
-    lq_calc_noise < NS > (c, S, R, g, Q, xr, t);
+    lq_calc_noise < NS, HAVE_SQ > (c, S, R, g, Q, xr, t);
     lq_noise_commit(S, R, g, t);
     res = t.res;
 }
@@ -1241,7 +1264,7 @@ lq_outer_loop(const LhCtx & c, LhQS & S, LhChanLds & Q, LhQR & R, LhGrR & gb, co
 #endif
             for (;;) {
                 pn_before = R.pn_sfb_count1;
-                gw.part2_3_length = lq_count_bits < 1, NS > (c, S, R, gw, Q);
+                gw.part2_3_length = lq_count_bits < 1, NS > (c, S, R, gw, Q, xr);
                 if (!(gw.part2_3_length > huff_bits && gw.global_gain <= maxggain))
                     break;
                 gw.global_gain++;
@@ -1263,7 +1286,7 @@ lq_outer_loop(const LhCtx & c, LhQS & S, LhChanLds & Q, LhQR & R, LhGrR & gb, co
                 int const same = (R.pn_sfb_count1 == pn_before);
                 if (!same || (gw.part2_3_length > best_part2_3_length && gw.global_gain <= maxggain)) {
                     gw.global_gain += same;     /* (the count that was not run said: too many bits) */
-                    while ((gw.part2_3_length = lq_count_bits < 1, NS > (c, S, R, gw, Q)) > best_part2_3_length
+                    while ((gw.part2_3_length = lq_count_bits < 1, NS > (c, S, R, gw, Q, xr)) > best_part2_3_length
                            && gw.global_gain <= maxggain)
                         gw.global_gain++;
                 }
@@ -1273,7 +1296,11 @@ lq_outer_loop(const LhCtx & c, LhQS & S, LhChanLds & Q, LhQR & R, LhGrR & gb, co
             {
                 LH_PT(t_cn);
                 LQ_T(S, 30);            /* the gain loop's exit checks, the recount rule */
+#if defined(LH_NOISE_EARLY) && !defined(LH_EMU)
+                lq_noise_point < NS, 1 > (c, S, R, gw, Q, xr, nt, noise_info);
+#else
                 lq_noise_point < NS > (c, S, R, gw, Q, xr, nt, noise_info);
+#endif
                 LH_PA(9, t_cn);
             }
             noise_info.bits = gw.part2_3_length;
