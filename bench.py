@@ -397,14 +397,14 @@ def check_against_oracle(batch, enc_args, host_streams, which, procs=1):
 
 
 def pmc_record_for(args):
-    """The committed PMC record of the workload this run benches (recorded with tools/r05_collect.sh)."""
+    """The committed PMC record of the workload this run benches (recorded with tools/r06_collect.sh)."""
     if args.vbr is not None:
-        return "r05_pmc_vbrold2.json" if args.vbr_old else "r05_pmc_vbr2.json"
+        return "r06_pmc_vbrold2.json" if args.vbr_old else "r06_pmc_vbr2.json"
     if args.brate == 320 and args.samplerate == 48000:
-        return "r05_pmc_cbr320.json"
+        return "r06_pmc_cbr320.json"
     if args.samplerate < 32000:
-        return "r05_pmc_lsf.json"
-    return "r05_pmc.json"
+        return "r06_pmc_lsf.json"
+    return "r06_pmc.json"
 
 
 def roofline_block(frames, sr, kavg_s, parts, pmc_name):
@@ -671,14 +671,14 @@ def main():
             batch = None
             res["extra"] = {
                 "vbr_v2_config2": short_run(torch, lamehip, dev, device_index, 44100, 1024, 5.0, 2, 5000, 3.0,
-                                            "r05_pmc_vbr2.json", vbr_q=2),
+                                            "r06_pmc_vbr2.json", vbr_q=2),
                 "vbr_old_v2": short_run(torch, lamehip, dev, device_index, 44100, 1024, 5.0, 2, 5000, 3.0,
-                                        "r05_pmc_vbrold2.json", vbr_q=2, vbr_mode=2),
+                                        "r06_pmc_vbrold2.json", vbr_q=2, vbr_mode=2),
                 "cbr320_48k_bursts_config4": short_run(torch, lamehip, dev, device_index, 48000, 1024, 5.0, 2, 9000,
-                                                       40.0, "r05_pmc_cbr320.json", brate=320, mode=1),
+                                                       40.0, "r06_pmc_cbr320.json", brate=320, mode=1),
                 # MPEG-2 (one granule of 576 samples per frame): the kernel object compiled with -DLH_LSF
                 "mpeg2_22k_cbr64": short_run(torch, lamehip, dev, device_index, 22050, 1024, 10.0, 2, 7000, 3.0,
-                                             "r05_pmc_lsf.json", brate=64),
+                                             "r06_pmc_lsf.json", brate=64),
             }
         if not args.no_end_to_end and not args.no_extras and world == 1:
             if batch is not None:
