@@ -625,6 +625,47 @@ lh_ctx_load(void)
     return o;
 }
 
+/* The usual case (round 6): a long block of the normal type of an MPEG-1 stream under the settings of the CBR / ABR presets
+ * around 128 kb/s -- noise shaping 2 with amplification rule 1, no full outer loop, no sfb21 band, no substep shaping.
+ * The stages that run once or more per granule and channel exist a second time with these as constants (suffix n: the same
+ * source, the fields below pinned before the body runs), which drops the other block types' and presets' code from them. */
+LH_DEVFN int
+lh_cfg_is_usual(const LhCtx & c)
+{
+    return !LH_IS_LSF && c.ns == 2 && c.ns_amp == 1 && c.full_outer_loop == 0 && c.sfb21_extra == 0;
+}
+
+LH_DEVFN int
+lh_granule_is_usual(const LhCtx & c, int block_type, int substep)
+{
+    return lh_cfg_is_usual(c) && block_type == LH_NORM_TYPE && (substep & 2) == 0;
+}
+
+LH_DEVFN void
+lh_pin_usual(LhCtx & c)
+{
+    c.ns = 2;
+    c.ns_amp = 1;
+    c.full_outer_loop = 0;
+    c.sfb21_extra = 0;
+    c.rate8k = 0;
+}
+
+/* (the values lh_init_outer_loop_body gives these fields in the usual case) */
+LH_DEVFN void
+lh_pin_usual(LhQR & R)
+{
+    R.block_type = LH_NORM_TYPE;
+    R.sfb_lmax = LH_SBPSY_L;
+    R.sfb_smin = LH_SBPSY_S;
+    R.psy_lmax = LH_SBPSY_L;
+    R.psymax = LH_SBPSY_L;
+    R.sfbmax = LH_SBPSY_L;
+    R.sfbdivide = 11;
+    if ((R.substep_shaping & 2) != 0)
+        __builtin_unreachable();
+}
+
 LH_DEVFN void
 lh_rg_put(const LhCtx & c, const LhQR & R, const LhGrR & g)
 {

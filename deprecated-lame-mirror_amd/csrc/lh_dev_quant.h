@@ -884,6 +884,24 @@ lh_calc_xmin(int qch, int gr, int rch)
     LH_WAVE_SYNC();
 }
 
+/* the same for the usual case (lh_granule_is_usual): every band a long one, no short-block tail */
+LH_STAGEFN void
+lh_calc_xmin_n(int qch, int gr, int rch)
+{
+    LhCtx   c = lh_ctx_load();
+    LhQR    R = lh_uniform(lh_lds.rg[qch].R);
+    lh_pin_usual(c);
+    lh_pin_usual(R);
+    {
+        int const slot = (lh_uni_i(lh_lds.psy_slot) + gr) % 3;
+        lh_calc_xmin_body(c, lh_lds.u.quant.ch[qch], R, lh_lds.xr[qch][gr], lh_lds.psy_en[slot][rch],
+                          lh_lds.psy_thm[slot][rch]);
+    }
+    if (c.lane == 0)
+        lh_lds.rg[qch].R = R;
+    LH_WAVE_SYNC();
+}
+
 /* ---------------------------------------------------------------------- */
 /* geometry of the granule + spectrum re-ordering for short blocks
  * (reference quantize.c:226-346) */
@@ -1001,6 +1019,17 @@ lh_init_outer_loop(int qch, int gr, int block_type, int substep, int reorder = 1
     LhGrR   g;
     lh_init_outer_loop_body(c, lh_lds.u.quant.ch[qch], R, g, lh_lds.xr[qch][gr], lh_uni_i(block_type),
                             lh_uni_i(substep), lh_uni_i(reorder));
+    lh_rg_put(c, R, g);
+}
+
+LH_STAGEFN void
+lh_init_outer_loop_n(int qch, int gr, int substep)
+{
+    LhCtx   c = lh_ctx_load();
+    LhQR    R;
+    LhGrR   g;
+    lh_pin_usual(c);
+    lh_init_outer_loop_body(c, lh_lds.u.quant.ch[qch], R, g, lh_lds.xr[qch][gr], LH_NORM_TYPE, lh_uni_i(substep), 0);
     lh_rg_put(c, R, g);
 }
 
@@ -1202,6 +1231,19 @@ lh_best_scalefac_store(int qch, int gr, const int8_t * g0sf, int g0_block_type)
     LhCtx const c = lh_ctx_load();
     LhQR const R = lh_uniform(lh_lds.rg[qch].R);
     LhGrR   g = lh_uniform(lh_lds.rg[qch].g);
+    lh_best_scalefac_store_body(c, lh_lds.u.quant.ch[qch], R, g, lh_uni_i(gr), LH_AS_GLOBAL(const int8_t, g0sf),
+                                lh_uni_i(g0_block_type), lh_lds.scfsi[qch]);
+    lh_rg_put(c, R, g);
+}
+
+LH_STAGEFN void
+lh_best_scalefac_store_n(int qch, int gr, const int8_t * g0sf, int g0_block_type)
+{
+    LhCtx   c = lh_ctx_load();
+    LhQR    R = lh_uniform(lh_lds.rg[qch].R);
+    LhGrR   g = lh_uniform(lh_lds.rg[qch].g);
+    lh_pin_usual(c);
+    lh_pin_usual(R);
     lh_best_scalefac_store_body(c, lh_lds.u.quant.ch[qch], R, g, lh_uni_i(gr), LH_AS_GLOBAL(const int8_t, g0sf),
                                 lh_uni_i(g0_block_type), lh_lds.scfsi[qch]);
     lh_rg_put(c, R, g);
@@ -1653,6 +1695,18 @@ lh_best_huffman_divide(int qch)
     LhCtx const c = lh_ctx_load();
     LhQR const R = lh_uniform(lh_lds.rg[qch].R);
     LhGrR   g = lh_uniform(lh_lds.rg[qch].g);
+    lh_best_huffman_divide_body(c, lh_lds.u.quant.ch[qch], R, g);
+    lh_rg_put(c, R, g);
+}
+
+LH_STAGEFN void
+lh_best_huffman_divide_n(int qch)
+{
+    LhCtx   c = lh_ctx_load();
+    LhQR    R = lh_uniform(lh_lds.rg[qch].R);
+    LhGrR   g = lh_uniform(lh_lds.rg[qch].g);
+    lh_pin_usual(c);
+    lh_pin_usual(R);
     lh_best_huffman_divide_body(c, lh_lds.u.quant.ch[qch], R, g);
     lh_rg_put(c, R, g);
 }

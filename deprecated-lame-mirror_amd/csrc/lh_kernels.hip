@@ -238,13 +238,20 @@ lh_prepare_granule(const LhCtx & c, int ch, int gr, int msoff, int substep)
     LhQR    R;
     LhGrR   g;
     int     nonzero;
-    lh_init_outer_loop(ch, gr, L.block_type[gr][ch], substep);
+    int const usual = lh_uni_i(lh_granule_is_usual(c, L.block_type[gr][ch], substep));
+    if (usual)
+        lh_init_outer_loop_n(ch, gr, substep);
+    else
+        lh_init_outer_loop(ch, gr, L.block_type[gr][ch], substep);
     R = lh_uniform(L.rg[ch].R);
     g = lh_uniform(L.rg[ch].g);
     nonzero = lh_init_xrpow(c, Q, R, g, L.xr[ch][gr]);
     if (nonzero) {
         lh_rg_put(c, R, g);
-        lh_calc_xmin(ch, gr, msoff + ch);
+        if (usual)
+            lh_calc_xmin_n(ch, gr, msoff + ch);
+        else
+            lh_calc_xmin(ch, gr, msoff + ch);
         R = lh_uniform(L.rg[ch].R);
         LH_DBG_XMIN(c, gr, ch, msoff + ch, Q, R.psymax);
         lh_zero_tail(c, Q, R);
@@ -664,11 +671,19 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
                 LH_PT(t_ol);
                 if (abr && !R.ath_over)
                     targ_bits[ch] = analog_silence_bits;    /* reference quantize.c:1953-1954 */
+                /* (four stages of one source: five or four slots x the usual case or any, lh_dev_qloop.h) */
+                int const usual = lh_uni_i(lh_granule_is_usual(c, R.block_type, R.substep_shaping));
                 if (lq_needs_tail(c, Q, R)) {
-                    lq_outer_loop_stage5(ch, gr, targ_bits[ch]);
+                    if (usual)
+                        lq_outer_loop_stage5n(ch, gr, targ_bits[ch]);
+                    else
+                        lq_outer_loop_stage5(ch, gr, targ_bits[ch]);
                 }
                 else {
-                    lq_outer_loop_stage4(ch, gr, targ_bits[ch]);
+                    if (usual)
+                        lq_outer_loop_stage4n(ch, gr, targ_bits[ch]);
+                    else
+                        lq_outer_loop_stage4(ch, gr, targ_bits[ch]);
                 }
                 R = lh_uniform(L.rg[ch].R);
                 g = lh_uniform(L.rg[ch].g);
@@ -676,9 +691,16 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
             }
             LH_PT(t_fin);
             lh_rg_put(c, R, g);
-            lh_best_scalefac_store(ch, gr, fo->gr[0][ch].scalefac, L.block_type[0][ch]);
-            if (cfg->use_best_huffman == 1)
-                lh_best_huffman_divide(ch);
+            if (lh_uni_i(lh_granule_is_usual(c, R.block_type, R.substep_shaping))) {
+                lh_best_scalefac_store_n(ch, gr, fo->gr[0][ch].scalefac, L.block_type[0][ch]);
+                if (cfg->use_best_huffman == 1)
+                    lh_best_huffman_divide_n(ch);
+            }
+            else {
+                lh_best_scalefac_store(ch, gr, fo->gr[0][ch].scalefac, L.block_type[0][ch]);
+                if (cfg->use_best_huffman == 1)
+                    lh_best_huffman_divide(ch);
+            }
             g = lh_uniform(L.rg[ch].g);
             LH_PA(6, t_fin);
             lh_store_granule(c, Q, R, g, xr, o);
