@@ -567,6 +567,7 @@ struct LhCtx {
      * registers) instead of once per use */
     int     ns, ns_amp, sfb21_extra, full_outer_loop, subblock_gain;
     int     rate8k;             /* (LH_LSF build) an 8 kHz stream: 17 long / 9 short coded bands */
+    int     l21;                /* sfb_l[21]: the first line of the last long band (the usual-case stages' padded sums fit up to 418) */
 };
 
 LH_DEVFN void
@@ -577,6 +578,7 @@ lh_ctx_hot(LhCtx & c)
     c.sfb21_extra = lh_uni_i(c.cfg->sfb21_extra);
     c.full_outer_loop = lh_uni_i(c.cfg->full_outer_loop);
     c.subblock_gain = lh_uni_i(c.cfg->subblock_gain);
+    c.l21 = lh_uni_i(c.T->sfb_l[LH_SBPSY_L]);
 #ifdef LH_LSF
     c.rate8k = lh_uni_i(c.cfg->samplerate <= 8000);
 #else
@@ -632,7 +634,9 @@ lh_ctx_load(void)
 LH_DEVFN int
 lh_cfg_is_usual(const LhCtx & c)
 {
-    return !LH_IS_LSF && c.ns == 2 && c.ns_amp == 1 && c.full_outer_loop == 0 && c.sfb21_extra == 0;
+    /* (l21: the 44.1 and 48 kHz band tables; at 32 kHz the bands' padded squares -- LhQS.pad, lh_dev_qloop.h -- would not fit
+     * the scratch: those streams take the general stages) */
+    return !LH_IS_LSF && c.ns == 2 && c.ns_amp == 1 && c.full_outer_loop == 0 && c.sfb21_extra == 0 && c.l21 <= 418;
 }
 
 LH_DEVFN int
@@ -649,6 +653,8 @@ lh_pin_usual(LhCtx & c)
     c.full_outer_loop = 0;
     c.sfb21_extra = 0;
     c.rate8k = 0;
+    if (c.l21 > 418)
+        __builtin_unreachable();
 }
 
 /* (the values lh_init_outer_loop_body gives these fields in the usual case) */

@@ -55,10 +55,19 @@ struct LhQS {
      * squares of its lines, a constant of the granule (lq_zero_band_noise) */
     float   zk;
     int     nzend;              /* wave-uniform: the lines from here on are zero in the working image (set by every count) */
+    /* The usual-case stages (pad = 1, a constant there) keep calc_noise's squared errors band by band, every band on a
+     * 32-byte boundary and padded with zeros to a multiple of eight terms: the band lanes then add whole blocks of eight
+     * (adding +0.0f changes nothing) and are switched off once per block, not once per pair.  sqi: where the slot's pair
+     * goes (byte offset into the scratch; pairs of the bands that are not summed go to a dump), sqb: lane = band, the
+     * band's first term. */
+    int     pad;
+    uint32_t sqi[5];
+    int     sqb;
 #if defined(LH_TRACE) && !defined(LH_EMU)
     mutable LhTr tr;            /* development aid: cycles per segment of the search (lh_dev_common.h) */
 #endif
 };
+#define LQ_SQ_DUMP 568          /* (floats; the padded bands end at 488 for the widest table: checked in lq_load) */
 
 LH_DEVFN int
 lq_bit(uint64_t m, int b)
@@ -208,6 +217,24 @@ lq_load(const LhCtx & c, LhQS & S, LhChanLds & Q, const LhQR & R, const LhGrR & 
 #pragma unroll
         for (int j = 0; j < 3; j++)
             Q.hl3_small[c.lane + 64 * j] = w[8 + j];
+    }
+    if (S.pad) {
+        /* (the scratch is the channel's xrpow copy, read above: all zero first, the squares overwrite their places) */
+        uint32_t const w8 = (c.lane < LH_SBPSY_L) ? (uint32_t) ((S.wid + 7) & ~7) : 0u;
+        uint32_t const upto = lh_wave_scan_u32(w8);
+        S.sqb = (int) (upto - w8);
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            int const b = S.bnd[k] & 63;
+            int const at = (int) lh_shfl_u32((uint32_t) S.sqb, b) + 2 * (c.lane + 64 * k) - (int) lh_shfl_u32((uint32_t) S.sta, b);
+            S.sqi[k] = 4u * (uint32_t) ((S.bnd[k] < LH_SBPSY_L) ? at : LQ_SQ_DUMP);
+        }
+        LH_WAVE_SYNC();
+        for (int i = c.lane; i < 576 / 4; i += 64) {
+            lh_f32x4 z;
+            z.x = z.y = z.z = z.w = 0.0f;
+            ((lh_f32x4 *) Q.xrpow)[i] = z;
+        }
     }
     LH_WAVE_SYNC();
 }
@@ -674,6 +701,54 @@ lq_band_sums(const float *sq, int n, int jj, int maxw, int fresh)
     return noise;
 }
 
+/* The same over the padded layout (LhQS.pad): the band's terms start at sq[base] (a 32-byte boundary), zeros follow its last
+ * term up to a multiple of eight.  Sixteen terms per block from four 16-byte reads; a lane is switched off for a whole
+ * group of eight once its band has ended; the next block's reads are issued before this block's additions. */
+LH_DEVFN float
+lq_band_sums_pad(const float *sq, int base, int n, int maxw)
+{
+    float   noise = 0;
+#if !defined(LH_EMU)
+    struct alignas(16) Q4 { float x, y, z, w; };
+    const Q4 *src = (const Q4 *) (sq + base);
+    int     rem = n;            /* terms the lane still has to add (<= 0: none) */
+    Q4      a0 = src[0], a1 = src[1], a2 = src[2], a3 = src[3];
+#define LH_CP_OCT(K, A, B) "v_cmpx_gt_i32_e64 %[tm], %[rem], " #K "\n\t" \
+                           "v_add_f32 %[ns], %[ns], %[" #A "0]\n\tv_add_f32 %[ns], %[ns], %[" #A "1]\n\t" \
+                           "v_add_f32 %[ns], %[ns], %[" #A "2]\n\tv_add_f32 %[ns], %[ns], %[" #A "3]\n\t" \
+                           "v_add_f32 %[ns], %[ns], %[" #B "0]\n\tv_add_f32 %[ns], %[ns], %[" #B "1]\n\t" \
+                           "v_add_f32 %[ns], %[ns], %[" #B "2]\n\tv_add_f32 %[ns], %[ns], %[" #B "3]\n\t"
+#define LH_CP_BLOCK(U, V, W, X) do { unsigned long long sv_, tm_; \
+                asm volatile("s_mov_b64 %[sv], exec\n\t" LH_CP_OCT(0, a, b) LH_CP_OCT(8, c, d) "s_mov_b64 exec, %[sv]" \
+                             : [ns] "+v"(noise), [sv] "=&s"(sv_), [tm] "=&s"(tm_) \
+                             : [rem] "v"(rem), [a0] "v"(U.x), [a1] "v"(U.y), [a2] "v"(U.z), [a3] "v"(U.w), \
+                               [b0] "v"(V.x), [b1] "v"(V.y), [b2] "v"(V.z), [b3] "v"(V.w), \
+                               [c0] "v"(W.x), [c1] "v"(W.y), [c2] "v"(W.z), [c3] "v"(W.w), \
+                               [d0] "v"(X.x), [d1] "v"(X.y), [d2] "v"(X.z), [d3] "v"(X.w)); } while (0)
+    for (int k0 = 0; k0 < maxw; k0 += 32) {
+        Q4 const b0 = src[4], b1 = src[5], b2 = src[6], b3 = src[7];
+        LH_CP_BLOCK(a0, a1, a2, a3);
+        rem -= 16;
+        if (k0 + 16 >= maxw)
+            break;
+        a0 = src[8];
+        a1 = src[9];
+        a2 = src[10];
+        a3 = src[11];
+        LH_CP_BLOCK(b0, b1, b2, b3);
+        rem -= 16;
+        src += 8;
+    }
+#undef LH_CP_BLOCK
+#undef LH_CP_OCT
+#else
+    (void) maxw;
+    for (int i = 0; i < n; i++)
+        noise += sq[base + i];
+#endif
+    return noise;
+}
+
 /* The noise of every band for the case that all of its lines are quantised to zero (reference quantize_pvt.c:750-790 with
  * ix = 0: temp = |xr| - pow43[0] * step = |xr|, whatever the step): the squares of the band's lines added in order, over
  * as many lines as calc_noise looks at (max_nonzero_coeff cuts the last band short).  Once per search, after lq_load. */
@@ -701,12 +776,18 @@ lq_zero_band_noise(const LhCtx & c, LhQS & S, const LhQR & R, LhChanLds & Q, con
         lh_f32x2 v;
         v.x = t0 * t0;
         v.y = t1 * t1;
-        if (k < 4 || p < 288)
+        if (S.pad) {
+            /* (a line above max_nonzero_coeff is no term of any sum: its place holds a zero) */
+            v.x = lh_u32_as_f32(lh_f32_as_u32(v.x) & S.vm[k]);
+            v.y = lh_u32_as_f32(lh_f32_as_u32(v.y) & S.vm[k]);
+            *(lh_f32x2 *) ((char *) sq + S.sqi[k]) = v;
+        }
+        else if (k < 4 || p < 288)
             ((lh_f32x2 *) sq)[p] = v;
     }
     LH_WAVE_ORDER();
     maxw = (int) lh_wave_max_u32(mine ? (unsigned) (2 * l) : 0u);
-    S.zk = lq_band_sums(sq, 2 * l, (j < 576) ? (j >> 1) : 0, maxw, mine);
+    S.zk = S.pad ? lq_band_sums_pad(sq, S.sqb, mine ? 2 * l : 0, maxw) : lq_band_sums(sq, 2 * l, (j < 576) ? (j >> 1) : 0, maxw, mine);
     LH_WAVE_SYNC();
 }
 
@@ -775,7 +856,12 @@ lq_noise_squares(const LhCtx & c, const LhQS & S, const LhGrR & g, LhChanLds & Q
         lh_f32x2 v;
         v.x = t0 * t0;
         v.y = t1 * t1;
-        if (k < 4 || p < 288)
+        if (S.pad) {
+            v.x = lh_u32_as_f32(lh_f32_as_u32(v.x) & S.vm[k]);
+            v.y = lh_u32_as_f32(lh_f32_as_u32(v.y) & S.vm[k]);
+            *(lh_f32x2 *) ((char *) sq + S.sqi[k]) = v;
+        }
+        else if (k < 4 || p < 288)
             ((lh_f32x2 *) sq)[p] = v;
     }
 }
@@ -818,7 +904,7 @@ lq_calc_noise(const LhCtx & c, const LhQS & S, const LhQR & R, const LhGrR & g, 
     {
         int const n = 2 * l;
         int const jj = (j < 576) ? (j >> 1) : 0;
-        noise = lq_band_sums(sq, n, jj, maxw, fresh);
+        noise = S.pad ? lq_band_sums_pad(sq, S.sqb, n, maxw) : lq_band_sums(sq, n, jj, maxw, fresh);
         noise = zb ? S.zk : noise;
     }
     LQ_MARK("cn_log");
@@ -1366,6 +1452,11 @@ lq_stage_body(int qch, int gr, int targ_bits)
     }
     LhChanLds & Q = lh_lds.u.quant.ch[qch];
     LhQS    S;
+#if defined(LH_NOISE_EARLY) || defined(LH_NO_PAD)
+    S.pad = 0;
+#else
+    S.pad = SPEC;
+#endif
     R.s_mnc = lh_uni_i((int) Q.sfb_of_line[R.mnc]);
 #if defined(LH_TRACE) && !defined(LH_EMU)
     lh_tr_begin(S.tr);
@@ -1410,6 +1501,7 @@ lq_vbrold_body(int qch, int gr, int min_bits, int max_bits, int cont)
     max_bits = lh_uni_i(max_bits);
     int const top = max_bits;
     R.s_mnc = lh_uni_i((int) Q.sfb_of_line[R.mnc]);
+    S.pad = 0;
     lq_load(c, S, Q, R, g, qch);
     lq_zero_band_noise < NS > (c, S, R, Q, xr);
     if (lh_uni_i(cont)) {

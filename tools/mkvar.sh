@@ -6,10 +6,10 @@ set -e
 N=$1; shift
 cd "$(dirname "$0")/../deprecated-lame-mirror_amd/csrc"
 HIPCC=/opt/rocm/bin/hipcc
-COMMON="--offload-arch=gfx950 -O2 -fno-slp-vectorize -falign-functions=256 -std=c++17 -fno-fast-math -ffp-contract=off -fPIC -I. -I../../include"
+COMMON="--offload-arch=gfx950 ${VAR_OPT:--O2} -fno-slp-vectorize -falign-functions=256 -std=c++17 -fno-fast-math -ffp-contract=off -fPIC -I. -I../../include"
 Q=lh_kernels_q.o; A=lh_analysis.o; S=lh_subband.o
 case "${VAR_SRC:-q}" in
-  q) $HIPCC $COMMON -mllvm -amdgpu-sched-strategy=iterative-ilp -DLH_SPLIT "$@" -c lh_kernels.hip -o /tmp/var_$N.o; Q=/tmp/var_$N.o;;
+  q) $HIPCC $COMMON ${VAR_SCHED--mllvm -amdgpu-sched-strategy=iterative-ilp} -DLH_SPLIT "$@" -c lh_kernels.hip -o /tmp/var_$N.o; Q=/tmp/var_$N.o;;
   analysis) $HIPCC $COMMON "$@" -c lh_analysis.hip -o /tmp/var_$N.o; A=/tmp/var_$N.o;;
   subband) $HIPCC $COMMON "$@" -c lh_subband.hip -o /tmp/var_$N.o; S=/tmp/var_$N.o;;
 esac
