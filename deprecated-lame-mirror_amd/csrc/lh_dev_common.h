@@ -627,28 +627,33 @@ lh_ctx_load(void)
     return o;
 }
 
-/* The usual case (round 6): a long block of the normal type of an MPEG-1 stream under the settings of the CBR / ABR presets
- * around 128 kb/s -- noise shaping 2 with amplification rule 1, no full outer loop, no sfb21 band, no substep shaping.
- * The stages that run once or more per granule and channel exist a second time with these as constants (suffix n: the same
- * source, the fields below pinned before the body runs), which drops the other block types' and presets' code from them. */
+/* The usual case (round 6): a long block of the normal type of a 44.1 / 48 kHz stream under the settings of the CBR / ABR
+ * presets at the default quality -- noise shaping 1 or 2 (the presets up to 128 kb/s scale the scalefactors: 2) with
+ * amplification rule 1, no full outer loop, no sfb21 band, no substep shaping.  The stages that run once or more per granule
+ * and channel exist again with these as constants (suffix n, the search also m for noise shaping 1: the same source, the
+ * fields below pinned before the body runs), which drops the other block types' and presets' code from them. */
 LH_DEVFN int
-lh_cfg_is_usual(const LhCtx & c)
+lh_cfg_class(const LhCtx & c)
 {
     /* (l21: the 44.1 and 48 kHz band tables; at 32 kHz the bands' padded squares -- LhQS.pad, lh_dev_qloop.h -- would not fit
-     * the scratch: those streams take the general stages) */
-    return !LH_IS_LSF && c.ns == 2 && c.ns_amp == 1 && c.full_outer_loop == 0 && c.sfb21_extra == 0 && c.l21 <= 418;
+     * the scratch: those streams take the general stages).  0: none; else the noise shaping of the class */
+    int const ok = !LH_IS_LSF && (c.ns == 1 || c.ns == 2) && c.ns_amp == 1 && c.full_outer_loop == 0 && c.sfb21_extra == 0
+        && c.l21 <= 418;
+    return ok ? c.ns : 0;
 }
 
 LH_DEVFN int
 lh_granule_is_usual(const LhCtx & c, int block_type, int substep)
 {
-    return lh_cfg_is_usual(c) && block_type == LH_NORM_TYPE && (substep & 2) == 0;
+    return (block_type == LH_NORM_TYPE && (substep & 2) == 0) ? lh_cfg_class(c) : 0;
 }
 
+/* nsh: the class's noise shaping (0: a stage that does not look at it) */
 LH_DEVFN void
-lh_pin_usual(LhCtx & c)
+lh_pin_usual(LhCtx & c, int nsh)
 {
-    c.ns = 2;
+    if (nsh)
+        c.ns = nsh;
     c.ns_amp = 1;
     c.full_outer_loop = 0;
     c.sfb21_extra = 0;

@@ -1439,7 +1439,8 @@ lq_outer_loop(const LhCtx & c, LhQS & S, LhChanLds & Q, LhQR & R, LhGrR & gb, co
  * 20 kHz. */
 /* SPEC: the stage compiled for the usual case (lh_granule_is_usual, lh_dev_common.h) -- what that checked is a constant in
  * its code, and what the other cases need (the region split and band ranges of the other block types, the amplification
- * rules of the other presets, substep shaping, the band above the last scalefactor band) is not in it */
+ * rules of the other presets, substep shaping, the band above the last scalefactor band) is not in it; SPEC = the class's
+ * noise shaping (lh_cfg_class) */
 template < int NS, int SPEC = 0 > LH_DEVFN void
 lq_stage_body(int qch, int gr, int targ_bits)
 {
@@ -1447,7 +1448,7 @@ lq_stage_body(int qch, int gr, int targ_bits)
     LhQR    R = lh_uniform(lh_lds.rg[qch].R);
     LhGrR   g = lh_uniform(lh_lds.rg[qch].g);
     if (SPEC) {
-        lh_pin_usual(c);
+        lh_pin_usual(c, SPEC);
         lh_pin_usual(R);
     }
     LhChanLds & Q = lh_lds.u.quant.ch[qch];
@@ -1455,7 +1456,7 @@ lq_stage_body(int qch, int gr, int targ_bits)
 #if defined(LH_NOISE_EARLY) || defined(LH_NO_PAD)
     S.pad = 0;
 #else
-    S.pad = SPEC;
+    S.pad = (SPEC != 0);
 #endif
     R.s_mnc = lh_uni_i((int) Q.sfb_of_line[R.mnc]);
 #if defined(LH_TRACE) && !defined(LH_EMU)
@@ -1607,11 +1608,24 @@ lq_outer_loop_stage4(int qch, int gr, int targ_bits)
 LH_STAGEFN void
 lq_outer_loop_stage4n(int qch, int gr, int targ_bits)
 {
-    lq_stage_body < 4, 1 > (qch, gr, targ_bits);
+    lq_stage_body < 4, 2 > (qch, gr, targ_bits);
 }
 
 LH_STAGEFN void
 lq_outer_loop_stage5n(int qch, int gr, int targ_bits)
+{
+    lq_stage_body < 5, 2 > (qch, gr, targ_bits);
+}
+
+/* (noise shaping 1: the presets above 128 kb/s) */
+LH_STAGEFN void
+lq_outer_loop_stage4m(int qch, int gr, int targ_bits)
+{
+    lq_stage_body < 4, 1 > (qch, gr, targ_bits);
+}
+
+LH_STAGEFN void
+lq_outer_loop_stage5m(int qch, int gr, int targ_bits)
 {
     lq_stage_body < 5, 1 > (qch, gr, targ_bits);
 }

@@ -890,7 +890,7 @@ lh_calc_xmin_n(int qch, int gr, int rch)
 {
     LhCtx   c = lh_ctx_load();
     LhQR    R = lh_uniform(lh_lds.rg[qch].R);
-    lh_pin_usual(c);
+    lh_pin_usual(c, 0);
     lh_pin_usual(R);
     {
         int const slot = (lh_uni_i(lh_lds.psy_slot) + gr) % 3;
@@ -1028,7 +1028,7 @@ lh_init_outer_loop_n(int qch, int gr, int substep)
     LhCtx   c = lh_ctx_load();
     LhQR    R;
     LhGrR   g;
-    lh_pin_usual(c);
+    lh_pin_usual(c, 0);
     lh_init_outer_loop_body(c, lh_lds.u.quant.ch[qch], R, g, lh_lds.xr[qch][gr], LH_NORM_TYPE, lh_uni_i(substep), 0);
     lh_rg_put(c, R, g);
 }
@@ -1242,7 +1242,7 @@ lh_best_scalefac_store_n(int qch, int gr, const int8_t * g0sf, int g0_block_type
     LhCtx   c = lh_ctx_load();
     LhQR    R = lh_uniform(lh_lds.rg[qch].R);
     LhGrR   g = lh_uniform(lh_lds.rg[qch].g);
-    lh_pin_usual(c);
+    lh_pin_usual(c, 0);
     lh_pin_usual(R);
     lh_best_scalefac_store_body(c, lh_lds.u.quant.ch[qch], R, g, lh_uni_i(gr), LH_AS_GLOBAL(const int8_t, g0sf),
                                 lh_uni_i(g0_block_type), lh_lds.scfsi[qch]);
@@ -1705,7 +1705,7 @@ lh_best_huffman_divide_n(int qch)
     LhCtx   c = lh_ctx_load();
     LhQR    R = lh_uniform(lh_lds.rg[qch].R);
     LhGrR   g = lh_uniform(lh_lds.rg[qch].g);
-    lh_pin_usual(c);
+    lh_pin_usual(c, 0);
     lh_pin_usual(R);
     lh_best_huffman_divide_body(c, lh_lds.u.quant.ch[qch], R, g);
     lh_rg_put(c, R, g);

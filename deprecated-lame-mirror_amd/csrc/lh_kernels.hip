@@ -671,17 +671,21 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
                 LH_PT(t_ol);
                 if (abr && !R.ath_over)
                     targ_bits[ch] = analog_silence_bits;    /* reference quantize.c:1953-1954 */
-                /* (four stages of one source: five or four slots x the usual case or any, lh_dev_qloop.h) */
+                /* (six stages of one source: five or four slots x the usual case at noise shaping 2 or 1, or any: lh_dev_qloop.h) */
                 int const usual = lh_uni_i(lh_granule_is_usual(c, R.block_type, R.substep_shaping));
                 if (lq_needs_tail(c, Q, R)) {
-                    if (usual)
+                    if (usual == 2)
                         lq_outer_loop_stage5n(ch, gr, targ_bits[ch]);
+                    else if (usual == 1)
+                        lq_outer_loop_stage5m(ch, gr, targ_bits[ch]);
                     else
                         lq_outer_loop_stage5(ch, gr, targ_bits[ch]);
                 }
                 else {
-                    if (usual)
+                    if (usual == 2)
                         lq_outer_loop_stage4n(ch, gr, targ_bits[ch]);
+                    else if (usual == 1)
+                        lq_outer_loop_stage4m(ch, gr, targ_bits[ch]);
                     else
                         lq_outer_loop_stage4(ch, gr, targ_bits[ch]);
                 }
