@@ -648,6 +648,13 @@ lh_granule_is_usual(const LhCtx & c, int block_type, int substep)
     return (block_type == LH_NORM_TYPE && (substep & 2) == 0) ? lh_cfg_class(c) : 0;
 }
 
+/* the same for a short block (the search stages only; substep shaping and the subblock gains as the presets have them) */
+LH_DEVFN int
+lh_granule_is_usual_short(const LhCtx & c, int block_type, int substep)
+{
+    return (block_type == LH_SHORT_TYPE && (substep & 2) == 0 && c.subblock_gain == 1) ? lh_cfg_class(c) : 0;
+}
+
 /* nsh: the class's noise shaping (0: a stage that does not look at it) */
 LH_DEVFN void
 lh_pin_usual(LhCtx & c, int nsh)
@@ -673,6 +680,21 @@ lh_pin_usual(LhQR & R)
     R.psymax = LH_SBPSY_L;
     R.sfbmax = LH_SBPSY_L;
     R.sfbdivide = 11;
+    if ((R.substep_shaping & 2) != 0)
+        __builtin_unreachable();
+}
+
+/* (... in the short-block case of the same presets) */
+LH_DEVFN void
+lh_pin_usual_short(LhQR & R)
+{
+    R.block_type = LH_SHORT_TYPE;
+    R.sfb_lmax = 0;
+    R.sfb_smin = 0;
+    R.psy_lmax = 0;
+    R.psymax = 3 * LH_SBPSY_S;
+    R.sfbmax = 3 * LH_SBPSY_S;
+    R.sfbdivide = 3 * LH_SBPSY_S - 18;
     if ((R.substep_shaping & 2) != 0)
         __builtin_unreachable();
 }

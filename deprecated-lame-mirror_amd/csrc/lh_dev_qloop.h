@@ -1441,7 +1441,7 @@ lq_outer_loop(const LhCtx & c, LhQS & S, LhChanLds & Q, LhQR & R, LhGrR & gb, co
  * its code, and what the other cases need (the region split and band ranges of the other block types, the amplification
  * rules of the other presets, substep shaping, the band above the last scalefactor band) is not in it; SPEC = the class's
  * noise shaping (lh_cfg_class) */
-template < int NS, int SPEC = 0 > LH_DEVFN void
+template < int NS, int SPEC = 0, int SHORT = 0 > LH_DEVFN void
 lq_stage_body(int qch, int gr, int targ_bits)
 {
     LhCtx   c = lh_ctx_load();
@@ -1449,14 +1449,19 @@ lq_stage_body(int qch, int gr, int targ_bits)
     LhGrR   g = lh_uniform(lh_lds.rg[qch].g);
     if (SPEC) {
         lh_pin_usual(c, SPEC);
-        lh_pin_usual(R);
+        if (SHORT) {
+            c.subblock_gain = 1;
+            lh_pin_usual_short(R);
+        }
+        else
+            lh_pin_usual(R);
     }
     LhChanLds & Q = lh_lds.u.quant.ch[qch];
     LhQS    S;
 #if defined(LH_NOISE_EARLY) || defined(LH_NO_PAD)
     S.pad = 0;
 #else
-    S.pad = (SPEC != 0);
+    S.pad = (SPEC != 0 && !SHORT);
 #endif
     R.s_mnc = lh_uni_i((int) Q.sfb_of_line[R.mnc]);
 #if defined(LH_TRACE) && !defined(LH_EMU)
@@ -1615,6 +1620,31 @@ LH_STAGEFN void
 lq_outer_loop_stage5n(int qch, int gr, int targ_bits)
 {
     lq_stage_body < 5, 2 > (qch, gr, targ_bits);
+}
+
+/* (short blocks of the same classes: s / t) */
+LH_STAGEFN void
+lq_outer_loop_stage4s(int qch, int gr, int targ_bits)
+{
+    lq_stage_body < 4, 2, 1 > (qch, gr, targ_bits);
+}
+
+LH_STAGEFN void
+lq_outer_loop_stage5s(int qch, int gr, int targ_bits)
+{
+    lq_stage_body < 5, 2, 1 > (qch, gr, targ_bits);
+}
+
+LH_STAGEFN void
+lq_outer_loop_stage4t(int qch, int gr, int targ_bits)
+{
+    lq_stage_body < 4, 1, 1 > (qch, gr, targ_bits);
+}
+
+LH_STAGEFN void
+lq_outer_loop_stage5t(int qch, int gr, int targ_bits)
+{
+    lq_stage_body < 5, 1, 1 > (qch, gr, targ_bits);
 }
 
 /* (noise shaping 1: the presets above 128 kb/s) */

@@ -671,13 +671,19 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
                 LH_PT(t_ol);
                 if (abr && !R.ath_over)
                     targ_bits[ch] = analog_silence_bits;    /* reference quantize.c:1953-1954 */
-                /* (six stages of one source: five or four slots x the usual case at noise shaping 2 or 1, or any: lh_dev_qloop.h) */
+                /* (ten stages of one source: five or four slots x {normal long block, short block} of the usual classes at noise shaping
+                 * 2 or 1, or anything: lh_dev_qloop.h) */
                 int const usual = lh_uni_i(lh_granule_is_usual(c, R.block_type, R.substep_shaping));
+                int const ushort = lh_uni_i(lh_granule_is_usual_short(c, R.block_type, R.substep_shaping));
                 if (lq_needs_tail(c, Q, R)) {
                     if (usual == 2)
                         lq_outer_loop_stage5n(ch, gr, targ_bits[ch]);
                     else if (usual == 1)
                         lq_outer_loop_stage5m(ch, gr, targ_bits[ch]);
+                    else if (ushort == 2)
+                        lq_outer_loop_stage5s(ch, gr, targ_bits[ch]);
+                    else if (ushort == 1)
+                        lq_outer_loop_stage5t(ch, gr, targ_bits[ch]);
                     else
                         lq_outer_loop_stage5(ch, gr, targ_bits[ch]);
                 }
@@ -686,6 +692,10 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
                         lq_outer_loop_stage4n(ch, gr, targ_bits[ch]);
                     else if (usual == 1)
                         lq_outer_loop_stage4m(ch, gr, targ_bits[ch]);
+                    else if (ushort == 2)
+                        lq_outer_loop_stage4s(ch, gr, targ_bits[ch]);
+                    else if (ushort == 1)
+                        lq_outer_loop_stage4t(ch, gr, targ_bits[ch]);
                     else
                         lq_outer_loop_stage4(ch, gr, targ_bits[ch]);
                 }
