@@ -749,12 +749,18 @@ lh_vbr_fit(const LhCtx & c, LhChanLds & Q, LhQR & R, LhGrR & g, int steps, int s
  * pass 0: VBR_new_prepare's per-granule part + "searches scalefactors" + "encode as is";
  * pass 1: "alter our encoded data, until it fits" with the budget `target'.
  * gate = max_bits of the granule from on_pe (after the frame-level scaling). */
-LH_STAGEFN void
-lh_vbr_granule(int qch, int gr, int rch, int pass, int gate, int target, int substep, LhGranule * o,
-               const int8_t * g0sf)
+/* USUAL: the first pass over a normal long block of an MPEG-1 stream (block type and pass are constants: the short-block
+ * geometry, reordering and constraint solver and the second pass are not compiled into that variant) */
+template < int USUAL > LH_DEVFN void
+lh_vbr_granule_body(int qch, int gr, int rch, int pass, int gate, int target, int substep, LhGranule * o,
+                    const int8_t * g0sf)
 {
-    LhCtx const c = lh_ctx_load();
+    LhCtx   c = lh_ctx_load();
     LhLds & L = lh_lds;
+    if (USUAL) {
+        c.rate8k = 0;
+        pass = 0;
+    }
     LhChanLds & Q = L.u.quant.ch[qch];
     LhVbrSave & sv = L.vbr[gr][qch];
     float  *xr = L.xr[qch][gr];
@@ -770,7 +776,7 @@ lh_vbr_granule(int qch, int gr, int rch, int pass, int gate, int target, int sub
 
     LH_PT(t_q);
     LH_PT(t_a);
-    lh_init_outer_loop_body(c, Q, R, g, xr, lh_uni_i(L.block_type[gr][qch]), lh_uni_i(substep), pass == 0);
+    lh_init_outer_loop_body(c, Q, R, g, xr, USUAL ? LH_NORM_TYPE : lh_uni_i(L.block_type[gr][qch]), lh_uni_i(substep), pass == 0);
     LH_PA(15, t_a);
     if (pass == 0) {
         {
@@ -874,6 +880,19 @@ lh_vbr_granule(int qch, int gr, int rch, int pass, int gate, int target, int sub
     if (s == 0)
         sv.use_bits = g.part2_3_length + g.part2_length;
     LH_WAVE_SYNC();
+}
+
+LH_STAGEFN void
+lh_vbr_granule(int qch, int gr, int rch, int pass, int gate, int target, int substep, LhGranule * o,
+               const int8_t * g0sf)
+{
+    lh_vbr_granule_body < 0 > (qch, gr, rch, pass, gate, target, substep, o, g0sf);
+}
+
+LH_STAGEFN void
+lh_vbr_granule_n(int qch, int gr, int rch, int gate, int substep, LhGranule * o, const int8_t * g0sf)
+{
+    lh_vbr_granule_body < 1 > (qch, gr, rch, 0, gate, 0, substep, o, g0sf);
 }
 
 
@@ -1059,7 +1078,10 @@ lh_vbr_frame(LhFrameOut * fo_in, int mode_ext, int msoff)
     LH_SYNC_WG();
     for (int gr = 0; gr < ngr; gr++) {
         if (w < nch)
-            lh_vbr_granule(w, gr, msoff + w, 0, max_bits[gr][w], 0, substep, &fo->gr[gr][w], fo->gr[0][w].scalefac);
+            if (!LH_IS_LSF && lh_uni_i(L.block_type[gr][w]) == LH_NORM_TYPE)
+                lh_vbr_granule_n(w, gr, msoff + w, max_bits[gr][w], substep, &fo->gr[gr][w], fo->gr[0][w].scalefac);
+            else
+                lh_vbr_granule(w, gr, msoff + w, 0, max_bits[gr][w], 0, substep, &fo->gr[gr][w], fo->gr[0][w].scalefac);
         else {
             /* mono: no second channel, its payload slot is all zero */
             uint32_t *z = (uint32_t *) &fo->gr[gr][w];
