@@ -304,18 +304,17 @@ lq_quantize(const LhCtx & c, LhQS & S, const LhQR & R, const LhGrR & g)
      * (LhTables.qthr; both in tests/test_quantizer_identity.py) ---- */
     {
         uint32_t nq[5];
-        uint32_t bmax = 0;
 #pragma unroll
         for (int k = 0; k < NS; k++) {
             float const a0 = qa[2 * k], a1 = qa[2 * k + 1];
             uint32_t const b0 = qb[2 * k], b1 = qb[2 * k + 1];
             float const t0 = qt_[2 * k], t1 = qt_[2 * k + 1];
             uint32_t const r0 = b0 - (a0 < t0 ? 1u : 0u), r1 = b1 - (a1 < t1 ? 1u : 0u);
-            bmax = b0 > bmax ? b0 : bmax;
-            bmax = b1 > bmax ? b1 : bmax;
             nq[k] = ((r0 & 0xffffu) | (r1 << 16)) & S.vm[k];
         }
-        if (LH_RARE(lh_ballot(bmax > (uint32_t) LH_MAGIC_INT + 255u))) {
+        /* (the lane's largest xrpow bounds its products -- a float product is monotone in either factor -- and a product of
+         * at most 255 rounds to at most 255: one multiplication and one comparison instead of a maximum over the eight) */
+        if (LH_RARE(lh_ballot(istep * S.lmax > 255.0f))) {
             /* rare: a quantised value >= 256, its rounding offset lives in HBM */
 #pragma unroll
             for (int k = 0; k < NS; k++) {
