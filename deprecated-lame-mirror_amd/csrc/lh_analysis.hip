@@ -50,6 +50,11 @@ __shared__ unsigned long long *lh_ap_base;
 #define LH_STAGE_IDX(i) LH_FZ(i)
 #include "lh_static_tables.h"
 #include "lh_dev_common.h"
+#if !defined(LH_EMU)
+#define LH_KRESTRICT __restrict__
+#else
+#define LH_KRESTRICT
+#endif
 
 /* The 1024 samples a granule's transforms read (from bufp = frame window + 576 gr + 304 on, reference psymodel.c:1420) are
  * staged as scaled floats in the work area, channel ch at work[1024 ch ..], and transformed in place; sample i of that span */
@@ -121,7 +126,7 @@ extern "C" __global__ void __launch_bounds__(64)
 #else
 void
 #endif
-lh_attack_kernel(const LhConfig * cfg, const int16_t * pcm, const float *pcmf, const LhStreamDesc * descs, LhMidFrame * frames,
+lh_attack_kernel(const LhConfig * LH_KRESTRICT cfg, const int16_t * LH_KRESTRICT pcm, const float *pcmf, const LhStreamDesc * descs, LhMidFrame * frames,
                  int nstreams)
 {
     /* [2][LH_FIR_SPAN] samples, then (in place) [2][576] filtered ones: 5 KB of its own, not the analysis kernel's image --
@@ -218,7 +223,7 @@ extern "C" __global__ void __launch_bounds__(64)
 #else
 void
 #endif
-lh_attack_scan_kernel(const LhConfig * cfg, const LhTables * T, const LhStreamDesc * descs, const LhStreamState * states,
+lh_attack_scan_kernel(const LhConfig * LH_KRESTRICT cfg, const LhTables * LH_KRESTRICT T, const LhStreamDesc * descs, const LhStreamState * states,
                       LhMidFrame * frames, int nstreams)
 {
     int const sidx = (int) blockIdx.x;
@@ -651,7 +656,7 @@ extern "C" __global__ void __launch_bounds__(LH_NT, 6)
 #else
 void
 #endif
-lh_analysis_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, const float *pcmf, const LhStreamDesc * descs,
+lh_analysis_kernel(const LhConfig * LH_KRESTRICT cfg, const LhTables * LH_KRESTRICT T, const int16_t * LH_KRESTRICT pcm, const float *pcmf, const LhStreamDesc * descs,
                    LhMidFrame * frames, int nstreams, LhStreamState * states)
 {
 #if defined(LH_APROF) && !defined(LH_EMU)

@@ -843,6 +843,13 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
 #ifndef LH_WAVES_PER_EU
 #define LH_WAVES_PER_EU 2
 #endif
+/* (the settings and the tables are never written by a kernel: with noalias the loads of their fields move out of the frame loop
+ * and across the payload stores: +1 %) */
+#if !defined(LH_EMU) && !defined(LH_NO_RESTRICT)
+#define LH_RESTRICT __restrict__
+#else
+#define LH_RESTRICT
+#endif
 /* the LH_LSF build of this file (MPEG-2 / 2.5 streams) is a second object in the same library: its own names */
 #if defined(LH_LSF) && !defined(LH_SPLIT)
 #define lh_encode_kernel lh_encode_kernel_lsf
@@ -878,7 +885,7 @@ lh_encode_frame(LhCtx & c, LhFrameOut * fo, LhWaveCarry & carry)
 #endif
 /* all frames of one stream (the workgroup's whole job) */
 LH_DEVFN void
-lh_encode_stream(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, const float *pcmf,
+lh_encode_stream(const LhConfig * LH_RESTRICT cfg, const LhTables * LH_RESTRICT T, const int16_t * pcm, const float *pcmf,
                  const LhStreamDesc * descs, LhStreamState * states, LhFrameOut * out, uint8_t * bytes,
                  int nstreams LH_MID_PARAM)
 {
@@ -1011,7 +1018,7 @@ extern "C" __global__ void __launch_bounds__(LH_BLOCK, LH_WAVES_PER_EU)
 #else
 void
 #endif
-lh_encode_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, const float *pcmf,
+lh_encode_kernel(const LhConfig * LH_RESTRICT cfg, const LhTables * LH_RESTRICT T, const int16_t * pcm, const float *pcmf,
                  const LhStreamDesc * descs, LhStreamState * states, LhFrameOut * out, uint8_t * bytes,
                  int nstreams LH_MID_PARAM)
 {

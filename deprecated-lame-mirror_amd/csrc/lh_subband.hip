@@ -32,6 +32,11 @@
 #define LH_MF_PADDED ((LH_MF_NEEDED + 63) / 64 * 64)
 #include "lh_static_tables.h"
 #include "lh_dev_common.h"
+#if !defined(LH_EMU)
+#define LH_KRESTRICT __restrict__
+#else
+#define LH_KRESTRICT
+#endif
 
 #include "lh_dev_mdct.h"
 
@@ -58,7 +63,7 @@ extern "C" __global__ void __launch_bounds__(LH_NT, 2)
 #else
 void
 #endif
-lh_subband_kernel(const LhConfig * cfg, const LhTables * T, const int16_t * pcm, const float *pcmf, const LhStreamDesc * descs,
+lh_subband_kernel(const LhConfig * LH_KRESTRICT cfg, const LhTables * LH_KRESTRICT T, const int16_t * LH_KRESTRICT pcm, const float *pcmf, const LhStreamDesc * descs,
                   LhStreamState * states, LhMidFrame * frames, int nstreams)
 {
     LhLds & L = lh_lds;
