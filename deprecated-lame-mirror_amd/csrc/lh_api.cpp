@@ -1633,11 +1633,17 @@ batch_mid_reserve(lamehip_batch * b, long long total)
         (void) hipFree(b->mid.frames);
     b->mid.frames = nullptr;
     b->mid_cap = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (double) want * (double) sizeof(LhMidFrame) > 0.8 * (double) free_b)
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (double) want * (double) sizeof(LhMidFrame) > 0.8 * (double) free_b) {
+        /* (not an error: the launch takes the fused kernel; lamehip_last_error() says why it was slower) */
+        snprintf(g_err, sizeof(g_err), "split pipeline not used: %lld frames need %.1f GB of analysis records, %.1f GB free",
+                 total, (double) want * (double) sizeof(LhMidFrame) / 1e9, (double) free_b / 1e9);
         return -1;
+    }
     if (hipMalloc((void **) &b->mid.frames, (size_t) want * sizeof(LhMidFrame)) != hipSuccess) {
         (void) hipGetLastError();
         b->mid.frames = nullptr;
+        snprintf(g_err, sizeof(g_err), "split pipeline not used: hipMalloc of %.1f GB of analysis records failed",
+                 (double) want * (double) sizeof(LhMidFrame) / 1e9);
         return -1;
     }
     b->mid_cap = want;

@@ -1486,12 +1486,30 @@ lq_stage_body(int qch, int gr, int targ_bits)
  * which is set aside: image, scalefactors, xrpow).  `cont': the granule comes with the scalefactors
  * of an earlier pass over the frame (R / g in the channel's slot, Q.sf[0]); xrpow, the allowed noise and the
  * geometry are fresh in Q as for any search. */
-template < int NS > LH_DEVFN void
+/* SPEC (1: without, 2: with the sfb21 band): the same for the usual case of this loop -- a normal long block of an MPEG-1 stream
+ * under the vbr_rh presets (noise shaping 1, amplification rule 1, no full outer loop, no substep shaping): lh_vbrold_class() */
+template < int NS, int SPEC = 0 > LH_DEVFN void
 lq_vbrold_body(int qch, int gr, int min_bits, int max_bits, int cont)
 {
-    LhCtx const c = lh_ctx_load();
+    LhCtx   c = lh_ctx_load();
     LhQR    R = lh_uniform(lh_lds.rg[qch].R);
     LhGrR   g = lh_uniform(lh_lds.rg[qch].g);
+    if (SPEC) {
+        c.ns = 1;
+        c.ns_amp = 1;
+        c.full_outer_loop = 0;
+        c.sfb21_extra = (SPEC == 2);
+        c.rate8k = 0;
+        R.block_type = LH_NORM_TYPE;
+        R.sfb_lmax = LH_SBPSY_L;
+        R.sfb_smin = LH_SBPSY_S;
+        R.psy_lmax = (SPEC == 2) ? LH_SBMAX_L : LH_SBPSY_L;
+        R.psymax = R.psy_lmax;
+        R.sfbmax = LH_SBPSY_L;
+        R.sfbdivide = 11;
+        if ((R.substep_shaping & 2) != 0)
+            __builtin_unreachable();
+    }
     LhChanLds & Q = lh_lds.u.quant.ch[qch];
     const float *xr = lh_lds.xr[qch][lh_uni_i(gr)];
     LhQS    S;
@@ -1589,6 +1607,39 @@ LH_STAGEFN void
 lq_vbrold_stage4(int qch, int gr, int min_bits, int max_bits, int cont)
 {
     lq_vbrold_body < 4 > (qch, gr, min_bits, max_bits, cont);
+}
+
+/* 0: none; 1 / 2: the usual case without / with the sfb21 band */
+LH_DEVFN int
+lh_vbrold_class(const LhCtx & c, int block_type, int substep)
+{
+    int const ok = !LH_IS_LSF && block_type == LH_NORM_TYPE && c.ns == 1 && c.ns_amp == 1 && c.full_outer_loop == 0
+        && (substep & 2) == 0;
+    return ok ? 1 + (c.sfb21_extra != 0) : 0;
+}
+
+LH_STAGEFN void
+lq_vbrold_stage5n(int qch, int gr, int min_bits, int max_bits, int cont)
+{
+    lq_vbrold_body < 5, 2 > (qch, gr, min_bits, max_bits, cont);
+}
+
+LH_STAGEFN void
+lq_vbrold_stage4n(int qch, int gr, int min_bits, int max_bits, int cont)
+{
+    lq_vbrold_body < 4, 2 > (qch, gr, min_bits, max_bits, cont);
+}
+
+LH_STAGEFN void
+lq_vbrold_stage5m(int qch, int gr, int min_bits, int max_bits, int cont)
+{
+    lq_vbrold_body < 5, 1 > (qch, gr, min_bits, max_bits, cont);
+}
+
+LH_STAGEFN void
+lq_vbrold_stage4m(int qch, int gr, int min_bits, int max_bits, int cont)
+{
+    lq_vbrold_body < 4, 1 > (qch, gr, min_bits, max_bits, cont);
 }
 #endif
 

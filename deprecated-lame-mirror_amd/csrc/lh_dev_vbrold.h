@@ -132,10 +132,23 @@ lh_vbrold_granule(int qch, int gr, int rch, int pass, int min_bits, int max_bits
     if (live) {
         lh_zero_tail(c, Q, R);
         lh_rg_put(c, R, g);
-        if (lq_needs_tail(c, Q, R))
-            lq_vbrold_stage5(qch, gr, min_bits, max_bits, pass != 0);
-        else
-            lq_vbrold_stage4(qch, gr, min_bits, max_bits, pass != 0);
+        int const cls = lh_uni_i(lh_vbrold_class(c, R.block_type, R.substep_shaping));
+        if (lq_needs_tail(c, Q, R)) {
+            if (cls == 2)
+                lq_vbrold_stage5n(qch, gr, min_bits, max_bits, pass != 0);
+            else if (cls == 1)
+                lq_vbrold_stage5m(qch, gr, min_bits, max_bits, pass != 0);
+            else
+                lq_vbrold_stage5(qch, gr, min_bits, max_bits, pass != 0);
+        }
+        else {
+            if (cls == 2)
+                lq_vbrold_stage4n(qch, gr, min_bits, max_bits, pass != 0);
+            else if (cls == 1)
+                lq_vbrold_stage4m(qch, gr, min_bits, max_bits, pass != 0);
+            else
+                lq_vbrold_stage4(qch, gr, min_bits, max_bits, pass != 0);
+        }
         R = lh_uniform(L.rg[qch].R);
         g = lh_uniform(L.rg[qch].g);
     }
