@@ -709,17 +709,30 @@ lh_scale_bitcount(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g, int
 }
 
 /* reference quantize_pvt.c:554-573 */
+/* logt_lds (wave-uniform): calc_noise's copy of the logarithm's table is in LDS (every loop but the new VBR one, whose step
+ * tables lie there): the two look-ups are LDS round trips instead of trips to the vector cache */
 LH_DEVFN float
-lh_ath_adjust(const LhTables * T, float a, float x, float athFloor, float ATHfixpoint)
+lh_ath_adjust(const LhTables * T, float a, float x, float athFloor, float ATHfixpoint, int logt_lds = 0)
 {
     float const o = 90.30873362f;
     float const p = (ATHfixpoint < 1.f) ? 94.82444863f : ATHfixpoint;
-    float   u = (float) (lh_fast_log2(T->log_table, x) * (LH_LOG2_OVER_LOG10 * (10.0f)));
     float const v = a * a;
+    float   lx, lv = 0.0f;
+    if (logt_lds) {
+        LH_FAST_LOG2_VIA(LH_LOGT_LDS, x, lx);
+        if (v > 1E-20f)
+            LH_FAST_LOG2_VIA(LH_LOGT_LDS, v, lv);
+    }
+    else {
+        lx = lh_fast_log2(T->log_table, x);
+        if (v > 1E-20f)
+            lv = lh_fast_log2(T->log_table, v);
+    }
+    float   u = (float) (lx * (LH_LOG2_OVER_LOG10 * (10.0f)));
     float   w = 0.0f;
     u -= athFloor;
     if (v > 1E-20f)
-        w = (float) (1.f + lh_fast_log2(T->log_table, v) * (LH_LOG2_OVER_LOG10 * (10.0f / o)));
+        w = (float) (1.f + lv * (LH_LOG2_OVER_LOG10 * (10.0f / o)));
     if (w < 0)
         w = 0.f;
     u *= w;
@@ -736,6 +749,7 @@ lh_calc_xmin_body(const LhCtx & c, LhChanLds & Q, LhQR & R, const float *xr, con
     const LhQTabs *qt = LH_QT;
     int const s = c.lane;
     float const adj = lh_lds.ss.ath_adjust_factor;
+    int const logt_lds = lh_uni_i(!(cfg->vbr == 1 || cfg->vbr == 4));
     int     over = 0;
     if (s < R.psymax) {
         int const is_long = (s < R.psy_lmax);
@@ -745,13 +759,13 @@ lh_calc_xmin_body(const LhCtx & c, LhChanLds & Q, LhQR & R, const float *xr, con
         int const width = Q.width[s];
         int     j = Q.start[s];
         if (is_long) {
-            ath = lh_ath_adjust(T, adj, T->ath_l[sfb], T->ath_floor, cfg->ATHfixpoint);
+            ath = lh_ath_adjust(T, adj, T->ath_l[sfb], T->ath_floor, cfg->ATHfixpoint, logt_lds);
             fact = T->longfact[sfb];
             e = ren[sfb];
             t = rthm[sfb];
         }
         else {
-            ath = lh_ath_adjust(T, adj, T->ath_s[sfb], T->ath_floor, cfg->ATHfixpoint);
+            ath = lh_ath_adjust(T, adj, T->ath_s[sfb], T->ath_floor, cfg->ATHfixpoint, logt_lds);
             fact = T->shortfact[sfb];
             e = ren[22 + sfb * 3 + b];
             t = rthm[22 + sfb * 3 + b];
