@@ -83,7 +83,7 @@ lh_granule_at(const LhStreamDesc & d, int g)
     int const fr = g / LH_NGR;
     o.live = g < LH_NGR * nf;
     o.gr = g - fr * LH_NGR;
-    o.at = d.out_index + fr;
+    o.at = d.out_index + d.mid_rel + fr;
     o.frame_base = (long long) (576 * LH_NGR) * (d.frame_begin + fr) - LH_MF_START;
     return o;
 }
@@ -97,6 +97,7 @@ lh_desc_uniform(const LhStreamDesc * descs, int sidx)
     d.pcm_base = lh_uni_ll(d.pcm_base);
     d.nsamples = lh_uni_ll(d.nsamples);
     d.out_index = lh_uni_ll(d.out_index);
+    d.mid_rel = lh_uni_i(d.mid_rel);
     d.frame_begin = lh_uni_i(d.frame_begin);
     d.frame_end = lh_uni_i(d.frame_end);
     return d;
@@ -251,7 +252,7 @@ lh_attack_scan_kernel(const LhConfig * LH_KRESTRICT cfg, const LhTables * LH_KRE
 #pragma unroll
     for (int j = 0; j < LH_SCAN_BLOCK; j++) {
         int const g = (j < ng) ? j : 0;
-        pk_blk[j] = frames[d.out_index + g / LH_NGR].small.gr[g % LH_NGR].peak[chn][i < 9 ? i : 0];
+        pk_blk[j] = frames[d.out_index + d.mid_rel + g / LH_NGR].small.gr[g % LH_NGR].peak[chn][i < 9 ? i : 0];
     }
     for (int g0 = 0; g0 < ng; g0 += LH_SCAN_BLOCK) {
         float   pk_cur[LH_SCAN_BLOCK], ssf_blk[LH_SCAN_BLOCK];
@@ -260,7 +261,7 @@ lh_attack_scan_kernel(const LhConfig * LH_KRESTRICT cfg, const LhTables * LH_KRE
         for (int j = 0; j < LH_SCAN_BLOCK; j++) {
             int const gn = g0 + LH_SCAN_BLOCK + j, g = (gn < ng) ? gn : 0;
             pk_cur[j] = pk_blk[j];
-            pk_blk[j] = frames[d.out_index + g / LH_NGR].small.gr[g % LH_NGR].peak[chn][i < 9 ? i : 0];
+            pk_blk[j] = frames[d.out_index + d.mid_rel + g / LH_NGR].small.gr[g % LH_NGR].peak[chn][i < 9 ? i : 0];
         }
 #pragma unroll
         for (int j = 0; j < LH_SCAN_BLOCK; j++) {
@@ -309,7 +310,7 @@ lh_attack_scan_kernel(const LhConfig * LH_KRESTRICT cfg, const LhTables * LH_KRE
             if (g >= ng)
                 break;
             int const fr = g / LH_NGR, gr = g - fr * LH_NGR;
-            LhMidGr *mg = &frames[d.out_index + fr].small.gr[gr];
+            LhMidGr *mg = &frames[d.out_index + d.mid_rel + fr].small.gr[gr];
             int    *nsa = nsa_blk[j];
             float const ssf = ssf_blk[j];
             int     uselong = 1;

@@ -1023,7 +1023,7 @@ handle_encode_frames(lame_t g, int upto, unsigned char *mp3buf, int mp3buf_size,
     d.frame_begin = f0;
     d.frame_end = upto;
     d.bytes_base = d.bytes_cap = 0;
-    d.flush = d.pad = 0;
+    d.flush = d.mid_rel = 0;
     HIPCHK(hipMemcpyAsync(g->d_desc, &d, sizeof(d), hipMemcpyHostToDevice, g->stream));
     {
         int     rc = g->dc.launch((const int16_t *) 0, g->d_pcm, g->d_desc, g->d_state, g->d_out, (uint8_t *) 0, 1,
@@ -1615,34 +1615,64 @@ struct lamehip_batch {
                                  * while its kernel runs) */
     float   part_ms[3];         /* analysis, sub-band, encode kernel of the last launch (0: fused launch) */
     int     last_split;
+    /* a launch in windows of frames (batch_plan): the windows' descriptors (host, then HBM: [window][stream]) and three events
+     * per window (its start, behind its analysis kernels, behind its sub-band kernel) */
+    std::vector < LhStreamDesc > h_wdesc;
+    LhStreamDesc *d_wdesc;
+    long long wdesc_cap;
+    std::vector < hipEvent_t > ev_win;
+    int     last_windows;       /* sub-launches of the last launch (1: the whole launch at once) */
 };
 
-/* room for `total' frames in the split pipeline's pools; a failed allocation (or a launch too long for the device's
- * memory) leaves the batch on the fused kernel for this launch */
+/* what batch_plan decides about a launch (outside the devices' launch order: it may allocate) and batch_launch carries out */
+struct LhLaunchPlan {
+    long long total;            /* frames of the launch */
+    int     max_frames;         /* of its longest stream */
+    int     split;              /* the split pipeline (else the fused kernel) */
+    int     window;             /* frames per stream and sub-launch; 0: the whole launch at once */
+    int     nwin;
+};
+
+/* room for `need' records in the split pipeline's pool (0), or not (-1: the pool is gone, *free_records says how many would
+ * fit and lamehip_last_error() why) */
 static int
-batch_mid_reserve(lamehip_batch * b, long long total)
+batch_mid_reserve(lamehip_batch * b, long long need, long long *free_records = nullptr)
 {
     /* (the encode kernel touches the record BEHIND the one it works on, the launch's last frame included: one spare
      * record has to exist whatever the launch's total is -- a later launch whose total equals the capacity must not
      * read past the pool) */
-    if (total + 1 <= b->mid_cap)
+    if (free_records)
+        *free_records = 0;
+    if (need + 1 <= b->mid_cap)
         return 0;
     size_t  free_b = 0, total_b = 0;
-    long long const want = total + 64;
+    long long const want = need + 64;
     if (b->mid.frames)
         (void) hipFree(b->mid.frames);
     b->mid.frames = nullptr;
     b->mid_cap = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (double) want * (double) sizeof(LhMidFrame) > 0.8 * (double) free_b) {
-        /* (not an error: the launch takes the fused kernel; lamehip_last_error() says why it was slower) */
-        snprintf(g_err, sizeof(g_err), "split pipeline not used: %lld frames need %.1f GB of analysis records, %.1f GB free",
-                 total, (double) want * (double) sizeof(LhMidFrame) / 1e9, (double) free_b / 1e9);
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess)
+        free_b = 0;
+    {
+        /* LAMEHIP_MID_BUDGET_MB=n: no more than n MB count as free (test aid: the window size as a device with little
+         * memory left would choose it) */
+        const char *e = getenv("LAMEHIP_MID_BUDGET_MB");
+        long const mb = e ? strtol(e, nullptr, 10) : 0;
+        if (mb > 0 && (size_t) mb * 1000000u < free_b)
+            free_b = (size_t) mb * 1000000u;
+    }
+    if (free_records)
+        *free_records = (long long) (0.8 * (double) free_b / (double) sizeof(LhMidFrame)) - 64;
+    if ((double) want * (double) sizeof(LhMidFrame) > 0.8 * (double) free_b) {
+        /* (not an error: the launch runs in windows or takes the fused kernel; lamehip_last_error() says why) */
+        snprintf(g_err, sizeof(g_err), "split pipeline: %lld frames need %.1f GB of analysis records, %.1f GB free",
+                 need, (double) want * (double) sizeof(LhMidFrame) / 1e9, (double) free_b / 1e9);
         return -1;
     }
     if (hipMalloc((void **) &b->mid.frames, (size_t) want * sizeof(LhMidFrame)) != hipSuccess) {
         (void) hipGetLastError();
         b->mid.frames = nullptr;
-        snprintf(g_err, sizeof(g_err), "split pipeline not used: hipMalloc of %.1f GB of analysis records failed",
+        snprintf(g_err, sizeof(g_err), "split pipeline: hipMalloc of %.1f GB of analysis records failed",
                  (double) want * (double) sizeof(LhMidFrame) / 1e9);
         return -1;
     }
@@ -1650,32 +1680,140 @@ batch_mid_reserve(lamehip_batch * b, long long total)
     return 0;
 }
 
-/* one launch of the batch's frames [frame_begin, frame_end) per stream, as `descs' (device copy) / `h_descs' say, between
- * ev0 and ev1 on the batch's stream: the split pipeline when the batch uses it and its pools can be had, else the fused kernel */
+/* LAMEHIP_MID_WINDOW=n, looked at before every launch: the split pipeline works through a launch in windows of n frames per
+ * stream whatever the memory would allow (tuning / test aid; 0 or unset: windows only when the records of the whole launch
+ * do not fit) */
 static int
-batch_launch(lamehip_batch * b, const int16_t * pcm, const float *pcmf, const LhStreamDesc * descs, const LhStreamDesc * h_descs,
-             uint8_t * bytes)
+batch_window_env(void)
 {
-    long long total = 0;
-    int     max_frames = 0, rc;
+    const char *e = getenv("LAMEHIP_MID_WINDOW");
+    long const v = e ? strtol(e, nullptr, 10) : 0;
+    return (v > 0 && v < (1l << 30)) ? (int) v : 0;
+}
+
+#define LH_MID_WINDOW_MIN 64    /* frames: below that the fused kernel is the better launch (a sub-launch ends with its slowest stream) */
+
+/* records a launch in windows of w frames needs at once (every stream's first window is its largest) */
+static long long
+batch_window_records(const lamehip_batch * b, const LhStreamDesc * h_descs, int w)
+{
+    long long n = 0;
+    for (int s = 0; s < b->B; s++) {
+        int const nf = h_descs[s].frame_end - h_descs[s].frame_begin;
+        if (nf > 0)
+            n += nf < w ? nf : w;
+    }
+    return n;
+}
+
+/* What the launch of the frames `h_descs' names will be: the split pipeline over the whole launch when its analysis records
+ * fit the device (34 KB per frame: 81 GB at 1024 x 60 s), else the split pipeline over windows of as many frames per stream as
+ * do fit -- each window a launch of its own, analysis kernels then encode kernel, the streams' state carried in
+ * LhStreamState as between two launches of an incremental batch --, else (under LH_MID_WINDOW_MIN frames per window, more
+ * than 65 535 streams, LAMEHIP_FUSED / LAMEHIP_SPLIT_DENY) the fused kernel.  The windows' descriptors go to HBM here, on the
+ * batch's stream.  Allocates: call it before the devices' launch order is taken. */
+static int
+batch_plan(lamehip_batch * b, const LhStreamDesc * h_descs, LhLaunchPlan * p)
+{
+    long long free_records = 0;
+    int     nactive = 0;
+    memset(p, 0, sizeof(*p));
     for (int s = 0; s < b->B; s++) {
         int const nf = h_descs[s].frame_end - h_descs[s].frame_begin;
         if (nf > 0) {
-            total += nf;
-            if (nf > max_frames)
-                max_frames = nf;
+            p->total += nf;
+            nactive++;
+            if (nf > p->max_frames)
+                p->max_frames = nf;
         }
     }
+    p->nwin = 1;
     /* (the analysis and sub-band kernels index the stream by blockIdx.y, which ends at 65535: a larger batch keeps the
      * fused kernel, whose grid is one-dimensional) */
-    int     split = b->split && total > 0 && b->B <= 65535 && !batch_split_denied() && batch_mid_reserve(b, total) == 0;
-    if (split && !b->ev_part[0]) {
+    if (!(b->split && p->total > 0 && b->B <= 65535 && !batch_split_denied()))
+        return 0;
+    int     w = batch_window_env();
+    if (w >= p->max_frames)
+        w = 0;
+    if (w == 0) {
+        if (batch_mid_reserve(b, p->total, &free_records) == 0) {
+            p->split = 1;
+            return 0;
+        }
+        w = nactive ? (int) (free_records / nactive < p->max_frames ? free_records / nactive : p->max_frames) : 0;
+        if (w < LH_MID_WINDOW_MIN) {
+            size_t const n = strlen(g_err);
+            snprintf(g_err + n, sizeof(g_err) - n, ": fused kernel");
+            return 0;
+        }
+    }
+    if (batch_mid_reserve(b, batch_window_records(b, h_descs, w)) != 0)
+        return 0;
+    p->split = 1;
+    p->window = w;
+    p->nwin = (p->max_frames + w - 1) / w;
+    /* window k of a stream: its frames [begin + k w, begin + (k + 1) w) at the payload's places, their records from the
+     * start of the pool on, stream after stream; the flush goes with the stream's last frame (a stream without frames
+     * keeps its descriptor in window 0: what an incremental batch's launch may hold) */
+    b->h_wdesc.resize((size_t) p->nwin * (size_t) b->B);
+    for (int k = 0; k < p->nwin; k++) {
+        long long at = 0;
+        for (int s = 0; s < b->B; s++) {
+            LhStreamDesc d = h_descs[s];
+            int const nf = d.frame_end > d.frame_begin ? d.frame_end - d.frame_begin : 0;
+            long long const lo = (long long) k * w < nf ? (long long) k * w : nf, hi = lo + w < nf ? lo + w : nf;
+            if (nf > 0) {
+                d.out_index = h_descs[s].out_index + lo;
+                d.frame_begin = h_descs[s].frame_begin + (int) lo;
+                d.frame_end = h_descs[s].frame_begin + (int) hi;
+                d.flush = h_descs[s].flush && hi == nf && lo < hi;
+                d.mid_rel = (int) (at - d.out_index);
+                at += hi - lo;
+            }
+            else if (k > 0)
+                d.flush = 0;
+            b->h_wdesc[(size_t) k * (size_t) b->B + (size_t) s] = d;
+        }
+    }
+    if ((long long) b->h_wdesc.size() > b->wdesc_cap) {
+        LhStreamDesc *bigger = nullptr;
+        HIPCHK(hipMalloc((void **) &bigger, b->h_wdesc.size() * sizeof(LhStreamDesc)));
+        if (b->d_wdesc)
+            (void) hipFree(b->d_wdesc);
+        b->d_wdesc = bigger;
+        b->wdesc_cap = (long long) b->h_wdesc.size();
+    }
+    HIPCHK(hipMemcpyAsync(b->d_wdesc, b->h_wdesc.data(), b->h_wdesc.size() * sizeof(LhStreamDesc), hipMemcpyHostToDevice, b->stream));
+    while (b->ev_win.size() < 3 * (size_t) p->nwin) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess)
+            return set_err("hipEventCreate", hipGetLastError());
+        b->ev_win.push_back(e);
+    }
+    return 0;
+}
+
+/* one launch of the batch's frames [frame_begin, frame_end) per stream, as `descs' (device copy) / `h_descs' say, between
+ * ev0 and ev1 on the batch's stream, the way batch_plan decided */
+static int
+batch_launch(lamehip_batch * b, const int16_t * pcm, const float *pcmf, const LhStreamDesc * descs, const LhLaunchPlan & p, uint8_t * bytes)
+{
+    int     rc = 0, split = p.split;
+    if (split && !p.window && !b->ev_part[0]) {
         if (hipEventCreate(&b->ev_part[0]) != hipSuccess || hipEventCreate(&b->ev_part[1]) != hipSuccess)
-            split = 0;
+            return set_err("hipEventCreate", hipGetLastError());
     }
     HIPCHK(hipEventRecord(b->ev0, b->stream));
-    if (split)
-        rc = b->dc.launch_split(pcm, pcmf, descs, b->d_state, b->d_out, bytes, b->B, max_frames, b->mid, (void *) b->stream, b->ev_part);
+    if (split && p.window) {
+        for (int k = 0; k < p.nwin && !rc; k++) {
+            int const left = p.max_frames - k * p.window;
+            HIPCHK(hipEventRecord(b->ev_win[3 * (size_t) k], b->stream));
+            rc = b->dc.launch_split(pcm, pcmf, b->d_wdesc + (size_t) k * (size_t) b->B, b->d_state, b->d_out, bytes, b->B,
+                                    left < p.window ? left : p.window, b->mid, (void *) b->stream, &b->ev_win[3 * (size_t) k + 1]);
+        }
+    }
+    else if (split)
+        rc = b->dc.launch_split(pcm, pcmf, descs, b->d_state, b->d_out, bytes, b->B, p.max_frames, b->mid, (void *) b->stream, b->ev_part);
     else
         rc = b->dc.launch(pcm, pcmf, descs, b->d_state, b->d_out, bytes, b->B, (void *) b->stream);
     if (rc)
@@ -1688,6 +1826,7 @@ batch_launch(lamehip_batch * b, const int16_t * pcm, const float *pcmf, const Lh
     if (b->ev_wait)
         HIPCHK(hipEventRecord(b->ev_wait, b->stream));
     b->last_split = split;
+    b->last_windows = (split && p.window) ? p.nwin : 1;
     return 0;
 }
 
@@ -1806,6 +1945,9 @@ lamehip_batch_create_on(int device, const lame_t proto, int nstreams, long capac
     b->mid_cap = 0;
     b->split = batch_use_split();
     b->ev_part[0] = b->ev_part[1] = nullptr;
+    b->d_wdesc = nullptr;
+    b->wdesc_cap = 0;
+    b->last_windows = 1;
     b->ev_wait = nullptr;
     b->part_ms[0] = b->part_ms[1] = b->part_ms[2] = 0;
     b->last_split = 0;
@@ -1864,6 +2006,10 @@ lamehip_batch_destroy(lamehip_batch * b)
         (void) hipEventDestroy(b->ev_part[0]);
     if (b->ev_part[1])
         (void) hipEventDestroy(b->ev_part[1]);
+    for (hipEvent_t e : b->ev_win)
+        (void) hipEventDestroy(e);
+    if (b->d_wdesc)
+        (void) hipFree(b->d_wdesc);
     free(b->rs);
     if (b->h_stage)
         (void) hipHostFree(b->h_stage);
@@ -2352,8 +2498,12 @@ batch_encode_range(lamehip_batch * b, const std::vector < int >&upto, int end)
         HIPCHK(hipStreamSynchronize(b->stream));
         return 0;
     }
-    if ((rc = batch_launch(b, b->d_pcm, (const float *) 0, (const LhStreamDesc *) b->d_stage, descs, (uint8_t *) 0)) != 0)
-        return rc;
+    {
+        LhLaunchPlan plan;
+        if ((rc = batch_plan(b, descs, &plan)) != 0
+            || (rc = batch_launch(b, b->d_pcm, (const float *) 0, (const LhStreamDesc *) b->d_stage, plan, (uint8_t *) 0)) != 0)
+            return rc;
+    }
     b->launched = 1;
     b->h_new.resize((size_t) total);
     HIPCHK(hipMemcpyAsync(b->h_new.data(), b->d_out, (size_t) total * sizeof(LhFrameOut), hipMemcpyDeviceToHost, b->stream));
@@ -2528,7 +2678,7 @@ lamehip_batch_encode(lamehip_batch * b)
         d.frame_begin = 0;
         d.frame_end = b->nframes[(size_t) s];
         d.flush = 1;
-        d.pad = 0;
+        d.mid_rel = 0;
         d.bytes_base = bytes_total;
         /* room for every frame at the largest frame size the settings allow (+1 for CBR padding) */
         d.bytes_cap = b->dev_pack ? (long long) b->nframes[(size_t) s] * max_frame_bytes : 0;
@@ -2565,6 +2715,14 @@ lamehip_batch_encode(lamehip_batch * b)
     }
     HIPCHK(hipMemcpyAsync(b->d_desc, b->h_desc.data(), (size_t) b->B * sizeof(LhStreamDesc),
                           hipMemcpyHostToDevice, b->stream));
+    /* (what the launch will be -- and the pool it needs -- before the device's launch order is taken: an allocation of tens
+     * of GB must not keep other batches' launches waiting) */
+    LhLaunchPlan plan;
+    {
+        int const rc = batch_plan(b, b->h_desc.data(), &plan);
+        if (rc)
+            return rc;
+    }
     {
         /* Launches that fill the device run one after the other, in launch order, whatever HIP streams their batches
          * own: a launch of >= 512 streams keeps every SIMD's register file and every CU's LDS (2 x 256 VGPRs, 4 x 40 KB),
@@ -2578,7 +2736,7 @@ lamehip_batch_encode(lamehip_batch * b)
         if (big && ser.ev)
             HIPCHK(hipStreamWaitEvent(b->stream, ser.ev, 0));
         int     rc = batch_launch(b, b->rate_in ? (const int16_t *) 0 : b->d_pcm, b->rate_in ? b->d_pcmf : (const float *) 0,
-                                  b->d_desc, b->h_desc.data(), b->dev_pack ? b->d_bytes : (uint8_t *) 0);
+                                  b->d_desc, plan, b->dev_pack ? b->d_bytes : (uint8_t *) 0);
         if (rc)
             return rc;
         if (b->dev_pack) {
@@ -2805,8 +2963,8 @@ lamehip_batch_reserve(lamehip_batch * b)
         b->d_out = bigger;
         b->out_cap = total;
     }
-    if (b->split && total > 0)
-        (void) batch_mid_reserve(b, total);     /* (no room: the launch will take the fused kernel) */
+    if (b->split && total > 0 && !batch_window_env())
+        (void) batch_mid_reserve(b, total);     /* (no room: the launch will run in windows, or take the fused kernel) */
     return 0;
 }
 
@@ -2837,7 +2995,24 @@ lamehip_batch_sync(lamehip_batch * b)
         if (hipEventElapsedTime(&ms, b->ev0, b->ev1) == hipSuccess)
             b->last_ms = ms;
         b->part_ms[0] = b->part_ms[1] = b->part_ms[2] = 0;
-        if (b->last_split) {
+        if (b->last_split && b->last_windows > 1) {
+            /* a launch in windows: the three parts summed over the windows (a window ends where the next one starts) */
+            for (int k = 0; k < b->last_windows; k++) {
+                hipEvent_t const e0 = b->ev_win[3 * (size_t) k], e1 = b->ev_win[3 * (size_t) k + 1], e2 = b->ev_win[3 * (size_t) k + 2];
+                hipEvent_t const e3 = (k + 1 < b->last_windows) ? b->ev_win[3 * (size_t) k + 3] : b->ev1;
+                float   a = 0, s_ = 0, q = 0;
+                if (hipEventElapsedTime(&a, e0, e1) != hipSuccess || hipEventElapsedTime(&s_, e1, e2) != hipSuccess
+                    || hipEventElapsedTime(&q, e2, e3) != hipSuccess) {
+                    (void) hipGetLastError();
+                    b->part_ms[0] = b->part_ms[1] = b->part_ms[2] = 0.0f;
+                    break;
+                }
+                b->part_ms[0] += a;
+                b->part_ms[1] += s_;
+                b->part_ms[2] += q;
+            }
+        }
+        else if (b->last_split) {
             if (hipEventElapsedTime(&b->part_ms[0], b->ev0, b->ev_part[0]) != hipSuccess
                 || hipEventElapsedTime(&b->part_ms[1], b->ev_part[0], b->ev_part[1]) != hipSuccess
                 || hipEventElapsedTime(&b->part_ms[2], b->ev_part[1], b->ev1) != hipSuccess) {
@@ -2866,6 +3041,13 @@ lamehip_batch_last_kernel_parts_ms(lamehip_batch * b, float *parts3)
     parts3[1] = b->part_ms[1];
     parts3[2] = b->part_ms[2];
     return b->last_split;
+}
+
+/* sub-launches of the last launch: 1, or the number of frame windows the split pipeline worked through (batch_plan) */
+extern "C" int
+lamehip_batch_last_windows(lamehip_batch * b)
+{
+    return b ? b->last_windows : 0;
 }
 
 extern "C" int

@@ -86,7 +86,8 @@ typedef struct LhStreamDesc {
     long long bytes_base;       /* device bit packing: this stream's slice of the byte pool ... */
     long long bytes_cap;        /* ... and its size */
     int     flush;              /* pad the last frame out after frame_end - 1 (end of the stream) */
-    int     pad;
+    int     mid_rel;            /* split pipeline: frame f's analysis record is LhMidPools.frames[out_index + mid_rel + (f - frame_begin)];
+                                 * 0 unless the launch runs in windows of frames (batch_launch, lh_api.cpp) */
 } LhStreamDesc;
 
 /* ---- what the analysis kernels hand to the encode kernel ("mid" data; lh_analysis.hip, lh_subband.hip) ----
@@ -94,7 +95,7 @@ typedef struct LhStreamDesc {
  * for all frames of a launch at once, at high occupancy, and parked in HBM; the encode kernel's frame prologue only
  * runs the recurrences (pre-echo clamp against the previous granules, ATH level, thresholds under the masking adjustment
  * the last frame's loop left, partition -> band sums, perceptual entropy).  One record (LhMidFrame) per frame of the launch,
- * at LhStreamDesc.out_index + (frame - frame_begin) like the payload. */
+ * at LhStreamDesc.out_index + mid_rel + (frame - frame_begin): the payload's index unless the launch runs in windows. */
 typedef struct LhMidGr {
     float   peak[4][12];        /* [chn L,R,M,S][k < 9]: largest |high-passed sample| of the granule's nine sub-blocks of 64 samples
                                  * (reference psymodel.c:806-830 before the clamp to 1) */

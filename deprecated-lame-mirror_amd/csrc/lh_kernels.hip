@@ -929,6 +929,7 @@ lh_encode_stream(const LhConfig * LH_RESTRICT cfg, const LhTables * LH_RESTRICT 
     c.d.bytes_base = lh_uni_ll(c.d.bytes_base);
     c.d.bytes_cap = lh_uni_ll(c.d.bytes_cap);
     c.d.flush = lh_uni_i(c.d.flush);
+    c.d.mid_rel = lh_uni_i(c.d.mid_rel);
     c.tid = (int) threadIdx.x;
     c.lane = c.tid & 63;
     c.wave = lh_uni_i(c.tid >> 6);      /* scalar: everything indexed by the wave id gets scalar addressing */
@@ -983,7 +984,7 @@ lh_encode_stream(const LhConfig * LH_RESTRICT cfg, const LhTables * LH_RESTRICT 
             L.ctx.frame_base = c.frame_base;    /* read by the stages after the next workgroup barrier */
             L.psy_slot = slot;
 #ifdef LH_SPLIT
-            L.ctx.mid = mid.frames + (c.d.out_index + (f - c.d.frame_begin));
+            L.ctx.mid = mid.frames + (c.d.out_index + c.d.mid_rel + (f - c.d.frame_begin));
 #endif
         }
 #ifdef LH_SPLIT

@@ -81,6 +81,7 @@ lh_subband_kernel(const LhConfig * LH_KRESTRICT cfg, const LhTables * LH_KRESTRI
     c.d.pcm_base = lh_uni_ll(c.d.pcm_base);
     c.d.nsamples = lh_uni_ll(c.d.nsamples);
     c.d.out_index = lh_uni_ll(c.d.out_index);
+    c.d.mid_rel = lh_uni_i(c.d.mid_rel);
     c.d.frame_begin = lh_uni_i(c.d.frame_begin);
     c.d.frame_end = lh_uni_i(c.d.frame_end);
     c.tid = (int) threadIdx.x;
@@ -118,7 +119,7 @@ lh_subband_kernel(const LhConfig * LH_KRESTRICT cfg, const LhTables * LH_KRESTRI
     LH_SYNC_WG_LDS();
     LH_AP(8);
     for (int f = f0; f < f1; f++) {
-        long long const at = c.d.out_index + (f - c.d.frame_begin);
+        long long const at = c.d.out_index + c.d.mid_rel + (f - c.d.frame_begin);
         lh_stage_span < LH_MF_NEEDED, LH_NT > (c, L.mf[0], L.mf[1], (long long) fs * f - LH_MF_START);
         if (tid < 4) {
             /* (a one-granule frame: the transforms also run over the window's second granule, which is thrown away) */

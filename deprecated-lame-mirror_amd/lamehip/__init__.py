@@ -70,6 +70,8 @@ def load_library():
     lib.lamehip_batch_last_kernel_parts_ms.restype = C.c_int
     lib.lamehip_batch_last_kernel_parts_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     lib.lamehip_batch_kernel_waves.argtypes = [C.c_void_p]
+    lib.lamehip_batch_last_windows.restype = C.c_int
+    lib.lamehip_batch_last_windows.argtypes = [C.c_void_p]
     _lib = lib
     return lib
 
@@ -335,6 +337,10 @@ class Batch:
         parts = (C.c_float * 3)()
         split = self.lib.lamehip_batch_last_kernel_parts_ms(self.b, parts)
         return bool(split == 1), [float(parts[0]), float(parts[1]), float(parts[2])]
+
+    def windows(self):
+        """Sub-launches of the last launch: 1, or the frame windows the split pipeline worked through (lamehip.h)."""
+        return int(self.lib.lamehip_batch_last_windows(self.b))
 
     def kernel_waves(self):
         return int(self.lib.lamehip_batch_kernel_waves(self.b))

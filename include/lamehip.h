@@ -305,6 +305,13 @@ float   lamehip_batch_last_kernel_ms(lamehip_batch *);
  * (polyphase + MDCT: csrc/lh_subband.hip), then the per-stream encode kernel -- parts3[0..2] = their times in ms.  Returns 1,
  * or 0 when the launch was the single fused kernel (environment LAMEHIP_FUSED=1, or no memory for the pools). */
 int     lamehip_batch_last_kernel_parts_ms(lamehip_batch *, float *parts3);
+/* The analysis kernels leave 34 KB per frame for the encode kernel (81 GB at 1024 streams x 60 s).  A launch whose records do not
+ * fit the device's free memory is worked through in WINDOWS of as many frames per stream as do fit -- analysis kernels, then
+ * the encode kernel, window after window on the batch's HIP stream, the streams' state carried between them as between two
+ * launches of an incremental batch; results are the same bytes.  Returns the number of windows of the last launch (1: all at
+ * once; parts3 above are sums over the windows).  Environment LAMEHIP_MID_WINDOW=n forces windows of n frames (tuning, tests);
+ * under 64 frames per window the launch takes the fused kernel instead and lamehip_last_error() says so. */
+int     lamehip_batch_last_windows(lamehip_batch *);
 /* waves per stream of the kernel this batch encodes with: 2 (one per channel) */
 int     lamehip_batch_kernel_waves(lamehip_batch *);
 int     lamehip_batch_reset(lamehip_batch *);   /* re-initialise all stream states for another run */

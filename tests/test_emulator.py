@@ -20,7 +20,7 @@ class LhStreamDesc(C.Structure):
     _fields_ = [("pcm_l", C.c_longlong), ("pcm_r", C.c_longlong), ("pcm_base", C.c_longlong),
                 ("nsamples", C.c_longlong), ("out_index", C.c_longlong), ("frame_begin", C.c_int),
                 ("frame_end", C.c_int), ("bytes_base", C.c_longlong), ("bytes_cap", C.c_longlong),
-                ("flush", C.c_int), ("pad", C.c_int)]
+                ("flush", C.c_int), ("mid_rel", C.c_int)]
 
 
 @pytest.fixture(scope="module")

@@ -843,6 +843,135 @@ def test_batch_on_the_fused_kernel_matches_oracle(kw, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kw,window", [(dict(brate=128), 7), (dict(brate=128), 16), (dict(vbr_q=2), 5), (dict(vbr_q=4, vbr_mode=2), 9),
+                                       (dict(abr=150), 11), (dict(brate=320, samplerate=48000, mode=1), 3),
+                                       (dict(brate=64, samplerate=22050), 13), (dict(brate=96, channels=1), 6)])
+def test_launch_in_frame_windows_matches_oracle(kw, window, monkeypatch):
+    """LAMEHIP_MID_WINDOW=n: the split pipeline works through the launch in windows of n frames per stream (what a launch
+    whose analysis records do not fit the device's memory does by itself) -- a ragged batch (one stream shorter than a window,
+    one empty beyond its priming, bursts that switch blocks across window edges): payload == oracle frame by frame, the
+    device packer's bytes == the host packer's, the kernel parts add up to the launch."""
+    kw = dict(kw)
+    sr = kw.pop("samplerate", 44100)
+    ch = kw.get("channels", 2)
+    enc = lamehip.Encoder(sr, **kw)
+    cfg, tab = enc.config(), enc.tables()
+    orc = helpers.Oracle()
+    fs = 1152 if sr >= 32000 else 576
+    lens = [fs * 41 + 17, fs * 3, fs * 23 + 500, 1, fs * 64, fs * 30 + 1]
+    pcms = [helpers.synth_stream(5100 + i, n, sr, 1.0 / (3 + 4 * i)) for i, n in enumerate(lens)]
+    if ch == 1:
+        pcms = [np.stack([x[0], x[0]]) for x in pcms]
+    monkeypatch.setenv("LAMEHIP_MID_WINDOW", str(window))
+    for dev_pack in (False, True):
+        b = lamehip.Batch(enc, len(pcms), max(lens) + 16)
+        if dev_pack:
+            b.set_device_packing(True)
+        for s, x in enumerate(pcms):
+            if ch == 1:
+                b.set_pcm(s, x[0])
+            else:
+                b.set_pcm(s, x[0], x[1])
+        b.encode()
+        nf = max(b.frames(s) for s in range(len(pcms)))
+        assert b.windows() == (nf + window - 1) // window and b.windows() > 1
+        split, parts = b.kernel_parts_ms()
+        assert split and all(p > 0 for p in parts) and abs(sum(parts) - b.kernel_ms()) < 0.05 * b.kernel_ms() + 0.2
+        for s, x in enumerate(pcms):
+            got, want = b.get_frames(s), orc.encode_frames(cfg, tab, x)
+            assert len(got) == len(want)
+            for f in range(len(want)):
+                d = struct_diff(want[f], got[f])
+                assert not d, (s, f, d[:4])
+            if dev_pack:
+                assert b.get_bytes(s) == b.pack(s), s
+        # the same batch once more, all at once: the launch goes back to one window and the same payload
+        monkeypatch.setenv("LAMEHIP_MID_WINDOW", "0")
+        first = [b.pack(s) for s in range(len(pcms))]
+        b.encode()
+        assert b.windows() == 1
+        assert [b.pack(s) for s in range(len(pcms))] == first
+        monkeypatch.setenv("LAMEHIP_MID_WINDOW", str(window))
+        b.close()
+    enc.close()
+
+
+@pytest.mark.gpu
+def test_window_size_follows_the_free_memory(monkeypatch):
+    """LAMEHIP_MID_BUDGET_MB stands for a device with little memory left: the launch's analysis records (34 368 B per frame)
+    do not fit, so the launch runs in windows of as many frames per stream as do; with room for fewer than 64 frames per
+    stream it takes the fused kernel and lamehip_last_error() says why.  The bytes are the same either way."""
+    sr, B, secs = 44100, 48, 3.0
+    enc = lamehip.Encoder(sr, 128)
+    n = int(sr * secs)
+    pcms = [helpers.synth_stream(5500 + s, n, sr, 1.0 / 6) for s in range(B)]
+    b = lamehip.Batch(enc, B, n + 16)
+    for s, x in enumerate(pcms):
+        b.set_pcm(s, x[0], x[1])
+    b.encode()
+    assert b.windows() == 1 and b.kernel_parts_ms()[0]
+    want = [b.pack(s) for s in range(B)]
+    nf = b.frames(0)
+    rec = 34368
+    b.close()
+    # room for ~80 frames per stream (0.8 of the budget counts, 64 records are kept spare)
+    for budget_frames, kind in ((80, "windows"), (40, "fused")):
+        monkeypatch.setenv("LAMEHIP_MID_BUDGET_MB", str(int((budget_frames * B + 64) * rec / 0.8 / 1e6) + 1))
+        b = lamehip.Batch(enc, B, n + 16)
+        for s, x in enumerate(pcms):
+            b.set_pcm(s, x[0], x[1])
+        b.encode()
+        split, _ = b.kernel_parts_ms()
+        if kind == "windows":
+            assert split and 1 < b.windows() <= (nf + 63) // 64 and b.windows() >= (nf + budget_frames + 1) // (budget_frames + 2), b.windows()
+        else:
+            assert not split and b.windows() == 1
+            assert "fused kernel" in lamehip.last_error(), lamehip.last_error()
+        assert [b.pack(s) for s in range(B)] == want, kind
+        b.close()
+    enc.close()
+
+
+@pytest.mark.gpu
+def test_incremental_batch_in_frame_windows(monkeypatch):
+    """An incremental batch whose launches run in windows (every other one): the bytes are the one-shot batch's."""
+    sr, B = 44100, 4
+    enc = lamehip.Encoder(sr, 128)
+    lens = [sr + 4111 * s for s in range(B)]
+    pcms = [helpers.synth_stream(5300 + s, lens[s], sr, 1.0 / 4) for s in range(B)]
+    one = lamehip.Batch(enc, B, max(lens) + 16)
+    for s, x in enumerate(pcms):
+        one.set_pcm(s, x[0], x[1])
+    one.encode()
+    want = [one.pack(s) for s in range(B)]
+    one.close()
+    b = lamehip.Batch(enc, B, max(lens) + 16)
+    got = [b""] * B
+    pos, rnd, wins = 0, 0, []
+    while pos < max(lens):
+        n = 9000 + 1152 * (rnd % 3)
+        for s in range(B):
+            a, e = min(pos, lens[s]), min(pos + n, lens[s])
+            if e > a:
+                b.append(s, np.ascontiguousarray(pcms[s][0][a:e]), np.ascontiguousarray(pcms[s][1][a:e]))
+        monkeypatch.setenv("LAMEHIP_MID_WINDOW", "3" if rnd % 2 else "0")
+        b.encode_available()
+        wins.append(b.windows())
+        for s in range(B):
+            got[s] += b.drain(s)
+        pos += n
+        rnd += 1
+    monkeypatch.setenv("LAMEHIP_MID_WINDOW", "2")
+    b.finish()
+    for s in range(B):
+        got[s] += b.drain(s)
+        assert got[s] == want[s], s
+    assert max(wins) > 1 and min(wins) == 1, wins
+    b.close()
+    enc.close()
+
+
+@pytest.mark.gpu
 def test_incremental_batch_changes_kernels_between_launches(monkeypatch):
     """An incremental batch whose launches alternate between the split pipeline and the fused kernel (LAMEHIP_SPLIT_DENY=1
     stands for a pool allocation that failed mid-stream): either kernel leaves the stream state as the other expects it, the
