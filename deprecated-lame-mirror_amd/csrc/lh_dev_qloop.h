@@ -32,6 +32,8 @@ struct LhQS {
     uint32_t pw[5];             /* working image: low half = even line */
     int     bnd[5];             /* band of the pair (63: the slot holds no pair) */
     uint32_t vm[5];             /* all ones when the pair lies at or below max_nonzero_coeff, else 0 */
+    int     bq[5];              /* bnd, or 31 where vm is 0: no band mask of a long-block granule (22 bands) has that bit, so a
+                                 * one-bit field extract at bq selects nothing for a pair that is not there (lq_quantize) */
     float   lmax;               /* the lane's largest xrpow (xrpow_max = the maximum over the lanes) */
     /* lane = band */
     int     sfw, sfbest;        /* scalefactor: working, best */
@@ -167,6 +169,7 @@ lq_load(const LhCtx & c, LhQS & S, LhChanLds & Q, const LhQR & R, const LhGrR & 
         S.xp[2 * k + 1] = ok ? x.y : 0.0f;
         S.bnd[k] = ok ? b : 63;
         S.vm[k] = (ok && p <= pm) ? 0xffffffffu : 0u;
+        S.bq[k] = (ok && p <= pm) ? b : 31;
         S.pw[k] = 0u;
         mx = S.xp[2 * k] > mx ? S.xp[2 * k] : mx;
         mx = S.xp[2 * k + 1] > mx ? S.xp[2 * k + 1] : mx;
@@ -227,7 +230,9 @@ lq_load(const LhCtx & c, LhQS & S, LhChanLds & Q, const LhQR & R, const LhGrR & 
         for (int k = 0; k < 5; k++) {
             int const b = S.bnd[k] & 63;
             int const at = (int) lh_shfl_u32((uint32_t) S.sqb, b) + 2 * (c.lane + 64 * k) - (int) lh_shfl_u32((uint32_t) S.sta, b);
-            S.sqi[k] = 4u * (uint32_t) ((S.bnd[k] < LH_SBPSY_L) ? at : LQ_SQ_DUMP);
+            /* (a line above max_nonzero_coeff is no term of any sum: its place keeps the zero it has from here, its square
+             * goes to the dump word -- no masking of the squares on the way) */
+            S.sqi[k] = 4u * (uint32_t) ((S.bnd[k] < LH_SBPSY_L && S.vm[k]) ? at : LQ_SQ_DUMP);
         }
         LH_WAVE_SYNC();
         for (int i = c.lane; i < 576 / 4; i += 64) {
@@ -273,7 +278,8 @@ lq_quantize(const LhCtx & c, LhQS & S, const LhQR & R, const LhGrR & g)
         qt_[2 * k + 1] = qt->qthr[qb[2 * k + 1] & 255u];
     }
     /* ---- which bands are quantised, and how (lane = band) ---- */
-    uint64_t ncmask = 0, m01mask = 0;
+    /* (without the previous call's data: every band anew, none by the 0 / 1 comparator; bit 31 stays clear, see LhQS.bq) */
+    uint64_t ncmask = 0x7fffffffull, m01mask = 0;
     int     zero_mnc = 0, plain = 1;
     int const pm = R.mnc >> 1;
     if (USE_PREV && (g.global_gain == R.pn_global_gain || R.pn_sfb_count1 > 0)) {
@@ -304,13 +310,27 @@ lq_quantize(const LhCtx & c, LhQS & S, const LhQR & R, const LhGrR & g)
      * (LhTables.qthr; both in tests/test_quantizer_identity.py) ---- */
     {
         uint32_t nq[5];
+#if !defined(LH_EMU) && !defined(LH_NO_JOIN)
+        /* all of the threshold look-ups behind ONE s_waitcnt (the compiler's own would be one per comparison: eight issue
+         * slots of a wave that has none to spare; the look-ups went out before the band masks were formed) */
+        if (NS == 4)
+            asm volatile("" : "+v"(qt_[0]), "+v"(qt_[1]), "+v"(qt_[2]), "+v"(qt_[3]), "+v"(qt_[4]), "+v"(qt_[5]), "+v"(qt_[6]), "+v"(qt_[7]));
+        else
+            asm volatile("" : "+v"(qt_[0]), "+v"(qt_[1]), "+v"(qt_[2]), "+v"(qt_[3]), "+v"(qt_[4]), "+v"(qt_[5]), "+v"(qt_[6]), "+v"(qt_[7]),
+                         "+v"(qt_[8]), "+v"(qt_[9]));
+#endif
 #pragma unroll
         for (int k = 0; k < NS; k++) {
             float const a0 = qa[2 * k], a1 = qa[2 * k + 1];
             uint32_t const b0 = qb[2 * k], b1 = qb[2 * k + 1];
             float const t0 = qt_[2 * k], t1 = qt_[2 * k + 1];
             uint32_t const r0 = b0 - (a0 < t0 ? 1u : 0u), r1 = b1 - (a1 < t1 ? 1u : 0u);
+#if !defined(LH_EMU) && !defined(LH_NO_BFE_SELECT)
+            /* (the two low halves into one word: one v_perm_b32 instead of v_and + v_lshl_or; masked where it is used) */
+            nq[k] = __builtin_amdgcn_perm(r1, r0, 0x05040100u);
+#else
             nq[k] = ((r0 & 0xffffu) | (r1 << 16)) & S.vm[k];
+#endif
         }
         /* (the lane's largest xrpow bounds its products -- a float product is monotone in either factor -- and a product of
          * at most 255 rounds to at most 255: one multiplication and one comparison instead of a maximum over the eight) */
@@ -323,22 +343,49 @@ lq_quantize(const LhCtx & c, LhQS & S, const LhQR & R, const LhGrR & g)
                 nq[k] = ((uint32_t) (q0 & 0xffff) | ((uint32_t) q1 << 16)) & S.vm[k];
             }
         }
-        if (plain) {
+#if !defined(LH_EMU) && !defined(LH_NO_BFE_SELECT)
+        /* (with the previous call's data in play, a long-block granule takes the selecting path below every time: "all bands
+         * anew, none by the 0 / 1 comparator" is one more pair of masks to it, not a branch of its own) */
+        int const merged = USE_PREV && R.block_type != LH_SHORT_TYPE;
+#else
+        int const merged = 0;
+#endif
+        if (plain && !merged) {
 #pragma unroll
             for (int k = 0; k < NS; k++)
-                S.pw[k] = nq[k];
+                S.pw[k] = nq[k] & S.vm[k];
         }
         else {
             /* (1 - 0.4054) / istep: istep is one of 16 mantissas times a power of two, and a correctly rounded quotient
              * scales exactly -- the 16 quotients sit in lanes 32..47 of S.istepv */
             float const compareval0 = cmpv;
+#if !defined(LH_EMU) && !defined(LH_NO_BFE_SELECT)
+            /* long-block granules have 22 bands: the two band masks fit a word each, a signed one-bit field extract at the
+             * lane's band (v_bfe_i32) is 0 or ~0 for the whole word, and two v_bfi_b32 take the place of the two selects --
+             * four instructions per slot instead of eight (two 64-bit bit tests of three instructions each + the selects) */
+            if (R.block_type != LH_SHORT_TYPE) {
+                int const ncw = (int) (uint32_t) ncmask, z1w = (int) (uint32_t) m01mask;
+#pragma unroll
+                for (int k = 0; k < NS; k++) {
+                    /* (at bq: a pair above max_nonzero_coeff extracts bit 31 = 0 twice and keeps its zero, so neither
+                     * candidate needs the mask) */
+                    uint32_t const NC = (uint32_t) __builtin_amdgcn_sbfe(ncw, (unsigned) S.bq[k], 1u);
+                    uint32_t const Z1 = (uint32_t) __builtin_amdgcn_sbfe(z1w, (unsigned) S.bq[k], 1u);
+                    uint32_t const v01 = lh_vec_u32(((compareval0 > S.xp[2 * k + 1]) ? 0u : 0x10000u)
+                                                    | ((compareval0 > S.xp[2 * k]) ? 0u : 1u));
+                    uint32_t const t = (Z1 & v01) | (~Z1 & nq[k]);
+                    S.pw[k] = (NC & t) | (~NC & S.pw[k]);
+                }
+            }
+            else
+#endif
 #pragma unroll
             for (int k = 0; k < NS; k++) {
                 int const nc = lq_bit(ncmask, S.bnd[k]), z1 = lq_bit(m01mask, S.bnd[k]);
                 /* (through lh_vec_u32: formed for every lane, not under an EXEC mask per slot with its branch) */
                 uint32_t const v01 = lh_vec_u32((((compareval0 > S.xp[2 * k]) ? 0u : 1u)
                                                  | (((compareval0 > S.xp[2 * k + 1]) ? 0u : 1u) << 16)) & S.vm[k]);
-                S.pw[k] = nc ? (z1 ? v01 : nq[k]) : S.pw[k];
+                S.pw[k] = nc ? (z1 ? v01 : (nq[k] & S.vm[k])) : S.pw[k];
             }
             if (LH_RARE(zero_mnc)) {
                 /* (rare and wave-uniform: a branch that falls through instead of four selects on every call) */
@@ -707,7 +754,60 @@ LH_DEVFN float
 lq_band_sums_pad(const float *sq, int base, int n, int maxw)
 {
     float   noise = 0;
-#if !defined(LH_EMU)
+#if !defined(LH_EMU) && !defined(LH_SUMS_C)
+    /* One instruction stream for the whole walk: blocks of sixteen terms (four 16-byte reads) in two register sets, the next
+     * block's reads in flight under this block's additions; EXEC only ever narrows -- a lane leaves when its band's terms
+     * are through (checked per octet: the zero padding runs up to a multiple of eight) and the loop ends with the last lane,
+     * so neither the wave's largest width nor a scalar loop count is needed; EXEC comes back at the end, behind a wait for
+     * the reads still in flight (the temporaries are plain clobbers: nothing of the caller's lives in v[220:251] here). */
+    (void) maxw;
+    int     rem = n;            /* terms the lane still has to add (<= 0: none) */
+    uint32_t ad = lh_lds_off(sq) + 4u * (uint32_t) base;
+    unsigned long long sv_, tm_;
+#define LQ_OCT(R0, R1, R2, R3, R4, R5, R6, R7) \
+        "v_add_f32 %[ns], %[ns], v" #R0 "\n\tv_add_f32 %[ns], %[ns], v" #R1 "\n\tv_add_f32 %[ns], %[ns], v" #R2 "\n\t" \
+        "v_add_f32 %[ns], %[ns], v" #R3 "\n\tv_add_f32 %[ns], %[ns], v" #R4 "\n\tv_add_f32 %[ns], %[ns], v" #R5 "\n\t" \
+        "v_add_f32 %[ns], %[ns], v" #R6 "\n\tv_add_f32 %[ns], %[ns], v" #R7 "\n\t"
+    asm volatile("s_mov_b64 %[sv], exec\n\t"
+                 "v_cmpx_gt_i32_e64 %[tm], %[rem], 0\n\t"
+                 "s_cbranch_execz .Llq_sum_done_%=\n\t"
+                 "ds_read_b128 v[220:223], %[ad]\n\t"
+                 "ds_read_b128 v[224:227], %[ad] offset:16\n\t"
+                 "ds_read_b128 v[228:231], %[ad] offset:32\n\t"
+                 "ds_read_b128 v[232:235], %[ad] offset:48\n\t"
+                 ".Llq_sum_loop_%=:\n\t"
+                 "ds_read_b128 v[236:239], %[ad] offset:64\n\t"
+                 "ds_read_b128 v[240:243], %[ad] offset:80\n\t"
+                 "ds_read_b128 v[244:247], %[ad] offset:96\n\t"
+                 "ds_read_b128 v[248:251], %[ad] offset:112\n\t"
+                 "s_waitcnt lgkmcnt(4)\n\t"
+                 LQ_OCT(220, 221, 222, 223, 224, 225, 226, 227)
+                 "v_cmpx_gt_i32_e64 %[tm], %[rem], 8\n\t"
+                 LQ_OCT(228, 229, 230, 231, 232, 233, 234, 235)
+                 "v_cmpx_gt_i32_e64 %[tm], %[rem], 16\n\t"
+                 "s_cbranch_execz .Llq_sum_done_%=\n\t"
+                 "ds_read_b128 v[220:223], %[ad] offset:128\n\t"
+                 "ds_read_b128 v[224:227], %[ad] offset:144\n\t"
+                 "ds_read_b128 v[228:231], %[ad] offset:160\n\t"
+                 "ds_read_b128 v[232:235], %[ad] offset:176\n\t"
+                 "s_waitcnt lgkmcnt(4)\n\t"
+                 LQ_OCT(236, 237, 238, 239, 240, 241, 242, 243)
+                 "v_cmpx_gt_i32_e64 %[tm], %[rem], 24\n\t"
+                 LQ_OCT(244, 245, 246, 247, 248, 249, 250, 251)
+                 "v_add_u32_e32 %[rem], -32, %[rem]\n\t"
+                 "v_add_u32_e32 %[ad], 0x80, %[ad]\n\t"
+                 "v_cmpx_gt_i32_e64 %[tm], %[rem], 0\n\t"
+                 "s_cbranch_execnz .Llq_sum_loop_%=\n\t"
+                 ".Llq_sum_done_%=:\n\t"
+                 "s_mov_b64 exec, %[sv]\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : [ns] "+v"(noise), [rem] "+v"(rem), [ad] "+v"(ad), [sv] "=&s"(sv_), [tm] "=&s"(tm_)
+                 :
+                 : "memory", "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231",
+                   "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243",
+                   "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251");
+#undef LQ_OCT
+#elif !defined(LH_EMU)
     struct alignas(16) Q4 { float x, y, z, w; };
     const Q4 *src = (const Q4 *) (sq + base);
     int     rem = n;            /* terms the lane still has to add (<= 0: none) */
@@ -775,12 +875,8 @@ lq_zero_band_noise(const LhCtx & c, LhQS & S, const LhQR & R, LhChanLds & Q, con
         lh_f32x2 v;
         v.x = t0 * t0;
         v.y = t1 * t1;
-        if (S.pad) {
-            /* (a line above max_nonzero_coeff is no term of any sum: its place holds a zero) */
-            v.x = lh_u32_as_f32(lh_f32_as_u32(v.x) & S.vm[k]);
-            v.y = lh_u32_as_f32(lh_f32_as_u32(v.y) & S.vm[k]);
+        if (S.pad)
             *(lh_f32x2 *) ((char *) sq + S.sqi[k]) = v;
-        }
         else if (k < 4 || p < 288)
             ((lh_f32x2 *) sq)[p] = v;
     }
@@ -855,11 +951,8 @@ lq_noise_squares(const LhCtx & c, const LhQS & S, const LhGrR & g, LhChanLds & Q
         lh_f32x2 v;
         v.x = t0 * t0;
         v.y = t1 * t1;
-        if (S.pad) {
-            v.x = lh_u32_as_f32(lh_f32_as_u32(v.x) & S.vm[k]);
-            v.y = lh_u32_as_f32(lh_f32_as_u32(v.y) & S.vm[k]);
+        if (S.pad)
             *(lh_f32x2 *) ((char *) sq + S.sqi[k]) = v;
-        }
         else if (k < 4 || p < 288)
             ((lh_f32x2 *) sq)[p] = v;
     }
@@ -963,12 +1056,22 @@ lq_noise_commit(LhQS & S, LhQR & R, const LhGrR & g, const LhNoiseTmp & t)
 /* multiply the lines of the bands in `bands' by factor (xrpow only grows, so the lane's maximum
  * follows) */
 template < int NS > LH_DEVFN void
-lq_scale_mask(LhQS & S, uint64_t bands, float factor)
+lq_scale_mask(LhQS & S, uint64_t bands, float factor, int wide = 1)
 {
 #pragma unroll
     for (int k = 0; k < NS; k++) {
         /* (x * 1.0f == x for every float: one select on the factor instead of one per line) */
-        float const f = lq_bit(bands, S.bnd[k]) ? factor : 1.0f;
+        float   f;
+#if !defined(LH_EMU) && !defined(LH_NO_BFE_SELECT)
+        /* (long blocks, 22 bands: the band's bit spread over a word by v_bfe_i32 picks the factor's or 1.0f's bits -- two
+         * instructions instead of the 64-bit test's three and a select, see lq_quantize) */
+        if (!wide) {
+            uint32_t const on = (uint32_t) __builtin_amdgcn_sbfe((int) (uint32_t) bands, (unsigned) S.bnd[k], 1u);
+            f = lh_u32_as_f32((on & lh_f32_as_u32(factor)) | (~on & 0x3f800000u));
+        }
+        else
+#endif
+            f = lq_bit(bands, S.bnd[k]) ? factor : 1.0f;
         float const v0 = S.xp[2 * k] * f, v1 = S.xp[2 * k + 1] * f;
         S.xp[2 * k] = v0;
         S.xp[2 * k + 1] = v1;
@@ -1029,7 +1132,7 @@ lq_amp_scalefac_bands(const LhCtx & c, LhQS & S, const LhQR & R, LhGrR & g)
     int const amplify = hit && !(pass_first && s == first);
     S.ph = (hit && shaping) ? !S.ph : S.ph;
     S.sfw += amplify;
-    lq_scale_mask < NS > (S, lh_ballot(amplify), widen);
+    lq_scale_mask < NS > (S, lh_ballot(amplify), widen, R.block_type == LH_SHORT_TYPE);
 }
 
 /* reference takehiro.c:1135-1188 (MPEG-1) on the working scalefactors.  The two maxima the
@@ -1101,7 +1204,7 @@ lq_inc_scalefac_scale(const LhCtx & c, LhQS & S, const LhQR & R, LhGrR & g)
     }
     g.preflag = 0;
     g.scalefac_scale = 1;
-    lq_scale_mask < NS > (S, lh_ballot(amp), ifqstep34);
+    lq_scale_mask < NS > (S, lh_ballot(amp), ifqstep34, R.block_type == LH_SHORT_TYPE);
 }
 
 /* reference quantize.c:847-921 (short blocks) */
