@@ -431,6 +431,25 @@ lq_count(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
         int     e0, e1, e2, a1, a2;
         if (USE_PREV)
             R.pn_sfb_count1 = 0;
+#if !defined(LH_EMU)
+        /* What the count1 region will look up depends on the image alone, not on where the region starts: the clamped words,
+         * the neighbour's word and the look-ups themselves go out before the reduction below, whose DPP chain has idle issue
+         * slots (two chains leave one wait state per step) and whose result the look-ups' round trip then does not follow. */
+        uint32_t cl[5], qlen[5];
+        {
+            uint32_t const qtab = lh_lds_off(&Q) + (uint32_t) ((const char *) qt->t3233p - (const char *) &Q);
+#pragma unroll
+            for (int k = 0; k < NS; k++)
+                cl[k] = lh_pk_min_u16(S.pw[k], 0x000f000fu);
+#pragma unroll
+            for (int k = 0; k < NS; k++) {
+                uint32_t const nxt = (k + 1 < NS) ? cl[k + 1 < NS ? k + 1 : k] : 0u;
+                uint32_t const u1 = lh_lane_above_u32(cl[k], nxt);
+                uint32_t const t = cl[k] | (u1 << 2);
+                qlen[k] = lh_lds_read_u32(lh_dot2_u16(t, 4u | (8u << 16), qtab));
+            }
+        }
+#endif
         {
             /* highest non-zero pair + 1 and highest pair holding a value > 1 + 1: slots ascend, the
              * last hit of a lane is its highest; then the maximum over the lanes */
@@ -490,9 +509,6 @@ lq_count(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
          * v | w << 1 | x << 2 | y << 3 from the two packed words (all four values are 0 or 1 there) and looks up both
          * tables' lengths; lanes whose pair starts no quadruple of the region look up something and drop it. */
         uint32_t qsum = 0;
-#ifndef LH_EMU
-        uint32_t cl[5];
-#endif
         {
             int const pb = bv >> 1;
             uint32_t const first = (uint32_t) (lane - pb);      /* pair - pb of slot 0 */
@@ -504,18 +520,9 @@ lq_count(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
              * t are v + 4 x and w + 4 y, and 4 (v + 2 w + 4 x + 8 y) = 4 lo + 8 hi.  The values are clamped to 15
              * first (the clamped words serve the grid look-ups below as well), so that the lanes whose pairs hold
              * larger values -- their result is dropped -- read inside the workgroup's image. */
-            uint32_t const qtab = lh_lds_off(&Q) + (uint32_t) ((const char *) qt->t3233p - (const char *) &Q);
 #pragma unroll
             for (int k = 0; k < NS; k++)
-                cl[k] = lh_pk_min_u16(S.pw[k], 0x000f000fu);
-#pragma unroll
-            for (int k = 0; k < NS; k++) {
-                uint32_t const nxt = (k + 1 < NS) ? cl[k + 1 < NS ? k + 1 : k] : 0u;
-                uint32_t const u1 = lh_lane_above_u32(cl[k], nxt);
-                uint32_t const t = cl[k] | (u1 << 2);
-                uint32_t const len = lh_lds_read_u32(lh_dot2_u16(t, 4u | (8u << 16), qtab));
-                qsum += ((firstq + 64u * (uint32_t) k) < n2) ? len : 0u;
-            }
+                qsum += ((firstq + 64u * (uint32_t) k) < n2) ? qlen[k] : 0u;
 #else
 #pragma unroll
             for (int k = 0; k < NS; k++) {
@@ -531,16 +538,36 @@ lq_count(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
         LQ_MARK("cb_max");
         uint32_t m[3] = { 0u, 0u, 0u };
         {
+            /* (the slots' candidates first, then three-way maxima: v_max3_u32 halves the chain of two-way ones) */
+            uint32_t cm[3][5];
 #pragma unroll
             for (int k = 0; k < NS; k++) {
                 int const p = lane + 64 * k;
                 uint32_t const lo = S.pw[k] & 0xffffu, hi = S.pw[k] >> 16;
                 uint32_t const mx = lo > hi ? lo : hi;
                 int const in0 = p < e0, in1 = p < e1, in2 = p < e2;
-                uint32_t const c0 = in0 ? mx : 0u, c1 = (in1 && !in0) ? mx : 0u, c2 = (in2 && !in1) ? mx : 0u;
-                m[0] = c0 > m[0] ? c0 : m[0];
-                m[1] = c1 > m[1] ? c1 : m[1];
-                m[2] = c2 > m[2] ? c2 : m[2];
+                cm[0][k] = in0 ? mx : 0u;
+                cm[1][k] = (in1 && !in0) ? mx : 0u;
+                cm[2][k] = (in2 && !in1) ? mx : 0u;
+            }
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+#if !defined(LH_EMU)
+                uint32_t a, r;
+                if (NS > 4)
+                    asm("v_max3_u32 %0, %1, %2, %3" : "=v"(a) : "v"(cm[j][2]), "v"(cm[j][3]), "v"(cm[j][4]));
+                else if (NS > 3)
+                    asm("v_max_u32_e32 %0, %1, %2" : "=v"(a) : "v"(cm[j][2]), "v"(cm[j][3]));
+                else
+                    a = (NS > 2) ? cm[j][2] : 0u;
+                asm("v_max3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(cm[j][0]), "v"(cm[j][1]), "v"(a));
+                m[j] = r;
+#else
+                uint32_t r = 0;
+                for (int k = 0; k < NS; k++)
+                    r = cm[j][k] > r ? cm[j][k] : r;
+                m[j] = r;
+#endif
             }
             lh_wave_max_n < 3 > (m);
         }

@@ -1113,6 +1113,18 @@ lh_init_xrpow(const LhCtx & c, LhChanLds & Q, const LhQR & R, LhGrR & g, const f
 LH_DEVFN int
 lh_quant_compare(const LhNoiseRes & best, const LhNoiseRes & calc)
 {
+#if !defined(LH_EMU)
+    /* Scalar integers throughout: every operand is wave-uniform, and truth values the compiler keeps as lane masks are
+     * merged with vector selects (a dozen instructions of this rule, once per iteration of the search).  The one float
+     * comparison runs on the vector unit -- there is no scalar one -- and comes back through v_readfirstlane. */
+    unsigned const fewer = (calc.bits < best.bits) ? 1u : 0u;
+    if (best.over_count > 0) {
+        unsigned const le = (calc.over_SSD <= best.over_SSD) ? 1u : 0u;
+        return (int) ((calc.over_SSD == best.over_SSD) ? fewer : le);
+    }
+    return (int) ((unsigned) lh_uni_i((calc.max_noise < 0) &&
+                                      ((calc.max_noise * 10 + calc.bits) <= (best.max_noise * 10 + best.bits))) & fewer);
+#else
     int     better;
     if (best.over_count > 0) {
         better = calc.over_SSD <= best.over_SSD;
@@ -1126,6 +1138,7 @@ lh_quant_compare(const LhNoiseRes & best, const LhNoiseRes & calc)
     if (best.over_count == 0)
         better = better && calc.bits < best.bits;
     return better;
+#endif
 }
 
 /* ---------------------------------------------------------------------- */
