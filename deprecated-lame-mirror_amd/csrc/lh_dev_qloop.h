@@ -498,6 +498,9 @@ lq_count(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
         e0 = lh_uni_i(a1 >> 1);
         e1 = lh_uni_i(a2 >> 1);
         e2 = (R.block_type == LH_NORM_TYPE) ? (bv >> 1) : e1;
+        /* region 1 may reach beyond the second slot: any block type but the normal one (it runs up to big_values there), or
+         * band edges other than those of 44.1 / 48 kHz */
+        int const wide1 = (R.block_type != LH_NORM_TYPE) || (c.l21 > 418);
         LQ_MARK("cb_quads");
         LQ_T(S, 4);
         LH_WAVE_ORDER();
@@ -545,7 +548,10 @@ lq_count(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
                 int const p = lane + 64 * k;
                 uint32_t const lo = S.pw[k] & 0xffffu, hi = S.pw[k] >> 16;
                 uint32_t const mx = lo > hi ? lo : hi;
-                int const in0 = p < e0, in1 = p < e1, in2 = p < e2;
+                /* (region 0 ends within the first slot's 64 pairs whatever the block type, region 1 of a normal block with
+                 * the band edges of 44.1 / 48 kHz within the first two: build_region_split, lh_host_init.c, checks the tables
+                 * -- the other slots' comparisons, selects and terms are not in the code) */
+                int const in0 = (k == 0) && p < e0, in1 = (k <= 1 || wide1) && p < e1, in2 = p < e2;
                 cm[0][k] = in0 ? mx : 0u;
                 cm[1][k] = (in1 && !in0) ? mx : 0u;
                 cm[2][k] = (in2 && !in1) ? mx : 0u;
@@ -599,7 +605,7 @@ lq_count(const LhCtx & c, LhQS & S, LhQR & R, LhGrR & g, LhChanLds & Q)
 #pragma unroll
             for (int k = 0; k < NS; k++) {
                 int const p = lane + 64 * k;
-                int const in0 = p < e0, in1 = p < e1, in2 = p < e2;
+                int const in0 = (k == 0) && p < e0, in1 = (k <= 1 || wide1) && p < e1, in2 = p < e2;
 #ifndef LH_EMU
                 uint32_t const go = in0 ? G0 : (in1 ? G1 : G2);
                 uint32_t const v = lh_lds_read_u32(lh_dot2_u16(cl[k], 64u | (4u << 16), go));

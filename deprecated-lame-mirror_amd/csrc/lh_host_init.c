@@ -1302,10 +1302,13 @@ lower_until_inside(const int *edge, int base, int guess, int limit)
     return n < 0 ? guess : n;
 }
 
-static void
+/* Returns 0 when a table breaks what the device count relies on (lq_count, lh_dev_qloop.h): the first region of a granule
+ * ends within the first 64 pairs -- one register slot of a wave -- for every block type, and with the long-block band edges
+ * of 44.1 / 48 kHz (edge 21 at or below line 418) the second region of a normal block ends within the first 128. */
+static int
 build_region_split(LhTables * t)
 {
-    int     bv;
+    int     bv, ok = 1;
     for (bv = 2; bv <= 576; bv += 2) {
         int     below = 1, r0;
         while (t->sfb_l[below] < bv)
@@ -1319,7 +1322,13 @@ build_region_split(LhTables * t)
         int const r0 = t->bv_scf[bv - 2], r1 = t->bv_scf[bv - 1];
         int const a1 = t->sfb_l[r0 + 1], a2 = t->sfb_l[(r0 + r1 + 2 < LH_SBMAX_L) ? r0 + r1 + 2 : LH_SBMAX_L];
         t->bvpack[bv / 2 - 1] = (uint32_t) r0 | ((uint32_t) r1 << 4) | ((uint32_t) a1 << 8) | ((uint32_t) a2 << 18);
+        if (a1 > 128 || (t->sfb_l[LH_SBPSY_L] <= 418 && a2 > 256))
+            ok = 0;
     }
+    /* (start / stop blocks: region 0 ends at band edge 8; short blocks: at three times short edge 3) */
+    if (t->sfb_l[7 + 1] > 128 || 3 * t->sfb_s[3] > 128)
+        ok = 0;
+    return ok;
 }
 
 /* per-band weights on the masking threshold: four groups of bands (bass, alto, treble, the band
@@ -1818,7 +1827,8 @@ lh_tables_build(LhConfig * c, const LhInitAux * aux, LhTables * t)
     build_power_tables(t);
     if (!power_tables_scale_exactly(t))
         return -1;
-    build_region_split(t);
+    if (!build_region_split(t))
+        return -1;
     build_huffman_grids(t);
     build_quant_thresholds(t);
     if (!build_vbr_quant_thresholds(t))
