@@ -32,6 +32,8 @@ struct LhQS {
     uint32_t pw[5];             /* working image: low half = even line */
     int     bnd[5];             /* band of the pair (63: the slot holds no pair) */
     uint32_t vm[5];             /* all ones when the pair lies at or below max_nonzero_coeff, else 0 */
+    int     bigq;               /* a quantiser call of this search saw a product above 255: the image may hold values >= 256 (sticky; 0
+                                 * since lq_load: calc_noise then skips its own test of the image's high bytes) */
     int     bq[5];              /* bnd, or 31 where vm is 0: no band mask of a long-block granule (22 bands) has that bit, so a
                                  * one-bit field extract at bq selects nothing for a pair that is not there (lq_quantize) */
     float   lmax;               /* the lane's largest xrpow (xrpow_max = the maximum over the lanes) */
@@ -191,6 +193,7 @@ lq_load(const LhCtx & c, LhQS & S, LhChanLds & Q, const LhQR & R, const LhGrR & 
         S.ph = Q.pseudohalf[s];
     }
     S.zk = 0;
+    S.bigq = 0;
     S.nzend = 0;                /* (the working image starts all zero) */
     S.tselw = 0;                /* table_select is all zero after lh_init_outer_loop */
     S.tselb = S.tselw;
@@ -256,13 +259,21 @@ lq_quantize(const LhCtx & c, LhQS & S, const LhQR & R, const LhGrR & g)
     const LhQTabs *qt = LH_QT;
     int const lane = c.lane;
     float   istep, cmpv = 0.0f;
+    int     big_prod;
     {
         int const d = g.global_gain - 210, ga = d >> 4, gb_ = d & 15;
-        float const thr = lq_ldexp(lh_u32_as_f32(lh_bcast_u32(lh_f32_as_u32(S.thrv), gb_)), 3 * ga);
         istep = lq_ldexp(lh_u32_as_f32(lh_bcast_u32(lh_f32_as_u32(S.istepv), gb_)), -3 * ga);
         cmpv = lq_ldexp(lh_u32_as_f32(lh_bcast_u32(lh_f32_as_u32(S.istepv), 32 + gb_)), 3 * ga);
-        if (LH_RARE(lh_ballot(S.lmax > thr)))
-            return 0;
+        /* (the lane's largest xrpow bounds its products -- a float product is monotone in either factor -- and a product of
+         * at most 255 rounds to at most 255 and lies far below IXMAX_VAL: one multiplication and one comparison decide both
+         * that no line is too large for the step and that the rounding offsets in LDS suffice) */
+        big_prod = lh_ballot(istep * S.lmax > 255.0f) != 0;
+        if (LH_RARE(big_prod)) {
+            float const thr = lq_ldexp(lh_u32_as_f32(lh_bcast_u32(lh_f32_as_u32(S.thrv), gb_)), 3 * ga);
+            if (lh_ballot(S.lmax > thr))
+                return 0;
+            S.bigq = 1;
+        }
     }
     /* the products, their first rounding and the look-ups of the second one go out BEFORE the band masks are formed
      * (scalar work with branches of its own): the masks then fill the look-ups' LDS round trip instead of preceding it */
@@ -332,9 +343,7 @@ lq_quantize(const LhCtx & c, LhQS & S, const LhQR & R, const LhGrR & g)
             nq[k] = ((r0 & 0xffffu) | (r1 << 16)) & S.vm[k];
 #endif
         }
-        /* (the lane's largest xrpow bounds its products -- a float product is monotone in either factor -- and a product of
-         * at most 255 rounds to at most 255: one multiplication and one comparison instead of a maximum over the eight) */
-        if (LH_RARE(lh_ballot(istep * S.lmax > 255.0f))) {
+        if (LH_RARE(big_prod)) {
             /* rare: a quantised value >= 256, its rounding offset lives in HBM */
 #pragma unroll
             for (int k = 0; k < NS; k++) {
@@ -966,7 +975,8 @@ lq_noise_squares(const LhCtx & c, const LhQS & S, const LhGrR & g, LhChanLds & Q
         p43[2 * k + 1] = qt->pow43h[q1 & 255u];
         big |= (int) ((q0 | q1) >> 8);
     }
-    if (LH_RARE(lh_ballot(big != 0))) {
+    /* (values of 256 and more exist only when a quantiser call of this search said so: LhQS.bigq) */
+    if (LH_RARE(S.bigq) && lh_ballot(big != 0)) {
 #pragma unroll
         for (int k = 0; k < NS; k++) {
             unsigned const q0 = S.pw[k] & 0xffffu, q1 = S.pw[k] >> 16;
