@@ -801,7 +801,7 @@ lq_band_sums_pad(const float *sq, int base, int n, int maxw)
      * block's reads in flight under this block's additions; EXEC only ever narrows -- a lane leaves when its band's terms
      * are through (checked per octet: the zero padding runs up to a multiple of eight) and the loop ends with the last lane,
      * so neither the wave's largest width nor a scalar loop count is needed; EXEC comes back at the end, behind a wait for
-     * the reads still in flight (the temporaries are plain clobbers: nothing of the caller's lives in v[220:251] here). */
+     * the reads still in flight (the temporaries are plain clobbers, all of them registers a callee need not preserve: v[192:199], v[208:215], v[224:231], v[240:247] -- the others of that range would be saved to scratch at the stage's entry, 4 KB per call that the L2 writes back to HBM). */
     (void) maxw;
     int     rem = n;            /* terms the lane still has to add (<= 0: none) */
     uint32_t ad = lh_lds_off(sq) + 4u * (uint32_t) base;
@@ -813,29 +813,29 @@ lq_band_sums_pad(const float *sq, int base, int n, int maxw)
     asm volatile("s_mov_b64 %[sv], exec\n\t"
                  "v_cmpx_gt_i32_e64 %[tm], %[rem], 0\n\t"
                  "s_cbranch_execz .Llq_sum_done_%=\n\t"
-                 "ds_read_b128 v[220:223], %[ad]\n\t"
-                 "ds_read_b128 v[224:227], %[ad] offset:16\n\t"
-                 "ds_read_b128 v[228:231], %[ad] offset:32\n\t"
-                 "ds_read_b128 v[232:235], %[ad] offset:48\n\t"
+                 "ds_read_b128 v[192:195], %[ad]\n\t"
+                 "ds_read_b128 v[196:199], %[ad] offset:16\n\t"
+                 "ds_read_b128 v[208:211], %[ad] offset:32\n\t"
+                 "ds_read_b128 v[212:215], %[ad] offset:48\n\t"
                  ".Llq_sum_loop_%=:\n\t"
-                 "ds_read_b128 v[236:239], %[ad] offset:64\n\t"
-                 "ds_read_b128 v[240:243], %[ad] offset:80\n\t"
-                 "ds_read_b128 v[244:247], %[ad] offset:96\n\t"
-                 "ds_read_b128 v[248:251], %[ad] offset:112\n\t"
+                 "ds_read_b128 v[224:227], %[ad] offset:64\n\t"
+                 "ds_read_b128 v[228:231], %[ad] offset:80\n\t"
+                 "ds_read_b128 v[240:243], %[ad] offset:96\n\t"
+                 "ds_read_b128 v[244:247], %[ad] offset:112\n\t"
                  "s_waitcnt lgkmcnt(4)\n\t"
-                 LQ_OCT(220, 221, 222, 223, 224, 225, 226, 227)
+                 LQ_OCT(192, 193, 194, 195, 196, 197, 198, 199)
                  "v_cmpx_gt_i32_e64 %[tm], %[rem], 8\n\t"
-                 LQ_OCT(228, 229, 230, 231, 232, 233, 234, 235)
+                 LQ_OCT(208, 209, 210, 211, 212, 213, 214, 215)
                  "v_cmpx_gt_i32_e64 %[tm], %[rem], 16\n\t"
                  "s_cbranch_execz .Llq_sum_done_%=\n\t"
-                 "ds_read_b128 v[220:223], %[ad] offset:128\n\t"
-                 "ds_read_b128 v[224:227], %[ad] offset:144\n\t"
-                 "ds_read_b128 v[228:231], %[ad] offset:160\n\t"
-                 "ds_read_b128 v[232:235], %[ad] offset:176\n\t"
+                 "ds_read_b128 v[192:195], %[ad] offset:128\n\t"
+                 "ds_read_b128 v[196:199], %[ad] offset:144\n\t"
+                 "ds_read_b128 v[208:211], %[ad] offset:160\n\t"
+                 "ds_read_b128 v[212:215], %[ad] offset:176\n\t"
                  "s_waitcnt lgkmcnt(4)\n\t"
-                 LQ_OCT(236, 237, 238, 239, 240, 241, 242, 243)
+                 LQ_OCT(224, 225, 226, 227, 228, 229, 230, 231)
                  "v_cmpx_gt_i32_e64 %[tm], %[rem], 24\n\t"
-                 LQ_OCT(244, 245, 246, 247, 248, 249, 250, 251)
+                 LQ_OCT(240, 241, 242, 243, 244, 245, 246, 247)
                  "v_add_u32_e32 %[rem], -32, %[rem]\n\t"
                  "v_add_u32_e32 %[ad], 0x80, %[ad]\n\t"
                  "v_cmpx_gt_i32_e64 %[tm], %[rem], 0\n\t"
@@ -845,9 +845,9 @@ lq_band_sums_pad(const float *sq, int base, int n, int maxw)
                  "s_waitcnt lgkmcnt(0)"
                  : [ns] "+v"(noise), [rem] "+v"(rem), [ad] "+v"(ad), [sv] "=&s"(sv_), [tm] "=&s"(tm_)
                  :
-                 : "memory", "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231",
-                   "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243",
-                   "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251");
+                 : "memory", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", "v208", "v209", "v210", "v211",
+                   "v212", "v213", "v214", "v215", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231",
+                   "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247");
 #undef LQ_OCT
 #elif !defined(LH_EMU)
     struct alignas(16) Q4 { float x, y, z, w; };
