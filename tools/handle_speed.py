@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """One stream through the lame.h-shaped handle API (one launch per call).  On the GPU box: python tools/handle_speed.py [seconds]
 Calls of 1152 samples, as the reference's frontend makes them, and larger ones (a call encodes every frame that became complete
-in ONE launch): what a launch costs beyond its frames.  Round 6: 72 x real time at 1152 samples per call (round 5: 67 x), 77 ... 80 x from 4 frames per
+in ONE launch): what a launch costs beyond its frames.  Round 6: 76 x real time at 1152 samples per call (round 5: 67 x), 80 ... 83 x from 4 frames per
 call on -- holding frames back inside the library to launch less often would gain 7 %, and was not built."""
 import os
 import sys
